@@ -1,0 +1,356 @@
+/* dgemm.hip - FP64 GEMM on the CDNA4 matrix cores (v_mfma_f64_16x16x4_f64), the workhorse of the Schur assembly
+ * M_ij = tr(A_i X A_j Z^-1) and of the predictor-corrector n x n chain.
+ *
+ * Reference correspondence: the reference has no GEMM of its own on the hot path - the products live inside DSDP/SDPA
+ * (sdpisolver_dsdp.c:1503 DSDPSolve, sdpisolver_sdpa.cpp:1620 SDPA::solve) - and one DGEMM wrapper off it
+ * (lapack_interface.c:654-706), which lapack_interface_hip.c maps onto this kernel.
+ *
+ * Design (gfx950):
+ *  - 256 threads = 4 wavefronts in a 2 x 2 arrangement; workgroup tile BT x BT (128 or 64), K step 16.
+ *  - each wavefront owns (BT/2) x (BT/2) of C as (BT/32)^2 MFMA tiles of 16 x 16; one MFMA consumes a 16 x 4 slab of A
+ *    and a 4 x 16 slab of B, one double per lane:  lane l holds A[l & 15][l >> 4] and B[l >> 4][l & 15];
+ *    the f64 accumulator map is  col = l & 15, row = (l >> 4) + 4 * reg  (NOT the f32 map).
+ *  - operands are staged global -> registers -> LDS in their natural orientation, so both stagings are 16-byte wide and
+ *    coalesced:  K-contiguous operands sit in LDS as [row][16 + 2] doubles, row-contiguous ones as [16][BT + 16].
+ *    Both paddings make the ds_read_b64 operand fetches conflict free (bank = (addr / 4) mod 64 per 32-lane half).
+ *  - LDS is double buffered (2 x 2 x 18 KiB at BT = 128): one barrier per K step; the next tile's global loads are in
+ *    flight while the current tile is multiplied; two workgroups per CU keep the matrix pipe busy across barriers.
+ *  - split-K writes per-slice slabs and a second kernel sums them in slice order: results are bitwise reproducible.
+ */
+#include "hs_common.h"
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+struct __attribute__((aligned(8))) d2u { double x, y; };      /* global pair, only 8-byte alignment promised */
+struct __attribute__((aligned(16))) d2a { double x, y; };     /* LDS pair, 16-byte aligned */
+
+#define HS_BK     16
+#define HS_KCLD   (HS_BK + 2)
+
+template<int BT> struct TileGeo
+{
+   static constexpr int MCLD = BT + 16;
+   static constexpr int SZKC = BT * HS_KCLD;
+   static constexpr int SZMC = HS_BK * MCLD;
+   static constexpr int SZ   = SZKC > SZMC ? SZKC : SZMC;     /* doubles per operand tile */
+   static constexpr int NLD  = BT / 32;                       /* 16-byte loads per thread per operand tile */
+   static constexpr int WT   = BT / 32;                       /* MFMA tiles per wave per dimension */
+};
+
+/* global -> registers for one operand tile.  P points at the operand of this batch entry.
+ * KC: element (r, k) at P[r * ld + k];  MC: element (r, k) at P[k * ld + r].  r in [r0, r0 + BT), k in [k0, k0 + 16). */
+template<int BT, int LAY>
+__device__ __forceinline__ void tile_gload(d2a (&v)[TileGeo<BT>::NLD], const double* __restrict__ P, long long ld,
+   int r0, int R, int k0, int Kend, int tid)
+{
+   if ( LAY == HS_KC )
+   {
+      const int kp = tid & 7;
+      const int r  = tid >> 3;
+      const int k  = k0 + 2 * kp;
+#pragma unroll
+      for (int i = 0; i < TileGeo<BT>::NLD; ++i)
+      {
+         const int row = r0 + r + 32 * i;
+         d2a t; t.x = 0.0; t.y = 0.0;
+         if ( row < R )
+         {
+            const double* q = P + (long long) row * ld + k;
+            if ( k + 1 < Kend )
+            {
+               d2u u = *reinterpret_cast<const d2u*>(q);
+               t.x = u.x; t.y = u.y;
+            }
+            else if ( k < Kend )
+               t.x = q[0];
+         }
+         v[i] = t;
+      }
+   }
+   else
+   {
+      constexpr int TPR = BT / 2;            /* threads per k-row */
+      constexpr int RPP = 256 / TPR;         /* k-rows per pass */
+      const int c2  = tid % TPR;
+      const int kr  = tid / TPR;
+      const int col = r0 + 2 * c2;
+#pragma unroll
+      for (int i = 0; i < TileGeo<BT>::NLD; ++i)
+      {
+         const int k = k0 + kr + RPP * i;
+         d2a t; t.x = 0.0; t.y = 0.0;
+         if ( k < Kend )
+         {
+            const double* q = P + (long long) k * ld + col;
+            if ( col + 1 < R )
+            {
+               d2u u = *reinterpret_cast<const d2u*>(q);
+               t.x = u.x; t.y = u.y;
+            }
+            else if ( col < R )
+               t.x = q[0];
+         }
+         v[i] = t;
+      }
+   }
+}
+
+/* registers -> LDS */
+template<int BT, int LAY>
+__device__ __forceinline__ void tile_sstore(double* __restrict__ s, const d2a (&v)[TileGeo<BT>::NLD], int tid)
+{
+   if ( LAY == HS_KC )
+   {
+      const int kp = tid & 7;
+      const int r  = tid >> 3;
+#pragma unroll
+      for (int i = 0; i < TileGeo<BT>::NLD; ++i)
+         *reinterpret_cast<d2a*>(s + (r + 32 * i) * HS_KCLD + 2 * kp) = v[i];
+   }
+   else
+   {
+      constexpr int TPR = BT / 2;
+      constexpr int RPP = 256 / TPR;
+      const int c2 = tid % TPR;
+      const int kr = tid / TPR;
+#pragma unroll
+      for (int i = 0; i < TileGeo<BT>::NLD; ++i)
+         *reinterpret_cast<d2a*>(s + (kr + RPP * i) * TileGeo<BT>::MCLD + 2 * c2) = v[i];
+   }
+}
+
+/* LDS -> one MFMA operand: element (row woff + 16 t + (l & 15), k = 4 ks + (l >> 4)) */
+template<int BT, int LAY>
+__device__ __forceinline__ double tile_frag(const double* __restrict__ s, int woff, int t, int ks, int lane)
+{
+   if ( LAY == HS_KC )
+      return s[(woff + 16 * t + (lane & 15)) * HS_KCLD + 4 * ks + (lane >> 4)];
+   else
+      return s[(4 * ks + (lane >> 4)) * TileGeo<BT>::MCLD + woff + 16 * t + (lane & 15)];
+}
+
+template<int BT, int LA, int LB>
+__global__ void __launch_bounds__(256, 2) hs_dgemm_kernel(hs_gemm_args p, int kchunk)
+{
+   extern __shared__ __attribute__((aligned(16))) double hs_smem[];
+   constexpr int SZ = TileGeo<BT>::SZ;
+   constexpr int WT = TileGeo<BT>::WT;
+
+   const int tid  = threadIdx.x;
+   const int lane = tid & 63;
+   const int wave = tid >> 6;
+   const int wm   = wave >> 1;
+   const int wn   = wave & 1;
+
+   const int m0 = blockIdx.x * BT;
+   const int n0 = blockIdx.y * BT;
+
+   if ( (p.flags & HS_GEMM_LOWER) && (m0 + BT - 1 < n0) )
+      return;
+
+   int bz = blockIdx.z;
+   int ks0 = 0;
+   int kend = p.K;
+   double* C = p.C;
+   long long ldc = p.ldc;
+   double alpha = p.alpha;
+   double beta = p.beta;
+   if ( p.splitk > 1 )
+   {
+      ks0 = bz * kchunk;
+      kend = min(p.K, ks0 + kchunk);
+      C = p.ws + (long long) bz * p.M * p.N;
+      ldc = p.N;
+      alpha = 1.0;
+      beta = 0.0;
+      bz = 0;
+   }
+   const double* A = p.A + (long long) bz * p.strideA;
+   const double* B = p.B + (long long) bz * p.strideB;
+   C += (long long) bz * p.strideC;
+
+   v4d acc[WT][WT];
+#pragma unroll
+   for (int i = 0; i < WT; ++i)
+#pragma unroll
+      for (int j = 0; j < WT; ++j)
+         acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+   d2a ra[TileGeo<BT>::NLD];
+   d2a rb[TileGeo<BT>::NLD];
+
+   const int ntiles = (kend - ks0 + HS_BK - 1) / HS_BK;
+
+   if ( ntiles > 0 )
+   {
+      tile_gload<BT, LA>(ra, A, p.lda, m0, p.M, ks0, kend, tid);
+      tile_gload<BT, LB>(rb, B, p.ldb, n0, p.N, ks0, kend, tid);
+      tile_sstore<BT, LA>(hs_smem, ra, tid);
+      tile_sstore<BT, LB>(hs_smem + SZ, rb, tid);
+   }
+   __syncthreads();
+
+   for (int t = 0; t < ntiles; ++t)
+   {
+      const double* sa = hs_smem + (t & 1) * 2 * SZ;
+      const double* sb = sa + SZ;
+
+      if ( t + 1 < ntiles )
+      {
+         tile_gload<BT, LA>(ra, A, p.lda, m0, p.M, ks0 + (t + 1) * HS_BK, kend, tid);
+         tile_gload<BT, LB>(rb, B, p.ldb, n0, p.N, ks0 + (t + 1) * HS_BK, kend, tid);
+      }
+
+#pragma unroll
+      for (int ks = 0; ks < HS_BK / 4; ++ks)
+      {
+         double fa[WT];
+         double fb[WT];
+#pragma unroll
+         for (int i = 0; i < WT; ++i)
+         {
+            fa[i] = tile_frag<BT, LA>(sa, wm * (BT / 2), i, ks, lane);
+            fb[i] = tile_frag<BT, LB>(sb, wn * (BT / 2), i, ks, lane);
+         }
+#pragma unroll
+         for (int i = 0; i < WT; ++i)
+#pragma unroll
+            for (int j = 0; j < WT; ++j)
+               acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+
+      if ( t + 1 < ntiles )
+      {
+         double* da = hs_smem + ((t + 1) & 1) * 2 * SZ;
+         tile_sstore<BT, LA>(da, ra, tid);
+         tile_sstore<BT, LB>(da + SZ, rb, tid);
+      }
+      __syncthreads();
+   }
+
+   /* epilogue: accumulator register r of tile (i, j) is C[16 i + (lane >> 4) + 4 r][16 j + (lane & 15)] */
+#pragma unroll
+   for (int i = 0; i < WT; ++i)
+   {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+      {
+         const int row = m0 + wm * (BT / 2) + 16 * i + (lane >> 4) + 4 * r;
+         if ( row >= p.M )
+            continue;
+#pragma unroll
+         for (int j = 0; j < WT; ++j)
+         {
+            const int col = n0 + wn * (BT / 2) + 16 * j + (lane & 15);
+            if ( col < p.N )
+            {
+               double* c = C + (long long) row * ldc + col;
+               double v = alpha * acc[i][j][r];
+               if ( beta != 0.0 )
+                  v += beta * (*c);
+               *c = v;
+            }
+         }
+      }
+   }
+}
+
+/* sums the split-K slabs in slice order: C = alpha * sum_s ws[s] + beta * C */
+__global__ void __launch_bounds__(256) hs_splitk_reduce_kernel(int M, int N, int nslices, const double* __restrict__ ws,
+   double* __restrict__ C, long long ldc, double alpha, double beta, int lowerBT)
+{
+   const long long total = (long long) M * N;
+   for (long long e = (long long) blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long) gridDim.x * blockDim.x)
+   {
+      const int row = (int) (e / N);
+      const int col = (int) (e - (long long) row * N);
+      if ( lowerBT > 0 && (row / lowerBT) * lowerBT + lowerBT - 1 < (col / lowerBT) * lowerBT )
+         continue;
+      double s = 0.0;
+      for (int k = 0; k < nslices; ++k)
+         s += ws[(long long) k * total + e];
+      double* c = C + (long long) row * ldc + col;
+      double v = alpha * s;
+      if ( beta != 0.0 )
+         v += beta * (*c);
+      *c = v;
+   }
+}
+
+template<int BT, int LA, int LB>
+static int launch_cfg(hipStream_t stream, const hs_gemm_args* a, int kchunk)
+{
+   static bool attr_set = false;
+   const size_t smem = (size_t) 4 * TileGeo<BT>::SZ * sizeof(double);
+   if ( !attr_set )
+   {
+      HS_HIP( hipFuncSetAttribute(reinterpret_cast<const void*>(&hs_dgemm_kernel<BT, LA, LB>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem) );
+      attr_set = true;
+   }
+   dim3 grid((a->M + BT - 1) / BT, (a->N + BT - 1) / BT, a->splitk > 1 ? a->splitk : a->batch);
+   hipLaunchKernelGGL((hs_dgemm_kernel<BT, LA, LB>), grid, dim3(256), smem, stream, *a, kchunk);
+   HS_HIP( hipGetLastError() );
+   return HS_OK;
+}
+
+template<int BT>
+static int launch_lay(hipStream_t stream, const hs_gemm_args* a, int kchunk)
+{
+   if ( a->layA == HS_KC && a->layB == HS_KC ) return launch_cfg<BT, HS_KC, HS_KC>(stream, a, kchunk);
+   if ( a->layA == HS_KC && a->layB == HS_MC ) return launch_cfg<BT, HS_KC, HS_MC>(stream, a, kchunk);
+   if ( a->layA == HS_MC && a->layB == HS_KC ) return launch_cfg<BT, HS_MC, HS_KC>(stream, a, kchunk);
+   return launch_cfg<BT, HS_MC, HS_MC>(stream, a, kchunk);
+}
+
+int hs_dgemm_pick_splitk(int M, int N, int K, int lowerOnly)
+{
+   const long long tm = (M + 127) / 128;
+   const long long tn = (N + 127) / 128;
+   long long tiles = lowerOnly ? tm * (tm + 1) / 2 : tm * tn;
+   if ( tiles >= 512 || K < 1024 )
+      return 1;
+   long long s = (1024 + tiles - 1) / tiles;
+   const long long maxs = K / 256;
+   if ( s > maxs ) s = maxs;
+   if ( s > 64 ) s = 64;
+   return s < 1 ? 1 : (int) s;
+}
+
+int hs_dgemm(hipStream_t stream, const hs_gemm_args* a)
+{
+   if ( a->M < 0 || a->N < 0 || a->K < 0 || a->batch < 1 )
+      return HS_ERR_ARG;
+   if ( a->M == 0 || a->N == 0 )
+      return HS_OK;
+   if ( a->splitk > 1 && (a->batch != 1 || a->ws == NULL) )
+      return HS_ERR_ARG;
+
+   /* tile choice: big tiles once they fill the chip, small tiles otherwise */
+   const long long big = (long long) ((a->M + 127) / 128) * ((a->N + 127) / 128) * (a->splitk > 1 ? a->splitk : a->batch);
+   const bool useBig = big >= 192;
+   const int BT = useBig ? 128 : 64;
+
+   int kchunk = a->K;
+   if ( a->splitk > 1 )
+   {
+      kchunk = (a->K + a->splitk - 1) / a->splitk;
+      kchunk = ((kchunk + HS_BK - 1) / HS_BK) * HS_BK;
+   }
+
+   if ( useBig )
+      HS_CALL( launch_lay<128>(stream, a, kchunk) );
+   else
+      HS_CALL( launch_lay<64>(stream, a, kchunk) );
+
+   if ( a->splitk > 1 )
+   {
+      const long long total = (long long) a->M * a->N;
+      int blocks = (int) ((total + 255) / 256);
+      if ( blocks > 2048 ) blocks = 2048;
+      hipLaunchKernelGGL(hs_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a->M, a->N, a->splitk, a->ws,
+         a->C, a->ldc, a->alpha, a->beta, (a->flags & HS_GEMM_LOWER) ? BT : 0);
+      HS_HIP( hipGetLastError() );
+   }
+   return HS_OK;
+}

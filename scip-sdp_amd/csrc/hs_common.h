@@ -1,0 +1,74 @@
+/* hs_common.h - shared declarations of the hipsdp device engine (gfx950 / MI355X only).
+ *
+ * Everything in csrc/ is written for CDNA4: 64-lane wavefronts, v_mfma_f64_16x16x4_f64, 160 KiB LDS per CU,
+ * 8 XCDs with private L2.  There is no CPU fallback in this directory: every entry point that computes
+ * returns HS_ERR_NODEVICE when no HIP device is usable.
+ */
+#ifndef HS_COMMON_H
+#define HS_COMMON_H
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#define HS_OK            0
+#define HS_ERR_NODEVICE  1
+#define HS_ERR_HIP       2
+#define HS_ERR_ARG       3
+#define HS_ERR_NOMEM     4
+#define HS_ERR_NUMERIC   5
+
+#define HS_HIP(call)                                                                       \
+   do {                                                                                    \
+      hipError_t hs_e_ = (call);                                                           \
+      if ( hs_e_ != hipSuccess ) {                                                         \
+         hs_record_hip_error(hs_e_, #call, __FILE__, __LINE__);                            \
+         return (hs_e_ == hipErrorOutOfMemory) ? HS_ERR_NOMEM : HS_ERR_HIP;                \
+      }                                                                                    \
+   } while (0)
+
+#define HS_CALL(call)                                                                      \
+   do {                                                                                    \
+      int hs_r_ = (call);                                                                  \
+      if ( hs_r_ != HS_OK )                                                                \
+         return hs_r_;                                                                     \
+   } while (0)
+
+void hs_record_hip_error(hipError_t e, const char* what, const char* file, int line);
+const char* hs_last_error(void);
+
+/* operand storage of a GEMM operand as seen from the product C[M x N] = A[M x K] * B[K x N]:
+ *  HS_KC: the K index is contiguous in memory (A stored row-major [M][K], or B stored as [N][K])
+ *  HS_MC: the M (resp. N) index is contiguous   (A stored as [K][M],      or B stored row-major [K][N]) */
+#define HS_KC 0
+#define HS_MC 1
+
+#define HS_GEMM_LOWER   1   /* compute only tiles that touch the lower triangle (row >= col) of C */
+
+struct hs_gemm_args
+{
+   int            M, N, K;
+   int            layA, layB;       /* HS_KC / HS_MC */
+   const double*  A;
+   long long      lda;              /* leading dimension in doubles */
+   long long      strideA;          /* batch stride in doubles (0: shared operand) */
+   const double*  B;
+   long long      ldb;
+   long long      strideB;
+   double*        C;                /* row-major [M][N] */
+   long long      ldc;
+   long long      strideC;
+   double         alpha, beta;
+   int            batch;
+   int            flags;
+   int            splitk;           /* >1: K is cut into splitk slices; needs ws of splitk*M*N doubles; batch must be 1 */
+   double*        ws;
+};
+
+/* C = alpha * A * B + beta * C on the given stream; FP64 MFMA tiles (dgemm.hip) */
+int hs_dgemm(hipStream_t stream, const hs_gemm_args* args);
+
+/* choose a split-K factor for a [M x N x K] product so that at least ~2 waves of workgroups exist */
+int hs_dgemm_pick_splitk(int M, int N, int K, int lowerOnly);
+
+#endif
