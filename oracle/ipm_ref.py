@@ -1,0 +1,317 @@
+"""ipm_ref.py - TEST INFRASTRUCTURE (oracle).  CPU/numpy restatement of the interior-point method that the HIP engine
+(scip-sdp_amd/csrc/ipm.hip) runs on the GPU.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import this file; the product path never does.
+
+Parity status: the arithmetic of the reference's node solve lives in DSDP 5.8 / SDPA 7.4.4 / MOSEK (INSTALL:10-12), none
+of which is vendored under /root/reference (the reference only marshals into them: src/sdpi/sdpisolver_dsdp.c:1077-1130,
+1503; src/sdpi/sdpisolver_sdpa.cpp:1179-1273, 1620).  The iterates are therefore "parity unpinned"; what IS pinned is the
+result at the SDPI boundary: the known answers of unittests/src/checksdpi.c (tests 1-4, 9-11), the optima of
+check/testset/short.solu, and the acceptance conditions of src/sdpi/sdpsolchecker.c:58-265 (restated in checker.py).
+tests/test_oracle_golden.py checks this file against all of them.
+
+Problem form (src/sdpi/sdpisolver.h:37-42, src/sdpi/sdpi.c:39-58), after the backend's marshalling:
+
+   (D)  min  b^T y   s.t.  Z_k = sum_i A_i^k y_i - A_0^k  psd  (k = 1..K),   z = D y - c >= 0
+   (P)  max  sum_k <A_0^k, X_k> + c^T x   s.t.  sum_k <A_i^k, X_k> + (D^T x)_i = b_i,  X_k psd,  x >= 0
+
+every finite side of an LP row and every finite variable bound is one row of (D, c).
+
+Algorithm: homogeneous self-dual embedding (tau, kappa) with the HKM direction, Mehrotra predictor-corrector; the Schur
+complement is  M_ij = sum_k tr(A_i^k X_k A_j^k Z_k^-1) + (D^T diag(x/z) D)_ij  computed for i, j = 0..m ("variable 0" is
+the constant matrix), which yields M, g = M[0,1:] and omega = M[0,0] in one assembly.
+"""
+import numpy as np
+import scipy.linalg as sla
+
+
+class CoreProblem:
+    """Marshalled problem: b[m]; blocks: list of arrays A[m+1, n, n] (A[0] = constant matrix A_0, A[i] = A_i);
+    D[q, m], c[q] (rows D y - c >= 0)."""
+
+    def __init__(self, b, blocks, D=None, c=None):
+        self.b = np.asarray(b, dtype=np.float64)
+        self.m = self.b.shape[0]
+        self.blocks = [np.ascontiguousarray(A, dtype=np.float64) for A in blocks]
+        for A in self.blocks:
+            assert A.shape[0] == self.m + 1 and A.shape[1] == A.shape[2]
+        if D is None:
+            D = np.zeros((0, self.m))
+            c = np.zeros(0)
+        self.D = np.ascontiguousarray(D, dtype=np.float64).reshape(-1, self.m)
+        self.c = np.asarray(c, dtype=np.float64).reshape(-1)
+        self.q = self.D.shape[0]
+        assert self.c.shape[0] == self.q
+
+    @property
+    def N(self):
+        return sum(A.shape[1] for A in self.blocks) + self.q
+
+
+class Params:
+    def __init__(self, gaptol=1e-5, feastol=1e-5, maxiter=100, gamma=0.98, verbose=False, infeastol=1e-7):
+        self.gaptol = gaptol          # relative gap / absolute gap tolerance (relax_sdp.c:70)
+        self.feastol = feastol        # residual tolerance (relax_sdp.c:71)
+        self.maxiter = maxiter
+        self.gamma = gamma            # fraction of the step to the boundary
+        self.verbose = verbose
+        self.infeastol = infeastol    # tolerance of the Farkas certificates
+
+
+class Result:
+    pass
+
+
+STATUS_OPTIMAL = 0        # both problems feasible, converged
+STATUS_DINF = 1           # (D) infeasible: X-ray with <A_0,X> + c^T x > 0, A(X,x) = 0
+STATUS_DUNB = 2           # (D) unbounded / (P) infeasible: y-ray with b^T y < 0, A^T y psd
+STATUS_PDINF = 3          # both certificates
+STATUS_ITERLIM = 4
+STATUS_NUMERIC = 5
+
+
+def sym(M):
+    return 0.5 * (M + M.T)
+
+
+def schur_block(A, X, Zinv):
+    """Extended Schur contribution of one dense block: Mx[i, j] = tr(A_i X A_j Zinv), i, j = 0..m.
+
+    Same three products as the device path: T_j = A_j Zinv, U_j = X T_j, Mx = A_flat U_flat^T."""
+    m1, n, _ = A.shape
+    T = A.reshape(m1 * n, n) @ Zinv                      # GEMM1: stack of A_j times Zinv
+    U = np.matmul(X, T.reshape(m1, n, n))                # GEMM2: batched X * T_j
+    Mx = A.reshape(m1, n * n) @ U.reshape(m1, n * n).T   # GEMM3
+    return 0.5 * (Mx + Mx.T)
+
+
+def max_step_psd(L, dX):
+    """largest alpha with  L L^T + alpha dX  psd  (inf if dX psd):  -1 / lambda_min(L^-1 dX L^-T)."""
+    W = sla.solve_triangular(L, dX, lower=True)
+    W = sla.solve_triangular(L, W.T, lower=True)
+    lam = sla.eigh(sym(W), eigvals_only=True, subset_by_index=[0, 0])[0]
+    return np.inf if lam >= 0 else -1.0 / lam
+
+
+def max_step_vec(x, dx):
+    neg = dx < 0
+    if not np.any(neg):
+        return np.inf
+    return float(np.min(-x[neg] / dx[neg]))
+
+
+def hsd_solve(prob, par=None, start=None):
+    """Solves the core problem.  Returns Result with y, X (list), Z (list), x, z scaled back by tau, status, iterations."""
+    par = par or Params()
+    m, q, K = prob.m, prob.q, len(prob.blocks)
+    b, D, c = prob.b, prob.D, prob.c
+    Dext = np.concatenate([c.reshape(-1, 1), D], axis=1)      # [q, m+1], column 0 = constant
+    ns = [A.shape[1] for A in prob.blocks]
+    Aflat = [A.reshape(m + 1, -1) for A in prob.blocks]
+    N1 = prob.N + 1
+
+    normb = np.linalg.norm(b)
+    normC = np.sqrt(sum(np.sum(A[0] ** 2) for A in prob.blocks) + np.sum(c ** 2))
+
+    # starting point
+    if start is None:
+        xi = max(1.0, np.sqrt(max(normb, normC, 1.0)))
+        y = np.zeros(m)
+        X = [xi * np.eye(n) for n in ns]
+        Z = [xi * np.eye(n) for n in ns]
+        x = xi * np.ones(q)
+        z = xi * np.ones(q)
+        tau, kappa = 1.0, xi * xi
+    else:
+        y, X, Z, x, z, tau, kappa = start
+
+    res = Result()
+    res.status = STATUS_ITERLIM
+    res.history = []
+    it = 0
+    certwait = 0
+    nstall = 0
+    lastmu = np.inf
+    alpha_last = 1.0
+    for it in range(par.maxiter + 1):
+        # ---- residuals
+        AX = sum(Af @ Xk.reshape(-1) for Af, Xk in zip(Aflat, X)) if K else np.zeros(m + 1)
+        AX = AX + Dext.T @ x                                     # [<A_0,X> + c^T x ; A(X,x)]
+        rp = b * tau - AX[1:]
+        yt = np.concatenate([[-tau], y])
+        Rd = [np.tensordot(yt, A, axes=(0, 0)) - Zk for A, Zk in zip(prob.blocks, Z)]
+        rd = Dext @ yt - z
+        pobj = AX[0]                       # <A_0,X> + c^T x   (times tau scaling below)
+        dobj = b @ y
+        rg = pobj - dobj - kappa
+        mu = (sum(np.sum(Xk * Zk) for Xk, Zk in zip(X, Z)) + x @ z + tau * kappa) / N1
+
+        pinf = np.linalg.norm(rp) / tau / (1.0 + normb)
+        dinf = np.sqrt(sum(np.sum(R ** 2) for R in Rd) + np.sum(rd ** 2)) / tau / (1.0 + normC)
+        # absolute violation of (D) by y / tau, the quantity sdpsolchecker.c:201-257 bounds (|lambda_min| <= ||R_d||_F)
+        dabs = max([np.sqrt(np.sum(R ** 2)) for R in Rd] + [np.max(np.abs(rd)) if q else 0.0]) / tau
+        gap = abs(dobj - pobj) / tau
+        res.history.append((it, mu, pinf, dinf, gap, tau, kappa))
+        if par.verbose:
+            print("it %3d mu %.3e pinf %.3e dinf %.3e gap %.3e pobj %.8e dobj %.8e tau %.3e kap %.3e" %
+                  (it, mu, pinf, dinf, gap, pobj / tau, dobj / tau, tau, kappa))
+
+        # ---- termination
+        # optimal: absolute gap (sdpisolver_dsdp.c:1558-1571) and feasibility of y / tau within feastol
+        if pinf <= par.feastol and dabs <= par.feastol and gap <= par.gaptol:
+            res.status = STATUS_OPTIMAL
+            break
+        # Farkas certificates, scale free: homogeneous residual relative to the objective value it certifies
+        if tau < 1e-2 * min(1.0, kappa) or mu / (tau * tau) > 1e10:
+            hd = np.sqrt(sum(np.sum((R + tau * A[0]) ** 2) for R, A in zip(Rd, prob.blocks))
+                         + np.sum((rd + tau * c) ** 2))              # || A^T y - Z ||
+            hp = np.linalg.norm(AX[1:])                                # || A(X,x) ||
+            big = max(abs(dobj), abs(pobj))
+            cand_dunb = dobj < -1e-3 * big                              # y-ray candidate:  b^T y < 0
+            cand_dinf = pobj > 1e-3 * big                               # X-ray candidate:  <A_0,X> + c^T x > 0
+            ok_dunb = cand_dunb and hd <= par.infeastol * (-dobj)
+            ok_dinf = cand_dinf and hp <= par.infeastol * pobj
+            if (ok_dunb or ok_dinf) and (ok_dunb or not cand_dunb or certwait >= 5) \
+                    and (ok_dinf or not cand_dinf or certwait >= 5):
+                res.status = STATUS_PDINF if (ok_dunb and ok_dinf) else (STATUS_DUNB if ok_dunb else STATUS_DINF)
+                break
+            if ok_dunb or ok_dinf:
+                certwait += 1
+        if it == par.maxiter:
+            break
+        # stall: mu no longer decreases -> numerical limit reached
+        if mu > 0.9 * lastmu and alpha_last < 1e-2:
+            nstall += 1
+            if nstall >= 3:
+                res.status = STATUS_NUMERIC
+                break
+        else:
+            nstall = 0
+        lastmu = mu
+
+        # ---- factorizations and Schur complement
+        try:
+            Lz = [np.linalg.cholesky(Zk) for Zk in Z]
+            Lx = [np.linalg.cholesky(Xk) for Xk in X]
+        except np.linalg.LinAlgError:
+            res.status = STATUS_NUMERIC
+            break
+        Zinv = []
+        for L in Lz:
+            Li = sla.solve_triangular(L, np.eye(L.shape[0]), lower=True)
+            Zinv.append(Li.T @ Li)
+        Mx = np.zeros((m + 1, m + 1))
+        for A, Xk, Zi in zip(prob.blocks, X, Zinv):
+            Mx += schur_block(A, Xk, Zi)
+        if q:
+            Mx += Dext.T @ ((x / z)[:, None] * Dext)
+        g = Mx[0, 1:].copy()
+        M = Mx[1:, 1:]
+        try:
+            Lm = np.linalg.cholesky(M) if m else np.zeros((0, 0))
+        except np.linalg.LinAlgError:
+            # tiny diagonal shift, one retry
+            try:
+                Lm = np.linalg.cholesky(M + (1e-13 * np.trace(M) / max(m, 1) + 1e-300) * np.eye(m))
+            except np.linalg.LinAlgError:
+                res.status = STATUS_NUMERIC
+                break
+
+        def msolve(r):
+            if m == 0:
+                return r
+            w = sla.solve_triangular(Lm, r, lower=True)
+            return sla.solve_triangular(Lm.T, w, lower=False)
+
+        # Stable elimination of (dtau, dkappa).  With w = M^-1 g the direction (1, -w) is the near-null direction of the
+        # extended Schur matrix; omega - g^T M^-1 g is evaluated in factored form (a sum of non-negative terms) instead of
+        # by subtraction, which loses all digits once x/z and X Z^-1 have spread over 16 orders of magnitude.
+        w = msolve(g)
+        ub = msolve(b)
+        u2 = ub - w
+        wt = np.concatenate([[1.0], -w])
+        Bk = [np.tensordot(wt, A, axes=(0, 0)) for A in prob.blocks]      # A_0 - sum_i w_i A_i
+        beta = Dext @ wt                                                   # c - D w
+        S0 = sum(np.sum(Bm * (Xk @ Bm @ Zi)) for Bm, Xk, Zi in zip(Bk, X, Zinv)) + np.sum((x / z) * beta * beta)
+        den = S0 + kappa / tau + b @ ub
+
+        def direction(sigma, eta, E, e_lp, e_tk):
+            """one Newton direction; E/e_lp/e_tk are the second-order terms dXa dZa, dxa*dza, dtau_a*dkappa_a"""
+            H = []
+            for k in range(K):
+                G = eta * (X[k] @ Rd[k])
+                if E is not None:
+                    G = G + E[k]
+                H.append(sigma * mu * Zinv[k] - X[k] - sym(G @ Zinv[k]))
+            hl = sigma * mu / z - x - (eta * x * rd + (e_lp if e_lp is not None else 0.0)) / z
+            AH = sum(Af @ Hk.reshape(-1) for Af, Hk in zip(Aflat, H)) if K else np.zeros(m + 1)
+            AH = AH + Dext.T @ hl
+            h = AH[1:] - eta * rp
+            u1 = msolve(h)
+            BH = sum(np.sum(Bm * Hk) for Bm, Hk in zip(Bk, H)) + beta @ hl
+            num = -eta * rg + (sigma * mu - tau * kappa - e_tk) / tau - BH - eta * (w @ rp) + b @ u1
+            dtau = num / den
+            dy = u1 - u2 * dtau
+            dyt = np.concatenate([[-dtau], dy])
+            dZ = [np.tensordot(dyt, A, axes=(0, 0)) + eta * R for A, R in zip(prob.blocks, Rd)]
+            dz = Dext @ dyt + eta * rd
+            dX = []
+            for k in range(K):
+                G = X[k] @ dZ[k]
+                if E is not None:
+                    G = G + E[k]
+                dX.append(sigma * mu * Zinv[k] - X[k] - sym(G @ Zinv[k]))
+            dx = sigma * mu / z - x - (x * dz + (e_lp if e_lp is not None else 0.0)) / z
+            dkappa = (sigma * mu - tau * kappa - e_tk - kappa * dtau) / tau
+            return dy, dtau, dkappa, dX, dZ, dx, dz
+
+        def steplen(dtau, dkappa, dX, dZ, dx, dz):
+            a = np.inf
+            for k in range(K):
+                a = min(a, max_step_psd(Lx[k], dX[k]), max_step_psd(Lz[k], dZ[k]))
+            a = min(a, max_step_vec(x, dx), max_step_vec(z, dz))
+            if dtau < 0:
+                a = min(a, -tau / dtau)
+            if dkappa < 0:
+                a = min(a, -kappa / dkappa)
+            return a
+
+        # ---- predictor
+        dya, dta, dka, dXa, dZa, dxa, dza = direction(0.0, 1.0, None, None, 0.0)
+        aa = min(1.0, steplen(dta, dka, dXa, dZa, dxa, dza))
+        sigma = min(1.0, max(1e-8, (1.0 - aa) ** 3))
+        eta = 1.0 - sigma
+        # ---- corrector
+        E = [dXa[k] @ dZa[k] for k in range(K)]
+        dy, dt, dk, dX, dZ, dx, dz = direction(sigma, eta, E, dxa * dza, dta * dka)
+        amax = steplen(dt, dk, dX, dZ, dx, dz)
+        alpha = min(1.0, par.gamma * amax)
+        alpha_last = alpha
+        if not np.isfinite(alpha) or not np.all(np.isfinite(dy)):
+            res.status = STATUS_NUMERIC
+            break
+
+        y = y + alpha * dy
+        tau = tau + alpha * dt
+        kappa = kappa + alpha * dk
+        X = [sym(Xk + alpha * d) for Xk, d in zip(X, dX)]
+        Z = [sym(Zk + alpha * d) for Zk, d in zip(Z, dZ)]
+        x = x + alpha * dx
+        z = z + alpha * dz
+
+    res.iterations = it
+    res.tau, res.kappa = tau, kappa
+    res.raw = (y, X, Z, x, z, tau, kappa)
+    if res.status in (STATUS_OPTIMAL, STATUS_ITERLIM, STATUS_NUMERIC):
+        s = 1.0 / tau
+    else:
+        # rays are normalised by the objective value they certify
+        s = 1.0 / max(abs(b @ y), abs(AX[0]), 1e-300)
+    res.y = y * s
+    res.X = [Xk * s for Xk in X]
+    res.Z = [Zk * s for Zk in Z]
+    res.x = x * s
+    res.z = z * s
+    res.pobj = float(AX[0] * s)
+    res.dobj = float(b @ y * s)
+    res.pinf, res.dinf, res.dabs, res.gap, res.mu = pinf, dinf, dabs, gap, mu
+    return res
