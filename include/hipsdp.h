@@ -1,0 +1,148 @@
+/* hipsdp.h - C ABI of the MI355X interior-point engine (libhipsdp.so).
+ *
+ * This is the layer UNDER the SCIP-SDP solver interface: src/sdpi/sdpisolver_hip.c (the drop-in for the reference's
+ * src/sdpi/sdpisolver_{dsdp,sdpa,mosek}.c, see include/sdpisolver_hip.h) marshals the arguments of
+ * SCIPsdpiSolverLoadAndSolveWithPenalty (reference: src/sdpi/sdpisolver.h:258-322) into the calls below, exactly where
+ * the reference backends call DSDPCreate/SDPConeSetASparseVecMat/LPConeSetData2/DSDPSolve/DSDPComputeX
+ * (src/sdpi/sdpisolver_dsdp.c:983-1520) or SDPA::inputElement/initializeSolve/solve
+ * (src/sdpi/sdpisolver_sdpa.cpp:1179-1670).  Plain C types only; no torch, no C++ in the signatures.
+ *
+ * Problem handed to the engine (all fixings / index compaction already applied by the caller):
+ *
+ *    min  b^T y   s.t.  sum_i A_i^k y_i - A_0^k  psd  (k = 0..nblocks-1),    D y - c >= 0  (q rows)
+ *
+ * All functions return 0 (HIPSDP_OK) or an HIPSDP_ERR_* code; hipsdp_last_error() gives a message.
+ * There is NO CPU fallback: without a usable gfx950 device every computing call returns HIPSDP_ERR_NODEVICE.
+ */
+#ifndef HIPSDP_H
+#define HIPSDP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIPSDP_OK             0
+#define HIPSDP_ERR_NODEVICE   1
+#define HIPSDP_ERR_HIP        2
+#define HIPSDP_ERR_ARG        3
+#define HIPSDP_ERR_NOMEM      4
+#define HIPSDP_ERR_NUMERIC    5
+
+/* termination status of hipsdp_solve (hipsdp_info.status) */
+#define HIPSDP_STATUS_OPTIMAL   0    /* both problems feasible, tolerances met */
+#define HIPSDP_STATUS_DINF      1    /* the y-problem ("dual" in SCIP-SDP terms) is infeasible: X-ray found */
+#define HIPSDP_STATUS_DUNB      2    /* the y-problem is unbounded / the X-problem infeasible: y-ray found */
+#define HIPSDP_STATUS_PDINF     3    /* both certificates */
+#define HIPSDP_STATUS_ITERLIM   4
+#define HIPSDP_STATUS_NUMERIC   5    /* stalled / factorization failure */
+#define HIPSDP_STATUS_TIMELIM   6
+#define HIPSDP_STATUS_OBJLIM    7    /* the X-problem objective (a lower bound) exceeded the objective limit */
+#define HIPSDP_STATUS_UNSOLVED -1
+
+typedef struct hipsdp_solver hipsdp_solver;
+
+typedef struct hipsdp_params
+{
+   double gaptol;        /* absolute duality gap tolerance            (SCIP_SDPPAR_GAPTOL, type_sdpi.h:50) */
+   double feastol;       /* absolute feasibility tolerance of y        (SCIP_SDPPAR_SDPSOLVERFEASTOL, type_sdpi.h:52) */
+   double infeastol;     /* relative tolerance of Farkas certificates */
+   double objlimit;      /* stop when the lower bound exceeds this; >= 1e20: off (SCIP_SDPPAR_OBJLIMIT, type_sdpi.h:53) */
+   double timelimit;     /* seconds for this call; <= 0: off */
+   double gamma;         /* fraction of the step to the boundary */
+   double ws_gbytes;     /* workspace budget of the Schur assembly in GB; <= 0: default */
+   int    maxiter;
+   int    verbose;       /* 1: one line per iteration on stdout (SCIP_SDPPAR_SDPINFO) */
+   int    lanczos_steps; /* Lanczos steps per step-length estimate */
+   int    reserved;
+} hipsdp_params;
+
+typedef struct hipsdp_info
+{
+   int    status;
+   int    iterations;
+   double pobj;          /* sum_k <A_0^k, X_k> + c^T x   (X-problem, lower bound when feasible) */
+   double dobj;          /* b^T y */
+   double pinf;          /* ||b - A(X)|| / (1 + ||b||) */
+   double dinf;          /* ||A^T y - A_0 - Z|| / (1 + ||A_0||) */
+   double dabs;          /* max_k ||A^T y - A_0 - Z||_F : absolute violation bound of y */
+   double gap;           /* |pobj - dobj| */
+   double mu;
+   double tau, kappa;
+   double solve_seconds;    /* wall time of hipsdp_solve */
+   double schur_seconds;    /* device time spent in the Schur assembly (sum of HIP event intervals) */
+   double schur_flops;      /* algorithmic flops of the assemblies: (4 m1 n^3 + m1^2 n^2) per block and iteration */
+   int    schur_calls;
+   int    chol_fail;        /* number of step halvings forced by a failed Cholesky */
+} hipsdp_info;
+
+const char* hipsdp_last_error(void);
+const char* hipsdp_version(void);
+int  hipsdp_device_count(void);
+void hipsdp_default_params(hipsdp_params* p);
+
+int  hipsdp_create(hipsdp_solver** solver, int device);
+void hipsdp_free(hipsdp_solver** solver);
+
+/* Declares the shape: m variables, nblocks dense SDP blocks of the given sizes, q LP rows.  Allocates the device storage
+ * A_k[(m+1) x n_k^2] (row i = vec(A_i), row 0 = constant matrix), zero filled. */
+int  hipsdp_set_shape(hipsdp_solver* solver, int m, int nblocks, const int* blocksizes, int q);
+/* objective b[m] (host) */
+int  hipsdp_set_obj(hipsdp_solver* solver, const double* b);
+/* Scatter lower-triangular COO entries (row >= col) into block k: entry e belongs to matrix var[e] (0 = constant matrix,
+ * i = variable i, 1-based) at (row[e], col[e]); both triangles of the dense storage are written.  Host arrays. */
+int  hipsdp_add_entries(hipsdp_solver* solver, int block, long long nnz, const int* var, const int* row, const int* col,
+   const double* val);
+/* dense upload of a whole block: A[(m+1) * n * n] host, row-major */
+int  hipsdp_set_block_dense(hipsdp_solver* solver, int block, const double* A);
+/* LP rows: Dext[q x (m+1)] host, row-major, column 0 = c (constant), columns 1..m = D */
+int  hipsdp_set_lp(hipsdp_solver* solver, const double* Dext);
+/* device-resident access for generators / benchmarks: pointer to A_k on the device */
+int  hipsdp_block_device_ptr(hipsdp_solver* solver, int block, double** dptr);
+
+/* optional warm start (host arrays; X, Z: nblocks dense n_k x n_k matrices; x, z: q) */
+int  hipsdp_set_start(hipsdp_solver* solver, const double* y, const double* const* X, const double* const* Z,
+   const double* x, const double* z);
+
+int  hipsdp_solve(hipsdp_solver* solver, const hipsdp_params* params, hipsdp_info* info);
+
+/* solution readback (host arrays).  For STATUS_OPTIMAL the iterate scaled by 1 / tau; for the infeasibility statuses
+ * the normalised ray. */
+int  hipsdp_get_y(hipsdp_solver* solver, double* y);
+int  hipsdp_get_X(hipsdp_solver* solver, int block, double* X);
+int  hipsdp_get_Z(hipsdp_solver* solver, int block, double* Z);
+int  hipsdp_get_lp(hipsdp_solver* solver, double* x, double* z);
+
+/* smallest eigenvalue of  sum_i A_i^k y_i - A_0^k  for every block, on the device (backs the feasibility check of
+ * sdpsolchecker.c:201-257 inside the backend); y: m host values; lmin: nblocks host values */
+int  hipsdp_check_y(hipsdp_solver* solver, const double* y, double* lmin, double* lpviol);
+
+/* multi-GPU: Schur rows are sharded over the ranks of an RCCL communicator (one process per GPU); comm is a ncclComm_t */
+int  hipsdp_set_comm(hipsdp_solver* solver, void* comm, int rank, int nranks);
+int  hipsdp_comm_create(const void* unique_id_128bytes, int rank, int nranks, void** comm);
+int  hipsdp_comm_unique_id(void* unique_id_128bytes);
+void hipsdp_comm_destroy(void* comm);
+
+/* synthetic instance of BASELINE.md section 3 generated on the device (one dense block n, m variables, no LP rows):
+ * fills A_1..A_m; the caller supplies A_0 and b (see oracle/instances.py) or uses hipsdp_gen_finish */
+int  hipsdp_gen_planted(hipsdp_solver* solver, int n, int m, long long seed, double* b_out, double* ystar_out);
+
+/* ---- host-buffer dense kernels (unit-level entry points; used by lapack_interface_hip.c and by the parity tests) ---- */
+/* C[M x N] = alpha * op(A) * op(B) + beta * C, row-major; layA/layB: 0 = K contiguous, 1 = M (resp. N) contiguous */
+int  hipsdp_dgemm(int device, int layA, int layB, int M, int N, int K, double alpha, const double* A, long long lda,
+   const double* B, long long ldb, double beta, double* C, long long ldc, int lower_only, int splitk);
+/* Schur block Mx[(m1) x (m1)] = tr(A_i X A_j Zinv) for i, j = 0..m1-1 */
+int  hipsdp_schur_dense(int device, int m1, int n, const double* A, const double* X, const double* Zinv, double* Mx,
+   double ws_gbytes);
+int  hipsdp_potrf(int device, int n, double* A, int* fail);                       /* lower Cholesky in place, row-major */
+int  hipsdp_potrs(int device, int n, const double* A, int nrhs, double* rhs);     /* factor + solve, rhs[k * n + i] */
+int  hipsdp_trtri(int device, int n, const double* A, double* Linv);              /* A spd -> inverse of its Cholesky factor */
+int  hipsdp_lambda_min(int device, int n, const double* W, int steps, double* theta, double* resid);
+int  hipsdp_syev(int device, int n, const double* A, double* lam, double* V);     /* ascending, eigenvectors as rows */
+int  hipsdp_gemv_n(int device, int R, long long E, const double* A, int nv, const double* V, double* out);
+int  hipsdp_gemv_t(int device, int R, long long E, const double* A, const double* coef, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

@@ -1,0 +1,242 @@
+"""binding.py - ctypes view of libhipsdp.so's C ABI (include/hipsdp.h) for the test-suite, bench.py and
+__graft_entry__.py.  This is plumbing only: no arithmetic happens here, and nothing in this file imports oracle/.
+If the shared library is missing or there is no GPU, calls fail loudly (RuntimeError) - there is no fallback path."""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBPATH = os.path.join(_HERE, "lib", "libhipsdp.so")
+
+STATUS_NAMES = {0: "optimal", 1: "dual_infeasible", 2: "dual_unbounded", 3: "both_infeasible", 4: "iterlimit",
+                5: "numeric", 6: "timelimit", 7: "objlimit", -1: "unsolved"}
+
+
+class Params(C.Structure):
+    _fields_ = [("gaptol", C.c_double), ("feastol", C.c_double), ("infeastol", C.c_double), ("objlimit", C.c_double),
+                ("timelimit", C.c_double), ("gamma", C.c_double), ("ws_gbytes", C.c_double), ("maxiter", C.c_int),
+                ("verbose", C.c_int), ("lanczos_steps", C.c_int), ("reserved", C.c_int)]
+
+
+class Info(C.Structure):
+    _fields_ = [("status", C.c_int), ("iterations", C.c_int), ("pobj", C.c_double), ("dobj", C.c_double),
+                ("pinf", C.c_double), ("dinf", C.c_double), ("dabs", C.c_double), ("gap", C.c_double), ("mu", C.c_double),
+                ("tau", C.c_double), ("kappa", C.c_double), ("solve_seconds", C.c_double), ("schur_seconds", C.c_double),
+                ("schur_flops", C.c_double), ("schur_calls", C.c_int), ("chol_fail", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    """loads libhipsdp.so (raises if it was not built: run `python -c 'import __graft_entry__ as g; g.build()'`)"""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIBPATH):
+            raise RuntimeError("libhipsdp.so not built (%s); run __graft_entry__.build()" % LIBPATH)
+        _lib = C.CDLL(LIBPATH, mode=C.RTLD_GLOBAL)
+        _lib.hipsdp_last_error.restype = C.c_char_p
+        _lib.hipsdp_version.restype = C.c_char_p
+    return _lib
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed: rc=%d (%s)" % (what, rc, lib().hipsdp_last_error().decode()))
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def device_count():
+    return lib().hipsdp_device_count()
+
+
+class Solver:
+    """thin RAII wrapper of hipsdp_solver"""
+
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        _chk(lib().hipsdp_create(C.byref(self.h), device), "hipsdp_create")
+        self.m = 0
+        self.ns = []
+        self.q = 0
+
+    def close(self):
+        if self.h:
+            lib().hipsdp_free(C.byref(self.h))
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_shape(self, m, blocksizes, q):
+        bs = np.asarray(blocksizes, dtype=np.int32)
+        _chk(lib().hipsdp_set_shape(self.h, m, len(bs), _ip(bs), q), "hipsdp_set_shape")
+        self.m, self.ns, self.q = m, [int(v) for v in bs], q
+
+    def set_obj(self, b):
+        b = _f64(b)
+        _chk(lib().hipsdp_set_obj(self.h, _dp(b)), "hipsdp_set_obj")
+
+    def set_block_dense(self, k, A):
+        A = _f64(A)
+        assert A.size == (self.m + 1) * self.ns[k] ** 2
+        _chk(lib().hipsdp_set_block_dense(self.h, k, _dp(A)), "hipsdp_set_block_dense")
+
+    def add_entries(self, k, var, row, col, val):
+        var = np.ascontiguousarray(var, dtype=np.int32)
+        row = np.ascontiguousarray(row, dtype=np.int32)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        val = _f64(val)
+        _chk(lib().hipsdp_add_entries(self.h, k, C.c_longlong(len(val)), _ip(var), _ip(row), _ip(col), _dp(val)),
+             "hipsdp_add_entries")
+
+    def set_lp(self, Dext):
+        Dext = _f64(Dext)
+        _chk(lib().hipsdp_set_lp(self.h, _dp(Dext)), "hipsdp_set_lp")
+
+    def block_device_ptr(self, k):
+        p = C.POINTER(C.c_double)()
+        _chk(lib().hipsdp_block_device_ptr(self.h, k, C.byref(p)), "hipsdp_block_device_ptr")
+        return C.cast(p, C.c_void_p).value
+
+    def load_core(self, prob):
+        """prob: object with m, b, blocks (list of [m+1, n, n]), D [q, m], c [q] (the oracle's CoreProblem layout)"""
+        self.set_shape(prob.m, [A.shape[1] for A in prob.blocks], prob.q)
+        self.set_obj(prob.b)
+        for k, A in enumerate(prob.blocks):
+            self.set_block_dense(k, A)
+        if prob.q:
+            self.set_lp(np.concatenate([np.asarray(prob.c).reshape(-1, 1), prob.D], axis=1))
+
+    def solve(self, **kw):
+        p = Params()
+        lib().hipsdp_default_params(C.byref(p))
+        for k, v in kw.items():
+            setattr(p, k, v)
+        info = Info()
+        _chk(lib().hipsdp_solve(self.h, C.byref(p), C.byref(info)), "hipsdp_solve")
+        return info
+
+    def y(self):
+        out = np.zeros(self.m)
+        _chk(lib().hipsdp_get_y(self.h, _dp(out)), "hipsdp_get_y")
+        return out
+
+    def X(self, k):
+        out = np.zeros((self.ns[k], self.ns[k]))
+        _chk(lib().hipsdp_get_X(self.h, k, _dp(out)), "hipsdp_get_X")
+        return out
+
+    def Z(self, k):
+        out = np.zeros((self.ns[k], self.ns[k]))
+        _chk(lib().hipsdp_get_Z(self.h, k, _dp(out)), "hipsdp_get_Z")
+        return out
+
+    def lp(self):
+        x = np.zeros(self.q)
+        z = np.zeros(self.q)
+        _chk(lib().hipsdp_get_lp(self.h, _dp(x), _dp(z)), "hipsdp_get_lp")
+        return x, z
+
+    def check_y(self, y):
+        y = _f64(y)
+        lmin = np.zeros(max(1, len(self.ns)))
+        viol = C.c_double(0.0)
+        _chk(lib().hipsdp_check_y(self.h, _dp(y), _dp(lmin), C.byref(viol)), "hipsdp_check_y")
+        return lmin[:len(self.ns)], viol.value
+
+
+# ---- unit-level host-buffer kernels ---------------------------------------------------------------------------------
+
+def dgemm(A, B, layA=0, layB=1, alpha=1.0, beta=0.0, Cin=None, lower_only=False, splitk=0, device=0):
+    """row-major C = alpha op(A) op(B) + beta C.  layA = 0: A is [M, K]; 1: A is [K, M].  layB = 0: B is [N, K]; 1: [K, N]."""
+    A = _f64(A)
+    B = _f64(B)
+    M, K = (A.shape if layA == 0 else A.shape[::-1])
+    N = B.shape[0] if layB == 0 else B.shape[1]
+    Cout = np.zeros((M, N)) if Cin is None else _f64(Cin).copy()
+    _chk(lib().hipsdp_dgemm(device, layA, layB, M, N, K, C.c_double(alpha), _dp(A), C.c_longlong(A.shape[1]), _dp(B),
+                            C.c_longlong(B.shape[1]), C.c_double(beta), _dp(Cout), C.c_longlong(N), int(lower_only), splitk),
+         "hipsdp_dgemm")
+    return Cout
+
+
+def schur_dense(A, X, Zinv, ws_gbytes=0.0, device=0):
+    A = _f64(A)
+    m1, n = A.shape[0], A.shape[1]
+    X = _f64(X)
+    Zinv = _f64(Zinv)
+    Mx = np.zeros((m1, m1))
+    _chk(lib().hipsdp_schur_dense(device, m1, n, _dp(A), _dp(X), _dp(Zinv), _dp(Mx), C.c_double(ws_gbytes)),
+         "hipsdp_schur_dense")
+    return Mx
+
+
+def potrf(A, device=0):
+    L = _f64(A).copy()
+    fail = C.c_int(0)
+    _chk(lib().hipsdp_potrf(device, L.shape[0], _dp(L), C.byref(fail)), "hipsdp_potrf")
+    return np.tril(L), fail.value
+
+
+def potrs(A, rhs, device=0):
+    A = _f64(A)
+    r = _f64(rhs).copy()
+    r2 = r.reshape(-1, A.shape[0])
+    _chk(lib().hipsdp_potrs(device, A.shape[0], _dp(A), r2.shape[0], _dp(r2)), "hipsdp_potrs")
+    return r2.reshape(r.shape)
+
+
+def trtri(A, device=0):
+    A = _f64(A)
+    Li = np.zeros_like(A)
+    _chk(lib().hipsdp_trtri(device, A.shape[0], _dp(A), _dp(Li)), "hipsdp_trtri")
+    return Li
+
+
+def lambda_min(W, steps=0, device=0):
+    W = _f64(W)
+    th = C.c_double(0.0)
+    rs = C.c_double(0.0)
+    _chk(lib().hipsdp_lambda_min(device, W.shape[0], _dp(W), steps, C.byref(th), C.byref(rs)), "hipsdp_lambda_min")
+    return th.value, rs.value
+
+
+def syev(A, device=0):
+    A = _f64(A)
+    n = A.shape[0]
+    lam = np.zeros(n)
+    V = np.zeros((n, n))
+    _chk(lib().hipsdp_syev(device, n, _dp(A), _dp(lam), _dp(V)), "hipsdp_syev")
+    return lam, V
+
+
+def gemv_n(A, V, device=0):
+    A = _f64(A)
+    V = _f64(V).reshape(-1, A.shape[1])
+    out = np.zeros((V.shape[0], A.shape[0]))
+    _chk(lib().hipsdp_gemv_n(device, A.shape[0], C.c_longlong(A.shape[1]), _dp(A), V.shape[0], _dp(V), _dp(out)),
+         "hipsdp_gemv_n")
+    return out
+
+
+def gemv_t(A, coef, device=0):
+    A = _f64(A)
+    coef = _f64(coef)
+    out = np.zeros(A.shape[1])
+    _chk(lib().hipsdp_gemv_t(device, A.shape[0], C.c_longlong(A.shape[1]), _dp(A), _dp(coef), _dp(out)), "hipsdp_gemv_t")
+    return out

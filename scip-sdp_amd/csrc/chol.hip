@@ -1,0 +1,321 @@
+/* chol.hip - dense Cholesky of the Schur complement M and of the blocks X, Z; triangular inverse; triangular solves.
+ *
+ * The reference contains no Cholesky at all: the factorization of the Schur matrix is
+ * inside DSDP/SDPA.  This file is the MI355X version of that step:
+ *   - right-looking blocked factorization with 64-wide panels; the 64 x 64 diagonal block is factored (and inverted) by
+ *     one workgroup in LDS, the panel solve and the trailing update are FP64-MFMA GEMMs (dgemm.hip), so the O(n^3) part
+ *     runs on the matrix cores;
+ *   - the inverses of the diagonal blocks are kept: triangular solves and the triangular inverse then consist of small
+ *     matrix products only (no divisions on the critical path).
+ */
+#include "hs_kernels.h"
+
+#define NB 64
+#define HS_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if ( e_ != hipSuccess ) { hs_record_hip_error(e_, "kernel launch", __FILE__, __LINE__); return HS_ERR_HIP; } } while (0)
+
+/* Factor the nb x nb diagonal block at A (leading dimension lda), nb <= 64: A_blk = L L^T.  Writes L into the lower
+ * triangle of the block and inv(L) (64 x 64, identity-padded) into dinv.  flag: first failing global pivot index + 1. */
+__global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ A, long long lda, int nb, int j0,
+   double* __restrict__ dinv, int* __restrict__ flag)
+{
+   __shared__ double a[NB][NB + 1];
+   __shared__ double li[NB][NB + 1];
+   __shared__ int bad;
+   const int tid = threadIdx.x;
+   if ( tid == 0 )
+      bad = 0;
+   for (int e = tid; e < NB * NB; e += 256)
+   {
+      const int r = e / NB, c = e % NB;
+      double v = (r == c) ? 1.0 : 0.0;
+      if ( r < nb && c < nb && c <= r )
+         v = A[(long long) r * lda + c];
+      a[r][c] = v;
+   }
+   __syncthreads();
+
+   for (int k = 0; k < nb; ++k)
+   {
+      if ( tid == 0 )
+      {
+         double d = a[k][k];
+         if ( !(d > 0.0) )
+         {
+            if ( bad == 0 )
+               bad = j0 + k + 1;
+            d = 1.0;                 /* keep going with a harmless pivot; the caller reads the flag */
+            a[k][k] = 1.0;
+         }
+         a[k][k] = sqrt(d);
+      }
+      __syncthreads();
+      const double dk = a[k][k];
+      for (int i = k + 1 + tid; i < nb; i += 256)
+         a[i][k] /= dk;
+      __syncthreads();
+      /* trailing update of the lower triangle */
+      const int rem = nb - k - 1;
+      for (int e = tid; e < rem * rem; e += 256)
+      {
+         const int i = k + 1 + e / rem;
+         const int j = k + 1 + e % rem;
+         if ( j <= i )
+            a[i][j] -= a[i][k] * a[j][k];
+      }
+      __syncthreads();
+   }
+
+   /* inverse by forward substitution, one column per thread */
+   if ( tid < NB )
+   {
+      const int c = tid;
+      for (int i = 0; i < NB; ++i)
+      {
+         double s = (i == c) ? 1.0 : 0.0;
+         for (int k = c; k < i; ++k)
+            s -= a[i][k] * li[k][c];
+         li[i][c] = (i < c) ? 0.0 : s / a[i][i];
+      }
+   }
+   __syncthreads();
+
+   for (int e = tid; e < NB * NB; e += 256)
+   {
+      const int r = e / NB, c = e % NB;
+      dinv[e] = li[r][c];
+      if ( r < nb && c <= r )
+         A[(long long) r * lda + c] = a[r][c];
+   }
+   if ( tid == 0 && bad != 0 )
+      atomicCAS(flag, 0, bad);
+}
+
+int hs_potrf(hipStream_t s, int n, double* A, double* dinv, int* flag, double* ws_gemm)
+{
+   (void) ws_gemm;
+   if ( n <= 0 )
+      return HS_OK;
+   const long long lda = n;
+   const int nblk = (n + NB - 1) / NB;
+   for (int b = 0; b < nblk; ++b)
+   {
+      const int j0 = b * NB;
+      const int nb = (n - j0) < NB ? (n - j0) : NB;
+      double* Ajj = A + (long long) j0 * lda + j0;
+      double* dj = dinv + (long long) b * NB * NB;
+      hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, s, Ajj, lda, nb, j0, dj, flag);
+      HS_LAUNCH_CHECK();
+      const int j1 = j0 + nb;
+      const int rem = n - j1;
+      if ( rem <= 0 )
+         break;
+      /* panel: P = A[j1:, j0:j1] * inv(L_jj)^T   (in place: one workgroup column covers all nb columns) */
+      double* P = A + (long long) j1 * lda + j0;
+      hs_gemm_args g1 = {rem, nb, nb, HS_KC, HS_KC, P, lda, 0, dj, NB, 0, P, lda, 0, 1.0, 0.0, 1, 0, 1, NULL};
+      HS_CALL( hs_dgemm(s, &g1) );
+      /* trailing update: A22 -= P P^T on the lower triangle */
+      double* A22 = A + (long long) j1 * lda + j1;
+      hs_gemm_args g2 = {rem, rem, nb, HS_KC, HS_KC, P, lda, 0, P, lda, 0, A22, lda, 0, -1.0, 1.0, 1, HS_GEMM_LOWER, 1, NULL};
+      HS_CALL( hs_dgemm(s, &g2) );
+   }
+   return HS_OK;
+}
+
+__global__ void k_copy_block(const double* __restrict__ src, long long lds_, double* __restrict__ dst, long long ldd, int rows, int cols,
+   double scale)
+{
+   const int total = rows * cols;
+   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x)
+   {
+      const int r = e / cols, c = e % cols;
+      dst[(long long) r * ldd + c] = scale * src[(long long) r * lds_ + c];
+   }
+}
+
+int hs_trtri(hipStream_t s, int n, const double* L, const double* dinv, double* Linv, double* tmp)
+{
+   if ( n <= 0 )
+      return HS_OK;
+   const long long ld = n;
+   HS_CALL( hs_fill(s, Linv, (long long) n * n, 0.0) );
+   const int nblk = (n + NB - 1) / NB;
+   for (int b = 0; b < nblk; ++b)
+   {
+      const int i0 = b * NB;
+      const int nb = (n - i0) < NB ? (n - i0) : NB;
+      const double* db = dinv + (long long) b * NB * NB;
+      /* diagonal block */
+      hipLaunchKernelGGL(k_copy_block, dim3(16), dim3(256), 0, s, db, (long long) NB, Linv + (long long) i0 * ld + i0, ld, nb, nb, 1.0);
+      HS_LAUNCH_CHECK();
+      if ( b == 0 )
+         continue;
+      /* tmp[nb x i0] = L[i0:i0+nb, 0:i0] * Linv[0:i0, 0:i0] */
+      hs_gemm_args g1 = {nb, i0, i0, HS_KC, HS_MC, L + (long long) i0 * ld, ld, 0, Linv, ld, 0, tmp, (long long) i0, 0, 1.0, 0.0, 1, 0, 1, NULL};
+      HS_CALL( hs_dgemm(s, &g1) );
+      /* Linv[i0:i0+nb, 0:i0] = - inv(L_bb) * tmp */
+      hs_gemm_args g2 = {nb, i0, nb, HS_KC, HS_MC, db, NB, 0, tmp, (long long) i0, 0, Linv + (long long) i0 * ld, ld, 0, -1.0, 0.0, 1, 0, 1, NULL};
+      HS_CALL( hs_dgemm(s, &g2) );
+   }
+   return HS_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------- */
+/* triangular solves with up to 4 right-hand sides: one workgroup of 1024 threads walks the 64-wide block columns    */
+/* ---------------------------------------------------------------------------------------------------------------- */
+
+struct __attribute__((aligned(16))) dbl2c { double x, y; };
+
+template<int NRHS>
+__global__ void __launch_bounds__(1024) k_trsv(int n, const double* __restrict__ L, const double* __restrict__ dinv,
+   double* __restrict__ rhs, long long ldr, int mode)
+{
+   __shared__ double xs[NRHS][NB];
+   __shared__ double red[64][NB + 1];
+   const int tid = threadIdx.x;
+   const int grp = tid >> 4;       /* 64 row groups */
+   const int part = tid & 15;      /* 16 lanes per row, 4 columns each */
+   const int nblk = (n + NB - 1) / NB;
+   const long long ld = n;
+
+   if ( mode & 1 )
+   {
+      for (int b = 0; b < nblk; ++b)
+      {
+         const int j0 = b * NB;
+         const int nb = (n - j0) < NB ? (n - j0) : NB;
+         const double* db = dinv + (long long) b * NB * NB;
+         /* x_blk = inv(L_bb) * r_blk : row grp, 16 lanes share the 64-long dot product */
+         for (int k = 0; k < NRHS; ++k)
+         {
+            double sacc = 0.0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+            {
+               const int col = 4 * part + c;
+               const double rv = (col < nb) ? rhs[(long long) k * ldr + j0 + col] : 0.0;
+               sacc += db[grp * NB + col] * rv;
+            }
+            sacc += __shfl_xor(sacc, 1, 64);
+            sacc += __shfl_xor(sacc, 2, 64);
+            sacc += __shfl_xor(sacc, 4, 64);
+            sacc += __shfl_xor(sacc, 8, 64);
+            if ( part == 0 )
+               xs[k][grp] = sacc;
+         }
+         __syncthreads();
+         if ( tid < NB * NRHS )
+         {
+            const int k = tid / NB, i = tid % NB;
+            if ( i < nb )
+               rhs[(long long) k * ldr + j0 + i] = xs[k][i];
+         }
+         /* r[i] -= L[i, blk] * x_blk for the rows below */
+         for (int i = j0 + nb + grp; i < n; i += 64)
+         {
+            const double* lrow = L + (long long) i * ld + j0 + 4 * part;
+            double l0 = 0.0, l1 = 0.0, l2 = 0.0, l3 = 0.0;
+            if ( 4 * part + 3 < nb )
+            {
+               l0 = lrow[0]; l1 = lrow[1]; l2 = lrow[2]; l3 = lrow[3];
+            }
+            else
+            {
+               if ( 4 * part + 0 < nb ) l0 = lrow[0];
+               if ( 4 * part + 1 < nb ) l1 = lrow[1];
+               if ( 4 * part + 2 < nb ) l2 = lrow[2];
+            }
+#pragma unroll
+            for (int k = 0; k < NRHS; ++k)
+            {
+               double sacc = l0 * xs[k][4 * part] + l1 * xs[k][4 * part + 1] + l2 * xs[k][4 * part + 2] + l3 * xs[k][4 * part + 3];
+               sacc += __shfl_xor(sacc, 1, 64);
+               sacc += __shfl_xor(sacc, 2, 64);
+               sacc += __shfl_xor(sacc, 4, 64);
+               sacc += __shfl_xor(sacc, 8, 64);
+               if ( part == 0 )
+                  rhs[(long long) k * ldr + i] -= sacc;
+            }
+         }
+         __syncthreads();
+      }
+   }
+
+   if ( mode & 2 )
+   {
+      for (int b = nblk - 1; b >= 0; --b)
+      {
+         const int j0 = b * NB;
+         const int nb = (n - j0) < NB ? (n - j0) : NB;
+         const double* db = dinv + (long long) b * NB * NB;
+         for (int k = 0; k < NRHS; ++k)
+         {
+            /* s[c] = sum_{i below} L[i, j0 + c] * x[i] : partial sums per row group, then across groups */
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            for (int i = j0 + nb + grp; i < n; i += 64)
+            {
+               const double* lrow = L + (long long) i * ld + j0 + 4 * part;
+               const double xv = rhs[(long long) k * ldr + i];
+               if ( 4 * part + 3 < nb )
+               {
+                  a0 += lrow[0] * xv; a1 += lrow[1] * xv; a2 += lrow[2] * xv; a3 += lrow[3] * xv;
+               }
+               else
+               {
+                  if ( 4 * part + 0 < nb ) a0 += lrow[0] * xv;
+                  if ( 4 * part + 1 < nb ) a1 += lrow[1] * xv;
+                  if ( 4 * part + 2 < nb ) a2 += lrow[2] * xv;
+               }
+            }
+            red[grp][4 * part + 0] = a0;
+            red[grp][4 * part + 1] = a1;
+            red[grp][4 * part + 2] = a2;
+            red[grp][4 * part + 3] = a3;
+            __syncthreads();
+            if ( tid < NB )
+            {
+               double sacc = 0.0;
+               for (int g = 0; g < 64; ++g)
+                  sacc += red[g][tid];
+               const double yv = (tid < nb) ? rhs[(long long) k * ldr + j0 + tid] : 0.0;
+               xs[k][tid] = yv - sacc;
+            }
+            __syncthreads();
+         }
+         /* x_blk = inv(L_bb)^T * (y_blk - s) */
+         for (int k = 0; k < NRHS; ++k)
+         {
+            double sacc = 0.0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+            {
+               const int row = 4 * part + c;
+               sacc += db[row * NB + grp] * ((row < nb) ? xs[k][row] : 0.0);
+            }
+            sacc += __shfl_xor(sacc, 1, 64);
+            sacc += __shfl_xor(sacc, 2, 64);
+            sacc += __shfl_xor(sacc, 4, 64);
+            sacc += __shfl_xor(sacc, 8, 64);
+            if ( part == 0 && grp < nb )
+               rhs[(long long) k * ldr + j0 + grp] = sacc;
+         }
+         __syncthreads();
+      }
+   }
+}
+
+int hs_trsv(hipStream_t s, int n, const double* L, const double* dinv, int nrhs, double* rhs, long long ldr, int mode)
+{
+   if ( n <= 0 || nrhs <= 0 )
+      return HS_OK;
+   if ( nrhs > 4 )
+      return HS_ERR_ARG;
+   switch ( nrhs )
+   {
+   case 1: hipLaunchKernelGGL((k_trsv<1>), dim3(1), dim3(1024), 0, s, n, L, dinv, rhs, ldr, mode); break;
+   case 2: hipLaunchKernelGGL((k_trsv<2>), dim3(1), dim3(1024), 0, s, n, L, dinv, rhs, ldr, mode); break;
+   case 3: hipLaunchKernelGGL((k_trsv<3>), dim3(1), dim3(1024), 0, s, n, L, dinv, rhs, ldr, mode); break;
+   default: hipLaunchKernelGGL((k_trsv<4>), dim3(1), dim3(1024), 0, s, n, L, dinv, rhs, ldr, mode); break;
+   }
+   HS_LAUNCH_CHECK();
+   return HS_OK;
+}

@@ -1,0 +1,477 @@
+/* eig.hip - symmetric eigenvalue kernels.
+ *
+ *  (1) hs_lanczos_lmin: smallest eigenvalue of a dense symmetric matrix by Lanczos with full (twice-applied classical
+ *      Gram-Schmidt) re-orthogonalisation.  The interior-point step lengths need lambda_min(L^-1 dX L^-T) four times per
+ *      iteration; a Householder tridiagonalisation is n dependent rank-2 updates (latency bound on a GPU), whereas
+ *      Lanczos is a few dozen matrix-vector products whose matrix (2-8 MB at n = 500-1000) stays in L2 / Infinity Cache.
+ *      The Ritz value comes with its residual bound, and the caller steps with the pessimistic value theta - resid.
+ *  (2) hs_syev_jacobi: full eigen-decomposition by parallel-order cyclic Jacobi: every round applies n/2 disjoint plane
+ *      rotations two-sided in ONE kernel (each thread owns the 2 x 2 intersection of two rotation pairs), so a sweep is
+ *      n - 1 launches with n^2/4-way parallelism.  It backs the SCIPlapack* surface (lapack_interface.c:178-603: DSYEVR
+ *      with RANGE = 'I', 'V', 'A'); ordering and eigenvectors-as-rows follow lapack_interface.c:507-603.
+ */
+#include "hs_kernels.h"
+#include <math.h>
+
+#define HS_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if ( e_ != hipSuccess ) { hs_record_hip_error(e_, "kernel launch", __FILE__, __LINE__); return HS_ERR_HIP; } } while (0)
+
+/* ---------------------------------------------------------------------------------------------------------------- */
+/* Lanczos                                                                                                            */
+/* ---------------------------------------------------------------------------------------------------------------- */
+
+__device__ __forceinline__ double wsum(double v)
+{
+#pragma unroll
+   for (int off = 32; off > 0; off >>= 1)
+      v += __shfl_down(v, off, 64);
+   return v;
+}
+
+/* block-wide sum over 1024 threads, result broadcast to all */
+__device__ __forceinline__ double bsum1024(double v, double* sh)
+{
+   v = wsum(v);
+   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   __syncthreads();
+   if ( lane == 0 )
+      sh[wave] = v;
+   __syncthreads();
+   double r = 0.0;
+   for (int w = 0; w < (int) (blockDim.x >> 6); ++w)
+      r += sh[w];
+   return r;
+}
+
+__global__ void __launch_bounds__(1024) k_lanczos_init(int n, double* __restrict__ Q, double* __restrict__ meta)
+{
+   __shared__ double sh[16];
+   double s = 0.0;
+   for (int i = threadIdx.x; i < n; i += blockDim.x)
+   {
+      /* fixed pseudo-random start vector: reproducible, not orthogonal to anything in particular */
+      unsigned long long h = (unsigned long long) (i + 1) * 0x9E3779B97F4A7C15ULL;
+      h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ULL; h ^= h >> 32;
+      const double v = 0.5 + (double) (h >> 11) * (1.0 / 9007199254740992.0);
+      Q[i] = v;
+      s += v * v;
+   }
+   s = bsum1024(s, sh);
+   const double inv = 1.0 / sqrt(s);
+   for (int i = threadIdx.x; i < n; i += blockDim.x)
+      Q[i] *= inv;
+   if ( threadIdx.x == 0 )
+   {
+      meta[0] = -1.0;      /* breakdown step (none) */
+      meta[1] = 0.0;       /* largest |alpha| + beta seen (scale) */
+   }
+}
+
+/* One Lanczos step after v = W q_j was formed: alpha_j, re-orthogonalise v against q_0..q_j twice, beta_j, q_{j+1}.
+ * One workgroup; v lives in global memory (vbuf) and is updated in place. */
+__global__ void __launch_bounds__(1024) k_lanczos_step(int n, int j, double* __restrict__ Q, double* __restrict__ vbuf,
+   double* __restrict__ alpha, double* __restrict__ beta, double* __restrict__ meta)
+{
+   __shared__ double sh[16];
+   __shared__ double coef[256];
+   const int tid = threadIdx.x;
+   const int nwaves = blockDim.x >> 6;
+   const int lane = tid & 63, wave = tid >> 6;
+
+   for (int pass = 0; pass < 2; ++pass)
+   {
+      /* c_i = q_i . v : one wave per i */
+      for (int i = wave; i <= j; i += nwaves)
+      {
+         const double* q = Q + (long long) i * n;
+         double s = 0.0;
+         for (int e = lane; e < n; e += 64)
+            s += q[e] * vbuf[e];
+         s = wsum(s);
+         if ( lane == 0 )
+            coef[i] = s;
+      }
+      __syncthreads();
+      if ( pass == 0 && tid == 0 )
+         alpha[j] = coef[j];
+      /* v -= sum_i c_i q_i */
+      for (int e = tid; e < n; e += blockDim.x)
+      {
+         double s = vbuf[e];
+         for (int i = 0; i <= j; ++i)
+            s -= coef[i] * Q[(long long) i * n + e];
+         vbuf[e] = s;
+      }
+      __syncthreads();
+   }
+   double s = 0.0;
+   for (int e = tid; e < n; e += blockDim.x)
+      s += vbuf[e] * vbuf[e];
+   s = bsum1024(s, sh);
+   const double b = sqrt(s);
+   double scale = meta[1];
+   const double aj = fabs(alpha[j]);
+   __syncthreads();
+   if ( aj + b > scale )
+      scale = aj + b;
+   const bool broke = (meta[0] >= 0.0) || !(b > 1e-13 * scale) || !(b > 1e-300);
+   const double inv = broke ? 0.0 : 1.0 / b;
+   double* qn = Q + (long long) (j + 1) * n;
+   for (int e = tid; e < n; e += blockDim.x)
+      qn[e] = vbuf[e] * inv;
+   if ( tid == 0 )
+   {
+      beta[j] = broke ? 0.0 : b;
+      meta[1] = scale;
+      if ( broke && meta[0] < 0.0 )
+         meta[0] = (double) j;
+   }
+}
+
+/* Smallest eigenvalue of the k x k tridiagonal (alpha, beta) by 64-way multisection on the Sturm count, its eigenvector
+ * by inverse iteration; res = {theta, |beta_{k-1} s_{k-1}|, k}.  One wavefront. */
+__global__ void __launch_bounds__(64) k_tridiag_min(int kmax, const double* __restrict__ alpha, const double* __restrict__ beta,
+   const double* __restrict__ meta, double* __restrict__ res)
+{
+   __shared__ double d[260], e[260], sv[260], wk[4][260];
+   const int lane = threadIdx.x;
+   int k = kmax;
+   if ( meta[0] >= 0.0 )
+      k = (int) meta[0] + 1;
+   if ( k > 256 ) k = 256;
+   for (int i = lane; i < k; i += 64)
+   {
+      d[i] = alpha[i];
+      e[i] = (i + 1 < k) ? beta[i] : 0.0;
+   }
+   __syncthreads();
+   /* Gershgorin interval */
+   double lo = 1e300, hi = -1e300;
+   for (int i = 0; i < k; ++i)
+   {
+      const double r = (i > 0 ? fabs(e[i - 1]) : 0.0) + (i + 1 < k ? fabs(e[i]) : 0.0);
+      lo = fmin(lo, d[i] - r);
+      hi = fmax(hi, d[i] + r);
+   }
+   const double span0 = fmax(hi - lo, 1e-300);
+   lo -= 1e-12 * span0 + 1e-300;
+   hi += 1e-12 * span0 + 1e-300;
+   const double pivmin = 1e-300;
+   for (int round = 0; round < 14; ++round)
+   {
+      const double x = lo + (hi - lo) * (double) (lane + 1) / 65.0;
+      /* number of eigenvalues < x */
+      int cnt = 0;
+      double t = d[0] - x;
+      if ( fabs(t) < pivmin ) t = -pivmin;
+      if ( t < 0.0 ) ++cnt;
+      for (int i = 1; i < k; ++i)
+      {
+         t = d[i] - x - e[i - 1] * e[i - 1] / t;
+         if ( fabs(t) < pivmin ) t = -pivmin;
+         if ( t < 0.0 ) ++cnt;
+      }
+      const unsigned long long m = __ballot(cnt >= 1);
+      const int first = m ? __ffsll((long long) m) - 1 : 64;    /* first lane whose shift is above lambda_min */
+      const double w = (hi - lo) / 65.0;
+      const double nlo = lo + w * (double) first;
+      const double nhi = (first < 64) ? lo + w * (double) (first + 1) : hi;
+      lo = nlo; hi = nhi;
+      if ( hi - lo <= 4e-16 * fmax(fabs(lo), fabs(hi)) )
+         break;
+   }
+   const double theta = 0.5 * (lo + hi);
+
+   if ( lane == 0 )
+   {
+      /* inverse iteration with the shifted tridiagonal, Gaussian elimination with partial pivoting (three diagonals
+       * after pivoting: wk[0] = diagonal, wk[1] = first super, wk[2] = second super, wk[3] = multipliers / swaps) */
+      double resid = 0.0;
+      if ( k == 1 )
+      {
+         sv[0] = 1.0;
+      }
+      else
+      {
+         const double shift = theta;
+         const double tiny = 1e-14 * fmax(span0, fmax(fabs(theta), 1e-300));
+         for (int i = 0; i < k; ++i)
+            sv[i] = 1.0 / sqrt((double) k);
+         for (int iter = 0; iter < 3; ++iter)
+         {
+            /* factor */
+            double dd = d[0] - shift, du = e[0], du2 = 0.0;
+            for (int i = 0; i < k - 1; ++i)
+            {
+               const double dl = e[i];
+               const double dn = d[i + 1] - shift;
+               const double un = (i + 2 < k) ? e[i + 1] : 0.0;
+               if ( fabs(dd) >= fabs(dl) )
+               {
+                  if ( fabs(dd) < tiny ) dd = tiny;
+                  const double mlt = dl / dd;
+                  wk[0][i] = dd; wk[1][i] = du; wk[2][i] = 0.0;
+                  sv[i + 1] -= mlt * sv[i];
+                  dd = dn - mlt * du;
+                  du = un;
+               }
+               else
+               {
+                  const double mlt = dd / dl;
+                  wk[0][i] = dl; wk[1][i] = dn; wk[2][i] = un;
+                  const double tmp = sv[i]; sv[i] = sv[i + 1]; sv[i + 1] = tmp - mlt * sv[i + 1];
+                  dd = du - mlt * dn;
+                  du = -mlt * un;
+               }
+            }
+            if ( fabs(dd) < tiny ) dd = tiny;
+            wk[0][k - 1] = dd; wk[1][k - 1] = 0.0; wk[2][k - 1] = 0.0;
+            /* back substitution */
+            sv[k - 1] /= wk[0][k - 1];
+            if ( k >= 2 )
+               sv[k - 2] = (sv[k - 2] - wk[1][k - 2] * sv[k - 1]) / wk[0][k - 2];
+            for (int i = k - 3; i >= 0; --i)
+               sv[i] = (sv[i] - wk[1][i] * sv[i + 1] - wk[2][i] * sv[i + 2]) / wk[0][i];
+            double nrm = 0.0;
+            for (int i = 0; i < k; ++i)
+               nrm += sv[i] * sv[i];
+            nrm = sqrt(nrm);
+            if ( !(nrm > 0.0) || !(nrm < 1e300) )
+            {
+               for (int i = 0; i < k; ++i)
+                  sv[i] = 1.0 / sqrt((double) k);
+               break;
+            }
+            for (int i = 0; i < k; ++i)
+               sv[i] /= nrm;
+         }
+      }
+      const double blast = (meta[0] >= 0.0) ? 0.0 : beta[k - 1];
+      resid = fabs(blast * sv[k - 1]);
+      res[0] = theta;
+      res[1] = resid;
+      res[2] = (double) k;
+   }
+}
+
+long long hs_lanczos_ws(int n, int maxsteps)
+{
+   return (long long) (maxsteps + 2) * n + 4LL * maxsteps + 64 + 2048;
+}
+
+int hs_lanczos_lmin(hipStream_t s, int n, const double* W, int maxsteps, double* res, double* ws)
+{
+   if ( n <= 0 )
+      return HS_ERR_ARG;
+   int k = maxsteps < n ? maxsteps : n;
+   if ( k > 250 ) k = 250;
+   double* Q = ws;                                    /* (k + 1) x n */
+   double* vbuf = Q + (long long) (maxsteps + 1) * n;   /* n */
+   double* alpha = vbuf + n;
+   double* beta = alpha + maxsteps;
+   double* meta = beta + maxsteps;                    /* 2 (+ padding) */
+   double* gws = meta + 64;                           /* gemv split workspace, 2048 doubles */
+   hipLaunchKernelGGL(k_lanczos_init, dim3(1), dim3(1024), 0, s, n, Q, meta);
+   HS_LAUNCH_CHECK();
+   for (int j = 0; j < k; ++j)
+   {
+      const double* qj = Q + (long long) j * n;
+      HS_CALL( hs_gemv_n(s, n, n, W, n, 1, &qj, vbuf, n, gws, 2048) );
+      hipLaunchKernelGGL(k_lanczos_step, dim3(1), dim3(1024), 0, s, n, j, Q, vbuf, alpha, beta, meta);
+      HS_LAUNCH_CHECK();
+   }
+   hipLaunchKernelGGL(k_tridiag_min, dim3(1), dim3(64), 0, s, k, alpha, beta, meta, res);
+   HS_LAUNCH_CHECK();
+   return HS_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------- */
+/* Jacobi                                                                                                             */
+/* ---------------------------------------------------------------------------------------------------------------- */
+
+/* pair k of round r in the round-robin tournament over np = 2 * half players (np even) */
+__device__ __forceinline__ void jac_pair(int np, int r, int k, int* p, int* q)
+{
+   const int mod = np - 1;
+   int a, b;
+   if ( k == 0 )
+   {
+      a = np - 1;
+      b = r % mod;
+   }
+   else
+   {
+      a = (r + k) % mod;
+      b = (r - k + mod) % mod;
+   }
+   *p = a < b ? a : b;
+   *q = a < b ? b : a;
+}
+
+/* rotation angles for all pairs of a round; rot[k] = {c, s}; indices >= n (padding player) give the identity */
+__global__ void k_jacobi_angles(int n, int np, int r, const double* __restrict__ A, double* __restrict__ rot)
+{
+   const int k = blockIdx.x * blockDim.x + threadIdx.x;
+   if ( k >= np / 2 )
+      return;
+   int p, q;
+   jac_pair(np, r, k, &p, &q);
+   double c = 1.0, s = 0.0;
+   if ( q < n )
+   {
+      const double apq = A[(long long) p * n + q];
+      const double app = A[(long long) p * n + p];
+      const double aqq = A[(long long) q * n + q];
+      if ( fabs(apq) > 1e-300 && fabs(apq) > 1e-19 * (fabs(app) + fabs(aqq)) )
+      {
+         const double th = (aqq - app) / (2.0 * apq);
+         const double t = (th >= 0.0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+         c = 1.0 / sqrt(t * t + 1.0);
+         s = t * c;
+      }
+   }
+   rot[2 * k] = c;
+   rot[2 * k + 1] = s;
+}
+
+/* two-sided update A <- J^T A J and Vt <- J^T Vt: thread (k1, k2) owns the 2 x 2 intersection of pairs k1 (rows) and k2
+ * (columns); threads with k2 >= half own the rows of Vt instead */
+__global__ void k_jacobi_apply(int n, int np, int r, double* __restrict__ A, double* __restrict__ Vt,
+   const double* __restrict__ rot)
+{
+   const int half = np / 2;
+   const long long tot = (long long) half * half;
+   for (long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x; t < 2 * tot; t += (long long) gridDim.x * blockDim.x)
+   {
+      if ( t < tot )
+      {
+         const int k1 = (int) (t / half), k2 = (int) (t % half);
+         int p, q, u, v;
+         jac_pair(np, r, k1, &p, &q);
+         jac_pair(np, r, k2, &u, &v);
+         if ( q >= n && v >= n )
+            continue;
+         const double c1 = rot[2 * k1], s1 = rot[2 * k1 + 1];
+         const double c2 = rot[2 * k2], s2 = rot[2 * k2 + 1];
+         const bool hq = q < n, hv = v < n;
+         double apu = A[(long long) p * n + u];
+         double apv = hv ? A[(long long) p * n + v] : 0.0;
+         double aqu = hq ? A[(long long) q * n + u] : 0.0;
+         double aqv = (hq && hv) ? A[(long long) q * n + v] : 0.0;
+         /* rows: [p; q] <- [[c1, -s1], [s1, c1]] [p; q] */
+         const double bpu = c1 * apu - s1 * aqu, bqu = s1 * apu + c1 * aqu;
+         const double bpv = c1 * apv - s1 * aqv, bqv = s1 * apv + c1 * aqv;
+         /* columns: [u, v] <- [u, v] [[c2, s2], [-s2, c2]] */
+         apu = c2 * bpu - s2 * bpv; apv = s2 * bpu + c2 * bpv;
+         aqu = c2 * bqu - s2 * bqv; aqv = s2 * bqu + c2 * bqv;
+         A[(long long) p * n + u] = apu;
+         if ( hv ) A[(long long) p * n + v] = apv;
+         if ( hq ) A[(long long) q * n + u] = aqu;
+         if ( hq && hv ) A[(long long) q * n + v] = aqv;
+      }
+      else
+      {
+         /* Vt rows p, q; column pairs taken as consecutive columns */
+         const long long tt = t - tot;
+         const int k1 = (int) (tt / half), cc = (int) (tt % half);
+         int p, q;
+         jac_pair(np, r, k1, &p, &q);
+         if ( q >= n )
+            continue;
+         const double c1 = rot[2 * k1], s1 = rot[2 * k1 + 1];
+         for (int col = 2 * cc; col < 2 * cc + 2 && col < n; ++col)
+         {
+            const double vp = Vt[(long long) p * n + col], vq = Vt[(long long) q * n + col];
+            Vt[(long long) p * n + col] = c1 * vp - s1 * vq;
+            Vt[(long long) q * n + col] = s1 * vp + c1 * vq;
+         }
+      }
+   }
+}
+
+/* off-diagonal square sum and diagonal square sum -> out[0], out[1] (single workgroup) */
+__global__ void __launch_bounds__(1024) k_jacobi_offnorm(int n, const double* __restrict__ A, double* __restrict__ out)
+{
+   __shared__ double sh[16];
+   double off = 0.0, dg = 0.0;
+   const long long tot = (long long) n * n;
+   for (long long e = threadIdx.x; e < tot; e += blockDim.x)
+   {
+      const int r = (int) (e / n), c = (int) (e % n);
+      const double v = A[e];
+      if ( r == c ) dg += v * v; else off += v * v;
+   }
+   off = bsum1024(off, sh);
+   dg = bsum1024(dg, sh);
+   if ( threadIdx.x == 0 )
+   {
+      out[0] = off;
+      out[1] = dg;
+   }
+}
+
+/* ascending sort of the diagonal and matching row permutation of Vt into V (rank sort, one workgroup) */
+__global__ void __launch_bounds__(1024) k_jacobi_sort(int n, const double* __restrict__ A, const double* __restrict__ Vt,
+   double* __restrict__ lam, double* __restrict__ V)
+{
+   for (int i = threadIdx.x; i < n; i += blockDim.x)
+   {
+      const double di = A[(long long) i * n + i];
+      int rank = 0;
+      for (int j = 0; j < n; ++j)
+      {
+         const double dj = A[(long long) j * n + j];
+         if ( dj < di || (dj == di && j < i) )
+            ++rank;
+      }
+      lam[rank] = di;
+      for (int c = 0; c < n; ++c)
+         V[(long long) rank * n + c] = Vt[(long long) i * n + c];
+   }
+}
+
+long long hs_syev_ws(int n)
+{
+   return (long long) n * n + 2LL * n + 64;
+}
+
+int hs_syev_jacobi(hipStream_t s, int n, double* A, double* lam, double* V, int* info, double* ws)
+{
+   if ( n <= 0 )
+      return HS_ERR_ARG;
+   double* Vt = ws;                              /* n x n */
+   double* rot = Vt + (long long) n * n;         /* 2 * ceil(n/2) */
+   double* nrm = rot + 2LL * ((n + 1) / 2) + 2;  /* 2 */
+   HS_CALL( hs_symmetrize(s, A, n) );
+   HS_CALL( hs_set_identity(s, Vt, n, 1.0) );
+   const int np = (n + 1) & ~1;
+   const int half = np / 2;
+   int sweeps = 0;
+   if ( n > 1 )
+   {
+      const long long work = 2LL * half * half;
+      int grid = (int) ((work + 255) / 256);
+      if ( grid > 4096 ) grid = 4096;
+      for (sweeps = 0; sweeps < 30; ++sweeps)
+      {
+         double h[2];
+         hipLaunchKernelGGL(k_jacobi_offnorm, dim3(1), dim3(1024), 0, s, n, A, nrm);
+         HS_LAUNCH_CHECK();
+         HS_HIP( hipMemcpyAsync(h, nrm, 2 * sizeof(double), hipMemcpyDeviceToHost, s) );
+         HS_HIP( hipStreamSynchronize(s) );
+         if ( !(h[0] > 1e-30 * h[1]) || !(h[0] > 0.0) )
+            break;
+         for (int r = 0; r < np - 1; ++r)
+         {
+            hipLaunchKernelGGL(k_jacobi_angles, dim3((half + 255) / 256), dim3(256), 0, s, n, np, r, A, rot);
+            hipLaunchKernelGGL(k_jacobi_apply, dim3(grid), dim3(256), 0, s, n, np, r, A, Vt, rot);
+         }
+         HS_LAUNCH_CHECK();
+      }
+   }
+   hipLaunchKernelGGL(k_jacobi_sort, dim3(1), dim3(1024), 0, s, n, A, Vt, lam, V);
+   HS_LAUNCH_CHECK();
+   if ( info != NULL )
+      HS_HIP( hipMemsetAsync(info, 0, sizeof(int), s) );
+   (void) sweeps;
+   return HS_OK;
+}

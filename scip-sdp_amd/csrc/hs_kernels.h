@@ -1,0 +1,65 @@
+/* hs_kernels.h - launch wrappers of the bandwidth-bound kernels (kernels.hip), the dense factorizations (chol.hip) and the
+ * eigen kernels (eig.hip).  All pointers are device pointers unless a name ends in _h.  Every wrapper only enqueues work
+ * on the given stream; nothing here synchronizes. */
+#ifndef HS_KERNELS_H
+#define HS_KERNELS_H
+
+#include "hs_common.h"
+
+/* ---- kernels.hip ---------------------------------------------------------------------------------------------- */
+int hs_fill(hipStream_t s, double* p, long long n, double v);
+int hs_set_identity(hipStream_t s, double* A, int n, double v);
+int hs_copy(hipStream_t s, double* dst, const double* src, long long n);
+int hs_axpy(hipStream_t s, long long n, double a, const double* x, double* y);              /* y += a x */
+int hs_scale_add(hipStream_t s, long long n, double a, const double* x, double b, const double* y, double* out); /* out = a x + b y (y may be NULL) */
+int hs_mirror_lower(hipStream_t s, double* A, int n, long long lda);                        /* A[i][j] = A[j][i] for i < j */
+int hs_symmetrize(hipStream_t s, double* A, int n);                                         /* A = (A + A^T) / 2 */
+
+/* out[v * ldo + i] = sum_e A[i * lda + e] * V_v[e],  i < R, e < E, v < nv <= 4 (one pass over A for all nv vectors) */
+int hs_gemv_n(hipStream_t s, int R, long long E, const double* A, long long lda, int nv, const double* const* V,
+   double* out, long long ldo, double* ws, long long wsdoubles);
+/* out[e] = sum_i coef[i] * A[i * lda + e] + sa * add[e]   (add may be NULL) */
+int hs_gemv_t(hipStream_t s, int R, long long E, const double* A, long long lda, const double* coef, double sa,
+   const double* add, double* out);
+
+/* out[slot] = sum_e a[e] * b[e]  (deterministic two-stage; partials in ws, >= 512 doubles) ; accumulate: out[slot] += */
+int hs_dot(hipStream_t s, long long n, const double* a, const double* b, double* out, int accumulate, double* ws);
+/* out[slot] = max(out[slot] if accumulate, max_e |a[e]|) */
+int hs_absmax(hipStream_t s, long long n, const double* a, double* out, int accumulate, double* ws);
+/* out[slot] = min(out[slot] if accumulate, min over e with d[e] < 0 of -x[e] / d[e]); +1e300 when no such e */
+int hs_ratio_min(hipStream_t s, long long n, const double* x, const double* d, double* out, int accumulate, double* ws);
+
+/* H = s1 * Zinv - X - (GZ + GZ^T) / 2,  all n x n */
+int hs_dirmat(hipStream_t s, int n, double s1, const double* Zinv, const double* X, const double* GZ, double* H);
+
+/* LP block element-wise pieces (length q) */
+int hs_lp_dir(hipStream_t s, int q, double sigmu, double eta, const double* x, const double* z, const double* rd_or_dz,
+   const double* elp, double* out);      /* out = sigmu / z - x - (eta * x * r + elp) / z ; elp may be NULL */
+int hs_lp_scale_rows(hipStream_t s, int q, int cols, const double* x, const double* z, const double* D, double* S); /* S[r] = (x_r / z_r) D[r] */
+int hs_vec_mul(hipStream_t s, long long n, const double* a, const double* b, double* out);   /* out = a .* b */
+int hs_lp_s0(hipStream_t s, int q, const double* x, const double* z, const double* beta, double* out, int accumulate, double* ws); /* sum (x/z) beta^2 */
+
+/* ---- chol.hip ------------------------------------------------------------------------------------------------- */
+/* In-place blocked Cholesky of the lower triangle of the row-major n x n matrix A (lda = n): A = L L^T, L stored in the
+ * lower triangle (upper triangle is left untouched).  dinv receives the inverses of the 64 x 64 diagonal blocks of L
+ * (ceil(n/64) * 64 * 64 doubles).  *flag (device int) is set to 1 + index of the first non-positive pivot. */
+int hs_potrf(hipStream_t s, int n, double* A, double* dinv, int* flag, double* ws_gemm);
+/* Linv = L^-1 (lower triangular, full n x n storage, upper triangle zero); needs dinv from hs_potrf */
+int hs_trtri(hipStream_t s, int n, const double* L, const double* dinv, double* Linv, double* tmp);
+/* solves L y = r (nrhs <= 4 right-hand sides, rhs[k * ldr + i]) then optionally L^T x = y, in place.  mode 1: forward only,
+ * 2: backward only, 3: both */
+int hs_trsv(hipStream_t s, int n, const double* L, const double* dinv, int nrhs, double* rhs, long long ldr, int mode);
+
+/* ---- eig.hip -------------------------------------------------------------------------------------------------- */
+/* Lanczos estimate of the smallest eigenvalue of the symmetric n x n matrix W.  res[0] = Ritz value theta,
+ * res[1] = residual bound (an eigenvalue lies within res[1] of theta), res[2] = steps used.
+ * ws: (maxsteps + 2) * n + 4 * maxsteps + 64 doubles. */
+int hs_lanczos_lmin(hipStream_t s, int n, const double* W, int maxsteps, double* res, double* ws);
+long long hs_lanczos_ws(int n, int maxsteps);
+
+/* Cyclic Jacobi eigen-decomposition of the symmetric n x n matrix A (destroyed): eigenvalues ascending in lam[n],
+ * eigenvectors as rows of V (row k = k-th eigenvector).  info (device int) = sweeps used or -1. */
+int hs_syev_jacobi(hipStream_t s, int n, double* A, double* lam, double* V, int* info, double* ws);
+long long hs_syev_ws(int n);
+
+#endif

@@ -1,0 +1,1147 @@
+/* ipm.hip - the interior-point engine: homogeneous self-dual embedding, HKM direction, Mehrotra predictor-corrector.
+ *
+ * Replaces the third-party arithmetic behind the reference's backends (DSDPSetup/DSDPSolve/DSDPComputeX at
+ * src/sdpi/sdpisolver_dsdp.c:1489-1520; SDPA::initializeSolve/solve at src/sdpi/sdpisolver_sdpa.cpp:1600-1670).
+ * oracle/ipm_ref.py is the line-by-line CPU restatement used by the parity tests.
+ *
+ * Per iteration, per dense block (n x n, m1 = m + 1 matrices A_0..A_m stored as rows of length n^2):
+ *    chol(Z), Z^-1, chol(X)                                       chol.hip   (MFMA panels)
+ *    Schur  Mx_ij = tr(A_i X A_j Z^-1), i, j = 0..m               three MFMA GEMMs (below)
+ *    chol(M), M = Mx[1:,1:]; solves                               chol.hip
+ *    predictor / corrector right-hand sides and directions        2 passes over A each (kernels.hip) + 4 n^3 GEMMs
+ *    step lengths  lambda_min(L^-1 dX L^-T)                       eig.hip (Lanczos)
+ * The host thread only reads back a few dozen scalars three times per iteration and decides sigma / alpha / termination.
+ */
+#include "hs_kernels.h"
+#include "../../include/hipsdp.h"
+#include <vector>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#define HS_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if ( e_ != hipSuccess ) { hs_record_hip_error(e_, "kernel launch", __FILE__, __LINE__); return HS_ERR_HIP; } } while (0)
+
+/* ---- device scalar slots -------------------------------------------------------------------------------------- */
+enum
+{
+   SC_AX0 = 0,     /* <A_0, X> + c^T x */
+   SC_DOBJ,        /* b^T y */
+   SC_XZ,          /* sum <X, Z> + x^T z */
+   SC_RP2,         /* ||rp||^2 */
+   SC_RD2,         /* sum_k ||Rd_k||_F^2 + ||rd||^2 */
+   SC_RDLPMAX,     /* max |rd| */
+   SC_HP2,         /* ||A(X, x)||^2 */
+   SC_HD2,         /* ||A^T y - Z||^2 (certificate) */
+   SC_S0,
+   SC_BUB,         /* b^T M^-1 b */
+   SC_BH,          /* sum <B_k, H_k> + beta^T hl */
+   SC_WRP,         /* w^T rp */
+   SC_BU1,         /* b^T u1 */
+   SC_DTAU,
+   SC_DKAPPA,
+   SC_RATX,        /* LP ratio tests */
+   SC_RATZ,
+   SC_DEN,
+   SC_FIXED_END = 24
+};
+/* per block k: SC_FIXED_END + 8 k + {0: ||Rd_k||^2, 1..3: lanczos X (theta, resid, steps), 4..6: lanczos Z} */
+#define SC_BLK(k, i) (SC_FIXED_END + 8 * (k) + (i))
+
+struct Block
+{
+   int     n;
+   double* A;        /* (m + 1) x n^2 */
+   double *X, *Z, *Rd, *Lz, *LzInv, *Zinv, *Lx, *LxInv, *B, *H, *G, *GZ, *dXa, *dZa, *dX, *dZ, *E, *W, *T1;
+   double *dinvz, *dinvx;
+   double *Xs, *Zs;  /* saved iterate for step back-off */
+};
+
+struct hipsdp_solver
+{
+   int device;
+   hipStream_t stream;
+   int m, q;
+   std::vector<Block> blk;
+   double* b;        /* m */
+   double* Dext;     /* q x (m + 1) */
+   /* iterate */
+   double *y, *x, *z;
+   double tau, kappa;
+   /* work vectors */
+   double *yt, *dyt, *wt, *AX, *AH, *tmpe, *rp, *rd, *tmpq, *hl, *beta, *elp, *dxa, *dza, *dx, *dz, *xs, *zs, *ys;
+   double *u1, *rhs2, *u2, *dy, *dya;
+   double *Mx, *Lm, *dinvm, *Slp;
+   double *sc, *red_ws, *gemv_ws, *lan_ws;
+   long long gemv_ws_len;
+   int* flags;       /* device ints: 0 chol Z, 1 chol X, 2 chol M */
+   double *Tws, *Uws, *Kws;
+   long long chunk_cols, kws_len;
+   int nsc;
+   bool shaped, solved, have_start;
+   int last_status;
+   double sol_scale;
+   hipEvent_t ev0, ev1;
+   /* multi GPU */
+   void* comm; int rank, nranks;
+   hipsdp_params par;
+};
+
+static thread_local char g_err[512] = "";
+static void set_err(const char* msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
+
+extern "C" const char* hipsdp_last_error(void)
+{
+   const char* h = hs_last_error();
+   if ( g_err[0] != 0 )
+      return g_err;
+   return h;
+}
+
+extern "C" const char* hipsdp_version(void) { return "hipsdp 0.1 (gfx950)"; }
+
+extern "C" int hipsdp_device_count(void)
+{
+   int n = 0;
+   if ( hipGetDeviceCount(&n) != hipSuccess )
+      return 0;
+   return n;
+}
+
+extern "C" void hipsdp_default_params(hipsdp_params* p)
+{
+   p->gaptol = 1e-5;
+   p->feastol = 1e-5;
+   p->infeastol = 1e-7;
+   p->objlimit = 1e20;
+   p->timelimit = 0.0;
+   p->gamma = 0.98;
+   p->ws_gbytes = 0.0;
+   p->maxiter = 100;
+   p->verbose = 0;
+   p->lanczos_steps = 48;
+   p->reserved = 0;
+}
+
+template<class T>
+static int dalloc(T** p, long long count)
+{
+   *p = NULL;
+   if ( count <= 0 )
+      count = 1;
+   HS_HIP( hipMalloc((void**) p, (size_t) count * sizeof(T)) );
+   return HS_OK;
+}
+
+static void dfree(void* p) { if ( p != NULL ) (void) hipFree(p); }
+
+static void free_problem(hipsdp_solver* s)
+{
+   for (auto& B : s->blk)
+   {
+      double* ptrs[] = {B.A, B.X, B.Z, B.Rd, B.Lz, B.LzInv, B.Zinv, B.Lx, B.LxInv, B.B, B.H, B.G, B.GZ, B.dXa, B.dZa, B.dX, B.dZ,
+         B.E, B.W, B.T1, B.dinvz, B.dinvx, B.Xs, B.Zs};
+      for (double* p : ptrs) dfree(p);
+   }
+   s->blk.clear();
+   double* ptrs[] = {s->b, s->Dext, s->y, s->x, s->z, s->yt, s->dyt, s->wt, s->AX, s->AH, s->tmpe, s->rp, s->rd, s->tmpq, s->hl,
+      s->beta, s->elp, s->dxa, s->dza, s->dx, s->dz, s->xs, s->zs, s->ys, s->u1, s->rhs2, s->u2, s->dy, s->dya, s->Mx, s->Lm,
+      s->dinvm, s->Slp, s->sc, s->red_ws, s->gemv_ws, s->lan_ws, s->Tws, s->Uws, s->Kws};
+   for (double* p : ptrs) dfree(p);
+   dfree(s->flags);
+   s->b = s->Dext = s->y = s->x = s->z = s->yt = s->dyt = s->wt = s->AX = s->AH = s->tmpe = s->rp = s->rd = s->tmpq = s->hl = NULL;
+   s->beta = s->elp = s->dxa = s->dza = s->dx = s->dz = s->xs = s->zs = s->ys = s->u1 = s->rhs2 = s->u2 = s->dy = s->dya = NULL;
+   s->Mx = s->Lm = s->dinvm = s->Slp = s->sc = s->red_ws = s->gemv_ws = s->lan_ws = s->Tws = s->Uws = s->Kws = NULL;
+   s->flags = NULL;
+   s->shaped = false;
+   s->solved = false;
+}
+
+extern "C" int hipsdp_create(hipsdp_solver** out, int device)
+{
+   g_err[0] = 0;
+   int nd = hipsdp_device_count();
+   if ( nd <= 0 )
+   {
+      set_err("no HIP device available (hipsdp has no CPU fallback)");
+      return HIPSDP_ERR_NODEVICE;
+   }
+   if ( device < 0 || device >= nd )
+      return HIPSDP_ERR_ARG;
+   HS_HIP( hipSetDevice(device) );
+   hipsdp_solver* s = new hipsdp_solver();
+   memset((void*) &s->par, 0, sizeof(s->par));
+   s->device = device;
+   s->m = s->q = 0;
+   s->b = s->Dext = s->y = s->x = s->z = NULL;
+   s->shaped = s->solved = s->have_start = false;
+   s->comm = NULL; s->rank = 0; s->nranks = 1;
+   s->flags = NULL;
+   s->last_status = HIPSDP_STATUS_UNSOLVED;
+   s->sol_scale = 1.0;
+   s->b = s->Dext = s->y = s->x = s->z = s->yt = s->dyt = s->wt = s->AX = s->AH = s->tmpe = s->rp = s->rd = s->tmpq = s->hl = NULL;
+   s->beta = s->elp = s->dxa = s->dza = s->dx = s->dz = s->xs = s->zs = s->ys = s->u1 = s->rhs2 = s->u2 = s->dy = s->dya = NULL;
+   s->Mx = s->Lm = s->dinvm = s->Slp = s->sc = s->red_ws = s->gemv_ws = s->lan_ws = s->Tws = s->Uws = s->Kws = NULL;
+   hipsdp_default_params(&s->par);
+   if ( hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess
+      || hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess )
+   {
+      delete s;
+      set_err("stream/event creation failed");
+      return HIPSDP_ERR_HIP;
+   }
+   *out = s;
+   return HIPSDP_OK;
+}
+
+extern "C" void hipsdp_free(hipsdp_solver** ps)
+{
+   if ( ps == NULL || *ps == NULL )
+      return;
+   hipsdp_solver* s = *ps;
+   (void) hipSetDevice(s->device);
+   (void) hipStreamSynchronize(s->stream);
+   free_problem(s);
+   (void) hipEventDestroy(s->ev0);
+   (void) hipEventDestroy(s->ev1);
+   (void) hipStreamDestroy(s->stream);
+   delete s;
+   *ps = NULL;
+}
+
+extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int* blocksizes, int q)
+{
+   g_err[0] = 0;
+   if ( s == NULL || m < 0 || nblocks < 0 || q < 0 )
+      return HIPSDP_ERR_ARG;
+   HS_HIP( hipSetDevice(s->device) );
+   HS_HIP( hipStreamSynchronize(s->stream) );
+   free_problem(s);
+   s->m = m;
+   s->q = q;
+   const long long m1 = m + 1;
+   int nmax = 1;
+   for (int k = 0; k < nblocks; ++k)
+   {
+      Block B;
+      memset(&B, 0, sizeof(B));
+      B.n = blocksizes[k];
+      if ( B.n <= 0 )
+         return HIPSDP_ERR_ARG;
+      if ( B.n > nmax ) nmax = B.n;
+      const long long n2 = (long long) B.n * B.n;
+      s->blk.push_back(B);
+      Block& R = s->blk.back();
+      HS_CALL( dalloc(&R.A, m1 * n2) );
+      HS_HIP( hipMemsetAsync(R.A, 0, (size_t) (m1 * n2) * sizeof(double), s->stream) );
+      double** mats[] = {&R.X, &R.Z, &R.Rd, &R.Lz, &R.LzInv, &R.Zinv, &R.Lx, &R.LxInv, &R.B, &R.H, &R.G, &R.GZ, &R.dXa, &R.dZa,
+         &R.dX, &R.dZ, &R.E, &R.W, &R.T1, &R.Xs, &R.Zs};
+      for (double** pm : mats)
+         HS_CALL( dalloc(pm, n2) );
+      const long long nd = (long long) ((B.n + 63) / 64) * 64 * 64;
+      HS_CALL( dalloc(&R.dinvz, nd) );
+      HS_CALL( dalloc(&R.dinvx, nd) );
+   }
+   HS_CALL( dalloc(&s->b, m) );
+   HS_CALL( dalloc(&s->Dext, (long long) q * m1) );
+   HS_CALL( dalloc(&s->y, m) ); HS_CALL( dalloc(&s->ys, m) );
+   double** qv[] = {&s->x, &s->z, &s->rd, &s->tmpq, &s->hl, &s->beta, &s->elp, &s->dxa, &s->dza, &s->dx, &s->dz, &s->xs, &s->zs};
+   for (double** p : qv) HS_CALL( dalloc(p, q) );
+   double** ev[] = {&s->yt, &s->dyt, &s->wt, &s->AX, &s->AH, &s->tmpe};
+   for (double** p : ev) HS_CALL( dalloc(p, m1) );
+   double** mv[] = {&s->rp, &s->u1, &s->u2, &s->dy, &s->dya};
+   for (double** p : mv) HS_CALL( dalloc(p, m) );
+   HS_CALL( dalloc(&s->rhs2, 2LL * m) );
+   HS_CALL( dalloc(&s->Mx, m1 * m1) );
+   HS_CALL( dalloc(&s->Lm, (long long) m * m) );
+   HS_CALL( dalloc(&s->dinvm, (long long) ((m + 63) / 64) * 64 * 64) );
+   HS_CALL( dalloc(&s->Slp, (long long) q * m1) );
+   s->nsc = SC_FIXED_END + 8 * (nblocks > 0 ? nblocks : 1) + 8;
+   HS_CALL( dalloc(&s->sc, s->nsc) );
+   HS_CALL( dalloc(&s->red_ws, 1024) );
+   s->gemv_ws_len = 8192 + 4LL * 1024 * 4;
+   HS_CALL( dalloc(&s->gemv_ws, s->gemv_ws_len) );
+   HS_CALL( dalloc(&s->lan_ws, hs_lanczos_ws(nmax, 256)) );
+   HS_CALL( dalloc(&s->flags, 8) );
+   s->Tws = s->Uws = s->Kws = NULL;
+   s->chunk_cols = 0;
+   s->kws_len = 0;
+   HS_HIP( hipMemsetAsync(s->Dext, 0, (size_t) ((long long) q * m1 > 0 ? (long long) q * m1 : 1) * sizeof(double), s->stream) );
+   HS_HIP( hipMemsetAsync(s->b, 0, (size_t) (m > 0 ? m : 1) * sizeof(double), s->stream) );
+   HS_HIP( hipStreamSynchronize(s->stream) );
+   s->shaped = true;
+   s->have_start = false;
+   return HIPSDP_OK;
+}
+
+extern "C" int hipsdp_set_obj(hipsdp_solver* s, const double* b)
+{
+   if ( s == NULL || !s->shaped ) return HIPSDP_ERR_ARG;
+   HS_HIP( hipSetDevice(s->device) );
+   if ( s->m > 0 )
+      HS_HIP( hipMemcpy(s->b, b, (size_t) s->m * sizeof(double), hipMemcpyHostToDevice) );
+   s->solved = false;
+   return HIPSDP_OK;
+}
+
+__global__ void k_scatter_coo(long long nnz, int n, const int* __restrict__ var, const int* __restrict__ row,
+   const int* __restrict__ col, const double* __restrict__ val, double* __restrict__ A)
+{
+   const long long n2 = (long long) n * n;
+   for (long long e = (long long) blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (long long) gridDim.x * blockDim.x)
+   {
+      const int r = row[e], c = col[e];
+      double* a = A + (long long) var[e] * n2;
+      a[(long long) r * n + c] = val[e];
+      a[(long long) c * n + r] = val[e];
+   }
+}
+
+extern "C" int hipsdp_add_entries(hipsdp_solver* s, int block, long long nnz, const int* var, const int* row, const int* col,
+   const double* val)
+{
+   if ( s == NULL || !s->shaped || block < 0 || block >= (int) s->blk.size() || nnz < 0 )
+      return HIPSDP_ERR_ARG;
+   if ( nnz == 0 )
+      return HIPSDP_OK;
+   HS_HIP( hipSetDevice(s->device) );
+   Block& B = s->blk[block];
+   for (long long e = 0; e < nnz; ++e)
+      if ( var[e] < 0 || var[e] > s->m || row[e] < 0 || row[e] >= B.n || col[e] < 0 || col[e] >= B.n )
+      {
+         set_err("hipsdp_add_entries: index out of range");
+         return HIPSDP_ERR_ARG;
+      }
+   int *dv, *dr, *dc; double* dval;
+   HS_CALL( dalloc(&dv, nnz) ); HS_CALL( dalloc(&dr, nnz) ); HS_CALL( dalloc(&dc, nnz) ); HS_CALL( dalloc(&dval, nnz) );
+   HS_HIP( hipMemcpyAsync(dv, var, (size_t) nnz * sizeof(int), hipMemcpyHostToDevice, s->stream) );
+   HS_HIP( hipMemcpyAsync(dr, row, (size_t) nnz * sizeof(int), hipMemcpyHostToDevice, s->stream) );
+   HS_HIP( hipMemcpyAsync(dc, col, (size_t) nnz * sizeof(int), hipMemcpyHostToDevice, s->stream) );
+   HS_HIP( hipMemcpyAsync(dval, val, (size_t) nnz * sizeof(double), hipMemcpyHostToDevice, s->stream) );
+   long long g = (nnz + 255) / 256; if ( g > 4096 ) g = 4096;
+   hipLaunchKernelGGL(k_scatter_coo, dim3((unsigned) g), dim3(256), 0, s->stream, nnz, B.n, dv, dr, dc, dval, B.A);
+   HS_LAUNCH_CHECK();
+   HS_HIP( hipStreamSynchronize(s->stream) );
+   dfree(dv); dfree(dr); dfree(dc); dfree(dval);
+   s->solved = false;
+   return HIPSDP_OK;
+}
+
+extern "C" int hipsdp_set_block_dense(hipsdp_solver* s, int block, const double* A)
+{
+   if ( s == NULL || !s->shaped || block < 0 || block >= (int) s->blk.size() )
+      return HIPSDP_ERR_ARG;
+   HS_HIP( hipSetDevice(s->device) );
+   Block& B = s->blk[block];
+   HS_HIP( hipMemcpy(B.A, A, (size_t) (s->m + 1) * B.n * B.n * sizeof(double), hipMemcpyHostToDevice) );
+   s->solved = false;
+   return HIPSDP_OK;
+}
+
+extern "C" int hipsdp_set_lp(hipsdp_solver* s, const double* Dext)
+{
+   if ( s == NULL || !s->shaped ) return HIPSDP_ERR_ARG;
+   HS_HIP( hipSetDevice(s->device) );
+   if ( s->q > 0 )
+      HS_HIP( hipMemcpy(s->Dext, Dext, (size_t) s->q * (s->m + 1) * sizeof(double), hipMemcpyHostToDevice) );
+   s->solved = false;
+   return HIPSDP_OK;
+}
+
+extern "C" int hipsdp_block_device_ptr(hipsdp_solver* s, int block, double** dptr)
+{
+   if ( s == NULL || !s->shaped || block < 0 || block >= (int) s->blk.size() )
+      return HIPSDP_ERR_ARG;
+   *dptr = s->blk[block].A;
+   return HIPSDP_OK;
+}
+
+extern "C" int hipsdp_set_start(hipsdp_solver* s, const double* y, const double* const* X, const double* const* Z,
+   const double* x, const double* z)
+{
+   if ( s == NULL || !s->shaped ) return HIPSDP_ERR_ARG;
+   HS_HIP( hipSetDevice(s->device) );
+   if ( s->m > 0 )
+      HS_HIP( hipMemcpy(s->y, y, (size_t) s->m * sizeof(double), hipMemcpyHostToDevice) );
+   for (size_t k = 0; k < s->blk.size(); ++k)
+   {
+      const size_t bytes = (size_t) s->blk[k].n * s->blk[k].n * sizeof(double);
+      HS_HIP( hipMemcpy(s->blk[k].X, X[k], bytes, hipMemcpyHostToDevice) );
+      HS_HIP( hipMemcpy(s->blk[k].Z, Z[k], bytes, hipMemcpyHostToDevice) );
+   }
+   if ( s->q > 0 )
+   {
+      HS_HIP( hipMemcpy(s->x, x, (size_t) s->q * sizeof(double), hipMemcpyHostToDevice) );
+      HS_HIP( hipMemcpy(s->z, z, (size_t) s->q * sizeof(double), hipMemcpyHostToDevice) );
+   }
+   s->have_start = true;
+   return HIPSDP_OK;
+}
+
+/* ---- small fused kernels of the iteration ---------------------------------------------------------------------- */
+
+/* ext[0] = s0, ext[1 + i] = s1 * v[i] */
+__global__ void k_make_ext(int m, double s0, double s1, const double* __restrict__ v, double* __restrict__ ext)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if ( i == 0 )
+      ext[0] = s0;
+   if ( i < m )
+      ext[1 + i] = s1 * v[i];
+}
+
+/* rp = b * tau - AX[1:] */
+__global__ void k_rp(int m, double tau, const double* __restrict__ b, const double* __restrict__ AX, double* __restrict__ rp)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if ( i < m )
+      rp[i] = b[i] * tau - AX[1 + i];
+}
+
+/* rhs2 = [g ; b] with g = Mx[0, 1:] */
+__global__ void k_rhs2(int m, const double* __restrict__ Mx, const double* __restrict__ b, double* __restrict__ rhs2)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if ( i < m )
+   {
+      rhs2[i] = Mx[1 + i];
+      rhs2[m + i] = b[i];
+   }
+}
+
+/* after the two solves: w = rhs2[0:m], ub = rhs2[m:2m];  u2 = ub - w;  wt = [1, -w] */
+__global__ void k_after_solve2(int m, const double* __restrict__ rhs2, double* __restrict__ u2, double* __restrict__ wt)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if ( i == 0 )
+      wt[0] = 1.0;
+   if ( i < m )
+   {
+      u2[i] = rhs2[m + i] - rhs2[i];
+      wt[1 + i] = -rhs2[i];
+   }
+}
+
+/* h = AH[1:] - eta * rp */
+__global__ void k_h(int m, double eta, const double* __restrict__ AH, const double* __restrict__ rp, double* __restrict__ h)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if ( i < m )
+      h[i] = AH[1 + i] - eta * rp[i];
+}
+
+/* dtau = num / den, dy = u1 - u2 * dtau, dyt = [-dtau, dy], dkappa */
+__global__ void k_finish_dir(int m, double eta, double rg, double sigmu, double tau, double kappa, double etk,
+   const double* __restrict__ u1, const double* __restrict__ u2, double* __restrict__ dy, double* __restrict__ dyt,
+   double* __restrict__ sc)
+{
+   const double den = sc[SC_S0] + kappa / tau + sc[SC_BUB];
+   const double num = -eta * rg + (sigmu - tau * kappa - etk) / tau - sc[SC_BH] - eta * sc[SC_WRP] + sc[SC_BU1];
+   const double dtau = num / den;
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if ( i == 0 )
+   {
+      sc[SC_DTAU] = dtau;
+      sc[SC_DKAPPA] = (sigmu - tau * kappa - etk - kappa * dtau) / tau;
+      sc[SC_DEN] = den;
+      dyt[0] = -dtau;
+   }
+   if ( i < m )
+   {
+      const double v = u1[i] - u2[i] * dtau;
+      dy[i] = v;
+      dyt[1 + i] = v;
+   }
+}
+
+/* out = Rd + tau * A0  (certificate residual A^T y - Z) */
+__global__ void k_cert(long long n2, double tau, const double* __restrict__ Rd, const double* __restrict__ A0, double* __restrict__ out)
+{
+   for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long) gridDim.x * blockDim.x)
+      out[i] = Rd[i] + tau * A0[i];
+}
+
+static inline dim3 g1d(long long n) { long long g = (n + 255) / 256; if ( g < 1 ) g = 1; if ( g > 4096 ) g = 4096; return dim3((unsigned) g); }
+
+/* ---- GEMM convenience ------------------------------------------------------------------------------------------ */
+static int gemm(hipsdp_solver* s, int layA, int layB, int M, int N, int K, double alpha, const double* A, long long lda,
+   const double* B, long long ldb, double beta, double* C, long long ldc, int flags = 0)
+{
+   hs_gemm_args g = {M, N, K, layA, layB, A, lda, 0, B, ldb, 0, C, ldc, 0, alpha, beta, 1, flags, 1, NULL};
+   return hs_dgemm(s->stream, &g);
+}
+
+/* ---- Schur assembly of one block into Mx (lower triangle, accumulating) ----------------------------------------- */
+static int ensure_schur_ws(hipsdp_solver* s)
+{
+   if ( s->Tws != NULL )
+      return HS_OK;
+   const long long m1 = s->m + 1;
+   long long n2max = 1;
+   for (auto& B : s->blk) { const long long n2 = (long long) B.n * B.n; if ( n2 > n2max ) n2max = n2; }
+   double budget = s->par.ws_gbytes > 0.0 ? s->par.ws_gbytes : 24.0;
+   const char* env = getenv("HIPSDP_WS_GB");
+   if ( env != NULL && atof(env) > 0.0 )
+      budget = atof(env);
+   long long cols = (long long) (budget * 1e9 / (2.0 * 8.0 * (double) n2max));
+   if ( cols >= m1 )
+      cols = m1;
+   else
+   {
+      cols = (cols / 128) * 128;
+      if ( cols < 128 ) cols = 128;
+      if ( cols > m1 ) cols = m1;
+   }
+   s->chunk_cols = cols;
+   HS_CALL( dalloc(&s->Tws, cols * n2max) );
+   HS_CALL( dalloc(&s->Uws, cols * n2max) );
+   /* split-K slabs of GEMM3 */
+   int sk = hs_dgemm_pick_splitk((int) m1, (int) cols, (int) (n2max > 2000000000LL ? 2000000000LL : n2max), 1);
+   s->kws_len = (long long) sk * m1 * cols;
+   HS_CALL( dalloc(&s->Kws, s->kws_len) );
+   return HS_OK;
+}
+
+static int schur_block(hipsdp_solver* s, Block& B, int j_begin, int j_end)
+{
+   const int m1 = s->m + 1;
+   const int n = B.n;
+   const long long n2 = (long long) n * n;
+   for (int j0 = j_begin; j0 < j_end; j0 += (int) s->chunk_cols)
+   {
+      const int cj = (j_end - j0) < s->chunk_cols ? (j_end - j0) : (int) s->chunk_cols;
+      /* GEMM1: T[(cj n) x n] = A[j0 .. j0 + cj) (stack of n x n) * Zinv */
+      {
+         const long long rows = (long long) cj * n;
+         if ( rows > 2000000000LL ) return HS_ERR_ARG;
+         hs_gemm_args g = {(int) rows, n, n, HS_KC, HS_MC, B.A + (long long) j0 * n2, n, 0, B.Zinv, n, 0, s->Tws, n, 0, 1.0, 0.0, 1, 0, 1, NULL};
+         HS_CALL( hs_dgemm(s->stream, &g) );
+      }
+      /* GEMM2: U_j = X * T_j, batched over the cj matrices of the chunk */
+      {
+         hs_gemm_args g = {n, n, n, HS_KC, HS_MC, B.X, n, 0, s->Tws, n, n2, s->Uws, n, n2, 1.0, 0.0, cj, 0, 1, NULL};
+         HS_CALL( hs_dgemm(s->stream, &g) );
+      }
+      /* GEMM3: Mx[j0:, j0:j0+cj] += A_flat[j0:] * U_flat^T   (rows i >= j0 only: lower triangle) */
+      {
+         const int rows = m1 - j0;
+         if ( n2 > 2000000000LL ) return HS_ERR_ARG;
+         int sk = hs_dgemm_pick_splitk(rows, cj, (int) n2, 1);
+         while ( sk > 1 && (long long) sk * rows * cj > s->kws_len ) --sk;
+         hs_gemm_args g = {rows, cj, (int) n2, HS_KC, HS_KC, B.A + (long long) j0 * n2, n2, 0, s->Uws, n2, 0,
+            s->Mx + (long long) j0 * m1 + j0, m1, 0, 1.0, 1.0, 1, HS_GEMM_LOWER, sk, s->Kws};
+         HS_CALL( hs_dgemm(s->stream, &g) );
+      }
+   }
+   return HS_OK;
+}
+
+/* ---- the solve ---------------------------------------------------------------------------------------------------- */
+
+struct HostScalars
+{
+   std::vector<double> v;
+};
+
+static int read_scalars(hipsdp_solver* s, HostScalars& h, int* flags3)
+{
+   h.v.resize(s->nsc);
+   HS_HIP( hipMemcpyAsync(h.v.data(), s->sc, (size_t) s->nsc * sizeof(double), hipMemcpyDeviceToHost, s->stream) );
+   if ( flags3 != NULL )
+      HS_HIP( hipMemcpyAsync(flags3, s->flags, 3 * sizeof(int), hipMemcpyDeviceToHost, s->stream) );
+   HS_HIP( hipStreamSynchronize(s->stream) );
+   return HS_OK;
+}
+
+/* A(V) over all blocks + LP: out[m + 1] = sum_k A_k vec(V_k) + Dext^T vlp */
+static int apply_A(hipsdp_solver* s, double* const* Vk, const double* vlp, double* out)
+{
+   const int m1 = s->m + 1;
+   bool first = true;
+   for (size_t k = 0; k < s->blk.size(); ++k)
+   {
+      Block& B = s->blk[k];
+      const double* v = Vk[k];
+      double* dst = first ? out : s->tmpe;
+      HS_CALL( hs_gemv_n(s->stream, m1, (long long) B.n * B.n, B.A, (long long) B.n * B.n, 1, &v, dst, m1, s->gemv_ws, s->gemv_ws_len) );
+      if ( !first )
+         HS_CALL( hs_axpy(s->stream, m1, 1.0, s->tmpe, out) );
+      first = false;
+   }
+   if ( first )
+      HS_CALL( hs_fill(s->stream, out, m1, 0.0) );
+   if ( s->q > 0 )
+      HS_CALL( hs_gemv_t(s->stream, s->q, m1, s->Dext, m1, vlp, 1.0, out, out) );
+   return HS_OK;
+}
+
+/* one Newton direction; results in (dy, dyt, SC_DTAU, SC_DKAPPA), B.dX, B.dZ, s->dx, s->dz */
+static int direction(hipsdp_solver* s, double sigma, double eta, double mu, double rg, bool useE, double etk)
+{
+   const int m = s->m, m1 = s->m + 1, q = s->q;
+   const double sigmu = sigma * mu;
+   std::vector<double*> Hs;
+   for (auto& B : s->blk)
+   {
+      const int n = B.n;
+      const long long n2 = (long long) n * n;
+      if ( useE )
+         HS_CALL( hs_copy(s->stream, B.G, B.E, n2) );
+      HS_CALL( gemm(s, HS_KC, HS_MC, n, n, n, eta, B.X, n, B.Rd, n, useE ? 1.0 : 0.0, B.G, n) );
+      HS_CALL( gemm(s, HS_KC, HS_MC, n, n, n, 1.0, B.G, n, B.Zinv, n, 0.0, B.GZ, n) );
+      HS_CALL( hs_dirmat(s->stream, n, sigmu, B.Zinv, B.X, B.GZ, B.H) );
+      Hs.push_back(B.H);
+   }
+   if ( q > 0 )
+      HS_CALL( hs_lp_dir(s->stream, q, sigmu, eta, s->x, s->z, s->rd, useE ? s->elp : NULL, s->hl) );
+   HS_CALL( apply_A(s, Hs.data(), s->hl, s->AH) );
+   if ( m > 0 )
+   {
+      hipLaunchKernelGGL(k_h, g1d(m), dim3(256), 0, s->stream, m, eta, s->AH, s->rp, s->u1);
+      HS_LAUNCH_CHECK();
+      HS_CALL( hs_trsv(s->stream, m, s->Lm, s->dinvm, 1, s->u1, m, 3) );
+   }
+   /* BH = sum <B_k, H_k> + beta^T hl ; wrp ; bu1 */
+   HS_CALL( hs_fill(s->stream, s->sc + SC_BH, 1, 0.0) );
+   for (auto& B : s->blk)
+      HS_CALL( hs_dot(s->stream, (long long) B.n * B.n, B.B, B.H, s->sc + SC_BH, 1, s->red_ws) );
+   if ( q > 0 )
+      HS_CALL( hs_dot(s->stream, q, s->beta, s->hl, s->sc + SC_BH, 1, s->red_ws) );
+   HS_CALL( hs_dot(s->stream, m, s->rhs2, s->rp, s->sc + SC_WRP, 0, s->red_ws) );       /* w = rhs2[0:m] */
+   HS_CALL( hs_dot(s->stream, m, s->b, s->u1, s->sc + SC_BU1, 0, s->red_ws) );
+   hipLaunchKernelGGL(k_finish_dir, g1d(m > 0 ? m : 1), dim3(256), 0, s->stream, m, eta, rg, sigmu, s->tau, s->kappa, etk,
+      s->u1, s->u2, s->dy, s->dyt, s->sc);
+   HS_LAUNCH_CHECK();
+   for (auto& B : s->blk)
+   {
+      const int n = B.n;
+      const long long n2 = (long long) n * n;
+      HS_CALL( hs_gemv_t(s->stream, m1, n2, B.A, n2, s->dyt, eta, B.Rd, B.dZ) );
+      if ( useE )
+         HS_CALL( hs_copy(s->stream, B.G, B.E, n2) );
+      HS_CALL( gemm(s, HS_KC, HS_MC, n, n, n, 1.0, B.X, n, B.dZ, n, useE ? 1.0 : 0.0, B.G, n) );
+      HS_CALL( gemm(s, HS_KC, HS_MC, n, n, n, 1.0, B.G, n, B.Zinv, n, 0.0, B.GZ, n) );
+      HS_CALL( hs_dirmat(s->stream, n, sigmu, B.Zinv, B.X, B.GZ, B.dX) );
+   }
+   if ( q > 0 )
+   {
+      const double* v = s->dyt;
+      HS_CALL( hs_gemv_n(s->stream, q, m1, s->Dext, m1, 1, &v, s->tmpq, q, s->gemv_ws, s->gemv_ws_len) );
+      HS_CALL( hs_scale_add(s->stream, q, 1.0, s->tmpq, eta, s->rd, s->dz) );
+      HS_CALL( hs_lp_dir(s->stream, q, sigmu, 1.0, s->x, s->z, s->dz, useE ? s->elp : NULL, s->dx) );
+   }
+   return HS_OK;
+}
+
+/* enqueue the step-length estimates for the current direction */
+static int steplen_enqueue(hipsdp_solver* s)
+{
+   int k = 0;
+   for (auto& B : s->blk)
+   {
+      const int n = B.n;
+      HS_CALL( gemm(s, HS_KC, HS_MC, n, n, n, 1.0, B.LxInv, n, B.dX, n, 0.0, B.T1, n) );
+      HS_CALL( gemm(s, HS_KC, HS_KC, n, n, n, 1.0, B.T1, n, B.LxInv, n, 0.0, B.W, n) );
+      HS_CALL( hs_lanczos_lmin(s->stream, n, B.W, s->par.lanczos_steps, s->sc + SC_BLK(k, 1), s->lan_ws) );
+      HS_CALL( gemm(s, HS_KC, HS_MC, n, n, n, 1.0, B.LzInv, n, B.dZ, n, 0.0, B.T1, n) );
+      HS_CALL( gemm(s, HS_KC, HS_KC, n, n, n, 1.0, B.T1, n, B.LzInv, n, 0.0, B.W, n) );
+      HS_CALL( hs_lanczos_lmin(s->stream, n, B.W, s->par.lanczos_steps, s->sc + SC_BLK(k, 4), s->lan_ws) );
+      ++k;
+   }
+   HS_CALL( hs_ratio_min(s->stream, s->q, s->x, s->dx, s->sc + SC_RATX, 0, s->red_ws) );
+   HS_CALL( hs_ratio_min(s->stream, s->q, s->z, s->dz, s->sc + SC_RATZ, 0, s->red_ws) );
+   return HS_OK;
+}
+
+static double steplen_host(hipsdp_solver* s, const HostScalars& h)
+{
+   double a = 1e300;
+   for (size_t k = 0; k < s->blk.size(); ++k)
+   {
+      for (int which = 0; which < 2; ++which)
+      {
+         const double theta = h.v[SC_BLK(k, which ? 4 : 1)];
+         const double resid = h.v[SC_BLK(k, which ? 5 : 2)];
+         const double lo = theta - resid;          /* pessimistic smallest eigenvalue */
+         if ( lo < 0.0 )
+            a = fmin(a, -1.0 / lo);
+      }
+   }
+   a = fmin(a, fmin(h.v[SC_RATX], h.v[SC_RATZ]));
+   const double dtau = h.v[SC_DTAU], dkap = h.v[SC_DKAPPA];
+   if ( dtau < 0.0 ) a = fmin(a, -s->tau / dtau);
+   if ( dkap < 0.0 ) a = fmin(a, -s->kappa / dkap);
+   return a;
+}
+
+extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info* info)
+{
+   g_err[0] = 0;
+   if ( s == NULL || !s->shaped || info == NULL )
+      return HIPSDP_ERR_ARG;
+   HS_HIP( hipSetDevice(s->device) );
+   if ( params != NULL )
+      s->par = *params;
+   const hipsdp_params& par = s->par;
+   const int m = s->m, m1 = s->m + 1, q = s->q;
+   const int K = (int) s->blk.size();
+   hipStream_t st = s->stream;
+   const auto t_begin = std::chrono::steady_clock::now();
+   memset(info, 0, sizeof(*info));
+   info->status = HIPSDP_STATUS_UNSOLVED;
+   HS_CALL( ensure_schur_ws(s) );
+
+   long long N = q;
+   for (auto& B : s->blk) N += B.n;
+   const double N1 = (double) (N + 1);
+
+   /* norms of b and of the constant part (host needs them once) */
+   HS_CALL( hs_dot(st, m, s->b, s->b, s->sc + 0, 0, s->red_ws) );
+   HS_CALL( hs_fill(st, s->sc + 1, 1, 0.0) );
+   for (auto& B : s->blk)
+      HS_CALL( hs_dot(st, (long long) B.n * B.n, B.A, B.A, s->sc + 1, 1, s->red_ws) );
+   if ( q > 0 )
+   {
+      /* column 0 of Dext: strided -> gather through gemv with unit vector would be overkill; copy it */
+      HS_HIP( hipMemcpy2DAsync(s->tmpq, sizeof(double), s->Dext, (size_t) m1 * sizeof(double), sizeof(double), (size_t) q, hipMemcpyDeviceToDevice, st) );
+      HS_CALL( hs_dot(st, q, s->tmpq, s->tmpq, s->sc + 1, 1, s->red_ws) );
+   }
+   double h2[2];
+   HS_HIP( hipMemcpyAsync(h2, s->sc, 2 * sizeof(double), hipMemcpyDeviceToHost, st) );
+   HS_HIP( hipStreamSynchronize(st) );
+   const double normb = sqrt(h2[0]);
+   const double normC = sqrt(h2[1]);
+
+   /* ---- starting point */
+   if ( !s->have_start )
+   {
+      const double xi = fmax(1.0, sqrt(fmax(fmax(normb, normC), 1.0)));
+      HS_CALL( hs_fill(st, s->y, m, 0.0) );
+      for (auto& B : s->blk)
+      {
+         HS_CALL( hs_set_identity(st, B.X, B.n, xi) );
+         HS_CALL( hs_set_identity(st, B.Z, B.n, xi) );
+      }
+      HS_CALL( hs_fill(st, s->x, q, xi) );
+      HS_CALL( hs_fill(st, s->z, q, xi) );
+      s->tau = 1.0;
+      s->kappa = xi * xi;
+   }
+   else
+   {
+      s->tau = 1.0;
+      s->kappa = 1.0;
+   }
+   s->have_start = false;
+
+   int status = HIPSDP_STATUS_ITERLIM;
+   int it = 0, certwait = 0, nstall = 0;
+   double lastmu = 1e300, alpha_last = 1.0;
+   double mu = 0, pinf = 0, dinf = 0, dabs = 0, gap = 0, pobj = 0, dobj = 0;
+   HostScalars hs;
+   int hflags[3] = {0, 0, 0};
+   bool want_cert = false;
+   double schur_ms = 0.0;
+
+   for (it = 0; it <= par.maxiter; ++it)
+   {
+      /* ---- residuals */
+      hipLaunchKernelGGL(k_make_ext, g1d(m1), dim3(256), 0, st, m, -s->tau, 1.0, s->y, s->yt);
+      HS_LAUNCH_CHECK();
+      HS_CALL( hs_fill(st, s->sc + SC_RD2, 1, 0.0) );
+      HS_CALL( hs_fill(st, s->sc + SC_XZ, 1, 0.0) );
+      HS_CALL( hs_fill(st, s->sc + SC_HD2, 1, 0.0) );
+      std::vector<double*> Xs;
+      for (int k = 0; k < K; ++k)
+      {
+         Block& B = s->blk[k];
+         const long long n2 = (long long) B.n * B.n;
+         HS_CALL( hs_gemv_t(st, m1, n2, B.A, n2, s->yt, -1.0, B.Z, B.Rd) );
+         HS_CALL( hs_dot(st, n2, B.Rd, B.Rd, s->sc + SC_BLK(k, 0), 0, s->red_ws) );
+         HS_CALL( hs_dot(st, n2, B.X, B.Z, s->sc + SC_XZ, 1, s->red_ws) );
+         if ( want_cert )
+         {
+            hipLaunchKernelGGL(k_cert, g1d(n2), dim3(256), 0, st, n2, s->tau, B.Rd, B.A, B.T1);
+            HS_LAUNCH_CHECK();
+            HS_CALL( hs_dot(st, n2, B.T1, B.T1, s->sc + SC_HD2, 1, s->red_ws) );
+         }
+         Xs.push_back(B.X);
+      }
+      if ( q > 0 )
+      {
+         const double* v = s->yt;
+         HS_CALL( hs_gemv_n(st, q, m1, s->Dext, m1, 1, &v, s->tmpq, q, s->gemv_ws, s->gemv_ws_len) );
+         HS_CALL( hs_scale_add(st, q, 1.0, s->tmpq, -1.0, s->z, s->rd) );
+         HS_CALL( hs_dot(st, q, s->rd, s->rd, s->sc + SC_RD2, 1, s->red_ws) );
+         HS_CALL( hs_absmax(st, q, s->rd, s->sc + SC_RDLPMAX, 0, s->red_ws) );
+         HS_CALL( hs_dot(st, q, s->x, s->z, s->sc + SC_XZ, 1, s->red_ws) );
+         if ( want_cert )
+         {
+            /* rd + tau * c */
+            HS_HIP( hipMemcpy2DAsync(s->tmpq, sizeof(double), s->Dext, (size_t) m1 * sizeof(double), sizeof(double), (size_t) q, hipMemcpyDeviceToDevice, st) );
+            HS_CALL( hs_scale_add(st, q, s->tau, s->tmpq, 1.0, s->rd, s->tmpq) );
+            HS_CALL( hs_dot(st, q, s->tmpq, s->tmpq, s->sc + SC_HD2, 1, s->red_ws) );
+         }
+      }
+      else
+         HS_CALL( hs_fill(st, s->sc + SC_RDLPMAX, 1, 0.0) );
+      HS_CALL( apply_A(s, Xs.data(), s->x, s->AX) );
+      HS_CALL( hs_copy(st, s->sc + SC_AX0, s->AX, 1) );
+      hipLaunchKernelGGL(k_rp, g1d(m > 0 ? m : 1), dim3(256), 0, st, m, s->tau, s->b, s->AX, s->rp);
+      HS_LAUNCH_CHECK();
+      HS_CALL( hs_dot(st, m, s->rp, s->rp, s->sc + SC_RP2, 0, s->red_ws) );
+      HS_CALL( hs_dot(st, m, s->AX + 1, s->AX + 1, s->sc + SC_HP2, 0, s->red_ws) );
+      HS_CALL( hs_dot(st, m, s->b, s->y, s->sc + SC_DOBJ, 0, s->red_ws) );
+      HS_CALL( read_scalars(s, hs, NULL) );
+
+      const double tau = s->tau, kappa = s->kappa;
+      pobj = hs.v[SC_AX0];
+      dobj = hs.v[SC_DOBJ];
+      const double rg = pobj - dobj - kappa;
+      mu = (hs.v[SC_XZ] + tau * kappa) / N1;
+      double rd2 = hs.v[SC_RD2];
+      double rdmax = hs.v[SC_RDLPMAX];
+      for (int k = 0; k < K; ++k)
+      {
+         rd2 += hs.v[SC_BLK(k, 0)];
+         rdmax = fmax(rdmax, sqrt(hs.v[SC_BLK(k, 0)]));
+      }
+      pinf = sqrt(hs.v[SC_RP2]) / tau / (1.0 + normb);
+      dinf = sqrt(rd2) / tau / (1.0 + normC);
+      dabs = rdmax / tau;
+      gap = fabs(dobj - pobj) / tau;
+      if ( par.verbose )
+         printf("hipsdp it %3d mu %.3e pinf %.3e dinf %.3e gap %.3e pobj %.8e dobj %.8e tau %.3e kap %.3e\n", it, mu, pinf, dinf,
+            gap, pobj / tau, dobj / tau, tau, kappa);
+
+      if ( !std::isfinite(mu) || !std::isfinite(pinf) || !std::isfinite(dinf) )
+      {
+         status = HIPSDP_STATUS_NUMERIC;
+         break;
+      }
+      /* ---- termination (mirrors oracle/ipm_ref.py) */
+      if ( pinf <= par.feastol && dabs <= par.feastol && gap <= par.gaptol )
+      {
+         status = HIPSDP_STATUS_OPTIMAL;
+         break;
+      }
+      if ( par.objlimit < 1e20 && pinf <= par.feastol && pobj / tau > par.objlimit )
+      {
+         status = HIPSDP_STATUS_OBJLIM;
+         break;
+      }
+      const bool certzone = (tau < 1e-2 * fmin(1.0, kappa)) || (mu / (tau * tau) > 1e10);
+      if ( certzone && want_cert )
+      {
+         const double hd = sqrt(hs.v[SC_HD2]);
+         const double hp = sqrt(hs.v[SC_HP2]);
+         const double big = fmax(fabs(dobj), fabs(pobj));
+         const bool cand_dunb = dobj < -1e-3 * big;
+         const bool cand_dinf = pobj > 1e-3 * big;
+         const bool ok_dunb = cand_dunb && hd <= par.infeastol * (-dobj);
+         const bool ok_dinf = cand_dinf && hp <= par.infeastol * pobj;
+         if ( (ok_dunb || ok_dinf) && (ok_dunb || !cand_dunb || certwait >= 5) && (ok_dinf || !cand_dinf || certwait >= 5) )
+         {
+            status = (ok_dunb && ok_dinf) ? HIPSDP_STATUS_PDINF : (ok_dunb ? HIPSDP_STATUS_DUNB : HIPSDP_STATUS_DINF);
+            break;
+         }
+         if ( ok_dunb || ok_dinf )
+            ++certwait;
+      }
+      if ( certzone && !want_cert )
+      {
+         /* the certificate residual was not computed in this pass: redo the (cheap) residual pass with it */
+         want_cert = true;
+         --it;
+         continue;
+      }
+      want_cert = certzone;
+      if ( it == par.maxiter )
+         break;
+      if ( mu > 0.9 * lastmu && alpha_last < 1e-2 )
+      {
+         if ( ++nstall >= 3 )
+         {
+            status = HIPSDP_STATUS_NUMERIC;
+            break;
+         }
+      }
+      else
+         nstall = 0;
+      lastmu = mu;
+      if ( par.timelimit > 0.0 )
+      {
+         const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+         if ( el > par.timelimit )
+         {
+            status = HIPSDP_STATUS_TIMELIM;
+            break;
+         }
+      }
+
+      /* ---- factorizations */
+      HS_HIP( hipMemsetAsync(s->flags, 0, 8 * sizeof(int), st) );
+      for (auto& B : s->blk)
+      {
+         const int n = B.n;
+         const long long n2 = (long long) n * n;
+         HS_CALL( hs_copy(st, B.Lz, B.Z, n2) );
+         HS_CALL( hs_potrf(st, n, B.Lz, B.dinvz, s->flags + 0, NULL) );
+         HS_CALL( hs_trtri(st, n, B.Lz, B.dinvz, B.LzInv, B.T1) );
+         HS_CALL( gemm(s, HS_MC, HS_MC, n, n, n, 1.0, B.LzInv, n, B.LzInv, n, 0.0, B.Zinv, n, HS_GEMM_LOWER) );
+         HS_CALL( hs_mirror_lower(st, B.Zinv, n, n) );
+         HS_CALL( hs_copy(st, B.Lx, B.X, n2) );
+         HS_CALL( hs_potrf(st, n, B.Lx, B.dinvx, s->flags + 1, NULL) );
+         HS_CALL( hs_trtri(st, n, B.Lx, B.dinvx, B.LxInv, B.T1) );
+      }
+
+      /* ---- Schur complement (extended by the constant matrix as "variable 0") */
+      HS_HIP( hipEventRecord(s->ev0, st) );
+      HS_CALL( hs_fill(st, s->Mx, (long long) m1 * m1, 0.0) );
+      for (auto& B : s->blk)
+         HS_CALL( schur_block(s, B, 0, m1) );
+      if ( q > 0 )
+      {
+         HS_CALL( hs_lp_scale_rows(st, q, m1, s->x, s->z, s->Dext, s->Slp) );
+         HS_CALL( gemm(s, HS_MC, HS_MC, m1, m1, q, 1.0, s->Dext, m1, s->Slp, m1, 1.0, s->Mx, m1, HS_GEMM_LOWER) );
+      }
+      HS_CALL( hs_mirror_lower(st, s->Mx, m1, m1) );
+      HS_HIP( hipEventRecord(s->ev1, st) );
+      if ( m > 0 )
+      {
+         HS_HIP( hipMemcpy2DAsync(s->Lm, (size_t) m * sizeof(double), s->Mx + m1 + 1, (size_t) m1 * sizeof(double),
+               (size_t) m * sizeof(double), (size_t) m, hipMemcpyDeviceToDevice, st) );
+         HS_CALL( hs_potrf(st, m, s->Lm, s->dinvm, s->flags + 2, NULL) );
+         hipLaunchKernelGGL(k_rhs2, g1d(m), dim3(256), 0, st, m, s->Mx, s->b, s->rhs2);
+         HS_LAUNCH_CHECK();
+         HS_CALL( hs_trsv(st, m, s->Lm, s->dinvm, 2, s->rhs2, m, 3) );
+      }
+      hipLaunchKernelGGL(k_after_solve2, g1d(m1), dim3(256), 0, st, m, s->rhs2, s->u2, s->wt);
+      HS_LAUNCH_CHECK();
+      /* B_k = A_0 - sum w_i A_i ; beta = c - D w ; S0 ; b^T M^-1 b */
+      HS_CALL( hs_fill(st, s->sc + SC_S0, 1, 0.0) );
+      for (auto& B : s->blk)
+      {
+         const int n = B.n;
+         const long long n2 = (long long) n * n;
+         HS_CALL( hs_gemv_t(st, m1, n2, B.A, n2, s->wt, 0.0, NULL, B.B) );
+         HS_CALL( gemm(s, HS_KC, HS_MC, n, n, n, 1.0, B.X, n, B.B, n, 0.0, B.T1, n) );
+         HS_CALL( gemm(s, HS_KC, HS_MC, n, n, n, 1.0, B.T1, n, B.Zinv, n, 0.0, B.W, n) );
+         HS_CALL( hs_dot(st, n2, B.B, B.W, s->sc + SC_S0, 1, s->red_ws) );
+      }
+      if ( q > 0 )
+      {
+         const double* v = s->wt;
+         HS_CALL( hs_gemv_n(st, q, m1, s->Dext, m1, 1, &v, s->beta, q, s->gemv_ws, s->gemv_ws_len) );
+         HS_CALL( hs_lp_s0(st, q, s->x, s->z, s->beta, s->sc + SC_S0, 1, s->red_ws) );
+      }
+      HS_CALL( hs_dot(st, m, s->b, s->rhs2 + m, s->sc + SC_BUB, 0, s->red_ws) );
+
+      /* ---- predictor */
+      HS_CALL( direction(s, 0.0, 1.0, mu, rg, false, 0.0) );
+      HS_CALL( steplen_enqueue(s) );
+      HS_CALL( read_scalars(s, hs, hflags) );
+      {
+         float ms = 0.f;
+         if ( hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess )
+            schur_ms += ms;
+         info->schur_calls++;
+         for (auto& B : s->blk)
+            info->schur_flops += 4.0 * m1 * (double) B.n * B.n * B.n + (double) m1 * m1 * (double) B.n * B.n;
+      }
+      if ( hflags[0] != 0 || hflags[1] != 0 || hflags[2] != 0 )
+      {
+         if ( par.verbose )
+            printf("hipsdp: Cholesky failure flags Z=%d X=%d M=%d\n", hflags[0], hflags[1], hflags[2]);
+         status = HIPSDP_STATUS_NUMERIC;
+         break;
+      }
+      const double aa = fmin(1.0, steplen_host(s, hs));
+      const double dta = hs.v[SC_DTAU], dka = hs.v[SC_DKAPPA];
+      if ( !std::isfinite(aa) || !std::isfinite(dta) )
+      {
+         status = HIPSDP_STATUS_NUMERIC;
+         break;
+      }
+      double sigma = (1.0 - aa) * (1.0 - aa) * (1.0 - aa);
+      sigma = fmin(1.0, fmax(1e-8, sigma));
+      const double eta = 1.0 - sigma;
+      /* second-order terms from the predictor */
+      for (auto& B : s->blk)
+      {
+         const int n = B.n;
+         const long long n2 = (long long) n * n;
+         HS_CALL( hs_copy(st, B.dXa, B.dX, n2) );
+         HS_CALL( hs_copy(st, B.dZa, B.dZ, n2) );
+         HS_CALL( gemm(s, HS_KC, HS_MC, n, n, n, 1.0, B.dXa, n, B.dZa, n, 0.0, B.E, n) );
+      }
+      if ( q > 0 )
+         HS_CALL( hs_vec_mul(st, q, s->dx, s->dz, s->elp) );
+
+      /* ---- corrector */
+      HS_CALL( direction(s, sigma, eta, mu, rg, true, dta * dka) );
+      HS_CALL( steplen_enqueue(s) );
+      HS_CALL( read_scalars(s, hs, NULL) );
+      const double amax = steplen_host(s, hs);
+      double alpha = fmin(1.0, par.gamma * amax);
+      const double dt = hs.v[SC_DTAU], dk = hs.v[SC_DKAPPA];
+      if ( !std::isfinite(alpha) || !std::isfinite(dt) || !std::isfinite(dk) )
+      {
+         status = HIPSDP_STATUS_NUMERIC;
+         break;
+      }
+
+      /* ---- update, with a Cholesky check of the new X and Z (the Lanczos bound is an estimate) */
+      for (auto& B : s->blk)
+      {
+         const long long n2 = (long long) B.n * B.n;
+         HS_CALL( hs_copy(st, B.Xs, B.X, n2) );
+         HS_CALL( hs_copy(st, B.Zs, B.Z, n2) );
+      }
+      for (int attempt = 0; attempt < 8; ++attempt)
+      {
+         HS_HIP( hipMemsetAsync(s->flags, 0, 8 * sizeof(int), st) );
+         for (auto& B : s->blk)
+         {
+            const int n = B.n;
+            const long long n2 = (long long) n * n;
+            HS_CALL( hs_scale_add(st, n2, alpha, B.dX, 1.0, B.Xs, B.X) );
+            HS_CALL( hs_scale_add(st, n2, alpha, B.dZ, 1.0, B.Zs, B.Z) );
+            HS_CALL( hs_copy(st, B.Lx, B.X, n2) );
+            HS_CALL( hs_potrf(st, n, B.Lx, B.dinvx, s->flags + 1, NULL) );
+            HS_CALL( hs_copy(st, B.Lz, B.Z, n2) );
+            HS_CALL( hs_potrf(st, n, B.Lz, B.dinvz, s->flags + 0, NULL) );
+         }
+         if ( K == 0 )
+            break;
+         HS_HIP( hipMemcpyAsync(hflags, s->flags, 3 * sizeof(int), hipMemcpyDeviceToHost, st) );
+         HS_HIP( hipStreamSynchronize(st) );
+         if ( hflags[0] == 0 && hflags[1] == 0 )
+            break;
+         alpha *= 0.5;
+         info->chol_fail++;
+      }
+      if ( K > 0 && (hflags[0] != 0 || hflags[1] != 0) )
+      {
+         for (auto& B : s->blk)
+         {
+            const long long n2 = (long long) B.n * B.n;
+            HS_CALL( hs_copy(st, B.X, B.Xs, n2) );
+            HS_CALL( hs_copy(st, B.Z, B.Zs, n2) );
+         }
+         status = HIPSDP_STATUS_NUMERIC;
+         break;
+      }
+      HS_CALL( hs_axpy(st, m, alpha, s->dy, s->y) );
+      HS_CALL( hs_axpy(st, q, alpha, s->dx, s->x) );
+      HS_CALL( hs_axpy(st, q, alpha, s->dz, s->z) );
+      s->tau += alpha * dt;
+      s->kappa += alpha * dk;
+      alpha_last = alpha;
+   }
+
+   HS_HIP( hipStreamSynchronize(st) );
+   s->last_status = status;
+   s->solved = true;
+   if ( status == HIPSDP_STATUS_DINF || status == HIPSDP_STATUS_DUNB || status == HIPSDP_STATUS_PDINF )
+      s->sol_scale = 1.0 / fmax(fmax(fabs(dobj), fabs(pobj)), 1e-300);
+   else
+      s->sol_scale = 1.0 / s->tau;
+   info->status = status;
+   info->iterations = it;
+   info->pobj = pobj * s->sol_scale;
+   info->dobj = dobj * s->sol_scale;
+   info->pinf = pinf;
+   info->dinf = dinf;
+   info->dabs = dabs;
+   info->gap = gap;
+   info->mu = mu;
+   info->tau = s->tau;
+   info->kappa = s->kappa;
+   info->schur_seconds = schur_ms * 1e-3;
+   info->solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+   return HIPSDP_OK;
+}
+
+/* ---- readback ------------------------------------------------------------------------------------------------------ */
+
+static int read_scaled(hipsdp_solver* s, const double* d, long long n, double scale, double* out)
+{
+   if ( n <= 0 ) return HIPSDP_OK;
+   HS_HIP( hipSetDevice(s->device) );
+   HS_HIP( hipMemcpy(out, d, (size_t) n * sizeof(double), hipMemcpyDeviceToHost) );
+   for (long long i = 0; i < n; ++i)
+      out[i] *= scale;
+   return HIPSDP_OK;
+}
+
+extern "C" int hipsdp_get_y(hipsdp_solver* s, double* y)
+{
+   if ( s == NULL || !s->solved ) return HIPSDP_ERR_ARG;
+   return read_scaled(s, s->y, s->m, s->sol_scale, y);
+}
+
+extern "C" int hipsdp_get_X(hipsdp_solver* s, int block, double* X)
+{
+   if ( s == NULL || !s->solved || block < 0 || block >= (int) s->blk.size() ) return HIPSDP_ERR_ARG;
+   return read_scaled(s, s->blk[block].X, (long long) s->blk[block].n * s->blk[block].n, s->sol_scale, X);
+}
+
+extern "C" int hipsdp_get_Z(hipsdp_solver* s, int block, double* Z)
+{
+   if ( s == NULL || !s->solved || block < 0 || block >= (int) s->blk.size() ) return HIPSDP_ERR_ARG;
+   return read_scaled(s, s->blk[block].Z, (long long) s->blk[block].n * s->blk[block].n, s->sol_scale, Z);
+}
+
+extern "C" int hipsdp_get_lp(hipsdp_solver* s, double* x, double* z)
+{
+   if ( s == NULL || !s->solved ) return HIPSDP_ERR_ARG;
+   if ( x != NULL ) HS_CALL( read_scaled(s, s->x, s->q, s->sol_scale, x) );
+   if ( z != NULL ) HS_CALL( read_scaled(s, s->z, s->q, s->sol_scale, z) );
+   return HIPSDP_OK;
+}
+
+extern "C" int hipsdp_check_y(hipsdp_solver* s, const double* y, double* lmin, double* lpviol)
+{
+   if ( s == NULL || !s->shaped ) return HIPSDP_ERR_ARG;
+   HS_HIP( hipSetDevice(s->device) );
+   const int m = s->m, m1 = m + 1, q = s->q;
+   hipStream_t st = s->stream;
+   if ( m > 0 )
+      HS_HIP( hipMemcpyAsync(s->ys, y, (size_t) m * sizeof(double), hipMemcpyHostToDevice, st) );
+   hipLaunchKernelGGL(k_make_ext, g1d(m1), dim3(256), 0, st, m, -1.0, 1.0, s->ys, s->dyt);
+   HS_LAUNCH_CHECK();
+   int k = 0;
+   for (auto& B : s->blk)
+   {
+      const long long n2 = (long long) B.n * B.n;
+      HS_CALL( hs_gemv_t(st, m1, n2, B.A, n2, s->dyt, 0.0, NULL, B.W) );
+      /* run Lanczos to (numerical) convergence: up to min(n, 250) steps */
+      HS_CALL( hs_lanczos_lmin(st, B.n, B.W, 250, s->sc + SC_BLK(k, 1), s->lan_ws) );
+      ++k;
+   }
+   HS_CALL( hs_fill(st, s->sc + SC_RATX, 1, 0.0) );
+   if ( q > 0 )
+   {
+      const double* v = s->dyt;
+      HS_CALL( hs_gemv_n(st, q, m1, s->Dext, m1, 1, &v, s->tmpq, q, s->gemv_ws, s->gemv_ws_len) );
+      /* violation = max(0, -min(D y - c)) : use absmax on the negative part via ratio trick: min over rows */
+      HS_CALL( hs_fill(st, s->hl, q, -1.0) );
+      HS_CALL( hs_ratio_min(st, q, s->tmpq, s->hl, s->sc + SC_RATX, 0, s->red_ws) );   /* min_r (D y - c)_r */
+   }
+   HostScalars h;
+   HS_CALL( read_scalars(s, h, NULL) );
+   for (size_t b = 0; b < s->blk.size(); ++b)
+      lmin[b] = h.v[SC_BLK(b, 1)] - h.v[SC_BLK(b, 2)];
+   if ( lpviol != NULL )
+      *lpviol = q > 0 ? fmax(0.0, -h.v[SC_RATX]) : 0.0;
+   return HIPSDP_OK;
+}
+
+extern "C" int hipsdp_set_comm(hipsdp_solver* s, void* comm, int rank, int nranks)
+{
+   if ( s == NULL ) return HIPSDP_ERR_ARG;
+   s->comm = comm; s->rank = rank; s->nranks = nranks;
+   return HIPSDP_OK;
+}

@@ -1,0 +1,590 @@
+/* kernels.hip - the bandwidth-bound pieces of the interior-point iteration: the two passes over the packed constraint
+ * matrices A (row i = vec(A_i), the "svec-free" full storage used by the MFMA Schur assembly),
+ *
+ *    A(X)_i   = <A_i, X>                 hs_gemv_n   (one coalesced pass, up to four X at once)
+ *    A^T(y)   = sum_i y_i A_i            hs_gemv_t   (one coalesced pass)
+ *
+ * plus reductions and element-wise updates.  These replace work that the reference leaves to DSDP/SDPA
+ * (sdpisolver_dsdp.c:1503, sdpisolver_sdpa.cpp:1620).  All are HBM-bound: 8 bytes of A per 2 flops.
+ * Reductions are two-stage with a fixed combination order, so results are bitwise reproducible run to run.
+ */
+#include "hs_kernels.h"
+
+struct __attribute__((aligned(16))) dbl2 { double x, y; };
+
+static inline int hs_launch_ok(void)
+{
+   return hipGetLastError() == hipSuccess ? HS_OK : HS_ERR_HIP;
+}
+
+#define HS_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if ( e_ != hipSuccess ) { hs_record_hip_error(e_, "kernel launch", __FILE__, __LINE__); return HS_ERR_HIP; } } while (0)
+
+/* ---------------------------------------------------------------------------------------------------------------- */
+/* element-wise                                                                                                       */
+/* ---------------------------------------------------------------------------------------------------------------- */
+
+__global__ void k_fill(double* p, long long n, double v)
+{
+   for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x)
+      p[i] = v;
+}
+
+__global__ void k_identity(double* A, int n, double v)
+{
+   const long long total = (long long) n * n;
+   for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long) gridDim.x * blockDim.x)
+   {
+      const int r = (int) (i / n);
+      const int c = (int) (i - (long long) r * n);
+      A[i] = (r == c) ? v : 0.0;
+   }
+}
+
+__global__ void k_scale_add(long long n, double a, const double* __restrict__ x, double b, const double* __restrict__ y,
+   double* __restrict__ out)
+{
+   for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x)
+   {
+      double v = a * x[i];
+      if ( y != NULL )
+         v += b * y[i];
+      out[i] = v;
+   }
+}
+
+__global__ void k_mirror_lower(double* A, int n, long long lda)
+{
+   const long long total = (long long) n * n;
+   for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long) gridDim.x * blockDim.x)
+   {
+      const int r = (int) (i / n);
+      const int c = (int) (i - (long long) r * n);
+      if ( r < c )
+         A[(long long) r * lda + c] = A[(long long) c * lda + r];
+   }
+}
+
+__global__ void k_symmetrize(double* A, int n)
+{
+   const long long total = (long long) n * n;
+   for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long) gridDim.x * blockDim.x)
+   {
+      const int r = (int) (i / n);
+      const int c = (int) (i - (long long) r * n);
+      if ( r > c )
+      {
+         const double v = 0.5 * (A[(long long) r * n + c] + A[(long long) c * n + r]);
+         A[(long long) r * n + c] = v;
+         A[(long long) c * n + r] = v;
+      }
+   }
+}
+
+__global__ void k_dirmat(int n, double s1, const double* __restrict__ Zinv, const double* __restrict__ X,
+   const double* __restrict__ GZ, double* __restrict__ H)
+{
+   const long long total = (long long) n * n;
+   for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long) gridDim.x * blockDim.x)
+   {
+      const int r = (int) (i / n);
+      const int c = (int) (i - (long long) r * n);
+      const double g = 0.5 * (GZ[i] + GZ[(long long) c * n + r]);
+      H[i] = s1 * Zinv[i] - X[i] - g;
+   }
+}
+
+__global__ void k_lp_dir(int q, double sigmu, double eta, const double* __restrict__ x, const double* __restrict__ z,
+   const double* __restrict__ r, const double* __restrict__ elp, double* __restrict__ out)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if ( i < q )
+   {
+      double t = eta * x[i] * r[i];
+      if ( elp != NULL )
+         t += elp[i];
+      out[i] = sigmu / z[i] - x[i] - t / z[i];
+   }
+}
+
+__global__ void k_lp_scale_rows(int q, int cols, const double* __restrict__ x, const double* __restrict__ z,
+   const double* __restrict__ D, double* __restrict__ S)
+{
+   const long long total = (long long) q * cols;
+   for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long) gridDim.x * blockDim.x)
+   {
+      const int r = (int) (i / cols);
+      S[i] = (x[r] / z[r]) * D[i];
+   }
+}
+
+__global__ void k_vec_mul(long long n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out)
+{
+   for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x)
+      out[i] = a[i] * b[i];
+}
+
+static inline int grid_for(long long n, int block, int cap)
+{
+   long long g = (n + block - 1) / block;
+   if ( g > cap ) g = cap;
+   if ( g < 1 ) g = 1;
+   return (int) g;
+}
+
+int hs_fill(hipStream_t s, double* p, long long n, double v)
+{
+   if ( n <= 0 ) return HS_OK;
+   hipLaunchKernelGGL(k_fill, dim3(grid_for(n, 256, 2048)), dim3(256), 0, s, p, n, v);
+   HS_LAUNCH_CHECK();
+   return HS_OK;
+}
+
+int hs_set_identity(hipStream_t s, double* A, int n, double v)
+{
+   if ( n <= 0 ) return HS_OK;
+   hipLaunchKernelGGL(k_identity, dim3(grid_for((long long) n * n, 256, 2048)), dim3(256), 0, s, A, n, v);
+   HS_LAUNCH_CHECK();
+   return HS_OK;
+}
+
+int hs_copy(hipStream_t s, double* dst, const double* src, long long n)
+{
+   if ( n <= 0 ) return HS_OK;
+   HS_HIP( hipMemcpyAsync(dst, src, (size_t) n * sizeof(double), hipMemcpyDeviceToDevice, s) );
+   return HS_OK;
+}
+
+int hs_scale_add(hipStream_t s, long long n, double a, const double* x, double b, const double* y, double* out)
+{
+   if ( n <= 0 ) return HS_OK;
+   hipLaunchKernelGGL(k_scale_add, dim3(grid_for(n, 256, 2048)), dim3(256), 0, s, n, a, x, b, y, out);
+   HS_LAUNCH_CHECK();
+   return HS_OK;
+}
+
+int hs_axpy(hipStream_t s, long long n, double a, const double* x, double* y)
+{
+   return hs_scale_add(s, n, a, x, 1.0, y, y);
+}
+
+int hs_mirror_lower(hipStream_t s, double* A, int n, long long lda)
+{
+   if ( n <= 1 ) return HS_OK;
+   hipLaunchKernelGGL(k_mirror_lower, dim3(grid_for((long long) n * n, 256, 2048)), dim3(256), 0, s, A, n, lda);
+   HS_LAUNCH_CHECK();
+   return HS_OK;
+}
+
+int hs_symmetrize(hipStream_t s, double* A, int n)
+{
+   if ( n <= 1 ) return HS_OK;
+   hipLaunchKernelGGL(k_symmetrize, dim3(grid_for((long long) n * n, 256, 2048)), dim3(256), 0, s, A, n);
+   HS_LAUNCH_CHECK();
+   return HS_OK;
+}
+
+int hs_dirmat(hipStream_t s, int n, double s1, const double* Zinv, const double* X, const double* GZ, double* H)
+{
+   if ( n <= 0 ) return HS_OK;
+   hipLaunchKernelGGL(k_dirmat, dim3(grid_for((long long) n * n, 256, 2048)), dim3(256), 0, s, n, s1, Zinv, X, GZ, H);
+   HS_LAUNCH_CHECK();
+   return HS_OK;
+}
+
+int hs_lp_dir(hipStream_t s, int q, double sigmu, double eta, const double* x, const double* z, const double* r,
+   const double* elp, double* out)
+{
+   if ( q <= 0 ) return HS_OK;
+   hipLaunchKernelGGL(k_lp_dir, dim3((q + 255) / 256), dim3(256), 0, s, q, sigmu, eta, x, z, r, elp, out);
+   HS_LAUNCH_CHECK();
+   return HS_OK;
+}
+
+int hs_lp_scale_rows(hipStream_t s, int q, int cols, const double* x, const double* z, const double* D, double* S)
+{
+   if ( q <= 0 ) return HS_OK;
+   hipLaunchKernelGGL(k_lp_scale_rows, dim3(grid_for((long long) q * cols, 256, 2048)), dim3(256), 0, s, q, cols, x, z, D, S);
+   HS_LAUNCH_CHECK();
+   return HS_OK;
+}
+
+int hs_vec_mul(hipStream_t s, long long n, const double* a, const double* b, double* out)
+{
+   if ( n <= 0 ) return HS_OK;
+   hipLaunchKernelGGL(k_vec_mul, dim3(grid_for(n, 256, 2048)), dim3(256), 0, s, n, a, b, out);
+   HS_LAUNCH_CHECK();
+   return HS_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------- */
+/* block reduction helpers (wave = 64 lanes)                                                                          */
+/* ---------------------------------------------------------------------------------------------------------------- */
+
+struct OpSum { __device__ static double id() { return 0.0; } __device__ static double f(double a, double b) { return a + b; } };
+struct OpMax { __device__ static double id() { return 0.0; } __device__ static double f(double a, double b) { return a > b ? a : b; } };
+struct OpMin { __device__ static double id() { return 1e300; } __device__ static double f(double a, double b) { return a < b ? a : b; } };
+
+template<class OP>
+__device__ __forceinline__ double wave_reduce(double v)
+{
+#pragma unroll
+   for (int off = 32; off > 0; off >>= 1)
+      v = OP::f(v, __shfl_down(v, off, 64));
+   return v;
+}
+
+/* reduces over the 256 threads of a block; result valid in thread 0 */
+template<class OP>
+__device__ __forceinline__ double block_reduce_256(double v, double* sh)
+{
+   v = wave_reduce<OP>(v);
+   const int lane = threadIdx.x & 63;
+   const int wave = threadIdx.x >> 6;
+   if ( lane == 0 )
+      sh[wave] = v;
+   __syncthreads();
+   double r = OP::id();
+   if ( threadIdx.x == 0 )
+   {
+      r = sh[0];
+      for (int w = 1; w < (int) (blockDim.x >> 6); ++w)
+         r = OP::f(r, sh[w]);
+   }
+   __syncthreads();
+   return r;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------- */
+/* generic two-stage reductions                                                                                       */
+/* ---------------------------------------------------------------------------------------------------------------- */
+
+#define RED_DOT      0
+#define RED_ABSMAX   1
+#define RED_RATIOMIN 2
+#define RED_LPS0     3
+
+template<int KIND> struct RedTraits;
+template<> struct RedTraits<RED_DOT>      { typedef OpSum OP; };
+template<> struct RedTraits<RED_ABSMAX>   { typedef OpMax OP; };
+template<> struct RedTraits<RED_RATIOMIN> { typedef OpMin OP; };
+template<> struct RedTraits<RED_LPS0>     { typedef OpSum OP; };
+
+template<int KIND>
+__device__ __forceinline__ double red_elem(long long i, const double* a, const double* b, const double* c)
+{
+   if ( KIND == RED_DOT )
+      return a[i] * b[i];
+   if ( KIND == RED_ABSMAX )
+      return fabs(a[i]);
+   if ( KIND == RED_RATIOMIN )
+   {
+      const double d = b[i];
+      return d < 0.0 ? -a[i] / d : 1e300;
+   }
+   /* RED_LPS0: (x / z) * beta^2 */
+   return (a[i] / b[i]) * c[i] * c[i];
+}
+
+template<int KIND>
+__global__ void __launch_bounds__(256) k_reduce_stage1(long long n, const double* __restrict__ a, const double* __restrict__ b,
+   const double* __restrict__ c, double* __restrict__ part, double* __restrict__ out, int accumulate, int direct)
+{
+   typedef typename RedTraits<KIND>::OP OP;
+   __shared__ double sh[4];
+   double v = OP::id();
+   for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x)
+      v = OP::f(v, red_elem<KIND>(i, a, b, c));
+   v = block_reduce_256<OP>(v, sh);
+   if ( threadIdx.x == 0 )
+   {
+      if ( direct )
+         *out = accumulate ? OP::f(*out, v) : v;
+      else
+         part[blockIdx.x] = v;
+   }
+}
+
+template<int KIND>
+__global__ void __launch_bounds__(256) k_reduce_stage2(int nparts, const double* __restrict__ part, double* __restrict__ out,
+   int accumulate)
+{
+   typedef typename RedTraits<KIND>::OP OP;
+   __shared__ double sh[4];
+   double v = OP::id();
+   for (int i = threadIdx.x; i < nparts; i += blockDim.x)
+      v = OP::f(v, part[i]);
+   v = block_reduce_256<OP>(v, sh);
+   if ( threadIdx.x == 0 )
+      *out = accumulate ? OP::f(*out, v) : v;
+}
+
+template<int KIND>
+static int reduce_launch(hipStream_t s, long long n, const double* a, const double* b, const double* c, double* out,
+   int accumulate, double* ws)
+{
+   if ( n <= 0 )
+   {
+      if ( !accumulate )
+      {
+         const double idv = (KIND == RED_RATIOMIN) ? 1e300 : 0.0;
+         HS_CALL( hs_fill(s, out, 1, idv) );
+      }
+      return HS_OK;
+   }
+   const int g = grid_for(n, 2048, 256);
+   if ( g == 1 )
+   {
+      hipLaunchKernelGGL((k_reduce_stage1<KIND>), dim3(1), dim3(256), 0, s, n, a, b, c, ws, out, accumulate, 1);
+      HS_LAUNCH_CHECK();
+      return HS_OK;
+   }
+   hipLaunchKernelGGL((k_reduce_stage1<KIND>), dim3(g), dim3(256), 0, s, n, a, b, c, ws, out, accumulate, 0);
+   HS_LAUNCH_CHECK();
+   hipLaunchKernelGGL((k_reduce_stage2<KIND>), dim3(1), dim3(256), 0, s, g, ws, out, accumulate);
+   HS_LAUNCH_CHECK();
+   return HS_OK;
+}
+
+int hs_dot(hipStream_t s, long long n, const double* a, const double* b, double* out, int accumulate, double* ws)
+{
+   return reduce_launch<RED_DOT>(s, n, a, b, NULL, out, accumulate, ws);
+}
+
+int hs_absmax(hipStream_t s, long long n, const double* a, double* out, int accumulate, double* ws)
+{
+   return reduce_launch<RED_ABSMAX>(s, n, a, NULL, NULL, out, accumulate, ws);
+}
+
+int hs_ratio_min(hipStream_t s, long long n, const double* x, const double* d, double* out, int accumulate, double* ws)
+{
+   return reduce_launch<RED_RATIOMIN>(s, n, x, d, NULL, out, accumulate, ws);
+}
+
+int hs_lp_s0(hipStream_t s, int q, const double* x, const double* z, const double* beta, double* out, int accumulate, double* ws)
+{
+   return reduce_launch<RED_LPS0>(s, q, x, z, beta, out, accumulate, ws);
+}
+
+/* ---------------------------------------------------------------------------------------------------------------- */
+/* A(X): row-wise dot products, one pass over A for up to four vectors                                                */
+/* ---------------------------------------------------------------------------------------------------------------- */
+
+struct gemvn_vecs { const double* v[4]; };
+
+template<int NV, bool VEC>
+__global__ void __launch_bounds__(256) k_gemv_n(int R, long long E, const double* __restrict__ A, long long lda,
+   gemvn_vecs V, double* __restrict__ out, long long ldo, int nsplit, long long chunk)
+{
+   __shared__ double sh[4];
+   const int row = blockIdx.x;
+   const int sp = blockIdx.y;
+   const long long e0 = sp * chunk;
+   long long e1 = e0 + chunk;
+   if ( e1 > E ) e1 = E;
+   const double* a = A + (long long) row * lda;
+   double acc[NV];
+#pragma unroll
+   for (int v = 0; v < NV; ++v)
+      acc[v] = 0.0;
+
+   if ( VEC )
+   {
+      /* chunk and e0 are even, all bases 16-byte aligned */
+      for (long long e = e0 + 2 * threadIdx.x; e + 1 < e1; e += 512)
+      {
+         const dbl2 x = *reinterpret_cast<const dbl2*>(a + e);
+#pragma unroll
+         for (int v = 0; v < NV; ++v)
+         {
+            const dbl2 w = *reinterpret_cast<const dbl2*>(V.v[v] + e);
+            acc[v] += x.x * w.x;
+            acc[v] += x.y * w.y;
+         }
+      }
+      if ( ((e1 - e0) & 1) && threadIdx.x == 0 )
+      {
+#pragma unroll
+         for (int v = 0; v < NV; ++v)
+            acc[v] += a[e1 - 1] * V.v[v][e1 - 1];
+      }
+   }
+   else
+   {
+      for (long long e = e0 + threadIdx.x; e < e1; e += 256)
+      {
+         const double x = a[e];
+#pragma unroll
+         for (int v = 0; v < NV; ++v)
+            acc[v] += x * V.v[v][e];
+      }
+   }
+#pragma unroll
+   for (int v = 0; v < NV; ++v)
+   {
+      const double r = block_reduce_256<OpSum>(acc[v], sh);
+      if ( threadIdx.x == 0 )
+         out[((long long) sp * NV + v) * ldo + row] = r;
+   }
+}
+
+__global__ void k_gemv_n_combine(int R, int nv, int nsplit, const double* __restrict__ part, long long ldp,
+   double* __restrict__ out, long long ldo)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if ( i >= R )
+      return;
+   for (int v = 0; v < nv; ++v)
+   {
+      double s = 0.0;
+      for (int k = 0; k < nsplit; ++k)
+         s += part[((long long) k * nv + v) * ldp + i];
+      out[(long long) v * ldo + i] = s;
+   }
+}
+
+template<int NV>
+static int gemv_n_launch(hipStream_t s, int R, long long E, const double* A, long long lda, const double* const* V,
+   double* out, long long ldo, double* ws, long long wsdoubles)
+{
+   gemvn_vecs vv;
+   bool vec = ((lda & 1) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+   for (int v = 0; v < 4; ++v)
+   {
+      vv.v[v] = v < NV ? V[v] : V[0];
+      if ( v < NV && (reinterpret_cast<uintptr_t>(V[v]) & 15) != 0 )
+         vec = false;
+   }
+   /* enough workgroups to cover the chip: split long rows when there are few of them */
+   int nsplit = 1;
+   if ( R < 512 && E >= 16384 )
+   {
+      nsplit = (int) ((1024 + R - 1) / R);
+      const long long maxs = E / 8192;
+      if ( nsplit > maxs ) nsplit = (int) maxs;
+      if ( nsplit < 1 ) nsplit = 1;
+      if ( (long long) nsplit * NV * R > wsdoubles ) nsplit = 1;
+   }
+   long long chunk = (E + nsplit - 1) / nsplit;
+   chunk = (chunk + 1) & ~1LL;
+   double* dst = nsplit > 1 ? ws : out;
+   const long long ldd = nsplit > 1 ? R : ldo;
+   dim3 grid(R, nsplit);
+   if ( vec )
+      hipLaunchKernelGGL((k_gemv_n<NV, true>), grid, dim3(256), 0, s, R, E, A, lda, vv, dst, ldd, nsplit, chunk);
+   else
+      hipLaunchKernelGGL((k_gemv_n<NV, false>), grid, dim3(256), 0, s, R, E, A, lda, vv, dst, ldd, nsplit, chunk);
+   HS_LAUNCH_CHECK();
+   if ( nsplit > 1 )
+   {
+      hipLaunchKernelGGL(k_gemv_n_combine, dim3((R + 255) / 256), dim3(256), 0, s, R, NV, nsplit, ws, (long long) R, out, ldo);
+      HS_LAUNCH_CHECK();
+   }
+   return HS_OK;
+}
+
+int hs_gemv_n(hipStream_t s, int R, long long E, const double* A, long long lda, int nv, const double* const* V,
+   double* out, long long ldo, double* ws, long long wsdoubles)
+{
+   if ( R <= 0 )
+      return HS_OK;
+   if ( nv < 1 || nv > 4 )
+      return HS_ERR_ARG;
+   if ( E <= 0 )
+   {
+      for (int v = 0; v < nv; ++v)
+         HS_CALL( hs_fill(s, out + (long long) v * ldo, R, 0.0) );
+      return HS_OK;
+   }
+   switch ( nv )
+   {
+   case 1: return gemv_n_launch<1>(s, R, E, A, lda, V, out, ldo, ws, wsdoubles);
+   case 2: return gemv_n_launch<2>(s, R, E, A, lda, V, out, ldo, ws, wsdoubles);
+   case 3: return gemv_n_launch<3>(s, R, E, A, lda, V, out, ldo, ws, wsdoubles);
+   default: return gemv_n_launch<4>(s, R, E, A, lda, V, out, ldo, ws, wsdoubles);
+   }
+}
+
+/* ---------------------------------------------------------------------------------------------------------------- */
+/* A^T(y): column-wise linear combination, one pass over A                                                            */
+/* ---------------------------------------------------------------------------------------------------------------- */
+
+template<bool VEC>
+__global__ void __launch_bounds__(256) k_gemv_t(int R, long long E, const double* __restrict__ A, long long lda,
+   const double* __restrict__ coef, double sa, const double* __restrict__ add, double* __restrict__ out)
+{
+   if ( VEC )
+   {
+      const long long e = 2 * ((long long) blockIdx.x * blockDim.x + threadIdx.x);
+      if ( e >= E )
+         return;
+      if ( e + 1 < E )
+      {
+         double s0 = 0.0, s1 = 0.0;
+         const double* a = A + e;
+         int i = 0;
+         for (; i + 4 <= R; i += 4)
+         {
+            const dbl2 x0 = *reinterpret_cast<const dbl2*>(a + (long long) (i + 0) * lda);
+            const dbl2 x1 = *reinterpret_cast<const dbl2*>(a + (long long) (i + 1) * lda);
+            const dbl2 x2 = *reinterpret_cast<const dbl2*>(a + (long long) (i + 2) * lda);
+            const dbl2 x3 = *reinterpret_cast<const dbl2*>(a + (long long) (i + 3) * lda);
+            const double c0 = coef[i], c1 = coef[i + 1], c2 = coef[i + 2], c3 = coef[i + 3];
+            s0 += c0 * x0.x; s1 += c0 * x0.y;
+            s0 += c1 * x1.x; s1 += c1 * x1.y;
+            s0 += c2 * x2.x; s1 += c2 * x2.y;
+            s0 += c3 * x3.x; s1 += c3 * x3.y;
+         }
+         for (; i < R; ++i)
+         {
+            const dbl2 x0 = *reinterpret_cast<const dbl2*>(a + (long long) i * lda);
+            const double c0 = coef[i];
+            s0 += c0 * x0.x; s1 += c0 * x0.y;
+         }
+         if ( add != NULL )
+         {
+            s0 += sa * add[e];
+            s1 += sa * add[e + 1];
+         }
+         out[e] = s0;
+         out[e + 1] = s1;
+      }
+      else
+      {
+         double s0 = 0.0;
+         for (int i = 0; i < R; ++i)
+            s0 += coef[i] * A[(long long) i * lda + e];
+         if ( add != NULL )
+            s0 += sa * add[e];
+         out[e] = s0;
+      }
+   }
+   else
+   {
+      const long long e = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+      if ( e >= E )
+         return;
+      double s0 = 0.0;
+      for (int i = 0; i < R; ++i)
+         s0 += coef[i] * A[(long long) i * lda + e];
+      if ( add != NULL )
+         s0 += sa * add[e];
+      out[e] = s0;
+   }
+}
+
+int hs_gemv_t(hipStream_t s, int R, long long E, const double* A, long long lda, const double* coef, double sa,
+   const double* add, double* out)
+{
+   if ( E <= 0 )
+      return HS_OK;
+   const bool vec = ((lda & 1) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && R > 0;
+   if ( vec )
+   {
+      const long long nthreads = (E + 1) / 2;
+      hipLaunchKernelGGL((k_gemv_t<true>), dim3((unsigned) ((nthreads + 255) / 256)), dim3(256), 0, s, R, E, A, lda, coef, sa, add, out);
+   }
+   else
+      hipLaunchKernelGGL((k_gemv_t<false>), dim3((unsigned) ((E + 255) / 256)), dim3(256), 0, s, R, E, A, lda, coef, sa, add, out);
+   HS_LAUNCH_CHECK();
+   return HS_OK;
+}

@@ -1,0 +1,220 @@
+/* units.hip - host-buffer entry points around single device kernels.  They serve two callers: lapack_interface_hip.c (the
+ * SCIPlapack* surface of src/sdpi/lapack_interface.h:50-127 takes host arrays) and the per-kernel parity tests in tests/.
+ * Each call: H2D, kernel(s) on the default stream, D2H.  Nothing here has a CPU code path. */
+#include "hs_kernels.h"
+#include "../../include/hipsdp.h"
+#include <vector>
+#include <cstring>
+#include <cstdlib>
+
+namespace {
+
+struct DevBuf
+{
+   double* p;
+   DevBuf() : p(NULL) {}
+   ~DevBuf() { if ( p ) (void) hipFree(p); }
+   int alloc(long long n) { if ( n <= 0 ) n = 1; hipError_t e = hipMalloc((void**) &p, (size_t) n * sizeof(double)); if ( e != hipSuccess ) { hs_record_hip_error(e, "hipMalloc", __FILE__, __LINE__); return e == hipErrorOutOfMemory ? HS_ERR_NOMEM : HS_ERR_HIP; } return HS_OK; }
+   int up(const double* h, long long n) { if ( n <= 0 ) return HS_OK; hipError_t e = hipMemcpy(p, h, (size_t) n * sizeof(double), hipMemcpyHostToDevice); if ( e != hipSuccess ) { hs_record_hip_error(e, "H2D", __FILE__, __LINE__); return HS_ERR_HIP; } return HS_OK; }
+   int down(double* h, long long n) { if ( n <= 0 ) return HS_OK; hipError_t e = hipMemcpy(h, p, (size_t) n * sizeof(double), hipMemcpyDeviceToHost); if ( e != hipSuccess ) { hs_record_hip_error(e, "D2H", __FILE__, __LINE__); return HS_ERR_HIP; } return HS_OK; }
+};
+
+int pick_device(int device)
+{
+   int nd = 0;
+   if ( hipGetDeviceCount(&nd) != hipSuccess || nd <= 0 )
+      return HIPSDP_ERR_NODEVICE;
+   if ( device < 0 || device >= nd )
+      return HIPSDP_ERR_ARG;
+   HS_HIP( hipSetDevice(device) );
+   return HS_OK;
+}
+
+long long span(int rows, int cols, long long ld) { return rows <= 0 ? 0 : (long long) (rows - 1) * ld + cols; }
+
+}
+
+extern "C" int hipsdp_dgemm(int device, int layA, int layB, int M, int N, int K, double alpha, const double* A, long long lda,
+   const double* B, long long ldb, double beta, double* C, long long ldc, int lower_only, int splitk)
+{
+   HS_CALL( pick_device(device) );
+   const long long na = layA == HS_KC ? span(M, K, lda) : span(K, M, lda);
+   const long long nb = layB == HS_KC ? span(N, K, ldb) : span(K, N, ldb);
+   const long long nc = span(M, N, ldc);
+   DevBuf dA, dB, dC, dW;
+   HS_CALL( dA.alloc(na) ); HS_CALL( dB.alloc(nb) ); HS_CALL( dC.alloc(nc) );
+   HS_CALL( dA.up(A, na) ); HS_CALL( dB.up(B, nb) ); HS_CALL( dC.up(C, nc) );
+   if ( splitk <= 0 )
+      splitk = hs_dgemm_pick_splitk(M, N, K, lower_only);
+   if ( splitk > 1 )
+      HS_CALL( dW.alloc((long long) splitk * M * N) );
+   hs_gemm_args g = {M, N, K, layA, layB, dA.p, lda, 0, dB.p, ldb, 0, dC.p, ldc, 0, alpha, beta, 1, lower_only ? HS_GEMM_LOWER : 0, splitk, dW.p};
+   HS_CALL( hs_dgemm(0, &g) );
+   HS_HIP( hipDeviceSynchronize() );
+   HS_CALL( dC.down(C, nc) );
+   return HIPSDP_OK;
+}
+
+extern "C" int hipsdp_schur_dense(int device, int m1, int n, const double* A, const double* X, const double* Zinv, double* Mx,
+   double ws_gbytes)
+{
+   HS_CALL( pick_device(device) );
+   const long long n2 = (long long) n * n;
+   DevBuf dA, dX, dZ, dM, dT, dU, dK;
+   HS_CALL( dA.alloc(m1 * n2) ); HS_CALL( dX.alloc(n2) ); HS_CALL( dZ.alloc(n2) ); HS_CALL( dM.alloc((long long) m1 * m1) );
+   HS_CALL( dA.up(A, m1 * n2) ); HS_CALL( dX.up(X, n2) ); HS_CALL( dZ.up(Zinv, n2) );
+   long long cols = m1;
+   if ( ws_gbytes > 0.0 )
+   {
+      cols = (long long) (ws_gbytes * 1e9 / (16.0 * (double) n2));
+      if ( cols < 1 ) cols = 1;
+      if ( cols > m1 ) cols = m1;
+   }
+   HS_CALL( dT.alloc(cols * n2) ); HS_CALL( dU.alloc(cols * n2) );
+   int skmax = hs_dgemm_pick_splitk(m1, (int) cols, (int) n2, 1);
+   HS_CALL( dK.alloc((long long) skmax * m1 * cols) );
+   HS_CALL( hs_fill(0, dM.p, (long long) m1 * m1, 0.0) );
+   for (int j0 = 0; j0 < m1; j0 += (int) cols)
+   {
+      const int cj = (m1 - j0) < cols ? (m1 - j0) : (int) cols;
+      hs_gemm_args g1 = {cj * n, n, n, HS_KC, HS_MC, dA.p + (long long) j0 * n2, n, 0, dZ.p, n, 0, dT.p, n, 0, 1.0, 0.0, 1, 0, 1, NULL};
+      HS_CALL( hs_dgemm(0, &g1) );
+      hs_gemm_args g2 = {n, n, n, HS_KC, HS_MC, dX.p, n, 0, dT.p, n, n2, dU.p, n, n2, 1.0, 0.0, cj, 0, 1, NULL};
+      HS_CALL( hs_dgemm(0, &g2) );
+      const int rows = m1 - j0;
+      int sk = hs_dgemm_pick_splitk(rows, cj, (int) n2, 1);
+      if ( sk > skmax ) sk = skmax;
+      hs_gemm_args g3 = {rows, cj, (int) n2, HS_KC, HS_KC, dA.p + (long long) j0 * n2, n2, 0, dU.p, n2, 0, dM.p + (long long) j0 * m1 + j0, m1, 0,
+         1.0, 1.0, 1, HS_GEMM_LOWER, sk, dK.p};
+      HS_CALL( hs_dgemm(0, &g3) );
+   }
+   HS_CALL( hs_mirror_lower(0, dM.p, m1, m1) );
+   HS_HIP( hipDeviceSynchronize() );
+   HS_CALL( dM.down(Mx, (long long) m1 * m1) );
+   return HIPSDP_OK;
+}
+
+extern "C" int hipsdp_potrf(int device, int n, double* A, int* fail)
+{
+   HS_CALL( pick_device(device) );
+   const long long n2 = (long long) n * n;
+   DevBuf dA, dD;
+   int* dflag = NULL;
+   HS_CALL( dA.alloc(n2) ); HS_CALL( dD.alloc((long long) ((n + 63) / 64) * 4096) );
+   HS_HIP( hipMalloc((void**) &dflag, sizeof(int)) );
+   HS_HIP( hipMemset(dflag, 0, sizeof(int)) );
+   HS_CALL( dA.up(A, n2) );
+   int rc = hs_potrf(0, n, dA.p, dD.p, dflag, NULL);
+   if ( rc == HS_OK && hipDeviceSynchronize() != hipSuccess ) rc = HS_ERR_HIP;
+   int hflag = 0;
+   if ( rc == HS_OK && hipMemcpy(&hflag, dflag, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ) rc = HS_ERR_HIP;
+   (void) hipFree(dflag);
+   HS_CALL( rc );
+   HS_CALL( dA.down(A, n2) );
+   if ( fail != NULL ) *fail = hflag;
+   return HIPSDP_OK;
+}
+
+extern "C" int hipsdp_potrs(int device, int n, const double* A, int nrhs, double* rhs)
+{
+   HS_CALL( pick_device(device) );
+   if ( nrhs < 1 || nrhs > 4 ) return HIPSDP_ERR_ARG;
+   const long long n2 = (long long) n * n;
+   DevBuf dA, dD, dR;
+   int* dflag = NULL;
+   HS_CALL( dA.alloc(n2) ); HS_CALL( dD.alloc((long long) ((n + 63) / 64) * 4096) ); HS_CALL( dR.alloc((long long) nrhs * n) );
+   HS_HIP( hipMalloc((void**) &dflag, sizeof(int)) );
+   HS_HIP( hipMemset(dflag, 0, sizeof(int)) );
+   HS_CALL( dA.up(A, n2) ); HS_CALL( dR.up(rhs, (long long) nrhs * n) );
+   int rc = hs_potrf(0, n, dA.p, dD.p, dflag, NULL);
+   if ( rc == HS_OK ) rc = hs_trsv(0, n, dA.p, dD.p, nrhs, dR.p, n, 3);
+   if ( rc == HS_OK && hipDeviceSynchronize() != hipSuccess ) rc = HS_ERR_HIP;
+   int hflag = 0;
+   if ( rc == HS_OK && hipMemcpy(&hflag, dflag, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ) rc = HS_ERR_HIP;
+   (void) hipFree(dflag);
+   HS_CALL( rc );
+   HS_CALL( dR.down(rhs, (long long) nrhs * n) );
+   return hflag == 0 ? HIPSDP_OK : HIPSDP_ERR_NUMERIC;
+}
+
+extern "C" int hipsdp_trtri(int device, int n, const double* A, double* Linv)
+{
+   HS_CALL( pick_device(device) );
+   const long long n2 = (long long) n * n;
+   DevBuf dA, dD, dL, dT;
+   int* dflag = NULL;
+   HS_CALL( dA.alloc(n2) ); HS_CALL( dD.alloc((long long) ((n + 63) / 64) * 4096) ); HS_CALL( dL.alloc(n2) ); HS_CALL( dT.alloc(n2) );
+   HS_HIP( hipMalloc((void**) &dflag, sizeof(int)) );
+   HS_HIP( hipMemset(dflag, 0, sizeof(int)) );
+   HS_CALL( dA.up(A, n2) );
+   int rc = hs_potrf(0, n, dA.p, dD.p, dflag, NULL);
+   if ( rc == HS_OK ) rc = hs_trtri(0, n, dA.p, dD.p, dL.p, dT.p);
+   if ( rc == HS_OK && hipDeviceSynchronize() != hipSuccess ) rc = HS_ERR_HIP;
+   int hflag = 0;
+   if ( rc == HS_OK && hipMemcpy(&hflag, dflag, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ) rc = HS_ERR_HIP;
+   (void) hipFree(dflag);
+   HS_CALL( rc );
+   HS_CALL( dL.down(Linv, n2) );
+   return hflag == 0 ? HIPSDP_OK : HIPSDP_ERR_NUMERIC;
+}
+
+extern "C" int hipsdp_lambda_min(int device, int n, const double* W, int steps, double* theta, double* resid)
+{
+   HS_CALL( pick_device(device) );
+   if ( n <= 0 ) return HIPSDP_ERR_ARG;
+   if ( steps <= 0 ) steps = n < 250 ? n : 250;
+   if ( steps > 250 ) steps = 250;
+   const long long n2 = (long long) n * n;
+   DevBuf dW, dR, dS;
+   HS_CALL( dW.alloc(n2) ); HS_CALL( dR.alloc(8) ); HS_CALL( dS.alloc(hs_lanczos_ws(n, steps)) );
+   HS_CALL( dW.up(W, n2) );
+   HS_CALL( hs_lanczos_lmin(0, n, dW.p, steps, dR.p, dS.p) );
+   HS_HIP( hipDeviceSynchronize() );
+   double h[3];
+   HS_CALL( dR.down(h, 3) );
+   *theta = h[0];
+   if ( resid != NULL ) *resid = h[1];
+   return HIPSDP_OK;
+}
+
+extern "C" int hipsdp_syev(int device, int n, const double* A, double* lam, double* V)
+{
+   HS_CALL( pick_device(device) );
+   if ( n <= 0 ) return HIPSDP_ERR_ARG;
+   const long long n2 = (long long) n * n;
+   DevBuf dA, dL, dV, dS;
+   HS_CALL( dA.alloc(n2) ); HS_CALL( dL.alloc(n) ); HS_CALL( dV.alloc(n2) ); HS_CALL( dS.alloc(hs_syev_ws(n)) );
+   HS_CALL( dA.up(A, n2) );
+   HS_CALL( hs_syev_jacobi(0, n, dA.p, dL.p, dV.p, NULL, dS.p) );
+   HS_HIP( hipDeviceSynchronize() );
+   HS_CALL( dL.down(lam, n) );
+   if ( V != NULL ) HS_CALL( dV.down(V, n2) );
+   return HIPSDP_OK;
+}
+
+extern "C" int hipsdp_gemv_n(int device, int R, long long E, const double* A, int nv, const double* V, double* out)
+{
+   HS_CALL( pick_device(device) );
+   if ( nv < 1 || nv > 4 ) return HIPSDP_ERR_ARG;
+   DevBuf dA, dV, dO, dS;
+   HS_CALL( dA.alloc(R * E) ); HS_CALL( dV.alloc(nv * E) ); HS_CALL( dO.alloc((long long) nv * R) ); HS_CALL( dS.alloc(65536) );
+   HS_CALL( dA.up(A, R * E) ); HS_CALL( dV.up(V, nv * E) );
+   const double* vp[4];
+   for (int v = 0; v < 4; ++v) vp[v] = dV.p + (long long) (v < nv ? v : 0) * E;
+   HS_CALL( hs_gemv_n(0, R, E, dA.p, E, nv, vp, dO.p, R, dS.p, 65536) );
+   HS_HIP( hipDeviceSynchronize() );
+   HS_CALL( dO.down(out, (long long) nv * R) );
+   return HIPSDP_OK;
+}
+
+extern "C" int hipsdp_gemv_t(int device, int R, long long E, const double* A, const double* coef, double* out)
+{
+   HS_CALL( pick_device(device) );
+   DevBuf dA, dC, dO;
+   HS_CALL( dA.alloc(R * E) ); HS_CALL( dC.alloc(R) ); HS_CALL( dO.alloc(E) );
+   HS_CALL( dA.up(A, R * E) ); HS_CALL( dC.up(coef, R) );
+   HS_CALL( hs_gemv_t(0, R, E, dA.p, E, dC.p, 0.0, NULL, dO.p) );
+   HS_HIP( hipDeviceSynchronize() );
+   HS_CALL( dO.down(out, E) );
+   return HIPSDP_OK;
+}
