@@ -84,6 +84,28 @@ def schur_block(A, X, Zinv):
     return 0.5 * (Mx + Mx.T)
 
 
+def chol_psd(M, regtol=1e-13):
+    """Cholesky of a positive SEMI-definite matrix (the Schur complement has dependent columns when the constraint
+    matrices are linearly dependent): a pivot below regtol * M_kk is replaced by regtol * M_kk (a small positive pivot keeps
+    the direction alive, so that an unbounded ray along it can still be found).  Same rule as k_potrf_diag (scip-sdp_amd/csrc/chol.hip) in semidefinite mode."""
+    try:
+        L = np.linalg.cholesky(M)
+        if np.all(np.diag(L) ** 2 > regtol * np.diag(M)):
+            return L
+    except np.linalg.LinAlgError:
+        pass
+    n = M.shape[0]
+    L = np.tril(M).astype(np.float64).copy()
+    for k in range(n):
+        d = L[k, k]
+        if not (d > regtol * M[k, k]) or not (d > 1e-300):
+            d = regtol * M[k, k] if M[k, k] > 1e-280 else 1.0
+        L[k, k] = np.sqrt(d)
+        L[k + 1:, k] /= L[k, k]
+        L[k + 1:, k + 1:] -= np.tril(np.outer(L[k + 1:, k], L[k + 1:, k]))
+    return L
+
+
 def max_step_psd(L, dX):
     """largest alpha with  L L^T + alpha dX  psd  (inf if dX psd):  -1 / lambda_min(L^-1 dX L^-T)."""
     W = sla.solve_triangular(L, dX, lower=True)
@@ -206,15 +228,7 @@ def hsd_solve(prob, par=None, start=None):
             Mx += Dext.T @ ((x / z)[:, None] * Dext)
         g = Mx[0, 1:].copy()
         M = Mx[1:, 1:]
-        try:
-            Lm = np.linalg.cholesky(M) if m else np.zeros((0, 0))
-        except np.linalg.LinAlgError:
-            # tiny diagonal shift, one retry
-            try:
-                Lm = np.linalg.cholesky(M + (1e-13 * np.trace(M) / max(m, 1) + 1e-300) * np.eye(m))
-            except np.linalg.LinAlgError:
-                res.status = STATUS_NUMERIC
-                break
+        Lm = chol_psd(M) if m else np.zeros((0, 0))
 
         def msolve(r):
             if m == 0:

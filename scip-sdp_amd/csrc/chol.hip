@@ -16,7 +16,7 @@
 /* Factor the nb x nb diagonal block at A (leading dimension lda), nb <= 64: A_blk = L L^T.  Writes L into the lower
  * triangle of the block and inv(L) (64 x 64, identity-padded) into dinv.  flag: first failing global pivot index + 1. */
 __global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ A, long long lda, int nb, int j0,
-   double* __restrict__ dinv, int* __restrict__ flag)
+   double* __restrict__ dinv, int* __restrict__ flag, const double* __restrict__ diag0, double regtol)
 {
    __shared__ double a[NB][NB + 1];
    __shared__ double li[NB][NB + 1];
@@ -39,12 +39,19 @@ __global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ A, long
       if ( tid == 0 )
       {
          double d = a[k][k];
-         if ( !(d > 0.0) )
+         if ( diag0 != NULL )
+         {
+            /* semidefinite mode (Schur complement with dependent columns): a pivot that cancelled to rounding level is
+             * replaced by a small positive one, which keeps the direction alive so that a ray along it can be found */
+            const double d0 = diag0[j0 + k];
+            if ( !(d > regtol * d0) || !(d > 1e-300) )
+               d = (d0 > 1e-280) ? regtol * d0 : 1.0;
+         }
+         else if ( !(d > 0.0) )
          {
             if ( bad == 0 )
                bad = j0 + k + 1;
             d = 1.0;                 /* keep going with a harmless pivot; the caller reads the flag */
-            a[k][k] = 1.0;
          }
          a[k][k] = sqrt(d);
       }
@@ -90,9 +97,8 @@ __global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ A, long
       atomicCAS(flag, 0, bad);
 }
 
-int hs_potrf(hipStream_t s, int n, double* A, double* dinv, int* flag, double* ws_gemm)
+int hs_potrf(hipStream_t s, int n, double* A, double* dinv, int* flag, const double* diag0)
 {
-   (void) ws_gemm;
    if ( n <= 0 )
       return HS_OK;
    const long long lda = n;
@@ -103,7 +109,7 @@ int hs_potrf(hipStream_t s, int n, double* A, double* dinv, int* flag, double* w
       const int nb = (n - j0) < NB ? (n - j0) : NB;
       double* Ajj = A + (long long) j0 * lda + j0;
       double* dj = dinv + (long long) b * NB * NB;
-      hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, s, Ajj, lda, nb, j0, dj, flag);
+      hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, s, Ajj, lda, nb, j0, dj, flag, diag0, 1e-13);
       HS_LAUNCH_CHECK();
       const int j1 = j0 + nb;
       const int rem = n - j1;

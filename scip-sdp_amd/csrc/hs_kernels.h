@@ -42,8 +42,10 @@ int hs_lp_s0(hipStream_t s, int q, const double* x, const double* z, const doubl
 /* ---- chol.hip ------------------------------------------------------------------------------------------------- */
 /* In-place blocked Cholesky of the lower triangle of the row-major n x n matrix A (lda = n): A = L L^T, L stored in the
  * lower triangle (upper triangle is left untouched).  dinv receives the inverses of the 64 x 64 diagonal blocks of L
- * (ceil(n/64) * 64 * 64 doubles).  *flag (device int) is set to 1 + index of the first non-positive pivot. */
-int hs_potrf(hipStream_t s, int n, double* A, double* dinv, int* flag, double* ws_gemm);
+ * (ceil(n/64) * 64 * 64 doubles).  *flag (device int) is set to 1 + index of the first non-positive pivot.
+ * diag0 == NULL: strict (definite) mode.  diag0 != NULL (the n original diagonal entries): semidefinite mode, pivots
+ * below 1e-13 * diag0[k] are replaced by 1e-13 * diag0[k] and no failure is flagged. */
+int hs_potrf(hipStream_t s, int n, double* A, double* dinv, int* flag, const double* diag0);
 /* Linv = L^-1 (lower triangular, full n x n storage, upper triangle zero); needs dinv from hs_potrf */
 int hs_trtri(hipStream_t s, int n, const double* L, const double* dinv, double* Linv, double* tmp);
 /* solves L y = r (nrhs <= 4 right-hand sides, rhs[k * ldr + i]) then optionally L^T x = y, in place.  mode 1: forward only,

@@ -912,7 +912,10 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       {
          HS_HIP( hipMemcpy2DAsync(s->Lm, (size_t) m * sizeof(double), s->Mx + m1 + 1, (size_t) m1 * sizeof(double),
                (size_t) m * sizeof(double), (size_t) m, hipMemcpyDeviceToDevice, st) );
-         HS_CALL( hs_potrf(st, m, s->Lm, s->dinvm, s->flags + 2, NULL) );
+         /* original diagonal of M for the semidefinite pivot rule */
+         HS_HIP( hipMemcpy2DAsync(s->dya, sizeof(double), s->Mx + m1 + 1, (size_t) (m1 + 1) * sizeof(double), sizeof(double), (size_t) m,
+               hipMemcpyDeviceToDevice, st) );
+         HS_CALL( hs_potrf(st, m, s->Lm, s->dinvm, s->flags + 2, s->dya) );
          hipLaunchKernelGGL(k_rhs2, g1d(m), dim3(256), 0, st, m, s->Mx, s->b, s->rhs2);
          HS_LAUNCH_CHECK();
          HS_CALL( hs_trsv(st, m, s->Lm, s->dinvm, 2, s->rhs2, m, 3) );
