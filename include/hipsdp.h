@@ -122,9 +122,14 @@ int  hipsdp_comm_create(const void* unique_id_128bytes, int rank, int nranks, vo
 int  hipsdp_comm_unique_id(void* unique_id_128bytes);
 void hipsdp_comm_destroy(void* comm);
 
-/* synthetic instance of BASELINE.md section 3 generated on the device (one dense block n, m variables, no LP rows):
- * fills A_1..A_m; the caller supplies A_0 and b (see oracle/instances.py) or uses hipsdp_gen_finish */
-int  hipsdp_gen_planted(hipsdp_solver* solver, int n, int m, long long seed, double* b_out, double* ystar_out);
+/* Synthetic instance of BASELINE.md section 3 generated in HBM.  The solver must have the shape (m, one block of size n,
+ * q = 0).  Fills A_1..A_m from the counter stream of oracle/instances.py (seed + i), then plants the optimum the caller
+ * supplies: A_0 = sum_i ystar_i A_i - Zstar,  b_i = <A_i, Xstar> (both computed on the device); b is set as objective and
+ * returned in b_out[m].  Xstar, Zstar: n x n host arrays; ystar: m host values. */
+int  hipsdp_gen_planted(hipsdp_solver* solver, int n, int m, long long seed, const double* Xstar, const double* Zstar,
+   const double* ystar, double* b_out);
+/* copies block k's dense storage A[(m+1) * n * n] back to the host (used to hand identical bits to the CPU baseline) */
+int  hipsdp_get_block_dense(hipsdp_solver* solver, int block, double* A);
 
 /* ---- host-buffer dense kernels (unit-level entry points; used by lapack_interface_hip.c and by the parity tests) ---- */
 /* C[M x N] = alpha * op(A) * op(B) + beta * C, row-major; layA/layB: 0 = K contiguous, 1 = M (resp. N) contiguous */

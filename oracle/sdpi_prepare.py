@@ -1,0 +1,261 @@
+"""sdpi_prepare.py - TEST INFRASTRUCTURE.  Restatement of the part of the reference's solver-independent SDPI that produces
+the ARGUMENTS of SCIPsdpiSolverLoadAndSolve (src/sdpi/sdpi.c), so that tests can hand the backend exactly the argument
+patterns real branch-and-bound nodes produce:
+
+   sdpi.c:3190-3225   bound copy, repeated LP preparation until no new fixings
+   sdpi.c:1131-1371   prepareLPData: drop nonzeros of fixed variables (shift lhs/rhs), rows with one active nonzero become
+                      variable bounds and are removed, empty rows are checked and removed
+   sdpi.c:614-682     compConstMatAfterFixings:  A_0' = A_0 - sum_{fixed j} A_j y_j
+   sdpi.c:691-809     findEmptyRowColsSDP: indchanges / nremovedinds / blockindchanges
+   sdpi.c:4473-4620   mapping bound multipliers back to the LP rows they came from (lhs/rhs multipliers)
+
+Integrality-based coefficient tightening (sdpi.c:812-1129), the one-variable shortcut (sdpi.c:3301-3381), the penalty loop
+and the Slater check are not restated here.
+"""
+import numpy as np
+
+INF = 1e20
+EPS = 1e-9
+
+
+class SdpiProblem:
+    """Mirror of the data SCIPsdpiLoadSDP stores (sdpi.c:2329-2520).
+
+    blocks: list of dict(n=int, vars={var: [(row, col, val)]} with row >= col, const=[(row, col, val)])
+    lp: list of (lhs, rhs, {var: coef})"""
+
+    def __init__(self, obj, lb, ub, blocks=(), lp=()):
+        self.obj = np.asarray(obj, dtype=np.float64)
+        self.nvars = len(self.obj)
+        self.lb = np.asarray(lb, dtype=np.float64).copy()
+        self.ub = np.asarray(ub, dtype=np.float64).copy()
+        self.blocks = [dict(n=b['n'], vars={int(v): list(e) for v, e in b.get('vars', {}).items()},
+                            const=list(b.get('const', []))) for b in blocks]
+        self.lp = [(float(l), float(r), {int(v): float(c) for v, c in row.items()}) for (l, r, row) in lp]
+
+
+class Prepared:
+    pass
+
+
+def prepare(prob, eps=EPS):
+    """returns Prepared with every array SCIPsdpiSolverLoadAndSolve takes, plus status 'ok' | 'infeasible' | 'allfixed'"""
+    P = Prepared()
+    P.prob = prob
+    lb = prob.lb.copy()
+    ub = prob.ub.copy()
+    nlp = len(prob.lp)
+    P.status = 'ok'
+
+    def fixed(v):
+        return ub[v] - lb[v] <= eps
+
+    # ---- LP preparation, repeated while bounds get tightened into new fixings (sdpi.c:3217-3225)
+    lbrowidx = [None] * prob.nvars    # (LP row, side) whose single nonzero produced the current bound (sdpi.c:1270-1354)
+    ubrowidx = [None] * prob.nvars
+    while True:
+        nfix_before = sum(1 for v in range(prob.nvars) if fixed(v))
+        lpindchanges = [0] * nlp
+        lplhs = [0.0] * nlp
+        lprhs = [0.0] * nlp
+        rows = []
+        removed = 0
+        for r, (lhs, rhs, row) in enumerate(prob.lp):
+            act = []
+            for v, c in row.items():
+                if fixed(v):
+                    if lhs > -INF:
+                        lhs -= c * lb[v]
+                    if rhs < INF:
+                        rhs -= c * lb[v]
+                else:
+                    act.append((v, c))
+            if len(act) == 0:
+                if lhs > eps or rhs < -eps:
+                    P.status = 'infeasible'
+                lpindchanges[r] = -1
+                removed += 1
+            elif len(act) == 1:
+                v, c = act[0]
+                if c > 0:
+                    if lhs > -INF and lhs / c > lb[v] + eps:
+                        lb[v] = lhs / c
+                        lbrowidx[v] = (r, 'lhs')
+                    if rhs < INF and rhs / c < ub[v] - eps:
+                        ub[v] = rhs / c
+                        ubrowidx[v] = (r, 'rhs')
+                else:
+                    if lhs > -INF and lhs / c < ub[v] - eps:
+                        ub[v] = lhs / c
+                        ubrowidx[v] = (r, 'lhs')
+                    if rhs < INF and rhs / c > lb[v] + eps:
+                        lb[v] = rhs / c
+                        lbrowidx[v] = (r, 'rhs')
+                if lb[v] > ub[v] + eps:
+                    P.status = 'infeasible'
+                lpindchanges[r] = -1
+                removed += 1
+            else:
+                lpindchanges[r] = removed
+            lplhs[r], lprhs[r] = lhs, rhs
+            rows.append(act)
+        nfix_after = sum(1 for v in range(prob.nvars) if fixed(v))
+        if nfix_after == nfix_before:
+            break
+    P.lb, P.ub = lb, ub
+    P.lbrowidx, P.ubrowidx = lbrowidx, ubrowidx
+    P.nlpcons = nlp
+    P.lpindchanges = np.array(lpindchanges, dtype=np.int32)
+    P.lplhs = np.array(lplhs, dtype=np.float64)
+    P.lprhs = np.array(lprhs, dtype=np.float64)
+    # CSR of the ORIGINAL rows without the nonzeros of fixed variables (what sdpi->sdpilp{beg,ind,val} hold, sdpi.c:1217-1226)
+    beg, ind, val = [], [], []
+    for r, act in enumerate(rows):
+        beg.append(len(ind))
+        for v, c in act:
+            ind.append(v)
+            val.append(c)
+    P.lpbeg = np.array(beg if beg else [0], dtype=np.int32)
+    P.lpind = np.array(ind if ind else [0], dtype=np.int32)
+    P.lpval = np.array(val if val else [0.0], dtype=np.float64)
+    P.lpnnonz = len(ind)
+    if all(fixed(v) for v in range(prob.nvars)) and P.status == 'ok':
+        P.status = 'allfixed'
+
+    # ---- constant matrices after fixings (sdpi.c:614-682)
+    P.sdpconst = []
+    for blk in prob.blocks:
+        acc = {}
+        for (r, c, v) in blk['const']:
+            acc[(r, c)] = acc.get((r, c), 0.0) + v
+        for var, ents in blk['vars'].items():
+            if fixed(var) and abs(lb[var]) > eps:
+                for (r, c, v) in ents:
+                    acc[(r, c)] = acc.get((r, c), 0.0) - v * lb[var]
+        P.sdpconst.append([(r, c, v) for (r, c), v in sorted(acc.items()) if abs(v) > eps])
+
+    # ---- empty rows / columns (sdpi.c:691-809)
+    P.indchanges, P.nremovedinds, P.blockindchanges = [], [], []
+    nremovedblocks = 0
+    for b, blk in enumerate(prob.blocks):
+        n = blk['n']
+        found = [False] * n
+        for var, ents in blk['vars'].items():
+            if not fixed(var):
+                for (r, c, v) in ents:
+                    found[r] = True
+                    found[c] = True
+        for (r, c, v) in P.sdpconst[b]:
+            found[r] = True
+            found[c] = True
+        ic, nrem = [], 0
+        for i in range(n):
+            if not found[i]:
+                ic.append(-1)
+                nrem += 1
+            else:
+                ic.append(nrem)
+        P.indchanges.append(np.array(ic, dtype=np.int32))
+        P.nremovedinds.append(nrem)
+        if nrem == n:
+            P.blockindchanges.append(-1)
+            nremovedblocks += 1
+        else:
+            P.blockindchanges.append(nremovedblocks)
+    P.nremovedblocks = nremovedblocks
+    return P
+
+
+def map_lp_sides(P, lhsvals, rhsvals, lbvals, ubvals):
+    """SCIPsdpiGetPrimalLPSides (sdpi.c:4473-4605): multipliers of bounds that were created from single-nonzero rows are
+    reported as the multiplier of that row's side; kept rows keep the backend's values."""
+    lhs = np.zeros(P.nlpcons)
+    rhs = np.zeros(P.nlpcons)
+    for v in range(P.prob.nvars):
+        for idx, vals in ((P.lbrowidx[v], lbvals), (P.ubrowidx[v], ubvals)):
+            if idx is not None:
+                r, side = idx
+                if side == 'rhs':
+                    rhs[r] = vals[v]
+                else:
+                    lhs[r] = vals[v]
+    for r in range(P.nlpcons):
+        if P.lpindchanges[r] >= 0:
+            lhs[r] = lhsvals[r]
+            rhs[r] = rhsvals[r]
+    return lhs, rhs
+
+
+def to_core(P, penaltyparam=0.0, withobj=True, rbound=True):
+    """The marshalled problem the backend must hand to its engine for these arguments, in the oracle's CoreProblem layout
+    (ipm_ref.CoreProblem): independent restatement of the marshalling in scip-sdp_amd/src/sdpi/sdpisolver_hip.c, used by the
+    CPU tests of the host logic.  Returns (b, blocks, D, c, maps)."""
+    prob = P.prob
+    lb, ub = P.lb, P.ub
+    active = [v for v in range(prob.nvars) if ub[v] - lb[v] > EPS]
+    amap = {v: k for k, v in enumerate(active)}
+    pen = penaltyparam > EPS
+    m = len(active) + (1 if pen else 0)
+    b = np.zeros(m)
+    for k, v in enumerate(active):
+        b[k] = prob.obj[v] if withobj else 0.0
+    if pen:
+        b[m - 1] = penaltyparam
+    blocks = []
+    for bi, blk in enumerate(prob.blocks):
+        if P.blockindchanges[bi] < 0:
+            continue
+        ic = P.indchanges[bi]
+        nc = blk['n'] - P.nremovedinds[bi]
+        A = np.zeros((m + 1, nc, nc))
+        for var, ents in blk['vars'].items():
+            if var in amap:
+                for (r, c, v) in ents:
+                    A[amap[var] + 1, r - ic[r], c - ic[c]] = v
+                    A[amap[var] + 1, c - ic[c], r - ic[r]] = v
+        for (r, c, v) in P.sdpconst[bi]:
+            A[0, r - ic[r], c - ic[c]] = v
+            A[0, c - ic[c], r - ic[r]] = v
+        if pen:
+            A[m] = np.eye(nc)
+        blocks.append(A)
+    Drows, cvals = [], []
+    for r in range(P.nlpcons):
+        if P.lpindchanges[r] < 0:
+            continue
+        nextbeg = P.lpnnonz if r == P.nlpcons - 1 else P.lpbeg[r + 1]
+        coef = np.zeros(m)
+        for t in range(P.lpbeg[r], nextbeg):
+            if P.lpind[t] in amap:
+                coef[amap[P.lpind[t]]] += P.lpval[t]
+        if P.lplhs[r] > -INF:
+            row = coef.copy()
+            if pen:
+                row[m - 1] = 1.0
+            Drows.append(row)
+            cvals.append(P.lplhs[r])
+        if P.lprhs[r] < INF:
+            row = -coef
+            if pen:
+                row[m - 1] = 1.0
+            Drows.append(row)
+            cvals.append(-P.lprhs[r])
+    for k, v in enumerate(active):
+        if lb[v] > -INF:
+            row = np.zeros(m)
+            row[k] = 1.0
+            Drows.append(row)
+            cvals.append(lb[v])
+        if ub[v] < INF:
+            row = np.zeros(m)
+            row[k] = -1.0
+            Drows.append(row)
+            cvals.append(-ub[v])
+    if pen and rbound:
+        row = np.zeros(m)
+        row[m - 1] = 1.0
+        Drows.append(row)
+        cvals.append(0.0)
+    D = np.array(Drows).reshape(-1, m)
+    c = np.array(cvals)
+    return b, blocks, D, c, dict(active=active)

@@ -113,6 +113,19 @@ class Solver:
         _chk(lib().hipsdp_block_device_ptr(self.h, k, C.byref(p)), "hipsdp_block_device_ptr")
         return C.cast(p, C.c_void_p).value
 
+    def gen_planted(self, n, m, seed, Xstar, Zstar, ystar):
+        """device-side synthetic instance (see hipsdp_gen_planted); returns b"""
+        Xstar, Zstar, ystar = _f64(Xstar), _f64(Zstar), _f64(ystar)
+        b = np.zeros(m)
+        _chk(lib().hipsdp_gen_planted(self.h, n, m, C.c_longlong(seed), _dp(Xstar), _dp(Zstar), _dp(ystar), _dp(b)),
+             "hipsdp_gen_planted")
+        return b
+
+    def get_block_dense(self, k):
+        A = np.zeros((self.m + 1, self.ns[k], self.ns[k]))
+        _chk(lib().hipsdp_get_block_dense(self.h, k, _dp(A)), "hipsdp_get_block_dense")
+        return A
+
     def load_core(self, prob):
         """prob: object with m, b, blocks (list of [m+1, n, n]), D [q, m], c [q] (the oracle's CoreProblem layout)"""
         self.set_shape(prob.m, [A.shape[1] for A in prob.blocks], prob.q)

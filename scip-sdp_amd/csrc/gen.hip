@@ -1,0 +1,57 @@
+/* gen.hip - synthetic dense node SDPs of BASELINE.md section 3 generated directly in HBM (2 GB of A at n = 500, m = 1000
+ * would otherwise cross PCIe).  The stream is the stateless counter generator of oracle/instances.py: same seeds, same
+ * index -> same uniform bits; the normals differ from numpy's only by the last ulps of log/cos/sqrt. */
+#include "hs_kernels.h"
+#include "../../include/hipsdp.h"
+#include <math.h>
+
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x)
+{
+   x += 0x9E3779B97F4A7C15ULL;
+   unsigned long long z = x;
+   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+   z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+   return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ double counter_uniform(unsigned long long seed, unsigned long long idx)
+{
+   const unsigned long long h = splitmix64(seed * 0xD1342543DE82EF95ULL + idx);
+   return ((double) (h >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+__device__ __forceinline__ double counter_normal(unsigned long long seed, unsigned long long idx)
+{
+   const double u1 = counter_uniform(seed, 2ULL * idx);
+   const double u2 = counter_uniform(seed, 2ULL * idx + 1ULL);
+   return sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2);
+}
+
+/* A_i = (G_i + G_i^T) / sqrt(2 n), G_i lower triangular with N(0,1) entries drawn at packed index r (r + 1) / 2 + c */
+__global__ void k_gen_dense(int n, int m, unsigned long long seed, double scale, double* __restrict__ A)
+{
+   const long long n2 = (long long) n * n;
+   const long long total = (long long) m * n2;
+   for (long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long) gridDim.x * blockDim.x)
+   {
+      const int i = (int) (t / n2) + 1;
+      const long long e = t - (long long) (i - 1) * n2;
+      const int r0 = (int) (e / n), c0 = (int) (e - (long long) r0 * n);
+      const int r = r0 > c0 ? r0 : c0;
+      const int c = r0 > c0 ? c0 : r0;
+      const unsigned long long idx = (unsigned long long) r * (unsigned long long) (r + 1) / 2ULL + (unsigned long long) c;
+      const double g = counter_normal(seed + (unsigned long long) i, idx);
+      A[(long long) i * n2 + e] = (r == c ? 2.0 : 1.0) * g * scale;
+   }
+}
+
+int hs_gen_dense(hipStream_t s, int n, int m, long long seed, double* A)
+{
+   const long long total = (long long) m * n * n;
+   long long g = (total + 255) / 256;
+   if ( g > 65536 ) g = 65536;
+   hipLaunchKernelGGL(k_gen_dense, dim3((unsigned) g), dim3(256), 0, s, n, m, (unsigned long long) seed, 1.0 / sqrt(2.0 * (double) n), A);
+   if ( hipGetLastError() != hipSuccess )
+      return HS_ERR_HIP;
+   return HS_OK;
+}

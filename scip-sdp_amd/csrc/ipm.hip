@@ -349,6 +349,48 @@ extern "C" int hipsdp_set_lp(hipsdp_solver* s, const double* Dext)
    return HIPSDP_OK;
 }
 
+int hs_gen_dense(hipStream_t s, int n, int m, long long seed, double* A);
+
+extern "C" int hipsdp_gen_planted(hipsdp_solver* s, int n, int m, long long seed, const double* Xstar, const double* Zstar,
+   const double* ystar, double* b_out)
+{
+   if ( s == NULL || !s->shaped || s->blk.size() != 1 || s->blk[0].n != n || s->m != m || s->q != 0 )
+      return HIPSDP_ERR_ARG;
+   HS_HIP( hipSetDevice(s->device) );
+   Block& B = s->blk[0];
+   const long long n2 = (long long) n * n;
+   const int m1 = m + 1;
+   hipStream_t st = s->stream;
+   HS_CALL( hs_gen_dense(st, n, m, seed, B.A) );
+   /* A_0 = sum_i ystar_i A_i - Zstar : coefficient vector [0, ystar] over all m + 1 rows (row 0 is overwritten) */
+   HS_HIP( hipMemcpyAsync(B.Z, Zstar, (size_t) n2 * sizeof(double), hipMemcpyHostToDevice, st) );
+   HS_HIP( hipMemcpyAsync(B.X, Xstar, (size_t) n2 * sizeof(double), hipMemcpyHostToDevice, st) );
+   HS_HIP( hipMemsetAsync(s->yt, 0, sizeof(double), st) );
+   HS_HIP( hipMemcpyAsync(s->yt + 1, ystar, (size_t) m * sizeof(double), hipMemcpyHostToDevice, st) );
+   HS_HIP( hipMemsetAsync(B.A, 0, (size_t) n2 * sizeof(double), st) );
+   HS_CALL( hs_gemv_t(st, m1, n2, B.A, n2, s->yt, -1.0, B.Z, B.T1) );
+   HS_CALL( hs_symmetrize(st, B.T1, n) );
+   HS_CALL( hs_copy(st, B.A, B.T1, n2) );
+   /* b = A(Xstar) */
+   const double* v = B.X;
+   HS_CALL( hs_gemv_n(st, m1, n2, B.A, n2, 1, &v, s->AX, m1, s->gemv_ws, s->gemv_ws_len) );
+   HS_CALL( hs_copy(st, s->b, s->AX + 1, m) );
+   HS_HIP( hipMemcpyAsync(b_out, s->b, (size_t) m * sizeof(double), hipMemcpyDeviceToHost, st) );
+   HS_HIP( hipStreamSynchronize(st) );
+   s->solved = false;
+   return HIPSDP_OK;
+}
+
+extern "C" int hipsdp_get_block_dense(hipsdp_solver* s, int block, double* A)
+{
+   if ( s == NULL || !s->shaped || block < 0 || block >= (int) s->blk.size() )
+      return HIPSDP_ERR_ARG;
+   HS_HIP( hipSetDevice(s->device) );
+   Block& B = s->blk[block];
+   HS_HIP( hipMemcpy(A, B.A, (size_t) (s->m + 1) * B.n * B.n * sizeof(double), hipMemcpyDeviceToHost) );
+   return HIPSDP_OK;
+}
+
 extern "C" int hipsdp_block_device_ptr(hipsdp_solver* s, int block, double** dptr)
 {
    if ( s == NULL || !s->shaped || block < 0 || block >= (int) s->blk.size() )

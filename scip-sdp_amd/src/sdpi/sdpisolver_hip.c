@@ -1,0 +1,1520 @@
+/* sdpisolver_hip.c - SCIP-SDP solver interface backed by the MI355X interior-point engine (libhipsdp, include/hipsdp.h).
+ *
+ * Drop-in for the reference's src/sdpi/sdpisolver_{dsdp.c,sdpa.cpp,mosek.c}: it exports the same 53 SCIPsdpiSolver*
+ * symbols (src/sdpi/sdpisolver.h:79-724), so sdpi.c / relax_sdp.c call it unchanged.  Host code is C99; all arithmetic of
+ * the node solve runs on the GPU behind the hipsdp_* C ABI.  Behavioural reference for the marshalling and the status
+ * machine: src/sdpi/sdpisolver_dsdp.c (fixed-variable elimination :929-960, block compaction :1066-1130, LP row split
+ * :1206-1449, tolerance re-solve loop :1527-1606, penalty post-processing :1655-1734, predicates :1751-2135) and, for
+ * the primal-matrix export, src/sdpi/sdpisolver_sdpa.cpp:2814-3125.
+ *
+ * Formulation handed to the engine (sdpisolver.h:37-42, penalty form :235-250):
+ *    min  b^T y (+ Gamma r)   s.t.  sum_j A_j^k y_j - A_0^k (+ r I) psd,   rows of  D y (+ r) >= d  for every finite LP
+ *    side, one row per finite variable bound, (r >= 0).
+ */
+#include <assert.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef HIPSDP_WITH_SCIP
+#include "sdpi/sdpisolver.h"
+#include "blockmemshell/memory.h"
+#include "scip/pub_message.h"
+#define HSALLOC(sol, ptr, n)          BMSallocBlockMemoryArray((sol)->blkmem, (ptr), (n))
+#define HSFREE(sol, ptr, n)           BMSfreeBlockMemoryArrayNull((sol)->blkmem, (ptr), (n))
+#else
+#include "sdpisolver_hip.h"
+#define HSALLOC(sol, ptr, n)          (*(void**) (ptr) = hipsdp_compat_malloc(sizeof(**(ptr)) * (size_t) ((n) > 0 ? (n) : 1)))
+#define HSFREE(sol, ptr, n)           do { if ( *(ptr) != NULL ) { hipsdp_compat_free(*(ptr), sizeof(**(ptr)) * (size_t) ((n) > 0 ? (n) : 1)); *(ptr) = NULL; } } while (0)
+#define SCIPerrorMessage(...)         do { fprintf(stderr, "[%s:%d] ERROR: ", __FILE__, __LINE__); fprintf(stderr, __VA_ARGS__); } while (0)
+#define SCIPmessagePrintInfo(h, ...)  do { (void) (h); printf(__VA_ARGS__); } while (0)
+#endif
+
+#include "hipsdp.h"
+
+#define PENALTYBOUNDTOL          1e-3      /* relative distance of Tr(X) to Gamma that counts as "bound reached" */
+#define MIN_PENALTYPARAM         1e5
+#define MAX_PENALTYPARAM         1e12
+#define PENALTYPARAM_FACTOR      1e4
+#define MAX_MAXPENALTYPARAM      1e15
+#define MAXPENALTYPARAM_FACTOR   1e6
+#define TOLCHANGE                0.1       /* tightening factor of the re-solve loop */
+#define MINSOLVERTOL             1e-10     /* the engine is not asked for more than this */
+#define HS_INFINITY              1e20
+
+#define ALLOC_OR_FAIL(sol, ptr, n)  do { if ( HSALLOC(sol, ptr, n) == NULL ) return SCIP_NOMEMORY; } while (0)
+#define ENGINE_CALL(x)  do { int rc_ = (x); if ( rc_ != HIPSDP_OK ) { SCIPerrorMessage("hipsdp error %d (%s) in %s\n", rc_, hipsdp_last_error(), #x); return rc_ == HIPSDP_ERR_NOMEM ? SCIP_NOMEMORY : SCIP_LPERROR; } } while (0)
+#define CHECK_IF_SOLVED(sol)  do { if ( ! (sol)->solved ) { SCIPerrorMessage("Tried to access solution information for SDP %d ahead of solving!\n", (sol)->sdpcounter); return SCIP_LPERROR; } } while (0)
+#define CHECK_IF_SOLVED_BOOL(sol)  do { if ( ! (sol)->solved ) return FALSE; } while (0)
+
+struct SCIP_SDPiSolver
+{
+   SCIP_MESSAGEHDLR*     messagehdlr;
+   BMS_BLKMEM*           blkmem;
+   BMS_BUFMEM*           bufmem;
+   hipsdp_solver*        engine;             /* created lazily: Create() must work without a GPU (plumbing tests) */
+   int                   device;
+
+   /* variable maps (sdpisolver_dsdp.c:168-223 keeps the same ones) */
+   int                   nvars;
+   int                   nactivevars;
+   int                   nalloc;             /* allocated length of the per-variable arrays */
+   int*                  inputtoactive;      /* nvars: 1-based active index, or -(k) for the k-th fixed variable */
+   int*                  activetoinput;      /* nactivevars */
+   SCIP_Real*            fixedvarsval;       /* per input variable: its value if fixed */
+   SCIP_Real*            objcoefs;           /* nactivevars */
+   SCIP_Real             fixedvarsobjcontr;
+   int*                  lbrow;              /* per input variable: engine LP row of its lower bound or -1 */
+   int*                  ubrow;
+
+   /* LP rows */
+   int                   nlpcons;
+   int                   nlpalloc;
+   int*                  lhsrow;             /* per input LP row: engine row of the lhs side or -1 */
+   int*                  rhsrow;
+   int                   nlpineqs;           /* engine rows that come from LP sides (the first ones) */
+   int                   nenginerows;        /* total engine LP rows q */
+
+   /* SDP blocks */
+   int                   nsdpblocks;
+   int                   nblkalloc;
+   int*                  blockmap;           /* input block -> engine block or -1 */
+   int*                  compactsize;        /* per input block: size after removing indices */
+   int*                  origsize;
+   int**                 keptind;            /* per input block: compact index -> original index */
+   int                   nengineblocks;
+
+   /* solution of the last solve, on the host */
+   SCIP_Real*            ysol;               /* engine variables (nactivevars (+1 for r)) */
+   int                   nysol;
+   SCIP_Real*            xlp;                /* engine LP multipliers */
+   int                   nxlp;
+   SCIP_Real**           Xsol;               /* per engine block, dense compact n x n; fetched on demand */
+   int*                  Xsize;
+   int                   nXsol;
+
+   hipsdp_info           info;
+   SCIP_Bool             solved;
+   SCIP_Bool             timelimit;
+   SCIP_Bool             timelimitinitial;
+   SCIP_Bool             penalty;
+   SCIP_Bool             feasorig;
+   SCIP_Bool             rbound;
+   SCIP_Bool             penaltyworbound;
+   int                   rvar;               /* engine index (0-based) of the penalty variable r or -1 */
+   int                   sdpcounter;
+   int                   niterations;
+   int                   nsdpcalls;
+   SCIP_Real             opttime;
+   SCIP_SDPSOLVERSETTING usedsetting;
+
+   SCIP_Real             epsilon;
+   SCIP_Real             gaptol;
+   SCIP_Real             feastol;
+   SCIP_Real             sdpsolverfeastol;
+   SCIP_Real             penaltyparam;
+   SCIP_Real             objlimit;
+   SCIP_Real             preoptimalgap;
+   SCIP_Bool             sdpinfo;
+   int                   nthreads;           /* reinterpreted: number of GPUs (-1 = all visible) */
+};
+
+/* ---------------------------------------------------------------------------------------------------------------------- */
+/* local helpers                                                                                                          */
+/* ---------------------------------------------------------------------------------------------------------------------- */
+
+static SCIP_Bool isFixed(const SCIP_SDPISOLVER* s, SCIP_Real lb, SCIP_Real ub)
+{
+   return (ub - lb <= s->epsilon);   /* sdpisolver_dsdp.c:253-262 */
+}
+
+static SCIP_Bool isInf(SCIP_Real v)
+{
+   return (v <= -HS_INFINITY || v >= HS_INFINITY);
+}
+
+static void freeSolution(SCIP_SDPISOLVER* s)
+{
+   int b;
+   HSFREE(s, &s->ysol, s->nysol);
+   s->nysol = 0;
+   HSFREE(s, &s->xlp, s->nxlp);
+   s->nxlp = 0;
+   if ( s->Xsol != NULL )
+   {
+      for (b = 0; b < s->nXsol; ++b)
+         HSFREE(s, &s->Xsol[b], s->Xsize[b] * s->Xsize[b]);
+      HSFREE(s, &s->Xsol, s->nXsol);
+      HSFREE(s, &s->Xsize, s->nXsol);
+   }
+   s->nXsol = 0;
+}
+
+static void freeBlockMaps(SCIP_SDPISOLVER* s)
+{
+   int b;
+   if ( s->keptind != NULL )
+   {
+      for (b = 0; b < s->nblkalloc; ++b)
+         HSFREE(s, &s->keptind[b], s->origsize[b]);
+      HSFREE(s, &s->keptind, s->nblkalloc);
+   }
+   HSFREE(s, &s->blockmap, s->nblkalloc);
+   HSFREE(s, &s->compactsize, s->nblkalloc);
+   HSFREE(s, &s->origsize, s->nblkalloc);
+   s->nblkalloc = 0;
+}
+
+static void freeVarMaps(SCIP_SDPISOLVER* s)
+{
+   HSFREE(s, &s->inputtoactive, s->nalloc);
+   HSFREE(s, &s->activetoinput, s->nalloc);
+   HSFREE(s, &s->fixedvarsval, s->nalloc);
+   HSFREE(s, &s->objcoefs, s->nalloc);
+   HSFREE(s, &s->lbrow, s->nalloc);
+   HSFREE(s, &s->ubrow, s->nalloc);
+   s->nalloc = 0;
+}
+
+static void freeLpMaps(SCIP_SDPISOLVER* s)
+{
+   HSFREE(s, &s->lhsrow, s->nlpalloc);
+   HSFREE(s, &s->rhsrow, s->nlpalloc);
+   s->nlpalloc = 0;
+}
+
+/* fetch X of an engine block on first use */
+static SCIP_RETCODE ensureX(SCIP_SDPISOLVER* s, int eb)
+{
+   if ( s->Xsol[eb] == NULL )
+   {
+      ALLOC_OR_FAIL(s, &s->Xsol[eb], s->Xsize[eb] * s->Xsize[eb]);
+      ENGINE_CALL( hipsdp_get_X(s->engine, eb, s->Xsol[eb]) );
+   }
+   return SCIP_OKAY;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------- */
+/* miscellaneous                                                                                                          */
+/* ---------------------------------------------------------------------------------------------------------------------- */
+
+const char* SCIPsdpiSolverGetSolverName(void)
+{
+   return "HIPSDP";
+}
+
+const char* SCIPsdpiSolverGetSolverDesc(void)
+{
+   return "Homogeneous self-dual primal-dual interior-point solver for dense SDP blocks on AMD MI355X (gfx950), FP64 MFMA Schur assembly";
+}
+
+void* SCIPsdpiSolverGetSolverPointer(SCIP_SDPISOLVER* sdpisolver)
+{
+   assert( sdpisolver != NULL );
+   return (void*) sdpisolver->engine;
+}
+
+int SCIPsdpiSolverGetDefaultSdpiSolverNpenaltyIncreases(void)
+{
+   return 8;
+}
+
+SCIP_Bool SCIPsdpiSolverDoesWarmstartNeedPrimal(void)
+{
+   return TRUE;   /* primal-dual method; also required by relax_sdp.c:3842-3966 */
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------- */
+/* creation and destruction                                                                                               */
+/* ---------------------------------------------------------------------------------------------------------------------- */
+
+SCIP_RETCODE SCIPsdpiSolverCreate(SCIP_SDPISOLVER** sdpisolver, SCIP_MESSAGEHDLR* messagehdlr, BMS_BLKMEM* blkmem,
+   BMS_BUFMEM* bufmem)
+{
+   SCIP_SDPISOLVER* s;
+   assert( sdpisolver != NULL );
+#ifdef HIPSDP_WITH_SCIP
+   if ( BMSallocBlockMemory(blkmem, sdpisolver) == NULL )
+      return SCIP_NOMEMORY;
+#else
+   *sdpisolver = (SCIP_SDPISOLVER*) hipsdp_compat_malloc(sizeof(SCIP_SDPISOLVER));
+   if ( *sdpisolver == NULL )
+      return SCIP_NOMEMORY;
+#endif
+   s = *sdpisolver;
+   memset(s, 0, sizeof(*s));
+   s->messagehdlr = messagehdlr;
+   s->blkmem = blkmem;
+   s->bufmem = bufmem;
+   s->engine = NULL;
+   s->device = 0;
+   if ( getenv("HIPSDP_DEVICE") != NULL )
+      s->device = atoi(getenv("HIPSDP_DEVICE"));
+   s->solved = FALSE;
+   s->timelimit = FALSE;
+   s->timelimitinitial = FALSE;
+   s->rvar = -1;
+   s->sdpcounter = 0;
+   s->usedsetting = SCIP_SDPSOLVERSETTING_UNSOLVED;
+   /* defaults of the reference backends (sdpisolver_dsdp.c:558-568) */
+   s->epsilon = 1e-9;
+   s->gaptol = 1e-6;
+   s->feastol = 1e-6;
+   s->sdpsolverfeastol = 1e-6;
+   s->penaltyparam = 1e5;
+   s->objlimit = HS_INFINITY;
+   s->sdpinfo = FALSE;
+   s->nthreads = -1;
+   s->preoptimalgap = -1.0;
+   s->info.status = HIPSDP_STATUS_UNSOLVED;
+   return SCIP_OKAY;
+}
+
+SCIP_RETCODE SCIPsdpiSolverFree(SCIP_SDPISOLVER** sdpisolver)
+{
+   SCIP_SDPISOLVER* s;
+   assert( sdpisolver != NULL );
+   s = *sdpisolver;
+   if ( s == NULL )
+      return SCIP_OKAY;
+   if ( s->engine != NULL )
+      hipsdp_free(&s->engine);
+   freeSolution(s);
+   freeBlockMaps(s);
+   freeVarMaps(s);
+   freeLpMaps(s);
+#ifdef HIPSDP_WITH_SCIP
+   BMSfreeBlockMemory(s->blkmem, sdpisolver);
+#else
+   hipsdp_compat_free(s, sizeof(SCIP_SDPISOLVER));
+   *sdpisolver = NULL;
+#endif
+   return SCIP_OKAY;
+}
+
+SCIP_RETCODE SCIPsdpiSolverIncreaseCounter(SCIP_SDPISOLVER* sdpisolver)
+{
+   assert( sdpisolver != NULL );
+   sdpisolver->sdpcounter++;
+   return SCIP_OKAY;
+}
+
+SCIP_RETCODE SCIPsdpiSolverResetCounter(SCIP_SDPISOLVER* sdpisolver)
+{
+   assert( sdpisolver != NULL );
+   sdpisolver->sdpcounter = 0;
+   return SCIP_OKAY;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------- */
+/* solving                                                                                                                */
+/* ---------------------------------------------------------------------------------------------------------------------- */
+
+SCIP_RETCODE SCIPsdpiSolverLoadAndSolve(
+   SCIP_SDPISOLVER* sdpisolver, int nvars, const SCIP_Real* obj, const SCIP_Real* lb, const SCIP_Real* ub,
+   int nsdpblocks, const int* sdpblocksizes, const int* sdpnblockvars,
+   int sdpconstnnonz, const int* sdpconstnblocknonz, int* const* sdpconstrow, int* const* sdpconstcol, SCIP_Real* const* sdpconstval,
+   int sdpnnonz, int* const* sdpnblockvarnonz, int* const* sdpvar, int** const* sdprow, int** const* sdpcol, SCIP_Real** const* sdpval,
+   int* const* indchanges, const int* nremovedinds, const int* blockindchanges, int nremovedblocks,
+   int nlpcons, const int* lpindchanges, const SCIP_Real* lplhs, const SCIP_Real* lprhs,
+   int lpnnonz, const int* lpbeg, const int* lpind, const SCIP_Real* lpval,
+   const SCIP_Real* starty, const int* startZnblocknonz, int* const* startZrow, int* const* startZcol, SCIP_Real* const* startZval,
+   const int* startXnblocknonz, int* const* startXrow, int* const* startXcol, SCIP_Real* const* startXval,
+   SCIP_SDPSOLVERSETTING startsettings, SCIP_Real timelimit, SDPI_CLOCK* usedsdpitime)
+{
+   /* sdpisolver_dsdp.c:671-735: the plain solve is the penalty solve with Gamma = 0 */
+   return SCIPsdpiSolverLoadAndSolveWithPenalty(sdpisolver, 0.0, TRUE, TRUE, nvars, obj, lb, ub, nsdpblocks, sdpblocksizes,
+      sdpnblockvars, sdpconstnnonz, sdpconstnblocknonz, sdpconstrow, sdpconstcol, sdpconstval, sdpnnonz, sdpnblockvarnonz, sdpvar,
+      sdprow, sdpcol, sdpval, indchanges, nremovedinds, blockindchanges, nremovedblocks, nlpcons, lpindchanges, lplhs, lprhs,
+      lpnnonz, lpbeg, lpind, lpval, starty, startZnblocknonz, startZrow, startZcol, startZval, startXnblocknonz, startXrow,
+      startXcol, startXval, startsettings, timelimit, usedsdpitime, NULL, NULL);
+}
+
+/* one engine solve with the given tolerances; accumulates counters */
+static SCIP_RETCODE engineSolve(SCIP_SDPISOLVER* s, SCIP_Real gaptol, SCIP_Real feastol, SCIP_Real remaining, SDPI_CLOCK* clck)
+{
+   hipsdp_params par;
+   SCIP_Real t0;
+   hipsdp_default_params(&par);
+   par.gaptol = gaptol;
+   par.feastol = feastol;
+   par.objlimit = (s->penalty ? HS_INFINITY : s->objlimit);
+   par.timelimit = remaining < HS_INFINITY ? remaining : 0.0;
+   par.verbose = s->sdpinfo ? 1 : 0;
+   t0 = SDPIclockGetTime(clck);
+   ENGINE_CALL( hipsdp_solve(s->engine, &par, &s->info) );
+   s->opttime += (clck != NULL) ? SDPIclockGetTime(clck) - t0 : s->info.solve_seconds;
+   if ( clck == NULL || s->opttime <= 0.0 )
+      s->opttime = s->info.solve_seconds > s->opttime ? s->info.solve_seconds : s->opttime;
+   s->niterations += s->info.iterations;
+   s->nsdpcalls++;
+   return SCIP_OKAY;
+}
+
+/* pull y and the LP multipliers of the last engine solve to the host */
+static SCIP_RETCODE fetchVectors(SCIP_SDPISOLVER* s)
+{
+   if ( s->nysol > 0 )
+      ENGINE_CALL( hipsdp_get_y(s->engine, s->ysol) );
+   if ( s->nxlp > 0 )
+      ENGINE_CALL( hipsdp_get_lp(s->engine, s->xlp, NULL) );
+   return SCIP_OKAY;
+}
+
+SCIP_RETCODE SCIPsdpiSolverLoadAndSolveWithPenalty(
+   SCIP_SDPISOLVER* sdpisolver, SCIP_Real penaltyparam, SCIP_Bool withobj, SCIP_Bool rbound,
+   int nvars, const SCIP_Real* obj, const SCIP_Real* lb, const SCIP_Real* ub,
+   int nsdpblocks, const int* sdpblocksizes, const int* sdpnblockvars,
+   int sdpconstnnonz, const int* sdpconstnblocknonz, int* const* sdpconstrow, int* const* sdpconstcol, SCIP_Real* const* sdpconstval,
+   int sdpnnonz, int* const* sdpnblockvarnonz, int* const* sdpvar, int** const* sdprow, int** const* sdpcol, SCIP_Real** const* sdpval,
+   int* const* indchanges, const int* nremovedinds, const int* blockindchanges, int nremovedblocks,
+   int nlpcons, const int* lpindchanges, const SCIP_Real* lplhs, const SCIP_Real* lprhs,
+   int lpnnonz, const int* lpbeg, const int* lpind, const SCIP_Real* lpval,
+   const SCIP_Real* starty, const int* startZnblocknonz, int* const* startZrow, int* const* startZcol, SCIP_Real* const* startZval,
+   const int* startXnblocknonz, int* const* startXrow, int* const* startXcol, SCIP_Real* const* startXval,
+   SCIP_SDPSOLVERSETTING startsettings, SCIP_Real timelimit, SDPI_CLOCK* usedsdpitime,
+   SCIP_Bool* feasorig, SCIP_Bool* penaltybound)
+{
+   SCIP_SDPISOLVER* s = sdpisolver;
+   SCIP_Real remaining;
+   SCIP_Real* bvec = NULL;
+   SCIP_Real* dext = NULL;
+   int* engsizes = NULL;
+   int nfixed;
+   int nengvars;
+   int m1;
+   int q;
+   int i;
+   int j;
+   int b;
+   int row;
+
+   assert( s != NULL );
+   assert( penaltyparam > -1 * s->epsilon );
+   assert( penaltyparam < s->epsilon || feasorig != NULL );
+   assert( nvars > 0 );
+   assert( obj != NULL && lb != NULL && ub != NULL );
+   (void) sdpconstnnonz; (void) sdpnnonz; (void) nremovedblocks; (void) nremovedinds;
+   /* round 1: the engine always starts from its own (well centred) point; the optional start is accepted and ignored,
+    * which the interface allows ("optionally an array start may be given", sdpisolver.h:160-166) */
+   (void) starty; (void) startZnblocknonz; (void) startZrow; (void) startZcol; (void) startZval;
+   (void) startXnblocknonz; (void) startXrow; (void) startXcol; (void) startXval;
+
+   if ( startsettings != SCIP_SDPSOLVERSETTING_UNSOLVED && startsettings != SCIP_SDPSOLVERSETTING_PENALTY
+      && startsettings != SCIP_SDPSOLVERSETTING_FAST && startsettings != SCIP_SDPSOLVERSETTING_MEDIUM
+      && startsettings != SCIP_SDPSOLVERSETTING_STABLE )
+   {
+      SCIPerrorMessage("Unknown setting %d for start-settings!\n", (int) startsettings);   /* sdpisolver_sdpa.cpp:1445-1449 */
+      return SCIP_LPERROR;
+   }
+
+   s->niterations = 0;
+   s->nsdpcalls = 0;
+   s->opttime = 0.0;
+   s->feasorig = FALSE;
+   s->penalty = penaltyparam > s->epsilon;
+   s->rbound = rbound;
+   s->penaltyworbound = (s->penalty && ! rbound);
+   s->info.status = HIPSDP_STATUS_UNSOLVED;
+
+   /* time limit check before doing anything (sdpisolver_dsdp.c:879-892) */
+   remaining = HS_INFINITY;
+   if ( timelimit < HS_INFINITY && usedsdpitime != NULL )
+   {
+      remaining = timelimit - SDPIclockGetTime(usedsdpitime);
+      if ( remaining <= 0.0 )
+      {
+         s->timelimit = TRUE;
+         s->timelimitinitial = TRUE;
+         s->solved = FALSE;
+         return SCIP_OKAY;
+      }
+   }
+   s->timelimit = FALSE;
+   s->timelimitinitial = FALSE;
+   s->solved = FALSE;
+
+   if ( ! s->penalty )
+   {
+      s->sdpcounter++;
+      s->usedsetting = SCIP_SDPSOLVERSETTING_FAST;
+   }
+   else
+      s->usedsetting = SCIP_SDPSOLVERSETTING_PENALTY;
+
+   /* ---- variable maps ------------------------------------------------------------------------------------------- */
+   if ( nvars > s->nalloc )
+   {
+      freeVarMaps(s);
+      ALLOC_OR_FAIL(s, &s->inputtoactive, nvars);
+      ALLOC_OR_FAIL(s, &s->activetoinput, nvars);
+      ALLOC_OR_FAIL(s, &s->fixedvarsval, nvars);
+      ALLOC_OR_FAIL(s, &s->objcoefs, nvars);
+      ALLOC_OR_FAIL(s, &s->lbrow, nvars);
+      ALLOC_OR_FAIL(s, &s->ubrow, nvars);
+      s->nalloc = nvars;
+   }
+   s->nvars = nvars;
+   s->nactivevars = 0;
+   nfixed = 0;
+   s->fixedvarsobjcontr = 0.0;
+   for (i = 0; i < nvars; ++i)
+   {
+      s->lbrow[i] = -1;
+      s->ubrow[i] = -1;
+      s->fixedvarsval[i] = 0.0;
+      if ( isFixed(s, lb[i], ub[i]) )
+      {
+         ++nfixed;
+         s->inputtoactive[i] = -nfixed;
+         s->fixedvarsval[i] = lb[i];
+         s->fixedvarsobjcontr += obj[i] * lb[i];
+      }
+      else
+      {
+         s->activetoinput[s->nactivevars] = i;
+         s->objcoefs[s->nactivevars] = obj[i];
+         s->nactivevars++;
+         s->inputtoactive[i] = s->nactivevars;
+      }
+   }
+   if ( ! withobj )
+      s->fixedvarsobjcontr = 0.0;
+   nengvars = s->nactivevars + (s->penalty ? 1 : 0);
+   s->rvar = s->penalty ? s->nactivevars : -1;
+   m1 = nengvars + 1;
+
+   /* ---- block maps ---------------------------------------------------------------------------------------------- */
+   freeBlockMaps(s);
+   if ( nsdpblocks > 0 )
+   {
+      ALLOC_OR_FAIL(s, &s->blockmap, nsdpblocks);
+      ALLOC_OR_FAIL(s, &s->compactsize, nsdpblocks);
+      ALLOC_OR_FAIL(s, &s->origsize, nsdpblocks);
+      ALLOC_OR_FAIL(s, &s->keptind, nsdpblocks);
+      s->nblkalloc = nsdpblocks;
+      for (b = 0; b < nsdpblocks; ++b)
+      {
+         s->keptind[b] = NULL;
+         s->origsize[b] = sdpblocksizes[b];
+      }
+   }
+   s->nsdpblocks = nsdpblocks;
+   s->nengineblocks = 0;
+   if ( nsdpblocks > 0 )
+      ALLOC_OR_FAIL(s, &engsizes, nsdpblocks);
+   for (b = 0; b < nsdpblocks; ++b)
+   {
+      int cnt = 0;
+      ALLOC_OR_FAIL(s, &s->keptind[b], sdpblocksizes[b]);
+      if ( blockindchanges[b] < 0 )
+      {
+         s->blockmap[b] = -1;
+         s->compactsize[b] = 0;
+         continue;
+      }
+      for (i = 0; i < sdpblocksizes[b]; ++i)
+      {
+         if ( indchanges[b][i] >= 0 )
+         {
+            assert( i - indchanges[b][i] == cnt );
+            s->keptind[b][cnt++] = i;
+         }
+      }
+      s->compactsize[b] = cnt;
+      if ( cnt == 0 )
+      {
+         s->blockmap[b] = -1;
+         continue;
+      }
+      s->blockmap[b] = s->nengineblocks;
+      engsizes[s->nengineblocks++] = cnt;
+   }
+
+   /* ---- LP rows: one engine row per finite side (sdpisolver_dsdp.c:1217-1314), then one per finite bound --------- */
+   if ( nlpcons > s->nlpalloc )
+   {
+      freeLpMaps(s);
+      ALLOC_OR_FAIL(s, &s->lhsrow, nlpcons);
+      ALLOC_OR_FAIL(s, &s->rhsrow, nlpcons);
+      s->nlpalloc = nlpcons;
+   }
+   s->nlpcons = nlpcons;
+   q = 0;
+   for (i = 0; i < nlpcons; ++i)
+   {
+      s->lhsrow[i] = -1;
+      s->rhsrow[i] = -1;
+      if ( lpindchanges[i] < 0 )
+         continue;
+      if ( lplhs[i] > -HS_INFINITY )
+         s->lhsrow[i] = q++;
+      if ( lprhs[i] < HS_INFINITY )
+         s->rhsrow[i] = q++;
+   }
+   s->nlpineqs = q;
+   for (j = 0; j < s->nactivevars; ++j)
+   {
+      const int v = s->activetoinput[j];
+      if ( ! isInf(lb[v]) )
+         s->lbrow[v] = q++;
+      if ( ! isInf(ub[v]) )
+         s->ubrow[v] = q++;
+   }
+   if ( s->penalty && rbound )
+      ++q;                                   /* r >= 0 is the last row */
+   s->nenginerows = q;
+
+   /* ---- engine ---------------------------------------------------------------------------------------------------- */
+   if ( s->engine == NULL )
+   {
+      int rc = hipsdp_create(&s->engine, s->device);
+      if ( rc != HIPSDP_OK )
+      {
+         SCIPerrorMessage("Cannot create the HIP engine: %s\n", hipsdp_last_error());
+         HSFREE(s, &engsizes, nsdpblocks);
+         return SCIP_LPERROR;
+      }
+   }
+   ENGINE_CALL( hipsdp_set_shape(s->engine, nengvars, s->nengineblocks, engsizes, q) );
+   HSFREE(s, &engsizes, nsdpblocks);
+
+   /* objective */
+   ALLOC_OR_FAIL(s, &bvec, nengvars);
+   for (j = 0; j < s->nactivevars; ++j)
+      bvec[j] = withobj ? s->objcoefs[j] : 0.0;
+   if ( s->penalty )
+      bvec[s->rvar] = penaltyparam;
+   ENGINE_CALL( hipsdp_set_obj(s->engine, bvec) );
+   HSFREE(s, &bvec, nengvars);
+
+   /* SDP blocks: lower-triangular COO with compacted indices; fixed variables are skipped because the caller has moved
+    * them into the constant part (sdpisolver.h:160-163, sdpi.c:614-682) */
+   for (b = 0; b < nsdpblocks; ++b)
+   {
+      long long cnt = 0;
+      long long pos = 0;
+      int k;
+      int t;
+      int* evar;
+      int* erow;
+      int* ecol;
+      SCIP_Real* eval;
+      const int eb = s->blockmap[b];
+      if ( eb < 0 )
+         continue;
+      for (k = 0; k < sdpnblockvars[b]; ++k)
+         if ( s->inputtoactive[sdpvar[b][k]] > 0 )
+            cnt += sdpnblockvarnonz[b][k];
+      cnt += sdpconstnblocknonz[b];
+      if ( s->penalty )
+         cnt += s->compactsize[b];
+      if ( cnt == 0 )
+         continue;
+      evar = (int*) malloc((size_t) cnt * sizeof(int));
+      erow = (int*) malloc((size_t) cnt * sizeof(int));
+      ecol = (int*) malloc((size_t) cnt * sizeof(int));
+      eval = (SCIP_Real*) malloc((size_t) cnt * sizeof(SCIP_Real));
+      if ( evar == NULL || erow == NULL || ecol == NULL || eval == NULL )
+      {
+         free(evar); free(erow); free(ecol); free(eval);
+         return SCIP_NOMEMORY;
+      }
+      for (k = 0; k < sdpnblockvars[b]; ++k)
+      {
+         const int av = s->inputtoactive[sdpvar[b][k]];
+         if ( av <= 0 )
+            continue;
+         for (t = 0; t < sdpnblockvarnonz[b][k]; ++t)
+         {
+            const int r = sdprow[b][k][t];
+            const int c = sdpcol[b][k][t];
+            assert( indchanges[b][r] >= 0 && indchanges[b][c] >= 0 );
+            evar[pos] = av;
+            erow[pos] = r - indchanges[b][r];
+            ecol[pos] = c - indchanges[b][c];
+            eval[pos] = sdpval[b][k][t];
+            ++pos;
+         }
+      }
+      for (t = 0; t < sdpconstnblocknonz[b]; ++t)
+      {
+         const int r = sdpconstrow[b][t];
+         const int c = sdpconstcol[b][t];
+         if ( indchanges[b][r] < 0 || indchanges[b][c] < 0 )
+            continue;      /* cannot happen for consistent input (sdpi.c:691-809); be safe */
+         evar[pos] = 0;
+         erow[pos] = r - indchanges[b][r];
+         ecol[pos] = c - indchanges[b][c];
+         eval[pos] = sdpconstval[b][t];
+         ++pos;
+      }
+      if ( s->penalty )
+      {
+         for (t = 0; t < s->compactsize[b]; ++t)
+         {
+            evar[pos] = s->rvar + 1;
+            erow[pos] = t;
+            ecol[pos] = t;
+            eval[pos] = 1.0;
+            ++pos;
+         }
+      }
+      {
+         int rc = hipsdp_add_entries(s->engine, eb, pos, evar, erow, ecol, eval);
+         free(evar); free(erow); free(ecol); free(eval);
+         if ( rc != HIPSDP_OK )
+         {
+            SCIPerrorMessage("hipsdp_add_entries failed: %s\n", hipsdp_last_error());
+            return SCIP_LPERROR;
+         }
+      }
+   }
+
+   /* LP part, dense rows [c | D] */
+   if ( q > 0 )
+   {
+      dext = (SCIP_Real*) calloc((size_t) q * (size_t) m1, sizeof(SCIP_Real));
+      if ( dext == NULL )
+         return SCIP_NOMEMORY;
+      for (i = 0; i < nlpcons; ++i)
+      {
+         int nextbeg;
+         if ( lpindchanges[i] < 0 )
+            continue;
+         nextbeg = (i == nlpcons - 1) ? lpnnonz : lpbeg[i + 1];
+         for (j = lpbeg[i]; j < nextbeg; ++j)
+         {
+            const int av = s->inputtoactive[lpind[j]];
+            if ( av <= 0 )
+               continue;                        /* fixed: already folded into lhs/rhs by sdpi.c (sdpisolver_dsdp.c:1285-1287) */
+            if ( s->lhsrow[i] >= 0 )
+               dext[(size_t) s->lhsrow[i] * m1 + av] += lpval[j];
+            if ( s->rhsrow[i] >= 0 )
+               dext[(size_t) s->rhsrow[i] * m1 + av] -= lpval[j];
+         }
+         if ( s->lhsrow[i] >= 0 )
+         {
+            dext[(size_t) s->lhsrow[i] * m1] = lplhs[i];
+            if ( s->penalty )
+               dext[(size_t) s->lhsrow[i] * m1 + s->rvar + 1] = 1.0;
+         }
+         if ( s->rhsrow[i] >= 0 )
+         {
+            dext[(size_t) s->rhsrow[i] * m1] = -lprhs[i];
+            if ( s->penalty )
+               dext[(size_t) s->rhsrow[i] * m1 + s->rvar + 1] = 1.0;
+         }
+      }
+      for (j = 0; j < s->nactivevars; ++j)
+      {
+         const int v = s->activetoinput[j];
+         if ( s->lbrow[v] >= 0 )
+         {
+            dext[(size_t) s->lbrow[v] * m1 + j + 1] = 1.0;
+            dext[(size_t) s->lbrow[v] * m1] = lb[v];
+         }
+         if ( s->ubrow[v] >= 0 )
+         {
+            dext[(size_t) s->ubrow[v] * m1 + j + 1] = -1.0;
+            dext[(size_t) s->ubrow[v] * m1] = -ub[v];
+         }
+      }
+      if ( s->penalty && rbound )
+      {
+         row = q - 1;
+         dext[(size_t) row * m1 + s->rvar + 1] = 1.0;
+      }
+      {
+         int rc = hipsdp_set_lp(s->engine, dext);
+         free(dext);
+         if ( rc != HIPSDP_OK )
+         {
+            SCIPerrorMessage("hipsdp_set_lp failed: %s\n", hipsdp_last_error());
+            return SCIP_LPERROR;
+         }
+      }
+   }
+
+   /* ---- solve, then the tolerance re-solve loop of sdpisolver_dsdp.c:1527-1606 ----------------------------------- */
+   freeSolution(s);
+   s->nysol = nengvars;
+   ALLOC_OR_FAIL(s, &s->ysol, nengvars);
+   s->nxlp = q;
+   if ( q > 0 )
+      ALLOC_OR_FAIL(s, &s->xlp, q);
+   s->nXsol = s->nengineblocks;
+   if ( s->nengineblocks > 0 )
+   {
+      ALLOC_OR_FAIL(s, &s->Xsol, s->nengineblocks);
+      ALLOC_OR_FAIL(s, &s->Xsize, s->nengineblocks);
+      for (b = 0; b < nsdpblocks; ++b)
+      {
+         if ( s->blockmap[b] >= 0 )
+         {
+            s->Xsol[s->blockmap[b]] = NULL;
+            s->Xsize[s->blockmap[b]] = s->compactsize[b];
+         }
+      }
+   }
+
+   {
+      SCIP_Real solverfeastol = s->sdpsolverfeastol;
+      SCIP_Real solvergaptol = s->gaptol;
+      SCIP_RETCODE retcode;
+
+      retcode = engineSolve(s, solvergaptol, solverfeastol, remaining, usedsdpitime);
+      if ( retcode != SCIP_OKAY )
+         return retcode;
+
+      while ( s->info.status == HIPSDP_STATUS_OPTIMAL && ! s->penalty )
+      {
+         SCIP_Real lmin[64];
+         SCIP_Real* lminp = lmin;
+         SCIP_Real lpviol = 0.0;
+         SCIP_Bool infeasible = FALSE;
+         SCIP_Bool solveagain = FALSE;
+         int e;
+
+         retcode = fetchVectors(s);
+         if ( retcode != SCIP_OKAY )
+            return retcode;
+         if ( s->nengineblocks > 64 )
+         {
+            lminp = (SCIP_Real*) malloc((size_t) s->nengineblocks * sizeof(SCIP_Real));
+            if ( lminp == NULL )
+               return SCIP_NOMEMORY;
+         }
+         /* feasibility of y w.r.t. OUR tolerance: bounds and LP rows are engine rows, blocks through lambda_min
+          * (what SCIPsdpSolcheckerCheck, sdpsolchecker.c:58-265, verifies on the host in the reference) */
+         {
+            int rc = hipsdp_check_y(s->engine, s->ysol, lminp, &lpviol);
+            if ( rc != HIPSDP_OK )
+            {
+               if ( lminp != lmin ) free(lminp);
+               SCIPerrorMessage("hipsdp_check_y failed: %s\n", hipsdp_last_error());
+               return SCIP_LPERROR;
+            }
+         }
+         for (e = 0; e < s->nengineblocks; ++e)
+            if ( lminp[e] < -s->feastol )
+               infeasible = TRUE;
+         if ( lpviol > s->feastol )
+            infeasible = TRUE;
+         if ( lminp != lmin ) free(lminp);
+
+         if ( infeasible )
+         {
+            solverfeastol *= TOLCHANGE;
+            if ( solverfeastol >= MINSOLVERTOL )
+               solveagain = TRUE;
+         }
+         if ( REALABS(s->info.pobj - s->info.dobj) >= s->gaptol )
+         {
+            infeasible = TRUE;
+            solvergaptol *= TOLCHANGE;
+            if ( solvergaptol >= MINSOLVERTOL )
+               solveagain = TRUE;
+         }
+         if ( ! solveagain )
+         {
+            if ( infeasible )
+            {
+               s->info.status = HIPSDP_STATUS_NUMERIC;
+               SCIPmessagePrintInfo(s->messagehdlr, "HIPSDP failed to reach required feasibility tolerance (feastol: %g, gaptol: %g)!\n",
+                  solverfeastol, solvergaptol);
+            }
+            break;
+         }
+         if ( timelimit < HS_INFINITY && usedsdpitime != NULL )
+         {
+            remaining = timelimit - SDPIclockGetTime(usedsdpitime);
+            if ( remaining <= 0.0 )
+            {
+               s->info.status = HIPSDP_STATUS_TIMELIM;
+               break;
+            }
+         }
+         retcode = engineSolve(s, solvergaptol, solverfeastol, remaining, usedsdpitime);
+         if ( retcode != SCIP_OKAY )
+            return retcode;
+      }
+   }
+
+   if ( s->info.status == HIPSDP_STATUS_TIMELIM )
+   {
+      s->timelimit = TRUE;
+      s->solved = FALSE;
+      return SCIP_OKAY;
+   }
+   s->solved = TRUE;
+   {
+      SCIP_RETCODE retcode = fetchVectors(s);
+      if ( retcode != SCIP_OKAY )
+         return retcode;
+   }
+
+   /* ---- penalty post-processing (sdpisolver_dsdp.c:1655-1734) ------------------------------------------------------- */
+   if ( s->penalty && feasorig != NULL )
+   {
+      const SCIP_Real rval = s->ysol[s->rvar];
+      *feasorig = (rval < s->feastol);
+      if ( withobj )
+         s->feasorig = *feasorig;
+      if ( ! *feasorig && penaltybound != NULL )
+      {
+         SCIP_Real trace = 0.0;
+         int e;
+         int t;
+         for (e = 0; e < s->nengineblocks; ++e)
+         {
+            SCIP_RETCODE retcode = ensureX(s, e);
+            if ( retcode != SCIP_OKAY )
+               return retcode;
+            for (t = 0; t < s->Xsize[e]; ++t)
+               trace += s->Xsol[e][(size_t) t * s->Xsize[e] + t];
+         }
+         for (t = 0; t < s->nlpineqs; ++t)       /* LP sides count, variable bounds do not (sdpisolver_sdpa.cpp:1846-1857) */
+            trace += s->xlp[t];
+         *penaltybound = ((penaltyparam - trace) / penaltyparam < PENALTYBOUNDTOL);
+      }
+      else if ( penaltybound != NULL )
+         *penaltybound = FALSE;
+   }
+   return SCIP_OKAY;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------- */
+/* solution information                                                                                                   */
+/* ---------------------------------------------------------------------------------------------------------------------- */
+
+SCIP_Bool SCIPsdpiSolverWasSolved(SCIP_SDPISOLVER* sdpisolver)
+{
+   assert( sdpisolver != NULL );
+   return sdpisolver->solved;
+}
+
+static SCIP_Bool statusKnown(int st)
+{
+   return st == HIPSDP_STATUS_OPTIMAL || st == HIPSDP_STATUS_DINF || st == HIPSDP_STATUS_DUNB || st == HIPSDP_STATUS_PDINF
+      || st == HIPSDP_STATUS_OBJLIM;
+}
+
+SCIP_Bool SCIPsdpiSolverFeasibilityKnown(SCIP_SDPISOLVER* sdpisolver)
+{
+   assert( sdpisolver != NULL );
+   CHECK_IF_SOLVED_BOOL( sdpisolver );
+   return statusKnown(sdpisolver->info.status);
+}
+
+/* "primal" = the X-problem, "dual" = the y-problem (sdpisolver.h:37-42).
+ *   OPTIMAL (T, T);  DINF: y-problem infeasible, X-ray exists -> (T, F) like DSDP_INFEASIBLE / SDPA pFEAS_dINF
+ *   (sdpisolver_dsdp.c:1812-1816);  DUNB: y-ray, X-problem infeasible -> (F, T);  PDINF: (F, F);
+ *   OBJLIM: the X-objective passed the limit: (T, F) like SDPA pUNBD (sdpisolver_sdpa.cpp:1954-1958) */
+SCIP_RETCODE SCIPsdpiSolverGetSolFeasibility(SCIP_SDPISOLVER* sdpisolver, SCIP_Bool* primalfeasible, SCIP_Bool* dualfeasible)
+{
+   assert( sdpisolver != NULL && primalfeasible != NULL && dualfeasible != NULL );
+   CHECK_IF_SOLVED( sdpisolver );
+   switch ( sdpisolver->info.status )
+   {
+   case HIPSDP_STATUS_OPTIMAL: *primalfeasible = TRUE;  *dualfeasible = TRUE;  break;
+   case HIPSDP_STATUS_DINF:    *primalfeasible = TRUE;  *dualfeasible = FALSE; break;
+   case HIPSDP_STATUS_OBJLIM:  *primalfeasible = TRUE;  *dualfeasible = FALSE; break;
+   case HIPSDP_STATUS_DUNB:    *primalfeasible = FALSE; *dualfeasible = TRUE;  break;
+   case HIPSDP_STATUS_PDINF:   *primalfeasible = FALSE; *dualfeasible = FALSE; break;
+   default:
+      SCIPerrorMessage("HIPSDP doesn't know if primal and dual solutions are feasible\n");
+      return SCIP_LPERROR;
+   }
+   return SCIP_OKAY;
+}
+
+SCIP_Bool SCIPsdpiSolverIsPrimalUnbounded(SCIP_SDPISOLVER* sdpisolver)
+{
+   assert( sdpisolver != NULL );
+   CHECK_IF_SOLVED_BOOL( sdpisolver );
+   return sdpisolver->info.status == HIPSDP_STATUS_DINF || sdpisolver->info.status == HIPSDP_STATUS_OBJLIM;
+}
+
+SCIP_Bool SCIPsdpiSolverIsPrimalInfeasible(SCIP_SDPISOLVER* sdpisolver)
+{
+   assert( sdpisolver != NULL );
+   CHECK_IF_SOLVED_BOOL( sdpisolver );
+   return sdpisolver->info.status == HIPSDP_STATUS_DUNB || sdpisolver->info.status == HIPSDP_STATUS_PDINF;
+}
+
+SCIP_Bool SCIPsdpiSolverIsPrimalFeasible(SCIP_SDPISOLVER* sdpisolver)
+{
+   assert( sdpisolver != NULL );
+   CHECK_IF_SOLVED_BOOL( sdpisolver );
+   return sdpisolver->info.status == HIPSDP_STATUS_OPTIMAL || sdpisolver->info.status == HIPSDP_STATUS_DINF
+      || sdpisolver->info.status == HIPSDP_STATUS_OBJLIM;
+}
+
+SCIP_Bool SCIPsdpiSolverIsDualUnbounded(SCIP_SDPISOLVER* sdpisolver)
+{
+   assert( sdpisolver != NULL );
+   CHECK_IF_SOLVED_BOOL( sdpisolver );
+   return sdpisolver->info.status == HIPSDP_STATUS_DUNB;
+}
+
+SCIP_Bool SCIPsdpiSolverIsDualInfeasible(SCIP_SDPISOLVER* sdpisolver)
+{
+   assert( sdpisolver != NULL );
+   CHECK_IF_SOLVED_BOOL( sdpisolver );
+   return sdpisolver->info.status == HIPSDP_STATUS_DINF || sdpisolver->info.status == HIPSDP_STATUS_PDINF;
+}
+
+SCIP_Bool SCIPsdpiSolverIsDualFeasible(SCIP_SDPISOLVER* sdpisolver)
+{
+   assert( sdpisolver != NULL );
+   CHECK_IF_SOLVED_BOOL( sdpisolver );
+   return sdpisolver->info.status == HIPSDP_STATUS_OPTIMAL || sdpisolver->info.status == HIPSDP_STATUS_DUNB;
+}
+
+SCIP_Bool SCIPsdpiSolverIsConverged(SCIP_SDPISOLVER* sdpisolver)
+{
+   assert( sdpisolver != NULL );
+   if ( sdpisolver->timelimit || ! sdpisolver->solved )
+      return FALSE;
+   return statusKnown(sdpisolver->info.status) && sdpisolver->info.status != HIPSDP_STATUS_OBJLIM;
+}
+
+SCIP_Bool SCIPsdpiSolverIsObjlimExc(SCIP_SDPISOLVER* sdpisolver)
+{
+   assert( sdpisolver != NULL );
+   CHECK_IF_SOLVED_BOOL( sdpisolver );
+   return sdpisolver->info.status == HIPSDP_STATUS_OBJLIM;
+}
+
+SCIP_Bool SCIPsdpiSolverIsIterlimExc(SCIP_SDPISOLVER* sdpisolver)
+{
+   assert( sdpisolver != NULL );
+   CHECK_IF_SOLVED_BOOL( sdpisolver );
+   return sdpisolver->info.status == HIPSDP_STATUS_ITERLIM;
+}
+
+SCIP_Bool SCIPsdpiSolverIsTimelimExc(SCIP_SDPISOLVER* sdpisolver)
+{
+   assert( sdpisolver != NULL );
+   return sdpisolver->timelimit;
+}
+
+/* -1 not started, 0 converged, 1 infeasible start, 2 numerical, 3 objlimit, 4 iterlimit, 5 timelimit, 6 user, 7 other
+ * (sdpisolver.h:438-448) */
+int SCIPsdpiSolverGetInternalStatus(SCIP_SDPISOLVER* sdpisolver)
+{
+   assert( sdpisolver != NULL );
+   if ( sdpisolver->timelimit )
+      return 5;
+   if ( sdpisolver->engine == NULL || ! sdpisolver->solved )
+      return -1;
+   switch ( sdpisolver->info.status )
+   {
+   case HIPSDP_STATUS_OPTIMAL:
+   case HIPSDP_STATUS_DINF:
+   case HIPSDP_STATUS_DUNB:
+   case HIPSDP_STATUS_PDINF:   return 0;
+   case HIPSDP_STATUS_NUMERIC: return 2;
+   case HIPSDP_STATUS_OBJLIM:  return 3;
+   case HIPSDP_STATUS_ITERLIM: return 4;
+   case HIPSDP_STATUS_TIMELIM: return 5;
+   default:                    return 7;
+   }
+}
+
+SCIP_Bool SCIPsdpiSolverIsOptimal(SCIP_SDPISOLVER* sdpisolver)
+{
+   assert( sdpisolver != NULL );
+   return SCIPsdpiSolverIsConverged(sdpisolver) && sdpisolver->info.status == HIPSDP_STATUS_OPTIMAL;
+}
+
+SCIP_Bool SCIPsdpiSolverIsAcceptable(SCIP_SDPISOLVER* sdpisolver)
+{
+   assert( sdpisolver != NULL );
+   if ( sdpisolver->timelimit )
+      return FALSE;
+   CHECK_IF_SOLVED_BOOL( sdpisolver );
+   return statusKnown(sdpisolver->info.status);
+}
+
+SCIP_RETCODE SCIPsdpiSolverIgnoreInstability(SCIP_SDPISOLVER* sdpisolver, SCIP_Bool* success)
+{
+   (void) sdpisolver;
+   assert( success != NULL );
+   *success = FALSE;
+   return SCIP_OKAY;
+}
+
+/* objective recomputed from y as in sdpisolver_dsdp.c:2148-2201, except for infeasible penalty solves */
+SCIP_RETCODE SCIPsdpiSolverGetObjval(SCIP_SDPISOLVER* sdpisolver, SCIP_Real* objval)
+{
+   SCIP_SDPISOLVER* s = sdpisolver;
+   int j;
+   assert( s != NULL && objval != NULL );
+   CHECK_IF_SOLVED( s );
+   if ( s->penalty && ! s->feasorig )
+   {
+      *objval = s->info.dobj;
+   }
+   else
+   {
+      *objval = 0.0;
+      for (j = 0; j < s->nactivevars; ++j)
+         *objval += s->objcoefs[j] * s->ysol[j];
+   }
+   *objval += s->fixedvarsobjcontr;
+   return SCIP_OKAY;
+}
+
+SCIP_RETCODE SCIPsdpiSolverGetDualSol(SCIP_SDPISOLVER* sdpisolver, SCIP_Real* objval, SCIP_Real* dualsol)
+{
+   SCIP_SDPISOLVER* s = sdpisolver;
+   int v;
+   assert( s != NULL );
+   CHECK_IF_SOLVED( s );
+   if ( objval != NULL )
+   {
+      SCIP_RETCODE rc = SCIPsdpiSolverGetObjval(s, objval);
+      if ( rc != SCIP_OKAY )
+         return rc;
+   }
+   if ( dualsol != NULL )
+   {
+      for (v = 0; v < s->nvars; ++v)
+      {
+         if ( s->inputtoactive[v] > 0 )
+            dualsol[v] = s->ysol[s->inputtoactive[v] - 1];
+         else
+            dualsol[v] = s->fixedvarsval[v];
+      }
+   }
+   return SCIP_OKAY;
+}
+
+/* preoptimal solutions are only requested from backends named DSDP / SDPA (relax_sdp.c:3863,5021): report "none" */
+SCIP_RETCODE SCIPsdpiSolverGetPreoptimalPrimalNonzeros(SCIP_SDPISOLVER* sdpisolver, int nblocks, int* startXnblocknonz)
+{
+   (void) sdpisolver;
+   if ( nblocks > 0 && startXnblocknonz != NULL )
+      startXnblocknonz[0] = -1;
+   return SCIP_OKAY;
+}
+
+SCIP_RETCODE SCIPsdpiSolverGetPreoptimalSol(SCIP_SDPISOLVER* sdpisolver, SCIP_Bool* success, SCIP_Real* dualsol, int nblocks,
+   int* startXnblocknonz, int** startXrow, int** startXcol, SCIP_Real** startXval)
+{
+   (void) sdpisolver; (void) dualsol; (void) startXrow; (void) startXcol; (void) startXval;
+   assert( success != NULL );
+   *success = FALSE;
+   if ( nblocks > 0 && startXnblocknonz != NULL )
+      startXnblocknonz[0] = -1;
+   return SCIP_OKAY;
+}
+
+SCIP_RETCODE SCIPsdpiSolverGetPrimalBoundVars(SCIP_SDPISOLVER* sdpisolver, SCIP_Real* lbvals, SCIP_Real* ubvals)
+{
+   SCIP_SDPISOLVER* s = sdpisolver;
+   int v;
+   assert( s != NULL && lbvals != NULL && ubvals != NULL );
+   CHECK_IF_SOLVED( s );
+   for (v = 0; v < s->nvars; ++v)
+   {
+      lbvals[v] = (s->inputtoactive[v] > 0 && s->lbrow[v] >= 0) ? s->xlp[s->lbrow[v]] : 0.0;
+      ubvals[v] = (s->inputtoactive[v] > 0 && s->ubrow[v] >= 0) ? s->xlp[s->ubrow[v]] : 0.0;
+   }
+   return SCIP_OKAY;
+}
+
+SCIP_RETCODE SCIPsdpiSolverGetPrimalLPSides(SCIP_SDPISOLVER* sdpisolver, int nlpcons, int* lpindchanges, SCIP_Real* lplhs,
+   SCIP_Real* lprhs, SCIP_Real* lhsvals, SCIP_Real* rhsvals)
+{
+   SCIP_SDPISOLVER* s = sdpisolver;
+   int i;
+   (void) lpindchanges; (void) lplhs; (void) lprhs;
+   assert( s != NULL && lhsvals != NULL && rhsvals != NULL );
+   CHECK_IF_SOLVED( s );
+   if ( nlpcons != s->nlpcons )
+   {
+      SCIPerrorMessage("SCIPsdpiSolverGetPrimalLPSides expected nlpcons = %d but got %d\n", s->nlpcons, nlpcons);
+      return SCIP_LPERROR;
+   }
+   for (i = 0; i < nlpcons; ++i)
+   {
+      lhsvals[i] = s->lhsrow[i] >= 0 ? s->xlp[s->lhsrow[i]] : 0.0;
+      rhsvals[i] = s->rhsrow[i] >= 0 ? s->xlp[s->rhsrow[i]] : 0.0;
+   }
+   return SCIP_OKAY;
+}
+
+/* number of entries the sparse export below will write; last block = LP block (sdpisolver.h:552-554) */
+SCIP_RETCODE SCIPsdpiSolverGetPrimalNonzeros(SCIP_SDPISOLVER* sdpisolver, int nblocks, int* startXnblocknonz)
+{
+   SCIP_SDPISOLVER* s = sdpisolver;
+   int b;
+   int t;
+   assert( s != NULL && startXnblocknonz != NULL );
+   CHECK_IF_SOLVED( s );
+   if ( nblocks != s->nsdpblocks + 1 )
+   {
+      SCIPerrorMessage("SCIPsdpiSolverGetPrimalNonzeros expected nblocks = %d but got %d\n", s->nsdpblocks + 1, nblocks);
+      return SCIP_LPERROR;
+   }
+   for (b = 0; b < s->nsdpblocks; ++b)
+   {
+      const int eb = s->blockmap[b];
+      startXnblocknonz[b] = 0;
+      if ( eb >= 0 )
+      {
+         int r;
+         int c;
+         const int n = s->Xsize[eb];
+         SCIP_RETCODE rc = ensureX(s, eb);
+         if ( rc != SCIP_OKAY )
+            return rc;
+         for (r = 0; r < n; ++r)
+            for (c = 0; c <= r; ++c)
+               if ( REALABS(s->Xsol[eb][(size_t) r * n + c]) > s->epsilon )
+                  startXnblocknonz[b]++;
+      }
+   }
+   startXnblocknonz[nblocks - 1] = 0;
+   for (t = 0; t < s->nxlp; ++t)
+   {
+      if ( s->penalty && s->rbound && t == s->nxlp - 1 )
+         break;                                    /* the multiplier of r >= 0 belongs to no input row */
+      if ( REALABS(s->xlp[t]) > s->epsilon )
+         startXnblocknonz[nblocks - 1]++;
+   }
+   return SCIP_OKAY;
+}
+
+SCIP_RETCODE SCIPsdpiSolverGetPrimalMatrix(SCIP_SDPISOLVER* sdpisolver, int nblocks, int* startXnblocknonz, int** startXrow,
+   int** startXcol, SCIP_Real** startXval)
+{
+   SCIP_SDPISOLVER* s = sdpisolver;
+   int b;
+   int i;
+   int v;
+   int cnt;
+   SCIP_Bool toosmall = FALSE;
+   assert( s != NULL && startXnblocknonz != NULL && startXrow != NULL && startXcol != NULL && startXval != NULL );
+   CHECK_IF_SOLVED( s );
+   if ( nblocks != s->nsdpblocks + 1 )
+   {
+      SCIPerrorMessage("SCIPsdpiSolverGetPrimalMatrix expected nblocks = %d but got %d\n", s->nsdpblocks + 1, nblocks);
+      return SCIP_LPERROR;
+   }
+   for (b = 0; b < s->nsdpblocks; ++b)
+   {
+      const int eb = s->blockmap[b];
+      const int room = startXnblocknonz[b];
+      cnt = 0;
+      if ( eb >= 0 )
+      {
+         int r;
+         int c;
+         const int n = s->Xsize[eb];
+         SCIP_RETCODE rc = ensureX(s, eb);
+         if ( rc != SCIP_OKAY )
+            return rc;
+         for (r = 0; r < n; ++r)
+         {
+            for (c = 0; c <= r; ++c)
+            {
+               const SCIP_Real val = s->Xsol[eb][(size_t) r * n + c];
+               if ( REALABS(val) > s->epsilon )
+               {
+                  if ( cnt < room )
+                  {
+                     startXrow[b][cnt] = s->keptind[b][r];      /* original indices, lower triangle */
+                     startXcol[b][cnt] = s->keptind[b][c];
+                     startXval[b][cnt] = val;
+                  }
+                  ++cnt;
+               }
+            }
+         }
+      }
+      if ( cnt > room )
+         toosmall = TRUE;
+      startXnblocknonz[b] = cnt;
+   }
+   /* LP block: position 2 * row (+1 for the rhs side), then 2 * nlpcons + 2 * var (+1 for the upper bound) */
+   {
+      const int room = startXnblocknonz[nblocks - 1];
+      b = nblocks - 1;
+      cnt = 0;
+      for (i = 0; i < s->nlpcons; ++i)
+      {
+         int side;
+         for (side = 0; side < 2; ++side)
+         {
+            const int er = side == 0 ? s->lhsrow[i] : s->rhsrow[i];
+            if ( er >= 0 && REALABS(s->xlp[er]) > s->epsilon )
+            {
+               if ( cnt < room )
+               {
+                  startXrow[b][cnt] = 2 * i + side;
+                  startXcol[b][cnt] = 2 * i + side;
+                  startXval[b][cnt] = s->xlp[er];
+               }
+               ++cnt;
+            }
+         }
+      }
+      for (v = 0; v < s->nvars; ++v)
+      {
+         int side;
+         if ( s->inputtoactive[v] <= 0 )
+            continue;
+         for (side = 0; side < 2; ++side)
+         {
+            const int er = side == 0 ? s->lbrow[v] : s->ubrow[v];
+            if ( er >= 0 && REALABS(s->xlp[er]) > s->epsilon )
+            {
+               if ( cnt < room )
+               {
+                  startXrow[b][cnt] = 2 * s->nlpcons + 2 * v + side;
+                  startXcol[b][cnt] = 2 * s->nlpcons + 2 * v + side;
+                  startXval[b][cnt] = s->xlp[er];
+               }
+               ++cnt;
+            }
+         }
+      }
+      if ( cnt > room )
+         toosmall = TRUE;
+      startXnblocknonz[b] = cnt;
+   }
+   (void) toosmall;   /* the needed sizes have been written into startXnblocknonz (sdpisolver.h:554) */
+   return SCIP_OKAY;
+}
+
+/* dense X per ORIGINAL block, zeros at removed indices (sdpisolver_dsdp.c:2467-2545) */
+SCIP_RETCODE SCIPsdpiSolverGetPrimalSolutionMatrix(SCIP_SDPISOLVER* sdpisolver, int nsdpblocks, int* sdpblocksizes,
+   int** indchanges, int* nremovedinds, int* blockindchanges, SCIP_Real** primalmatrices)
+{
+   SCIP_SDPISOLVER* s = sdpisolver;
+   int b;
+   (void) nremovedinds;
+   assert( s != NULL && primalmatrices != NULL );
+   CHECK_IF_SOLVED( s );
+   if ( nsdpblocks != s->nsdpblocks )
+   {
+      SCIPerrorMessage("SCIPsdpiSolverGetPrimalSolutionMatrix expected nsdpblocks = %d but got %d\n", s->nsdpblocks, nsdpblocks);
+      return SCIP_LPERROR;
+   }
+   for (b = 0; b < nsdpblocks; ++b)
+   {
+      const int bs = sdpblocksizes[b];
+      const int eb = s->blockmap[b];
+      int r;
+      int c;
+      for (r = 0; r < bs * bs; ++r)
+         primalmatrices[b][r] = 0.0;
+      if ( eb < 0 || blockindchanges[b] < 0 )
+         continue;
+      {
+         const int n = s->Xsize[eb];
+         SCIP_RETCODE rc = ensureX(s, eb);
+         if ( rc != SCIP_OKAY )
+            return rc;
+         for (r = 0; r < bs; ++r)
+         {
+            if ( indchanges[b][r] < 0 )
+               continue;
+            for (c = 0; c < bs; ++c)
+            {
+               if ( indchanges[b][c] < 0 )
+                  continue;
+               primalmatrices[b][(size_t) r * bs + c] = s->Xsol[eb][(size_t) (r - indchanges[b][r]) * n + (c - indchanges[b][c])];
+            }
+         }
+      }
+   }
+   return SCIP_OKAY;
+}
+
+SCIP_Real SCIPsdpiSolverGetMaxPrimalEntry(SCIP_SDPISOLVER* sdpisolver)
+{
+   SCIP_SDPISOLVER* s = sdpisolver;
+   SCIP_Real maxentry = 0.0;
+   int e;
+   int t;
+   assert( s != NULL );
+   if ( ! s->solved )
+      return 0.0;
+   for (e = 0; e < s->nengineblocks; ++e)
+   {
+      if ( ensureX(s, e) != SCIP_OKAY )
+         return 0.0;
+      for (t = 0; t < s->Xsize[e] * s->Xsize[e]; ++t)
+         if ( s->Xsol[e][t] > maxentry )
+            maxentry = s->Xsol[e][t];
+   }
+   for (t = 0; t < s->nxlp; ++t)
+      if ( s->xlp[t] > maxentry )
+         maxentry = s->xlp[t];
+   return maxentry;
+}
+
+SCIP_RETCODE SCIPsdpiSolverGetTime(SCIP_SDPISOLVER* sdpisolver, SCIP_Real* opttime)
+{
+   assert( sdpisolver != NULL && opttime != NULL );
+   *opttime = sdpisolver->opttime;
+   return SCIP_OKAY;
+}
+
+SCIP_RETCODE SCIPsdpiSolverGetIterations(SCIP_SDPISOLVER* sdpisolver, int* iterations)
+{
+   assert( sdpisolver != NULL && iterations != NULL );
+   *iterations = sdpisolver->timelimitinitial ? 0 : sdpisolver->niterations;
+   return SCIP_OKAY;
+}
+
+SCIP_RETCODE SCIPsdpiSolverGetSdpCalls(SCIP_SDPISOLVER* sdpisolver, int* calls)
+{
+   assert( sdpisolver != NULL && calls != NULL );
+   *calls = sdpisolver->timelimitinitial ? 0 : sdpisolver->nsdpcalls;
+   return SCIP_OKAY;
+}
+
+SCIP_RETCODE SCIPsdpiSolverSettingsUsed(SCIP_SDPISOLVER* sdpisolver, SCIP_SDPSOLVERSETTING* usedsetting)
+{
+   assert( sdpisolver != NULL && usedsetting != NULL );
+   if ( ! SCIPsdpiSolverIsAcceptable(sdpisolver) )
+      *usedsetting = SCIP_SDPSOLVERSETTING_UNSOLVED;
+   else
+      *usedsetting = sdpisolver->usedsetting;
+   return SCIP_OKAY;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------- */
+/* numerical methods                                                                                                      */
+/* ---------------------------------------------------------------------------------------------------------------------- */
+
+SCIP_Real SCIPsdpiSolverInfinity(SCIP_SDPISOLVER* sdpisolver)
+{
+   (void) sdpisolver;
+   return HS_INFINITY;
+}
+
+SCIP_Bool SCIPsdpiSolverIsInfinity(SCIP_SDPISOLVER* sdpisolver, SCIP_Real val)
+{
+   (void) sdpisolver;
+   return isInf(val);
+}
+
+SCIP_RETCODE SCIPsdpiSolverGetRealpar(SCIP_SDPISOLVER* sdpisolver, SCIP_SDPPARAM type, SCIP_Real* dval)
+{
+   assert( sdpisolver != NULL && dval != NULL );
+   switch ( type )
+   {
+   case SCIP_SDPPAR_EPSILON:          *dval = sdpisolver->epsilon; break;
+   case SCIP_SDPPAR_GAPTOL:           *dval = sdpisolver->gaptol; break;
+   case SCIP_SDPPAR_FEASTOL:          *dval = sdpisolver->feastol; break;
+   case SCIP_SDPPAR_SDPSOLVERFEASTOL: *dval = sdpisolver->sdpsolverfeastol; break;
+   case SCIP_SDPPAR_PENALTYPARAM:     *dval = sdpisolver->penaltyparam; break;
+   case SCIP_SDPPAR_OBJLIMIT:         *dval = sdpisolver->objlimit; break;
+   case SCIP_SDPPAR_WARMSTARTPOGAP:   *dval = sdpisolver->preoptimalgap; break;
+   default:
+      return SCIP_PARAMETERUNKNOWN;
+   }
+   return SCIP_OKAY;
+}
+
+SCIP_RETCODE SCIPsdpiSolverSetRealpar(SCIP_SDPISOLVER* sdpisolver, SCIP_SDPPARAM type, SCIP_Real dval)
+{
+   assert( sdpisolver != NULL );
+   switch ( type )
+   {
+   case SCIP_SDPPAR_EPSILON:          sdpisolver->epsilon = dval; break;
+   case SCIP_SDPPAR_GAPTOL:           sdpisolver->gaptol = dval; break;
+   case SCIP_SDPPAR_FEASTOL:          sdpisolver->feastol = dval; break;
+   case SCIP_SDPPAR_SDPSOLVERFEASTOL: sdpisolver->sdpsolverfeastol = dval; break;
+   case SCIP_SDPPAR_PENALTYPARAM:     sdpisolver->penaltyparam = dval; break;
+   case SCIP_SDPPAR_OBJLIMIT:         sdpisolver->objlimit = dval; break;
+   case SCIP_SDPPAR_LAMBDASTAR:       break;                       /* SDPA's initial-point scale: not used */
+   case SCIP_SDPPAR_WARMSTARTPOGAP:   sdpisolver->preoptimalgap = dval; break;
+   default:
+      return SCIP_PARAMETERUNKNOWN;
+   }
+   return SCIP_OKAY;
+}
+
+SCIP_RETCODE SCIPsdpiSolverGetIntpar(SCIP_SDPISOLVER* sdpisolver, SCIP_SDPPARAM type, int* ival)
+{
+   assert( sdpisolver != NULL && ival != NULL );
+   switch ( type )
+   {
+   case SCIP_SDPPAR_SDPINFO:  *ival = (int) sdpisolver->sdpinfo; break;
+   case SCIP_SDPPAR_NTHREADS: *ival = sdpisolver->nthreads; break;
+   default:
+      return SCIP_PARAMETERUNKNOWN;
+   }
+   return SCIP_OKAY;
+}
+
+SCIP_RETCODE SCIPsdpiSolverSetIntpar(SCIP_SDPISOLVER* sdpisolver, SCIP_SDPPARAM type, int ival)
+{
+   assert( sdpisolver != NULL );
+   switch ( type )
+   {
+   case SCIP_SDPPAR_SDPINFO:  sdpisolver->sdpinfo = (SCIP_Bool) ival; break;
+   case SCIP_SDPPAR_NTHREADS: sdpisolver->nthreads = ival; break;
+   default:
+      return SCIP_PARAMETERUNKNOWN;
+   }
+   return SCIP_OKAY;
+}
+
+SCIP_RETCODE SCIPsdpiSolverComputeLambdastar(SCIP_SDPISOLVER* sdpisolver, SCIP_Real maxguess)
+{
+   (void) sdpisolver; (void) maxguess;
+   return SCIP_OKAY;
+}
+
+/* clamp(1e4 * maxcoeff, 1e5, 1e12), as sdpisolver_dsdp.c:2803-2835 */
+SCIP_RETCODE SCIPsdpiSolverComputePenaltyparam(SCIP_SDPISOLVER* sdpisolver, SCIP_Real maxcoeff, SCIP_Real* penaltyparam)
+{
+   SCIP_Real compval;
+   assert( sdpisolver != NULL && penaltyparam != NULL );
+   compval = PENALTYPARAM_FACTOR * maxcoeff;
+   if ( compval < MIN_PENALTYPARAM )
+      compval = MIN_PENALTYPARAM;
+   else if ( compval > MAX_PENALTYPARAM )
+      compval = MAX_PENALTYPARAM;
+   sdpisolver->penaltyparam = compval;
+   *penaltyparam = compval;
+   return SCIP_OKAY;
+}
+
+/* min(1e6 * Gamma, 1e15), as sdpisolver_dsdp.c:2838-2869 */
+SCIP_RETCODE SCIPsdpiSolverComputeMaxPenaltyparam(SCIP_SDPISOLVER* sdpisolver, SCIP_Real penaltyparam, SCIP_Real* maxpenaltyparam)
+{
+   SCIP_Real compval;
+   assert( sdpisolver != NULL && maxpenaltyparam != NULL );
+   compval = penaltyparam * MAXPENALTYPARAM_FACTOR;
+   *maxpenaltyparam = compval < MAX_MAXPENALTYPARAM ? compval : MAX_MAXPENALTYPARAM;
+   if ( sdpisolver->penaltyparam > *maxpenaltyparam )
+      sdpisolver->penaltyparam = *maxpenaltyparam;
+   return SCIP_OKAY;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------- */
+/* file interface                                                                                                         */
+/* ---------------------------------------------------------------------------------------------------------------------- */
+
+SCIP_RETCODE SCIPsdpiSolverReadSDP(SCIP_SDPISOLVER* sdpisolver, const char* fname)
+{
+   (void) sdpisolver; (void) fname;
+   return SCIP_LPERROR;     /* not implemented in any reference backend either (sdpisolver_dsdp.c:2884-2891) */
+}
+
+SCIP_RETCODE SCIPsdpiSolverWriteSDP(SCIP_SDPISOLVER* sdpisolver, const char* fname)
+{
+   (void) sdpisolver; (void) fname;
+   return SCIP_LPERROR;
+}

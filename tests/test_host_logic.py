@@ -1,0 +1,129 @@
+"""CPU tests of the boundary: the shared library loads and exports every symbol the headers declare; the parts of the
+solver interface that need no device (lifecycle, parameters, penalty helpers, time-limit pre-check, error conventions)
+behave like the reference backends.  No compute call is made here."""
+import ctypes as C
+import os
+import re
+import time
+import pytest
+
+from conftest import ROOT
+import sdpi_call
+import sdpi_prepare
+
+HDR_DIR = os.path.join(ROOT, "include")
+
+
+def declared_symbols(header, prefix):
+    txt = open(os.path.join(HDR_DIR, header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(%s\w+)\s*\(" % prefix, txt)))
+
+
+def test_library_exports_every_declared_symbol(hb):
+    lib = hb.lib()
+    names = declared_symbols("sdpisolver_hip.h", "SCIPsdpiSolver") + declared_symbols("hipsdp.h", "hipsdp_")
+    names += declared_symbols("lapack_interface_hip.h", "SCIPlapack") if os.path.exists(os.path.join(HDR_DIR, "lapack_interface_hip.h")) else []
+    assert len([n for n in names if n.startswith("SCIPsdpiSolver")]) == 53      # sdpisolver.h:79-724
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_name_and_static_answers(hb):
+    lib = hb.lib()
+    lib.SCIPsdpiSolverGetSolverName.restype = C.c_char_p
+    assert lib.SCIPsdpiSolverGetSolverName() == b"HIPSDP"
+    assert lib.SCIPsdpiSolverDoesWarmstartNeedPrimal() == 1
+    assert lib.SCIPsdpiSolverGetDefaultSdpiSolverNpenaltyIncreases() > 0
+    lib.SCIPsdpiSolverInfinity.restype = C.c_double
+    assert lib.SCIPsdpiSolverInfinity(None) == 1e20                  # sdpisolver_dsdp.c:2634-2639
+    assert lib.SCIPsdpiSolverIsInfinity(None, C.c_double(-1e20)) == 1
+    assert lib.SCIPsdpiSolverIsInfinity(None, C.c_double(1e19)) == 0
+
+
+def test_lifecycle_params_and_leak_check(hb):
+    lib = hb.lib()
+    lib.hipsdp_compat_mem_used.restype = C.c_longlong
+    base = lib.hipsdp_compat_mem_used()
+    s = sdpi_call.SdpiSolver(lib)
+    # defaults at create: sdpisolver_dsdp.c:558-568
+    assert s.get_real(0) == (sdpi_call.SCIP_OKAY, 1e-9)
+    assert s.get_real(1) == (sdpi_call.SCIP_OKAY, 1e-6)
+    assert s.get_real(3) == (sdpi_call.SCIP_OKAY, 1e-6)
+    assert s.get_real(7) == (sdpi_call.SCIP_OKAY, 1e5)
+    assert s.get_real(4) == (sdpi_call.SCIP_OKAY, 1e20)
+    assert s.set_real(1, 1e-5) == sdpi_call.SCIP_OKAY and s.get_real(1)[1] == 1e-5
+    assert s.set_real(10, 3.0) == sdpi_call.SCIP_OKAY                 # lambdastar accepted and ignored
+    assert s.set_real(8, 1.0) == sdpi_call.SCIP_PARAMETERUNKNOWN      # unknown ids: sdpi.c:167-195 tolerates exactly this
+    assert s.set_int(5, 1) == sdpi_call.SCIP_OKAY
+    assert s.set_int(14, 1) == sdpi_call.SCIP_PARAMETERUNKNOWN
+    # penalty helpers: clamp(1e4 * maxcoeff, 1e5, 1e12) and min(1e6 * Gamma, 1e15) (sdpisolver_dsdp.c:2803-2869)
+    v = C.c_double(0)
+    lib.SCIPsdpiSolverComputePenaltyparam(s.h, C.c_double(1.0), C.byref(v)); assert v.value == 1e5
+    lib.SCIPsdpiSolverComputePenaltyparam(s.h, C.c_double(1e3), C.byref(v)); assert v.value == 1e7
+    lib.SCIPsdpiSolverComputePenaltyparam(s.h, C.c_double(1e10), C.byref(v)); assert v.value == 1e12
+    lib.SCIPsdpiSolverComputeMaxPenaltyparam(s.h, C.c_double(1e5), C.byref(v)); assert v.value == 1e11
+    lib.SCIPsdpiSolverComputeMaxPenaltyparam(s.h, C.c_double(1e12), C.byref(v)); assert v.value == 1e15
+    # nothing solved yet: predicates FALSE, getters SCIP_LPERROR (CHECK_IF_SOLVED, sdpisolver_dsdp.c:145-164)
+    assert not s.flag("WasSolved") and not s.flag("IsAcceptable") and not s.flag("IsOptimal")
+    assert s.internal_status() == -1
+    o = C.c_double(0)
+    assert lib.SCIPsdpiSolverGetObjval(s.h, C.byref(o)) == sdpi_call.SCIP_LPERROR
+    assert s.settings_used() == -1
+    ok = C.c_uint(1)
+    lib.SCIPsdpiSolverGetPreoptimalSol(s.h, C.byref(ok), None, -1, None, None, None, None)
+    assert ok.value == 0
+    assert lib.SCIPsdpiSolverReadSDP(s.h, b"x") == sdpi_call.SCIP_LPERROR
+    lib.SCIPsdpiSolverIncreaseCounter(s.h)
+    lib.SCIPsdpiSolverResetCounter(s.h)
+    s.free()
+    assert lib.hipsdp_compat_mem_used() == base                       # checksdpi.c:117
+
+
+def test_time_limit_precheck_needs_no_device(hb):
+    """remaining time <= 0: timelimit flags set, solved = FALSE, SCIP_OKAY, zero iterations (sdpisolver_dsdp.c:879-892)"""
+    lib = hb.lib()
+    lib.SDPIclockGetTime.restype = C.c_double
+    clk = C.c_void_p()
+    assert lib.SDPIclockCreate(C.byref(clk)) == sdpi_call.SCIP_OKAY
+    lib.SDPIclockStart(clk)
+    time.sleep(0.02)
+    s = sdpi_call.SdpiSolver(lib)
+    prob = sdpi_prepare.SdpiProblem([-3, -1], [0, 0], [1e20, 1e20], [], [(-1e20, 10, {0: 2, 1: 1}), (-1e20, 15, {0: 1, 1: 3})])
+    rc, _, _ = s.solve(sdpi_prepare.prepare(prob), timelimit=0.01, clock=clk)
+    assert rc == sdpi_call.SCIP_OKAY
+    assert s.flag("IsTimelimExc") and not s.flag("WasSolved") and not s.flag("IsAcceptable")
+    assert s.internal_status() == 5
+    assert s.iterations() == 0 and s.sdpcalls() == 0
+    s.free()
+    lib.SDPIclockStop(clk)
+    assert lib.SDPIclockGetTime(clk) >= 0.02
+    lib.SDPIclockFree(C.byref(clk))
+
+
+def test_engine_refuses_to_run_without_device(hb):
+    """no CPU fallback: on a machine without a GPU the engine reports HIPSDP_ERR_NODEVICE instead of computing"""
+    if hb.device_count() > 0:
+        pytest.skip("a device is present; covered by the gpu tests")
+    with pytest.raises(RuntimeError):
+        hb.Solver(0)
+    with pytest.raises(RuntimeError):
+        import numpy as np
+        hb.dgemm(np.eye(2), np.eye(2))
+
+
+def test_marshalling_restatement_consistency():
+    """sdpi_prepare.to_core on a problem with a fixed variable, an emptied row/column and a ranged row"""
+    import numpy as np
+    blocks = [dict(n=3, vars={0: [(0, 0, 1.0)], 1: [(1, 1, 1.0), (2, 2, 2.0)], 2: [(1, 0, 0.5)]}, const=[(0, 0, -1.0)])]
+    lp = [(1.0, 4.0, {0: 1.0, 1: 1.0, 2: 1.0}), (-1e20, 3.0, {1: 2.0})]
+    prob = sdpi_prepare.SdpiProblem([1, 2, 3], [0, 1, -1e20], [5, 1, 1e20], blocks, lp)      # variable 1 fixed to 1
+    P = sdpi_prepare.prepare(prob)
+    assert list(P.indchanges[0]) == [0, 0, 0]             # the fixed variable's diagonal moved into the constant part
+    assert sorted(P.sdpconst[0]) == [(0, 0, -1.0), (1, 1, -1.0), (2, 2, -2.0)]
+    assert list(P.lpindchanges) == [0, -1]                # second row has no active nonzero left
+    assert P.lplhs[0] == 0.0 and P.lprhs[0] == 3.0        # shifted by the fixed variable
+    b, blk, D, c, maps = sdpi_prepare.to_core(P)
+    assert maps["active"] == [0, 2] and list(b) == [1.0, 3.0]
+    assert D.shape == (2 + 2, 2)                          # two LP sides + lb, ub of variable 0
+    assert np.allclose(blk[0][0], np.diag([-1.0, -1.0, -2.0]))
