@@ -1,0 +1,151 @@
+"""GPU parity tests of the whole node solve (engine level, C ABI hipsdp_*): same inputs through the HIP engine and the
+oracle, plus algorithm-independent certificates, plus size-independent properties at BASELINE's full size."""
+import json
+import os
+import numpy as np
+import pytest
+
+import ipm_ref
+import checker
+import instances
+import sdpa_io
+import sdpi_prepare
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5          # north_star: results agree to sdpsolvergaptol / feastol = 1e-5 (relax_sdp.c:70-71)
+
+
+def gpu_solve(hb, core, **kw):
+    s = hb.Solver(0)
+    s.load_core(core)
+    info = s.solve(**kw)
+    out = dict(info=info, y=s.y(), X=[s.X(k) for k in range(len(core.blocks))], lp=s.lp())
+    s.close()
+    return out
+
+
+def compare(hb, core, tol=1e-6):
+    ref = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=tol, feastol=tol))
+    g = gpu_solve(hb, core, gaptol=tol, feastol=tol)
+    assert g["info"].status == ref.status, (g["info"].status, ref.status)
+    return ref, g
+
+
+CASES = json.load(open(os.path.join(GOLDEN, "checksdpi_cases.json")))["cases"]
+
+
+def case_core(case):
+    blocks = [dict(n=b["n"], vars={int(k): [tuple(e) for e in v] for k, v in b["vars"].items()},
+                   const=[tuple(e) for e in b["const"]]) for b in case["blocks"]]
+    lp = [(l, r, {int(k): v for k, v in row.items()}) for (l, r, row) in case["lp"]]
+    P = sdpi_prepare.prepare(sdpi_prepare.SdpiProblem(case["obj"], case["lb"], case["ub"], blocks, lp))
+    b, blk, D, c, maps = sdpi_prepare.to_core(P)
+    return ipm_ref.CoreProblem(b, blk, D, c)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_engine_matches_oracle_on_reference_cases(gpu, case):
+    core = case_core(case)
+    ref, g = compare(gpu, core)
+    assert g["info"].iterations == ref.iterations
+    assert np.allclose(g["y"], ref.y, atol=1e-7, rtol=1e-7)
+    if core.q:
+        assert np.allclose(g["lp"][0], ref.x, atol=1e-6, rtol=1e-6)
+    for Xg, Xr in zip(g["X"], ref.X):
+        assert np.allclose(Xg, Xr, atol=1e-6, rtol=1e-6)
+    if ref.status == ipm_ref.STATUS_OPTIMAL:
+        ok, det = checker.certificate(core, g["y"], g["X"], g["lp"][0], TOL, TOL)
+        assert ok, det
+    if ref.status in (ipm_ref.STATUS_DINF, ipm_ref.STATUS_PDINF):
+        assert checker.farkas_dual_infeasible(core, g["X"], g["lp"][0], 1e-6)[0]
+    if ref.status in (ipm_ref.STATUS_DUNB, ipm_ref.STATUS_PDINF):
+        assert checker.farkas_dual_unbounded(core, g["y"], 1e-6)[0]
+
+
+@pytest.mark.parametrize("name", ["example_small.dat-s", "example_TT.dat-s.gz", "example_CLS.dat-s.gz", "example_MkP.dat-s.gz",
+                                  "example_inf.dat-s", "example_tightenmatrices.dat-s"])
+def test_engine_matches_oracle_on_reference_instances(gpu, name):
+    inst = sdpa_io.read_sdpa(os.path.join(GOLDEN, "instances", name))
+    D, c = sdpa_io.lp_dense(inst)
+    core = ipm_ref.CoreProblem(inst.obj, sdpa_io.dense_blocks(inst), D, c)
+    ref, g = compare(gpu, core)
+    assert abs(g["info"].dobj - ref.dobj) <= TOL * (1 + abs(ref.dobj))
+    ok, det = checker.certificate(core, g["y"], g["X"], g["lp"][0], TOL, TOL)
+    assert ok, det
+
+
+@pytest.mark.parametrize("n,m", [(5, 8), (20, 40), (50, 100), (100, 200)])
+def test_engine_matches_oracle_on_planted_blocks(gpu, n, m):
+    b, A, ys, Xs, Zs = instances.planted_dense(n, m)
+    core = ipm_ref.CoreProblem(b, [A])
+    ref, g = compare(gpu, core, tol=1e-5)
+    assert g["info"].iterations == ref.iterations
+    assert abs(g["info"].dobj - ref.dobj) <= 1e-8 * (1 + abs(ref.dobj))
+    assert np.max(np.abs(g["y"] - ref.y)) <= 1e-7
+    assert abs(g["info"].dobj - b @ ys) <= TOL * (1 + abs(b @ ys))
+
+
+def test_multi_block_with_lp_rows_and_bounds(gpu):
+    rng = np.random.default_rng(7)
+    m = 12
+    blocks = []
+    for n in (4, 9):
+        A = rng.standard_normal((m + 1, n, n))
+        A = A + A.transpose(0, 2, 1)
+        A[0] = -np.eye(n) * 3.0 + 0.1 * A[0]
+        blocks.append(A)
+    D = np.concatenate([rng.standard_normal((5, m)), np.eye(m), -np.eye(m)])
+    c = np.concatenate([-np.ones(5) * 4.0, -2.0 * np.ones(m), -2.0 * np.ones(m)])
+    core = ipm_ref.CoreProblem(rng.standard_normal(m), blocks, D, c)
+    ref, g = compare(gpu, core)
+    assert ref.status == ipm_ref.STATUS_OPTIMAL
+    assert np.max(np.abs(g["y"] - ref.y)) <= 1e-6
+    ok, det = checker.certificate(core, g["y"], g["X"], g["lp"][0], TOL, TOL)
+    assert ok, det
+
+
+def test_device_generator_matches_numpy_stream(gpu):
+    n, m = 16, 24
+    b, A, ys, Xs, Zs = instances.planted_dense(n, m)
+    s = gpu.Solver(0)
+    s.set_shape(m, [n], 0)
+    bdev = s.gen_planted(n, m, 20240, Xs, Zs, ys)
+    Adev = s.get_block_dense(0)
+    s.close()
+    assert np.max(np.abs(Adev[1:] - A[1:])) <= 1e-13          # same uniforms; log/cos/sqrt differ by ulps at most
+    assert np.max(np.abs(Adev[0] - A[0])) <= 1e-12
+    assert np.max(np.abs(bdev - b)) <= 1e-12
+
+
+def test_full_size_c2_properties(gpu):
+    """BASELINE config 2 (n = 500, m = 1000, dense, fp64): the oracle would need minutes here, so the check is by
+    size-independent properties: the planted optimum value, the y-side acceptance test of sdpsolchecker.c evaluated with
+    LAPACK on the host, complementarity, and run-to-run bitwise reproducibility."""
+    n, m = 500, 1000
+    Q, _ = np.linalg.qr(instances.counter_normal(20240 + 1000003, np.arange(n * n, dtype=np.uint64)).reshape(n, n))
+    r = n // 4
+    ev = 1.0 + instances.counter_uniform(20240 + 2000003, np.arange(n, dtype=np.uint64))
+    Xs = (Q * np.where(np.arange(n) < r, ev, 0.0)) @ Q.T
+    Zs = (Q * np.where(np.arange(n) < r, 0.0, ev)) @ Q.T
+    ys = 2.0 * instances.counter_uniform(20240 + 3000003, np.arange(m, dtype=np.uint64)) - 1.0
+    s = gpu.Solver(0)
+    s.set_shape(m, [n], 0)
+    b = s.gen_planted(n, m, 20240, Xs, Zs, ys)
+    info = s.solve(gaptol=1e-5, feastol=1e-5)
+    y1, X1 = s.y(), s.X(0)
+    assert info.status == 0
+    opt = float(b @ ys)
+    assert abs(info.dobj - opt) <= TOL * (1 + abs(opt))
+    assert abs(info.pobj - opt) <= TOL * (1 + abs(opt))
+    A = s.get_block_dense(0)
+    Z = np.tensordot(y1, A[1:], axes=(0, 0)) - A[0]
+    assert np.linalg.eigvalsh(0.5 * (Z + Z.T))[0] >= -TOL                       # sdpsolchecker.c:201-257
+    assert np.max(np.abs(A[1:].reshape(m, -1) @ X1.reshape(-1) - b)) <= TOL * (1 + np.abs(b).max())
+    assert np.linalg.eigvalsh(X1)[0] >= -TOL
+    assert abs(np.sum(X1 * Z)) <= 10 * TOL * (1 + abs(opt))                     # complementarity
+    info2 = s.solve(gaptol=1e-5, feastol=1e-5)
+    assert np.array_equal(s.y(), y1) and info2.iterations == info.iterations    # deterministic reductions
+    lmin, viol = s.check_y(y1)
+    assert lmin[0] >= -TOL
+    s.close()

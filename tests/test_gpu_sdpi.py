@@ -1,0 +1,138 @@
+"""GPU tests at the drop-in boundary: the reference's SDPI known-answer tests (unittests/src/checksdpi.c) driven through
+SCIPsdpiSolverLoadAndSolve[WithPenalty] of libhipsdp.so with arguments prepared like sdpi.c does (oracle/sdpi_prepare.py),
+asserting what solveTest() asserts (checksdpi.c:125-364) at the same EPS = 1e-6."""
+import ctypes as C
+import json
+import os
+import numpy as np
+import pytest
+
+import sdpi_prepare
+import sdpi_call
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+CASES = json.load(open(os.path.join(GOLDEN, "checksdpi_cases.json")))
+EPS = CASES["eps"]
+
+
+def build(case):
+    blocks = [dict(n=b["n"], vars={int(k): [tuple(e) for e in v] for k, v in b["vars"].items()},
+                   const=[tuple(e) for e in b["const"]]) for b in case["blocks"]]
+    lp = [(l, r, {int(k): v for k, v in row.items()}) for (l, r, row) in case["lp"]]
+    return sdpi_prepare.SdpiProblem(case["obj"], case["lb"], case["ub"], blocks, lp)
+
+
+def new_solver(gpu):
+    s = sdpi_call.SdpiSolver(gpu.lib())
+    assert s.set_real(3, EPS) == sdpi_call.SCIP_OKAY      # SDPSOLVERFEASTOL, checksdpi.c:96
+    assert s.set_real(1, EPS) == sdpi_call.SCIP_OKAY      # GAPTOL, checksdpi.c:97
+    return s
+
+
+@pytest.mark.parametrize("case", CASES["cases"], ids=[c["name"] for c in CASES["cases"]])
+def test_checksdpi_through_the_solver_interface(gpu, case):
+    lib = gpu.lib()
+    lib.hipsdp_compat_mem_used.restype = C.c_longlong
+    base = lib.hipsdp_compat_mem_used()
+    exp = case["expect"]
+    tol = exp.get("tol", EPS)
+    P = sdpi_prepare.prepare(build(case))
+    s = new_solver(gpu)
+    rc, _, _ = s.solve(P)
+    assert rc == sdpi_call.SCIP_OKAY
+    assert s.flag("WasSolved") and not s.flag("IsObjlimExc") and not s.flag("IsIterlimExc") and not s.flag("IsTimelimExc")
+    assert s.flag("IsAcceptable") and s.flag("FeasibilityKnown")
+    rc, primalfeasible, dualfeasible = s.sol_feasibility()
+    assert rc == sdpi_call.SCIP_OKAY
+    pe, de = exp["primal"], exp["dual"]
+    if pe == "feas" and de == "feas":
+        assert s.flag("IsOptimal") and s.flag("IsDualFeasible") and not s.flag("IsDualInfeasible") and not s.flag("IsDualUnbounded")
+        assert s.flag("IsPrimalFeasible") and not s.flag("IsPrimalInfeasible") and not s.flag("IsPrimalUnbounded")
+        assert s.internal_status() == 0 and s.settings_used() == 1
+    if pe == "feas":
+        assert primalfeasible and s.flag("IsPrimalFeasible") and not s.flag("IsPrimalInfeasible") and not s.flag("IsDualUnbounded")
+    elif pe == "unbounded":
+        assert not s.flag("IsPrimalInfeasible") and not s.flag("IsDualFeasible") and s.flag("IsDualInfeasible")
+    elif pe == "infeas":
+        assert not primalfeasible and not s.flag("IsPrimalFeasible") and not s.flag("IsPrimalUnbounded")
+    if de == "feas":
+        assert dualfeasible and s.flag("IsDualFeasible") and not s.flag("IsDualInfeasible") and not s.flag("IsPrimalUnbounded")
+    elif de == "unbounded":
+        assert not s.flag("IsPrimalFeasible") and s.flag("IsPrimalInfeasible")
+    elif de == "infeas":
+        assert not dualfeasible and not s.flag("IsDualFeasible") and not s.flag("IsDualUnbounded")
+    if "dualsol" in exp:
+        rc, objval, y = s.dual_sol()
+        assert rc == sdpi_call.SCIP_OKAY
+        assert np.allclose(y, exp["dualsol"], atol=tol)
+        assert abs(objval - exp["objval"]) <= 10 * tol
+    rc, lbv, ubv = s.bound_vars()
+    assert rc == sdpi_call.SCIP_OKAY
+    rc, lhs, rhs = s.lp_sides()
+    assert rc == sdpi_call.SCIP_OKAY
+    lhsm, rhsm = sdpi_prepare.map_lp_sides(P, lhs, rhs, lbv, ubv)          # sdpi.c:4473-4605
+    if "lbvals" in exp:
+        assert np.allclose(lbv, exp["lbvals"], atol=tol)
+    if "lhsvals" in exp:
+        assert np.allclose(lhsm, exp["lhsvals"], atol=tol)
+    if "rhsvals" in exp:
+        assert np.allclose(rhsm, exp["rhsvals"], atol=tol)
+    if "X" in exp:
+        rc, mats = s.primal_solution_matrix()
+        assert rc == sdpi_call.SCIP_OKAY
+        assert np.allclose(mats[0], exp["X"], atol=10 * tol)
+        rc, sparse = s.primal_matrix_sparse()
+        assert rc == sdpi_call.SCIP_OKAY
+        dense = np.zeros_like(mats[0])
+        r, c, v = sparse[0]
+        dense[r, c] = v
+        dense[c, r] = v
+        assert np.allclose(dense, mats[0], atol=2e-9)        # entries below epsilon = 1e-9 are dropped
+        assert np.all(r >= c)
+    assert s.iterations() > 0 and s.sdpcalls() >= 1 and s.opttime() > 0
+    s.free()
+    assert lib.hipsdp_compat_mem_used() == base
+
+
+def test_fixed_variables_and_removed_indices(gpu):
+    """a node after branching: one variable fixed, one block index emptied, one block removed completely; X must come
+    back in ORIGINAL indices with zeros at the removed ones (sdpisolver_dsdp.c:2467-2545)"""
+    blocks = [dict(n=3, vars={0: [(0, 0, 1.0)], 1: [(1, 1, 1.0)], 2: [(2, 2, 1.0)]}, const=[(0, 0, 1.0), (1, 1, 2.0)]),
+              dict(n=2, vars={2: [(0, 0, 1.0), (1, 1, 1.0)]}, const=[])]
+    prob = sdpi_prepare.SdpiProblem([1, 1, 1], [-1e20, -1e20, 0.0], [1e20, 1e20, 0.0], blocks, [])   # y3 fixed to 0
+    P = sdpi_prepare.prepare(prob)
+    assert list(P.indchanges[0]) == [0, 0, -1] and P.blockindchanges == [0, -1]
+    s = new_solver(gpu)
+    rc, _, _ = s.solve(P)
+    assert rc == sdpi_call.SCIP_OKAY and s.flag("IsOptimal")
+    rc, obj, y = s.dual_sol()
+    assert np.allclose(y, [1.0, 2.0, 0.0], atol=1e-5) and abs(obj - 3.0) <= 1e-5
+    rc, mats = s.primal_solution_matrix()
+    assert np.allclose(mats[0], np.diag([1.0, 1.0, 0.0]), atol=1e-5)
+    assert np.all(mats[1] == 0.0)
+    s.free()
+
+
+def test_penalty_formulation(gpu):
+    """sdpi.c:3452 / :3521 call patterns: (Gamma = 1, withobj = F, rbound = F) feasibility problem and (Gamma, T, T)"""
+    case = [c for c in CASES["cases"] if c["name"] == "test10"][0]
+    P = sdpi_prepare.prepare(build(case))
+    s = new_solver(gpu)
+    rc, feasorig, pbound = s.solve(P, penaltyparam=1.0, withobj=False, rbound=False)
+    assert rc == sdpi_call.SCIP_OKAY and s.flag("IsAcceptable")
+    rc, obj, y = s.dual_sol()
+    assert obj <= 1e-5            # a feasible problem has a non-positive penalty optimum (sdpisolver.h:246-248)
+    rc, feasorig, pbound = s.solve(P, penaltyparam=1e5, withobj=True, rbound=True)
+    assert rc == sdpi_call.SCIP_OKAY and s.flag("IsOptimal")
+    assert feasorig and s.settings_used() == 0
+    rc, obj, y = s.dual_sol()
+    assert np.allclose(y, [1, 1], atol=1e-4) and abs(obj + 2.0) <= 1e-4
+    # infeasible problem (test9): r stays positive, the feasibility problem has a positive optimum
+    case9 = [c for c in CASES["cases"] if c["name"] == "test9"][0]
+    P9 = sdpi_prepare.prepare(build(case9))
+    rc, feasorig, pbound = s.solve(P9, penaltyparam=1.0, withobj=False, rbound=False)
+    assert rc == sdpi_call.SCIP_OKAY and s.flag("IsOptimal") and not feasorig
+    rc, obj, y = s.dual_sol()
+    assert obj > 1e-3
+    s.free()
