@@ -138,6 +138,8 @@ int  hipsdp_dgemm(int device, int layA, int layB, int M, int N, int K, double al
 /* Schur block Mx[(m1) x (m1)] = tr(A_i X A_j Zinv) for i, j = 0..m1-1 */
 int  hipsdp_schur_dense(int device, int m1, int n, const double* A, const double* X, const double* Zinv, double* Mx,
    double ws_gbytes);
+/* the same matrix through the W formulation (W_j = G A_j R, Mx = W W^T); takes X and Z, factors them on the device */
+int  hipsdp_schur_w(int device, int m1, int n, const double* A, const double* X, const double* Z, double* Mx);
 int  hipsdp_potrf(int device, int n, double* A, int* fail);                       /* lower Cholesky in place, row-major */
 int  hipsdp_potrs(int device, int n, const double* A, int nrhs, double* rhs);     /* factor + solve, rhs[k * n + i] */
 int  hipsdp_trtri(int device, int n, const double* A, double* Linv);              /* A spd -> inverse of its Cholesky factor */

@@ -199,6 +199,16 @@ def schur_dense(A, X, Zinv, ws_gbytes=0.0, device=0):
     return Mx
 
 
+def schur_w(A, X, Z, device=0):
+    A = _f64(A)
+    m1, n = A.shape[0], A.shape[1]
+    X = _f64(X)
+    Z = _f64(Z)
+    Mx = np.zeros((m1, m1))
+    _chk(lib().hipsdp_schur_w(device, m1, n, _dp(A), _dp(X), _dp(Z), _dp(Mx)), "hipsdp_schur_w")
+    return Mx
+
+
 def potrf(A, device=0):
     L = _f64(A).copy()
     fail = C.c_int(0)

@@ -14,31 +14,43 @@
 #define HS_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if ( e_ != hipSuccess ) { hs_record_hip_error(e_, "kernel launch", __FILE__, __LINE__); return HS_ERR_HIP; } } while (0)
 
 /* Factor the nb x nb diagonal block at A (leading dimension lda), nb <= 64: A_blk = L L^T.  Writes L into the lower
- * triangle of the block and inv(L) (64 x 64, identity-padded) into dinv.  flag: first failing global pivot index + 1. */
+ * triangle of the block and inv(L) (64 x 64, identity-padded) into dinv.  flag: first failing global pivot index + 1.
+ *
+ * Thread t owns row i = t / 4 and the 16 columns j = (t % 4) + 4 jj in registers; column k is published through a
+ * double-buffered LDS vector, so a step costs one barrier.  All loops are fully unrolled (static register indices).
+ * The inverse is then formed by one wavefront, lane c = column c, right-looking so that the 63 - i updates of a step are
+ * independent instructions. */
 __global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ A, long long lda, int nb, int j0,
    double* __restrict__ dinv, int* __restrict__ flag, const double* __restrict__ diag0, double regtol)
 {
-   __shared__ double a[NB][NB + 1];
-   __shared__ double li[NB][NB + 1];
-   __shared__ int bad;
+   __shared__ double col[2][NB];
+   __shared__ double lm[NB][NB + 1];      /* final L (scaled), read by the inverse */
+   __shared__ double invd[NB];
    const int tid = threadIdx.x;
-   if ( tid == 0 )
-      bad = 0;
-   for (int e = tid; e < NB * NB; e += 256)
+   const int i = tid >> 2;
+   const int jc = tid & 3;
+   double r[16];
+#pragma unroll
+   for (int jj = 0; jj < 16; ++jj)
    {
-      const int r = e / NB, c = e % NB;
-      double v = (r == c) ? 1.0 : 0.0;
-      if ( r < nb && c < nb && c <= r )
-         v = A[(long long) r * lda + c];
-      a[r][c] = v;
+      const int j = jc + 4 * jj;
+      double v = (i == j) ? 1.0 : 0.0;
+      if ( i < nb && j <= i )
+         v = A[(long long) i * lda + j];
+      r[jj] = v;
    }
-   __syncthreads();
+   int bad = 0;
 
-   for (int k = 0; k < nb; ++k)
+#pragma unroll
+   for (int k = 0; k < NB; ++k)
    {
-      if ( tid == 0 )
+      /* owners of column k publish it (rows >= k) */
+      if ( jc == (k & 3) && i >= k )
+         col[k & 1][i] = r[k >> 2];
+      __syncthreads();
+      double d = col[k & 1][k];
+      if ( k < nb )
       {
-         double d = a[k][k];
          if ( diag0 != NULL )
          {
             /* semidefinite mode (Schur complement with dependent columns): a pivot that cancelled to rounding level is
@@ -53,48 +65,58 @@ __global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ A, long
                bad = j0 + k + 1;
             d = 1.0;                 /* keep going with a harmless pivot; the caller reads the flag */
          }
-         a[k][k] = sqrt(d);
       }
-      __syncthreads();
-      const double dk = a[k][k];
-      for (int i = k + 1 + tid; i < nb; i += 256)
-         a[i][k] /= dk;
-      __syncthreads();
-      /* trailing update of the lower triangle */
-      const int rem = nb - k - 1;
-      for (int e = tid; e < rem * rem; e += 256)
+      const double sd = sqrt(d);
+      const double isd = 1.0 / sd;
+      const double lik = (i > k) ? col[k & 1][i] * isd : 0.0;
+      if ( jc == (k & 3) )
       {
-         const int i = k + 1 + e / rem;
-         const int j = k + 1 + e % rem;
-         if ( j <= i )
-            a[i][j] -= a[i][k] * a[j][k];
+         /* final value of column k in my row */
+         const double lv = (i > k) ? lik : ((i == k) ? sd : 0.0);
+         r[k >> 2] = lv;
+         lm[i][k] = lv;
+         if ( i == k )
+            invd[k] = isd;
       }
-      __syncthreads();
-   }
-
-   /* inverse by forward substitution, one column per thread */
-   if ( tid < NB )
-   {
-      const int c = tid;
-      for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int jj = (k >> 2); jj < 16; ++jj)
       {
-         double s = (i == c) ? 1.0 : 0.0;
-         for (int k = c; k < i; ++k)
-            s -= a[i][k] * li[k][c];
-         li[i][c] = (i < c) ? 0.0 : s / a[i][i];
+         const int j = jc + 4 * jj;
+         if ( j > k && j <= i )
+            r[jj] -= lik * (col[k & 1][j] * isd);
       }
    }
    __syncthreads();
 
-   for (int e = tid; e < NB * NB; e += 256)
+   /* write L back */
+#pragma unroll
+   for (int jj = 0; jj < 16; ++jj)
    {
-      const int r = e / NB, c = e % NB;
-      dinv[e] = li[r][c];
-      if ( r < nb && c <= r )
-         A[(long long) r * lda + c] = a[r][c];
+      const int j = jc + 4 * jj;
+      if ( i < nb && j <= i )
+         A[(long long) i * lda + j] = r[jj];
    }
    if ( tid == 0 && bad != 0 )
       atomicCAS(flag, 0, bad);
+
+   /* inverse: lane c solves L x = e_c */
+   if ( tid < NB )
+   {
+      const int c = tid;
+      double sv[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+         sv[j] = (j == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int ii = 0; ii < NB; ++ii)
+      {
+         const double xi = sv[ii] * invd[ii];
+         dinv[ii * NB + c] = xi;
+#pragma unroll
+         for (int j = ii + 1; j < NB; ++j)
+            sv[j] -= lm[j][ii] * xi;
+      }
+   }
 }
 
 int hs_potrf(hipStream_t s, int n, double* A, double* dinv, int* flag, const double* diag0)

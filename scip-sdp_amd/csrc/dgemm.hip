@@ -142,15 +142,44 @@ __global__ void __launch_bounds__(256, 2) hs_dgemm_kernel(hs_gemm_args p, int kc
    const int wm   = wave >> 1;
    const int wn   = wave & 1;
 
-   const int m0 = blockIdx.x * BT;
-   const int n0 = blockIdx.y * BT;
+   int m0, n0, bz, ks0 = 0, kend = p.K;
+   if ( p.flags & HS_GEMM_XCD )
+   {
+      /* linear block id -> (xcd, sub-slice, tile): all workgroups with the same id % 8 (one XCD under round-robin
+       * dispatch; a speed assumption only) own the K slices [xcd * c, xcd * c + c) */
+      const int c = p.splitk >> 3;
+      const int b = blockIdx.x;
+      const int xcd = b & 7;
+      const int rest = b >> 3;
+      const int sub = rest % c;
+      int t = rest / c;
+      int ti, tj;
+      if ( p.flags & HS_GEMM_LOWER )
+      {
+         ti = (int) ((sqrt(8.0 * (double) t + 1.0) - 1.0) * 0.5);
+         while ( (ti + 1) * (ti + 2) / 2 <= t ) ++ti;
+         while ( ti * (ti + 1) / 2 > t ) --ti;
+         tj = t - ti * (ti + 1) / 2;
+      }
+      else
+      {
+         const int tn = (p.N + BT - 1) / BT;
+         ti = t / tn;
+         tj = t - ti * tn;
+      }
+      m0 = ti * BT;
+      n0 = tj * BT;
+      bz = xcd * c + sub;
+   }
+   else
+   {
+      m0 = blockIdx.x * BT;
+      n0 = blockIdx.y * BT;
+      bz = blockIdx.z;
+      if ( (p.flags & HS_GEMM_LOWER) && (m0 + BT - 1 < n0) )
+         return;
+   }
 
-   if ( (p.flags & HS_GEMM_LOWER) && (m0 + BT - 1 < n0) )
-      return;
-
-   int bz = blockIdx.z;
-   int ks0 = 0;
-   int kend = p.K;
    double* C = p.C;
    long long ldc = p.ldc;
    double alpha = p.alpha;
@@ -165,6 +194,10 @@ __global__ void __launch_bounds__(256, 2) hs_dgemm_kernel(hs_gemm_args p, int kc
       beta = 0.0;
       bz = 0;
    }
+   if ( p.flags & HS_GEMM_B_LOWTRI )
+      ks0 = max(ks0, (n0 / HS_BK) * HS_BK);
+   if ( p.flags & HS_GEMM_A_LOWTRI )
+      kend = min(kend, m0 + BT);
    const double* A = p.A + (long long) bz * p.strideA;
    const double* B = p.B + (long long) bz * p.strideB;
    C += (long long) bz * p.strideC;
@@ -289,6 +322,12 @@ static int launch_cfg(hipStream_t stream, const hs_gemm_args* a, int kchunk)
       attr_set = true;
    }
    dim3 grid((a->M + BT - 1) / BT, (a->N + BT - 1) / BT, a->splitk > 1 ? a->splitk : a->batch);
+   if ( a->flags & HS_GEMM_XCD )
+   {
+      const long long tm = (a->M + BT - 1) / BT, tn = (a->N + BT - 1) / BT;
+      const long long nt = (a->flags & HS_GEMM_LOWER) ? tm * (tm + 1) / 2 : tm * tn;
+      grid = dim3((unsigned) (nt * a->splitk), 1, 1);
+   }
    hipLaunchKernelGGL((hs_dgemm_kernel<BT, LA, LB>), grid, dim3(256), smem, stream, *a, kchunk);
    HS_HIP( hipGetLastError() );
    return HS_OK;
@@ -325,10 +364,12 @@ int hs_dgemm(hipStream_t stream, const hs_gemm_args* a)
       return HS_OK;
    if ( a->splitk > 1 && (a->batch != 1 || a->ws == NULL) )
       return HS_ERR_ARG;
+   if ( (a->flags & HS_GEMM_XCD) && (a->splitk < 8 || (a->splitk & 7) != 0 || ((a->flags & HS_GEMM_LOWER) && a->M != a->N)) )
+      return HS_ERR_ARG;
 
    /* tile choice: big tiles once they fill the chip, small tiles otherwise */
    const long long big = (long long) ((a->M + 127) / 128) * ((a->N + 127) / 128) * (a->splitk > 1 ? a->splitk : a->batch);
-   const bool useBig = big >= 192;
+   const bool useBig = big >= 192 || (a->flags & HS_GEMM_XCD);
    const int BT = useBig ? 128 : 64;
 
    int kchunk = a->K;

@@ -43,7 +43,11 @@ const char* hs_last_error(void);
 #define HS_KC 0
 #define HS_MC 1
 
-#define HS_GEMM_LOWER   1   /* compute only tiles that touch the lower triangle (row >= col) of C */
+#define HS_GEMM_LOWER     1   /* compute only tiles that touch the lower triangle (row >= col) of C */
+#define HS_GEMM_A_LOWTRI  2   /* A[m][k] = 0 for k > m (lower triangular left factor): tiles stop at k = m0 + tile */
+#define HS_GEMM_B_LOWTRI  4   /* B[k][n] = 0 for k < n (lower triangular right factor): tiles start at k = n0 */
+#define HS_GEMM_XCD       8   /* split-K only: workgroups that share an XCD (blockIdx % 8) walk the same K range, so the
+                               * operand panels are fetched from HBM once per XCD and re-used from its L2 */
 
 struct hs_gemm_args
 {

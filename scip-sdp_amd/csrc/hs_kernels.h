@@ -39,6 +39,27 @@ int hs_lp_scale_rows(hipStream_t s, int q, int cols, const double* x, const doub
 int hs_vec_mul(hipStream_t s, long long n, const double* a, const double* b, double* out);   /* out = a .* b */
 int hs_lp_s0(hipStream_t s, int q, const double* x, const double* z, const double* beta, double* out, int accumulate, double* ws); /* sum (x/z) beta^2 */
 
+int hs_zero_upper(hipStream_t s, double* A, int n);                                         /* A[i][j] = 0 for i < j */
+
+/* ---- schur.hip ------------------------------------------------------------------------------------------------ */
+struct hs_schur_ws
+{
+   double*   T;            /* chunk_cols x n^2 */
+   double*   U;            /* chunk_cols x n^2 */
+   double*   K;            /* split-K slabs */
+   long long chunk_cols;
+   long long kws_len;
+   int       full;         /* 1: T and U hold all m1 matrices (hs_schur_W usable) */
+};
+int  hs_schur_ws_alloc(hs_schur_ws* w, int m1, long long n2max, double budget_gb);
+void hs_schur_ws_free(hs_schur_ws* w);
+/* accumulate the lower triangle of Mx (ld m1) for the columns [j_begin, j_end) with U_j = X A_j Zinv */
+int  hs_schur_U(hipStream_t s, int m1, int n, const double* A, const double* X, const double* Zinv, double* Mx,
+   hs_schur_ws* w, int j_begin, int j_end);
+/* accumulate the lower triangle of Mx with W_j = G A_j R (R: lower Cholesky factor of X with a ZERO upper triangle,
+ * G: inverse of the lower Cholesky factor of Z) */
+int  hs_schur_W(hipStream_t s, int m1, int n, const double* A, const double* R, const double* G, double* Mx, hs_schur_ws* w);
+
 /* ---- chol.hip ------------------------------------------------------------------------------------------------- */
 /* In-place blocked Cholesky of the lower triangle of the row-major n x n matrix A (lda = n): A = L L^T, L stored in the
  * lower triangle (upper triangle is left untouched).  dinv receives the inverses of the 64 x 64 diagonal blocks of L

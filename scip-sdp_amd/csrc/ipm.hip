@@ -76,8 +76,8 @@ struct hipsdp_solver
    double *sc, *red_ws, *gemv_ws, *lan_ws;
    long long gemv_ws_len;
    int* flags;       /* device ints: 0 chol Z, 1 chol X, 2 chol M */
-   double *Tws, *Uws, *Kws;
-   long long chunk_cols, kws_len;
+   hs_schur_ws sws;
+   bool schur_mode_U;
    int nsc;
    bool shaped, solved, have_start;
    int last_status;
@@ -147,12 +147,13 @@ static void free_problem(hipsdp_solver* s)
    s->blk.clear();
    double* ptrs[] = {s->b, s->Dext, s->y, s->x, s->z, s->yt, s->dyt, s->wt, s->AX, s->AH, s->tmpe, s->rp, s->rd, s->tmpq, s->hl,
       s->beta, s->elp, s->dxa, s->dza, s->dx, s->dz, s->xs, s->zs, s->ys, s->u1, s->rhs2, s->u2, s->dy, s->dya, s->Mx, s->Lm,
-      s->dinvm, s->Slp, s->sc, s->red_ws, s->gemv_ws, s->lan_ws, s->Tws, s->Uws, s->Kws};
+      s->dinvm, s->Slp, s->sc, s->red_ws, s->gemv_ws, s->lan_ws};
    for (double* p : ptrs) dfree(p);
+   hs_schur_ws_free(&s->sws);
    dfree(s->flags);
    s->b = s->Dext = s->y = s->x = s->z = s->yt = s->dyt = s->wt = s->AX = s->AH = s->tmpe = s->rp = s->rd = s->tmpq = s->hl = NULL;
    s->beta = s->elp = s->dxa = s->dza = s->dx = s->dz = s->xs = s->zs = s->ys = s->u1 = s->rhs2 = s->u2 = s->dy = s->dya = NULL;
-   s->Mx = s->Lm = s->dinvm = s->Slp = s->sc = s->red_ws = s->gemv_ws = s->lan_ws = s->Tws = s->Uws = s->Kws = NULL;
+   s->Mx = s->Lm = s->dinvm = s->Slp = s->sc = s->red_ws = s->gemv_ws = s->lan_ws = NULL;
    s->flags = NULL;
    s->shaped = false;
    s->solved = false;
@@ -182,7 +183,7 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
    s->sol_scale = 1.0;
    s->b = s->Dext = s->y = s->x = s->z = s->yt = s->dyt = s->wt = s->AX = s->AH = s->tmpe = s->rp = s->rd = s->tmpq = s->hl = NULL;
    s->beta = s->elp = s->dxa = s->dza = s->dx = s->dz = s->xs = s->zs = s->ys = s->u1 = s->rhs2 = s->u2 = s->dy = s->dya = NULL;
-   s->Mx = s->Lm = s->dinvm = s->Slp = s->sc = s->red_ws = s->gemv_ws = s->lan_ws = s->Tws = s->Uws = s->Kws = NULL;
+   s->Mx = s->Lm = s->dinvm = s->Slp = s->sc = s->red_ws = s->gemv_ws = s->lan_ws = NULL;
    hipsdp_default_params(&s->par);
    if ( hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess
       || hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess )
@@ -264,9 +265,7 @@ extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int*
    HS_CALL( dalloc(&s->gemv_ws, s->gemv_ws_len) );
    HS_CALL( dalloc(&s->lan_ws, hs_lanczos_ws(nmax, 256)) );
    HS_CALL( dalloc(&s->flags, 8) );
-   s->Tws = s->Uws = s->Kws = NULL;
-   s->chunk_cols = 0;
-   s->kws_len = 0;
+   s->sws.T = s->sws.U = s->sws.K = NULL;
    HS_HIP( hipMemsetAsync(s->Dext, 0, (size_t) ((long long) q * m1 > 0 ? (long long) q * m1 : 1) * sizeof(double), s->stream) );
    HS_HIP( hipMemsetAsync(s->b, 0, (size_t) (m > 0 ? m : 1) * sizeof(double), s->stream) );
    HS_HIP( hipStreamSynchronize(s->stream) );
@@ -514,68 +513,21 @@ static int gemm(hipsdp_solver* s, int layA, int layB, int M, int N, int K, doubl
    return hs_dgemm(s->stream, &g);
 }
 
-/* ---- Schur assembly of one block into Mx (lower triangle, accumulating) ----------------------------------------- */
+/* ---- Schur workspace ------------------------------------------------------------------------------------------------ */
 static int ensure_schur_ws(hipsdp_solver* s)
 {
-   if ( s->Tws != NULL )
+   if ( s->sws.T != NULL )
       return HS_OK;
-   const long long m1 = s->m + 1;
+   const int m1 = s->m + 1;
    long long n2max = 1;
    for (auto& B : s->blk) { const long long n2 = (long long) B.n * B.n; if ( n2 > n2max ) n2max = n2; }
-   double budget = s->par.ws_gbytes > 0.0 ? s->par.ws_gbytes : 24.0;
+   double budget = s->par.ws_gbytes > 0.0 ? s->par.ws_gbytes : 40.0;
    const char* env = getenv("HIPSDP_WS_GB");
    if ( env != NULL && atof(env) > 0.0 )
       budget = atof(env);
-   long long cols = (long long) (budget * 1e9 / (2.0 * 8.0 * (double) n2max));
-   if ( cols >= m1 )
-      cols = m1;
-   else
-   {
-      cols = (cols / 128) * 128;
-      if ( cols < 128 ) cols = 128;
-      if ( cols > m1 ) cols = m1;
-   }
-   s->chunk_cols = cols;
-   HS_CALL( dalloc(&s->Tws, cols * n2max) );
-   HS_CALL( dalloc(&s->Uws, cols * n2max) );
-   /* split-K slabs of GEMM3 */
-   int sk = hs_dgemm_pick_splitk((int) m1, (int) cols, (int) (n2max > 2000000000LL ? 2000000000LL : n2max), 1);
-   s->kws_len = (long long) sk * m1 * cols;
-   HS_CALL( dalloc(&s->Kws, s->kws_len) );
-   return HS_OK;
-}
-
-static int schur_block(hipsdp_solver* s, Block& B, int j_begin, int j_end)
-{
-   const int m1 = s->m + 1;
-   const int n = B.n;
-   const long long n2 = (long long) n * n;
-   for (int j0 = j_begin; j0 < j_end; j0 += (int) s->chunk_cols)
-   {
-      const int cj = (j_end - j0) < s->chunk_cols ? (j_end - j0) : (int) s->chunk_cols;
-      /* GEMM1: T[(cj n) x n] = A[j0 .. j0 + cj) (stack of n x n) * Zinv */
-      {
-         const long long rows = (long long) cj * n;
-         if ( rows > 2000000000LL ) return HS_ERR_ARG;
-         hs_gemm_args g = {(int) rows, n, n, HS_KC, HS_MC, B.A + (long long) j0 * n2, n, 0, B.Zinv, n, 0, s->Tws, n, 0, 1.0, 0.0, 1, 0, 1, NULL};
-         HS_CALL( hs_dgemm(s->stream, &g) );
-      }
-      /* GEMM2: U_j = X * T_j, batched over the cj matrices of the chunk */
-      {
-         hs_gemm_args g = {n, n, n, HS_KC, HS_MC, B.X, n, 0, s->Tws, n, n2, s->Uws, n, n2, 1.0, 0.0, cj, 0, 1, NULL};
-         HS_CALL( hs_dgemm(s->stream, &g) );
-      }
-      /* GEMM3: Mx[j0:, j0:j0+cj] += A_flat[j0:] * U_flat^T   (rows i >= j0 only: lower triangle) */
-      {
-         const int rows = m1 - j0;
-         if ( n2 > 2000000000LL ) return HS_ERR_ARG;
-         int sk = hs_dgemm_pick_splitk(rows, cj, (int) n2, 1);
-         while ( sk > 1 && (long long) sk * rows * cj > s->kws_len ) --sk;
-         hs_gemm_args g = {rows, cj, (int) n2, HS_KC, HS_KC, B.A + (long long) j0 * n2, n2, 0, s->Uws, n2, 0,
-            s->Mx + (long long) j0 * m1 + j0, m1, 0, 1.0, 1.0, 1, HS_GEMM_LOWER, sk, s->Kws};
-         HS_CALL( hs_dgemm(s->stream, &g) );
-      }
-   }
+   HS_CALL( hs_schur_ws_alloc(&s->sws, m1, n2max, budget) );
+   const char* mode = getenv("HIPSDP_SCHUR");
+   s->schur_mode_U = (mode != NULL && mode[0] == 'U') || !s->sws.full || s->nranks > 1;
    return HS_OK;
 }
 
@@ -935,6 +887,7 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
          HS_CALL( hs_mirror_lower(st, B.Zinv, n, n) );
          HS_CALL( hs_copy(st, B.Lx, B.X, n2) );
          HS_CALL( hs_potrf(st, n, B.Lx, B.dinvx, s->flags + 1, NULL) );
+         HS_CALL( hs_zero_upper(st, B.Lx, n) );
          HS_CALL( hs_trtri(st, n, B.Lx, B.dinvx, B.LxInv, B.T1) );
       }
 
@@ -942,7 +895,12 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       HS_HIP( hipEventRecord(s->ev0, st) );
       HS_CALL( hs_fill(st, s->Mx, (long long) m1 * m1, 0.0) );
       for (auto& B : s->blk)
-         HS_CALL( schur_block(s, B, 0, m1) );
+      {
+         if ( s->schur_mode_U )
+            HS_CALL( hs_schur_U(st, m1, B.n, B.A, B.X, B.Zinv, s->Mx, &s->sws, 0, m1) );
+         else
+            HS_CALL( hs_schur_W(st, m1, B.n, B.A, B.Lx, B.LzInv, s->Mx, &s->sws) );
+      }
       if ( q > 0 )
       {
          HS_CALL( hs_lp_scale_rows(st, q, m1, s->x, s->z, s->Dext, s->Slp) );

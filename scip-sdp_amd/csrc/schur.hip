@@ -1,0 +1,124 @@
+/* schur.hip - assembly of the (extended) Schur complement of one dense block,
+ *
+ *      Mx[i][j] = tr(A_i X A_j Z^-1),   i, j = 0 .. m1 - 1        (row 0 = constant matrix A_0, rows 1.. = variables)
+ *
+ * as FP64-MFMA GEMMs over the row storage A[m1][n^2].  This is the step north_star names first; in the reference it happens
+ * inside DSDP/SDPA (sdpisolver_dsdp.c:1503, sdpisolver_sdpa.cpp:1620).  Two formulations:
+ *
+ *  hs_schur_W  (single GPU, needs 2 m1 n^2 doubles of workspace):  with X = R R^T (R = chol X) and Z^-1 = G^T G
+ *              (G = inverse Cholesky factor of Z)        W_j = G A_j R,      Mx = W W^T   (SYRK over K = n^2)
+ *              GEMM1  T = [A_0; ..; A_m] R        one (m1 n) x n x n product, R lower triangular: K range starts at n0
+ *              GEMM2  W_j = G T_j                 batched, G lower triangular: K range ends at m0 + tile
+ *              GEMM3  Mx += W W^T                 lower tiles only; K is cut into 8c slices, the workgroups of one XCD
+ *                                                 walk the same slice so W is read from HBM once, then served by L2
+ *  hs_schur_U  (chunked over variables, shards over GPUs)          U_j = X A_j Z^-1,   Mx[:, J] = A_flat U_J^T
+ *              only the rows/columns of a chunk J are needed at a time: a rank computes its J and the row blocks are
+ *              all-gathered (multi.hip); workspace 2 |J| n^2.
+ *
+ * Algorithmic flops per assembly: 4 m1 n^3 + m1^2 n^2.
+ */
+#include "hs_kernels.h"
+
+int hs_schur_ws_alloc(hs_schur_ws* w, int m1, long long n2max, double budget_gb)
+{
+   w->T = w->U = w->K = NULL;
+   const double need_full = 2.0 * 8.0 * (double) m1 * (double) n2max;
+   long long cols = m1;
+   w->full = 1;
+   if ( need_full > budget_gb * 1e9 )
+   {
+      w->full = 0;
+      cols = (long long) (budget_gb * 1e9 / (2.0 * 8.0 * (double) n2max));
+      cols = (cols / 128) * 128;
+      if ( cols < 128 ) cols = 128;
+      if ( cols > m1 ) cols = m1;
+   }
+   w->chunk_cols = cols;
+   hipError_t e = hipMalloc((void**) &w->T, (size_t) (cols * n2max) * sizeof(double));
+   if ( e == hipSuccess ) e = hipMalloc((void**) &w->U, (size_t) (cols * n2max) * sizeof(double));
+   if ( e != hipSuccess )
+   {
+      hs_record_hip_error(e, "hipMalloc(schur workspace)", __FILE__, __LINE__);
+      return e == hipErrorOutOfMemory ? HS_ERR_NOMEM : HS_ERR_HIP;
+   }
+   int sk = hs_dgemm_pick_splitk(m1, (int) cols, (int) (n2max > 2000000000LL ? 2000000000LL : n2max), 1);
+   if ( sk < 16 ) sk = 16;
+   w->kws_len = (long long) sk * m1 * (w->full ? m1 : cols);
+   e = hipMalloc((void**) &w->K, (size_t) w->kws_len * sizeof(double));
+   if ( e != hipSuccess )
+   {
+      hs_record_hip_error(e, "hipMalloc(split-K slabs)", __FILE__, __LINE__);
+      return e == hipErrorOutOfMemory ? HS_ERR_NOMEM : HS_ERR_HIP;
+   }
+   return HS_OK;
+}
+
+void hs_schur_ws_free(hs_schur_ws* w)
+{
+   if ( w->T ) (void) hipFree(w->T);
+   if ( w->U ) (void) hipFree(w->U);
+   if ( w->K ) (void) hipFree(w->K);
+   w->T = w->U = w->K = NULL;
+}
+
+int hs_schur_U(hipStream_t s, int m1, int n, const double* A, const double* X, const double* Zinv, double* Mx,
+   hs_schur_ws* w, int j_begin, int j_end)
+{
+   const long long n2 = (long long) n * n;
+   if ( n2 > 2000000000LL )
+      return HS_ERR_ARG;
+   for (int j0 = j_begin; j0 < j_end; j0 += (int) w->chunk_cols)
+   {
+      const int cj = (j_end - j0) < w->chunk_cols ? (j_end - j0) : (int) w->chunk_cols;
+      const long long rows = (long long) cj * n;
+      if ( rows > 2000000000LL )
+         return HS_ERR_ARG;
+      /* GEMM1: T[(cj n) x n] = A[j0 .. j0 + cj) (stack of n x n) * Zinv */
+      hs_gemm_args g1 = {(int) rows, n, n, HS_KC, HS_MC, A + (long long) j0 * n2, n, 0, Zinv, n, 0, w->T, n, 0, 1.0, 0.0, 1, 0, 1, NULL};
+      HS_CALL( hs_dgemm(s, &g1) );
+      /* GEMM2: U_j = X * T_j, batched over the cj matrices of the chunk */
+      hs_gemm_args g2 = {n, n, n, HS_KC, HS_MC, X, n, 0, w->T, n, n2, w->U, n, n2, 1.0, 0.0, cj, 0, 1, NULL};
+      HS_CALL( hs_dgemm(s, &g2) );
+      /* GEMM3: Mx[j0:, j0:j0+cj] += A_flat[j0:] * U_flat^T   (rows i >= j0 only: lower triangle) */
+      const int rowsM = m1 - j0;
+      int sk = hs_dgemm_pick_splitk(rowsM, cj, (int) n2, 1);
+      while ( sk > 1 && (long long) sk * rowsM * cj > w->kws_len ) --sk;
+      hs_gemm_args g3 = {rowsM, cj, (int) n2, HS_KC, HS_KC, A + (long long) j0 * n2, n2, 0, w->U, n2, 0,
+         Mx + (long long) j0 * m1 + j0, m1, 0, 1.0, 1.0, 1, HS_GEMM_LOWER, sk, w->K};
+      HS_CALL( hs_dgemm(s, &g3) );
+   }
+   return HS_OK;
+}
+
+int hs_schur_W(hipStream_t s, int m1, int n, const double* A, const double* R, const double* G, double* Mx, hs_schur_ws* w)
+{
+   const long long n2 = (long long) n * n;
+   const long long rows = (long long) m1 * n;
+   if ( !w->full || n2 > 2000000000LL || rows > 2000000000LL )
+      return HS_ERR_ARG;
+   /* GEMM1: T = A_stack * R, R lower triangular */
+   hs_gemm_args g1 = {(int) rows, n, n, HS_KC, HS_MC, A, n, 0, R, n, 0, w->T, n, 0, 1.0, 0.0, 1, HS_GEMM_B_LOWTRI, 1, NULL};
+   HS_CALL( hs_dgemm(s, &g1) );
+   /* GEMM2: W_j = G * T_j, G lower triangular */
+   hs_gemm_args g2 = {n, n, n, HS_KC, HS_MC, G, n, 0, w->T, n, n2, w->U, n, n2, 1.0, 0.0, m1, HS_GEMM_A_LOWTRI, 1, NULL};
+   HS_CALL( hs_dgemm(s, &g2) );
+   /* GEMM3: Mx += W W^T on the lower tiles */
+   int flags = HS_GEMM_LOWER;
+   int sk;
+   if ( m1 >= 256 && n2 >= 16384 )
+   {
+      const long long tm = (m1 + 127) / 128;
+      const long long ntri = tm * (tm + 1) / 2;
+      sk = (ntri * 8 >= 448) ? 8 : 16;
+      while ( sk > 8 && (long long) sk * m1 * m1 > w->kws_len ) sk -= 8;
+      flags |= HS_GEMM_XCD;
+   }
+   else
+   {
+      sk = hs_dgemm_pick_splitk(m1, m1, (int) n2, 1);
+      while ( sk > 1 && (long long) sk * m1 * m1 > w->kws_len ) --sk;
+   }
+   hs_gemm_args g3 = {m1, m1, (int) n2, HS_KC, HS_KC, w->U, n2, 0, w->U, n2, 0, Mx, m1, 0, 1.0, 1.0, 1, flags, sk, w->K};
+   HS_CALL( hs_dgemm(s, &g3) );
+   return HS_OK;
+}

@@ -58,38 +58,59 @@ extern "C" int hipsdp_dgemm(int device, int layA, int layB, int M, int N, int K,
 extern "C" int hipsdp_schur_dense(int device, int m1, int n, const double* A, const double* X, const double* Zinv, double* Mx,
    double ws_gbytes)
 {
+   /* ws_gbytes > 0: the chunked U formulation with that budget; ws_gbytes <= 0: the W formulation (needs chol X and the
+    * inverse Cholesky factor of Z, both formed here on the device from X and Zinv^-1... the caller passes Zinv, so Z^-1 = G^T G
+    * is obtained from the Cholesky factor of Zinv: Zinv = C C^T  ->  G = C^T is upper; to stay with lower factors the W
+    * path is exercised through hipsdp_schur_w below) */
    HS_CALL( pick_device(device) );
    const long long n2 = (long long) n * n;
-   DevBuf dA, dX, dZ, dM, dT, dU, dK;
+   DevBuf dA, dX, dZ, dM;
    HS_CALL( dA.alloc(m1 * n2) ); HS_CALL( dX.alloc(n2) ); HS_CALL( dZ.alloc(n2) ); HS_CALL( dM.alloc((long long) m1 * m1) );
    HS_CALL( dA.up(A, m1 * n2) ); HS_CALL( dX.up(X, n2) ); HS_CALL( dZ.up(Zinv, n2) );
-   long long cols = m1;
-   if ( ws_gbytes > 0.0 )
+   hs_schur_ws w;
+   HS_CALL( hs_schur_ws_alloc(&w, m1, n2, ws_gbytes > 0.0 ? ws_gbytes : 1e9) );
+   if ( ws_gbytes > 0.0 && w.chunk_cols > 1 )
    {
-      cols = (long long) (ws_gbytes * 1e9 / (16.0 * (double) n2));
+      /* allow chunks smaller than the 128 granularity of the engine so that tiny tests exercise the chunk loop */
+      long long cols = (long long) (ws_gbytes * 1e9 / (16.0 * (double) n2));
       if ( cols < 1 ) cols = 1;
-      if ( cols > m1 ) cols = m1;
+      if ( cols < w.chunk_cols ) w.chunk_cols = cols;
    }
-   HS_CALL( dT.alloc(cols * n2) ); HS_CALL( dU.alloc(cols * n2) );
-   int skmax = hs_dgemm_pick_splitk(m1, (int) cols, (int) n2, 1);
-   HS_CALL( dK.alloc((long long) skmax * m1 * cols) );
    HS_CALL( hs_fill(0, dM.p, (long long) m1 * m1, 0.0) );
-   for (int j0 = 0; j0 < m1; j0 += (int) cols)
-   {
-      const int cj = (m1 - j0) < cols ? (m1 - j0) : (int) cols;
-      hs_gemm_args g1 = {cj * n, n, n, HS_KC, HS_MC, dA.p + (long long) j0 * n2, n, 0, dZ.p, n, 0, dT.p, n, 0, 1.0, 0.0, 1, 0, 1, NULL};
-      HS_CALL( hs_dgemm(0, &g1) );
-      hs_gemm_args g2 = {n, n, n, HS_KC, HS_MC, dX.p, n, 0, dT.p, n, n2, dU.p, n, n2, 1.0, 0.0, cj, 0, 1, NULL};
-      HS_CALL( hs_dgemm(0, &g2) );
-      const int rows = m1 - j0;
-      int sk = hs_dgemm_pick_splitk(rows, cj, (int) n2, 1);
-      if ( sk > skmax ) sk = skmax;
-      hs_gemm_args g3 = {rows, cj, (int) n2, HS_KC, HS_KC, dA.p + (long long) j0 * n2, n2, 0, dU.p, n2, 0, dM.p + (long long) j0 * m1 + j0, m1, 0,
-         1.0, 1.0, 1, HS_GEMM_LOWER, sk, dK.p};
-      HS_CALL( hs_dgemm(0, &g3) );
-   }
-   HS_CALL( hs_mirror_lower(0, dM.p, m1, m1) );
-   HS_HIP( hipDeviceSynchronize() );
+   int rc = hs_schur_U(0, m1, n, dA.p, dX.p, dZ.p, dM.p, &w, 0, m1);
+   if ( rc == HS_OK ) rc = hs_mirror_lower(0, dM.p, m1, m1);
+   if ( rc == HS_OK && hipDeviceSynchronize() != hipSuccess ) rc = HS_ERR_HIP;
+   hs_schur_ws_free(&w);
+   HS_CALL( rc );
+   HS_CALL( dM.down(Mx, (long long) m1 * m1) );
+   return HIPSDP_OK;
+}
+
+/* W formulation: X and Z (not its inverse) are given; chol(X), chol(Z), inverse factor and the three GEMMs on the device */
+extern "C" int hipsdp_schur_w(int device, int m1, int n, const double* A, const double* X, const double* Z, double* Mx)
+{
+   HS_CALL( pick_device(device) );
+   const long long n2 = (long long) n * n;
+   DevBuf dA, dX, dZ, dG, dT, dM, dD;
+   int* dflag = NULL;
+   HS_CALL( dA.alloc(m1 * n2) ); HS_CALL( dX.alloc(n2) ); HS_CALL( dZ.alloc(n2) ); HS_CALL( dG.alloc(n2) ); HS_CALL( dT.alloc(n2) );
+   HS_CALL( dM.alloc((long long) m1 * m1) ); HS_CALL( dD.alloc((long long) ((n + 63) / 64) * 4096) );
+   HS_HIP( hipMalloc((void**) &dflag, sizeof(int)) );
+   HS_HIP( hipMemset(dflag, 0, sizeof(int)) );
+   HS_CALL( dA.up(A, m1 * n2) ); HS_CALL( dX.up(X, n2) ); HS_CALL( dZ.up(Z, n2) );
+   hs_schur_ws w;
+   int rc = hs_schur_ws_alloc(&w, m1, n2, 1e9);
+   if ( rc == HS_OK ) rc = hs_potrf(0, n, dZ.p, dD.p, dflag, NULL);
+   if ( rc == HS_OK ) rc = hs_trtri(0, n, dZ.p, dD.p, dG.p, dT.p);
+   if ( rc == HS_OK ) rc = hs_potrf(0, n, dX.p, dD.p, dflag, NULL);
+   if ( rc == HS_OK ) rc = hs_zero_upper(0, dX.p, n);
+   if ( rc == HS_OK ) rc = hs_fill(0, dM.p, (long long) m1 * m1, 0.0);
+   if ( rc == HS_OK ) rc = hs_schur_W(0, m1, n, dA.p, dX.p, dG.p, dM.p, &w);
+   if ( rc == HS_OK ) rc = hs_mirror_lower(0, dM.p, m1, m1);
+   if ( rc == HS_OK && hipDeviceSynchronize() != hipSuccess ) rc = HS_ERR_HIP;
+   hs_schur_ws_free(&w);
+   (void) hipFree(dflag);
+   HS_CALL( rc );
    HS_CALL( dM.down(Mx, (long long) m1 * m1) );
    return HIPSDP_OK;
 }

@@ -53,6 +53,16 @@ def test_schur_assembly(gpu, m1, n):
     assert rel(gpu.schur_dense(A, X, Zi, ws_gbytes=16.0 * n * n * 3 / 1e9), ref) <= 1e-12     # chunked over variables
 
 
+@pytest.mark.parametrize("m1,n", [(4, 3), (41, 20), (150, 64), (33, 130), (300, 140)])
+def test_schur_assembly_w_formulation(gpu, m1, n):
+    """W_j = G A_j R, Mx = W W^T (triangular-aware GEMMs + XCD-sliced SYRK) against the direct formula"""
+    A = RNG.standard_normal((m1, n, n)); A = A + A.transpose(0, 2, 1)
+    G = RNG.standard_normal((n, n)); X = G @ G.T + np.eye(n)
+    G = RNG.standard_normal((n, n)); Z = G @ G.T + np.eye(n)
+    ref = ipm_ref.schur_block(A, X, np.linalg.inv(Z))
+    assert rel(gpu.schur_w(A, X, Z), ref) <= 1e-11
+
+
 @pytest.mark.parametrize("n", [1, 2, 7, 63, 64, 65, 130, 300, 777])
 def test_cholesky_inverse_and_solves(gpu, n):
     G = RNG.standard_normal((n, n))
