@@ -143,33 +143,46 @@ __global__ void __launch_bounds__(256, 2) hs_dgemm_kernel(hs_gemm_args p, int kc
    const int wn   = wave & 1;
 
    int m0, n0, bz, ks0 = 0, kend = p.K;
-   if ( p.flags & HS_GEMM_XCD )
+   if ( p.flags & (HS_GEMM_XCD | HS_GEMM_REMAP) )
    {
-      /* linear block id -> (xcd, sub-slice, tile): all workgroups with the same id % 8 (one XCD under round-robin
-       * dispatch; a speed assumption only) own the K slices [xcd * c, xcd * c + c) */
-      const int c = p.splitk >> 3;
-      const int b = blockIdx.x;
-      const int xcd = b & 7;
-      const int rest = b >> 3;
-      const int sub = rest % c;
-      int t = rest / c;
+      /* 1-D grid.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD; a speed assumption only),
+       * so the logical index L = (b % 8) * P + b / 8 hands every XCD a CONTIGUOUS range of logical work items: neighbours in
+       * L share operand panels through that XCD's L2 instead of fetching them from HBM once per XCD. */
+      const long long tm = (p.M + BT - 1) / BT, tn = (p.N + BT - 1) / BT;
+      const long long ntile = (p.flags & HS_GEMM_LOWER) ? tm * (tm + 1) / 2 : tm * tn;
+      const long long nz = p.splitk > 1 ? p.splitk : p.batch;
+      const long long total = ntile * nz;
+      const long long P = (total + 7) / 8;
+      const long long b = blockIdx.x;
+      const long long L = (b & 7) * P + (b >> 3);
+      if ( (b >> 3) >= P || L >= total )
+         return;
+      long long t;
+      if ( p.flags & HS_GEMM_XCD )
+      {
+         bz = (int) (L / ntile);          /* slice-major: an XCD walks one or two K slices over all tiles */
+         t = L - (long long) bz * ntile;
+      }
+      else
+      {
+         bz = (int) (L / ntile);          /* batch-major, then row tile, then column tile */
+         t = L - (long long) bz * ntile;
+      }
       int ti, tj;
       if ( p.flags & HS_GEMM_LOWER )
       {
          ti = (int) ((sqrt(8.0 * (double) t + 1.0) - 1.0) * 0.5);
-         while ( (ti + 1) * (ti + 2) / 2 <= t ) ++ti;
-         while ( ti * (ti + 1) / 2 > t ) --ti;
-         tj = t - ti * (ti + 1) / 2;
+         while ( (long long) (ti + 1) * (ti + 2) / 2 <= t ) ++ti;
+         while ( (long long) ti * (ti + 1) / 2 > t ) --ti;
+         tj = (int) (t - (long long) ti * (ti + 1) / 2);
       }
       else
       {
-         const int tn = (p.N + BT - 1) / BT;
-         ti = t / tn;
-         tj = t - ti * tn;
+         ti = (int) (t / tn);
+         tj = (int) (t - (long long) ti * tn);
       }
       m0 = ti * BT;
       n0 = tj * BT;
-      bz = xcd * c + sub;
    }
    else
    {
@@ -322,11 +335,15 @@ static int launch_cfg(hipStream_t stream, const hs_gemm_args* a, int kchunk)
       attr_set = true;
    }
    dim3 grid((a->M + BT - 1) / BT, (a->N + BT - 1) / BT, a->splitk > 1 ? a->splitk : a->batch);
-   if ( a->flags & HS_GEMM_XCD )
+   if ( a->flags & (HS_GEMM_XCD | HS_GEMM_REMAP) )
    {
       const long long tm = (a->M + BT - 1) / BT, tn = (a->N + BT - 1) / BT;
       const long long nt = (a->flags & HS_GEMM_LOWER) ? tm * (tm + 1) / 2 : tm * tn;
-      grid = dim3((unsigned) (nt * a->splitk), 1, 1);
+      const long long total = nt * (a->splitk > 1 ? a->splitk : a->batch);
+      const long long P = (total + 7) / 8;
+      if ( 8 * P > 2147483647LL )
+         return HS_ERR_ARG;
+      grid = dim3((unsigned) (8 * P), 1, 1);
    }
    hipLaunchKernelGGL((hs_dgemm_kernel<BT, LA, LB>), grid, dim3(256), smem, stream, *a, kchunk);
    HS_HIP( hipGetLastError() );
@@ -356,6 +373,28 @@ int hs_dgemm_pick_splitk(int M, int N, int K, int lowerOnly)
    return s < 1 ? 1 : (int) s;
 }
 
+int hs_dgemm_pick_xcd_slices(long long ntile, long long K)
+{
+   /* candidates s with K / s >= 1024; score = occupied fraction of the last round of 512 slots, prefer fewer rounds */
+   int best = 2;
+   double bestscore = -1.0;
+   for (int s = 2; s <= 128; ++s)
+   {
+      if ( K / s < 1024 && s > 2 )
+         break;
+      const long long total = ntile * s;
+      const long long rounds = (total + 511) / 512;
+      const double eff = (double) total / (double) (rounds * 512);
+      const double score = eff - 0.02 * (double) (rounds - 1);
+      if ( total >= 256 && score > bestscore )
+      {
+         bestscore = score;
+         best = s;
+      }
+   }
+   return best;
+}
+
 int hs_dgemm(hipStream_t stream, const hs_gemm_args* a)
 {
    if ( a->M < 0 || a->N < 0 || a->K < 0 || a->batch < 1 )
@@ -364,7 +403,9 @@ int hs_dgemm(hipStream_t stream, const hs_gemm_args* a)
       return HS_OK;
    if ( a->splitk > 1 && (a->batch != 1 || a->ws == NULL) )
       return HS_ERR_ARG;
-   if ( (a->flags & HS_GEMM_XCD) && (a->splitk < 8 || (a->splitk & 7) != 0 || ((a->flags & HS_GEMM_LOWER) && a->M != a->N)) )
+   if ( (a->flags & HS_GEMM_XCD) && (a->splitk < 2 || ((a->flags & HS_GEMM_LOWER) && a->M != a->N)) )
+      return HS_ERR_ARG;
+   if ( (a->flags & HS_GEMM_REMAP) && (a->flags & HS_GEMM_LOWER) && a->M != a->N )
       return HS_ERR_ARG;
 
    /* tile choice: big tiles once they fill the chip, small tiles otherwise */

@@ -120,7 +120,7 @@ extern "C" void hipsdp_default_params(hipsdp_params* p)
    p->ws_gbytes = 0.0;
    p->maxiter = 100;
    p->verbose = 0;
-   p->lanczos_steps = 48;
+   p->lanczos_steps = 24;
    p->reserved = 0;
 }
 
@@ -677,6 +677,13 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
    HS_HIP( hipSetDevice(s->device) );
    if ( params != NULL )
       s->par = *params;
+   {
+      const char* env = getenv("HIPSDP_LANCZOS");
+      if ( env != NULL && atoi(env) > 0 )
+         s->par.lanczos_steps = atoi(env);
+      if ( s->par.lanczos_steps < 4 ) s->par.lanczos_steps = 4;
+      if ( s->par.lanczos_steps > 250 ) s->par.lanczos_steps = 250;
+   }
    const hipsdp_params& par = s->par;
    const int m = s->m, m1 = s->m + 1, q = s->q;
    const int K = (int) s->blk.size();

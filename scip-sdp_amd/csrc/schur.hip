@@ -43,6 +43,12 @@ int hs_schur_ws_alloc(hs_schur_ws* w, int m1, long long n2max, double budget_gb)
    }
    int sk = hs_dgemm_pick_splitk(m1, (int) cols, (int) (n2max > 2000000000LL ? 2000000000LL : n2max), 1);
    if ( sk < 16 ) sk = 16;
+   if ( w->full )
+   {
+      const long long tm = (m1 + 127) / 128;
+      const int sx = hs_dgemm_pick_xcd_slices(tm * (tm + 1) / 2, n2max);
+      if ( sx > sk ) sk = sx;
+   }
    w->kws_len = (long long) sk * m1 * (w->full ? m1 : cols);
    e = hipMalloc((void**) &w->K, (size_t) w->kws_len * sizeof(double));
    if ( e != hipSuccess )
@@ -74,10 +80,10 @@ int hs_schur_U(hipStream_t s, int m1, int n, const double* A, const double* X, c
       if ( rows > 2000000000LL )
          return HS_ERR_ARG;
       /* GEMM1: T[(cj n) x n] = A[j0 .. j0 + cj) (stack of n x n) * Zinv */
-      hs_gemm_args g1 = {(int) rows, n, n, HS_KC, HS_MC, A + (long long) j0 * n2, n, 0, Zinv, n, 0, w->T, n, 0, 1.0, 0.0, 1, 0, 1, NULL};
+      hs_gemm_args g1 = {(int) rows, n, n, HS_KC, HS_MC, A + (long long) j0 * n2, n, 0, Zinv, n, 0, w->T, n, 0, 1.0, 0.0, 1, HS_GEMM_REMAP, 1, NULL};
       HS_CALL( hs_dgemm(s, &g1) );
       /* GEMM2: U_j = X * T_j, batched over the cj matrices of the chunk */
-      hs_gemm_args g2 = {n, n, n, HS_KC, HS_MC, X, n, 0, w->T, n, n2, w->U, n, n2, 1.0, 0.0, cj, 0, 1, NULL};
+      hs_gemm_args g2 = {n, n, n, HS_KC, HS_MC, X, n, 0, w->T, n, n2, w->U, n, n2, 1.0, 0.0, cj, HS_GEMM_REMAP, 1, NULL};
       HS_CALL( hs_dgemm(s, &g2) );
       /* GEMM3: Mx[j0:, j0:j0+cj] += A_flat[j0:] * U_flat^T   (rows i >= j0 only: lower triangle) */
       const int rowsM = m1 - j0;
@@ -97,10 +103,10 @@ int hs_schur_W(hipStream_t s, int m1, int n, const double* A, const double* R, c
    if ( !w->full || n2 > 2000000000LL || rows > 2000000000LL )
       return HS_ERR_ARG;
    /* GEMM1: T = A_stack * R, R lower triangular */
-   hs_gemm_args g1 = {(int) rows, n, n, HS_KC, HS_MC, A, n, 0, R, n, 0, w->T, n, 0, 1.0, 0.0, 1, HS_GEMM_B_LOWTRI, 1, NULL};
+   hs_gemm_args g1 = {(int) rows, n, n, HS_KC, HS_MC, A, n, 0, R, n, 0, w->T, n, 0, 1.0, 0.0, 1, HS_GEMM_B_LOWTRI | HS_GEMM_REMAP, 1, NULL};
    HS_CALL( hs_dgemm(s, &g1) );
    /* GEMM2: W_j = G * T_j, G lower triangular */
-   hs_gemm_args g2 = {n, n, n, HS_KC, HS_MC, G, n, 0, w->T, n, n2, w->U, n, n2, 1.0, 0.0, m1, HS_GEMM_A_LOWTRI, 1, NULL};
+   hs_gemm_args g2 = {n, n, n, HS_KC, HS_MC, G, n, 0, w->T, n, n2, w->U, n, n2, 1.0, 0.0, m1, HS_GEMM_A_LOWTRI | HS_GEMM_REMAP, 1, NULL};
    HS_CALL( hs_dgemm(s, &g2) );
    /* GEMM3: Mx += W W^T on the lower tiles */
    int flags = HS_GEMM_LOWER;
@@ -109,8 +115,8 @@ int hs_schur_W(hipStream_t s, int m1, int n, const double* A, const double* R, c
    {
       const long long tm = (m1 + 127) / 128;
       const long long ntri = tm * (tm + 1) / 2;
-      sk = (ntri * 8 >= 448) ? 8 : 16;
-      while ( sk > 8 && (long long) sk * m1 * m1 > w->kws_len ) sk -= 8;
+      sk = hs_dgemm_pick_xcd_slices(ntri, n2);
+      while ( sk > 2 && (long long) sk * m1 * m1 > w->kws_len ) --sk;
       flags |= HS_GEMM_XCD;
    }
    else
