@@ -743,6 +743,7 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
    HostScalars hs;
    int hflags[3] = {0, 0, 0};
    bool want_cert = false;
+   bool factors_valid = false;
    double schur_ms = 0.0;
 
    for (it = 0; it <= par.maxiter; ++it)
@@ -881,19 +882,25 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
          }
       }
 
-      /* ---- factorizations */
+      /* ---- factorizations (the factors of an accepted step are re-used: they were computed by its Cholesky check) */
       HS_HIP( hipMemsetAsync(s->flags, 0, 8 * sizeof(int), st) );
       for (auto& B : s->blk)
       {
          const int n = B.n;
          const long long n2 = (long long) n * n;
-         HS_CALL( hs_copy(st, B.Lz, B.Z, n2) );
-         HS_CALL( hs_potrf(st, n, B.Lz, B.dinvz, s->flags + 0, NULL) );
+         if ( !factors_valid )
+         {
+            HS_CALL( hs_copy(st, B.Lz, B.Z, n2) );
+            HS_CALL( hs_potrf(st, n, B.Lz, B.dinvz, s->flags + 0, NULL) );
+         }
          HS_CALL( hs_trtri(st, n, B.Lz, B.dinvz, B.LzInv, B.T1) );
          HS_CALL( gemm(s, HS_MC, HS_MC, n, n, n, 1.0, B.LzInv, n, B.LzInv, n, 0.0, B.Zinv, n, HS_GEMM_LOWER) );
          HS_CALL( hs_mirror_lower(st, B.Zinv, n, n) );
-         HS_CALL( hs_copy(st, B.Lx, B.X, n2) );
-         HS_CALL( hs_potrf(st, n, B.Lx, B.dinvx, s->flags + 1, NULL) );
+         if ( !factors_valid )
+         {
+            HS_CALL( hs_copy(st, B.Lx, B.X, n2) );
+            HS_CALL( hs_potrf(st, n, B.Lx, B.dinvx, s->flags + 1, NULL) );
+         }
          HS_CALL( hs_zero_upper(st, B.Lx, n) );
          HS_CALL( hs_trtri(st, n, B.Lx, B.dinvx, B.LxInv, B.T1) );
       }
@@ -1043,6 +1050,7 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
          status = HIPSDP_STATUS_NUMERIC;
          break;
       }
+      factors_valid = (K > 0);
       HS_CALL( hs_axpy(st, m, alpha, s->dy, s->y) );
       HS_CALL( hs_axpy(st, q, alpha, s->dx, s->x) );
       HS_CALL( hs_axpy(st, q, alpha, s->dz, s->z) );
