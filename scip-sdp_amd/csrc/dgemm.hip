@@ -191,6 +191,8 @@ __global__ void __launch_bounds__(256, 2) hs_dgemm_kernel(hs_gemm_args p, int kc
       bz = blockIdx.z;
       if ( (p.flags & HS_GEMM_LOWER) && (m0 + BT - 1 < n0) )
          return;
+      if ( (p.flags & HS_GEMM_UPPER) && (n0 + BT - 1 < m0) )
+         return;
    }
 
    double* C = p.C;
@@ -312,6 +314,8 @@ __global__ void __launch_bounds__(256) hs_splitk_reduce_kernel(int M, int N, int
       const int col = (int) (e - (long long) row * N);
       if ( lowerBT > 0 && (row / lowerBT) * lowerBT + lowerBT - 1 < (col / lowerBT) * lowerBT )
          continue;
+      if ( lowerBT < 0 && (col / (-lowerBT)) * (-lowerBT) + (-lowerBT) - 1 < (row / (-lowerBT)) * (-lowerBT) )
+         continue;
       double s = 0.0;
       for (int k = 0; k < nslices; ++k)
          s += ws[(long long) k * total + e];
@@ -431,7 +435,7 @@ int hs_dgemm(hipStream_t stream, const hs_gemm_args* a)
       int blocks = (int) ((total + 255) / 256);
       if ( blocks > 2048 ) blocks = 2048;
       hipLaunchKernelGGL(hs_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a->M, a->N, a->splitk, a->ws,
-         a->C, a->ldc, a->alpha, a->beta, (a->flags & HS_GEMM_LOWER) ? BT : 0);
+         a->C, a->ldc, a->alpha, a->beta, (a->flags & HS_GEMM_LOWER) ? BT : ((a->flags & HS_GEMM_UPPER) ? -BT : 0));
       HS_HIP( hipGetLastError() );
    }
    return HS_OK;

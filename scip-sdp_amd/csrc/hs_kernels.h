@@ -60,6 +60,14 @@ int  hs_schur_U(hipStream_t s, int m1, int n, const double* A, const double* X, 
  * G: inverse of the lower Cholesky factor of Z) */
 int  hs_schur_W(hipStream_t s, int m1, int n, const double* A, const double* R, const double* G, double* Mx, hs_schur_ws* w);
 
+int  hs_schur_Urows(hipStream_t s, int m1, int n, const double* A, const double* X, const double* Zinv, double* Mx,
+   hs_schur_ws* w, int r_begin, int r_end);
+void hs_shard_rows(int m1, int nranks, int rank, int* chunk_rows, int* first_begin, int* second_begin);
+int  hs_mirror_upper(hipStream_t s, double* A, int n, long long lda);                       /* A[i][j] = A[j][i] for i > j */
+/* multi.hip: in-place all-gather of equal pieces, piece of rank r at buf + r * count */
+int  hs_allgather_inplace(void* comm, double* buf, long long count_per_rank, int rank, hipStream_t stream);
+int  hs_allgather(void* comm, const double* send, double* recv, long long count_per_rank, hipStream_t stream);
+
 /* ---- chol.hip ------------------------------------------------------------------------------------------------- */
 /* In-place blocked Cholesky of the lower triangle of the row-major n x n matrix A (lda = n): A = L L^T, L stored in the
  * lower triangle (upper triangle is left untouched).  dinv receives the inverses of the 64 x 64 diagonal blocks of L

@@ -77,7 +77,9 @@ struct hipsdp_solver
    long long gemv_ws_len;
    int* flags;       /* device ints: 0 chol Z, 1 chol X, 2 chol M */
    hs_schur_ws sws;
-   bool schur_mode_U;
+   bool schur_mode_U, schur_mode_rows;
+   double* Mgather;
+   long long mx_rows;
    int nsc;
    bool shaped, solved, have_start;
    int last_status;
@@ -150,6 +152,8 @@ static void free_problem(hipsdp_solver* s)
       s->dinvm, s->Slp, s->sc, s->red_ws, s->gemv_ws, s->lan_ws};
    for (double* p : ptrs) dfree(p);
    hs_schur_ws_free(&s->sws);
+   dfree(s->Mgather);
+   s->Mgather = NULL;
    dfree(s->flags);
    s->b = s->Dext = s->y = s->x = s->z = s->yt = s->dyt = s->wt = s->AX = s->AH = s->tmpe = s->rp = s->rd = s->tmpq = s->hl = NULL;
    s->beta = s->elp = s->dxa = s->dza = s->dx = s->dz = s->xs = s->zs = s->ys = s->u1 = s->rhs2 = s->u2 = s->dy = s->dya = NULL;
@@ -178,6 +182,9 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
    s->b = s->Dext = s->y = s->x = s->z = NULL;
    s->shaped = s->solved = s->have_start = false;
    s->comm = NULL; s->rank = 0; s->nranks = 1;
+   s->Mgather = NULL;
+   s->schur_mode_rows = false;
+   s->sws.T = s->sws.U = s->sws.K = NULL;
    s->flags = NULL;
    s->last_status = HIPSDP_STATUS_UNSOLVED;
    s->sol_scale = 1.0;
@@ -254,7 +261,7 @@ extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int*
    double** mv[] = {&s->rp, &s->u1, &s->u2, &s->dy, &s->dya};
    for (double** p : mv) HS_CALL( dalloc(p, m) );
    HS_CALL( dalloc(&s->rhs2, 2LL * m) );
-   HS_CALL( dalloc(&s->Mx, m1 * m1) );
+   HS_CALL( dalloc(&s->Mx, (m1 + 32) * m1) );      /* row padding: the 2 G shard chunks may overhang by < 2 G rows */
    HS_CALL( dalloc(&s->Lm, (long long) m * m) );
    HS_CALL( dalloc(&s->dinvm, (long long) ((m + 63) / 64) * 64 * 64) );
    HS_CALL( dalloc(&s->Slp, (long long) q * m1) );
@@ -528,6 +535,12 @@ static int ensure_schur_ws(hipsdp_solver* s)
    HS_CALL( hs_schur_ws_alloc(&s->sws, m1, n2max, budget) );
    const char* mode = getenv("HIPSDP_SCHUR");
    s->schur_mode_U = (mode != NULL && mode[0] == 'U') || !s->sws.full || s->nranks > 1;
+   s->schur_mode_rows = (mode != NULL && mode[0] == 'R');
+   if ( s->nranks > 1 && s->Mgather == NULL )
+   {
+      const long long c = (m1 + 2 * s->nranks - 1) / (2 * s->nranks);
+      HS_CALL( dalloc(&s->Mgather, c * m1 * s->nranks) );
+   }
    return HS_OK;
 }
 
@@ -908,12 +921,43 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       /* ---- Schur complement (extended by the constant matrix as "variable 0") */
       HS_HIP( hipEventRecord(s->ev0, st) );
       HS_CALL( hs_fill(st, s->Mx, (long long) m1 * m1, 0.0) );
-      for (auto& B : s->blk)
+      if ( s->nranks > 1 || s->schur_mode_rows )
       {
-         if ( s->schur_mode_U )
-            HS_CALL( hs_schur_U(st, m1, B.n, B.A, B.X, B.Zinv, s->Mx, &s->sws, 0, m1) );
-         else
-            HS_CALL( hs_schur_W(st, m1, B.n, B.A, B.Lx, B.LzInv, s->Mx, &s->sws) );
+         /* sharded assembly: this rank computes two row chunks of the upper triangle, the chunks are all-gathered */
+         int c, b1, b2;
+         hs_shard_rows(m1, s->nranks, s->rank, &c, &b1, &b2);
+         for (auto& B : s->blk)
+         {
+            HS_CALL( hs_schur_Urows(st, m1, B.n, B.A, B.X, B.Zinv, s->Mx, &s->sws, b1, b1 + c) );
+            HS_CALL( hs_schur_Urows(st, m1, B.n, B.A, B.X, B.Zinv, s->Mx, &s->sws, b2, b2 + c) );
+         }
+         if ( s->nranks > 1 )
+         {
+            const long long cnt = (long long) c * m1;
+            /* chunks 0 .. G-1 sit at their final place; chunks G .. 2G-1 are owned in reverse rank order */
+            HS_CALL( hs_allgather_inplace(s->comm, s->Mx, cnt, s->rank, st) );
+            HS_CALL( hs_allgather(s->comm, s->Mx + (long long) b2 * m1, s->Mgather, cnt, st) );
+            for (int r = 0; r < s->nranks; ++r)
+            {
+               const long long dstrow = (long long) (2 * s->nranks - 1 - r) * c;
+               if ( dstrow >= m1 )
+                  continue;
+               long long rowsleft = m1 - dstrow;
+               if ( rowsleft > c ) rowsleft = c;
+               HS_CALL( hs_copy(st, s->Mx + dstrow * m1, s->Mgather + (long long) r * cnt, rowsleft * m1) );
+            }
+         }
+         HS_CALL( hs_mirror_upper(st, s->Mx, m1, m1) );
+      }
+      else
+      {
+         for (auto& B : s->blk)
+         {
+            if ( s->schur_mode_U )
+               HS_CALL( hs_schur_U(st, m1, B.n, B.A, B.X, B.Zinv, s->Mx, &s->sws, 0, m1) );
+            else
+               HS_CALL( hs_schur_W(st, m1, B.n, B.A, B.Lx, B.LzInv, s->Mx, &s->sws) );
+         }
       }
       if ( q > 0 )
       {
@@ -1159,7 +1203,15 @@ extern "C" int hipsdp_check_y(hipsdp_solver* s, const double* y, double* lmin, d
 
 extern "C" int hipsdp_set_comm(hipsdp_solver* s, void* comm, int rank, int nranks)
 {
-   if ( s == NULL ) return HIPSDP_ERR_ARG;
+   if ( s == NULL || nranks < 1 || nranks > 16 || rank < 0 || rank >= nranks || (nranks > 1 && comm == NULL) )
+      return HIPSDP_ERR_ARG;
    s->comm = comm; s->rank = rank; s->nranks = nranks;
+   /* the Schur workspace depends on the mode: drop it so that the next solve re-creates it */
+   if ( s->sws.T != NULL )
+   {
+      HS_HIP( hipSetDevice(s->device) );
+      HS_HIP( hipStreamSynchronize(s->stream) );
+      hs_schur_ws_free(&s->sws);
+   }
    return HIPSDP_OK;
 }

@@ -64,6 +64,18 @@ __global__ void k_mirror_lower(double* A, int n, long long lda)
    }
 }
 
+__global__ void k_mirror_upper(double* A, int n, long long lda)
+{
+   const long long total = (long long) n * n;
+   for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long) gridDim.x * blockDim.x)
+   {
+      const int r = (int) (i / n);
+      const int c = (int) (i - (long long) r * n);
+      if ( r > c )
+         A[(long long) r * lda + c] = A[(long long) c * lda + r];
+   }
+}
+
 __global__ void k_zero_upper(double* A, int n)
 {
    const long long total = (long long) n * n;
@@ -183,6 +195,14 @@ int hs_mirror_lower(hipStream_t s, double* A, int n, long long lda)
 {
    if ( n <= 1 ) return HS_OK;
    hipLaunchKernelGGL(k_mirror_lower, dim3(grid_for((long long) n * n, 256, 2048)), dim3(256), 0, s, A, n, lda);
+   HS_LAUNCH_CHECK();
+   return HS_OK;
+}
+
+int hs_mirror_upper(hipStream_t s, double* A, int n, long long lda)
+{
+   if ( n <= 1 ) return HS_OK;
+   hipLaunchKernelGGL(k_mirror_upper, dim3(grid_for((long long) n * n, 256, 2048)), dim3(256), 0, s, A, n, lda);
    HS_LAUNCH_CHECK();
    return HS_OK;
 }

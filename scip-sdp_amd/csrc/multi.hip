@@ -1,6 +1,6 @@
 /* multi.hip - RCCL plumbing (one process per GPU).  The communicator is created from a unique id that the launcher
  * (bench.py via torch.distributed, or any MPI-like bootstrap) broadcasts; the engine only sees an opaque pointer. */
-#include "hs_common.h"
+#include "hs_kernels.h"
 #include "../../include/hipsdp.h"
 #include <rccl/rccl.h>
 #include <cstring>
@@ -35,6 +35,13 @@ extern "C" void hipsdp_comm_destroy(void* comm)
 int hs_allgather_inplace(void* comm, double* buf, long long count_per_rank, int rank, hipStream_t stream)
 {
    if ( ncclAllGather(buf + (long long) rank * count_per_rank, buf, (size_t) count_per_rank, ncclDouble, (ncclComm_t) comm, stream) != ncclSuccess )
+      return HS_ERR_HIP;
+   return HS_OK;
+}
+
+int hs_allgather(void* comm, const double* send, double* recv, long long count_per_rank, hipStream_t stream)
+{
+   if ( ncclAllGather(send, recv, (size_t) count_per_rank, ncclDouble, (ncclComm_t) comm, stream) != ncclSuccess )
       return HS_ERR_HIP;
    return HS_OK;
 }

@@ -128,3 +128,43 @@ int hs_schur_W(hipStream_t s, int m1, int n, const double* A, const double* R, c
    HS_CALL( hs_dgemm(s, &g3) );
    return HS_OK;
 }
+
+/* Row-block form of the U formulation for sharding over ranks:  Mx[r, c] for r in [r_begin, r_end), c >= r (upper triangle of
+ * those rows), stored as contiguous rows of Mx so that the row blocks of all ranks can be all-gathered.
+ *    Mx[r0:r1, r0:] += U_chunk [cj x n^2] * A_flat[r0:]^T */
+int hs_schur_Urows(hipStream_t s, int m1, int n, const double* A, const double* X, const double* Zinv, double* Mx,
+   hs_schur_ws* w, int r_begin, int r_end)
+{
+   const long long n2 = (long long) n * n;
+   if ( n2 > 2000000000LL )
+      return HS_ERR_ARG;
+   if ( r_end > m1 ) r_end = m1;
+   for (int r0 = r_begin; r0 < r_end; r0 += (int) w->chunk_cols)
+   {
+      const int cj = (r_end - r0) < w->chunk_cols ? (r_end - r0) : (int) w->chunk_cols;
+      const long long rows = (long long) cj * n;
+      if ( rows > 2000000000LL )
+         return HS_ERR_ARG;
+      hs_gemm_args g1 = {(int) rows, n, n, HS_KC, HS_MC, A + (long long) r0 * n2, n, 0, Zinv, n, 0, w->T, n, 0, 1.0, 0.0, 1, HS_GEMM_REMAP, 1, NULL};
+      HS_CALL( hs_dgemm(s, &g1) );
+      hs_gemm_args g2 = {n, n, n, HS_KC, HS_MC, X, n, 0, w->T, n, n2, w->U, n, n2, 1.0, 0.0, cj, HS_GEMM_REMAP, 1, NULL};
+      HS_CALL( hs_dgemm(s, &g2) );
+      const int colsM = m1 - r0;
+      int sk = hs_dgemm_pick_splitk(cj, colsM, (int) n2, 0);
+      while ( sk > 1 && (long long) sk * cj * colsM > w->kws_len ) --sk;
+      hs_gemm_args g3 = {cj, colsM, (int) n2, HS_KC, HS_KC, w->U, n2, 0, A + (long long) r0 * n2, n2, 0,
+         Mx + (long long) r0 * m1 + r0, m1, 0, 1.0, 1.0, 1, HS_GEMM_UPPER, sk, w->K};
+      HS_CALL( hs_dgemm(s, &g3) );
+   }
+   return HS_OK;
+}
+
+/* balanced two-chunk assignment of the rows of the (upper) triangle: 2 G chunks of c = ceil(m1 / (2 G)) rows; rank g owns
+ * chunk g and chunk 2 G - 1 - g, whose triangle areas add up to the same total for every g */
+void hs_shard_rows(int m1, int nranks, int rank, int* chunk_rows, int* first_begin, int* second_begin)
+{
+   const int c = (m1 + 2 * nranks - 1) / (2 * nranks);
+   *chunk_rows = c;
+   *first_begin = rank * c;
+   *second_begin = (2 * nranks - 1 - rank) * c;
+}

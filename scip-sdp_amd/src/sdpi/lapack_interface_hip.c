@@ -1,0 +1,194 @@
+/* lapack_interface_hip.c - HIP-backed drop-in for src/sdpi/lapack_interface.c (reference :178-820).
+ *
+ * Every routine moves its (host, column-major) arguments through the hipsdp_* host-buffer kernels of libhipsdp.so:
+ *   eigen problems  -> hipsdp_syev   (parallel-order Jacobi on the device; ascending values, eigenvectors as rows - exactly
+ *                                     the convention lapack_interface.c:507-603 produces from DSYEVR)
+ *   DGEMV / DGEMM   -> hipsdp_gemv_t / hipsdp_dgemm (FP64 MFMA), with the column-major <-> row-major mapping spelled out
+ *   DGELSD          -> minimum-norm least squares through the eigen-decomposition of A^T A (device GEMM + device Jacobi)
+ * A symmetric matrix reads the same in row- and column-major order, so no transposition is needed for the eigen calls.
+ * No host LAPACK is involved anywhere; without a device the calls return SCIP_ERROR.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef HIPSDP_WITH_SCIP
+#include "sdpi/lapack_interface.h"
+#else
+#include "lapack_interface_hip.h"
+#endif
+#include "hipsdp.h"
+
+static int lapack_device(void)
+{
+   const char* e = getenv("HIPSDP_DEVICE");
+   return e != NULL ? atoi(e) : 0;
+}
+
+#define DEV_CALL(x) do { if ( (x) != HIPSDP_OK ) return SCIP_ERROR; } while (0)
+
+/* full decomposition into freshly allocated arrays (caller frees) */
+static SCIP_RETCODE decompose(int n, const SCIP_Real* A, SCIP_Real** lam, SCIP_Real** V)
+{
+   *lam = (SCIP_Real*) malloc((size_t) n * sizeof(SCIP_Real));
+   *V = (SCIP_Real*) malloc((size_t) n * (size_t) n * sizeof(SCIP_Real));
+   if ( *lam == NULL || *V == NULL )
+   {
+      free(*lam); free(*V);
+      return SCIP_NOMEMORY;
+   }
+   if ( hipsdp_syev(lapack_device(), n, A, *lam, *V) != HIPSDP_OK )
+   {
+      free(*lam); free(*V);
+      return SCIP_ERROR;
+   }
+   return SCIP_OKAY;
+}
+
+/* i-th smallest eigenvalue, 1-based (DSYEVR RANGE = 'I', IL = IU = i; lapack_interface.c:178-288) */
+SCIP_RETCODE SCIPlapackComputeIthEigenvalue(BMS_BUFMEM* bufmem, SCIP_Bool geteigenvectors, int n, SCIP_Real* A, int i,
+   SCIP_Real* eigenvalue, SCIP_Real* eigenvector)
+{
+   SCIP_Real* lam;
+   SCIP_Real* V;
+   SCIP_RETCODE rc;
+   (void) bufmem;
+   if ( n <= 0 || i < 1 || i > n || A == NULL || eigenvalue == NULL )
+      return SCIP_ERROR;
+   rc = decompose(n, A, &lam, &V);
+   if ( rc != SCIP_OKAY )
+      return rc;
+   *eigenvalue = lam[i - 1];
+   if ( geteigenvectors && eigenvector != NULL )
+      memcpy(eigenvector, V + (size_t) (i - 1) * n, (size_t) n * sizeof(SCIP_Real));
+   free(lam); free(V);
+   return SCIP_OKAY;
+}
+
+/* the reference keeps a DSYEVX variant as fallback (lapack_interface.c:291-395); same result, same routine here */
+SCIP_RETCODE SCIPlapackComputeIthEigenvalueAlternative(BMS_BUFMEM* bufmem, SCIP_Bool geteigenvectors, int n, SCIP_Real* A,
+   int i, SCIP_Real* eigenvalue, SCIP_Real* eigenvector)
+{
+   return SCIPlapackComputeIthEigenvalue(bufmem, geteigenvectors, n, A, i, eigenvalue, eigenvector);
+}
+
+/* eigenpairs with eigenvalue in (-1e20, -tol] (DSYEVR RANGE = 'V'; lapack_interface.c:398-503) */
+SCIP_RETCODE SCIPlapackComputeEigenvectorsNegative(BMS_BUFMEM* bufmem, int n, SCIP_Real* A, SCIP_Real tol, int* neigenvalues,
+   SCIP_Real* eigenvalues, SCIP_Real* eigenvectors)
+{
+   SCIP_Real* lam;
+   SCIP_Real* V;
+   SCIP_RETCODE rc;
+   int k = 0;
+   (void) bufmem;
+   if ( n <= 0 || A == NULL || neigenvalues == NULL || eigenvalues == NULL || eigenvectors == NULL )
+      return SCIP_ERROR;
+   rc = decompose(n, A, &lam, &V);
+   if ( rc != SCIP_OKAY )
+      return rc;
+   while ( k < n && lam[k] <= -tol && lam[k] > -1e20 )
+   {
+      eigenvalues[k] = lam[k];
+      memcpy(eigenvectors + (size_t) k * n, V + (size_t) k * n, (size_t) n * sizeof(SCIP_Real));
+      ++k;
+   }
+   *neigenvalues = k;
+   free(lam); free(V);
+   return SCIP_OKAY;
+}
+
+/* all eigenpairs ascending, eigenvectors as rows (DSYEVR RANGE = 'A'; lapack_interface.c:507-603) */
+SCIP_RETCODE SCIPlapackComputeEigenvectorDecomposition(BMS_BUFMEM* bufmem, int n, SCIP_Real* A, SCIP_Real* eigenvalues,
+   SCIP_Real* eigenvectors)
+{
+   (void) bufmem;
+   if ( n <= 0 || A == NULL || eigenvalues == NULL || eigenvectors == NULL )
+      return SCIP_ERROR;
+   DEV_CALL( hipsdp_syev(lapack_device(), n, A, eigenvalues, eigenvectors) );
+   return SCIP_OKAY;
+}
+
+/* y = A x, A column-major nrows x ncols with LDA = nrows (DGEMV 'N'; lapack_interface.c:607-650):
+ * y[r] = sum_c A[c * nrows + r] x[c]  =  "sum over rows c of the row-major matrix [ncols][nrows]" */
+SCIP_RETCODE SCIPlapackMatrixVectorMult(int nrows, int ncols, SCIP_Real* matrix, SCIP_Real* vector, SCIP_Real* result)
+{
+   if ( nrows <= 0 || ncols <= 0 )
+      return SCIP_ERROR;
+   DEV_CALL( hipsdp_gemv_t(lapack_device(), ncols, (long long) nrows, matrix, vector, result) );
+   return SCIP_OKAY;
+}
+
+/* C = op(A) op(B), all column-major, LDC = M (DGEMM; lapack_interface.c:654-706).  In memory the column-major C[M x N] is
+ * the row-major C'[N][M] = op(B)^T op(A)^T, so the device product is C' = A' B' with
+ *   A'[N x K]:  B not transposed -> B is [K x N] col-major = row-major [N][K]  (K contiguous, ld K)
+ *               B transposed     -> B is [N x K] col-major = row-major [K][N]  (N contiguous, ld N)
+ *   B'[K x M]:  A not transposed -> A is [M x K] col-major = row-major [K][M]  (M contiguous, ld M)
+ *               A transposed     -> A is [K x M] col-major = row-major [M][K]  (K contiguous, ld K) */
+SCIP_RETCODE SCIPlapackMatrixMatrixMult(int nrowsA, int ncolsA, SCIP_Real* matrixA, SCIP_Bool transposeA, int nrowsB,
+   int ncolsB, SCIP_Real* matrixB, SCIP_Bool transposeB, SCIP_Real* result)
+{
+   const int M = transposeA ? ncolsA : nrowsA;
+   const int N = transposeB ? nrowsB : ncolsB;
+   const int K = transposeA ? nrowsA : ncolsA;
+   const int Kb = transposeB ? ncolsB : nrowsB;
+   if ( K != Kb || M <= 0 || N <= 0 || K <= 0 )
+      return SCIP_ERROR;
+   DEV_CALL( hipsdp_dgemm(lapack_device(), transposeB ? 1 : 0, transposeA ? 0 : 1, N, M, K, 1.0,
+         matrixB, (long long) (transposeB ? N : K), matrixA, (long long) (transposeA ? K : M), 0.0, result, (long long) M, 0, 1) );
+   return SCIP_OKAY;
+}
+
+/* minimum-norm solution of min ||b - A x||, A column-major m x n, possibly rank deficient (DGELSD; lapack_interface.c:
+ * 712-820).  x = sum_{lambda_k > tol} v_k (v_k^T A^T b) / lambda_k with (lambda_k, v_k) the eigenpairs of A^T A. */
+SCIP_RETCODE SCIPlapackLinearSolve(BMS_BUFMEM* bufmem, int m, int n, SCIP_Real* A, SCIP_Real* b, SCIP_Real* x)
+{
+   SCIP_Real* AtA;
+   SCIP_Real* Atb;
+   SCIP_Real* lam;
+   SCIP_Real* V;
+   SCIP_RETCODE rc;
+   SCIP_Real lmax = 0.0;
+   int k;
+   int j;
+   (void) bufmem;
+   if ( m <= 0 || n <= 0 )
+      return SCIP_ERROR;
+   AtA = (SCIP_Real*) malloc((size_t) n * (size_t) n * sizeof(SCIP_Real));
+   Atb = (SCIP_Real*) malloc((size_t) n * sizeof(SCIP_Real));
+   if ( AtA == NULL || Atb == NULL )
+   {
+      free(AtA); free(Atb);
+      return SCIP_NOMEMORY;
+   }
+   /* A col-major [m x n] = row-major At[n][m]; AtA = At At^T: both operands "K contiguous" with K = m */
+   if ( hipsdp_dgemm(lapack_device(), 0, 0, n, n, m, 1.0, A, (long long) m, A, (long long) m, 0.0, AtA, (long long) n, 0, 1) != HIPSDP_OK
+      || hipsdp_gemv_n(lapack_device(), n, (long long) m, A, 1, b, Atb) != HIPSDP_OK )
+   {
+      free(AtA); free(Atb);
+      return SCIP_ERROR;
+   }
+   rc = decompose(n, AtA, &lam, &V);
+   if ( rc != SCIP_OKAY )
+   {
+      free(AtA); free(Atb);
+      return rc;
+   }
+   for (k = 0; k < n; ++k)
+      if ( lam[k] > lmax )
+         lmax = lam[k];
+   for (j = 0; j < n; ++j)
+      x[j] = 0.0;
+   for (k = 0; k < n; ++k)
+   {
+      SCIP_Real coef = 0.0;
+      if ( lam[k] <= 1e-13 * lmax * (SCIP_Real) (m > n ? m : n) )
+         continue;
+      for (j = 0; j < n; ++j)
+         coef += V[(size_t) k * n + j] * Atb[j];
+      coef /= lam[k];
+      for (j = 0; j < n; ++j)
+         x[j] += coef * V[(size_t) k * n + j];
+   }
+   free(AtA); free(Atb); free(lam); free(V);
+   return SCIP_OKAY;
+}

@@ -1,0 +1,81 @@
+"""world_size-2 gloo test (CPU) of the multi-GPU path: the Schur row sharding, the two all-gathers and the re-assembly,
+restated in numpy (oracle/shard_ref.py), must reproduce the single-process Schur complement.  The RCCL call itself runs only
+on the multi-GPU bench; the layout logic it relies on is what this test pins."""
+import os
+import socket
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import ipm_ref
+import shard_ref
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, m1, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(11)                         # every rank holds the same (replicated) data
+    A = rng.standard_normal((m1, n, n)); A = A + A.transpose(0, 2, 1)
+    G = rng.standard_normal((n, n)); X = G @ G.T + np.eye(n)
+    G = rng.standard_normal((n, n)); Zi = np.linalg.inv(G @ G.T + np.eye(n))
+    c, b1, b2, first, second = shard_ref.local_contribution(A, X, Zi, world, rank)
+
+    def gather(block):
+        pad = np.zeros((c, m1))
+        pad[:block.shape[0]] = block
+        out = [torch.zeros(c, m1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(out, torch.from_numpy(pad))
+        return [o.numpy() for o in out]
+
+    firsts = gather(first)
+    seconds = gather(second)
+    # trim the padded tails to the row counts the owners really have
+    firsts = [f[:max(0, min(c, m1 - r * c))] for r, f in enumerate(firsts)]
+    seconds = [s[:max(0, min(c, m1 - (2 * world - 1 - r) * c))] for r, s in enumerate(seconds)]
+    Mx = shard_ref.assemble(m1, world, c, firsts, seconds)
+    ref = ipm_ref.schur_block(A, X, Zi)
+    err = float(np.abs(Mx - ref).max() / np.abs(ref).max())
+    # per-rank work balance: number of upper-triangle entries computed
+    work = sum(max(0, m1 - r) for r in list(range(b1, min(b1 + c, m1))) + list(range(b2, min(b2 + c, m1))))
+    q.put((rank, err, work))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_schur_two_ranks():
+    world, m1, n = 2, 23, 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, m1, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, work in res:
+        assert err <= 1e-12, (rank, err)
+    works = [w for _, _, w in res]
+    assert max(works) - min(works) <= 2 * m1            # the paired chunks balance the triangle
+
+
+def test_shard_rows_cover_everything_once():
+    for m1 in (5, 23, 1001, 4001):
+        for G in (1, 2, 4, 8):
+            seen = np.zeros(m1 + 2 * G, dtype=int)
+            for g in range(G):
+                c, b1, b2 = shard_ref.shard_rows(m1, G, g)
+                seen[b1:b1 + c] += 1
+                seen[b2:b2 + c] += 1
+            assert np.all(seen[:m1] == 1)

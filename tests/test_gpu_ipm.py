@@ -149,3 +149,19 @@ def test_full_size_c2_properties(gpu):
     lmin, viol = s.check_y(y1)
     assert lmin[0] >= -TOL
     s.close()
+
+
+@pytest.mark.parametrize("mode", ["U", "R"])
+def test_alternative_schur_formulations_give_the_same_solve(gpu, mode, monkeypatch):
+    """HIPSDP_SCHUR=U: chunked U_j = X A_j Z^-1 formulation; =R: the row-sharded form every rank of a multi-GPU run executes
+    (here all chunks on one device).  Both must reproduce the default (W formulation) solve and the oracle."""
+    b, A, ys, Xs, Zs = instances.planted_dense(40, 70)
+    core = ipm_ref.CoreProblem(b, [A])
+    ref = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-6, feastol=1e-6))
+    base = gpu_solve(gpu, core, gaptol=1e-6, feastol=1e-6)
+    monkeypatch.setenv("HIPSDP_SCHUR", mode)
+    alt = gpu_solve(gpu, core, gaptol=1e-6, feastol=1e-6)
+    monkeypatch.delenv("HIPSDP_SCHUR")
+    assert alt["info"].status == 0 and alt["info"].iterations == base["info"].iterations == ref.iterations
+    assert np.max(np.abs(alt["y"] - base["y"])) <= 1e-8
+    assert np.max(np.abs(alt["y"] - ref.y)) <= 1e-6

@@ -113,3 +113,75 @@ def test_gemv_passes(gpu, R, E):
     c = RNG.standard_normal(R)
     assert rel(gpu.gemv_n(A, V), V @ A.T) <= 1e-13 * E ** 0.5
     assert rel(gpu.gemv_t(A, c), c @ A) <= 1e-13 * R ** 0.5
+
+
+# ---- the SCIPlapack* surface (include/lapack_interface_hip.h) -----------------------------------------------------------
+import ctypes as C
+
+
+def _pd(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def test_sciplapack_matrix_matrix_mult_checklapack(gpu):
+    """unittests/src/checklapack.c:80-119 verbatim: A = {1,2,3,4}, B = {5,6,7,8} column-major, transposeB = TRUE"""
+    lib = gpu.lib()
+    A = np.array([1, 2, 3, 4], dtype=float)
+    B = np.array([5, 6, 7, 8], dtype=float)
+    out = np.zeros(4)
+    rc = lib.SCIPlapackMatrixMatrixMult(2, 2, _pd(A), 0, 2, 2, _pd(B), 1, _pd(out))
+    assert rc == 1
+    assert np.allclose(out, [26, 38, 30, 44])
+    # all four transpose combinations on rectangular data against numpy (column-major views)
+    rng = np.random.default_rng(5)
+    for ta in (0, 1):
+        for tb in (0, 1):
+            M, N, K = 5, 7, 4
+            Af = rng.standard_normal((K, M) if ta else (M, K))
+            Bf = rng.standard_normal((N, K) if tb else (K, N))
+            ref = (Af.T if ta else Af) @ (Bf.T if tb else Bf)
+            a = np.asfortranarray(Af).reshape(-1, order="F").copy()
+            b = np.asfortranarray(Bf).reshape(-1, order="F").copy()
+            o = np.zeros(M * N)
+            rc = lib.SCIPlapackMatrixMatrixMult(Af.shape[0], Af.shape[1], _pd(a), ta, Bf.shape[0], Bf.shape[1], _pd(b), tb, _pd(o))
+            assert rc == 1
+            assert np.allclose(o.reshape(N, M).T, ref, atol=1e-13)
+
+
+def test_sciplapack_eigen_and_gemv(gpu):
+    lib = gpu.lib()
+    rng = np.random.default_rng(6)
+    n = 12
+    G = rng.standard_normal((n, n))
+    W = G + G.T
+    ev, U = np.linalg.eigh(W)
+    val = C.c_double(0)
+    vec = np.zeros(n)
+    for i in (1, 3, n):
+        a = W.copy().reshape(-1)
+        assert lib.SCIPlapackComputeIthEigenvalue(None, 1, n, _pd(a), i, C.byref(val), _pd(vec)) == 1
+        assert abs(val.value - ev[i - 1]) <= 1e-11
+        assert np.allclose(W @ vec, val.value * vec, atol=1e-10) and abs(np.linalg.norm(vec) - 1) <= 1e-12
+    lam = np.zeros(n)
+    V = np.zeros(n * n)
+    a = W.copy().reshape(-1)
+    assert lib.SCIPlapackComputeEigenvectorDecomposition(None, n, _pd(a), _pd(lam), _pd(V)) == 1
+    V = V.reshape(n, n)
+    assert np.allclose(lam, ev, atol=1e-11) and np.allclose(V.T @ np.diag(lam) @ V, W, atol=1e-10)   # rows are eigenvectors
+    cnt = C.c_int(0)
+    a = W.copy().reshape(-1)
+    assert lib.SCIPlapackComputeEigenvectorsNegative(None, n, _pd(a), C.c_double(1e-6), C.byref(cnt), _pd(lam), _pd(V.reshape(-1))) == 1
+    assert cnt.value == int(np.sum(ev <= -1e-6)) and np.allclose(lam[:cnt.value], ev[:cnt.value], atol=1e-11)
+    Mx = rng.standard_normal((5, 3))
+    x = rng.standard_normal(3)
+    y = np.zeros(5)
+    m_cm = Mx.reshape(-1, order="F").copy()
+    assert lib.SCIPlapackMatrixVectorMult(5, 3, _pd(m_cm), _pd(x), _pd(y)) == 1
+    assert np.allclose(y, Mx @ x, atol=1e-13)
+    # least squares, rank deficient
+    A = rng.standard_normal((6, 4)); A[:, 3] = A[:, 0] + A[:, 1]
+    b = rng.standard_normal(6)
+    xs = np.zeros(4)
+    a_cm = A.reshape(-1, order="F").copy()
+    assert lib.SCIPlapackLinearSolve(None, 6, 4, _pd(a_cm), _pd(b.copy()), _pd(xs)) == 1
+    assert np.allclose(xs, np.linalg.lstsq(A, b, rcond=None)[0], atol=1e-8)
