@@ -39,6 +39,10 @@ int hs_lp_scale_rows(hipStream_t s, int q, int cols, const double* x, const doub
 int hs_vec_mul(hipStream_t s, long long n, const double* a, const double* b, double* out);   /* out = a .* b */
 int hs_lp_s0(hipStream_t s, int q, const double* x, const double* z, const double* beta, double* out, int accumulate, double* ws); /* sum (x/z) beta^2 */
 
+/* packed lower copies for the bandwidth-bound passes (half the bytes of the full storage) */
+int hs_pack_rows(hipStream_t s, int m1, int n, long long Lp, const double* A, double* Apk);
+int hs_pack_weighted(hipStream_t s, int n, const double* V, double* pk);
+int hs_unpack_sym(hipStream_t s, int n, const double* pk, double sa, const double* add, double* out);
 int hs_zero_upper(hipStream_t s, double* A, int n);                                         /* A[i][j] = 0 for i < j */
 
 /* ---- schur.hip ------------------------------------------------------------------------------------------------ */

@@ -56,6 +56,10 @@ struct Block
    double *X, *Z, *Rd, *Lz, *LzInv, *Zinv, *Lx, *LxInv, *B, *H, *G, *GZ, *dXa, *dZa, *dX, *dZ, *E, *W, *T1;
    double *dinvz, *dinvx;
    double *Xs, *Zs;  /* saved iterate for step back-off */
+   double *Apk;      /* (m + 1) x Lp packed lower copy of A for the HBM-bound passes; NULL when memory is short */
+   double *pkv;      /* 2 Lp: packed vector in / out */
+   long long Lp;
+   bool apk_valid;
 };
 
 struct hipsdp_solver
@@ -143,7 +147,7 @@ static void free_problem(hipsdp_solver* s)
    for (auto& B : s->blk)
    {
       double* ptrs[] = {B.A, B.X, B.Z, B.Rd, B.Lz, B.LzInv, B.Zinv, B.Lx, B.LxInv, B.B, B.H, B.G, B.GZ, B.dXa, B.dZa, B.dX, B.dZ,
-         B.E, B.W, B.T1, B.dinvz, B.dinvx, B.Xs, B.Zs};
+         B.E, B.W, B.T1, B.dinvz, B.dinvx, B.Xs, B.Zs, B.Apk, B.pkv};
       for (double* p : ptrs) dfree(p);
    }
    s->blk.clear();
@@ -250,6 +254,23 @@ extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int*
       const long long nd = (long long) ((B.n + 63) / 64) * 64 * 64;
       HS_CALL( dalloc(&R.dinvz, nd) );
       HS_CALL( dalloc(&R.dinvx, nd) );
+      R.Lp = (((long long) B.n * (B.n + 1) / 2) + 1) & ~1LL;
+      R.apk_valid = false;
+      R.Apk = NULL;
+      R.pkv = NULL;
+      if ( getenv("HIPSDP_NOPACK") == NULL && B.n >= 8 )
+      {
+         if ( hipMalloc((void**) &R.Apk, (size_t) (m1 * R.Lp) * sizeof(double)) != hipSuccess )
+         {
+            (void) hipGetLastError();
+            R.Apk = NULL;                 /* not enough memory for the packed copy: the passes use the full storage */
+         }
+         else
+         {
+            HS_CALL( dalloc(&R.pkv, 2 * R.Lp) );
+            HS_HIP( hipMemsetAsync(R.pkv, 0, (size_t) (2 * R.Lp) * sizeof(double), s->stream) );   /* pad entries stay 0 */
+         }
+      }
    }
    HS_CALL( dalloc(&s->b, m) );
    HS_CALL( dalloc(&s->Dext, (long long) q * m1) );
@@ -330,6 +351,7 @@ extern "C" int hipsdp_add_entries(hipsdp_solver* s, int block, long long nnz, co
    HS_LAUNCH_CHECK();
    HS_HIP( hipStreamSynchronize(s->stream) );
    dfree(dv); dfree(dr); dfree(dc); dfree(dval);
+   B.apk_valid = false;
    s->solved = false;
    return HIPSDP_OK;
 }
@@ -341,6 +363,7 @@ extern "C" int hipsdp_set_block_dense(hipsdp_solver* s, int block, const double*
    HS_HIP( hipSetDevice(s->device) );
    Block& B = s->blk[block];
    HS_HIP( hipMemcpy(B.A, A, (size_t) (s->m + 1) * B.n * B.n * sizeof(double), hipMemcpyHostToDevice) );
+   B.apk_valid = false;
    s->solved = false;
    return HIPSDP_OK;
 }
@@ -383,6 +406,7 @@ extern "C" int hipsdp_gen_planted(hipsdp_solver* s, int n, int m, long long seed
    HS_CALL( hs_copy(st, s->b, s->AX + 1, m) );
    HS_HIP( hipMemcpyAsync(b_out, s->b, (size_t) m * sizeof(double), hipMemcpyDeviceToHost, st) );
    HS_HIP( hipStreamSynchronize(st) );
+   B.apk_valid = false;
    s->solved = false;
    return HIPSDP_OK;
 }
@@ -561,6 +585,46 @@ static int read_scalars(hipsdp_solver* s, HostScalars& h, int* flags3)
    return HS_OK;
 }
 
+/* the two passes over the constraint matrices of one block; with a packed copy they move half the bytes */
+static int ensure_packed(hipsdp_solver* s)
+{
+   for (auto& B : s->blk)
+   {
+      if ( B.Apk != NULL && !B.apk_valid )
+      {
+         HS_CALL( hs_pack_rows(s->stream, s->m + 1, B.n, B.Lp, B.A, B.Apk) );
+         B.apk_valid = true;
+      }
+   }
+   return HS_OK;
+}
+
+/* out[m + 1] = <A_i, V>, V symmetric */
+static int pass_A(hipsdp_solver* s, Block& B, const double* V, double* out)
+{
+   const int m1 = s->m + 1;
+   if ( B.Apk != NULL )
+   {
+      HS_CALL( hs_pack_weighted(s->stream, B.n, V, B.pkv) );
+      const double* v = B.pkv;
+      return hs_gemv_n(s->stream, m1, B.Lp, B.Apk, B.Lp, 1, &v, out, m1, s->gemv_ws, s->gemv_ws_len);
+   }
+   return hs_gemv_n(s->stream, m1, (long long) B.n * B.n, B.A, (long long) B.n * B.n, 1, &V, out, m1, s->gemv_ws, s->gemv_ws_len);
+}
+
+/* out[n x n] = sum_i coef_i A_i + sa * add */
+static int pass_AT(hipsdp_solver* s, Block& B, const double* coef, double sa, const double* add, double* out)
+{
+   const int m1 = s->m + 1;
+   if ( B.Apk != NULL )
+   {
+      HS_CALL( hs_gemv_t(s->stream, m1, B.Lp, B.Apk, B.Lp, coef, 0.0, NULL, B.pkv + B.Lp) );
+      return hs_unpack_sym(s->stream, B.n, B.pkv + B.Lp, sa, add, out);
+   }
+   const long long n2 = (long long) B.n * B.n;
+   return hs_gemv_t(s->stream, m1, n2, B.A, n2, coef, sa, add, out);
+}
+
 /* A(V) over all blocks + LP: out[m + 1] = sum_k A_k vec(V_k) + Dext^T vlp */
 static int apply_A(hipsdp_solver* s, double* const* Vk, const double* vlp, double* out)
 {
@@ -571,7 +635,7 @@ static int apply_A(hipsdp_solver* s, double* const* Vk, const double* vlp, doubl
       Block& B = s->blk[k];
       const double* v = Vk[k];
       double* dst = first ? out : s->tmpe;
-      HS_CALL( hs_gemv_n(s->stream, m1, (long long) B.n * B.n, B.A, (long long) B.n * B.n, 1, &v, dst, m1, s->gemv_ws, s->gemv_ws_len) );
+      HS_CALL( pass_A(s, B, v, dst) );
       if ( !first )
          HS_CALL( hs_axpy(s->stream, m1, 1.0, s->tmpe, out) );
       first = false;
@@ -624,7 +688,7 @@ static int direction(hipsdp_solver* s, double sigma, double eta, double mu, doub
    {
       const int n = B.n;
       const long long n2 = (long long) n * n;
-      HS_CALL( hs_gemv_t(s->stream, m1, n2, B.A, n2, s->dyt, eta, B.Rd, B.dZ) );
+      HS_CALL( pass_AT(s, B, s->dyt, eta, B.Rd, B.dZ) );
       if ( useE )
          HS_CALL( hs_copy(s->stream, B.G, B.E, n2) );
       HS_CALL( gemm(s, HS_KC, HS_MC, n, n, n, 1.0, B.X, n, B.dZ, n, useE ? 1.0 : 0.0, B.G, n) );
@@ -705,6 +769,7 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
    memset(info, 0, sizeof(*info));
    info->status = HIPSDP_STATUS_UNSOLVED;
    HS_CALL( ensure_schur_ws(s) );
+   HS_CALL( ensure_packed(s) );
 
    long long N = q;
    for (auto& B : s->blk) N += B.n;
@@ -772,7 +837,7 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       {
          Block& B = s->blk[k];
          const long long n2 = (long long) B.n * B.n;
-         HS_CALL( hs_gemv_t(st, m1, n2, B.A, n2, s->yt, -1.0, B.Z, B.Rd) );
+         HS_CALL( pass_AT(s, B, s->yt, -1.0, B.Z, B.Rd) );
          HS_CALL( hs_dot(st, n2, B.Rd, B.Rd, s->sc + SC_BLK(k, 0), 0, s->red_ws) );
          HS_CALL( hs_dot(st, n2, B.X, B.Z, s->sc + SC_XZ, 1, s->red_ws) );
          if ( want_cert )
@@ -986,7 +1051,7 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       {
          const int n = B.n;
          const long long n2 = (long long) n * n;
-         HS_CALL( hs_gemv_t(st, m1, n2, B.A, n2, s->wt, 0.0, NULL, B.B) );
+         HS_CALL( pass_AT(s, B, s->wt, 0.0, NULL, B.B) );
          HS_CALL( gemm(s, HS_KC, HS_MC, n, n, n, 1.0, B.X, n, B.B, n, 0.0, B.T1, n) );
          HS_CALL( gemm(s, HS_KC, HS_MC, n, n, n, 1.0, B.T1, n, B.Zinv, n, 0.0, B.W, n) );
          HS_CALL( hs_dot(st, n2, B.B, B.W, s->sc + SC_S0, 1, s->red_ws) );
@@ -1174,11 +1239,12 @@ extern "C" int hipsdp_check_y(hipsdp_solver* s, const double* y, double* lmin, d
       HS_HIP( hipMemcpyAsync(s->ys, y, (size_t) m * sizeof(double), hipMemcpyHostToDevice, st) );
    hipLaunchKernelGGL(k_make_ext, g1d(m1), dim3(256), 0, st, m, -1.0, 1.0, s->ys, s->dyt);
    HS_LAUNCH_CHECK();
+   HS_CALL( ensure_packed(s) );
    int k = 0;
    for (auto& B : s->blk)
    {
       const long long n2 = (long long) B.n * B.n;
-      HS_CALL( hs_gemv_t(st, m1, n2, B.A, n2, s->dyt, 0.0, NULL, B.W) );
+      HS_CALL( pass_AT(s, B, s->dyt, 0.0, NULL, B.W) );
       /* run Lanczos to (numerical) convergence: up to min(n, 250) steps */
       HS_CALL( hs_lanczos_lmin(st, B.n, B.W, 250, s->sc + SC_BLK(k, 1), s->lan_ws) );
       ++k;

@@ -76,6 +76,48 @@ __global__ void k_mirror_upper(double* A, int n, long long lda)
    }
 }
 
+/* packed lower storage: entry (r, c), r >= c, at t = r (r + 1) / 2 + c; rows padded to an even length Lp */
+__global__ void k_pack_rows(int m1, int n, long long Lp, const double* __restrict__ A, double* __restrict__ Apk)
+{
+   const long long n2 = (long long) n * n;
+   const long long total = (long long) m1 * n2;
+   for (long long e = (long long) blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long) gridDim.x * blockDim.x)
+   {
+      const long long i = e / n2;
+      const long long rc = e - i * n2;
+      const int r = (int) (rc / n), c = (int) (rc - (long long) r * n);
+      if ( c <= r )
+         Apk[i * Lp + (long long) r * (r + 1) / 2 + c] = A[e];
+   }
+}
+
+/* pk[t] = w * V[r][c] with w = 1 on the diagonal, 2 off it: <A_i, V> = sum_t Apk[i][t] pk[t] for symmetric V */
+__global__ void k_pack_weighted(int n, const double* __restrict__ V, double* __restrict__ pk)
+{
+   const long long total = (long long) n * n;
+   for (long long e = (long long) blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long) gridDim.x * blockDim.x)
+   {
+      const int r = (int) (e / n), c = (int) (e - (long long) (e / n) * n);
+      if ( c <= r )
+         pk[(long long) r * (r + 1) / 2 + c] = (r == c ? 1.0 : 2.0) * V[e];
+   }
+}
+
+/* out[r][c] = pk[t(max(r,c), min(r,c))] + sa * add[r][c] */
+__global__ void k_unpack_sym(int n, const double* __restrict__ pk, double sa, const double* __restrict__ add, double* __restrict__ out)
+{
+   const long long total = (long long) n * n;
+   for (long long e = (long long) blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long) gridDim.x * blockDim.x)
+   {
+      const int r0 = (int) (e / n), c0 = (int) (e - (long long) (e / n) * n);
+      const int r = r0 > c0 ? r0 : c0, c = r0 > c0 ? c0 : r0;
+      double v = pk[(long long) r * (r + 1) / 2 + c];
+      if ( add != NULL )
+         v += sa * add[e];
+      out[e] = v;
+   }
+}
+
 __global__ void k_zero_upper(double* A, int n)
 {
    const long long total = (long long) n * n;
@@ -203,6 +245,28 @@ int hs_mirror_upper(hipStream_t s, double* A, int n, long long lda)
 {
    if ( n <= 1 ) return HS_OK;
    hipLaunchKernelGGL(k_mirror_upper, dim3(grid_for((long long) n * n, 256, 2048)), dim3(256), 0, s, A, n, lda);
+   HS_LAUNCH_CHECK();
+   return HS_OK;
+}
+
+int hs_pack_rows(hipStream_t s, int m1, int n, long long Lp, const double* A, double* Apk)
+{
+   HS_HIP( hipMemsetAsync(Apk, 0, (size_t) m1 * (size_t) Lp * sizeof(double), s) );
+   hipLaunchKernelGGL(k_pack_rows, dim3(grid_for((long long) m1 * n * n, 256, 65536)), dim3(256), 0, s, m1, n, Lp, A, Apk);
+   HS_LAUNCH_CHECK();
+   return HS_OK;
+}
+
+int hs_pack_weighted(hipStream_t s, int n, const double* V, double* pk)
+{
+   hipLaunchKernelGGL(k_pack_weighted, dim3(grid_for((long long) n * n, 256, 2048)), dim3(256), 0, s, n, V, pk);
+   HS_LAUNCH_CHECK();
+   return HS_OK;
+}
+
+int hs_unpack_sym(hipStream_t s, int n, const double* pk, double sa, const double* add, double* out)
+{
+   hipLaunchKernelGGL(k_unpack_sym, dim3(grid_for((long long) n * n, 256, 2048)), dim3(256), 0, s, n, pk, sa, add, out);
    HS_LAUNCH_CHECK();
    return HS_OK;
 }
