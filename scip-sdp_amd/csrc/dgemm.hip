@@ -95,6 +95,43 @@ __device__ __forceinline__ void tile_gload(d2a (&v)[TileGeo<BT>::NLD], const dou
    }
 }
 
+/* interior tiles: no bounds checks, no branches.  base = this thread's first element of the operand tile at K step 0;
+ * KC: element (r0 + r + 32 i, k0 + 2 kp), MC: element (k0 + kr + RPP i, r0 + 2 c2); step = K-step index */
+template<int BT, int LAY>
+__device__ __forceinline__ void tile_gload_fast(d2a (&v)[TileGeo<BT>::NLD], const double* __restrict__ base, long long ld, int step)
+{
+   if ( LAY == HS_KC )
+   {
+      const double* q = base + (long long) step * HS_BK;
+#pragma unroll
+      for (int i = 0; i < TileGeo<BT>::NLD; ++i)
+      {
+         const d2u u = *reinterpret_cast<const d2u*>(q + (long long) (32 * i) * ld);
+         v[i].x = u.x; v[i].y = u.y;
+      }
+   }
+   else
+   {
+      constexpr int RPP = 256 / (BT / 2);
+      const double* q = base + (long long) step * HS_BK * ld;
+#pragma unroll
+      for (int i = 0; i < TileGeo<BT>::NLD; ++i)
+      {
+         const d2u u = *reinterpret_cast<const d2u*>(q + (long long) (RPP * i) * ld);
+         v[i].x = u.x; v[i].y = u.y;
+      }
+   }
+}
+
+template<int BT, int LAY>
+__device__ __forceinline__ const double* tile_fast_base(const double* __restrict__ P, long long ld, int r0, int k0, int tid)
+{
+   if ( LAY == HS_KC )
+      return P + (long long) (r0 + (tid >> 3)) * ld + k0 + 2 * (tid & 7);
+   constexpr int TPR = BT / 2;
+   return P + (long long) (k0 + tid / TPR) * ld + r0 + 2 * (tid % TPR);
+}
+
 /* registers -> LDS */
 template<int BT, int LAY>
 __device__ __forceinline__ void tile_sstore(double* __restrict__ s, const d2a (&v)[TileGeo<BT>::NLD], int tid)
@@ -228,6 +265,12 @@ __global__ void __launch_bounds__(256, 2) hs_dgemm_kernel(hs_gemm_args p, int kc
    d2a rb[TileGeo<BT>::NLD];
 
    const int ntiles = (kend - ks0 + HS_BK - 1) / HS_BK;
+   /* K steps that lie completely inside [ks0, kend) of a tile that lies completely inside C take the check-free loads */
+   const int nfullk = (kend - ks0) / HS_BK;
+   const int nfulla = (m0 + BT <= p.M) ? nfullk : 0;
+   const int nfullb = (n0 + BT <= p.N) ? nfullk : 0;
+   const double* fa = tile_fast_base<BT, LA>(A, p.lda, m0, ks0, tid);
+   const double* fb = tile_fast_base<BT, LB>(B, p.ldb, n0, ks0, tid);
 
    if ( ntiles > 0 )
    {
@@ -243,11 +286,14 @@ __global__ void __launch_bounds__(256, 2) hs_dgemm_kernel(hs_gemm_args p, int kc
       const double* sa = hs_smem + (t & 1) * 2 * SZ;
       const double* sb = sa + SZ;
 
-      if ( t + 1 < ntiles )
-      {
+      if ( t + 1 < nfulla )
+         tile_gload_fast<BT, LA>(ra, fa, p.lda, t + 1);
+      else if ( t + 1 < ntiles )
          tile_gload<BT, LA>(ra, A, p.lda, m0, p.M, ks0 + (t + 1) * HS_BK, kend, tid);
+      if ( t + 1 < nfullb )
+         tile_gload_fast<BT, LB>(rb, fb, p.ldb, t + 1);
+      else if ( t + 1 < ntiles )
          tile_gload<BT, LB>(rb, B, p.ldb, n0, p.N, ks0 + (t + 1) * HS_BK, kend, tid);
-      }
 
 #pragma unroll
       for (int ks = 0; ks < HS_BK / 4; ++ks)
