@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(256, 2) hs_dgemm_kernel(hs_gemm_args p, int kc
 
    const int ntiles = (kend - ks0 + HS_BK - 1) / HS_BK;
    /* K steps that lie completely inside [ks0, kend) of a tile that lies completely inside C take the check-free loads */
-   const int nfullk = (kend - ks0) / HS_BK;
+   const int nfullk = (p.flags & HS_GEMM_NOFAST) ? 0 : (kend - ks0) / HS_BK;
    const int nfulla = (m0 + BT <= p.M) ? nfullk : 0;
    const int nfullb = (n0 + BT <= p.N) ? nfullk : 0;
    const double* fa = tile_fast_base<BT, LA>(A, p.lda, m0, ks0, tid);

@@ -56,6 +56,7 @@ struct Block
    double *X, *Z, *Rd, *Lz, *LzInv, *Zinv, *Lx, *LxInv, *B, *H, *G, *GZ, *dXa, *dZa, *dX, *dZ, *E, *W, *T1;
    double *dinvz, *dinvx;
    double *Xs, *Zs;  /* saved iterate for step back-off */
+   double *T2, *W2;  /* scratch of the second queue */
    double *Apk;      /* (m + 1) x Lp packed lower copy of A for the HBM-bound passes; NULL when memory is short */
    double *pkv;      /* 2 Lp: packed vector in / out */
    long long Lp;
@@ -66,6 +67,8 @@ struct hipsdp_solver
 {
    int device;
    hipStream_t stream;
+   hipStream_t stream2;          /* second queue: the Z-side chains run beside the X-side ones (both are latency bound) */
+   hipEvent_t evFork, evJoin;
    int m, q;
    std::vector<Block> blk;
    double* b;        /* m */
@@ -77,7 +80,7 @@ struct hipsdp_solver
    double *yt, *dyt, *wt, *AX, *AH, *tmpe, *rp, *rd, *tmpq, *hl, *beta, *elp, *dxa, *dza, *dx, *dz, *xs, *zs, *ys;
    double *u1, *rhs2, *u2, *dy, *dya;
    double *Mx, *Lm, *dinvm, *Slp;
-   double *sc, *red_ws, *gemv_ws, *lan_ws;
+   double *sc, *red_ws, *gemv_ws, *lan_ws, *lan_ws2;
    long long gemv_ws_len;
    int* flags;       /* device ints: 0 chol Z, 1 chol X, 2 chol M */
    hs_schur_ws sws;
@@ -147,13 +150,13 @@ static void free_problem(hipsdp_solver* s)
    for (auto& B : s->blk)
    {
       double* ptrs[] = {B.A, B.X, B.Z, B.Rd, B.Lz, B.LzInv, B.Zinv, B.Lx, B.LxInv, B.B, B.H, B.G, B.GZ, B.dXa, B.dZa, B.dX, B.dZ,
-         B.E, B.W, B.T1, B.dinvz, B.dinvx, B.Xs, B.Zs, B.Apk, B.pkv};
+         B.E, B.W, B.T1, B.dinvz, B.dinvx, B.Xs, B.Zs, B.Apk, B.pkv, B.T2, B.W2};
       for (double* p : ptrs) dfree(p);
    }
    s->blk.clear();
    double* ptrs[] = {s->b, s->Dext, s->y, s->x, s->z, s->yt, s->dyt, s->wt, s->AX, s->AH, s->tmpe, s->rp, s->rd, s->tmpq, s->hl,
       s->beta, s->elp, s->dxa, s->dza, s->dx, s->dz, s->xs, s->zs, s->ys, s->u1, s->rhs2, s->u2, s->dy, s->dya, s->Mx, s->Lm,
-      s->dinvm, s->Slp, s->sc, s->red_ws, s->gemv_ws, s->lan_ws};
+      s->dinvm, s->Slp, s->sc, s->red_ws, s->gemv_ws, s->lan_ws, s->lan_ws2};
    for (double* p : ptrs) dfree(p);
    hs_schur_ws_free(&s->sws);
    dfree(s->Mgather);
@@ -161,7 +164,7 @@ static void free_problem(hipsdp_solver* s)
    dfree(s->flags);
    s->b = s->Dext = s->y = s->x = s->z = s->yt = s->dyt = s->wt = s->AX = s->AH = s->tmpe = s->rp = s->rd = s->tmpq = s->hl = NULL;
    s->beta = s->elp = s->dxa = s->dza = s->dx = s->dz = s->xs = s->zs = s->ys = s->u1 = s->rhs2 = s->u2 = s->dy = s->dya = NULL;
-   s->Mx = s->Lm = s->dinvm = s->Slp = s->sc = s->red_ws = s->gemv_ws = s->lan_ws = NULL;
+   s->Mx = s->Lm = s->dinvm = s->Slp = s->sc = s->red_ws = s->gemv_ws = s->lan_ws = s->lan_ws2 = NULL;
    s->flags = NULL;
    s->shaped = false;
    s->solved = false;
@@ -194,9 +197,12 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
    s->sol_scale = 1.0;
    s->b = s->Dext = s->y = s->x = s->z = s->yt = s->dyt = s->wt = s->AX = s->AH = s->tmpe = s->rp = s->rd = s->tmpq = s->hl = NULL;
    s->beta = s->elp = s->dxa = s->dza = s->dx = s->dz = s->xs = s->zs = s->ys = s->u1 = s->rhs2 = s->u2 = s->dy = s->dya = NULL;
-   s->Mx = s->Lm = s->dinvm = s->Slp = s->sc = s->red_ws = s->gemv_ws = s->lan_ws = NULL;
+   s->Mx = s->Lm = s->dinvm = s->Slp = s->sc = s->red_ws = s->gemv_ws = s->lan_ws = s->lan_ws2 = NULL;
    hipsdp_default_params(&s->par);
    if ( hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess
+      || hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking) != hipSuccess
+      || hipEventCreateWithFlags(&s->evFork, hipEventDisableTiming) != hipSuccess
+      || hipEventCreateWithFlags(&s->evJoin, hipEventDisableTiming) != hipSuccess
       || hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess )
    {
       delete s;
@@ -215,8 +221,12 @@ extern "C" void hipsdp_free(hipsdp_solver** ps)
    (void) hipSetDevice(s->device);
    (void) hipStreamSynchronize(s->stream);
    free_problem(s);
+   (void) hipStreamSynchronize(s->stream2);
    (void) hipEventDestroy(s->ev0);
    (void) hipEventDestroy(s->ev1);
+   (void) hipEventDestroy(s->evFork);
+   (void) hipEventDestroy(s->evJoin);
+   (void) hipStreamDestroy(s->stream2);
    (void) hipStreamDestroy(s->stream);
    delete s;
    *ps = NULL;
@@ -248,7 +258,7 @@ extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int*
       HS_CALL( dalloc(&R.A, m1 * n2) );
       HS_HIP( hipMemsetAsync(R.A, 0, (size_t) (m1 * n2) * sizeof(double), s->stream) );
       double** mats[] = {&R.X, &R.Z, &R.Rd, &R.Lz, &R.LzInv, &R.Zinv, &R.Lx, &R.LxInv, &R.B, &R.H, &R.G, &R.GZ, &R.dXa, &R.dZa,
-         &R.dX, &R.dZ, &R.E, &R.W, &R.T1, &R.Xs, &R.Zs};
+         &R.dX, &R.dZ, &R.E, &R.W, &R.T1, &R.Xs, &R.Zs, &R.T2, &R.W2};
       for (double** pm : mats)
          HS_CALL( dalloc(pm, n2) );
       const long long nd = (long long) ((B.n + 63) / 64) * 64 * 64;
@@ -292,6 +302,7 @@ extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int*
    s->gemv_ws_len = 8192 + 4LL * 1024 * 4;
    HS_CALL( dalloc(&s->gemv_ws, s->gemv_ws_len) );
    HS_CALL( dalloc(&s->lan_ws, hs_lanczos_ws(nmax, 256)) );
+   HS_CALL( dalloc(&s->lan_ws2, hs_lanczos_ws(nmax, 256)) );
    HS_CALL( dalloc(&s->flags, 8) );
    s->sws.T = s->sws.U = s->sws.K = NULL;
    HS_HIP( hipMemsetAsync(s->Dext, 0, (size_t) ((long long) q * m1 > 0 ? (long long) q * m1 : 1) * sizeof(double), s->stream) );
@@ -537,11 +548,32 @@ __global__ void k_cert(long long n2, double tau, const double* __restrict__ Rd, 
 static inline dim3 g1d(long long n) { long long g = (n + 255) / 256; if ( g < 1 ) g = 1; if ( g > 4096 ) g = 4096; return dim3((unsigned) g); }
 
 /* ---- GEMM convenience ------------------------------------------------------------------------------------------ */
-static int gemm(hipsdp_solver* s, int layA, int layB, int M, int N, int K, double alpha, const double* A, long long lda,
+static int gemm_on(hipStream_t st, int layA, int layB, int M, int N, int K, double alpha, const double* A, long long lda,
    const double* B, long long ldb, double beta, double* C, long long ldc, int flags = 0)
 {
    hs_gemm_args g = {M, N, K, layA, layB, A, lda, 0, B, ldb, 0, C, ldc, 0, alpha, beta, 1, flags, 1, NULL};
-   return hs_dgemm(s->stream, &g);
+   return hs_dgemm(st, &g);
+}
+
+static int gemm(hipsdp_solver* s, int layA, int layB, int M, int N, int K, double alpha, const double* A, long long lda,
+   const double* B, long long ldb, double beta, double* C, long long ldc, int flags = 0)
+{
+   return gemm_on(s->stream, layA, layB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, flags);
+}
+
+/* fork: stream2 starts after everything queued on stream so far; join: stream continues after stream2 has drained */
+static int fork2(hipsdp_solver* s)
+{
+   HS_HIP( hipEventRecord(s->evFork, s->stream) );
+   HS_HIP( hipStreamWaitEvent(s->stream2, s->evFork, 0) );
+   return HS_OK;
+}
+
+static int join2(hipsdp_solver* s)
+{
+   HS_HIP( hipEventRecord(s->evJoin, s->stream2) );
+   HS_HIP( hipStreamWaitEvent(s->stream, s->evJoin, 0) );
+   return HS_OK;
 }
 
 /* ---- Schur workspace ------------------------------------------------------------------------------------------------ */
@@ -709,17 +741,20 @@ static int direction(hipsdp_solver* s, double sigma, double eta, double mu, doub
 static int steplen_enqueue(hipsdp_solver* s)
 {
    int k = 0;
+   hipStream_t st = s->stream, st2 = s->stream2;
+   HS_CALL( fork2(s) );
    for (auto& B : s->blk)
    {
       const int n = B.n;
-      HS_CALL( gemm(s, HS_KC, HS_MC, n, n, n, 1.0, B.LxInv, n, B.dX, n, 0.0, B.T1, n) );
-      HS_CALL( gemm(s, HS_KC, HS_KC, n, n, n, 1.0, B.T1, n, B.LxInv, n, 0.0, B.W, n) );
-      HS_CALL( hs_lanczos_lmin(s->stream, n, B.W, s->par.lanczos_steps, s->sc + SC_BLK(k, 1), s->lan_ws) );
-      HS_CALL( gemm(s, HS_KC, HS_MC, n, n, n, 1.0, B.LzInv, n, B.dZ, n, 0.0, B.T1, n) );
-      HS_CALL( gemm(s, HS_KC, HS_KC, n, n, n, 1.0, B.T1, n, B.LzInv, n, 0.0, B.W, n) );
-      HS_CALL( hs_lanczos_lmin(s->stream, n, B.W, s->par.lanczos_steps, s->sc + SC_BLK(k, 4), s->lan_ws) );
+      HS_CALL( gemm_on(st, HS_KC, HS_MC, n, n, n, 1.0, B.LxInv, n, B.dX, n, 0.0, B.T1, n) );
+      HS_CALL( gemm_on(st, HS_KC, HS_KC, n, n, n, 1.0, B.T1, n, B.LxInv, n, 0.0, B.W, n) );
+      HS_CALL( hs_lanczos_lmin(st, n, B.W, s->par.lanczos_steps, s->sc + SC_BLK(k, 1), s->lan_ws) );
+      HS_CALL( gemm_on(st2, HS_KC, HS_MC, n, n, n, 1.0, B.LzInv, n, B.dZ, n, 0.0, B.T2, n) );
+      HS_CALL( gemm_on(st2, HS_KC, HS_KC, n, n, n, 1.0, B.T2, n, B.LzInv, n, 0.0, B.W2, n) );
+      HS_CALL( hs_lanczos_lmin(st2, n, B.W2, s->par.lanczos_steps, s->sc + SC_BLK(k, 4), s->lan_ws2) );
       ++k;
    }
+   HS_CALL( join2(s) );
    HS_CALL( hs_ratio_min(s->stream, s->q, s->x, s->dx, s->sc + SC_RATX, 0, s->red_ws) );
    HS_CALL( hs_ratio_min(s->stream, s->q, s->z, s->dz, s->sc + SC_RATZ, 0, s->red_ws) );
    return HS_OK;
@@ -962,18 +997,22 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
 
       /* ---- factorizations (the factors of an accepted step are re-used: they were computed by its Cholesky check) */
       HS_HIP( hipMemsetAsync(s->flags, 0, 8 * sizeof(int), st) );
+      HS_CALL( fork2(s) );
       for (auto& B : s->blk)
       {
          const int n = B.n;
          const long long n2 = (long long) n * n;
+         hipStream_t st2 = s->stream2;
+         /* Z chain on the second queue */
          if ( !factors_valid )
          {
-            HS_CALL( hs_copy(st, B.Lz, B.Z, n2) );
-            HS_CALL( hs_potrf(st, n, B.Lz, B.dinvz, s->flags + 0, NULL) );
+            HS_CALL( hs_copy(st2, B.Lz, B.Z, n2) );
+            HS_CALL( hs_potrf(st2, n, B.Lz, B.dinvz, s->flags + 0, NULL) );
          }
-         HS_CALL( hs_trtri(st, n, B.Lz, B.dinvz, B.LzInv, B.T1) );
-         HS_CALL( gemm(s, HS_MC, HS_MC, n, n, n, 1.0, B.LzInv, n, B.LzInv, n, 0.0, B.Zinv, n, HS_GEMM_LOWER) );
-         HS_CALL( hs_mirror_lower(st, B.Zinv, n, n) );
+         HS_CALL( hs_trtri(st2, n, B.Lz, B.dinvz, B.LzInv, B.T2) );
+         HS_CALL( gemm_on(st2, HS_MC, HS_MC, n, n, n, 1.0, B.LzInv, n, B.LzInv, n, 0.0, B.Zinv, n, HS_GEMM_LOWER) );
+         HS_CALL( hs_mirror_lower(st2, B.Zinv, n, n) );
+         /* X chain on the first */
          if ( !factors_valid )
          {
             HS_CALL( hs_copy(st, B.Lx, B.X, n2) );
@@ -982,6 +1021,7 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
          HS_CALL( hs_zero_upper(st, B.Lx, n) );
          HS_CALL( hs_trtri(st, n, B.Lx, B.dinvx, B.LxInv, B.T1) );
       }
+      HS_CALL( join2(s) );
 
       /* ---- Schur complement (extended by the constant matrix as "variable 0") */
       HS_HIP( hipEventRecord(s->ev0, st) );
@@ -1128,17 +1168,20 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       for (int attempt = 0; attempt < 8; ++attempt)
       {
          HS_HIP( hipMemsetAsync(s->flags, 0, 8 * sizeof(int), st) );
+         HS_CALL( fork2(s) );
          for (auto& B : s->blk)
          {
             const int n = B.n;
             const long long n2 = (long long) n * n;
+            hipStream_t st2 = s->stream2;
             HS_CALL( hs_scale_add(st, n2, alpha, B.dX, 1.0, B.Xs, B.X) );
-            HS_CALL( hs_scale_add(st, n2, alpha, B.dZ, 1.0, B.Zs, B.Z) );
             HS_CALL( hs_copy(st, B.Lx, B.X, n2) );
             HS_CALL( hs_potrf(st, n, B.Lx, B.dinvx, s->flags + 1, NULL) );
-            HS_CALL( hs_copy(st, B.Lz, B.Z, n2) );
-            HS_CALL( hs_potrf(st, n, B.Lz, B.dinvz, s->flags + 0, NULL) );
+            HS_CALL( hs_scale_add(st2, n2, alpha, B.dZ, 1.0, B.Zs, B.Z) );
+            HS_CALL( hs_copy(st2, B.Lz, B.Z, n2) );
+            HS_CALL( hs_potrf(st2, n, B.Lz, B.dinvz, s->flags + 0, NULL) );
          }
+         HS_CALL( join2(s) );
          if ( K == 0 )
             break;
          HS_HIP( hipMemcpyAsync(hflags, s->flags, 3 * sizeof(int), hipMemcpyDeviceToHost, st) );

@@ -18,6 +18,7 @@
  * Algorithmic flops per assembly: 4 m1 n^3 + m1^2 n^2.
  */
 #include "hs_kernels.h"
+#include <stdlib.h>
 
 int hs_schur_ws_alloc(hs_schur_ws* w, int m1, long long n2max, double budget_gb)
 {
@@ -118,6 +119,7 @@ int hs_schur_W(hipStream_t s, int m1, int n, const double* A, const double* R, c
       sk = hs_dgemm_pick_xcd_slices(ntri, n2);
       while ( sk > 2 && (long long) sk * m1 * m1 > w->kws_len ) --sk;
       flags |= HS_GEMM_XCD;
+      if ( getenv("HIPSDP_SYRK_NOFAST") != NULL ) flags |= HS_GEMM_NOFAST;
    }
    else
    {

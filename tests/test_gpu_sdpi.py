@@ -136,3 +136,78 @@ def test_penalty_formulation(gpu):
     rc, obj, y = s.dual_sol()
     assert obj > 1e-3
     s.free()
+
+
+def _random_node(rng, nvars, sizes, nlp, nfixed):
+    """a random branch-and-bound-node-like problem: bounded variables, some fixed, sparse blocks, ranged LP rows"""
+    lb = -rng.uniform(0.5, 2.0, nvars)
+    ub = rng.uniform(0.5, 2.0, nvars)
+    for v in rng.choice(nvars, nfixed, replace=False):
+        val = float(rng.integers(-1, 2))
+        lb[v] = ub[v] = val
+    blocks = []
+    for n in sizes:
+        vars_ = {}
+        for v in range(nvars):
+            if rng.random() < 0.7:
+                ents = []
+                for _ in range(rng.integers(1, 4)):
+                    r = int(rng.integers(0, n)); c = int(rng.integers(0, r + 1))
+                    ents.append((r, c, float(rng.standard_normal())))
+                ents = list({(r, c): (r, c, x) for (r, c, x) in ents}.values())
+                vars_[v] = ents
+        const = [(i, i, -float(rng.uniform(2.0, 4.0))) for i in range(n)]        # A_0 = -dI: y = 0 is strictly feasible
+        blocks.append(dict(n=n, vars=vars_, const=const))
+    lp = []
+    for _ in range(nlp):
+        k = int(rng.integers(1, min(4, nvars) + 1))
+        idx = rng.choice(nvars, k, replace=False)
+        row = {int(v): float(rng.standard_normal()) for v in idx}
+        lhs = -float(rng.uniform(1.0, 3.0)) if rng.random() < 0.7 else -1e20
+        rhs = float(rng.uniform(1.0, 3.0)) if (rng.random() < 0.7 or lhs == -1e20) else 1e20
+        lp.append((lhs, rhs, row))
+    return sdpi_prepare.SdpiProblem(rng.standard_normal(nvars), lb, ub, blocks, lp)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_nodes_backend_vs_oracle(gpu, seed):
+    """end to end at the boundary: sdpi-style preparation -> SCIPsdpiSolverLoadAndSolve (HIP) against the independently
+    marshalled problem (sdpi_prepare.to_core) solved by the oracle; objective to 1e-5, y feasible by the LAPACK checker"""
+    import ipm_ref
+    import checker
+    rng = np.random.default_rng(1000 + seed)
+    prob = _random_node(rng, nvars=int(rng.integers(4, 12)), sizes=[int(rng.integers(2, 7)), int(rng.integers(2, 9))],
+                        nlp=int(rng.integers(0, 6)), nfixed=int(rng.integers(0, 3)))
+    P = sdpi_prepare.prepare(prob)
+    if P.status != 'ok':
+        pytest.skip("presolve decided the node")
+    b, blk, D, c, maps = sdpi_prepare.to_core(P)
+    core = ipm_ref.CoreProblem(b, blk, D, c)
+    ref = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-6, feastol=1e-6))
+    s = new_solver(gpu)
+    rc, _, _ = s.solve(P)
+    assert rc == sdpi_call.SCIP_OKAY
+    assert ref.status == ipm_ref.STATUS_OPTIMAL and s.flag("IsOptimal")
+    rc, objval, y = s.dual_sol()
+    fixedcontr = sum(prob.obj[v] * P.lb[v] for v in range(prob.nvars) if v not in maps["active"])
+    assert abs(objval - (ref.dobj + fixedcontr)) <= 1e-5 * (1 + abs(objval))
+    yact = np.array([y[v] for v in maps["active"]])
+    assert checker.check_dual(core, yact, 1e-5)["feasible"]
+    for v in range(prob.nvars):
+        if v not in maps["active"]:
+            assert y[v] == P.lb[v]
+    s.free()
+
+
+def test_time_limit_and_objective_limit(gpu):
+    case = [c for c in CASES["cases"] if c["name"] == "test11"][0]
+    P = sdpi_prepare.prepare(build(case))
+    s = new_solver(gpu)
+    assert s.set_real(4, 2.0) == sdpi_call.SCIP_OKAY             # OBJLIMIT below the optimum 5: the lower bound passes it
+    rc, _, _ = s.solve(P)
+    assert rc == sdpi_call.SCIP_OKAY and s.flag("WasSolved")
+    assert s.flag("IsObjlimExc") and s.flag("IsAcceptable") and not s.flag("IsOptimal") and s.internal_status() == 3
+    assert s.set_real(4, 1e20) == sdpi_call.SCIP_OKAY
+    rc, _, _ = s.solve(P)
+    assert s.flag("IsOptimal") and not s.flag("IsObjlimExc")
+    s.free()
