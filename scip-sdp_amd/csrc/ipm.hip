@@ -936,14 +936,16 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
          break;
       }
       /* ---- termination (mirrors oracle/ipm_ref.py) */
+      /* objective limit: with X feasible to tolerance, pobj is a lower bound of the minimisation problem
+       * (SCIP_SDPPAR_OBJLIMIT, type_sdpi.h:53); tested first so that a node whose optimum lies above the limit reports it */
+      if ( par.objlimit < 1e20 && pinf <= par.feastol && pobj / tau > par.objlimit + par.gaptol )
+      {
+         status = HIPSDP_STATUS_OBJLIM;
+         break;
+      }
       if ( pinf <= par.feastol && dabs <= par.feastol && gap <= par.gaptol )
       {
          status = HIPSDP_STATUS_OPTIMAL;
-         break;
-      }
-      if ( par.objlimit < 1e20 && pinf <= par.feastol && pobj / tau > par.objlimit )
-      {
-         status = HIPSDP_STATUS_OBJLIM;
          break;
       }
       const bool certzone = (tau < 1e-2 * fmin(1.0, kappa)) || (mu / (tau * tau) > 1e10);
