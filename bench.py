@@ -19,6 +19,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X FP64 matrix peak (vendor figure; rocBLAS dgemm reaches 72.8 on this pool)
+# HBM bytes per Schur assembly from the PMC passes committed under profiles/ (FETCH_SIZE doubled as MI355X_MICROARCH.md
+# prescribes for gfx950, plus WRITE_SIZE), keyed by (n, m); None when not measured for a size
+TRAFFIC_BYTES_PER_ASSEMBLY = {}
 
 
 def load_binding():
@@ -181,8 +184,8 @@ def main():
         "iterations_per_solve": iters / max(1, len(infos)),
         "solution_check": {"status_optimal_and_objective_matches_planted_optimum": bool(ok), "objective": last.dobj,
                            "planted_optimum": opt, "pinf": last.pinf, "dabs": last.dabs, "gap": last.gap},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS * world, "unit": "TFLOP/s",
+                     "frac": achieved / (FP64_MFMA_PEAK_TFLOPS * world), "traffic": TRAFFIC_BYTES_PER_ASSEMBLY.get((n, m)),
                      "kernel": "hs_dgemm_kernel (Schur assembly: stack GEMM, batched GEMM, split-K GEMM + slice reduce)",
                      "algorithmic_flops_per_assembly": schur_fl / max(1, schur_calls),
                      "avg_assembly_ms": 1e3 * schur_s / max(1, schur_calls),

@@ -590,9 +590,9 @@ static int ensure_schur_ws(hipsdp_solver* s)
       budget = atof(env);
    HS_CALL( hs_schur_ws_alloc(&s->sws, m1, n2max, budget) );
    const char* mode = getenv("HIPSDP_SCHUR");
-   s->schur_mode_U = (mode != NULL && mode[0] == 'U') || !s->sws.full || s->nranks > 1;
+   s->schur_mode_U = (mode != NULL && mode[0] == 'U') || !s->sws.full || s->comm != NULL;
    s->schur_mode_rows = (mode != NULL && mode[0] == 'R');
-   if ( s->nranks > 1 && s->Mgather == NULL )
+   if ( s->comm != NULL && s->Mgather == NULL )
    {
       const long long c = (m1 + 2 * s->nranks - 1) / (2 * s->nranks);
       HS_CALL( dalloc(&s->Mgather, c * m1 * s->nranks) );
@@ -607,9 +607,19 @@ struct HostScalars
    std::vector<double> v;
 };
 
+int hs_bcast_doubles(void* comm, double* buf, long long count, hipStream_t stream);
+int hs_bcast_ints(void* comm, int* buf, long long count, hipStream_t stream);
+
 static int read_scalars(hipsdp_solver* s, HostScalars& h, int* flags3)
 {
    h.v.resize(s->nsc);
+   if ( s->comm != NULL )
+   {
+      /* all ranks computed the same numbers; broadcasting rank 0's copy makes the control flow identical by construction */
+      HS_CALL( hs_bcast_doubles(s->comm, s->sc, s->nsc, s->stream) );
+      if ( flags3 != NULL )
+         HS_CALL( hs_bcast_ints(s->comm, s->flags, 3, s->stream) );
+   }
    HS_HIP( hipMemcpyAsync(h.v.data(), s->sc, (size_t) s->nsc * sizeof(double), hipMemcpyDeviceToHost, s->stream) );
    if ( flags3 != NULL )
       HS_HIP( hipMemcpyAsync(flags3, s->flags, 3 * sizeof(int), hipMemcpyDeviceToHost, s->stream) );
@@ -1028,7 +1038,7 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       /* ---- Schur complement (extended by the constant matrix as "variable 0") */
       HS_HIP( hipEventRecord(s->ev0, st) );
       HS_CALL( hs_fill(st, s->Mx, (long long) m1 * m1, 0.0) );
-      if ( s->nranks > 1 || s->schur_mode_rows )
+      if ( s->comm != NULL || s->schur_mode_rows )
       {
          /* sharded assembly: this rank computes two row chunks of the upper triangle, the chunks are all-gathered */
          int c, b1, b2;
@@ -1038,7 +1048,7 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
             HS_CALL( hs_schur_Urows(st, m1, B.n, B.A, B.X, B.Zinv, s->Mx, &s->sws, b1, b1 + c) );
             HS_CALL( hs_schur_Urows(st, m1, B.n, B.A, B.X, B.Zinv, s->Mx, &s->sws, b2, b2 + c) );
          }
-         if ( s->nranks > 1 )
+         if ( s->comm != NULL )
          {
             const long long cnt = (long long) c * m1;
             /* chunks 0 .. G-1 sit at their final place; chunks G .. 2G-1 are owned in reverse rank order */
@@ -1186,6 +1196,8 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
          HS_CALL( join2(s) );
          if ( K == 0 )
             break;
+         if ( s->comm != NULL )
+            HS_CALL( hs_bcast_ints(s->comm, s->flags, 3, st) );
          HS_HIP( hipMemcpyAsync(hflags, s->flags, 3 * sizeof(int), hipMemcpyDeviceToHost, st) );
          HS_HIP( hipStreamSynchronize(st) );
          if ( hflags[0] == 0 && hflags[1] == 0 )

@@ -45,3 +45,17 @@ int hs_allgather(void* comm, const double* send, double* recv, long long count_p
       return HS_ERR_HIP;
    return HS_OK;
 }
+
+int hs_bcast_doubles(void* comm, double* buf, long long count, hipStream_t stream)
+{
+   if ( ncclBroadcast(buf, buf, (size_t) count, ncclDouble, 0, (ncclComm_t) comm, stream) != ncclSuccess )
+      return HS_ERR_HIP;
+   return HS_OK;
+}
+
+int hs_bcast_ints(void* comm, int* buf, long long count, hipStream_t stream)
+{
+   if ( ncclBroadcast(buf, buf, (size_t) count, ncclInt, 0, (ncclComm_t) comm, stream) != ncclSuccess )
+      return HS_ERR_HIP;
+   return HS_OK;
+}

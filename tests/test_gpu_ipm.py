@@ -165,3 +165,28 @@ def test_alternative_schur_formulations_give_the_same_solve(gpu, mode, monkeypat
     assert alt["info"].status == 0 and alt["info"].iterations == base["info"].iterations == ref.iterations
     assert np.max(np.abs(alt["y"] - base["y"])) <= 1e-8
     assert np.max(np.abs(alt["y"] - ref.y)) <= 1e-6
+
+
+def test_rccl_code_path_with_a_single_rank_communicator(gpu):
+    """the multi-GPU branch of the engine (row-sharded Schur, ncclAllGather x2, ncclBroadcast of the decision scalars) driven
+    through a real RCCL communicator of size 1: every collective call, its buffers and its stream ordering are executed on the
+    device; only the inter-GPU transport is not (that needs the multi-GPU bench)."""
+    import ctypes as C
+    lib = gpu.lib()
+    uid = (C.c_ubyte * 128)()
+    assert lib.hipsdp_comm_unique_id(uid) == 0
+    b, A, ys, Xs, Zs = instances.planted_dense(40, 70)
+    core = ipm_ref.CoreProblem(b, [A])
+    ref = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-6, feastol=1e-6))
+    s = gpu.Solver(0)
+    s.load_core(core)
+    comm = C.c_void_p()
+    assert lib.hipsdp_comm_create(uid, 0, 1, C.byref(comm)) == 0
+    assert lib.hipsdp_set_comm(s.h, comm, 0, 1) == 0
+    info = s.solve(gaptol=1e-6, feastol=1e-6)
+    y = s.y()
+    assert lib.hipsdp_set_comm(s.h, None, 0, 1) == 0
+    s.close()
+    lib.hipsdp_comm_destroy(comm)
+    assert info.status == 0 and info.iterations == ref.iterations
+    assert np.max(np.abs(y - ref.y)) <= 1e-6
