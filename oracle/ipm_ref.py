@@ -108,9 +108,11 @@ def chol_psd(M, regtol=1e-13):
 
 def max_step_psd(L, dX):
     """largest alpha with  L L^T + alpha dX  psd  (inf if dX psd):  -1 / lambda_min(L^-1 dX L^-T)."""
-    W = sla.solve_triangular(L, dX, lower=True)
-    W = sla.solve_triangular(L, W.T, lower=True)
-    lam = sla.eigh(sym(W), eigvals_only=True, subset_by_index=[0, 0])[0]
+    W = sla.solve_triangular(L, dX, lower=True, check_finite=False)
+    W = sla.solve_triangular(L, W.T, lower=True, check_finite=False)
+    if not np.all(np.isfinite(W)):
+        return np.nan
+    lam = sla.eigh(sym(W), eigvals_only=True, subset_by_index=[0, 0], check_finite=False)[0]
     return np.inf if lam >= 0 else -1.0 / lam
 
 
@@ -154,6 +156,8 @@ def hsd_solve(prob, par=None, start=None):
     nstall = 0
     lastmu = np.inf
     alpha_last = 1.0
+    bestmerit = np.inf
+    sincebest = 0
     for it in range(par.maxiter + 1):
         # ---- residuals
         AX = sum(Af @ Xk.reshape(-1) for Af, Xk in zip(Aflat, X)) if K else np.zeros(m + 1)
@@ -209,6 +213,17 @@ def hsd_solve(prob, par=None, start=None):
         else:
             nstall = 0
         lastmu = mu
+        # no progress: the worst scaled violation has not improved by 10 % for 6 iterations (accuracy limit of the problem)
+        if not (tau < 1e-2 * min(1.0, kappa) or mu / (tau * tau) > 1e10):
+            merit = max(pinf / par.feastol, dabs / par.feastol, gap / par.gaptol)
+            if merit < 0.9 * bestmerit:
+                bestmerit = merit
+                sincebest = 0
+            else:
+                sincebest += 1
+                if sincebest >= 6:
+                    res.status = STATUS_NUMERIC
+                    break
 
         # ---- factorizations and Schur complement
         try:
@@ -219,7 +234,7 @@ def hsd_solve(prob, par=None, start=None):
             break
         Zinv = []
         for L in Lz:
-            Li = sla.solve_triangular(L, np.eye(L.shape[0]), lower=True)
+            Li = sla.solve_triangular(L, np.eye(L.shape[0]), lower=True, check_finite=False)
             Zinv.append(Li.T @ Li)
         Mx = np.zeros((m + 1, m + 1))
         for A, Xk, Zi in zip(prob.blocks, X, Zinv):
@@ -233,8 +248,8 @@ def hsd_solve(prob, par=None, start=None):
         def msolve(r):
             if m == 0:
                 return r
-            w = sla.solve_triangular(Lm, r, lower=True)
-            return sla.solve_triangular(Lm.T, w, lower=False)
+            w = sla.solve_triangular(Lm, r, lower=True, check_finite=False)
+            return sla.solve_triangular(Lm.T, w, lower=False, check_finite=False)
 
         # Stable elimination of (dtau, dkappa).  With w = M^-1 g the direction (1, -w) is the near-null direction of the
         # extended Schur matrix; omega - g^T M^-1 g is evaluated in factored form (a sum of non-negative terms) instead of
@@ -289,14 +304,23 @@ def hsd_solve(prob, par=None, start=None):
                 a = min(a, -kappa / dkappa)
             return a
 
+        if not (np.isfinite(den) and np.all(np.isfinite(u2))):
+            res.status = STATUS_NUMERIC
+            break
         # ---- predictor
         dya, dta, dka, dXa, dZa, dxa, dza = direction(0.0, 1.0, None, None, 0.0)
+        if not (np.isfinite(dta) and np.all(np.isfinite(dya)) and all(np.all(np.isfinite(d)) for d in dXa + dZa)):
+            res.status = STATUS_NUMERIC
+            break
         aa = min(1.0, steplen(dta, dka, dXa, dZa, dxa, dza))
         sigma = min(1.0, max(1e-8, (1.0 - aa) ** 3))
         eta = 1.0 - sigma
         # ---- corrector
         E = [dXa[k] @ dZa[k] for k in range(K)]
         dy, dt, dk, dX, dZ, dx, dz = direction(sigma, eta, E, dxa * dza, dta * dka)
+        if not (np.isfinite(dt) and np.all(np.isfinite(dy)) and all(np.all(np.isfinite(d)) for d in dX + dZ)):
+            res.status = STATUS_NUMERIC
+            break
         amax = steplen(dt, dk, dX, dZ, dx, dz)
         alpha = min(1.0, par.gamma * amax)
         alpha_last = alpha

@@ -861,7 +861,8 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
 
    int status = HIPSDP_STATUS_ITERLIM;
    int it = 0, certwait = 0, nstall = 0;
-   double lastmu = 1e300, alpha_last = 1.0;
+   double lastmu = 1e300, alpha_last = 1.0, bestmerit = 1e300;
+   int sincebest = 0;
    double mu = 0, pinf = 0, dinf = 0, dabs = 0, gap = 0, pobj = 0, dobj = 0;
    HostScalars hs;
    int hflags[3] = {0, 0, 0};
@@ -997,6 +998,21 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       else
          nstall = 0;
       lastmu = mu;
+      /* no progress: the worst scaled violation has not improved by 10 % for 6 iterations (accuracy limit of the problem) */
+      if ( !certzone )
+      {
+         const double merit = fmax(fmax(pinf / par.feastol, dabs / par.feastol), gap / par.gaptol);
+         if ( merit < 0.9 * bestmerit )
+         {
+            bestmerit = merit;
+            sincebest = 0;
+         }
+         else if ( ++sincebest >= 6 )
+         {
+            status = HIPSDP_STATUS_NUMERIC;
+            break;
+         }
+      }
       if ( par.timelimit > 0.0 )
       {
          const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
