@@ -80,7 +80,8 @@ struct hipsdp_solver
    double *yt, *dyt, *wt, *AX, *AH, *tmpe, *rp, *rd, *tmpq, *hl, *beta, *elp, *dxa, *dza, *dx, *dz, *xs, *zs, *ys;
    double *u1, *rhs2, *u2, *dy, *dya;
    double *Mx, *Lm, *dinvm, *Slp;
-   double *sc, *red_ws, *gemv_ws, *lan_ws, *lan_ws2;
+   double *sc, *red_ws, *gemv_ws, *lan_ws, *lan_ws2, *gws1, *gws2;
+   long long gws_len;
    long long gemv_ws_len;
    int* flags;       /* device ints: 0 chol Z, 1 chol X, 2 chol M */
    hs_schur_ws sws;
@@ -156,7 +157,7 @@ static void free_problem(hipsdp_solver* s)
    s->blk.clear();
    double* ptrs[] = {s->b, s->Dext, s->y, s->x, s->z, s->yt, s->dyt, s->wt, s->AX, s->AH, s->tmpe, s->rp, s->rd, s->tmpq, s->hl,
       s->beta, s->elp, s->dxa, s->dza, s->dx, s->dz, s->xs, s->zs, s->ys, s->u1, s->rhs2, s->u2, s->dy, s->dya, s->Mx, s->Lm,
-      s->dinvm, s->Slp, s->sc, s->red_ws, s->gemv_ws, s->lan_ws, s->lan_ws2};
+      s->dinvm, s->Slp, s->sc, s->red_ws, s->gemv_ws, s->lan_ws, s->lan_ws2, s->gws1, s->gws2};
    for (double* p : ptrs) dfree(p);
    hs_schur_ws_free(&s->sws);
    dfree(s->Mgather);
@@ -164,7 +165,7 @@ static void free_problem(hipsdp_solver* s)
    dfree(s->flags);
    s->b = s->Dext = s->y = s->x = s->z = s->yt = s->dyt = s->wt = s->AX = s->AH = s->tmpe = s->rp = s->rd = s->tmpq = s->hl = NULL;
    s->beta = s->elp = s->dxa = s->dza = s->dx = s->dz = s->xs = s->zs = s->ys = s->u1 = s->rhs2 = s->u2 = s->dy = s->dya = NULL;
-   s->Mx = s->Lm = s->dinvm = s->Slp = s->sc = s->red_ws = s->gemv_ws = s->lan_ws = s->lan_ws2 = NULL;
+   s->Mx = s->Lm = s->dinvm = s->Slp = s->sc = s->red_ws = s->gemv_ws = s->lan_ws = s->lan_ws2 = s->gws1 = s->gws2 = NULL;
    s->flags = NULL;
    s->shaped = false;
    s->solved = false;
@@ -197,7 +198,7 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
    s->sol_scale = 1.0;
    s->b = s->Dext = s->y = s->x = s->z = s->yt = s->dyt = s->wt = s->AX = s->AH = s->tmpe = s->rp = s->rd = s->tmpq = s->hl = NULL;
    s->beta = s->elp = s->dxa = s->dza = s->dx = s->dz = s->xs = s->zs = s->ys = s->u1 = s->rhs2 = s->u2 = s->dy = s->dya = NULL;
-   s->Mx = s->Lm = s->dinvm = s->Slp = s->sc = s->red_ws = s->gemv_ws = s->lan_ws = s->lan_ws2 = NULL;
+   s->Mx = s->Lm = s->dinvm = s->Slp = s->sc = s->red_ws = s->gemv_ws = s->lan_ws = s->lan_ws2 = s->gws1 = s->gws2 = NULL;
    hipsdp_default_params(&s->par);
    if ( hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess
       || hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking) != hipSuccess
@@ -303,6 +304,10 @@ extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int*
    HS_CALL( dalloc(&s->gemv_ws, s->gemv_ws_len) );
    HS_CALL( dalloc(&s->lan_ws, hs_lanczos_ws(nmax, 256)) );
    HS_CALL( dalloc(&s->lan_ws2, hs_lanczos_ws(nmax, 256)) );
+   s->gws_len = 8LL * nmax * nmax;
+   if ( s->gws_len > 8LL * 1024 * 1024 ) s->gws_len = 8LL * 1024 * 1024;
+   HS_CALL( dalloc(&s->gws1, s->gws_len) );
+   HS_CALL( dalloc(&s->gws2, s->gws_len) );
    HS_CALL( dalloc(&s->flags, 8) );
    s->sws.T = s->sws.U = s->sws.K = NULL;
    HS_HIP( hipMemsetAsync(s->Dext, 0, (size_t) ((long long) q * m1 > 0 ? (long long) q * m1 : 1) * sizeof(double), s->stream) );
@@ -548,17 +553,29 @@ __global__ void k_cert(long long n2, double tau, const double* __restrict__ Rd, 
 static inline dim3 g1d(long long n) { long long g = (n + 255) / 256; if ( g < 1 ) g = 1; if ( g > 4096 ) g = 4096; return dim3((unsigned) g); }
 
 /* ---- GEMM convenience ------------------------------------------------------------------------------------------ */
-static int gemm_on(hipStream_t st, int layA, int layB, int M, int N, int K, double alpha, const double* A, long long lda,
-   const double* B, long long ldb, double beta, double* C, long long ldc, int flags = 0)
+/* n x n x n products of the predictor-corrector chain: at n = 500 they are 64 tiles on 256 CUs, so K is cut into slices
+ * (slabs in ws, summed in slice order) to occupy the chip; ws = NULL: no split */
+static int gemm_on(hipStream_t st, double* ws, long long wslen, int layA, int layB, int M, int N, int K, double alpha,
+   const double* A, long long lda, const double* B, long long ldb, double beta, double* C, long long ldc, int flags = 0)
 {
-   hs_gemm_args g = {M, N, K, layA, layB, A, lda, 0, B, ldb, 0, C, ldc, 0, alpha, beta, 1, flags, 1, NULL};
+   int sk = 1;
+   const long long tiles = (long long) ((M + 63) / 64) * ((N + 63) / 64);
+   if ( ws != NULL && tiles <= 160 && tiles >= 4 && K >= 192 )
+   {
+      sk = (int) ((384 + tiles - 1) / tiles);
+      if ( sk > K / 64 ) sk = K / 64;
+      if ( sk > 8 ) sk = 8;
+      while ( sk > 1 && (long long) sk * M * N > wslen ) --sk;
+      if ( sk < 2 ) sk = 1;
+   }
+   hs_gemm_args g = {M, N, K, layA, layB, A, lda, 0, B, ldb, 0, C, ldc, 0, alpha, beta, 1, flags, sk, sk > 1 ? ws : NULL};
    return hs_dgemm(st, &g);
 }
 
 static int gemm(hipsdp_solver* s, int layA, int layB, int M, int N, int K, double alpha, const double* A, long long lda,
    const double* B, long long ldb, double beta, double* C, long long ldc, int flags = 0)
 {
-   return gemm_on(s->stream, layA, layB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, flags);
+   return gemm_on(s->stream, s->gws1, s->gws_len, layA, layB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, flags);
 }
 
 /* fork: stream2 starts after everything queued on stream so far; join: stream continues after stream2 has drained */
@@ -756,11 +773,11 @@ static int steplen_enqueue(hipsdp_solver* s)
    for (auto& B : s->blk)
    {
       const int n = B.n;
-      HS_CALL( gemm_on(st, HS_KC, HS_MC, n, n, n, 1.0, B.LxInv, n, B.dX, n, 0.0, B.T1, n) );
-      HS_CALL( gemm_on(st, HS_KC, HS_KC, n, n, n, 1.0, B.T1, n, B.LxInv, n, 0.0, B.W, n) );
+      HS_CALL( gemm_on(st, s->gws1, s->gws_len, HS_KC, HS_MC, n, n, n, 1.0, B.LxInv, n, B.dX, n, 0.0, B.T1, n) );
+      HS_CALL( gemm_on(st, s->gws1, s->gws_len, HS_KC, HS_KC, n, n, n, 1.0, B.T1, n, B.LxInv, n, 0.0, B.W, n) );
       HS_CALL( hs_lanczos_lmin(st, n, B.W, s->par.lanczos_steps, s->sc + SC_BLK(k, 1), s->lan_ws) );
-      HS_CALL( gemm_on(st2, HS_KC, HS_MC, n, n, n, 1.0, B.LzInv, n, B.dZ, n, 0.0, B.T2, n) );
-      HS_CALL( gemm_on(st2, HS_KC, HS_KC, n, n, n, 1.0, B.T2, n, B.LzInv, n, 0.0, B.W2, n) );
+      HS_CALL( gemm_on(st2, s->gws2, s->gws_len, HS_KC, HS_MC, n, n, n, 1.0, B.LzInv, n, B.dZ, n, 0.0, B.T2, n) );
+      HS_CALL( gemm_on(st2, s->gws2, s->gws_len, HS_KC, HS_KC, n, n, n, 1.0, B.T2, n, B.LzInv, n, 0.0, B.W2, n) );
       HS_CALL( hs_lanczos_lmin(st2, n, B.W2, s->par.lanczos_steps, s->sc + SC_BLK(k, 4), s->lan_ws2) );
       ++k;
    }
@@ -1038,7 +1055,7 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
             HS_CALL( hs_potrf(st2, n, B.Lz, B.dinvz, s->flags + 0, NULL) );
          }
          HS_CALL( hs_trtri(st2, n, B.Lz, B.dinvz, B.LzInv, B.T2) );
-         HS_CALL( gemm_on(st2, HS_MC, HS_MC, n, n, n, 1.0, B.LzInv, n, B.LzInv, n, 0.0, B.Zinv, n, HS_GEMM_LOWER) );
+         HS_CALL( gemm_on(st2, s->gws2, s->gws_len, HS_MC, HS_MC, n, n, n, 1.0, B.LzInv, n, B.LzInv, n, 0.0, B.Zinv, n, HS_GEMM_LOWER) );
          HS_CALL( hs_mirror_lower(st2, B.Zinv, n, n) );
          /* X chain on the first */
          if ( !factors_valid )

@@ -49,6 +49,7 @@ int hs_schur_ws_alloc(hs_schur_ws* w, int m1, long long n2max, double budget_gb)
       const long long tm = (m1 + 127) / 128;
       const int sx = hs_dgemm_pick_xcd_slices(tm * (tm + 1) / 2, n2max);
       if ( sx > sk ) sk = sx;
+      if ( sk < 64 ) sk = 64;
    }
    w->kws_len = (long long) sk * m1 * (w->full ? m1 : cols);
    e = hipMalloc((void**) &w->K, (size_t) w->kws_len * sizeof(double));
@@ -117,9 +118,13 @@ int hs_schur_W(hipStream_t s, int m1, int n, const double* A, const double* R, c
       const long long tm = (m1 + 127) / 128;
       const long long ntri = tm * (tm + 1) / 2;
       sk = hs_dgemm_pick_xcd_slices(ntri, n2);
+      if ( getenv("HIPSDP_SYRK_SLICES") != NULL && atoi(getenv("HIPSDP_SYRK_SLICES")) >= 2 )
+         sk = atoi(getenv("HIPSDP_SYRK_SLICES"));
       while ( sk > 2 && (long long) sk * m1 * m1 > w->kws_len ) --sk;
-      flags |= HS_GEMM_XCD;
-      if ( getenv("HIPSDP_SYRK_NOFAST") != NULL ) flags |= HS_GEMM_NOFAST;
+      if ( getenv("HIPSDP_SYRK_NOXCD") == NULL )
+         flags |= HS_GEMM_XCD;
+      if ( getenv("HIPSDP_SYRK_FAST") == NULL )
+         flags |= HS_GEMM_NOFAST;          /* measured on this shape: the checked loads are 5 % faster (tools/gemm_syrk.cpp) */
    }
    else
    {
