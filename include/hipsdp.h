@@ -92,6 +92,14 @@ int  hipsdp_set_obj(hipsdp_solver* solver, const double* b);
  * i = variable i, 1-based) at (row[e], col[e]); both triangles of the dense storage are written.  Host arrays. */
 int  hipsdp_add_entries(hipsdp_solver* solver, int block, long long nnz, const int* var, const int* row, const int* col,
    const double* val);
+/* Master copy (optional, for callers that solve many nodes of one problem): the matrices of ALL nvars variables in ORIGINAL
+ * block sizes are uploaded once (COO, var 0-based, lower triangle) and stay in HBM across hipsdp_set_shape calls.  A node's
+ * compact block is then filled on the device:  A_engine[a + 1][r][c] = master[activevars[a]][kept[r]][kept[c]]. */
+int  hipsdp_master_define(hipsdp_solver* solver, int nvars, int nblocks, const int* blocksizes);
+int  hipsdp_master_add_entries(hipsdp_solver* solver, int block, long long nnz, const int* var, const int* row, const int* col,
+   const double* val);
+int  hipsdp_master_gather(hipsdp_solver* solver, int engine_block, int master_block, int nactive, const int* activevars,
+   int nkept, const int* kept);
 /* dense upload of a whole block: A[(m+1) * n * n] host, row-major */
 int  hipsdp_set_block_dense(hipsdp_solver* solver, int block, const double* A);
 /* LP rows: Dext[q x (m+1)] host, row-major, column 0 = c (constant), columns 1..m = D */

@@ -93,6 +93,10 @@ struct hipsdp_solver
    int last_status;
    double sol_scale;
    hipEvent_t ev0, ev1;
+   /* device-resident master copy of the constraint matrices in ORIGINAL indices (survives set_shape) */
+   int master_nvars;
+   std::vector<int> master_sizes;
+   std::vector<double*> master_A;
    /* multi GPU */
    void* comm; int rank, nranks;
    hipsdp_params par;
@@ -190,6 +194,7 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
    s->b = s->Dext = s->y = s->x = s->z = NULL;
    s->shaped = s->solved = s->have_start = false;
    s->comm = NULL; s->rank = 0; s->nranks = 1;
+   s->master_nvars = 0;
    s->Mgather = NULL;
    s->schur_mode_rows = false;
    s->sws.T = s->sws.U = s->sws.K = NULL;
@@ -214,6 +219,14 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
    return HIPSDP_OK;
 }
 
+static void master_free(hipsdp_solver* s)
+{
+   for (double* p : s->master_A) dfree(p);
+   s->master_A.clear();
+   s->master_sizes.clear();
+   s->master_nvars = 0;
+}
+
 extern "C" void hipsdp_free(hipsdp_solver** ps)
 {
    if ( ps == NULL || *ps == NULL )
@@ -222,6 +235,7 @@ extern "C" void hipsdp_free(hipsdp_solver** ps)
    (void) hipSetDevice(s->device);
    (void) hipStreamSynchronize(s->stream);
    free_problem(s);
+   master_free(s);
    (void) hipStreamSynchronize(s->stream2);
    (void) hipEventDestroy(s->ev0);
    (void) hipEventDestroy(s->ev1);
@@ -367,6 +381,108 @@ extern "C" int hipsdp_add_entries(hipsdp_solver* s, int block, long long nnz, co
    HS_LAUNCH_CHECK();
    HS_HIP( hipStreamSynchronize(s->stream) );
    dfree(dv); dfree(dr); dfree(dc); dfree(dval);
+   B.apk_valid = false;
+   s->solved = false;
+   return HIPSDP_OK;
+}
+
+/* ---- master copy: the matrices A_v of ALL variables in original indices, uploaded once and kept across node solves.  A
+ * node's compact block (active variables, kept rows/columns) is then gathered on the device (the
+ * sdprow/sdpcol/sdpval arrays do not change between the nodes of a branch-and-bound run). */
+extern "C" int hipsdp_master_define(hipsdp_solver* s, int nvars, int nblocks, const int* blocksizes)
+{
+   if ( s == NULL || nvars < 0 || nblocks < 0 )
+      return HIPSDP_ERR_ARG;
+   HS_HIP( hipSetDevice(s->device) );
+   HS_HIP( hipStreamSynchronize(s->stream) );
+   master_free(s);
+   s->master_nvars = nvars;
+   for (int b = 0; b < nblocks; ++b)
+   {
+      if ( blocksizes[b] <= 0 )
+         return HIPSDP_ERR_ARG;
+      double* p = NULL;
+      const long long cnt = (long long) nvars * blocksizes[b] * blocksizes[b];
+      HS_CALL( dalloc(&p, cnt) );
+      HS_HIP( hipMemsetAsync(p, 0, (size_t) (cnt > 0 ? cnt : 1) * sizeof(double), s->stream) );
+      s->master_A.push_back(p);
+      s->master_sizes.push_back(blocksizes[b]);
+   }
+   HS_HIP( hipStreamSynchronize(s->stream) );
+   return HIPSDP_OK;
+}
+
+extern "C" int hipsdp_master_add_entries(hipsdp_solver* s, int block, long long nnz, const int* var, const int* row,
+   const int* col, const double* val)
+{
+   if ( s == NULL || block < 0 || block >= (int) s->master_A.size() || nnz < 0 )
+      return HIPSDP_ERR_ARG;
+   if ( nnz == 0 )
+      return HIPSDP_OK;
+   HS_HIP( hipSetDevice(s->device) );
+   const int n = s->master_sizes[block];
+   for (long long e = 0; e < nnz; ++e)
+      if ( var[e] < 0 || var[e] >= s->master_nvars || row[e] < 0 || row[e] >= n || col[e] < 0 || col[e] >= n )
+      {
+         set_err("hipsdp_master_add_entries: index out of range");
+         return HIPSDP_ERR_ARG;
+      }
+   int *dv, *dr, *dc; double* dval;
+   HS_CALL( dalloc(&dv, nnz) ); HS_CALL( dalloc(&dr, nnz) ); HS_CALL( dalloc(&dc, nnz) ); HS_CALL( dalloc(&dval, nnz) );
+   HS_HIP( hipMemcpyAsync(dv, var, (size_t) nnz * sizeof(int), hipMemcpyHostToDevice, s->stream) );
+   HS_HIP( hipMemcpyAsync(dr, row, (size_t) nnz * sizeof(int), hipMemcpyHostToDevice, s->stream) );
+   HS_HIP( hipMemcpyAsync(dc, col, (size_t) nnz * sizeof(int), hipMemcpyHostToDevice, s->stream) );
+   HS_HIP( hipMemcpyAsync(dval, val, (size_t) nnz * sizeof(double), hipMemcpyHostToDevice, s->stream) );
+   long long g = (nnz + 255) / 256; if ( g > 4096 ) g = 4096;
+   hipLaunchKernelGGL(k_scatter_coo, dim3((unsigned) g), dim3(256), 0, s->stream, nnz, n, dv, dr, dc, dval, s->master_A[block]);
+   HS_LAUNCH_CHECK();
+   HS_HIP( hipStreamSynchronize(s->stream) );
+   dfree(dv); dfree(dr); dfree(dc); dfree(dval);
+   return HIPSDP_OK;
+}
+
+/* A_engine[a + 1][r'][c'] = master[activevars[a]][kept[r']][kept[c']] */
+__global__ void k_master_gather(int nactive, int nk, int N, const int* __restrict__ act, const int* __restrict__ kept,
+   const double* __restrict__ master, double* __restrict__ A)
+{
+   const long long nk2 = (long long) nk * nk;
+   const long long total = (long long) nactive * nk2;
+   for (long long e = (long long) blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long) gridDim.x * blockDim.x)
+   {
+      const long long a = e / nk2;
+      const long long rc = e - a * nk2;
+      const int r = (int) (rc / nk), c = (int) (rc - (long long) r * nk);
+      A[(a + 1) * nk2 + rc] = master[((long long) act[a] * N + kept[r]) * N + kept[c]];
+   }
+}
+
+extern "C" int hipsdp_master_gather(hipsdp_solver* s, int engine_block, int master_block, int nactive, const int* activevars,
+   int nkept, const int* kept)
+{
+   if ( s == NULL || !s->shaped || engine_block < 0 || engine_block >= (int) s->blk.size() || master_block < 0
+      || master_block >= (int) s->master_A.size() || nactive < 0 || nactive > s->m || nkept != s->blk[engine_block].n )
+      return HIPSDP_ERR_ARG;
+   if ( nactive == 0 )
+      return HIPSDP_OK;
+   HS_HIP( hipSetDevice(s->device) );
+   const int N = s->master_sizes[master_block];
+   for (int a = 0; a < nactive; ++a)
+      if ( activevars[a] < 0 || activevars[a] >= s->master_nvars )
+         return HIPSDP_ERR_ARG;
+   for (int r = 0; r < nkept; ++r)
+      if ( kept[r] < 0 || kept[r] >= N )
+         return HIPSDP_ERR_ARG;
+   int *dact, *dkept;
+   HS_CALL( dalloc(&dact, nactive) ); HS_CALL( dalloc(&dkept, nkept) );
+   HS_HIP( hipMemcpyAsync(dact, activevars, (size_t) nactive * sizeof(int), hipMemcpyHostToDevice, s->stream) );
+   HS_HIP( hipMemcpyAsync(dkept, kept, (size_t) nkept * sizeof(int), hipMemcpyHostToDevice, s->stream) );
+   Block& B = s->blk[engine_block];
+   long long g = ((long long) nactive * nkept * nkept + 255) / 256; if ( g > 65536 ) g = 65536;
+   hipLaunchKernelGGL(k_master_gather, dim3((unsigned) g), dim3(256), 0, s->stream, nactive, nkept, N, dact, dkept,
+      s->master_A[master_block], B.A);
+   HS_LAUNCH_CHECK();
+   HS_HIP( hipStreamSynchronize(s->stream) );
+   dfree(dact); dfree(dkept);
    B.apk_valid = false;
    s->solved = false;
    return HIPSDP_OK;

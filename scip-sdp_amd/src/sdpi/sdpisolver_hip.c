@@ -118,6 +118,13 @@ struct SCIP_SDPiSolver
    SCIP_Real             preoptimalgap;
    SCIP_Bool             sdpinfo;
    int                   nthreads;           /* reinterpreted: number of GPUs (-1 = all visible) */
+
+   /* fingerprint of the SDP arrays whose device-resident master copy the engine holds */
+   SCIP_Bool             mastervalid;
+   unsigned long long    masterhash;
+   int                   masternvars;
+   int                   masternblocks;
+   int                   masternnz;
 };
 
 /* ---------------------------------------------------------------------------------------------------------------------- */
@@ -182,6 +189,55 @@ static void freeLpMaps(SCIP_SDPISOLVER* s)
    HSFREE(s, &s->lhsrow, s->nlpalloc);
    HSFREE(s, &s->rhsrow, s->nlpalloc);
    s->nlpalloc = 0;
+}
+
+/* FNV-1a over the structure of the SDP arrays plus up to ~4096 evenly sampled entries: cheap (O(#block variables)), and
+ * it changes whenever SCIPsdpiLoadSDP hands over different data (sdpi.c:2329-2520 re-allocates and re-fills the arrays) */
+static unsigned long long hashMix(unsigned long long h, unsigned long long v)
+{
+   int i;
+   for (i = 0; i < 8; ++i)
+   {
+      h ^= (v >> (8 * i)) & 0xffULL;
+      h *= 1099511628211ULL;
+   }
+   return h;
+}
+
+static unsigned long long sdpFingerprint(int nvars, int nsdpblocks, const int* sdpblocksizes, const int* sdpnblockvars, int sdpnnonz,
+   int* const* sdpnblockvarnonz, int* const* sdpvar, int** const* sdprow, int** const* sdpcol, SCIP_Real** const* sdpval)
+{
+   unsigned long long h = 1469598103934665603ULL;
+   long long seen = 0;
+   const long long stride = sdpnnonz > 4096 ? sdpnnonz / 4096 : 1;
+   int b;
+   int k;
+   int t;
+   h = hashMix(h, (unsigned long long) nvars);
+   h = hashMix(h, (unsigned long long) nsdpblocks);
+   h = hashMix(h, (unsigned long long) sdpnnonz);
+   for (b = 0; b < nsdpblocks; ++b)
+   {
+      h = hashMix(h, (unsigned long long) sdpblocksizes[b]);
+      h = hashMix(h, (unsigned long long) sdpnblockvars[b]);
+      for (k = 0; k < sdpnblockvars[b]; ++k)
+      {
+         const int nn = sdpnblockvarnonz[b][k];
+         h = hashMix(h, (unsigned long long) sdpvar[b][k]);
+         h = hashMix(h, (unsigned long long) nn);
+         /* first sample position >= seen that is a multiple of stride */
+         t = (int) ((stride - (seen % stride)) % stride);
+         for (; t < nn; t += (int) stride)
+         {
+            unsigned long long bits;
+            memcpy(&bits, &sdpval[b][k][t], sizeof(bits));
+            h = hashMix(h, bits);
+            h = hashMix(h, ((unsigned long long) sdprow[b][k][t] << 32) | (unsigned long long) (unsigned int) sdpcol[b][k][t]);
+         }
+         seen += nn;
+      }
+   }
+   return h;
 }
 
 /* fetch X of an engine block on first use */
@@ -589,13 +645,75 @@ SCIP_RETCODE SCIPsdpiSolverLoadAndSolveWithPenalty(
    ENGINE_CALL( hipsdp_set_obj(s->engine, bvec) );
    HSFREE(s, &bvec, nengvars);
 
-   /* SDP blocks: lower-triangular COO with compacted indices; fixed variables are skipped because the caller has moved
-    * them into the constant part (sdpisolver.h:160-163, sdpi.c:614-682) */
+   /* SDP blocks.  The matrices A_v are uploaded ONCE in original indices (master copy in HBM, re-used while the caller's
+    * arrays are unchanged: relax_sdp.c:4455-4495 reloads them only when the number of variables or blocks changes); every
+    * node then only sends its list of active variables and kept indices and the engine gathers the compact block on the
+    * device.  Fixed variables are skipped here because the caller has moved them into the constant part
+    * (sdpisolver.h:160-163, sdpi.c:614-682). */
+   {
+      const unsigned long long fp = sdpFingerprint(nvars, nsdpblocks, sdpblocksizes, sdpnblockvars, sdpnnonz, sdpnblockvarnonz,
+         sdpvar, sdprow, sdpcol, sdpval);
+      const SCIP_Bool usecache = (getenv("HIPSDP_NOCACHE") == NULL);
+      if ( ! usecache || ! s->mastervalid || s->masterhash != fp || s->masternvars != nvars || s->masternblocks != nsdpblocks
+         || s->masternnz != sdpnnonz )
+      {
+         s->mastervalid = FALSE;
+         ENGINE_CALL( hipsdp_master_define(s->engine, nvars, nsdpblocks, sdpblocksizes) );
+         for (b = 0; b < nsdpblocks; ++b)
+         {
+            long long cnt = 0;
+            long long pos = 0;
+            int k;
+            int t;
+            int* evar;
+            int* erow;
+            int* ecol;
+            SCIP_Real* eval;
+            for (k = 0; k < sdpnblockvars[b]; ++k)
+               cnt += sdpnblockvarnonz[b][k];
+            if ( cnt == 0 )
+               continue;
+            evar = (int*) malloc((size_t) cnt * sizeof(int));
+            erow = (int*) malloc((size_t) cnt * sizeof(int));
+            ecol = (int*) malloc((size_t) cnt * sizeof(int));
+            eval = (SCIP_Real*) malloc((size_t) cnt * sizeof(SCIP_Real));
+            if ( evar == NULL || erow == NULL || ecol == NULL || eval == NULL )
+            {
+               free(evar); free(erow); free(ecol); free(eval);
+               return SCIP_NOMEMORY;
+            }
+            for (k = 0; k < sdpnblockvars[b]; ++k)
+            {
+               for (t = 0; t < sdpnblockvarnonz[b][k]; ++t)
+               {
+                  evar[pos] = sdpvar[b][k];
+                  erow[pos] = sdprow[b][k][t];
+                  ecol[pos] = sdpcol[b][k][t];
+                  eval[pos] = sdpval[b][k][t];
+                  ++pos;
+               }
+            }
+            {
+               int rc = hipsdp_master_add_entries(s->engine, b, pos, evar, erow, ecol, eval);
+               free(evar); free(erow); free(ecol); free(eval);
+               if ( rc != HIPSDP_OK )
+               {
+                  SCIPerrorMessage("hipsdp_master_add_entries failed: %s\n", hipsdp_last_error());
+                  return SCIP_LPERROR;
+               }
+            }
+         }
+         s->mastervalid = TRUE;
+         s->masterhash = fp;
+         s->masternvars = nvars;
+         s->masternblocks = nsdpblocks;
+         s->masternnz = sdpnnonz;
+      }
+   }
    for (b = 0; b < nsdpblocks; ++b)
    {
       long long cnt = 0;
       long long pos = 0;
-      int k;
       int t;
       int* evar;
       int* erow;
@@ -604,12 +722,9 @@ SCIP_RETCODE SCIPsdpiSolverLoadAndSolveWithPenalty(
       const int eb = s->blockmap[b];
       if ( eb < 0 )
          continue;
-      for (k = 0; k < sdpnblockvars[b]; ++k)
-         if ( s->inputtoactive[sdpvar[b][k]] > 0 )
-            cnt += sdpnblockvarnonz[b][k];
-      cnt += sdpconstnblocknonz[b];
-      if ( s->penalty )
-         cnt += s->compactsize[b];
+      ENGINE_CALL( hipsdp_master_gather(s->engine, eb, b, s->nactivevars, s->activetoinput, s->compactsize[b], s->keptind[b]) );
+      /* per node: constant matrix (changes with the fixings) and the identity of the penalty variable */
+      cnt = sdpconstnblocknonz[b] + (s->penalty ? s->compactsize[b] : 0);
       if ( cnt == 0 )
          continue;
       evar = (int*) malloc((size_t) cnt * sizeof(int));
@@ -620,23 +735,6 @@ SCIP_RETCODE SCIPsdpiSolverLoadAndSolveWithPenalty(
       {
          free(evar); free(erow); free(ecol); free(eval);
          return SCIP_NOMEMORY;
-      }
-      for (k = 0; k < sdpnblockvars[b]; ++k)
-      {
-         const int av = s->inputtoactive[sdpvar[b][k]];
-         if ( av <= 0 )
-            continue;
-         for (t = 0; t < sdpnblockvarnonz[b][k]; ++t)
-         {
-            const int r = sdprow[b][k][t];
-            const int c = sdpcol[b][k][t];
-            assert( indchanges[b][r] >= 0 && indchanges[b][c] >= 0 );
-            evar[pos] = av;
-            erow[pos] = r - indchanges[b][r];
-            ecol[pos] = c - indchanges[b][c];
-            eval[pos] = sdpval[b][k][t];
-            ++pos;
-         }
       }
       for (t = 0; t < sdpconstnblocknonz[b]; ++t)
       {
