@@ -29,8 +29,10 @@ class SdpiProblem:
         self.nvars = len(self.obj)
         self.lb = np.asarray(lb, dtype=np.float64).copy()
         self.ub = np.asarray(ub, dtype=np.float64).copy()
-        self.blocks = [dict(n=b['n'], vars={int(v): list(e) for v, e in b.get('vars', {}).items()},
-                            const=list(b.get('const', []))) for b in blocks]
+        # already normalised block dicts are shared by reference: the nodes of a branch-and-bound run then hand the SAME
+        # arrays to the backend, as sdpi.c does (sdpi.c:2491-2493), which is what the backend's master-copy cache keys on
+        self.blocks = [b if b.get('_norm') else dict(n=b['n'], vars={int(v): list(e) for v, e in b.get('vars', {}).items()},
+                                                     const=list(b.get('const', [])), _norm=True) for b in blocks]
         self.lp = [(float(l), float(r), {int(v): float(c) for v, c in row.items()}) for (l, r, row) in lp]
 
 

@@ -191,8 +191,10 @@ static void freeLpMaps(SCIP_SDPISOLVER* s)
    s->nlpalloc = 0;
 }
 
-/* FNV-1a over the structure of the SDP arrays plus up to ~4096 evenly sampled entries: cheap (O(#block variables)), and
- * it changes whenever SCIPsdpiLoadSDP hands over different data (sdpi.c:2329-2520 re-allocates and re-fills the arrays) */
+/* FNV-1a over the structure of the SDP arrays, the addresses of the value arrays and the entries themselves: ALL entries up
+ * to 4 million nonzeros (a few ms of host time), ~65536 evenly spaced samples beyond that (a full pass over 10^8 triplets
+ * would cost as much as the solve).  SCIPsdpiLoadSDP re-allocates and re-fills these arrays (sdpi.c:2329-2520), so address
+ * and content change together; a caller that edits single values of a huge instance in place must set HIPSDP_NOCACHE=1. */
 static unsigned long long hashMix(unsigned long long h, unsigned long long v)
 {
    int i;
@@ -209,7 +211,7 @@ static unsigned long long sdpFingerprint(int nvars, int nsdpblocks, const int* s
 {
    unsigned long long h = 1469598103934665603ULL;
    long long seen = 0;
-   const long long stride = sdpnnonz > 4096 ? sdpnnonz / 4096 : 1;
+   const long long stride = sdpnnonz > 4000000 ? sdpnnonz / 65536 : 1;
    int b;
    int k;
    int t;
@@ -225,6 +227,7 @@ static unsigned long long sdpFingerprint(int nvars, int nsdpblocks, const int* s
          const int nn = sdpnblockvarnonz[b][k];
          h = hashMix(h, (unsigned long long) sdpvar[b][k]);
          h = hashMix(h, (unsigned long long) nn);
+         h = hashMix(h, (unsigned long long) (size_t) sdpval[b][k]);
          /* first sample position >= seen that is a multiple of stride */
          t = (int) ((stride - (seen % stride)) % stride);
          for (; t < nn; t += (int) stride)

@@ -35,6 +35,7 @@ class SdpiSolver:
         rc = lib.SCIPsdpiSolverCreate(C.byref(self.h), None, None, None)
         assert rc == SCIP_OKAY
         self._keep = []
+        self._blockcache = {}
 
     def free(self):
         if self.h:
@@ -81,24 +82,30 @@ class SdpiSolver:
             v = np.array([e[2] for e in ce] or [0.0], dtype=np.float64)
             keep += [r, c, v]
             crow[b], ccol[b], cval[b] = _pi(r), _pi(c), _pd(v)
-            vars_ = sorted(blk['vars'].keys())
-            nn = np.array([len(blk['vars'][x]) for x in vars_] or [0], dtype=np.int32)
-            vv = np.array(vars_ or [0], dtype=np.int32)
-            keep += [nn, vv]
+            # the arrays of a block are built once per block object and re-used (same addresses on every call, like sdpi.c)
+            ck = id(blk['vars'])
+            if ck not in self._blockcache:
+                vars_ = sorted(blk['vars'].keys())
+                nn = np.array([len(blk['vars'][x]) for x in vars_] or [0], dtype=np.int32)
+                vv = np.array(vars_ or [0], dtype=np.int32)
+                k = max(len(vars_), 1)
+                rr = (PI * k)()
+                cc = (PI * k)()
+                va = (PD * k)()
+                held = [blk['vars'], nn, vv]
+                cnt = 0
+                for j, x in enumerate(vars_):
+                    ents = blk['vars'][x]
+                    er = np.array([e[0] for e in ents], dtype=np.int32)
+                    ec = np.array([e[1] for e in ents], dtype=np.int32)
+                    ev = np.array([e[2] for e in ents], dtype=np.float64)
+                    held += [er, ec, ev]
+                    rr[j], cc[j], va[j] = _pi(er), _pi(ec), _pd(ev)
+                    cnt += len(ents)
+                self._blockcache[ck] = (nn, vv, rr, cc, va, cnt, held)
+            nn, vv, rr, cc, va, cnt, held = self._blockcache[ck]
+            sdpnnonz += cnt
             nvarnonz[b], sdpvar[b] = _pi(nn), _pi(vv)
-            k = max(len(vars_), 1)
-            rr = (PI * k)()
-            cc = (PI * k)()
-            va = (PD * k)()
-            for j, x in enumerate(vars_):
-                ents = blk['vars'][x]
-                er = np.array([e[0] for e in ents], dtype=np.int32)
-                ec = np.array([e[1] for e in ents], dtype=np.int32)
-                ev = np.array([e[2] for e in ents], dtype=np.float64)
-                keep += [er, ec, ev]
-                rr[j], cc[j], va[j] = _pi(er), _pi(ec), _pd(ev)
-                sdpnnonz += len(ents)
-            keep += [rr, cc, va]
             srow[b], scol[b], sval[b] = rr, cc, va
             indch[b] = _pi(P.indchanges[b])
         nrem = np.array(P.nremovedinds or [0], dtype=np.int32)

@@ -230,7 +230,7 @@ def test_master_copy_is_reused_and_invalidated(gpu):
     def make(lb, ub, blocks):
         return sdpi_prepare.SdpiProblem(np.linspace(-1, 1, nvars), lb, ub, blocks, [])
 
-    blocks = [dict(n=n, vars=vars_, const=const)]
+    blocks = make(-np.ones(nvars), np.ones(nvars), [dict(n=n, vars=vars_, const=const)]).blocks     # normalised once, shared
     lb = -np.ones(nvars); ub = np.ones(nvars)
     s = new_solver(gpu)
 
@@ -249,11 +249,12 @@ def test_master_copy_is_reused_and_invalidated(gpu):
 
     t1, o1 = run(make(lb, ub, blocks))
     lb2, ub2 = lb.copy(), ub.copy()
-    lb2[3] = ub2[3] = 1.0
-    lb2[7] = ub2[7] = -1.0
+    lb2[3] = ub2[3] = 0.0
+    lb2[7] = ub2[7] = 0.0
+    lb2[11] = ub2[11] = 0.1
     t2, o2 = run(make(lb2, ub2, blocks))                   # same arrays, other fixings: master copy re-used
     vars3 = dict(vars_)
     vars3[5] = [(r, c, x * (2.0 if (r, c) == (0, 0) else 1.0)) for (r, c, x) in vars_[5]]
     t3, o3 = run(make(lb, ub, [dict(n=n, vars=vars3, const=const)]))   # one changed value: fingerprint must differ
-    assert abs(o3 - o1) > 1e-9 or True                    # values differ in general; correctness is asserted inside run()
+    print("master copy: first call %.4f s (upload), second call %.4f s (re-used), changed data %.4f s" % (t1, t2, t3))
     s.free()
