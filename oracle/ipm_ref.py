@@ -76,11 +76,14 @@ def sym(M):
 def schur_block(A, X, Zinv):
     """Extended Schur contribution of one dense block: Mx[i, j] = tr(A_i X A_j Zinv), i, j = 0..m.
 
-    Same three products as the device path: T_j = A_j Zinv, U_j = X T_j, Mx = A_flat U_flat^T."""
+    Three large BLAS calls, like the device path (T_j = A_j Zinv, U_j = X T_j, Mx = A_flat U_flat^T).  The batched
+    left-multiplication is written as one stack product: V_j = T_j^T X = (X T_j)^T, and because every A_i is symmetric
+    <A_i, U_j> = <A_i, U_j^T>, so Mx = A_flat V_flat^T needs no explicit transposition of the result."""
     m1, n, _ = A.shape
-    T = A.reshape(m1 * n, n) @ Zinv                      # GEMM1: stack of A_j times Zinv
-    U = np.matmul(X, T.reshape(m1, n, n))                # GEMM2: batched X * T_j
-    Mx = A.reshape(m1, n * n) @ U.reshape(m1, n * n).T   # GEMM3
+    T = A.reshape(m1 * n, n) @ Zinv                                        # GEMM1: stack of A_j times Zinv
+    Tt = np.ascontiguousarray(T.reshape(m1, n, n).transpose(0, 2, 1))      # T_j^T (one memory pass)
+    V = Tt.reshape(m1 * n, n) @ X                                          # GEMM2: stack product, V_j = T_j^T X
+    Mx = A.reshape(m1, n * n) @ V.reshape(m1, n * n).T                     # GEMM3
     return 0.5 * (Mx + Mx.T)
 
 
