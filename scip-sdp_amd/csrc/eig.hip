@@ -429,6 +429,141 @@ __global__ void __launch_bounds__(1024) k_jacobi_sort(int n, const double* __res
    }
 }
 
+/* n <= 64: the whole decomposition in ONE launch of one workgroup, matrix and eigenvector matrix in LDS, parallel-order
+ * rounds separated by workgroup barriers, convergence test in the kernel (the typical SCIP-SDP block has 2-50 rows and is
+ * latency bound: cons_sdp.c calls the eigen routine for every candidate solution, lapack_interface.c:178-288) */
+#define JS 64
+__global__ void __launch_bounds__(256) k_jacobi_small(int n, const double* __restrict__ Ain, double* __restrict__ lam,
+   double* __restrict__ V, int* __restrict__ info)
+{
+   __shared__ double a[JS][JS + 1];
+   __shared__ double vt[JS][JS + 1];
+   __shared__ double rc[JS / 2], rs[JS / 2];
+   __shared__ double red[8];
+   __shared__ int order[JS];
+   const int tid = threadIdx.x;
+   const int np = (n + 1) & ~1;
+   const int half = np / 2;
+   for (int e = tid; e < JS * JS; e += 256)
+   {
+      const int r = e / JS, c = e % JS;
+      double v = 0.0;
+      if ( r < n && c < n )
+         v = 0.5 * (Ain[(long long) r * n + c] + Ain[(long long) c * n + r]);
+      a[r][c] = v;
+      vt[r][c] = (r == c) ? 1.0 : 0.0;
+   }
+   __syncthreads();
+   int sweeps = 0;
+   for (sweeps = 0; sweeps < 40 && n > 1; ++sweeps)
+   {
+      /* off-diagonal vs diagonal mass */
+      double off = 0.0, dg = 0.0;
+      for (int e = tid; e < n * n; e += 256)
+      {
+         const int r = e / n, c = e % n;
+         const double v = a[r][c];
+         if ( r == c ) dg += v * v; else off += v * v;
+      }
+      for (int o = 32; o > 0; o >>= 1)
+      {
+         off += __shfl_down(off, o, 64);
+         dg += __shfl_down(dg, o, 64);
+      }
+      if ( (tid & 63) == 0 )
+      {
+         red[(tid >> 6) * 2] = off;
+         red[(tid >> 6) * 2 + 1] = dg;
+      }
+      __syncthreads();
+      off = red[0] + red[2] + red[4] + red[6];
+      dg = red[1] + red[3] + red[5] + red[7];
+      __syncthreads();
+      if ( !(off > 1e-30 * dg) || !(off > 0.0) )
+         break;
+      for (int r = 0; r < np - 1; ++r)
+      {
+         if ( tid < half )
+         {
+            int p, q;
+            jac_pair(np, r, tid, &p, &q);
+            double c = 1.0, s = 0.0;
+            if ( q < n )
+            {
+               const double apq = a[p][q], app = a[p][p], aqq = a[q][q];
+               if ( fabs(apq) > 1e-300 && fabs(apq) > 1e-19 * (fabs(app) + fabs(aqq)) )
+               {
+                  const double th = (aqq - app) / (2.0 * apq);
+                  const double t = (th >= 0.0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+                  c = 1.0 / sqrt(t * t + 1.0);
+                  s = t * c;
+               }
+            }
+            rc[tid] = c;
+            rs[tid] = s;
+         }
+         __syncthreads();
+         /* two-sided update: item (k1, k2) owns the 2 x 2 intersection of pair k1 (rows) and pair k2 (columns) */
+         for (int it = tid; it < half * half; it += 256)
+         {
+            const int k1 = it / half, k2 = it % half;
+            int p, q, u, v;
+            jac_pair(np, r, k1, &p, &q);
+            jac_pair(np, r, k2, &u, &v);
+            const bool hq = q < n, hv = v < n;
+            const double c1 = rc[k1], s1 = rs[k1], c2 = rc[k2], s2 = rs[k2];
+            const double apu = a[p][u], apv = hv ? a[p][v] : 0.0, aqu = hq ? a[q][u] : 0.0, aqv = (hq && hv) ? a[q][v] : 0.0;
+            const double bpu = c1 * apu - s1 * aqu, bqu = s1 * apu + c1 * aqu;
+            const double bpv = c1 * apv - s1 * aqv, bqv = s1 * apv + c1 * aqv;
+            a[p][u] = c2 * bpu - s2 * bpv;
+            if ( hv ) a[p][v] = s2 * bpu + c2 * bpv;
+            if ( hq ) a[q][u] = c2 * bqu - s2 * bqv;
+            if ( hq && hv ) a[q][v] = s2 * bqu + c2 * bqv;
+         }
+         /* eigenvector rows: item (k1, column) */
+         for (int it = tid; it < half * n; it += 256)
+         {
+            const int k1 = it / n, col = it % n;
+            int p, q;
+            jac_pair(np, r, k1, &p, &q);
+            if ( q < n )
+            {
+               const double c1 = rc[k1], s1 = rs[k1];
+               const double vp = vt[p][col], vq = vt[q][col];
+               vt[p][col] = c1 * vp - s1 * vq;
+               vt[q][col] = s1 * vp + c1 * vq;
+            }
+         }
+         __syncthreads();
+      }
+   }
+   /* rank sort of the diagonal */
+   if ( tid < n )
+   {
+      const double di = a[tid][tid];
+      int rank = 0;
+      for (int j = 0; j < n; ++j)
+      {
+         const double dj = a[j][j];
+         if ( dj < di || (dj == di && j < tid) )
+            ++rank;
+      }
+      order[rank] = tid;
+      lam[rank] = di;
+   }
+   __syncthreads();
+   if ( V != NULL )
+   {
+      for (int e = tid; e < n * n; e += 256)
+      {
+         const int r = e / n, c = e % n;
+         V[e] = vt[order[r]][c];
+      }
+   }
+   if ( tid == 0 && info != NULL )
+      *info = sweeps;
+}
+
 long long hs_syev_ws(int n)
 {
    return (long long) n * n + 2LL * n + 64;
@@ -438,6 +573,12 @@ int hs_syev_jacobi(hipStream_t s, int n, double* A, double* lam, double* V, int*
 {
    if ( n <= 0 )
       return HS_ERR_ARG;
+   if ( n <= JS )
+   {
+      hipLaunchKernelGGL(k_jacobi_small, dim3(1), dim3(256), 0, s, n, A, lam, V, info);
+      HS_LAUNCH_CHECK();
+      return HS_OK;
+   }
    double* Vt = ws;                              /* n x n */
    double* rot = Vt + (long long) n * n;         /* 2 * ceil(n/2) */
    double* nrm = rot + 2LL * ((n + 1) / 2) + 2;  /* 2 */
