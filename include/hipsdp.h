@@ -54,6 +54,8 @@ typedef struct hipsdp_params
    int    verbose;       /* 1: one line per iteration on stdout (SCIP_SDPPAR_SDPINFO) */
    int    lanczos_steps; /* Lanczos steps per step-length estimate */
    int    reserved;
+   double pabstol;       /* > 0: optimal termination also needs ||b - A(X)||_2 <= pabstol, ABSOLUTE: the caller's own check of
+                          * the X-side is absolute (sdpsolchecker.c:775-931 with SCIP_SDPPAR_FEASTOL) while pinf is relative */
 } hipsdp_params;
 
 typedef struct hipsdp_info

@@ -48,13 +48,15 @@ class CoreProblem:
 
 
 class Params:
-    def __init__(self, gaptol=1e-5, feastol=1e-5, maxiter=100, gamma=0.98, verbose=False, infeastol=1e-7):
+    def __init__(self, gaptol=1e-5, feastol=1e-5, maxiter=100, gamma=0.98, verbose=False, infeastol=1e-7, pabstol=0.0):
         self.gaptol = gaptol          # relative gap / absolute gap tolerance (relax_sdp.c:70)
         self.feastol = feastol        # residual tolerance (relax_sdp.c:71)
         self.maxiter = maxiter
         self.gamma = gamma            # fraction of the step to the boundary
         self.verbose = verbose
         self.infeastol = infeastol    # tolerance of the Farkas certificates
+        self.pabstol = pabstol        # > 0: optimal termination also needs ||b - A(X)||_2 <= pabstol (absolute, the bound
+                                      # sdpsolchecker.c:775-931 applies with SCIP_SDPPAR_FEASTOL)
 
 
 class Result:
@@ -186,7 +188,9 @@ def hsd_solve(prob, par=None, start=None):
 
         # ---- termination
         # optimal: absolute gap (sdpisolver_dsdp.c:1558-1571) and feasibility of y / tau within feastol
-        if pinf <= par.feastol and dabs <= par.feastol and gap <= par.gaptol:
+        pabs = np.linalg.norm(rp) / tau
+        pabsok = par.pabstol <= 0.0 or pabs <= par.pabstol
+        if pinf <= par.feastol and pabsok and dabs <= par.feastol and gap <= par.gaptol:
             res.status = STATUS_OPTIMAL
             break
         # Farkas certificates, scale free: homogeneous residual relative to the objective value it certifies
@@ -219,6 +223,8 @@ def hsd_solve(prob, par=None, start=None):
         # no progress: the worst scaled violation has not improved by 10 % for 6 iterations (accuracy limit of the problem)
         if not (tau < 1e-2 * min(1.0, kappa) or mu / (tau * tau) > 1e10):
             merit = max(pinf / par.feastol, dabs / par.feastol, gap / par.gaptol)
+            if par.pabstol > 0.0:
+                merit = max(merit, pabs / par.pabstol)
             if merit < 0.9 * bestmerit:
                 bestmerit = merit
                 sincebest = 0

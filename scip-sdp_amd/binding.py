@@ -15,7 +15,7 @@ STATUS_NAMES = {0: "optimal", 1: "dual_infeasible", 2: "dual_unbounded", 3: "bot
 class Params(C.Structure):
     _fields_ = [("gaptol", C.c_double), ("feastol", C.c_double), ("infeastol", C.c_double), ("objlimit", C.c_double),
                 ("timelimit", C.c_double), ("gamma", C.c_double), ("ws_gbytes", C.c_double), ("maxiter", C.c_int),
-                ("verbose", C.c_int), ("lanczos_steps", C.c_int), ("reserved", C.c_int)]
+                ("verbose", C.c_int), ("lanczos_steps", C.c_int), ("reserved", C.c_int), ("pabstol", C.c_double)]
 
 
 class Info(C.Structure):

@@ -16,19 +16,54 @@
 /* Factor the nb x nb diagonal block at A (leading dimension lda), nb <= 64: A_blk = L L^T.  Writes L into the lower
  * triangle of the block and inv(L) (64 x 64, identity-padded) into dinv.  flag: first failing global pivot index + 1.
  *
- * Thread t owns row i = t / 4 and the 16 columns j = (t % 4) + 4 jj in registers; column k is published through a
- * double-buffered LDS vector, so a step costs one barrier.  All loops are fully unrolled (static register indices).
- * The inverse is then formed by one wavefront, lane c = column c, right-looking so that the 63 - i updates of a step are
- * independent instructions. */
+ * 256 threads.  Factorization: thread t owns row i = t / 4 and the 16 columns j = (t % 4) + 4 jj in registers; column k
+ * is published through a double-buffered LDS vector, so a step costs one barrier; a step issues all its LDS reads up
+ * front and has no branches in the update; pivots go through v_rsq_f64 + Goldschmidt steps (square root and reciprocal
+ * together, no division).  Inverse: the four 16 x 16 diagonal blocks are inverted by one wavefront each (lane c = column
+ * c, right-looking), the six off-diagonal blocks X_ij = -X_ii (sum_k L_ik X_kj) are 16 x 16 x 16 products on the matrix
+ * cores (the f64 accumulator layout of the inner sum is exactly the B-operand layout of the outer product), one block
+ * diagonal per barrier.  All loops are fully unrolled (static register indices). */
+__device__ __forceinline__ void sqrt_and_rsqrt(double d, double* sd, double* isd)
+{
+   double y = __builtin_amdgcn_rsq(d);
+   double g = d * y;
+   double h = 0.5 * y;
+   double r = fma(-h, g, 0.5);
+   g = fma(g, r, g);
+   h = fma(h, r, h);
+   r = fma(-h, g, 0.5);
+   g = fma(g, r, g);
+   h = fma(h, r, h);
+   /* one residual correction of the square root: g += (d - g^2) * h, and of the reciprocal */
+   g = fma(fma(-g, g, d), h, g);
+   double y2 = 2.0 * h;
+   y2 = fma(fma(-g, y2, 1.0), y2, y2);
+   *sd = g;
+   *isd = y2;
+}
+
+struct __attribute__((aligned(16))) dpair { double x, y; };
+typedef double v4dc __attribute__((ext_vector_type(4)));
+
+#define PD_LD (NB + 2)
+#define PD_SMEM_BYTES ((2 * 4 * 18 + 2 * NB * PD_LD + 2 * NB) * (int) sizeof(double))
+
+template<int NBK>      /* padded block size actually processed: 16, 32 or 64 (tiny blocks skip the identity padding) */
 __global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ A, long long lda, int nb, int j0,
    double* __restrict__ dinv, int* __restrict__ flag, const double* __restrict__ diag0, double regtol)
 {
-   __shared__ double col[2][NB];
-   __shared__ double lm[NB][NB + 1];      /* final L (scaled), read by the inverse */
-   __shared__ double invd[NB];
+   extern __shared__ __attribute__((aligned(16))) double pd_smem[];
+   double (*colp)[4][18] = reinterpret_cast<double (*)[4][18]>(pd_smem);                  /* column k, permuted: row i at [i & 3][i >> 2] */
+   double (*lmT)[PD_LD] = reinterpret_cast<double (*)[PD_LD]>(pd_smem + 2 * 4 * 18);      /* lmT[k][i] = L[i][k] (final) */
+   double (*X)[PD_LD] = reinterpret_cast<double (*)[PD_LD]>(pd_smem + 2 * 4 * 18 + NB * PD_LD);   /* inv(L), row major */
+   double* invd = pd_smem + 2 * 4 * 18 + 2 * NB * PD_LD;
+   double* d0s = invd + NB;
    const int tid = threadIdx.x;
+   const int lane = tid & 63;
+   const int wave = tid >> 6;
    const int i = tid >> 2;
    const int jc = tid & 3;
+   const int ir = i & 3, iq = i >> 2;
    double r[16];
 #pragma unroll
    for (int jj = 0; jj < 16; ++jj)
@@ -39,23 +74,32 @@ __global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ A, long
          v = A[(long long) i * lda + j];
       r[jj] = v;
    }
+   if ( diag0 != NULL && tid < nb )
+      d0s[tid] = diag0[j0 + tid];
    int bad = 0;
 
 #pragma unroll
-   for (int k = 0; k < NB; ++k)
+   for (int k = 0; k < NBK; ++k)
    {
       /* owners of column k publish it (rows >= k) */
       if ( jc == (k & 3) && i >= k )
-         col[k & 1][i] = r[k >> 2];
+         colp[k & 1][ir][iq] = r[k >> 2];
       __syncthreads();
-      double d = col[k & 1][k];
+      /* everything a step needs from LDS is requested up front (no branches between the reads): the pivot, my row's entry
+       * and the 16 entries of my columns; entries above the diagonal are updated too (they are never read) */
+      double d = colp[k & 1][k & 3][k >> 2];
+      const double ci = colp[k & 1][ir][iq];
+      dpair cj[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+         cj[q] = *reinterpret_cast<const dpair*>(&colp[k & 1][jc][2 * q]);
       if ( k < nb )
       {
          if ( diag0 != NULL )
          {
             /* semidefinite mode (Schur complement with dependent columns): a pivot that cancelled to rounding level is
              * replaced by a small positive one, which keeps the direction alive so that a ray along it can be found */
-            const double d0 = diag0[j0 + k];
+            const double d0 = d0s[k];
             if ( !(d > regtol * d0) || !(d > 1e-300) )
                d = (d0 > 1e-280) ? regtol * d0 : 1.0;
          }
@@ -66,24 +110,29 @@ __global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ A, long
             d = 1.0;                 /* keep going with a harmless pivot; the caller reads the flag */
          }
       }
-      const double sd = sqrt(d);
-      const double isd = 1.0 / sd;
-      const double lik = (i > k) ? col[k & 1][i] * isd : 0.0;
+      double sd, isd;
+      sqrt_and_rsqrt(d, &sd, &isd);
+      const double lik = (i > k) ? ci * isd : 0.0;
+      const double t = lik * isd;
       if ( jc == (k & 3) )
       {
          /* final value of column k in my row */
          const double lv = (i > k) ? lik : ((i == k) ? sd : 0.0);
          r[k >> 2] = lv;
-         lm[i][k] = lv;
+         lmT[k][i] = lv;
          if ( i == k )
             invd[k] = isd;
       }
-#pragma unroll
-      for (int jj = (k >> 2); jj < 16; ++jj)
+      else if ( jc > (k & 3) )
       {
-         const int j = jc + 4 * jj;
-         if ( j > k && j <= i )
-            r[jj] -= lik * (col[k & 1][j] * isd);
+         const double cv = ((k >> 2) & 1) ? cj[k >> 3].y : cj[k >> 3].x;
+         r[k >> 2] = fma(-t, cv, r[k >> 2]);
+      }
+#pragma unroll
+      for (int jj = (k >> 2) + 1; jj < 16; ++jj)
+      {
+         const double cv = (jj & 1) ? cj[jj >> 1].y : cj[jj >> 1].x;
+         r[jj] = fma(-t, cv, r[jj]);
       }
    }
    __syncthreads();
@@ -99,24 +148,90 @@ __global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ A, long
    if ( tid == 0 && bad != 0 )
       atomicCAS(flag, 0, bad);
 
-   /* inverse: lane c solves L x = e_c */
-   if ( tid < NB )
+   /* inverse, diagonal 16 x 16 blocks: wavefront w, lane c < 16 solves L_ww x = e_c */
+   constexpr int NBLK = NBK / 16;
+   if ( wave < NBLK && lane < 16 )
    {
-      const int c = tid;
-      double sv[NB];
+      const int base = 16 * wave;
+      double sv[16];
 #pragma unroll
-      for (int j = 0; j < NB; ++j)
-         sv[j] = (j == c) ? 1.0 : 0.0;
+      for (int j = 0; j < 16; ++j)
+         sv[j] = (j == lane) ? 1.0 : 0.0;
 #pragma unroll
-      for (int ii = 0; ii < NB; ++ii)
+      for (int ii = 0; ii < 16; ++ii)
       {
-         const double xi = sv[ii] * invd[ii];
-         dinv[ii * NB + c] = xi;
+         const double xi = sv[ii] * invd[base + ii];
+         X[base + ii][base + lane] = xi;
+         if ( ((ii + 1) & 1) && ii + 1 < 16 )
+            sv[ii + 1] -= lmT[base + ii][base + ii + 1] * xi;
 #pragma unroll
-         for (int j = ii + 1; j < NB; ++j)
-            sv[j] -= lm[j][ii] * xi;
+         for (int j = (ii + 2) & ~1; j < 16; j += 2)
+         {
+            const dpair l2 = *reinterpret_cast<const dpair*>(&lmT[base + ii][base + j]);
+            sv[j] -= l2.x * xi;
+            sv[j + 1] -= l2.y * xi;
+         }
       }
    }
+   __syncthreads();
+   /* off-diagonal blocks by block diagonals: block (bi, bj = bi - dd) on wavefront bj */
+#pragma unroll
+   for (int dd = 1; dd < NBLK; ++dd)
+   {
+      if ( wave < NBLK - dd )
+      {
+         const int bj = wave, bi = wave + dd;
+         const int lr = lane & 15, lk = lane >> 4;
+         v4dc acc = (v4dc){0.0, 0.0, 0.0, 0.0};
+         for (int kb = bj; kb < bi; ++kb)
+         {
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx)
+            {
+               const double a = lmT[16 * kb + 4 * sidx + lk][16 * bi + lr];       /* L[16 bi + lr][16 kb + 4 s + lk] */
+               const double bv = X[16 * kb + 4 * sidx + lk][16 * bj + lr];
+               acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc, 0, 0, 0);
+            }
+         }
+         v4dc acc2 = (v4dc){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+         for (int sidx = 0; sidx < 4; ++sidx)
+         {
+            const double a = X[16 * bi + lr][16 * bi + 4 * sidx + lk];
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[sidx], acc2, 0, 0, 0);
+         }
+#pragma unroll
+         for (int rr = 0; rr < 4; ++rr)
+            X[16 * bi + lk + 4 * rr][16 * bj + lr] = -acc2[rr];
+      }
+      __syncthreads();
+   }
+   /* inv(L), identity padded, block upper triangle zero */
+   for (int e = tid; e < NB * NB; e += 256)
+   {
+      const int rr = e >> 6, cc = e & 63;
+      double v;
+      if ( rr >= NBK || cc >= NBK )
+         v = (rr == cc) ? 1.0 : 0.0;
+      else
+         v = ((rr >> 4) >= (cc >> 4)) ? X[rr][cc] : 0.0;
+      dinv[e] = v;
+   }
+}
+
+template<int NBK>
+static int launch_potrf_diag(hipStream_t s, double* Ajj, long long lda, int nb, int j0, double* dj, int* flag, const double* diag0)
+{
+   static bool attr_set = false;
+   if ( !attr_set )
+   {
+      HS_HIP( hipFuncSetAttribute(reinterpret_cast<const void*>(&k_potrf_diag<NBK>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            PD_SMEM_BYTES) );
+      attr_set = true;
+   }
+   hipLaunchKernelGGL((k_potrf_diag<NBK>), dim3(1), dim3(256), PD_SMEM_BYTES, s, Ajj, lda, nb, j0, dj, flag, diag0, 1e-13);
+   HS_LAUNCH_CHECK();
+   return HS_OK;
 }
 
 int hs_potrf(hipStream_t s, int n, double* A, double* dinv, int* flag, const double* diag0)
@@ -131,8 +246,12 @@ int hs_potrf(hipStream_t s, int n, double* A, double* dinv, int* flag, const dou
       const int nb = (n - j0) < NB ? (n - j0) : NB;
       double* Ajj = A + (long long) j0 * lda + j0;
       double* dj = dinv + (long long) b * NB * NB;
-      hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, s, Ajj, lda, nb, j0, dj, flag, diag0, 1e-13);
-      HS_LAUNCH_CHECK();
+      if ( nb <= 16 )
+         HS_CALL( launch_potrf_diag<16>(s, Ajj, lda, nb, j0, dj, flag, diag0) );
+      else if ( nb <= 32 )
+         HS_CALL( launch_potrf_diag<32>(s, Ajj, lda, nb, j0, dj, flag, diag0) );
+      else
+         HS_CALL( launch_potrf_diag<64>(s, Ajj, lda, nb, j0, dj, flag, diag0) );
       const int j1 = j0 + nb;
       const int rem = n - j1;
       if ( rem <= 0 )

@@ -15,6 +15,8 @@
 
 #define HS_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if ( e_ != hipSuccess ) { hs_record_hip_error(e_, "kernel launch", __FILE__, __LINE__); return HS_ERR_HIP; } } while (0)
 
+__global__ void k_lmin_tiny(int n, const double* __restrict__ Ain, double* __restrict__ res);
+
 /* ---------------------------------------------------------------------------------------------------------------- */
 /* Lanczos                                                                                                            */
 /* ---------------------------------------------------------------------------------------------------------------- */
@@ -262,6 +264,13 @@ int hs_lanczos_lmin(hipStream_t s, int n, const double* W, int maxsteps, double*
 {
    if ( n <= 0 )
       return HS_ERR_ARG;
+   if ( n <= 16 )
+   {
+      /* tiny blocks are launch bound: one wavefront diagonalises the matrix exactly in ONE launch (vs 2 per Lanczos step) */
+      hipLaunchKernelGGL(k_lmin_tiny, dim3(1), dim3(64), 0, s, n, W, res);
+      HS_LAUNCH_CHECK();
+      return HS_OK;
+   }
    int k = maxsteps < n ? maxsteps : n;
    if ( k > 250 ) k = 250;
    double* Q = ws;                                    /* (k + 1) x n */
@@ -562,6 +571,94 @@ __global__ void __launch_bounds__(256) k_jacobi_small(int n, const double* __res
    }
    if ( tid == 0 && info != NULL )
       *info = sweeps;
+}
+
+/* n <= 16: smallest eigenvalue only, ONE wavefront (np/2 <= 8 rotation pairs, <= 64 two-sided 2 x 2 items: one per lane),
+ * no eigenvectors; res = { lambda_min, 0 (exact: no residual bound), n } like the Lanczos result */
+__global__ void __launch_bounds__(64) k_lmin_tiny(int n, const double* __restrict__ Ain, double* __restrict__ res)
+{
+   __shared__ double a[16][17];
+   __shared__ double rc[8], rs[8];
+   const int tid = threadIdx.x;
+   const int np = (n + 1) & ~1;
+   const int half = np / 2;
+   for (int e = tid; e < 256; e += 64)
+   {
+      const int r = e >> 4, c = e & 15;
+      double v = 0.0;
+      if ( r < n && c < n )
+         v = 0.5 * (Ain[r * n + c] + Ain[c * n + r]);
+      a[r][c] = v;
+   }
+   __syncthreads();
+   const int k1 = tid / half, k2 = tid - k1 * half;
+   const bool item = tid < half * half;
+   for (int sweeps = 0; sweeps < 30 && n > 1; ++sweeps)
+   {
+      double off = 0.0, dg = 0.0;
+      for (int e = tid; e < 256; e += 64)
+      {
+         const int r = e >> 4, c = e & 15;
+         const double v = a[r][c];
+         if ( r == c ) dg += v * v; else off += v * v;
+      }
+      for (int o = 32; o > 0; o >>= 1)
+      {
+         off += __shfl_xor(off, o, 64);
+         dg += __shfl_xor(dg, o, 64);
+      }
+      if ( !(off > 1e-30 * dg) || !(off > 0.0) )
+         break;
+      for (int r = 0; r < np - 1; ++r)
+      {
+         if ( tid < half )
+         {
+            int p, q;
+            jac_pair(np, r, tid, &p, &q);
+            double c = 1.0, sn = 0.0;
+            if ( q < n )
+            {
+               const double apq = a[p][q], app = a[p][p], aqq = a[q][q];
+               if ( fabs(apq) > 1e-300 && fabs(apq) > 1e-19 * (fabs(app) + fabs(aqq)) )
+               {
+                  const double th = (aqq - app) / (2.0 * apq);
+                  const double t = (th >= 0.0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+                  c = 1.0 / sqrt(t * t + 1.0);
+                  sn = t * c;
+               }
+            }
+            rc[tid] = c;
+            rs[tid] = sn;
+         }
+         __syncthreads();
+         if ( item )
+         {
+            /* the 2 x 2 items of a round are disjoint: read-modify-write in place.  Rows / columns >= n are the zero
+             * padding of a[][] (np <= 16) and rotate with c = 1, s = 0, so they stay zero */
+            int p, q, u, v;
+            jac_pair(np, r, k1, &p, &q);
+            jac_pair(np, r, k2, &u, &v);
+            const double c1 = rc[k1], s1 = rs[k1], c2 = rc[k2], s2 = rs[k2];
+            const double apu = a[p][u], apv = a[p][v], aqu = a[q][u], aqv = a[q][v];
+            const double bpu = c1 * apu - s1 * aqu, bqu = s1 * apu + c1 * aqu;
+            const double bpv = c1 * apv - s1 * aqv, bqv = s1 * apv + c1 * aqv;
+            a[p][u] = c2 * bpu - s2 * bpv;
+            a[p][v] = s2 * bpu + c2 * bpv;
+            a[q][u] = c2 * bqu - s2 * bqv;
+            a[q][v] = s2 * bqu + c2 * bqv;
+         }
+         __syncthreads();
+      }
+   }
+   if ( tid == 0 )
+   {
+      double lm = a[0][0];
+      for (int j = 1; j < n; ++j)
+         lm = fmin(lm, a[j][j]);
+      res[0] = lm;
+      res[1] = 0.0;
+      res[2] = (double) n;
+   }
 }
 
 long long hs_syev_ws(int n)

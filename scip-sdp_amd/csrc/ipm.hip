@@ -69,6 +69,7 @@ struct hipsdp_solver
    hipStream_t stream;
    hipStream_t stream2;          /* second queue: the Z-side chains run beside the X-side ones (both are latency bound) */
    hipEvent_t evFork, evJoin;
+   bool use2;                    /* false for tiny blocks: they are launch bound and the cross-queue events only add latency */
    int m, q;
    std::vector<Block> blk;
    double* b;        /* m */
@@ -136,6 +137,7 @@ extern "C" void hipsdp_default_params(hipsdp_params* p)
    p->verbose = 0;
    p->lanczos_steps = 24;
    p->reserved = 0;
+   p->pabstol = 0.0;
 }
 
 template<class T>
@@ -697,6 +699,8 @@ static int gemm(hipsdp_solver* s, int layA, int layB, int M, int N, int K, doubl
 /* fork: stream2 starts after everything queued on stream so far; join: stream continues after stream2 has drained */
 static int fork2(hipsdp_solver* s)
 {
+   if ( !s->use2 )
+      return HS_OK;
    HS_HIP( hipEventRecord(s->evFork, s->stream) );
    HS_HIP( hipStreamWaitEvent(s->stream2, s->evFork, 0) );
    return HS_OK;
@@ -704,6 +708,8 @@ static int fork2(hipsdp_solver* s)
 
 static int join2(hipsdp_solver* s)
 {
+   if ( !s->use2 )
+      return HS_OK;
    HS_HIP( hipEventRecord(s->evJoin, s->stream2) );
    HS_HIP( hipStreamWaitEvent(s->stream, s->evJoin, 0) );
    return HS_OK;
@@ -884,7 +890,7 @@ static int direction(hipsdp_solver* s, double sigma, double eta, double mu, doub
 static int steplen_enqueue(hipsdp_solver* s)
 {
    int k = 0;
-   hipStream_t st = s->stream, st2 = s->stream2;
+   hipStream_t st = s->stream, st2 = s->use2 ? s->stream2 : s->stream;
    HS_CALL( fork2(s) );
    for (auto& B : s->blk)
    {
@@ -948,6 +954,11 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
    info->status = HIPSDP_STATUS_UNSOLVED;
    HS_CALL( ensure_schur_ws(s) );
    HS_CALL( ensure_packed(s) );
+   {
+      int nmaxb = 0;
+      for (auto& B : s->blk) if ( B.n > nmaxb ) nmaxb = B.n;
+      s->use2 = (nmaxb >= 128) && getenv("HIPSDP_ONEQUEUE") == NULL;
+   }
 
    long long N = q;
    for (auto& B : s->blk) N += B.n;
@@ -1067,6 +1078,8 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
          rdmax = fmax(rdmax, sqrt(hs.v[SC_BLK(k, 0)]));
       }
       pinf = sqrt(hs.v[SC_RP2]) / tau / (1.0 + normb);
+      const double pabs = sqrt(hs.v[SC_RP2]) / tau;
+      const bool pabsok = par.pabstol <= 0.0 || pabs <= par.pabstol;
       dinf = sqrt(rd2) / tau / (1.0 + normC);
       dabs = rdmax / tau;
       gap = fabs(dobj - pobj) / tau;
@@ -1087,7 +1100,7 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
          status = HIPSDP_STATUS_OBJLIM;
          break;
       }
-      if ( pinf <= par.feastol && dabs <= par.feastol && gap <= par.gaptol )
+      if ( pinf <= par.feastol && pabsok && dabs <= par.feastol && gap <= par.gaptol )
       {
          status = HIPSDP_STATUS_OPTIMAL;
          break;
@@ -1134,7 +1147,9 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       /* no progress: the worst scaled violation has not improved by 10 % for 6 iterations (accuracy limit of the problem) */
       if ( !certzone )
       {
-         const double merit = fmax(fmax(pinf / par.feastol, dabs / par.feastol), gap / par.gaptol);
+         double merit = fmax(fmax(pinf / par.feastol, dabs / par.feastol), gap / par.gaptol);
+         if ( par.pabstol > 0.0 )
+            merit = fmax(merit, pabs / par.pabstol);
          if ( merit < 0.9 * bestmerit )
          {
             bestmerit = merit;
@@ -1163,7 +1178,7 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       {
          const int n = B.n;
          const long long n2 = (long long) n * n;
-         hipStream_t st2 = s->stream2;
+         hipStream_t st2 = s->use2 ? s->stream2 : s->stream;
          /* Z chain on the second queue */
          if ( !factors_valid )
          {
@@ -1334,7 +1349,7 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
          {
             const int n = B.n;
             const long long n2 = (long long) n * n;
-            hipStream_t st2 = s->stream2;
+            hipStream_t st2 = s->use2 ? s->stream2 : s->stream;
             HS_CALL( hs_scale_add(st, n2, alpha, B.dX, 1.0, B.Xs, B.X) );
             HS_CALL( hs_copy(st, B.Lx, B.X, n2) );
             HS_CALL( hs_potrf(st, n, B.Lx, B.dinvx, s->flags + 1, NULL) );

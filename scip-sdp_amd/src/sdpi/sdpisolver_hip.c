@@ -398,6 +398,9 @@ static SCIP_RETCODE engineSolve(SCIP_SDPISOLVER* s, SCIP_Real gaptol, SCIP_Real 
    hipsdp_default_params(&par);
    par.gaptol = gaptol;
    par.feastol = feastol;
+   /* the caller validates the X-side ABSOLUTELY with SCIP_SDPPAR_FEASTOL (sdpsolchecker.c:775-931) while the engine's own
+    * measure is relative to 1 + ||b||: when the outer tolerance is the looser one, ask for it explicitly */
+   par.pabstol = (s->feastol > feastol) ? s->feastol : 0.0;
    par.objlimit = (s->penalty ? HS_INFINITY : s->objlimit);
    par.timelimit = remaining < HS_INFINITY ? remaining : 0.0;
    par.verbose = s->sdpinfo ? 1 : 0;

@@ -26,8 +26,9 @@ def gpu_solve(hb, core, **kw):
 
 
 def compare(hb, core, tol=1e-6):
-    ref = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=tol, feastol=tol))
-    g = gpu_solve(hb, core, gaptol=tol, feastol=tol)
+    # solver tolerance tol, acceptance (TOL = 10 tol) absolute on the X-side: the reference's sdpsolverfeastol / feastol pair
+    ref = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=tol, feastol=tol, pabstol=10 * tol))
+    g = gpu_solve(hb, core, gaptol=tol, feastol=tol, pabstol=10 * tol)
     assert g["info"].status == ref.status, (g["info"].status, ref.status)
     return ref, g
 
