@@ -573,12 +573,27 @@ __global__ void __launch_bounds__(256) k_jacobi_small(int n, const double* __res
       *info = sweeps;
 }
 
+/* rsqrt with two Newton steps (v_rsq_f64 is a low-precision seed) */
+__device__ __forceinline__ double rsqrt_nr(double x)
+{
+   double y = __builtin_amdgcn_rsq(x);
+   double h = 0.5 * y, g = x * y;
+   double r = fma(-h, g, 0.5);
+   g = fma(g, r, g); h = fma(h, r, h);
+   r = fma(-h, g, 0.5);
+   h = fma(h, r, h);
+   return 2.0 * h;
+}
+
 /* n <= 16: smallest eigenvalue only, ONE wavefront (np/2 <= 8 rotation pairs, <= 64 two-sided 2 x 2 items: one per lane),
- * no eigenvectors; res = { lambda_min, 0 (exact: no residual bound), n } like the Lanczos result */
+ * no eigenvectors; res = { lambda_min, 0 (exact: no residual bound), n } like the Lanczos result.  The tournament table is
+ * built once; the rotation comes from two reciprocal square roots (no division, no sqrt expansion):
+ * with d = a_qq - a_pp, b = 2 a_pq, r = hypot(d, b):  cos^2 = (1 + |d| / r) / 2,  sin = sgn(d) b / (2 r cos). */
 __global__ void __launch_bounds__(64) k_lmin_tiny(int n, const double* __restrict__ Ain, double* __restrict__ res)
 {
    __shared__ double a[16][17];
    __shared__ double rc[8], rs[8];
+   __shared__ unsigned char tp[15][8], tq[15][8];
    const int tid = threadIdx.x;
    const int np = (n + 1) & ~1;
    const int half = np / 2;
@@ -589,6 +604,14 @@ __global__ void __launch_bounds__(64) k_lmin_tiny(int n, const double* __restric
       if ( r < n && c < n )
          v = 0.5 * (Ain[r * n + c] + Ain[c * n + r]);
       a[r][c] = v;
+   }
+   for (int e = tid; e < (np - 1) * half; e += 64)
+   {
+      const int r = e / half, k = e - r * half;
+      int p, q;
+      jac_pair(np, r, k, &p, &q);
+      tp[r][k] = (unsigned char) p;
+      tq[r][k] = (unsigned char) q;
    }
    __syncthreads();
    const int k1 = tid / half, k2 = tid - k1 * half;
@@ -607,24 +630,27 @@ __global__ void __launch_bounds__(64) k_lmin_tiny(int n, const double* __restric
          off += __shfl_xor(off, o, 64);
          dg += __shfl_xor(dg, o, 64);
       }
-      if ( !(off > 1e-30 * dg) || !(off > 0.0) )
+      /* |lambda - a_ii| <= ||off||_F: 1e-13 of the diagonal norm is far inside what a step length needs */
+      if ( !(off > 1e-26 * dg) || !(off > 0.0) )
          break;
       for (int r = 0; r < np - 1; ++r)
       {
          if ( tid < half )
          {
-            int p, q;
-            jac_pair(np, r, tid, &p, &q);
+            const int p = tp[r][tid], q = tq[r][tid];
             double c = 1.0, sn = 0.0;
             if ( q < n )
             {
-               const double apq = a[p][q], app = a[p][p], aqq = a[q][q];
-               if ( fabs(apq) > 1e-300 && fabs(apq) > 1e-19 * (fabs(app) + fabs(aqq)) )
+               const double apq = a[p][q], d = a[q][q] - a[p][p];
+               const double b2 = 2.0 * apq;
+               const double h2 = fma(d, d, b2 * b2);
+               if ( fabs(apq) > 1e-300 && h2 > 1e-280 && h2 < 1e280 && fabs(apq) > 1e-19 * (fabs(a[p][p]) + fabs(a[q][q])) )
                {
-                  const double th = (aqq - app) / (2.0 * apq);
-                  const double t = (th >= 0.0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
-                  c = 1.0 / sqrt(t * t + 1.0);
-                  sn = t * c;
+                  const double ir = rsqrt_nr(h2);
+                  const double x = 0.5 * fma(fabs(d), ir, 1.0);
+                  const double ic = rsqrt_nr(x);
+                  c = x * ic;
+                  sn = (d >= 0.0 ? 0.5 : -0.5) * b2 * ir * ic;
                }
             }
             rc[tid] = c;
@@ -635,9 +661,7 @@ __global__ void __launch_bounds__(64) k_lmin_tiny(int n, const double* __restric
          {
             /* the 2 x 2 items of a round are disjoint: read-modify-write in place.  Rows / columns >= n are the zero
              * padding of a[][] (np <= 16) and rotate with c = 1, s = 0, so they stay zero */
-            int p, q, u, v;
-            jac_pair(np, r, k1, &p, &q);
-            jac_pair(np, r, k2, &u, &v);
+            const int p = tp[r][k1], q = tq[r][k1], u = tp[r][k2], v = tq[r][k2];
             const double c1 = rc[k1], s1 = rs[k1], c2 = rc[k2], s2 = rs[k2];
             const double apu = a[p][u], apv = a[p][v], aqu = a[q][u], aqv = a[q][v];
             const double bpu = c1 * apu - s1 * aqu, bqu = s1 * apu + c1 * aqu;
