@@ -15,7 +15,8 @@
 
 #define HS_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if ( e_ != hipSuccess ) { hs_record_hip_error(e_, "kernel launch", __FILE__, __LINE__); return HS_ERR_HIP; } } while (0)
 
-__global__ void k_lmin_tiny(int n, const double* __restrict__ Ain, double* __restrict__ res);
+__global__ void k_lmin_tiny(int n, const double* __restrict__ A0, const double* __restrict__ A1, double* __restrict__ res0,
+   double* __restrict__ res1);
 
 /* ---------------------------------------------------------------------------------------------------------------- */
 /* Lanczos                                                                                                            */
@@ -131,21 +132,30 @@ __global__ void __launch_bounds__(1024) k_lanczos_step(int n, int j, double* __r
 
 /* Smallest eigenvalue of the k x k tridiagonal (alpha, beta) by 64-way multisection on the Sturm count, its eigenvector
  * by inverse iteration; res = {theta, |beta_{k-1} s_{k-1}|, k}.  One wavefront. */
-__global__ void __launch_bounds__(64) k_tridiag_min(int kmax, const double* __restrict__ alpha, const double* __restrict__ beta,
-   const double* __restrict__ meta, double* __restrict__ res)
+struct tridiag_smem { double d[260], e[260], sv[260], wk[4][260]; };
+
+/* executed by ONE wavefront (all 64 lanes); other wavefronts of the workgroup must not call it */
+/* (ovr_idx, ovr_alpha, ovr_beta): entry ovr_idx of alpha / beta is taken from the arguments instead of memory (the
+ * caller has just stored it and must not rely on reading it back through the vector cache); meta0 = breakdown step */
+__device__ void tridiag_min_wave(int kmax, const double* __restrict__ alpha, const double* __restrict__ beta,
+   double meta0, int ovr_idx, double ovr_alpha, double ovr_beta, double* __restrict__ res, tridiag_smem& T)
 {
-   __shared__ double d[260], e[260], sv[260], wk[4][260];
-   const int lane = threadIdx.x;
+   double (&d)[260] = T.d;
+   double (&e)[260] = T.e;
+   double (&sv)[260] = T.sv;
+   double (&wk)[4][260] = T.wk;
+   const int lane = threadIdx.x & 63;
    int k = kmax;
-   if ( meta[0] >= 0.0 )
-      k = (int) meta[0] + 1;
+   if ( meta0 >= 0.0 )
+      k = (int) meta0 + 1;
    if ( k > 256 ) k = 256;
    for (int i = lane; i < k; i += 64)
    {
-      d[i] = alpha[i];
-      e[i] = (i + 1 < k) ? beta[i] : 0.0;
+      d[i] = (i == ovr_idx) ? ovr_alpha : alpha[i];
+      e[i] = (i + 1 < k) ? ((i == ovr_idx) ? ovr_beta : beta[i]) : 0.0;
    }
-   __syncthreads();
+   __builtin_amdgcn_s_waitcnt(0);
+   __builtin_amdgcn_wave_barrier();
    /* Gershgorin interval */
    double lo = 1e300, hi = -1e300;
    for (int i = 0; i < k; ++i)
@@ -247,7 +257,7 @@ __global__ void __launch_bounds__(64) k_tridiag_min(int kmax, const double* __re
                sv[i] /= nrm;
          }
       }
-      const double blast = (meta[0] >= 0.0) ? 0.0 : beta[k - 1];
+      const double blast = (meta0 >= 0.0) ? 0.0 : ((k - 1 == ovr_idx) ? ovr_beta : beta[k - 1]);
       resid = fabs(blast * sv[k - 1]);
       res[0] = theta;
       res[1] = resid;
@@ -255,22 +265,163 @@ __global__ void __launch_bounds__(64) k_tridiag_min(int kmax, const double* __re
    }
 }
 
-long long hs_lanczos_ws(int n, int maxsteps)
+__global__ void __launch_bounds__(64) k_tridiag_min(int kmax, const double* __restrict__ alpha, const double* __restrict__ beta,
+   const double* __restrict__ meta, double* __restrict__ res)
 {
-   return (long long) (maxsteps + 2) * n + 4LL * maxsteps + 64 + 2048;
+   __shared__ tridiag_smem T;
+   tridiag_min_wave(kmax, alpha, beta, meta[0], -1, 0.0, 0.0, res, T);
 }
 
-int hs_lanczos_lmin(hipStream_t s, int n, const double* W, int maxsteps, double* res, double* ws)
+/* ---- fused Lanczos: ONE launch per step, two matrices per launch ------------------------------------------------- */
+/* Launch j (0 <= j <= k) of a run of k steps.  Every workgroup first finishes step j - 1 REDUNDANTLY (same data, same
+ * order: identical bits in every workgroup): alpha_{j-1}, twice-applied classical Gram-Schmidt of v = W q_{j-1} against
+ * q_0 .. q_{j-1}, beta_{j-1}, q_j (kept in LDS; workgroup 0 also stores it and the scalars).  Then workgroup g forms its
+ * rows of v = W q_j.  The kernel boundary is the only grid-wide synchronisation; v and the meta scalars alternate
+ * between two buffers so that no workgroup reads what another one writes in the same launch.  Launch k ends with the
+ * tridiagonal eigenproblem on workgroup 0.  blockIdx.y selects the matrix (X-side / Z-side of a block). */
+struct lanczos_job { const double* W; double* Q; double* v0; double* v1; double* alpha; double* beta; double* meta; double* res; };
+struct lanczos_jobs { lanczos_job job[2]; };
+
+__global__ void __launch_bounds__(1024) k_lanczos_fused(int n, int j, int k, lanczos_jobs jobs)
+{
+   extern __shared__ __attribute__((aligned(16))) double lz_smem[];
+   __shared__ double sh[16];
+   __shared__ double coef[256];
+   __shared__ tridiag_smem T;
+   double* vs = lz_smem;            /* n: v, then q_j */
+   const lanczos_job J = jobs.job[blockIdx.y];
+   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   const bool writer = blockIdx.x == 0;
+   const double* min_ = J.meta + 2 * (j & 1);
+   double* mout = J.meta + 2 * ((j + 1) & 1);
+   const double* vin = ((j + 1) & 1) ? J.v1 : J.v0;       /* written by launch j - 1 */
+   double* vout = (j & 1) ? J.v1 : J.v0;
+   bool broke = false;
+   double last_alpha = 0.0, last_beta = 0.0, meta0 = -1.0;
+
+   if ( j == 0 )
+   {
+      double sacc = 0.0;
+      for (int i = tid; i < n; i += 1024)
+      {
+         /* fixed pseudo-random start vector: reproducible, not orthogonal to anything in particular */
+         unsigned long long h = (unsigned long long) (i + 1) * 0x9E3779B97F4A7C15ULL;
+         h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ULL; h ^= h >> 32;
+         const double v = 0.5 + (double) (h >> 11) * (1.0 / 9007199254740992.0);
+         vs[i] = v;
+         sacc += v * v;
+      }
+      sacc = bsum1024(sacc, sh);
+      const double inv = 1.0 / sqrt(sacc);
+      for (int i = tid; i < n; i += 1024)
+      {
+         const double qv = vs[i] * inv;
+         vs[i] = qv;
+         if ( writer )
+            J.Q[i] = qv;
+      }
+      if ( writer && tid == 0 )
+      {
+         mout[0] = -1.0;      /* breakdown step (none) */
+         mout[1] = 0.0;       /* largest |alpha| + beta seen (scale) */
+      }
+   }
+   else
+   {
+      const int jj = j - 1;       /* the step being finished */
+      for (int e = tid; e < n; e += 1024)
+         vs[e] = vin[e];
+      __syncthreads();
+      double aj = 0.0;
+      for (int pass = 0; pass < 2; ++pass)
+      {
+         /* c_i = q_i . v : one wave per i */
+         for (int i = wave; i <= jj; i += 16)
+         {
+            const double* q = J.Q + (long long) i * n;
+            double sacc = 0.0;
+            for (int e = lane; e < n; e += 64)
+               sacc += q[e] * vs[e];
+            sacc = wsum(sacc);
+            if ( lane == 0 )
+               coef[i] = sacc;
+         }
+         __syncthreads();
+         if ( pass == 0 )
+            aj = coef[jj];
+         /* v -= sum_i c_i q_i */
+         for (int e = tid; e < n; e += 1024)
+         {
+            double sacc = vs[e];
+            for (int i = 0; i <= jj; ++i)
+               sacc -= coef[i] * J.Q[(long long) i * n + e];
+            vs[e] = sacc;
+         }
+         __syncthreads();
+      }
+      double sacc = 0.0;
+      for (int e = tid; e < n; e += 1024)
+         sacc += vs[e] * vs[e];
+      sacc = bsum1024(sacc, sh);
+      const double b = sqrt(sacc);
+      double scale = min_[1];
+      if ( fabs(aj) + b > scale )
+         scale = fabs(aj) + b;
+      broke = (min_[0] >= 0.0) || !(b > 1e-13 * scale) || !(b > 1e-300);
+      const double inv = broke ? 0.0 : 1.0 / b;
+      double* qn = J.Q + (long long) j * n;
+      for (int e = tid; e < n; e += 1024)
+      {
+         const double qv = vs[e] * inv;
+         vs[e] = qv;
+         if ( writer )
+            qn[e] = qv;
+      }
+      last_alpha = aj;
+      last_beta = broke ? 0.0 : b;
+      meta0 = (broke && min_[0] < 0.0) ? (double) jj : min_[0];
+      if ( writer && tid == 0 )
+      {
+         J.alpha[jj] = last_alpha;
+         J.beta[jj] = last_beta;
+         mout[1] = scale;
+         mout[0] = meta0;
+      }
+   }
+   __syncthreads();
+   if ( j < k )
+   {
+      /* my rows of v = W q_j (q_j = 0 after a breakdown: harmless) */
+      const int G = gridDim.x;
+      const int rows = (n + G - 1) / G;
+      const int r0 = blockIdx.x * rows;
+      const int r1 = min(n, r0 + rows);
+      for (int r = r0 + wave; r < r1; r += 16)
+      {
+         const double* wr = J.W + (long long) r * n;
+         double sacc = 0.0;
+         for (int e = lane; e < n; e += 64)
+            sacc += wr[e] * vs[e];
+         sacc = wsum(sacc);
+         if ( lane == 0 )
+            vout[r] = sacc;
+      }
+   }
+   else if ( writer && wave == 0 )
+   {
+      tridiag_min_wave(k, J.alpha, J.beta, meta0, j - 1, last_alpha, last_beta, J.res, T);
+   }
+}
+
+long long hs_lanczos_ws(int n, int maxsteps)
+{
+   return (long long) (maxsteps + 3) * n + 4LL * maxsteps + 64 + 2048;
+}
+
+static int hs_lanczos_lmin_unfused(hipStream_t s, int n, const double* W, int maxsteps, double* res, double* ws)
 {
    if ( n <= 0 )
       return HS_ERR_ARG;
-   if ( n <= 16 )
-   {
-      /* tiny blocks are launch bound: one wavefront diagonalises the matrix exactly in ONE launch (vs 2 per Lanczos step) */
-      hipLaunchKernelGGL(k_lmin_tiny, dim3(1), dim3(64), 0, s, n, W, res);
-      HS_LAUNCH_CHECK();
-      return HS_OK;
-   }
    int k = maxsteps < n ? maxsteps : n;
    if ( k > 250 ) k = 250;
    double* Q = ws;                                    /* (k + 1) x n */
@@ -291,6 +442,69 @@ int hs_lanczos_lmin(hipStream_t s, int n, const double* W, int maxsteps, double*
    hipLaunchKernelGGL(k_tridiag_min, dim3(1), dim3(64), 0, s, k, alpha, beta, meta, res);
    HS_LAUNCH_CHECK();
    return HS_OK;
+}
+
+static void lanczos_job_init(lanczos_job* J, int n, int maxsteps, const double* W, double* res, double* ws)
+{
+   J->W = W;
+   J->Q = ws;                                          /* (maxsteps + 1) x n */
+   J->v0 = ws + (long long) (maxsteps + 1) * n;        /* n */
+   J->v1 = J->v0 + n;                                  /* n */
+   J->alpha = J->v1 + n;
+   J->beta = J->alpha + maxsteps;
+   J->meta = J->beta + maxsteps;                       /* 2 x 2 (+ padding) */
+   J->res = res;
+}
+
+/* smallest eigenvalue of one or two symmetric n x n matrices (W1 may be NULL); res = {theta, residual bound, steps} */
+int hs_lanczos_lmin2(hipStream_t s, int n, const double* W0, const double* W1, int maxsteps, double* res0, double* res1,
+   double* ws0, double* ws1)
+{
+   if ( n <= 0 )
+      return HS_ERR_ARG;
+   const int nb = (W1 != NULL) ? 2 : 1;
+   if ( n <= 16 )
+   {
+      /* tiny blocks are launch bound: one wavefront per matrix diagonalises it exactly in ONE launch */
+      hipLaunchKernelGGL(k_lmin_tiny, dim3(nb), dim3(64), 0, s, n, W0, W1, res0, res1);
+      HS_LAUNCH_CHECK();
+      return HS_OK;
+   }
+   int k = maxsteps < n ? maxsteps : n;
+   if ( k > 250 ) k = 250;
+   if ( n > 8192 )
+   {
+      /* the fused kernel keeps one vector in LDS */
+      HS_CALL( hs_lanczos_lmin_unfused(s, n, W0, maxsteps, res0, ws0) );
+      if ( W1 != NULL )
+         HS_CALL( hs_lanczos_lmin_unfused(s, n, W1, maxsteps, res1, ws1) );
+      return HS_OK;
+   }
+   static bool attr_set = false;
+   if ( !attr_set )
+   {
+      HS_HIP( hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lanczos_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8) );
+      attr_set = true;
+   }
+   lanczos_jobs jobs;
+   lanczos_job_init(&jobs.job[0], n, maxsteps, W0, res0, ws0);
+   if ( W1 != NULL )
+      lanczos_job_init(&jobs.job[1], n, maxsteps, W1, res1, ws1);
+   else
+      jobs.job[1] = jobs.job[0];
+   int G = (n + 15) / 16;          /* >= 16 rows per workgroup: one per wavefront */
+   if ( G > 128 ) G = 128;
+   for (int j = 0; j <= k; ++j)
+   {
+      hipLaunchKernelGGL(k_lanczos_fused, dim3(G, nb), dim3(1024), (size_t) n * sizeof(double), s, n, j, k, jobs);
+      HS_LAUNCH_CHECK();
+   }
+   return HS_OK;
+}
+
+int hs_lanczos_lmin(hipStream_t s, int n, const double* W, int maxsteps, double* res, double* ws)
+{
+   return hs_lanczos_lmin2(s, n, W, NULL, maxsteps, res, NULL, ws, NULL);
 }
 
 /* ---------------------------------------------------------------------------------------------------------------- */
@@ -589,8 +803,11 @@ __device__ __forceinline__ double rsqrt_nr(double x)
  * no eigenvectors; res = { lambda_min, 0 (exact: no residual bound), n } like the Lanczos result.  The tournament table is
  * built once; the rotation comes from two reciprocal square roots (no division, no sqrt expansion):
  * with d = a_qq - a_pp, b = 2 a_pq, r = hypot(d, b):  cos^2 = (1 + |d| / r) / 2,  sin = sgn(d) b / (2 r cos). */
-__global__ void __launch_bounds__(64) k_lmin_tiny(int n, const double* __restrict__ Ain, double* __restrict__ res)
+__global__ void __launch_bounds__(64) k_lmin_tiny(int n, const double* __restrict__ A0, const double* __restrict__ A1,
+   double* __restrict__ res0, double* __restrict__ res1)
 {
+   const double* __restrict__ Ain = blockIdx.x ? A1 : A0;
+   double* __restrict__ res = blockIdx.x ? res1 : res0;
    __shared__ double a[16][17];
    __shared__ double rc[8], rs[8];
    __shared__ unsigned char tp[15][8], tq[15][8];

@@ -91,6 +91,8 @@ int hs_trsv(hipStream_t s, int n, const double* L, const double* dinv, int nrhs,
  * ws: (maxsteps + 2) * n + 4 * maxsteps + 64 doubles. */
 int hs_lanczos_lmin(hipStream_t s, int n, const double* W, int maxsteps, double* res, double* ws);
 long long hs_lanczos_ws(int n, int maxsteps);
+int hs_lanczos_lmin2(hipStream_t s, int n, const double* W0, const double* W1, int maxsteps, double* res0, double* res1,
+   double* ws0, double* ws1);
 
 /* Cyclic Jacobi eigen-decomposition of the symmetric n x n matrix A (destroyed): eigenvalues ascending in lam[n],
  * eigenvectors as rows of V (row k = k-th eigenvector).  info (device int) = sweeps used or -1. */

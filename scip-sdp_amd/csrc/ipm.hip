@@ -897,13 +897,17 @@ static int steplen_enqueue(hipsdp_solver* s)
       const int n = B.n;
       HS_CALL( gemm_on(st, s->gws1, s->gws_len, HS_KC, HS_MC, n, n, n, 1.0, B.LxInv, n, B.dX, n, 0.0, B.T1, n) );
       HS_CALL( gemm_on(st, s->gws1, s->gws_len, HS_KC, HS_KC, n, n, n, 1.0, B.T1, n, B.LxInv, n, 0.0, B.W, n) );
-      HS_CALL( hs_lanczos_lmin(st, n, B.W, s->par.lanczos_steps, s->sc + SC_BLK(k, 1), s->lan_ws) );
       HS_CALL( gemm_on(st2, s->gws2, s->gws_len, HS_KC, HS_MC, n, n, n, 1.0, B.LzInv, n, B.dZ, n, 0.0, B.T2, n) );
       HS_CALL( gemm_on(st2, s->gws2, s->gws_len, HS_KC, HS_KC, n, n, n, 1.0, B.T2, n, B.LzInv, n, 0.0, B.W2, n) );
-      HS_CALL( hs_lanczos_lmin(st2, n, B.W2, s->par.lanczos_steps, s->sc + SC_BLK(k, 4), s->lan_ws2) );
-      ++k;
    }
    HS_CALL( join2(s) );
+   /* the X-side and the Z-side eigenvalue of a block run in the same launches (one launch per Lanczos step) */
+   for (auto& B : s->blk)
+   {
+      HS_CALL( hs_lanczos_lmin2(st, B.n, B.W, B.W2, s->par.lanczos_steps, s->sc + SC_BLK(k, 1), s->sc + SC_BLK(k, 4), s->lan_ws,
+            s->lan_ws2) );
+      ++k;
+   }
    HS_CALL( hs_ratio_min(s->stream, s->q, s->x, s->dx, s->sc + SC_RATX, 0, s->red_ws) );
    HS_CALL( hs_ratio_min(s->stream, s->q, s->z, s->dz, s->sc + SC_RATZ, 0, s->red_ws) );
    return HS_OK;
