@@ -145,6 +145,10 @@ int  hipsdp_get_block_dense(hipsdp_solver* solver, int block, double* A);
 /* C[M x N] = alpha * op(A) * op(B) + beta * C, row-major; layA/layB: 0 = K contiguous, 1 = M (resp. N) contiguous */
 int  hipsdp_dgemm(int device, int layA, int layB, int M, int N, int K, double alpha, const double* A, long long lda,
    const double* B, long long ldb, double beta, double* C, long long ldc, int lower_only, int splitk);
+/* both GEMM kernels (one tile per workgroup; persistent with LDS-DMA staging) on the same device-generated operands:
+ * used_v2 = 1 when the persistent kernel accepts the shape, ndiff = elements of C that differ in any bit (must be 0) */
+int  hipsdp_dgemm_selfcheck(int device, int M, int N, int K, int layB, int batch, int splitk, int flags, double beta,
+   int* used_v2, long long* ndiff);
 /* Schur block Mx[(m1) x (m1)] = tr(A_i X A_j Zinv) for i, j = 0..m1-1 */
 int  hipsdp_schur_dense(int device, int m1, int n, const double* A, const double* X, const double* Zinv, double* Mx,
    double ws_gbytes);

@@ -209,6 +209,15 @@ def schur_w(A, X, Z, device=0):
     return Mx
 
 
+def dgemm_selfcheck(M, N, K, layB=1, batch=1, splitk=1, flags=0, beta=0.0, device=0):
+    """both GEMM kernels on the same device-generated operands -> (used_v2, number of elements of C differing in any bit)"""
+    used = C.c_int(0)
+    nd = C.c_longlong(0)
+    _chk(lib().hipsdp_dgemm_selfcheck(device, M, N, K, layB, batch, splitk, flags, C.c_double(beta), C.byref(used), C.byref(nd)),
+         "hipsdp_dgemm_selfcheck")
+    return used.value, nd.value
+
+
 def potrf(A, device=0):
     L = _f64(A).copy()
     fail = C.c_int(0)

@@ -471,7 +471,14 @@ int hs_dgemm(hipStream_t stream, const hs_gemm_args* a)
    }
 
    if ( useBig )
-      HS_CALL( launch_lay<128>(stream, a, kchunk) );
+   {
+      /* the persistent LDS-DMA kernel (dgemm2.hip) takes the shapes it is eligible for: identical results */
+      const int r2 = hs_dgemm2_try(stream, a, kchunk);
+      if ( r2 < 0 )
+         return -r2;
+      if ( r2 == 0 )
+         HS_CALL( launch_lay<128>(stream, a, kchunk) );
+   }
    else
       HS_CALL( launch_lay<64>(stream, a, kchunk) );
 

@@ -1,0 +1,410 @@
+/* dgemm2.hip - persistent FP64 MFMA GEMM with LDS-DMA staging: the Schur-assembly shapes of schur.hip.
+ *
+ * Same product, same flags and the same summation order per output element as dgemm.hip (K ascending in steps of 4 inside
+ * one accumulator chain, split-K slabs summed in slice order), so both kernels give identical bits.  What differs is how
+ * the work reaches the matrix cores:
+ *
+ *  - PERSISTENT workgroups (2 per CU) walk a static list of work items (output tile x batch entry / K slice).  The items of
+ *    one XCD (blockIdx % 8) are a contiguous range of the logical order and its workgroups take them interleaved, so
+ *    neighbours in time share operand panels through that XCD's L2.  Triangular operands make the K range depend on the
+ *    tile; the enumeration rotates the varying coordinate so that every workgroup sees all K lengths in turn.
+ *  - operands go global -> LDS directly (global_load_lds_dwordx4, no staging registers, no ds_write pass) into a ring of
+ *    NS slots of BKS = 8 K-steps; NS - 1 stages are in flight while one is multiplied, across item boundaries: the first
+ *    stages of the next tile are on their way while the current tile is finished and stored, which is where the short-K
+ *    products (K = 116 .. 500 per tile) lose time in the one-tile-per-workgroup kernel.
+ *  - an LDS-DMA wave instruction writes 1 KiB contiguously (lane l -> base + 16 l); the per-lane SOURCE address is free.
+ *    K-contiguous operand: a piece is 16 rows x 4 chunks (16 B) stored [chunk][row], so the 32 lanes of a ds_read_b64 half
+ *    cover 256 contiguous bytes (conflict free).  Row-contiguous operand: a piece is one K row of 128 columns, chunk j of
+ *    an odd row is stored at j ^ 8, which separates the two K rows a half-wave reads.
+ *  - edge rows / columns are clamped to the last valid one (their products are not stored); K tails read from a 16-byte
+ *    zero constant.  Requirements (else hs_dgemm uses dgemm.hip): A K-contiguous, even leading dimensions, strides, K and
+ *    (row-contiguous B) N, 16-byte aligned operands.
+ *  - completion of the DMA is tracked with counted s_waitcnt vmcnt (in-order return), raw s_barrier; the epilogue drains
+ *    the counter once (vmcnt(0)) before its stores so that stores never sit between a DMA and the wait that retires it.
+ */
+#include "hs_common.h"
+#include <stdlib.h>
+
+typedef double v4d2 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* hs_lds_ptr;
+typedef const __attribute__((address_space(1))) void* hs_gbl_ptr;
+
+#define G2_BT   128
+#define G2_BKS  8
+#define G2_NS   4
+#define G2_OPSZ (G2_BT * G2_BKS)            /* doubles per operand per stage */
+#define G2_SLOT (2 * G2_OPSZ)
+#define G2_GPS  4                           /* LDS-DMA instructions per wave per stage: 2 per operand */
+
+__device__ __attribute__((aligned(16))) double hs_g2_zero[2] = {0.0, 0.0};
+
+struct g2_item
+{
+   int m0, n0, bz, ks0, kend;
+};
+
+/* position in the logical order -> item.  Order: batch entry / K slice major, then row tile, then column tile (lower:
+ * packed lower-triangular tile index).  rot rotates the coordinate on which the K range depends. */
+__device__ __forceinline__ void g2_decode(const hs_gemm_args& p, long long pos, long long ntile, int tm, int tn, int kchunk,
+   int rotdiv, g2_item* it)
+{
+   int bz = (int) (pos / ntile);
+   const long long t = pos - (long long) bz * ntile;
+   int ti, tj;
+   if ( p.flags & HS_GEMM_LOWER )
+   {
+      ti = (int) ((sqrt(8.0 * (double) t + 1.0) - 1.0) * 0.5);
+      while ( (long long) (ti + 1) * (ti + 2) / 2 <= t ) ++ti;
+      while ( (long long) ti * (ti + 1) / 2 > t ) --ti;
+      tj = (int) (t - (long long) ti * (ti + 1) / 2);
+   }
+   else
+   {
+      ti = (int) (t / tn);
+      tj = (int) (t - (long long) ti * tn);
+      if ( rotdiv > 0 )
+      {
+         if ( p.flags & HS_GEMM_B_LOWTRI )
+            tj = (int) ((tj + (pos / tn) / rotdiv) % tn);
+         else if ( p.flags & HS_GEMM_A_LOWTRI )
+            ti = (int) ((ti + bz / rotdiv) % tm);
+      }
+   }
+   it->m0 = ti * G2_BT;
+   it->n0 = tj * G2_BT;
+   it->bz = bz;
+   int ks0 = 0, kend = p.K;
+   if ( p.splitk > 1 )
+   {
+      ks0 = bz * kchunk;
+      kend = min(p.K, ks0 + kchunk);
+   }
+   if ( p.flags & HS_GEMM_B_LOWTRI )
+      ks0 = max(ks0, (it->n0 / 16) * 16);
+   if ( p.flags & HS_GEMM_A_LOWTRI )
+      kend = min(kend, it->m0 + G2_BT);
+   it->ks0 = ks0;
+   it->kend = kend > ks0 ? kend : ks0;
+}
+
+template<int N> __device__ __forceinline__ void g2_wait_vm()
+{
+   asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
+
+/* fragment: element (row woff + 16 t + (l & 15), k = 4 ks + (l >> 4)) of a stage image */
+template<int LAY>
+__device__ __forceinline__ double g2_frag(const double* __restrict__ slot, int woff, int t, int ks, int lane)
+{
+   const int k = 4 * ks + (lane >> 4);
+   if ( LAY == HS_KC )
+   {
+      const int row = woff + 16 * t + (lane & 15);
+      return slot[(row >> 4) * 128 + (k >> 1) * 32 + (row & 15) * 2 + (k & 1)];
+   }
+   else
+   {
+      const int col = woff + 16 * t + (lane & 15);
+      return slot[k * 128 + (((col >> 1) ^ ((k & 1) << 3)) << 1) + (col & 1)];
+   }
+}
+
+template<int LB>
+__global__ void __launch_bounds__(256, 2) hs_dgemm2_kernel(hs_gemm_args p, int kchunk, long long ntile, long long total, int rotdiv)
+{
+   extern __shared__ __attribute__((aligned(1024))) double g2_smem[];
+   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+   const int tm = (p.M + G2_BT - 1) / G2_BT, tn = (p.N + G2_BT - 1) / G2_BT;
+
+   /* my items: XCD x owns [x * T8, (x + 1) * T8), its Wx workgroups take them interleaved */
+   const int Wx = gridDim.x >> 3;
+   const long long T8 = (total + 7) / 8;
+   const long long base = (long long) (blockIdx.x & 7) * T8;
+   long long lim = base + T8;
+   if ( lim > total ) lim = total;
+   const long long first = base + (blockIdx.x >> 3);
+
+   /* ---- producer state: next stage to issue */
+   long long ppos = first;
+   bool pdone = ppos >= lim;
+   const double* pa[2];
+   const double* pb[2];
+   int pk = 0, pkend = 0;              /* K position of the next stage of the producer's item, its K end */
+   /* per-lane constants of the two pieces a wave loads per operand and stage */
+   const int ar = lane & 15, ac = lane >> 4;                                   /* K-contiguous operand: row in piece, chunk */
+   auto producer_load_item = [&]()
+   {
+      g2_item it;
+      g2_decode(p, ppos, ntile, tm, tn, kchunk, rotdiv, &it);
+      const double* A = p.A + (long long) (p.splitk > 1 ? 0 : it.bz) * p.strideA;
+      const double* B = p.B + (long long) (p.splitk > 1 ? 0 : it.bz) * p.strideB;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+      {
+         const int piece = wave * 2 + i;
+         int row = it.m0 + piece * 16 + ar;
+         if ( row > p.M - 1 ) row = p.M - 1;
+         pa[i] = A + (long long) row * p.lda + it.ks0 + 2 * ac;
+         if ( LB == HS_KC )
+         {
+            int rowb = it.n0 + piece * 16 + ar;
+            if ( rowb > p.N - 1 ) rowb = p.N - 1;
+            pb[i] = B + (long long) rowb * p.ldb + it.ks0 + 2 * ac;
+         }
+         else
+         {
+            const int kk = wave * 2 + i;
+            int col = it.n0 + 2 * (lane ^ ((kk & 1) << 3));
+            if ( col > p.N - 2 ) col = p.N - 2;
+            pb[i] = B + (long long) (it.ks0 + kk) * p.ldb + col;
+         }
+      }
+      pk = it.ks0;
+      pkend = it.kend;
+   };
+   /* skip empty items (cannot happen for the shapes dispatched here, but an empty K range must not stall the ring) */
+   auto producer_settle = [&]()
+   {
+      while ( !pdone )
+      {
+         producer_load_item();
+         if ( pk < pkend )
+            break;
+         ppos += Wx;
+         pdone = ppos >= lim;
+      }
+   };
+   int gp = 0;                          /* stages issued */
+   auto issue_stage = [&]()
+   {
+      double* slot = g2_smem + (gp % G2_NS) * G2_SLOT;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+      {
+         const int piece = wave * 2 + i;
+         const double* src = (pk + 2 * ac < pkend) ? pa[i] : hs_g2_zero;
+         __builtin_amdgcn_global_load_lds((hs_gbl_ptr) src, (hs_lds_ptr) (slot + piece * 128), 16, 0, 0);
+         pa[i] += G2_BKS;
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+      {
+         const int piece = wave * 2 + i;
+         const double* src;
+         if ( LB == HS_KC )
+         {
+            src = (pk + 2 * ac < pkend) ? pb[i] : hs_g2_zero;
+            pb[i] += G2_BKS;
+         }
+         else
+         {
+            src = (pk + piece < pkend) ? pb[i] : hs_g2_zero;
+            pb[i] += (long long) G2_BKS * p.ldb;
+         }
+         __builtin_amdgcn_global_load_lds((hs_gbl_ptr) src, (hs_lds_ptr) (slot + G2_OPSZ + piece * 128), 16, 0, 0);
+      }
+      pk += G2_BKS;
+      ++gp;
+      if ( pk >= pkend )
+      {
+         ppos += Wx;
+         pdone = ppos >= lim;
+         producer_settle();
+      }
+   };
+
+   /* ---- consumer state */
+   long long cpos = first;
+   bool cdone = cpos >= lim;
+   g2_item cit;
+   int cleft = 0;                       /* stages left in the consumer's item */
+   auto consumer_settle = [&]()
+   {
+      while ( !cdone )
+      {
+         g2_decode(p, cpos, ntile, tm, tn, kchunk, rotdiv, &cit);
+         cleft = (cit.kend - cit.ks0 + G2_BKS - 1) / G2_BKS;
+         if ( cleft > 0 )
+            break;
+         cpos += Wx;
+         cdone = cpos >= lim;
+      }
+   };
+
+   v4d2 acc[4][4];
+#pragma unroll
+   for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+         acc[i][j] = (v4d2){0.0, 0.0, 0.0, 0.0};
+
+   producer_settle();
+   consumer_settle();
+#pragma unroll
+   for (int s = 0; s < G2_NS - 1; ++s)
+      if ( !pdone )
+         issue_stage();
+
+   int gc = 0;                          /* stage being consumed */
+   int landed = 0;                      /* stages [.., landed) are known complete (drained by an epilogue) */
+   while ( !cdone )
+   {
+      /* stage gc must have landed; newer stages may stay in flight (in-order return) */
+      if ( gc >= landed )
+      {
+         const int newer = gp - 1 - gc;
+         if ( newer >= 2 ) g2_wait_vm<2 * G2_GPS>();
+         else if ( newer == 1 ) g2_wait_vm<G2_GPS>();
+         else g2_wait_vm<0>();
+      }
+      __builtin_amdgcn_s_barrier();
+      if ( !pdone )
+         issue_stage();
+      const double* sa = g2_smem + (gc % G2_NS) * G2_SLOT;
+      const double* sb = sa + G2_OPSZ;
+#pragma unroll
+      for (int ks = 0; ks < G2_BKS / 4; ++ks)
+      {
+         double fa[4], fb[4];
+#pragma unroll
+         for (int i = 0; i < 4; ++i)
+         {
+            fa[i] = g2_frag<HS_KC>(sa, wm * 64, i, ks, lane);
+            fb[i] = g2_frag<LB>(sb, wn * 64, i, ks, lane);
+         }
+#pragma unroll
+         for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+               acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      ++gc;
+      if ( --cleft == 0 )
+      {
+         /* epilogue: drain the DMA counter first, so that no store sits between a DMA and the wait that retires it */
+         g2_wait_vm<0>();
+         landed = gp;
+         double* C = p.C;
+         long long ldc = p.ldc;
+         double alpha = p.alpha, beta = p.beta;
+         if ( p.splitk > 1 )
+         {
+            C = p.ws + (long long) cit.bz * p.M * p.N;
+            ldc = p.N;
+            alpha = 1.0;
+            beta = 0.0;
+         }
+         else
+            C += (long long) cit.bz * p.strideC;
+#pragma unroll
+         for (int i = 0; i < 4; ++i)
+         {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+            {
+               const int row = cit.m0 + wm * 64 + 16 * i + (lane >> 4) + 4 * r;
+#pragma unroll
+               for (int j = 0; j < 4; ++j)
+               {
+                  const int col = cit.n0 + wn * 64 + 16 * j + (lane & 15);
+                  if ( row < p.M && col < p.N )
+                  {
+                     double* c = C + (long long) row * ldc + col;
+                     double v = alpha * acc[i][j][r];
+                     if ( beta != 0.0 )
+                        v += beta * (*c);
+                     *c = v;
+                  }
+               }
+            }
+         }
+#pragma unroll
+         for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+               acc[i][j] = (v4d2){0.0, 0.0, 0.0, 0.0};
+         cpos += Wx;
+         cdone = cpos >= lim;
+         consumer_settle();
+      }
+   }
+}
+
+/* 1: launched, 0: not eligible (caller uses dgemm.hip), < 0: error code negated */
+static int g2_disabled = -1;
+static int g2_taken = 0;
+
+/* test hook: on = 0 forces dgemm.hip for every product, on = 1 restores the default; returns how many products the
+ * persistent kernel has taken so far */
+int hs_dgemm2_enable(int on)
+{
+   g2_disabled = on ? 0 : 1;
+   return g2_taken;
+}
+
+int hs_dgemm2_try(hipStream_t stream, const hs_gemm_args* a, int kchunk)
+{
+   if ( g2_disabled < 0 )
+   {
+      const char* env = getenv("HIPSDP_GEMM_V1");
+      g2_disabled = (env != NULL && env[0] == '1') ? 1 : 0;
+   }
+   if ( g2_disabled )
+      return 0;
+   if ( a->layA != HS_KC || (a->flags & (HS_GEMM_UPPER)) )
+      return 0;
+   if ( (a->lda & 1) || (a->ldb & 1) || (a->strideA & 1) || (a->strideB & 1) || (a->K & 1) || a->K < 16 )
+      return 0;
+   if ( (((uintptr_t) a->A) & 15) || (((uintptr_t) a->B) & 15) )
+      return 0;
+   if ( a->layB == HS_MC && ((a->N & 1) || a->N < 2) )
+      return 0;
+   if ( (a->flags & HS_GEMM_LOWER) && a->M != a->N )
+      return 0;
+   if ( a->splitk > 1 && (kchunk & 15) )
+      return 0;
+   const long long tm = (a->M + G2_BT - 1) / G2_BT, tn = (a->N + G2_BT - 1) / G2_BT;
+   const long long ntile = (a->flags & HS_GEMM_LOWER) ? tm * (tm + 1) / 2 : tm * tn;
+   const long long nz = a->splitk > 1 ? a->splitk : a->batch;
+   const long long total = ntile * nz;
+   if ( total < 384 )
+      return 0;
+   int grid = 512;                     /* 2 workgroups per CU, 64 per XCD */
+   const int Wx = grid / 8;
+   /* rotation of the coordinate the K range depends on (see g2_decode): only when the interleave would pin it */
+   int rotdiv = 0;
+   if ( !(a->flags & HS_GEMM_LOWER) )
+   {
+      if ( (a->flags & HS_GEMM_B_LOWTRI) && tn > 1 && (Wx % tn) == 0 )
+         rotdiv = (int) (Wx / tn);
+      else if ( (a->flags & HS_GEMM_A_LOWTRI) && tm > 1 && (Wx % (tm * tn)) == 0 )
+         rotdiv = (int) (Wx / (tm * tn));
+   }
+   const size_t smem = (size_t) G2_NS * G2_SLOT * sizeof(double);
+   static bool attr_set[2] = {false, false};
+   if ( a->layB == HS_KC )
+   {
+      if ( !attr_set[0] )
+      {
+         if ( hipFuncSetAttribute(reinterpret_cast<const void*>(&hs_dgemm2_kernel<HS_KC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem) != hipSuccess )
+            return -HS_ERR_HIP;
+         attr_set[0] = true;
+      }
+      hipLaunchKernelGGL((hs_dgemm2_kernel<HS_KC>), dim3(grid), dim3(256), smem, stream, *a, kchunk, ntile, total, rotdiv);
+   }
+   else
+   {
+      if ( !attr_set[1] )
+      {
+         if ( hipFuncSetAttribute(reinterpret_cast<const void*>(&hs_dgemm2_kernel<HS_MC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem) != hipSuccess )
+            return -HS_ERR_HIP;
+         attr_set[1] = true;
+      }
+      hipLaunchKernelGGL((hs_dgemm2_kernel<HS_MC>), dim3(grid), dim3(256), smem, stream, *a, kchunk, ntile, total, rotdiv);
+   }
+   if ( hipGetLastError() != hipSuccess )
+      return -HS_ERR_HIP;
+   ++g2_taken;
+   return 1;
+}

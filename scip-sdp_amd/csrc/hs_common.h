@@ -78,6 +78,9 @@ struct hs_gemm_args
 
 /* C = alpha * A * B + beta * C on the given stream; FP64 MFMA tiles (dgemm.hip) */
 int hs_dgemm(hipStream_t stream, const hs_gemm_args* args);
+/* persistent LDS-DMA variant for the 128-tile shapes (dgemm2.hip): 1 launched, 0 not eligible, < 0 error (negated code) */
+int hs_dgemm2_try(hipStream_t stream, const hs_gemm_args* args, int kchunk);
+int hs_dgemm2_enable(int on);
 
 /* choose a split-K factor for a [M x N x K] product so that at least ~2 waves of workgroups exist */
 int hs_dgemm_pick_splitk(int M, int N, int K, int lowerOnly);

@@ -55,6 +55,75 @@ extern "C" int hipsdp_dgemm(int device, int layA, int layB, int M, int N, int K,
    return HIPSDP_OK;
 }
 
+/* fills with reproducible values in [-0.5, 0.5) */
+__global__ void k_unit_fill(long long n, unsigned long long seed, double* __restrict__ x)
+{
+   for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x)
+   {
+      unsigned long long h = (unsigned long long) (i + 1) * 0x9E3779B97F4A7C15ULL + seed;
+      h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ULL; h ^= h >> 32; h *= 0x94D049BB133111EBULL; h ^= h >> 29;
+      x[i] = (double) (h >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+   }
+}
+
+__global__ void k_unit_maxdiff(long long n, const double* __restrict__ a, const double* __restrict__ b, unsigned long long* __restrict__ ndiff)
+{
+   unsigned long long cnt = 0;
+   for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x)
+      if ( __double_as_longlong(a[i]) != __double_as_longlong(b[i]) )
+         ++cnt;
+   if ( cnt )
+      atomicAdd(ndiff, cnt);
+}
+
+/* The same product through both GEMM kernels (dgemm.hip, dgemm2.hip) on device-generated operands: the results must agree
+ * bit for bit.  A is K-contiguous; layB, batch, splitk and flags as in hs_gemm_args (C packed, ldc = N).  used_v2 = 1 when
+ * the persistent kernel accepted the shape; ndiff = number of differing elements of C (over all batch entries). */
+extern "C" int hipsdp_dgemm_selfcheck(int device, int M, int N, int K, int layB, int batch, int splitk, int flags, double beta,
+   int* used_v2, long long* ndiff)
+{
+   HS_CALL( pick_device(device) );
+   if ( M <= 0 || N <= 0 || K <= 0 || batch < 1 )
+      return HIPSDP_ERR_ARG;
+   const long long na = (long long) M * K, nb = (long long) N * K, nc = (long long) M * N;
+   const long long sB = (batch > 1) ? nb : 0;
+   DevBuf dA, dB, dC1, dC2, dW;
+   unsigned long long* dn = NULL;
+   HS_CALL( dA.alloc(na) ); HS_CALL( dB.alloc(batch > 1 ? nb * batch : nb) ); HS_CALL( dC1.alloc(nc * batch) ); HS_CALL( dC2.alloc(nc * batch) );
+   if ( splitk > 1 )
+      HS_CALL( dW.alloc((long long) splitk * nc) );
+   HS_HIP( hipMalloc((void**) &dn, sizeof(unsigned long long)) );
+   HS_HIP( hipMemset(dn, 0, sizeof(unsigned long long)) );
+   hipLaunchKernelGGL(k_unit_fill, dim3(1024), dim3(256), 0, 0, na, 11ULL, dA.p);
+   hipLaunchKernelGGL(k_unit_fill, dim3(1024), dim3(256), 0, 0, batch > 1 ? nb * batch : nb, 23ULL, dB.p);
+   hipLaunchKernelGGL(k_unit_fill, dim3(1024), dim3(256), 0, 0, nc * batch, 37ULL, dC1.p);
+   HS_HIP( hipMemcpy(dC2.p, dC1.p, (size_t) (nc * batch) * sizeof(double), hipMemcpyDeviceToDevice) );
+   hs_gemm_args g = {M, N, K, HS_KC, layB, dA.p, K, 0, dB.p, layB == HS_KC ? (long long) K : (long long) N, sB, dC1.p, N, nc, 1.25, beta,
+      batch, flags, splitk, dW.p};
+   int rc = HS_OK;
+   hs_dgemm2_enable(0);
+   rc = hs_dgemm(0, &g);
+   const int before = hs_dgemm2_enable(1);
+   g.C = dC2.p;
+   if ( rc == HS_OK )
+      rc = hs_dgemm(0, &g);
+   const int after = hs_dgemm2_enable(1);
+   if ( rc == HS_OK && hipDeviceSynchronize() != hipSuccess )
+      rc = HS_ERR_HIP;
+   unsigned long long hn = 0;
+   if ( rc == HS_OK )
+   {
+      hipLaunchKernelGGL(k_unit_maxdiff, dim3(1024), dim3(256), 0, 0, nc * batch, dC1.p, dC2.p, dn);
+      if ( hipMemcpy(&hn, dn, sizeof(hn), hipMemcpyDeviceToHost) != hipSuccess )
+         rc = HS_ERR_HIP;
+   }
+   (void) hipFree(dn);
+   HS_CALL( rc );
+   *used_v2 = after - before;
+   *ndiff = (long long) hn;
+   return HIPSDP_OK;
+}
+
 extern "C" int hipsdp_schur_dense(int device, int m1, int n, const double* A, const double* X, const double* Zinv, double* Mx,
    double ws_gbytes)
 {

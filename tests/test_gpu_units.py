@@ -185,3 +185,25 @@ def test_sciplapack_eigen_and_gemv(gpu):
     a_cm = A.reshape(-1, order="F").copy()
     assert lib.SCIPlapackLinearSolve(None, 6, 4, _pd(a_cm), _pd(b.copy()), _pd(xs)) == 1
     assert np.allclose(xs, np.linalg.lstsq(A, b, rcond=None)[0], atol=1e-8)
+
+
+# flags of hs_gemm_args (csrc/hs_common.h)
+GEMM_LOWER, GEMM_A_LOWTRI, GEMM_B_LOWTRI, GEMM_XCD, GEMM_REMAP, GEMM_NOFAST = 1, 2, 4, 8, 16, 64
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,layB,batch,splitk,flags,beta,expect_v2", [
+    (50000, 500, 500, 1, 1, 1, GEMM_B_LOWTRI, 0.0, 1),                  # stack product of the Schur assembly (A_j R), K tail of 4
+    (50000, 500, 500, 1, 1, 1, 0, 0.0, 1),                              # the same without the triangular clipping
+    (500, 500, 500, 1, 40, 1, GEMM_A_LOWTRI | GEMM_REMAP, 0.0, 1),      # batched product G T_j
+    (1001, 1001, 30000, 0, 1, 14, GEMM_LOWER | GEMM_XCD | GEMM_NOFAST, 1.0, 1),   # Gram product W W^T in K slices, ragged last tile
+    (3000, 2500, 500, 1, 1, 1, 0, 0.5, 1),                              # beta != 0
+    (2900, 2600, 330, 0, 1, 1, 0, 0.0, 1),                              # both K contiguous, ragged tiles, K tail of 2
+    (3001, 2001, 402, 0, 1, 1, 0, 0.0, 1),                              # odd M and N
+    (3000, 2502, 128, 1, 1, 1, 0, 0.0, 1),                              # row-contiguous B, ragged last column tile
+    (3000, 2500, 501, 1, 1, 1, 0, 0.0, 0),                              # odd K: not eligible, both runs take the tile kernel
+])
+def test_persistent_gemm_matches_tile_gemm_bitwise(gpu, M, N, K, layB, batch, splitk, flags, beta, expect_v2):
+    used, ndiff = gpu.dgemm_selfcheck(M, N, K, layB=layB, batch=batch, splitk=splitk, flags=flags, beta=beta)
+    assert used == expect_v2
+    assert ndiff == 0
