@@ -113,7 +113,9 @@ template<int LB>
 __global__ void __launch_bounds__(256, 2) hs_dgemm2_kernel(hs_gemm_args p, int kchunk, long long ntile, long long total, int rotdiv)
 {
    extern __shared__ __attribute__((aligned(1024))) double g2_smem[];
-   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+   const int tid = threadIdx.x, lane = tid & 63;
+   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       /* wave-uniform: scalar branches below */
+   const int wm = wave >> 1, wn = wave & 1;
    const int tm = (p.M + G2_BT - 1) / G2_BT, tn = (p.N + G2_BT - 1) / G2_BT;
 
    /* my items: XCD x owns [x * T8, (x + 1) * T8), its Wx workgroups take them interleaved */
@@ -218,12 +220,14 @@ __global__ void __launch_bounds__(256, 2) hs_dgemm2_kernel(hs_gemm_args p, int k
    bool cdone = cpos >= lim;
    g2_item cit;
    int cleft = 0;                       /* stages left in the consumer's item */
+   int ck = 0;                          /* K position of the stage being consumed */
    auto consumer_settle = [&]()
    {
       while ( !cdone )
       {
          g2_decode(p, cpos, ntile, tm, tn, kchunk, rotdiv, &cit);
          cleft = (cit.kend - cit.ks0 + G2_BKS - 1) / G2_BKS;
+         ck = cit.ks0;
          if ( cleft > 0 )
             break;
          cpos += Wx;
@@ -262,9 +266,28 @@ __global__ void __launch_bounds__(256, 2) hs_dgemm2_kernel(hs_gemm_args p, int k
          issue_stage();
       const double* sa = g2_smem + (gc % G2_NS) * G2_SLOT;
       const double* sb = sa + G2_OPSZ;
+      /* triangular operands: inside the diagonal band of the tile whole 16 x 4 operand slabs are zero; their MFMAs are
+       * skipped (adding a zero product changes nothing, so the result is the same) */
+      const bool triB = (p.flags & HS_GEMM_B_LOWTRI) && ck < cit.n0 + G2_BT;
+      const bool triA = (p.flags & HS_GEMM_A_LOWTRI) && ck + G2_BKS > cit.m0;
 #pragma unroll
       for (int ks = 0; ks < G2_BKS / 4; ++ks)
       {
+         const int kk = ck + 4 * ks;
+         /* B[k][n] = 0 for k < n: column slab j (columns from cn) is zero when kk + 3 < cn */
+         int jlim = 4;
+         if ( triB )
+         {
+            const int d = kk + 3 - (cit.n0 + wn * 64);
+            jlim = d < 0 ? 0 : min(4, d / 16 + 1);
+         }
+         /* A[m][k] = 0 for k > m: row slab i (rows from rm) is zero when kk > rm + 15 */
+         int imin = 0;
+         if ( triA )
+         {
+            const int e = kk - 15 - (cit.m0 + wm * 64);
+            imin = e <= 0 ? 0 : min(4, (e + 15) / 16);
+         }
          double fa[4], fb[4];
 #pragma unroll
          for (int i = 0; i < 4; ++i)
@@ -276,8 +299,10 @@ __global__ void __launch_bounds__(256, 2) hs_dgemm2_kernel(hs_gemm_args p, int k
          for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-               acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
+               if ( i >= imin && j < jlim )
+                  acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
       }
+      ck += G2_BKS;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       ++gc;
       if ( --cleft == 0 )

@@ -76,6 +76,20 @@ __global__ void k_unit_maxdiff(long long n, const double* __restrict__ a, const 
       atomicAdd(ndiff, cnt);
 }
 
+/* zero the part of an operand that a triangular flag declares zero: mode 0: X[r][c] = 0 for c > r (rows x cols, K contiguous A:
+ * k > m), mode 1: X[r][c] = 0 for r < c (B stored [K][N]: k < n) - the same predicate, kept apart for readability */
+__global__ void k_unit_tri(int rows, int cols, long long stride, int batch, double* __restrict__ x)
+{
+   const long long per = (long long) rows * cols;
+   for (long long e = (long long) blockIdx.x * blockDim.x + threadIdx.x; e < per * batch; e += (long long) gridDim.x * blockDim.x)
+   {
+      const long long b = e / per, w = e - b * per;
+      const int r = (int) (w / cols), c = (int) (w - (long long) r * cols);
+      if ( c > r )
+         x[b * stride + w] = 0.0;
+   }
+}
+
 /* The same product through both GEMM kernels (dgemm.hip, dgemm2.hip) on device-generated operands: the results must agree
  * bit for bit.  A is K-contiguous; layB, batch, splitk and flags as in hs_gemm_args (C packed, ldc = N).  used_v2 = 1 when
  * the persistent kernel accepted the shape; ndiff = number of differing elements of C (over all batch entries). */
@@ -97,6 +111,10 @@ extern "C" int hipsdp_dgemm_selfcheck(int device, int M, int N, int K, int layB,
    hipLaunchKernelGGL(k_unit_fill, dim3(1024), dim3(256), 0, 0, na, 11ULL, dA.p);
    hipLaunchKernelGGL(k_unit_fill, dim3(1024), dim3(256), 0, 0, batch > 1 ? nb * batch : nb, 23ULL, dB.p);
    hipLaunchKernelGGL(k_unit_fill, dim3(1024), dim3(256), 0, 0, nc * batch, 37ULL, dC1.p);
+   if ( flags & HS_GEMM_A_LOWTRI )
+      hipLaunchKernelGGL(k_unit_tri, dim3(1024), dim3(256), 0, 0, M, K, 0LL, 1, dA.p);
+   if ( (flags & HS_GEMM_B_LOWTRI) && layB == HS_MC )
+      hipLaunchKernelGGL(k_unit_tri, dim3(1024), dim3(256), 0, 0, K, N, nb, batch, dB.p);
    HS_HIP( hipMemcpy(dC2.p, dC1.p, (size_t) (nc * batch) * sizeof(double), hipMemcpyDeviceToDevice) );
    hs_gemm_args g = {M, N, K, HS_KC, layB, dA.p, K, 0, dB.p, layB == HS_KC ? (long long) K : (long long) N, sB, dC1.p, N, nc, 1.25, beta,
       batch, flags, splitk, dW.p};

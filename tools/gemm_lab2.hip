@@ -83,10 +83,13 @@ template<int N> __device__ __forceinline__ void wait_vm()
    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
 }
 
+__device__ unsigned long long g_clk[4];
+
 template<int BKS, int NS, int LB, int WGPC, int EXP>
 __global__ void __launch_bounds__(256, WGPC) k_v2(int M, int N, int K, int lda, int ldb, const double* __restrict__ A,
    const double* __restrict__ B, double* __restrict__ C)
 {
+   const unsigned long long c0 = clock64(), w0 = wall_clock64();
    extern __shared__ __attribute__((aligned(1024))) double smem[];
    constexpr int OPSZ = BT * BKS;            /* doubles per operand per stage */
    constexpr int SLOT = 2 * OPSZ;
@@ -154,6 +157,11 @@ __global__ void __launch_bounds__(256, WGPC) k_v2(int M, int N, int K, int lda, 
 #pragma unroll
          for (int j = 0; j < 4; ++j)
             C[(long long) (m0 + wm * 64 + 16 * i + (lane >> 4) + 4 * r) * N + n0 + wn * 64 + 16 * j + (lane & 15)] = acc[i][j][r];
+   if ( blockIdx.x == 1000 && tid == 0 )
+   {
+      g_clk[0] = clock64() - c0;
+      g_clk[1] = wall_clock64() - w0;
+   }
 }
 
 static double* dA; static double* dB; static double* dC; static double* dR;
@@ -177,8 +185,115 @@ static void run(int M, int N, int K, int lda, int ldb, const char* what)
    CK(hipMemcpy(hC.data(), dC, (size_t) M * N * 8, hipMemcpyDeviceToHost));
    double err = 0.0, nrm = 0.0;
    for (size_t i = 0; i < (size_t) M * N; i += 97) { err = fmax(err, fabs(hC[i] - hR[i])); nrm = fmax(nrm, fabs(hR[i])); }
+   unsigned long long hclk[4];
+   CK(hipMemcpyFromSymbol(hclk, HIP_SYMBOL(g_clk), sizeof(hclk)));
+   printf("[core clock %.0f MHz] ", 100.0 * (double) hclk[0] / (double) hclk[1]);
    printf("v2 BKS=%2d NS=%d LB=%d WG/CU=%d EXP=%d smem=%6zu %-10s %8.3f ms  %6.2f TF   maxerr %.2e (ref max %.2e)\n", BKS, NS, LB, WGPC, EXP, smem, what, ms,
       2.0 * M * N * K / ms / 1e9, err, nrm);
+}
+
+
+/* 256 x 128 tile, 8 waves (4 x 2), one workgroup per CU: 25 % less operand traffic per flop */
+template<int BKS, int NS, int LB>
+__global__ void __launch_bounds__(512, 1) k_v3(int M, int N, int K, int lda, int ldb, const double* __restrict__ A,
+   const double* __restrict__ B, double* __restrict__ C)
+{
+   extern __shared__ __attribute__((aligned(1024))) double smem[];
+   constexpr int OPA = 256 * BKS, OPB = 128 * BKS;
+   constexpr int SLOT = OPA + OPB;
+   constexpr int GPS = (OPA + OPB) * 8 / 1024 / 8;      /* glds per wave per stage: 3 at BKS = 8 */
+   const int tid = threadIdx.x, lane = tid & 63;
+   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+   const int wm = wave >> 1, wn = wave & 1;
+   const int tn = N / 128;
+   int b = blockIdx.x;
+   { const int P = gridDim.x / 8; b = (b & 7) * P + (b >> 3); }
+   const int m0 = (b / tn) * 256, n0 = (b % tn) * 128;
+   v4d acc[4][4];
+#pragma unroll
+   for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+         acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+   const int nst = K / BKS;
+   auto issue = [&](int st)
+   {
+      double* slot = smem + (st % NS) * SLOT;
+      const int k0 = st * BKS;
+      /* A: 16 pieces of 16 rows (BKS = 8), 2 per wave */
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+      {
+         const int piece = wave * 2 + i;
+         glds16(A + (long long) (m0 + piece * 16 + (lane & 15)) * lda + k0 + 2 * (lane >> 4), slot + piece * 128);
+      }
+      /* B: 8 pieces, 1 per wave */
+      if ( LB == HS_KC )
+         glds16(B + (long long) (n0 + wave * 16 + (lane & 15)) * ldb + k0 + 2 * (lane >> 4), slot + OPA + wave * 128);
+      else
+         glds16(B + (long long) (k0 + wave) * ldb + n0 + 2 * (lane ^ ((wave & 1) << 3)), slot + OPA + wave * 128);
+   };
+#pragma unroll
+   for (int s = 0; s < NS - 1; ++s)
+      if ( s < nst )
+         issue(s);
+   for (int t = 0; t < nst; ++t)
+   {
+      if ( t + NS - 2 < nst )
+         wait_vm<(NS - 2) * GPS>();
+      else
+         wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+      if ( t + NS - 1 < nst )
+         issue(t + NS - 1);
+      const double* sa = smem + (t % NS) * SLOT;
+      const double* sb = sa + OPA;
+#pragma unroll
+      for (int ks = 0; ks < BKS / 4; ++ks)
+      {
+         double fa[4], fb[4];
+#pragma unroll
+         for (int i = 0; i < 4; ++i)
+         {
+            fa[i] = stage_frag<BKS, HS_KC>(sa, wm * 64, i, ks, lane);
+            fb[i] = stage_frag<BKS, LB>(sb, wn * 64, i, ks, lane);
+         }
+#pragma unroll
+         for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+               acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+   }
+#pragma unroll
+   for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+         for (int j = 0; j < 4; ++j)
+            C[(long long) (m0 + wm * 64 + 16 * i + (lane >> 4) + 4 * r) * N + n0 + wn * 64 + 16 * j + (lane & 15)] = acc[i][j][r];
+}
+
+template<int BKS, int NS, int LB>
+static void run3(int M, int N, int K, int lda, int ldb)
+{
+   const size_t smem = (size_t) NS * (256 + 128) * BKS * 8;
+   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_v3<BKS, NS, LB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem));
+   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+   const int grid = (M / 256) * (N / 128);
+   CK(hipMemset(dC, 0, (size_t) M * N * 8));
+   for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((k_v3<BKS, NS, LB>), dim3(grid), dim3(512), smem, 0, M, N, K, lda, ldb, dA, dB, dC);
+   CK(hipGetLastError());
+   CK(hipEventRecord(e0, 0));
+   const int reps = 5;
+   for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((k_v3<BKS, NS, LB>), dim3(grid), dim3(512), smem, 0, M, N, K, lda, ldb, dA, dB, dC);
+   CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+   float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+   CK(hipMemcpy(hC.data(), dC, (size_t) M * N * 8, hipMemcpyDeviceToHost));
+   double err = 0.0;
+   for (size_t i = 0; i < (size_t) M * N; i += 97) err = fmax(err, fabs(hC[i] - hR[i]));
+   printf("v3 256x128 BKS=%2d NS=%d LB=%d smem=%6zu   %8.3f ms  %6.2f TF   maxerr %.2e\n", BKS, NS, LB, smem, ms, 2.0 * M * N * K / ms / 1e9, err);
 }
 
 static void ref(int M, int N, int K, int lda, int ldb, int LB, int flags)
@@ -228,6 +343,8 @@ int main()
       if ( LB == 0 )
       {
          run<8, 4, 0, 2>(M, N, K, ld, ld, "");
+         run3<8, 4, 0>(M, N, K, ld, ld);
+         run3<8, 6, 0>(M, N, K, ld, ld);
          run<16, 2, 0, 2>(M, N, K, ld, ld, "");
          run<8, 4, 0, 2, 1>(M, N, K, ld, ld, "same tile");
          run<16, 2, 0, 2, 1>(M, N, K, ld, ld, "same tile");
@@ -237,6 +354,8 @@ int main()
       else
       {
          run<8, 4, 1, 2>(M, N, K, ld, ld, "");
+         run3<8, 4, 1>(M, N, K, ld, ld);
+         run3<8, 6, 1>(M, N, K, ld, ld);
          run<16, 2, 1, 2>(M, N, K, ld, ld, "");
          run<8, 4, 1, 2, 1>(M, N, K, ld, ld, "same tile");
          run<16, 2, 1, 2, 1>(M, N, K, ld, ld, "same tile");

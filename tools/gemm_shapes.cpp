@@ -28,13 +28,13 @@ int main()
    for (int f : fl)
    {
       hs_gemm_args g = {m1 * n, n, n, HS_KC, HS_MC, A, n, 0, S, n, 0, T, n, 0, 1.0, 0.0, 1, f, 1, NULL};
-      printf("stack   flags %2d : %.3f ms\n", f, timeit(g, 5));
+      printf("stack   flags %7d : %.3f ms\n", f, timeit(g, 5));
    }
    int fa[] = {0, HS_GEMM_REMAP, HS_GEMM_A_LOWTRI, HS_GEMM_A_LOWTRI | HS_GEMM_REMAP};
    for (int f : fa)
    {
       hs_gemm_args g = {n, n, n, HS_KC, HS_MC, S, n, 0, T, n, n2, W, n, n2, 1.0, 0.0, m1, f, 1, NULL};
-      printf("batched flags %2d : %.3f ms\n", f, timeit(g, 5));
+      printf("batched flags %7d : %.3f ms\n", f, timeit(g, 5));
    }
    /* batched in the transposed formulation: C_j = T_j^T * S^T  (A = T_j in MC layout, B = S as [N][K]) */
    for (int f : {0, HS_GEMM_REMAP})
