@@ -466,3 +466,254 @@ int hs_trsv(hipStream_t s, int n, const double* L, const double* dinv, int nrhs,
    HS_LAUNCH_CHECK();
    return HS_OK;
 }
+
+/* ---- triangular solves across workgroups -------------------------------------------------------------------------- */
+/* One workgroup per 64-row block, all co-resident (the grid is at most a few hundred small workgroups).  Forward: block b
+ * accumulates r_b - sum_{c<b} L_bc x_c as the x_c become available, then x_b = inv(L_bb) (..), publishes x_b and raises
+ * its flag; backward the same with c > b and transposed blocks.  A block waits only on blocks that are strictly earlier
+ * in the dependency order, so any dispatch order terminates; the flags carry the epoch of the call (no reset between
+ * calls), the hand-off is release/acquire at agent scope (the acquire refreshes this CU's vector cache), and every spin
+ * is bounded: on expiry the error word behind the flags is set and the block leaves without publishing (later blocks then
+ * expire too, the launch ends, and the interior-point loop stops on the non-finite step it gets).  The next L block is
+ * requested before the flag of the current one is awaited. */
+#define TRSV_SPIN_LIMIT (1 << 20)
+
+__device__ __forceinline__ bool trsv_wait(const int* flag, int epoch, int* err)
+{
+   int spins = 0;
+   while ( __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch )
+   {
+      if ( ++spins > TRSV_SPIN_LIMIT )
+      {
+         atomicExch(err, 1);
+         return false;
+      }
+      __builtin_amdgcn_s_sleep(1);
+   }
+   return true;
+}
+
+template<int NRHS>
+__global__ void __launch_bounds__(256) k_trsv_fwd(int n, const double* __restrict__ L, const double* __restrict__ dinv,
+   double* __restrict__ rhs, long long ldr, int* __restrict__ flags, int epoch)
+{
+   __shared__ double xs[NRHS][NB];
+   __shared__ int ok;
+   const int b = blockIdx.x;
+   const int tid = threadIdx.x;
+   const int row = tid >> 2, q = tid & 3;          /* 64 rows, 4 lanes per row, 16 columns each */
+   const long long ld = n;
+   const int j0 = b * NB;
+   const int nb = (n - j0) < NB ? (n - j0) : NB;
+   int* err = flags + gridDim.x;
+   double acc[NRHS];
+#pragma unroll
+   for (int k = 0; k < NRHS; ++k)
+      acc[k] = 0.0;
+   const bool rowok = row < nb;
+   const double* lrow = L + (long long) (j0 + (rowok ? row : 0)) * ld + 16 * q;
+   double lcur[16], lnext[16];
+   if ( b > 0 )
+   {
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+         lcur[c] = lrow[c];
+   }
+   for (int cb = 0; cb < b; ++cb)
+   {
+      if ( cb + 1 < b )
+      {
+#pragma unroll
+         for (int c = 0; c < 16; ++c)
+            lnext[c] = lrow[(long long) (cb + 1) * NB + c];
+      }
+      if ( tid == 0 )
+         ok = trsv_wait(flags + cb, epoch, err) ? 1 : 0;
+      __syncthreads();
+      if ( !ok )
+         return;
+      if ( tid < NB * NRHS )
+         xs[tid / NB][tid % NB] = rhs[(long long) (tid / NB) * ldr + cb * NB + (tid % NB)];
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < NRHS; ++k)
+      {
+         double sacc = 0.0;
+#pragma unroll
+         for (int c = 0; c < 16; ++c)
+            sacc += lcur[c] * xs[k][16 * q + c];
+         acc[k] += sacc;
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+         lcur[c] = lnext[c];
+      __syncthreads();
+   }
+   /* y = r_b - acc (reduced over the 4 lanes of a row), x_b = inv(L_bb) y */
+#pragma unroll
+   for (int k = 0; k < NRHS; ++k)
+   {
+      double sacc = acc[k];
+      sacc += __shfl_xor(sacc, 1, 64);
+      sacc += __shfl_xor(sacc, 2, 64);
+      if ( q == 0 )
+         xs[k][row] = rowok ? rhs[(long long) k * ldr + j0 + row] - sacc : 0.0;
+   }
+   __syncthreads();
+   const double* db = dinv + (long long) b * NB * NB + row * NB + 16 * q;
+#pragma unroll
+   for (int k = 0; k < NRHS; ++k)
+   {
+      double sacc = 0.0;
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+         sacc += db[c] * xs[k][16 * q + c];
+      sacc += __shfl_xor(sacc, 1, 64);
+      sacc += __shfl_xor(sacc, 2, 64);
+      if ( q == 0 && rowok )
+         rhs[(long long) k * ldr + j0 + row] = sacc;
+   }
+   __syncthreads();
+   if ( tid == 0 )
+   {
+      __threadfence();
+      __hip_atomic_store(flags + b, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+   }
+}
+
+template<int NRHS>
+__global__ void __launch_bounds__(256) k_trsv_bwd(int n, const double* __restrict__ L, const double* __restrict__ dinv,
+   double* __restrict__ rhs, long long ldr, int* __restrict__ flags, int epoch)
+{
+   __shared__ double xs[NRHS][NB];
+   __shared__ double red[4][NRHS][NB];
+   __shared__ int ok;
+   const int nblk = gridDim.x;
+   const int b = blockIdx.x;
+   const int tid = threadIdx.x;
+   const int col = tid & 63, g = tid >> 6;          /* column of the block, 4 row groups of 16 rows */
+   const long long ld = n;
+   const int j0 = b * NB;
+   const int nb = (n - j0) < NB ? (n - j0) : NB;
+   int* err = flags + nblk;
+   const bool colok = col < nb;
+   double acc[NRHS];
+#pragma unroll
+   for (int k = 0; k < NRHS; ++k)
+      acc[k] = 0.0;
+   /* s[col] = sum over later blocks cb, rows i of the block: L[cb * 64 + i][j0 + col] * x[cb * 64 + i] */
+   for (int cb = nblk - 1; cb > b; --cb)
+   {
+      const int i0 = cb * NB;
+      const int nbc = (n - i0) < NB ? (n - i0) : NB;
+      double lv[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+      {
+         const int i = 16 * g + c;
+         lv[c] = (i < nbc && colok) ? L[(long long) (i0 + i) * ld + j0 + col] : 0.0;
+      }
+      if ( tid == 0 )
+         ok = trsv_wait(flags + cb, epoch, err) ? 1 : 0;
+      __syncthreads();
+      if ( !ok )
+         return;
+      if ( tid < NB * NRHS )
+      {
+         const int i = tid % NB;
+         xs[tid / NB][i] = (i < nbc) ? rhs[(long long) (tid / NB) * ldr + i0 + i] : 0.0;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < NRHS; ++k)
+      {
+         double sacc = 0.0;
+#pragma unroll
+         for (int c = 0; c < 16; ++c)
+            sacc += lv[c] * xs[k][16 * g + c];
+         acc[k] += sacc;
+      }
+      __syncthreads();
+   }
+#pragma unroll
+   for (int k = 0; k < NRHS; ++k)
+      red[g][k][col] = acc[k];
+   __syncthreads();
+   if ( tid < NB * NRHS )
+   {
+      const int k = tid / NB, i = tid % NB;
+      const double sacc = red[0][k][i] + red[1][k][i] + red[2][k][i] + red[3][k][i];
+      xs[k][i] = (i < nb) ? rhs[(long long) k * ldr + j0 + i] - sacc : 0.0;
+   }
+   __syncthreads();
+   /* x_b = inv(L_bb)^T v : out[col] = sum_i dinv[i][col] v[i] */
+   const double* db = dinv + (long long) b * NB * NB;
+#pragma unroll
+   for (int k = 0; k < NRHS; ++k)
+   {
+      double sacc = 0.0;
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+         sacc += db[(16 * g + c) * NB + col] * xs[k][16 * g + c];
+      red[g][k][col] = sacc;
+   }
+   __syncthreads();
+   if ( tid < NB * NRHS )
+   {
+      const int k = tid / NB, i = tid % NB;
+      if ( i < nb )
+         rhs[(long long) k * ldr + j0 + i] = red[0][k][i] + red[1][k][i] + red[2][k][i] + red[3][k][i];
+   }
+   __syncthreads();
+   if ( tid == 0 )
+   {
+      __threadfence();
+      __hip_atomic_store(flags + b, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+   }
+}
+
+/* number of ints of the flag workspace of hs_trsv_sync for an n x n factor (zero it once after allocation) */
+long long hs_trsv_sync_ws(int n)
+{
+   return (long long) (n + NB - 1) / NB + 8;
+}
+
+/* the multi-workgroup solve; sync_ws from hs_trsv_sync_ws, *epoch is advanced by the call (start it at 0) */
+int hs_trsv_sync(hipStream_t s, int n, const double* L, const double* dinv, int nrhs, double* rhs, long long ldr, int mode,
+   int* sync_ws, int* epoch)
+{
+   if ( n <= 0 || nrhs <= 0 )
+      return HS_OK;
+   if ( nrhs > 4 )
+      return HS_ERR_ARG;
+   const int nblk = (n + NB - 1) / NB;
+   if ( sync_ws == NULL || epoch == NULL || nblk > 512 || nblk < 3 )
+      return hs_trsv(s, n, L, dinv, nrhs, rhs, ldr, mode);
+   if ( mode & 1 )
+   {
+      const int e = ++(*epoch);
+      switch ( nrhs )
+      {
+      case 1: hipLaunchKernelGGL((k_trsv_fwd<1>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e); break;
+      case 2: hipLaunchKernelGGL((k_trsv_fwd<2>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e); break;
+      case 3: hipLaunchKernelGGL((k_trsv_fwd<3>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e); break;
+      default: hipLaunchKernelGGL((k_trsv_fwd<4>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e); break;
+      }
+      HS_LAUNCH_CHECK();
+   }
+   if ( mode & 2 )
+   {
+      const int e = ++(*epoch);
+      switch ( nrhs )
+      {
+      case 1: hipLaunchKernelGGL((k_trsv_bwd<1>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e); break;
+      case 2: hipLaunchKernelGGL((k_trsv_bwd<2>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e); break;
+      case 3: hipLaunchKernelGGL((k_trsv_bwd<3>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e); break;
+      default: hipLaunchKernelGGL((k_trsv_bwd<4>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e); break;
+      }
+      HS_LAUNCH_CHECK();
+   }
+   return HS_OK;
+}
+
+

@@ -84,6 +84,11 @@ int hs_trtri(hipStream_t s, int n, const double* L, const double* dinv, double* 
 /* solves L y = r (nrhs <= 4 right-hand sides, rhs[k * ldr + i]) then optionally L^T x = y, in place.  mode 1: forward only,
  * 2: backward only, 3: both */
 int hs_trsv(hipStream_t s, int n, const double* L, const double* dinv, int nrhs, double* rhs, long long ldr, int mode);
+/* the same solve with one workgroup per 64-row block (flag hand-off between blocks); sync_ws: hs_trsv_sync_ws(n) ints, zeroed
+ * once; *epoch: call counter owned by the caller (start at 0) */
+long long hs_trsv_sync_ws(int n);
+int hs_trsv_sync(hipStream_t s, int n, const double* L, const double* dinv, int nrhs, double* rhs, long long ldr, int mode,
+   int* sync_ws, int* epoch);
 
 /* ---- eig.hip -------------------------------------------------------------------------------------------------- */
 /* Lanczos estimate of the smallest eigenvalue of the symmetric n x n matrix W.  res[0] = Ritz value theta,

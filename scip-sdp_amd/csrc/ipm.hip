@@ -82,6 +82,8 @@ struct hipsdp_solver
    double *u1, *rhs2, *u2, *dy, *dya;
    double *Mx, *Lm, *dinvm, *Slp;
    double *sc, *red_ws, *gemv_ws, *lan_ws, *lan_ws2, *gws1, *gws2;
+   int* trsv_ws;           /* block flags of the multi-workgroup triangular solves */
+   int trsv_epoch;
    long long gws_len;
    long long gemv_ws_len;
    int* flags;       /* device ints: 0 chol Z, 1 chol X, 2 chol M */
@@ -169,6 +171,8 @@ static void free_problem(hipsdp_solver* s)
    dfree(s->Mgather);
    s->Mgather = NULL;
    dfree(s->flags);
+   dfree(s->trsv_ws);
+   s->trsv_ws = NULL;
    s->b = s->Dext = s->y = s->x = s->z = s->yt = s->dyt = s->wt = s->AX = s->AH = s->tmpe = s->rp = s->rd = s->tmpq = s->hl = NULL;
    s->beta = s->elp = s->dxa = s->dza = s->dx = s->dz = s->xs = s->zs = s->ys = s->u1 = s->rhs2 = s->u2 = s->dy = s->dya = NULL;
    s->Mx = s->Lm = s->dinvm = s->Slp = s->sc = s->red_ws = s->gemv_ws = s->lan_ws = s->lan_ws2 = s->gws1 = s->gws2 = NULL;
@@ -201,6 +205,8 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
    s->schur_mode_rows = false;
    s->sws.T = s->sws.U = s->sws.K = NULL;
    s->flags = NULL;
+   s->trsv_ws = NULL;
+   s->trsv_epoch = 0;
    s->last_status = HIPSDP_STATUS_UNSOLVED;
    s->sol_scale = 1.0;
    s->b = s->Dext = s->y = s->x = s->z = s->yt = s->dyt = s->wt = s->AX = s->AH = s->tmpe = s->rp = s->rd = s->tmpq = s->hl = NULL;
@@ -325,6 +331,9 @@ extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int*
    HS_CALL( dalloc(&s->gws1, s->gws_len) );
    HS_CALL( dalloc(&s->gws2, s->gws_len) );
    HS_CALL( dalloc(&s->flags, 8) );
+   HS_CALL( dalloc(&s->trsv_ws, hs_trsv_sync_ws(m)) );
+   HS_HIP( hipMemset(s->trsv_ws, 0, (size_t) hs_trsv_sync_ws(m) * sizeof(int)) );
+   s->trsv_epoch = 0;
    s->sws.T = s->sws.U = s->sws.K = NULL;
    HS_HIP( hipMemsetAsync(s->Dext, 0, (size_t) ((long long) q * m1 > 0 ? (long long) q * m1 : 1) * sizeof(double), s->stream) );
    HS_HIP( hipMemsetAsync(s->b, 0, (size_t) (m > 0 ? m : 1) * sizeof(double), s->stream) );
@@ -852,7 +861,7 @@ static int direction(hipsdp_solver* s, double sigma, double eta, double mu, doub
    {
       hipLaunchKernelGGL(k_h, g1d(m), dim3(256), 0, s->stream, m, eta, s->AH, s->rp, s->u1);
       HS_LAUNCH_CHECK();
-      HS_CALL( hs_trsv(s->stream, m, s->Lm, s->dinvm, 1, s->u1, m, 3) );
+      HS_CALL( hs_trsv_sync(s->stream, m, s->Lm, s->dinvm, 1, s->u1, m, 3, s->trsv_ws, &s->trsv_epoch) );
    }
    /* BH = sum <B_k, H_k> + beta^T hl ; wrp ; bu1 */
    HS_CALL( hs_fill(s->stream, s->sc + SC_BH, 1, 0.0) );
@@ -1261,7 +1270,7 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
          HS_CALL( hs_potrf(st, m, s->Lm, s->dinvm, s->flags + 2, s->dya) );
          hipLaunchKernelGGL(k_rhs2, g1d(m), dim3(256), 0, st, m, s->Mx, s->b, s->rhs2);
          HS_LAUNCH_CHECK();
-         HS_CALL( hs_trsv(st, m, s->Lm, s->dinvm, 2, s->rhs2, m, 3) );
+         HS_CALL( hs_trsv_sync(st, m, s->Lm, s->dinvm, 2, s->rhs2, m, 3, s->trsv_ws, &s->trsv_epoch) );
       }
       hipLaunchKernelGGL(k_after_solve2, g1d(m1), dim3(256), 0, st, m, s->rhs2, s->u2, s->wt);
       HS_LAUNCH_CHECK();

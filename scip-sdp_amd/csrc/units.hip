@@ -234,8 +234,15 @@ extern "C" int hipsdp_potrs(int device, int n, const double* A, int nrhs, double
    HS_HIP( hipMalloc((void**) &dflag, sizeof(int)) );
    HS_HIP( hipMemset(dflag, 0, sizeof(int)) );
    HS_CALL( dA.up(A, n2) ); HS_CALL( dR.up(rhs, (long long) nrhs * n) );
+   /* the solve runs through the multi-workgroup kernels when the factor has at least 3 blocks (as in the engine) */
+   int* dsync = NULL;
+   int epoch = 0;
+   HS_HIP( hipMalloc((void**) &dsync, (size_t) hs_trsv_sync_ws(n) * sizeof(int)) );
+   HS_HIP( hipMemset(dsync, 0, (size_t) hs_trsv_sync_ws(n) * sizeof(int)) );
    int rc = hs_potrf(0, n, dA.p, dD.p, dflag, NULL);
-   if ( rc == HS_OK ) rc = hs_trsv(0, n, dA.p, dD.p, nrhs, dR.p, n, 3);
+   if ( rc == HS_OK ) rc = hs_trsv_sync(0, n, dA.p, dD.p, nrhs, dR.p, n, 3, dsync, &epoch);
+   if ( rc == HS_OK && hipDeviceSynchronize() != hipSuccess ) rc = HS_ERR_HIP;
+   (void) hipFree(dsync);
    if ( rc == HS_OK && hipDeviceSynchronize() != hipSuccess ) rc = HS_ERR_HIP;
    int hflag = 0;
    if ( rc == HS_OK && hipMemcpy(&hflag, dflag, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ) rc = HS_ERR_HIP;

@@ -63,7 +63,7 @@ def test_schur_assembly_w_formulation(gpu, m1, n):
     assert rel(gpu.schur_w(A, X, Z), ref) <= 1e-11
 
 
-@pytest.mark.parametrize("n", [1, 2, 7, 63, 64, 65, 130, 300, 777])
+@pytest.mark.parametrize("n", [1, 2, 7, 63, 64, 65, 130, 192, 300, 777, 1000, 1601])
 def test_cholesky_inverse_and_solves(gpu, n):
     G = RNG.standard_normal((n, n))
     S = G @ G.T + n * np.eye(n)
