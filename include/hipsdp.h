@@ -75,6 +75,8 @@ typedef struct hipsdp_info
    double schur_flops;      /* algorithmic flops of the assemblies: (4 m1 n^3 + m1^2 n^2) per block and iteration */
    int    schur_calls;
    int    chol_fail;        /* number of step halvings forced by a failed Cholesky */
+   int    warm_started;     /* 1: the point given with hipsdp_set_start was interior and has been used */
+   int    reserved;
 } hipsdp_info;
 
 const char* hipsdp_last_error(void);

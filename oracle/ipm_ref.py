@@ -128,6 +128,28 @@ def max_step_vec(x, dx):
     return float(np.min(-x[neg] / dx[neg]))
 
 
+def warm_start_point(prob, y, X, Z, x, z):
+    """start tuple for hsd_solve from a caller-supplied point (sdpisolver.h:160-173; consumed as in
+    sdpisolver_sdpa.cpp:1481-1592) or None: the point is used only if it is strictly interior (X_k, Z_k positive definite,
+    x, z > 0); tau = 1, kappa = mean complementarity"""
+    X = [sym(np.asarray(Xk, dtype=np.float64)) for Xk in X]
+    Z = [sym(np.asarray(Zk, dtype=np.float64)) for Zk in Z]
+    x = np.asarray(x, dtype=np.float64).reshape(-1)
+    z = np.asarray(z, dtype=np.float64).reshape(-1)
+    try:
+        for M in X + Z:
+            np.linalg.cholesky(M)
+    except np.linalg.LinAlgError:
+        return None
+    if prob.q and (x.min() <= 0.0 or z.min() <= 0.0):
+        return None
+    N = prob.N
+    mu0 = (sum(np.sum(Xk * Zk) for Xk, Zk in zip(X, Z)) + (x @ z if prob.q else 0.0)) / max(N, 1)
+    if not np.isfinite(mu0) or mu0 <= 0.0:
+        return None
+    return (np.asarray(y, dtype=np.float64).copy(), X, Z, x.copy(), z.copy(), 1.0, float(mu0))
+
+
 def hsd_solve(prob, par=None, start=None):
     """Solves the core problem.  Returns Result with y, X (list), Z (list), x, z scaled back by tau, status, iterations."""
     par = par or Params()

@@ -22,7 +22,8 @@ class Info(C.Structure):
     _fields_ = [("status", C.c_int), ("iterations", C.c_int), ("pobj", C.c_double), ("dobj", C.c_double),
                 ("pinf", C.c_double), ("dinf", C.c_double), ("dabs", C.c_double), ("gap", C.c_double), ("mu", C.c_double),
                 ("tau", C.c_double), ("kappa", C.c_double), ("solve_seconds", C.c_double), ("schur_seconds", C.c_double),
-                ("schur_flops", C.c_double), ("schur_calls", C.c_int), ("chol_fail", C.c_int)]
+                ("schur_flops", C.c_double), ("schur_calls", C.c_int), ("chol_fail", C.c_int), ("warm_started", C.c_int),
+                ("reserved", C.c_int)]
 
 
 _lib = None
@@ -134,6 +135,17 @@ class Solver:
             self.set_block_dense(k, A)
         if prob.q:
             self.set_lp(np.concatenate([np.asarray(prob.c).reshape(-1, 1), prob.D], axis=1))
+
+    def set_start(self, y, X, Z, x=None, z=None):
+        """start point of the next solve (used by the engine only if strictly interior: Info.warm_started)"""
+        y = _f64(y)
+        Xs = [_f64(M) for M in X]
+        Zs = [_f64(M) for M in Z]
+        PX = (C.POINTER(C.c_double) * max(len(Xs), 1))(*[_dp(M) for M in Xs])
+        PZ = (C.POINTER(C.c_double) * max(len(Zs), 1))(*[_dp(M) for M in Zs])
+        xx = _f64(x if x is not None else np.zeros(max(self.q, 1)))
+        zz = _f64(z if z is not None else np.zeros(max(self.q, 1)))
+        _chk(lib().hipsdp_set_start(self.h, _dp(y), PX, PZ, _dp(xx), _dp(zz)), "hipsdp_set_start")
 
     def solve(self, **kw):
         p = Params()

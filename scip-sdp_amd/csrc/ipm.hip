@@ -596,6 +596,14 @@ extern "C" int hipsdp_set_start(hipsdp_solver* s, const double* y, const double*
 
 /* ---- small fused kernels of the iteration ---------------------------------------------------------------------- */
 
+/* flag = 1 when some x[i] <= 0 or z[i] <= 0 (or is not finite) */
+__global__ void k_flag_nonpositive(int q, const double* __restrict__ x, const double* __restrict__ z, int* __restrict__ flag)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if ( i < q && (!(x[i] > 0.0) || !(z[i] > 0.0) || !(x[i] < 1e300) || !(z[i] < 1e300)) )
+      atomicExch(flag, 1);
+}
+
 /* ext[0] = s0, ext[1 + i] = s1 * v[i] */
 __global__ void k_make_ext(int m, double s0, double s1, const double* __restrict__ v, double* __restrict__ ext)
 {
@@ -995,6 +1003,46 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
    const double normC = sqrt(h2[1]);
 
    /* ---- starting point */
+   bool start_factors = false;
+   if ( s->have_start )
+   {
+      /* a caller-supplied point (warm start, sdpisolver.h:160-173) is used when it is strictly interior: X_k, Z_k positive
+       * definite (checked by the factorizations the first iteration needs anyway) and x, z > 0; kappa = its mean
+       * complementarity (tau = 1).  Otherwise the solve falls back to the cold start below. */
+      HS_HIP( hipMemsetAsync(s->flags, 0, 8 * sizeof(int), st) );
+      HS_CALL( hs_fill(st, s->sc + SC_XZ, 1, 0.0) );
+      for (auto& B : s->blk)
+      {
+         const long long n2 = (long long) B.n * B.n;
+         HS_CALL( hs_symmetrize(st, B.X, B.n) );
+         HS_CALL( hs_symmetrize(st, B.Z, B.n) );
+         HS_CALL( hs_copy(st, B.Lz, B.Z, n2) );
+         HS_CALL( hs_potrf(st, B.n, B.Lz, B.dinvz, s->flags + 0, NULL) );
+         HS_CALL( hs_copy(st, B.Lx, B.X, n2) );
+         HS_CALL( hs_potrf(st, B.n, B.Lx, B.dinvx, s->flags + 1, NULL) );
+         HS_CALL( hs_dot(st, n2, B.X, B.Z, s->sc + SC_XZ, 1, s->red_ws) );
+      }
+      if ( q > 0 )
+      {
+         hipLaunchKernelGGL(k_flag_nonpositive, g1d(q), dim3(256), 0, st, q, s->x, s->z, s->flags + 3);
+         HS_LAUNCH_CHECK();
+         HS_CALL( hs_dot(st, q, s->x, s->z, s->sc + SC_XZ, 1, s->red_ws) );
+      }
+      int f4[4];
+      double xz = 0.0;
+      HS_HIP( hipMemcpyAsync(f4, s->flags, 4 * sizeof(int), hipMemcpyDeviceToHost, st) );
+      HS_HIP( hipMemcpyAsync(&xz, s->sc + SC_XZ, sizeof(double), hipMemcpyDeviceToHost, st) );
+      HS_HIP( hipStreamSynchronize(st) );
+      const double mu0 = xz / (double) (N > 0 ? N : 1);
+      if ( f4[0] == 0 && f4[1] == 0 && f4[3] == 0 && std::isfinite(mu0) && mu0 > 0.0 )
+      {
+         s->tau = 1.0;
+         s->kappa = mu0;
+         start_factors = true;
+      }
+      else
+         s->have_start = false;
+   }
    if ( !s->have_start )
    {
       const double xi = fmax(1.0, sqrt(fmax(fmax(normb, normC), 1.0)));
@@ -1009,11 +1057,7 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       s->tau = 1.0;
       s->kappa = xi * xi;
    }
-   else
-   {
-      s->tau = 1.0;
-      s->kappa = 1.0;
-   }
+   info->warm_started = s->have_start ? 1 : 0;
    s->have_start = false;
 
    int status = HIPSDP_STATUS_ITERLIM;
@@ -1024,7 +1068,7 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
    HostScalars hs;
    int hflags[3] = {0, 0, 0};
    bool want_cert = false;
-   bool factors_valid = false;
+   bool factors_valid = start_factors;      /* the factors of an accepted warm start are those of the first iteration */
    double schur_ms = 0.0;
 
    for (it = 0; it <= par.maxiter; ++it)

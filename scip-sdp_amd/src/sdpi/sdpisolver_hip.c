@@ -391,6 +391,110 @@ SCIP_RETCODE SCIPsdpiSolverLoadAndSolve(
 }
 
 /* one engine solve with the given tolerances; accumulates counters */
+/* Warm start (sdpisolver.h:160-173; consumed like sdpisolver_sdpa.cpp:1481-1592): y in original variable indices; Z and X
+ * as sparse lower triangles in ORIGINAL block indices, block nsdpblocks = diagonal LP block with index 2 * row (+ 1 for the
+ * rhs side) for LP rows and 2 * nlpcons + 2 * var (+ 1 for the upper bound) for variable bounds.  Entries of removed rows /
+ * columns / sides are dropped.  The engine uses the point only if it is strictly interior (hipsdp_set_start). */
+static SCIP_RETCODE loadStartPoint(SCIP_SDPISOLVER* s, int nvars, int nsdpblocks, int* const* indchanges, int nlpcons,
+   const SCIP_Real* starty, const int* startZnblocknonz, int* const* startZrow, int* const* startZcol, SCIP_Real* const* startZval,
+   const int* startXnblocknonz, int* const* startXrow, int* const* startXcol, SCIP_Real* const* startXval, int nengvars, int q)
+{
+   SCIP_Real* y0 = NULL;
+   SCIP_Real* x0 = NULL;
+   SCIP_Real* z0 = NULL;
+   SCIP_Real** X0 = NULL;
+   SCIP_Real** Z0 = NULL;
+   SCIP_RETCODE retcode = SCIP_OKAY;
+   int b;
+   int i;
+   int which;
+   const int neb = s->nengineblocks;
+
+   y0 = (SCIP_Real*) calloc((size_t) (nengvars > 0 ? nengvars : 1), sizeof(SCIP_Real));
+   x0 = (SCIP_Real*) calloc((size_t) (q > 0 ? q : 1), sizeof(SCIP_Real));
+   z0 = (SCIP_Real*) calloc((size_t) (q > 0 ? q : 1), sizeof(SCIP_Real));
+   X0 = (SCIP_Real**) calloc((size_t) (neb > 0 ? neb : 1), sizeof(SCIP_Real*));
+   Z0 = (SCIP_Real**) calloc((size_t) (neb > 0 ? neb : 1), sizeof(SCIP_Real*));
+   if ( y0 == NULL || x0 == NULL || z0 == NULL || X0 == NULL || Z0 == NULL )
+      retcode = SCIP_NOMEMORY;
+   for (b = 0; b < nsdpblocks && retcode == SCIP_OKAY; ++b)
+   {
+      const int eb = s->blockmap[b];
+      if ( eb < 0 )
+         continue;
+      X0[eb] = (SCIP_Real*) calloc((size_t) s->compactsize[b] * (size_t) s->compactsize[b], sizeof(SCIP_Real));
+      Z0[eb] = (SCIP_Real*) calloc((size_t) s->compactsize[b] * (size_t) s->compactsize[b], sizeof(SCIP_Real));
+      if ( X0[eb] == NULL || Z0[eb] == NULL )
+         retcode = SCIP_NOMEMORY;
+   }
+   if ( retcode == SCIP_OKAY )
+   {
+      for (i = 0; i < s->nactivevars; ++i)
+         y0[i] = starty[s->activetoinput[i]];
+      for (which = 0; which < 2; ++which)
+      {
+         const int* nnz = which ? startXnblocknonz : startZnblocknonz;
+         int* const* rows = which ? startXrow : startZrow;
+         int* const* cols = which ? startXcol : startZcol;
+         SCIP_Real* const* vals = which ? startXval : startZval;
+         SCIP_Real* lpvec = which ? x0 : z0;
+         for (b = 0; b < nsdpblocks; ++b)
+         {
+            const int eb = s->blockmap[b];
+            SCIP_Real* D;
+            int n;
+            if ( eb < 0 )
+               continue;
+            D = which ? X0[eb] : Z0[eb];
+            n = s->compactsize[b];
+            for (i = 0; i < nnz[b]; ++i)
+            {
+               const int r = rows[b][i];
+               const int c = cols[b][i];
+               if ( r < 0 || c < 0 || r >= s->origsize[b] || c >= s->origsize[b] )
+                  continue;
+               if ( indchanges[b][r] < 0 || indchanges[b][c] < 0 )
+                  continue;                     /* the row / column may have been fixed to zero in the meantime */
+               D[(size_t) (r - indchanges[b][r]) * n + (c - indchanges[b][c])] = vals[b][i];
+               D[(size_t) (c - indchanges[b][c]) * n + (r - indchanges[b][r])] = vals[b][i];
+            }
+         }
+         /* diagonal LP block */
+         for (i = 0; i < nnz[nsdpblocks]; ++i)
+         {
+            const int idx = rows[nsdpblocks][i];
+            int erow = -1;
+            if ( idx < 0 || idx >= 2 * nlpcons + 2 * nvars || idx != cols[nsdpblocks][i] )
+               continue;
+            if ( idx < 2 * nlpcons )
+               erow = (idx % 2 == 0) ? s->lhsrow[idx / 2] : s->rhsrow[idx / 2];
+            else
+            {
+               const int v = (idx - 2 * nlpcons) / 2;
+               erow = ((idx - 2 * nlpcons) % 2 == 0) ? s->lbrow[v] : s->ubrow[v];
+            }
+            if ( erow >= 0 && erow < q )
+               lpvec[erow] = vals[nsdpblocks][i];
+         }
+      }
+      if ( hipsdp_set_start(s->engine, y0, (const double* const*) X0, (const double* const*) Z0, x0, z0) != HIPSDP_OK )
+      {
+         SCIPerrorMessage("hipsdp_set_start failed: %s\n", hipsdp_last_error());
+         retcode = SCIP_LPERROR;
+      }
+   }
+   if ( X0 != NULL && Z0 != NULL )
+   {
+      for (b = 0; b < neb; ++b)
+      {
+         free(X0[b]);
+         free(Z0[b]);
+      }
+   }
+   free(X0); free(Z0); free(y0); free(x0); free(z0);
+   return retcode;
+}
+
 static SCIP_RETCODE engineSolve(SCIP_SDPISOLVER* s, SCIP_Real gaptol, SCIP_Real feastol, SCIP_Real remaining, SDPI_CLOCK* clck)
 {
    hipsdp_params par;
@@ -458,10 +562,7 @@ SCIP_RETCODE SCIPsdpiSolverLoadAndSolveWithPenalty(
    assert( nvars > 0 );
    assert( obj != NULL && lb != NULL && ub != NULL );
    (void) sdpconstnnonz; (void) sdpnnonz; (void) nremovedblocks; (void) nremovedinds;
-   /* round 1: the engine always starts from its own (well centred) point; the optional start is accepted and ignored,
-    * which the interface allows ("optionally an array start may be given", sdpisolver.h:160-166) */
-   (void) starty; (void) startZnblocknonz; (void) startZrow; (void) startZcol; (void) startZval;
-   (void) startXnblocknonz; (void) startXrow; (void) startXcol; (void) startXval;
+   /* the optional start point (sdpisolver.h:160-173) is handed to the engine after the problem is loaded, see below */
 
    if ( startsettings != SCIP_SDPSOLVERSETTING_UNSOLVED && startsettings != SCIP_SDPSOLVERSETTING_PENALTY
       && startsettings != SCIP_SDPSOLVERSETTING_FAST && startsettings != SCIP_SDPSOLVERSETTING_MEDIUM
@@ -839,6 +940,16 @@ SCIP_RETCODE SCIPsdpiSolverLoadAndSolveWithPenalty(
             return SCIP_LPERROR;
          }
       }
+   }
+
+   /* ---- optional warm start: not for penalty formulations (sdpisolver_sdpa.cpp:1481,1596) */
+   if ( starty != NULL && startZnblocknonz != NULL && startXnblocknonz != NULL && startZrow != NULL && startZcol != NULL
+      && startZval != NULL && startXrow != NULL && startXcol != NULL && startXval != NULL && !s->penalty )
+   {
+      SCIP_RETCODE startrc = loadStartPoint(s, nvars, nsdpblocks, indchanges, nlpcons, starty, startZnblocknonz, startZrow, startZcol,
+         startZval, startXnblocknonz, startXrow, startXcol, startXval, nengvars, q);
+      if ( startrc != SCIP_OKAY )
+         return startrc;
    }
 
    /* ---- solve, then the tolerance re-solve loop of sdpisolver_dsdp.c:1527-1606 ----------------------------------- */

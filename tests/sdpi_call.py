@@ -52,8 +52,10 @@ class SdpiSolver:
     def set_int(self, par, val):
         return self.lib.SCIPsdpiSolverSetIntpar(self.h, par, val)
 
-    def solve(self, P, penaltyparam=0.0, withobj=True, rbound=True, timelimit=1e20, clock=None):
-        """P: oracle.sdpi_prepare.Prepared.  Returns (retcode, feasorig, penaltybound)."""
+    def solve(self, P, penaltyparam=0.0, withobj=True, rbound=True, timelimit=1e20, clock=None, start=None):
+        """P: oracle.sdpi_prepare.Prepared.  Returns (retcode, feasorig, penaltybound).
+        start: optional dict(y=[nvars], Z=[(rows, cols, vals)] * (nblocks + 1), X=likewise) in ORIGINAL indices, the last
+        entry being the diagonal LP block (sdpisolver.h:160-173)."""
         prob = P.prob
         keep = []
         nb = len(prob.blocks)
@@ -113,6 +115,25 @@ class SdpiSolver:
         keep += [constn, nrem, bic, crow, ccol, cval, nvarnonz, sdpvar, srow, scol, sval, indch]
         feasorig = C.c_uint(0)
         penaltybound = C.c_uint(0)
+        startargs = [None] * 9
+        if start is not None:
+            sy = np.ascontiguousarray(start['y'], dtype=np.float64)
+            keep.append(sy)
+            packed = []
+            for key in ('Z', 'X'):
+                nnz = np.array([len(t[0]) for t in start[key]], dtype=np.int32)
+                rows = (PI * (nb + 1))()
+                cols = (PI * (nb + 1))()
+                vals = (PD * (nb + 1))()
+                for k, (r, c, v) in enumerate(start[key]):
+                    ra = np.array(list(r) or [0], dtype=np.int32)
+                    ca = np.array(list(c) or [0], dtype=np.int32)
+                    va = np.array(list(v) or [0.0], dtype=np.float64)
+                    keep.extend([ra, ca, va])
+                    rows[k], cols[k], vals[k] = _pi(ra), _pi(ca), _pd(va)
+                keep.extend([nnz, rows, cols, vals])
+                packed += [_pi(nnz), rows, cols, vals]
+            startargs = [_pd(sy)] + packed
         self._keep = keep
         rc = self.lib.SCIPsdpiSolverLoadAndSolveWithPenalty(
             self.h, C.c_double(penaltyparam), C.c_uint(1 if withobj else 0), C.c_uint(1 if rbound else 0),
@@ -123,7 +144,7 @@ class SdpiSolver:
             indch, _pi(nrem), _pi(bic), C.c_int(P.nremovedblocks),
             C.c_int(P.nlpcons), _pi(P.lpindchanges), _pd(P.lplhs), _pd(P.lprhs),
             C.c_int(P.lpnnonz), _pi(P.lpbeg), _pi(P.lpind), _pd(P.lpval),
-            None, None, None, None, None, None, None, None, None,
+            *startargs,
             C.c_int(UNSOLVED), C.c_double(timelimit), clock,
             C.byref(feasorig), C.byref(penaltybound))
         self._P = P

@@ -191,3 +191,71 @@ def test_rccl_code_path_with_a_single_rank_communicator(gpu):
     lib.hipsdp_comm_destroy(comm)
     assert info.status == 0 and info.iterations == ref.iterations
     assert np.max(np.abs(y - ref.y)) <= 1e-6
+
+
+def _solve_with_start(hb, core, start, tol=1e-6):
+    s = hb.Solver(0)
+    s.load_core(core)
+    if start is not None:
+        s.set_start(*start)
+    info = s.solve(gaptol=tol, feastol=tol)
+    out = dict(info=info, y=s.y(), X=[s.X(k) for k in range(len(core.blocks))], Z=[s.Z(k) for k in range(len(core.blocks))], lp=s.lp())
+    s.close()
+    return out
+
+
+def test_warm_start_from_an_interior_point_matches_oracle_and_saves_iterations(gpu):
+    """(f)-3: a start point handed in through hipsdp_set_start (what SCIPsdpiSolverLoadAndSolve receives as starty / startZ /
+    startX, sdpisolver.h:160-173) is used when strictly interior; the oracle applies the same rule."""
+    b, A, ys, Xs, Zs = instances.planted_dense(30, 45)
+    core = ipm_ref.CoreProblem(b, [A])
+    cold = _solve_with_start(gpu, core, None)
+    assert cold["info"].status == 0 and cold["info"].warm_started == 0
+    # the optimum pushed into the interior (relax_sdp.c builds its warm-start points the same way: convex combination with
+    # a scaled identity)
+    d = 1e-2
+    y0 = cold["y"]
+    X0 = [(1 - d) * cold["X"][0] + d * np.eye(30)]
+    Z0 = [(1 - d) * cold["Z"][0] + d * np.eye(30)]
+    warm = _solve_with_start(gpu, core, (y0, X0, Z0))
+    st = ipm_ref.warm_start_point(core, y0, X0, Z0, np.zeros(0), np.zeros(0))
+    assert st is not None
+    ref = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-6, feastol=1e-6), start=st)
+    assert warm["info"].status == 0 and warm["info"].warm_started == 1
+    assert warm["info"].iterations == ref.iterations
+    assert warm["info"].iterations < cold["info"].iterations
+    assert abs(warm["info"].dobj - cold["info"].dobj) <= 1e-6 * (1 + abs(cold["info"].dobj))
+    assert np.max(np.abs(warm["y"] - ref.y)) <= 1e-6
+
+
+def test_warm_start_that_is_not_interior_falls_back_to_the_cold_start(gpu):
+    b, A, ys, Xs, Zs = instances.planted_dense(20, 30)
+    core = ipm_ref.CoreProblem(b, [A])
+    cold = _solve_with_start(gpu, core, None)
+    # X* and Z* themselves are singular (complementary): no Cholesky factor, the engine must ignore the point
+    bad = _solve_with_start(gpu, core, (ys, [Xs], [Zs]))
+    assert ipm_ref.warm_start_point(core, ys, [Xs], [Zs], np.zeros(0), np.zeros(0)) is None
+    assert bad["info"].warm_started == 0
+    assert bad["info"].status == 0 and bad["info"].iterations == cold["info"].iterations
+    assert np.max(np.abs(bad["y"] - cold["y"])) <= 1e-12
+
+
+def test_warm_start_with_lp_rows(gpu):
+    case = next(c for c in CASES if c["name"] == "test10")
+    core = case_core(case)
+    cold = _solve_with_start(gpu, core, None)
+    assert cold["info"].status == 0
+    x, z = cold["lp"]
+    d = 1e-2
+    n = core.blocks[0].shape[1]
+    start = (cold["y"], [(1 - d) * cold["X"][0] + d * np.eye(n)], [(1 - d) * cold["Z"][0] + d * np.eye(n)], (1 - d) * x + d, (1 - d) * z + d)
+    warm = _solve_with_start(gpu, core, start)
+    st = ipm_ref.warm_start_point(core, *start)
+    ref = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-6, feastol=1e-6), start=st)
+    assert warm["info"].warm_started == 1 and warm["info"].status == ref.status == 0
+    assert warm["info"].iterations == ref.iterations
+    assert np.max(np.abs(warm["y"] - ref.y)) <= 1e-6
+    # non-positive multiplier: rejected
+    xb = x.copy(); xb[0] = 0.0
+    bad = _solve_with_start(gpu, core, (start[0], start[1], start[2], xb, start[4]))
+    assert bad["info"].warm_started == 0 and bad["info"].status == 0

@@ -258,3 +258,35 @@ def test_master_copy_is_reused_and_invalidated(gpu):
     t3, o3 = run(make(lb, ub, [dict(n=n, vars=vars3, const=const)]))   # one changed value: fingerprint must differ
     print("master copy: first call %.4f s (upload), second call %.4f s (re-used), changed data %.4f s" % (t1, t2, t3))
     s.free()
+
+
+def test_warm_start_through_the_solver_interface(gpu):
+    """starty / startZ / startX of SCIPsdpiSolverLoadAndSolve (sdpisolver.h:160-173): an interior point near the optimum of
+    checksdpi test11 (min x, x I - [1 2; 2 4] psd: y = 5, X = [0.2 0.4; 0.4 0.8]) saves iterations; entries of the diagonal LP
+    block with the 2 * nlpcons + 2 * var (+1) convention are mapped to the bound rows (test10-like problem with bounds)."""
+    case = [c for c in CASES["cases"] if c["name"] == "test11"][0]
+    P = sdpi_prepare.prepare(build(case))
+    s = new_solver(gpu)
+    rc, _, _ = s.solve(P)
+    assert rc == sdpi_call.SCIP_OKAY and s.flag("IsOptimal")
+    cold_it = s.iterations()
+    y0 = 5.05
+    Z0 = np.array([[y0 - 1.0, -2.0], [-2.0, y0 - 4.0]])
+    X0 = np.array([[0.2, 0.4], [0.4, 0.8]]) + 0.01 * np.eye(2)
+    assert np.linalg.eigvalsh(Z0)[0] > 0
+    low = [(0, 0), (1, 0), (1, 1)]
+    start = dict(y=[y0],
+                 Z=[([r for r, c in low], [c for r, c in low], [Z0[r, c] for r, c in low]), ([], [], [])],
+                 X=[([r for r, c in low], [c for r, c in low], [X0[r, c] for r, c in low]), ([], [], [])])
+    rc, _, _ = s.solve(P, start=start)
+    assert rc == sdpi_call.SCIP_OKAY and s.flag("IsOptimal")
+    rc, obj, y = s.dual_sol()
+    assert abs(y[0] - 5.0) <= 1e-5
+    assert s.iterations() < cold_it
+    # a start that is not interior (singular X) is ignored: same iteration count as the cold start
+    startbad = dict(start)
+    Xs = np.array([[0.2, 0.4], [0.4, 0.8]])
+    startbad["X"] = [([r for r, c in low], [c for r, c in low], [Xs[r, c] for r, c in low]), ([], [], [])]
+    rc, _, _ = s.solve(P, start=startbad)
+    assert s.flag("IsOptimal") and s.iterations() == cold_it
+    s.free()

@@ -160,3 +160,20 @@ def test_schur_block_matches_einsum():
     G = rng.standard_normal((n, n)); Zi = np.linalg.inv(G @ G.T + np.eye(n))
     ref = np.einsum('iab,bc,jcd,da->ij', A, X, A, Zi)
     assert np.allclose(ipm_ref.schur_block(A, X, Zi), 0.5 * (ref + ref.T), rtol=1e-12, atol=1e-12)
+
+
+def test_oracle_warm_start_rule():
+    """warm_start_point accepts strictly interior points only; a warm start near the optimum needs fewer iterations"""
+    import instances
+    b, A, ys, Xs, Zs = instances.planted_dense(12, 18)
+    core = ipm_ref.CoreProblem(b, [A])
+    cold = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-6, feastol=1e-6))
+    assert ipm_ref.warm_start_point(core, ys, [Xs], [Zs], np.zeros(0), np.zeros(0)) is None      # singular pair
+    d = 1e-2
+    st = ipm_ref.warm_start_point(core, cold.y, [(1 - d) * cold.X[0] + d * np.eye(12)], [(1 - d) * cold.Z[0] + d * np.eye(12)],
+                                  np.zeros(0), np.zeros(0))
+    assert st is not None and st[5] == 1.0 and st[6] > 0
+    warm = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-6, feastol=1e-6), start=st)
+    assert warm.status == cold.status == ipm_ref.STATUS_OPTIMAL
+    assert warm.iterations < cold.iterations
+    assert abs(warm.dobj - cold.dobj) <= 1e-6 * (1 + abs(cold.dobj))
