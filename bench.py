@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X FP64 matrix peak (vendor figure; rocBLAS dgemm reaches 72.8 on this pool)
 # HBM bytes per Schur assembly from the PMC passes committed under profiles/ (FETCH_SIZE doubled as MI355X_MICROARCH.md
 # prescribes for gfx950, plus WRITE_SIZE), keyed by (n, m); None when not measured for a size
-TRAFFIC_BYTES_PER_ASSEMBLY = {(500, 1000): 20.49e9}      # profiles/r01_c_pmc_traffic_c2.txt
+TRAFFIC_BYTES_PER_ASSEMBLY = {(500, 1000): 18.70e9}      # profiles/r01_d_pmc_traffic_c2.txt
 
 
 def load_binding():
@@ -186,7 +186,7 @@ def main():
                            "planted_optimum": opt, "pinf": last.pinf, "dabs": last.dabs, "gap": last.gap},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS * world, "unit": "TFLOP/s",
                      "frac": achieved / (FP64_MFMA_PEAK_TFLOPS * world), "traffic": TRAFFIC_BYTES_PER_ASSEMBLY.get((n, m)),
-                     "kernel": "hs_dgemm_kernel (Schur assembly: stack GEMM, batched GEMM, split-K GEMM + slice reduce)",
+                     "kernel": "hs_dgemm2_kernel (Schur assembly: stack GEMM, batched GEMM, K-sliced Gram GEMM + slice reduce)",
                      "algorithmic_flops_per_assembly": schur_fl / max(1, schur_calls),
                      "avg_assembly_ms": 1e3 * schur_s / max(1, schur_calls),
                      "assemblies": schur_calls,
