@@ -31,7 +31,9 @@ typedef const __attribute__((address_space(1))) void* hs_gbl_ptr;
 
 #define G2_BT   128
 #define G2_BKS  8
+#ifndef G2_NS
 #define G2_NS   4
+#endif
 #define G2_OPSZ (G2_BT * G2_BKS)            /* doubles per operand per stage */
 #define G2_SLOT (2 * G2_OPSZ)
 #define G2_GPS  4                           /* LDS-DMA instructions per wave per stage: 2 per operand */
@@ -257,7 +259,8 @@ __global__ void __launch_bounds__(256, 2) hs_dgemm2_kernel(hs_gemm_args p, int k
       if ( gc >= landed )
       {
          const int newer = gp - 1 - gc;
-         if ( newer >= 2 ) g2_wait_vm<2 * G2_GPS>();
+         if ( G2_NS >= 5 && newer >= 3 ) g2_wait_vm<3 * G2_GPS>();
+         else if ( newer >= 2 ) g2_wait_vm<2 * G2_GPS>();
          else if ( newer == 1 ) g2_wait_vm<G2_GPS>();
          else g2_wait_vm<0>();
       }

@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""stress_gpu.py [count] [seed0] - developer tool: random engine problems (dense/sparse blocks across the 64 and 128 size
+boundaries, LP rows, feasible / infeasible / unbounded mixes) on the HIP engine against the oracle: status, objective,
+certificates."""
+import os, sys, time, importlib.util
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+spec = importlib.util.spec_from_file_location("hipsdp_binding", os.path.join(ROOT, "scip-sdp_amd", "binding.py"))
+hb = importlib.util.module_from_spec(spec); spec.loader.exec_module(hb)
+import numpy as np, ipm_ref, checker
+
+def rand_core(rng):
+    kind = rng.integers(0, 5)
+    K = int(rng.integers(1, 4))
+    ns = [int(rng.choice([2, 3, 5, 9, 17, 33, 63, 64, 65, 70, 100])) for _ in range(K)]
+    if sum(n * n for n in ns) > 12000:
+        ns = ns[:1]
+    m = int(rng.choice([1, 2, 5, 13, 40, 64, 65, 129, 140, 200]))
+    if m * sum(n * n for n in ns) > 2.5e6:
+        m = max(1, int(2.5e6 / sum(n * n for n in ns)))
+    q = int(rng.choice([0, 0, 3, 17, 64, 150]))
+    blocks = []
+    for n in ns:
+        A = np.zeros((m + 1, n, n))
+        dens = rng.choice([1.0, 0.3, 0.05])
+        for i in range(1, m + 1):
+            G = rng.standard_normal((n, n)) * (rng.random((n, n)) < dens)
+            A[i] = (G + G.T) / np.sqrt(2 * n)
+        blocks.append(A)
+    D = rng.standard_normal((q, m)) * (rng.random((q, m)) < 0.3) if q else np.zeros((0, m))
+    # kinds: 0/1 planted optimum, 2 strictly feasible both (A0 = -dI, random b with bounded set via box rows), 3 y-infeasible, 4 random
+    y0 = rng.uniform(-1, 1, m)
+    if kind in (0, 1):
+        b = np.zeros(m)
+        for A in blocks:
+            n = A.shape[1]
+            Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+            r = max(1, n // 3)
+            ev = rng.uniform(1, 2, n)
+            Xs = (Q * np.where(np.arange(n) < r, ev, 0)) @ Q.T
+            Zs = (Q * np.where(np.arange(n) < r, 0, ev)) @ Q.T
+            A[0] = np.tensordot(y0, A[1:], axes=(0, 0)) - Zs
+            b += A[1:].reshape(m, -1) @ Xs.reshape(-1)
+        c = np.zeros(q)
+        if q:
+            xs = rng.uniform(0, 1, q) * (rng.random(q) < 0.5)
+            zs = rng.uniform(0.5, 1.5, q) * (xs == 0)
+            c = D @ y0 - zs
+            b += D.T @ xs
+    elif kind == 2:
+        for A in blocks:
+            A[0] = -rng.uniform(1, 3) * np.eye(A.shape[1])
+        c = D @ y0 - rng.uniform(0.5, 2, q) if q else np.zeros(0)
+        b = rng.standard_normal(m)
+    elif kind == 3:
+        # infeasible y-problem: block 0 demands sum A y - A0 psd with A0 = +dI and A_i negative semidefinite
+        for k, A in enumerate(blocks):
+            n = A.shape[1]
+            if k == 0:
+                for i in range(1, m + 1):
+                    v = rng.standard_normal(n)
+                    A[i] = -np.outer(v, v) / n
+                A[0] = np.eye(n)
+            else:
+                A[0] = -np.eye(n)
+        # y >= 0 rows make it truly infeasible
+        D = np.concatenate([D, np.eye(m)], axis=0)
+        c = np.concatenate([(D[:q] @ y0 - 1.0) if q else np.zeros(0), np.zeros(m)])
+        b = rng.standard_normal(m)
+    else:
+        for A in blocks:
+            G = rng.standard_normal(A.shape[1:]); A[0] = (G + G.T) / 2 - 2 * np.eye(A.shape[1])
+        c = rng.standard_normal(D.shape[0])
+        b = rng.standard_normal(m)
+    return ipm_ref.CoreProblem(b, blocks, D, c), kind
+
+def main():
+    count = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    bad = 0
+    t0 = time.time()
+    for t in range(count):
+        rng = np.random.default_rng(seed0 + t)
+        core, kind = rand_core(rng)
+        ref = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-6, feastol=1e-6, pabstol=1e-5))
+        s = hb.Solver(0); s.load_core(core)
+        info = s.solve(gaptol=1e-6, feastol=1e-6, pabstol=1e-5)
+        y = s.y(); X = [s.X(k) for k in range(len(core.blocks))]; lp = s.lp(); s.close()
+        msg = []
+        if info.status != ref.status:
+            msg.append("status gpu %d oracle %d" % (info.status, ref.status))
+        elif ref.status == ipm_ref.STATUS_OPTIMAL:
+            if abs(info.dobj - ref.dobj) > 1e-5 * (1 + abs(ref.dobj)):
+                msg.append("dobj gpu %.9g oracle %.9g" % (info.dobj, ref.dobj))
+            ok, det = checker.certificate(core, y, X, lp[0], 1e-5, 1e-5)
+            if not ok:
+                msg.append("certificate fails: %s" % det)
+        elif ref.status in (ipm_ref.STATUS_DINF, ipm_ref.STATUS_PDINF):
+            if not checker.farkas_dual_infeasible(core, X, lp[0], 1e-6)[0]:
+                msg.append("X-ray fails")
+        if abs(info.iterations - ref.iterations) > 2:
+            msg.append("iterations gpu %d oracle %d" % (info.iterations, ref.iterations))
+        tag = "ns %s m %d q %d kind %d status %d it %d" % ([A.shape[1] for A in core.blocks], core.m, core.q, kind, info.status, info.iterations)
+        if msg:
+            bad += 1
+            print("seed %d: %s :: %s" % (seed0 + t, tag, "; ".join(msg)), flush=True)
+    print("%d problems, %d with differences, %.1f s" % (count, bad, time.time() - t0))
+    return 1 if bad else 0
+
+if __name__ == "__main__":
+    sys.exit(main())
