@@ -23,3 +23,26 @@ def test_example_small_optimum():
 def test_example_inf_is_infeasible():
     best, y, nodes, failed = run("example_inf.dat-s")
     assert best is None and failed == 0
+
+
+# dual-form CBF examples of the reference (instances/*.cbf; optima: check/testset/short.solu:2,10,11,16)
+CBF_SOLU = {"example_small_cbf.cbf": -8.0, "example_cbf_dual.cbf": 4.0, "example_multaggr.cbf": -1.0,
+            "example_diagzeroimpl.cbf": -1.0}
+
+
+@pytest.mark.parametrize("name", sorted(CBF_SOLU))
+def test_cbf_examples_reach_short_solu_optima(name):
+    import cbf_io
+    prob, ints, sense, c0 = cbf_io.read_cbf(os.path.join(GOLDEN, "instances", name))
+    best, y, nodes, failed = bnb.branch_and_bound(prob, ints, bnb.oracle_node_solver(), maxnodes=500)
+    assert failed == 0 and best is not None
+    assert sense * best + c0 == pytest.approx(CBF_SOLU[name], abs=1e-5)
+    assert all(abs(y[v] - round(y[v])) <= 1e-9 for v in ints)
+
+
+def test_cbf_reader_rejects_primal_form_sections(tmp_path):
+    import cbf_io
+    f = tmp_path / "p.cbf"
+    f.write_text("VER\n1\n\nPSDVAR\n1\n2\n")
+    with pytest.raises(NotImplementedError):
+        cbf_io.read_cbf(str(f))

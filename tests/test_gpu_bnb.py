@@ -61,3 +61,22 @@ def test_bnb_reproduces_short_solu(gpu, name):
     # a few nodes of example_small have a relaxation whose optimum (-8, equal to the incumbent) is not attained: tau -> 0 with
     # linear convergence and the primal residual at rounding level; they are reported as unsolved and simply branched on
     assert failed <= max(4, nodes // 10)
+
+
+# dual-form CBF examples (oracle/cbf_io.py): check/testset/short.solu:2,10,11,16
+CBF_SOLU = {"example_small_cbf.cbf": -8.0, "example_cbf_dual.cbf": 4.0, "example_multaggr.cbf": -1.0,
+            "example_diagzeroimpl.cbf": -1.0}
+
+
+@pytest.mark.parametrize("name", sorted(CBF_SOLU))
+def test_bnb_reproduces_short_solu_cbf(gpu, name):
+    import cbf_io
+    prob, ints, sense, c0 = cbf_io.read_cbf(os.path.join(GOLDEN, "instances", name))
+    s, solve, stats = hip_node_solver(gpu, 1e-6)
+    best, y, nodes, failed = bnb.branch_and_bound(prob, ints, solve, maxnodes=500)
+    s.free()
+    print("%s: optimum %s, %d nodes, %d IPM iterations, %d unresolved nodes" % (name, best, nodes, stats["iters"], failed))
+    assert best is not None
+    assert abs(sense * best + c0 - CBF_SOLU[name]) <= 1e-4
+    assert all(abs(y[v] - round(y[v])) <= 1e-9 for v in ints)
+    assert failed <= max(4, nodes // 10)
