@@ -46,17 +46,18 @@ struct __attribute__((aligned(16))) dpair { double x, y; };
 typedef double v4dc __attribute__((ext_vector_type(4)));
 
 #define PD_LD (NB + 2)
-#define PD_SMEM_BYTES ((2 * 4 * 18 + 2 * NB * PD_LD + 2 * NB) * (int) sizeof(double))
+#define PD_COLP (2 * 2 * 4 * 18)
+#define PD_SMEM_BYTES ((PD_COLP + 2 * NB * PD_LD + 2 * NB) * (int) sizeof(double))
 
 template<int NBK>      /* padded block size actually processed: 16, 32 or 64 (tiny blocks skip the identity padding) */
 __global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ A, long long lda, int nb, int j0,
    double* __restrict__ dinv, int* __restrict__ flag, const double* __restrict__ diag0, double regtol)
 {
    extern __shared__ __attribute__((aligned(16))) double pd_smem[];
-   double (*colp)[4][18] = reinterpret_cast<double (*)[4][18]>(pd_smem);                  /* column k, permuted: row i at [i & 3][i >> 2] */
-   double (*lmT)[PD_LD] = reinterpret_cast<double (*)[PD_LD]>(pd_smem + 2 * 4 * 18);      /* lmT[k][i] = L[i][k] (final) */
-   double (*X)[PD_LD] = reinterpret_cast<double (*)[PD_LD]>(pd_smem + 2 * 4 * 18 + NB * PD_LD);   /* inv(L), row major */
-   double* invd = pd_smem + 2 * 4 * 18 + 2 * NB * PD_LD;
+   double (*colp)[2][4][18] = reinterpret_cast<double (*)[2][4][18]>(pd_smem);            /* columns k, k + 1, permuted: row i at [i & 3][i >> 2]; two buffers */
+   double (*lmT)[PD_LD] = reinterpret_cast<double (*)[PD_LD]>(pd_smem + PD_COLP);          /* lmT[k][i] = L[i][k] (final) */
+   double (*X)[PD_LD] = reinterpret_cast<double (*)[PD_LD]>(pd_smem + PD_COLP + NB * PD_LD);   /* inv(L), row major */
+   double* invd = pd_smem + PD_COLP + 2 * NB * PD_LD;
    double* d0s = invd + NB;
    const int tid = threadIdx.x;
    const int lane = tid & 63;
@@ -78,61 +79,105 @@ __global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ A, long
       d0s[tid] = diag0[j0 + tid];
    int bad = 0;
 
+   /* two columns per barrier: columns k and k + 1 are published together; every thread eliminates column k from
+    * column k + 1 itself (2 x 2 pivot block), then applies the rank-2 update r_ij -= l_ik l_jk + l_i,k+1 l_j,k+1 as two
+    * fused multiply-adds per entry:  with  t0 = l_ik / l_kk,  u = l_i,k+1 / l_k+1,k+1,  l_j,k+1 l_k+1,k+1 = a_j,k+1 - l_jk l_k+1,k:
+    *   r_ij -= (t0 - u l_k+1,k / l_kk) a_jk + u a_j,k+1 */
 #pragma unroll
-   for (int k = 0; k < NBK; ++k)
+   for (int k = 0; k < NBK; k += 2)
    {
-      /* owners of column k publish it (rows >= k) */
+      const int buf = (k >> 1) & 1;
+      /* owners publish columns k and k + 1 (rows >= k) */
       if ( jc == (k & 3) && i >= k )
-         colp[k & 1][ir][iq] = r[k >> 2];
+         colp[buf][0][ir][iq] = r[k >> 2];
+      if ( jc == ((k + 1) & 3) && i >= k )
+         colp[buf][1][ir][iq] = r[(k + 1) >> 2];
       __syncthreads();
-      /* everything a step needs from LDS is requested up front (no branches between the reads): the pivot, my row's entry
-       * and the 16 entries of my columns; entries above the diagonal are updated too (they are never read) */
-      double d = colp[k & 1][k & 3][k >> 2];
-      const double ci = colp[k & 1][ir][iq];
-      dpair cj[8];
+      /* everything a step needs from LDS is requested up front (no branches between the reads) */
+      double d0 = colp[buf][0][k & 3][k >> 2];
+      const double a10 = colp[buf][0][(k + 1) & 3][(k + 1) >> 2];
+      double d1 = colp[buf][1][(k + 1) & 3][(k + 1) >> 2];
+      const double ci0 = colp[buf][0][ir][iq];
+      const double ci1 = colp[buf][1][ir][iq];
+      dpair ca[8], cb[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q)
-         cj[q] = *reinterpret_cast<const dpair*>(&colp[k & 1][jc][2 * q]);
+      {
+         ca[q] = *reinterpret_cast<const dpair*>(&colp[buf][0][jc][2 * q]);
+         cb[q] = *reinterpret_cast<const dpair*>(&colp[buf][1][jc][2 * q]);
+      }
       if ( k < nb )
       {
          if ( diag0 != NULL )
          {
             /* semidefinite mode (Schur complement with dependent columns): a pivot that cancelled to rounding level is
              * replaced by a small positive one, which keeps the direction alive so that a ray along it can be found */
-            const double d0 = d0s[k];
-            if ( !(d > regtol * d0) || !(d > 1e-300) )
-               d = (d0 > 1e-280) ? regtol * d0 : 1.0;
+            const double dd = d0s[k];
+            if ( !(d0 > regtol * dd) || !(d0 > 1e-300) )
+               d0 = (dd > 1e-280) ? regtol * dd : 1.0;
          }
-         else if ( !(d > 0.0) )
+         else if ( !(d0 > 0.0) )
          {
             if ( bad == 0 )
                bad = j0 + k + 1;
-            d = 1.0;                 /* keep going with a harmless pivot; the caller reads the flag */
+            d0 = 1.0;                 /* keep going with a harmless pivot; the caller reads the flag */
          }
       }
-      double sd, isd;
-      sqrt_and_rsqrt(d, &sd, &isd);
-      const double lik = (i > k) ? ci * isd : 0.0;
-      const double t = lik * isd;
+      double sd0, isd0;
+      sqrt_and_rsqrt(d0, &sd0, &isd0);
+      const double l10 = a10 * isd0;
+      d1 = fma(-l10, l10, d1);
+      if ( k + 1 < nb )
+      {
+         if ( diag0 != NULL )
+         {
+            const double dd = d0s[k + 1];
+            if ( !(d1 > regtol * dd) || !(d1 > 1e-300) )
+               d1 = (dd > 1e-280) ? regtol * dd : 1.0;
+         }
+         else if ( !(d1 > 0.0) )
+         {
+            if ( bad == 0 )
+               bad = j0 + k + 2;
+            d1 = 1.0;
+         }
+      }
+      double sd1, isd1;
+      sqrt_and_rsqrt(d1, &sd1, &isd1);
+      const double li0 = (i > k) ? ci0 * isd0 : 0.0;
+      const double li1 = (i > k + 1) ? fma(-li0, l10, ci1) * isd1 : 0.0;
+      const double u = li1 * isd1;
+      const double al = fma(-u * l10, isd0, li0 * isd0);
       if ( jc == (k & 3) )
       {
          /* final value of column k in my row */
-         const double lv = (i > k) ? lik : ((i == k) ? sd : 0.0);
+         const double lv = (i > k) ? li0 : ((i == k) ? sd0 : 0.0);
          r[k >> 2] = lv;
          lmT[k][i] = lv;
          if ( i == k )
-            invd[k] = isd;
+            invd[k] = isd0;
       }
-      else if ( jc > (k & 3) )
+      else if ( jc == ((k + 1) & 3) )
       {
-         const double cv = ((k >> 2) & 1) ? cj[k >> 3].y : cj[k >> 3].x;
-         r[k >> 2] = fma(-t, cv, r[k >> 2]);
+         const double lv = (i > k + 1) ? li1 : ((i == k + 1) ? sd1 : 0.0);
+         r[(k + 1) >> 2] = lv;
+         lmT[k + 1][i] = lv;
+         if ( i == k + 1 )
+            invd[k + 1] = isd1;
+      }
+      else if ( jc > ((k + 1) & 3) )
+      {
+         /* the columns k + 2, k + 3 of this group of four (k and k + 1 share a group: k is even) */
+         const double va = ((k >> 2) & 1) ? ca[k >> 3].y : ca[k >> 3].x;
+         const double vb = ((k >> 2) & 1) ? cb[k >> 3].y : cb[k >> 3].x;
+         r[k >> 2] = fma(-u, vb, fma(-al, va, r[k >> 2]));
       }
 #pragma unroll
       for (int jj = (k >> 2) + 1; jj < 16; ++jj)
       {
-         const double cv = (jj & 1) ? cj[jj >> 1].y : cj[jj >> 1].x;
-         r[jj] = fma(-t, cv, r[jj]);
+         const double va = (jj & 1) ? ca[jj >> 1].y : ca[jj >> 1].x;
+         const double vb = (jj & 1) ? cb[jj >> 1].y : cb[jj >> 1].x;
+         r[jj] = fma(-u, vb, fma(-al, va, r[jj]));
       }
    }
    __syncthreads();
