@@ -1,6 +1,6 @@
 """developer smoke script: unit kernels vs numpy, solves vs the oracle (run on the GPU box)"""
 import sys, os, time, importlib.util
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 spec = importlib.util.spec_from_file_location('hipsdp_binding', os.path.join(ROOT, 'scip-sdp_amd', 'binding.py'))
 hb = importlib.util.module_from_spec(spec); spec.loader.exec_module(hb)

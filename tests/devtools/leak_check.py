@@ -2,7 +2,7 @@
 """leak_check.py - developer tool: device memory must return to its starting level after many create / shape / solve / free
 cycles (engine and solver-interface level)"""
 import os, sys, importlib.util, ctypes as C
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 spec = importlib.util.spec_from_file_location("hipsdp_binding", os.path.join(ROOT, "scip-sdp_amd", "binding.py"))
 hb = importlib.util.module_from_spec(spec); spec.loader.exec_module(hb)

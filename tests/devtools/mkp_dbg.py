@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """mkp_dbg.py [instance] - developer tool: solve a golden instance on the GPU engine and print the full certificate check"""
 import os, sys, json, types
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import importlib.util
 spec = importlib.util.spec_from_file_location("hipsdp_binding", os.path.join(ROOT, "scip-sdp_amd", "binding.py"))
