@@ -49,9 +49,22 @@ typedef double v4dc __attribute__((ext_vector_type(4)));
 #define PD_COLP (2 * 2 * 4 * 18)
 #define PD_SMEM_BYTES ((PD_COLP + 2 * NB * PD_LD + 2 * NB) * (int) sizeof(double))
 
+/* optional fused inputs / outputs of a single-block factorization (n <= 64; everything NULL for the blocked driver):
+ * the matrix is base + alpha * dir (full symmetric storage, ld = lda) and is also stored to Mout; L gets a zero upper
+ * triangle; Linv receives inv(L) as n x n (ld = nb); Gram receives inv(L)^T inv(L) = inverse of the matrix (n <= 32) */
+struct pd_ext
+{
+   const double* base;
+   const double* dir;
+   double        alpha;
+   double*       Mout;
+   double*       Linv;
+   double*       Gram;
+};
+
 template<int NBK>      /* padded block size actually processed: 16, 32 or 64 (tiny blocks skip the identity padding) */
 __global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ A, long long lda, int nb, int j0,
-   double* __restrict__ dinv, int* __restrict__ flag, const double* __restrict__ diag0, double regtol)
+   double* __restrict__ dinv, int* __restrict__ flag, const double* __restrict__ diag0, double regtol, pd_ext ext)
 {
    extern __shared__ __attribute__((aligned(16))) double pd_smem[];
    double (*colp)[2][4][18] = reinterpret_cast<double (*)[2][4][18]>(pd_smem);            /* columns k, k + 1, permuted: row i at [i & 3][i >> 2]; two buffers */
@@ -72,7 +85,21 @@ __global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ A, long
       const int j = jc + 4 * jj;
       double v = (i == j) ? 1.0 : 0.0;
       if ( i < nb && j <= i )
-         v = A[(long long) i * lda + j];
+      {
+         if ( ext.base != NULL )
+         {
+            v = ext.base[(long long) i * lda + j];
+            if ( ext.dir != NULL )
+               v = fma(ext.alpha, ext.dir[(long long) i * lda + j], v);
+            if ( ext.Mout != NULL )
+            {
+               ext.Mout[(long long) i * lda + j] = v;
+               ext.Mout[(long long) j * lda + i] = v;
+            }
+         }
+         else
+            v = A[(long long) i * lda + j];
+      }
       r[jj] = v;
    }
    if ( diag0 != NULL && tid < nb )
@@ -189,6 +216,8 @@ __global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ A, long
       const int j = jc + 4 * jj;
       if ( i < nb && j <= i )
          A[(long long) i * lda + j] = r[jj];
+      else if ( ext.base != NULL && i < nb && j < nb )
+         A[(long long) i * lda + j] = 0.0;
    }
    if ( tid == 0 && bad != 0 )
       atomicCAS(flag, 0, bad);
@@ -261,12 +290,30 @@ __global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ A, long
       else
          v = ((rr >> 4) >= (cc >> 4)) ? X[rr][cc] : 0.0;
       dinv[e] = v;
+      if ( ext.Linv != NULL && rr < nb && cc < nb )
+         ext.Linv[rr * nb + cc] = v;
+   }
+   if ( ext.Gram != NULL && NBK <= 32 )
+   {
+      /* inverse of the matrix: Gram[r][c] = sum_{k >= max(r, c)} X[k][r] X[k][c] */
+      for (int e = tid; e < nb * nb; e += 256)
+      {
+         const int rr = e / nb, cc = e - rr * nb;
+         double acc = 0.0;
+         for (int k = (rr > cc ? rr : cc); k < nb; ++k)
+            acc += X[k][rr] * X[k][cc];
+         ext.Gram[e] = acc;
+      }
    }
 }
 
 template<int NBK>
-static int launch_potrf_diag(hipStream_t s, double* Ajj, long long lda, int nb, int j0, double* dj, int* flag, const double* diag0)
+static int launch_potrf_diag(hipStream_t s, double* Ajj, long long lda, int nb, int j0, double* dj, int* flag, const double* diag0,
+   const pd_ext* extp = NULL)
 {
+   pd_ext ext = {NULL, NULL, 0.0, NULL, NULL, NULL};
+   if ( extp != NULL )
+      ext = *extp;
    static bool attr_set = false;
    if ( !attr_set )
    {
@@ -274,9 +321,26 @@ static int launch_potrf_diag(hipStream_t s, double* Ajj, long long lda, int nb, 
             PD_SMEM_BYTES) );
       attr_set = true;
    }
-   hipLaunchKernelGGL((k_potrf_diag<NBK>), dim3(1), dim3(256), PD_SMEM_BYTES, s, Ajj, lda, nb, j0, dj, flag, diag0, 1e-13);
+   hipLaunchKernelGGL((k_potrf_diag<NBK>), dim3(1), dim3(256), PD_SMEM_BYTES, s, Ajj, lda, nb, j0, dj, flag, diag0, 1e-13, ext);
    HS_LAUNCH_CHECK();
    return HS_OK;
+}
+
+/* single-block factorization (n <= 64) of base + alpha * dir with the fused outputs described at pd_ext: one launch for what
+ * the general path does with scale_add, copy, potrf, zero_upper, trtri (+ gemm, mirror for the inverse) */
+int hs_potrf_small_ext(hipStream_t s, int n, double* L, double* dinv, int* flag, const double* base, const double* dir, double alpha,
+   double* Mout, double* Linv, double* Gram)
+{
+   if ( n <= 0 )
+      return HS_OK;
+   if ( n > NB || base == NULL || (Gram != NULL && n > 32) )
+      return HS_ERR_ARG;
+   pd_ext ext = {base, dir, alpha, Mout, Linv, Gram};
+   if ( n <= 16 )
+      return launch_potrf_diag<16>(s, L, n, n, 0, dinv, flag, NULL, &ext);
+   if ( n <= 32 )
+      return launch_potrf_diag<32>(s, L, n, n, 0, dinv, flag, NULL, &ext);
+   return launch_potrf_diag<64>(s, L, n, n, 0, dinv, flag, NULL, &ext);
 }
 
 int hs_potrf(hipStream_t s, int n, double* A, double* dinv, int* flag, const double* diag0)

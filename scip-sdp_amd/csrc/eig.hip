@@ -16,7 +16,7 @@
 #define HS_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if ( e_ != hipSuccess ) { hs_record_hip_error(e_, "kernel launch", __FILE__, __LINE__); return HS_ERR_HIP; } } while (0)
 
 __global__ void k_lmin_tiny(int n, const double* __restrict__ A0, const double* __restrict__ A1, double* __restrict__ res0,
-   double* __restrict__ res1);
+   double* __restrict__ res1, const double* __restrict__ L0, const double* __restrict__ L1);
 
 /* ---------------------------------------------------------------------------------------------------------------- */
 /* Lanczos                                                                                                            */
@@ -466,7 +466,7 @@ int hs_lanczos_lmin2(hipStream_t s, int n, const double* W0, const double* W1, i
    if ( n <= 16 )
    {
       /* tiny blocks are launch bound: one wavefront per matrix diagonalises it exactly in ONE launch */
-      hipLaunchKernelGGL(k_lmin_tiny, dim3(nb), dim3(64), 0, s, n, W0, W1, res0, res1);
+      hipLaunchKernelGGL(k_lmin_tiny, dim3(nb), dim3(64), 0, s, n, W0, W1, res0, res1, (const double*) NULL, (const double*) NULL);
       HS_LAUNCH_CHECK();
       return HS_OK;
    }
@@ -499,6 +499,17 @@ int hs_lanczos_lmin2(hipStream_t s, int n, const double* W0, const double* W1, i
       hipLaunchKernelGGL(k_lanczos_fused, dim3(G, nb), dim3(1024), (size_t) n * sizeof(double), s, n, j, k, jobs);
       HS_LAUNCH_CHECK();
    }
+   return HS_OK;
+}
+
+/* n <= 16: lambda_min(L0 D0 L0^T) and lambda_min(L1 D1 L1^T) in ONE launch (products and eigenvalues) */
+int hs_lmin_scaled_tiny(hipStream_t s, int n, const double* L0, const double* D0, const double* L1, const double* D1, double* res0,
+   double* res1)
+{
+   if ( n <= 0 || n > 16 )
+      return HS_ERR_ARG;
+   hipLaunchKernelGGL(k_lmin_tiny, dim3(2), dim3(64), 0, s, n, D0, D1, res0, res1, L0, L1);
+   HS_LAUNCH_CHECK();
    return HS_OK;
 }
 
@@ -804,9 +815,10 @@ __device__ __forceinline__ double rsqrt_nr(double x)
  * built once; the rotation comes from two reciprocal square roots (no division, no sqrt expansion):
  * with d = a_qq - a_pp, b = 2 a_pq, r = hypot(d, b):  cos^2 = (1 + |d| / r) / 2,  sin = sgn(d) b / (2 r cos). */
 __global__ void __launch_bounds__(64) k_lmin_tiny(int n, const double* __restrict__ A0, const double* __restrict__ A1,
-   double* __restrict__ res0, double* __restrict__ res1)
+   double* __restrict__ res0, double* __restrict__ res1, const double* __restrict__ L0, const double* __restrict__ L1)
 {
    const double* __restrict__ Ain = blockIdx.x ? A1 : A0;
+   const double* __restrict__ Lin = blockIdx.x ? L1 : L0;      /* non-NULL: the matrix is L A L^T (the scaled step) */
    double* __restrict__ res = blockIdx.x ? res1 : res0;
    __shared__ double a[16][17];
    __shared__ double rc[8], rs[8];
@@ -814,13 +826,60 @@ __global__ void __launch_bounds__(64) k_lmin_tiny(int n, const double* __restric
    const int tid = threadIdx.x;
    const int np = (n + 1) & ~1;
    const int half = np / 2;
-   for (int e = tid; e < 256; e += 64)
+   if ( Lin == NULL )
    {
-      const int r = e >> 4, c = e & 15;
-      double v = 0.0;
-      if ( r < n && c < n )
-         v = 0.5 * (Ain[r * n + c] + Ain[c * n + r]);
-      a[r][c] = v;
+      for (int e = tid; e < 256; e += 64)
+      {
+         const int r = e >> 4, c = e & 15;
+         double v = 0.0;
+         if ( r < n && c < n )
+            v = 0.5 * (Ain[r * n + c] + Ain[c * n + r]);
+         a[r][c] = v;
+      }
+   }
+   else
+   {
+      /* W = L A L^T formed here (two 16 x 16 x 16 products) instead of by two GEMM launches */
+      __shared__ double sl[16][17], st[16][17];
+      for (int e = tid; e < 256; e += 64)
+      {
+         const int r = e >> 4, c = e & 15;
+         const bool in = r < n && c < n;
+         sl[r][c] = in ? Lin[r * n + c] : 0.0;
+         a[r][c] = in ? Ain[r * n + c] : 0.0;
+      }
+      __syncthreads();
+      for (int e = tid; e < 256; e += 64)
+      {
+         const int r = e >> 4, c = e & 15;
+         double acc = 0.0;
+         for (int k = 0; k < 16; ++k)
+            acc += sl[r][k] * a[k][c];
+         st[r][c] = acc;
+      }
+      __syncthreads();
+      double w[4];
+      for (int q = 0; q < 4; ++q)
+      {
+         const int e = tid + 64 * q;
+         const int r = e >> 4, c = e & 15;
+         double acc = 0.0;
+         for (int k = 0; k < 16; ++k)
+            acc += st[r][k] * sl[c][k];
+         w[q] = acc;
+      }
+      __syncthreads();
+      for (int q = 0; q < 4; ++q)
+      {
+         const int e = tid + 64 * q;
+         st[e >> 4][e & 15] = w[q];
+      }
+      __syncthreads();
+      for (int e = tid; e < 256; e += 64)
+      {
+         const int r = e >> 4, c = e & 15;
+         a[r][c] = 0.5 * (st[r][c] + st[c][r]);
+      }
    }
    for (int e = tid; e < (np - 1) * half; e += 64)
    {

@@ -30,6 +30,9 @@ int hs_absmax(hipStream_t s, long long n, const double* a, double* out, int accu
 int hs_ratio_min(hipStream_t s, long long n, const double* x, const double* d, double* out, int accumulate, double* ws);
 
 /* H = s1 * Zinv - X - (GZ + GZ^T) / 2,  all n x n */
+/* n <= 32: out = s1 Zinv - X - sym((c X R + E) Zinv) in one launch (E may be NULL) */
+int hs_dir_block_small(hipStream_t s, int n, double c, const double* X, const double* R, const double* E, const double* Zinv,
+   double s1, double* out);
 int hs_dirmat(hipStream_t s, int n, double s1, const double* Zinv, const double* X, const double* GZ, double* H);
 
 /* LP block element-wise pieces (length q) */
@@ -83,6 +86,10 @@ int hs_potrf(hipStream_t s, int n, double* A, double* dinv, int* flag, const dou
 int hs_trtri(hipStream_t s, int n, const double* L, const double* dinv, double* Linv, double* tmp);
 /* solves L y = r (nrhs <= 4 right-hand sides, rhs[k * ldr + i]) then optionally L^T x = y, in place.  mode 1: forward only,
  * 2: backward only, 3: both */
+/* n <= 64: Cholesky of base + alpha * dir in one launch; optionally stores the matrix (Mout), inv(L) as n x n (Linv) and,
+ * for n <= 32, the inverse of the matrix (Gram); L gets a zero upper triangle */
+int hs_potrf_small_ext(hipStream_t s, int n, double* L, double* dinv, int* flag, const double* base, const double* dir, double alpha,
+   double* Mout, double* Linv, double* Gram);
 int hs_trsv(hipStream_t s, int n, const double* L, const double* dinv, int nrhs, double* rhs, long long ldr, int mode);
 /* the same solve with one workgroup per 64-row block (flag hand-off between blocks); sync_ws: hs_trsv_sync_ws(n) ints, zeroed
  * once; *epoch: call counter owned by the caller (start at 0) */
@@ -96,6 +103,8 @@ int hs_trsv_sync(hipStream_t s, int n, const double* L, const double* dinv, int 
  * ws: (maxsteps + 2) * n + 4 * maxsteps + 64 doubles. */
 int hs_lanczos_lmin(hipStream_t s, int n, const double* W, int maxsteps, double* res, double* ws);
 long long hs_lanczos_ws(int n, int maxsteps);
+int hs_lmin_scaled_tiny(hipStream_t s, int n, const double* L0, const double* D0, const double* L1, const double* D1, double* res0,
+   double* res1);
 int hs_lanczos_lmin2(hipStream_t s, int n, const double* W0, const double* W1, int maxsteps, double* res0, double* res1,
    double* ws0, double* ws1);
 

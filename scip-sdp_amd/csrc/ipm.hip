@@ -61,6 +61,7 @@ struct Block
    double *pkv;      /* 2 Lp: packed vector in / out */
    long long Lp;
    bool apk_valid;
+   bool derived_valid;   /* n <= 64: LxInv, LzInv (and Zinv for n <= 32) belong to the current X, Z (written by the fused factorization) */
 };
 
 struct hipsdp_solver
@@ -855,11 +856,16 @@ static int direction(hipsdp_solver* s, double sigma, double eta, double mu, doub
    {
       const int n = B.n;
       const long long n2 = (long long) n * n;
-      if ( useE )
-         HS_CALL( hs_copy(s->stream, B.G, B.E, n2) );
-      HS_CALL( gemm(s, HS_KC, HS_MC, n, n, n, eta, B.X, n, B.Rd, n, useE ? 1.0 : 0.0, B.G, n) );
-      HS_CALL( gemm(s, HS_KC, HS_MC, n, n, n, 1.0, B.G, n, B.Zinv, n, 0.0, B.GZ, n) );
-      HS_CALL( hs_dirmat(s->stream, n, sigmu, B.Zinv, B.X, B.GZ, B.H) );
+      if ( n <= 32 )
+         HS_CALL( hs_dir_block_small(s->stream, n, eta, B.X, B.Rd, useE ? B.E : NULL, B.Zinv, sigmu, B.H) );
+      else
+      {
+         if ( useE )
+            HS_CALL( hs_copy(s->stream, B.G, B.E, n2) );
+         HS_CALL( gemm(s, HS_KC, HS_MC, n, n, n, eta, B.X, n, B.Rd, n, useE ? 1.0 : 0.0, B.G, n) );
+         HS_CALL( gemm(s, HS_KC, HS_MC, n, n, n, 1.0, B.G, n, B.Zinv, n, 0.0, B.GZ, n) );
+         HS_CALL( hs_dirmat(s->stream, n, sigmu, B.Zinv, B.X, B.GZ, B.H) );
+      }
       Hs.push_back(B.H);
    }
    if ( q > 0 )
@@ -887,11 +893,16 @@ static int direction(hipsdp_solver* s, double sigma, double eta, double mu, doub
       const int n = B.n;
       const long long n2 = (long long) n * n;
       HS_CALL( pass_AT(s, B, s->dyt, eta, B.Rd, B.dZ) );
-      if ( useE )
-         HS_CALL( hs_copy(s->stream, B.G, B.E, n2) );
-      HS_CALL( gemm(s, HS_KC, HS_MC, n, n, n, 1.0, B.X, n, B.dZ, n, useE ? 1.0 : 0.0, B.G, n) );
-      HS_CALL( gemm(s, HS_KC, HS_MC, n, n, n, 1.0, B.G, n, B.Zinv, n, 0.0, B.GZ, n) );
-      HS_CALL( hs_dirmat(s->stream, n, sigmu, B.Zinv, B.X, B.GZ, B.dX) );
+      if ( n <= 32 )
+         HS_CALL( hs_dir_block_small(s->stream, n, 1.0, B.X, B.dZ, useE ? B.E : NULL, B.Zinv, sigmu, B.dX) );
+      else
+      {
+         if ( useE )
+            HS_CALL( hs_copy(s->stream, B.G, B.E, n2) );
+         HS_CALL( gemm(s, HS_KC, HS_MC, n, n, n, 1.0, B.X, n, B.dZ, n, useE ? 1.0 : 0.0, B.G, n) );
+         HS_CALL( gemm(s, HS_KC, HS_MC, n, n, n, 1.0, B.G, n, B.Zinv, n, 0.0, B.GZ, n) );
+         HS_CALL( hs_dirmat(s->stream, n, sigmu, B.Zinv, B.X, B.GZ, B.dX) );
+      }
    }
    if ( q > 0 )
    {
@@ -912,6 +923,8 @@ static int steplen_enqueue(hipsdp_solver* s)
    for (auto& B : s->blk)
    {
       const int n = B.n;
+      if ( n <= 16 )
+         continue;                   /* products and eigenvalues of tiny blocks share one launch below */
       HS_CALL( gemm_on(st, s->gws1, s->gws_len, HS_KC, HS_MC, n, n, n, 1.0, B.LxInv, n, B.dX, n, 0.0, B.T1, n) );
       HS_CALL( gemm_on(st, s->gws1, s->gws_len, HS_KC, HS_KC, n, n, n, 1.0, B.T1, n, B.LxInv, n, 0.0, B.W, n) );
       HS_CALL( gemm_on(st2, s->gws2, s->gws_len, HS_KC, HS_MC, n, n, n, 1.0, B.LzInv, n, B.dZ, n, 0.0, B.T2, n) );
@@ -921,8 +934,11 @@ static int steplen_enqueue(hipsdp_solver* s)
    /* the X-side and the Z-side eigenvalue of a block run in the same launches (one launch per Lanczos step) */
    for (auto& B : s->blk)
    {
-      HS_CALL( hs_lanczos_lmin2(st, B.n, B.W, B.W2, s->par.lanczos_steps, s->sc + SC_BLK(k, 1), s->sc + SC_BLK(k, 4), s->lan_ws,
-            s->lan_ws2) );
+      if ( B.n <= 16 )
+         HS_CALL( hs_lmin_scaled_tiny(st, B.n, B.LxInv, B.dX, B.LzInv, B.dZ, s->sc + SC_BLK(k, 1), s->sc + SC_BLK(k, 4)) );
+      else
+         HS_CALL( hs_lanczos_lmin2(st, B.n, B.W, B.W2, s->par.lanczos_steps, s->sc + SC_BLK(k, 1), s->sc + SC_BLK(k, 4), s->lan_ws,
+               s->lan_ws2) );
       ++k;
    }
    HS_CALL( hs_ratio_min(s->stream, s->q, s->x, s->dx, s->sc + SC_RATX, 0, s->red_ws) );
@@ -1004,6 +1020,8 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
 
    /* ---- starting point */
    bool start_factors = false;
+   for (auto& B : s->blk)
+      B.derived_valid = false;
    if ( s->have_start )
    {
       /* a caller-supplied point (warm start, sdpisolver.h:160-173) is used when it is strictly interior: X_k, Z_k positive
@@ -1236,6 +1254,23 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
          const int n = B.n;
          const long long n2 = (long long) n * n;
          hipStream_t st2 = s->use2 ? s->stream2 : s->stream;
+         if ( n <= 64 )
+         {
+            /* single-block factors: one launch per matrix yields L (zero upper), inv(L) as n x n and, for n <= 32, the inverse
+             * of Z; after an accepted step they already exist (the step's Cholesky check produced them) */
+            if ( !(factors_valid && B.derived_valid) )
+            {
+               HS_CALL( hs_potrf_small_ext(st2, n, B.Lz, B.dinvz, s->flags + 0, B.Z, NULL, 0.0, NULL, B.LzInv, n <= 32 ? B.Zinv : NULL) );
+               HS_CALL( hs_potrf_small_ext(st, n, B.Lx, B.dinvx, s->flags + 1, B.X, NULL, 0.0, NULL, B.LxInv, NULL) );
+               B.derived_valid = true;
+            }
+            if ( n > 32 )
+            {
+               HS_CALL( gemm_on(st2, s->gws2, s->gws_len, HS_MC, HS_MC, n, n, n, 1.0, B.LzInv, n, B.LzInv, n, 0.0, B.Zinv, n, HS_GEMM_LOWER) );
+               HS_CALL( hs_mirror_lower(st2, B.Zinv, n, n) );
+            }
+            continue;
+         }
          /* Z chain on the second queue */
          if ( !factors_valid )
          {
@@ -1407,6 +1442,13 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
             const int n = B.n;
             const long long n2 = (long long) n * n;
             hipStream_t st2 = s->use2 ? s->stream2 : s->stream;
+            if ( n <= 64 )
+            {
+               HS_CALL( hs_potrf_small_ext(st, n, B.Lx, B.dinvx, s->flags + 1, B.Xs, B.dX, alpha, B.X, B.LxInv, NULL) );
+               HS_CALL( hs_potrf_small_ext(st2, n, B.Lz, B.dinvz, s->flags + 0, B.Zs, B.dZ, alpha, B.Z, B.LzInv, n <= 32 ? B.Zinv : NULL) );
+               B.derived_valid = true;
+               continue;
+            }
             HS_CALL( hs_scale_add(st, n2, alpha, B.dX, 1.0, B.Xs, B.X) );
             HS_CALL( hs_copy(st, B.Lx, B.X, n2) );
             HS_CALL( hs_potrf(st, n, B.Lx, B.dinvx, s->flags + 1, NULL) );

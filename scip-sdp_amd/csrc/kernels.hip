@@ -301,6 +301,62 @@ int hs_symmetrize(hipStream_t s, double* A, int n)
    return HS_OK;
 }
 
+/* small blocks (n <= 32): the whole chain  out = s1 Zinv - X - sym((c X R + E) Zinv)  in one workgroup, operands in LDS.
+ * Same products as the three-launch path (gemm, gemm, k_dirmat), one launch: the B&B-sized problems are bound by the launch
+ * count. */
+__global__ void __launch_bounds__(256) k_dir_block_small(int n, double c, const double* __restrict__ X, const double* __restrict__ R,
+   const double* __restrict__ E, const double* __restrict__ Zinv, double s1, double* __restrict__ out)
+{
+   __shared__ double sx[32][33], sr[32][33], sz[32][33], sg[32][33];
+   const int tid = threadIdx.x;
+   const int n2 = n * n;
+   for (int e = tid; e < n2; e += 256)
+   {
+      const int r = e / n, cc = e - r * n;
+      sx[r][cc] = X[e];
+      sr[r][cc] = R[e];
+      sz[r][cc] = Zinv[e];
+   }
+   __syncthreads();
+   for (int e = tid; e < n2; e += 256)
+   {
+      const int r = e / n, cc = e - r * n;
+      double acc = 0.0;
+      for (int k = 0; k < n; ++k)
+         acc += sx[r][k] * sr[k][cc];
+      acc *= c;
+      if ( E != NULL )
+         acc += E[e];
+      sg[r][cc] = acc;
+   }
+   __syncthreads();
+   /* GZ into sr (R is no longer needed) */
+   for (int e = tid; e < n2; e += 256)
+   {
+      const int r = e / n, cc = e - r * n;
+      double acc = 0.0;
+      for (int k = 0; k < n; ++k)
+         acc += sg[r][k] * sz[k][cc];
+      sr[r][cc] = acc;
+   }
+   __syncthreads();
+   for (int e = tid; e < n2; e += 256)
+   {
+      const int r = e / n, cc = e - r * n;
+      out[e] = s1 * sz[r][cc] - sx[r][cc] - 0.5 * (sr[r][cc] + sr[cc][r]);
+   }
+}
+
+int hs_dir_block_small(hipStream_t s, int n, double c, const double* X, const double* R, const double* E, const double* Zinv,
+   double s1, double* out)
+{
+   if ( n <= 0 ) return HS_OK;
+   if ( n > 32 ) return HS_ERR_ARG;
+   hipLaunchKernelGGL(k_dir_block_small, dim3(1), dim3(256), 0, s, n, c, X, R, E, Zinv, s1, out);
+   HS_LAUNCH_CHECK();
+   return HS_OK;
+}
+
 int hs_dirmat(hipStream_t s, int n, double s1, const double* Zinv, const double* X, const double* GZ, double* H)
 {
    if ( n <= 0 ) return HS_OK;
