@@ -23,6 +23,12 @@ int hs_gemv_t(hipStream_t s, int R, long long E, const double* A, long long lda,
    const double* add, double* out);
 
 /* out[slot] = sum_e a[e] * b[e]  (deterministic two-stage; partials in ws, >= 512 doubles) ; accumulate: out[slot] += */
+/* deferred scalar reductions (kernels.hip): between begin and end, reductions over short vectors, scalar fills and scalar
+ * copies on that stream are recorded and then executed in order by one launch */
+void hs_red_batch_begin(hipStream_t s);
+int hs_red_batch_end(void);
+int hs_fill_scalar(hipStream_t s, double* p, double v);
+int hs_copy_scalar(hipStream_t s, double* dst, const double* src);
 int hs_dot(hipStream_t s, long long n, const double* a, const double* b, double* out, int accumulate, double* ws);
 /* out[slot] = max(out[slot] if accumulate, max_e |a[e]|) */
 int hs_absmax(hipStream_t s, long long n, const double* a, double* out, int accumulate, double* ws);

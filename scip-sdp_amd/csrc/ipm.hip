@@ -769,6 +769,7 @@ int hs_bcast_ints(void* comm, int* buf, long long count, hipStream_t stream);
 
 static int read_scalars(hipsdp_solver* s, HostScalars& h, int* flags3)
 {
+   HS_CALL( hs_red_batch_end() );      /* recorded reductions must run before the scalars are read */
    h.v.resize(s->nsc);
    if ( s->comm != NULL )
    {
@@ -878,13 +879,15 @@ static int direction(hipsdp_solver* s, double sigma, double eta, double mu, doub
       HS_CALL( hs_trsv_sync(s->stream, m, s->Lm, s->dinvm, 1, s->u1, m, 3, s->trsv_ws, &s->trsv_epoch) );
    }
    /* BH = sum <B_k, H_k> + beta^T hl ; wrp ; bu1 */
-   HS_CALL( hs_fill(s->stream, s->sc + SC_BH, 1, 0.0) );
+   hs_red_batch_begin(s->stream);
+   HS_CALL( hs_fill_scalar(s->stream, s->sc + SC_BH, 0.0) );
    for (auto& B : s->blk)
       HS_CALL( hs_dot(s->stream, (long long) B.n * B.n, B.B, B.H, s->sc + SC_BH, 1, s->red_ws) );
    if ( q > 0 )
       HS_CALL( hs_dot(s->stream, q, s->beta, s->hl, s->sc + SC_BH, 1, s->red_ws) );
    HS_CALL( hs_dot(s->stream, m, s->rhs2, s->rp, s->sc + SC_WRP, 0, s->red_ws) );       /* w = rhs2[0:m] */
    HS_CALL( hs_dot(s->stream, m, s->b, s->u1, s->sc + SC_BU1, 0, s->red_ws) );
+   HS_CALL( hs_red_batch_end() );
    hipLaunchKernelGGL(k_finish_dir, g1d(m > 0 ? m : 1), dim3(256), 0, s->stream, m, eta, rg, sigmu, s->tau, s->kappa, etk,
       s->u1, s->u2, s->dy, s->dyt, s->sc);
    HS_LAUNCH_CHECK();
@@ -941,8 +944,10 @@ static int steplen_enqueue(hipsdp_solver* s)
                s->lan_ws2) );
       ++k;
    }
+   hs_red_batch_begin(s->stream);
    HS_CALL( hs_ratio_min(s->stream, s->q, s->x, s->dx, s->sc + SC_RATX, 0, s->red_ws) );
    HS_CALL( hs_ratio_min(s->stream, s->q, s->z, s->dz, s->sc + SC_RATZ, 0, s->red_ws) );
+   HS_CALL( hs_red_batch_end() );
    return HS_OK;
 }
 
@@ -1094,9 +1099,10 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       /* ---- residuals */
       hipLaunchKernelGGL(k_make_ext, g1d(m1), dim3(256), 0, st, m, -s->tau, 1.0, s->y, s->yt);
       HS_LAUNCH_CHECK();
-      HS_CALL( hs_fill(st, s->sc + SC_RD2, 1, 0.0) );
-      HS_CALL( hs_fill(st, s->sc + SC_XZ, 1, 0.0) );
-      HS_CALL( hs_fill(st, s->sc + SC_HD2, 1, 0.0) );
+      hs_red_batch_begin(st);         /* the reductions of this phase run in one launch, right before the scalars are read */
+      HS_CALL( hs_fill_scalar(st, s->sc + SC_RD2, 0.0) );
+      HS_CALL( hs_fill_scalar(st, s->sc + SC_XZ, 0.0) );
+      HS_CALL( hs_fill_scalar(st, s->sc + SC_HD2, 0.0) );
       std::vector<double*> Xs;
       for (int k = 0; k < K; ++k)
       {
@@ -1130,9 +1136,9 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
          }
       }
       else
-         HS_CALL( hs_fill(st, s->sc + SC_RDLPMAX, 1, 0.0) );
+         HS_CALL( hs_fill_scalar(st, s->sc + SC_RDLPMAX, 0.0) );
       HS_CALL( apply_A(s, Xs.data(), s->x, s->AX) );
-      HS_CALL( hs_copy(st, s->sc + SC_AX0, s->AX, 1) );
+      HS_CALL( hs_copy_scalar(st, s->sc + SC_AX0, s->AX) );
       hipLaunchKernelGGL(k_rp, g1d(m > 0 ? m : 1), dim3(256), 0, st, m, s->tau, s->b, s->AX, s->rp);
       HS_LAUNCH_CHECK();
       HS_CALL( hs_dot(st, m, s->rp, s->rp, s->sc + SC_RP2, 0, s->red_ws) );
@@ -1354,7 +1360,8 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       hipLaunchKernelGGL(k_after_solve2, g1d(m1), dim3(256), 0, st, m, s->rhs2, s->u2, s->wt);
       HS_LAUNCH_CHECK();
       /* B_k = A_0 - sum w_i A_i ; beta = c - D w ; S0 ; b^T M^-1 b */
-      HS_CALL( hs_fill(st, s->sc + SC_S0, 1, 0.0) );
+      hs_red_batch_begin(st);
+      HS_CALL( hs_fill_scalar(st, s->sc + SC_S0, 0.0) );
       for (auto& B : s->blk)
       {
          const int n = B.n;
@@ -1371,6 +1378,7 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
          HS_CALL( hs_lp_s0(st, q, s->x, s->z, s->beta, s->sc + SC_S0, 1, s->red_ws) );
       }
       HS_CALL( hs_dot(st, m, s->b, s->rhs2 + m, s->sc + SC_BUB, 0, s->red_ws) );
+      HS_CALL( hs_red_batch_end() );
 
       /* ---- predictor */
       HS_CALL( direction(s, 0.0, 1.0, mu, rg, false, 0.0) );

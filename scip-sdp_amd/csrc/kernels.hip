@@ -492,16 +492,129 @@ __global__ void __launch_bounds__(256) k_reduce_stage2(int nparts, const double*
       *out = accumulate ? OP::f(*out, v) : v;
 }
 
+/* ---- deferred reductions -------------------------------------------------------------------------------------------
+ * The small-problem regime is bound by the number of launches, and an interior-point iteration contains runs of scalar
+ * reductions (dot products, maxima, ratio tests, zeroing of scalar slots) whose inputs are not touched again until the
+ * host reads the scalars.  Between hs_red_batch_begin and hs_red_batch_end such calls (vectors of at most
+ * RB_MAXN entries) are only recorded; the end launches ONE single-workgroup kernel that executes the records in order
+ * (so accumulation into a common slot keeps its order).  A call that does not fit flushes the records first. */
+#define RB_MAX   28
+#define RB_MAXN  16384
+#define RB_FILL  100
+#define RB_COPY1 101
+
+struct rb_desc { int kind; int accumulate; long long n; const double* a; const double* b; const double* c; double* out; double v; };
+struct rb_args { int cnt; rb_desc d[RB_MAX]; };
+static thread_local struct { bool open; hipStream_t s; rb_args args; } g_rb = {false, NULL, {0, {}}};
+
+template<int KIND>
+__device__ __forceinline__ double rb_run(const rb_desc& D, double* sh)
+{
+   typedef typename RedTraits<KIND>::OP OP;
+   double v = OP::id();
+   for (long long i = threadIdx.x; i < D.n; i += 256)
+      v = OP::f(v, red_elem<KIND>(i, D.a, D.b, D.c));
+   v = block_reduce_256<OP>(v, sh);
+   if ( threadIdx.x == 0 )
+      *D.out = D.accumulate ? OP::f(*D.out, v) : v;
+   return v;
+}
+
+__global__ void __launch_bounds__(256) k_red_batch(rb_args A)
+{
+   __shared__ double sh[4];
+   for (int t = 0; t < A.cnt; ++t)
+   {
+      const rb_desc& D = A.d[t];
+      switch ( D.kind )
+      {
+      case RED_DOT:      rb_run<RED_DOT>(D, sh); break;
+      case RED_ABSMAX:   rb_run<RED_ABSMAX>(D, sh); break;
+      case RED_RATIOMIN: rb_run<RED_RATIOMIN>(D, sh); break;
+      case RED_LPS0:     rb_run<RED_LPS0>(D, sh); break;
+      case RB_FILL:      if ( threadIdx.x == 0 ) *D.out = D.v; break;
+      default:           if ( threadIdx.x == 0 ) *D.out = *D.a; break;      /* RB_COPY1 */
+      }
+      /* the next record may read what this one wrote (same workgroup, global memory) */
+      __threadfence_block();
+      __syncthreads();
+   }
+}
+
+static int rb_flush(void)
+{
+   if ( g_rb.args.cnt > 0 )
+   {
+      hipLaunchKernelGGL(k_red_batch, dim3(1), dim3(256), 0, g_rb.s, g_rb.args);
+      g_rb.args.cnt = 0;
+      HS_LAUNCH_CHECK();
+   }
+   return HS_OK;
+}
+
+void hs_red_batch_begin(hipStream_t s)
+{
+   if ( g_rb.open )
+      (void) rb_flush();
+   g_rb.open = true;
+   g_rb.s = s;
+   g_rb.args.cnt = 0;
+}
+
+int hs_red_batch_end(void)
+{
+   const int rc = g_rb.open ? rb_flush() : HS_OK;
+   g_rb.open = false;
+   return rc;
+}
+
+/* 1: recorded; 0: not recordable (the caller launches normally, after the records were flushed to keep the order) */
+static int rb_record(hipStream_t s, int kind, long long n, const double* a, const double* b, const double* c, double* out,
+   int accumulate, double v)
+{
+   if ( !g_rb.open )
+      return 0;
+   if ( s != g_rb.s || n > RB_MAXN )
+   {
+      (void) rb_flush();
+      return 0;
+   }
+   if ( g_rb.args.cnt == RB_MAX )
+      (void) rb_flush();
+   rb_desc& D = g_rb.args.d[g_rb.args.cnt++];
+   D.kind = kind; D.accumulate = accumulate; D.n = n; D.a = a; D.b = b; D.c = c; D.out = out; D.v = v;
+   return 1;
+}
+
+/* any other kernel launched on the stream while a batch is open must see the records executed first when it depends on
+ * them; the engine only opens batches around runs where that is not the case, but scalar fills / copies of one element
+ * are part of such runs and are recorded too */
+int hs_fill_scalar(hipStream_t s, double* p, double v)
+{
+   if ( rb_record(s, RB_FILL, 1, NULL, NULL, NULL, p, 0, v) )
+      return HS_OK;
+   return hs_fill(s, p, 1, v);
+}
+
+int hs_copy_scalar(hipStream_t s, double* dst, const double* src)
+{
+   if ( rb_record(s, RB_COPY1, 1, src, NULL, NULL, dst, 0, 0.0) )
+      return HS_OK;
+   return hs_copy(s, dst, src, 1);
+}
+
 template<int KIND>
 static int reduce_launch(hipStream_t s, long long n, const double* a, const double* b, const double* c, double* out,
    int accumulate, double* ws)
 {
+   if ( n > 0 && rb_record(s, KIND, n, a, b, c, out, accumulate, 0.0) )
+      return HS_OK;
    if ( n <= 0 )
    {
       if ( !accumulate )
       {
          const double idv = (KIND == RED_RATIOMIN) ? 1e300 : 0.0;
-         HS_CALL( hs_fill(s, out, 1, idv) );
+         HS_CALL( hs_fill_scalar(s, out, idv) );
       }
       return HS_OK;
    }
