@@ -29,6 +29,8 @@ void hs_red_batch_begin(hipStream_t s);
 int hs_red_batch_end(void);
 int hs_fill_scalar(hipStream_t s, double* p, double v);
 int hs_copy_scalar(hipStream_t s, double* dst, const double* src);
+int hs_axpy3(hipStream_t s, double a, long long n1, const double* x1, double* y1, long long n2, const double* x2, double* y2,
+   long long n3, const double* x3, double* y3);
 int hs_dot(hipStream_t s, long long n, const double* a, const double* b, double* out, int accumulate, double* ws);
 /* out[slot] = max(out[slot] if accumulate, max_e |a[e]|) */
 int hs_absmax(hipStream_t s, long long n, const double* a, double* out, int accumulate, double* ws);

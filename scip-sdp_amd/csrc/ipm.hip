@@ -15,6 +15,7 @@
 #include "hs_kernels.h"
 #include "../../include/hipsdp.h"
 #include <vector>
+#include <utility>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -292,7 +293,9 @@ extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int*
       R.apk_valid = false;
       R.Apk = NULL;
       R.pkv = NULL;
-      if ( getenv("HIPSDP_NOPACK") == NULL && B.n >= 8 )
+      /* the packed copy halves the HBM traffic of the passes; small blocks are launch bound and their passes take one
+       * launch less on the full storage */
+      if ( getenv("HIPSDP_NOPACK") == NULL && B.n > 64 )
       {
          if ( hipMalloc((void**) &R.Apk, (size_t) (m1 * R.Lp) * sizeof(double)) != hipSuccess )
          {
@@ -1414,9 +1417,7 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       {
          const int n = B.n;
          const long long n2 = (long long) n * n;
-         HS_CALL( hs_copy(st, B.dXa, B.dX, n2) );
-         HS_CALL( hs_copy(st, B.dZa, B.dZ, n2) );
-         HS_CALL( gemm(s, HS_KC, HS_MC, n, n, n, 1.0, B.dXa, n, B.dZa, n, 0.0, B.E, n) );
+         HS_CALL( gemm(s, HS_KC, HS_MC, n, n, n, 1.0, B.dX, n, B.dZ, n, 0.0, B.E, n) );
       }
       if ( q > 0 )
          HS_CALL( hs_vec_mul(st, q, s->dx, s->dz, s->elp) );
@@ -1438,6 +1439,8 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       for (auto& B : s->blk)
       {
          const long long n2 = (long long) B.n * B.n;
+         if ( B.n <= 64 )
+            continue;            /* single-block factorization: the trial iterate is written to Xs / Zs and swapped in */
          HS_CALL( hs_copy(st, B.Xs, B.X, n2) );
          HS_CALL( hs_copy(st, B.Zs, B.Z, n2) );
       }
@@ -1452,9 +1455,8 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
             hipStream_t st2 = s->use2 ? s->stream2 : s->stream;
             if ( n <= 64 )
             {
-               HS_CALL( hs_potrf_small_ext(st, n, B.Lx, B.dinvx, s->flags + 1, B.Xs, B.dX, alpha, B.X, B.LxInv, NULL) );
-               HS_CALL( hs_potrf_small_ext(st2, n, B.Lz, B.dinvz, s->flags + 0, B.Zs, B.dZ, alpha, B.Z, B.LzInv, n <= 32 ? B.Zinv : NULL) );
-               B.derived_valid = true;
+               HS_CALL( hs_potrf_small_ext(st, n, B.Lx, B.dinvx, s->flags + 1, B.X, B.dX, alpha, B.Xs, B.LxInv, NULL) );
+               HS_CALL( hs_potrf_small_ext(st2, n, B.Lz, B.dinvz, s->flags + 0, B.Z, B.dZ, alpha, B.Zs, B.LzInv, n <= 32 ? B.Zinv : NULL) );
                continue;
             }
             HS_CALL( hs_scale_add(st, n2, alpha, B.dX, 1.0, B.Xs, B.X) );
@@ -1481,16 +1483,27 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
          for (auto& B : s->blk)
          {
             const long long n2 = (long long) B.n * B.n;
+            B.derived_valid = false;
+            if ( B.n <= 64 )
+               continue;         /* X, Z were never overwritten */
             HS_CALL( hs_copy(st, B.X, B.Xs, n2) );
             HS_CALL( hs_copy(st, B.Z, B.Zs, n2) );
          }
          status = HIPSDP_STATUS_NUMERIC;
          break;
       }
+      for (auto& B : s->blk)
+      {
+         if ( B.n <= 64 )
+         {
+            /* accept the trial iterate: its factors, inverse factors (and inverse) are those of the fused factorization */
+            std::swap(B.X, B.Xs);
+            std::swap(B.Z, B.Zs);
+            B.derived_valid = true;
+         }
+      }
       factors_valid = (K > 0);
-      HS_CALL( hs_axpy(st, m, alpha, s->dy, s->y) );
-      HS_CALL( hs_axpy(st, q, alpha, s->dx, s->x) );
-      HS_CALL( hs_axpy(st, q, alpha, s->dz, s->z) );
+      HS_CALL( hs_axpy3(st, alpha, m, s->dy, s->y, q, s->dx, s->x, q, s->dz, s->z) );
       s->tau += alpha * dt;
       s->kappa += alpha * dk;
       alpha_last = alpha;

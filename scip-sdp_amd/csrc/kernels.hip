@@ -234,6 +234,34 @@ int hs_copy(hipStream_t s, double* dst, const double* src, long long n)
    return HS_OK;
 }
 
+/* y_k += a * x_k for three vectors in one launch (the iterate update y, x, z) */
+__global__ void k_axpy3(double a, long long n1, const double* __restrict__ x1, double* __restrict__ y1, long long n2,
+   const double* __restrict__ x2, double* __restrict__ y2, long long n3, const double* __restrict__ x3, double* __restrict__ y3)
+{
+   const long long total = n1 + n2 + n3;
+   for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long) gridDim.x * blockDim.x)
+   {
+      if ( i < n1 )
+         y1[i] += a * x1[i];
+      else if ( i < n1 + n2 )
+         y2[i - n1] += a * x2[i - n1];
+      else
+         y3[i - n1 - n2] += a * x3[i - n1 - n2];
+   }
+}
+
+int hs_axpy3(hipStream_t s, double a, long long n1, const double* x1, double* y1, long long n2, const double* x2, double* y2,
+   long long n3, const double* x3, double* y3)
+{
+   if ( n1 < 0 ) n1 = 0;
+   if ( n2 < 0 ) n2 = 0;
+   if ( n3 < 0 ) n3 = 0;
+   if ( n1 + n2 + n3 == 0 ) return HS_OK;
+   hipLaunchKernelGGL(k_axpy3, dim3(grid_for(n1 + n2 + n3, 256, 2048)), dim3(256), 0, s, a, n1, x1, y1, n2, x2, y2, n3, x3, y3);
+   HS_LAUNCH_CHECK();
+   return HS_OK;
+}
+
 int hs_scale_add(hipStream_t s, long long n, double a, const double* x, double b, const double* y, double* out)
 {
    if ( n <= 0 ) return HS_OK;
