@@ -98,6 +98,10 @@ int hs_trtri(hipStream_t s, int n, const double* L, const double* dinv, double* 
  * for n <= 32, the inverse of the matrix (Gram); L gets a zero upper triangle */
 int hs_potrf_small_ext(hipStream_t s, int n, double* L, double* dinv, int* flag, const double* base, const double* dir, double alpha,
    double* Mout, double* Linv, double* Gram);
+/* all blocks n <= 32: the extended Schur matrix (SDP blocks + LP part, symmetric), Lm = Mx[1:, 1:] and its diagonal in one
+ * launch; returns 1 if done, 0 if the sizes do not qualify, < 0 on error */
+int hs_schur_small(hipStream_t s, int m1, int nblk, const int* n, const double* const* A, const double* const* X,
+   const double* const* Zinv, int q, const double* Dext, const double* x, const double* z, double* Mx, double* Lm, double* diagM);
 int hs_trsv(hipStream_t s, int n, const double* L, const double* dinv, int nrhs, double* rhs, long long ldr, int mode);
 /* the same solve with one workgroup per 64-row block (flag hand-off between blocks); sync_ws: hs_trsv_sync_ws(n) ints, zeroed
  * once; *epoch: call counter owned by the caller (start at 0) */

@@ -91,6 +91,7 @@ struct hipsdp_solver
    int* flags;       /* device ints: 0 chol Z, 1 chol X, 2 chol M */
    hs_schur_ws sws;
    bool schur_mode_U, schur_mode_rows;
+   bool schur_mode_forced;      /* HIPSDP_SCHUR set: the single-launch assembly of small problems is not used either */
    double* Mgather;
    long long mx_rows;
    int nsc;
@@ -752,6 +753,7 @@ static int ensure_schur_ws(hipsdp_solver* s)
    const char* mode = getenv("HIPSDP_SCHUR");
    s->schur_mode_U = (mode != NULL && mode[0] == 'U') || !s->sws.full || s->comm != NULL;
    s->schur_mode_rows = (mode != NULL && mode[0] == 'R');
+   s->schur_mode_forced = (mode != NULL);
    if ( s->comm != NULL && s->Mgather == NULL )
    {
       const long long c = (m1 + 2 * s->nranks - 1) / (2 * s->nranks);
@@ -1302,6 +1304,28 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
 
       /* ---- Schur complement (extended by the constant matrix as "variable 0") */
       HS_HIP( hipEventRecord(s->ev0, st) );
+      bool schur_small = false;
+      if ( s->comm == NULL && !s->schur_mode_rows && !s->schur_mode_forced && K > 0 )
+      {
+         /* B&B-sized problems: one launch for the whole extended Schur matrix and the copies the factorization needs */
+         std::vector<int> bn;
+         std::vector<const double*> bA, bX, bZ;
+         for (auto& B : s->blk)
+         {
+            bn.push_back(B.n); bA.push_back(B.A); bX.push_back(B.X); bZ.push_back(B.Zinv);
+         }
+         const int rs = hs_schur_small(st, m1, K, bn.data(), bA.data(), bX.data(), bZ.data(), q, s->Dext, s->x, s->z, s->Mx,
+            m > 0 ? s->Lm : NULL, s->dya);
+         if ( rs < 0 )
+            return -rs;
+         schur_small = (rs == 1);
+      }
+      if ( schur_small )
+      {
+         /* nothing else to assemble */
+      }
+      else
+      {
       HS_CALL( hs_fill(st, s->Mx, (long long) m1 * m1, 0.0) );
       if ( s->comm != NULL || s->schur_mode_rows )
       {
@@ -1347,14 +1371,18 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
          HS_CALL( gemm(s, HS_MC, HS_MC, m1, m1, q, 1.0, s->Dext, m1, s->Slp, m1, 1.0, s->Mx, m1, HS_GEMM_LOWER) );
       }
       HS_CALL( hs_mirror_lower(st, s->Mx, m1, m1) );
+      }
       HS_HIP( hipEventRecord(s->ev1, st) );
       if ( m > 0 )
       {
-         HS_HIP( hipMemcpy2DAsync(s->Lm, (size_t) m * sizeof(double), s->Mx + m1 + 1, (size_t) m1 * sizeof(double),
-               (size_t) m * sizeof(double), (size_t) m, hipMemcpyDeviceToDevice, st) );
-         /* original diagonal of M for the semidefinite pivot rule */
-         HS_HIP( hipMemcpy2DAsync(s->dya, sizeof(double), s->Mx + m1 + 1, (size_t) (m1 + 1) * sizeof(double), sizeof(double), (size_t) m,
-               hipMemcpyDeviceToDevice, st) );
+         if ( !schur_small )
+         {
+            HS_HIP( hipMemcpy2DAsync(s->Lm, (size_t) m * sizeof(double), s->Mx + m1 + 1, (size_t) m1 * sizeof(double),
+                  (size_t) m * sizeof(double), (size_t) m, hipMemcpyDeviceToDevice, st) );
+            /* original diagonal of M for the semidefinite pivot rule */
+            HS_HIP( hipMemcpy2DAsync(s->dya, sizeof(double), s->Mx + m1 + 1, (size_t) (m1 + 1) * sizeof(double), sizeof(double), (size_t) m,
+                  hipMemcpyDeviceToDevice, st) );
+         }
          HS_CALL( hs_potrf(st, m, s->Lm, s->dinvm, s->flags + 2, s->dya) );
          hipLaunchKernelGGL(k_rhs2, g1d(m), dim3(256), 0, st, m, s->Mx, s->b, s->rhs2);
          HS_LAUNCH_CHECK();

@@ -175,3 +175,133 @@ void hs_shard_rows(int m1, int nranks, int rank, int* chunk_rows, int* first_beg
    *first_begin = rank * c;
    *second_begin = (2 * nranks - 1 - rank) * c;
 }
+
+
+/* ---- small problems: the whole extended Schur matrix in ONE launch ------------------------------------------------- */
+/* All blocks n <= 32: workgroup j forms U_j^k = X_k A_j^k Zinv_k in LDS for every block, then the entries (i, j), i >= j, of
+ *    Mx = sum_k <A_i^k, U_j^k> + Dext^T diag(x / z) Dext
+ * and stores them symmetrically, together with the copies the factorization wants (Lm = Mx[1:, 1:], its diagonal).
+ * Replaces fill + 3 GEMM launches per block + row scaling + GEMM + mirror + 2 strided copies: B&B-sized problems are bound
+ * by the launch count.  Same sums as the general path up to the order of the additions. */
+#define SS_MAXBLK 8
+#define SS_MAXM1  1024
+struct ss_args
+{
+   int nblk;
+   int n[SS_MAXBLK];
+   const double* A[SS_MAXBLK];
+   const double* X[SS_MAXBLK];
+   const double* Zinv[SS_MAXBLK];
+};
+
+__global__ void __launch_bounds__(256) k_schur_small(int m1, ss_args B, int q, const double* __restrict__ Dext,
+   const double* __restrict__ x, const double* __restrict__ z, double* __restrict__ Mx, double* __restrict__ Lm,
+   double* __restrict__ diagM)
+{
+   __shared__ double sx[32][33], sz[32][33], sa[32][33], st[32][33], su[32][33];
+   __shared__ double colv[SS_MAXM1];
+   const int j = blockIdx.x;
+   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   for (int i = tid; i < m1; i += 256)
+      colv[i] = 0.0;
+   __syncthreads();
+   for (int k = 0; k < B.nblk; ++k)
+   {
+      const int n = B.n[k];
+      const int n2 = n * n;
+      const double* Aj = B.A[k] + (long long) j * n2;
+      for (int e = tid; e < n2; e += 256)
+      {
+         const int r = e / n, c = e - r * n;
+         sx[r][c] = B.X[k][e];
+         sz[r][c] = B.Zinv[k][e];
+         sa[r][c] = Aj[e];
+      }
+      __syncthreads();
+      for (int e = tid; e < n2; e += 256)
+      {
+         const int r = e / n, c = e - r * n;
+         double acc = 0.0;
+         for (int t = 0; t < n; ++t)
+            acc += sx[r][t] * sa[t][c];
+         st[r][c] = acc;
+      }
+      __syncthreads();
+      for (int e = tid; e < n2; e += 256)
+      {
+         const int r = e / n, c = e - r * n;
+         double acc = 0.0;
+         for (int t = 0; t < n; ++t)
+            acc += st[r][t] * sz[t][c];
+         su[r][c] = acc;
+      }
+      __syncthreads();
+      /* <A_i, U_j> for i >= j: one wavefront per i */
+      for (int i = j + wave; i < m1; i += 4)
+      {
+         const double* Ai = B.A[k] + (long long) i * n2;
+         double acc = 0.0;
+         for (int e = lane; e < n2; e += 64)
+         {
+            const int r = e / n, c = e - r * n;
+            acc += Ai[e] * su[r][c];
+         }
+#pragma unroll
+         for (int off = 32; off > 0; off >>= 1)
+            acc += __shfl_down(acc, off, 64);
+         if ( lane == 0 )
+            colv[i] += acc;
+      }
+      __syncthreads();
+   }
+   /* LP part: sum_r Dext[r][i] (x_r / z_r) Dext[r][j] */
+   if ( q > 0 )
+   {
+      for (int i = j + tid; i < m1; i += 256)
+      {
+         double acc = 0.0;
+         for (int r = 0; r < q; ++r)
+            acc += Dext[(long long) r * m1 + i] * ((x[r] / z[r]) * Dext[(long long) r * m1 + j]);
+         colv[i] += acc;
+      }
+      __syncthreads();
+   }
+   const int m = m1 - 1;
+   for (int i = j + tid; i < m1; i += 256)
+   {
+      const double v = colv[i];
+      Mx[(long long) i * m1 + j] = v;
+      Mx[(long long) j * m1 + i] = v;
+      if ( Lm != NULL && j >= 1 )
+      {
+         Lm[(long long) (i - 1) * m + (j - 1)] = v;
+         Lm[(long long) (j - 1) * m + (i - 1)] = v;
+         if ( i == j )
+            diagM[j - 1] = v;
+      }
+   }
+}
+
+/* 1: assembled; 0: not applicable (sizes), caller takes the general path; < 0: error */
+int hs_schur_small(hipStream_t s, int m1, int nblk, const int* n, const double* const* A, const double* const* X,
+   const double* const* Zinv, int q, const double* Dext, const double* x, const double* z, double* Mx, double* Lm, double* diagM)
+{
+   if ( nblk > SS_MAXBLK || m1 > SS_MAXM1 || m1 < 1 || (long long) q * m1 > 2000000LL )
+      return 0;
+   ss_args B;
+   B.nblk = nblk;
+   for (int k = 0; k < nblk; ++k)
+   {
+      if ( n[k] > 32 || n[k] < 1 )
+         return 0;
+      B.n[k] = n[k]; B.A[k] = A[k]; B.X[k] = X[k]; B.Zinv[k] = Zinv[k];
+   }
+   for (int k = nblk; k < SS_MAXBLK; ++k)
+   {
+      B.n[k] = 0; B.A[k] = NULL; B.X[k] = NULL; B.Zinv[k] = NULL;
+   }
+   hipLaunchKernelGGL(k_schur_small, dim3(m1), dim3(256), 0, s, m1, B, q, Dext, x, z, Mx, Lm, diagM);
+   if ( hipGetLastError() != hipSuccess )
+      return -HS_ERR_HIP;
+   return 1;
+}
