@@ -830,6 +830,117 @@ static int pass_AT(hipsdp_solver* s, Block& B, const double* coef, double sa, co
    return hs_gemv_t(s->stream, m1, n2, B.A, n2, coef, sa, add, out);
 }
 
+/* small problems: A(V) over all blocks + LP part + the element-wise kernel that always follows, in one launch.
+ * epi 0: out only; 1: h[i] = out[1 + i] - eta * rp[i] (k_h); 2: rp[i] = b[i] * tau - out[1 + i] (k_rp) */
+#define AS_MAXBLK 8
+struct as_args { int nblk; int n2[AS_MAXBLK]; const double* A[AS_MAXBLK]; const double* V[AS_MAXBLK]; };
+
+__global__ void __launch_bounds__(256) k_apply_A_small(int m1, as_args B, int q, const double* __restrict__ Dext,
+   const double* __restrict__ vlp, double* __restrict__ out, int epi, double scal, const double* __restrict__ vin,
+   double* __restrict__ vout)
+{
+   __shared__ double sh[4];
+   const int i = blockIdx.x;
+   const int tid = threadIdx.x;
+   double acc = 0.0;
+   for (int k = 0; k < B.nblk; ++k)
+   {
+      const double* a = B.A[k] + (long long) i * B.n2[k];
+      const double* v = B.V[k];
+      for (int e = tid; e < B.n2[k]; e += 256)
+         acc += a[e] * v[e];
+   }
+   for (int r = tid; r < q; r += 256)
+      acc += Dext[(long long) r * m1 + i] * vlp[r];
+   for (int off = 32; off > 0; off >>= 1)
+      acc += __shfl_down(acc, off, 64);
+   if ( (tid & 63) == 0 )
+      sh[tid >> 6] = acc;
+   __syncthreads();
+   if ( tid == 0 )
+   {
+      const double v = sh[0] + sh[1] + sh[2] + sh[3];
+      out[i] = v;
+      if ( i >= 1 )
+      {
+         if ( epi == 1 )
+            vout[i - 1] = v - scal * vin[i - 1];
+         else if ( epi == 2 )
+            vout[i - 1] = vin[i - 1] * scal - v;
+      }
+   }
+}
+
+/* small problems, LP rows: t_r = Dext[r, :] . v, then the element-wise kernels that follow, in one launch (one wavefront per row).
+ * mode 0: out1 = t - z (the residual rd);  mode 1: out1 = t + eta * rd (dz), out2 = sigmu / z - x - (x * out1 + elp) / z (dx) */
+__global__ void __launch_bounds__(256) k_lp_rows_small(int q, int m1, const double* __restrict__ Dext, const double* __restrict__ v,
+   int mode, double eta, double sigmu, const double* __restrict__ x, const double* __restrict__ z, const double* __restrict__ rd,
+   const double* __restrict__ elp, double* __restrict__ out1, double* __restrict__ out2)
+{
+   const int lane = threadIdx.x & 63;
+   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+   if ( r >= q )
+      return;
+   const double* d = Dext + (long long) r * m1;
+   double t = 0.0;
+   for (int i = lane; i < m1; i += 64)
+      t += d[i] * v[i];
+   for (int off = 32; off > 0; off >>= 1)
+      t += __shfl_down(t, off, 64);
+   if ( lane == 0 )
+   {
+      if ( mode == 0 )
+         out1[r] = t - z[r];
+      else
+      {
+         const double dzr = t + eta * rd[r];
+         out1[r] = dzr;
+         double tt = x[r] * dzr;
+         if ( elp != NULL )
+            tt += elp[r];
+         out2[r] = sigmu / z[r] - x[r] - tt / z[r];
+      }
+   }
+}
+
+static bool small_problem(const hipsdp_solver* s)
+{
+   if ( s->blk.size() > AS_MAXBLK || s->q > 4096 || s->m + 1 > 4096 )
+      return false;
+   long long tot = 0;
+   for (auto& B : s->blk)
+   {
+      if ( B.Apk != NULL )
+         return false;
+      tot += (long long) B.n * B.n;
+   }
+   return tot <= 8192;
+}
+
+/* returns 1 when the fused launch was used */
+static int apply_A_small(hipsdp_solver* s, double* const* Vk, const double* vlp, double* out, int epi, double scal,
+   const double* vin, double* vout)
+{
+   if ( !small_problem(s) )
+      return 0;
+   as_args B;
+   B.nblk = (int) s->blk.size();
+   for (int k = 0; k < AS_MAXBLK; ++k)
+   {
+      B.n2[k] = 0; B.A[k] = NULL; B.V[k] = NULL;
+   }
+   for (size_t k = 0; k < s->blk.size(); ++k)
+   {
+      B.n2[k] = s->blk[k].n * s->blk[k].n;
+      B.A[k] = s->blk[k].A;
+      B.V[k] = Vk[k];
+   }
+   hipLaunchKernelGGL(k_apply_A_small, dim3(s->m + 1), dim3(256), 0, s->stream, s->m + 1, B, s->q, s->Dext, vlp, out, epi, scal, vin, vout);
+   if ( hipGetLastError() != hipSuccess )
+      return -HS_ERR_HIP;
+   return 1;
+}
+
 /* A(V) over all blocks + LP: out[m + 1] = sum_k A_k vec(V_k) + Dext^T vlp */
 static int apply_A(hipsdp_solver* s, double* const* Vk, const double* vlp, double* out)
 {
@@ -876,11 +987,18 @@ static int direction(hipsdp_solver* s, double sigma, double eta, double mu, doub
    }
    if ( q > 0 )
       HS_CALL( hs_lp_dir(s->stream, q, sigmu, eta, s->x, s->z, s->rd, useE ? s->elp : NULL, s->hl) );
-   HS_CALL( apply_A(s, Hs.data(), s->hl, s->AH) );
+   const int fusedA = apply_A_small(s, Hs.data(), s->hl, s->AH, 1, eta, s->rp, s->u1);
+   if ( fusedA < 0 )
+      return -fusedA;
+   if ( fusedA == 0 )
+      HS_CALL( apply_A(s, Hs.data(), s->hl, s->AH) );
    if ( m > 0 )
    {
-      hipLaunchKernelGGL(k_h, g1d(m), dim3(256), 0, s->stream, m, eta, s->AH, s->rp, s->u1);
-      HS_LAUNCH_CHECK();
+      if ( fusedA == 0 )
+      {
+         hipLaunchKernelGGL(k_h, g1d(m), dim3(256), 0, s->stream, m, eta, s->AH, s->rp, s->u1);
+         HS_LAUNCH_CHECK();
+      }
       HS_CALL( hs_trsv_sync(s->stream, m, s->Lm, s->dinvm, 1, s->u1, m, 3, s->trsv_ws, &s->trsv_epoch) );
    }
    /* BH = sum <B_k, H_k> + beta^T hl ; wrp ; bu1 */
@@ -914,10 +1032,19 @@ static int direction(hipsdp_solver* s, double sigma, double eta, double mu, doub
    }
    if ( q > 0 )
    {
-      const double* v = s->dyt;
-      HS_CALL( hs_gemv_n(s->stream, q, m1, s->Dext, m1, 1, &v, s->tmpq, q, s->gemv_ws, s->gemv_ws_len) );
-      HS_CALL( hs_scale_add(s->stream, q, 1.0, s->tmpq, eta, s->rd, s->dz) );
-      HS_CALL( hs_lp_dir(s->stream, q, sigmu, 1.0, s->x, s->z, s->dz, useE ? s->elp : NULL, s->dx) );
+      if ( small_problem(s) )
+      {
+         hipLaunchKernelGGL(k_lp_rows_small, dim3((q + 3) / 4), dim3(256), 0, s->stream, q, m1, s->Dext, s->dyt, 1, eta, sigmu, s->x, s->z,
+            s->rd, useE ? s->elp : NULL, s->dz, s->dx);
+         HS_LAUNCH_CHECK();
+      }
+      else
+      {
+         const double* v = s->dyt;
+         HS_CALL( hs_gemv_n(s->stream, q, m1, s->Dext, m1, 1, &v, s->tmpq, q, s->gemv_ws, s->gemv_ws_len) );
+         HS_CALL( hs_scale_add(s->stream, q, 1.0, s->tmpq, eta, s->rd, s->dz) );
+         HS_CALL( hs_lp_dir(s->stream, q, sigmu, 1.0, s->x, s->z, s->dz, useE ? s->elp : NULL, s->dx) );
+      }
    }
    return HS_OK;
 }
@@ -1126,9 +1253,18 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       }
       if ( q > 0 )
       {
-         const double* v = s->yt;
-         HS_CALL( hs_gemv_n(st, q, m1, s->Dext, m1, 1, &v, s->tmpq, q, s->gemv_ws, s->gemv_ws_len) );
-         HS_CALL( hs_scale_add(st, q, 1.0, s->tmpq, -1.0, s->z, s->rd) );
+         if ( small_problem(s) )
+         {
+            hipLaunchKernelGGL(k_lp_rows_small, dim3((q + 3) / 4), dim3(256), 0, st, q, m1, s->Dext, s->yt, 0, 0.0, 0.0, s->x, s->z,
+               (const double*) NULL, (const double*) NULL, s->rd, (double*) NULL);
+            HS_LAUNCH_CHECK();
+         }
+         else
+         {
+            const double* v = s->yt;
+            HS_CALL( hs_gemv_n(st, q, m1, s->Dext, m1, 1, &v, s->tmpq, q, s->gemv_ws, s->gemv_ws_len) );
+            HS_CALL( hs_scale_add(st, q, 1.0, s->tmpq, -1.0, s->z, s->rd) );
+         }
          HS_CALL( hs_dot(st, q, s->rd, s->rd, s->sc + SC_RD2, 1, s->red_ws) );
          HS_CALL( hs_absmax(st, q, s->rd, s->sc + SC_RDLPMAX, 0, s->red_ws) );
          HS_CALL( hs_dot(st, q, s->x, s->z, s->sc + SC_XZ, 1, s->red_ws) );
@@ -1142,10 +1278,19 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       }
       else
          HS_CALL( hs_fill_scalar(st, s->sc + SC_RDLPMAX, 0.0) );
-      HS_CALL( apply_A(s, Xs.data(), s->x, s->AX) );
-      HS_CALL( hs_copy_scalar(st, s->sc + SC_AX0, s->AX) );
-      hipLaunchKernelGGL(k_rp, g1d(m > 0 ? m : 1), dim3(256), 0, st, m, s->tau, s->b, s->AX, s->rp);
-      HS_LAUNCH_CHECK();
+      {
+         const int fusedA = apply_A_small(s, Xs.data(), s->x, s->AX, 2, s->tau, s->b, s->rp);
+         if ( fusedA < 0 )
+            return -fusedA;
+         if ( fusedA == 0 )
+            HS_CALL( apply_A(s, Xs.data(), s->x, s->AX) );
+         HS_CALL( hs_copy_scalar(st, s->sc + SC_AX0, s->AX) );
+         if ( fusedA == 0 )
+         {
+            hipLaunchKernelGGL(k_rp, g1d(m > 0 ? m : 1), dim3(256), 0, st, m, s->tau, s->b, s->AX, s->rp);
+            HS_LAUNCH_CHECK();
+         }
+      }
       HS_CALL( hs_dot(st, m, s->rp, s->rp, s->sc + SC_RP2, 0, s->red_ws) );
       HS_CALL( hs_dot(st, m, s->AX + 1, s->AX + 1, s->sc + SC_HP2, 0, s->red_ws) );
       HS_CALL( hs_dot(st, m, s->b, s->y, s->sc + SC_DOBJ, 0, s->red_ws) );
