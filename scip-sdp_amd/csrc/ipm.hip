@@ -84,6 +84,7 @@ struct hipsdp_solver
    double *u1, *rhs2, *u2, *dy, *dya;
    double *Mx, *Lm, *dinvm, *Slp;
    double *sc, *red_ws, *gemv_ws, *lan_ws, *lan_ws2, *gws1, *gws2;
+   double* hsc;            /* pinned host mirror of sc followed by the flags (one device->host copy per read-back) */
    int* trsv_ws;           /* block flags of the multi-workgroup triangular solves */
    int trsv_epoch;
    long long gws_len;
@@ -173,7 +174,8 @@ static void free_problem(hipsdp_solver* s)
    hs_schur_ws_free(&s->sws);
    dfree(s->Mgather);
    s->Mgather = NULL;
-   dfree(s->flags);
+   if ( s->hsc != NULL ) (void) hipHostFree(s->hsc);
+   s->hsc = NULL;
    dfree(s->trsv_ws);
    s->trsv_ws = NULL;
    s->b = s->Dext = s->y = s->x = s->z = s->yt = s->dyt = s->wt = s->AX = s->AH = s->tmpe = s->rp = s->rd = s->tmpq = s->hl = NULL;
@@ -208,6 +210,7 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
    s->schur_mode_rows = false;
    s->sws.T = s->sws.U = s->sws.K = NULL;
    s->flags = NULL;
+   s->hsc = NULL;
    s->trsv_ws = NULL;
    s->trsv_epoch = 0;
    s->last_status = HIPSDP_STATUS_UNSOLVED;
@@ -325,7 +328,9 @@ extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int*
    HS_CALL( dalloc(&s->dinvm, (long long) ((m + 63) / 64) * 64 * 64) );
    HS_CALL( dalloc(&s->Slp, (long long) q * m1) );
    s->nsc = SC_FIXED_END + 8 * (nblocks > 0 ? nblocks : 1) + 8;
-   HS_CALL( dalloc(&s->sc, s->nsc) );
+   HS_CALL( dalloc(&s->sc, s->nsc + 4) );          /* the 8 int flags live behind the scalars: one read-back covers both */
+   s->flags = reinterpret_cast<int*>(s->sc + s->nsc);
+   HS_HIP( hipHostMalloc((void**) &s->hsc, (size_t) (s->nsc + 4) * sizeof(double), hipHostMallocDefault) );
    HS_CALL( dalloc(&s->red_ws, 1024) );
    s->gemv_ws_len = 8192 + 4LL * 1024 * 4;
    HS_CALL( dalloc(&s->gemv_ws, s->gemv_ws_len) );
@@ -335,7 +340,6 @@ extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int*
    if ( s->gws_len > 8LL * 1024 * 1024 ) s->gws_len = 8LL * 1024 * 1024;
    HS_CALL( dalloc(&s->gws1, s->gws_len) );
    HS_CALL( dalloc(&s->gws2, s->gws_len) );
-   HS_CALL( dalloc(&s->flags, 8) );
    HS_CALL( dalloc(&s->trsv_ws, hs_trsv_sync_ws(m)) );
    HS_HIP( hipMemset(s->trsv_ws, 0, (size_t) hs_trsv_sync_ws(m) * sizeof(int)) );
    s->trsv_epoch = 0;
@@ -783,10 +787,11 @@ static int read_scalars(hipsdp_solver* s, HostScalars& h, int* flags3)
       if ( flags3 != NULL )
          HS_CALL( hs_bcast_ints(s->comm, s->flags, 3, s->stream) );
    }
-   HS_HIP( hipMemcpyAsync(h.v.data(), s->sc, (size_t) s->nsc * sizeof(double), hipMemcpyDeviceToHost, s->stream) );
-   if ( flags3 != NULL )
-      HS_HIP( hipMemcpyAsync(flags3, s->flags, 3 * sizeof(int), hipMemcpyDeviceToHost, s->stream) );
+   HS_HIP( hipMemcpyAsync(s->hsc, s->sc, (size_t) (s->nsc + (flags3 != NULL ? 4 : 0)) * sizeof(double), hipMemcpyDeviceToHost, s->stream) );
    HS_HIP( hipStreamSynchronize(s->stream) );
+   memcpy(h.v.data(), s->hsc, (size_t) s->nsc * sizeof(double));
+   if ( flags3 != NULL )
+      memcpy(flags3, s->hsc + s->nsc, 3 * sizeof(int));
    return HS_OK;
 }
 
@@ -1644,8 +1649,9 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
             break;
          if ( s->comm != NULL )
             HS_CALL( hs_bcast_ints(s->comm, s->flags, 3, st) );
-         HS_HIP( hipMemcpyAsync(hflags, s->flags, 3 * sizeof(int), hipMemcpyDeviceToHost, st) );
+         HS_HIP( hipMemcpyAsync(s->hsc + s->nsc, s->flags, 4 * sizeof(int), hipMemcpyDeviceToHost, st) );
          HS_HIP( hipStreamSynchronize(st) );
+         memcpy(hflags, s->hsc + s->nsc, 3 * sizeof(int));
          if ( hflags[0] == 0 && hflags[1] == 0 )
             break;
          alpha *= 0.5;
