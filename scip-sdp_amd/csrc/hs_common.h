@@ -37,6 +37,11 @@
 void hs_record_hip_error(hipError_t e, const char* what, const char* file, int line);
 const char* hs_last_error(void);
 
+/* recycling allocator for device blocks of at most 4 MiB (hs_util.cpp); larger requests go to hipMalloc / hipFree */
+int hs_pool_alloc(void** p, size_t bytes);
+void hs_pool_free(void* p);
+void hs_pool_trim(void);
+
 /* operand storage of a GEMM operand as seen from the product C[M x N] = A[M x K] * B[K x N]:
  *  HS_KC: the K index is contiguous in memory (A stored row-major [M][K], or B stored as [N][K])
  *  HS_MC: the M (resp. N) index is contiguous   (A stored as [K][M],      or B stored row-major [K][N]) */

@@ -85,6 +85,7 @@ struct hipsdp_solver
    double *Mx, *Lm, *dinvm, *Slp;
    double *sc, *red_ws, *gemv_ws, *lan_ws, *lan_ws2, *gws1, *gws2;
    double* hsc;            /* pinned host mirror of sc followed by the flags (one device->host copy per read-back) */
+   long long hsc_cap;      /* doubles; kept across re-shapes (pinned allocations are slow) */
    int* trsv_ws;           /* block flags of the multi-workgroup triangular solves */
    int trsv_epoch;
    long long gws_len;
@@ -110,6 +111,7 @@ struct hipsdp_solver
 };
 
 static thread_local char g_err[512] = "";
+static int g_live_solvers = 0;      /* handles alive in this process: the device memory pool is trimmed when the last one goes */
 static void set_err(const char* msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
 
 extern "C" const char* hipsdp_last_error(void)
@@ -152,11 +154,10 @@ static int dalloc(T** p, long long count)
    *p = NULL;
    if ( count <= 0 )
       count = 1;
-   HS_HIP( hipMalloc((void**) p, (size_t) count * sizeof(T)) );
-   return HS_OK;
+   return hs_pool_alloc((void**) p, (size_t) count * sizeof(T));
 }
 
-static void dfree(void* p) { if ( p != NULL ) (void) hipFree(p); }
+static void dfree(void* p) { hs_pool_free(p); }
 
 static void free_problem(hipsdp_solver* s)
 {
@@ -174,8 +175,6 @@ static void free_problem(hipsdp_solver* s)
    hs_schur_ws_free(&s->sws);
    dfree(s->Mgather);
    s->Mgather = NULL;
-   if ( s->hsc != NULL ) (void) hipHostFree(s->hsc);
-   s->hsc = NULL;
    dfree(s->trsv_ws);
    s->trsv_ws = NULL;
    s->b = s->Dext = s->y = s->x = s->z = s->yt = s->dyt = s->wt = s->AX = s->AH = s->tmpe = s->rp = s->rd = s->tmpq = s->hl = NULL;
@@ -211,6 +210,7 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
    s->sws.T = s->sws.U = s->sws.K = NULL;
    s->flags = NULL;
    s->hsc = NULL;
+   s->hsc_cap = 0;
    s->trsv_ws = NULL;
    s->trsv_epoch = 0;
    s->last_status = HIPSDP_STATUS_UNSOLVED;
@@ -229,6 +229,7 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
       set_err("stream/event creation failed");
       return HIPSDP_ERR_HIP;
    }
+   (void) __sync_add_and_fetch(&g_live_solvers, 1);
    *out = s;
    return HIPSDP_OK;
 }
@@ -250,6 +251,8 @@ extern "C" void hipsdp_free(hipsdp_solver** ps)
    (void) hipStreamSynchronize(s->stream);
    free_problem(s);
    master_free(s);
+   if ( s->hsc != NULL ) (void) hipHostFree(s->hsc);
+   s->hsc = NULL;
    (void) hipStreamSynchronize(s->stream2);
    (void) hipEventDestroy(s->ev0);
    (void) hipEventDestroy(s->ev1);
@@ -259,6 +262,8 @@ extern "C" void hipsdp_free(hipsdp_solver** ps)
    (void) hipStreamDestroy(s->stream);
    delete s;
    *ps = NULL;
+   if ( __sync_sub_and_fetch(&g_live_solvers, 1) <= 0 )
+      hs_pool_trim();
 }
 
 extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int* blocksizes, int q)
@@ -330,7 +335,13 @@ extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int*
    s->nsc = SC_FIXED_END + 8 * (nblocks > 0 ? nblocks : 1) + 8;
    HS_CALL( dalloc(&s->sc, s->nsc + 4) );          /* the 8 int flags live behind the scalars: one read-back covers both */
    s->flags = reinterpret_cast<int*>(s->sc + s->nsc);
-   HS_HIP( hipHostMalloc((void**) &s->hsc, (size_t) (s->nsc + 4) * sizeof(double), hipHostMallocDefault) );
+   if ( s->hsc_cap < s->nsc + 4 )
+   {
+      if ( s->hsc != NULL ) (void) hipHostFree(s->hsc);
+      s->hsc = NULL;
+      s->hsc_cap = 2LL * (s->nsc + 4);
+      HS_HIP( hipHostMalloc((void**) &s->hsc, (size_t) s->hsc_cap * sizeof(double), hipHostMallocDefault) );
+   }
    HS_CALL( dalloc(&s->red_ws, 1024) );
    s->gemv_ws_len = 8192 + 4LL * 1024 * 4;
    HS_CALL( dalloc(&s->gemv_ws, s->gemv_ws_len) );

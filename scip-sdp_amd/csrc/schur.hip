@@ -35,8 +35,8 @@ int hs_schur_ws_alloc(hs_schur_ws* w, int m1, long long n2max, double budget_gb)
       if ( cols > m1 ) cols = m1;
    }
    w->chunk_cols = cols;
-   hipError_t e = hipMalloc((void**) &w->T, (size_t) (cols * n2max) * sizeof(double));
-   if ( e == hipSuccess ) e = hipMalloc((void**) &w->U, (size_t) (cols * n2max) * sizeof(double));
+   hipError_t e = hs_pool_alloc((void**) &w->T, (size_t) (cols * n2max) * sizeof(double)) == HS_OK ? hipSuccess : hipErrorOutOfMemory;
+   if ( e == hipSuccess ) e = hs_pool_alloc((void**) &w->U, (size_t) (cols * n2max) * sizeof(double)) == HS_OK ? hipSuccess : hipErrorOutOfMemory;
    if ( e != hipSuccess )
    {
       hs_record_hip_error(e, "hipMalloc(schur workspace)", __FILE__, __LINE__);
@@ -52,7 +52,7 @@ int hs_schur_ws_alloc(hs_schur_ws* w, int m1, long long n2max, double budget_gb)
       if ( sk < 64 ) sk = 64;
    }
    w->kws_len = (long long) sk * m1 * (w->full ? m1 : cols);
-   e = hipMalloc((void**) &w->K, (size_t) w->kws_len * sizeof(double));
+   e = hs_pool_alloc((void**) &w->K, (size_t) w->kws_len * sizeof(double)) == HS_OK ? hipSuccess : hipErrorOutOfMemory;
    if ( e != hipSuccess )
    {
       hs_record_hip_error(e, "hipMalloc(split-K slabs)", __FILE__, __LINE__);
@@ -63,9 +63,9 @@ int hs_schur_ws_alloc(hs_schur_ws* w, int m1, long long n2max, double budget_gb)
 
 void hs_schur_ws_free(hs_schur_ws* w)
 {
-   if ( w->T ) (void) hipFree(w->T);
-   if ( w->U ) (void) hipFree(w->U);
-   if ( w->K ) (void) hipFree(w->K);
+   hs_pool_free(w->T);
+   hs_pool_free(w->U);
+   hs_pool_free(w->K);
    w->T = w->U = w->K = NULL;
 }
 
