@@ -1242,9 +1242,10 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
    bool factors_valid = start_factors;      /* the factors of an accepted warm start are those of the first iteration */
    double schur_ms = 0.0;
 
-   for (it = 0; it <= par.maxiter; ++it)
+   /* ---- residuals of the current iterate: enqueued at the top of an iteration, or (small problems) already at the end of
+    * the previous one together with the step's Cholesky check, so that one read-back serves both */
+   auto enqueue_residuals = [&]() -> int
    {
-      /* ---- residuals */
       hipLaunchKernelGGL(k_make_ext, g1d(m1), dim3(256), 0, st, m, -s->tau, 1.0, s->y, s->yt);
       HS_LAUNCH_CHECK();
       hs_red_batch_begin(st);         /* the reductions of this phase run in one launch, right before the scalars are read */
@@ -1310,7 +1311,22 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       HS_CALL( hs_dot(st, m, s->rp, s->rp, s->sc + SC_RP2, 0, s->red_ws) );
       HS_CALL( hs_dot(st, m, s->AX + 1, s->AX + 1, s->sc + SC_HP2, 0, s->red_ws) );
       HS_CALL( hs_dot(st, m, s->b, s->y, s->sc + SC_DOBJ, 0, s->red_ws) );
-      HS_CALL( read_scalars(s, hs, NULL) );
+      return HS_OK;
+   };
+   bool residuals_ready = false;
+   bool small_all = (s->comm == NULL);
+   for (auto& B : s->blk)
+      if ( B.n > 64 )
+         small_all = false;
+
+   for (it = 0; it <= par.maxiter; ++it)
+   {
+      if ( !residuals_ready )
+      {
+         HS_CALL( enqueue_residuals() );
+         HS_CALL( read_scalars(s, hs, NULL) );
+      }
+      residuals_ready = false;
 
       const double tau = s->tau, kappa = s->kappa;
       pobj = hs.v[SC_AX0];
@@ -1633,70 +1649,127 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
          HS_CALL( hs_copy(st, B.Xs, B.X, n2) );
          HS_CALL( hs_copy(st, B.Zs, B.Z, n2) );
       }
-      for (int attempt = 0; attempt < 8; ++attempt)
+      if ( small_all && K > 0 )
       {
-         HS_HIP( hipMemsetAsync(s->flags, 0, 8 * sizeof(int), st) );
-         HS_CALL( fork2(s) );
-         for (auto& B : s->blk)
+         /* small problems: the whole step is applied optimistically and the residual phase of the next iteration is enqueued
+          * behind the Cholesky check, so that ONE read-back returns the flags and the new residuals; a failed check takes the
+          * step back (pointer swaps, a correcting axpy) and halves it */
+         const double tau0 = s->tau, kappa0 = s->kappa;
+         double applied = 0.0;
+         bool accepted = false;
+         for (int attempt = 0; attempt < 8; ++attempt)
          {
-            const int n = B.n;
-            const long long n2 = (long long) n * n;
-            hipStream_t st2 = s->use2 ? s->stream2 : s->stream;
-            if ( n <= 64 )
+            HS_HIP( hipMemsetAsync(s->flags, 0, 8 * sizeof(int), st) );
+            for (auto& B : s->blk)
             {
+               const int n = B.n;
                HS_CALL( hs_potrf_small_ext(st, n, B.Lx, B.dinvx, s->flags + 1, B.X, B.dX, alpha, B.Xs, B.LxInv, NULL) );
-               HS_CALL( hs_potrf_small_ext(st2, n, B.Lz, B.dinvz, s->flags + 0, B.Z, B.dZ, alpha, B.Zs, B.LzInv, n <= 32 ? B.Zinv : NULL) );
-               continue;
+               HS_CALL( hs_potrf_small_ext(st, n, B.Lz, B.dinvz, s->flags + 0, B.Z, B.dZ, alpha, B.Zs, B.LzInv, n <= 32 ? B.Zinv : NULL) );
+               std::swap(B.X, B.Xs);
+               std::swap(B.Z, B.Zs);
             }
-            HS_CALL( hs_scale_add(st, n2, alpha, B.dX, 1.0, B.Xs, B.X) );
-            HS_CALL( hs_copy(st, B.Lx, B.X, n2) );
-            HS_CALL( hs_potrf(st, n, B.Lx, B.dinvx, s->flags + 1, NULL) );
-            HS_CALL( hs_scale_add(st2, n2, alpha, B.dZ, 1.0, B.Zs, B.Z) );
-            HS_CALL( hs_copy(st2, B.Lz, B.Z, n2) );
-            HS_CALL( hs_potrf(st2, n, B.Lz, B.dinvz, s->flags + 0, NULL) );
+            HS_CALL( hs_axpy3(st, alpha - applied, m, s->dy, s->y, q, s->dx, s->x, q, s->dz, s->z) );
+            applied = alpha;
+            s->tau = tau0 + alpha * dt;
+            s->kappa = kappa0 + alpha * dk;
+            HS_CALL( enqueue_residuals() );
+            HS_CALL( read_scalars(s, hs, hflags) );
+            if ( hflags[0] == 0 && hflags[1] == 0 )
+            {
+               accepted = true;
+               break;
+            }
+            for (auto& B : s->blk)
+            {
+               std::swap(B.X, B.Xs);
+               std::swap(B.Z, B.Zs);
+            }
+            alpha *= 0.5;
+            info->chol_fail++;
          }
-         HS_CALL( join2(s) );
-         if ( K == 0 )
+         if ( !accepted )
+         {
+            HS_CALL( hs_axpy3(st, -applied, m, s->dy, s->y, q, s->dx, s->x, q, s->dz, s->z) );
+            s->tau = tau0;
+            s->kappa = kappa0;
+            for (auto& B : s->blk)
+               B.derived_valid = false;
+            status = HIPSDP_STATUS_NUMERIC;
             break;
-         if ( s->comm != NULL )
-            HS_CALL( hs_bcast_ints(s->comm, s->flags, 3, st) );
-         HS_HIP( hipMemcpyAsync(s->hsc + s->nsc, s->flags, 4 * sizeof(int), hipMemcpyDeviceToHost, st) );
-         HS_HIP( hipStreamSynchronize(st) );
-         memcpy(hflags, s->hsc + s->nsc, 3 * sizeof(int));
-         if ( hflags[0] == 0 && hflags[1] == 0 )
-            break;
-         alpha *= 0.5;
-         info->chol_fail++;
+         }
+         for (auto& B : s->blk)
+            B.derived_valid = true;
+         factors_valid = true;
+         residuals_ready = true;
+         alpha_last = alpha;
       }
-      if ( K > 0 && (hflags[0] != 0 || hflags[1] != 0) )
+      else
       {
+         for (int attempt = 0; attempt < 8; ++attempt)
+         {
+            HS_HIP( hipMemsetAsync(s->flags, 0, 8 * sizeof(int), st) );
+            HS_CALL( fork2(s) );
+            for (auto& B : s->blk)
+            {
+               const int n = B.n;
+               const long long n2 = (long long) n * n;
+               hipStream_t st2 = s->use2 ? s->stream2 : s->stream;
+               if ( n <= 64 )
+               {
+                  HS_CALL( hs_potrf_small_ext(st, n, B.Lx, B.dinvx, s->flags + 1, B.X, B.dX, alpha, B.Xs, B.LxInv, NULL) );
+                  HS_CALL( hs_potrf_small_ext(st2, n, B.Lz, B.dinvz, s->flags + 0, B.Z, B.dZ, alpha, B.Zs, B.LzInv, n <= 32 ? B.Zinv : NULL) );
+                  continue;
+               }
+               HS_CALL( hs_scale_add(st, n2, alpha, B.dX, 1.0, B.Xs, B.X) );
+               HS_CALL( hs_copy(st, B.Lx, B.X, n2) );
+               HS_CALL( hs_potrf(st, n, B.Lx, B.dinvx, s->flags + 1, NULL) );
+               HS_CALL( hs_scale_add(st2, n2, alpha, B.dZ, 1.0, B.Zs, B.Z) );
+               HS_CALL( hs_copy(st2, B.Lz, B.Z, n2) );
+               HS_CALL( hs_potrf(st2, n, B.Lz, B.dinvz, s->flags + 0, NULL) );
+            }
+            HS_CALL( join2(s) );
+            if ( K == 0 )
+               break;
+            if ( s->comm != NULL )
+               HS_CALL( hs_bcast_ints(s->comm, s->flags, 3, st) );
+            HS_HIP( hipMemcpyAsync(s->hsc + s->nsc, s->flags, 4 * sizeof(int), hipMemcpyDeviceToHost, st) );
+            HS_HIP( hipStreamSynchronize(st) );
+            memcpy(hflags, s->hsc + s->nsc, 3 * sizeof(int));
+            if ( hflags[0] == 0 && hflags[1] == 0 )
+               break;
+            alpha *= 0.5;
+            info->chol_fail++;
+         }
+         if ( K > 0 && (hflags[0] != 0 || hflags[1] != 0) )
+         {
+            for (auto& B : s->blk)
+            {
+               const long long n2 = (long long) B.n * B.n;
+               B.derived_valid = false;
+               if ( B.n <= 64 )
+                  continue;         /* X, Z were never overwritten */
+               HS_CALL( hs_copy(st, B.X, B.Xs, n2) );
+               HS_CALL( hs_copy(st, B.Z, B.Zs, n2) );
+            }
+            status = HIPSDP_STATUS_NUMERIC;
+            break;
+         }
          for (auto& B : s->blk)
          {
-            const long long n2 = (long long) B.n * B.n;
-            B.derived_valid = false;
             if ( B.n <= 64 )
-               continue;         /* X, Z were never overwritten */
-            HS_CALL( hs_copy(st, B.X, B.Xs, n2) );
-            HS_CALL( hs_copy(st, B.Z, B.Zs, n2) );
+            {
+               /* accept the trial iterate: its factors, inverse factors (and inverse) are those of the fused factorization */
+               std::swap(B.X, B.Xs);
+               std::swap(B.Z, B.Zs);
+               B.derived_valid = true;
+            }
          }
-         status = HIPSDP_STATUS_NUMERIC;
-         break;
+         factors_valid = (K > 0);
+         HS_CALL( hs_axpy3(st, alpha, m, s->dy, s->y, q, s->dx, s->x, q, s->dz, s->z) );
+         s->tau += alpha * dt;
+         s->kappa += alpha * dk;
+         alpha_last = alpha;
       }
-      for (auto& B : s->blk)
-      {
-         if ( B.n <= 64 )
-         {
-            /* accept the trial iterate: its factors, inverse factors (and inverse) are those of the fused factorization */
-            std::swap(B.X, B.Xs);
-            std::swap(B.Z, B.Zs);
-            B.derived_valid = true;
-         }
-      }
-      factors_valid = (K > 0);
-      HS_CALL( hs_axpy3(st, alpha, m, s->dy, s->y, q, s->dx, s->x, q, s->dz, s->z) );
-      s->tau += alpha * dt;
-      s->kappa += alpha * dk;
-      alpha_last = alpha;
    }
 
    HS_HIP( hipStreamSynchronize(st) );
