@@ -28,6 +28,11 @@ int hs_gemv_t(hipStream_t s, int R, long long E, const double* A, long long lda,
 void hs_red_batch_begin(hipStream_t s);
 int hs_red_batch_end(void);
 int hs_fill_scalar(hipStream_t s, double* p, double v);
+/* single-block solves (m <= 64) and the direction's closing kernel can be part of a batch: see kernels.hip */
+int hs_red_batch_solve(hipStream_t s, int m, const double* dinv, int nrhs, double* vec, long long ld);
+struct hs_rb_finish { int m; double eta, rg, sigmu, tau, kappa, etk; const double* u1; const double* u2; double* dy; double* dyt; double* sc;
+   int s0, bub, bh, wrp, bu1, dtau, dkappa, den; };
+int hs_red_batch_finish(hipStream_t s, const void* fin, size_t bytes);
 int hs_copy_scalar(hipStream_t s, double* dst, const double* src);
 int hs_axpy3(hipStream_t s, double a, long long n1, const double* x1, double* y1, long long n2, const double* x2, double* y2,
    long long n3, const double* x3, double* y3);

@@ -666,6 +666,41 @@ __global__ void k_after_solve2(int m, const double* __restrict__ rhs2, double* _
    }
 }
 
+/* m <= 64 (single-block factor, dinv = inv(L) as 64 x 64): rhs2 = [g ; b] with g = Mx[0, 1:], both solves M x = r as
+ * x = inv(L)^T (inv(L) r), then u2 = ub - w and wt = [1, -w]: k_rhs2 + the triangular solves + k_after_solve2 in one launch */
+__global__ void __launch_bounds__(128) k_solve2_small(int m, const double* __restrict__ Mx, const double* __restrict__ b,
+   const double* __restrict__ dinv, double* __restrict__ rhs2, double* __restrict__ u2, double* __restrict__ wt)
+{
+   __shared__ double r[2][64], t[2][64];
+   const int k = threadIdx.x >> 6, i = threadIdx.x & 63;
+   r[k][i] = (i < m) ? (k == 0 ? Mx[1 + i] : b[i]) : 0.0;
+   __syncthreads();
+   double acc = 0.0;
+   if ( i < m )
+      for (int j = 0; j <= i; ++j)
+         acc += dinv[i * 64 + j] * r[k][j];
+   t[k][i] = acc;
+   __syncthreads();
+   acc = 0.0;
+   if ( i < m )
+      for (int j = i; j < m; ++j)
+         acc += dinv[j * 64 + i] * t[k][j];
+   r[k][i] = acc;
+   __syncthreads();
+   if ( i < m )
+      rhs2[k * m + i] = r[k][i];
+   if ( k == 0 )
+   {
+      if ( i == 0 )
+         wt[0] = 1.0;
+      if ( i < m )
+      {
+         u2[i] = r[1][i] - r[0][i];
+         wt[1 + i] = -r[0][i];
+      }
+   }
+}
+
 /* h = AH[1:] - eta * rp */
 __global__ void k_h(int m, double eta, const double* __restrict__ AH, const double* __restrict__ rp, double* __restrict__ h)
 {
@@ -1008,7 +1043,8 @@ static int direction(hipsdp_solver* s, double sigma, double eta, double mu, doub
       return -fusedA;
    if ( fusedA == 0 )
       HS_CALL( apply_A(s, Hs.data(), s->hl, s->AH) );
-   if ( m > 0 )
+   const bool fuse_solve = (fusedA == 1) && m > 0 && m <= 64;      /* single-block factor of M: solve, reductions and closing kernel in one launch */
+   if ( m > 0 && !fuse_solve )
    {
       if ( fusedA == 0 )
       {
@@ -1019,6 +1055,8 @@ static int direction(hipsdp_solver* s, double sigma, double eta, double mu, doub
    }
    /* BH = sum <B_k, H_k> + beta^T hl ; wrp ; bu1 */
    hs_red_batch_begin(s->stream);
+   if ( fuse_solve )
+      (void) hs_red_batch_solve(s->stream, m, s->dinvm, 1, s->u1, m);
    HS_CALL( hs_fill_scalar(s->stream, s->sc + SC_BH, 0.0) );
    for (auto& B : s->blk)
       HS_CALL( hs_dot(s->stream, (long long) B.n * B.n, B.B, B.H, s->sc + SC_BH, 1, s->red_ws) );
@@ -1026,10 +1064,20 @@ static int direction(hipsdp_solver* s, double sigma, double eta, double mu, doub
       HS_CALL( hs_dot(s->stream, q, s->beta, s->hl, s->sc + SC_BH, 1, s->red_ws) );
    HS_CALL( hs_dot(s->stream, m, s->rhs2, s->rp, s->sc + SC_WRP, 0, s->red_ws) );       /* w = rhs2[0:m] */
    HS_CALL( hs_dot(s->stream, m, s->b, s->u1, s->sc + SC_BU1, 0, s->red_ws) );
+   bool finished = false;
+   if ( fuse_solve )
+   {
+      hs_rb_finish F = {m, eta, rg, sigmu, s->tau, s->kappa, etk, s->u1, s->u2, s->dy, s->dyt, s->sc,
+         SC_S0, SC_BUB, SC_BH, SC_WRP, SC_BU1, SC_DTAU, SC_DKAPPA, SC_DEN};
+      finished = hs_red_batch_finish(s->stream, &F, sizeof(F)) == 1;
+   }
    HS_CALL( hs_red_batch_end() );
-   hipLaunchKernelGGL(k_finish_dir, g1d(m > 0 ? m : 1), dim3(256), 0, s->stream, m, eta, rg, sigmu, s->tau, s->kappa, etk,
-      s->u1, s->u2, s->dy, s->dyt, s->sc);
-   HS_LAUNCH_CHECK();
+   if ( !finished )
+   {
+      hipLaunchKernelGGL(k_finish_dir, g1d(m > 0 ? m : 1), dim3(256), 0, s->stream, m, eta, rg, sigmu, s->tau, s->kappa, etk,
+         s->u1, s->u2, s->dy, s->dyt, s->sc);
+      HS_LAUNCH_CHECK();
+   }
    for (auto& B : s->blk)
    {
       const int n = B.n;
@@ -1561,12 +1609,23 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
                   hipMemcpyDeviceToDevice, st) );
          }
          HS_CALL( hs_potrf(st, m, s->Lm, s->dinvm, s->flags + 2, s->dya) );
-         hipLaunchKernelGGL(k_rhs2, g1d(m), dim3(256), 0, st, m, s->Mx, s->b, s->rhs2);
-         HS_LAUNCH_CHECK();
-         HS_CALL( hs_trsv_sync(st, m, s->Lm, s->dinvm, 2, s->rhs2, m, 3, s->trsv_ws, &s->trsv_epoch) );
+         if ( m <= 64 )
+         {
+            hipLaunchKernelGGL(k_solve2_small, dim3(1), dim3(128), 0, st, m, s->Mx, s->b, s->dinvm, s->rhs2, s->u2, s->wt);
+            HS_LAUNCH_CHECK();
+         }
+         else
+         {
+            hipLaunchKernelGGL(k_rhs2, g1d(m), dim3(256), 0, st, m, s->Mx, s->b, s->rhs2);
+            HS_LAUNCH_CHECK();
+            HS_CALL( hs_trsv_sync(st, m, s->Lm, s->dinvm, 2, s->rhs2, m, 3, s->trsv_ws, &s->trsv_epoch) );
+         }
       }
-      hipLaunchKernelGGL(k_after_solve2, g1d(m1), dim3(256), 0, st, m, s->rhs2, s->u2, s->wt);
-      HS_LAUNCH_CHECK();
+      if ( m == 0 || m > 64 )
+      {
+         hipLaunchKernelGGL(k_after_solve2, g1d(m1), dim3(256), 0, st, m, s->rhs2, s->u2, s->wt);
+         HS_LAUNCH_CHECK();
+      }
       /* B_k = A_0 - sum w_i A_i ; beta = c - D w ; S0 ; b^T M^-1 b */
       hs_red_batch_begin(st);
       HS_CALL( hs_fill_scalar(st, s->sc + SC_S0, 0.0) );

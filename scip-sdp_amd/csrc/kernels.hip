@@ -9,6 +9,7 @@
  * Reductions are two-stage with a fixed combination order, so results are bitwise reproducible run to run.
  */
 #include "hs_kernels.h"
+#include <string.h>
 
 struct __attribute__((aligned(16))) dbl2 { double x, y; };
 
@@ -530,9 +531,13 @@ __global__ void __launch_bounds__(256) k_reduce_stage2(int nparts, const double*
 #define RB_MAXN  16384
 #define RB_FILL  100
 #define RB_COPY1 101
+#define RB_SOLVE 102      /* out[0:n] <- inv(L)^T inv(L) out[0:n] with a = inv(L) as 64 x 64 (single-block factor, n <= 64); accumulate = number of right-hand sides, c = (const double*) stride in doubles */
+#define RB_FINISH 103     /* the direction's closing element-wise kernel (k_finish_dir of ipm.hip) with its parameters in fin */
 
 struct rb_desc { int kind; int accumulate; long long n; const double* a; const double* b; const double* c; double* out; double v; };
-struct rb_args { int cnt; rb_desc d[RB_MAX]; };
+struct rb_finish { int m; double eta, rg, sigmu, tau, kappa, etk; const double* u1; const double* u2; double* dy; double* dyt; double* sc;
+   int s0, bub, bh, wrp, bu1, dtau, dkappa, den; };
+struct rb_args { int cnt; rb_desc d[RB_MAX]; rb_finish fin; };
 static thread_local struct { bool open; hipStream_t s; rb_args args; } g_rb = {false, NULL, {0, {}}};
 
 template<int KIND>
@@ -561,7 +566,59 @@ __global__ void __launch_bounds__(256) k_red_batch(rb_args A)
       case RED_RATIOMIN: rb_run<RED_RATIOMIN>(D, sh); break;
       case RED_LPS0:     rb_run<RED_LPS0>(D, sh); break;
       case RB_FILL:      if ( threadIdx.x == 0 ) *D.out = D.v; break;
-      default:           if ( threadIdx.x == 0 ) *D.out = *D.a; break;      /* RB_COPY1 */
+      case RB_COPY1:     if ( threadIdx.x == 0 ) *D.out = *D.a; break;
+      case RB_SOLVE:
+      {
+         __shared__ double tv[64];
+         const int m = (int) D.n;
+         const long long stride = (long long) D.v;
+         for (int k = 0; k < D.accumulate; ++k)
+         {
+            double* vec = D.out + k * stride;
+            if ( threadIdx.x < 64 )
+            {
+               const int i = threadIdx.x;
+               double acc = 0.0;
+               if ( i < m )
+                  for (int j = 0; j <= i; ++j)
+                     acc += D.a[i * 64 + j] * vec[j];
+               tv[i] = acc;
+            }
+            __syncthreads();
+            if ( threadIdx.x < m )
+            {
+               const int j = threadIdx.x;
+               double acc = 0.0;
+               for (int i = j; i < m; ++i)
+                  acc += D.a[i * 64 + j] * tv[i];
+               vec[j] = acc;
+            }
+            __syncthreads();
+         }
+         break;
+      }
+      default:      /* RB_FINISH */
+      {
+         const rb_finish& F = A.fin;
+         const double den = F.sc[F.s0] + F.kappa / F.tau + F.sc[F.bub];
+         const double num = -F.eta * F.rg + (F.sigmu - F.tau * F.kappa - F.etk) / F.tau - F.sc[F.bh] - F.eta * F.sc[F.wrp] + F.sc[F.bu1];
+         const double dtau = num / den;
+         __syncthreads();
+         if ( threadIdx.x == 0 )
+         {
+            F.sc[F.dtau] = dtau;
+            F.sc[F.dkappa] = (F.sigmu - F.tau * F.kappa - F.etk - F.kappa * dtau) / F.tau;
+            F.sc[F.den] = den;
+            F.dyt[0] = -dtau;
+         }
+         for (int i = threadIdx.x; i < F.m; i += 256)
+         {
+            const double v = F.u1[i] - F.u2[i] * dtau;
+            F.dy[i] = v;
+            F.dyt[1 + i] = v;
+         }
+         break;
+      }
       }
       /* the next record may read what this one wrote (same workgroup, global memory) */
       __threadfence_block();
@@ -629,6 +686,28 @@ int hs_copy_scalar(hipStream_t s, double* dst, const double* src)
    if ( rb_record(s, RB_COPY1, 1, src, NULL, NULL, dst, 0, 0.0) )
       return HS_OK;
    return hs_copy(s, dst, src, 1);
+}
+
+/* records  vec[k] <- inv(L)^T inv(L) vec[k]  (k < nrhs, vectors ld apart) for a single-block factor (m <= 64, dinv = inv(L) as
+ * 64 x 64); 1: recorded, 0: no batch open */
+int hs_red_batch_solve(hipStream_t s, int m, const double* dinv, int nrhs, double* vec, long long ld)
+{
+   if ( m > 64 )
+      return 0;
+   return rb_record(s, RB_SOLVE, m, dinv, NULL, NULL, vec, nrhs, (double) ld);
+}
+
+/* records the closing kernel of a direction; the parameter block is copied.  1: recorded, 0: no batch open */
+int hs_red_batch_finish(hipStream_t s, const void* fin, size_t bytes)
+{
+   if ( !g_rb.open || s != g_rb.s || bytes != sizeof(rb_finish) )
+      return 0;
+   if ( g_rb.args.cnt == RB_MAX )
+      (void) rb_flush();
+   memcpy(&g_rb.args.fin, fin, sizeof(rb_finish));
+   rb_desc& D = g_rb.args.d[g_rb.args.cnt++];
+   D.kind = RB_FINISH; D.accumulate = 0; D.n = 0; D.a = NULL; D.b = NULL; D.c = NULL; D.out = NULL; D.v = 0.0;
+   return 1;
 }
 
 template<int KIND>
