@@ -1190,6 +1190,7 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
    const auto t_begin = std::chrono::steady_clock::now();
    memset(info, 0, sizeof(*info));
    info->status = HIPSDP_STATUS_UNSOLVED;
+   hs_red_batch_reset();
    HS_CALL( ensure_schur_ws(s) );
    HS_CALL( ensure_packed(s) );
    {

@@ -646,6 +646,13 @@ void hs_red_batch_begin(hipStream_t s)
    g_rb.args.cnt = 0;
 }
 
+/* drops whatever is recorded (an earlier call may have left a batch open on an error path) */
+void hs_red_batch_reset(void)
+{
+   g_rb.open = false;
+   g_rb.args.cnt = 0;
+}
+
 int hs_red_batch_end(void)
 {
    const int rc = g_rb.open ? rb_flush() : HS_OK;
