@@ -828,6 +828,49 @@ __global__ void __launch_bounds__(256) k_gemv_n(int R, long long E, const double
    }
 }
 
+/* one vector, many rows: four rows per workgroup, so that the vector (which every row needs and which does not stay in the
+ * L2 next to the streaming A once it is a few MB) is read a quarter as often */
+__global__ void __launch_bounds__(256) k_gemv_n_rows4(int R, long long E, const double* __restrict__ A, long long lda,
+   const double* __restrict__ v, double* __restrict__ out)
+{
+   __shared__ double sh[4];
+   const int row0 = blockIdx.x * 4;
+   const double* a0 = A + (long long) row0 * lda;
+   const double* a1 = a0 + (row0 + 1 < R ? lda : 0);
+   const double* a2 = a0 + (row0 + 2 < R ? 2 * lda : 0);
+   const double* a3 = a0 + (row0 + 3 < R ? 3 * lda : 0);
+   double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+   /* E even, all bases 16-byte aligned (checked by the caller) */
+   for (long long e = 2 * threadIdx.x; e + 1 < E; e += 512)
+   {
+      const dbl2 w = *reinterpret_cast<const dbl2*>(v + e);
+      const dbl2 x0 = *reinterpret_cast<const dbl2*>(a0 + e);
+      const dbl2 x1 = *reinterpret_cast<const dbl2*>(a1 + e);
+      const dbl2 x2 = *reinterpret_cast<const dbl2*>(a2 + e);
+      const dbl2 x3 = *reinterpret_cast<const dbl2*>(a3 + e);
+      acc0 += x0.x * w.x; acc0 += x0.y * w.y;
+      acc1 += x1.x * w.x; acc1 += x1.y * w.y;
+      acc2 += x2.x * w.x; acc2 += x2.y * w.y;
+      acc3 += x3.x * w.x; acc3 += x3.y * w.y;
+   }
+   if ( (E & 1) && threadIdx.x == 0 )
+   {
+      const double w = v[E - 1];
+      acc0 += a0[E - 1] * w; acc1 += a1[E - 1] * w; acc2 += a2[E - 1] * w; acc3 += a3[E - 1] * w;
+   }
+   const double r0 = block_reduce_256<OpSum>(acc0, sh);
+   const double r1 = block_reduce_256<OpSum>(acc1, sh);
+   const double r2 = block_reduce_256<OpSum>(acc2, sh);
+   const double r3 = block_reduce_256<OpSum>(acc3, sh);
+   if ( threadIdx.x == 0 )
+   {
+      out[row0] = r0;
+      if ( row0 + 1 < R ) out[row0 + 1] = r1;
+      if ( row0 + 2 < R ) out[row0 + 2] = r2;
+      if ( row0 + 3 < R ) out[row0 + 3] = r3;
+   }
+}
+
 __global__ void k_gemv_n_combine(int R, int nv, int nsplit, const double* __restrict__ part, long long ldp,
    double* __restrict__ out, long long ldo)
 {
@@ -854,6 +897,12 @@ static int gemv_n_launch(hipStream_t s, int R, long long E, const double* A, lon
       vv.v[v] = v < NV ? V[v] : V[0];
       if ( v < NV && (reinterpret_cast<uintptr_t>(V[v]) & 15) != 0 )
          vec = false;
+   }
+   if ( NV == 1 && vec && R >= 1024 && E >= (1LL << 18) )
+   {
+      hipLaunchKernelGGL(k_gemv_n_rows4, dim3((R + 3) / 4), dim3(256), 0, s, R, E, A, lda, vv.v[0], out);
+      HS_LAUNCH_CHECK();
+      return HS_OK;
    }
    /* enough workgroups to cover the chip: split long rows when there are few of them */
    int nsplit = 1;
