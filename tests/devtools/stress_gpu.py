@@ -12,7 +12,7 @@ import numpy as np, ipm_ref, checker
 def rand_core(rng):
     kind = rng.integers(0, 5)
     K = int(rng.integers(1, 4))
-    ns = [int(rng.choice([2, 3, 5, 9, 17, 33, 63, 64, 65, 70, 100])) for _ in range(K)]
+    ns = [int(rng.choice([2, 3, 5, 9, 16, 17, 32, 33, 63, 64, 65, 70, 100])) for _ in range(K)]
     if sum(n * n for n in ns) > 12000:
         ns = ns[:1]
     m = int(rng.choice([1, 2, 5, 13, 40, 64, 65, 129, 140, 200]))
