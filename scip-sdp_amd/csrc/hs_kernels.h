@@ -44,7 +44,9 @@ int hs_absmax(hipStream_t s, long long n, const double* a, double* out, int accu
 int hs_ratio_min(hipStream_t s, long long n, const double* x, const double* d, double* out, int accumulate, double* ws);
 
 /* H = s1 * Zinv - X - (GZ + GZ^T) / 2,  all n x n */
-/* n <= 32: out = s1 Zinv - X - sym((c X R + E) Zinv) in one launch (E may be NULL) */
+/* largest block size of the single-workgroup ("small") variants that keep whole matrices in LDS */
+#define HS_SMALL_N 48
+/* n <= HS_SMALL_N: out = s1 Zinv - X - sym((c X R + E) Zinv) in one launch (E may be NULL) */
 int hs_dir_block_small(hipStream_t s, int n, double c, const double* X, const double* R, const double* E, const double* Zinv,
    double s1, double* out);
 int hs_dirmat(hipStream_t s, int n, double s1, const double* Zinv, const double* X, const double* GZ, double* H);

@@ -1024,7 +1024,7 @@ static int direction(hipsdp_solver* s, double sigma, double eta, double mu, doub
    {
       const int n = B.n;
       const long long n2 = (long long) n * n;
-      if ( n <= 32 )
+      if ( n <= HS_SMALL_N )
          HS_CALL( hs_dir_block_small(s->stream, n, eta, B.X, B.Rd, useE ? B.E : NULL, B.Zinv, sigmu, B.H) );
       else
       {
@@ -1083,7 +1083,7 @@ static int direction(hipsdp_solver* s, double sigma, double eta, double mu, doub
       const int n = B.n;
       const long long n2 = (long long) n * n;
       HS_CALL( pass_AT(s, B, s->dyt, eta, B.Rd, B.dZ) );
-      if ( n <= 32 )
+      if ( n <= HS_SMALL_N )
          HS_CALL( hs_dir_block_small(s->stream, n, 1.0, B.X, B.dZ, useE ? B.E : NULL, B.Zinv, sigmu, B.dX) );
       else
       {

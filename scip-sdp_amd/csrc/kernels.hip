@@ -336,15 +336,20 @@ int hs_symmetrize(hipStream_t s, double* A, int n)
 __global__ void __launch_bounds__(256) k_dir_block_small(int n, double c, const double* __restrict__ X, const double* __restrict__ R,
    const double* __restrict__ E, const double* __restrict__ Zinv, double s1, double* __restrict__ out)
 {
-   __shared__ double sx[32][33], sr[32][33], sz[32][33], sg[32][33];
+   extern __shared__ double db_smem[];
+   const int ld = n + 1;
+   double* sx = db_smem;
+   double* sr = sx + n * ld;
+   double* sz = sr + n * ld;
+   double* sg = sz + n * ld;
    const int tid = threadIdx.x;
    const int n2 = n * n;
    for (int e = tid; e < n2; e += 256)
    {
       const int r = e / n, cc = e - r * n;
-      sx[r][cc] = X[e];
-      sr[r][cc] = R[e];
-      sz[r][cc] = Zinv[e];
+      sx[r * ld + cc] = X[e];
+      sr[r * ld + cc] = R[e];
+      sz[r * ld + cc] = Zinv[e];
    }
    __syncthreads();
    for (int e = tid; e < n2; e += 256)
@@ -352,11 +357,11 @@ __global__ void __launch_bounds__(256) k_dir_block_small(int n, double c, const 
       const int r = e / n, cc = e - r * n;
       double acc = 0.0;
       for (int k = 0; k < n; ++k)
-         acc += sx[r][k] * sr[k][cc];
+         acc += sx[r * ld + k] * sr[k * ld + cc];
       acc *= c;
       if ( E != NULL )
          acc += E[e];
-      sg[r][cc] = acc;
+      sg[r * ld + cc] = acc;
    }
    __syncthreads();
    /* GZ into sr (R is no longer needed) */
@@ -365,14 +370,14 @@ __global__ void __launch_bounds__(256) k_dir_block_small(int n, double c, const 
       const int r = e / n, cc = e - r * n;
       double acc = 0.0;
       for (int k = 0; k < n; ++k)
-         acc += sg[r][k] * sz[k][cc];
-      sr[r][cc] = acc;
+         acc += sg[r * ld + k] * sz[k * ld + cc];
+      sr[r * ld + cc] = acc;
    }
    __syncthreads();
    for (int e = tid; e < n2; e += 256)
    {
       const int r = e / n, cc = e - r * n;
-      out[e] = s1 * sz[r][cc] - sx[r][cc] - 0.5 * (sr[r][cc] + sr[cc][r]);
+      out[e] = s1 * sz[r * ld + cc] - sx[r * ld + cc] - 0.5 * (sr[r * ld + cc] + sr[cc * ld + r]);
    }
 }
 
@@ -380,8 +385,15 @@ int hs_dir_block_small(hipStream_t s, int n, double c, const double* X, const do
    double s1, double* out)
 {
    if ( n <= 0 ) return HS_OK;
-   if ( n > 32 ) return HS_ERR_ARG;
-   hipLaunchKernelGGL(k_dir_block_small, dim3(1), dim3(256), 0, s, n, c, X, R, E, Zinv, s1, out);
+   if ( n > HS_SMALL_N ) return HS_ERR_ARG;
+   static bool attr_set = false;
+   if ( !attr_set )
+   {
+      HS_HIP( hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dir_block_small), hipFuncAttributeMaxDynamicSharedMemorySize,
+            4 * HS_SMALL_N * (HS_SMALL_N + 1) * (int) sizeof(double)) );
+      attr_set = true;
+   }
+   hipLaunchKernelGGL(k_dir_block_small, dim3(1), dim3(256), (size_t) 4 * n * (n + 1) * sizeof(double), s, n, c, X, R, E, Zinv, s1, out);
    HS_LAUNCH_CHECK();
    return HS_OK;
 }

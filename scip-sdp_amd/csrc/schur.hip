@@ -178,7 +178,7 @@ void hs_shard_rows(int m1, int nranks, int rank, int* chunk_rows, int* first_beg
 
 
 /* ---- small problems: the whole extended Schur matrix in ONE launch ------------------------------------------------- */
-/* All blocks n <= 32: workgroup j forms U_j^k = X_k A_j^k Zinv_k in LDS for every block, then the entries (i, j), i >= j, of
+/* All blocks n <= HS_SMALL_N: workgroup j forms U_j^k = X_k A_j^k Zinv_k in LDS for every block, then the entries (i, j), i >= j, of
  *    Mx = sum_k <A_i^k, U_j^k> + Dext^T diag(x / z) Dext
  * and stores them symmetrically, together with the copies the factorization wants (Lm = Mx[1:, 1:], its diagonal).
  * Replaces fill + 3 GEMM launches per block + row scaling + GEMM + mirror + 2 strided copies: B&B-sized problems are bound
@@ -194,12 +194,18 @@ struct ss_args
    const double* Zinv[SS_MAXBLK];
 };
 
-__global__ void __launch_bounds__(256) k_schur_small(int m1, ss_args B, int q, const double* __restrict__ Dext,
+__global__ void __launch_bounds__(256) k_schur_small(int m1, int nmax, ss_args B, int q, const double* __restrict__ Dext,
    const double* __restrict__ x, const double* __restrict__ z, double* __restrict__ Mx, double* __restrict__ Lm,
    double* __restrict__ diagM)
 {
-   __shared__ double sx[32][33], sz[32][33], sa[32][33], st[32][33], su[32][33];
+   extern __shared__ double ss_smem[];
    __shared__ double colv[SS_MAXM1];
+   const int ldm = nmax + 1;
+   double* sx = ss_smem;
+   double* sz = sx + nmax * ldm;
+   double* sa = sz + nmax * ldm;
+   double* st = sa + nmax * ldm;
+   double* su = st + nmax * ldm;
    const int j = blockIdx.x;
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
    for (int i = tid; i < m1; i += 256)
@@ -213,9 +219,9 @@ __global__ void __launch_bounds__(256) k_schur_small(int m1, ss_args B, int q, c
       for (int e = tid; e < n2; e += 256)
       {
          const int r = e / n, c = e - r * n;
-         sx[r][c] = B.X[k][e];
-         sz[r][c] = B.Zinv[k][e];
-         sa[r][c] = Aj[e];
+         sx[r * ldm + c] = B.X[k][e];
+         sz[r * ldm + c] = B.Zinv[k][e];
+         sa[r * ldm + c] = Aj[e];
       }
       __syncthreads();
       for (int e = tid; e < n2; e += 256)
@@ -223,8 +229,8 @@ __global__ void __launch_bounds__(256) k_schur_small(int m1, ss_args B, int q, c
          const int r = e / n, c = e - r * n;
          double acc = 0.0;
          for (int t = 0; t < n; ++t)
-            acc += sx[r][t] * sa[t][c];
-         st[r][c] = acc;
+            acc += sx[r * ldm + t] * sa[t * ldm + c];
+         st[r * ldm + c] = acc;
       }
       __syncthreads();
       for (int e = tid; e < n2; e += 256)
@@ -232,8 +238,8 @@ __global__ void __launch_bounds__(256) k_schur_small(int m1, ss_args B, int q, c
          const int r = e / n, c = e - r * n;
          double acc = 0.0;
          for (int t = 0; t < n; ++t)
-            acc += st[r][t] * sz[t][c];
-         su[r][c] = acc;
+            acc += st[r * ldm + t] * sz[t * ldm + c];
+         su[r * ldm + c] = acc;
       }
       __syncthreads();
       /* <A_i, U_j> for i >= j: one wavefront per i */
@@ -244,7 +250,7 @@ __global__ void __launch_bounds__(256) k_schur_small(int m1, ss_args B, int q, c
          for (int e = lane; e < n2; e += 64)
          {
             const int r = e / n, c = e - r * n;
-            acc += Ai[e] * su[r][c];
+            acc += Ai[e] * su[r * ldm + c];
          }
 #pragma unroll
          for (int off = 32; off > 0; off >>= 1)
@@ -290,17 +296,29 @@ int hs_schur_small(hipStream_t s, int m1, int nblk, const int* n, const double* 
       return 0;
    ss_args B;
    B.nblk = nblk;
+   int nmax = 1;
    for (int k = 0; k < nblk; ++k)
    {
-      if ( n[k] > 32 || n[k] < 1 )
+      if ( n[k] > HS_SMALL_N || n[k] < 1 )
          return 0;
+      if ( n[k] > nmax )
+         nmax = n[k];
       B.n[k] = n[k]; B.A[k] = A[k]; B.X[k] = X[k]; B.Zinv[k] = Zinv[k];
    }
    for (int k = nblk; k < SS_MAXBLK; ++k)
    {
       B.n[k] = 0; B.A[k] = NULL; B.X[k] = NULL; B.Zinv[k] = NULL;
    }
-   hipLaunchKernelGGL(k_schur_small, dim3(m1), dim3(256), 0, s, m1, B, q, Dext, x, z, Mx, Lm, diagM);
+   static bool attr_set = false;
+   if ( !attr_set )
+   {
+      if ( hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_small), hipFuncAttributeMaxDynamicSharedMemorySize,
+            5 * HS_SMALL_N * (HS_SMALL_N + 1) * (int) sizeof(double)) != hipSuccess )
+         return -HS_ERR_HIP;
+      attr_set = true;
+   }
+   hipLaunchKernelGGL(k_schur_small, dim3(m1), dim3(256), (size_t) 5 * nmax * (nmax + 1) * sizeof(double), s, m1, nmax, B, q, Dext, x, z,
+      Mx, Lm, diagM);
    if ( hipGetLastError() != hipSuccess )
       return -HS_ERR_HIP;
    return 1;
