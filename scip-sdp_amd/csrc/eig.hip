@@ -444,6 +444,168 @@ static int hs_lanczos_lmin_unfused(hipStream_t s, int n, const double* W, int ma
    return HS_OK;
 }
 
+/* ---- 16 < n <= 64: the whole Lanczos run in ONE launch --------------------------------------------------------------- */
+/* One workgroup per matrix (blockIdx.x = X side / Z side).  W = L D L^T is formed in LDS, then k Lanczos steps with
+ * twice-applied classical Gram-Schmidt run with W and the basis in LDS, and wavefront 0 solves the tridiagonal problem.
+ * Same algorithm and start vector as k_lanczos_fused; replaces 4 GEMM launches + k + 1 launches per pair of estimates. */
+#define LS_MAXK 32
+__global__ void __launch_bounds__(256) k_lanczos_small(int n, int k, const double* __restrict__ D0, const double* __restrict__ D1,
+   double* __restrict__ res0, double* __restrict__ res1, const double* __restrict__ L0, const double* __restrict__ L1)
+{
+   extern __shared__ double lz2_smem[];
+   __shared__ double alpha[LS_MAXK], beta[LS_MAXK], coef[LS_MAXK + 1];
+   __shared__ double shr[4];
+   __shared__ tridiag_smem T;
+   const double* __restrict__ Din = blockIdx.x ? D1 : D0;
+   const double* __restrict__ Lin = blockIdx.x ? L1 : L0;
+   double* __restrict__ res = blockIdx.x ? res1 : res0;
+   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   const int ld = n + 1;
+   double* w = lz2_smem;                /* n x ld: W */
+   double* sl = w + n * ld;             /* L, later the Lanczos basis Q[(k + 1)][n] */
+   double* st = sl + n * ld;            /* L D, later v */
+   for (int e = tid; e < n * n; e += 256)
+   {
+      const int r = e / n, c = e - r * n;
+      sl[r * ld + c] = Lin[e];
+      w[r * ld + c] = Din[e];
+   }
+   __syncthreads();
+   for (int e = tid; e < n * n; e += 256)
+   {
+      const int r = e / n, c = e - r * n;
+      double acc = 0.0;
+      for (int t = 0; t < n; ++t)
+         acc += sl[r * ld + t] * w[t * ld + c];
+      st[r * ld + c] = acc;
+   }
+   __syncthreads();
+   {
+      /* W = (L D) L^T, symmetrised; each thread keeps its entries in registers across the barrier (n^2 <= 16 per thread) */
+      double keep[16];
+      int cnt = 0;
+      for (int e = tid; e < n * n; e += 256)
+      {
+         const int r = e / n, c = e - r * n;
+         double acc = 0.0, acct = 0.0;
+         for (int t = 0; t < n; ++t)
+         {
+            acc += st[r * ld + t] * sl[c * ld + t];
+            acct += st[c * ld + t] * sl[r * ld + t];
+         }
+         keep[cnt++] = 0.5 * (acc + acct);
+      }
+      __syncthreads();
+      cnt = 0;
+      for (int e = tid; e < n * n; e += 256)
+      {
+         const int r = e / n, c = e - r * n;
+         w[r * ld + c] = keep[cnt++];
+      }
+   }
+   __syncthreads();
+   double* Q = sl;                      /* (k + 1) x n, k + 1 <= n + 1 rows of length n fit in n x ld */
+   double* v = st;
+   /* start vector */
+   double sacc = 0.0;
+   if ( tid < n )
+   {
+      unsigned long long h = (unsigned long long) (tid + 1) * 0x9E3779B97F4A7C15ULL;
+      h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ULL; h ^= h >> 32;
+      const double q0 = 0.5 + (double) (h >> 11) * (1.0 / 9007199254740992.0);
+      v[tid] = q0;
+      sacc = q0 * q0;
+   }
+   sacc = wsum(sacc);
+   if ( lane == 0 ) shr[wave] = sacc;
+   __syncthreads();
+   {
+      const double inv = 1.0 / sqrt(shr[0] + shr[1] + shr[2] + shr[3]);
+      if ( tid < n )
+         Q[tid] = v[tid] * inv;
+   }
+   __syncthreads();
+   double scale = 0.0;
+   int kbreak = -1;
+   for (int j = 0; j < k; ++j)
+   {
+      const double* qj = Q + j * n;
+      /* v = W q_j */
+      if ( tid < n )
+      {
+         double acc = 0.0;
+         for (int t = 0; t < n; ++t)
+            acc += w[tid * ld + t] * qj[t];
+         v[tid] = acc;
+      }
+      __syncthreads();
+      double aj = 0.0;
+      for (int pass = 0; pass < 2; ++pass)
+      {
+         /* c_i = q_i . v : one wavefront per i */
+         for (int i = wave; i <= j; i += 4)
+         {
+            const double* q = Q + i * n;
+            const double pr = (lane < n) ? q[lane] * v[lane] : 0.0;
+            const double sm = wsum(pr);
+            if ( lane == 0 )
+               coef[i] = sm;
+         }
+         __syncthreads();
+         if ( pass == 0 )
+            aj = coef[j];
+         if ( tid < n )
+         {
+            double acc = v[tid];
+            for (int i = 0; i <= j; ++i)
+               acc -= coef[i] * Q[i * n + tid];
+            v[tid] = acc;
+         }
+         __syncthreads();
+      }
+      double nr = (tid < n) ? v[tid] * v[tid] : 0.0;
+      nr = wsum(nr);
+      if ( lane == 0 ) shr[wave] = nr;
+      __syncthreads();
+      const double b = sqrt(shr[0] + shr[1] + shr[2] + shr[3]);
+      __syncthreads();
+      if ( fabs(aj) + b > scale )
+         scale = fabs(aj) + b;
+      const bool broke = (kbreak >= 0) || !(b > 1e-13 * scale) || !(b > 1e-300);
+      if ( tid == 0 )
+      {
+         alpha[j] = aj;
+         beta[j] = broke ? 0.0 : b;
+      }
+      if ( broke && kbreak < 0 )
+         kbreak = j;
+      if ( tid < n )
+         Q[(j + 1) * n + tid] = broke ? 0.0 : v[tid] / b;
+      __syncthreads();
+   }
+   if ( wave == 0 )
+      tridiag_min_wave(k, alpha, beta, (double) kbreak, -1, 0.0, 0.0, res, T);
+}
+
+int hs_lanczos_scaled_small(hipStream_t s, int n, int maxsteps, const double* L0, const double* D0, const double* L1, const double* D1,
+   double* res0, double* res1)
+{
+   if ( n <= 16 || n > 64 )
+      return HS_ERR_ARG;
+   int k = maxsteps < n ? maxsteps : n;
+   if ( k > LS_MAXK ) k = LS_MAXK;
+   static bool attr_set = false;
+   if ( !attr_set )
+   {
+      HS_HIP( hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lanczos_small), hipFuncAttributeMaxDynamicSharedMemorySize,
+            3 * 64 * 65 * (int) sizeof(double)) );
+      attr_set = true;
+   }
+   hipLaunchKernelGGL(k_lanczos_small, dim3(2), dim3(256), (size_t) 3 * n * (n + 1) * sizeof(double), s, n, k, D0, D1, res0, res1, L0, L1);
+   HS_LAUNCH_CHECK();
+   return HS_OK;
+}
+
 static void lanczos_job_init(lanczos_job* J, int n, int maxsteps, const double* W, double* res, double* ws)
 {
    J->W = W;

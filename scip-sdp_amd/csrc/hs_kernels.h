@@ -123,6 +123,10 @@ int hs_trsv_sync(hipStream_t s, int n, const double* L, const double* dinv, int 
  * ws: (maxsteps + 2) * n + 4 * maxsteps + 64 doubles. */
 int hs_lanczos_lmin(hipStream_t s, int n, const double* W, int maxsteps, double* res, double* ws);
 long long hs_lanczos_ws(int n, int maxsteps);
+/* 16 < n <= 64: lambda_min(L0 D0 L0^T), lambda_min(L1 D1 L1^T) by Lanczos with the products, all steps and the tridiagonal
+ * problem in one launch */
+int hs_lanczos_scaled_small(hipStream_t s, int n, int maxsteps, const double* L0, const double* D0, const double* L1, const double* D1,
+   double* res0, double* res1);
 int hs_lmin_scaled_tiny(hipStream_t s, int n, const double* L0, const double* D0, const double* L1, const double* D1, double* res0,
    double* res1);
 int hs_lanczos_lmin2(hipStream_t s, int n, const double* W0, const double* W1, int maxsteps, double* res0, double* res1,

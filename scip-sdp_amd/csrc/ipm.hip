@@ -1122,8 +1122,8 @@ static int steplen_enqueue(hipsdp_solver* s)
    for (auto& B : s->blk)
    {
       const int n = B.n;
-      if ( n <= 16 )
-         continue;                   /* products and eigenvalues of tiny blocks share one launch below */
+      if ( n <= 64 )
+         continue;                   /* products and eigenvalues of small blocks share one launch below */
       HS_CALL( gemm_on(st, s->gws1, s->gws_len, HS_KC, HS_MC, n, n, n, 1.0, B.LxInv, n, B.dX, n, 0.0, B.T1, n) );
       HS_CALL( gemm_on(st, s->gws1, s->gws_len, HS_KC, HS_KC, n, n, n, 1.0, B.T1, n, B.LxInv, n, 0.0, B.W, n) );
       HS_CALL( gemm_on(st2, s->gws2, s->gws_len, HS_KC, HS_MC, n, n, n, 1.0, B.LzInv, n, B.dZ, n, 0.0, B.T2, n) );
@@ -1135,6 +1135,9 @@ static int steplen_enqueue(hipsdp_solver* s)
    {
       if ( B.n <= 16 )
          HS_CALL( hs_lmin_scaled_tiny(st, B.n, B.LxInv, B.dX, B.LzInv, B.dZ, s->sc + SC_BLK(k, 1), s->sc + SC_BLK(k, 4)) );
+      else if ( B.n <= 64 )
+         HS_CALL( hs_lanczos_scaled_small(st, B.n, s->par.lanczos_steps, B.LxInv, B.dX, B.LzInv, B.dZ, s->sc + SC_BLK(k, 1),
+               s->sc + SC_BLK(k, 4)) );
       else
          HS_CALL( hs_lanczos_lmin2(st, B.n, B.W, B.W2, s->par.lanczos_steps, s->sc + SC_BLK(k, 1), s->sc + SC_BLK(k, 4), s->lan_ws,
                s->lan_ws2) );
