@@ -128,11 +128,17 @@ int  hipsdp_get_lp(hipsdp_solver* solver, double* x, double* z);
  * sdpsolchecker.c:201-257 inside the backend); y: m host values; lmin: nblocks host values */
 int  hipsdp_check_y(hipsdp_solver* solver, const double* y, double* lmin, double* lpviol);
 
-/* multi-GPU: Schur rows are sharded over the ranks of an RCCL communicator (one process per GPU); comm is a ncclComm_t */
+/* multi-GPU: Schur rows are sharded over the ranks of an RCCL communicator (one process per GPU); comm comes from hipsdp_comm_create[_host] */
 int  hipsdp_set_comm(hipsdp_solver* solver, void* comm, int rank, int nranks);
+/* host-only helper: column ranges of the sharded assembly, bounds[0 .. nranks]; rank g owns [bounds[g], bounds[g + 1]) */
+int  hipsdp_shard_columns(int m1, int n, int nranks, int* bounds);
 int  hipsdp_comm_create(const void* unique_id_128bytes, int rank, int nranks, void** comm);
 int  hipsdp_comm_unique_id(void* unique_id_128bytes);
 void hipsdp_comm_destroy(void* comm);
+/* host-staged communicator for several ranks on ONE device (RCCL refuses that): payloads travel through the POSIX
+ * shared-memory segment `name` ("/something", unique per job; every rank passes the same name and staging size).  Same
+ * collectives, same results; meant for validating the sharded path on a one-GPU machine, not for speed. */
+int  hipsdp_comm_create_host(const char* name, int rank, int nranks, long long staging_bytes, double timeout_seconds, void** comm);
 
 /* Synthetic instance of BASELINE.md section 3 generated in HBM.  The solver must have the shape (m, one block of size n,
  * q = 0).  Fills A_1..A_m from the counter stream of oracle/instances.py (seed + i), then plants the optimum the caller
@@ -156,6 +162,9 @@ int  hipsdp_schur_dense(int device, int m1, int n, const double* A, const double
    double ws_gbytes);
 /* the same matrix through the W formulation (W_j = G A_j R, Mx = W W^T); takes X and Z, factors them on the device */
 int  hipsdp_schur_w(int device, int m1, int n, const double* A, const double* X, const double* Z, double* Mx);
+/* milliseconds one rank of an nranks-way sharded assembly spends on its share of the Schur matrix (by_columns: column slices
+ * of the W formulation, else row chunks of the U formulation); synthetic operands made in HBM */
+int  hipsdp_schur_shard_time(int device, int m1, int n, int nranks, int rank, int by_columns, int reps, double ws_gbytes, double* ms);
 int  hipsdp_potrf(int device, int n, double* A, int* fail);                       /* lower Cholesky in place, row-major */
 int  hipsdp_potrs(int device, int n, const double* A, int nrhs, double* rhs);     /* factor + solve, rhs[k * n + i] */
 int  hipsdp_trtri(int device, int n, const double* A, double* Linv);              /* A spd -> inverse of its Cholesky factor */

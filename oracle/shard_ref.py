@@ -2,7 +2,11 @@
 (scip-sdp_amd/csrc/schur.hip: hs_shard_rows / hs_schur_Urows, and the all-gather sequence in csrc/ipm.hip), used by the
 world_size-2 gloo test.  Rank g of G computes two row chunks of the upper triangle, chunk g and chunk 2G-1-g of
 c = ceil(m1 / 2G) rows each (equal triangle area per rank); chunks 0..G-1 are gathered in place, chunks G..2G-1 arrive in
-reverse rank order and are copied to their rows; finally the upper triangle is mirrored."""
+reverse rank order and are copied to their rows; finally the upper triangle is mirrored.
+
+Second form (the default of the engine with several ranks; hs_shard_cols / hs_schur_Wcols + one all-reduce): with X = R R^T,
+Z^-1 = G^T G and W_j = G A_j R, Mx = sum over the entries (r, c) of the W_j; the rank that owns the columns [c0, c0 + cw)
+adds W[:, :, c0:c0+cw] flattened times its transpose, and the partial matrices are summed over the ranks."""
 import numpy as np
 
 
@@ -44,3 +48,51 @@ def assemble(m1, nranks, c, first_chunks, second_chunks):
     Mx = Mx[:m1]
     up = np.triu(Mx)
     return up + np.triu(Mx, 1).T
+
+
+def shard_cols(m1, n, nranks):
+    """restatement of hs_shard_cols: boundaries at multiples of 16, minimal slowest rank under the cost model of schur.hip
+    (width rounded up to the 128-wide tile in the two triangular products, plain width in W W^T)"""
+    gran = 16
+    P = (n + gran - 1) // gran
+    col = lambda p: min(p * gran, n)
+
+    def cost(p0, p1):
+        c0, w = col(p0), col(p1) - col(p0)
+        if w <= 0:
+            return 0.0
+        wt = 128.0 * ((w + 127) // 128)
+        return wt * (2.0 * (n - c0 - 0.5 * w) + n) + float(w) * m1
+
+    prev = [1e300] * (P + 1)
+    prev[0] = 0.0
+    frm = [[0] * (P + 1) for _ in range(nranks + 1)]
+    for g in range(1, nranks + 1):
+        cur = [1e300] * (P + 1)
+        for p in range(P + 1):
+            b, arg = 1e300, 0
+            for q in range(p + 1):
+                if prev[q] >= 1e300:
+                    continue
+                v = max(prev[q], cost(q, p))
+                if v < b:
+                    b, arg = v, q
+            cur[p], frm[g][p] = b, arg
+        prev = cur
+    bounds = [0] * (nranks + 1)
+    bounds[nranks] = n
+    p = P
+    for g in range(nranks, 0, -1):
+        p = frm[g][p]
+        bounds[g - 1] = col(p)
+    return bounds
+
+
+def column_slice_contribution(A, R, G, c0, cw):
+    """what hs_schur_Wcols adds for the columns [c0, c0 + cw): W_slice W_slice^T with W_j = G A_j R"""
+    m1, n, _ = A.shape
+    if cw <= 0:
+        return np.zeros((m1, m1))
+    T = A[:, :, c0:] @ R[c0:, c0:c0 + cw]           # R lower triangular: rows < c0 of these columns are zero
+    W = np.matmul(G, T).reshape(m1, -1)
+    return W @ W.T

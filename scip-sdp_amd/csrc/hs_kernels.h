@@ -71,6 +71,7 @@ struct hs_schur_ws
    double*   U;            /* chunk_cols x n^2 */
    double*   K;            /* split-K slabs */
    long long chunk_cols;
+   long long n2;           /* doubles per matrix the allocation was sized for */
    long long kws_len;
    int       full;         /* 1: T and U hold all m1 matrices (hs_schur_W usable) */
 };
@@ -86,6 +87,12 @@ int  hs_schur_W(hipStream_t s, int m1, int n, const double* A, const double* R, 
 int  hs_schur_Urows(hipStream_t s, int m1, int n, const double* A, const double* X, const double* Zinv, double* Mx,
    hs_schur_ws* w, int r_begin, int r_end);
 void hs_shard_rows(int m1, int nranks, int rank, int* chunk_rows, int* first_begin, int* second_begin);
+/* column-slice sharding of the W formulation: this rank's share [c0, c0 + cw) of the columns of the W_j, accumulated into the
+ * lower tiles of Mx; the ranks' partial matrices add up to the Schur matrix (all-reduce) */
+int  hs_schur_Wcols(hipStream_t s, int m1, int n, const double* A, const double* R, const double* G, double* Mx, hs_schur_ws* w,
+   int c0, int cw);
+void hs_shard_cols(int m1, int n, int nranks, int rank, int* c_begin, int* c_width);
+int  hs_allreduce_sum(void* comm, double* buf, long long count, hipStream_t stream);
 int  hs_mirror_upper(hipStream_t s, double* A, int n, long long lda);                       /* A[i][j] = A[j][i] for i > j */
 /* multi.hip: in-place all-gather of equal pieces, piece of rank r at buf + r * count */
 int  hs_allgather_inplace(void* comm, double* buf, long long count_per_rank, int rank, hipStream_t stream);

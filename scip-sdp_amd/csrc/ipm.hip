@@ -93,6 +93,8 @@ struct hipsdp_solver
    int* flags;       /* device ints: 0 chol Z, 1 chol X, 2 chol M */
    hs_schur_ws sws;
    bool schur_mode_U, schur_mode_rows;
+   bool schur_mode_cols;        /* several ranks (or HIPSDP_SCHUR=K<shards>): column slices of the W formulation + all-reduce */
+   int  schur_sim_shards;       /* HIPSDP_SCHUR=K<shards> without a communicator: all slices on this device, one after the other */
    bool schur_mode_forced;      /* HIPSDP_SCHUR set: the single-launch assembly of small problems is not used either */
    double* Mgather;
    long long mx_rows;
@@ -207,6 +209,7 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
    s->master_nvars = 0;
    s->Mgather = NULL;
    s->schur_mode_rows = false;
+   s->schur_mode_cols = false; s->schur_sim_shards = 0;
    s->sws.T = s->sws.U = s->sws.K = NULL;
    s->flags = NULL;
    s->hsc = NULL;
@@ -799,8 +802,32 @@ static int ensure_schur_ws(hipsdp_solver* s)
    const char* env = getenv("HIPSDP_WS_GB");
    if ( env != NULL && atof(env) > 0.0 )
       budget = atof(env);
-   HS_CALL( hs_schur_ws_alloc(&s->sws, m1, n2max, budget) );
    const char* mode = getenv("HIPSDP_SCHUR");
+   s->schur_mode_cols = false;
+   s->schur_sim_shards = 0;
+   int shards = s->comm != NULL ? s->nranks : 0;
+   if ( s->comm == NULL && mode != NULL && mode[0] == 'K' && atoi(mode + 1) >= 1 && atoi(mode + 1) <= 64 )
+      shards = s->schur_sim_shards = atoi(mode + 1);
+   if ( shards > 0 && !(mode != NULL && (mode[0] == 'R' || mode[0] == 'U')) )
+   {
+      /* column slices: the workspace holds the widest slice any rank gets (every rank derives the same number, so all
+       * ranks take the same branch - the two sharded forms use different collectives) */
+      long long slice_max = 1;
+      for (auto& B : s->blk)
+         for (int g = 0; g < shards; ++g)
+         {
+            int c0, cw;
+            hs_shard_cols(m1, B.n, shards, g, &c0, &cw);
+            if ( (long long) B.n * cw > slice_max ) slice_max = (long long) B.n * cw;
+         }
+      if ( 2.0 * 8.0 * (double) m1 * (double) slice_max <= budget * 1e9 )
+      {
+         HS_CALL( hs_schur_ws_alloc(&s->sws, m1, slice_max, budget) );
+         s->schur_mode_cols = true;
+      }
+   }
+   if ( !s->schur_mode_cols )
+      HS_CALL( hs_schur_ws_alloc(&s->sws, m1, n2max, budget) );
    s->schur_mode_U = (mode != NULL && mode[0] == 'U') || !s->sws.full || s->comm != NULL;
    s->schur_mode_rows = (mode != NULL && mode[0] == 'R');
    s->schur_mode_forced = (mode != NULL);
@@ -1556,7 +1583,21 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       else
       {
       HS_CALL( hs_fill(st, s->Mx, (long long) m1 * m1, 0.0) );
-      if ( s->comm != NULL || s->schur_mode_rows )
+      if ( s->schur_mode_cols )
+      {
+         /* sharded assembly, W formulation: this rank's column slice of every W_j, partial matrices summed over the ranks */
+         const int shards = s->comm != NULL ? s->nranks : s->schur_sim_shards;
+         for (int g = (s->comm != NULL ? s->rank : 0); g < (s->comm != NULL ? s->rank + 1 : shards); ++g)
+            for (auto& B : s->blk)
+            {
+               int c0, cw;
+               hs_shard_cols(m1, B.n, shards, g, &c0, &cw);
+               HS_CALL( hs_schur_Wcols(st, m1, B.n, B.A, B.Lx, B.LzInv, s->Mx, &s->sws, c0, cw) );
+            }
+         if ( s->comm != NULL )
+            HS_CALL( hs_allreduce_sum(s->comm, s->Mx, (long long) m1 * m1, st) );
+      }
+      else if ( s->comm != NULL || s->schur_mode_rows )
       {
          /* sharded assembly: this rank computes two row chunks of the upper triangle, the chunks are all-gathered */
          int c, b1, b2;
@@ -1931,6 +1972,21 @@ extern "C" int hipsdp_check_y(hipsdp_solver* s, const double* y, double* lmin, d
       lmin[b] = h.v[SC_BLK(b, 1)] - h.v[SC_BLK(b, 2)];
    if ( lpviol != NULL )
       *lpviol = q > 0 ? fmax(0.0, -h.v[SC_RATX]) : 0.0;
+   return HIPSDP_OK;
+}
+
+/* host-only: the column ranges of the sharded W formulation, bounds[0 .. nranks] (rank g owns [bounds[g], bounds[g + 1])) */
+extern "C" int hipsdp_shard_columns(int m1, int n, int nranks, int* bounds)
+{
+   if ( m1 < 1 || n < 1 || nranks < 1 || nranks > 64 || bounds == NULL )
+      return HIPSDP_ERR_ARG;
+   for (int g = 0; g < nranks; ++g)
+   {
+      int c0, cw;
+      hs_shard_cols(m1, n, nranks, g, &c0, &cw);
+      bounds[g] = c0;
+      bounds[g + 1] = c0 + cw;
+   }
    return HIPSDP_OK;
 }
 

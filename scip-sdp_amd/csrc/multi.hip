@@ -1,9 +1,136 @@
-/* multi.hip - RCCL plumbing (one process per GPU).  The communicator is created from a unique id that the launcher
- * (bench.py via torch.distributed, or any MPI-like bootstrap) broadcasts; the engine only sees an opaque pointer. */
+/* multi.hip - inter-rank plumbing (one process per GPU).
+ *
+ * Two transports sit behind the same four collectives the engine uses (all-gather of Schur row chunks, broadcast of the
+ * scalar block and the flags):
+ *   - RCCL over xGMI: the production transport.  The communicator is created from a unique id that the launcher
+ *     (bench.py via torch.distributed, or any MPI-like bootstrap) broadcasts.
+ *   - host-staged: a POSIX shared-memory segment with a generation barrier; payloads go device -> segment -> device.
+ *     RCCL refuses two ranks on one device, so this is how the sharded path is exercised by several processes on a
+ *     one-GPU box (tests/test_gpu_multi.py).  It moves bytes only - every flop still runs on the device. */
 #include "hs_kernels.h"
 #include "../../include/hipsdp.h"
 #include <rccl/rccl.h>
+#include <atomic>
+#include <chrono>
 #include <cstring>
+#include <cstdio>
+#include <new>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+namespace {
+
+struct shm_header
+{
+   std::atomic<int> arrived;
+   std::atomic<int> generation;
+   std::atomic<int> failed;
+   int pad[13];
+};
+
+struct hs_comm
+{
+   int kind;               /* 0 = RCCL, 1 = host-staged */
+   int rank, nranks;
+   ncclComm_t nccl;
+   /* host-staged */
+   char name[96];
+   shm_header* hdr;
+   char* data;
+   size_t data_bytes;
+   size_t map_bytes;
+   double timeout_s;
+};
+
+/* generation barrier; a rank that times out marks the segment failed so that the others leave as well */
+int shm_barrier(hs_comm* c)
+{
+   shm_header* h = c->hdr;
+   const int gen = h->generation.load(std::memory_order_acquire);
+   if ( h->arrived.fetch_add(1, std::memory_order_acq_rel) == c->nranks - 1 )
+   {
+      h->arrived.store(0, std::memory_order_relaxed);
+      h->generation.store(gen + 1, std::memory_order_release);
+      return HS_OK;
+   }
+   const auto t0 = std::chrono::steady_clock::now();
+   long long spins = 0;
+   while ( h->generation.load(std::memory_order_acquire) == gen )
+   {
+      if ( h->failed.load(std::memory_order_relaxed) )
+         return HS_ERR_HIP;
+      if ( (++spins & 1023) == 0 )
+      {
+         const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+         if ( el > c->timeout_s )
+         {
+            h->failed.store(1, std::memory_order_relaxed);
+            fprintf(stderr, "hipsdp: host-staged communicator: rank %d waited %.0f s at a barrier\n", c->rank, el);
+            return HS_ERR_HIP;
+         }
+         sched_yield();
+      }
+   }
+   return HS_OK;
+}
+
+/* all ranks contribute bytes_per_rank from send (device); everyone receives the concatenation in recv (device) */
+int shm_allgather(hs_comm* c, const char* send, char* recv, size_t bytes_per_rank, hipStream_t stream)
+{
+   const size_t piece_max = c->data_bytes / (size_t) c->nranks & ~(size_t) 7;
+   if ( piece_max == 0 )
+      return HS_ERR_ARG;
+   for (size_t off = 0; off < bytes_per_rank; off += piece_max)
+   {
+      const size_t piece = bytes_per_rank - off < piece_max ? bytes_per_rank - off : piece_max;
+      HS_HIP( hipMemcpyAsync(c->data + (size_t) c->rank * piece, send + off, piece, hipMemcpyDeviceToHost, stream) );
+      HS_HIP( hipStreamSynchronize(stream) );
+      HS_CALL( shm_barrier(c) );
+      for (int r = 0; r < c->nranks; ++r)
+         HS_HIP( hipMemcpyAsync(recv + (size_t) r * bytes_per_rank + off, c->data + (size_t) r * piece, piece, hipMemcpyHostToDevice, stream) );
+      HS_HIP( hipStreamSynchronize(stream) );
+      HS_CALL( shm_barrier(c) );       /* nobody overwrites the segment before everyone has read it */
+   }
+   return HS_OK;
+}
+
+int shm_bcast(hs_comm* c, char* buf, size_t bytes, hipStream_t stream)
+{
+   for (size_t off = 0; off < bytes; off += c->data_bytes)
+   {
+      const size_t piece = bytes - off < c->data_bytes ? bytes - off : c->data_bytes;
+      if ( c->rank == 0 )
+      {
+         HS_HIP( hipMemcpyAsync(c->data, buf + off, piece, hipMemcpyDeviceToHost, stream) );
+         HS_HIP( hipStreamSynchronize(stream) );
+      }
+      HS_CALL( shm_barrier(c) );
+      if ( c->rank != 0 )
+      {
+         HS_HIP( hipMemcpyAsync(buf + off, c->data, piece, hipMemcpyHostToDevice, stream) );
+         HS_HIP( hipStreamSynchronize(stream) );
+      }
+      HS_CALL( shm_barrier(c) );
+   }
+   return HS_OK;
+}
+
+/* buf[i] = sum over ranks of part[r][i], added in rank order on every rank (identical bits everywhere) */
+__global__ void k_sum_parts(long long count, int nparts, const double* __restrict__ part, double* __restrict__ buf)
+{
+   for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long) gridDim.x * blockDim.x)
+   {
+      double acc = part[i];
+      for (int r = 1; r < nparts; ++r)
+         acc += part[(long long) r * count + i];
+      buf[i] = acc;
+   }
+}
+
+} /* namespace */
 
 extern "C" int hipsdp_comm_unique_id(void* unique_id_128bytes)
 {
@@ -17,45 +144,144 @@ extern "C" int hipsdp_comm_unique_id(void* unique_id_128bytes)
 
 extern "C" int hipsdp_comm_create(const void* unique_id_128bytes, int rank, int nranks, void** comm)
 {
+   if ( comm == NULL || unique_id_128bytes == NULL || nranks < 1 || rank < 0 || rank >= nranks )
+      return HIPSDP_ERR_ARG;
    ncclUniqueId id;
    memcpy(&id, unique_id_128bytes, sizeof(id));
-   ncclComm_t c;
-   if ( ncclCommInitRank(&c, nranks, id, rank) != ncclSuccess )
+   hs_comm* c = new (std::nothrow) hs_comm();
+   if ( c == NULL )
+      return HIPSDP_ERR_NOMEM;
+   c->kind = 0; c->rank = rank; c->nranks = nranks;
+   if ( ncclCommInitRank(&c->nccl, nranks, id, rank) != ncclSuccess )
+   {
+      delete c;
       return HIPSDP_ERR_HIP;
+   }
+   *comm = (void*) c;
+   return HIPSDP_OK;
+}
+
+extern "C" int hipsdp_comm_create_host(const char* name, int rank, int nranks, long long staging_bytes, double timeout_seconds,
+   void** comm)
+{
+   if ( comm == NULL || name == NULL || name[0] != '/' || strlen(name) >= sizeof(((hs_comm*) 0)->name) || nranks < 1 || rank < 0
+      || rank >= nranks || staging_bytes < 4096 )
+      return HIPSDP_ERR_ARG;
+   hs_comm* c = new (std::nothrow) hs_comm();
+   if ( c == NULL )
+      return HIPSDP_ERR_NOMEM;
+   c->kind = 1; c->rank = rank; c->nranks = nranks; c->nccl = NULL;
+   c->timeout_s = timeout_seconds > 0.0 ? timeout_seconds : 120.0;
+   strcpy(c->name, name);
+   c->data_bytes = (size_t) staging_bytes & ~(size_t) 63;
+   c->map_bytes = sizeof(shm_header) + c->data_bytes;
+   /* every rank opens-or-creates and sizes the segment; fresh pages are zero, which is the initial barrier state */
+   const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+   if ( fd < 0 || ftruncate(fd, (off_t) c->map_bytes) != 0 )
+   {
+      if ( fd >= 0 ) close(fd);
+      delete c;
+      fprintf(stderr, "hipsdp: host-staged communicator: cannot create %s\n", name);
+      return HIPSDP_ERR_HIP;
+   }
+   void* p = mmap(NULL, c->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+   close(fd);
+   if ( p == MAP_FAILED )
+   {
+      delete c;
+      return HIPSDP_ERR_NOMEM;
+   }
+   c->hdr = (shm_header*) p;
+   c->data = (char*) p + sizeof(shm_header);
+   /* once everyone has mapped it the name can go: the memory lives until the last unmap */
+   const int rc = shm_barrier(c);
+   if ( rank == 0 )
+      shm_unlink(name);
+   if ( rc != HS_OK )
+   {
+      munmap(p, c->map_bytes);
+      delete c;
+      return HIPSDP_ERR_HIP;
+   }
    *comm = (void*) c;
    return HIPSDP_OK;
 }
 
 extern "C" void hipsdp_comm_destroy(void* comm)
 {
-   if ( comm != NULL )
-      (void) ncclCommDestroy((ncclComm_t) comm);
+   hs_comm* c = (hs_comm*) comm;
+   if ( c == NULL )
+      return;
+   if ( c->kind == 0 )
+      (void) ncclCommDestroy(c->nccl);
+   else
+      munmap((void*) c->hdr, c->map_bytes);
+   delete c;
 }
 
 int hs_allgather_inplace(void* comm, double* buf, long long count_per_rank, int rank, hipStream_t stream)
 {
-   if ( ncclAllGather(buf + (long long) rank * count_per_rank, buf, (size_t) count_per_rank, ncclDouble, (ncclComm_t) comm, stream) != ncclSuccess )
+   hs_comm* c = (hs_comm*) comm;
+   if ( c->kind == 1 )
+      return shm_allgather(c, (const char*) (buf + (long long) rank * count_per_rank), (char*) buf, (size_t) count_per_rank * sizeof(double), stream);
+   if ( ncclAllGather(buf + (long long) rank * count_per_rank, buf, (size_t) count_per_rank, ncclDouble, c->nccl, stream) != ncclSuccess )
       return HS_ERR_HIP;
    return HS_OK;
 }
 
 int hs_allgather(void* comm, const double* send, double* recv, long long count_per_rank, hipStream_t stream)
 {
-   if ( ncclAllGather(send, recv, (size_t) count_per_rank, ncclDouble, (ncclComm_t) comm, stream) != ncclSuccess )
+   hs_comm* c = (hs_comm*) comm;
+   if ( c->kind == 1 )
+      return shm_allgather(c, (const char*) send, (char*) recv, (size_t) count_per_rank * sizeof(double), stream);
+   if ( ncclAllGather(send, recv, (size_t) count_per_rank, ncclDouble, c->nccl, stream) != ncclSuccess )
       return HS_ERR_HIP;
    return HS_OK;
 }
 
 int hs_bcast_doubles(void* comm, double* buf, long long count, hipStream_t stream)
 {
-   if ( ncclBroadcast(buf, buf, (size_t) count, ncclDouble, 0, (ncclComm_t) comm, stream) != ncclSuccess )
+   hs_comm* c = (hs_comm*) comm;
+   if ( c->kind == 1 )
+      return shm_bcast(c, (char*) buf, (size_t) count * sizeof(double), stream);
+   if ( ncclBroadcast(buf, buf, (size_t) count, ncclDouble, 0, c->nccl, stream) != ncclSuccess )
       return HS_ERR_HIP;
    return HS_OK;
 }
 
 int hs_bcast_ints(void* comm, int* buf, long long count, hipStream_t stream)
 {
-   if ( ncclBroadcast(buf, buf, (size_t) count, ncclInt, 0, (ncclComm_t) comm, stream) != ncclSuccess )
+   hs_comm* c = (hs_comm*) comm;
+   if ( c->kind == 1 )
+      return shm_bcast(c, (char*) buf, (size_t) count * sizeof(int), stream);
+   if ( ncclBroadcast(buf, buf, (size_t) count, ncclInt, 0, c->nccl, stream) != ncclSuccess )
+      return HS_ERR_HIP;
+   return HS_OK;
+}
+
+int hs_allreduce_sum(void* comm, double* buf, long long count, hipStream_t stream)
+{
+   hs_comm* c = (hs_comm*) comm;
+   if ( count <= 0 )
+      return HS_OK;
+   if ( c->kind == 1 )
+   {
+      /* gather the ranks' parts into a device buffer, add them up on the device */
+      double* part = NULL;
+      HS_HIP( hipMalloc((void**) &part, (size_t) count * (size_t) c->nranks * sizeof(double)) );
+      int rc = shm_allgather(c, (const char*) buf, (char*) part, (size_t) count * sizeof(double), stream);
+      if ( rc == HS_OK )
+      {
+         long long blocks = (count + 255) / 256;
+         if ( blocks > 4096 ) blocks = 4096;
+         hipLaunchKernelGGL(k_sum_parts, dim3((unsigned) blocks), dim3(256), 0, stream, count, c->nranks, part, buf);
+         if ( hipGetLastError() != hipSuccess || hipStreamSynchronize(stream) != hipSuccess )
+            rc = HS_ERR_HIP;
+      }
+      (void) hipFree(part);
+      return rc;
+   }
+   if ( ncclAllReduce(buf, buf, (size_t) count, ncclDouble, ncclSum, c->nccl, stream) != ncclSuccess )
       return HS_ERR_HIP;
    return HS_OK;
 }

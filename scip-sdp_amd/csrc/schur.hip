@@ -18,6 +18,8 @@
  * Algorithmic flops per assembly: 4 m1 n^3 + m1^2 n^2.
  */
 #include "hs_kernels.h"
+#include <vector>
+#include <cmath>
 #include <stdlib.h>
 
 int hs_schur_ws_alloc(hs_schur_ws* w, int m1, long long n2max, double budget_gb)
@@ -35,6 +37,7 @@ int hs_schur_ws_alloc(hs_schur_ws* w, int m1, long long n2max, double budget_gb)
       if ( cols > m1 ) cols = m1;
    }
    w->chunk_cols = cols;
+   w->n2 = n2max;
    hipError_t e = hs_pool_alloc((void**) &w->T, (size_t) (cols * n2max) * sizeof(double)) == HS_OK ? hipSuccess : hipErrorOutOfMemory;
    if ( e == hipSuccess ) e = hs_pool_alloc((void**) &w->U, (size_t) (cols * n2max) * sizeof(double)) == HS_OK ? hipSuccess : hipErrorOutOfMemory;
    if ( e != hipSuccess )
@@ -134,6 +137,101 @@ int hs_schur_W(hipStream_t s, int m1, int n, const double* A, const double* R, c
    hs_gemm_args g3 = {m1, m1, (int) n2, HS_KC, HS_KC, w->U, n2, 0, w->U, n2, 0, Mx, m1, 0, 1.0, 1.0, 1, flags, sk, w->K};
    HS_CALL( hs_dgemm(s, &g3) );
    return HS_OK;
+}
+
+/* Column-slice form of the W formulation for sharding over ranks.  Mx = sum over the n^2 entries (r, c) of the W_j of
+ * W[:, (r, c)] W[:, (r, c)]^T, so the entries can be dealt out: the rank that owns the columns c in [c0, c0 + cw) forms
+ *    T_j[:, c0:c0+cw] = A_j R[:, c0:c0+cw]  (R lower triangular: rows c0.. of R only, the product starts at k = c0),
+ *    W_j[:, c0:c0+cw] = G T_j[:, c0:c0+cw]
+ * for ALL j and adds W_slice W_slice^T (lower tiles) to Mx: every one of the three products is split 1/ranks, the triangular
+ * savings stay, and the partial matrices are summed by one all-reduce.  Slices are stored compactly (n x cw per matrix). */
+int hs_schur_Wcols(hipStream_t s, int m1, int n, const double* A, const double* R, const double* G, double* Mx, hs_schur_ws* w,
+   int c0, int cw)
+{
+   if ( cw <= 0 )
+      return HS_OK;
+   const long long rows = (long long) m1 * n;
+   const long long nk = (long long) n * cw;
+   if ( c0 < 0 || c0 + cw > n || rows > 2000000000LL || nk > 2000000000LL || (long long) m1 * nk > w->chunk_cols * w->n2 )
+      return HS_ERR_ARG;
+   hs_gemm_args g1 = {(int) rows, cw, n - c0, HS_KC, HS_MC, A + c0, n, 0, R + (long long) c0 * n + c0, n, 0, w->T, cw, 0, 1.0, 0.0, 1,
+      HS_GEMM_B_LOWTRI, 1, NULL};
+   HS_CALL( hs_dgemm(s, &g1) );
+   hs_gemm_args g2 = {n, cw, n, HS_KC, HS_MC, G, n, 0, w->T, cw, nk, w->U, cw, nk, 1.0, 0.0, m1, HS_GEMM_A_LOWTRI | HS_GEMM_REMAP, 1, NULL};
+   HS_CALL( hs_dgemm(s, &g2) );
+   int flags = HS_GEMM_LOWER;
+   int sk;
+   if ( m1 >= 256 && nk >= 16384 )
+   {
+      const long long tm = (m1 + 127) / 128;
+      sk = hs_dgemm_pick_xcd_slices(tm * (tm + 1) / 2, nk);
+      while ( sk > 2 && (long long) sk * m1 * m1 > w->kws_len ) --sk;
+      flags |= HS_GEMM_XCD | HS_GEMM_NOFAST;
+   }
+   else
+   {
+      sk = hs_dgemm_pick_splitk(m1, m1, (int) nk, 1);
+      while ( sk > 1 && (long long) sk * m1 * m1 > w->kws_len ) --sk;
+   }
+   hs_gemm_args g3 = {m1, m1, (int) nk, HS_KC, HS_KC, w->U, nk, 0, w->U, nk, 0, Mx, m1, 0, 1.0, 1.0, 1, flags, sk, w->K};
+   HS_CALL( hs_dgemm(s, &g3) );
+   return HS_OK;
+}
+
+/* columns of rank `rank`: a contiguous range with boundaries at multiples of 16, chosen so that the slowest rank is as fast as
+ * possible under this cost model (units of m1 n multiply-adds; the products run in 128-wide tiles, so a slice costs its
+ * width rounded up to 128 in the first two products):
+ *    wt (2 (n - c0 - w / 2) + n)   [A_j R starts at k = c; G T_j]   +   w m1   [W W^T],      wt = 128 ceil(w / 128)
+ * Exact minimisation over all contiguous partitions (dynamic programme over <= n / 16 boundaries).  Ranks may end up without
+ * a column when n is small; they contribute a zero matrix to the sum.  Every rank computes the same table. */
+void hs_shard_cols(int m1, int n, int nranks, int rank, int* c_begin, int* c_width)
+{
+   static thread_local int memo_key[3] = {-1, -1, -1};
+   static thread_local int memo_bounds[65];
+   if ( nranks > 64 ) nranks = 64;
+   if ( memo_key[0] != m1 || memo_key[1] != n || memo_key[2] != nranks )
+   {
+      const int gran = 16;
+      const int P = (n + gran - 1) / gran;                 /* boundary p stands for column min(p * gran, n) */
+      auto col = [&](int p) -> int { return p * gran < n ? p * gran : n; };
+      auto cost = [&](int p0, int p1) -> double {
+         const int c0 = col(p0), w = col(p1) - c0;
+         if ( w <= 0 ) return 0.0;
+         const double wt = 128.0 * (double) ((w + 127) / 128);
+         return wt * (2.0 * ((double) n - (double) c0 - 0.5 * (double) w) + (double) n) + (double) w * (double) m1;
+      };
+      /* best[g][p]: smallest possible maximum over the first g ranks covering boundaries 0 .. p */
+      std::vector<double> prev(P + 1, 1e300), cur(P + 1);
+      std::vector<std::vector<int> > from(nranks + 1, std::vector<int>(P + 1, 0));
+      prev[0] = 0.0;
+      for (int g = 1; g <= nranks; ++g)
+      {
+         for (int p = 0; p <= P; ++p)
+         {
+            double b = 1e300; int arg = 0;
+            for (int q = 0; q <= p; ++q)
+            {
+               if ( prev[q] >= 1e300 ) continue;
+               const double v = fmax(prev[q], cost(q, p));
+               if ( v < b ) { b = v; arg = q; }
+            }
+            cur[p] = b; from[g][p] = arg;
+         }
+         prev = cur;
+      }
+      int p = P;
+      memo_bounds[nranks] = n;
+      for (int g = nranks; g >= 1; --g)
+      {
+         p = from[g][p];
+         memo_bounds[g - 1] = col(p);
+      }
+      memo_key[0] = m1; memo_key[1] = n; memo_key[2] = nranks;
+   }
+   if ( rank < 0 ) rank = 0;
+   if ( rank >= nranks ) rank = nranks - 1;
+   *c_begin = memo_bounds[rank];
+   *c_width = memo_bounds[rank + 1] - memo_bounds[rank];
 }
 
 /* Row-block form of the U formulation for sharding over ranks:  Mx[r, c] for r in [r_begin, r_end), c >= r (upper triangle of

@@ -173,6 +173,56 @@ extern "C" int hipsdp_schur_dense(int device, int m1, int n, const double* A, co
    return HIPSDP_OK;
 }
 
+/* time of the Schur work ONE rank of an nranks-way sharded assembly does (row chunks or a column slice, + mirror), on synthetic operands
+ * generated in HBM: lets the per-rank cost at 2/4/8 ranks be measured on a one-GPU machine (tests/devtools/shard_time.py) */
+extern "C" int hipsdp_schur_shard_time(int device, int m1, int n, int nranks, int rank, int by_columns, int reps, double ws_gbytes,
+   double* ms)
+{
+   HS_CALL( pick_device(device) );
+   if ( m1 < 1 || n < 1 || nranks < 1 || rank < 0 || rank >= nranks || reps < 1 || ms == NULL )
+      return HIPSDP_ERR_ARG;
+   const long long n2 = (long long) n * n;
+   DevBuf dA, dX, dZ, dM;
+   HS_CALL( dA.alloc(m1 * n2) ); HS_CALL( dX.alloc(n2) ); HS_CALL( dZ.alloc(n2) ); HS_CALL( dM.alloc((long long) (m1 + 32) * m1) );
+   hipLaunchKernelGGL(k_unit_fill, dim3(1024), dim3(256), 0, 0, m1 * n2, 11ULL, dA.p);
+   hipLaunchKernelGGL(k_unit_fill, dim3(1024), dim3(256), 0, 0, n2, 23ULL, dX.p);
+   hipLaunchKernelGGL(k_unit_fill, dim3(1024), dim3(256), 0, 0, n2, 37ULL, dZ.p);
+   hs_schur_ws w;
+   int c, b1, b2, c0 = 0, cw = 0;
+   hs_shard_rows(m1, nranks, rank, &c, &b1, &b2);
+   hs_shard_cols(m1, n, nranks, rank, &c0, &cw);
+   HS_CALL( hs_schur_ws_alloc(&w, m1, by_columns ? (long long) n * (cw > 0 ? cw : 1) : n2, ws_gbytes > 0.0 ? ws_gbytes : 40.0) );
+   hipEvent_t e0, e1;
+   HS_HIP( hipEventCreate(&e0) ); HS_HIP( hipEventCreate(&e1) );
+   int rc = HS_OK;
+   for (int it = 0; it <= reps && rc == HS_OK; ++it)
+   {
+      if ( it == 1 )
+         rc = hipEventRecord(e0, 0) == hipSuccess ? HS_OK : HS_ERR_HIP;        /* iteration 0 is the warm-up */
+      if ( rc == HS_OK ) rc = hs_fill(0, dM.p, (long long) m1 * m1, 0.0);
+      if ( by_columns )
+      {
+         if ( rc == HS_OK ) rc = hs_schur_Wcols(0, m1, n, dA.p, dX.p, dZ.p, dM.p, &w, c0, cw);
+         if ( rc == HS_OK ) rc = hs_mirror_lower(0, dM.p, m1, m1);
+      }
+      else
+      {
+         if ( rc == HS_OK ) rc = hs_schur_Urows(0, m1, n, dA.p, dX.p, dZ.p, dM.p, &w, b1, b1 + c);
+         if ( rc == HS_OK ) rc = hs_schur_Urows(0, m1, n, dA.p, dX.p, dZ.p, dM.p, &w, b2, b2 + c);
+         if ( rc == HS_OK ) rc = hs_mirror_upper(0, dM.p, m1, m1);
+      }
+   }
+   float t = 0.f;
+   if ( rc == HS_OK && (hipEventRecord(e1, 0) != hipSuccess || hipEventSynchronize(e1) != hipSuccess
+         || hipEventElapsedTime(&t, e0, e1) != hipSuccess) )
+      rc = HS_ERR_HIP;
+   (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+   hs_schur_ws_free(&w);
+   HS_CALL( rc );
+   *ms = (double) t / (double) reps;
+   return HIPSDP_OK;
+}
+
 /* W formulation: X and Z (not its inverse) are given; chol(X), chol(Z), inverse factor and the three GEMMs on the device */
 extern "C" int hipsdp_schur_w(int device, int m1, int n, const double* A, const double* X, const double* Z, double* Mx)
 {

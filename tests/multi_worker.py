@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""multi_worker.py RANK WORLD SHM_NAME N M LPROWS OUT.json - one rank of a sharded node solve (test helper).
+
+Every rank builds the same instance (as bench.py does at N > 1), joins the communicator and runs the engine with its share of
+the Schur rows.  WORLD ranks may share one device through the host-staged communicator (RCCL refuses two ranks on one GPU).
+The result every rank saw goes to OUT.json for tests/test_gpu_multi.py to compare."""
+import ctypes as C
+import importlib.util
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+spec = importlib.util.spec_from_file_location("hipsdp_binding", os.path.join(ROOT, "scip-sdp_amd", "binding.py"))
+hb = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(hb)
+import numpy as np
+import ipm_ref
+import instances
+
+
+def main():
+    rank, world, name, n, m, q, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), \
+        int(sys.argv[6]), sys.argv[7]
+    b, A, ys, Xs, Zs = instances.planted_dense(n, m)
+    if q > 0:
+        rng = np.random.default_rng(5)
+        D = rng.standard_normal((q, m))
+        c = D @ ys - rng.uniform(0.1, 1.0, q)            # strictly satisfied at the planted y: the optimum does not move
+        core = ipm_ref.CoreProblem(b, [A], D, c)
+    else:
+        core = ipm_ref.CoreProblem(b, [A])
+    lib = hb.lib()
+    s = hb.Solver(0)
+    s.load_core(core)
+    comm = C.c_void_p()
+    if world > 1:
+        rc = lib.hipsdp_comm_create_host(name.encode(), rank, world, C.c_longlong(1 << 20), C.c_double(60.0), C.byref(comm))
+        assert rc == 0, rc
+        assert lib.hipsdp_set_comm(s.h, comm, rank, world) == 0
+    info = s.solve(gaptol=1e-6, feastol=1e-6)
+    y = s.y()
+    X = s.X(0)
+    if world > 1:
+        assert lib.hipsdp_set_comm(s.h, None, 0, 1) == 0
+    s.close()
+    if world > 1:
+        lib.hipsdp_comm_destroy(comm)
+    json.dump(dict(rank=rank, status=int(info.status), iterations=int(info.iterations), pobj=float(info.pobj),
+                   dobj=float(info.dobj), y=[float(v) for v in y], xtrace=float(np.trace(X)),
+                   xfro=float(np.linalg.norm(X))), open(out, "w"))
+
+
+if __name__ == "__main__":
+    main()

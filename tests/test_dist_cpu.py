@@ -4,6 +4,7 @@ on the multi-GPU bench; the layout logic it relies on is what this test pins."""
 import os
 import socket
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -79,3 +80,91 @@ def test_shard_rows_cover_everything_once():
                 seen[b1:b1 + c] += 1
                 seen[b2:b2 + c] += 1
             assert np.all(seen[:m1] == 1)
+
+
+def _barrier_worker(rank, world, name, q):
+    """create + destroy of the host-staged communicator needs no device: the creation ends in its first barrier"""
+    import ctypes as C
+    from conftest import _load_binding as load_binding
+    lib = load_binding().lib()
+    comm = C.c_void_p()
+    rc = lib.hipsdp_comm_create_host(name.encode(), rank, world, C.c_longlong(1 << 16), C.c_double(30.0), C.byref(comm))
+    if rc == 0:
+        lib.hipsdp_comm_destroy(comm)
+    q.put((rank, rc))
+
+
+def test_host_staged_communicator_rendezvous():
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = "/hipsdp_cpu_%d" % os.getpid()
+    procs = [ctx.Process(target=_barrier_worker, args=(r, world, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(r, 0) for r in range(world)]
+    assert not os.path.exists("/dev/shm" + name)            # rank 0 unlinks the name once everyone has mapped it
+
+
+def test_host_staged_communicator_rejects_bad_arguments():
+    import ctypes as C
+    from conftest import _load_binding as load_binding
+    lib = load_binding().lib()
+    comm = C.c_void_p()
+    assert lib.hipsdp_comm_create_host(b"no_slash", 0, 1, C.c_longlong(1 << 16), C.c_double(1.0), C.byref(comm)) != 0
+    assert lib.hipsdp_comm_create_host(b"/x", 2, 2, C.c_longlong(1 << 16), C.c_double(1.0), C.byref(comm)) != 0
+    assert lib.hipsdp_comm_create_host(b"/x", 0, 1, C.c_longlong(16), C.c_double(1.0), C.byref(comm)) != 0
+
+
+def _cols_worker(rank, world, port, m1, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(12)
+    A = rng.standard_normal((m1, n, n)); A = A + A.transpose(0, 2, 1)
+    Gm = rng.standard_normal((n, n)); X = Gm @ Gm.T + np.eye(n)
+    Gm = rng.standard_normal((n, n)); Z = Gm @ Gm.T + np.eye(n)
+    R = np.linalg.cholesky(X)
+    G = np.linalg.inv(np.linalg.cholesky(Z))
+    bounds = shard_ref.shard_cols(m1, n, world)
+    part = torch.from_numpy(shard_ref.column_slice_contribution(A, R, G, bounds[rank], bounds[rank + 1] - bounds[rank]))
+    dist.all_reduce(part, op=dist.ReduceOp.SUM)
+    ref = ipm_ref.schur_block(A, X, np.linalg.inv(Z))
+    q.put((rank, float(np.abs(part.numpy() - ref).max() / np.abs(ref).max()), bounds))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_column_sliced_schur_two_ranks():
+    world, m1, n = 2, 9, 40
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cols_worker, args=(r, world, port, m1, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, err, bounds in res:
+        assert err < 1e-12
+        assert bounds[0] == 0 and bounds[-1] == n and all(b % 16 == 0 for b in bounds[:-1])
+
+
+@pytest.mark.parametrize("m1,n,world", [(1001, 500, 1), (1001, 500, 2), (1001, 500, 8), (2001, 1000, 4), (2001, 1000, 8), (4001, 2000, 8),
+                                        (31, 20, 4), (5, 7, 3), (200, 130, 16)])
+def test_engine_column_partition_matches_the_restatement(m1, n, world):
+    """the partition every rank derives on its own (host code of libhipsdp.so, no device needed) is the restated one: it
+    tiles [0, n) without gaps, and no rank exceeds the others by more than the tile quantum allows"""
+    import ctypes as C
+    from conftest import _load_binding
+    lib = _load_binding().lib()
+    b = (C.c_int * (world + 1))()
+    assert lib.hipsdp_shard_columns(m1, n, world, b) == 0
+    bounds = list(b)
+    assert bounds == shard_ref.shard_cols(m1, n, world)
+    assert bounds[0] == 0 and bounds[-1] == n and all(x <= y for x, y in zip(bounds, bounds[1:]))
+    assert lib.hipsdp_shard_columns(m1, n, 0, b) != 0

@@ -152,11 +152,13 @@ def test_full_size_c2_properties(gpu):
     s.close()
 
 
-@pytest.mark.parametrize("mode", ["U", "R"])
-def test_alternative_schur_formulations_give_the_same_solve(gpu, mode, monkeypatch):
-    """HIPSDP_SCHUR=U: chunked U_j = X A_j Z^-1 formulation; =R: the row-sharded form every rank of a multi-GPU run executes
-    (here all chunks on one device).  Both must reproduce the default (W formulation) solve and the oracle."""
-    b, A, ys, Xs, Zs = instances.planted_dense(40, 70)
+@pytest.mark.parametrize("mode,n,m", [("U", 40, 70), ("R", 40, 70), ("K1", 40, 70), ("K2", 40, 70), ("K3", 70, 30), ("K8", 150, 40)])
+def test_alternative_schur_formulations_give_the_same_solve(gpu, mode, n, m, monkeypatch):
+    """HIPSDP_SCHUR=U: chunked U_j = X A_j Z^-1 formulation; =R: the row-sharded form (all chunks on one device); =K<g>: the
+    column-sliced W formulation the ranks of a multi-GPU run execute (all g slices on one device, added up in place of the
+    all-reduce; K8 at n = 150 has uneven and n = 40 at K3 would have empty slices).  All must reproduce the default solve and
+    the oracle."""
+    b, A, ys, Xs, Zs = instances.planted_dense(n, m)
     core = ipm_ref.CoreProblem(b, [A])
     ref = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-6, feastol=1e-6))
     base = gpu_solve(gpu, core, gaptol=1e-6, feastol=1e-6)

@@ -1,0 +1,52 @@
+"""Sharded node solve with several PROCESSES (gpu-marked): WORLD ranks on the one device of the test box, joined by the
+host-staged communicator (RCCL refuses two ranks per device), must give the solve a single rank gives.  This runs exactly the
+code the multi-GPU bench runs per rank - row-sharded Schur assembly, two all-gathers, re-assembly, broadcast of the decision
+scalars - with a different byte transport underneath."""
+import json
+import os
+import subprocess
+import sys
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def run_world(tmp_path, world, n, m, q, tag, env=None):
+    name = "/hipsdp_t_%d_%s" % (os.getpid(), tag)
+    outs = [str(tmp_path / ("%s_r%d.json" % (tag, r))) for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "multi_worker.py"), str(r), str(world), name, str(n), str(m),
+                               str(q), outs[r]], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              env=dict(os.environ, **(env or {}))) for r in range(world)]
+    logs = []
+    try:
+        for p in procs:
+            o, _ = p.communicate(timeout=280)
+            logs.append(o.decode(errors="replace"))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, logs[r][-3000:])
+    return [json.load(open(o)) for o in outs]
+
+
+@pytest.mark.parametrize("form", ["columns", "rows"])
+@pytest.mark.parametrize("world,n,m,q", [(2, 40, 70, 0), (3, 33, 50, 7), (4, 70, 130, 0), (2, 24, 1, 0), (4, 20, 5, 3)])
+def test_ranks_sharing_the_schur_matrix_reproduce_the_single_rank_solve(gpu, tmp_path, world, n, m, q, form):
+    """form = columns: the default (column slices of the W formulation, all-reduce); rows: HIPSDP_SCHUR=R (row chunks of the U
+    formulation, two all-gathers).  n = 20 and 33 leave ranks without a column: they contribute zeros."""
+    one = run_world(tmp_path, 1, n, m, q, "w1")[0]
+    many = run_world(tmp_path, world, n, m, q, "w%d" % world, env={"HIPSDP_SCHUR": "R"} if form == "rows" else None)
+    assert one["status"] == 0
+    y1 = np.array(one["y"])
+    for r in many:
+        assert r["status"] == 0 and r["iterations"] == one["iterations"], (r["status"], r["iterations"], one["iterations"])
+        assert np.max(np.abs(np.array(r["y"]) - y1)) <= 1e-8 * max(1.0, np.max(np.abs(y1)))
+        assert abs(r["xtrace"] - one["xtrace"]) <= 1e-7 * max(1.0, abs(one["xtrace"]))
+    # all ranks hold the same iterate (the decision scalars are broadcast, everything else is replicated arithmetic)
+    for r in many[1:]:
+        assert r["iterations"] == many[0]["iterations"]
+        assert np.max(np.abs(np.array(r["y"]) - np.array(many[0]["y"]))) <= 1e-12 * max(1.0, np.max(np.abs(y1)))
