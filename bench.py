@@ -117,7 +117,7 @@ def main():
     n, m = args.n, args.m
     solver = hb.Solver(local_rank if world > 1 else 0)
     solver.set_shape(m, [n], 0)
-    # N > 1: ONE node SDP, its Schur rows sharded over the ranks (north_star); every rank holds the same instance
+    # N > 1: ONE node SDP, its Schur assembly sharded over the ranks (north_star); every rank holds the same instance
     Xs, Zs, ys = planted_pair(n, m, args.seed)
     b = solver.gen_planted(n, m, args.seed, Xs, Zs, ys)
     opt = float(b @ ys)
@@ -177,8 +177,8 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: synthetic single dense block n=%d, m=%d, fp64, planted optimum, cold start, "
-                               "gaptol=feastol=1e-5, A resident in HBM; N > 1: Schur rows sharded over the GPUs, RCCL all-gather per iteration" % (n, m),
-                   "parallelism": "schur-rows x%d" % world,
+                               "gaptol=feastol=1e-5, A resident in HBM; N > 1: Schur assembly sharded over the GPUs (column slices of W_j = G A_j R), one RCCL all-reduce of the partial Schur matrices per iteration" % (n, m),
+                   "parallelism": "schur-shards x%d" % world,
                    "n": n, "m": m, "seed": args.seed},
         "iters_per_sec": iters / elapsed,
         "iterations_per_solve": iters / max(1, len(infos)),
