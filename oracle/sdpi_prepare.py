@@ -9,8 +9,8 @@ patterns real branch-and-bound nodes produce:
    sdpi.c:691-809     findEmptyRowColsSDP: indchanges / nremovedinds / blockindchanges
    sdpi.c:4473-4620   mapping bound multipliers back to the LP rows they came from (lhs/rhs multipliers)
 
-Integrality-based coefficient tightening (sdpi.c:812-1129), the one-variable shortcut (sdpi.c:3301-3381), the penalty loop
-and the Slater check are not restated here.
+The one-variable shortcut (sdpi.c:3301-3381), the penalty loop and the Slater check are restated in sdpi_driver.py;
+integrality-based coefficient tightening (sdpi.c:812-1129) is not restated.
 """
 import numpy as np
 

@@ -170,6 +170,12 @@ class SdpiSolver:
         rc = self.lib.SCIPsdpiSolverGetDualSol(self.h, C.byref(o), _pd(y))
         return rc, o.value, y
 
+    def objval(self):
+        o = C.c_double(0.0)
+        rc = self.lib.SCIPsdpiSolverGetObjval(self.h, C.byref(o))
+        assert rc == SCIP_OKAY, rc
+        return o.value
+
     def bound_vars(self):
         n = self._P.prob.nvars
         l = np.zeros(n)
