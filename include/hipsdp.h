@@ -128,6 +128,13 @@ int  hipsdp_get_lp(hipsdp_solver* solver, double* x, double* z);
  * sdpsolchecker.c:201-257 inside the backend); y: m host values; lmin: nblocks host values */
 int  hipsdp_check_y(hipsdp_solver* solver, const double* y, double* lmin, double* lpviol);
 
+/* Eigenvector cuts for the LP-based mode (replaces the host loop of cons_sdp.c:896-1010 / :1612-1803 for one block): for every
+ * eigenvector v of Z(y) = sum_i A_i y_i - A_0 of block `block` with eigenvalue <= -tol (most negative first, at most maxcuts)
+ *     sum_i coefs[c][i] y_i >= lhs[c],   coefs[c][i] = v^T A_i v,  lhs[c] = v^T A_0 v
+ * is violated at y by -eigvals[c].  y: m host values (engine variables); coefs: maxcuts x m; vecs: maxcuts x n or NULL. */
+int  hipsdp_eigencuts(hipsdp_solver* solver, int block, const double* y, double tol, int maxcuts, int* ncuts, double* eigvals,
+                      double* coefs, double* lhs, double* vecs);
+
 /* multi-GPU: Schur rows are sharded over the ranks of an RCCL communicator (one process per GPU); comm comes from hipsdp_comm_create[_host] */
 int  hipsdp_set_comm(hipsdp_solver* solver, void* comm, int rank, int nranks);
 /* host-only helper: column ranges of the sharded assembly, bounds[0 .. nranks]; rank g owns [bounds[g], bounds[g + 1]) */

@@ -184,6 +184,18 @@ class Solver:
         _chk(lib().hipsdp_check_y(self.h, _dp(y), _dp(lmin), C.byref(viol)), "hipsdp_check_y")
         return lmin[:len(self.ns)], viol.value
 
+    def eigencuts(self, block, y, tol, maxcuts):
+        """eigenvector cuts of one block at y: (eigvals[k], coefs[k, m], lhs[k], vecs[k, n]); cut c: coefs[c] @ y >= lhs[c]"""
+        y = _f64(y)
+        m, n = len(y), self.ns[block]
+        k = C.c_int(0)
+        ev = np.zeros(max(1, maxcuts))
+        co = np.zeros((max(1, maxcuts), max(1, m)))
+        lh = np.zeros(max(1, maxcuts))
+        ve = np.zeros((max(1, maxcuts), n))
+        _chk(lib().hipsdp_eigencuts(self.h, block, _dp(y), C.c_double(tol), maxcuts, C.byref(k), _dp(ev), _dp(co), _dp(lh), _dp(ve)),
+             "hipsdp_eigencuts")
+        return ev[:k.value], co[:k.value, :m], lh[:k.value], ve[:k.value]
 
 # ---- unit-level host-buffer kernels ---------------------------------------------------------------------------------
 

@@ -1975,6 +1975,82 @@ extern "C" int hipsdp_check_y(hipsdp_solver* s, const double* y, double* lmin, d
    return HIPSDP_OK;
 }
 
+/* H = v v^T for row `row` of V (ld n) */
+__global__ void k_outer_row(int n, const double* __restrict__ V, int row, double* __restrict__ H)
+{
+   const double* v = V + (long long) row * n;
+   for (long long e = (long long) blockIdx.x * blockDim.x + threadIdx.x; e < (long long) n * n; e += (long long) gridDim.x * blockDim.x)
+      H[e] = v[e / n] * v[e % n];
+}
+
+/* Eigenvector cuts of one block at the point y (LP-based mode of the reference: cons_sdp.c:896-1010 produceCutFromEigenvector,
+ * :1612-1803 separateSol): every eigenvector v of Z(y) = sum_i A_i y_i - A_0 with eigenvalue <= -tol gives the valid inequality
+ *    sum_i (v^T A_i v) y_i >= v^T A_0 v.
+ * Z(y) (one pass over A), its eigen-decomposition (Jacobi) and the coefficients <A_i, v v^T> (one pass over A per cut) are
+ * formed on the device.  The most negative eigenvalues come first; at most maxcuts cuts.
+ * eigvals[maxcuts], coefs[maxcuts x m], lhs[maxcuts], vecs[maxcuts x n] (may be NULL) are host arrays. */
+extern "C" int hipsdp_eigencuts(hipsdp_solver* s, int block, const double* y, double tol, int maxcuts, int* ncuts, double* eigvals,
+   double* coefs, double* lhs, double* vecs)
+{
+   if ( s == NULL || !s->shaped || block < 0 || block >= (int) s->blk.size() || y == NULL || maxcuts < 0 || ncuts == NULL )
+      return HIPSDP_ERR_ARG;
+   *ncuts = 0;
+   if ( maxcuts == 0 )
+      return HIPSDP_OK;
+   if ( eigvals == NULL || coefs == NULL || lhs == NULL )
+      return HIPSDP_ERR_ARG;
+   HS_HIP( hipSetDevice(s->device) );
+   const int m = s->m, m1 = m + 1;
+   Block& B = s->blk[block];
+   const int n = B.n;
+   const long long n2 = (long long) n * n;
+   hipStream_t st = s->stream;
+   if ( m > 0 )
+      HS_HIP( hipMemcpyAsync(s->ys, y, (size_t) m * sizeof(double), hipMemcpyHostToDevice, st) );
+   hipLaunchKernelGGL(k_make_ext, g1d(m1), dim3(256), 0, st, m, -1.0, 1.0, s->ys, s->dyt);
+   HS_LAUNCH_CHECK();
+   HS_CALL( ensure_packed(s) );
+   HS_CALL( pass_AT(s, B, s->dyt, 0.0, NULL, B.W) );
+   double *lam = NULL, *V = NULL, *ws = NULL, *out = NULL;
+   std::vector<double> hlam(n), hout;
+   int rc = dalloc(&lam, n);
+   if ( rc == HS_OK ) rc = dalloc(&V, n2);
+   if ( rc == HS_OK ) rc = dalloc(&ws, hs_syev_ws(n));
+   if ( rc == HS_OK ) rc = dalloc(&out, m1);
+   if ( rc == HS_OK ) rc = hs_syev_jacobi(st, n, B.W, lam, V, NULL, ws);
+   if ( rc == HS_OK && (hipMemcpyAsync(hlam.data(), lam, (size_t) n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess
+         || hipStreamSynchronize(st) != hipSuccess) )
+      rc = HS_ERR_HIP;
+   int k = 0;
+   if ( rc == HS_OK )
+   {
+      while ( k < n && k < maxcuts && hlam[k] <= -tol )
+         ++k;
+      hout.resize(m1);
+   }
+   for (int c = 0; c < k && rc == HS_OK; ++c)
+   {
+      hipLaunchKernelGGL(k_outer_row, g1d(n2), dim3(256), 0, st, n, V, c, B.W2);
+      if ( hipGetLastError() != hipSuccess ) { rc = HS_ERR_HIP; break; }
+      rc = pass_A(s, B, B.W2, out);
+      if ( rc == HS_OK && (hipMemcpyAsync(hout.data(), out, (size_t) m1 * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess
+            || hipStreamSynchronize(st) != hipSuccess) )
+         rc = HS_ERR_HIP;
+      if ( rc != HS_OK )
+         break;
+      eigvals[c] = hlam[c];
+      lhs[c] = hout[0];
+      for (int i = 0; i < m; ++i)
+         coefs[(size_t) c * m + i] = hout[1 + i];
+      if ( vecs != NULL && hipMemcpy(vecs + (size_t) c * n, V + (size_t) c * n, (size_t) n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess )
+         rc = HS_ERR_HIP;
+   }
+   dfree(lam); dfree(V); dfree(ws); dfree(out);
+   HS_CALL( rc );
+   *ncuts = k;
+   return HIPSDP_OK;
+}
+
 /* host-only: the column ranges of the sharded W formulation, bounds[0 .. nranks] (rank g owns [bounds[g], bounds[g + 1])) */
 extern "C" int hipsdp_shard_columns(int m1, int n, int nranks, int* bounds)
 {

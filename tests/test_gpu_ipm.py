@@ -261,3 +261,35 @@ def test_warm_start_with_lp_rows(gpu):
     xb = x.copy(); xb[0] = 0.0
     bad = _solve_with_start(gpu, core, (start[0], start[1], start[2], xb, start[4]))
     assert bad["info"].warm_started == 0 and bad["info"].status == 0
+
+
+def test_eigenvector_cuts_on_the_device(gpu):
+    """LP-based mode of the reference (cons_sdp.c:896-1010, :1612-1803): at a point y with Z(y) not psd the device returns,
+    for every eigenvalue <= -tol, the cut sum_i (v^T A_i v) y_i >= v^T A_0 v.  Checked against the numpy restatement
+    (oracle/eigcuts_ref.py): eigenvalues, coefficients up to the sign of v, violation = -eigenvalue, validity at the planted
+    feasible point."""
+    import eigcuts_ref
+    for (n, m, seed) in [(12, 7, 0), (40, 25, 1), (90, 30, 2)]:
+        b, A, ys, Xs, Zs = instances.planted_dense(n, m)
+        core = ipm_ref.CoreProblem(b, [A])
+        rng = np.random.default_rng(seed)
+        y = ys + 0.7 * rng.standard_normal(m)                      # leaves the feasible set
+        s = gpu.Solver(0)
+        s.load_core(core)
+        ev, co, lh, ve = s.eigencuts(0, y, 1e-6, 5)
+        rev, rco, rlh, rve = eigcuts_ref.cuts_dense(A, y, 1e-6, 5)
+        assert len(ev) == len(rev) and len(ev) >= 1
+        assert np.max(np.abs(ev - rev)) <= 1e-9 * max(1.0, np.max(np.abs(rev)))
+        for c in range(len(ev)):
+            v = ve[c]
+            assert abs(np.linalg.norm(v) - 1.0) <= 1e-10
+            assert abs(abs(v @ rve[c]) - 1.0) <= 1e-6               # same eigenvector up to sign (eigenvalues are simple here)
+            assert np.max(np.abs(co[c] - rco[c])) <= 1e-6 * max(1.0, np.max(np.abs(rco[c])))
+            assert abs(lh[c] - rlh[c]) <= 1e-6 * max(1.0, abs(rlh[c]))
+            assert abs((co[c] @ y - lh[c]) - ev[c]) <= 1e-8 * max(1.0, abs(ev[c]))     # violated by exactly -lambda
+            assert co[c] @ ys - lh[c] >= -1e-9                       # valid for the feasible point
+        # nothing to cut at a feasible point; maxcuts = 0 is allowed
+        ev0, _, _, _ = s.eigencuts(0, ys, 1e-6, 5)
+        assert len(ev0) == 0
+        assert len(s.eigencuts(0, y, 1e-6, 0)[0]) == 0
+        s.close()

@@ -177,3 +177,21 @@ def test_oracle_warm_start_rule():
     assert warm.status == cold.status == ipm_ref.STATUS_OPTIMAL
     assert warm.iterations < cold.iterations
     assert abs(warm.dobj - cold.dobj) <= 1e-6 * (1 + abs(cold.dobj))
+
+
+def test_eigenvector_cut_restatement_matches_the_sparse_formula():
+    """oracle/eigcuts_ref.py: the dense coefficients v^T A_j v equal the reference's sparse accumulation
+    (cons_sdp.c:826-865: off-diagonal entries of the lower triangle counted twice)"""
+    import eigcuts_ref
+    rng = np.random.default_rng(4)
+    n, m = 6, 4
+    A = rng.standard_normal((m + 1, n, n))
+    A = A + A.transpose(0, 2, 1)
+    y = rng.standard_normal(m)
+    ev, co, lh, ve = eigcuts_ref.cuts_dense(A, y, 1e-9, 3)
+    assert len(ev) >= 1
+    for c, v in enumerate(ve):
+        for i in range(m):
+            ents = [(r, cc, A[1 + i, r, cc]) for r in range(n) for cc in range(r + 1)]
+            assert abs(eigcuts_ref.vAv_sparse(ents, v) - co[c, i]) <= 1e-12 * max(1.0, abs(co[c, i]))
+        assert abs((co[c] @ y - lh[c]) - ev[c]) <= 1e-10
