@@ -176,6 +176,8 @@ int  hipsdp_potrf(int device, int n, double* A, int* fail);                     
 int  hipsdp_potrs(int device, int n, const double* A, int nrhs, double* rhs);     /* factor + solve, rhs[k * n + i] */
 int  hipsdp_trtri(int device, int n, const double* A, double* Linv);              /* A spd -> inverse of its Cholesky factor */
 int  hipsdp_lambda_min(int device, int n, const double* W, int steps, double* theta, double* resid);
+/* lambda_min(L D L^T), n <= 64, L lower triangular, D symmetric: the small-block step-length kernels; theta[2], resid[2] */
+int  hipsdp_lambda_min_scaled(int device, int n, const double* L, const double* D, int steps, double* theta, double* resid);
 int  hipsdp_syev(int device, int n, const double* A, double* lam, double* V);     /* ascending, eigenvectors as rows */
 int  hipsdp_gemv_n(int device, int R, long long E, const double* A, int nv, const double* V, double* out);
 int  hipsdp_gemv_t(int device, int R, long long E, const double* A, const double* coef, double* out);

@@ -134,6 +134,15 @@ __global__ void __launch_bounds__(1024) k_lanczos_step(int n, int j, double* __r
  * by inverse iteration; res = {theta, |beta_{k-1} s_{k-1}|, k}.  One wavefront. */
 struct tridiag_smem { double d[260], e[260], sv[260], wk[4][260]; };
 
+/* reciprocal by v_rcp_f64 and one Newton step (full precision for finite, normal t): a third of the latency of a division,
+ * which is what the sequential recurrences below are made of */
+__device__ __forceinline__ double rcp_newton(double t)
+{
+   double r = __builtin_amdgcn_rcp(t);
+   r = fma(fma(-t, r, 1.0), r, r);
+   return r;
+}
+
 /* executed by ONE wavefront (all 64 lanes); other wavefronts of the workgroup must not call it */
 /* (ovr_idx, ovr_alpha, ovr_beta): entry ovr_idx of alpha / beta is taken from the arguments instead of memory (the
  * caller has just stored it and must not rely on reading it back through the vector cache); meta0 = breakdown step */
@@ -152,7 +161,9 @@ __device__ void tridiag_min_wave(int kmax, const double* __restrict__ alpha, con
    for (int i = lane; i < k; i += 64)
    {
       d[i] = (i == ovr_idx) ? ovr_alpha : alpha[i];
-      e[i] = (i + 1 < k) ? ((i == ovr_idx) ? ovr_beta : beta[i]) : 0.0;
+      const double ei = (i + 1 < k) ? ((i == ovr_idx) ? ovr_beta : beta[i]) : 0.0;
+      e[i] = ei;
+      wk[3][i] = ei * ei;
    }
    __builtin_amdgcn_s_waitcnt(0);
    __builtin_amdgcn_wave_barrier();
@@ -167,19 +178,20 @@ __device__ void tridiag_min_wave(int kmax, const double* __restrict__ alpha, con
    const double span0 = fmax(hi - lo, 1e-300);
    lo -= 1e-12 * span0 + 1e-300;
    hi += 1e-12 * span0 + 1e-300;
-   const double pivmin = 1e-300;
+   const double pivmin = 1e-290;
    for (int round = 0; round < 14; ++round)
    {
       const double x = lo + (hi - lo) * (double) (lane + 1) / 65.0;
-      /* number of eigenvalues < x */
+      /* number of eigenvalues < x (Sturm count; |t| is kept inside [pivmin, 1 / pivmin] so that the reciprocal is exact enough) */
       int cnt = 0;
       double t = d[0] - x;
       if ( fabs(t) < pivmin ) t = -pivmin;
       if ( t < 0.0 ) ++cnt;
       for (int i = 1; i < k; ++i)
       {
-         t = d[i] - x - e[i - 1] * e[i - 1] / t;
+         t = d[i] - x - wk[3][i - 1] * rcp_newton(t);
          if ( fabs(t) < pivmin ) t = -pivmin;
+         if ( !(fabs(t) < 1e290) ) t = (t < 0.0) ? -1e290 : 1e290;
          if ( t < 0.0 ) ++cnt;
       }
       const unsigned long long m = __ballot(cnt >= 1);
@@ -195,8 +207,9 @@ __device__ void tridiag_min_wave(int kmax, const double* __restrict__ alpha, con
 
    if ( lane == 0 )
    {
-      /* inverse iteration with the shifted tridiagonal, Gaussian elimination with partial pivoting (three diagonals
-       * after pivoting: wk[0] = diagonal, wk[1] = first super, wk[2] = second super, wk[3] = multipliers / swaps) */
+      /* inverse iteration with the shifted tridiagonal: Gaussian elimination with partial pivoting, factored ONCE (three
+       * diagonals after pivoting: wk[0] = reciprocal of the diagonal, wk[1] = first super, wk[2] = second super, wk[3] =
+       * multipliers, d[] = 1 where rows were swapped), then three solves made of multiplications only */
       double resid = 0.0;
       if ( k == 1 )
       {
@@ -206,55 +219,74 @@ __device__ void tridiag_min_wave(int kmax, const double* __restrict__ alpha, con
       {
          const double shift = theta;
          const double tiny = 1e-14 * fmax(span0, fmax(fabs(theta), 1e-300));
+         double dd = d[0] - shift, du = e[0];
+         for (int i = 0; i < k - 1; ++i)
+         {
+            const double dl = e[i];
+            const double dn = d[i + 1] - shift;
+            const double un = (i + 2 < k) ? e[i + 1] : 0.0;
+            if ( fabs(dd) >= fabs(dl) )
+            {
+               if ( fabs(dd) < tiny ) dd = tiny;
+               const double rinv = rcp_newton(dd);
+               const double mlt = dl * rinv;
+               wk[0][i] = rinv; wk[1][i] = du; wk[2][i] = 0.0; wk[3][i] = mlt; d[i] = 0.0;
+               dd = dn - mlt * du;
+               du = un;
+            }
+            else
+            {
+               const double rinv = rcp_newton(dl);
+               const double mlt = dd * rinv;
+               wk[0][i] = rinv; wk[1][i] = dn; wk[2][i] = un; wk[3][i] = mlt; d[i] = 1.0;
+               dd = du - mlt * dn;
+               du = -mlt * un;
+            }
+         }
+         if ( fabs(dd) < tiny ) dd = tiny;
+         wk[0][k - 1] = rcp_newton(dd); wk[1][k - 1] = 0.0; wk[2][k - 1] = 0.0;
+         const double s0 = 1.0 / sqrt((double) k);
          for (int i = 0; i < k; ++i)
-            sv[i] = 1.0 / sqrt((double) k);
+            sv[i] = s0;
          for (int iter = 0; iter < 3; ++iter)
          {
-            /* factor */
-            double dd = d[0] - shift, du = e[0], du2 = 0.0;
+            /* forward: apply the row operations; the running entry stays in a register */
+            double cur = sv[0];
             for (int i = 0; i < k - 1; ++i)
             {
-               const double dl = e[i];
-               const double dn = d[i + 1] - shift;
-               const double un = (i + 2 < k) ? e[i + 1] : 0.0;
-               if ( fabs(dd) >= fabs(dl) )
+               const double nxt = sv[i + 1];
+               if ( d[i] == 0.0 )
                {
-                  if ( fabs(dd) < tiny ) dd = tiny;
-                  const double mlt = dl / dd;
-                  wk[0][i] = dd; wk[1][i] = du; wk[2][i] = 0.0;
-                  sv[i + 1] -= mlt * sv[i];
-                  dd = dn - mlt * du;
-                  du = un;
+                  sv[i] = cur;
+                  cur = nxt - wk[3][i] * cur;
                }
                else
                {
-                  const double mlt = dd / dl;
-                  wk[0][i] = dl; wk[1][i] = dn; wk[2][i] = un;
-                  const double tmp = sv[i]; sv[i] = sv[i + 1]; sv[i + 1] = tmp - mlt * sv[i + 1];
-                  dd = du - mlt * dn;
-                  du = -mlt * un;
+                  sv[i] = nxt;
+                  cur = cur - wk[3][i] * nxt;
                }
             }
-            if ( fabs(dd) < tiny ) dd = tiny;
-            wk[0][k - 1] = dd; wk[1][k - 1] = 0.0; wk[2][k - 1] = 0.0;
             /* back substitution */
-            sv[k - 1] /= wk[0][k - 1];
-            if ( k >= 2 )
-               sv[k - 2] = (sv[k - 2] - wk[1][k - 2] * sv[k - 1]) / wk[0][k - 2];
-            for (int i = k - 3; i >= 0; --i)
-               sv[i] = (sv[i] - wk[1][i] * sv[i + 1] - wk[2][i] * sv[i + 2]) / wk[0][i];
-            double nrm = 0.0;
-            for (int i = 0; i < k; ++i)
-               nrm += sv[i] * sv[i];
+            double x1 = cur * wk[0][k - 1], x2 = 0.0;
+            double nrm = x1 * x1;
+            sv[k - 1] = x1;
+            for (int i = k - 2; i >= 0; --i)
+            {
+               const double xi = (sv[i] - wk[1][i] * x1 - wk[2][i] * x2) * wk[0][i];
+               sv[i] = xi;
+               nrm += xi * xi;
+               x2 = x1; x1 = xi;
+            }
             nrm = sqrt(nrm);
             if ( !(nrm > 0.0) || !(nrm < 1e300) )
             {
                for (int i = 0; i < k; ++i)
-                  sv[i] = 1.0 / sqrt((double) k);
+                  sv[i] = s0;
                break;
             }
+            const double rn = 1.0 / nrm;
             for (int i = 0; i < k; ++i)
-               sv[i] /= nrm;
+               sv[i] *= rn;
          }
       }
       const double blast = (meta0 >= 0.0) ? 0.0 : ((k - 1 == ovr_idx) ? ovr_beta : beta[k - 1]);
@@ -445,67 +477,43 @@ static int hs_lanczos_lmin_unfused(hipStream_t s, int n, const double* W, int ma
 }
 
 /* ---- 16 < n <= 64: the whole Lanczos run in ONE launch --------------------------------------------------------------- */
-/* One workgroup per matrix (blockIdx.x = X side / Z side).  W = L D L^T is formed in LDS, then k Lanczos steps with
- * twice-applied classical Gram-Schmidt run with W and the basis in LDS, and wavefront 0 solves the tridiagonal problem.
- * Same algorithm and start vector as k_lanczos_fused; replaces 4 GEMM launches + k + 1 launches per pair of estimates. */
+/* One workgroup per matrix (blockIdx.x = X side / Z side).  The operator W = L D L^T is applied in factored form (three
+ * products with n x n matrices held in LDS per step; W itself is never formed, and the operator is exactly symmetric when D
+ * is), k Lanczos steps with twice-applied classical Gram-Schmidt run with the basis in LDS, and wavefront 0 solves the
+ * tridiagonal problem.  Every product and reduction is split over 4 adjacent lanes per row (n <= 64 rows x 4 = 256 threads),
+ * so the dependent chains are n / 4 long.  Same algorithm and start vector as k_lanczos_fused; replaces 4 GEMM launches +
+ * k + 1 launches per pair of estimates. */
 #define LS_MAXK 32
+__device__ __forceinline__ double quad_sum(double x)
+{
+   x += __shfl_xor(x, 1, 64);
+   x += __shfl_xor(x, 2, 64);
+   return x;
+}
+
 __global__ void __launch_bounds__(256) k_lanczos_small(int n, int k, const double* __restrict__ D0, const double* __restrict__ D1,
    double* __restrict__ res0, double* __restrict__ res1, const double* __restrict__ L0, const double* __restrict__ L1)
 {
    extern __shared__ double lz2_smem[];
    __shared__ double alpha[LS_MAXK], beta[LS_MAXK], coef[LS_MAXK + 1];
+   __shared__ double t1[64], t2[64], v[64];
    __shared__ double shr[4];
    __shared__ tridiag_smem T;
    const double* __restrict__ Din = blockIdx.x ? D1 : D0;
    const double* __restrict__ Lin = blockIdx.x ? L1 : L0;
    double* __restrict__ res = blockIdx.x ? res1 : res0;
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-   const int ld = n + 1;
-   double* w = lz2_smem;                /* n x ld: W */
-   double* sl = w + n * ld;             /* L, later the Lanczos basis Q[(k + 1)][n] */
-   double* st = sl + n * ld;            /* L D, later v */
+   const int row = tid >> 2, part = tid & 3;
+   const int ld = n | 1;                /* odd row pitch: rows and columns are both conflict-free */
+   double* sl = lz2_smem;               /* n x ld: L */
+   double* sd = sl + n * ld;            /* n x ld: D */
+   double* Q = sd + n * ld;             /* (k + 1) x n */
    for (int e = tid; e < n * n; e += 256)
    {
       const int r = e / n, c = e - r * n;
-      sl[r * ld + c] = Lin[e];
-      w[r * ld + c] = Din[e];
+      sl[r * ld + c] = (c <= r) ? Lin[e] : 0.0;
+      sd[r * ld + c] = Din[e];
    }
-   __syncthreads();
-   for (int e = tid; e < n * n; e += 256)
-   {
-      const int r = e / n, c = e - r * n;
-      double acc = 0.0;
-      for (int t = 0; t < n; ++t)
-         acc += sl[r * ld + t] * w[t * ld + c];
-      st[r * ld + c] = acc;
-   }
-   __syncthreads();
-   {
-      /* W = (L D) L^T, symmetrised; each thread keeps its entries in registers across the barrier (n^2 <= 16 per thread) */
-      double keep[16];
-      int cnt = 0;
-      for (int e = tid; e < n * n; e += 256)
-      {
-         const int r = e / n, c = e - r * n;
-         double acc = 0.0, acct = 0.0;
-         for (int t = 0; t < n; ++t)
-         {
-            acc += st[r * ld + t] * sl[c * ld + t];
-            acct += st[c * ld + t] * sl[r * ld + t];
-         }
-         keep[cnt++] = 0.5 * (acc + acct);
-      }
-      __syncthreads();
-      cnt = 0;
-      for (int e = tid; e < n * n; e += 256)
-      {
-         const int r = e / n, c = e - r * n;
-         w[r * ld + c] = keep[cnt++];
-      }
-   }
-   __syncthreads();
-   double* Q = sl;                      /* (k + 1) x n, k + 1 <= n + 1 rows of length n fit in n x ld */
-   double* v = st;
    /* start vector */
    double sacc = 0.0;
    if ( tid < n )
@@ -530,45 +538,97 @@ __global__ void __launch_bounds__(256) k_lanczos_small(int n, int k, const doubl
    for (int j = 0; j < k; ++j)
    {
       const double* qj = Q + j * n;
-      /* v = W q_j */
-      if ( tid < n )
+      /* t1 = L^T q_j  (L lower triangular: column `row` starts at its diagonal) */
       {
          double acc = 0.0;
-         for (int t = 0; t < n; ++t)
-            acc += w[tid * ld + t] * qj[t];
-         v[tid] = acc;
+         if ( row < n )
+         {
+#pragma unroll 4
+            for (int t = row + part; t < n; t += 4)
+               acc += sl[t * ld + row] * qj[t];
+         }
+         acc = quad_sum(acc);
+         if ( row < n && part == 0 )
+            t1[row] = acc;
       }
       __syncthreads();
+      /* t2 = D t1 */
+      {
+         double acc = 0.0;
+         if ( row < n )
+         {
+#pragma unroll 4
+            for (int t = part; t < n; t += 4)
+               acc += sd[row * ld + t] * t1[t];
+         }
+         acc = quad_sum(acc);
+         if ( row < n && part == 0 )
+            t2[row] = acc;
+      }
+      __syncthreads();
+      /* v = L t2 */
+      {
+         double acc = 0.0;
+         if ( row < n )
+         {
+#pragma unroll 4
+            for (int t = part; t <= row; t += 4)
+               acc += sl[row * ld + t] * t2[t];
+         }
+         acc = quad_sum(acc);
+         if ( row < n && part == 0 )
+            v[row] = acc;
+      }
+      __syncthreads();
+      double nrm2 = 0.0;
       double aj = 0.0;
+      /* classical Gram-Schmidt against q_0 .. q_j, twice: with |alpha| >> beta (the regime of an interior-point iteration)
+       * the first pass cancels many digits, and a norm-based "twice is enough" test fires at almost every step anyway */
       for (int pass = 0; pass < 2; ++pass)
       {
-         /* c_i = q_i . v : one wavefront per i */
-         for (int i = wave; i <= j; i += 4)
+         /* c_i = q_i . v, i <= j: four lanes per i */
          {
-            const double* q = Q + i * n;
-            const double pr = (lane < n) ? q[lane] * v[lane] : 0.0;
-            const double sm = wsum(pr);
-            if ( lane == 0 )
-               coef[i] = sm;
+            double acc = 0.0;
+            if ( row <= j )
+            {
+               const double* q = Q + row * n;
+#pragma unroll 4
+               for (int e = part; e < n; e += 4)
+                  acc += q[e] * v[e];
+            }
+            acc = quad_sum(acc);
+            if ( row <= j && part == 0 )
+               coef[row] = acc;
          }
          __syncthreads();
          if ( pass == 0 )
             aj = coef[j];
-         if ( tid < n )
+         /* v -= sum_i c_i q_i: four lanes per entry; squared norm of the result per wavefront */
          {
-            double acc = v[tid];
-            for (int i = 0; i <= j; ++i)
-               acc -= coef[i] * Q[i * n + tid];
-            v[tid] = acc;
+            double acc = 0.0;
+            if ( row < n )
+            {
+#pragma unroll 4
+               for (int i = part; i <= j; i += 4)
+                  acc += coef[i] * Q[i * n + row];
+            }
+            acc = quad_sum(acc);
+            double vn = 0.0;
+            if ( row < n && part == 0 )
+            {
+               vn = v[row] - acc;
+               v[row] = vn;
+            }
+            if ( pass == 1 )
+            {
+               const double sq = wsum(vn * vn);
+               if ( lane == 0 ) shr[wave] = sq;
+            }
          }
          __syncthreads();
       }
-      double nr = (tid < n) ? v[tid] * v[tid] : 0.0;
-      nr = wsum(nr);
-      if ( lane == 0 ) shr[wave] = nr;
-      __syncthreads();
-      const double b = sqrt(shr[0] + shr[1] + shr[2] + shr[3]);
-      __syncthreads();
+      nrm2 = shr[0] + shr[1] + shr[2] + shr[3];
+      const double b = sqrt(nrm2);
       if ( fabs(aj) + b > scale )
          scale = fabs(aj) + b;
       const bool broke = (kbreak >= 0) || !(b > 1e-13 * scale) || !(b > 1e-300);
@@ -598,10 +658,11 @@ int hs_lanczos_scaled_small(hipStream_t s, int n, int maxsteps, const double* L0
    if ( !attr_set )
    {
       HS_HIP( hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lanczos_small), hipFuncAttributeMaxDynamicSharedMemorySize,
-            3 * 64 * 65 * (int) sizeof(double)) );
+            (2 * 64 * 65 + (LS_MAXK + 1) * 64) * (int) sizeof(double)) );
       attr_set = true;
    }
-   hipLaunchKernelGGL(k_lanczos_small, dim3(2), dim3(256), (size_t) 3 * n * (n + 1) * sizeof(double), s, n, k, D0, D1, res0, res1, L0, L1);
+   const size_t smem = ((size_t) 2 * n * (n | 1) + (size_t) (k + 1) * n) * sizeof(double);
+   hipLaunchKernelGGL(k_lanczos_small, dim3(2), dim3(256), smem, s, n, k, D0, D1, res0, res1, L0, L1);
    HS_LAUNCH_CHECK();
    return HS_OK;
 }

@@ -342,6 +342,28 @@ extern "C" int hipsdp_lambda_min(int device, int n, const double* W, int steps, 
    return HIPSDP_OK;
 }
 
+/* lambda_min(L D L^T) as the step-length code computes it for small blocks (n <= 16: one-wavefront Jacobi; 16 < n <= 64:
+ * single-launch Lanczos): theta and the residual bound, for the X-side and the Z-side slot at once (same operands) */
+extern "C" int hipsdp_lambda_min_scaled(int device, int n, const double* L, const double* D, int steps, double* theta, double* resid)
+{
+   HS_CALL( pick_device(device) );
+   if ( n <= 0 || n > 64 || theta == NULL ) return HIPSDP_ERR_ARG;
+   const long long n2 = (long long) n * n;
+   DevBuf dL, dD, dR;
+   HS_CALL( dL.alloc(n2) ); HS_CALL( dD.alloc(n2) ); HS_CALL( dR.alloc(16) );
+   HS_CALL( dL.up(L, n2) ); HS_CALL( dD.up(D, n2) );
+   if ( n <= 16 )
+      HS_CALL( hs_lmin_scaled_tiny(0, n, dL.p, dD.p, dL.p, dD.p, dR.p, dR.p + 8) );
+   else
+      HS_CALL( hs_lanczos_scaled_small(0, n, steps > 0 ? steps : 24, dL.p, dD.p, dL.p, dD.p, dR.p, dR.p + 8) );
+   HS_HIP( hipDeviceSynchronize() );
+   double h[16];
+   HS_CALL( dR.down(h, 16) );
+   theta[0] = h[0]; theta[1] = h[8];
+   if ( resid != NULL ) { resid[0] = h[1]; resid[1] = h[9]; }
+   return HIPSDP_OK;
+}
+
 extern "C" int hipsdp_syev(int device, int n, const double* A, double* lam, double* V)
 {
    HS_CALL( pick_device(device) );

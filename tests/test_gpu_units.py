@@ -207,3 +207,34 @@ def test_persistent_gemm_matches_tile_gemm_bitwise(gpu, M, N, K, layB, batch, sp
     used, ndiff = gpu.dgemm_selfcheck(M, N, K, layB=layB, batch=batch, splitk=splitk, flags=flags, beta=beta)
     assert used == expect_v2
     assert ndiff == 0
+
+
+@pytest.mark.parametrize("n", [2, 5, 16, 17, 24, 25, 33, 43, 48, 63, 64])
+def test_small_block_step_length_eigenvalue(gpu, n):
+    """lambda_min(L D L^T) by the small-block kernels (one-wavefront Jacobi up to n = 16, single-launch Lanczos with the
+    tridiagonal problem in registers above): theta - resid <= lambda_min <= theta (Lanczos: Ritz value and its residual
+    bound), and both slots of the launch agree"""
+    import ctypes as C
+    lib = gpu.lib()
+    rng = np.random.default_rng(n)
+    for trial in range(5):
+        L = np.tril(rng.standard_normal((n, n))) + 2.0 * np.eye(n)
+        G = rng.standard_normal((n, n))
+        D = (G + G.T) / 2 - (0.5 * trial) * np.eye(n)
+        if trial >= 3:
+            # the regime of an interior-point iteration: L = inverse Cholesky factor of a nearly singular X, eigenvalues of
+            # L D L^T spread over ten orders of magnitude (|alpha_j| >> beta_j in the Lanczos recurrence)
+            L = np.diag(10.0 ** np.linspace(0, 5, n)) @ L
+        ref = float(np.linalg.eigvalsh(L @ D @ L.T)[0])
+        th = np.zeros(2)
+        rs = np.zeros(2)
+        Lc, Dc = np.ascontiguousarray(L), np.ascontiguousarray(D)
+        rc = lib.hipsdp_lambda_min_scaled(0, n, Lc.ctypes.data_as(C.POINTER(C.c_double)), Dc.ctypes.data_as(C.POINTER(C.c_double)), 24,
+                                          th.ctypes.data_as(C.POINTER(C.c_double)), rs.ctypes.data_as(C.POINTER(C.c_double)))
+        assert rc == 0
+        assert th[0] == th[1] and rs[0] == rs[1]
+        scale = np.abs(np.linalg.eigvalsh(L @ D @ L.T)).max()
+        assert th[0] >= ref - 1e-9 * scale, (th, ref)
+        assert th[0] - rs[0] <= ref + 1e-9 * scale, (th, rs, ref)
+        if n <= 25:
+            assert abs(th[0] - ref) <= 1e-8 * scale          # full Krylov space (or Jacobi): exact
