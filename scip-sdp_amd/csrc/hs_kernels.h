@@ -27,6 +27,7 @@ int hs_gemv_t(hipStream_t s, int R, long long E, const double* A, long long lda,
  * copies on that stream are recorded and then executed in order by one launch */
 void hs_red_batch_begin(hipStream_t s);
 int hs_red_batch_end(void);
+int hs_red_batch_end_publish(hipStream_t s, int n, const double* src, double* dst, unsigned long long seq, unsigned long long* flag);
 void hs_red_batch_reset(void);
 int hs_fill_scalar(hipStream_t s, double* p, double v);
 /* single-block solves (m <= 64) and the direction's closing kernel can be part of a batch: see kernels.hip */

@@ -84,7 +84,11 @@ struct hipsdp_solver
    double *u1, *rhs2, *u2, *dy, *dya;
    double *Mx, *Lm, *dinvm, *Slp;
    double *sc, *red_ws, *gemv_ws, *lan_ws, *lan_ws2, *gws1, *gws2;
-   double* hsc;            /* pinned host mirror of sc followed by the flags (one device->host copy per read-back) */
+   double* hsc;            /* pinned, device-visible host mirror of sc followed by the flags and a sequence number: the last kernel
+                            * before a read-back stores the scalars there itself and the host waits for the number */
+   double* hsc_dev;        /* device view of hsc */
+   bool use_publish;       /* HIPSDP_READBACK=copy selects hipMemcpyAsync + hipStreamSynchronize instead */
+   unsigned long long pub_seq;
    long long hsc_cap;      /* doubles; kept across re-shapes (pinned allocations are slow) */
    int* trsv_ws;           /* block flags of the multi-workgroup triangular solves */
    int trsv_epoch;
@@ -213,6 +217,12 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
    s->sws.T = s->sws.U = s->sws.K = NULL;
    s->flags = NULL;
    s->hsc = NULL;
+   s->hsc_dev = NULL;
+   s->pub_seq = 0;
+   {
+      const char* rb = getenv("HIPSDP_READBACK");
+      s->use_publish = !(rb != NULL && rb[0] == 'c');
+   }
    s->hsc_cap = 0;
    s->trsv_ws = NULL;
    s->trsv_epoch = 0;
@@ -338,12 +348,14 @@ extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int*
    s->nsc = SC_FIXED_END + 8 * (nblocks > 0 ? nblocks : 1) + 8;
    HS_CALL( dalloc(&s->sc, s->nsc + 4) );          /* the 8 int flags live behind the scalars: one read-back covers both */
    s->flags = reinterpret_cast<int*>(s->sc + s->nsc);
-   if ( s->hsc_cap < s->nsc + 4 )
+   if ( s->hsc_cap < s->nsc + 8 )
    {
       if ( s->hsc != NULL ) (void) hipHostFree(s->hsc);
       s->hsc = NULL;
-      s->hsc_cap = 2LL * (s->nsc + 4);
-      HS_HIP( hipHostMalloc((void**) &s->hsc, (size_t) s->hsc_cap * sizeof(double), hipHostMallocDefault) );
+      s->hsc_cap = 2LL * (s->nsc + 8);
+      HS_HIP( hipHostMalloc((void**) &s->hsc, (size_t) s->hsc_cap * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) );
+      HS_HIP( hipHostGetDevicePointer((void**) &s->hsc_dev, s->hsc, 0) );
+      memset(s->hsc, 0, (size_t) s->hsc_cap * sizeof(double));
    }
    HS_CALL( dalloc(&s->red_ws, 1024) );
    s->gemv_ws_len = 8192 + 4LL * 1024 * 4;
@@ -849,9 +861,48 @@ struct HostScalars
 int hs_bcast_doubles(void* comm, double* buf, long long count, hipStream_t stream);
 int hs_bcast_ints(void* comm, int* buf, long long count, hipStream_t stream);
 
+/* Read-back without a copy engine and without a stream synchronisation: a kernel stores n doubles of sc to the host mirror
+ * and then a sequence number; the host polls the number (coherent pinned memory).  The stream is queried now and then so
+ * that a failed launch cannot leave the host spinning. */
+static int publish_and_wait(hipsdp_solver* s, int off, int n)
+{
+   const unsigned long long seq = ++s->pub_seq;
+   volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(s->hsc + s->hsc_cap - 1);
+   HS_CALL( hs_red_batch_end_publish(s->stream, n, s->sc + off, s->hsc_dev + off, seq,
+         reinterpret_cast<unsigned long long*>(s->hsc_dev + s->hsc_cap - 1)) );
+   long long spins = 0;
+   while ( *flag != seq )
+   {
+      if ( (++spins & 0x3FFF) == 0 )
+      {
+         const hipError_t e = hipStreamQuery(s->stream);
+         if ( e == hipSuccess )
+         {
+            if ( *flag == seq )
+               break;
+            HS_HIP( hipStreamSynchronize(s->stream) );
+            if ( *flag != seq )
+            {
+               set_err("read-back kernel finished without publishing its results");
+               return HS_ERR_HIP;
+            }
+            break;
+         }
+         if ( e != hipErrorNotReady )
+         {
+            hs_record_hip_error(e, "hipStreamQuery(read-back)", __FILE__, __LINE__);
+            return HS_ERR_HIP;
+         }
+      }
+   }
+   __atomic_thread_fence(__ATOMIC_ACQUIRE);
+   return HS_OK;
+}
+
 static int read_scalars(hipsdp_solver* s, HostScalars& h, int* flags3)
 {
-   HS_CALL( hs_red_batch_end() );      /* recorded reductions must run before the scalars are read */
+   if ( s->comm != NULL || !s->use_publish )
+      HS_CALL( hs_red_batch_end() );      /* recorded reductions must run before the scalars are read */
    h.v.resize(s->nsc);
    if ( s->comm != NULL )
    {
@@ -860,8 +911,16 @@ static int read_scalars(hipsdp_solver* s, HostScalars& h, int* flags3)
       if ( flags3 != NULL )
          HS_CALL( hs_bcast_ints(s->comm, s->flags, 3, s->stream) );
    }
-   HS_HIP( hipMemcpyAsync(s->hsc, s->sc, (size_t) (s->nsc + (flags3 != NULL ? 4 : 0)) * sizeof(double), hipMemcpyDeviceToHost, s->stream) );
-   HS_HIP( hipStreamSynchronize(s->stream) );
+   if ( s->comm == NULL && s->use_publish )
+   {
+      /* the batch kernel (or a one-block kernel when the batch is empty) stores the scalars to the host mirror itself */
+      HS_CALL( publish_and_wait(s, 0, s->nsc + 4) );
+   }
+   else
+   {
+      HS_HIP( hipMemcpyAsync(s->hsc, s->sc, (size_t) (s->nsc + (flags3 != NULL ? 4 : 0)) * sizeof(double), hipMemcpyDeviceToHost, s->stream) );
+      HS_HIP( hipStreamSynchronize(s->stream) );
+   }
    memcpy(h.v.data(), s->hsc, (size_t) s->nsc * sizeof(double));
    if ( flags3 != NULL )
       memcpy(flags3, s->hsc + s->nsc, 3 * sizeof(int));
@@ -1836,8 +1895,13 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
                break;
             if ( s->comm != NULL )
                HS_CALL( hs_bcast_ints(s->comm, s->flags, 3, st) );
-            HS_HIP( hipMemcpyAsync(s->hsc + s->nsc, s->flags, 4 * sizeof(int), hipMemcpyDeviceToHost, st) );
-            HS_HIP( hipStreamSynchronize(st) );
+            if ( s->comm == NULL && s->use_publish )
+               HS_CALL( publish_and_wait(s, s->nsc, 2) );
+            else
+            {
+               HS_HIP( hipMemcpyAsync(s->hsc + s->nsc, s->flags, 4 * sizeof(int), hipMemcpyDeviceToHost, st) );
+               HS_HIP( hipStreamSynchronize(st) );
+            }
             memcpy(hflags, s->hsc + s->nsc, 3 * sizeof(int));
             if ( hflags[0] == 0 && hflags[1] == 0 )
                break;

@@ -549,7 +549,10 @@ __global__ void __launch_bounds__(256) k_reduce_stage2(int nparts, const double*
 struct rb_desc { int kind; int accumulate; long long n; const double* a; const double* b; const double* c; double* out; double v; };
 struct rb_finish { int m; double eta, rg, sigmu, tau, kappa, etk; const double* u1; const double* u2; double* dy; double* dyt; double* sc;
    int s0, bub, bh, wrp, bu1, dtau, dkappa, den; };
-struct rb_args { int cnt; rb_desc d[RB_MAX]; rb_finish fin; };
+/* pub_*: after the records, copy pub_n doubles to host-visible memory and raise the sequence number there (the host waits for
+ * the number instead of a copy + stream synchronisation) */
+struct rb_args { int cnt; rb_desc d[RB_MAX]; rb_finish fin; int pub_n; const double* pub_src; double* pub_dst;
+   unsigned long long pub_seq; unsigned long long* pub_flag; };
 static thread_local struct { bool open; hipStream_t s; rb_args args; } g_rb = {false, NULL, {0, {}}};
 
 template<int KIND>
@@ -636,14 +639,24 @@ __global__ void __launch_bounds__(256) k_red_batch(rb_args A)
       __threadfence_block();
       __syncthreads();
    }
+   if ( A.pub_n > 0 )
+   {
+      for (int i = threadIdx.x; i < A.pub_n; i += 256)
+         __builtin_nontemporal_store(A.pub_src[i], A.pub_dst + i);
+      __threadfence_system();
+      __syncthreads();
+      if ( threadIdx.x == 0 )
+         __hip_atomic_store(A.pub_flag, A.pub_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+   }
 }
 
 static int rb_flush(void)
 {
-   if ( g_rb.args.cnt > 0 )
+   if ( g_rb.args.cnt > 0 || g_rb.args.pub_n > 0 )
    {
       hipLaunchKernelGGL(k_red_batch, dim3(1), dim3(256), 0, g_rb.s, g_rb.args);
       g_rb.args.cnt = 0;
+      g_rb.args.pub_n = 0;
       HS_LAUNCH_CHECK();
    }
    return HS_OK;
@@ -663,6 +676,7 @@ void hs_red_batch_reset(void)
 {
    g_rb.open = false;
    g_rb.args.cnt = 0;
+   g_rb.args.pub_n = 0;
 }
 
 int hs_red_batch_end(void)
@@ -670,6 +684,20 @@ int hs_red_batch_end(void)
    const int rc = g_rb.open ? rb_flush() : HS_OK;
    g_rb.open = false;
    return rc;
+}
+
+/* closes the batch (if one is open) and makes its kernel - or a kernel of its own when nothing is recorded - copy n doubles
+ * from src (device) to dst (device view of coherent host memory) and then store seq to flag (same kind of memory) */
+int hs_red_batch_end_publish(hipStream_t s, int n, const double* src, double* dst, unsigned long long seq, unsigned long long* flag)
+{
+   if ( g_rb.open && g_rb.s != s )
+      HS_CALL( hs_red_batch_end() );
+   g_rb.s = s;
+   g_rb.args.pub_n = n; g_rb.args.pub_src = src; g_rb.args.pub_dst = dst; g_rb.args.pub_seq = seq; g_rb.args.pub_flag = flag;
+   if ( !g_rb.open )
+      g_rb.args.cnt = 0;
+   g_rb.open = false;
+   return rb_flush();
 }
 
 /* 1: recorded; 0: not recordable (the caller launches normally, after the records were flushed to keep the order) */
