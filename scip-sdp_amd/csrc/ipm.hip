@@ -1774,6 +1774,8 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       const double dta = hs.v[SC_DTAU], dka = hs.v[SC_DKAPPA];
       if ( !std::isfinite(aa) || !std::isfinite(dta) )
       {
+         if ( par.verbose )
+            printf("hipsdp: predictor not finite (alpha %g dtau %g)\n", aa, dta);
          status = HIPSDP_STATUS_NUMERIC;
          break;
       }
@@ -1799,6 +1801,8 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       const double dt = hs.v[SC_DTAU], dk = hs.v[SC_DKAPPA];
       if ( !std::isfinite(alpha) || !std::isfinite(dt) || !std::isfinite(dk) )
       {
+         if ( par.verbose )
+            printf("hipsdp: corrector not finite (alpha %g dtau %g dkappa %g)\n", alpha, dt, dk);
          status = HIPSDP_STATUS_NUMERIC;
          break;
       }
@@ -1852,6 +1856,8 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
          }
          if ( !accepted )
          {
+            if ( par.verbose )
+               printf("hipsdp: no step length down to %g keeps X and Z positive definite\n", alpha);
             HS_CALL( hs_axpy3(st, -applied, m, s->dy, s->y, q, s->dx, s->x, q, s->dz, s->z) );
             s->tau = tau0;
             s->kappa = kappa0;
@@ -1910,6 +1916,8 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
          }
          if ( K > 0 && (hflags[0] != 0 || hflags[1] != 0) )
          {
+            if ( par.verbose )
+               printf("hipsdp: no step length down to %g keeps X and Z positive definite\n", alpha);
             for (auto& B : s->blk)
             {
                const long long n2 = (long long) B.n * B.n;

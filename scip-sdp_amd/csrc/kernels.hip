@@ -584,29 +584,50 @@ __global__ void __launch_bounds__(256) k_red_batch(rb_args A)
       case RB_COPY1:     if ( threadIdx.x == 0 ) *D.out = *D.a; break;
       case RB_SOLVE:
       {
-         __shared__ double tv[64];
+         /* vec <- Linv^T (Linv vec) for `accumulate` right-hand sides, m <= 64: the factor is staged in LDS once (odd pitch:
+          * rows and columns conflict-free), every row of either product is split over four adjacent lanes */
+         __shared__ double sL[64 * 65];
+         __shared__ double tv[64], tw[64];
          const int m = (int) D.n;
          const long long stride = (long long) D.v;
+         const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
+         for (int e = threadIdx.x; e < m * m; e += 256)
+         {
+            const int i = e / m, j = e - i * m;
+            sL[i * 65 + j] = (j <= i) ? D.a[i * 64 + j] : 0.0;
+         }
          for (int k = 0; k < D.accumulate; ++k)
          {
             double* vec = D.out + k * stride;
-            if ( threadIdx.x < 64 )
+            if ( threadIdx.x < m )
+               tv[threadIdx.x] = vec[threadIdx.x];
+            __syncthreads();
             {
-               const int i = threadIdx.x;
                double acc = 0.0;
-               if ( i < m )
-                  for (int j = 0; j <= i; ++j)
-                     acc += D.a[i * 64 + j] * vec[j];
-               tv[i] = acc;
+               if ( row < m )
+               {
+#pragma unroll 4
+                  for (int j = part; j <= row; j += 4)
+                     acc += sL[row * 65 + j] * tv[j];
+               }
+               acc += __shfl_xor(acc, 1, 64);
+               acc += __shfl_xor(acc, 2, 64);
+               if ( row < m && part == 0 )
+                  tw[row] = acc;
             }
             __syncthreads();
-            if ( threadIdx.x < m )
             {
-               const int j = threadIdx.x;
                double acc = 0.0;
-               for (int i = j; i < m; ++i)
-                  acc += D.a[i * 64 + j] * tv[i];
-               vec[j] = acc;
+               if ( row < m )
+               {
+#pragma unroll 4
+                  for (int i = row + part; i < m; i += 4)
+                     acc += sL[i * 65 + row] * tw[i];
+               }
+               acc += __shfl_xor(acc, 1, 64);
+               acc += __shfl_xor(acc, 2, 64);
+               if ( row < m && part == 0 )
+                  vec[row] = acc;
             }
             __syncthreads();
          }
