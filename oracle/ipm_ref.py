@@ -89,10 +89,18 @@ def schur_block(A, X, Zinv):
     return 0.5 * (Mx + Mx.T)
 
 
+import os as _os
+PIVOT_RULE = int(_os.environ.get('HIPSDP_PIVOT_RULE', '2'))     # 0: keep forced columns, 1: zero all forced columns, 2: zero those with a non-positive pivot
+
+
 def chol_psd(M, regtol=1e-13):
     """Cholesky of a positive SEMI-definite matrix (the Schur complement has dependent columns when the constraint
     matrices are linearly dependent): a pivot below regtol * M_kk is replaced by regtol * M_kk (a small positive pivot keeps
-    the direction alive, so that an unbounded ray along it can still be found).  Same rule as k_potrf_diag (scip-sdp_amd/csrc/chol.hip) in semidefinite mode."""
+    the direction alive, so that an unbounded ray along it can still be found).  When the pivot is not even positive the
+    rest of that column is rounding noise of a column that is zero in exact arithmetic and is set to zero: dividing the noise
+    by the forced pivot and eliminating with it amplifies it exponentially over a run of dependent columns (600 random
+    problems of tests/devtools/stress_gpu.py: 27 numerical failures without, 6 with).  Same rule as k_potrf_diag
+    (scip-sdp_amd/csrc/chol.hip) in semidefinite mode."""
     try:
         L = np.linalg.cholesky(M)
         if np.all(np.diag(L) ** 2 > regtol * np.diag(M)):
@@ -104,7 +112,12 @@ def chol_psd(M, regtol=1e-13):
     for k in range(n):
         d = L[k, k]
         if not (d > regtol * M[k, k]) or not (d > 1e-300):
+            zero = PIVOT_RULE == 1 or (PIVOT_RULE == 2 and not (d > 0.0))
             d = regtol * M[k, k] if M[k, k] > 1e-280 else 1.0
+            if zero:
+                L[k, k] = np.sqrt(d)
+                L[k + 1:, k] = 0.0
+                continue
         L[k, k] = np.sqrt(d)
         L[k + 1:, k] /= L[k, k]
         L[k + 1:, k + 1:] -= np.tril(np.outer(L[k + 1:, k], L[k + 1:, k]))

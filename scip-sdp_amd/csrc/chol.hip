@@ -9,6 +9,7 @@
  *     matrix products only (no divisions on the critical path).
  */
 #include "hs_kernels.h"
+#include <cstdlib>
 
 #define NB 64
 #define HS_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if ( e_ != hipSuccess ) { hs_record_hip_error(e_, "kernel launch", __FILE__, __LINE__); return HS_ERR_HIP; } } while (0)
@@ -60,6 +61,8 @@ struct pd_ext
    double*       Mout;
    double*       Linv;
    double*       Gram;
+   int           rule;      /* 0: forced pivots keep their column, 1: forced columns are zeroed, 2: zeroed when the pivot was <= 0 */
+   int*          regmask;   /* semidefinite mode: regmask[j0 + k] = 1 when the pivot of column k was forced (may be NULL) */
 };
 
 template<int NBK>      /* padded block size actually processed: 16, 32 or 64 (tiny blocks skip the identity padding) */
@@ -133,15 +136,23 @@ __global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ A, long
          ca[q] = *reinterpret_cast<const dpair*>(&colp[buf][0][jc][2 * q]);
          cb[q] = *reinterpret_cast<const dpair*>(&colp[buf][1][jc][2 * q]);
       }
+      bool reg0 = false, reg1 = false;
       if ( k < nb )
       {
          if ( diag0 != NULL )
          {
             /* semidefinite mode (Schur complement with dependent columns): a pivot that cancelled to rounding level is
-             * replaced by a small positive one, which keeps the direction alive so that a ray along it can be found */
+             * replaced by a small positive one, which keeps the direction alive so that a ray along it can be found; when
+             * the pivot is not even positive (rule 2; rule 1: every forced pivot) the rest of the column is rounding noise of
+             * a column that is zero in exact arithmetic, and it is SET to zero: dividing noise by the forced pivot and
+             * eliminating with it amplifies the noise exponentially over a run of dependent columns (observed: entries at
+             * 1e158 for m = 200 with rank 136) */
             const double dd = d0s[k];
             if ( !(d0 > regtol * dd) || !(d0 > 1e-300) )
+            {
+               reg0 = (ext.rule == 1) || (ext.rule == 2 && !(d0 > 0.0));
                d0 = (dd > 1e-280) ? regtol * dd : 1.0;
+            }
          }
          else if ( !(d0 > 0.0) )
          {
@@ -152,7 +163,8 @@ __global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ A, long
       }
       double sd0, isd0;
       sqrt_and_rsqrt(d0, &sd0, &isd0);
-      const double l10 = a10 * isd0;
+      const double e0 = reg0 ? 0.0 : isd0;           /* scale of the sub-column (0: forced pivot) */
+      const double l10 = a10 * e0;
       d1 = fma(-l10, l10, d1);
       if ( k + 1 < nb )
       {
@@ -160,7 +172,10 @@ __global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ A, long
          {
             const double dd = d0s[k + 1];
             if ( !(d1 > regtol * dd) || !(d1 > 1e-300) )
+            {
+               reg1 = (ext.rule == 1) || (ext.rule == 2 && !(d1 > 0.0));
                d1 = (dd > 1e-280) ? regtol * dd : 1.0;
+            }
          }
          else if ( !(d1 > 0.0) )
          {
@@ -171,10 +186,16 @@ __global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ A, long
       }
       double sd1, isd1;
       sqrt_and_rsqrt(d1, &sd1, &isd1);
-      const double li0 = (i > k) ? ci0 * isd0 : 0.0;
-      const double li1 = (i > k + 1) ? fma(-li0, l10, ci1) * isd1 : 0.0;
-      const double u = li1 * isd1;
-      const double al = fma(-u * l10, isd0, li0 * isd0);
+      const double e1 = reg1 ? 0.0 : isd1;
+      const double li0 = (i > k) ? ci0 * e0 : 0.0;
+      const double li1 = (i > k + 1) ? fma(-li0, l10, ci1) * e1 : 0.0;
+      const double u = li1 * e1;
+      const double al = fma(-u * l10, e0, li0 * e0);
+      if ( ext.regmask != NULL && tid == 0 )
+      {
+         if ( k < nb ) ext.regmask[j0 + k] = reg0 ? 1 : 0;
+         if ( k + 1 < nb ) ext.regmask[j0 + k + 1] = reg1 ? 1 : 0;
+      }
       if ( jc == (k & 3) )
       {
          /* final value of column k in my row */
@@ -311,7 +332,7 @@ template<int NBK>
 static int launch_potrf_diag(hipStream_t s, double* Ajj, long long lda, int nb, int j0, double* dj, int* flag, const double* diag0,
    const pd_ext* extp = NULL)
 {
-   pd_ext ext = {NULL, NULL, 0.0, NULL, NULL, NULL};
+   pd_ext ext = {NULL, NULL, 0.0, NULL, NULL, NULL, 2, NULL};
    if ( extp != NULL )
       ext = *extp;
    static bool attr_set = false;
@@ -335,7 +356,7 @@ int hs_potrf_small_ext(hipStream_t s, int n, double* L, double* dinv, int* flag,
       return HS_OK;
    if ( n > NB || base == NULL || (Gram != NULL && n > 32) )
       return HS_ERR_ARG;
-   pd_ext ext = {base, dir, alpha, Mout, Linv, Gram};
+   pd_ext ext = {base, dir, alpha, Mout, Linv, Gram, 2, NULL};
    if ( n <= 16 )
       return launch_potrf_diag<16>(s, L, n, n, 0, dinv, flag, NULL, &ext);
    if ( n <= 32 )
@@ -343,10 +364,32 @@ int hs_potrf_small_ext(hipStream_t s, int n, double* L, double* dinv, int* flag,
    return launch_potrf_diag<64>(s, L, n, n, 0, dinv, flag, NULL, &ext);
 }
 
+/* the columns of the panel that belong to forced pivots of the diagonal block are zero in exact arithmetic */
+__global__ void k_zero_forced_cols(int rows, int nb, double* __restrict__ P, long long lda, const int* __restrict__ mask)
+{
+   for (long long e = (long long) blockIdx.x * blockDim.x + threadIdx.x; e < (long long) rows * nb; e += (long long) gridDim.x * blockDim.x)
+   {
+      const int r = (int) (e / nb), c = (int) (e - (long long) r * nb);
+      if ( mask[c] )
+         P[(long long) r * lda + c] = 0.0;
+   }
+}
+
 int hs_potrf(hipStream_t s, int n, double* A, double* dinv, int* flag, const double* diag0)
+{
+   return hs_potrf_psd(s, n, A, dinv, flag, diag0, NULL);
+}
+
+/* diag0 != NULL: semidefinite mode; regmask (n ints, device; required when n > 64 in that mode) receives the forced pivots */
+int hs_potrf_psd(hipStream_t s, int n, double* A, double* dinv, int* flag, const double* diag0, int* regmask)
 {
    if ( n <= 0 )
       return HS_OK;
+   if ( diag0 != NULL && regmask == NULL && n > NB )
+      return HS_ERR_ARG;
+   static int rule = getenv("HIPSDP_PIVOT_RULE") != NULL ? atoi(getenv("HIPSDP_PIVOT_RULE")) : 2;
+   pd_ext ext = {NULL, NULL, 0.0, NULL, NULL, NULL, rule, regmask};
+   const pd_ext* extp = (diag0 != NULL && regmask != NULL) ? &ext : NULL;
    const long long lda = n;
    const int nblk = (n + NB - 1) / NB;
    for (int b = 0; b < nblk; ++b)
@@ -356,11 +399,11 @@ int hs_potrf(hipStream_t s, int n, double* A, double* dinv, int* flag, const dou
       double* Ajj = A + (long long) j0 * lda + j0;
       double* dj = dinv + (long long) b * NB * NB;
       if ( nb <= 16 )
-         HS_CALL( launch_potrf_diag<16>(s, Ajj, lda, nb, j0, dj, flag, diag0) );
+         HS_CALL( launch_potrf_diag<16>(s, Ajj, lda, nb, j0, dj, flag, diag0, extp) );
       else if ( nb <= 32 )
-         HS_CALL( launch_potrf_diag<32>(s, Ajj, lda, nb, j0, dj, flag, diag0) );
+         HS_CALL( launch_potrf_diag<32>(s, Ajj, lda, nb, j0, dj, flag, diag0, extp) );
       else
-         HS_CALL( launch_potrf_diag<64>(s, Ajj, lda, nb, j0, dj, flag, diag0) );
+         HS_CALL( launch_potrf_diag<64>(s, Ajj, lda, nb, j0, dj, flag, diag0, extp) );
       const int j1 = j0 + nb;
       const int rem = n - j1;
       if ( rem <= 0 )
@@ -369,6 +412,13 @@ int hs_potrf(hipStream_t s, int n, double* A, double* dinv, int* flag, const dou
       double* P = A + (long long) j1 * lda + j0;
       hs_gemm_args g1 = {rem, nb, nb, HS_KC, HS_KC, P, lda, 0, dj, NB, 0, P, lda, 0, 1.0, 0.0, 1, 0, 1, NULL};
       HS_CALL( hs_dgemm(s, &g1) );
+      if ( extp != NULL )
+      {
+         long long blocks = ((long long) rem * nb + 255) / 256;
+         if ( blocks > 1024 ) blocks = 1024;
+         hipLaunchKernelGGL(k_zero_forced_cols, dim3((unsigned) blocks), dim3(256), 0, s, rem, nb, P, lda, regmask + j0);
+         HS_LAUNCH_CHECK();
+      }
       /* trailing update: A22 -= P P^T on the lower triangle */
       double* A22 = A + (long long) j1 * lda + j1;
       hs_gemm_args g2 = {rem, rem, nb, HS_KC, HS_KC, P, lda, 0, P, lda, 0, A22, lda, 0, -1.0, 1.0, 1, HS_GEMM_LOWER, 1, NULL};

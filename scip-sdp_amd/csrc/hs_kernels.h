@@ -106,6 +106,7 @@ int  hs_allgather(void* comm, const double* send, double* recv, long long count_
  * diag0 == NULL: strict (definite) mode.  diag0 != NULL (the n original diagonal entries): semidefinite mode, pivots
  * below 1e-13 * diag0[k] are replaced by 1e-13 * diag0[k] and no failure is flagged. */
 int hs_potrf(hipStream_t s, int n, double* A, double* dinv, int* flag, const double* diag0);
+int hs_potrf_psd(hipStream_t s, int n, double* A, double* dinv, int* flag, const double* diag0, int* regmask);
 /* Linv = L^-1 (lower triangular, full n x n storage, upper triangle zero); needs dinv from hs_potrf */
 int hs_trtri(hipStream_t s, int n, const double* L, const double* dinv, double* Linv, double* tmp);
 /* solves L y = r (nrhs <= 4 right-hand sides, rhs[k * ldr + i]) then optionally L^T x = y, in place.  mode 1: forward only,

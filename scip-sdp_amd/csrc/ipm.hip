@@ -83,6 +83,7 @@ struct hipsdp_solver
    double *yt, *dyt, *wt, *AX, *AH, *tmpe, *rp, *rd, *tmpq, *hl, *beta, *elp, *dxa, *dza, *dx, *dz, *xs, *zs, *ys;
    double *u1, *rhs2, *u2, *dy, *dya;
    double *Mx, *Lm, *dinvm, *Slp;
+   int* regmask;           /* forced pivots of the last factorization of M (semidefinite pivot rule) */
    double *sc, *red_ws, *gemv_ws, *lan_ws, *lan_ws2, *gws1, *gws2;
    double* hsc;            /* pinned, device-visible host mirror of sc followed by the flags and a sequence number: the last kernel
                             * before a read-back stores the scalars there itself and the host waits for the number */
@@ -183,6 +184,8 @@ static void free_problem(hipsdp_solver* s)
    s->Mgather = NULL;
    dfree(s->trsv_ws);
    s->trsv_ws = NULL;
+   dfree(s->regmask);
+   s->regmask = NULL;
    s->b = s->Dext = s->y = s->x = s->z = s->yt = s->dyt = s->wt = s->AX = s->AH = s->tmpe = s->rp = s->rd = s->tmpq = s->hl = NULL;
    s->beta = s->elp = s->dxa = s->dza = s->dx = s->dz = s->xs = s->zs = s->ys = s->u1 = s->rhs2 = s->u2 = s->dy = s->dya = NULL;
    s->Mx = s->Lm = s->dinvm = s->Slp = s->sc = s->red_ws = s->gemv_ws = s->lan_ws = s->lan_ws2 = s->gws1 = s->gws2 = NULL;
@@ -225,6 +228,7 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
    }
    s->hsc_cap = 0;
    s->trsv_ws = NULL;
+   s->regmask = NULL;
    s->trsv_epoch = 0;
    s->last_status = HIPSDP_STATUS_UNSOLVED;
    s->sol_scale = 1.0;
@@ -345,6 +349,7 @@ extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int*
    HS_CALL( dalloc(&s->Lm, (long long) m * m) );
    HS_CALL( dalloc(&s->dinvm, (long long) ((m + 63) / 64) * 64 * 64) );
    HS_CALL( dalloc(&s->Slp, (long long) q * m1) );
+   HS_CALL( dalloc(&s->regmask, m) );
    s->nsc = SC_FIXED_END + 8 * (nblocks > 0 ? nblocks : 1) + 8;
    HS_CALL( dalloc(&s->sc, s->nsc + 4) );          /* the 8 int flags live behind the scalars: one read-back covers both */
    s->flags = reinterpret_cast<int*>(s->sc + s->nsc);
@@ -1712,7 +1717,7 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
             HS_HIP( hipMemcpy2DAsync(s->dya, sizeof(double), s->Mx + m1 + 1, (size_t) (m1 + 1) * sizeof(double), sizeof(double), (size_t) m,
                   hipMemcpyDeviceToDevice, st) );
          }
-         HS_CALL( hs_potrf(st, m, s->Lm, s->dinvm, s->flags + 2, s->dya) );
+         HS_CALL( hs_potrf_psd(st, m, s->Lm, s->dinvm, s->flags + 2, s->dya, s->regmask) );
          if ( m <= 64 )
          {
             hipLaunchKernelGGL(k_solve2_small, dim3(1), dim3(128), 0, st, m, s->Mx, s->b, s->dinvm, s->rhs2, s->u2, s->wt);

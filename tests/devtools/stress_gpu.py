@@ -75,6 +75,7 @@ def rand_core(rng):
     return ipm_ref.CoreProblem(b, blocks, D, c), kind
 
 def main():
+    nfail = [0, 0]
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     bad = 0
@@ -87,6 +88,8 @@ def main():
         info = s.solve(gaptol=1e-6, feastol=1e-6, pabstol=1e-5)
         y = s.y(); X = [s.X(k) for k in range(len(core.blocks))]; lp = s.lp(); s.close()
         msg = []
+        nfail[0] += 1 if info.status >= 4 else 0
+        nfail[1] += 1 if ref.status >= 4 else 0
         if info.status != ref.status:
             msg.append("status gpu %d oracle %d" % (info.status, ref.status))
         elif ref.status == ipm_ref.STATUS_OPTIMAL:
@@ -104,7 +107,7 @@ def main():
         if msg:
             bad += 1
             print("seed %d: %s :: %s" % (seed0 + t, tag, "; ".join(msg)), flush=True)
-    print("%d problems, %d with differences, %.1f s" % (count, bad, time.time() - t0))
+    print("%d problems, %d with differences, %.1f s; numerical failures: gpu %d oracle %d" % (count, bad, time.time() - t0, nfail[0], nfail[1]))
     return 1 if bad else 0
 
 if __name__ == "__main__":
