@@ -63,11 +63,14 @@ def planted_pair(n, m, seed):
     return Xs, Zs, ys
 
 
-def cpu_baseline(solver, b, n, m, gpu_iterations, budget_iters=2):
+def cpu_baseline(solver, b, n, m, gpu_iterations, budget_iters=None):
     """CPU restatement (numpy + OpenBLAS threads) of the same algorithm on the same bits: a bounded sample of IPM iterations
     timed on the host cores, extrapolated to the iteration count of the full solve."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ipm_ref
+    if budget_iters is None:
+        # about 10-30 s of CPU work: 4 iterations at C2 (7.5e11 flop each), 1 at T1 (1.2e13)
+        budget_iters = 4 if 4.0 * m * n ** 3 + float(m) ** 2 * n ** 2 < 2e12 else 1
     try:
         from threadpoolctl import threadpool_info
         threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
