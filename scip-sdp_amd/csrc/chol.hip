@@ -61,6 +61,8 @@ struct pd_ext
    double*       Mout;
    double*       Linv;
    double*       Gram;
+   int           set_flag;  /* 1: this launch is the only writer of *flag between two reads: it stores its result (0 = fine) instead
+                              * of recording a failure into a flag that somebody cleared beforehand */
    int           rule;      /* 0: forced pivots keep their column, 1: forced columns are zeroed, 2: zeroed when the pivot was <= 0 */
    int*          regmask;   /* semidefinite mode: regmask[j0 + k] = 1 when the pivot of column k was forced (may be NULL) */
 };
@@ -240,8 +242,13 @@ __global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ A, long
       else if ( ext.base != NULL && i < nb && j < nb )
          A[(long long) i * lda + j] = 0.0;
    }
-   if ( tid == 0 && bad != 0 )
-      atomicCAS(flag, 0, bad);
+   if ( tid == 0 )
+   {
+      if ( ext.set_flag )
+         *flag = bad;
+      else if ( bad != 0 )
+         atomicCAS(flag, 0, bad);
+   }
 
    /* inverse, diagonal 16 x 16 blocks: wavefront w, lane c < 16 solves L_ww x = e_c */
    constexpr int NBLK = NBK / 16;
@@ -332,7 +339,7 @@ template<int NBK>
 static int launch_potrf_diag(hipStream_t s, double* Ajj, long long lda, int nb, int j0, double* dj, int* flag, const double* diag0,
    const pd_ext* extp = NULL)
 {
-   pd_ext ext = {NULL, NULL, 0.0, NULL, NULL, NULL, 2, NULL};
+   pd_ext ext = {NULL, NULL, 0.0, NULL, NULL, NULL, 0, 2, NULL};
    if ( extp != NULL )
       ext = *extp;
    static bool attr_set = false;
@@ -350,13 +357,13 @@ static int launch_potrf_diag(hipStream_t s, double* Ajj, long long lda, int nb, 
 /* single-block factorization (n <= 64) of base + alpha * dir with the fused outputs described at pd_ext: one launch for what
  * the general path does with scale_add, copy, potrf, zero_upper, trtri (+ gemm, mirror for the inverse) */
 int hs_potrf_small_ext(hipStream_t s, int n, double* L, double* dinv, int* flag, const double* base, const double* dir, double alpha,
-   double* Mout, double* Linv, double* Gram)
+   double* Mout, double* Linv, double* Gram, int set_flag)
 {
    if ( n <= 0 )
       return HS_OK;
    if ( n > NB || base == NULL || (Gram != NULL && n > 32) )
       return HS_ERR_ARG;
-   pd_ext ext = {base, dir, alpha, Mout, Linv, Gram, 2, NULL};
+   pd_ext ext = {base, dir, alpha, Mout, Linv, Gram, set_flag, 2, NULL};
    if ( n <= 16 )
       return launch_potrf_diag<16>(s, L, n, n, 0, dinv, flag, NULL, &ext);
    if ( n <= 32 )
@@ -377,19 +384,19 @@ __global__ void k_zero_forced_cols(int rows, int nb, double* __restrict__ P, lon
 
 int hs_potrf(hipStream_t s, int n, double* A, double* dinv, int* flag, const double* diag0)
 {
-   return hs_potrf_psd(s, n, A, dinv, flag, diag0, NULL);
+   return hs_potrf_psd(s, n, A, dinv, flag, diag0, NULL, 0);
 }
 
 /* diag0 != NULL: semidefinite mode; regmask (n ints, device; required when n > 64 in that mode) receives the forced pivots */
-int hs_potrf_psd(hipStream_t s, int n, double* A, double* dinv, int* flag, const double* diag0, int* regmask)
+int hs_potrf_psd(hipStream_t s, int n, double* A, double* dinv, int* flag, const double* diag0, int* regmask, int set_flag)
 {
    if ( n <= 0 )
       return HS_OK;
    if ( diag0 != NULL && regmask == NULL && n > NB )
       return HS_ERR_ARG;
    static int rule = getenv("HIPSDP_PIVOT_RULE") != NULL ? atoi(getenv("HIPSDP_PIVOT_RULE")) : 2;
-   pd_ext ext = {NULL, NULL, 0.0, NULL, NULL, NULL, rule, regmask};
-   const pd_ext* extp = (diag0 != NULL && regmask != NULL) ? &ext : NULL;
+   pd_ext ext = {NULL, NULL, 0.0, NULL, NULL, NULL, (set_flag && n <= NB) ? 1 : 0, rule, regmask};
+   const pd_ext* extp = ((diag0 != NULL && regmask != NULL) || ext.set_flag) ? &ext : NULL;
    const long long lda = n;
    const int nblk = (n + NB - 1) / NB;
    for (int b = 0; b < nblk; ++b)
@@ -412,7 +419,7 @@ int hs_potrf_psd(hipStream_t s, int n, double* A, double* dinv, int* flag, const
       double* P = A + (long long) j1 * lda + j0;
       hs_gemm_args g1 = {rem, nb, nb, HS_KC, HS_KC, P, lda, 0, dj, NB, 0, P, lda, 0, 1.0, 0.0, 1, 0, 1, NULL};
       HS_CALL( hs_dgemm(s, &g1) );
-      if ( extp != NULL )
+      if ( diag0 != NULL && regmask != NULL )
       {
          long long blocks = ((long long) rem * nb + 255) / 256;
          if ( blocks > 1024 ) blocks = 1024;

@@ -106,7 +106,9 @@ int  hs_allgather(void* comm, const double* send, double* recv, long long count_
  * diag0 == NULL: strict (definite) mode.  diag0 != NULL (the n original diagonal entries): semidefinite mode, pivots
  * below 1e-13 * diag0[k] are replaced by 1e-13 * diag0[k] and no failure is flagged. */
 int hs_potrf(hipStream_t s, int n, double* A, double* dinv, int* flag, const double* diag0);
-int hs_potrf_psd(hipStream_t s, int n, double* A, double* dinv, int* flag, const double* diag0, int* regmask);
+/* set_flag: the (single-launch, n <= 64) factorization stores its result into *flag instead of recording a failure into a
+ * cleared flag - for callers where it is the only writer of that flag between two reads */
+int hs_potrf_psd(hipStream_t s, int n, double* A, double* dinv, int* flag, const double* diag0, int* regmask, int set_flag);
 /* Linv = L^-1 (lower triangular, full n x n storage, upper triangle zero); needs dinv from hs_potrf */
 int hs_trtri(hipStream_t s, int n, const double* L, const double* dinv, double* Linv, double* tmp);
 /* solves L y = r (nrhs <= 4 right-hand sides, rhs[k * ldr + i]) then optionally L^T x = y, in place.  mode 1: forward only,
@@ -114,7 +116,7 @@ int hs_trtri(hipStream_t s, int n, const double* L, const double* dinv, double* 
 /* n <= 64: Cholesky of base + alpha * dir in one launch; optionally stores the matrix (Mout), inv(L) as n x n (Linv) and,
  * for n <= 32, the inverse of the matrix (Gram); L gets a zero upper triangle */
 int hs_potrf_small_ext(hipStream_t s, int n, double* L, double* dinv, int* flag, const double* base, const double* dir, double alpha,
-   double* Mout, double* Linv, double* Gram);
+   double* Mout, double* Linv, double* Gram, int set_flag);
 /* all blocks n <= 32: the extended Schur matrix (SDP blocks + LP part, symmetric), Lm = Mx[1:, 1:] and its diagonal in one
  * launch; returns 1 if done, 0 if the sizes do not qualify, < 0 on error */
 int hs_schur_small(hipStream_t s, int m1, int nblk, const int* n, const double* const* A, const double* const* X,

@@ -1461,6 +1461,9 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
    for (auto& B : s->blk)
       if ( B.n > 64 )
          small_all = false;
+   /* one block of at most 64 rows: every Cholesky flag has exactly one writing launch between two reads, which then stores its
+    * result itself and the flags need no clearing */
+   const int setf = (small_all && s->blk.size() == 1) ? 1 : 0;
 
    for (it = 0; it <= par.maxiter; ++it)
    {
@@ -1578,7 +1581,8 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       }
 
       /* ---- factorizations (the factors of an accepted step are re-used: they were computed by its Cholesky check) */
-      HS_HIP( hipMemsetAsync(s->flags, 0, 8 * sizeof(int), st) );
+      if ( !(setf && m <= 64) )
+         HS_HIP( hipMemsetAsync(s->flags, 0, 8 * sizeof(int), st) );
       HS_CALL( fork2(s) );
       for (auto& B : s->blk)
       {
@@ -1591,8 +1595,8 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
              * of Z; after an accepted step they already exist (the step's Cholesky check produced them) */
             if ( !(factors_valid && B.derived_valid) )
             {
-               HS_CALL( hs_potrf_small_ext(st2, n, B.Lz, B.dinvz, s->flags + 0, B.Z, NULL, 0.0, NULL, B.LzInv, n <= 32 ? B.Zinv : NULL) );
-               HS_CALL( hs_potrf_small_ext(st, n, B.Lx, B.dinvx, s->flags + 1, B.X, NULL, 0.0, NULL, B.LxInv, NULL) );
+               HS_CALL( hs_potrf_small_ext(st2, n, B.Lz, B.dinvz, s->flags + 0, B.Z, NULL, 0.0, NULL, B.LzInv, n <= 32 ? B.Zinv : NULL, setf) );
+               HS_CALL( hs_potrf_small_ext(st, n, B.Lx, B.dinvx, s->flags + 1, B.X, NULL, 0.0, NULL, B.LxInv, NULL, setf) );
                B.derived_valid = true;
             }
             if ( n > 32 )
@@ -1717,7 +1721,7 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
             HS_HIP( hipMemcpy2DAsync(s->dya, sizeof(double), s->Mx + m1 + 1, (size_t) (m1 + 1) * sizeof(double), sizeof(double), (size_t) m,
                   hipMemcpyDeviceToDevice, st) );
          }
-         HS_CALL( hs_potrf_psd(st, m, s->Lm, s->dinvm, s->flags + 2, s->dya, s->regmask) );
+         HS_CALL( hs_potrf_psd(st, m, s->Lm, s->dinvm, s->flags + 2, s->dya, s->regmask, setf) );
          if ( m <= 64 )
          {
             hipLaunchKernelGGL(k_solve2_small, dim3(1), dim3(128), 0, st, m, s->Mx, s->b, s->dinvm, s->rhs2, s->u2, s->wt);
@@ -1831,12 +1835,13 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
          bool accepted = false;
          for (int attempt = 0; attempt < 8; ++attempt)
          {
-            HS_HIP( hipMemsetAsync(s->flags, 0, 8 * sizeof(int), st) );
+            if ( !setf )
+               HS_HIP( hipMemsetAsync(s->flags, 0, 8 * sizeof(int), st) );
             for (auto& B : s->blk)
             {
                const int n = B.n;
-               HS_CALL( hs_potrf_small_ext(st, n, B.Lx, B.dinvx, s->flags + 1, B.X, B.dX, alpha, B.Xs, B.LxInv, NULL) );
-               HS_CALL( hs_potrf_small_ext(st, n, B.Lz, B.dinvz, s->flags + 0, B.Z, B.dZ, alpha, B.Zs, B.LzInv, n <= 32 ? B.Zinv : NULL) );
+               HS_CALL( hs_potrf_small_ext(st, n, B.Lx, B.dinvx, s->flags + 1, B.X, B.dX, alpha, B.Xs, B.LxInv, NULL, setf) );
+               HS_CALL( hs_potrf_small_ext(st, n, B.Lz, B.dinvz, s->flags + 0, B.Z, B.dZ, alpha, B.Zs, B.LzInv, n <= 32 ? B.Zinv : NULL, setf) );
                std::swap(B.X, B.Xs);
                std::swap(B.Z, B.Zs);
             }
@@ -1890,8 +1895,8 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
                hipStream_t st2 = s->use2 ? s->stream2 : s->stream;
                if ( n <= 64 )
                {
-                  HS_CALL( hs_potrf_small_ext(st, n, B.Lx, B.dinvx, s->flags + 1, B.X, B.dX, alpha, B.Xs, B.LxInv, NULL) );
-                  HS_CALL( hs_potrf_small_ext(st2, n, B.Lz, B.dinvz, s->flags + 0, B.Z, B.dZ, alpha, B.Zs, B.LzInv, n <= 32 ? B.Zinv : NULL) );
+                  HS_CALL( hs_potrf_small_ext(st, n, B.Lx, B.dinvx, s->flags + 1, B.X, B.dX, alpha, B.Xs, B.LxInv, NULL, setf) );
+                  HS_CALL( hs_potrf_small_ext(st2, n, B.Lz, B.dinvz, s->flags + 0, B.Z, B.dZ, alpha, B.Zs, B.LzInv, n <= 32 ? B.Zinv : NULL, setf) );
                   continue;
                }
                HS_CALL( hs_scale_add(st, n2, alpha, B.dX, 1.0, B.Xs, B.X) );
