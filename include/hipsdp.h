@@ -56,6 +56,9 @@ typedef struct hipsdp_params
    int    reserved;
    double pabstol;       /* > 0: optimal termination also needs ||b - A(X)||_2 <= pabstol, ABSOLUTE: the caller's own check of
                           * the X-side is absolute (sdpsolchecker.c:775-931 with SCIP_SDPPAR_FEASTOL) while pinf is relative */
+   double preoptgap;     /* > 0: the first iterate that is feasible to feastol with relative gap
+                          * gap / (1 + |pobj| / 2 + |dobj| / 2) < preoptgap is kept as "preoptimal solution"
+                          * (SCIP_SDPPAR_WARMSTARTPOGAP, type_sdpi.h:61; capture rule of sdpisolver_dsdp.c:323-358) */
 } hipsdp_params;
 
 typedef struct hipsdp_info
@@ -123,6 +126,10 @@ int  hipsdp_get_y(hipsdp_solver* solver, double* y);
 int  hipsdp_get_X(hipsdp_solver* solver, int block, double* X);
 int  hipsdp_get_Z(hipsdp_solver* solver, int block, double* Z);
 int  hipsdp_get_lp(hipsdp_solver* solver, double* x, double* z);
+/* the preoptimal iterate of the last solve (params.preoptgap > 0): *available = 0 when none was captured; y (m), x (q) and
+ * X of a block as hipsdp_get_y / get_lp / get_X return the final ones; any output pointer may be NULL */
+int  hipsdp_get_preoptimal(hipsdp_solver* solver, int* available, double* y, double* x);
+int  hipsdp_get_preoptimal_X(hipsdp_solver* solver, int block, double* X);
 
 /* smallest eigenvalue of  sum_i A_i^k y_i - A_0^k  for every block, on the device (backs the feasibility check of
  * sdpsolchecker.c:201-257 inside the backend); y: m host values; lmin: nblocks host values */

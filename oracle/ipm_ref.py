@@ -48,7 +48,8 @@ class CoreProblem:
 
 
 class Params:
-    def __init__(self, gaptol=1e-5, feastol=1e-5, maxiter=100, gamma=0.98, verbose=False, infeastol=1e-7, pabstol=0.0):
+    def __init__(self, gaptol=1e-5, feastol=1e-5, maxiter=100, gamma=0.98, verbose=False, infeastol=1e-7, pabstol=0.0, preoptgap=0.0):
+        self.preoptgap = preoptgap    # > 0: keep the first feasible iterate with relative gap below it (Result.pre)
         self.gaptol = gaptol          # relative gap / absolute gap tolerance (relax_sdp.c:70)
         self.feastol = feastol        # residual tolerance (relax_sdp.c:71)
         self.maxiter = maxiter
@@ -191,6 +192,7 @@ def hsd_solve(prob, par=None, start=None):
     res = Result()
     res.status = STATUS_ITERLIM
     res.history = []
+    res.pre = None
     it = 0
     certwait = 0
     nstall = 0
@@ -220,6 +222,12 @@ def hsd_solve(prob, par=None, start=None):
         if par.verbose:
             print("it %3d mu %.3e pinf %.3e dinf %.3e gap %.3e pobj %.8e dobj %.8e tau %.3e kap %.3e" %
                   (it, mu, pinf, dinf, gap, pobj / tau, dobj / tau, tau, kappa))
+
+        # ---- preoptimal iterate: first one feasible to tolerance with relative gap below preoptgap (capture rule of
+        # sdpisolver_dsdp.c:323-358; SCIP_SDPPAR_WARMSTARTPOGAP)
+        if par.preoptgap > 0.0 and res.pre is None and pinf <= par.feastol and dabs <= par.feastol \
+                and gap / (1.0 + 0.5 * abs(pobj / tau) + 0.5 * abs(dobj / tau)) < par.preoptgap:
+            res.pre = dict(it=it, y=y / tau, X=[Xk / tau for Xk in X], x=x / tau)
 
         # ---- termination
         # optimal: absolute gap (sdpisolver_dsdp.c:1558-1571) and feasibility of y / tau within feastol

@@ -15,7 +15,7 @@ STATUS_NAMES = {0: "optimal", 1: "dual_infeasible", 2: "dual_unbounded", 3: "bot
 class Params(C.Structure):
     _fields_ = [("gaptol", C.c_double), ("feastol", C.c_double), ("infeastol", C.c_double), ("objlimit", C.c_double),
                 ("timelimit", C.c_double), ("gamma", C.c_double), ("ws_gbytes", C.c_double), ("maxiter", C.c_int),
-                ("verbose", C.c_int), ("lanczos_steps", C.c_int), ("reserved", C.c_int), ("pabstol", C.c_double)]
+                ("verbose", C.c_int), ("lanczos_steps", C.c_int), ("reserved", C.c_int), ("pabstol", C.c_double), ("preoptgap", C.c_double)]
 
 
 class Info(C.Structure):
@@ -176,6 +176,21 @@ class Solver:
         z = np.zeros(self.q)
         _chk(lib().hipsdp_get_lp(self.h, _dp(x), _dp(z)), "hipsdp_get_lp")
         return x, z
+
+    def preoptimal(self):
+        """(y, [X_k], x) of the preoptimal iterate of the last solve (params preoptgap > 0) or None"""
+        avail = C.c_int(0)
+        y = np.zeros(max(1, self.m))
+        x = np.zeros(max(1, self.q))
+        _chk(lib().hipsdp_get_preoptimal(self.h, C.byref(avail), _dp(y), _dp(x)), "hipsdp_get_preoptimal")
+        if not avail.value:
+            return None
+        Xs = []
+        for k, n in enumerate(self.ns):
+            X = np.zeros((n, n))
+            _chk(lib().hipsdp_get_preoptimal_X(self.h, k, _dp(X)), "hipsdp_get_preoptimal_X")
+            Xs.append(X)
+        return y[:self.m], Xs, x[:self.q]
 
     def check_y(self, y):
         y = _f64(y)

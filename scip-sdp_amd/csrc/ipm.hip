@@ -58,6 +58,7 @@ struct Block
    double *dinvz, *dinvx;
    double *Xs, *Zs;  /* saved iterate for step back-off */
    double *T2, *W2;  /* scratch of the second queue */
+   double *Xpre;     /* X of the preoptimal iterate (allocated at the first capture) */
    double *Apk;      /* (m + 1) x Lp packed lower copy of A for the HBM-bound passes; NULL when memory is short */
    double *pkv;      /* 2 Lp: packed vector in / out */
    long long Lp;
@@ -83,6 +84,9 @@ struct hipsdp_solver
    double *yt, *dyt, *wt, *AX, *AH, *tmpe, *rp, *rd, *tmpq, *hl, *beta, *elp, *dxa, *dza, *dx, *dz, *xs, *zs, *ys;
    double *u1, *rhs2, *u2, *dy, *dya;
    double *Mx, *Lm, *dinvm, *Slp;
+   double *pre_y, *pre_x;  /* preoptimal iterate (params.preoptgap): y and the LP multipliers; X per block in Block::Xpre */
+   bool pre_valid;
+   double pre_scale;       /* 1 / tau at the capture */
    int* regmask;           /* forced pivots of the last factorization of M (semidefinite pivot rule) */
    double *sc, *red_ws, *gemv_ws, *lan_ws, *lan_ws2, *gws1, *gws2;
    double* hsc;            /* pinned, device-visible host mirror of sc followed by the flags and a sequence number: the last kernel
@@ -153,6 +157,7 @@ extern "C" void hipsdp_default_params(hipsdp_params* p)
    p->lanczos_steps = 24;
    p->reserved = 0;
    p->pabstol = 0.0;
+   p->preoptgap = 0.0;
 }
 
 template<class T>
@@ -171,7 +176,7 @@ static void free_problem(hipsdp_solver* s)
    for (auto& B : s->blk)
    {
       double* ptrs[] = {B.A, B.X, B.Z, B.Rd, B.Lz, B.LzInv, B.Zinv, B.Lx, B.LxInv, B.B, B.H, B.G, B.GZ, B.dXa, B.dZa, B.dX, B.dZ,
-         B.E, B.W, B.T1, B.dinvz, B.dinvx, B.Xs, B.Zs, B.Apk, B.pkv, B.T2, B.W2};
+         B.E, B.W, B.T1, B.dinvz, B.dinvx, B.Xs, B.Zs, B.Apk, B.pkv, B.T2, B.W2, B.Xpre};
       for (double* p : ptrs) dfree(p);
    }
    s->blk.clear();
@@ -186,6 +191,9 @@ static void free_problem(hipsdp_solver* s)
    s->trsv_ws = NULL;
    dfree(s->regmask);
    s->regmask = NULL;
+   dfree(s->pre_y); dfree(s->pre_x);
+   s->pre_y = s->pre_x = NULL;
+   s->pre_valid = false;
    s->b = s->Dext = s->y = s->x = s->z = s->yt = s->dyt = s->wt = s->AX = s->AH = s->tmpe = s->rp = s->rd = s->tmpq = s->hl = NULL;
    s->beta = s->elp = s->dxa = s->dza = s->dx = s->dz = s->xs = s->zs = s->ys = s->u1 = s->rhs2 = s->u2 = s->dy = s->dya = NULL;
    s->Mx = s->Lm = s->dinvm = s->Slp = s->sc = s->red_ws = s->gemv_ws = s->lan_ws = s->lan_ws2 = s->gws1 = s->gws2 = NULL;
@@ -228,6 +236,9 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
    }
    s->hsc_cap = 0;
    s->trsv_ws = NULL;
+   s->pre_y = s->pre_x = NULL;
+   s->pre_valid = false;
+   s->pre_scale = 1.0;
    s->regmask = NULL;
    s->trsv_epoch = 0;
    s->last_status = HIPSDP_STATUS_UNSOLVED;
@@ -1285,6 +1296,7 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
    memset(info, 0, sizeof(*info));
    info->status = HIPSDP_STATUS_UNSOLVED;
    hs_red_batch_reset();
+   s->pre_valid = false;
    HS_CALL( ensure_schur_ws(s) );
    HS_CALL( ensure_packed(s) );
    {
@@ -1500,6 +1512,28 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       {
          status = HIPSDP_STATUS_NUMERIC;
          break;
+      }
+      /* ---- preoptimal iterate (warm-start point for the children of a node: relax_sdp.c "warmstartpreoptsol"): the first
+       * interior iterate that is feasible to tolerance with a relative gap below preoptgap, as DSDP's monitor captures it
+       * (sdpisolver_dsdp.c:323-358) */
+      if ( par.preoptgap > 0.0 && !s->pre_valid && pinf <= par.feastol && dabs <= par.feastol
+         && gap / (1.0 + 0.5 * fabs(pobj / tau) + 0.5 * fabs(dobj / tau)) < par.preoptgap )
+      {
+         if ( s->pre_y == NULL )
+         {
+            HS_CALL( dalloc(&s->pre_y, m) );
+            HS_CALL( dalloc(&s->pre_x, q) );
+         }
+         if ( m > 0 ) HS_CALL( hs_copy(st, s->pre_y, s->y, m) );
+         if ( q > 0 ) HS_CALL( hs_copy(st, s->pre_x, s->x, q) );
+         for (auto& B : s->blk)
+         {
+            if ( B.Xpre == NULL )
+               HS_CALL( dalloc(&B.Xpre, (long long) B.n * B.n) );
+            HS_CALL( hs_copy(st, B.Xpre, B.X, (long long) B.n * B.n) );
+         }
+         s->pre_scale = 1.0 / tau;
+         s->pre_valid = true;
       }
       /* ---- termination (mirrors oracle/ipm_ref.py) */
       /* objective limit: with X feasible to tolerance, pobj is a lower bound of the minimisation problem
@@ -2017,6 +2051,23 @@ extern "C" int hipsdp_get_lp(hipsdp_solver* s, double* x, double* z)
    if ( x != NULL ) HS_CALL( read_scaled(s, s->x, s->q, s->sol_scale, x) );
    if ( z != NULL ) HS_CALL( read_scaled(s, s->z, s->q, s->sol_scale, z) );
    return HIPSDP_OK;
+}
+
+extern "C" int hipsdp_get_preoptimal(hipsdp_solver* s, int* available, double* y, double* x)
+{
+   if ( s == NULL || !s->solved || available == NULL ) return HIPSDP_ERR_ARG;
+   *available = s->pre_valid ? 1 : 0;
+   if ( !s->pre_valid )
+      return HIPSDP_OK;
+   if ( y != NULL ) HS_CALL( read_scaled(s, s->pre_y, s->m, s->pre_scale, y) );
+   if ( x != NULL ) HS_CALL( read_scaled(s, s->pre_x, s->q, s->pre_scale, x) );
+   return HIPSDP_OK;
+}
+
+extern "C" int hipsdp_get_preoptimal_X(hipsdp_solver* s, int block, double* X)
+{
+   if ( s == NULL || !s->solved || !s->pre_valid || X == NULL || block < 0 || block >= (int) s->blk.size() ) return HIPSDP_ERR_ARG;
+   return read_scaled(s, s->blk[block].Xpre, (long long) s->blk[block].n * s->blk[block].n, s->pre_scale, X);
 }
 
 extern "C" int hipsdp_check_y(hipsdp_solver* s, const double* y, double* lmin, double* lpviol)

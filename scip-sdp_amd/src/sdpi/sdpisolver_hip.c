@@ -505,6 +505,7 @@ static SCIP_RETCODE engineSolve(SCIP_SDPISOLVER* s, SCIP_Real gaptol, SCIP_Real 
    /* the caller validates the X-side ABSOLUTELY with SCIP_SDPPAR_FEASTOL (sdpsolchecker.c:775-931) while the engine's own
     * measure is relative to 1 + ||b||: when the outer tolerance is the looser one, ask for it explicitly */
    par.pabstol = (s->feastol > feastol) ? s->feastol : 0.0;
+   par.preoptgap = (! s->penalty && s->preoptimalgap > 0.0) ? s->preoptimalgap : 0.0;
    par.objlimit = (s->penalty ? HS_INFINITY : s->objlimit);
    par.timelimit = remaining < HS_INFINITY ? remaining : 0.0;
    par.verbose = s->sdpinfo ? 1 : 0;
@@ -1308,23 +1309,118 @@ SCIP_RETCODE SCIPsdpiSolverGetDualSol(SCIP_SDPISOLVER* sdpisolver, SCIP_Real* ob
    return SCIP_OKAY;
 }
 
-/* preoptimal solutions are only requested from backends named DSDP / SDPA (relax_sdp.c:3863,5021): report "none" */
+/* Preoptimal solution (sdpisolver_dsdp.c:2257-2319, sdpisolver_sdpa.cpp:2426-2670): the engine keeps the first iterate that is
+ * feasible to tolerance with relative gap below SCIP_SDPPAR_WARMSTARTPOGAP (hipsdp_params.preoptgap); y and, as in the SDPA
+ * backend, the primal matrix in the sparse original-index format of SCIPsdpiSolverGetPrimalMatrix.  relax_sdp.c only asks
+ * backends named DSDP / SDPA for it (relax_sdp.c:3863, 5021), see INTEGRATION.md.  The two functions below present the
+ * preoptimal X / LP multipliers to the regular extraction code by swapping the solution arrays for the duration of the call. */
+static SCIP_RETCODE preoptimalPrimal(SCIP_SDPISOLVER* s, SCIP_Bool fill, int nblocks, int* startXnblocknonz, int** startXrow,
+   int** startXcol, SCIP_Real** startXval)
+{
+   SCIP_Real** Xpre = NULL;
+   SCIP_Real* xpre = NULL;
+   SCIP_Real** saveX = s->Xsol;
+   SCIP_Real* savex = s->xlp;
+   SCIP_RETCODE retcode = SCIP_OKAY;
+   int avail = 0;
+   int e;
+
+   if ( HSALLOC(s, &Xpre, s->nengineblocks > 0 ? s->nengineblocks : 1) == NULL )
+      return SCIP_NOMEMORY;
+   for (e = 0; e < s->nengineblocks; ++e)
+      Xpre[e] = NULL;
+   if ( HSALLOC(s, &xpre, s->nxlp > 0 ? s->nxlp : 1) == NULL )
+      retcode = SCIP_NOMEMORY;
+   for (e = 0; e < s->nengineblocks && retcode == SCIP_OKAY; ++e)
+   {
+      if ( HSALLOC(s, &Xpre[e], s->Xsize[e] * s->Xsize[e]) == NULL )
+         retcode = SCIP_NOMEMORY;
+      else if ( hipsdp_get_preoptimal_X(s->engine, e, Xpre[e]) != HIPSDP_OK )
+         retcode = SCIP_LPERROR;
+   }
+   if ( retcode == SCIP_OKAY && hipsdp_get_preoptimal(s->engine, &avail, NULL, xpre) != HIPSDP_OK )
+      retcode = SCIP_LPERROR;
+   if ( retcode == SCIP_OKAY )
+   {
+      s->Xsol = Xpre;
+      s->xlp = xpre;
+      if ( fill )
+         retcode = SCIPsdpiSolverGetPrimalMatrix(s, nblocks, startXnblocknonz, startXrow, startXcol, startXval);
+      else
+         retcode = SCIPsdpiSolverGetPrimalNonzeros(s, nblocks, startXnblocknonz);
+      s->Xsol = saveX;
+      s->xlp = savex;
+   }
+   for (e = 0; e < s->nengineblocks; ++e)
+      if ( Xpre[e] != NULL )
+         HSFREE(s, &Xpre[e], s->Xsize[e] * s->Xsize[e]);
+   if ( xpre != NULL )
+      HSFREE(s, &xpre, s->nxlp > 0 ? s->nxlp : 1);
+   HSFREE(s, &Xpre, s->nengineblocks > 0 ? s->nengineblocks : 1);
+   return retcode;
+}
+
+static SCIP_Bool preoptimalAvailable(SCIP_SDPISOLVER* s)
+{
+   int avail = 0;
+   if ( ! s->solved || s->penalty || s->engine == NULL || s->preoptimalgap <= 0.0 )
+      return FALSE;
+   if ( hipsdp_get_preoptimal(s->engine, &avail, NULL, NULL) != HIPSDP_OK )
+      return FALSE;
+   return avail != 0;
+}
+
 SCIP_RETCODE SCIPsdpiSolverGetPreoptimalPrimalNonzeros(SCIP_SDPISOLVER* sdpisolver, int nblocks, int* startXnblocknonz)
 {
-   (void) sdpisolver;
-   if ( nblocks > 0 && startXnblocknonz != NULL )
-      startXnblocknonz[0] = -1;
-   return SCIP_OKAY;
+   SCIP_SDPISOLVER* s = sdpisolver;
+   assert( s != NULL && startXnblocknonz != NULL );
+   if ( ! preoptimalAvailable(s) || nblocks != s->nsdpblocks + 1 )
+   {
+      if ( nblocks > 0 )
+         startXnblocknonz[0] = -1;
+      return SCIP_OKAY;
+   }
+   return preoptimalPrimal(s, FALSE, nblocks, startXnblocknonz, NULL, NULL, NULL);
 }
 
 SCIP_RETCODE SCIPsdpiSolverGetPreoptimalSol(SCIP_SDPISOLVER* sdpisolver, SCIP_Bool* success, SCIP_Real* dualsol, int nblocks,
    int* startXnblocknonz, int** startXrow, int** startXcol, SCIP_Real** startXval)
 {
-   (void) sdpisolver; (void) dualsol; (void) startXrow; (void) startXcol; (void) startXval;
-   assert( success != NULL );
+   SCIP_SDPISOLVER* s = sdpisolver;
+   assert( s != NULL && success != NULL );
    *success = FALSE;
-   if ( nblocks > 0 && startXnblocknonz != NULL )
-      startXnblocknonz[0] = -1;
+   if ( ! preoptimalAvailable(s) )
+   {
+      if ( nblocks > 0 && startXnblocknonz != NULL )
+         startXnblocknonz[0] = -1;
+      return SCIP_OKAY;
+   }
+   if ( dualsol != NULL )
+   {
+      SCIP_Real* ypre = NULL;
+      int avail = 0;
+      int v;
+      ALLOC_OR_FAIL(s, &ypre, s->nysol > 0 ? s->nysol : 1);
+      if ( hipsdp_get_preoptimal(s->engine, &avail, ypre, NULL) != HIPSDP_OK )
+      {
+         HSFREE(s, &ypre, s->nysol > 0 ? s->nysol : 1);
+         return SCIP_LPERROR;
+      }
+      for (v = 0; v < s->nvars; ++v)
+         dualsol[v] = s->inputtoactive[v] > 0 ? ypre[s->inputtoactive[v] - 1] : s->fixedvarsval[v];
+      HSFREE(s, &ypre, s->nysol > 0 ? s->nysol : 1);
+   }
+   if ( nblocks != -1 )
+   {
+      SCIP_RETCODE retcode;
+      assert( startXnblocknonz != NULL && startXrow != NULL && startXcol != NULL && startXval != NULL );
+      if ( nblocks != s->nsdpblocks + 1 )
+         return SCIP_LPERROR;
+      retcode = preoptimalPrimal(s, TRUE, nblocks, startXnblocknonz, startXrow, startXcol, startXval);
+      if ( retcode != SCIP_OKAY )
+         return retcode;
+   }
+   *success = TRUE;
    return SCIP_OKAY;
 }
 

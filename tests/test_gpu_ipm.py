@@ -293,3 +293,38 @@ def test_eigenvector_cuts_on_the_device(gpu):
         assert len(ev0) == 0
         assert len(s.eigencuts(0, y, 1e-6, 0)[0]) == 0
         s.close()
+
+
+def test_preoptimal_iterate_matches_the_oracle(gpu):
+    """params.preoptgap (SCIP_SDPPAR_WARMSTARTPOGAP): the engine keeps the first iterate that is feasible to tolerance with a
+    relative gap below it - the same iterate the oracle keeps, strictly interior, and not the final one"""
+    rng = np.random.default_rng(8)
+    for (n, m, q) in [(12, 9, 0), (30, 40, 6)]:
+        b, A, ys, Xs, Zs = instances.planted_dense(n, m)
+        if q:
+            D = rng.standard_normal((q, m))
+            c = D @ ys - rng.uniform(0.1, 1.0, q)
+            core = ipm_ref.CoreProblem(b, [A], D, c)
+        else:
+            core = ipm_ref.CoreProblem(b, [A])
+        ref = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-7, feastol=1e-6, preoptgap=1e-2))
+        assert ref.status == 0 and ref.pre is not None and ref.pre["it"] < ref.iterations
+        s = gpu.Solver(0)
+        s.load_core(core)
+        info = s.solve(gaptol=1e-7, feastol=1e-6, preoptgap=1e-2)
+        pre = s.preoptimal()
+        yfin = s.y()
+        assert info.status == 0 and info.iterations == ref.iterations and pre is not None
+        y, X, x = pre
+        assert np.max(np.abs(y - ref.pre["y"])) <= 1e-6 * max(1.0, np.max(np.abs(ref.pre["y"])))
+        assert np.max(np.abs(X[0] - ref.pre["X"][0])) <= 1e-6 * max(1.0, np.max(np.abs(ref.pre["X"][0])))
+        if q:
+            assert np.max(np.abs(x - ref.pre["x"])) <= 1e-6 * max(1.0, np.max(np.abs(ref.pre["x"])))
+        assert np.linalg.eigvalsh(X[0])[0] > 0.0                          # interior
+        Z = np.tensordot(y, A[1:], axes=(0, 0)) - A[0]
+        assert np.linalg.eigvalsh(Z)[0] > -1e-5
+        assert np.max(np.abs(y - yfin)) > 1e-9                            # not the final iterate
+        # without the parameter nothing is kept
+        s.solve(gaptol=1e-7, feastol=1e-6)
+        assert s.preoptimal() is None
+        s.close()

@@ -290,3 +290,53 @@ def test_warm_start_through_the_solver_interface(gpu):
     rc, _, _ = s.solve(P, start=startbad)
     assert s.flag("IsOptimal") and s.iterations() == cold_it
     s.free()
+
+
+def test_preoptimal_solution_through_the_solver_interface(gpu):
+    """SCIPsdpiSolverGetPreoptimalSol / GetPreoptimalPrimalNonzeros (sdpisolver.h; SDPA semantics sdpisolver_sdpa.cpp:2426-2670):
+    with SCIP_SDPPAR_WARMSTARTPOGAP set the backend returns the preoptimal y in original indices and X in the sparse
+    original-index format with the LP block last; without it success = FALSE and the first count is -1"""
+    case = [c for c in CASES["cases"] if c["name"] == "test11"][0]          # min x, x I - [1 2; 2 4] psd: y = 5, X = [.2 .4; .4 .8]
+    P = sdpi_prepare.prepare(build(case))
+    s = new_solver(gpu)
+    PI, PD = C.POINTER(C.c_int), C.POINTER(C.c_double)
+    lib = gpu.lib()
+
+    def ask():
+        nb = len(P.prob.blocks) + 1
+        cnt = np.zeros(nb, dtype=np.int32)
+        assert lib.SCIPsdpiSolverGetPreoptimalPrimalNonzeros(s.h, nb, cnt.ctypes.data_as(PI)) == sdpi_call.SCIP_OKAY
+        if cnt[0] < 0:
+            return None
+        rows = [np.zeros(max(int(k), 1), dtype=np.int32) for k in cnt]
+        cols = [np.zeros(max(int(k), 1), dtype=np.int32) for k in cnt]
+        vals = [np.zeros(max(int(k), 1)) for k in cnt]
+        pr, pc, pv = (PI * nb)(), (PI * nb)(), (PD * nb)()
+        for b in range(nb):
+            pr[b], pc[b], pv[b] = rows[b].ctypes.data_as(PI), cols[b].ctypes.data_as(PI), vals[b].ctypes.data_as(PD)
+        ok = C.c_uint(0)
+        y = np.zeros(P.prob.nvars)
+        cnt2 = cnt.copy()
+        assert lib.SCIPsdpiSolverGetPreoptimalSol(s.h, C.byref(ok), y.ctypes.data_as(PD), nb, cnt2.ctypes.data_as(PI), pr, pc, pv) \
+            == sdpi_call.SCIP_OKAY
+        assert ok.value == 1 and list(cnt2) == list(cnt)
+        return y, [(rows[b][:cnt[b]], cols[b][:cnt[b]], vals[b][:cnt[b]]) for b in range(nb)]
+
+    rc, _, _ = s.solve(P)
+    assert rc == sdpi_call.SCIP_OKAY and s.flag("IsOptimal")
+    assert ask() is None                                                       # parameter not set (default -1)
+    assert s.set_real(12, 1e-2) == sdpi_call.SCIP_OKAY                         # SCIP_SDPPAR_WARMSTARTPOGAP
+    rc, _, _ = s.solve(P)
+    assert rc == sdpi_call.SCIP_OKAY and s.flag("IsOptimal")
+    got = ask()
+    assert got is not None
+    y, X = got
+    rc, obj, yfin = s.dual_sol()
+    assert abs(y[0] - 5.0) <= 0.2      # near the optimum (on this tiny problem the first feasible iterate may be the last one)
+    r, c, v = X[0]
+    M = np.zeros((2, 2))
+    for rr, cc, vv in zip(r, c, v):
+        M[rr, cc] = vv
+        M[cc, rr] = vv
+    assert np.linalg.eigvalsh(M)[0] > 0.0 and np.max(np.abs(M - np.array([[0.2, 0.4], [0.4, 0.8]]))) <= 0.1
+    s.free()
