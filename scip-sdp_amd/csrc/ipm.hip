@@ -923,9 +923,8 @@ static int read_scalars(hipsdp_solver* s, HostScalars& h, int* flags3)
    if ( s->comm != NULL )
    {
       /* all ranks computed the same numbers; broadcasting rank 0's copy makes the control flow identical by construction */
-      HS_CALL( hs_bcast_doubles(s->comm, s->sc, s->nsc, s->stream) );
-      if ( flags3 != NULL )
-         HS_CALL( hs_bcast_ints(s->comm, s->flags, 3, s->stream) );
+      /* the flags live right behind the scalars: one broadcast covers both */
+      HS_CALL( hs_bcast_doubles(s->comm, s->sc, s->nsc + (flags3 != NULL ? 2 : 0), s->stream) );
    }
    if ( s->comm == NULL && s->use_publish )
    {
