@@ -33,10 +33,11 @@ def instance_to_sdpi(inst):
 
 
 class NodeResult:
-    def __init__(self, status, obj=None, y=None):
+    def __init__(self, status, obj=None, y=None, aux=None):
         self.status = status      # 'optimal' | 'infeasible' | 'unbounded' | 'failed'
         self.obj = obj
         self.y = y
+        self.aux = aux            # whatever the node solver wants its children to see (P.parent_aux): warm-start data
 
 
 def check_fixed_point(prob, y, tol=1e-6):
@@ -74,12 +75,13 @@ def branch_and_bound(prob, intvars, solve_node, inttol=1e-5, maxnodes=20000, ver
     class _Stack:
         def append(self, item):
             counter[0] += 1
-            heapq.heappush(heap, (self.bound, counter[0], item[0], item[1]))
+            heapq.heappush(heap, (self.bound, counter[0], item[0], item[1], self.aux))
     stack = _Stack()
     stack.bound = -math.inf
+    stack.aux = None
     stack.append((prob.lb.copy(), prob.ub.copy()))
     while heap and nnodes < maxnodes:
-        pbound, _, lb, ub = heapq.heappop(heap)
+        pbound, _, lb, ub, paux = heapq.heappop(heap)
         if pbound >= best[0] - 1e-6 * max(1.0, abs(best[0])):
             continue                                       # the parent's bound already prunes this node
         nnodes += 1
@@ -94,8 +96,10 @@ def branch_and_bound(prob, intvars, solve_node, inttol=1e-5, maxnodes=20000, ver
                 if val < best[0] - 1e-9:
                     best = [val, y]
             continue
+        P.parent_aux = paux
         res = solve_node(P)
         stack.bound = res.obj if res.status == 'optimal' else pbound
+        stack.aux = res.aux if res.status == 'optimal' else paux
         if res.status == 'infeasible':
             continue
         if res.status != 'optimal':

@@ -80,3 +80,25 @@ def test_bnb_reproduces_short_solu_cbf(gpu, name):
     assert abs(sense * best + c0 - CBF_SOLU[name]) <= 1e-4
     assert all(abs(y[v] - round(y[v])) <= 1e-9 for v in ints)
     assert failed <= max(4, nodes // 10)
+
+
+@pytest.mark.parametrize("name", ["example_TT.dat-s.gz", "example_CLS.dat-s.gz", "example_small.dat-s"])
+def test_bnb_with_warm_started_nodes(gpu, name):
+    """BASELINE config 3 names warm starts: every child starts from its parent's (y, Z(y), X) pushed into the interior
+    (tests/warm_bnb.py; simple variant of relax_sdp.c's "warmstartipfactor" combination), handed over through starty / startZ* /
+    startX* in original indices with the LP block last.  Same optimum, fewer interior-point iterations per node."""
+    import warm_bnb
+    inst = sdpa_io.read_sdpa(os.path.join(GOLDEN, "instances", name))
+    prob = bnb.instance_to_sdpi(inst)
+    out = {}
+    for lam in (0.0, 0.5):
+        s, solve, stats = warm_bnb.warm_node_solver(gpu.lib(), 1e-6, lam)
+        best, y, nodes, failed = bnb.branch_and_bound(prob, inst.intvars, solve)
+        s.free()
+        out[lam] = (best, nodes, failed, stats["iters"] / max(1, stats["calls"]), stats["warm"], stats["time"])
+        print("%s interior factor %.1f: optimum %s, %d nodes, %.1f IPM iterations per node, %d warm starts, %.3f s in the engine, %d unresolved"
+              % (name, lam, best, nodes, out[lam][3], stats["warm"], stats["time"], failed))
+    assert abs(out[0.5][0] - SOLU[name]) <= 1e-4 * max(1.0, abs(SOLU[name]))
+    assert out[0.5][4] >= out[0.5][1] - 1 - out[0.5][2]                 # every node but the root was warm started
+    assert out[0.5][3] <= 0.9 * out[0.0][3]                               # at least 10 % fewer iterations per node
+    assert out[0.5][2] <= max(2, out[0.5][1] // 20)
