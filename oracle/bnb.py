@@ -97,10 +97,11 @@ def branch_and_bound(prob, intvars, solve_node, inttol=1e-5, maxnodes=20000, ver
                     best = [val, y]
             continue
         P.parent_aux = paux
+        P.cutoff = best[0]            # incumbent value: a node solver may stop as soon as its lower bound exceeds it
         res = solve_node(P)
         stack.bound = res.obj if res.status == 'optimal' else pbound
         stack.aux = res.aux if res.status == 'optimal' else paux
-        if res.status == 'infeasible':
+        if res.status in ('infeasible', 'cutoff'):
             continue
         if res.status != 'optimal':
             nfailed += 1

@@ -68,12 +68,13 @@ def make_start(prob, P, aux, lam):
     return dict(y=y, Z=Zb, X=Xb)
 
 
-def warm_node_solver(lib, tol, lam):
-    """lam <= 0: cold starts (same bookkeeping)"""
+def warm_node_solver(lib, tol, lam, use_objlimit=False):
+    """lam <= 0: cold starts (same bookkeeping); use_objlimit: hand the incumbent to the backend as SCIP_SDPPAR_OBJLIMIT
+    (relaxing/SDP/objlimit of the reference, relax_sdp.c:4074-4079), nodes that exceed it stop early"""
     s = sdpi_call.SdpiSolver(lib)
     for par in (1, 2, 3):
         assert s.set_real(par, tol) == sdpi_call.SCIP_OKAY
-    stats = dict(calls=0, iters=0, warm=0, time=0.0)
+    stats = dict(calls=0, iters=0, warm=0, time=0.0, cutoff=0)
 
     def solve(P):
         prob = P.prob
@@ -81,6 +82,9 @@ def warm_node_solver(lib, tol, lam):
         if lam > 0.0 and getattr(P, "parent_aux", None) is not None:
             start = make_start(prob, P, P.parent_aux, lam)
             stats["warm"] += 1
+        if use_objlimit:
+            cut = getattr(P, "cutoff", np.inf)
+            assert s.set_real(4, cut if np.isfinite(cut) else INF) == sdpi_call.SCIP_OKAY
         rc, _, _ = s.solve(P, start=start)
         assert rc == sdpi_call.SCIP_OKAY
         stats["calls"] += 1
@@ -88,6 +92,9 @@ def warm_node_solver(lib, tol, lam):
         stats["time"] += s.opttime()
         if s.flag("IsDualInfeasible"):
             return bnb.NodeResult('infeasible')
+        if use_objlimit and s.flag("IsObjlimExc"):
+            stats["cutoff"] += 1
+            return bnb.NodeResult('cutoff')
         if s.flag("IsDualUnbounded"):
             return bnb.NodeResult('unbounded')
         if not s.flag("IsOptimal"):
