@@ -328,3 +328,28 @@ def test_preoptimal_iterate_matches_the_oracle(gpu):
         s.solve(gaptol=1e-7, feastol=1e-6)
         assert s.preoptimal() is None
         s.close()
+
+
+@pytest.mark.parametrize("mode", ["K3", "R", "U"])
+def test_sharded_forms_with_several_blocks_and_lp_rows(gpu, mode, monkeypatch):
+    """blocks of different sizes (70 crosses the 64 boundary, 20 leaves slices of the column form empty) plus LP rows: the
+    sharded Schur forms add the blocks' contributions, then the LP term, exactly like the default assembly"""
+    rng = np.random.default_rng(17)
+    m = 30
+    blocks = []
+    for n in (70, 20):
+        A = rng.standard_normal((m + 1, n, n))
+        A = A + A.transpose(0, 2, 1)
+        A[0] = -np.eye(n) * 3.0 + 0.1 * A[0]
+        blocks.append(A)
+    D = np.concatenate([rng.standard_normal((4, m)), np.eye(m), -np.eye(m)])
+    c = np.concatenate([-np.ones(4) * 4.0, -2.0 * np.ones(m), -2.0 * np.ones(m)])
+    core = ipm_ref.CoreProblem(rng.standard_normal(m), blocks, D, c)
+    base = gpu_solve(gpu, core, gaptol=1e-6, feastol=1e-6)
+    monkeypatch.setenv("HIPSDP_SCHUR", mode)
+    alt = gpu_solve(gpu, core, gaptol=1e-6, feastol=1e-6)
+    monkeypatch.delenv("HIPSDP_SCHUR")
+    assert base["info"].status == 0 and alt["info"].status == 0 and alt["info"].iterations == base["info"].iterations
+    assert np.max(np.abs(alt["y"] - base["y"])) <= 1e-8
+    ok, det = checker.certificate(core, alt["y"], alt["X"], alt["lp"][0], TOL, TOL)
+    assert ok, det
