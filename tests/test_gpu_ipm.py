@@ -353,3 +353,32 @@ def test_sharded_forms_with_several_blocks_and_lp_rows(gpu, mode, monkeypatch):
     assert np.max(np.abs(alt["y"] - base["y"])) <= 1e-8
     ok, det = checker.certificate(core, alt["y"], alt["X"], alt["lp"][0], TOL, TOL)
     assert ok, det
+
+
+def test_full_size_t1_properties(gpu):
+    """BASELINE's 1-GPU target size (n = 1000, m = 2000: 16 GB of constraint matrices generated in HBM): size-independent
+    properties only - planted optimum value on both sides, the y-side acceptance test (lambda_min of sum A_i y_i - A_0 on
+    the device, what sdpsolchecker.c:201-257 checks), X psd, and run-to-run bitwise reproducibility."""
+    n, m = 1000, 2000
+    Q, _ = np.linalg.qr(instances.counter_normal(20240 + 1000003, np.arange(n * n, dtype=np.uint64)).reshape(n, n))
+    r = n // 4
+    ev = 1.0 + instances.counter_uniform(20240 + 2000003, np.arange(n, dtype=np.uint64))
+    Xs = (Q * np.where(np.arange(n) < r, ev, 0.0)) @ Q.T
+    Zs = (Q * np.where(np.arange(n) < r, 0.0, ev)) @ Q.T
+    ys = 2.0 * instances.counter_uniform(20240 + 3000003, np.arange(m, dtype=np.uint64)) - 1.0
+    s = gpu.Solver(0)
+    s.set_shape(m, [n], 0)
+    b = s.gen_planted(n, m, 20240, Xs, Zs, ys)
+    info = s.solve(gaptol=1e-5, feastol=1e-5)
+    y1, X1 = s.y(), s.X(0)
+    opt = float(b @ ys)
+    assert info.status == 0
+    assert abs(info.dobj - opt) <= TOL * (1 + abs(opt)) and abs(info.pobj - opt) <= TOL * (1 + abs(opt))
+    assert abs(float(b @ y1) - opt) <= TOL * (1 + abs(opt))
+    lmin, viol = s.check_y(y1)
+    assert lmin[0] >= -TOL and viol == 0.0
+    assert np.linalg.eigvalsh(X1)[0] >= -TOL
+    info2 = s.solve(gaptol=1e-5, feastol=1e-5)
+    assert np.array_equal(s.y(), y1) and info2.iterations == info.iterations
+    assert info.schur_flops / max(info.schur_seconds, 1e-12) > 30e12           # north_star: >= 30 % of the FP64 matrix peak
+    s.close()
