@@ -1247,7 +1247,8 @@ static int steplen_enqueue(hipsdp_solver* s)
    hs_red_batch_begin(s->stream);
    HS_CALL( hs_ratio_min(s->stream, s->q, s->x, s->dx, s->sc + SC_RATX, 0, s->red_ws) );
    HS_CALL( hs_ratio_min(s->stream, s->q, s->z, s->dz, s->sc + SC_RATZ, 0, s->red_ws) );
-   HS_CALL( hs_red_batch_end() );
+   /* the batch stays open: both callers read the scalars next, and the read-back's launch executes the records and stores
+    * the results to the host in one go (read_scalars closes the batch either way) */
    return HS_OK;
 }
 
