@@ -118,6 +118,8 @@ struct hipsdp_solver
    std::vector<double*> master_A;
    /* multi GPU */
    void* comm; int rank, nranks;
+   double* passg;          /* gather buffer of the row-sharded passes: nranks * ceil(m1 / nranks) doubles */
+   int shard_passes;       /* -1: by size (>= 64 MB per pass), 0 / 1: HIPSDP_SHARD_PASSES */
    hipsdp_params par;
 };
 
@@ -187,6 +189,8 @@ static void free_problem(hipsdp_solver* s)
    hs_schur_ws_free(&s->sws);
    dfree(s->Mgather);
    s->Mgather = NULL;
+   dfree(s->passg);
+   s->passg = NULL;
    dfree(s->trsv_ws);
    s->trsv_ws = NULL;
    dfree(s->regmask);
@@ -221,6 +225,8 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
    s->b = s->Dext = s->y = s->x = s->z = NULL;
    s->shaped = s->solved = s->have_start = false;
    s->comm = NULL; s->rank = 0; s->nranks = 1;
+   s->passg = NULL;
+   s->shard_passes = getenv("HIPSDP_SHARD_PASSES") != NULL ? atoi(getenv("HIPSDP_SHARD_PASSES")) : -1;
    s->master_nvars = 0;
    s->Mgather = NULL;
    s->schur_mode_rows = false;
@@ -956,10 +962,55 @@ static int ensure_packed(hipsdp_solver* s)
    return HS_OK;
 }
 
+int hs_allreduce_sum(void* comm, double* buf, long long count, hipStream_t stream);
+
+/* Several ranks: a pass over the constraint matrices of a block is HBM-bound and every rank holds all of A, so each rank
+ * sweeps only its ceil(m1 / ranks) matrices: A(V) is completed by an all-gather of m1 numbers, A^T(coef) by an all-reduce of
+ * the (packed) n x n partial sums.  Every rank decides from the sizes alone (same decision everywhere). */
+static bool passes_sharded(const hipsdp_solver* s, const Block& B)
+{
+   if ( s->comm == NULL || s->nranks < 2 )
+      return false;
+   if ( s->shard_passes >= 0 )
+      return s->shard_passes != 0;
+   return 8.0 * (double) (s->m + 1) * (double) B.n * (double) B.n >= 64e6;
+}
+
+static void pass_rows(const hipsdp_solver* s, int* chunk, int* r0, int* r1)
+{
+   const int m1 = s->m + 1;
+   const int c = (m1 + s->nranks - 1) / s->nranks;
+   *chunk = c;
+   *r0 = s->rank * c < m1 ? s->rank * c : m1;
+   *r1 = *r0 + c < m1 ? *r0 + c : m1;
+}
+
 /* out[m + 1] = <A_i, V>, V symmetric */
 static int pass_A(hipsdp_solver* s, Block& B, const double* V, double* out)
 {
    const int m1 = s->m + 1;
+   if ( passes_sharded(s, B) )
+   {
+      int c, r0, r1;
+      pass_rows(s, &c, &r0, &r1);
+      if ( s->passg == NULL )
+         HS_CALL( dalloc(&s->passg, (long long) c * s->nranks) );
+      double* mine = s->passg + (long long) s->rank * c;
+      if ( B.Apk != NULL )
+      {
+         HS_CALL( hs_pack_weighted(s->stream, B.n, V, B.pkv) );
+         const double* v = B.pkv;
+         if ( r1 > r0 )
+            HS_CALL( hs_gemv_n(s->stream, r1 - r0, B.Lp, B.Apk + (long long) r0 * B.Lp, B.Lp, 1, &v, mine, r1 - r0, s->gemv_ws, s->gemv_ws_len) );
+      }
+      else if ( r1 > r0 )
+      {
+         const long long n2 = (long long) B.n * B.n;
+         HS_CALL( hs_gemv_n(s->stream, r1 - r0, n2, B.A + (long long) r0 * n2, n2, 1, &V, mine, r1 - r0, s->gemv_ws, s->gemv_ws_len) );
+      }
+      HS_CALL( hs_allgather_inplace(s->comm, s->passg, c, s->rank, s->stream) );
+      return hs_copy(s->stream, out, s->passg, m1);
+   }
    if ( B.Apk != NULL )
    {
       HS_CALL( hs_pack_weighted(s->stream, B.n, V, B.pkv) );
@@ -973,12 +1024,27 @@ static int pass_A(hipsdp_solver* s, Block& B, const double* V, double* out)
 static int pass_AT(hipsdp_solver* s, Block& B, const double* coef, double sa, const double* add, double* out)
 {
    const int m1 = s->m + 1;
+   const long long n2 = (long long) B.n * B.n;
+   if ( passes_sharded(s, B) )
+   {
+      int c, r0, r1;
+      pass_rows(s, &c, &r0, &r1);
+      if ( B.Apk != NULL )
+      {
+         HS_CALL( hs_gemv_t(s->stream, r1 - r0, B.Lp, B.Apk + (long long) r0 * B.Lp, B.Lp, coef + r0, 0.0, NULL, B.pkv + B.Lp) );
+         HS_CALL( hs_allreduce_sum(s->comm, B.pkv + B.Lp, B.Lp, s->stream) );
+         return hs_unpack_sym(s->stream, B.n, B.pkv + B.Lp, sa, add, out);
+      }
+      /* the additive term enters once: on rank 0 */
+      HS_CALL( hs_gemv_t(s->stream, r1 - r0, n2, B.A + (long long) r0 * n2, n2, coef + r0, s->rank == 0 ? sa : 0.0,
+            s->rank == 0 ? add : NULL, out) );
+      return hs_allreduce_sum(s->comm, out, n2, s->stream);
+   }
    if ( B.Apk != NULL )
    {
       HS_CALL( hs_gemv_t(s->stream, m1, B.Lp, B.Apk, B.Lp, coef, 0.0, NULL, B.pkv + B.Lp) );
       return hs_unpack_sym(s->stream, B.n, B.pkv + B.Lp, sa, add, out);
    }
-   const long long n2 = (long long) B.n * B.n;
    return hs_gemv_t(s->stream, m1, n2, B.A, n2, coef, sa, add, out);
 }
 
