@@ -180,7 +180,7 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: synthetic single dense block n=%d, m=%d, fp64, planted optimum, cold start, "
-                               "gaptol=feastol=1e-5, A resident in HBM; N > 1: Schur assembly sharded over the GPUs (column slices of W_j = G A_j R), one RCCL all-reduce of the partial Schur matrices per iteration" % (n, m),
+                               "gaptol=feastol=1e-5, A resident in HBM; N > 1: Schur assembly (column slices of W_j = G A_j R, RCCL all-reduce of the partial Schur matrices) and the passes over A (by rows, RCCL all-gather / all-reduce) sharded over the GPUs, everything else replicated" % (n, m),
                    "parallelism": "schur-shards x%d" % world,
                    "n": n, "m": m, "seed": args.seed},
         "iters_per_sec": iters / elapsed,
