@@ -839,26 +839,42 @@ static int ensure_schur_ws(hipsdp_solver* s)
    const char* mode = getenv("HIPSDP_SCHUR");
    s->schur_mode_cols = false;
    s->schur_sim_shards = 0;
-   int shards = s->comm != NULL ? s->nranks : 0;
-   if ( s->comm == NULL && mode != NULL && mode[0] == 'K' && atoi(mode + 1) >= 1 && atoi(mode + 1) <= 64 )
-      shards = s->schur_sim_shards = atoi(mode + 1);
-   if ( shards > 0 && !(mode != NULL && (mode[0] == 'R' || mode[0] == 'U')) )
-   {
-      /* column slices: the workspace holds the widest slice any rank gets (every rank derives the same number, so all
-       * ranks take the same branch - the two sharded forms use different collectives) */
-      long long slice_max = 1;
+   /* Column slices of the W formulation: S slices in total, every rank works through S / ranks of them one after the other
+    * (one rank: all of them).  S = ranks when the workspace for one slice fits the budget, otherwise the smallest multiple
+    * that does - this is also how one GPU keeps the cheaper W formulation when T and W do not fit as a whole (n = 2000,
+    * m = 4000: 2 x 128 GB).  The workspace holds the widest slice; every rank derives the same numbers, so all ranks take
+    * the same branch (the two sharded forms use different collectives). */
+   const int ranks = s->comm != NULL ? s->nranks : 1;
+   auto widest = [&](int S) -> long long {
+      long long w = 1;
       for (auto& B : s->blk)
-         for (int g = 0; g < shards; ++g)
+         for (int g = 0; g < S; ++g)
          {
             int c0, cw;
-            hs_shard_cols(m1, B.n, shards, g, &c0, &cw);
-            if ( (long long) B.n * cw > slice_max ) slice_max = (long long) B.n * cw;
+            hs_shard_cols(m1, B.n, S, g, &c0, &cw);
+            if ( (long long) B.n * cw > w ) w = (long long) B.n * cw;
          }
-      if ( 2.0 * 8.0 * (double) m1 * (double) slice_max <= budget * 1e9 )
-      {
-         HS_CALL( hs_schur_ws_alloc(&s->sws, m1, slice_max, budget) );
-         s->schur_mode_cols = true;
-      }
+      return w;
+   };
+   int S = 0;
+   if ( s->comm == NULL && mode != NULL && mode[0] == 'K' && atoi(mode + 1) >= 1 && atoi(mode + 1) <= 64 )
+      S = atoi(mode + 1);
+   else if ( !(mode != NULL && (mode[0] == 'R' || mode[0] == 'U')) && (mode == NULL || s->comm != NULL) )
+   {
+      const bool whole_fits = 2.0 * 8.0 * (double) m1 * (double) n2max <= budget * 1e9;
+      if ( s->comm != NULL || !whole_fits )
+         for (int k = 1; k * ranks <= 64; ++k)
+            if ( (s->comm != NULL || k > 1) && 2.0 * 8.0 * (double) m1 * (double) widest(k * ranks) <= budget * 1e9 )
+            {
+               S = k * ranks;
+               break;
+            }
+   }
+   if ( S > 0 && 2.0 * 8.0 * (double) m1 * (double) widest(S) <= budget * 1e9 )
+   {
+      HS_CALL( hs_schur_ws_alloc(&s->sws, m1, widest(S), budget) );
+      s->schur_mode_cols = true;
+      s->schur_sim_shards = S;
    }
    if ( !s->schur_mode_cols )
       HS_CALL( hs_schur_ws_alloc(&s->sws, m1, n2max, budget) );
@@ -1753,13 +1769,15 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       HS_CALL( hs_fill(st, s->Mx, (long long) m1 * m1, 0.0) );
       if ( s->schur_mode_cols )
       {
-         /* sharded assembly, W formulation: this rank's column slice of every W_j, partial matrices summed over the ranks */
-         const int shards = s->comm != NULL ? s->nranks : s->schur_sim_shards;
-         for (int g = (s->comm != NULL ? s->rank : 0); g < (s->comm != NULL ? s->rank + 1 : shards); ++g)
+         /* W formulation in column slices: this rank's slices of every W_j, partial matrices summed over the ranks */
+         const int S = s->schur_sim_shards;
+         const int per = S / (s->comm != NULL ? s->nranks : 1);
+         const int g0 = (s->comm != NULL ? s->rank : 0) * per;
+         for (int g = g0; g < g0 + per; ++g)
             for (auto& B : s->blk)
             {
                int c0, cw;
-               hs_shard_cols(m1, B.n, shards, g, &c0, &cw);
+               hs_shard_cols(m1, B.n, S, g, &c0, &cw);
                HS_CALL( hs_schur_Wcols(st, m1, B.n, B.A, B.Lx, B.LzInv, s->Mx, &s->sws, c0, cw) );
             }
          if ( s->comm != NULL )

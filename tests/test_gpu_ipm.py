@@ -382,3 +382,15 @@ def test_full_size_t1_properties(gpu):
     assert np.array_equal(s.y(), y1) and info2.iterations == info.iterations
     assert info.schur_flops / max(info.schur_seconds, 1e-12) > 30e12           # north_star: >= 30 % of the FP64 matrix peak
     s.close()
+
+
+def test_w_formulation_in_slices_when_the_workspace_is_small(gpu):
+    """when T and W do not fit the workspace budget as a whole (n = 2000, m = 4000 on one GPU: 2 x 128 GB) the engine keeps
+    the cheaper W formulation by working through column slices one after the other; forced here with a tiny budget"""
+    b, A, ys, Xs, Zs = instances.planted_dense(100, 60)
+    core = ipm_ref.CoreProblem(b, [A])
+    base = gpu_solve(gpu, core, gaptol=1e-6, feastol=1e-6)
+    for gb in (0.004, 0.0012):                                   # 4 MB -> 3 slices, 1.2 MB -> the 16-column granularity
+        alt = gpu_solve(gpu, core, gaptol=1e-6, feastol=1e-6, ws_gbytes=gb)
+        assert alt["info"].status == 0 and alt["info"].iterations == base["info"].iterations
+        assert np.max(np.abs(alt["y"] - base["y"])) <= 1e-8

@@ -33,7 +33,7 @@ def run_world(tmp_path, world, n, m, q, tag, env=None):
     return [json.load(open(o)) for o in outs]
 
 
-@pytest.mark.parametrize("form", ["columns", "rows", "columns+passes"])
+@pytest.mark.parametrize("form", ["columns", "rows", "columns+passes", "columns, small workspace"])
 @pytest.mark.parametrize("world,n,m,q", [(2, 40, 70, 0), (3, 33, 50, 7), (4, 70, 130, 0), (2, 24, 1, 0), (4, 20, 5, 3)])
 def test_ranks_sharing_the_schur_matrix_reproduce_the_single_rank_solve(gpu, tmp_path, world, n, m, q, form):
     """form = columns: the default (column slices of the W formulation, all-reduce); rows: HIPSDP_SCHUR=R (row chunks of the U
@@ -42,6 +42,8 @@ def test_ranks_sharing_the_schur_matrix_reproduce_the_single_rank_solve(gpu, tmp
     production).  n = 20 and 33 leave ranks without a column, m = 1 and 5 leave ranks without a row: they contribute zeros."""
     one = run_world(tmp_path, 1, n, m, q, "w1")[0]
     env = {"HIPSDP_SCHUR": "R"} if form == "rows" else ({"HIPSDP_SHARD_PASSES": "1"} if form == "columns+passes" else {"HIPSDP_SHARD_PASSES": "0"})
+    if form == "columns, small workspace":
+        env["HIPSDP_WS_GB"] = "0.0004"          # 400 kB: several column slices per rank (or the row form when even 16 columns do not fit)
     many = run_world(tmp_path, world, n, m, q, "w%d" % world, env=env)
     assert one["status"] == 0
     y1 = np.array(one["y"])
