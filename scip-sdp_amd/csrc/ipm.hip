@@ -836,6 +836,15 @@ static int ensure_schur_ws(hipsdp_solver* s)
    const char* env = getenv("HIPSDP_WS_GB");
    if ( env != NULL && atof(env) > 0.0 )
       budget = atof(env);
+   else if ( s->par.ws_gbytes <= 0.0 && s->comm == NULL )
+   {
+      /* one rank, nothing prescribed: three quarters of what is free now (A and its packed copy are allocated), at least the
+       * default - wider slices and fewer of them when the whole T, W pair does not fit (several ranks keep the fixed default:
+       * every rank must derive the same slicing) */
+      size_t fr = 0, tot = 0;
+      if ( hipMemGetInfo(&fr, &tot) == hipSuccess && 0.75e-9 * (double) fr > budget )
+         budget = 0.75e-9 * (double) fr;
+   }
    const char* mode = getenv("HIPSDP_SCHUR");
    s->schur_mode_cols = false;
    s->schur_sim_shards = 0;
