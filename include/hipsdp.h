@@ -144,6 +144,18 @@ int  hipsdp_eigencuts(hipsdp_solver* solver, int block, const double* y, double 
 
 /* multi-GPU: Schur rows are sharded over the ranks of an RCCL communicator (one process per GPU); comm comes from hipsdp_comm_create[_host] */
 int  hipsdp_set_comm(hipsdp_solver* solver, void* comm, int rank, int nranks);
+/* Constraint matrices sharded by variable ("A is sharded by variable when it cannot be replicated",
+ * n = 4000 / m = 8000 is 1 TB of A): rank g of the communicator holds the matrices of the variables [g c, (g + 1) c),
+ * c = ceil((m + 1) / ranks) (index 0 = the constant matrix, which every rank keeps as well); hipsdp_add_entries,
+ * hipsdp_set_block_dense and hipsdp_gen_planted store only what the rank holds, the passes over A are completed by an
+ * all-gather / all-reduce, and the Schur assembly forms W_j = G A_j R where A_j lives, re-distributes the ENTRIES of the W_j
+ * with one all-to-all per column slice (rank h receives its n / ranks rows of all W_j) and sums the partial Gram matrices.
+ * mode 1: shard; -1: shard only when the replicated matrices would take more than 60 % of the device memory; 0: replicate
+ * (default).  Call after hipsdp_set_comm and before hipsdp_set_shape; the mode applies to every later hipsdp_set_shape. */
+int  hipsdp_shard_matrices(hipsdp_solver* solver, int mode);
+/* measurement transport: a communicator of nranks ranks of which only `rank` exists - collectives move nothing, results are
+ * meaningless; it times one rank's share of a sharded solve at sizes that need several GPUs (tests/devtools/shard_time.py) */
+int  hipsdp_comm_create_null(int rank, int nranks, void** comm);
 /* host-only helper: column ranges of the sharded assembly, bounds[0 .. nranks]; rank g owns [bounds[g], bounds[g + 1]) */
 int  hipsdp_shard_columns(int m1, int n, int nranks, int* bounds);
 int  hipsdp_comm_create(const void* unique_id_128bytes, int rank, int nranks, void** comm);

@@ -28,14 +28,14 @@ __device__ __forceinline__ double counter_normal(unsigned long long seed, unsign
 }
 
 /* A_i = (G_i + G_i^T) / sqrt(2 n), G_i lower triangular with N(0,1) entries drawn at packed index r (r + 1) / 2 + c */
-__global__ void k_gen_dense(int n, int m, unsigned long long seed, double scale, double* __restrict__ A)
+__global__ void k_gen_dense(int n, int i0, int cnt, unsigned long long seed, double scale, double* __restrict__ A)
 {
    const long long n2 = (long long) n * n;
-   const long long total = (long long) m * n2;
+   const long long total = (long long) cnt * n2;
    for (long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long) gridDim.x * blockDim.x)
    {
-      const int i = (int) (t / n2) + 1;
-      const long long e = t - (long long) (i - 1) * n2;
+      const int i = (int) (t / n2) + i0;
+      const long long e = t - (long long) (i - i0) * n2;
       const int r0 = (int) (e / n), c0 = (int) (e - (long long) r0 * n);
       const int r = r0 > c0 ? r0 : c0;
       const int c = r0 > c0 ? c0 : r0;
@@ -45,12 +45,15 @@ __global__ void k_gen_dense(int n, int m, unsigned long long seed, double scale,
    }
 }
 
-int hs_gen_dense(hipStream_t s, int n, int m, long long seed, double* A)
+/* the matrices A_i, i0 <= i < i1 (i >= 1), written to A + i n^2 */
+int hs_gen_dense(hipStream_t s, int n, int i0, int i1, long long seed, double* A)
 {
-   const long long total = (long long) m * n * n;
+   if ( i1 <= i0 )
+      return HS_OK;
+   const long long total = (long long) (i1 - i0) * n * n;
    long long g = (total + 255) / 256;
    if ( g > 65536 ) g = 65536;
-   hipLaunchKernelGGL(k_gen_dense, dim3((unsigned) g), dim3(256), 0, s, n, m, (unsigned long long) seed, 1.0 / sqrt(2.0 * (double) n), A);
+   hipLaunchKernelGGL(k_gen_dense, dim3((unsigned) g), dim3(256), 0, s, n, i0, i1 - i0, (unsigned long long) seed, 1.0 / sqrt(2.0 * (double) n), A);
    if ( hipGetLastError() != hipSuccess )
       return HS_ERR_HIP;
    return HS_OK;

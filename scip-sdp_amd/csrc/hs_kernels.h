@@ -71,6 +71,8 @@ struct hs_schur_ws
    double*   T;            /* chunk_cols x n^2 */
    double*   U;            /* chunk_cols x n^2 */
    double*   K;            /* split-K slabs */
+   double*   V;            /* variable-sharded form only: the received pieces, m1 x (rows of this rank) x (slice width) */
+   long long capT, capV;   /* variable-sharded form: doubles in T (= U) and in V */
    long long chunk_cols;
    long long n2;           /* doubles per matrix the allocation was sized for */
    long long kws_len;
@@ -93,6 +95,16 @@ void hs_shard_rows(int m1, int nranks, int rank, int* chunk_rows, int* first_beg
 int  hs_schur_Wcols(hipStream_t s, int m1, int n, const double* A, const double* R, const double* G, double* Mx, hs_schur_ws* w,
    int c0, int cw);
 void hs_shard_cols(int m1, int n, int nranks, int rank, int* c_begin, int* c_width);
+/* variable-sharded form (A_j lives on the rank that owns variable j; A is the pointer row 0 WOULD have): the column slice
+ * [c0, c0 + cw) of W_j = G A_j R is formed for the rank's own rows [r0, r1) of A, cut into row ranges, exchanged all-to-all so
+ * that every rank holds its row range of ALL W_j, and that rank's part of W W^T is accumulated into the lower tiles of Mx.
+ * All ranks call it with the same (c0, cw); the partial matrices add up to the Schur matrix (all-reduce afterwards). */
+int  hs_schur_Wvar(hipStream_t s, void* comm, int rank, int nranks, int m1, int n, const double* A, const double* R, const double* G,
+   double* Mx, hs_schur_ws* w, int c0, int cw);
+int  hs_schur_ws_alloc_var(hs_schur_ws* w, int m1, int nranks, int n, int cwmax);
+void hs_var_rows(int m1, int nranks, int rank, int* r0, int* r1);            /* rows of A (variables) a rank owns */
+void hs_var_wrows(int n, int nranks, int rank, int* q0, int* q1);            /* rows of the W_j a rank receives */
+int  hs_alltoall(void* comm, const double* send, double* recv, const long long* cnt, hipStream_t stream);
 int  hs_allreduce_sum(void* comm, double* buf, long long count, hipStream_t stream);
 int  hs_mirror_upper(hipStream_t s, double* A, int n, long long lda);                       /* A[i][j] = A[j][i] for i > j */
 /* multi.hip: in-place all-gather of equal pieces, piece of rank r at buf + r * count */

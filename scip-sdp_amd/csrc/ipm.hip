@@ -53,7 +53,12 @@ enum
 struct Block
 {
    int     n;
-   double* A;        /* (m + 1) x n^2 */
+   double* A;        /* (m + 1) x n^2: row i at A + i n^2.  Matrices sharded by variable: only the rows [a_r0, a_r1) of the solver exist
+                      * (A = Aown - a_r0 n^2 is the address row 0 WOULD have) */
+   double* Aown;     /* the allocation behind A */
+   double* A0;       /* the constant matrix (row 0): A itself, or a replicated copy on the ranks that do not own row 0 */
+   double* A0sep;    /* that copy (NULL where A0 == A) */
+   double* Apkown;   /* the allocation behind Apk */
    double *X, *Z, *Rd, *Lz, *LzInv, *Zinv, *Lx, *LxInv, *B, *H, *G, *GZ, *dXa, *dZa, *dX, *dZ, *E, *W, *T1;
    double *dinvz, *dinvx;
    double *Xs, *Zs;  /* saved iterate for step back-off */
@@ -120,6 +125,10 @@ struct hipsdp_solver
    void* comm; int rank, nranks;
    double* passg;          /* gather buffer of the row-sharded passes: nranks * ceil(m1 / nranks) doubles */
    int shard_passes;       /* -1: by size (>= 64 MB per pass), 0 / 1: HIPSDP_SHARD_PASSES */
+   int shardA_req;         /* hipsdp_shard_matrices: 0 replicated (default), 1 by variable, -1 by size against the free memory */
+   int var_cw;             /* matrices sharded by variable: columns per slice of the Schur assembly */
+   bool shardA;            /* decided by set_shape: this problem's constraint matrices are sharded by variable */
+   int a_r0, a_r1;         /* rows of A (0 = constant matrix, i = variable i) this rank holds; [0, m + 1) when replicated */
    hipsdp_params par;
 };
 
@@ -177,8 +186,8 @@ static void free_problem(hipsdp_solver* s)
 {
    for (auto& B : s->blk)
    {
-      double* ptrs[] = {B.A, B.X, B.Z, B.Rd, B.Lz, B.LzInv, B.Zinv, B.Lx, B.LxInv, B.B, B.H, B.G, B.GZ, B.dXa, B.dZa, B.dX, B.dZ,
-         B.E, B.W, B.T1, B.dinvz, B.dinvx, B.Xs, B.Zs, B.Apk, B.pkv, B.T2, B.W2, B.Xpre};
+      double* ptrs[] = {B.Aown, B.A0sep, B.X, B.Z, B.Rd, B.Lz, B.LzInv, B.Zinv, B.Lx, B.LxInv, B.B, B.H, B.G, B.GZ, B.dXa, B.dZa, B.dX, B.dZ,
+         B.E, B.W, B.T1, B.dinvz, B.dinvx, B.Xs, B.Zs, B.Apkown, B.pkv, B.T2, B.W2, B.Xpre};
       for (double* p : ptrs) dfree(p);
    }
    s->blk.clear();
@@ -225,6 +234,7 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
    s->b = s->Dext = s->y = s->x = s->z = NULL;
    s->shaped = s->solved = s->have_start = false;
    s->comm = NULL; s->rank = 0; s->nranks = 1;
+   s->shardA_req = 0; s->shardA = false; s->a_r0 = 0; s->a_r1 = 1;
    s->passg = NULL;
    s->shard_passes = getenv("HIPSDP_SHARD_PASSES") != NULL ? atoi(getenv("HIPSDP_SHARD_PASSES")) : -1;
    s->master_nvars = 0;
@@ -312,6 +322,21 @@ extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int*
    s->q = q;
    const long long m1 = m + 1;
    int nmax = 1;
+   /* Constraint matrices sharded by variable (several ranks only): asked for, or - left to the sizes - when the replicated
+    * matrices with their packed copy would take more than 60 % of the device memory.  Every rank decides from the same numbers. */
+   s->shardA = false;
+   s->a_r0 = 0; s->a_r1 = (int) m1;
+   if ( s->comm != NULL && s->nranks > 1 && s->shardA_req != 0 )
+   {
+      double bytes = 0.0;
+      for (int k = 0; k < nblocks; ++k)
+         bytes += 12.0 * (double) m1 * (double) blocksizes[k] * (double) blocksizes[k];
+      size_t fr = 0, tot = 0;
+      s->shardA = s->shardA_req > 0 || (hipMemGetInfo(&fr, &tot) == hipSuccess && bytes > 0.6 * (double) tot);
+      if ( s->shardA )
+         hs_var_rows((int) m1, s->nranks, s->rank, &s->a_r0, &s->a_r1);
+   }
+   const long long arows = s->a_r1 - s->a_r0;
    for (int k = 0; k < nblocks; ++k)
    {
       Block B;
@@ -323,8 +348,16 @@ extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int*
       const long long n2 = (long long) B.n * B.n;
       s->blk.push_back(B);
       Block& R = s->blk.back();
-      HS_CALL( dalloc(&R.A, m1 * n2) );
-      HS_HIP( hipMemsetAsync(R.A, 0, (size_t) (m1 * n2) * sizeof(double), s->stream) );
+      HS_CALL( dalloc(&R.Aown, arows * n2) );
+      HS_HIP( hipMemsetAsync(R.Aown, 0, (size_t) (arows * n2) * sizeof(double), s->stream) );
+      R.A = R.Aown - (long long) s->a_r0 * n2;
+      R.A0 = R.A;
+      if ( s->a_r0 > 0 || arows == 0 )
+      {
+         HS_CALL( dalloc(&R.A0sep, n2) );
+         HS_HIP( hipMemsetAsync(R.A0sep, 0, (size_t) n2 * sizeof(double), s->stream) );
+         R.A0 = R.A0sep;
+      }
       double** mats[] = {&R.X, &R.Z, &R.Rd, &R.Lz, &R.LzInv, &R.Zinv, &R.Lx, &R.LxInv, &R.B, &R.H, &R.G, &R.GZ, &R.dXa, &R.dZa,
          &R.dX, &R.dZ, &R.E, &R.W, &R.T1, &R.Xs, &R.Zs, &R.T2, &R.W2};
       for (double** pm : mats)
@@ -340,13 +373,14 @@ extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int*
        * launch less on the full storage */
       if ( getenv("HIPSDP_NOPACK") == NULL && B.n > 64 )
       {
-         if ( hipMalloc((void**) &R.Apk, (size_t) (m1 * R.Lp) * sizeof(double)) != hipSuccess )
+         if ( hipMalloc((void**) &R.Apkown, (size_t) ((arows > 0 ? arows : 1) * R.Lp) * sizeof(double)) != hipSuccess )
          {
             (void) hipGetLastError();
-            R.Apk = NULL;                 /* not enough memory for the packed copy: the passes use the full storage */
+            R.Apkown = NULL;              /* not enough memory for the packed copy: the passes use the full storage */
          }
          else
          {
+            R.Apk = R.Apkown - (long long) s->a_r0 * R.Lp;
             HS_CALL( dalloc(&R.pkv, 2 * R.Lp) );
             HS_HIP( hipMemsetAsync(R.pkv, 0, (size_t) (2 * R.Lp) * sizeof(double), s->stream) );   /* pad entries stay 0 */
          }
@@ -411,13 +445,17 @@ extern "C" int hipsdp_set_obj(hipsdp_solver* s, const double* b)
 }
 
 __global__ void k_scatter_coo(long long nnz, int n, const int* __restrict__ var, const int* __restrict__ row,
-   const int* __restrict__ col, const double* __restrict__ val, double* __restrict__ A)
+   const int* __restrict__ col, const double* __restrict__ val, double* __restrict__ A, int r0, int r1, double* __restrict__ A0)
 {
    const long long n2 = (long long) n * n;
    for (long long e = (long long) blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (long long) gridDim.x * blockDim.x)
    {
       const int r = row[e], c = col[e];
-      double* a = A + (long long) var[e] * n2;
+      const int v = var[e];
+      /* matrices sharded by variable: rows this rank does not hold are skipped, the constant matrix goes to its replicated copy */
+      double* a = (v == 0) ? A0 : A + (long long) v * n2;
+      if ( v != 0 && (v < r0 || v >= r1) )
+         continue;
       a[(long long) r * n + c] = val[e];
       a[(long long) c * n + r] = val[e];
    }
@@ -445,7 +483,7 @@ extern "C" int hipsdp_add_entries(hipsdp_solver* s, int block, long long nnz, co
    HS_HIP( hipMemcpyAsync(dc, col, (size_t) nnz * sizeof(int), hipMemcpyHostToDevice, s->stream) );
    HS_HIP( hipMemcpyAsync(dval, val, (size_t) nnz * sizeof(double), hipMemcpyHostToDevice, s->stream) );
    long long g = (nnz + 255) / 256; if ( g > 4096 ) g = 4096;
-   hipLaunchKernelGGL(k_scatter_coo, dim3((unsigned) g), dim3(256), 0, s->stream, nnz, B.n, dv, dr, dc, dval, B.A);
+   hipLaunchKernelGGL(k_scatter_coo, dim3((unsigned) g), dim3(256), 0, s->stream, nnz, B.n, dv, dr, dc, dval, B.A, s->a_r0, s->a_r1, B.A0);
    HS_LAUNCH_CHECK();
    HS_HIP( hipStreamSynchronize(s->stream) );
    dfree(dv); dfree(dr); dfree(dc); dfree(dval);
@@ -502,7 +540,8 @@ extern "C" int hipsdp_master_add_entries(hipsdp_solver* s, int block, long long 
    HS_HIP( hipMemcpyAsync(dc, col, (size_t) nnz * sizeof(int), hipMemcpyHostToDevice, s->stream) );
    HS_HIP( hipMemcpyAsync(dval, val, (size_t) nnz * sizeof(double), hipMemcpyHostToDevice, s->stream) );
    long long g = (nnz + 255) / 256; if ( g > 4096 ) g = 4096;
-   hipLaunchKernelGGL(k_scatter_coo, dim3((unsigned) g), dim3(256), 0, s->stream, nnz, n, dv, dr, dc, dval, s->master_A[block]);
+   hipLaunchKernelGGL(k_scatter_coo, dim3((unsigned) g), dim3(256), 0, s->stream, nnz, n, dv, dr, dc, dval, s->master_A[block], 0, 2147483647,
+      s->master_A[block]);
    HS_LAUNCH_CHECK();
    HS_HIP( hipStreamSynchronize(s->stream) );
    dfree(dv); dfree(dr); dfree(dc); dfree(dval);
@@ -530,6 +569,11 @@ extern "C" int hipsdp_master_gather(hipsdp_solver* s, int engine_block, int mast
    if ( s == NULL || !s->shaped || engine_block < 0 || engine_block >= (int) s->blk.size() || master_block < 0
       || master_block >= (int) s->master_A.size() || nactive < 0 || nactive > s->m || nkept != s->blk[engine_block].n )
       return HIPSDP_ERR_ARG;
+   if ( s->shardA )
+   {
+      set_err("hipsdp_master_gather: not available with matrices sharded by variable");
+      return HIPSDP_ERR_ARG;
+   }
    if ( nactive == 0 )
       return HIPSDP_OK;
    HS_HIP( hipSetDevice(s->device) );
@@ -562,7 +606,11 @@ extern "C" int hipsdp_set_block_dense(hipsdp_solver* s, int block, const double*
       return HIPSDP_ERR_ARG;
    HS_HIP( hipSetDevice(s->device) );
    Block& B = s->blk[block];
-   HS_HIP( hipMemcpy(B.A, A, (size_t) (s->m + 1) * B.n * B.n * sizeof(double), hipMemcpyHostToDevice) );
+   const size_t n2b = (size_t) B.n * B.n * sizeof(double);
+   if ( s->a_r1 > s->a_r0 )
+      HS_HIP( hipMemcpy(B.Aown, A + (size_t) s->a_r0 * B.n * B.n, (size_t) (s->a_r1 - s->a_r0) * n2b, hipMemcpyHostToDevice) );
+   if ( B.A0sep != NULL )
+      HS_HIP( hipMemcpy(B.A0sep, A, n2b, hipMemcpyHostToDevice) );
    B.apk_valid = false;
    s->solved = false;
    return HIPSDP_OK;
@@ -578,7 +626,10 @@ extern "C" int hipsdp_set_lp(hipsdp_solver* s, const double* Dext)
    return HIPSDP_OK;
 }
 
-int hs_gen_dense(hipStream_t s, int n, int m, long long seed, double* A);
+int hs_gen_dense(hipStream_t s, int n, int i0, int i1, long long seed, double* A);
+static int ensure_packed(hipsdp_solver* s);
+static int pass_A(hipsdp_solver* s, Block& B, const double* V, double* out);
+static int pass_AT(hipsdp_solver* s, Block& B, const double* coef, double sa, const double* add, double* out);
 
 extern "C" int hipsdp_gen_planted(hipsdp_solver* s, int n, int m, long long seed, const double* Xstar, const double* Zstar,
    const double* ystar, double* b_out)
@@ -590,19 +641,33 @@ extern "C" int hipsdp_gen_planted(hipsdp_solver* s, int n, int m, long long seed
    const long long n2 = (long long) n * n;
    const int m1 = m + 1;
    hipStream_t st = s->stream;
-   HS_CALL( hs_gen_dense(st, n, m, seed, B.A) );
+   HS_CALL( hs_gen_dense(st, n, s->a_r0 > 1 ? s->a_r0 : 1, s->a_r1, seed, B.A) );
    /* A_0 = sum_i ystar_i A_i - Zstar : coefficient vector [0, ystar] over all m + 1 rows (row 0 is overwritten) */
    HS_HIP( hipMemcpyAsync(B.Z, Zstar, (size_t) n2 * sizeof(double), hipMemcpyHostToDevice, st) );
    HS_HIP( hipMemcpyAsync(B.X, Xstar, (size_t) n2 * sizeof(double), hipMemcpyHostToDevice, st) );
    HS_HIP( hipMemsetAsync(s->yt, 0, sizeof(double), st) );
    HS_HIP( hipMemcpyAsync(s->yt + 1, ystar, (size_t) m * sizeof(double), hipMemcpyHostToDevice, st) );
-   HS_HIP( hipMemsetAsync(B.A, 0, (size_t) n2 * sizeof(double), st) );
+   HS_HIP( hipMemsetAsync(B.A0, 0, (size_t) n2 * sizeof(double), st) );
+   if ( s->shardA )
+   {
+      /* every rank generated the matrices it holds; the two sums over all variables go through the sharded passes (row 0 is
+       * zero and has coefficient 0 in the first, and its entry of the second is not used) */
+      B.apk_valid = false;
+      HS_CALL( ensure_packed(s) );
+      HS_CALL( pass_AT(s, B, s->yt, -1.0, B.Z, B.T1) );
+      HS_CALL( hs_symmetrize(st, B.T1, n) );
+      HS_CALL( hs_copy(st, B.A0, B.T1, n2) );
+      HS_CALL( pass_A(s, B, B.X, s->AX) );
+   }
+   else
+   {
    HS_CALL( hs_gemv_t(st, m1, n2, B.A, n2, s->yt, -1.0, B.Z, B.T1) );
    HS_CALL( hs_symmetrize(st, B.T1, n) );
    HS_CALL( hs_copy(st, B.A, B.T1, n2) );
    /* b = A(Xstar) */
    const double* v = B.X;
    HS_CALL( hs_gemv_n(st, m1, n2, B.A, n2, 1, &v, s->AX, m1, s->gemv_ws, s->gemv_ws_len) );
+   }
    HS_CALL( hs_copy(st, s->b, s->AX + 1, m) );
    HS_HIP( hipMemcpyAsync(b_out, s->b, (size_t) m * sizeof(double), hipMemcpyDeviceToHost, st) );
    HS_HIP( hipStreamSynchronize(st) );
@@ -617,7 +682,12 @@ extern "C" int hipsdp_get_block_dense(hipsdp_solver* s, int block, double* A)
       return HIPSDP_ERR_ARG;
    HS_HIP( hipSetDevice(s->device) );
    Block& B = s->blk[block];
-   HS_HIP( hipMemcpy(A, B.A, (size_t) (s->m + 1) * B.n * B.n * sizeof(double), hipMemcpyDeviceToHost) );
+   /* matrices sharded by variable: the rows this rank holds and the constant matrix are written, the rest is left alone */
+   const size_t n2b = (size_t) B.n * B.n * sizeof(double);
+   if ( s->a_r1 > s->a_r0 )
+      HS_HIP( hipMemcpy(A + (size_t) s->a_r0 * B.n * B.n, B.Aown, (size_t) (s->a_r1 - s->a_r0) * n2b, hipMemcpyDeviceToHost) );
+   if ( B.A0sep != NULL )
+      HS_HIP( hipMemcpy(A, B.A0sep, n2b, hipMemcpyDeviceToHost) );
    return HIPSDP_OK;
 }
 
@@ -625,7 +695,7 @@ extern "C" int hipsdp_block_device_ptr(hipsdp_solver* s, int block, double** dpt
 {
    if ( s == NULL || !s->shaped || block < 0 || block >= (int) s->blk.size() )
       return HIPSDP_ERR_ARG;
-   *dptr = s->blk[block].A;
+   *dptr = s->blk[block].Aown;
    return HIPSDP_OK;
 }
 
@@ -848,6 +918,26 @@ static int ensure_schur_ws(hipsdp_solver* s)
    const char* mode = getenv("HIPSDP_SCHUR");
    s->schur_mode_cols = false;
    s->schur_sim_shards = 0;
+   if ( s->shardA )
+   {
+      /* Matrices sharded by variable: the W_j are formed where A_j lives, in S column slices of at most cw columns; the three
+       * buffers of a slice (T and W of the own variables, the received row range of all W_j) take about 3 (m1 / ranks) n cw
+       * doubles.  The widest slice that fits the budget (a multiple of 128, or all n columns); same numbers on every rank. */
+      int nmaxb = 1;
+      for (auto& B : s->blk) if ( B.n > nmaxb ) nmaxb = B.n;
+      const double per_col = 3.0 * 8.0 * (double) ((m1 + s->nranks - 1) / s->nranks + 1) * (double) nmaxb;
+      long long cw = (long long) (budget * 1e9 / per_col);
+      const char* ecw = getenv("HIPSDP_VAR_SLICE");          /* test hook: force narrow slices */
+      if ( ecw != NULL && atoi(ecw) > 0 )
+         cw = atoi(ecw);
+      else if ( cw < nmaxb )
+         cw = cw / 128 * 128 > 0 ? cw / 128 * 128 : 128;
+      if ( cw > nmaxb ) cw = nmaxb;
+      s->var_cw = (int) cw;
+      HS_CALL( hs_schur_ws_alloc_var(&s->sws, m1, s->nranks, nmaxb, (int) cw) );
+      s->schur_mode_U = false; s->schur_mode_rows = false; s->schur_mode_forced = true;
+      return HS_OK;
+   }
    /* Column slices of the W formulation: S slices in total, every rank works through S / ranks of them one after the other
     * (one rank: all of them).  S = ranks when the workspace for one slice fits the budget, otherwise the smallest multiple
     * that does - this is also how one GPU keeps the cheaper W formulation when T and W do not fit as a whole (n = 2000,
@@ -980,7 +1070,8 @@ static int ensure_packed(hipsdp_solver* s)
    {
       if ( B.Apk != NULL && !B.apk_valid )
       {
-         HS_CALL( hs_pack_rows(s->stream, s->m + 1, B.n, B.Lp, B.A, B.Apk) );
+         if ( s->a_r1 > s->a_r0 )
+            HS_CALL( hs_pack_rows(s->stream, s->a_r1 - s->a_r0, B.n, B.Lp, B.Aown, B.Apkown) );
          B.apk_valid = true;
       }
    }
@@ -996,6 +1087,8 @@ static bool passes_sharded(const hipsdp_solver* s, const Block& B)
 {
    if ( s->comm == NULL || s->nranks < 2 )
       return false;
+   if ( s->shardA )
+      return true;              /* the only rows there are (hs_var_rows is the row split of the sharded passes) */
    if ( s->shard_passes >= 0 )
       return s->shard_passes != 0;
    return 8.0 * (double) (s->m + 1) * (double) B.n * (double) B.n >= 64e6;
@@ -1148,7 +1241,7 @@ __global__ void __launch_bounds__(256) k_lp_rows_small(int q, int m1, const doub
 
 static bool small_problem(const hipsdp_solver* s)
 {
-   if ( s->blk.size() > AS_MAXBLK || s->q > 4096 || s->m + 1 > 4096 )
+   if ( s->blk.size() > AS_MAXBLK || s->q > 4096 || s->m + 1 > 4096 || s->shardA )
       return false;
    long long tot = 0;
    for (auto& B : s->blk)
@@ -1369,6 +1462,11 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
    g_err[0] = 0;
    if ( s == NULL || !s->shaped || info == NULL )
       return HIPSDP_ERR_ARG;
+   if ( s->shardA && (s->comm == NULL || s->nranks < 2) )
+   {
+      set_err("hipsdp_solve: the matrices of this problem are sharded by variable, the communicator is gone");
+      return HIPSDP_ERR_ARG;
+   }
    HS_HIP( hipSetDevice(s->device) );
    if ( params != NULL )
       s->par = *params;
@@ -1404,7 +1502,7 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
    HS_CALL( hs_dot(st, m, s->b, s->b, s->sc + 0, 0, s->red_ws) );
    HS_CALL( hs_fill(st, s->sc + 1, 1, 0.0) );
    for (auto& B : s->blk)
-      HS_CALL( hs_dot(st, (long long) B.n * B.n, B.A, B.A, s->sc + 1, 1, s->red_ws) );
+      HS_CALL( hs_dot(st, (long long) B.n * B.n, B.A0, B.A0, s->sc + 1, 1, s->red_ws) );
    if ( q > 0 )
    {
       /* column 0 of Dext: strided -> gather through gemv with unit vector would be overkill; copy it */
@@ -1508,7 +1606,7 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
          HS_CALL( hs_dot(st, n2, B.X, B.Z, s->sc + SC_XZ, 1, s->red_ws) );
          if ( want_cert )
          {
-            hipLaunchKernelGGL(k_cert, g1d(n2), dim3(256), 0, st, n2, s->tau, B.Rd, B.A, B.T1);
+            hipLaunchKernelGGL(k_cert, g1d(n2), dim3(256), 0, st, n2, s->tau, B.Rd, B.A0, B.T1);
             HS_LAUNCH_CHECK();
             HS_CALL( hs_dot(st, n2, B.T1, B.T1, s->sc + SC_HD2, 1, s->red_ws) );
          }
@@ -1754,7 +1852,7 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       /* ---- Schur complement (extended by the constant matrix as "variable 0") */
       HS_HIP( hipEventRecord(s->ev0, st) );
       bool schur_small = false;
-      if ( s->comm == NULL && !s->schur_mode_rows && !s->schur_mode_forced && K > 0 )
+      if ( s->comm == NULL && !s->shardA && !s->schur_mode_rows && !s->schur_mode_forced && K > 0 )
       {
          /* B&B-sized problems: one launch for the whole extended Schur matrix and the copies the factorization needs */
          std::vector<int> bn;
@@ -1776,7 +1874,16 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       else
       {
       HS_CALL( hs_fill(st, s->Mx, (long long) m1 * m1, 0.0) );
-      if ( s->schur_mode_cols )
+      if ( s->shardA )
+      {
+         /* matrices sharded by variable: W_j where A_j lives, all-to-all of the row ranges, partial Gram matrices summed */
+         for (auto& B : s->blk)
+            for (int c0 = 0; c0 < B.n; c0 += s->var_cw)
+               HS_CALL( hs_schur_Wvar(st, s->comm, s->rank, s->nranks, m1, B.n, B.A, B.Lx, B.LzInv, s->Mx, &s->sws, c0,
+                     B.n - c0 < s->var_cw ? B.n - c0 : s->var_cw) );
+         HS_CALL( hs_allreduce_sum(s->comm, s->Mx, (long long) m1 * m1, st) );
+      }
+      else if ( s->schur_mode_cols )
       {
          /* W formulation in column slices: this rank's slices of every W_j, partial matrices summed over the ranks */
          const int S = s->schur_sim_shards;
@@ -2289,6 +2396,17 @@ extern "C" int hipsdp_shard_columns(int m1, int n, int nranks, int* bounds)
       bounds[g] = c0;
       bounds[g + 1] = c0 + cw;
    }
+   return HIPSDP_OK;
+}
+
+/* mode 1: the constraint matrices of the NEXT hipsdp_set_shape are sharded by variable over the ranks of the communicator
+ * (rank g holds rows [g c, (g + 1) c) of A, c = ceil((m + 1) / ranks); the constant matrix is kept everywhere); -1: only when
+ * the replicated matrices would not fit; 0 (default): replicated.  Call after hipsdp_set_comm and before hipsdp_set_shape. */
+extern "C" int hipsdp_shard_matrices(hipsdp_solver* s, int mode)
+{
+   if ( s == NULL || mode < -1 || mode > 1 )
+      return HIPSDP_ERR_ARG;
+   s->shardA_req = mode;
    return HIPSDP_OK;
 }
 

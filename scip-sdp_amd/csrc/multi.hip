@@ -118,6 +118,49 @@ int shm_bcast(hs_comm* c, char* buf, size_t bytes, hipStream_t stream)
    return HS_OK;
 }
 
+/* all-to-all with the count matrix cnt[src * nranks + dst] (doubles) known to every rank: a rank's send buffer holds its pieces
+ * in destination order, its receive buffer the pieces in source order.  One source rank at a time goes through the segment. */
+int shm_alltoall(hs_comm* c, const double* send, double* recv, const long long* cnt, hipStream_t stream)
+{
+   const int G = c->nranks;
+   const long long cap = (long long) (c->data_bytes / sizeof(double));
+   if ( cap <= 0 )
+      return HS_ERR_ARG;
+   long long recvoff = 0;                  /* where the piece of the current source starts in my receive buffer */
+   for (int src = 0; src < G; ++src)
+   {
+      long long total = 0, mineoff = 0;
+      for (int d = 0; d < G; ++d)
+      {
+         if ( d == c->rank ) mineoff = total;
+         total += cnt[(long long) src * G + d];
+      }
+      const long long minecnt = cnt[(long long) src * G + c->rank];
+      for (long long off = 0; off < total; off += cap)
+      {
+         const long long piece = total - off < cap ? total - off : cap;
+         if ( c->rank == src )
+         {
+            HS_HIP( hipMemcpyAsync(c->data, send + off, (size_t) piece * sizeof(double), hipMemcpyDeviceToHost, stream) );
+            HS_HIP( hipStreamSynchronize(stream) );
+         }
+         HS_CALL( shm_barrier(c) );
+         /* my part of the window [off, off + piece) of the source's send buffer */
+         const long long lo = mineoff > off ? mineoff : off;
+         const long long hi = mineoff + minecnt < off + piece ? mineoff + minecnt : off + piece;
+         if ( hi > lo )
+         {
+            HS_HIP( hipMemcpyAsync(recv + recvoff + (lo - mineoff), c->data + (size_t) (lo - off) * sizeof(double),
+                  (size_t) (hi - lo) * sizeof(double), hipMemcpyHostToDevice, stream) );
+            HS_HIP( hipStreamSynchronize(stream) );
+         }
+         HS_CALL( shm_barrier(c) );
+      }
+      recvoff += minecnt;
+   }
+   return HS_OK;
+}
+
 /* buf[i] = sum over ranks of part[r][i], added in rank order on every rank (identical bits everywhere) */
 __global__ void k_sum_parts(long long count, int nparts, const double* __restrict__ part, double* __restrict__ buf)
 {
@@ -214,7 +257,7 @@ extern "C" void hipsdp_comm_destroy(void* comm)
       return;
    if ( c->kind == 0 )
       (void) ncclCommDestroy(c->nccl);
-   else
+   else if ( c->kind == 1 )
       munmap((void*) c->hdr, c->map_bytes);
    delete c;
 }
@@ -222,6 +265,8 @@ extern "C" void hipsdp_comm_destroy(void* comm)
 int hs_allgather_inplace(void* comm, double* buf, long long count_per_rank, int rank, hipStream_t stream)
 {
    hs_comm* c = (hs_comm*) comm;
+   if ( c->kind == 2 )
+      return HS_OK;
    if ( c->kind == 1 )
       return shm_allgather(c, (const char*) (buf + (long long) rank * count_per_rank), (char*) buf, (size_t) count_per_rank * sizeof(double), stream);
    if ( ncclAllGather(buf + (long long) rank * count_per_rank, buf, (size_t) count_per_rank, ncclDouble, c->nccl, stream) != ncclSuccess )
@@ -232,6 +277,11 @@ int hs_allgather_inplace(void* comm, double* buf, long long count_per_rank, int 
 int hs_allgather(void* comm, const double* send, double* recv, long long count_per_rank, hipStream_t stream)
 {
    hs_comm* c = (hs_comm*) comm;
+   if ( c->kind == 2 )
+   {
+      HS_HIP( hipMemcpyAsync(recv + (long long) c->rank * count_per_rank, send, (size_t) count_per_rank * sizeof(double), hipMemcpyDeviceToDevice, stream) );
+      return HS_OK;
+   }
    if ( c->kind == 1 )
       return shm_allgather(c, (const char*) send, (char*) recv, (size_t) count_per_rank * sizeof(double), stream);
    if ( ncclAllGather(send, recv, (size_t) count_per_rank, ncclDouble, c->nccl, stream) != ncclSuccess )
@@ -242,6 +292,8 @@ int hs_allgather(void* comm, const double* send, double* recv, long long count_p
 int hs_bcast_doubles(void* comm, double* buf, long long count, hipStream_t stream)
 {
    hs_comm* c = (hs_comm*) comm;
+   if ( c->kind == 2 )
+      return HS_OK;
    if ( c->kind == 1 )
       return shm_bcast(c, (char*) buf, (size_t) count * sizeof(double), stream);
    if ( ncclBroadcast(buf, buf, (size_t) count, ncclDouble, 0, c->nccl, stream) != ncclSuccess )
@@ -252,6 +304,8 @@ int hs_bcast_doubles(void* comm, double* buf, long long count, hipStream_t strea
 int hs_bcast_ints(void* comm, int* buf, long long count, hipStream_t stream)
 {
    hs_comm* c = (hs_comm*) comm;
+   if ( c->kind == 2 )
+      return HS_OK;
    if ( c->kind == 1 )
       return shm_bcast(c, (char*) buf, (size_t) count * sizeof(int), stream);
    if ( ncclBroadcast(buf, buf, (size_t) count, ncclInt, 0, c->nccl, stream) != ncclSuccess )
@@ -263,6 +317,8 @@ int hs_allreduce_sum(void* comm, double* buf, long long count, hipStream_t strea
 {
    hs_comm* c = (hs_comm*) comm;
    if ( count <= 0 )
+      return HS_OK;
+   if ( c->kind == 2 )
       return HS_OK;
    if ( c->kind == 1 )
    {
@@ -284,4 +340,53 @@ int hs_allreduce_sum(void* comm, double* buf, long long count, hipStream_t strea
    if ( ncclAllReduce(buf, buf, (size_t) count, ncclDouble, ncclSum, c->nccl, stream) != ncclSuccess )
       return HS_ERR_HIP;
    return HS_OK;
+}
+
+/* all-to-all of the column-slice pieces of the variable-sharded Schur assembly (schur.hip: hs_schur_Wvar).
+ * cnt[src * nranks + dst] doubles go from src to dst; every rank passes the same matrix. */
+int hs_alltoall(void* comm, const double* send, double* recv, const long long* cnt, hipStream_t stream)
+{
+   hs_comm* c = (hs_comm*) comm;
+   const int G = c->nranks;
+   if ( c->kind == 1 )
+      return shm_alltoall(c, send, recv, cnt, stream);
+   long long soff = 0, roff = 0;
+   if ( c->kind == 2 )
+   {
+      /* measurement transport: only the piece a rank keeps for itself moves */
+      for (int d = 0; d < c->rank; ++d) soff += cnt[(long long) c->rank * G + d];
+      for (int r = 0; r < c->rank; ++r) roff += cnt[(long long) r * G + c->rank];
+      const long long k = cnt[(long long) c->rank * G + c->rank];
+      if ( k > 0 )
+         HS_HIP( hipMemcpyAsync(recv + roff, send + soff, (size_t) k * sizeof(double), hipMemcpyDeviceToDevice, stream) );
+      return HS_OK;
+   }
+   if ( ncclGroupStart() != ncclSuccess )
+      return HS_ERR_HIP;
+   bool ok = true;
+   for (int p = 0; p < G; ++p)
+   {
+      const long long ks = cnt[(long long) c->rank * G + p], kr = cnt[(long long) p * G + c->rank];
+      if ( ks > 0 && ncclSend(send + soff, (size_t) ks, ncclDouble, p, c->nccl, stream) != ncclSuccess ) ok = false;
+      if ( kr > 0 && ncclRecv(recv + roff, (size_t) kr, ncclDouble, p, c->nccl, stream) != ncclSuccess ) ok = false;
+      soff += ks; roff += kr;
+   }
+   if ( ncclGroupEnd() != ncclSuccess || !ok )
+      return HS_ERR_HIP;
+   return HS_OK;
+}
+
+/* Measurement transport: a communicator of nranks ranks of which only this one exists.  Collectives move nothing (the
+ * all-to-all keeps the rank's own piece), so a solve through it computes garbage - it exists to time ONE rank's share of a
+ * sharded assembly at sizes that need several GPUs (tests/devtools/shard_time.py). */
+extern "C" int hipsdp_comm_create_null(int rank, int nranks, void** comm)
+{
+   if ( comm == NULL || nranks < 1 || rank < 0 || rank >= nranks )
+      return HIPSDP_ERR_ARG;
+   hs_comm* c = new (std::nothrow) hs_comm();
+   if ( c == NULL )
+      return HIPSDP_ERR_NOMEM;
+   c->kind = 2; c->rank = rank; c->nranks = nranks; c->nccl = NULL; c->hdr = NULL;
+   *comm = (void*) c;
+   return HIPSDP_OK;
 }

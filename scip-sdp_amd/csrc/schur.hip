@@ -24,7 +24,8 @@
 
 int hs_schur_ws_alloc(hs_schur_ws* w, int m1, long long n2max, double budget_gb)
 {
-   w->T = w->U = w->K = NULL;
+   w->T = w->U = w->K = w->V = NULL;
+   w->capT = w->capV = 0;
    const double need_full = 2.0 * 8.0 * (double) m1 * (double) n2max;
    long long cols = m1;
    w->full = 1;
@@ -69,7 +70,8 @@ void hs_schur_ws_free(hs_schur_ws* w)
    hs_pool_free(w->T);
    hs_pool_free(w->U);
    hs_pool_free(w->K);
-   w->T = w->U = w->K = NULL;
+   hs_pool_free(w->V);
+   w->T = w->U = w->K = w->V = NULL;
 }
 
 int hs_schur_U(hipStream_t s, int m1, int n, const double* A, const double* X, const double* Zinv, double* Mx,
@@ -184,6 +186,130 @@ int hs_schur_Wcols(hipStream_t s, int m1, int n, const double* A, const double* 
  *    wt (2 (n - c0 - w / 2) + n)   [A_j R starts at k = c; G T_j]   +   w m1   [W W^T],      wt = 128 ceil(w / 128)
  * Exact minimisation over all contiguous partitions (dynamic programme over <= n / 16 boundaries).  Ranks may end up without
  * a column when n is small; they contribute a zero matrix to the sum.  Every rank computes the same table. */
+/* ---- variable-sharded form: A_j on the rank that owns variable j (n = 4000, m = 8000: 1 TB of A does not fit replicated) ----
+ * W_j = G A_j R is formed where A_j lives, but the Gram product W W^T pairs every i with every j.  The sum over the n^2 entries
+ * of the W_j can be cut anywhere, so the entries are re-distributed instead of the matrices: an all-to-all sends row range h of
+ * every own W_j (current column slice) to rank h, after which rank h holds its n / G rows of ALL m1 matrices and adds its part
+ * of the Gram matrix; one all-reduce of Mx closes the assembly.  Per rank and assembly: 1 / G of both n^3 products (triangular
+ * savings of R kept, of G between row ranges), 1 / G of the Gram product, (G - 1) / G of m1 n^2 / G doubles sent and received,
+ * each over G - 1 links at once. */
+void hs_var_rows(int m1, int nranks, int rank, int* r0, int* r1)
+{
+   const int c = (m1 + nranks - 1) / nranks;
+   *r0 = (long long) rank * c < m1 ? rank * c : m1;
+   *r1 = *r0 + c < m1 ? *r0 + c : m1;
+}
+
+void hs_var_wrows(int n, int nranks, int rank, int* q0, int* q1)
+{
+   *q0 = (int) ((long long) n * rank / nranks);
+   *q1 = (int) ((long long) n * (rank + 1) / nranks);
+}
+
+int hs_schur_ws_alloc_var(hs_schur_ws* w, int m1, int nranks, int n, int cwmax)
+{
+   w->T = w->U = w->K = w->V = NULL;
+   w->full = 0; w->chunk_cols = 0; w->n2 = 0;
+   const long long cj = (m1 + nranks - 1) / nranks;
+   long long rowsmax = 1;
+   for (int h = 0; h < nranks; ++h)
+   {
+      int q0, q1;
+      hs_var_wrows(n, nranks, h, &q0, &q1);
+      if ( q1 - q0 > rowsmax ) rowsmax = q1 - q0;
+   }
+   w->capT = cj * (long long) n * cwmax;
+   w->capV = (long long) m1 * rowsmax * cwmax;
+   const long long nkV = rowsmax * cwmax;
+   int sk = hs_dgemm_pick_splitk(m1, m1, (int) (nkV > 2000000000LL ? 2000000000LL : nkV), 1);
+   if ( sk < 16 ) sk = 16;
+   const long long tm = (m1 + 127) / 128;
+   const int sx = hs_dgemm_pick_xcd_slices(tm * (tm + 1) / 2, nkV);
+   if ( sx > sk ) sk = sx;
+   if ( sk < 64 ) sk = 64;
+   while ( sk > 2 && 8.0 * (double) sk * (double) m1 * (double) m1 > 8e9 ) --sk;       /* large m: the tiles alone fill the chip */
+   w->kws_len = (long long) sk * m1 * m1;
+   if ( hs_pool_alloc((void**) &w->T, (size_t) w->capT * sizeof(double)) != HS_OK
+      || hs_pool_alloc((void**) &w->U, (size_t) w->capT * sizeof(double)) != HS_OK
+      || hs_pool_alloc((void**) &w->V, (size_t) w->capV * sizeof(double)) != HS_OK
+      || hs_pool_alloc((void**) &w->K, (size_t) w->kws_len * sizeof(double)) != HS_OK )
+   {
+      hs_record_hip_error(hipErrorOutOfMemory, "hipMalloc(variable-sharded schur workspace)", __FILE__, __LINE__);
+      return HS_ERR_NOMEM;
+   }
+   return HS_OK;
+}
+
+int hs_schur_Wvar(hipStream_t s, void* comm, int rank, int nranks, int m1, int n, const double* A, const double* R, const double* G,
+   double* Mx, hs_schur_ws* w, int c0, int cw)
+{
+   if ( cw <= 0 )
+      return HS_OK;
+   if ( nranks < 1 || nranks > 64 || w->V == NULL || c0 < 0 || c0 + cw > n )
+      return HS_ERR_ARG;
+   const long long n2 = (long long) n * n;
+   const long long nk = (long long) n * cw;
+   int r0, r1, p0, p1;
+   hs_var_rows(m1, nranks, rank, &r0, &r1);
+   hs_var_wrows(n, nranks, rank, &p0, &p1);
+   const int cj = r1 - r0;
+   const long long Kme = (long long) (p1 - p0) * cw;
+   if ( (long long) cj * nk > w->capT || (long long) m1 * Kme > w->capV || (long long) cj * n > 2000000000LL || nk > 2000000000LL
+      || Kme > 2000000000LL )
+      return HS_ERR_ARG;
+   long long cnt[64 * 64];
+   for (int src = 0; src < nranks; ++src)
+   {
+      int a0, a1;
+      hs_var_rows(m1, nranks, src, &a0, &a1);
+      for (int dst = 0; dst < nranks; ++dst)
+      {
+         int q0, q1;
+         hs_var_wrows(n, nranks, dst, &q0, &q1);
+         cnt[src * nranks + dst] = (long long) (a1 - a0) * (q1 - q0) * cw;
+      }
+   }
+   if ( cj > 0 )
+   {
+      /* T_j[:, slice] = A_j[:, c0:] R[c0:, slice] for the own j (R lower triangular: the product starts at k = c0) */
+      hs_gemm_args g1 = {cj * n, cw, n - c0, HS_KC, HS_MC, A + (long long) r0 * n2 + c0, n, 0, R + (long long) c0 * n + c0, n, 0, w->T, cw, 0,
+         1.0, 0.0, 1, HS_GEMM_B_LOWTRI, 1, NULL};
+      HS_CALL( hs_dgemm(s, &g1) );
+      /* W_j[q0:q1, slice] = G[q0:q1, 0:q1] T_j[0:q1, slice], written where the piece for rank h starts in the send buffer */
+      for (int h = 0; h < nranks; ++h)
+      {
+         int q0, q1;
+         hs_var_wrows(n, nranks, h, &q0, &q1);
+         if ( q1 <= q0 )
+            continue;
+         const long long piece = (long long) (q1 - q0) * cw;
+         hs_gemm_args g2 = {q1 - q0, cw, q1, HS_KC, HS_MC, G + (long long) q0 * n, n, 0, w->T, cw, nk, w->U + (long long) cj * q0 * cw, cw, piece,
+            1.0, 0.0, cj, HS_GEMM_REMAP, 1, NULL};
+         HS_CALL( hs_dgemm(s, &g2) );
+      }
+   }
+   HS_CALL( hs_alltoall(comm, w->U, w->V, cnt, s) );
+   if ( Kme <= 0 )
+      return HS_OK;
+   int flags = HS_GEMM_LOWER;
+   int sk;
+   if ( m1 >= 256 && Kme >= 16384 )
+   {
+      const long long tm = (m1 + 127) / 128;
+      sk = hs_dgemm_pick_xcd_slices(tm * (tm + 1) / 2, Kme);
+      while ( sk > 2 && (long long) sk * m1 * m1 > w->kws_len ) --sk;
+      flags |= HS_GEMM_XCD | HS_GEMM_NOFAST;
+   }
+   else
+   {
+      sk = hs_dgemm_pick_splitk(m1, m1, (int) Kme, 1);
+      while ( sk > 1 && (long long) sk * m1 * m1 > w->kws_len ) --sk;
+   }
+   hs_gemm_args g3 = {m1, m1, (int) Kme, HS_KC, HS_KC, w->V, Kme, 0, w->V, Kme, 0, Mx, m1, 0, 1.0, 1.0, 1, flags, sk, w->K};
+   HS_CALL( hs_dgemm(s, &g3) );
+   return HS_OK;
+}
+
 void hs_shard_cols(int m1, int n, int nranks, int rank, int* c_begin, int* c_width)
 {
    static thread_local int memo_key[3] = {-1, -1, -1};

@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
-"""multi_worker.py RANK WORLD SHM_NAME N M LPROWS OUT.json - one rank of a sharded node solve (test helper).
+"""multi_worker.py RANK WORLD SHM_NAME N M LPROWS OUT.json [LOAD] - one rank of a sharded node solve (test helper).
 
 Every rank builds the same instance (as bench.py does at N > 1), joins the communicator and runs the engine with its share of
 the Schur rows.  WORLD ranks may share one device through the host-staged communicator (RCCL refuses two ranks on one GPU).
-The result every rank saw goes to OUT.json for tests/test_gpu_multi.py to compare."""
+The result every rank saw goes to OUT.json for tests/test_gpu_multi.py to compare.
+
+LOAD = vars-dense | vars-coo | vars-gen: the constraint matrices are sharded by variable (hipsdp_shard_matrices) and loaded
+through hipsdp_set_block_dense / hipsdp_add_entries / generated on the device by hipsdp_gen_planted (every rank passes the whole
+instance; a rank stores the matrices it holds).  dense | coo | gen: the same loaders with replicated matrices."""
 import ctypes as C
 import importlib.util
 import json
@@ -31,14 +35,32 @@ def main():
         core = ipm_ref.CoreProblem(b, [A], D, c)
     else:
         core = ipm_ref.CoreProblem(b, [A])
+    load = sys.argv[8] if len(sys.argv) > 8 else "dense"
     lib = hb.lib()
     s = hb.Solver(0)
-    s.load_core(core)
     comm = C.c_void_p()
     if world > 1:
-        rc = lib.hipsdp_comm_create_host(name.encode(), rank, world, C.c_longlong(1 << 20), C.c_double(60.0), C.byref(comm))
+        staging = int(os.environ.get("HIPSDP_TEST_STAGING", str(1 << 20)))
+        rc = lib.hipsdp_comm_create_host(name.encode(), rank, world, C.c_longlong(staging), C.c_double(60.0), C.byref(comm))
         assert rc == 0, rc
         assert lib.hipsdp_set_comm(s.h, comm, rank, world) == 0
+        if load.startswith("vars-"):
+            assert lib.hipsdp_shard_matrices(s.h, 1) == 0
+    kind = load.split("-")[-1]
+    if kind == "dense":
+        s.load_core(core)
+    elif kind == "coo":
+        s.set_shape(core.m, [n], core.q)
+        s.set_obj(core.b)
+        v, r, c = np.nonzero(np.tril(np.ones((n, n)))[None, :, :] * (A != 0))
+        s.add_entries(0, v.astype(np.int32), r.astype(np.int32), c.astype(np.int32), A[v, r, c])
+        if core.q:
+            s.set_lp(np.hstack([core.c[:, None], core.D]))
+    else:
+        assert q == 0
+        s.set_shape(m, [n], 0)
+        bg = s.gen_planted(n, m, 77, Xs, Zs, ys)
+        b = bg
     info = s.solve(gaptol=1e-6, feastol=1e-6)
     y = s.y()
     X = s.X(0)
