@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--m", type=int, default=1000)
     ap.add_argument("--seed", type=int, default=20240)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--shard-matrices", choices=["auto", "on", "off"], default="auto",
+                    help="N > 1: constraint matrices sharded by variable (auto: when the replicated matrices would not fit)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -119,11 +121,8 @@ def main():
         raise RuntimeError("bench.py needs an MI355X: no HIP device visible and hipsdp has no CPU path")
     n, m = args.n, args.m
     solver = hb.Solver(local_rank if world > 1 else 0)
-    solver.set_shape(m, [n], 0)
-    # N > 1: ONE node SDP, its Schur assembly sharded over the ranks (north_star); every rank holds the same instance
-    Xs, Zs, ys = planted_pair(n, m, args.seed)
-    b = solver.gen_planted(n, m, args.seed, Xs, Zs, ys)
-    opt = float(b @ ys)
+    # N > 1: ONE node SDP, its Schur assembly sharded over the ranks (north_star); every rank holds the same instance - or,
+    # when the replicated constraint matrices would not fit the device (n=4000, m=8000: 1 TB), only the matrices of its variables
     comm = None
     if world > 1:
         import ctypes as C
@@ -138,6 +137,11 @@ def main():
         rc = hb.lib().hipsdp_comm_create(raw, rank, world, C.byref(comm))
         assert rc == 0, "hipsdp_comm_create failed: %s" % hb.lib().hipsdp_last_error().decode()
         assert hb.lib().hipsdp_set_comm(solver.h, comm, rank, world) == 0
+        assert hb.lib().hipsdp_shard_matrices(solver.h, {"auto": -1, "on": 1, "off": 0}[args.shard_matrices]) == 0
+    solver.set_shape(m, [n], 0)
+    Xs, Zs, ys = planted_pair(n, m, args.seed)
+    b = solver.gen_planted(n, m, args.seed, Xs, Zs, ys)
+    opt = float(b @ ys)
 
     def barrier():
         if dist is not None:
@@ -182,6 +186,8 @@ def main():
         "config": {"workload": "BASELINE configs[1]: synthetic single dense block n=%d, m=%d, fp64, planted optimum, cold start, "
                                "gaptol=feastol=1e-5, A resident in HBM; N > 1: Schur assembly (column slices of W_j = G A_j R, RCCL all-reduce of the partial Schur matrices) and the passes over A (by rows, RCCL all-gather / all-reduce) sharded over the GPUs, everything else replicated" % (n, m),
                    "parallelism": "schur-shards x%d" % world,
+                   "matrices": "sharded by variable (W_j formed where A_j lives, all-to-all of the W entries, all-reduce of the partial "
+                               "Schur matrices)" if hb.lib().hipsdp_matrices_sharded(solver.h) else "replicated",
                    "n": n, "m": m, "seed": args.seed},
         "iters_per_sec": iters / elapsed,
         "iterations_per_solve": iters / max(1, len(infos)),

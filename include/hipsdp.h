@@ -153,6 +153,7 @@ int  hipsdp_set_comm(hipsdp_solver* solver, void* comm, int rank, int nranks);
  * mode 1: shard; -1: shard only when the replicated matrices would take more than 60 % of the device memory; 0: replicate
  * (default).  Call after hipsdp_set_comm and before hipsdp_set_shape; the mode applies to every later hipsdp_set_shape. */
 int  hipsdp_shard_matrices(hipsdp_solver* solver, int mode);
+int  hipsdp_matrices_sharded(hipsdp_solver* solver);       /* what the last hipsdp_set_shape decided: 1 sharded, 0 replicated */
 /* measurement transport: a communicator of nranks ranks of which only `rank` exists - collectives move nothing, results are
  * meaningless; it times one rank's share of a sharded solve at sizes that need several GPUs (tests/devtools/shard_time.py) */
 int  hipsdp_comm_create_null(int rank, int nranks, void** comm);
@@ -191,6 +192,9 @@ int  hipsdp_schur_w(int device, int m1, int n, const double* A, const double* X,
 /* milliseconds one rank of an nranks-way sharded assembly spends on its share of the Schur matrix (by_columns: column slices
  * of the W formulation, else row chunks of the U formulation); synthetic operands made in HBM */
 int  hipsdp_schur_shard_time(int device, int m1, int n, int nranks, int rank, int by_columns, int reps, double ws_gbytes, double* ms);
+/* the same for one rank of the variable-sharded assembly (hipsdp_shard_matrices): only that rank's rows of A are allocated, the
+ * column slices are cw wide, the all-to-all keeps the rank's own piece; *a2a_bytes = bytes the rank would send per assembly */
+int  hipsdp_schur_var_share_time(int device, int m1, int n, int nranks, int rank, int cw, int reps, double* ms, double* a2a_bytes);
 int  hipsdp_potrf(int device, int n, double* A, int* fail);                       /* lower Cholesky in place, row-major */
 int  hipsdp_potrs(int device, int n, const double* A, int nrhs, double* rhs);     /* factor + solve, rhs[k * n + i] */
 int  hipsdp_trtri(int device, int n, const double* A, double* Linv);              /* A spd -> inverse of its Cholesky factor */

@@ -6,7 +6,12 @@ reverse rank order and are copied to their rows; finally the upper triangle is m
 
 Second form (the default of the engine with several ranks; hs_shard_cols / hs_schur_Wcols + one all-reduce): with X = R R^T,
 Z^-1 = G^T G and W_j = G A_j R, Mx = sum over the entries (r, c) of the W_j; the rank that owns the columns [c0, c0 + cw)
-adds W[:, :, c0:c0+cw] flattened times its transpose, and the partial matrices are summed over the ranks."""
+adds W[:, :, c0:c0+cw] flattened times its transpose, and the partial matrices are summed over the ranks.
+
+Third form (matrices sharded by variable, hipsdp_shard_matrices; hs_var_rows / hs_var_wrows / hs_schur_Wvar + all-to-all +
+all-reduce): rank g holds A_j only for its own rows j in [g c, (g + 1) c), c = ceil(m1 / G), forms the column slice of its
+W_j, cuts the rows of the slice into G ranges [n h / G, n (h + 1) / G) and sends range h to rank h; rank h then holds its row
+range of ALL W_j and adds that part of the Gram matrix."""
 import numpy as np
 
 
@@ -96,3 +101,29 @@ def column_slice_contribution(A, R, G, c0, cw):
     T = A[:, :, c0:] @ R[c0:, c0:c0 + cw]           # R lower triangular: rows < c0 of these columns are zero
     W = np.matmul(G, T).reshape(m1, -1)
     return W @ W.T
+
+
+def var_rows(m1, nranks, rank):
+    """rows of A (0 = constant matrix, i = variable i) rank holds: hs_var_rows, also the row split of the sharded passes"""
+    c = (m1 + nranks - 1) // nranks
+    r0 = min(rank * c, m1)
+    return r0, min(r0 + c, m1)
+
+
+def var_wrows(n, nranks, rank):
+    """rows of the W_j a rank receives in the all-to-all: hs_var_wrows"""
+    return n * rank // nranks, n * (rank + 1) // nranks
+
+
+def var_send_pieces(A_own, R, G, nranks, c0, cw):
+    """what hs_schur_Wvar puts into the send buffer for the column slice [c0, c0 + cw): for every destination h the rows
+    [q0_h, q1_h) of W_j[:, c0:c0+cw], j over the own rows, as one array [own rows, q1 - q0, cw]"""
+    n = R.shape[0]
+    W = np.matmul(G, np.matmul(A_own, R[:, c0:c0 + cw])) if A_own.shape[0] else np.zeros((0, n, cw))
+    return [np.ascontiguousarray(W[:, slice(*var_wrows(n, nranks, h)), :]) for h in range(nranks)]
+
+
+def var_gram(received):
+    """received[src]: [rows of src, my row range, cw] in source order -> my part of W W^T for this slice"""
+    Wt = np.concatenate([r.reshape(r.shape[0], r.shape[1] * r.shape[2]) for r in received], axis=0)
+    return Wt @ Wt.T

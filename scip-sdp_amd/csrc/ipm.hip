@@ -2410,6 +2410,12 @@ extern "C" int hipsdp_shard_matrices(hipsdp_solver* s, int mode)
    return HIPSDP_OK;
 }
 
+/* 1 when the matrices of the current shape are sharded by variable, 0 when replicated */
+extern "C" int hipsdp_matrices_sharded(hipsdp_solver* s)
+{
+   return s != NULL && s->shaped && s->shardA ? 1 : 0;
+}
+
 extern "C" int hipsdp_set_comm(hipsdp_solver* s, void* comm, int rank, int nranks)
 {
    if ( s == NULL || nranks < 1 || nranks > 16 || rank < 0 || rank >= nranks || (nranks > 1 && comm == NULL) )

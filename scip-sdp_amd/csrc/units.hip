@@ -223,6 +223,56 @@ extern "C" int hipsdp_schur_shard_time(int device, int m1, int n, int nranks, in
    return HIPSDP_OK;
 }
 
+/* the same for the variable-sharded assembly (hs_schur_Wvar): rank `rank` of `nranks` holds only its own rows of A - which is how
+ * one rank's share of n = 4000, m = 8000 (128 GB of the 1 TB of A) fits one device.  The all-to-all runs through the measurement
+ * transport (nothing but the rank's own piece moves); *a2a_bytes = what the rank would send (= receive) per assembly. */
+extern "C" int hipsdp_comm_create_null(int rank, int nranks, void** comm);
+extern "C" void hipsdp_comm_destroy(void* comm);
+extern "C" int hipsdp_schur_var_share_time(int device, int m1, int n, int nranks, int rank, int cw, int reps, double* ms, double* a2a_bytes)
+{
+   HS_CALL( pick_device(device) );
+   if ( m1 < 1 || n < 1 || nranks < 1 || nranks > 64 || rank < 0 || rank >= nranks || reps < 1 || ms == NULL || cw < 1 )
+      return HIPSDP_ERR_ARG;
+   if ( cw > n ) cw = n;
+   const long long n2 = (long long) n * n;
+   int r0, r1, q0, q1;
+   hs_var_rows(m1, nranks, rank, &r0, &r1);
+   hs_var_wrows(n, nranks, rank, &q0, &q1);
+   DevBuf dA, dX, dZ, dM;
+   HS_CALL( dA.alloc((long long) (r1 - r0 > 0 ? r1 - r0 : 1) * n2) ); HS_CALL( dX.alloc(n2) ); HS_CALL( dZ.alloc(n2) );
+   HS_CALL( dM.alloc((long long) (m1 + 32) * m1) );
+   hipLaunchKernelGGL(k_unit_fill, dim3(1024), dim3(256), 0, 0, (long long) (r1 - r0) * n2, 11ULL, dA.p);
+   hipLaunchKernelGGL(k_unit_fill, dim3(1024), dim3(256), 0, 0, n2, 23ULL, dX.p);
+   hipLaunchKernelGGL(k_unit_fill, dim3(1024), dim3(256), 0, 0, n2, 37ULL, dZ.p);
+   void* comm = NULL;
+   HS_CALL( hipsdp_comm_create_null(rank, nranks, &comm) );
+   hs_schur_ws w;
+   int rc = hs_schur_ws_alloc_var(&w, m1, nranks, n, cw);
+   hipEvent_t e0, e1;
+   HS_HIP( hipEventCreate(&e0) ); HS_HIP( hipEventCreate(&e1) );
+   for (int it = 0; it <= reps && rc == HS_OK; ++it)
+   {
+      if ( it == 1 )
+         rc = hipEventRecord(e0, 0) == hipSuccess ? HS_OK : HS_ERR_HIP;        /* iteration 0 is the warm-up */
+      if ( rc == HS_OK ) rc = hs_fill(0, dM.p, (long long) m1 * m1, 0.0);
+      for (int c0 = 0; c0 < n && rc == HS_OK; c0 += cw)
+         rc = hs_schur_Wvar(0, comm, rank, nranks, m1, n, dA.p - (long long) r0 * n2, dX.p, dZ.p, dM.p, &w, c0, n - c0 < cw ? n - c0 : cw);
+      if ( rc == HS_OK ) rc = hs_mirror_lower(0, dM.p, m1, m1);
+   }
+   float t = 0.f;
+   if ( rc == HS_OK && (hipEventRecord(e1, 0) != hipSuccess || hipEventSynchronize(e1) != hipSuccess
+         || hipEventElapsedTime(&t, e0, e1) != hipSuccess) )
+      rc = HS_ERR_HIP;
+   (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+   hs_schur_ws_free(&w);
+   hipsdp_comm_destroy(comm);
+   HS_CALL( rc );
+   *ms = (double) t / (double) reps;
+   if ( a2a_bytes != NULL )
+      *a2a_bytes = 8.0 * (double) (r1 - r0) * (double) (n - (q1 - q0)) * (double) n;
+   return HIPSDP_OK;
+}
+
 /* W formulation: X and Z (not its inverse) are given; chol(X), chol(Z), inverse factor and the three GEMMs on the device */
 extern "C" int hipsdp_schur_w(int device, int m1, int n, const double* A, const double* X, const double* Z, double* Mx)
 {

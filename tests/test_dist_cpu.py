@@ -168,3 +168,64 @@ def test_engine_column_partition_matches_the_restatement(m1, n, world):
     assert bounds == shard_ref.shard_cols(m1, n, world)
     assert bounds[0] == 0 and bounds[-1] == n and all(x <= y for x, y in zip(bounds, bounds[1:]))
     assert lib.hipsdp_shard_columns(m1, n, 0, b) != 0
+
+
+def _var_worker(rank, world, port, m1, n, cw, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(13)
+    A = rng.standard_normal((m1, n, n)); A = A + A.transpose(0, 2, 1)
+    Gm = rng.standard_normal((n, n)); X = Gm @ Gm.T + np.eye(n)
+    Gm = rng.standard_normal((n, n)); Z = Gm @ Gm.T + np.eye(n)
+    R = np.linalg.cholesky(X)
+    G = np.linalg.inv(np.linalg.cholesky(Z))
+    r0, r1 = shard_ref.var_rows(m1, world, rank)
+    A_own = A[r0:r1].copy()                                  # the only matrices this rank touches
+    q0, q1 = shard_ref.var_wrows(n, world, rank)
+    part = torch.zeros(m1, m1, dtype=torch.float64)
+    for c0 in range(0, n, cw):
+        w = min(cw, n - c0)
+        send = [torch.from_numpy(p) for p in shard_ref.var_send_pieces(A_own, R, G, world, c0, w)]
+        recv = []
+        for src in range(world):
+            s0, s1 = shard_ref.var_rows(m1, world, src)
+            recv.append(torch.zeros(s1 - s0, q1 - q0, w, dtype=torch.float64))
+        # gloo has no all_to_all: the same exchange as pairwise sends and receives (RCCL: ncclSend / ncclRecv in one group)
+        reqs = []
+        for peer in range(world):
+            if peer == rank:
+                recv[rank].copy_(send[rank])
+                continue
+            if send[peer].numel() > 0:
+                reqs.append(dist.isend(send[peer].contiguous(), dst=peer, tag=c0))
+            if recv[peer].numel() > 0:
+                reqs.append(dist.irecv(recv[peer], src=peer, tag=c0))
+        for r in reqs:
+            r.wait()
+        part += torch.from_numpy(shard_ref.var_gram([t.numpy() for t in recv]))
+    dist.all_reduce(part, op=dist.ReduceOp.SUM)
+    ref = ipm_ref.schur_block(A, X, np.linalg.inv(Z))
+    q.put((rank, float(np.abs(part.numpy() - ref).max() / np.abs(ref).max()), (r0, r1), (q0, q1)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,m1,n,cw", [(2, 9, 12, 12), (3, 7, 10, 4), (2, 1, 5, 5)])
+def test_variable_sharded_schur(world, m1, n, cw):
+    """matrices sharded by variable: own W_j, exchange of row ranges, partial Gram matrices, all-reduce (restatement of
+    hs_schur_Wvar); the row ranges cover everything once"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_var_worker, args=(r, world, port, m1, n, cw, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, rows, wrows in res:
+        assert err < 1e-12, (rank, err)
+    assert res[0][2][0] == 0 and res[-1][2][1] == m1 and all(res[k][2][1] == res[k + 1][2][0] for k in range(world - 1))
+    assert res[0][3][0] == 0 and res[-1][3][1] == n and all(res[k][3][1] == res[k + 1][3][0] for k in range(world - 1))
