@@ -82,3 +82,15 @@ def test_matrices_sharded_by_variable_reproduce_the_single_rank_solve(gpu, tmp_p
         assert abs(r["xtrace"] - one["xtrace"]) <= 1e-7 * max(1.0, abs(one["xtrace"]))
     for r in many[1:]:
         assert np.max(np.abs(np.array(r["y"]) - np.array(many[0]["y"]))) <= 1e-12 * max(1.0, np.max(np.abs(y1)))
+
+
+def test_matrices_sharded_by_variable_at_a_size_that_uses_the_mfma_tile_kernels(gpu, tmp_path):
+    """n = 300, m = 400 on two ranks: the three products of hs_schur_Wvar run on the persistent 128-tile FP64-MFMA kernel, the
+    instance is generated on the device by rows, the packed copies hold a rank's rows only"""
+    one = run_world(tmp_path, 1, 300, 400, 0, "b1", load="gen")[0]
+    many = run_world(tmp_path, 2, 300, 400, 0, "b2", env={"HIPSDP_TEST_STAGING": str(1 << 26), "HIPSDP_VAR_SLICE": "160"}, load="vars-gen")
+    assert one["status"] == 0
+    y1 = np.array(one["y"])
+    for r in many:
+        assert r["status"] == 0 and r["iterations"] == one["iterations"]
+        assert np.max(np.abs(np.array(r["y"]) - y1)) <= 1e-8 * max(1.0, np.max(np.abs(y1)))
