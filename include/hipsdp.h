@@ -162,6 +162,11 @@ int  hipsdp_shard_columns(int m1, int n, int nranks, int* bounds);
 int  hipsdp_comm_create(const void* unique_id_128bytes, int rank, int nranks, void** comm);
 int  hipsdp_comm_unique_id(void* unique_id_128bytes);
 void hipsdp_comm_destroy(void* comm);
+/* SPMD hosts (N identical processes, one per GPU, making the same calls): the process-wide communicator the environment
+ * describes - HIPSDP_WORLD / WORLD_SIZE, HIPSDP_RANK / RANK, and HIPSDP_COMM_FILE=path (RCCL: rank 0 writes the unique id there,
+ * the others read it) or HIPSDP_COMM_SHM=/name (host-staged, ranks sharing one device).  *comm = NULL with one rank.  Created at
+ * the first call, shared by all solvers of the process, never destroyed.  sdpisolver_hip.c calls it when it creates its engine. */
+int  hipsdp_comm_from_env(int device, void** comm, int* rank, int* nranks);
 /* host-staged communicator for several ranks on ONE device (RCCL refuses that): payloads travel through the POSIX
  * shared-memory segment `name` ("/something", unique per job; every rank passes the same name and staging size).  Same
  * collectives, same results; meant for validating the sharded path on a one-GPU machine, not for speed. */

@@ -1796,7 +1796,16 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       if ( par.timelimit > 0.0 )
       {
          const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
-         if ( el > par.timelimit )
+         int over = el > par.timelimit ? 1 : 0;
+         if ( s->comm != NULL )
+         {
+            /* the clocks of the ranks differ: rank 0's decision counts everywhere */
+            HS_HIP( hipMemcpyAsync(s->flags + 7, &over, sizeof(int), hipMemcpyHostToDevice, st) );
+            HS_CALL( hs_bcast_ints(s->comm, s->flags + 7, 1, st) );
+            HS_HIP( hipMemcpyAsync(&over, s->flags + 7, sizeof(int), hipMemcpyDeviceToHost, st) );
+            HS_HIP( hipStreamSynchronize(st) );
+         }
+         if ( over )
          {
             status = HIPSDP_STATUS_TIMELIM;
             break;

@@ -390,3 +390,88 @@ extern "C" int hipsdp_comm_create_null(int rank, int nranks, void** comm)
    *comm = (void*) c;
    return HIPSDP_OK;
 }
+
+/* SPMD hosts (N identical processes, one per GPU, all making the same calls - e.g. N copies of SCIP-SDP started by a launcher):
+ * the process-wide communicator described by the environment, created at the first call and kept until the process ends.
+ *   HIPSDP_WORLD / WORLD_SIZE, HIPSDP_RANK / RANK     size and rank (world <= 1 or unset: *comm = NULL, single GPU)
+ *   HIPSDP_COMM_SHM=/name                             host-staged transport (ranks sharing one device; validation)
+ *   HIPSDP_COMM_FILE=path                             RCCL: rank 0 writes the 128-byte unique id to this file (write + rename),
+ *                                                     the others wait for it (HIPSDP_COMM_TIMEOUT seconds, default 120)
+ * Used by sdpisolver_hip.c at engine creation: the drop-in backend then shards every node SDP over the ranks. */
+extern "C" int hipsdp_comm_from_env(int device, void** comm, int* rank, int* nranks)
+{
+   static void* g_comm = NULL;
+   static int g_rank = 0, g_world = 1, g_state = 0;        /* 0 not tried, 1 ready, 2 failed */
+   if ( comm == NULL || rank == NULL || nranks == NULL )
+      return HIPSDP_ERR_ARG;
+   *comm = NULL; *rank = 0; *nranks = 1;
+   if ( g_state == 2 )
+      return HIPSDP_ERR_HIP;
+   if ( g_state == 0 )
+   {
+      const char* ew = getenv("HIPSDP_WORLD") != NULL ? getenv("HIPSDP_WORLD") : getenv("WORLD_SIZE");
+      const char* er = getenv("HIPSDP_RANK") != NULL ? getenv("HIPSDP_RANK") : getenv("RANK");
+      const int world = ew != NULL ? atoi(ew) : 1;
+      const int r = er != NULL ? atoi(er) : 0;
+      g_state = 1;
+      if ( world > 1 )
+      {
+         const char* shm = getenv("HIPSDP_COMM_SHM");
+         const char* file = getenv("HIPSDP_COMM_FILE");
+         const double tmo = getenv("HIPSDP_COMM_TIMEOUT") != NULL && atof(getenv("HIPSDP_COMM_TIMEOUT")) > 0.0 ? atof(getenv("HIPSDP_COMM_TIMEOUT")) : 120.0;
+         int rc = HIPSDP_ERR_ARG;
+         if ( r < 0 || r >= world || world > 16 )
+            fprintf(stderr, "hipsdp: rank %d of %d ranks is not usable\n", r, world);
+         else if ( hipSetDevice(device) != hipSuccess )
+            rc = HIPSDP_ERR_HIP;
+         else if ( shm != NULL )
+            rc = hipsdp_comm_create_host(shm, r, world, 64LL << 20, tmo, &g_comm);
+         else if ( file != NULL )
+         {
+            unsigned char id[128];
+            bool have = false;
+            if ( r == 0 )
+            {
+               char tmp[4096];
+               snprintf(tmp, sizeof(tmp), "%s.tmp", file);
+               FILE* f = hipsdp_comm_unique_id(id) == HIPSDP_OK ? fopen(tmp, "wb") : NULL;
+               have = f != NULL && fwrite(id, 1, sizeof(id), f) == sizeof(id);
+               if ( f != NULL ) have = (fclose(f) == 0) && have;
+               have = have && rename(tmp, file) == 0;
+            }
+            else
+            {
+               const auto t0 = std::chrono::steady_clock::now();
+               while ( !have && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < tmo )
+               {
+                  FILE* f = fopen(file, "rb");
+                  if ( f != NULL )
+                  {
+                     have = fread(id, 1, sizeof(id), f) == sizeof(id);
+                     fclose(f);
+                  }
+                  if ( !have )
+                     usleep(20000);
+               }
+            }
+            if ( !have )
+               fprintf(stderr, "hipsdp: rank %d could not %s the communicator id file %s\n", r, r == 0 ? "write" : "read", file);
+            else
+               rc = hipsdp_comm_create(id, r, world, &g_comm);
+            if ( r == 0 && rc == HIPSDP_OK )
+               (void) unlink(file);           /* everyone has joined: the id is of no further use */
+         }
+         else
+            fprintf(stderr, "hipsdp: %d ranks but neither HIPSDP_COMM_FILE nor HIPSDP_COMM_SHM is set\n", world);
+         if ( rc != HIPSDP_OK )
+         {
+            g_state = 2;
+            g_comm = NULL;
+            return rc;
+         }
+         g_rank = r; g_world = world;
+      }
+   }
+   *comm = g_comm; *rank = g_rank; *nranks = g_world;
+   return HIPSDP_OK;
+}

@@ -310,6 +310,8 @@ SCIP_RETCODE SCIPsdpiSolverCreate(SCIP_SDPISOLVER** sdpisolver, SCIP_MESSAGEHDLR
    s->device = 0;
    if ( getenv("HIPSDP_DEVICE") != NULL )
       s->device = atoi(getenv("HIPSDP_DEVICE"));
+   else if ( getenv("LOCAL_RANK") != NULL && (getenv("HIPSDP_WORLD") != NULL || getenv("WORLD_SIZE") != NULL) )
+      s->device = atoi(getenv("LOCAL_RANK"));        /* SPMD launch: one process per GPU */
    s->solved = FALSE;
    s->timelimit = FALSE;
    s->timelimitinitial = FALSE;
@@ -739,6 +741,21 @@ SCIP_RETCODE SCIPsdpiSolverLoadAndSolveWithPenalty(
          SCIPerrorMessage("Cannot create the HIP engine: %s\n", hipsdp_last_error());
          HSFREE(s, &engsizes, nsdpblocks);
          return SCIP_LPERROR;
+      }
+      /* SPMD launch (N copies of the host program, one per GPU, WORLD_SIZE / RANK in the environment): every node SDP is
+       * sharded over the ranks of the process-wide communicator; all copies make the same calls and see the same results.
+       * SCIP_SDPPAR_NTHREADS (reinterpreted as the number of GPUs) = 1 keeps this solver on its own GPU. */
+      if ( s->nthreads != 1 )
+      {
+         void* comm = NULL;
+         int crank = 0, cworld = 1;
+         if ( hipsdp_comm_from_env(s->device, &comm, &crank, &cworld) != HIPSDP_OK
+            || (comm != NULL && hipsdp_set_comm(s->engine, comm, crank, cworld) != HIPSDP_OK) )
+         {
+            SCIPerrorMessage("Cannot join the communicator of the SPMD launch: %s\n", hipsdp_last_error());
+            HSFREE(s, &engsizes, nsdpblocks);
+            return SCIP_LPERROR;
+         }
       }
    }
    ENGINE_CALL( hipsdp_set_shape(s->engine, nengvars, s->nengineblocks, engsizes, q) );

@@ -94,3 +94,38 @@ def test_matrices_sharded_by_variable_at_a_size_that_uses_the_mfma_tile_kernels(
     for r in many:
         assert r["status"] == 0 and r["iterations"] == one["iterations"]
         assert np.max(np.abs(np.array(r["y"]) - y1)) <= 1e-8 * max(1.0, np.max(np.abs(y1)))
+
+
+@pytest.mark.parametrize("name,world", [("example_CLS.dat-s.gz", 2), ("example_small.dat-s", 3)])
+def test_spmd_copies_of_a_branch_and_bound_run_over_the_solver_interface(gpu, tmp_path, name, world):
+    """N identical processes run the same branch-and-bound over SCIPsdpiSolverLoadAndSolve (tests/spmd_worker.py knows nothing
+    about ranks); HIPSDP_WORLD / HIPSDP_RANK / HIPSDP_COMM_SHM make sdpisolver_hip.c join the process-wide communicator, so every
+    node SDP is sharded over the ranks.  All copies must walk the same tree to the same optimum as a single process."""
+    def run(n, tag):
+        outs = [str(tmp_path / ("%s_%d.json" % (tag, r))) for r in range(n)]
+        env = dict(os.environ)
+        if n > 1:
+            env.update(HIPSDP_WORLD=str(n), HIPSDP_COMM_SHM="/hipsdp_spmd_%d_%s" % (os.getpid(), tag), HIPSDP_COMM_TIMEOUT="60")
+        procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "spmd_worker.py"), name, outs[r]], stdout=subprocess.PIPE,
+                                  stderr=subprocess.STDOUT, env=dict(env, HIPSDP_RANK=str(r))) for r in range(n)]
+        logs = []
+        try:
+            for p in procs:
+                o, _ = p.communicate(timeout=280)
+                logs.append(o.decode(errors="replace"))
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        for r, p in enumerate(procs):
+            assert p.returncode == 0, "copy %d failed:\n%s" % (r, logs[r][-3000:])
+        return [json.load(open(o)) for o in outs]
+
+    one = run(1, "s1")[0]
+    many = run(world, "s%d" % world)
+    assert one["best"] is not None      # example_small has nodes the plain call cannot settle (sdpi.c answers them with the penalty form)
+    for r in many:
+        assert r["failed"] == one["failed"] and r["nodes"] == one["nodes"] and r["calls"] == one["calls"], (r["nodes"], one["nodes"])
+        assert abs(r["best"] - one["best"]) <= 1e-7 * max(1.0, abs(one["best"]))
+        assert abs(r["iters"] - one["iters"]) <= 0.05 * one["iters"]       # the general kernels replace the single-launch small ones
+        assert r["y"] == many[0]["y"]                                       # the copies agree to the last bit
