@@ -1184,9 +1184,276 @@ __global__ void __launch_bounds__(64) k_lmin_tiny(int n, const double* __restric
    }
 }
 
+/* ---- n > 64: block Jacobi.  The matrix is cut into 32 x 32 blocks; a round of the round-robin tournament over the blocks pairs
+ * them up, every pair (P, Q) is one independent 64 x 64 symmetric subproblem [[A_PP, A_PQ], [A_QP, A_QQ]] that ONE workgroup
+ * (nearly) diagonalises in LDS by a few sweeps of the same parallel-order two-sided Jacobi as k_jacobi_small, leaving its
+ * accumulated rotation J_k; then  A <- J^T A J,  Vt <- J^T Vt  with J = diag(J_k) are three 64-deep products per pair and
+ * 64-column chunk (rows of A, rows of Vt, columns of A).  A sweep over all block pairs is nb - 1 rounds of 3 launches instead of
+ * the n - 1 rounds of 2 launches of the element-wise form, and the O(n^3) part runs as dense 64 x 64 x 64 products from LDS.
+ * Rows / columns beyond n are zero padding: a rotation with a zero off-diagonal entry is never formed, so the padded
+ * coordinates stay unit vectors and are dropped by the final sort. */
+#define BJ_B 32
+#define BJ_M 64
+#define BJ_T 512            /* threads of the subproblem workgroup */
+
+/* reciprocal square root: v_rsq_f64 seed + two coupled Newton steps (no division, no sqrt expansion) */
+__device__ __forceinline__ double bj_rsqrt(double x)
+{
+   double y = __builtin_amdgcn_rsq(x);
+   double h = 0.5 * y, g = x * y;
+   double r = fma(-h, g, 0.5);
+   g = fma(g, r, g); h = fma(h, r, h);
+   r = fma(-h, g, 0.5);
+   h = fma(h, r, h);
+   return 2.0 * h;
+}
+
+__global__ void k_bjac_pad(int n, int N, const double* __restrict__ A, double* __restrict__ Ap, double* __restrict__ Vtp)
+{
+   for (long long e = (long long) blockIdx.x * blockDim.x + threadIdx.x; e < (long long) N * N; e += (long long) gridDim.x * blockDim.x)
+   {
+      const int r = (int) (e / N), c = (int) (e % N);
+      Ap[e] = (r < n && c < n) ? 0.5 * (A[(long long) r * n + c] + A[(long long) c * n + r]) : 0.0;
+      Vtp[e] = (r == c) ? 1.0 : 0.0;
+   }
+}
+
+__device__ __forceinline__ int bj_grow(int P, int Q, int i) { return i < BJ_B ? P * BJ_B + i : Q * BJ_B + (i - BJ_B); }
+
+/* one workgroup per block pair (P, Q) of round r: J[pair] (64 x 64, S = J^T diag J up to what the sweeps leave).
+ * cross = 1: only the 32 x 32 pairs (i in P, j in Q) are rotated, 32 rounds of 32 disjoint pairs (i, (i + round) mod 32) - over the
+ * nb - 1 rounds of a sweep every cross pair of the matrix is met exactly once; cross = 0: only the pairs inside P and inside Q
+ * (two 32-player tournaments side by side, 31 rounds), run once per sweep.  Together: a cyclic ordering of all n (n - 1) / 2 pairs. */
+__global__ void __launch_bounds__(BJ_T) k_bjac_sub(int N, int nbp, int r, const double* __restrict__ Ap, double* __restrict__ J, int maxsw,
+   int cross)
+{
+   __shared__ double a[BJ_M][BJ_M + 1];
+   __shared__ double vt[BJ_M][BJ_M + 1];
+   __shared__ double2 cs[BJ_M / 2];
+   __shared__ int2 pq[BJ_M / 2];
+   __shared__ double red[2 * (BJ_T / 64)];
+   const int tid = threadIdx.x;
+   int P, Q;
+   jac_pair(nbp, r, blockIdx.x, &P, &Q);
+   for (int e = tid; e < BJ_M * BJ_M; e += BJ_T)
+   {
+      const int i = e / BJ_M, j = e % BJ_M;
+      a[i][j] = Ap[(long long) bj_grow(P, Q, i) * N + bj_grow(P, Q, j)];
+      vt[i][j] = (i == j) ? 1.0 : 0.0;
+   }
+   __syncthreads();
+   const int rounds = cross ? BJ_B : BJ_B - 1;
+   for (int sw = 0; sw < maxsw; ++sw)
+   {
+      double off = 0.0, dg = 0.0;
+      for (int e = tid; e < BJ_M * BJ_M; e += BJ_T)
+      {
+         const int i = e / BJ_M, j = e % BJ_M;
+         const double v = a[i][j];
+         if ( i == j ) dg += v * v; else off += v * v;
+      }
+      for (int o = 32; o > 0; o >>= 1)
+      {
+         off += __shfl_down(off, o, 64);
+         dg += __shfl_down(dg, o, 64);
+      }
+      if ( (tid & 63) == 0 )
+      {
+         red[(tid >> 6) * 2] = off;
+         red[(tid >> 6) * 2 + 1] = dg;
+      }
+      __syncthreads();
+      off = 0.0; dg = 0.0;
+      for (int w = 0; w < BJ_T / 64; ++w) { off += red[2 * w]; dg += red[2 * w + 1]; }
+      __syncthreads();
+      if ( !(off > 1e-32 * dg) || !(off > 0.0) )
+         break;
+      for (int rr = 0; rr < rounds; ++rr)
+      {
+         if ( tid < BJ_M / 2 )
+         {
+            int p, q;
+            if ( cross )
+            {
+               p = tid;
+               q = BJ_B + ((tid + rr) & (BJ_B - 1));
+            }
+            else
+            {
+               jac_pair(BJ_B, rr, tid & (BJ_B / 2 - 1), &p, &q);
+               if ( tid >= BJ_B / 2 ) { p += BJ_B; q += BJ_B; }
+            }
+            double c = 1.0, s = 0.0;
+            const double apq = a[p][q], app = a[p][p], aqq = a[q][q];
+            if ( fabs(apq) > 1e-300 && fabs(apq) > 1e-19 * (fabs(app) + fabs(aqq)) )
+            {
+               /* the small-angle rotation from two reciprocal square roots: with d = a_qq - a_pp, b = 2 a_pq, r = hypot(d, b)
+                * cos^2 = (1 + |d| / r) / 2,  sin = sgn(d) b / (2 r cos)  (scaled by 1 / max(|d|, |b|) against overflow) */
+               double d = aqq - app, b = 2.0 * apq;
+               const double sc = 1.0 / fmax(fabs(d), fabs(b));
+               d *= sc; b *= sc;
+               const double ir = bj_rsqrt(d * d + b * b);
+               const double c2 = 0.5 + 0.5 * fabs(d) * ir;
+               const double ic = bj_rsqrt(c2);
+               c = c2 * ic;
+               s = (d >= 0.0 ? 0.5 : -0.5) * b * ir * ic;
+            }
+            cs[tid] = make_double2(c, s);
+            pq[tid] = make_int2(p, q);
+         }
+         __syncthreads();
+         for (int it = tid; it < (BJ_M / 2) * (BJ_M / 2); it += BJ_T)
+         {
+            const int k1 = it / (BJ_M / 2), k2 = it % (BJ_M / 2);
+            const int2 r1 = pq[k1], r2 = pq[k2];
+            const double2 g1 = cs[k1], g2 = cs[k2];
+            const int p = r1.x, q = r1.y, u = r2.x, v = r2.y;
+            const double c1 = g1.x, s1 = g1.y, c2 = g2.x, s2 = g2.y;
+            const double apu = a[p][u], apv = a[p][v], aqu = a[q][u], aqv = a[q][v];
+            const double bpu = c1 * apu - s1 * aqu, bqu = s1 * apu + c1 * aqu;
+            const double bpv = c1 * apv - s1 * aqv, bqv = s1 * apv + c1 * aqv;
+            a[p][u] = c2 * bpu - s2 * bpv;
+            a[p][v] = s2 * bpu + c2 * bpv;
+            a[q][u] = c2 * bqu - s2 * bqv;
+            a[q][v] = s2 * bqu + c2 * bqv;
+         }
+         for (int it = tid; it < (BJ_M / 2) * BJ_M; it += BJ_T)
+         {
+            const int k1 = it / BJ_M, col = it % BJ_M;
+            const int2 r1 = pq[k1];
+            const double2 g1 = cs[k1];
+            const double vp = vt[r1.x][col], vq = vt[r1.y][col];
+            vt[r1.x][col] = g1.x * vp - g1.y * vq;
+            vt[r1.y][col] = g1.y * vp + g1.x * vq;
+         }
+         __syncthreads();
+      }
+   }
+   double* Jk = J + (long long) blockIdx.x * BJ_M * BJ_M;
+   for (int e = tid; e < BJ_M * BJ_M; e += BJ_T)
+      Jk[e] = vt[e / BJ_M][e % BJ_M];
+}
+
+/* mode 0 (blockIdx.z = 0: A, 1: Vt): rows [P; Q] of the matrix, columns of chunk blockIdx.y  <-  J_k * (those rows);
+ * mode 1: columns [P; Q] of A, rows of chunk blockIdx.y  <-  (those columns) * J_k^T.  64 x 64 x 64 per workgroup from LDS, 4 x 4 per thread */
+__global__ void __launch_bounds__(256) k_bjac_apply(int N, int nbp, int r, int mode, double* __restrict__ Ap, double* __restrict__ Vtp,
+   const double* __restrict__ J)
+{
+   __shared__ double L[BJ_M][BJ_M + 1];     /* [i][k] */
+   __shared__ double R[BJ_M][BJ_M + 4];     /* [k][j] */
+   const int tid = threadIdx.x;
+   int P, Q;
+   jac_pair(nbp, r, blockIdx.x, &P, &Q);
+   const double* Jk = J + (long long) blockIdx.x * BJ_M * BJ_M;
+   double* M = (mode == 0 && blockIdx.z == 1) ? Vtp : Ap;
+   const int c0 = blockIdx.y * BJ_M;
+   for (int e = tid; e < BJ_M * BJ_M; e += 256)
+   {
+      const int i = e / BJ_M, j = e % BJ_M;
+      if ( mode == 0 )
+      {
+         L[i][j] = Jk[e];                                                   /* J[i][k] */
+         R[i][j] = M[(long long) bj_grow(P, Q, i) * N + c0 + j];            /* strip[k][j] */
+      }
+      else
+      {
+         L[i][j] = M[(long long) (c0 + i) * N + bj_grow(P, Q, j)];          /* strip[i][k] */
+         R[j][i] = Jk[e];                                                   /* R[k][j] = J[j][k] */
+      }
+   }
+   __syncthreads();
+   const int ti = tid / 16, tj = tid % 16;
+   double acc[4][4];
+#pragma unroll
+   for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int y = 0; y < 4; ++y) acc[x][y] = 0.0;
+#pragma unroll 8
+   for (int k = 0; k < BJ_M; ++k)
+   {
+      double l[4], rr[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) l[x] = L[4 * ti + x][k];
+#pragma unroll
+      for (int y = 0; y < 4; ++y) rr[y] = R[k][4 * tj + y];
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+         for (int y = 0; y < 4; ++y) acc[x][y] = fma(l[x], rr[y], acc[x][y]);
+   }
+#pragma unroll
+   for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int y = 0; y < 4; ++y)
+      {
+         const int i = 4 * ti + x, j = 4 * tj + y;
+         if ( mode == 0 )
+            M[(long long) bj_grow(P, Q, i) * N + c0 + j] = acc[x][y];
+         else
+            M[(long long) (c0 + i) * N + bj_grow(P, Q, j)] = acc[x][y];
+      }
+}
+
+/* off-diagonal and diagonal square sums, many workgroups: part[2 b], part[2 b + 1] */
+__global__ void __launch_bounds__(256) k_bjac_offnorm(int N, const double* __restrict__ A, double* __restrict__ part)
+{
+   __shared__ double red[8];
+   double off = 0.0, dg = 0.0;
+   for (long long e = (long long) blockIdx.x * blockDim.x + threadIdx.x; e < (long long) N * N; e += (long long) gridDim.x * blockDim.x)
+   {
+      const double v = A[e];
+      if ( e / N == e % N ) dg += v * v; else off += v * v;
+   }
+   for (int o = 32; o > 0; o >>= 1)
+   {
+      off += __shfl_down(off, o, 64);
+      dg += __shfl_down(dg, o, 64);
+   }
+   if ( (threadIdx.x & 63) == 0 )
+   {
+      red[(threadIdx.x >> 6) * 2] = off;
+      red[(threadIdx.x >> 6) * 2 + 1] = dg;
+   }
+   __syncthreads();
+   if ( threadIdx.x == 0 )
+   {
+      part[2 * blockIdx.x] = red[0] + red[2] + red[4] + red[6];
+      part[2 * blockIdx.x + 1] = red[1] + red[3] + red[5] + red[7];
+   }
+}
+
+/* ascending rank sort of the first n diagonal entries of the padded matrix, rows of Vt permuted and cut to n columns */
+__global__ void __launch_bounds__(256) k_bjac_sort(int n, int N, const double* __restrict__ Ap, const double* __restrict__ Vtp,
+   double* __restrict__ lam, double* __restrict__ V)
+{
+   __shared__ int rank_s;
+   const int i = blockIdx.x;
+   const double di = Ap[(long long) i * N + i];
+   if ( threadIdx.x == 0 ) rank_s = 0;
+   __syncthreads();
+   int cnt = 0;
+   for (int j = threadIdx.x; j < n; j += blockDim.x)
+   {
+      const double dj = Ap[(long long) j * N + j];
+      if ( dj < di || (dj == di && j < i) )
+         ++cnt;
+   }
+   atomicAdd(&rank_s, cnt);
+   __syncthreads();
+   const int rank = rank_s;
+   if ( threadIdx.x == 0 ) lam[rank] = di;
+   if ( V != NULL )
+      for (int c = threadIdx.x; c < n; c += blockDim.x)
+         V[(long long) rank * n + c] = Vtp[(long long) i * N + c];
+}
+
+#define BJ_OFFBLOCKS 256
+static int bj_padded(int n) { const int nb = (n + BJ_B - 1) / BJ_B; return ((nb + 1) & ~1) * BJ_B; }
+
 long long hs_syev_ws(int n)
 {
-   return (long long) n * n + 2LL * n + 64;
+   const long long N = bj_padded(n);
+   return 2 * N * N + (N / BJ_M) * BJ_M * BJ_M + 2 * BJ_OFFBLOCKS + 64;
 }
 
 int hs_syev_jacobi(hipStream_t s, int n, double* A, double* lam, double* V, int* info, double* ws)
@@ -1197,6 +1464,56 @@ int hs_syev_jacobi(hipStream_t s, int n, double* A, double* lam, double* V, int*
    {
       hipLaunchKernelGGL(k_jacobi_small, dim3(1), dim3(256), 0, s, n, A, lam, V, info);
       HS_LAUNCH_CHECK();
+      return HS_OK;
+   }
+   if ( getenv("HIPSDP_JACOBI_ELEMENTWISE") == NULL )
+   {
+      const int N = bj_padded(n), nbp = N / BJ_B;
+      double* Ap = ws;
+      double* Vtp = Ap + (long long) N * N;
+      double* J = Vtp + (long long) N * N;
+      double* part = J + (long long) (nbp / 2) * BJ_M * BJ_M;
+      long long pg = ((long long) N * N + 255) / 256; if ( pg > 4096 ) pg = 4096;
+      hipLaunchKernelGGL(k_bjac_pad, dim3((unsigned) pg), dim3(256), 0, s, n, N, A, Ap, Vtp);
+      HS_LAUNCH_CHECK();
+      /* the update of a sweep leaves rounding noise of about N eps relative to the diagonal: below that nothing more is gained */
+      double tol = 0.25 * (double) N * 2.2e-16; tol = tol * tol;
+      if ( tol < 1e-30 ) tol = 1e-30;
+      double prev = 1e300;
+      int sweeps_b = 0;
+      int inner0 = 1, inner = 1;               /* inner sweeps of a subproblem: first outer sweep (dense subproblems), later ones */
+      if ( getenv("HIPSDP_BJ_INNER") != NULL )
+         (void) sscanf(getenv("HIPSDP_BJ_INNER"), "%d,%d", &inner0, &inner);
+      for (sweeps_b = 0; sweeps_b < 40; ++sweeps_b)
+      {
+         double h[2 * BJ_OFFBLOCKS];
+         hipLaunchKernelGGL(k_bjac_offnorm, dim3(BJ_OFFBLOCKS), dim3(256), 0, s, N, Ap, part);
+         HS_LAUNCH_CHECK();
+         HS_HIP( hipMemcpyAsync(h, part, sizeof(h), hipMemcpyDeviceToHost, s) );
+         HS_HIP( hipStreamSynchronize(s) );
+         double off = 0.0, dg = 0.0;
+         for (int b = 0; b < BJ_OFFBLOCKS; ++b) { off += h[2 * b]; dg += h[2 * b + 1]; }
+         if ( getenv("HIPSDP_JACOBI_VERBOSE") != NULL )
+            fprintf(stderr, "block jacobi n=%d sweep %d: off^2 / diag^2 = %.3e (tol %.1e)\n", n, sweeps_b, off / dg, tol);
+         if ( !(off > tol * dg) || !(off > 0.0) )
+            break;
+         if ( off <= 1e-24 * dg && off > 0.25 * prev )
+            break;                                      /* at the noise floor: no longer shrinking */
+         prev = off;
+         for (int r = -1; r < nbp - 1; ++r)
+         {
+            /* r = -1: the pairs inside the blocks (pairing of round 0); r >= 0: the cross pairs of the block pairs of round r */
+            const int rr = r < 0 ? 0 : r;
+            hipLaunchKernelGGL(k_bjac_sub, dim3(nbp / 2), dim3(BJ_T), 0, s, N, nbp, rr, Ap, J, sweeps_b == 0 ? inner0 : inner, r < 0 ? 0 : 1);
+            hipLaunchKernelGGL(k_bjac_apply, dim3(nbp / 2, N / BJ_M, 2), dim3(256), 0, s, N, nbp, rr, 0, Ap, Vtp, J);
+            hipLaunchKernelGGL(k_bjac_apply, dim3(nbp / 2, N / BJ_M, 1), dim3(256), 0, s, N, nbp, rr, 1, Ap, Vtp, J);
+         }
+         HS_LAUNCH_CHECK();
+      }
+      hipLaunchKernelGGL(k_bjac_sort, dim3(n), dim3(256), 0, s, n, N, Ap, Vtp, lam, V);
+      HS_LAUNCH_CHECK();
+      if ( info != NULL )
+         HS_HIP( hipMemsetAsync(info, 0, sizeof(int), s) );
       return HS_OK;
    }
    double* Vt = ws;                              /* n x n */

@@ -94,15 +94,16 @@ def test_lambda_min_lanczos(gpu, n):
     assert theta2 - resid2 <= ev[0] + 0.35 * abs(ev[0])             # and the pessimistic value is not wildly off
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 10, 43, 128])
+@pytest.mark.parametrize("n", [1, 2, 3, 10, 43, 64, 65, 97, 128, 300, 513, 1000])
 def test_syev_matches_dsyevr_semantics(gpu, n):
-    """ascending eigenvalues, eigenvectors as ROWS (lapack_interface.c:507-603)"""
+    """ascending eigenvalues, eigenvectors as ROWS (lapack_interface.c:507-603); n > 64 runs the block Jacobi (32 x 32 blocks,
+    64 x 64 pair subproblems in LDS, rotations applied as 64-deep products), 65 / 97 / 300 / 513 / 1000 need zero padding"""
     G = RNG.standard_normal((n, n))
     W = G + G.T
     lam, V = gpu.syev(W)
     ev = np.linalg.eigvalsh(W)
-    assert rel(lam, ev) <= 1e-12
-    assert np.abs(V @ V.T - np.eye(n)).max() <= 1e-12
+    assert rel(lam, ev) <= 2e-12
+    assert np.abs(V @ V.T - np.eye(n)).max() <= 2e-12
     assert np.abs(V @ W @ V.T - np.diag(lam)).max() <= 1e-11 * max(1.0, np.abs(ev).max())
 
 
