@@ -912,6 +912,7 @@ __global__ void __launch_bounds__(256) k_jacobi_small(int n, const double* __res
    }
    __syncthreads();
    int sweeps = 0;
+   double prevoff = 1e300;
    for (sweeps = 0; sweeps < 40 && n > 1; ++sweeps)
    {
       /* off-diagonal vs diagonal mass */
@@ -938,6 +939,11 @@ __global__ void __launch_bounds__(256) k_jacobi_small(int n, const double* __res
       __syncthreads();
       if ( !(off > 1e-30 * dg) || !(off > 0.0) )
          break;
+      /* the rotations of a sweep leave rounding noise of about n eps^2 relative to the diagonal mass: once there, the
+       * (quadratically convergent) iteration no longer shrinks the off-diagonal part and further sweeps only add noise */
+      if ( off <= 1e-24 * dg && off > 0.25 * prevoff )
+         break;
+      prevoff = off;
       for (int r = 0; r < np - 1; ++r)
       {
          if ( tid < half )
