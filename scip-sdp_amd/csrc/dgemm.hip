@@ -427,11 +427,13 @@ int hs_dgemm_pick_xcd_slices(long long ntile, long long K)
 {
    /* candidates s with K / s >= 1024; score = occupied fraction of the last round of 512 slots, prefer fewer rounds */
    int best = 2;
+   int widest = 2;
    double bestscore = -1.0;
    for (int s = 2; s <= 128; ++s)
    {
       if ( K / s < 1024 && s > 2 )
          break;
+      widest = s;
       const long long total = ntile * s;
       const long long rounds = (total + 511) / 512;
       const double eff = (double) total / (double) (rounds * 512);
@@ -442,6 +444,10 @@ int hs_dgemm_pick_xcd_slices(long long ntile, long long K)
          best = s;
       }
    }
+   /* few tiles and a short K (m1 = 256 .. 700 with n below about 200): no candidate fills half the chip - take the most slices
+    * the minimum slice length allows instead of the 2 the search starts from (n = 200, m = 300: 234 instead of 12 workgroups) */
+   if ( bestscore < 0.0 )
+      best = widest;
    return best;
 }
 
