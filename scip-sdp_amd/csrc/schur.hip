@@ -103,6 +103,13 @@ int hs_schur_U(hipStream_t s, int m1, int n, const double* A, const double* X, c
    return HS_OK;
 }
 
+/* smallest m1 for which the Gram product runs in XCD-walked K slices (below: plain split-K over the lower tiles) */
+static int hs_syrk_min_m1(void)
+{
+   const char* e = getenv("HIPSDP_SYRK_MINM");
+   return e != NULL && atoi(e) > 0 ? atoi(e) : 256;
+}
+
 int hs_schur_W(hipStream_t s, int m1, int n, const double* A, const double* R, const double* G, double* Mx, hs_schur_ws* w)
 {
    const long long n2 = (long long) n * n;
@@ -118,7 +125,9 @@ int hs_schur_W(hipStream_t s, int m1, int n, const double* A, const double* R, c
    /* GEMM3: Mx += W W^T on the lower tiles */
    int flags = HS_GEMM_LOWER;
    int sk;
-   if ( m1 >= 256 && n2 >= 16384 )
+   /* measured (tools/syrk_threshold.sh): the XCD-walked slices win by 8-10 % for n >= 256 at every m1 >= 256, and for n = 128 from
+    * m1 = 1000 on; below that plain split-K over the lower tiles is 5-40 % faster */
+   if ( m1 >= hs_syrk_min_m1() && n2 >= 16384 && (n2 >= 50000 || m1 >= 900) )
    {
       const long long tm = (m1 + 127) / 128;
       const long long ntri = tm * (tm + 1) / 2;
