@@ -143,6 +143,8 @@ int  hipsdp_eigencuts(hipsdp_solver* solver, int block, const double* y, double 
                       double* coefs, double* lhs, double* vecs);
 
 /* multi-GPU: Schur rows are sharded over the ranks of an RCCL communicator (one process per GPU); comm comes from hipsdp_comm_create[_host] */
+/* Small problems (one assembly below HIPSDP_SHARD_MIN_FLOPS, default 2e10 algorithmic flops) are not sharded: every rank solves
+ * them alone with the single-rank kernels and rank 0's outcome (status, iterate, preoptimal iterate) is broadcast once per solve. */
 int  hipsdp_set_comm(hipsdp_solver* solver, void* comm, int rank, int nranks);
 /* Constraint matrices sharded by variable ("A is sharded by variable when it cannot be replicated",
  * n = 4000 / m = 8000 is 1 TB of A): rank g of the communicator holds the matrices of the variables [g c, (g + 1) c),

@@ -1457,7 +1457,107 @@ static double steplen_host(hipsdp_solver* s, const HostScalars& h)
    return a;
 }
 
+/* Several ranks and a small problem: sharding an assembly of less than about 2 * 10^10 flops costs more in collectives than it
+ * saves, and the single-launch kernels of the B&B-sized regime only exist for one rank.  Every rank then runs the whole solve on
+ * its own (identical deterministic arithmetic) and ONE exchange at the end makes rank 0's outcome the outcome everywhere - which
+ * also covers the one thing that can differ between the ranks, the clock behind the time limit. */
+static bool replicate_small(const hipsdp_solver* s)
+{
+   if ( s->comm == NULL || s->nranks < 2 || s->shardA )
+      return false;
+   double lim = 2e10;
+   const char* e = getenv("HIPSDP_SHARD_MIN_FLOPS");
+   if ( e != NULL )
+      lim = atof(e);
+   double fl = 0.0;
+   const double m1 = (double) s->m + 1.0;
+   for (auto& B : s->blk)
+      fl += 4.0 * m1 * (double) B.n * (double) B.n * (double) B.n + m1 * m1 * (double) B.n * (double) B.n;
+   return fl < lim;
+}
+
+struct CommOff        /* the communicator is out of sight while a replicated (small) problem is worked on */
+{
+   hipsdp_solver* s; void* saved; bool on;
+   CommOff(hipsdp_solver* s_, bool on_) : s(s_), saved(s_->comm), on(on_) { if ( on ) s->comm = NULL; }
+   ~CommOff() { if ( on ) s->comm = saved; }
+};
+
+static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info* info);
+
+static int sync_outcome(hipsdp_solver* s, int rc, hipsdp_info* info)
+{
+   struct Pack { int rc, solved, last_status, pre_valid; double sol_scale, tau, kappa, pre_scale; hipsdp_info info; } pk;
+   memset(&pk, 0, sizeof(pk));
+   pk.rc = rc; pk.solved = s->solved ? 1 : 0; pk.last_status = s->last_status; pk.pre_valid = s->pre_valid ? 1 : 0;
+   pk.sol_scale = s->sol_scale; pk.tau = s->tau; pk.kappa = s->kappa; pk.pre_scale = s->pre_scale; pk.info = *info;
+   const long long nint = (long long) ((sizeof(Pack) + sizeof(int) - 1) / sizeof(int));
+   int* d = NULL;
+   hipStream_t st = s->stream;
+   HS_CALL( dalloc(&d, nint) );
+   int r = HS_OK;
+   if ( hipMemcpyAsync(d, &pk, sizeof(pk), hipMemcpyHostToDevice, st) != hipSuccess ) r = HS_ERR_HIP;
+   if ( r == HS_OK ) r = hs_bcast_ints(s->comm, d, nint, st);
+   if ( r == HS_OK && (hipMemcpyAsync(&pk, d, sizeof(pk), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) )
+      r = HS_ERR_HIP;
+   dfree(d);
+   HS_CALL( r );
+   s->solved = pk.solved != 0; s->last_status = pk.last_status; s->sol_scale = pk.sol_scale; s->tau = pk.tau; s->kappa = pk.kappa;
+   s->pre_scale = pk.pre_scale;
+   *info = pk.info;
+   if ( pk.rc != HIPSDP_OK || !s->solved )
+   {
+      s->pre_valid = false;
+      return pk.rc;
+   }
+   const int m = s->m, q = s->q;
+   if ( m > 0 ) HS_CALL( hs_bcast_doubles(s->comm, s->y, m, st) );
+   if ( q > 0 ) { HS_CALL( hs_bcast_doubles(s->comm, s->x, q, st) ); HS_CALL( hs_bcast_doubles(s->comm, s->z, q, st) ); }
+   for (auto& B : s->blk)
+   {
+      const long long n2 = (long long) B.n * B.n;
+      HS_CALL( hs_bcast_doubles(s->comm, B.X, n2, st) );
+      HS_CALL( hs_bcast_doubles(s->comm, B.Z, n2, st) );
+      B.derived_valid = false;
+   }
+   if ( pk.pre_valid )
+   {
+      if ( s->pre_y == NULL )
+      {
+         HS_CALL( dalloc(&s->pre_y, m) );
+         HS_CALL( dalloc(&s->pre_x, q) );
+      }
+      if ( m > 0 ) HS_CALL( hs_bcast_doubles(s->comm, s->pre_y, m, st) );
+      if ( q > 0 ) HS_CALL( hs_bcast_doubles(s->comm, s->pre_x, q, st) );
+      for (auto& B : s->blk)
+      {
+         if ( B.Xpre == NULL )
+            HS_CALL( dalloc(&B.Xpre, (long long) B.n * B.n) );
+         HS_CALL( hs_bcast_doubles(s->comm, B.Xpre, (long long) B.n * B.n, st) );
+      }
+   }
+   s->pre_valid = pk.pre_valid != 0;
+   HS_HIP( hipStreamSynchronize(st) );
+   return HIPSDP_OK;
+}
+
 extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info* info)
+{
+   if ( s == NULL || !s->shaped || info == NULL )
+      return HIPSDP_ERR_ARG;
+   HS_HIP( hipSetDevice(s->device) );
+   const bool alone = replicate_small(s);
+   int rc;
+   {
+      CommOff off(s, alone);
+      rc = solve_impl(s, params, info);
+   }
+   if ( alone )
+      rc = sync_outcome(s, rc, info);
+   return rc;
+}
+
+static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info* info)
 {
    g_err[0] = 0;
    if ( s == NULL || !s->shaped || info == NULL )
@@ -2283,6 +2383,7 @@ extern "C" int hipsdp_check_y(hipsdp_solver* s, const double* y, double* lmin, d
 {
    if ( s == NULL || !s->shaped ) return HIPSDP_ERR_ARG;
    HS_HIP( hipSetDevice(s->device) );
+   CommOff off(s, replicate_small(s));
    const int m = s->m, m1 = m + 1, q = s->q;
    hipStream_t st = s->stream;
    if ( m > 0 )
@@ -2342,6 +2443,7 @@ extern "C" int hipsdp_eigencuts(hipsdp_solver* s, int block, const double* y, do
    if ( eigvals == NULL || coefs == NULL || lhs == NULL )
       return HIPSDP_ERR_ARG;
    HS_HIP( hipSetDevice(s->device) );
+   CommOff off(s, replicate_small(s));
    const int m = s->m, m1 = m + 1;
    Block& B = s->blk[block];
    const int n = B.n;

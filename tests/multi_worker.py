@@ -14,6 +14,9 @@ import json
 import os
 import sys
 
+# the test problems are small: without this the engine would run them replicated (hipsdp.h, HIPSDP_SHARD_MIN_FLOPS) and the
+# sharded code these tests are about would never execute
+os.environ.setdefault("HIPSDP_SHARD_MIN_FLOPS", "0")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 spec = importlib.util.spec_from_file_location("hipsdp_binding", os.path.join(ROOT, "scip-sdp_amd", "binding.py"))
