@@ -52,7 +52,7 @@ typedef struct hipsdp_params
    double ws_gbytes;     /* workspace budget of the Schur assembly in GB; <= 0: default */
    int    maxiter;
    int    verbose;       /* 1: one line per iteration on stdout (SCIP_SDPPAR_SDPINFO) */
-   int    lanczos_steps; /* Lanczos steps per step-length estimate; 0 (default): 24, or 16 when every block has >= 256 rows */
+   int    lanczos_steps; /* Lanczos steps per step-length estimate; 0 (default): 24, or 16 when every block has > 64 rows */
    int    reserved;
    double pabstol;       /* > 0: optimal termination also needs ||b - A(X)||_2 <= pabstol, ABSOLUTE: the caller's own check of
                           * the X-side is absolute (sdpsolchecker.c:775-931 with SCIP_SDPPAR_FEASTOL) while pinf is relative */

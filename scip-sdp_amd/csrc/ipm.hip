@@ -165,7 +165,7 @@ extern "C" void hipsdp_default_params(hipsdp_params* p)
    p->ws_gbytes = 0.0;
    p->maxiter = 100;
    p->verbose = 0;
-   p->lanczos_steps = 0;        /* by block size: 24, or 16 for blocks of 256 rows and more */
+   p->lanczos_steps = 0;        /* by block size: 24, or 16 when every block has more than 64 rows */
    p->reserved = 0;
    p->pabstol = 0.0;
    p->preoptgap = 0.0;
@@ -1576,12 +1576,13 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
          s->par.lanczos_steps = atoi(env);
       if ( s->par.lanczos_steps <= 0 )
       {
-         /* default: 24 steps; 16 once every block has 256 rows or more - there each step is a launch of its own and the estimate
-          * (used with its residual bound subtracted, the Cholesky of the new iterate being the exact test) costs 4 % of an iteration;
-          * measured on the bench instances: same iteration counts from 8 steps on (tools/lanczos_steps.sh) */
+         /* default: 24 steps; 16 once every block has more than 64 rows - there each step is a launch of its own and the estimate
+          * (used with its residual bound subtracted, the Cholesky of the new iterate being the exact test) costs 4 % of an iteration
+          * at n = 500 and 20 % at n = 200; measured on the bench instances: same iteration counts from 12 steps on
+          * (tools/lanczos_steps.sh) */
          int nmin = 1 << 30;
          for (auto& B : s->blk) if ( B.n < nmin ) nmin = B.n;
-         s->par.lanczos_steps = (!s->blk.empty() && nmin >= 256) ? 16 : 24;
+         s->par.lanczos_steps = (!s->blk.empty() && nmin > 64) ? 16 : 24;
       }
       if ( s->par.lanczos_steps < 4 ) s->par.lanczos_steps = 4;
       if ( s->par.lanczos_steps > 250 ) s->par.lanczos_steps = 250;
