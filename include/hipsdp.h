@@ -152,7 +152,7 @@ int  hipsdp_set_comm(hipsdp_solver* solver, void* comm, int rank, int nranks);
  * hipsdp_set_block_dense and hipsdp_gen_planted store only what the rank holds, the passes over A are completed by an
  * all-gather / all-reduce, and the Schur assembly forms W_j = G A_j R where A_j lives, re-distributes the ENTRIES of the W_j
  * with one all-to-all per column slice (rank h receives its n / ranks rows of all W_j) and sums the partial Gram matrices.
- * mode 1: shard; -1: shard only when the replicated matrices would take more than 60 % of the device memory; 0: replicate
+ * mode 1: shard; -1: shard only when the replicated matrices would take more than 75 % of the device memory; 0: replicate
  * (default).  Call after hipsdp_set_comm and before hipsdp_set_shape; the mode applies to every later hipsdp_set_shape. */
 int  hipsdp_shard_matrices(hipsdp_solver* solver, int mode);
 int  hipsdp_matrices_sharded(hipsdp_solver* solver);       /* what the last hipsdp_set_shape decided: 1 sharded, 0 replicated */

@@ -323,7 +323,7 @@ extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int*
    const long long m1 = m + 1;
    int nmax = 1;
    /* Constraint matrices sharded by variable (several ranks only): asked for, or - left to the sizes - when the replicated
-    * matrices with their packed copy would take more than 60 % of the device memory.  Every rank decides from the same numbers. */
+    * matrices with their packed copy would take more than 75 % of the device memory.  Every rank decides from the same numbers. */
    s->shardA = false;
    s->a_r0 = 0; s->a_r1 = (int) m1;
    if ( s->comm != NULL && s->nranks > 1 && s->shardA_req != 0 )
@@ -332,7 +332,7 @@ extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int*
       for (int k = 0; k < nblocks; ++k)
          bytes += 12.0 * (double) m1 * (double) blocksizes[k] * (double) blocksizes[k];
       size_t fr = 0, tot = 0;
-      s->shardA = s->shardA_req > 0 || (hipMemGetInfo(&fr, &tot) == hipSuccess && bytes > 0.6 * (double) tot);
+      s->shardA = s->shardA_req > 0 || (hipMemGetInfo(&fr, &tot) == hipSuccess && bytes > 0.75 * (double) tot);
       if ( s->shardA )
          hs_var_rows((int) m1, s->nranks, s->rank, &s->a_r0, &s->a_r1);
    }
