@@ -137,3 +137,17 @@ def test_spmd_copies_of_a_branch_and_bound_run_over_the_solver_interface(gpu, tm
         else:
             assert r["iters"] == one["iters"]                              # replicated small solves: the very same kernels
         assert r["y"] == many[0]["y"]                                       # the copies agree to the last bit
+
+
+@pytest.mark.parametrize("load", ["gen", "vars-gen"])
+def test_two_ranks_at_the_bench_size(gpu, tmp_path, load):
+    """BASELINE configs[1] (n = 500, m = 1000, the instance generated on the device) solved by two processes: replicated matrices
+    (column slices + all-reduce, passes swept by rows) and matrices sharded by variable (all-to-all of the W entries) must give
+    the single-process solve - this is bench.py --gpus 2 with the host-staged transport in place of RCCL"""
+    one = run_world(tmp_path, 1, 500, 1000, 0, "c1", load="gen")[0]
+    many = run_world(tmp_path, 2, 500, 1000, 0, "c2", env={"HIPSDP_TEST_STAGING": str(64 << 20)}, load=load)
+    assert one["status"] == 0
+    y1 = np.array(one["y"])
+    for r in many:
+        assert r["status"] == 0 and r["iterations"] == one["iterations"]
+        assert np.max(np.abs(np.array(r["y"]) - y1)) <= 1e-10 * max(1.0, np.max(np.abs(y1)))
