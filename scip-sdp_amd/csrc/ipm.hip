@@ -326,7 +326,7 @@ extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int*
     * matrices with their packed copy would take more than 75 % of the device memory.  Every rank decides from the same numbers. */
    s->shardA = false;
    s->a_r0 = 0; s->a_r1 = (int) m1;
-   if ( s->comm != NULL && s->nranks > 1 && s->shardA_req != 0 )
+   if ( s->comm != NULL && s->shardA_req != 0 && (s->nranks > 1 || s->shardA_req > 0) )
    {
       double bytes = 0.0;
       for (int k = 0; k < nblocks; ++k)
@@ -1085,10 +1085,12 @@ int hs_allreduce_sum(void* comm, double* buf, long long count, hipStream_t strea
  * the (packed) n x n partial sums.  Every rank decides from the sizes alone (same decision everywhere). */
 static bool passes_sharded(const hipsdp_solver* s, const Block& B)
 {
-   if ( s->comm == NULL || s->nranks < 2 )
+   if ( s->comm == NULL )
       return false;
    if ( s->shardA )
       return true;              /* the only rows there are (hs_var_rows is the row split of the sharded passes) */
+   if ( s->nranks < 2 )
+      return s->shard_passes == 1;        /* a communicator of one rank: only when forced (exercises the collectives) */
    if ( s->shard_passes >= 0 )
       return s->shard_passes != 0;
    return 8.0 * (double) (s->m + 1) * (double) B.n * (double) B.n >= 64e6;
@@ -1562,7 +1564,7 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
    g_err[0] = 0;
    if ( s == NULL || !s->shaped || info == NULL )
       return HIPSDP_ERR_ARG;
-   if ( s->shardA && (s->comm == NULL || s->nranks < 2) )
+   if ( s->shardA && s->comm == NULL )
    {
       set_err("hipsdp_solve: the matrices of this problem are sharded by variable, the communicator is gone");
       return HIPSDP_ERR_ARG;

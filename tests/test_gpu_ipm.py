@@ -195,6 +195,34 @@ def test_rccl_code_path_with_a_single_rank_communicator(gpu):
     assert np.max(np.abs(y - ref.y)) <= 1e-6
 
 
+def test_rccl_all_to_all_and_sharded_passes_with_a_single_rank_communicator(gpu, monkeypatch):
+    """the variable-sharded branch (hipsdp_shard_matrices: ncclSend / ncclRecv group of the all-to-all, ncclAllReduce of the partial
+    Schur matrix, ncclAllGather / ncclAllReduce of the row-swept passes) through a real RCCL communicator of size 1, two column
+    slices per assembly"""
+    import ctypes as C
+    monkeypatch.setenv("HIPSDP_VAR_SLICE", "48")
+    lib = gpu.lib()
+    uid = (C.c_ubyte * 128)()
+    assert lib.hipsdp_comm_unique_id(uid) == 0
+    b, A, ys, Xs, Zs = instances.planted_dense(80, 70)
+    core = ipm_ref.CoreProblem(b, [A])
+    ref = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-6, feastol=1e-6))
+    s = gpu.Solver(0)
+    comm = C.c_void_p()
+    assert lib.hipsdp_comm_create(uid, 0, 1, C.byref(comm)) == 0
+    assert lib.hipsdp_set_comm(s.h, comm, 0, 1) == 0
+    assert lib.hipsdp_shard_matrices(s.h, 1) == 0
+    s.load_core(core)
+    assert lib.hipsdp_matrices_sharded(s.h) == 1
+    info = s.solve(gaptol=1e-6, feastol=1e-6)
+    y = s.y()
+    assert lib.hipsdp_set_comm(s.h, None, 0, 1) == 0
+    s.close()
+    lib.hipsdp_comm_destroy(comm)
+    assert info.status == 0 and abs(info.iterations - ref.iterations) <= 1
+    assert np.max(np.abs(y - ref.y)) <= 1e-6
+
+
 def _solve_with_start(hb, core, start, tol=1e-6):
     s = hb.Solver(0)
     s.load_core(core)
