@@ -241,7 +241,7 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
    s->Mgather = NULL;
    s->schur_mode_rows = false;
    s->schur_mode_cols = false; s->schur_sim_shards = 0;
-   s->sws.T = s->sws.U = s->sws.K = NULL;
+   s->sws.T = s->sws.U = s->sws.K = s->sws.V = NULL;
    s->flags = NULL;
    s->hsc = NULL;
    s->hsc_dev = NULL;
@@ -425,7 +425,7 @@ extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int*
    HS_CALL( dalloc(&s->trsv_ws, hs_trsv_sync_ws(m)) );
    HS_HIP( hipMemset(s->trsv_ws, 0, (size_t) hs_trsv_sync_ws(m) * sizeof(int)) );
    s->trsv_epoch = 0;
-   s->sws.T = s->sws.U = s->sws.K = NULL;
+   s->sws.T = s->sws.U = s->sws.K = s->sws.V = NULL;
    HS_HIP( hipMemsetAsync(s->Dext, 0, (size_t) ((long long) q * m1 > 0 ? (long long) q * m1 : 1) * sizeof(double), s->stream) );
    HS_HIP( hipMemsetAsync(s->b, 0, (size_t) (m > 0 ? m : 1) * sizeof(double), s->stream) );
    HS_HIP( hipStreamSynchronize(s->stream) );
