@@ -12,8 +12,11 @@ import sdpa_io
 INF = 1e20
 
 
-def instance_to_sdpi(inst):
-    """SdpaInstance -> SdpiProblem (variables free; bounds come from single-variable LP rows, as in reader_sdpa.c)"""
+def instance_to_sdpi(inst, integrality=False):
+    """SdpaInstance -> SdpiProblem (variables free; bounds come from single-variable LP rows, as in reader_sdpa.c).
+    integrality=True hands the integrality flags on, which switches the coefficient tightening of the LP rows on
+    (sdpi.c:812-1129) - tightened rows make more nodes lose their interior, so this belongs with the full SCIPsdpiSolve driver
+    (penalty fallback), not with the plain single-call harness."""
     blocks = []
     for blk in inst.sdpblocks:
         vars_ = {}
@@ -29,7 +32,11 @@ def instance_to_sdpi(inst):
         coefs = {var - 1: v for var, v in row.items() if var != 0}
         lp.append((row.get(0, 0.0), INF, coefs))          # sum d_ri y_i - d_r0 >= 0
     m = inst.m
-    return sdpi_prepare.SdpiProblem(inst.obj, [-INF] * m, [INF] * m, blocks, lp)
+    isint = [False] * m
+    if integrality:
+        for v in getattr(inst, 'intvars', []):
+            isint[v] = True
+    return sdpi_prepare.SdpiProblem(inst.obj, [-INF] * m, [INF] * m, blocks, lp, isintegral=isint)
 
 
 class NodeResult:
@@ -85,7 +92,7 @@ def branch_and_bound(prob, intvars, solve_node, inttol=1e-5, maxnodes=20000, ver
         if pbound >= best[0] - 1e-6 * max(1.0, abs(best[0])):
             continue                                       # the parent's bound already prunes this node
         nnodes += 1
-        node = sdpi_prepare.SdpiProblem(prob.obj, lb, ub, prob.blocks, prob.lp)
+        node = sdpi_prepare.SdpiProblem(prob.obj, lb, ub, prob.blocks, prob.lp, isintegral=prob.isintegral)
         P = sdpi_prepare.prepare(node)
         if P.status == 'infeasible':
             continue

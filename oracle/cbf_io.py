@@ -17,7 +17,7 @@ import sdpi_prepare
 INF = 1e20
 
 
-def read_cbf(path):
+def read_cbf(path, integrality=False):
     with open(path, 'rt') as f:
         lines = [l.split('#')[0].strip() for l in f.read().splitlines()]
     lines = [l for l in lines if l]
@@ -127,5 +127,5 @@ def read_cbf(path):
     c = np.zeros(nvars)
     for j, v in obj.items():
         c[j] = sense * v
-    prob = sdpi_prepare.SdpiProblem(c, lb, ub, blocks, lp)
+    prob = sdpi_prepare.SdpiProblem(c, lb, ub, blocks, lp, isintegral=[integrality and v in set(intvars) for v in range(len(c))])
     return prob, sorted(intvars), sense, objconst

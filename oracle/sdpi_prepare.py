@@ -9,9 +9,12 @@ patterns real branch-and-bound nodes produce:
    sdpi.c:691-809     findEmptyRowColsSDP: indchanges / nremovedinds / blockindchanges
    sdpi.c:4473-4620   mapping bound multipliers back to the LP rows they came from (lhs/rhs multipliers)
 
-The one-variable shortcut (sdpi.c:3301-3381), the penalty loop and the Slater check are restated in sdpi_driver.py;
-integrality-based coefficient tightening (sdpi.c:812-1129) is not restated.
+   sdpi.c:812-1129    tightenRowCoefs: integrality-based coefficient tightening of the rows with at least two active nonzeros
+                      (Achterberg's Algorithm 10.1), rows whose both sides are redundant in their activity bounds are removed
+
+The one-variable shortcut (sdpi.c:3301-3381), the penalty loop and the Slater check are restated in sdpi_driver.py.
 """
+import math
 import numpy as np
 
 INF = 1e20
@@ -24,9 +27,11 @@ class SdpiProblem:
     blocks: list of dict(n=int, vars={var: [(row, col, val)]} with row >= col, const=[(row, col, val)])
     lp: list of (lhs, rhs, {var: coef})"""
 
-    def __init__(self, obj, lb, ub, blocks=(), lp=()):
+    def __init__(self, obj, lb, ub, blocks=(), lp=(), isintegral=None):
         self.obj = np.asarray(obj, dtype=np.float64)
         self.nvars = len(self.obj)
+        # integrality flags as SCIPsdpiLoadSDP receives them (sdpi.c:2329): only used by the coefficient tightening
+        self.isintegral = [False] * self.nvars if isintegral is None else [bool(v) for v in isintegral]
         self.lb = np.asarray(lb, dtype=np.float64).copy()
         self.ub = np.asarray(ub, dtype=np.float64).copy()
         # already normalised block dicts are shared by reference: the nodes of a branch-and-bound run then hand the SAME
@@ -38,6 +43,82 @@ class SdpiProblem:
 
 class Prepared:
     pass
+
+
+def tighten_row_coefs(lb, ub, act, lhs, rhs, isintegral, eps=EPS):
+    """sdpi.c:812-1129 (tightenRowCoefs; Achterberg, Algorithm 10.1) for one row  lhs <= sum_j a_j y_j <= rhs  over its active
+    variables: act = [(var, coef)].  Returns (act', lhs', rhs', lhsredundant, rhsredundant, nchgcoefs).  For an integral y_j with
+    a_j > 0, minact + a_j >= lhs and maxact - a_j <= rhs:  a'_j = max(lhs - minact, maxact - rhs), lhs -= (a_j - a'_j) lb_j,
+    rhs -= (a_j - a'_j) ub_j (mirrored for a_j < 0); a coefficient that becomes zero leaves the row (the last entry takes its
+    place, as in the reference).  The reference accumulates the activities in quad precision; here the terms are kept and summed
+    with math.fsum (correctly rounded)."""
+    act = list(act)
+    if abs(lhs - rhs) < eps:                              # equations are left alone (:864-866)
+        return act, lhs, rhs, False, False, 0
+    minterms, maxterms = [], []
+    minactinf = maxactinf = False
+    maxintabsval, hasint = 0.0, False
+    for v, c in act:
+        if isintegral[v]:
+            maxintabsval = max(maxintabsval, abs(c))
+            hasint = True
+        hi, lo = (ub[v], lb[v]) if c > 0.0 else (lb[v], ub[v])       # the bound that maximises / minimises c * y
+        if abs(hi) < INF:
+            maxterms.append(c * hi)
+        else:
+            maxactinf = True
+        if abs(lo) < INF:
+            minterms.append(c * lo)
+        else:
+            minactinf = True
+    if not hasint or (minactinf and maxactinf):
+        return act, lhs, rhs, False, False, 0
+    minact = -INF if minactinf else math.fsum(minterms)
+    maxact = INF if maxactinf else math.fsum(maxterms)
+    lhsred = lhs <= -INF or minact >= lhs - eps
+    rhsred = rhs >= INF or maxact <= rhs + eps
+    if lhsred and rhsred:
+        return act, lhs, rhs, True, True, 0
+    if minact + maxintabsval < lhs - eps or maxact - maxintabsval > rhs + eps:
+        return act, lhs, rhs, lhsred, rhsred, 0
+    nchg = 0
+    i = 0
+    while i < len(act):
+        v, c = act[i]
+        if not isintegral[v]:
+            i += 1
+            continue
+        if c > 0.0 and minact + c >= lhs - eps and maxact - c <= rhs + eps:
+            newval = max(lhs - minact, maxact - rhs)
+            blo, bhi = lb[v], ub[v]                        # lhs moves with the lower bound, rhs with the upper bound
+        elif c < 0.0 and minact - c >= lhs - eps and maxact + c <= rhs + eps:
+            newval = min(minact - lhs, rhs - maxact)
+            blo, bhi = ub[v], lb[v]
+        else:
+            i += 1
+            continue
+        if abs(newval - c) > eps:
+            lhsdelta = (newval - c) * blo
+            rhsdelta = (newval - c) * bhi
+            if lhs > -INF:
+                lhs = math.fsum([lhs, lhsdelta])
+            if rhs < INF:
+                rhs = math.fsum([rhs, rhsdelta])
+            nchg += 1
+            if (c > 0.0 and newval > eps) or (c < 0.0 and newval < -eps):
+                if lhs > -INF:
+                    minterms.append(lhsdelta)
+                    minact = math.fsum(minterms)
+                if rhs < INF:
+                    maxterms.append(rhsdelta)
+                    maxact = math.fsum(maxterms)
+                act[i] = (v, newval)
+            else:
+                act[i] = act[-1]
+                act.pop()
+                continue
+        i += 1
+    return act, lhs, rhs, lhsred, rhsred, nchg
 
 
 def prepare(prob, eps=EPS):
@@ -98,7 +179,16 @@ def prepare(prob, eps=EPS):
                 lpindchanges[r] = -1
                 removed += 1
             else:
-                lpindchanges[r] = removed
+                # at least two active nonzeros: coefficient tightening by integrality (sdpi.c:1240-1268); a row both of whose
+                # sides are redundant in the activity bounds is dropped
+                act, lhs, rhs, lhsred, rhsred, nchg = tighten_row_coefs(lb, ub, act, lhs, rhs, prob.isintegral, eps)
+                P.nchgcoefs = getattr(P, 'nchgcoefs', 0) + nchg
+                if lhsred and rhsred:
+                    lpindchanges[r] = -1
+                    removed += 1
+                    act = []
+                else:
+                    lpindchanges[r] = removed
             lplhs[r], lprhs[r] = lhs, rhs
             rows.append(act)
         nfix_after = sum(1 for v in range(prob.nvars) if fixed(v))

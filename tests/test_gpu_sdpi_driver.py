@@ -102,7 +102,7 @@ def test_bnb_with_the_full_driver_per_node(gpu, name, optimum):
     """every node goes through the driver: one-variable nodes are decided by the shortcut (device eigenvalues), nodes the
     backend cannot solve acceptably fall back to the penalty formulation like sdpi.c:3437"""
     inst = sdpa_io.read_sdpa(os.path.join(GOLDEN, "instances", name))
-    prob = bnb.instance_to_sdpi(inst)
+    prob = bnb.instance_to_sdpi(inst, integrality=True)      # as SCIP-SDP runs: LP rows tightened by integrality at every node
     be = backend(gpu)
     lmin = hip_lmin(gpu)
     stats = dict(onevar=0, penalty=0, calls=0)

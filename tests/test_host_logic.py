@@ -127,3 +127,57 @@ def test_marshalling_restatement_consistency():
     assert maps["active"] == [0, 2] and list(b) == [1.0, 3.0]
     assert D.shape == (2 + 2, 2)                          # two LP sides + lb, ub of variable 0
     assert np.allclose(blk[0][0], np.diag([-1.0, -1.0, -2.0]))
+
+
+def test_coefficient_tightening_textbook_row():
+    """sdpi.c:812-1129 restated: 3 x + 2 y <= 4 over binaries becomes x + y <= 1 (Achterberg, Algorithm 10.1)"""
+    act, lhs, rhs, lred, rred, nchg = sdpi_prepare.tighten_row_coefs([0.0, 0.0], [1.0, 1.0], [(0, 3.0), (1, 2.0)], -1e20, 4.0, [True, True])
+    assert dict(act) == {0: 1.0, 1: 1.0} and rhs == 1.0 and lhs == -1e20 and nchg == 2 and lred and not rred
+    # continuous variables and equations are left alone; a row redundant on both sides is reported as such
+    assert sdpi_prepare.tighten_row_coefs([0.0, 0.0], [1.0, 1.0], [(0, 3.0), (1, 2.0)], -1e20, 4.0, [False, False])[5] == 0
+    assert sdpi_prepare.tighten_row_coefs([0.0, 0.0], [1.0, 1.0], [(0, 3.0), (1, 2.0)], 4.0, 4.0, [True, True])[5] == 0
+    out = sdpi_prepare.tighten_row_coefs([0.0, 0.0], [1.0, 1.0], [(0, 3.0), (1, 2.0)], -1.0, 6.0, [True, True])
+    assert out[3] and out[4]
+
+
+def test_coefficient_tightening_keeps_the_points_with_integral_values():
+    """brute force over small boxes: with the integral variables at integer values (continuous ones sampled on a grid) a point
+    satisfies the tightened row exactly when it satisfied the original one"""
+    import itertools
+    import numpy as np
+    rng = np.random.default_rng(42)
+    changed = 0
+    for trial in range(300):
+        k = int(rng.integers(2, 5))
+        lb = rng.integers(-2, 1, k).astype(float)
+        ub = lb + rng.integers(1, 4, k)
+        isint = [bool(b) for b in rng.integers(0, 2, k)]
+        coef = rng.integers(-5, 6, k).astype(float)
+        coef[coef == 0.0] = 1.0
+        act = [(j, coef[j]) for j in range(k)]
+        lo_act = sum(c * (lb[j] if c > 0 else ub[j]) for j, c in act)
+        hi_act = sum(c * (ub[j] if c > 0 else lb[j]) for j, c in act)
+        lhs = -1e20 if rng.random() < 0.5 else float(np.floor(lo_act + rng.random() * (hi_act - lo_act)))
+        rhs = 1e20 if (lhs > -1e20 and rng.random() < 0.5) else float(np.ceil(max(lhs if lhs > -1e20 else lo_act, lo_act) + rng.random() * (hi_act - lo_act)))
+        new, nlhs, nrhs, lred, rred, nchg = sdpi_prepare.tighten_row_coefs(lb, ub, act, lhs, rhs, isint)
+        changed += nchg
+        nd = dict(new)
+        grids = [np.arange(lb[j], ub[j] + 0.5) if isint[j] else np.linspace(lb[j], ub[j], 5) for j in range(k)]
+        for pt in itertools.product(*grids):
+            old = lhs - 1e-9 <= sum(c * pt[j] for j, c in act) <= rhs + 1e-9
+            val = sum(nd.get(j, 0.0) * pt[j] for j in range(k))
+            newok = (nlhs <= -1e20 or nlhs - 1e-9 <= val) and (nrhs >= 1e20 or val <= nrhs + 1e-9)
+            if lred and rred:
+                assert old                                   # a redundant row holds on the whole box
+            else:
+                assert old == newok, (trial, pt, act, lhs, rhs, new, nlhs, nrhs)
+    assert changed > 20          # the random rows do exercise the tightening
+
+
+def test_prepare_tightens_rows_with_integral_variables():
+    prob = sdpi_prepare.SdpiProblem([1, 1, 1], [0, 0, 0], [1, 1, 5], [], [(-1e20, 4.0, {0: 3.0, 1: 2.0}), (-1e20, 9.0, {0: 1.0, 2: 1.0})],
+                                    isintegral=[True, True, False])
+    P = sdpi_prepare.prepare(prob)
+    assert P.status == 'ok' and P.nchgcoefs == 2
+    assert list(P.lpindchanges) == [0, -1]                    # row 1 (x0 + y2 <= 9 with x0 <= 1, y2 <= 5) is redundant and removed
+    assert P.lprhs[0] == 1.0 and list(P.lpval[:2]) == [1.0, 1.0] and list(P.lpind[:2]) == [0, 1]
