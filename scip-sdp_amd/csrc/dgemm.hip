@@ -470,11 +470,22 @@ int hs_dgemm(hipStream_t stream, const hs_gemm_args* a)
    const int BT = useBig ? 128 : 64;
 
    int kchunk = a->K;
+   hs_gemm_args eff = *a;
    if ( a->splitk > 1 )
    {
       kchunk = (a->K + a->splitk - 1) / a->splitk;
       kchunk = ((kchunk + HS_BK - 1) / HS_BK) * HS_BK;
+      /* rounding the slice length up to the K step can leave the last slices EMPTY (K = 10000 in 39 slices: 272 per slice, 37
+       * slices).  The persistent kernel skips an empty item, so its slab kept whatever the workspace held and the reduction
+       * added it (seen with two blocks sharing the workspace: stress seeds 1000 / 1010 of STRESS_BIG).  Only the slices that
+       * exist are launched and reduced. */
+      int nsl = (a->K + kchunk - 1) / kchunk;
+      if ( nsl < 1 ) nsl = 1;
+      eff.splitk = nsl;
+      if ( nsl == 1 )
+         eff.flags &= ~HS_GEMM_XCD;
    }
+   a = &eff;
 
    if ( useBig )
    {

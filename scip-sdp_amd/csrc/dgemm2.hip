@@ -380,6 +380,25 @@ int hs_dgemm2_try(hipStream_t stream, const hs_gemm_args* a, int kchunk)
    }
    if ( g2_disabled )
       return 0;
+   {
+      /* diagnostic: HIPSDP_GEMM_V1_MASK routes classes of products to the tile kernel (1: B triangular, 2: A triangular, 4: lower
+       * tiles / Gram, 8: all others, 16: batched, 32: split-K) */
+      static int mask = -1;
+      if ( mask < 0 )
+         mask = getenv("HIPSDP_GEMM_V1_MASK") != NULL ? atoi(getenv("HIPSDP_GEMM_V1_MASK")) : 0;
+      if ( mask != 0 )
+      {
+         int cls = 0;
+         if ( a->flags & HS_GEMM_B_LOWTRI ) cls |= 1;
+         if ( a->flags & HS_GEMM_A_LOWTRI ) cls |= 2;
+         if ( a->flags & HS_GEMM_LOWER ) cls |= 4;
+         if ( cls == 0 ) cls = 8;
+         if ( a->batch > 1 ) cls |= 16;
+         if ( a->splitk > 1 ) cls |= 32;
+         if ( cls & mask )
+            return 0;
+      }
+   }
    if ( a->layA != HS_KC || (a->flags & (HS_GEMM_UPPER)) )
       return 0;
    if ( (a->lda & 1) || (a->ldb & 1) || (a->strideA & 1) || (a->strideB & 1) || (a->K & 1) || a->K < 16 )

@@ -123,6 +123,9 @@ extern "C" int hipsdp_dgemm_selfcheck(int device, int M, int N, int K, int layB,
    rc = hs_dgemm(0, &g);
    const int before = hs_dgemm2_enable(1);
    g.C = dC2.p;
+   /* the second run must not inherit the slabs of the first: a slice one kernel never writes would go unnoticed */
+   if ( splitk > 1 )
+      hipLaunchKernelGGL(k_unit_fill, dim3(1024), dim3(256), 0, 0, (long long) splitk * nc, 51ULL, dW.p);
    if ( rc == HS_OK )
       rc = hs_dgemm(0, &g);
    const int after = hs_dgemm2_enable(1);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""stress_gpu.py [count] [seed0] - developer tool: random engine problems (dense/sparse blocks across the 64 and 128 size
+"""stress_gpu.py [count] [seed0] (STRESS_BIG=1: blocks of 100-257 rows, 129-400 variables) - developer tool: random engine problems (dense/sparse blocks across the 64 and 128 size
 boundaries, LP rows, feasible / infeasible / unbounded mixes) on the HIP engine against the oracle: status, objective,
 certificates."""
 import os, sys, time, importlib.util
@@ -12,12 +12,20 @@ import numpy as np, ipm_ref, checker
 def rand_core(rng):
     kind = rng.integers(0, 5)
     K = int(rng.integers(1, 4))
-    ns = [int(rng.choice([2, 3, 5, 9, 16, 17, 32, 33, 63, 64, 65, 70, 100])) for _ in range(K)]
-    if sum(n * n for n in ns) > 12000:
-        ns = ns[:1]
-    m = int(rng.choice([1, 2, 5, 13, 40, 64, 65, 129, 140, 200]))
-    if m * sum(n * n for n in ns) > 2.5e6:
-        m = max(1, int(2.5e6 / sum(n * n for n in ns)))
+    if os.environ.get("STRESS_BIG"):
+        # the regime between the B&B-sized and the bench-sized problems: general kernels, MFMA tile paths, K-sliced Gram product
+        K = int(rng.integers(1, 3))
+        ns = [int(rng.choice([100, 129, 160, 200, 257])) for _ in range(K)]
+        m = int(rng.choice([129, 200, 257, 300, 400]))
+        if m * sum(n * n for n in ns) > 3e7:
+            ns = ns[:1]
+    else:
+        ns = [int(rng.choice([2, 3, 5, 9, 16, 17, 32, 33, 63, 64, 65, 70, 100])) for _ in range(K)]
+        if sum(n * n for n in ns) > 12000:
+            ns = ns[:1]
+        m = int(rng.choice([1, 2, 5, 13, 40, 64, 65, 129, 140, 200]))
+        if m * sum(n * n for n in ns) > 2.5e6:
+            m = max(1, int(2.5e6 / sum(n * n for n in ns)))
     q = int(rng.choice([0, 0, 3, 17, 64, 150]))
     blocks = []
     for n in ns:

@@ -203,6 +203,9 @@ GEMM_LOWER, GEMM_A_LOWTRI, GEMM_B_LOWTRI, GEMM_XCD, GEMM_REMAP, GEMM_NOFAST = 1,
     (3001, 2001, 402, 0, 1, 1, 0, 0.0, 1),                              # odd M and N
     (3000, 2502, 128, 1, 1, 1, 0, 0.0, 1),                              # row-contiguous B, ragged last column tile
     (3000, 2500, 501, 1, 1, 1, 0, 0.0, 0),                              # odd K: not eligible, both runs take the tile kernel
+    (401, 401, 25000, 0, 1, 64, GEMM_LOWER, 1.0, 1),                    # 64 slices asked, 63 exist after rounding the slice length: no empty slab is reduced
+    (401, 401, 10000, 0, 1, 39, GEMM_LOWER, 1.0, 0),                    # 37 of 39 slices exist (too few items for the persistent kernel)
+    (700, 700, 20000, 0, 1, 19, GEMM_LOWER | GEMM_XCD | GEMM_NOFAST, 1.0, 1),     # XCD-walked slices with an empty tail (1056 per slice)
 ])
 def test_persistent_gemm_matches_tile_gemm_bitwise(gpu, M, N, K, layB, batch, splitk, flags, beta, expect_v2):
     used, ndiff = gpu.dgemm_selfcheck(M, N, K, layB=layB, batch=batch, splitk=splitk, flags=flags, beta=beta)
