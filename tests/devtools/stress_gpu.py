@@ -12,7 +12,12 @@ import numpy as np, ipm_ref, checker
 def rand_core(rng):
     kind = rng.integers(0, 5)
     K = int(rng.integers(1, 4))
-    if os.environ.get("STRESS_BIG"):
+    if os.environ.get("STRESS_BIG") == "2":
+        # towards the bench size: several blocks through the persistent GEMM paths (the oracle needs seconds per iteration)
+        K = int(rng.integers(1, 3))
+        ns = [int(rng.choice([300, 385, 500])) for _ in range(K)]
+        m = int(rng.choice([300, 600, 1000]))
+    elif os.environ.get("STRESS_BIG"):
         # the regime between the B&B-sized and the bench-sized problems: general kernels, MFMA tile paths, K-sliced Gram product
         K = int(rng.integers(1, 3))
         ns = [int(rng.choice([100, 129, 160, 200, 257])) for _ in range(K)]
