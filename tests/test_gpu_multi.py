@@ -13,11 +13,11 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def run_world(tmp_path, world, n, m, q, tag, env=None, load="dense"):
+def run_world(tmp_path, world, n, m, q, tag, env=None, load="dense", n2=0):
     name = "/hipsdp_t_%d_%s" % (os.getpid(), tag)
     outs = [str(tmp_path / ("%s_r%d.json" % (tag, r))) for r in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "multi_worker.py"), str(r), str(world), name, str(n), str(m),
-                               str(q), outs[r], load], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                               str(q), outs[r], load, str(n2)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                               env=dict(os.environ, **(env or {}))) for r in range(world)]
     logs = []
     try:
@@ -151,3 +151,18 @@ def test_two_ranks_at_the_bench_size(gpu, tmp_path, load):
     for r in many:
         assert r["status"] == 0 and r["iterations"] == one["iterations"]
         assert np.max(np.abs(np.array(r["y"]) - y1)) <= 1e-10 * max(1.0, np.max(np.abs(y1)))
+
+
+@pytest.mark.parametrize("load,env", [("dense", {}), ("dense", {"HIPSDP_SCHUR": "R"}), ("dense", {"HIPSDP_SHARD_PASSES": "1", "HIPSDP_WS_GB": "0.0004"}),
+                                      ("vars-dense", {"HIPSDP_VAR_SLICE": "32"}), ("vars-coo", {})])
+@pytest.mark.parametrize("world,n,n2,m,q", [(2, 70, 40, 90, 0), (3, 96, 130, 60, 5)])
+def test_two_blocks_of_different_sizes_on_several_ranks(gpu, tmp_path, world, n, n2, m, q, load, env):
+    """two dense blocks sharing the Schur workspace, the split-K slabs and the communicator buffers: column slices, row chunks,
+    row-swept passes with a small workspace, and matrices sharded by variable (dense and COO loaders) against the single process"""
+    one = run_world(tmp_path, 1, n, m, q, "t1", load=load.split("-")[-1], n2=n2)[0]
+    many = run_world(tmp_path, world, n, m, q, "t%d" % world, env=dict(env, HIPSDP_TEST_STAGING=str(1 << 22)), load=load, n2=n2)
+    assert one["status"] == 0
+    y1 = np.array(one["y"])
+    for r in many:
+        assert r["status"] == 0 and r["iterations"] == one["iterations"], (r["status"], r["iterations"], one["iterations"])
+        assert np.max(np.abs(np.array(r["y"]) - y1)) <= 1e-8 * max(1.0, np.max(np.abs(y1)))
