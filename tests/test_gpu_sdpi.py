@@ -169,6 +169,37 @@ def _random_node(rng, nvars, sizes, nlp, nfixed):
     return sdpi_prepare.SdpiProblem(rng.standard_normal(nvars), lb, ub, blocks, lp)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_random_mid_size_nodes_backend_vs_oracle(gpu, seed):
+    """the same end-to-end comparison with blocks of 66-150 rows and 70-200 variables: fixings, removed rows / columns and LP rows
+    through the general kernels (packed passes, blocked factorizations, MFMA tile products, split-K slabs shared by two blocks)"""
+    import ipm_ref
+    import checker
+    rng = np.random.default_rng(7000 + seed)
+    prob = _random_node(rng, nvars=int(rng.integers(70, 200)), sizes=[int(rng.integers(66, 150)), int(rng.integers(20, 110))],
+                        nlp=int(rng.integers(0, 40)), nfixed=int(rng.integers(0, 12)))
+    P = sdpi_prepare.prepare(prob)
+    if P.status != 'ok':
+        pytest.skip("presolve decided the node")
+    b, blk, D, c, maps = sdpi_prepare.to_core(P)
+    core = ipm_ref.CoreProblem(b, blk, D, c)
+    ref = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-6, feastol=1e-6))
+    s = new_solver(gpu)
+    rc, _, _ = s.solve(P)
+    assert rc == sdpi_call.SCIP_OKAY
+    if ref.status == ipm_ref.STATUS_DINF:               # the random LP rows can contradict each other: same verdict expected
+        assert s.flag("IsDualInfeasible") and not s.flag("IsOptimal")
+        s.free()
+        return
+    assert ref.status == ipm_ref.STATUS_OPTIMAL and s.flag("IsOptimal")
+    rc, objval, y = s.dual_sol()
+    fixedcontr = sum(prob.obj[v] * P.lb[v] for v in range(prob.nvars) if v not in maps["active"])
+    assert abs(objval - (ref.dobj + fixedcontr)) <= 1e-5 * (1 + abs(objval))
+    yact = np.array([y[v] for v in maps["active"]])
+    assert checker.check_dual(core, yact, 1e-5)["feasible"]
+    s.free()
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_random_nodes_backend_vs_oracle(gpu, seed):
     """end to end at the boundary: sdpi-style preparation -> SCIPsdpiSolverLoadAndSolve (HIP) against the independently
