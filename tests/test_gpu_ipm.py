@@ -234,10 +234,11 @@ def _solve_with_start(hb, core, start, tol=1e-6):
     return out
 
 
-def test_warm_start_from_an_interior_point_matches_oracle_and_saves_iterations(gpu):
+@pytest.mark.parametrize("n,m", [(30, 45), (130, 160)])
+def test_warm_start_from_an_interior_point_matches_oracle_and_saves_iterations(gpu, n, m):
     """(f)-3: a start point handed in through hipsdp_set_start (what SCIPsdpiSolverLoadAndSolve receives as starty / startZ /
     startX, sdpisolver.h:160-173) is used when strictly interior; the oracle applies the same rule."""
-    b, A, ys, Xs, Zs = instances.planted_dense(30, 45)
+    b, A, ys, Xs, Zs = instances.planted_dense(n, m)
     core = ipm_ref.CoreProblem(b, [A])
     cold = _solve_with_start(gpu, core, None)
     assert cold["info"].status == 0 and cold["info"].warm_started == 0
@@ -245,8 +246,8 @@ def test_warm_start_from_an_interior_point_matches_oracle_and_saves_iterations(g
     # a scaled identity)
     d = 1e-2
     y0 = cold["y"]
-    X0 = [(1 - d) * cold["X"][0] + d * np.eye(30)]
-    Z0 = [(1 - d) * cold["Z"][0] + d * np.eye(30)]
+    X0 = [(1 - d) * cold["X"][0] + d * np.eye(n)]
+    Z0 = [(1 - d) * cold["Z"][0] + d * np.eye(n)]
     warm = _solve_with_start(gpu, core, (y0, X0, Z0))
     st = ipm_ref.warm_start_point(core, y0, X0, Z0, np.zeros(0), np.zeros(0))
     assert st is not None
@@ -297,7 +298,7 @@ def test_eigenvector_cuts_on_the_device(gpu):
     (oracle/eigcuts_ref.py): eigenvalues, coefficients up to the sign of v, violation = -eigenvalue, validity at the planted
     feasible point."""
     import eigcuts_ref
-    for (n, m, seed) in [(12, 7, 0), (40, 25, 1), (90, 30, 2)]:
+    for (n, m, seed) in [(12, 7, 0), (40, 25, 1), (90, 30, 2), (200, 60, 3)]:
         b, A, ys, Xs, Zs = instances.planted_dense(n, m)
         core = ipm_ref.CoreProblem(b, [A])
         rng = np.random.default_rng(seed)
