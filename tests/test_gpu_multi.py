@@ -155,7 +155,7 @@ def test_two_ranks_at_the_bench_size(gpu, tmp_path, load):
 
 @pytest.mark.parametrize("load,env", [("dense", {}), ("dense", {"HIPSDP_SCHUR": "R"}), ("dense", {"HIPSDP_SHARD_PASSES": "1", "HIPSDP_WS_GB": "0.0004"}),
                                       ("vars-dense", {"HIPSDP_VAR_SLICE": "32"}), ("vars-coo", {})])
-@pytest.mark.parametrize("world,n,n2,m,q", [(2, 70, 40, 90, 0), (3, 96, 130, 60, 5)])
+@pytest.mark.parametrize("world,n,n2,m,q", [(2, 70, 40, 90, 0), (3, 96, 130, 60, 5), (2, 200, 129, 260, 30)])
 def test_two_blocks_of_different_sizes_on_several_ranks(gpu, tmp_path, world, n, n2, m, q, load, env):
     """two dense blocks sharing the Schur workspace, the split-K slabs and the communicator buffers: column slices, row chunks,
     row-swept passes with a small workspace, and matrices sharded by variable (dense and COO loaders) against the single process"""
