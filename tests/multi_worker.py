@@ -76,7 +76,10 @@ def main():
         s.set_shape(m, [n], 0)
         bg = s.gen_planted(n, m, 77, Xs, Zs, ys)
         b = bg
-    info = s.solve(gaptol=1e-6, feastol=1e-6)
+    kw = {}
+    if os.environ.get("HIPSDP_TEST_TIMELIMIT"):
+        kw["timelimit"] = float(os.environ["HIPSDP_TEST_TIMELIMIT"])
+    info = s.solve(gaptol=1e-6, feastol=1e-6, **kw)
     y = s.y()
     X = s.X(0)
     if world > 1:

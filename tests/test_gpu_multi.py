@@ -166,3 +166,14 @@ def test_two_blocks_of_different_sizes_on_several_ranks(gpu, tmp_path, world, n,
     for r in many:
         assert r["status"] == 0 and r["iterations"] == one["iterations"], (r["status"], r["iterations"], one["iterations"])
         assert np.max(np.abs(np.array(r["y"]) - y1)) <= 1e-8 * max(1.0, np.max(np.abs(y1)))
+
+
+@pytest.mark.parametrize("shard_small", [True, False])
+def test_time_limit_is_decided_by_rank_zero(gpu, tmp_path, shard_small):
+    """the clocks of the ranks differ, so rank 0's time-limit decision is broadcast (sharded solve: every iteration; replicated
+    small solve: with the outcome): all ranks stop at the same iteration with the same status, whatever their own clock says"""
+    env = {"HIPSDP_TEST_TIMELIMIT": "0.003", "HIPSDP_SHARD_MIN_FLOPS": "0" if shard_small else "2e10"}
+    many = run_world(tmp_path, 3, 70, 130, 0, "tl%d" % int(shard_small), env=env)
+    assert many[0]["status"] in (0, 6)                       # optimal if the box was fast enough, else HIPSDP_STATUS_TIMELIM
+    for r in many[1:]:
+        assert r["status"] == many[0]["status"] and r["iterations"] == many[0]["iterations"]
