@@ -181,3 +181,26 @@ def test_prepare_tightens_rows_with_integral_variables():
     assert P.status == 'ok' and P.nchgcoefs == 2
     assert list(P.lpindchanges) == [0, -1]                    # row 1 (x0 + y2 <= 9 with x0 <= 1, y2 <= 5) is redundant and removed
     assert P.lprhs[0] == 1.0 and list(P.lpval[:2]) == [1.0, 1.0] and list(P.lpind[:2]) == [0, 1]
+
+
+def test_communicator_from_the_environment_without_a_launch(hb):
+    """hipsdp_comm_from_env (what sdpisolver_hip.c calls when it creates its engine): no WORLD_SIZE / HIPSDP_WORLD, or a world of
+    one, means a single GPU - no communicator, no device call; a world without a rendezvous (neither HIPSDP_COMM_FILE nor
+    HIPSDP_COMM_SHM) is an error, not a hang.  Run in child processes: the communicator is process-wide state."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import ctypes as C, importlib.util, os, sys
+        spec = importlib.util.spec_from_file_location("hipsdp_binding", sys.argv[1])
+        hb = importlib.util.module_from_spec(spec); spec.loader.exec_module(hb)
+        comm, rank, world = C.c_void_p(), C.c_int(-1), C.c_int(-1)
+        rc = hb.lib().hipsdp_comm_from_env(0, C.byref(comm), C.byref(rank), C.byref(world))
+        print(rc, comm.value, rank.value, world.value)
+    """)
+    binding = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scip-sdp_amd", "binding.py")
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "HIPSDP_WORLD", "HIPSDP_RANK", "HIPSDP_COMM_FILE", "HIPSDP_COMM_SHM")}
+    out = subprocess.run([sys.executable, "-c", code, binding], env=base, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.split() == ["0", "None", "0", "1"], (out.stdout, out.stderr)
+    out = subprocess.run([sys.executable, "-c", code, binding], env=dict(base, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=120)
+    assert out.stdout.split() == ["0", "None", "0", "1"]
+    out = subprocess.run([sys.executable, "-c", code, binding], env=dict(base, HIPSDP_WORLD="4", HIPSDP_RANK="1"), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.split()[0] != "0" and out.stdout.split()[1] == "None", (out.stdout, out.stderr)
