@@ -57,7 +57,7 @@ def assemble(m1, nranks, c, first_chunks, second_chunks):
 
 def shard_cols(m1, n, nranks):
     """restatement of hs_shard_cols: boundaries at multiples of 16, minimal slowest rank under the cost model of schur.hip
-    (width rounded up to the 128-wide tile in the two triangular products, plain width in W W^T)"""
+    (width rounded up to the 128-wide tile - 64 for slices of at most 64 columns - in the two triangular products, plain width in W W^T)"""
     gran = 16
     P = (n + gran - 1) // gran
     col = lambda p: min(p * gran, n)
@@ -66,7 +66,7 @@ def shard_cols(m1, n, nranks):
         c0, w = col(p0), col(p1) - col(p0)
         if w <= 0:
             return 0.0
-        wt = 128.0 * ((w + 127) // 128)
+        wt = 64.0 if w <= 64 else 128.0 * ((w + 127) // 128)      # slices of <= 64 columns run on 64-wide tiles
         return wt * (2.0 * (n - c0 - 0.5 * w) + n) + float(w) * m1
 
     prev = [1e300] * (P + 1)

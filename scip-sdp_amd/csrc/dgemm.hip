@@ -466,7 +466,7 @@ int hs_dgemm(hipStream_t stream, const hs_gemm_args* a)
 
    /* tile choice: big tiles once they fill the chip, small tiles otherwise */
    const long long big = (long long) ((a->M + 127) / 128) * ((a->N + 127) / 128) * (a->splitk > 1 ? a->splitk : a->batch);
-   const bool useBig = big >= 192 || (a->flags & HS_GEMM_XCD);
+   const bool useBig = (big >= 192 || (a->flags & HS_GEMM_XCD)) && !(a->flags & HS_GEMM_TILE64);
    const int BT = useBig ? 128 : 64;
 
    int kchunk = a->K;

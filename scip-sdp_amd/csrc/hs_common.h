@@ -53,6 +53,7 @@ void hs_pool_trim(void);
 #define HS_GEMM_B_LOWTRI  4   /* B[k][n] = 0 for k < n (lower triangular right factor): tiles start at k = n0 */
 #define HS_GEMM_XCD       8   /* split-K only: workgroups that share an XCD (blockIdx % 8) walk the same K range, so the
                                * operand panels are fetched from HBM once per XCD and re-used from its L2 */
+#define HS_GEMM_TILE64  128   /* 64 x 64 tiles whatever the size: for products whose N is a narrow column slice (<= 64 columns) */
 #define HS_GEMM_NOFAST   64   /* always use the bounds-checked tile loads */
 #define HS_GEMM_UPPER    32   /* compute only tiles that touch the upper triangle (col >= row) of C */
 #define HS_GEMM_REMAP    16   /* XCD-contiguous tile order for batched / stack products: the tiles that share an operand

@@ -165,10 +165,12 @@ int hs_schur_Wcols(hipStream_t s, int m1, int n, const double* A, const double* 
    const long long nk = (long long) n * cw;
    if ( c0 < 0 || c0 + cw > n || rows > 2000000000LL || nk > 2000000000LL || (long long) m1 * nk > w->chunk_cols * w->n2 )
       return HS_ERR_ARG;
+   /* a slice of at most 64 columns (8 ranks at n = 500: 62) fills half a 128-wide tile: 64 x 64 tiles for the two n^3 products */
+   const int narrow = (cw <= 64 && getenv("HIPSDP_NO_TILE64") == NULL) ? HS_GEMM_TILE64 : 0;
    hs_gemm_args g1 = {(int) rows, cw, n - c0, HS_KC, HS_MC, A + c0, n, 0, R + (long long) c0 * n + c0, n, 0, w->T, cw, 0, 1.0, 0.0, 1,
-      HS_GEMM_B_LOWTRI, 1, NULL};
+      HS_GEMM_B_LOWTRI | narrow, 1, NULL};
    HS_CALL( hs_dgemm(s, &g1) );
-   hs_gemm_args g2 = {n, cw, n, HS_KC, HS_MC, G, n, 0, w->T, cw, nk, w->U, cw, nk, 1.0, 0.0, m1, HS_GEMM_A_LOWTRI | HS_GEMM_REMAP, 1, NULL};
+   hs_gemm_args g2 = {n, cw, n, HS_KC, HS_MC, G, n, 0, w->T, cw, nk, w->U, cw, nk, 1.0, 0.0, m1, HS_GEMM_A_LOWTRI | HS_GEMM_REMAP | narrow, 1, NULL};
    HS_CALL( hs_dgemm(s, &g2) );
    int flags = HS_GEMM_LOWER;
    int sk;
@@ -332,7 +334,7 @@ void hs_shard_cols(int m1, int n, int nranks, int rank, int* c_begin, int* c_wid
       auto cost = [&](int p0, int p1) -> double {
          const int c0 = col(p0), w = col(p1) - c0;
          if ( w <= 0 ) return 0.0;
-         const double wt = 128.0 * (double) ((w + 127) / 128);
+         const double wt = w <= 64 ? 64.0 : 128.0 * (double) ((w + 127) / 128);      /* slices of <= 64 columns run on 64-wide tiles */
          return wt * (2.0 * ((double) n - (double) c0 - 0.5 * (double) w) + (double) n) + (double) w * (double) m1;
       };
       /* best[g][p]: smallest possible maximum over the first g ranks covering boundaries 0 .. p */
