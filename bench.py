@@ -5,8 +5,12 @@ instance of BASELINE.md section 3, with A already resident in HBM (generated on 
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--n 500] [--m 1000] [--no-cpu]
 
-N > 1 is launched by torch.distributed.run (one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE from the environment).
-Rank 0 prints ONE JSON line.  The oracle (oracle/ipm_ref.py) is imported only inside cpu_baseline().
+N > 1: one process per GPU.  When the driver has already started the ranks (torch.distributed.run: RANK / LOCAL_RANK /
+WORLD_SIZE in the environment) this process is one of them and checks that --gpus equals WORLD_SIZE.  Started plainly as
+`python bench.py --gpus N`, it is the PARENT: before anything touches the GPU it starts the N ranks as child processes
+(python -m torch.distributed.run ... bench.py <same arguments>), waits for them, relays rank 0's JSON line and exits
+non-zero when any rank failed.  Rank 0 prints ONE JSON line.  The oracle (oracle/ipm_ref.py) is imported only inside
+cpu_baseline().
 """
 import argparse
 import importlib.util
@@ -19,9 +23,20 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X FP64 matrix peak (vendor figure; rocBLAS dgemm reaches 72.8 on this pool)
-# HBM bytes per Schur assembly from the PMC passes committed under profiles/ (FETCH_SIZE doubled as MI355X_MICROARCH.md
-# prescribes for gfx950, plus WRITE_SIZE), keyed by (n, m); None when not measured for a size
-TRAFFIC_BYTES_PER_ASSEMBLY = {(500, 1000): 18.79e9}      # profiles/r01_h_pmc_traffic_c2.txt
+# Numbers that only the PMC passes of rocprofv3 can give (a live bench run cannot collect counters): HBM bytes per Schur
+# assembly (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE), MFMA busy share and EXECUTED
+# FP64 matrix rate of the two n^3 products / the Gram product.  Keyed by (n, m), quoted from the committed file named in
+# "source" and labelled as such in the JSON line; one GPU only; None for sizes that were not profiled.
+PMC_FROM_PROFILES = {
+    (500, 1000): {"traffic_bytes_per_assembly": 18.79e9, "mfma_busy": {"n3_products": 0.608, "gram": 0.754},
+                  "executed_tflops": {"n3_products": 41.2, "gram": 53.1},
+                  "source": "profiles/r01_h_pmc_traffic_c2.txt, profiles/r01_f_pmc_mfma_util.txt (previous round's build)"},
+    (1000, 2000): {"traffic_bytes_per_assembly": None, "mfma_busy": {"n3_products": 0.683, "gram": 0.773},
+                   "executed_tflops": {"n3_products": 52.0, "gram": 60.0},
+                   "source": "profiles/r01_f_pmc_mfma_util.txt (previous round's build)"},
+}
+WORKLOAD_NAMES = {(500, 1000): "BASELINE configs[1] (C2)", (1000, 2000): "BASELINE.md T1 (north_star target size)",
+                  (2000, 4000): "BASELINE configs[3] (C4)", (4000, 8000): "BASELINE.md T8"}
 
 
 def load_binding():
@@ -91,7 +106,11 @@ def cpu_baseline(solver, b, n, m, gpu_iterations, budget_iters=None):
                       % (its, n, m, dt, gpu_iterations)}
 
 
-def main():
+def workload_name(n, m):
+    return WORKLOAD_NAMES.get((n, m), "custom size (not a BASELINE configuration)")
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -100,17 +119,287 @@ def main():
     ap.add_argument("--m", type=int, default=1000)
     ap.add_argument("--seed", type=int, default=20240)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip the t1 / sdpi_boundary / warm_start / phases sub-objects")
     ap.add_argument("--shard-matrices", choices=["auto", "on", "off"], default="auto",
                     help="N > 1: constraint matrices sharded by variable (auto: when the replicated matrices would not fit)")
-    args = ap.parse_args()
+    ap.add_argument("--master-port", type=int, default=0, help="parent mode: rendezvous port of the ranks (0: pick a free one)")
+    ap.add_argument("--launch-dry-run", action="store_true",
+                    help="exercise the N-rank launcher without a GPU: the ranks meet over gloo and rank 0 prints a line")
+    return ap.parse_args(argv)
 
+
+# ---- parent mode: `python bench.py --gpus N` without a launcher ---------------------------------------------------------
+
+def visible_gpus():
+    """number of GPUs without initialising one (torch.cuda.device_count() does not create a context on this image)"""
+    import torch
+    return int(torch.cuda.device_count())
+
+
+def launch_ranks(args, argv):
+    """Starts the N ranks as CHILD processes (never exec: nothing in this process may have touched the GPU, and it has not),
+    relays rank 0's JSON line, returns the exit code."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if not args.launch_dry_run:
+        have = visible_gpus()
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d asked for, but only %d GPU(s) are visible on this machine: a %d-rank RCCL run "
+                             "needs %d devices (one process per GPU); nothing was run\n" % (n, have, n, n))
+            return 3
+    port = args.master_port
+    if port <= 0:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + [a for a in argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    sys.stderr.write("bench.py: starting %d ranks: %s\n" % (n, " ".join(cmd)))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True)
+    out, _ = proc.communicate()
+    line = None
+    for ln in out.splitlines():
+        t = ln.strip()
+        if t.startswith("{") and t.endswith("}"):
+            try:
+                json.loads(t)
+                line = t
+            except ValueError:
+                pass
+        elif t:
+            sys.stderr.write(ln + "\n")
+    if proc.returncode != 0:
+        sys.stderr.write("bench.py: the %d-rank run failed (launcher exit code %d)\n" % (n, proc.returncode))
+        if line is not None:
+            sys.stderr.write("bench.py: partial result of rank 0: %s\n" % line)
+        return proc.returncode if proc.returncode > 0 else 1
+    if line is None:
+        sys.stderr.write("bench.py: the ranks finished but rank 0 printed no JSON line\n")
+        return 4
+    print(line)
+    return 0
+
+
+def dry_run_rank(args):
+    """--launch-dry-run: what a rank does up to the first collective, without a GPU (CPU test of the launcher)"""
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ["RANK"])
+    world = int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo")
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t)
+    dist.barrier()
+    if os.environ.get("BENCH_DRYRUN_FAIL_RANK") == str(rank):      # test hook: a rank that dies must fail the whole run
+        dist.destroy_process_group()
+        return 7
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "gpus_arg": args.gpus, "rank_sum": float(t.item()),
+                          "local_rank": int(os.environ.get("LOCAL_RANK", "-1")), "master_addr": os.environ.get("MASTER_ADDR")}))
+    dist.destroy_process_group()
+    return 0
+
+
+# ---- sub-benchmarks of the one JSON line ---------------------------------------------------------------------------------
+
+def run_solves(solver, steps, warmup, barrier, **kw):
+    for _ in range(warmup):
+        solver.solve(gaptol=1e-5, feastol=1e-5, **kw)
+    barrier()
+    t0 = time.perf_counter()
+    infos = [solver.solve(gaptol=1e-5, feastol=1e-5, **kw) for _ in range(steps)]
+    barrier()
+    return infos, time.perf_counter() - t0
+
+
+def schur_summary(infos, n, m, world=1):
+    schur_s = sum(i.schur_seconds for i in infos)
+    schur_fl = sum(i.schur_flops for i in infos)
+    calls = sum(i.schur_calls for i in infos)
+    ach = schur_fl / max(schur_s, 1e-12) / 1e12
+    return {"achieved": ach, "frac": ach / (FP64_MFMA_PEAK_TFLOPS * world), "avg_assembly_ms": 1e3 * schur_s / max(1, calls),
+            "assemblies": calls, "algorithmic_flops_per_assembly": schur_fl / max(1, calls),
+            "schur_share_of_solve_time": schur_s / max(1e-12, sum(i.solve_seconds for i in infos))}
+
+
+def phase_anatomy(hb, solver):
+    """one extra (untimed) solve with HIP events at the phase boundaries of the engine's stream (also roctx ranges)"""
+    import ctypes as C
+    lib = hb.lib()
+    lib.hipsdp_phase_name.restype = C.c_char_p
+    lib.hipsdp_set_profiling(solver.h, 1)
+    info = solver.solve(gaptol=1e-5, feastol=1e-5)
+    ms = (C.c_double * 8)()
+    lib.hipsdp_get_phase_times(solver.h, ms)
+    lib.hipsdp_set_profiling(solver.h, 0)
+    its = max(1, info.iterations)
+    out = {lib.hipsdp_phase_name(p).decode(): ms[p] / its for p in range(7)}
+    out["unit"] = "ms per iteration (device time between HIP events on the engine's stream)"
+    out["non_schur_ms_per_iteration"] = sum(ms[p] for p in range(7) if p != 2) / its
+    return out
+
+
+def bench_t1(hb, seed, barrier):
+    """n = 1000, m = 2000: the size north_star states its 1-GPU target on (>= 10x CPU, >= 30 % FP64-MFMA in the assembly)"""
+    n, m = 1000, 2000
+    s = hb.Solver(0)
+    try:
+        s.set_shape(m, [n], 0)
+        Xs, Zs, ys = planted_pair(n, m, seed)
+        b = s.gen_planted(n, m, seed, Xs, Zs, ys)
+        opt = float(b @ ys)
+        infos, el = run_solves(s, 2, 1, barrier)
+        ok = all(i.status == 0 for i in infos) and abs(infos[-1].dobj - opt) <= 1e-5 * (1 + abs(opt))
+        its = sum(i.iterations for i in infos)
+        out = {"workload": workload_name(n, m), "n": n, "m": m, "steps": len(infos), "solves_per_sec": len(infos) / el,
+               "ms_per_step": 1e3 * el / len(infos), "iters_per_sec": its / el, "iterations_per_solve": its / len(infos),
+               "matches_planted_optimum": bool(ok), "roofline": schur_summary(infos, n, m)}
+        pmc = PMC_FROM_PROFILES.get((n, m))
+        if pmc is not None:
+            out["roofline"]["from_committed_pmc_profile"] = pmc
+        return out
+    finally:
+        s.close()
+
+
+def bench_warm_start(solver, n, m, b, barrier, cold_iters):
+    """warm-start variant of SURVEY.md section 8(d): the start point is the optimum of the node pushed into the interior the way
+    relax_sdp's warmstartipfactor rule does it (convex combination with a scaled identity, factor 0.5) and y perturbed by 1e-3"""
+    y = solver.y()
+    X = solver.X(0)
+    Z = solver.Z(0)
+    rng = np.random.default_rng(7)
+    y0 = y + 1e-3 * rng.standard_normal(m)
+    lam = 0.5
+    sx = max(1.0, float(np.trace(X)) / n)
+    sz = max(1.0, float(np.trace(Z)) / n)
+    X0 = (1 - lam) * X + lam * sx * np.eye(n)
+    Z0 = (1 - lam) * Z + lam * sz * np.eye(n)
+    times, its, used = [], [], []
+    for _ in range(3):
+        solver.set_start(y0, [X0], [Z0])
+        barrier()
+        t0 = time.perf_counter()
+        info = solver.solve(gaptol=1e-5, feastol=1e-5)
+        barrier()
+        times.append(time.perf_counter() - t0)
+        its.append(info.iterations)
+        used.append(int(info.warm_started))
+    opt_ok = info.status == 0
+    return {"start_point": "optimum of the same node, X and Z moved half-way to a scaled identity, y perturbed by 1e-3 (parent-node "
+                           "stand-in); the upload of the start point (2 x n^2 doubles) is outside the timed region",
+            "solves_per_sec": 1.0 / (sum(times[1:]) / len(times[1:])), "iterations_per_solve": its[-1],
+            "cold_start_iterations": cold_iters, "start_point_used_by_engine": bool(all(used)), "status_optimal": bool(opt_ok)}
+
+
+def bench_sdpi_boundary(hb, solver, n, m, b, opt):
+    """The same node through the drop-in boundary SCIPsdpiSolverLoadAndSolve (48-argument call of sdpisolver.h:176-233): the
+    caller's COO arrays (lower triangles, 1.25e8 triplets at C2 = 2 GB) are host buffers, so the first call pays the PCIe upload
+    into the device-resident master copy; later calls (the other nodes of a tree) find it by fingerprint."""
+    import ctypes as C
+    lib = hb.lib()
+    A = solver.get_block_dense(0)                  # identical bits to the engine-level bench
+    il = np.tril_indices(n)
+    rows = np.ascontiguousarray(il[0], dtype=np.int32)
+    cols = np.ascontiguousarray(il[1], dtype=np.int32)
+    nnz_per = len(rows)
+    vals = np.ascontiguousarray(A[1:, il[0], il[1]])                       # [m, nnz_per]
+    cval = np.ascontiguousarray(A[0, il[0], il[1]])
+    keepc = np.abs(cval) > 0.0
+    crow_a, ccol_a, cval_a = rows[keepc].copy(), cols[keepc].copy(), cval[keepc].copy()
+    del A
+    PD, PI = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    PPD, PPI = C.POINTER(PD), C.POINTER(PI)
+    pi = lambda a: a.ctypes.data_as(PI)
+    pd = lambda a: a.ctypes.data_as(PD)
+    prow = (PI * m)(*[pi(rows)] * m)
+    pcol = (PI * m)(*[pi(cols)] * m)
+    pval = (PD * m)(*[vals[j].ctypes.data_as(PD) for j in range(m)])
+    srow, scol, sval = (PPI * 1)(prow), (PPI * 1)(pcol), (PPD * 1)(pval)
+    nvarnonz = np.full(m, nnz_per, dtype=np.int32)
+    sdpvar = np.arange(m, dtype=np.int32)
+    pnn, pvar = (PI * 1)(pi(nvarnonz)), (PI * 1)(pi(sdpvar))
+    obj = np.ascontiguousarray(b, dtype=np.float64)
+    lb = np.full(m, -1e20)
+    ub = np.full(m, 1e20)
+    sizes = np.array([n], dtype=np.int32)
+    nbv = np.array([m], dtype=np.int32)
+    constn = np.array([len(cval_a)], dtype=np.int32)
+    pcr, pcc, pcv = (PI * 1)(pi(crow_a)), (PI * 1)(pi(ccol_a)), (PD * 1)(pd(cval_a))
+    indch = np.zeros(n, dtype=np.int32)
+    pind = (PI * 1)(pi(indch))
+    nrem = np.zeros(1, dtype=np.int32)
+    bic = np.zeros(1, dtype=np.int32)
+    dummy_i = np.zeros(1, dtype=np.int32)
+    dummy_d = np.zeros(1)
+    h = C.c_void_p()
+    assert lib.SCIPsdpiSolverCreate(C.byref(h), None, None, None) == 1
+    for par, val in ((1, 1e-5), (2, 1e-5), (3, 1e-5)):        # GAPTOL, FEASTOL, SDPSOLVERFEASTOL as relax_sdp.c:70-71 sets them
+        lib.SCIPsdpiSolverSetRealpar(h, par, C.c_double(val))
+
+    def call():
+        t0 = time.perf_counter()
+        rc = lib.SCIPsdpiSolverLoadAndSolve(
+            h, C.c_int(m), pd(obj), pd(lb), pd(ub), C.c_int(1), pi(sizes), pi(nbv),
+            C.c_int(int(constn[0])), pi(constn), pcr, pcc, pcv,
+            C.c_int(int(m * nnz_per)), pnn, pvar, srow, scol, sval,
+            pind, pi(nrem), pi(bic), C.c_int(0),
+            C.c_int(0), pi(dummy_i), pd(dummy_d), pd(dummy_d), C.c_int(0), pi(dummy_i), pi(dummy_i), pd(dummy_d),
+            None, None, None, None, None, None, None, None, None,
+            C.c_int(-1), C.c_double(1e20), None)
+        dt = time.perf_counter() - t0
+        o = C.c_double(0.0)
+        ok = rc == 1 and bool(lib.SCIPsdpiSolverIsOptimal(h)) and lib.SCIPsdpiSolverGetObjval(h, C.byref(o)) == 1
+        it, calls = C.c_int(0), C.c_int(0)
+        lib.SCIPsdpiSolverGetIterations(h, C.byref(it))
+        lib.SCIPsdpiSolverGetSdpCalls(h, C.byref(calls))
+        return dt, ok, o.value, it.value, calls.value
+
+    try:
+        first = call()
+        later = [call() for _ in range(3)]
+    finally:
+        lib.SCIPsdpiSolverFree(C.byref(h))
+    tl = sum(x[0] for x in later) / len(later)
+    good = all(x[1] and abs(x[2] - opt) <= 1e-5 * (1 + abs(opt)) for x in [first] + later)
+    return {"entry_point": "SCIPsdpiSolverLoadAndSolve (sdpisolver.h:176-233), 1 dense block, %d COO triplets from host arrays" % (m * nnz_per),
+            "first_call_s": first[0], "first_call_includes": "fingerprint + 2 GB PCIe upload of the master copy + device gather + solve + "
+            "the backend's check of y (exact lambda_min certificate) - PCIe-inclusive, never `value`",
+            "cached_call_s": tl, "cached_solves_per_sec": 1.0 / tl, "cached_call_includes": "fingerprint of the caller's arrays, device "
+            "gather of the node's block, solve, check of y", "iterations": later[-1][3], "sdpcalls": later[-1][4],
+            "optimal_and_matches_planted_optimum": bool(good)}
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    in_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.gpus < 1:
+        sys.stderr.write("bench.py: --gpus must be >= 1\n")
+        return 2
+    if not in_launcher and args.gpus > 1:
+        return launch_ranks(args, argv)            # parent: no GPU call has been made in this process
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: rank %d: --gpus %d does not match WORLD_SIZE %d of the launcher; refusing to report a line whose "
+                         "n_gpus would not be what was asked for\n" % (rank, args.gpus, world))
+        return 2
+    if args.launch_dry_run:
+        return dry_run_rank(args)
+
     import torch
     dist = None
     if world > 1:
         import torch.distributed as dist
+        if torch.cuda.device_count() <= local_rank:
+            sys.stderr.write("bench.py: rank %d: LOCAL_RANK %d but only %d GPU(s) visible\n" % (rank, local_rank, torch.cuda.device_count()))
+            return 3
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl")
     elif torch.cuda.is_available():
@@ -119,25 +408,31 @@ def main():
     hb = load_binding()
     if hb.device_count() <= 0:
         raise RuntimeError("bench.py needs an MI355X: no HIP device visible and hipsdp has no CPU path")
+    import ctypes as C
+    lib = hb.lib()
     n, m = args.n, args.m
     solver = hb.Solver(local_rank if world > 1 else 0)
     # N > 1: ONE node SDP, its Schur assembly sharded over the ranks (north_star); every rank holds the same instance - or,
     # when the replicated constraint matrices would not fit the device (n=4000, m=8000: 1 TB), only the matrices of its variables
     comm = None
+    rccl_ranks = None
     if world > 1:
-        import ctypes as C
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
             buf = (C.c_ubyte * 128)()
-            assert hb.lib().hipsdp_comm_unique_id(buf) == 0
+            assert lib.hipsdp_comm_unique_id(buf) == 0
             uid = torch.tensor(list(buf), dtype=torch.uint8, device="cuda")
         dist.broadcast(uid, src=0)
         raw = (C.c_ubyte * 128)(*uid.cpu().tolist())
         comm = C.c_void_p()
-        rc = hb.lib().hipsdp_comm_create(raw, rank, world, C.byref(comm))
-        assert rc == 0, "hipsdp_comm_create failed: %s" % hb.lib().hipsdp_last_error().decode()
-        assert hb.lib().hipsdp_set_comm(solver.h, comm, rank, world) == 0
-        assert hb.lib().hipsdp_shard_matrices(solver.h, {"auto": -1, "on": 1, "off": 0}[args.shard_matrices]) == 0
+        rc = lib.hipsdp_comm_create(raw, rank, world, C.byref(comm))
+        assert rc == 0, "hipsdp_comm_create failed: %s" % lib.hipsdp_last_error().decode()
+        cnt, kind = C.c_int(0), C.c_int(-1)
+        assert lib.hipsdp_comm_count(comm, C.byref(cnt), C.byref(kind)) == 0
+        rccl_ranks = int(cnt.value)
+        assert rccl_ranks == world and kind.value == 0, "RCCL reports %d ranks (kind %d), launcher %d" % (rccl_ranks, kind.value, world)
+        assert lib.hipsdp_set_comm(solver.h, comm, rank, world) == 0
+        assert lib.hipsdp_shard_matrices(solver.h, {"auto": -1, "on": 1, "off": 0}[args.shard_matrices]) == 0
     solver.set_shape(m, [n], 0)
     Xs, Zs, ys = planted_pair(n, m, args.seed)
     b = solver.gen_planted(n, m, args.seed, Xs, Zs, ys)
@@ -149,13 +444,14 @@ def main():
         if torch.cuda.is_available():
             torch.cuda.synchronize()
 
-    infos = []
     for _ in range(args.warmup):
         solver.solve(gaptol=1e-5, feastol=1e-5)
+    if comm is not None:
+        lib.hipsdp_comm_stats_enable(comm, 1)
+        lib.hipsdp_comm_stats(comm, None, None, None, 1)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        infos.append(solver.solve(gaptol=1e-5, feastol=1e-5))
+    infos = [solver.solve(gaptol=1e-5, feastol=1e-5) for _ in range(args.steps)]
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -166,10 +462,22 @@ def main():
     last = infos[-1]
     ok = all(i.status == 0 for i in infos) and abs(last.dobj - opt) <= 1e-5 * (1 + abs(opt))
     iters = sum(i.iterations for i in infos)
-    schur_s = sum(i.schur_seconds for i in infos)
-    schur_fl = sum(i.schur_flops for i in infos)
-    schur_calls = sum(i.schur_calls for i in infos)
-    achieved = schur_fl / max(schur_s, 1e-12) / 1e12
+    sharded = bool(lib.hipsdp_matrices_sharded(solver.h))
+    roof = schur_summary(infos, n, m, world)
+    pmc = PMC_FROM_PROFILES.get((n, m)) if world == 1 else None
+    roofline = {"bound": "mfma", "achieved": roof["achieved"], "peak": FP64_MFMA_PEAK_TFLOPS * world, "unit": "TFLOP/s",
+                "frac": roof["frac"],
+                "frac_is": "ALGORITHMIC rate (4 m1 n^3 + m1^2 n^2 per assembly, SURVEY.md 8(d)) / FP64 matrix peak; the kernels execute "
+                           "fewer flops (triangular factors, lower tiles): see executed_tflops / mfma_busy",
+                "traffic": pmc["traffic_bytes_per_assembly"] if pmc else None,
+                "traffic_is": ("quoted from the committed PMC profile, not measured in this run: " + pmc["source"]) if pmc else
+                              "not measured for this size / rank count",
+                "executed_tflops": pmc["executed_tflops"] if pmc else None,
+                "mfma_busy": pmc["mfma_busy"] if pmc else None,
+                "kernel": "hs_dgemm2_kernel (Schur assembly: stack GEMM, batched GEMM, K-sliced Gram GEMM + slice reduce)",
+                "algorithmic_flops_per_assembly": roof["algorithmic_flops_per_assembly"],
+                "avg_assembly_ms": roof["avg_assembly_ms"], "assemblies": roof["assemblies"],
+                "schur_share_of_solve_time": roof["schur_share_of_solve_time"]}
     out = {
         "metric": "node-SDP solves/sec, dense block n x n with m vars (IPM iters/sec in iters_per_sec)",
         "value": args.steps / elapsed,
@@ -183,41 +491,63 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: synthetic single dense block n=%d, m=%d, fp64, planted optimum, cold start, "
-                               "gaptol=feastol=1e-5, A resident in HBM; N > 1: Schur assembly (column slices of W_j = G A_j R, RCCL all-reduce of the partial Schur matrices) and the passes over A (by rows, RCCL all-gather / all-reduce) sharded over the GPUs, everything else replicated" % (n, m),
-                   "parallelism": "schur-shards x%d" % world,
-                   "matrices": "sharded by variable (W_j formed where A_j lives, all-to-all of the W entries, all-reduce of the partial "
-                               "Schur matrices)" if hb.lib().hipsdp_matrices_sharded(solver.h) else "replicated",
+        "config": {"workload": "%s: synthetic single dense block n=%d, m=%d, fp64, planted optimum, cold start, gaptol=feastol=1e-5, "
+                               "A resident in HBM" % (workload_name(n, m), n, m),
+                   "parallelism": "1 GPU" if world == 1 else
+                                  "one node SDP over %d ranks: Schur assembly sharded (%s), passes over A by rows (RCCL all-gather / "
+                                  "all-reduce), everything else replicated" % (world, "W_j formed where A_j lives, all-to-all of the W "
+                                  "entries, all-reduce of the partial Schur matrices" if sharded else "column slices of W_j = G A_j R, "
+                                  "RCCL all-reduce of the partial Schur matrices"),
+                   "matrices": "sharded by variable" if sharded else "replicated",
                    "n": n, "m": m, "seed": args.seed},
         "iters_per_sec": iters / elapsed,
         "iterations_per_solve": iters / max(1, len(infos)),
         "solution_check": {"status_optimal_and_objective_matches_planted_optimum": bool(ok), "objective": last.dobj,
                            "planted_optimum": opt, "pinf": last.pinf, "dabs": last.dabs, "gap": last.gap},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS * world, "unit": "TFLOP/s",
-                     "frac": achieved / (FP64_MFMA_PEAK_TFLOPS * world), "traffic": TRAFFIC_BYTES_PER_ASSEMBLY.get((n, m)),
-                     "kernel": "hs_dgemm2_kernel (Schur assembly: stack GEMM, batched GEMM, K-sliced Gram GEMM + slice reduce)",
-                     "algorithmic_flops_per_assembly": schur_fl / max(1, schur_calls),
-                     "avg_assembly_ms": 1e3 * schur_s / max(1, schur_calls),
-                     "assemblies": schur_calls,
-                     "schur_share_of_solve_time": schur_s / max(1e-12, sum(i.solve_seconds for i in infos))},
+        "roofline": roofline,
     }
+    if comm is not None:
+        sec, calls, byt = (C.c_double * 4)(), (C.c_longlong * 4)(), (C.c_double * 4)()
+        lib.hipsdp_comm_stats(comm, sec, calls, byt, 1)
+        lib.hipsdp_comm_stats_enable(comm, 0)
+        names = ["schur_exchange", "passes_over_A", "decision_scalars", "other"]
+        out["rccl_ranks"] = rccl_ranks
+        out["collectives"] = {"unit": "ms per solve on rank 0 (device time between HIP events around each RCCL call)",
+                              **{names[p]: {"ms_per_solve": 1e3 * sec[p] / args.steps, "calls_per_solve": calls[p] / args.steps,
+                                            "MB_per_solve": byt[p] / args.steps / 1e6} for p in range(4)}}
+    if rank == 0 and world == 1 and not args.no_extras and ok:
+        try:
+            out["phases"] = phase_anatomy(hb, solver)
+        except Exception as e:                                   # the headline number stands on its own
+            out["phases"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(solver, b, n, m, int(round(iters / max(1, len(infos)))))
     elif rank == 0:
         out["cpu_baseline"] = None
+    if rank == 0 and world == 1 and not args.no_extras and ok and (n, m) == (500, 1000):
+        for key, fn in (("warm_start", lambda: bench_warm_start(solver, n, m, b, barrier, last.iterations)),
+                        ("sdpi_boundary", lambda: bench_sdpi_boundary(hb, solver, n, m, b, opt))):
+            try:
+                out[key] = fn()
+            except Exception as e:
+                out[key] = {"error": repr(e)}
     if comm is not None:
-        hb.lib().hipsdp_set_comm(solver.h, None, 0, 1)
+        lib.hipsdp_set_comm(solver.h, None, 0, 1)
     solver.close()
     if comm is not None:
-        hb.lib().hipsdp_comm_destroy(comm)
+        lib.hipsdp_comm_destroy(comm)
+    if rank == 0 and world == 1 and not args.no_extras and ok and (n, m) == (500, 1000):
+        try:
+            out["t1"] = bench_t1(hb, args.seed, barrier)
+        except Exception as e:
+            out["t1"] = {"error": repr(e)}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
-    if not ok:
-        sys.exit(2)
+    return 0 if ok else 2
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

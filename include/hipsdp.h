@@ -53,7 +53,10 @@ typedef struct hipsdp_params
    int    maxiter;
    int    verbose;       /* 1: one line per iteration on stdout (SCIP_SDPPAR_SDPINFO) */
    int    lanczos_steps; /* Lanczos steps per step-length estimate; 0 (default): 24, or 16 when every block has > 64 rows */
-   int    reserved;
+   int    settings;      /* conservativeness of the iteration, the backend's retry ladder (SCIP_SDPSOLVERSETTING, type_sdpi.h:69-77;
+                          * sdpisolver_sdpa.cpp:1415-1449, 1698-1795): 0 fast (default), 1 medium (step fraction <= 0.9, twice the
+                          * Lanczos steps, more patient stall tests, centrality floor 1e-4), 2 stable (step fraction <= 0.75, four
+                          * times the Lanczos steps, even more patient, centrality floor 1e-2) */
    double pabstol;       /* > 0: optimal termination also needs ||b - A(X)||_2 <= pabstol, ABSOLUTE: the caller's own check of
                           * the X-side is absolute (sdpsolchecker.c:775-931 with SCIP_SDPPAR_FEASTOL) while pinf is relative */
    double preoptgap;     /* > 0: the first iterate that is feasible to feastol with relative gap
@@ -79,7 +82,7 @@ typedef struct hipsdp_info
    int    schur_calls;
    int    chol_fail;        /* number of step halvings forced by a failed Cholesky */
    int    warm_started;     /* 1: the point given with hipsdp_set_start was interior and has been used */
-   int    reserved;
+   int    settings_used;    /* the hipsdp_params.settings this solve ran with */
 } hipsdp_info;
 
 const char* hipsdp_last_error(void);
@@ -99,13 +102,15 @@ int  hipsdp_set_obj(hipsdp_solver* solver, const double* b);
  * i = variable i, 1-based) at (row[e], col[e]); both triangles of the dense storage are written.  Host arrays. */
 int  hipsdp_add_entries(hipsdp_solver* solver, int block, long long nnz, const int* var, const int* row, const int* col,
    const double* val);
-/* Master copy (optional, for callers that solve many nodes of one problem): the matrices of ALL nvars variables in ORIGINAL
- * block sizes are uploaded once (COO, var 0-based, lower triangle) and stay in HBM across hipsdp_set_shape calls.  A node's
- * compact block is then filled on the device:  A_engine[a + 1][r][c] = master[activevars[a]][kept[r]][kept[c]]. */
-int  hipsdp_master_define(hipsdp_solver* solver, int nvars, int nblocks, const int* blocksizes);
-int  hipsdp_master_add_entries(hipsdp_solver* solver, int block, long long nnz, const int* var, const int* row, const int* col,
+/* Master copy (optional, for callers that solve many nodes of one problem): the matrices of the variables in ORIGINAL block
+ * sizes are uploaded once (COO, lower triangle) and stay in HBM across hipsdp_set_shape calls.  Block b has nblockvars[b] slots,
+ * one per variable that appears in it (nblockvars == NULL: nvars slots per block); entries name their slot.  A node's compact
+ * block is then filled on the device:  A_engine[a + 1][r][c] = master[slots[a]][kept[r]][kept[c]]  (slots[a] = -1: the
+ * a-th active variable does not appear in the block, zeros).  HIPSDP_ERR_NOMEM from define leaves no master copy behind. */
+int  hipsdp_master_define(hipsdp_solver* solver, int nvars, int nblocks, const int* blocksizes, const int* nblockvars);
+int  hipsdp_master_add_entries(hipsdp_solver* solver, int block, long long nnz, const int* slot, const int* row, const int* col,
    const double* val);
-int  hipsdp_master_gather(hipsdp_solver* solver, int engine_block, int master_block, int nactive, const int* activevars,
+int  hipsdp_master_gather(hipsdp_solver* solver, int engine_block, int master_block, int nactive, const int* slots,
    int nkept, const int* kept);
 /* dense upload of a whole block: A[(m+1) * n * n] host, row-major */
 int  hipsdp_set_block_dense(hipsdp_solver* solver, int block, const double* A);
@@ -134,6 +139,19 @@ int  hipsdp_get_preoptimal_X(hipsdp_solver* solver, int block, double* X);
 /* smallest eigenvalue of  sum_i A_i^k y_i - A_0^k  for every block, on the device (backs the feasibility check of
  * sdpsolchecker.c:201-257 inside the backend); y: m host values; lmin: nblocks host values */
 int  hipsdp_check_y(hipsdp_solver* solver, const double* y, double* lmin, double* lpviol);
+
+/* Several ranks making the same calls (SPMD): *flag becomes rank 0's value on every rank, so that decisions taken from a host
+ * clock (time limits) are the same everywhere and no rank is left alone in a collective.  One rank / no communicator: no-op. */
+int  hipsdp_sync_flag(hipsdp_solver* solver, int* flag);
+
+/* Phase anatomy of the last hipsdp_solve (profiling on): device milliseconds between HIP events recorded at the phase
+ * boundaries of the engine's main stream, summed over the iterations.  phases: 0 residuals + termination read-back,
+ * 1 factorizations of X and Z, 2 Schur assembly, 3 Cholesky of M + the two solves + the tau-elimination pass, 4 predictor,
+ * 5 corrector, 6 update with its Cholesky check.  The same boundaries are roctx ranges (rocprofv3 --marker-trace), always. */
+#define HIPSDP_NPHASES 7
+int  hipsdp_set_profiling(hipsdp_solver* solver, int on);
+int  hipsdp_get_phase_times(hipsdp_solver* solver, double* ms /* [HIPSDP_NPHASES] */);
+const char* hipsdp_phase_name(int phase);
 
 /* Eigenvector cuts for the LP-based mode (replaces the host loop of cons_sdp.c:896-1010 / :1612-1803 for one block): for every
  * eigenvector v of Z(y) = sum_i A_i y_i - A_0 of block `block` with eigenvalue <= -tol (most negative first, at most maxcuts)
@@ -164,6 +182,13 @@ int  hipsdp_shard_columns(int m1, int n, int nranks, int* bounds);
 int  hipsdp_comm_create(const void* unique_id_128bytes, int rank, int nranks, void** comm);
 int  hipsdp_comm_unique_id(void* unique_id_128bytes);
 void hipsdp_comm_destroy(void* comm);
+/* what the transport says about itself: *count = ncclCommCount for RCCL; *kind (may be NULL) 0 RCCL, 1 host-staged, 2 measurement */
+int  hipsdp_comm_count(void* comm, int* count, int* kind);
+/* optional statistics: a HIP event pair around every collective, booked under the phase the engine is in - 0 Schur exchange
+ * (all-reduce / all-gather / all-to-all), 1 passes over A, 2 decision scalars and flags, 3 other.  hipsdp_comm_stats waits for
+ * the recorded events and returns seconds[4], calls[4], bytes[4] since the last reset (any pointer may be NULL). */
+int  hipsdp_comm_stats_enable(void* comm, int on);
+int  hipsdp_comm_stats(void* comm, double* seconds, long long* calls, double* bytes, int reset);
 /* SPMD hosts (N identical processes, one per GPU, making the same calls): the process-wide communicator the environment
  * describes - HIPSDP_WORLD / WORLD_SIZE, HIPSDP_RANK / RANK, and HIPSDP_COMM_FILE=path (RCCL: rank 0 writes the unique id there,
  * the others read it) or HIPSDP_COMM_SHM=/name (host-staged, ranks sharing one device).  *comm = NULL with one rank.  Created at
@@ -209,6 +234,14 @@ int  hipsdp_lambda_min(int device, int n, const double* W, int steps, double* th
 /* lambda_min(L D L^T), n <= 64, L lower triangular, D symmetric: the small-block step-length kernels; theta[2], resid[2] */
 int  hipsdp_lambda_min_scaled(int device, int n, const double* L, const double* D, int steps, double* theta, double* resid);
 int  hipsdp_syev(int device, int n, const double* A, double* lam, double* V);     /* ascending, eigenvectors as rows */
+/* PSD projection chain of the warm-start producer (relax_sdp.c:2715-2766 for Z, :3405-3445 for X), fused on the device: sparse
+ * lower/upper triangle (row, col, val; both triangles are filled) -> eigen-decomposition -> eigenvalues below minev (by more
+ * than epsilon, SCIPisLT) raised to minev -> recombination -> entries with row <= col and |value| > epsilon in row-major order.
+ * mode 0: the reference's literal chain R[i][j] = sum_c V[i][c] lambda_c V[j][c] (V[k][:] = k-th eigenvector; this is what
+ * scaleTransposedMatrix + SCIPlapackMatrixMatrixMult(V, TRUE, S, FALSE) evaluate); mode 1: spectral R = sum_k lambda_k v_k v_k^T.
+ * cap = length of the output arrays; *nnz_out = entries produced (when it exceeds cap: HIPSDP_ERR_ARG, nothing is written). */
+int  hipsdp_psd_project(int device, int n, int nnz, const int* row, const int* col, const double* val, double minev, double epsilon,
+   int mode, int cap, int* nnz_out, int* rowout, int* colout, double* valout);
 int  hipsdp_gemv_n(int device, int R, long long E, const double* A, int nv, const double* V, double* out);
 int  hipsdp_gemv_t(int device, int R, long long E, const double* A, const double* coef, double* out);
 

@@ -48,7 +48,12 @@ class CoreProblem:
 
 
 class Params:
-    def __init__(self, gaptol=1e-5, feastol=1e-5, maxiter=100, gamma=0.98, verbose=False, infeastol=1e-7, pabstol=0.0, preoptgap=0.0):
+    def __init__(self, gaptol=1e-5, feastol=1e-5, maxiter=100, gamma=0.98, verbose=False, infeastol=1e-7, pabstol=0.0, preoptgap=0.0,
+                 settings=0):
+        # retry ladder of the backend (SCIP_SDPSOLVERSETTING, type_sdpi.h:69-77; sdpisolver_sdpa.cpp:1415-1449, 1698-1795):
+        # 0 fast, 1 medium, 2 stable - shorter steps, a higher centrality floor, more patient stall tests (same numbers as
+        # csrc/ipm.hip: solve_impl)
+        self.settings = settings
         self.preoptgap = preoptgap    # > 0: keep the first feasible iterate with relative gap below it (Result.pre)
         self.gaptol = gaptol          # relative gap / absolute gap tolerance (relax_sdp.c:70)
         self.feastol = feastol        # residual tolerance (relax_sdp.c:71)
@@ -189,7 +194,15 @@ def hsd_solve(prob, par=None, start=None):
     else:
         y, X, Z, x, z, tau, kappa = start
 
+    settings = min(2, max(0, int(par.settings)))
+    gamma_eff = par.gamma if settings == 0 else min(par.gamma, 0.9 if settings == 1 else 0.75)
+    stall_lim = (3, 5, 8)[settings]
+    nobest_lim = (6, 10, 15)[settings]
+    sigma_floor = (1e-8, 1e-4, 1e-2)[settings]
+    maxiter = par.maxiter
+
     res = Result()
+    res.settings_used = settings
     res.status = STATUS_ITERLIM
     res.history = []
     res.pre = None
@@ -200,7 +213,7 @@ def hsd_solve(prob, par=None, start=None):
     alpha_last = 1.0
     bestmerit = np.inf
     sincebest = 0
-    for it in range(par.maxiter + 1):
+    for it in range(maxiter + 1):
         # ---- residuals
         AX = sum(Af @ Xk.reshape(-1) for Af, Xk in zip(Aflat, X)) if K else np.zeros(m + 1)
         AX = AX + Dext.T @ x                                     # [<A_0,X> + c^T x ; A(X,x)]
@@ -252,12 +265,12 @@ def hsd_solve(prob, par=None, start=None):
                 break
             if ok_dunb or ok_dinf:
                 certwait += 1
-        if it == par.maxiter:
+        if it == maxiter:
             break
         # stall: mu no longer decreases -> numerical limit reached
         if mu > 0.9 * lastmu and alpha_last < 1e-2:
             nstall += 1
-            if nstall >= 3:
+            if nstall >= stall_lim:
                 res.status = STATUS_NUMERIC
                 break
         else:
@@ -273,7 +286,7 @@ def hsd_solve(prob, par=None, start=None):
                 sincebest = 0
             else:
                 sincebest += 1
-                if sincebest >= 6:
+                if sincebest >= nobest_lim:
                     res.status = STATUS_NUMERIC
                     break
 
@@ -365,7 +378,7 @@ def hsd_solve(prob, par=None, start=None):
             res.status = STATUS_NUMERIC
             break
         aa = min(1.0, steplen(dta, dka, dXa, dZa, dxa, dza))
-        sigma = min(1.0, max(1e-8, (1.0 - aa) ** 3))
+        sigma = min(1.0, max(sigma_floor, (1.0 - aa) ** 3))
         eta = 1.0 - sigma
         # ---- corrector
         E = [dXa[k] @ dZa[k] for k in range(K)]
@@ -374,7 +387,7 @@ def hsd_solve(prob, par=None, start=None):
             res.status = STATUS_NUMERIC
             break
         amax = steplen(dt, dk, dX, dZ, dx, dz)
-        alpha = min(1.0, par.gamma * amax)
+        alpha = min(1.0, gamma_eff * amax)
         alpha_last = alpha
         if not np.isfinite(alpha) or not np.all(np.isfinite(dy)):
             res.status = STATUS_NUMERIC

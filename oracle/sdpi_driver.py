@@ -292,28 +292,94 @@ def sdpi_solve(backend, prob, feastol=1e-6, gaptol=1e-5, penaltyparam=DEFAULT_PE
 # ---- a CPU backend with the same observable interface (numpy IPM of oracle/ipm_ref.py) -----------------------------------
 class OracleBackend:
     """the subset of tests/sdpi_call.SdpiSolver the driver uses, served by ipm_ref.hsd_solve on the problem
-    sdpi_prepare.to_core builds.  Penalty post-processing as sdpisolver_dsdp.c:1655-1734 / sdpisolver_sdpa.cpp:1846-1857."""
+    sdpi_prepare.to_core builds.  Penalty post-processing as sdpisolver_dsdp.c:1655-1734 / sdpisolver_sdpa.cpp:1846-1857.
+    ladder=True additionally restates what sdpisolver_hip.c does around the engine: the settings ladder of the backend
+    (sdpisolver_sdpa.cpp:1415-1449 start settings, :1698-1795 retries: not acceptable and no penalty formulation -> solve again
+    with medium, then stable settings) and, on every rung, the tolerance re-solve loop (sdpisolver_dsdp.c:1527-1606: y checked
+    against feastol with exact eigenvalues as sdpsolchecker.c:201-257, |pobj - dobj| against gaptol; a violation tightens the
+    solver's own tolerance by 0.1 down to 1e-10)."""
 
-    def __init__(self, feastol=1e-6, gaptol=1e-6):
+    UNSOLVED, PENALTY, FAST, MEDIUM, STABLE = -1, 0, 1, 2, 3
+
+    def __init__(self, feastol=1e-6, gaptol=1e-6, ladder=False, solverfeastol=None):
         self.feastol, self.gaptol = feastol, gaptol
+        self.solverfeastol = feastol if solverfeastol is None else solverfeastol
+        self.ladder = ladder
         self.res = None
         self._calls = 0
+        self._iters = 0
+        self.usedsetting = self.UNSOLVED
 
     def set_real(self, par, val):
         if par == PAR_GAPTOL:
             self.gaptol = val
+        elif par == 2:
+            self.feastol = val
+        elif par == 3:
+            self.solverfeastol = val
         return 1
 
-    def solve(self, P, penaltyparam=0.0, withobj=True, rbound=True, timelimit=1e20, clock=None, start=None):
+    def _check_y(self, core, y):
+        """min over blocks of lambda_min(sum_i A_i y_i - A_0), largest LP row violation"""
+        lmin = np.inf
+        for A in core.blocks:
+            Z = np.tensordot(np.concatenate([[-1.0], y]), A, axes=(0, 0))
+            lmin = min(lmin, float(np.linalg.eigvalsh(0.5 * (Z + Z.T))[0]))
+        viol = float(max(0.0, -np.min(core.D @ y - core.c))) if core.q else 0.0
+        return lmin, viol
+
+    def _rung(self, ipm_ref, core, level):
+        feast, gapt = self.solverfeastol, (self.gaptol if self.ladder else min(self.gaptol, 1e-6))
+        pab = self.feastol if self.feastol > feast else 0.0
+        res = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=gapt, feastol=feast, settings=level, pabstol=pab if self.ladder else 0.0))
+        self._calls += 1
+        self._iters += res.iterations
+        while self.ladder and res.status == ipm_ref.STATUS_OPTIMAL and not self.penalty:
+            lmin, viol = self._check_y(core, res.y)
+            infeasible = lmin < -self.feastol or viol > self.feastol
+            again = False
+            if infeasible:
+                feast *= 0.1
+                again = feast >= 1e-10
+            if abs(res.pobj - res.dobj) >= self.gaptol:
+                infeasible = True
+                gapt *= 0.1
+                again = again or gapt >= 1e-10
+            if not again:
+                if infeasible:
+                    res.status = ipm_ref.STATUS_NUMERIC
+                break
+            pab = self.feastol if self.feastol > feast else 0.0
+            res = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=gapt, feastol=feast, settings=level, pabstol=pab))
+            self._calls += 1
+            self._iters += res.iterations
+        return res
+
+    def solve(self, P, penaltyparam=0.0, withobj=True, rbound=True, timelimit=1e20, clock=None, start=None, startsettings=-1):
         import ipm_ref
         b, blocks, D, c, maps = sdpi_prepare.to_core(P, penaltyparam, withobj, rbound)
         self.P, self.maps = P, maps
         self.penalty = penaltyparam > sdpi_prepare.EPS
         self.withobj = withobj
         core = ipm_ref.CoreProblem(b, blocks, D, c)
-        self.res = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=min(self.gaptol, 1e-6), feastol=self.feastol))
-        self._calls = 1
         self.ipm = ipm_ref
+        self._calls = 0
+        self._iters = 0
+        acceptable = (ipm_ref.STATUS_OPTIMAL, ipm_ref.STATUS_DINF, ipm_ref.STATUS_DUNB, ipm_ref.STATUS_PDINF)
+        if not self.ladder:
+            level = 0
+        elif self.penalty or startsettings in (self.STABLE, self.PENALTY):
+            level = 2
+        elif startsettings == self.MEDIUM:
+            level = 1
+        else:
+            level = 0
+        while True:
+            self.res = self._rung(ipm_ref, core, level)
+            self.usedsetting = self.PENALTY if self.penalty else (self.FAST, self.MEDIUM, self.STABLE)[level]
+            if not self.ladder or self.penalty or level >= 2 or self.res.status in acceptable:
+                break
+            level += 1
         feasorig = penaltybound = False
         self.feasorig = False
         if self.penalty and self.res.status == ipm_ref.STATUS_OPTIMAL:
@@ -340,6 +406,9 @@ class OracleBackend:
             "IsPrimalInfeasible": s in (I.STATUS_DUNB, I.STATUS_PDINF),
         }[name]
 
+    def settings_used(self):
+        return self.usedsetting if self.flag("IsAcceptable") else self.UNSOLVED
+
     def _y(self):
         y = np.array(self.P.lb, dtype=np.float64)
         for k, v in enumerate(self.maps["active"]):
@@ -354,8 +423,17 @@ class OracleBackend:
             return float(self.res.dobj)           # the solver's own objective (sdpisolver_dsdp.c:2148-2190)
         return float(self.P.prob.obj @ self._y())
 
+    def max_primal_entry(self):
+        """largest entry of X over the SDP blocks and the LP multipliers (sdpisolver_sdpa.cpp:3090-3125)"""
+        m = 0.0
+        for X in self.res.X:
+            m = max(m, float(np.max(X))) if X.size else m
+        if self.res.x.size:
+            m = max(m, float(np.max(self.res.x)))
+        return m
+
     def iterations(self):
-        return int(self.res.iterations)
+        return int(self._iters)
 
     def sdpcalls(self):
         return self._calls

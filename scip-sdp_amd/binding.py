@@ -15,7 +15,7 @@ STATUS_NAMES = {0: "optimal", 1: "dual_infeasible", 2: "dual_unbounded", 3: "bot
 class Params(C.Structure):
     _fields_ = [("gaptol", C.c_double), ("feastol", C.c_double), ("infeastol", C.c_double), ("objlimit", C.c_double),
                 ("timelimit", C.c_double), ("gamma", C.c_double), ("ws_gbytes", C.c_double), ("maxiter", C.c_int),
-                ("verbose", C.c_int), ("lanczos_steps", C.c_int), ("reserved", C.c_int), ("pabstol", C.c_double), ("preoptgap", C.c_double)]
+                ("verbose", C.c_int), ("lanczos_steps", C.c_int), ("settings", C.c_int), ("pabstol", C.c_double), ("preoptgap", C.c_double)]
 
 
 class Info(C.Structure):
@@ -23,7 +23,7 @@ class Info(C.Structure):
                 ("pinf", C.c_double), ("dinf", C.c_double), ("dabs", C.c_double), ("gap", C.c_double), ("mu", C.c_double),
                 ("tau", C.c_double), ("kappa", C.c_double), ("solve_seconds", C.c_double), ("schur_seconds", C.c_double),
                 ("schur_flops", C.c_double), ("schur_calls", C.c_int), ("chol_fail", C.c_int), ("warm_started", C.c_int),
-                ("reserved", C.c_int)]
+                ("settings_used", C.c_int)]
 
 
 _lib = None
@@ -311,3 +311,18 @@ def gemv_t(A, coef, device=0):
     out = np.zeros(A.shape[1])
     _chk(lib().hipsdp_gemv_t(device, A.shape[0], C.c_longlong(A.shape[1]), _dp(A), _dp(coef), _dp(out)), "hipsdp_gemv_t")
     return out
+
+
+def psd_project(n, row, col, val, minev, epsilon=1e-9, mode=0, device=0):
+    """fused PSD projection chain (hipsdp_psd_project): returns (row, col, val) of the upper triangle, row-major order"""
+    row = np.ascontiguousarray(row, dtype=np.int32)
+    col = np.ascontiguousarray(col, dtype=np.int32)
+    val = _f64(val)
+    cap = n * (n + 1) // 2
+    ro = np.zeros(cap, dtype=np.int32)
+    co = np.zeros(cap, dtype=np.int32)
+    vo = np.zeros(cap)
+    k = C.c_int(0)
+    _chk(lib().hipsdp_psd_project(device, n, len(val), _ip(row), _ip(col), _dp(val), C.c_double(minev), C.c_double(epsilon), mode,
+                                  cap, C.byref(k), _ip(ro), _ip(co), _dp(vo)), "hipsdp_psd_project")
+    return ro[:k.value], co[:k.value], vo[:k.value]

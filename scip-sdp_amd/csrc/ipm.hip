@@ -14,6 +14,7 @@
  */
 #include "hs_kernels.h"
 #include "../../include/hipsdp.h"
+#include <rocprofiler-sdk-roctx/roctx.h>
 #include <vector>
 #include <utility>
 #include <chrono>
@@ -71,6 +72,21 @@ struct Block
    bool derived_valid;   /* n <= 64: LxInv, LzInv (and Zinv for n <= 32) belong to the current X, Z (written by the fused factorization) */
 };
 
+/* phases of an iteration: roctx ranges for rocprofv3 --marker-trace (always) and, with hipsdp_set_profiling, HIP events on the
+ * main stream whose intervals are summed per phase (hipsdp_get_phase_times) */
+enum { PH_RESID = 0, PH_FACTOR, PH_SCHUR, PH_MSOLVE, PH_PRED, PH_CORR, PH_UPDATE, PH_COUNT };
+static const char* const g_phase_names[PH_COUNT] = {"residuals", "factorizations", "schur", "chol_M_solves", "predictor", "corrector",
+   "update"};
+
+struct PhaseClock
+{
+   bool on;
+   int open;                                          /* phase whose roctx range is open, or -1 */
+   std::vector<hipEvent_t> pool;
+   std::vector<std::pair<int, hipEvent_t> > marks;
+   double ms[PH_COUNT];
+};
+
 struct hipsdp_solver
 {
    int device;
@@ -120,6 +136,7 @@ struct hipsdp_solver
    /* device-resident master copy of the constraint matrices in ORIGINAL indices (survives set_shape) */
    int master_nvars;
    std::vector<int> master_sizes;
+   std::vector<int> master_slots;         /* per master block: number of variable slots */
    std::vector<double*> master_A;
    /* multi GPU */
    void* comm; int rank, nranks;
@@ -130,7 +147,71 @@ struct hipsdp_solver
    bool shardA;            /* decided by set_shape: this problem's constraint matrices are sharded by variable */
    int a_r0, a_r1;         /* rows of A (0 = constant matrix, i = variable i) this rank holds; [0, m + 1) when replicated */
    hipsdp_params par;
+   PhaseClock pc;
 };
+
+void hs_comm_phase(int phase);      /* multi.hip: the phase the next collectives are booked under */
+
+static void phase_mark(hipsdp_solver* s, int ph)
+{
+   if ( s->pc.open >= 0 )
+      (void) roctxRangePop();
+   s->pc.open = ph;
+   if ( ph >= 0 )
+      (void) roctxRangePushA(g_phase_names[ph]);
+   if ( !s->pc.on )
+      return;
+   hipEvent_t e = NULL;
+   if ( !s->pc.pool.empty() )
+   {
+      e = s->pc.pool.back();
+      s->pc.pool.pop_back();
+   }
+   else if ( hipEventCreate(&e) != hipSuccess )
+      return;
+   if ( hipEventRecord(e, s->stream) == hipSuccess )
+      s->pc.marks.push_back(std::make_pair(ph, e));
+   else
+      s->pc.pool.push_back(e);
+}
+
+/* with profiling on: turns the recorded marks (the last one being the closing phase_mark(s, -1)) into per-phase sums; the
+ * stream must be idle */
+static void phase_finish(hipsdp_solver* s)
+{
+   for (size_t i = 0; i + 1 < s->pc.marks.size(); ++i)
+   {
+      float ms = 0.f;
+      const int ph = s->pc.marks[i].first;
+      if ( ph >= 0 && hipEventElapsedTime(&ms, s->pc.marks[i].second, s->pc.marks[i + 1].second) == hipSuccess )
+         s->pc.ms[ph] += (double) ms;
+   }
+   for (auto& mk : s->pc.marks)
+      s->pc.pool.push_back(mk.second);
+   s->pc.marks.clear();
+}
+
+extern "C" const char* hipsdp_phase_name(int phase)
+{
+   return phase >= 0 && phase < PH_COUNT ? g_phase_names[phase] : "";
+}
+
+extern "C" int hipsdp_set_profiling(hipsdp_solver* s, int on)
+{
+   if ( s == NULL )
+      return HIPSDP_ERR_ARG;
+   s->pc.on = on != 0;
+   return HIPSDP_OK;
+}
+
+extern "C" int hipsdp_get_phase_times(hipsdp_solver* s, double* ms)
+{
+   if ( s == NULL || ms == NULL )
+      return HIPSDP_ERR_ARG;
+   for (int p = 0; p < PH_COUNT; ++p)
+      ms[p] = s->pc.ms[p];
+   return HIPSDP_OK;
+}
 
 static thread_local char g_err[512] = "";
 static int g_live_solvers = 0;      /* handles alive in this process: the device memory pool is trimmed when the last one goes */
@@ -166,7 +247,7 @@ extern "C" void hipsdp_default_params(hipsdp_params* p)
    p->maxiter = 100;
    p->verbose = 0;
    p->lanczos_steps = 0;        /* by block size: 24, or 16 when every block has more than 64 rows */
-   p->reserved = 0;
+   p->settings = 0;
    p->pabstol = 0.0;
    p->preoptgap = 0.0;
 }
@@ -259,6 +340,9 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
    s->trsv_epoch = 0;
    s->last_status = HIPSDP_STATUS_UNSOLVED;
    s->sol_scale = 1.0;
+   s->pc.on = getenv("HIPSDP_PHASES") != NULL && atoi(getenv("HIPSDP_PHASES")) != 0;
+   s->pc.open = -1;
+   for (int p = 0; p < PH_COUNT; ++p) s->pc.ms[p] = 0.0;
    s->b = s->Dext = s->y = s->x = s->z = s->yt = s->dyt = s->wt = s->AX = s->AH = s->tmpe = s->rp = s->rd = s->tmpq = s->hl = NULL;
    s->beta = s->elp = s->dxa = s->dza = s->dx = s->dz = s->xs = s->zs = s->ys = s->u1 = s->rhs2 = s->u2 = s->dy = s->dya = NULL;
    s->Mx = s->Lm = s->dinvm = s->Slp = s->sc = s->red_ws = s->gemv_ws = s->lan_ws = s->lan_ws2 = s->gws1 = s->gws2 = NULL;
@@ -283,6 +367,7 @@ static void master_free(hipsdp_solver* s)
    for (double* p : s->master_A) dfree(p);
    s->master_A.clear();
    s->master_sizes.clear();
+   s->master_slots.clear();
    s->master_nvars = 0;
 }
 
@@ -297,6 +382,8 @@ extern "C" void hipsdp_free(hipsdp_solver** ps)
    master_free(s);
    if ( s->hsc != NULL ) (void) hipHostFree(s->hsc);
    s->hsc = NULL;
+   for (auto& mk : s->pc.marks) (void) hipEventDestroy(mk.second);
+   for (hipEvent_t e : s->pc.pool) (void) hipEventDestroy(e);
    (void) hipStreamSynchronize(s->stream2);
    (void) hipEventDestroy(s->ev0);
    (void) hipEventDestroy(s->ev1);
@@ -317,6 +404,34 @@ extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int*
       return HIPSDP_ERR_ARG;
    HS_HIP( hipSetDevice(s->device) );
    HS_HIP( hipStreamSynchronize(s->stream) );
+   /* The same shape again (the next node of a tree with the same fixings pattern, a re-load of the same problem): every
+    * allocation is kept - the constraint matrices (GBs at the bench sizes), their packed copy and the Schur workspace cost tens
+    * of milliseconds to free and allocate again - and only the contents are reset to what a fresh shape has. */
+   if ( s->shaped && s->m == m && s->q == q && (int) s->blk.size() == nblocks && !s->shardA && s->shardA_req == 0
+      && getenv("HIPSDP_NO_SHAPE_REUSE") == NULL )
+   {
+      bool same = true;
+      for (int k = 0; k < nblocks; ++k)
+         if ( s->blk[k].n != blocksizes[k] )
+            same = false;
+      if ( same )
+      {
+         const long long m1s = (long long) m + 1;
+         for (auto& B : s->blk)
+         {
+            HS_HIP( hipMemsetAsync(B.Aown, 0, (size_t) (m1s * B.n * B.n) * sizeof(double), s->stream) );
+            B.apk_valid = false;
+            B.derived_valid = false;
+         }
+         HS_HIP( hipMemsetAsync(s->Dext, 0, (size_t) ((long long) q * m1s > 0 ? (long long) q * m1s : 1) * sizeof(double), s->stream) );
+         HS_HIP( hipMemsetAsync(s->b, 0, (size_t) (m > 0 ? m : 1) * sizeof(double), s->stream) );
+         HS_HIP( hipStreamSynchronize(s->stream) );
+         s->have_start = false;
+         s->solved = false;
+         s->pre_valid = false;
+         return HIPSDP_OK;
+      }
+   }
    free_problem(s);
    s->m = m;
    s->q = q;
@@ -495,7 +610,7 @@ extern "C" int hipsdp_add_entries(hipsdp_solver* s, int block, long long nnz, co
 /* ---- master copy: the matrices A_v of ALL variables in original indices, uploaded once and kept across node solves.  A
  * node's compact block (active variables, kept rows/columns) is then gathered on the device (the
  * sdprow/sdpcol/sdpval arrays do not change between the nodes of a branch-and-bound run). */
-extern "C" int hipsdp_master_define(hipsdp_solver* s, int nvars, int nblocks, const int* blocksizes)
+extern "C" int hipsdp_master_define(hipsdp_solver* s, int nvars, int nblocks, const int* blocksizes, const int* nblockvars)
 {
    if ( s == NULL || nvars < 0 || nblocks < 0 )
       return HIPSDP_ERR_ARG;
@@ -508,11 +623,21 @@ extern "C" int hipsdp_master_define(hipsdp_solver* s, int nvars, int nblocks, co
       if ( blocksizes[b] <= 0 )
          return HIPSDP_ERR_ARG;
       double* p = NULL;
-      const long long cnt = (long long) nvars * blocksizes[b] * blocksizes[b];
-      HS_CALL( dalloc(&p, cnt) );
+      /* one slot per variable that appears in the block (nblockvars == NULL: one per variable) */
+      const int slots = nblockvars != NULL ? nblockvars[b] : nvars;
+      if ( slots < 0 || slots > nvars )
+         return HIPSDP_ERR_ARG;
+      const long long cnt = (long long) slots * blocksizes[b] * blocksizes[b];
+      const int rc = dalloc(&p, cnt);
+      if ( rc != HS_OK )
+      {
+         master_free(s);           /* the caller falls back to loading the node's block directly */
+         return rc;
+      }
       HS_HIP( hipMemsetAsync(p, 0, (size_t) (cnt > 0 ? cnt : 1) * sizeof(double), s->stream) );
       s->master_A.push_back(p);
       s->master_sizes.push_back(blocksizes[b]);
+      s->master_slots.push_back(slots);
    }
    HS_HIP( hipStreamSynchronize(s->stream) );
    return HIPSDP_OK;
@@ -528,7 +653,7 @@ extern "C" int hipsdp_master_add_entries(hipsdp_solver* s, int block, long long 
    HS_HIP( hipSetDevice(s->device) );
    const int n = s->master_sizes[block];
    for (long long e = 0; e < nnz; ++e)
-      if ( var[e] < 0 || var[e] >= s->master_nvars || row[e] < 0 || row[e] >= n || col[e] < 0 || col[e] >= n )
+      if ( var[e] < 0 || var[e] >= s->master_slots[block] || row[e] < 0 || row[e] >= n || col[e] < 0 || col[e] >= n )
       {
          set_err("hipsdp_master_add_entries: index out of range");
          return HIPSDP_ERR_ARG;
@@ -548,7 +673,7 @@ extern "C" int hipsdp_master_add_entries(hipsdp_solver* s, int block, long long 
    return HIPSDP_OK;
 }
 
-/* A_engine[a + 1][r'][c'] = master[activevars[a]][kept[r']][kept[c']] */
+/* A_engine[a + 1][r'][c'] = master[slot[a]][kept[r']][kept[c']], zero for slot[a] = -1 (variable absent from the block) */
 __global__ void k_master_gather(int nactive, int nk, int N, const int* __restrict__ act, const int* __restrict__ kept,
    const double* __restrict__ master, double* __restrict__ A)
 {
@@ -559,7 +684,7 @@ __global__ void k_master_gather(int nactive, int nk, int N, const int* __restric
       const long long a = e / nk2;
       const long long rc = e - a * nk2;
       const int r = (int) (rc / nk), c = (int) (rc - (long long) r * nk);
-      A[(a + 1) * nk2 + rc] = master[((long long) act[a] * N + kept[r]) * N + kept[c]];
+      A[(a + 1) * nk2 + rc] = act[a] >= 0 ? master[((long long) act[a] * N + kept[r]) * N + kept[c]] : 0.0;
    }
 }
 
@@ -579,7 +704,7 @@ extern "C" int hipsdp_master_gather(hipsdp_solver* s, int engine_block, int mast
    HS_HIP( hipSetDevice(s->device) );
    const int N = s->master_sizes[master_block];
    for (int a = 0; a < nactive; ++a)
-      if ( activevars[a] < 0 || activevars[a] >= s->master_nvars )
+      if ( activevars[a] < -1 || activevars[a] >= s->master_slots[master_block] )
          return HIPSDP_ERR_ARG;
    for (int r = 0; r < nkept; ++r)
       if ( kept[r] < 0 || kept[r] >= N )
@@ -1128,7 +1253,10 @@ static int pass_A(hipsdp_solver* s, Block& B, const double* V, double* out)
          const long long n2 = (long long) B.n * B.n;
          HS_CALL( hs_gemv_n(s->stream, r1 - r0, n2, B.A + (long long) r0 * n2, n2, 1, &V, mine, r1 - r0, s->gemv_ws, s->gemv_ws_len) );
       }
-      HS_CALL( hs_allgather_inplace(s->comm, s->passg, c, s->rank, s->stream) );
+      hs_comm_phase(1);
+      const int rcg = hs_allgather_inplace(s->comm, s->passg, c, s->rank, s->stream);
+      hs_comm_phase(2);
+      HS_CALL( rcg );
       return hs_copy(s->stream, out, s->passg, m1);
    }
    if ( B.Apk != NULL )
@@ -1152,13 +1280,19 @@ static int pass_AT(hipsdp_solver* s, Block& B, const double* coef, double sa, co
       if ( B.Apk != NULL )
       {
          HS_CALL( hs_gemv_t(s->stream, r1 - r0, B.Lp, B.Apk + (long long) r0 * B.Lp, B.Lp, coef + r0, 0.0, NULL, B.pkv + B.Lp) );
-         HS_CALL( hs_allreduce_sum(s->comm, B.pkv + B.Lp, B.Lp, s->stream) );
+         hs_comm_phase(1);
+         const int rcr = hs_allreduce_sum(s->comm, B.pkv + B.Lp, B.Lp, s->stream);
+         hs_comm_phase(2);
+         HS_CALL( rcr );
          return hs_unpack_sym(s->stream, B.n, B.pkv + B.Lp, sa, add, out);
       }
       /* the additive term enters once: on rank 0 */
       HS_CALL( hs_gemv_t(s->stream, r1 - r0, n2, B.A + (long long) r0 * n2, n2, coef + r0, s->rank == 0 ? sa : 0.0,
             s->rank == 0 ? add : NULL, out) );
-      return hs_allreduce_sum(s->comm, out, n2, s->stream);
+      hs_comm_phase(1);
+      const int rcr = hs_allreduce_sum(s->comm, out, n2, s->stream);
+      hs_comm_phase(2);
+      return rcr;
    }
    if ( B.Apk != NULL )
    {
@@ -1554,6 +1688,12 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       CommOff off(s, alone);
       rc = solve_impl(s, params, info);
    }
+   if ( s->pc.open >= 0 )          /* an error return inside the iteration: close the roctx range, drop the marks */
+   {
+      phase_mark(s, -1);
+      (void) hipStreamSynchronize(s->stream);
+      phase_finish(s);
+   }
    if ( alone )
       rc = sync_outcome(s, rc, info);
    return rc;
@@ -1572,6 +1712,8 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
    HS_HIP( hipSetDevice(s->device) );
    if ( params != NULL )
       s->par = *params;
+   else
+      hipsdp_default_params(&s->par);
    {
       const char* env = getenv("HIPSDP_LANCZOS");
       if ( env != NULL && atoi(env) > 0 )
@@ -1586,10 +1728,24 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
          for (auto& B : s->blk) if ( B.n < nmin ) nmin = B.n;
          s->par.lanczos_steps = (!s->blk.empty() && nmin > 64) ? 16 : 24;
       }
+      if ( s->par.settings < 0 ) s->par.settings = 0;
+      if ( s->par.settings > 2 ) s->par.settings = 2;
+      s->par.lanczos_steps <<= s->par.settings;          /* medium: twice, stable: four times the Lanczos steps */
       if ( s->par.lanczos_steps < 4 ) s->par.lanczos_steps = 4;
       if ( s->par.lanczos_steps > 250 ) s->par.lanczos_steps = 250;
    }
    const hipsdp_params& par = s->par;
+   /* the retry ladder of the backend (sdpisolver_sdpa.cpp:1415-1449: fast / default / stable parameter sets): more conservative
+    * settings take shorter steps, keep the iterates more central and wait longer before they call a stall (oracle/ipm_ref.py:
+    * Params.settings, same numbers) */
+   const int settings = par.settings;
+   const double gamma_eff = settings == 0 ? par.gamma : fmin(par.gamma, settings == 1 ? 0.9 : 0.75);
+   const int stall_lim = settings == 0 ? 3 : (settings == 1 ? 5 : 8);
+   const int nobest_lim = settings == 0 ? 6 : (settings == 1 ? 10 : 15);
+   const double sigma_floor = settings == 0 ? 1e-8 : (settings == 1 ? 1e-4 : 1e-2);
+   const int maxiter = par.maxiter;
+   hs_comm_phase(2);
+   for (int p = 0; p < PH_COUNT; ++p) s->pc.ms[p] = 0.0;
    const int m = s->m, m1 = s->m + 1, q = s->q;
    const int K = (int) s->blk.size();
    hipStream_t st = s->stream;
@@ -1778,10 +1934,11 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
     * result itself and the flags need no clearing */
    const int setf = (small_all && s->blk.size() == 1) ? 1 : 0;
 
-   for (it = 0; it <= par.maxiter; ++it)
+   for (it = 0; it <= maxiter; ++it)
    {
       if ( !residuals_ready )
       {
+         phase_mark(s, PH_RESID);
          HS_CALL( enqueue_residuals() );
          HS_CALL( read_scalars(s, hs, NULL) );
       }
@@ -1875,11 +2032,11 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
          continue;
       }
       want_cert = certzone;
-      if ( it == par.maxiter )
+      if ( it == maxiter )
          break;
       if ( mu > 0.9 * lastmu && alpha_last < 1e-2 )
       {
-         if ( ++nstall >= 3 )
+         if ( ++nstall >= stall_lim )
          {
             status = HIPSDP_STATUS_NUMERIC;
             break;
@@ -1899,7 +2056,7 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
             bestmerit = merit;
             sincebest = 0;
          }
-         else if ( ++sincebest >= 6 )
+         else if ( ++sincebest >= nobest_lim )
          {
             status = HIPSDP_STATUS_NUMERIC;
             break;
@@ -1925,6 +2082,7 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       }
 
       /* ---- factorizations (the factors of an accepted step are re-used: they were computed by its Cholesky check) */
+      phase_mark(s, PH_FACTOR);
       if ( !(setf && m <= 64) )
          HS_HIP( hipMemsetAsync(s->flags, 0, 8 * sizeof(int), st) );
       HS_CALL( fork2(s) );
@@ -1971,6 +2129,8 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       HS_CALL( join2(s) );
 
       /* ---- Schur complement (extended by the constant matrix as "variable 0") */
+      phase_mark(s, PH_SCHUR);
+      hs_comm_phase(0);
       HS_HIP( hipEventRecord(s->ev0, st) );
       bool schur_small = false;
       if ( s->comm == NULL && !s->shardA && !s->schur_mode_rows && !s->schur_mode_forced && K > 0 )
@@ -2066,6 +2226,8 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       HS_CALL( hs_mirror_lower(st, s->Mx, m1, m1) );
       }
       HS_HIP( hipEventRecord(s->ev1, st) );
+      hs_comm_phase(2);
+      phase_mark(s, PH_MSOLVE);
       if ( m > 0 )
       {
          if ( !schur_small )
@@ -2116,6 +2278,7 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       HS_CALL( hs_red_batch_end() );
 
       /* ---- predictor */
+      phase_mark(s, PH_PRED);
       HS_CALL( direction(s, 0.0, 1.0, mu, rg, false, 0.0) );
       HS_CALL( steplen_enqueue(s) );
       HS_CALL( read_scalars(s, hs, hflags) );
@@ -2144,8 +2307,9 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
          break;
       }
       double sigma = (1.0 - aa) * (1.0 - aa) * (1.0 - aa);
-      sigma = fmin(1.0, fmax(1e-8, sigma));
+      sigma = fmin(1.0, fmax(sigma_floor, sigma));
       const double eta = 1.0 - sigma;
+      phase_mark(s, PH_CORR);
       /* second-order terms from the predictor */
       for (auto& B : s->blk)
       {
@@ -2161,7 +2325,7 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       HS_CALL( steplen_enqueue(s) );
       HS_CALL( read_scalars(s, hs, NULL) );
       const double amax = steplen_host(s, hs);
-      double alpha = fmin(1.0, par.gamma * amax);
+      double alpha = fmin(1.0, gamma_eff * amax);
       const double dt = hs.v[SC_DTAU], dk = hs.v[SC_DKAPPA];
       if ( !std::isfinite(alpha) || !std::isfinite(dt) || !std::isfinite(dk) )
       {
@@ -2172,6 +2336,7 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       }
 
       /* ---- update, with a Cholesky check of the new X and Z (the Lanczos bound is an estimate) */
+      phase_mark(s, PH_UPDATE);
       for (auto& B : s->blk)
       {
          const long long n2 = (long long) B.n * B.n;
@@ -2313,7 +2478,9 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       }
    }
 
+   phase_mark(s, -1);
    HS_HIP( hipStreamSynchronize(st) );
+   phase_finish(s);
    s->last_status = status;
    s->solved = true;
    if ( status == HIPSDP_STATUS_DINF || status == HIPSDP_STATUS_DUNB || status == HIPSDP_STATUS_PDINF )
@@ -2331,6 +2498,7 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
    info->mu = mu;
    info->tau = s->tau;
    info->kappa = s->kappa;
+   info->settings_used = settings;
    info->schur_seconds = schur_ms * 1e-3;
    info->solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
    return HIPSDP_OK;
@@ -2391,6 +2559,35 @@ extern "C" int hipsdp_get_preoptimal_X(hipsdp_solver* s, int block, double* X)
    return read_scaled(s, s->blk[block].Xpre, (long long) s->blk[block].n * s->blk[block].n, s->pre_scale, X);
 }
 
+/* A[i][i] += v */
+__global__ void k_shift_diag(int n, double* __restrict__ A, double v)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if ( i < n )
+      A[(long long) i * n + i] += v;
+}
+
+/* SPMD: rank 0's flag everywhere (no-op for one rank) */
+extern "C" int hipsdp_sync_flag(hipsdp_solver* s, int* flag)
+{
+   if ( s == NULL || flag == NULL )
+      return HIPSDP_ERR_ARG;
+   if ( s->comm == NULL || s->nranks < 2 )
+      return HIPSDP_OK;
+   HS_HIP( hipSetDevice(s->device) );
+   int* d = NULL;
+   HS_CALL( dalloc(&d, 1) );
+   int rc = HS_OK;
+   if ( hipMemcpyAsync(d, flag, sizeof(int), hipMemcpyHostToDevice, s->stream) != hipSuccess ) rc = HS_ERR_HIP;
+   hs_comm_phase(2);
+   if ( rc == HS_OK ) rc = hs_bcast_ints(s->comm, d, 1, s->stream);
+   if ( rc == HS_OK && (hipMemcpyAsync(flag, d, sizeof(int), hipMemcpyDeviceToHost, s->stream) != hipSuccess
+         || hipStreamSynchronize(s->stream) != hipSuccess) )
+      rc = HS_ERR_HIP;
+   dfree(d);
+   return rc;
+}
+
 extern "C" int hipsdp_check_y(hipsdp_solver* s, const double* y, double* lmin, double* lpviol)
 {
    if ( s == NULL || !s->shaped ) return HIPSDP_ERR_ARG;
@@ -2425,6 +2622,47 @@ extern "C" int hipsdp_check_y(hipsdp_solver* s, const double* y, double* lmin, d
    HS_CALL( read_scalars(s, h, NULL) );
    for (size_t b = 0; b < s->blk.size(); ++b)
       lmin[b] = h.v[SC_BLK(b, 1)] - h.v[SC_BLK(b, 2)];
+   /* The reference accepts a solution on an EXACT eigenvalue (sdpsolchecker.c:201-257).  A Ritz value is an upper bound of
+    * lambda_min and "theta - resid" only says that SOME eigenvalue lies that close to theta; once the Krylov space cannot span
+    * the matrix (n above the 250 steps) an unconverged smaller eigenvalue would go unnoticed - and at an optimum Z(y) has a
+    * cluster at 0, the slow case.  So the bound is certified: a Cholesky factorization of W - sigma I with sigma just below the
+    * estimate succeeds only if lambda_min > sigma (then sigma is returned, a rigorous lower bound); if it fails the exact
+    * Jacobi eigenvalue is computed. */
+   for (size_t b = 0; b < s->blk.size(); ++b)
+   {
+      Block& B = s->blk[b];
+      const int n = B.n;
+      if ( n <= 200 )
+         continue;
+      const long long n2 = (long long) n * n;
+      const double theta = h.v[SC_BLK(b, 1)];
+      const double sigma = lmin[b] - 1e-9 * (1.0 + fabs(theta));
+      int fl = 0;
+      HS_CALL( hs_copy(st, B.T1, B.W, n2) );
+      hipLaunchKernelGGL(k_shift_diag, g1d(n), dim3(256), 0, st, n, B.T1, -sigma);
+      HS_LAUNCH_CHECK();
+      HS_HIP( hipMemsetAsync(s->flags + 5, 0, sizeof(int), st) );
+      HS_CALL( hs_potrf(st, n, B.T1, B.dinvx, s->flags + 5, NULL) );
+      HS_HIP( hipMemcpyAsync(&fl, s->flags + 5, sizeof(int), hipMemcpyDeviceToHost, st) );
+      HS_HIP( hipStreamSynchronize(st) );
+      if ( fl == 0 && std::isfinite(sigma) )
+      {
+         lmin[b] = sigma;
+         continue;
+      }
+      double *lam = NULL, *V = NULL, *ws = NULL;
+      double l0 = 0.0;
+      int rc = dalloc(&lam, n);
+      if ( rc == HS_OK ) rc = dalloc(&V, n2);
+      if ( rc == HS_OK ) rc = dalloc(&ws, hs_syev_ws(n));
+      if ( rc == HS_OK ) rc = hs_syev_jacobi(st, n, B.W, lam, V, NULL, ws);
+      if ( rc == HS_OK && (hipMemcpyAsync(&l0, lam, sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess
+            || hipStreamSynchronize(st) != hipSuccess) )
+         rc = HS_ERR_HIP;
+      dfree(lam); dfree(V); dfree(ws);
+      HS_CALL( rc );
+      lmin[b] = l0;
+   }
    if ( lpviol != NULL )
       *lpviol = q > 0 ? fmax(0.0, -h.v[SC_RATX]) : 0.0;
    return HIPSDP_OK;

@@ -14,7 +14,9 @@
 #include <chrono>
 #include <cstring>
 #include <cstdio>
+#include <ctime>
 #include <new>
+#include <vector>
 #include <fcntl.h>
 #include <sched.h>
 #include <sys/mman.h>
@@ -28,16 +30,31 @@ struct shm_header
    std::atomic<int> arrived;
    std::atomic<int> generation;
    std::atomic<int> failed;
-   int pad[13];
+   int pad0;
+   std::atomic<unsigned long long> ready;    /* magic ^ job nonce once rank 0 has initialised the header */
+   long long created_ns;                     /* CLOCK_REALTIME at creation: leftovers older than the join timeout are ignored */
+   int pad[8];
 };
+static_assert(sizeof(shm_header) == 64, "shm_header is one cache line");
+
+#define HS_COMM_PHASES 4      /* 0 Schur exchange, 1 passes over A, 2 decision scalars / flags, 3 other */
+
+struct comm_rec { int phase; hipEvent_t a, b; hipStream_t st; };
 
 struct hs_comm
 {
-   int kind;               /* 0 = RCCL, 1 = host-staged */
+   int kind;               /* 0 = RCCL, 1 = host-staged, 2 = measurement transport */
    int rank, nranks;
    ncclComm_t nccl;
+   /* optional statistics (hipsdp_comm_stats_enable): an event pair around every collective, resolved when the numbers are read */
+   bool stats;
+   std::vector<comm_rec> recs;
+   std::vector<hipEvent_t> evpool;
+   double sec[HS_COMM_PHASES];
+   long long calls[HS_COMM_PHASES];
+   double bytes[HS_COMM_PHASES];
    /* host-staged */
-   char name[96];
+   char name[128];
    shm_header* hdr;
    char* data;
    size_t data_bytes;
@@ -173,7 +190,106 @@ __global__ void k_sum_parts(long long count, int nparts, const double* __restric
    }
 }
 
+thread_local int g_comm_phase = 3;
+
+hipEvent_t stats_event(hs_comm* c)
+{
+   hipEvent_t e = NULL;
+   if ( !c->evpool.empty() )
+   {
+      e = c->evpool.back();
+      c->evpool.pop_back();
+   }
+   else if ( hipEventCreate(&e) != hipSuccess )
+      e = NULL;
+   return e;
+}
+
+/* brackets one collective with an event pair on its stream when statistics are on */
+struct CollTimer
+{
+   hs_comm* c; comm_rec r; bool on;
+   CollTimer(hs_comm* c_, hipStream_t st, double nbytes) : c(c_), on(false)
+   {
+      if ( c == NULL || !c->stats )
+         return;
+      const int ph = g_comm_phase >= 0 && g_comm_phase < HS_COMM_PHASES ? g_comm_phase : HS_COMM_PHASES - 1;
+      c->calls[ph]++;
+      c->bytes[ph] += nbytes;
+      r.phase = ph; r.st = st;
+      r.a = stats_event(c); r.b = stats_event(c);
+      if ( r.a == NULL || r.b == NULL )
+         return;
+      on = hipEventRecord(r.a, st) == hipSuccess;
+   }
+   ~CollTimer()
+   {
+      if ( on && hipEventRecord(r.b, r.st) == hipSuccess )
+         c->recs.push_back(r);
+   }
+};
+
 } /* namespace */
+
+/* the phase the next collectives of this thread are booked under (0 Schur exchange, 1 passes over A, 2 decision scalars) */
+void hs_comm_phase(int phase) { g_comm_phase = phase; }
+
+extern "C" int hipsdp_comm_stats_enable(void* comm, int on)
+{
+   hs_comm* c = (hs_comm*) comm;
+   if ( c == NULL )
+      return HIPSDP_ERR_ARG;
+   c->stats = on != 0;
+   return HIPSDP_OK;
+}
+
+/* seconds[4], calls[4], bytes[4] by phase since the last reset (device time between the event pairs; waits for the streams) */
+extern "C" int hipsdp_comm_stats(void* comm, double* seconds, long long* calls, double* bytes, int reset)
+{
+   hs_comm* c = (hs_comm*) comm;
+   if ( c == NULL )
+      return HIPSDP_ERR_ARG;
+   for (auto& r : c->recs)
+   {
+      float ms = 0.f;
+      if ( hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess )
+         c->sec[r.phase] += 1e-3 * (double) ms;
+      c->evpool.push_back(r.a);
+      c->evpool.push_back(r.b);
+   }
+   c->recs.clear();
+   for (int p = 0; p < HS_COMM_PHASES; ++p)
+   {
+      if ( seconds != NULL ) seconds[p] = c->sec[p];
+      if ( calls != NULL ) calls[p] = c->calls[p];
+      if ( bytes != NULL ) bytes[p] = c->bytes[p];
+      if ( reset )
+      {
+         c->sec[p] = 0.0; c->calls[p] = 0; c->bytes[p] = 0.0;
+      }
+   }
+   return HIPSDP_OK;
+}
+
+/* what the transport itself says about the communicator: *count = ncclCommCount for RCCL (the number of ranks RCCL joined),
+ * the configured number otherwise; *kind = 0 RCCL, 1 host-staged, 2 measurement transport */
+extern "C" int hipsdp_comm_count(void* comm, int* count, int* kind)
+{
+   hs_comm* c = (hs_comm*) comm;
+   if ( c == NULL || count == NULL )
+      return HIPSDP_ERR_ARG;
+   *count = c->nranks;
+   if ( kind != NULL )
+      *kind = c->kind;
+   if ( c->kind == 0 )
+   {
+      int n = 0;
+      if ( ncclCommCount(c->nccl, &n) != ncclSuccess )
+         return HIPSDP_ERR_HIP;
+      *count = n;
+   }
+   return HIPSDP_OK;
+}
 
 extern "C" int hipsdp_comm_unique_id(void* unique_id_128bytes)
 {
@@ -204,10 +320,39 @@ extern "C" int hipsdp_comm_create(const void* unique_id_128bytes, int rank, int 
    return HIPSDP_OK;
 }
 
+/* job nonce: what distinguishes this launch from an earlier (possibly crashed) one that used the same rendezvous name -
+ * HIPSDP_JOB_ID, else the launcher's run id / rendezvous port (torchrun sets TORCHELASTIC_RUN_ID and MASTER_PORT); 0 = unknown */
+static unsigned long long job_nonce(void)
+{
+   const char* keys[] = {"HIPSDP_JOB_ID", "TORCHELASTIC_RUN_ID", "MASTER_PORT"};
+   unsigned long long h = 0;
+   for (const char* k : keys)
+   {
+      const char* v = getenv(k);
+      if ( v == NULL || v[0] == 0 )
+         continue;
+      h = 1469598103934665603ULL;
+      for (const char* p = v; *p; ++p) h = (h ^ (unsigned char) *p) * 1099511628211ULL;
+      for (const char* p = k; *p; ++p) h = (h ^ (unsigned char) *p) * 1099511628211ULL;
+      if ( h == 0 ) h = 1;
+      break;
+   }
+   return h;
+}
+
+#define SHM_READY_MAGIC 0x68697073647001ULL
+
+static long long realtime_ns(void)
+{
+   struct timespec ts;
+   clock_gettime(CLOCK_REALTIME, &ts);
+   return (long long) ts.tv_sec * 1000000000LL + ts.tv_nsec;
+}
+
 extern "C" int hipsdp_comm_create_host(const char* name, int rank, int nranks, long long staging_bytes, double timeout_seconds,
    void** comm)
 {
-   if ( comm == NULL || name == NULL || name[0] != '/' || strlen(name) >= sizeof(((hs_comm*) 0)->name) || nranks < 1 || rank < 0
+   if ( comm == NULL || name == NULL || name[0] != '/' || strlen(name) + 20 >= sizeof(((hs_comm*) 0)->name) || nranks < 1 || rank < 0
       || rank >= nranks || staging_bytes < 4096 )
       return HIPSDP_ERR_ARG;
    hs_comm* c = new (std::nothrow) hs_comm();
@@ -215,31 +360,92 @@ extern "C" int hipsdp_comm_create_host(const char* name, int rank, int nranks, l
       return HIPSDP_ERR_NOMEM;
    c->kind = 1; c->rank = rank; c->nranks = nranks; c->nccl = NULL;
    c->timeout_s = timeout_seconds > 0.0 ? timeout_seconds : 120.0;
-   strcpy(c->name, name);
+   /* Safe against the leftovers of a crashed job: the job nonce is part of the segment name; rank 0 removes whatever carries the
+    * name, creates the segment exclusively, initialises the header itself and only then publishes (ready word = magic ^ nonce);
+    * the others never create - they wait for a segment with the right ready word that is still the one the name points to. */
+   const unsigned long long nonce = job_nonce();
+   if ( nonce != 0 )
+      snprintf(c->name, sizeof(c->name), "%s.%016llx", name, nonce);
+   else
+      strcpy(c->name, name);
    c->data_bytes = (size_t) staging_bytes & ~(size_t) 63;
    c->map_bytes = sizeof(shm_header) + c->data_bytes;
-   /* every rank opens-or-creates and sizes the segment; fresh pages are zero, which is the initial barrier state */
-   const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
-   if ( fd < 0 || ftruncate(fd, (off_t) c->map_bytes) != 0 )
+   void* p = MAP_FAILED;
+   const long long entered_ns = realtime_ns();
+   const auto t0 = std::chrono::steady_clock::now();
+   auto waited = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+   if ( rank == 0 )
    {
-      if ( fd >= 0 ) close(fd);
-      delete c;
-      fprintf(stderr, "hipsdp: host-staged communicator: cannot create %s\n", name);
-      return HIPSDP_ERR_HIP;
+      int fd = -1;
+      for (int attempt = 0; attempt < 4 && fd < 0; ++attempt)
+      {
+         (void) shm_unlink(c->name);
+         fd = shm_open(c->name, O_CREAT | O_EXCL | O_RDWR, 0600);
+      }
+      if ( fd < 0 || ftruncate(fd, (off_t) c->map_bytes) != 0 )
+      {
+         if ( fd >= 0 ) { close(fd); (void) shm_unlink(c->name); }
+         fprintf(stderr, "hipsdp: host-staged communicator: cannot create %s\n", c->name);
+         delete c;
+         return HIPSDP_ERR_HIP;
+      }
+      p = mmap(NULL, c->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+      close(fd);
+      if ( p == MAP_FAILED )
+      {
+         (void) shm_unlink(c->name);
+         delete c;
+         return HIPSDP_ERR_NOMEM;
+      }
+      shm_header* h = (shm_header*) p;
+      h->arrived.store(0, std::memory_order_relaxed);
+      h->generation.store(0, std::memory_order_relaxed);
+      h->failed.store(0, std::memory_order_relaxed);
+      h->created_ns = realtime_ns();
+      h->ready.store(SHM_READY_MAGIC ^ nonce, std::memory_order_release);
    }
-   void* p = mmap(NULL, c->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-   close(fd);
-   if ( p == MAP_FAILED )
+   else
    {
-      delete c;
-      return HIPSDP_ERR_NOMEM;
+      while ( p == MAP_FAILED )
+      {
+         const int fd = shm_open(c->name, O_RDWR, 0600);
+         struct stat st_fd, st_name;
+         char path[160];
+         snprintf(path, sizeof(path), "/dev/shm%s", c->name);
+         if ( fd >= 0 && fstat(fd, &st_fd) == 0 && (size_t) st_fd.st_size >= c->map_bytes )
+         {
+            void* q = mmap(NULL, c->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            if ( q != MAP_FAILED )
+            {
+               /* published by rank 0 of THIS job, and still the segment the name points to (rank 0 unlinks a stale one first) */
+               const bool ready = ((shm_header*) q)->ready.load(std::memory_order_acquire) == (SHM_READY_MAGIC ^ nonce)
+                  && ((shm_header*) q)->created_ns >= entered_ns - (long long) (c->timeout_s * 1e9);
+               const bool current = stat(path, &st_name) != 0 || (st_name.st_ino == st_fd.st_ino && st_name.st_dev == st_fd.st_dev);
+               if ( ready && current && stat(path, &st_name) == 0 )
+                  p = q;
+               else
+                  munmap(q, c->map_bytes);
+            }
+         }
+         if ( fd >= 0 ) close(fd);
+         if ( p == MAP_FAILED )
+         {
+            if ( waited() > c->timeout_s )
+            {
+               fprintf(stderr, "hipsdp: host-staged communicator: rank %d found no segment %s of this job within %.0f s\n", rank, c->name, c->timeout_s);
+               delete c;
+               return HIPSDP_ERR_HIP;
+            }
+            usleep(2000);
+         }
+      }
    }
    c->hdr = (shm_header*) p;
    c->data = (char*) p + sizeof(shm_header);
    /* once everyone has mapped it the name can go: the memory lives until the last unmap */
    const int rc = shm_barrier(c);
    if ( rank == 0 )
-      shm_unlink(name);
+      shm_unlink(c->name);
    if ( rc != HS_OK )
    {
       munmap(p, c->map_bytes);
@@ -255,6 +461,8 @@ extern "C" void hipsdp_comm_destroy(void* comm)
    hs_comm* c = (hs_comm*) comm;
    if ( c == NULL )
       return;
+   for (auto& r : c->recs) { (void) hipEventDestroy(r.a); (void) hipEventDestroy(r.b); }
+   for (hipEvent_t e : c->evpool) (void) hipEventDestroy(e);
    if ( c->kind == 0 )
       (void) ncclCommDestroy(c->nccl);
    else if ( c->kind == 1 )
@@ -265,6 +473,7 @@ extern "C" void hipsdp_comm_destroy(void* comm)
 int hs_allgather_inplace(void* comm, double* buf, long long count_per_rank, int rank, hipStream_t stream)
 {
    hs_comm* c = (hs_comm*) comm;
+   CollTimer tm(c, stream, 8.0 * (double) count_per_rank * c->nranks);
    if ( c->kind == 2 )
       return HS_OK;
    if ( c->kind == 1 )
@@ -277,6 +486,7 @@ int hs_allgather_inplace(void* comm, double* buf, long long count_per_rank, int 
 int hs_allgather(void* comm, const double* send, double* recv, long long count_per_rank, hipStream_t stream)
 {
    hs_comm* c = (hs_comm*) comm;
+   CollTimer tm(c, stream, 8.0 * (double) count_per_rank * c->nranks);
    if ( c->kind == 2 )
    {
       HS_HIP( hipMemcpyAsync(recv + (long long) c->rank * count_per_rank, send, (size_t) count_per_rank * sizeof(double), hipMemcpyDeviceToDevice, stream) );
@@ -292,6 +502,7 @@ int hs_allgather(void* comm, const double* send, double* recv, long long count_p
 int hs_bcast_doubles(void* comm, double* buf, long long count, hipStream_t stream)
 {
    hs_comm* c = (hs_comm*) comm;
+   CollTimer tm(c, stream, 8.0 * (double) count);
    if ( c->kind == 2 )
       return HS_OK;
    if ( c->kind == 1 )
@@ -304,6 +515,7 @@ int hs_bcast_doubles(void* comm, double* buf, long long count, hipStream_t strea
 int hs_bcast_ints(void* comm, int* buf, long long count, hipStream_t stream)
 {
    hs_comm* c = (hs_comm*) comm;
+   CollTimer tm(c, stream, 4.0 * (double) count);
    if ( c->kind == 2 )
       return HS_OK;
    if ( c->kind == 1 )
@@ -318,6 +530,7 @@ int hs_allreduce_sum(void* comm, double* buf, long long count, hipStream_t strea
    hs_comm* c = (hs_comm*) comm;
    if ( count <= 0 )
       return HS_OK;
+   CollTimer tm(c, stream, 8.0 * (double) count);
    if ( c->kind == 2 )
       return HS_OK;
    if ( c->kind == 1 )
@@ -348,6 +561,10 @@ int hs_alltoall(void* comm, const double* send, double* recv, const long long* c
 {
    hs_comm* c = (hs_comm*) comm;
    const int G = c->nranks;
+   double sent = 0.0;
+   for (int d = 0; d < G; ++d)
+      if ( d != c->rank ) sent += 8.0 * (double) cnt[(long long) c->rank * G + d];
+   CollTimer tm(c, stream, sent);
    if ( c->kind == 1 )
       return shm_alltoall(c, send, recv, cnt, stream);
    long long soff = 0, roff = 0;
@@ -428,12 +645,19 @@ extern "C" int hipsdp_comm_from_env(int device, void** comm, int* rank, int* nra
             rc = hipsdp_comm_create_host(shm, r, world, 64LL << 20, tmo, &g_comm);
          else if ( file != NULL )
          {
-            unsigned char id[128];
+            /* the file holds the 128-byte RCCL id followed by the job nonce.  Rank 0 removes leftovers of an earlier job before it
+             * writes (write + rename); the others accept only a file with this job's nonce that is not older than the join timeout */
+            unsigned char id[128 + 8];
+            const unsigned long long nonce = job_nonce();
+            const long long entered_ns = realtime_ns();
             bool have = false;
             if ( r == 0 )
             {
                char tmp[4096];
                snprintf(tmp, sizeof(tmp), "%s.tmp", file);
+               (void) unlink(file);
+               (void) unlink(tmp);
+               memcpy(id + 128, &nonce, 8);
                FILE* f = hipsdp_comm_unique_id(id) == HIPSDP_OK ? fopen(tmp, "wb") : NULL;
                have = f != NULL && fwrite(id, 1, sizeof(id), f) == sizeof(id);
                if ( f != NULL ) have = (fclose(f) == 0) && have;
@@ -447,7 +671,13 @@ extern "C" int hipsdp_comm_from_env(int device, void** comm, int* rank, int* nra
                   FILE* f = fopen(file, "rb");
                   if ( f != NULL )
                   {
+                     struct stat st;
+                     unsigned long long got = 0;
                      have = fread(id, 1, sizeof(id), f) == sizeof(id);
+                     if ( have )
+                        memcpy(&got, id + 128, 8);
+                     have = have && got == nonce && fstat(fileno(f), &st) == 0
+                        && (long long) st.st_mtime * 1000000000LL >= entered_ns - (long long) ((tmo + 2.0) * 1e9);
                      fclose(f);
                   }
                   if ( !have )
@@ -455,7 +685,7 @@ extern "C" int hipsdp_comm_from_env(int device, void** comm, int* rank, int* nra
                }
             }
             if ( !have )
-               fprintf(stderr, "hipsdp: rank %d could not %s the communicator id file %s\n", r, r == 0 ? "write" : "read", file);
+               fprintf(stderr, "hipsdp: rank %d could not %s the communicator id file %s of this job\n", r, r == 0 ? "write" : "read", file);
             else
                rc = hipsdp_comm_create(id, r, world, &g_comm);
             if ( r == 0 && rc == HIPSDP_OK )

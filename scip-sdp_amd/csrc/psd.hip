@@ -1,0 +1,184 @@
+/* psd.hip - the PSD projection chain of the warm-start producer, fused on the device.
+ *
+ * Reference: src/scipsdp/relax_sdp.c:2715-2766 (dual matrix Z of a block) and :3405-3445 (primal matrix X), helpers
+ * expandSparseMatrix :243-273 and scaleTransposedMatrix :276-302.  There the chain is five host steps with two trips through
+ * SCIPlapack* (eigen-decomposition, then DGEMM):
+ *    sparse lower triangle -> dense;  (lambda, V) = eig, V[k][:] = k-th eigenvector, ascending;
+ *    lambda_k < minev -> minev (SCIPisLT, i.e. by more than epsilon);  S = copy of V with entry [r][c] multiplied by lambda_c;
+ *    R = DGEMM(V, 'T', S, 'N');  upper triangle of R with |entry| > epsilon -> sparse (row <= col, row-major order).
+ * Read in row-major terms the product is  R[i][j] = sum_c V[i][c] lambda_c V[j][c]  - the eigenvalues weight the COMPONENTS
+ * of the eigenvectors, not the eigenvectors (scaleTransposedMatrix scales column c of the array whose ROWS are the
+ * eigenvectors).  mode 0 reproduces exactly that; mode 1 is the spectral form  R = sum_k lambda_k v_k v_k^T  (the projection
+ * onto {X : X >= minev I} the comment at relax_sdp.c:2747 describes).  Both keep every step on the device: one upload of the
+ * triplets, one download of the triplets. */
+#include "hs_kernels.h"
+#include "../../include/hipsdp.h"
+#include <cstdlib>
+
+namespace {
+
+__global__ void k_expand_coo(int nnz, int n, const int* __restrict__ row, const int* __restrict__ col, const double* __restrict__ val,
+   double* __restrict__ A)
+{
+   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += gridDim.x * blockDim.x)
+   {
+      const int r = row[e], c = col[e];
+      A[(long long) r * n + c] = val[e];
+      A[(long long) c * n + r] = val[e];
+   }
+}
+
+/* S = V with the clamped eigenvalues multiplied in: mode 0 S[k][j] = V[k][j] * lam'_j, mode 1 S[k][j] = lam'_k * V[k][j] */
+__global__ void k_clamp_scale(int n, const double* __restrict__ V, const double* __restrict__ lam, double minev, double eps, int mode,
+   double* __restrict__ S)
+{
+   const long long n2 = (long long) n * n;
+   for (long long e = (long long) blockIdx.x * blockDim.x + threadIdx.x; e < n2; e += (long long) gridDim.x * blockDim.x)
+   {
+      const int k = (int) (e / n), j = (int) (e - (long long) k * n);
+      double l = lam[mode == 0 ? j : k];
+      if ( l - minev < -eps )
+         l = minev;
+      S[e] = V[e] * l;
+   }
+}
+
+/* cnt[r] = number of c >= r with |R[r][c]| > eps */
+__global__ void __launch_bounds__(256) k_row_counts(int n, const double* __restrict__ R, double eps, int* __restrict__ cnt)
+{
+   __shared__ int sh[4];
+   const int r = blockIdx.x;
+   int c0 = 0;
+   for (int c = r + threadIdx.x; c < n; c += 256)
+      c0 += fabs(R[(long long) r * n + c]) > eps ? 1 : 0;
+   for (int off = 32; off > 0; off >>= 1)
+      c0 += __shfl_down(c0, off, 64);
+   if ( (threadIdx.x & 63) == 0 )
+      sh[threadIdx.x >> 6] = c0;
+   __syncthreads();
+   if ( threadIdx.x == 0 )
+      cnt[r] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+/* off[r] = sum of cnt[0 .. r-1], off[n] = total; one workgroup */
+__global__ void __launch_bounds__(1024) k_scan_counts(int n, const int* __restrict__ cnt, int* __restrict__ off)
+{
+   __shared__ int sh[1024];
+   __shared__ int carry;
+   if ( threadIdx.x == 0 )
+      carry = 0;
+   __syncthreads();
+   for (int base = 0; base < n; base += 1024)
+   {
+      const int i = base + threadIdx.x;
+      const int v = i < n ? cnt[i] : 0;
+      sh[threadIdx.x] = v;
+      __syncthreads();
+      for (int d = 1; d < 1024; d <<= 1)
+      {
+         const int t = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+         __syncthreads();
+         sh[threadIdx.x] += t;
+         __syncthreads();
+      }
+      if ( i < n )
+         off[i] = carry + sh[threadIdx.x] - v;
+      __syncthreads();
+      if ( threadIdx.x == 1023 )
+         carry += sh[1023];
+      __syncthreads();
+   }
+   if ( threadIdx.x == 0 )
+      off[n] = carry;
+}
+
+/* row r writes its kept entries in column order starting at off[r] (one wavefront per row: ballot-ordered compaction) */
+__global__ void __launch_bounds__(64) k_write_rows(int n, const double* __restrict__ R, double eps, const int* __restrict__ off, int cap,
+   int* __restrict__ row, int* __restrict__ col, double* __restrict__ val)
+{
+   const int r = blockIdx.x;
+   int pos = off[r];
+   for (int base = r; base < n; base += 64)
+   {
+      const int c = base + threadIdx.x;
+      const double v = c < n ? R[(long long) r * n + c] : 0.0;
+      const bool keep = c < n && fabs(v) > eps;
+      const unsigned long long mask = __ballot(keep);
+      const int before = __popcll(mask & ((1ULL << threadIdx.x) - 1ULL));
+      if ( keep && pos + before < cap )
+      {
+         row[pos + before] = r;
+         col[pos + before] = c;
+         val[pos + before] = v;
+      }
+      pos += __popcll(mask);
+   }
+}
+
+template<class T> struct PoolBuf
+{
+   T* p;
+   PoolBuf() : p(NULL) {}
+   ~PoolBuf() { if ( p != NULL ) hs_pool_free(p); }
+   int alloc(long long count) { return hs_pool_alloc((void**) &p, (size_t) (count > 0 ? count : 1) * sizeof(T)); }
+};
+
+}
+
+extern "C" int hipsdp_psd_project(int device, int n, int nnz, const int* row, const int* col, const double* val, double minev,
+   double epsilon, int mode, int cap, int* nnz_out, int* rowout, int* colout, double* valout)
+{
+   int nd = 0;
+   if ( hipGetDeviceCount(&nd) != hipSuccess || nd <= 0 )
+      return HIPSDP_ERR_NODEVICE;
+   if ( device < 0 || device >= nd || n <= 0 || nnz < 0 || (nnz > 0 && (row == NULL || col == NULL || val == NULL)) || nnz_out == NULL
+      || mode < 0 || mode > 1 || cap < 0 || (cap > 0 && (rowout == NULL || colout == NULL || valout == NULL)) )
+      return HIPSDP_ERR_ARG;
+   for (int e = 0; e < nnz; ++e)
+      if ( row[e] < 0 || row[e] >= n || col[e] < 0 || col[e] >= n )
+         return HIPSDP_ERR_ARG;
+   HS_HIP( hipSetDevice(device) );
+   hipStream_t st = 0;
+   const long long n2 = (long long) n * n;
+   PoolBuf<double> A, lam, V, S, ws, dval, oval;
+   PoolBuf<int> drow, dcol, cnt, off, orow, ocol;
+   HS_CALL( A.alloc(n2) ); HS_CALL( lam.alloc(n) ); HS_CALL( V.alloc(n2) ); HS_CALL( S.alloc(n2) ); HS_CALL( ws.alloc(hs_syev_ws(n)) );
+   HS_CALL( drow.alloc(nnz) ); HS_CALL( dcol.alloc(nnz) ); HS_CALL( dval.alloc(nnz) );
+   HS_CALL( cnt.alloc(n) ); HS_CALL( off.alloc(n + 1) );
+   HS_CALL( orow.alloc(cap) ); HS_CALL( ocol.alloc(cap) ); HS_CALL( oval.alloc(cap) );
+   HS_HIP( hipMemsetAsync(A.p, 0, (size_t) n2 * sizeof(double), st) );
+   if ( nnz > 0 )
+   {
+      HS_HIP( hipMemcpyAsync(drow.p, row, (size_t) nnz * sizeof(int), hipMemcpyHostToDevice, st) );
+      HS_HIP( hipMemcpyAsync(dcol.p, col, (size_t) nnz * sizeof(int), hipMemcpyHostToDevice, st) );
+      HS_HIP( hipMemcpyAsync(dval.p, val, (size_t) nnz * sizeof(double), hipMemcpyHostToDevice, st) );
+      int g = (nnz + 255) / 256; if ( g > 1024 ) g = 1024;
+      hipLaunchKernelGGL(k_expand_coo, dim3(g), dim3(256), 0, st, nnz, n, drow.p, dcol.p, dval.p, A.p);
+   }
+   HS_CALL( hs_syev_jacobi(st, n, A.p, lam.p, V.p, NULL, ws.p) );
+   long long g2 = (n2 + 255) / 256; if ( g2 > 4096 ) g2 = 4096;
+   hipLaunchKernelGGL(k_clamp_scale, dim3((unsigned) g2), dim3(256), 0, st, n, V.p, lam.p, minev, epsilon, mode, S.p);
+   {
+      /* mode 0: R = V S^T (both operands K contiguous); mode 1: R = V^T S (both M / N contiguous); R goes to A */
+      hs_gemm_args ga = {n, n, n, mode == 0 ? HS_KC : HS_MC, mode == 0 ? HS_KC : HS_MC, V.p, n, 0, S.p, n, 0, A.p, n, 0, 1.0, 0.0, 1, 0, 1, NULL};
+      HS_CALL( hs_dgemm(st, &ga) );
+   }
+   hipLaunchKernelGGL(k_row_counts, dim3(n), dim3(256), 0, st, n, A.p, epsilon, cnt.p);
+   hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, n, cnt.p, off.p);
+   hipLaunchKernelGGL(k_write_rows, dim3(n), dim3(64), 0, st, n, A.p, epsilon, off.p, cap, orow.p, ocol.p, oval.p);
+   if ( hipGetLastError() != hipSuccess )
+      return HIPSDP_ERR_HIP;
+   int total = 0;
+   HS_HIP( hipMemcpyAsync(&total, off.p + n, sizeof(int), hipMemcpyDeviceToHost, st) );
+   HS_HIP( hipStreamSynchronize(st) );
+   *nnz_out = total;
+   if ( total > cap )
+      return HIPSDP_ERR_ARG;             /* the needed length is in *nnz_out */
+   if ( total > 0 )
+   {
+      HS_HIP( hipMemcpy(rowout, orow.p, (size_t) total * sizeof(int), hipMemcpyDeviceToHost) );
+      HS_HIP( hipMemcpy(colout, ocol.p, (size_t) total * sizeof(int), hipMemcpyDeviceToHost) );
+      HS_HIP( hipMemcpy(valout, oval.p, (size_t) total * sizeof(double), hipMemcpyDeviceToHost) );
+   }
+   return HIPSDP_OK;
+}

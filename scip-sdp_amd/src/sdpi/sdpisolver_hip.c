@@ -11,6 +11,9 @@
  *    min  b^T y (+ Gamma r)   s.t.  sum_j A_j^k y_j - A_0^k (+ r I) psd,   rows of  D y (+ r) >= d  for every finite LP
  *    side, one row per finite variable bound, (r >= 0).
  */
+#ifndef _POSIX_C_SOURCE
+#define _POSIX_C_SOURCE 200809L
+#endif
 #include <assert.h>
 #include <math.h>
 #include <stdio.h>
@@ -131,6 +134,14 @@ struct SCIP_SDPiSolver
 /* ---------------------------------------------------------------------------------------------------------------------- */
 /* local helpers                                                                                                          */
 /* ---------------------------------------------------------------------------------------------------------------------- */
+
+/* wall clock of the marshalling stages, printed with HIPSDP_STAGE_TIMES=1 (tests/devtools/sdpi_overhead.py, bench.py) */
+static double wallNow(void)
+{
+   struct timespec ts;
+   clock_gettime(CLOCK_MONOTONIC, &ts);
+   return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec;
+}
 
 static SCIP_Bool isFixed(const SCIP_SDPISOLVER* s, SCIP_Real lb, SCIP_Real ub)
 {
@@ -500,11 +511,12 @@ static SCIP_RETCODE loadStartPoint(SCIP_SDPISOLVER* s, int nvars, int nsdpblocks
    return retcode;
 }
 
-static SCIP_RETCODE engineSolve(SCIP_SDPISOLVER* s, SCIP_Real gaptol, SCIP_Real feastol, SCIP_Real remaining, SDPI_CLOCK* clck)
+static SCIP_RETCODE engineSolve(SCIP_SDPISOLVER* s, int level, SCIP_Real gaptol, SCIP_Real feastol, SCIP_Real remaining, SDPI_CLOCK* clck)
 {
    hipsdp_params par;
    SCIP_Real t0;
    hipsdp_default_params(&par);
+   par.settings = level;                 /* 0 fast, 1 medium, 2 stable: the engine's side of the retry ladder */
    par.gaptol = gaptol;
    par.feastol = feastol;
    /* the caller validates the X-side ABSOLUTELY with SCIP_SDPPAR_FEASTOL (sdpsolchecker.c:775-931) while the engine's own
@@ -524,6 +536,270 @@ static SCIP_RETCODE engineSolve(SCIP_SDPISOLVER* s, SCIP_Real gaptol, SCIP_Real 
    return SCIP_OKAY;
 }
 
+/* Remaining time of the caller's clock, or HS_INFINITY.  *expired is the decision "no time left"; with several SPMD ranks it is
+ * rank 0's decision on every rank (each process has its own clock: a rank that left early would leave the others alone in the
+ * next RCCL collective, which has no timeout). */
+static SCIP_RETCODE timeLeft(SCIP_SDPISOLVER* s, SCIP_Real timelimit, SDPI_CLOCK* usedsdpitime, SCIP_Real* remaining, SCIP_Bool* expired)
+{
+   int flag = 0;
+   *remaining = HS_INFINITY;
+   *expired = FALSE;
+   if ( timelimit >= HS_INFINITY || usedsdpitime == NULL )
+      return SCIP_OKAY;
+   *remaining = timelimit - SDPIclockGetTime(usedsdpitime);
+   flag = (*remaining <= 0.0) ? 1 : 0;
+   if ( s->engine != NULL )
+      ENGINE_CALL( hipsdp_sync_flag(s->engine, &flag) );
+   *expired = (flag != 0);
+   if ( ! *expired && *remaining <= 0.0 )
+      *remaining = 1e-3;                 /* rank 0 still has time: go on with the others, the engine's own check is collective */
+   return SCIP_OKAY;
+}
+
+/* creates the engine on first use and joins the communicator of an SPMD launch */
+static SCIP_RETCODE ensureEngine(SCIP_SDPISOLVER* s)
+{
+   int rc;
+   if ( s->engine != NULL )
+      return SCIP_OKAY;
+   rc = hipsdp_create(&s->engine, s->device);
+   if ( rc != HIPSDP_OK )
+   {
+      SCIPerrorMessage("Cannot create the HIP engine: %s\n", hipsdp_last_error());
+      s->engine = NULL;
+      return SCIP_LPERROR;
+   }
+   /* SPMD launch (N copies of the host program, one per GPU, WORLD_SIZE / RANK in the environment): every node SDP is
+    * sharded over the ranks of the process-wide communicator; all copies make the same calls and see the same results.
+    * SCIP_SDPPAR_NTHREADS (reinterpreted as the number of GPUs) = 1 keeps this solver on its own GPU. */
+   if ( s->nthreads != 1 )
+   {
+      void* comm = NULL;
+      int crank = 0, cworld = 1;
+      if ( hipsdp_comm_from_env(s->device, &comm, &crank, &cworld) != HIPSDP_OK
+         || (comm != NULL && hipsdp_set_comm(s->engine, comm, crank, cworld) != HIPSDP_OK) )
+      {
+         SCIPerrorMessage("Cannot join the communicator of the SPMD launch: %s\n", hipsdp_last_error());
+         hipsdp_free(&s->engine);
+         return SCIP_LPERROR;
+      }
+   }
+   return SCIP_OKAY;
+}
+
+static SCIP_Bool spmdLaunch(const SCIP_SDPISOLVER* s)
+{
+   const char* w = getenv("HIPSDP_WORLD") != NULL ? getenv("HIPSDP_WORLD") : getenv("WORLD_SIZE");
+   return s->nthreads != 1 && w != NULL && atoi(w) > 1;
+}
+
+/* COO buffers of one upload */
+typedef struct { int* var; int* row; int* col; SCIP_Real* val; } CooBuf;
+
+static SCIP_Bool cooAlloc(CooBuf* c, long long cnt)
+{
+   const size_t k = (size_t) (cnt > 0 ? cnt : 1);
+   c->var = (int*) malloc(k * sizeof(int));
+   c->row = (int*) malloc(k * sizeof(int));
+   c->col = (int*) malloc(k * sizeof(int));
+   c->val = (SCIP_Real*) malloc(k * sizeof(SCIP_Real));
+   return c->var != NULL && c->row != NULL && c->col != NULL && c->val != NULL;
+}
+
+static void cooFree(CooBuf* c)
+{
+   free(c->var); free(c->row); free(c->col); free(c->val);
+   c->var = NULL; c->row = NULL; c->col = NULL; c->val = NULL;
+}
+
+/* fills the engine's compact blocks: non-constant part through the device-resident master copy (or directly when that does not
+ * fit), then the constant matrix of the node and the identity of the penalty variable */
+static SCIP_RETCODE loadBlocks(SCIP_SDPISOLVER* s, int nvars, int nsdpblocks, const int* sdpblocksizes, const int* sdpnblockvars,
+   const int* sdpconstnblocknonz, int* const* sdpconstrow, int* const* sdpconstcol, SCIP_Real* const* sdpconstval, int sdpnnonz,
+   int* const* sdpnblockvarnonz, int* const* sdpvar, int** const* sdprow, int** const* sdpcol, SCIP_Real** const* sdpval,
+   int* const* indchanges)
+{
+   clock_t tfp0, tfp1, tup1;                 /* processor time of this thread's marshalling work (printed with SDPINFO) */
+   unsigned long long fp;
+   SCIP_Bool usemaster = (getenv("HIPSDP_NOMASTER") == NULL);
+   const SCIP_Bool usecache = (getenv("HIPSDP_NOCACHE") == NULL);
+   CooBuf coo = {NULL, NULL, NULL, NULL};
+   int* slots = NULL;
+   SCIP_RETCODE retcode = SCIP_OKAY;
+   int b;
+   int k;
+   int t;
+
+   tfp0 = clock();
+   fp = sdpFingerprint(nvars, nsdpblocks, sdpblocksizes, sdpnblockvars, sdpnnonz, sdpnblockvarnonz, sdpvar, sdprow, sdpcol, sdpval);
+   tfp1 = clock();
+   if ( usemaster && (! usecache || ! s->mastervalid || s->masterhash != fp || s->masternvars != nvars || s->masternblocks != nsdpblocks
+         || s->masternnz != sdpnnonz) )
+   {
+      int rc;
+      s->mastervalid = FALSE;
+      rc = hipsdp_master_define(s->engine, nvars, nsdpblocks, sdpblocksizes, sdpnblockvars);
+      for (b = 0; b < nsdpblocks && rc == HIPSDP_OK; ++b)
+      {
+         long long cnt = 0;
+         long long pos = 0;
+         for (k = 0; k < sdpnblockvars[b]; ++k)
+            cnt += sdpnblockvarnonz[b][k];
+         if ( cnt == 0 )
+            continue;
+         if ( ! cooAlloc(&coo, cnt) )
+         {
+            cooFree(&coo);
+            return SCIP_NOMEMORY;
+         }
+         for (k = 0; k < sdpnblockvars[b]; ++k)
+         {
+            for (t = 0; t < sdpnblockvarnonz[b][k]; ++t)
+            {
+               coo.var[pos] = k;                      /* slot = position of the variable in the block's list */
+               coo.row[pos] = sdprow[b][k][t];
+               coo.col[pos] = sdpcol[b][k][t];
+               coo.val[pos] = sdpval[b][k][t];
+               ++pos;
+            }
+         }
+         rc = hipsdp_master_add_entries(s->engine, b, pos, coo.var, coo.row, coo.col, coo.val);
+         cooFree(&coo);
+      }
+      if ( rc == HIPSDP_ERR_NOMEM )
+      {
+         /* the master copy does not fit beside the engine's storage: drop it and load this node's blocks directly */
+         (void) hipsdp_master_define(s->engine, 0, 0, NULL, NULL);
+         usemaster = FALSE;
+         if ( s->sdpinfo )
+            printf("hipsdp: no room for the device-resident master copy, loading the node's blocks directly\n");
+      }
+      else if ( rc != HIPSDP_OK )
+      {
+         SCIPerrorMessage("uploading the master copy failed (%d): %s\n", rc, hipsdp_last_error());
+         return SCIP_LPERROR;
+      }
+      else
+      {
+         tup1 = clock();
+         if ( s->sdpinfo )
+            printf("hipsdp: fingerprint of %d nonzeros %.2f ms, upload of the master copy %.2f ms\n", sdpnnonz,
+               1e3 * (double) (tfp1 - tfp0) / (double) CLOCKS_PER_SEC, 1e3 * (double) (tup1 - tfp1) / (double) CLOCKS_PER_SEC);
+         s->mastervalid = TRUE;
+         s->masterhash = fp;
+         s->masternvars = nvars;
+         s->masternblocks = nsdpblocks;
+         s->masternnz = sdpnnonz;
+      }
+   }
+   if ( ! usemaster )
+      s->mastervalid = FALSE;
+
+   if ( s->nactivevars > 0 )
+   {
+      slots = (int*) malloc((size_t) s->nactivevars * sizeof(int));
+      if ( slots == NULL )
+         return SCIP_NOMEMORY;
+   }
+   for (b = 0; b < nsdpblocks && retcode == SCIP_OKAY; ++b)
+   {
+      long long cnt = 0;
+      long long pos = 0;
+      int rc;
+      const int eb = s->blockmap[b];
+      if ( eb < 0 )
+         continue;
+      if ( usemaster )
+      {
+         /* slot of every active variable in this block (-1: it does not appear) */
+         for (k = 0; k < s->nactivevars; ++k)
+            slots[k] = -1;
+         for (k = 0; k < sdpnblockvars[b]; ++k)
+         {
+            const int av = s->inputtoactive[sdpvar[b][k]];
+            if ( av > 0 )
+               slots[av - 1] = k;
+         }
+         rc = hipsdp_master_gather(s->engine, eb, b, s->nactivevars, slots, s->compactsize[b], s->keptind[b]);
+         if ( rc != HIPSDP_OK )
+         {
+            SCIPerrorMessage("hipsdp_master_gather failed (%d): %s\n", rc, hipsdp_last_error());
+            retcode = SCIP_LPERROR;
+            break;
+         }
+      }
+      else
+      {
+         for (k = 0; k < sdpnblockvars[b]; ++k)
+            if ( s->inputtoactive[sdpvar[b][k]] > 0 )
+               cnt += sdpnblockvarnonz[b][k];
+      }
+      /* per node: constant matrix (changes with the fixings) and the identity of the penalty variable */
+      cnt += sdpconstnblocknonz[b] + (s->penalty ? s->compactsize[b] : 0);
+      if ( cnt == 0 )
+         continue;
+      if ( ! cooAlloc(&coo, cnt) )
+      {
+         cooFree(&coo);
+         retcode = SCIP_NOMEMORY;
+         break;
+      }
+      if ( ! usemaster )
+      {
+         for (k = 0; k < sdpnblockvars[b]; ++k)
+         {
+            const int av = s->inputtoactive[sdpvar[b][k]];
+            if ( av <= 0 )
+               continue;
+            for (t = 0; t < sdpnblockvarnonz[b][k]; ++t)
+            {
+               const int r = sdprow[b][k][t];
+               const int c = sdpcol[b][k][t];
+               if ( indchanges[b][r] < 0 || indchanges[b][c] < 0 )
+                  continue;
+               coo.var[pos] = av;
+               coo.row[pos] = r - indchanges[b][r];
+               coo.col[pos] = c - indchanges[b][c];
+               coo.val[pos] = sdpval[b][k][t];
+               ++pos;
+            }
+         }
+      }
+      for (t = 0; t < sdpconstnblocknonz[b]; ++t)
+      {
+         const int r = sdpconstrow[b][t];
+         const int c = sdpconstcol[b][t];
+         if ( indchanges[b][r] < 0 || indchanges[b][c] < 0 )
+            continue;      /* cannot happen for consistent input (sdpi.c:691-809); be safe */
+         coo.var[pos] = 0;
+         coo.row[pos] = r - indchanges[b][r];
+         coo.col[pos] = c - indchanges[b][c];
+         coo.val[pos] = sdpconstval[b][t];
+         ++pos;
+      }
+      if ( s->penalty )
+      {
+         for (t = 0; t < s->compactsize[b]; ++t)
+         {
+            coo.var[pos] = s->rvar + 1;
+            coo.row[pos] = t;
+            coo.col[pos] = t;
+            coo.val[pos] = 1.0;
+            ++pos;
+         }
+      }
+      rc = hipsdp_add_entries(s->engine, eb, pos, coo.var, coo.row, coo.col, coo.val);
+      cooFree(&coo);
+      if ( rc != HIPSDP_OK )
+      {
+         SCIPerrorMessage("hipsdp_add_entries failed (%d): %s\n", rc, hipsdp_last_error());
+         retcode = (rc == HIPSDP_ERR_NOMEM) ? SCIP_NOMEMORY : SCIP_LPERROR;
+      }
+   }
+   free(slots);
+   return retcode;
+}
+
 /* pull y and the LP multipliers of the last engine solve to the host */
 static SCIP_RETCODE fetchVectors(SCIP_SDPISOLVER* s)
 {
@@ -531,6 +807,97 @@ static SCIP_RETCODE fetchVectors(SCIP_SDPISOLVER* s)
       ENGINE_CALL( hipsdp_get_y(s->engine, s->ysol) );
    if ( s->nxlp > 0 )
       ENGINE_CALL( hipsdp_get_lp(s->engine, s->xlp, NULL) );
+   return SCIP_OKAY;
+}
+
+static SCIP_Bool statusKnown(int st);
+
+/* one rung of the settings ladder: an engine solve, then the tolerance re-solve loop of sdpisolver_dsdp.c:1527-1606 (SDPA:
+ * checkFeastolAndResolve, sdpisolver_sdpa.cpp:369-494): while the engine says optimal, y is checked against OUR feasibility
+ * tolerance and the gap against OUR gap tolerance; a violation tightens the engine's tolerance by TOLCHANGE and solves again */
+static SCIP_RETCODE solveAndCheckTolerances(SCIP_SDPISOLVER* s, int level, SCIP_Real timelimit, SDPI_CLOCK* usedsdpitime,
+   SCIP_Real* remaining)
+{
+   SCIP_Real solverfeastol = s->sdpsolverfeastol;
+   SCIP_Real solvergaptol = s->gaptol;
+   SCIP_RETCODE retcode;
+
+   retcode = engineSolve(s, level, solvergaptol, solverfeastol, *remaining, usedsdpitime);
+   if ( retcode != SCIP_OKAY )
+      return retcode;
+
+   while ( s->info.status == HIPSDP_STATUS_OPTIMAL && ! s->penalty )
+   {
+      SCIP_Real lmin[64];
+      SCIP_Real* lminp = lmin;
+      SCIP_Real lpviol = 0.0;
+      SCIP_Bool infeasible = FALSE;
+      SCIP_Bool solveagain = FALSE;
+      SCIP_Bool expired = FALSE;
+      int e;
+
+      retcode = fetchVectors(s);
+      if ( retcode != SCIP_OKAY )
+         return retcode;
+      if ( s->nengineblocks > 64 )
+      {
+         lminp = (SCIP_Real*) malloc((size_t) s->nengineblocks * sizeof(SCIP_Real));
+         if ( lminp == NULL )
+            return SCIP_NOMEMORY;
+      }
+      /* feasibility of y w.r.t. OUR tolerance: bounds and LP rows are engine rows, blocks through lambda_min
+       * (what SCIPsdpSolcheckerCheck, sdpsolchecker.c:58-265, verifies on the host in the reference) */
+      {
+         int rc = hipsdp_check_y(s->engine, s->ysol, lminp, &lpviol);
+         if ( rc != HIPSDP_OK )
+         {
+            if ( lminp != lmin ) free(lminp);
+            SCIPerrorMessage("hipsdp_check_y failed: %s\n", hipsdp_last_error());
+            return SCIP_LPERROR;
+         }
+      }
+      for (e = 0; e < s->nengineblocks; ++e)
+         if ( lminp[e] < -s->feastol )
+            infeasible = TRUE;
+      if ( lpviol > s->feastol )
+         infeasible = TRUE;
+      if ( lminp != lmin ) free(lminp);
+
+      if ( infeasible )
+      {
+         solverfeastol *= TOLCHANGE;
+         if ( solverfeastol >= MINSOLVERTOL )
+            solveagain = TRUE;
+      }
+      if ( REALABS(s->info.pobj - s->info.dobj) >= s->gaptol )
+      {
+         infeasible = TRUE;
+         solvergaptol *= TOLCHANGE;
+         if ( solvergaptol >= MINSOLVERTOL )
+            solveagain = TRUE;
+      }
+      if ( ! solveagain )
+      {
+         if ( infeasible )
+         {
+            s->info.status = HIPSDP_STATUS_NUMERIC;
+            SCIPmessagePrintInfo(s->messagehdlr, "HIPSDP failed to reach required feasibility tolerance (feastol: %g, gaptol: %g)!\n",
+               solverfeastol, solvergaptol);
+         }
+         break;
+      }
+      retcode = timeLeft(s, timelimit, usedsdpitime, remaining, &expired);
+      if ( retcode != SCIP_OKAY )
+         return retcode;
+      if ( expired )
+      {
+         s->info.status = HIPSDP_STATUS_TIMELIM;
+         break;
+      }
+      retcode = engineSolve(s, level, solvergaptol, solverfeastol, *remaining, usedsdpitime);
+      if ( retcode != SCIP_OKAY )
+         return retcode;
+   }
    return SCIP_OKAY;
 }
 
@@ -561,9 +928,12 @@ SCIP_RETCODE SCIPsdpiSolverLoadAndSolveWithPenalty(
    int j;
    int b;
    int row;
+   const SCIP_Bool stagetimes = (getenv("HIPSDP_STAGE_TIMES") != NULL);
+   double tstage[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 
    assert( s != NULL );
    assert( penaltyparam > -1 * s->epsilon );
+   tstage[0] = wallNow();
    assert( penaltyparam < s->epsilon || feasorig != NULL );
    assert( nvars > 0 );
    assert( obj != NULL && lb != NULL && ub != NULL );
@@ -587,12 +957,21 @@ SCIP_RETCODE SCIPsdpiSolverLoadAndSolveWithPenalty(
    s->penaltyworbound = (s->penalty && ! rbound);
    s->info.status = HIPSDP_STATUS_UNSOLVED;
 
-   /* time limit check before doing anything (sdpisolver_dsdp.c:879-892) */
-   remaining = HS_INFINITY;
-   if ( timelimit < HS_INFINITY && usedsdpitime != NULL )
+   /* time limit check before doing anything (sdpisolver_dsdp.c:879-892); under an SPMD launch the engine (and with it the
+    * communicator) is needed first, because the decision has to be the same on every rank */
    {
-      remaining = timelimit - SDPIclockGetTime(usedsdpitime);
-      if ( remaining <= 0.0 )
+      SCIP_Bool expired = FALSE;
+      SCIP_RETCODE trc;
+      if ( s->engine == NULL && spmdLaunch(s) && timelimit < HS_INFINITY && usedsdpitime != NULL )
+      {
+         trc = ensureEngine(s);
+         if ( trc != SCIP_OKAY )
+            return trc;
+      }
+      trc = timeLeft(s, timelimit, usedsdpitime, &remaining, &expired);
+      if ( trc != SCIP_OKAY )
+         return trc;
+      if ( expired )
       {
          s->timelimit = TRUE;
          s->timelimitinitial = TRUE;
@@ -736,33 +1115,23 @@ SCIP_RETCODE SCIPsdpiSolverLoadAndSolveWithPenalty(
    s->nenginerows = q;
 
    /* ---- engine ---------------------------------------------------------------------------------------------------- */
-   if ( s->engine == NULL )
+   tstage[1] = wallNow();
    {
-      int rc = hipsdp_create(&s->engine, s->device);
+      SCIP_RETCODE erc = ensureEngine(s);
+      int rc;
+      if ( erc != SCIP_OKAY )
+      {
+         HSFREE(s, &engsizes, nsdpblocks);
+         return erc;
+      }
+      rc = hipsdp_set_shape(s->engine, nengvars, s->nengineblocks, engsizes, q);
+      HSFREE(s, &engsizes, nsdpblocks);
       if ( rc != HIPSDP_OK )
       {
-         SCIPerrorMessage("Cannot create the HIP engine: %s\n", hipsdp_last_error());
-         HSFREE(s, &engsizes, nsdpblocks);
-         return SCIP_LPERROR;
-      }
-      /* SPMD launch (N copies of the host program, one per GPU, WORLD_SIZE / RANK in the environment): every node SDP is
-       * sharded over the ranks of the process-wide communicator; all copies make the same calls and see the same results.
-       * SCIP_SDPPAR_NTHREADS (reinterpreted as the number of GPUs) = 1 keeps this solver on its own GPU. */
-      if ( s->nthreads != 1 )
-      {
-         void* comm = NULL;
-         int crank = 0, cworld = 1;
-         if ( hipsdp_comm_from_env(s->device, &comm, &crank, &cworld) != HIPSDP_OK
-            || (comm != NULL && hipsdp_set_comm(s->engine, comm, crank, cworld) != HIPSDP_OK) )
-         {
-            SCIPerrorMessage("Cannot join the communicator of the SPMD launch: %s\n", hipsdp_last_error());
-            HSFREE(s, &engsizes, nsdpblocks);
-            return SCIP_LPERROR;
-         }
+         SCIPerrorMessage("hipsdp_set_shape failed (%d): %s\n", rc, hipsdp_last_error());
+         return rc == HIPSDP_ERR_NOMEM ? SCIP_NOMEMORY : SCIP_LPERROR;
       }
    }
-   ENGINE_CALL( hipsdp_set_shape(s->engine, nengvars, s->nengineblocks, engsizes, q) );
-   HSFREE(s, &engsizes, nsdpblocks);
 
    /* objective */
    ALLOC_OR_FAIL(s, &bvec, nengvars);
@@ -770,141 +1139,31 @@ SCIP_RETCODE SCIPsdpiSolverLoadAndSolveWithPenalty(
       bvec[j] = withobj ? s->objcoefs[j] : 0.0;
    if ( s->penalty )
       bvec[s->rvar] = penaltyparam;
-   ENGINE_CALL( hipsdp_set_obj(s->engine, bvec) );
-   HSFREE(s, &bvec, nengvars);
+   {
+      const int rc = hipsdp_set_obj(s->engine, bvec);
+      HSFREE(s, &bvec, nengvars);
+      if ( rc != HIPSDP_OK )
+      {
+         SCIPerrorMessage("hipsdp_set_obj failed (%d): %s\n", rc, hipsdp_last_error());
+         return rc == HIPSDP_ERR_NOMEM ? SCIP_NOMEMORY : SCIP_LPERROR;
+      }
+   }
 
+   tstage[2] = wallNow();
    /* SDP blocks.  The matrices A_v are uploaded ONCE in original indices (master copy in HBM, re-used while the caller's
     * arrays are unchanged: relax_sdp.c:4455-4495 reloads them only when the number of variables or blocks changes); every
     * node then only sends its list of active variables and kept indices and the engine gathers the compact block on the
     * device.  Fixed variables are skipped here because the caller has moved them into the constant part
-    * (sdpisolver.h:160-163, sdpi.c:614-682). */
+    * (sdpisolver.h:160-163, sdpi.c:614-682).  A block's master storage has one slot per variable that appears in it; when
+    * even that does not fit the device the node's compact blocks are loaded directly (active variables, kept indices). */
    {
-      clock_t tfp0, tfp1, tup1;                 /* processor time of this thread's marshalling work (printed with SDPINFO) */
-      unsigned long long fp;
-      tfp0 = clock();
-      fp = sdpFingerprint(nvars, nsdpblocks, sdpblocksizes, sdpnblockvars, sdpnnonz, sdpnblockvarnonz, sdpvar, sdprow, sdpcol, sdpval);
-      tfp1 = clock();
-      const SCIP_Bool usecache = (getenv("HIPSDP_NOCACHE") == NULL);
-      if ( ! usecache || ! s->mastervalid || s->masterhash != fp || s->masternvars != nvars || s->masternblocks != nsdpblocks
-         || s->masternnz != sdpnnonz )
-      {
-         s->mastervalid = FALSE;
-         ENGINE_CALL( hipsdp_master_define(s->engine, nvars, nsdpblocks, sdpblocksizes) );
-         for (b = 0; b < nsdpblocks; ++b)
-         {
-            long long cnt = 0;
-            long long pos = 0;
-            int k;
-            int t;
-            int* evar;
-            int* erow;
-            int* ecol;
-            SCIP_Real* eval;
-            for (k = 0; k < sdpnblockvars[b]; ++k)
-               cnt += sdpnblockvarnonz[b][k];
-            if ( cnt == 0 )
-               continue;
-            evar = (int*) malloc((size_t) cnt * sizeof(int));
-            erow = (int*) malloc((size_t) cnt * sizeof(int));
-            ecol = (int*) malloc((size_t) cnt * sizeof(int));
-            eval = (SCIP_Real*) malloc((size_t) cnt * sizeof(SCIP_Real));
-            if ( evar == NULL || erow == NULL || ecol == NULL || eval == NULL )
-            {
-               free(evar); free(erow); free(ecol); free(eval);
-               return SCIP_NOMEMORY;
-            }
-            for (k = 0; k < sdpnblockvars[b]; ++k)
-            {
-               for (t = 0; t < sdpnblockvarnonz[b][k]; ++t)
-               {
-                  evar[pos] = sdpvar[b][k];
-                  erow[pos] = sdprow[b][k][t];
-                  ecol[pos] = sdpcol[b][k][t];
-                  eval[pos] = sdpval[b][k][t];
-                  ++pos;
-               }
-            }
-            {
-               int rc = hipsdp_master_add_entries(s->engine, b, pos, evar, erow, ecol, eval);
-               free(evar); free(erow); free(ecol); free(eval);
-               if ( rc != HIPSDP_OK )
-               {
-                  SCIPerrorMessage("hipsdp_master_add_entries failed: %s\n", hipsdp_last_error());
-                  return SCIP_LPERROR;
-               }
-            }
-         }
-         tup1 = clock();
-         if ( s->sdpinfo )
-            printf("hipsdp: fingerprint of %d nonzeros %.2f ms, upload of the master copy %.2f ms\n", sdpnnonz,
-               1e3 * (double) (tfp1 - tfp0) / (double) CLOCKS_PER_SEC, 1e3 * (double) (tup1 - tfp1) / (double) CLOCKS_PER_SEC);
-         s->mastervalid = TRUE;
-         s->masterhash = fp;
-         s->masternvars = nvars;
-         s->masternblocks = nsdpblocks;
-         s->masternnz = sdpnnonz;
-      }
-   }
-   for (b = 0; b < nsdpblocks; ++b)
-   {
-      long long cnt = 0;
-      long long pos = 0;
-      int t;
-      int* evar;
-      int* erow;
-      int* ecol;
-      SCIP_Real* eval;
-      const int eb = s->blockmap[b];
-      if ( eb < 0 )
-         continue;
-      ENGINE_CALL( hipsdp_master_gather(s->engine, eb, b, s->nactivevars, s->activetoinput, s->compactsize[b], s->keptind[b]) );
-      /* per node: constant matrix (changes with the fixings) and the identity of the penalty variable */
-      cnt = sdpconstnblocknonz[b] + (s->penalty ? s->compactsize[b] : 0);
-      if ( cnt == 0 )
-         continue;
-      evar = (int*) malloc((size_t) cnt * sizeof(int));
-      erow = (int*) malloc((size_t) cnt * sizeof(int));
-      ecol = (int*) malloc((size_t) cnt * sizeof(int));
-      eval = (SCIP_Real*) malloc((size_t) cnt * sizeof(SCIP_Real));
-      if ( evar == NULL || erow == NULL || ecol == NULL || eval == NULL )
-      {
-         free(evar); free(erow); free(ecol); free(eval);
-         return SCIP_NOMEMORY;
-      }
-      for (t = 0; t < sdpconstnblocknonz[b]; ++t)
-      {
-         const int r = sdpconstrow[b][t];
-         const int c = sdpconstcol[b][t];
-         if ( indchanges[b][r] < 0 || indchanges[b][c] < 0 )
-            continue;      /* cannot happen for consistent input (sdpi.c:691-809); be safe */
-         evar[pos] = 0;
-         erow[pos] = r - indchanges[b][r];
-         ecol[pos] = c - indchanges[b][c];
-         eval[pos] = sdpconstval[b][t];
-         ++pos;
-      }
-      if ( s->penalty )
-      {
-         for (t = 0; t < s->compactsize[b]; ++t)
-         {
-            evar[pos] = s->rvar + 1;
-            erow[pos] = t;
-            ecol[pos] = t;
-            eval[pos] = 1.0;
-            ++pos;
-         }
-      }
-      {
-         int rc = hipsdp_add_entries(s->engine, eb, pos, evar, erow, ecol, eval);
-         free(evar); free(erow); free(ecol); free(eval);
-         if ( rc != HIPSDP_OK )
-         {
-            SCIPerrorMessage("hipsdp_add_entries failed: %s\n", hipsdp_last_error());
-            return SCIP_LPERROR;
-         }
-      }
+      SCIP_RETCODE lrc = loadBlocks(s, nvars, nsdpblocks, sdpblocksizes, sdpnblockvars, sdpconstnblocknonz, sdpconstrow, sdpconstcol,
+         sdpconstval, sdpnnonz, sdpnblockvarnonz, sdpvar, sdprow, sdpcol, sdpval, indchanges);
+      if ( lrc != SCIP_OKAY )
+         return lrc;
    }
 
+   tstage[3] = wallNow();
    /* LP part, dense rows [c | D] */
    if ( q > 0 )
    {
@@ -1002,89 +1261,57 @@ SCIP_RETCODE SCIPsdpiSolverLoadAndSolveWithPenalty(
       }
    }
 
+   tstage[4] = wallNow();
+   /* Settings ladder (sdpisolver_sdpa.cpp:1415-1449 start settings, :1698-1795 retries): a plain solve starts with the settings
+    * the caller hands down (UNSOLVED / FAST -> fast); a penalty formulation is solved with the stable ones straight away.  When
+    * the result is not acceptable and no penalty formulation is being solved, the node is solved again - cold - with the next
+    * more conservative settings before the caller has to fall back to its penalty loop (sdpi.c:3437-3619: 2 + up to 8 further
+    * solves).  Every rung ends with the tolerance re-solve loop. */
    {
-      SCIP_Real solverfeastol = s->sdpsolverfeastol;
-      SCIP_Real solvergaptol = s->gaptol;
+      int level;
       SCIP_RETCODE retcode;
 
-      retcode = engineSolve(s, solvergaptol, solverfeastol, remaining, usedsdpitime);
-      if ( retcode != SCIP_OKAY )
-         return retcode;
-
-      while ( s->info.status == HIPSDP_STATUS_OPTIMAL && ! s->penalty )
+      if ( s->penalty || startsettings == SCIP_SDPSOLVERSETTING_STABLE || startsettings == SCIP_SDPSOLVERSETTING_PENALTY )
+         level = 2;
+      else if ( startsettings == SCIP_SDPSOLVERSETTING_MEDIUM )
+         level = 1;
+      else
+         level = 0;
+      if ( getenv("HIPSDP_NOLADDER") != NULL && ! s->penalty )
+         level = 0;
+      for (;;)
       {
-         SCIP_Real lmin[64];
-         SCIP_Real* lminp = lmin;
-         SCIP_Real lpviol = 0.0;
-         SCIP_Bool infeasible = FALSE;
-         SCIP_Bool solveagain = FALSE;
-         int e;
-
-         retcode = fetchVectors(s);
+         retcode = solveAndCheckTolerances(s, level, timelimit, usedsdpitime, &remaining);
          if ( retcode != SCIP_OKAY )
             return retcode;
-         if ( s->nengineblocks > 64 )
-         {
-            lminp = (SCIP_Real*) malloc((size_t) s->nengineblocks * sizeof(SCIP_Real));
-            if ( lminp == NULL )
-               return SCIP_NOMEMORY;
-         }
-         /* feasibility of y w.r.t. OUR tolerance: bounds and LP rows are engine rows, blocks through lambda_min
-          * (what SCIPsdpSolcheckerCheck, sdpsolchecker.c:58-265, verifies on the host in the reference) */
-         {
-            int rc = hipsdp_check_y(s->engine, s->ysol, lminp, &lpviol);
-            if ( rc != HIPSDP_OK )
-            {
-               if ( lminp != lmin ) free(lminp);
-               SCIPerrorMessage("hipsdp_check_y failed: %s\n", hipsdp_last_error());
-               return SCIP_LPERROR;
-            }
-         }
-         for (e = 0; e < s->nengineblocks; ++e)
-            if ( lminp[e] < -s->feastol )
-               infeasible = TRUE;
-         if ( lpviol > s->feastol )
-            infeasible = TRUE;
-         if ( lminp != lmin ) free(lminp);
-
-         if ( infeasible )
-         {
-            solverfeastol *= TOLCHANGE;
-            if ( solverfeastol >= MINSOLVERTOL )
-               solveagain = TRUE;
-         }
-         if ( REALABS(s->info.pobj - s->info.dobj) >= s->gaptol )
-         {
-            infeasible = TRUE;
-            solvergaptol *= TOLCHANGE;
-            if ( solvergaptol >= MINSOLVERTOL )
-               solveagain = TRUE;
-         }
-         if ( ! solveagain )
-         {
-            if ( infeasible )
-            {
-               s->info.status = HIPSDP_STATUS_NUMERIC;
-               SCIPmessagePrintInfo(s->messagehdlr, "HIPSDP failed to reach required feasibility tolerance (feastol: %g, gaptol: %g)!\n",
-                  solverfeastol, solvergaptol);
-            }
+         if ( ! s->penalty )
+            s->usedsetting = (level == 0) ? SCIP_SDPSOLVERSETTING_FAST : (level == 1 ? SCIP_SDPSOLVERSETTING_MEDIUM : SCIP_SDPSOLVERSETTING_STABLE);
+         if ( s->penalty || level >= 2 || statusKnown(s->info.status) || s->info.status == HIPSDP_STATUS_TIMELIM
+            || getenv("HIPSDP_NOLADDER") != NULL )
             break;
-         }
-         if ( timelimit < HS_INFINITY && usedsdpitime != NULL )
          {
-            remaining = timelimit - SDPIclockGetTime(usedsdpitime);
-            if ( remaining <= 0.0 )
+            SCIP_Bool expired = FALSE;
+            retcode = timeLeft(s, timelimit, usedsdpitime, &remaining, &expired);
+            if ( retcode != SCIP_OKAY )
+               return retcode;
+            if ( expired )
             {
                s->info.status = HIPSDP_STATUS_TIMELIM;
                break;
             }
          }
-         retcode = engineSolve(s, solvergaptol, solverfeastol, remaining, usedsdpitime);
-         if ( retcode != SCIP_OKAY )
-            return retcode;
+         ++level;
+         if ( s->sdpinfo || getenv("HIPSDP_LADDER_LOG") != NULL )
+            printf("hipsdp: numerical troubles (status %d) -- solving SDP %d again with %s settings\n", s->info.status, s->sdpcounter,
+               level == 1 ? "medium" : "stable");
       }
    }
 
+   tstage[5] = wallNow();
+   if ( stagetimes )
+      printf("hipsdp stages [ms]: maps %.3f, shape+objective %.3f, blocks %.3f, LP rows + start %.3f, solves + checks %.3f (engine %.3f, %d calls)\n",
+         1e3 * (tstage[1] - tstage[0]), 1e3 * (tstage[2] - tstage[1]), 1e3 * (tstage[3] - tstage[2]), 1e3 * (tstage[4] - tstage[3]),
+         1e3 * (tstage[5] - tstage[4]), 1e3 * s->info.solve_seconds, s->nsdpcalls);
    if ( s->info.status == HIPSDP_STATUS_TIMELIM )
    {
       s->timelimit = TRUE;

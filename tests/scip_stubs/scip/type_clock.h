@@ -1,0 +1,4 @@
+/* test-only stand-in (tests/scip_stubs/README.md) */
+#ifndef HIPSDP_TEST_STUB_TYPE_CLOCK_H
+#define HIPSDP_TEST_STUB_TYPE_CLOCK_H
+#endif

@@ -7,7 +7,7 @@ import numpy as np
 SCIP_OKAY = 1
 SCIP_LPERROR = -6
 SCIP_PARAMETERUNKNOWN = -12
-UNSOLVED = -1
+UNSOLVED, PENALTY, FAST, MEDIUM, STABLE = -1, 0, 1, 2, 3        # SCIP_SDPSOLVERSETTING (type_sdpi.h:69-77)
 
 PD = C.POINTER(C.c_double)
 PI = C.POINTER(C.c_int)
@@ -52,7 +52,7 @@ class SdpiSolver:
     def set_int(self, par, val):
         return self.lib.SCIPsdpiSolverSetIntpar(self.h, par, val)
 
-    def solve(self, P, penaltyparam=0.0, withobj=True, rbound=True, timelimit=1e20, clock=None, start=None):
+    def solve(self, P, penaltyparam=0.0, withobj=True, rbound=True, timelimit=1e20, clock=None, start=None, startsettings=UNSOLVED):
         """P: oracle.sdpi_prepare.Prepared.  Returns (retcode, feasorig, penaltybound).
         start: optional dict(y=[nvars], Z=[(rows, cols, vals)] * (nblocks + 1), X=likewise) in ORIGINAL indices, the last
         entry being the diagonal LP block (sdpisolver.h:160-173)."""
@@ -145,7 +145,7 @@ class SdpiSolver:
             C.c_int(P.nlpcons), _pi(P.lpindchanges), _pd(P.lplhs), _pd(P.lprhs),
             C.c_int(P.lpnnonz), _pi(P.lpbeg), _pi(P.lpind), _pd(P.lpval),
             *startargs,
-            C.c_int(UNSOLVED), C.c_double(timelimit), clock,
+            C.c_int(startsettings), C.c_double(timelimit), clock,
             C.byref(feasorig), C.byref(penaltybound))
         self._P = P
         return rc, bool(feasorig.value), bool(penaltybound.value)
@@ -224,6 +224,9 @@ class SdpiSolver:
         cnt2 = cnt.copy()
         rc = self.lib.SCIPsdpiSolverGetPrimalMatrix(self.h, nb, _pi(cnt2), pr, pc, pv)
         return rc, [(rows[b][:cnt2[b]], cols[b][:cnt2[b]], vals[b][:cnt2[b]]) for b in range(nb)]
+
+    def max_primal_entry(self):
+        return float(self.lib.SCIPsdpiSolverGetMaxPrimalEntry(self.h))
 
     def iterations(self):
         v = C.c_int(0)

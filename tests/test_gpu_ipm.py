@@ -413,6 +413,38 @@ def test_full_size_t1_properties(gpu):
     s.close()
 
 
+def test_full_size_c4_properties(gpu):
+    """BASELINE configs[3] (n = 2000, m = 4000) on ONE device: 128 GB of constraint matrices generated in HBM + their 64 GB packed
+    copy; the W formulation runs in column slices because T and W (2 x 128 GB) do not fit beside them.  About 20 s per solve, so
+    one solve only; size-independent properties: planted optimum on both sides, the y-side acceptance test with its rigorous
+    certificate (hipsdp_check_y: Cholesky of Z(y) - sigma I, exact eigenvalue when that fails), X psd, primal residual."""
+    n, m = 2000, 4000
+    Q, _ = np.linalg.qr(instances.counter_normal(20240 + 1000003, np.arange(n * n, dtype=np.uint64)).reshape(n, n))
+    r = n // 4
+    ev = 1.0 + instances.counter_uniform(20240 + 2000003, np.arange(n, dtype=np.uint64))
+    Xs = (Q * np.where(np.arange(n) < r, ev, 0.0)) @ Q.T
+    Zs = (Q * np.where(np.arange(n) < r, 0.0, ev)) @ Q.T
+    ys = 2.0 * instances.counter_uniform(20240 + 3000003, np.arange(m, dtype=np.uint64)) - 1.0
+    s = gpu.Solver(0)
+    try:
+        s.set_shape(m, [n], 0)
+        b = s.gen_planted(n, m, 20240, Xs, Zs, ys)
+        info = s.solve(gaptol=1e-5, feastol=1e-5)
+        y1, X1 = s.y(), s.X(0)
+        opt = float(b @ ys)
+        assert info.status == 0
+        assert abs(info.dobj - opt) <= TOL * (1 + abs(opt)) and abs(info.pobj - opt) <= TOL * (1 + abs(opt))
+        assert abs(float(b @ y1) - opt) <= TOL * (1 + abs(opt))
+        assert info.pinf <= 1e-5 and info.dabs <= 1e-5 and info.gap <= 1e-5
+        lmin, viol = s.check_y(y1)
+        assert lmin[0] >= -TOL and viol == 0.0
+        assert np.linalg.eigvalsh(X1)[0] >= -TOL
+        assert abs(np.sum(X1 * Zs)) <= 1e-2 * (1 + abs(opt))          # X is (nearly) complementary to the planted Z*
+        assert info.schur_flops / max(info.schur_seconds, 1e-12) > 30e12
+    finally:
+        s.close()
+
+
 def test_w_formulation_in_slices_when_the_workspace_is_small(gpu):
     """when T and W do not fit the workspace budget as a whole (n = 2000, m = 4000 on one GPU: 2 x 128 GB) the engine keeps
     the cheaper W formulation by working through column slices one after the other; forced here with a tiny budget"""

@@ -130,13 +130,17 @@ def test_spmd_copies_of_a_branch_and_bound_run_over_the_solver_interface(gpu, tm
     many = run(world, "s%d" % world)
     assert one["best"] is not None      # example_small has nodes the plain call cannot settle (sdpi.c answers them with the penalty form)
     for r in many:
-        assert r["failed"] == one["failed"] and r["nodes"] == one["nodes"] and r["calls"] == one["calls"], (r["nodes"], one["nodes"])
-        assert abs(r["best"] - one["best"]) <= 1e-7 * max(1.0, abs(one["best"]))
+        # the copies agree with each other to the last bit: same tree, same calls, same iterates
+        assert (r["failed"], r["nodes"], r["calls"], r["iters"]) == (many[0]["failed"], many[0]["nodes"], many[0]["calls"], many[0]["iters"])
+        assert r["y"] == many[0]["y"]
+        assert abs(r["best"] - one["best"]) <= 1e-6 * max(1.0, abs(one["best"]))
         if shard_small:
-            assert abs(r["iters"] - one["iters"]) <= 0.05 * one["iters"]   # the general kernels replace the single-launch small ones
+            # the general kernels replace the single-launch small ones: rounding differs, and the few nodes of example_small whose
+            # optimum is not attained (tau -> 0) may be settled on another rung of the settings ladder or be branched on instead -
+            # the tree may differ by such nodes, the optimum may not
+            assert r["failed"] <= 1 and abs(r["nodes"] - one["nodes"]) <= 4, (r["nodes"], one["nodes"], r["failed"])
         else:
-            assert r["iters"] == one["iters"]                              # replicated small solves: the very same kernels
-        assert r["y"] == many[0]["y"]                                       # the copies agree to the last bit
+            assert (r["failed"], r["nodes"], r["calls"], r["iters"]) == (one["failed"], one["nodes"], one["calls"], one["iters"])
 
 
 @pytest.mark.parametrize("load", ["gen", "vars-gen"])

@@ -127,4 +127,4 @@ def test_bnb_with_the_full_driver_per_node(gpu, name, optimum):
         return
     assert best is not None and abs(best - optimum) <= 1e-4 * max(1.0, abs(optimum))
     assert all(abs(y[v] - round(y[v])) <= 1e-9 for v in inst.intvars)
-    assert failed <= max(2, nodes // 20)
+    assert failed <= 1                 # measured: 0 on all five instances
