@@ -264,6 +264,17 @@ def potrf(A, device=0):
     return np.tril(L), fail.value
 
 
+def potrf_ex(A, psd=False, v1=False, device=0):
+    """blocked Cholesky in either form -> (L with the untouched upper part as stored, dinv, regmask, fail)"""
+    L = _f64(A).copy()
+    n = L.shape[0]
+    dinv = np.zeros(((n + 63) // 64) * 4096)
+    mask = np.zeros(n, dtype=np.int32)
+    fail = C.c_int(0)
+    _chk(lib().hipsdp_potrf_ex(device, n, _dp(L), int(psd), int(v1), _dp(dinv), _ip(mask), C.byref(fail)), "hipsdp_potrf_ex")
+    return L, dinv, mask, fail.value
+
+
 def potrs(A, rhs, device=0):
     A = _f64(A)
     r = _f64(rhs).copy()

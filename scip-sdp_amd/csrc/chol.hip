@@ -48,7 +48,7 @@ typedef double v4dc __attribute__((ext_vector_type(4)));
 
 #define PD_LD (NB + 2)
 #define PD_COLP (2 * 2 * 4 * 18)
-#define PD_SMEM_BYTES ((PD_COLP + 2 * NB * PD_LD + 2 * NB) * (int) sizeof(double))
+#define PD_SMEM_BYTES ((PD_COLP + 2 * NB * PD_LD + 3 * NB) * (int) sizeof(double))
 
 /* optional fused inputs / outputs of a single-block factorization (n <= 64; everything NULL for the blocked driver):
  * the matrix is base + alpha * dir (full symmetric storage, ld = lda) and is also stored to Mout; L gets a zero upper
@@ -65,11 +65,15 @@ struct pd_ext
                               * of recording a failure into a flag that somebody cleared beforehand */
    int           rule;      /* 0: forced pivots keep their column, 1: forced columns are zeroed, 2: zeroed when the pivot was <= 0 */
    int*          regmask;   /* semidefinite mode: regmask[j0 + k] = 1 when the pivot of column k was forced (may be NULL) */
+   int           from_lds;  /* 1 (k_potrf_step): the block to factor sits in the LDS tile that later holds inv(L), not in global memory */
+   int           nostore;   /* 1 (k_potrf_step, all workgroups but the first): L, inv(L), flag and mask stay in LDS / registers */
+   double*       Lout;      /* k_potrf_step: where the owner stores L_kk (64 x 64 staging block, ld 64) instead of the matrix itself: the
+                             * other step workgroups of the launch still read the unfactored block from the matrix */
 };
 
 template<int NBK>      /* padded block size actually processed: 16, 32 or 64 (tiny blocks skip the identity padding) */
-__global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ A, long long lda, int nb, int j0,
-   double* __restrict__ dinv, int* __restrict__ flag, const double* __restrict__ diag0, double regtol, pd_ext ext)
+__device__ __forceinline__ void pd_body(double* __restrict__ A, long long lda, int nb, int j0,
+   double* __restrict__ dinv, int* __restrict__ flag, const double* __restrict__ diag0, double regtol, const pd_ext& ext)
 {
    extern __shared__ __attribute__((aligned(16))) double pd_smem[];
    double (*colp)[2][4][18] = reinterpret_cast<double (*)[2][4][18]>(pd_smem);            /* columns k, k + 1, permuted: row i at [i & 3][i >> 2]; two buffers */
@@ -77,6 +81,7 @@ __global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ A, long
    double (*X)[PD_LD] = reinterpret_cast<double (*)[PD_LD]>(pd_smem + PD_COLP + NB * PD_LD);   /* inv(L), row major */
    double* invd = pd_smem + PD_COLP + 2 * NB * PD_LD;
    double* d0s = invd + NB;
+   double* forced = d0s + NB;          /* 1.0 where the pivot of the column was forced and its column zeroed (semidefinite mode) */
    const int tid = threadIdx.x;
    const int lane = tid & 63;
    const int wave = tid >> 6;
@@ -102,6 +107,8 @@ __global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ A, long
                ext.Mout[(long long) j * lda + i] = v;
             }
          }
+         else if ( ext.from_lds )
+            v = X[i][j];
          else
             v = A[(long long) i * lda + j];
       }
@@ -193,10 +200,15 @@ __global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ A, long
       const double li1 = (i > k + 1) ? fma(-li0, l10, ci1) * e1 : 0.0;
       const double u = li1 * e1;
       const double al = fma(-u * l10, e0, li0 * e0);
-      if ( ext.regmask != NULL && tid == 0 )
+      if ( tid == 0 )
       {
-         if ( k < nb ) ext.regmask[j0 + k] = reg0 ? 1 : 0;
-         if ( k + 1 < nb ) ext.regmask[j0 + k + 1] = reg1 ? 1 : 0;
+         forced[k] = reg0 ? 1.0 : 0.0;
+         forced[k + 1] = reg1 ? 1.0 : 0.0;
+         if ( ext.regmask != NULL && !ext.nostore )
+         {
+            if ( k < nb ) ext.regmask[j0 + k] = reg0 ? 1 : 0;
+            if ( k + 1 < nb ) ext.regmask[j0 + k + 1] = reg1 ? 1 : 0;
+         }
       }
       if ( jc == (k & 3) )
       {
@@ -233,16 +245,21 @@ __global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ A, long
    __syncthreads();
 
    /* write L back */
+   if ( !ext.nostore )
+   {
+   double* Lw = ext.Lout != NULL ? ext.Lout : A;
+   const long long ldw = ext.Lout != NULL ? NB : lda;
 #pragma unroll
    for (int jj = 0; jj < 16; ++jj)
    {
       const int j = jc + 4 * jj;
       if ( i < nb && j <= i )
-         A[(long long) i * lda + j] = r[jj];
+         Lw[(long long) i * ldw + j] = r[jj];
       else if ( ext.base != NULL && i < nb && j < nb )
-         A[(long long) i * lda + j] = 0.0;
+         Lw[(long long) i * ldw + j] = 0.0;
    }
-   if ( tid == 0 )
+   }
+   if ( tid == 0 && !ext.nostore )
    {
       if ( ext.set_flag )
          *flag = bad;
@@ -309,6 +326,7 @@ __global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ A, long
       __syncthreads();
    }
    /* inv(L), identity padded, block upper triangle zero */
+   if ( !ext.nostore )
    for (int e = tid; e < NB * NB; e += 256)
    {
       const int rr = e >> 6, cc = e & 63;
@@ -333,6 +351,238 @@ __global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ A, long
          ext.Gram[e] = acc;
       }
    }
+}
+
+template<int NBK>
+__global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ A, long long lda, int nb, int j0,
+   double* __restrict__ dinv, int* __restrict__ flag, const double* __restrict__ diag0, double regtol, pd_ext ext)
+{
+   pd_body<NBK>(A, lda, nb, j0, dinv, flag, diag0, regtol, ext);
+}
+
+/* ---- one block column of the blocked factorization in ONE launch -------------------------------------------------------
+ * Launch kb of hs_potrf_psd (n > 64).  Two kinds of workgroups that do not depend on each other:
+ *  - step workgroups (one per 64-row block of block column kb, the first one owns the diagonal block): apply the rank-64 update
+ *    from block column kb - 1 to their own block and to the diagonal block, factor and invert the diagonal block (every step
+ *    workgroup does that for itself: 64 x 64 work, identical bits, and nobody waits for anybody), form their panel block
+ *    P = B inv(L_kk)^T on the matrix cores, zero the columns of forced pivots (semidefinite mode) and store it;
+ *  - trailing workgroups (one per lower 64 x 64 tile right of block column kb): the update A_ij -= P_i P_j^T from block column
+ *    kb - 1, which the previous launch finished.  Column kb itself is left out - the step workgroups have just done it.
+ * So a block column costs one launch (diagonal kernel, panel GEMM, mask kernel and trailing GEMM before), and the trailing
+ * update of a column runs beside the next column's diagonal factorization instead of in front of it.
+ * The owner must not put L_kk into the matrix while other step workgroups of the same launch may still have to read the
+ * unfactored block (workgroups of a launch start whenever the device has room): it writes L_kk to a staging block behind the
+ * inverses (dinv holds 2 * ceil(n / 64) blocks) and the owner of the NEXT launch moves it into the matrix; the last block column
+ * has no other readers and is written directly.  Every output element
+ * sees the same operations in the same order as in the four-launch form: identical bits (tests/test_gpu_units.py). */
+__device__ __forceinline__ void ps_load_tile(const double* __restrict__ src, long long lda, int rows, double (*dst)[PD_LD])
+{
+   /* 64 x 64 block at src (rows valid, the rest zero) -> LDS tile; 256 threads; all loads of a thread are issued before its stores */
+   double v0[8], v1[8];
+#pragma unroll
+   for (int q = 0; q < 8; ++q)
+   {
+      const int e = threadIdx.x + 256 * q;
+      const int r = e >> 5, c = (e & 31) * 2;
+      v0[q] = 0.0; v1[q] = 0.0;
+      if ( r < rows )
+      {
+         v0[q] = src[(long long) r * lda + c];
+         v1[q] = src[(long long) r * lda + c + 1];
+      }
+   }
+#pragma unroll
+   for (int q = 0; q < 8; ++q)
+   {
+      const int e = threadIdx.x + 256 * q;
+      const int r = e >> 5, c = (e & 31) * 2;
+      dst[r][c] = v0[q];
+      dst[r][c + 1] = v1[q];
+   }
+}
+
+/* acc[t][.] (rows 16 wave .. + 15, column tile t) = sum_k Ta[row][k] Tb[col][k], k ascending in steps of 4 up to klim[t] */
+template<bool LOWTRI>
+__device__ __forceinline__ void ps_mma(const double (*Ta)[PD_LD], const double (*Tb)[PD_LD], int wave, int lane, v4dc* acc)
+{
+   const int lr = lane & 15, lk = lane >> 4;
+   /* the left operand of the wave (16 rows x 64) is read once and serves the four column tiles; fully unrolled, so that the
+    * LDS reads run ahead of the dependent MFMA chains */
+   double a[16];
+#pragma unroll
+   for (int sidx = 0; sidx < 16; ++sidx)
+      a[sidx] = Ta[16 * wave + lr][4 * sidx + lk];
+#pragma unroll
+   for (int t = 0; t < 4; ++t)
+   {
+      v4dc a4 = (v4dc){0.0, 0.0, 0.0, 0.0};
+      /* Tb block lower triangular (LOWTRI): Tb[col][k] = 0 for k beyond the column's 16-block */
+#pragma unroll
+      for (int sidx = 0; sidx < (LOWTRI ? 4 * (t + 1) : 16); ++sidx)
+      {
+         const double b = Tb[16 * t + lr][4 * sidx + lk];
+         a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[sidx], b, a4, 0, 0, 0);
+      }
+      acc[t] = a4;
+   }
+}
+
+template<int NBK>
+__global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, long long lda, int n, int kb, int nblk,
+   double* __restrict__ dinv, int* __restrict__ flag, const double* __restrict__ diag0, double regtol, pd_ext ext)
+{
+   extern __shared__ __attribute__((aligned(16))) double pd_smem[];
+   double* lstage = dinv + (long long) nblk * NB * NB;                                              /* staged L_kk blocks */
+   double (*bufA)[PD_LD] = reinterpret_cast<double (*)[PD_LD]>(pd_smem + PD_COLP);                 /* = lmT of the factorization */
+   double (*bufB)[PD_LD] = reinterpret_cast<double (*)[PD_LD]>(pd_smem + PD_COLP + NB * PD_LD);     /* = X (inverse) */
+   const double* forced = pd_smem + PD_COLP + 2 * NB * PD_LD + 2 * NB;
+   const int tid = threadIdx.x, lane = tid & 63;
+   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+   const int lr = lane & 15, lk = lane >> 4;
+   const int nS = nblk - kb;
+   const int j0 = kb * NB;
+   v4dc acc[4];
+
+   if ( (int) blockIdx.x >= nS )
+   {
+      /* trailing tile (bi, bj), kb + 1 <= bj <= bi < nblk, updated from block column kb - 1 */
+      const int tt = (int) blockIdx.x - nS;
+      int ti = (int) ((sqrt(8.0 * (double) tt + 1.0) - 1.0) * 0.5);
+      while ( (ti + 1) * (ti + 2) / 2 <= tt ) ++ti;
+      while ( ti * (ti + 1) / 2 > tt ) --ti;
+      const int tj = tt - ti * (ti + 1) / 2;
+      const int bi = kb + 1 + ti, bj = kb + 1 + tj;
+      const int ri = min(NB, n - bi * NB), rj = min(NB, n - bj * NB);
+      const double* Pi = A + (long long) bi * NB * lda + (j0 - NB);
+      const double* Pj = A + (long long) bj * NB * lda + (j0 - NB);
+      ps_load_tile(Pi, lda, ri, bufA);
+      if ( bi != bj )
+         ps_load_tile(Pj, lda, rj, bufB);
+      __syncthreads();
+      ps_mma<false>(bufA, bi != bj ? bufB : bufA, wave, lane, acc);
+      double* C = A + (long long) bi * NB * lda + (long long) bj * NB;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+         for (int rr = 0; rr < 4; ++rr)
+         {
+            const int row = 16 * wave + lk + 4 * rr, col = 16 * t + lr;
+            if ( row < ri && col < rj )
+            {
+               double* c = C + (long long) row * lda + col;
+               double v = -acc[t][rr];
+               v += *c;
+               *c = v;
+            }
+         }
+      return;
+   }
+
+   /* ---- step workgroup of block row rb */
+   const int rb = kb + (int) blockIdx.x;
+   const int r0 = rb * NB;
+   const int nb = min(NB, n - j0);
+   const int rows = min(NB, n - r0);
+   double* Akk = A + (long long) j0 * lda + j0;
+   double* Ark = A + (long long) r0 * lda + j0;
+   v4dc accB[4];
+#pragma unroll
+   for (int t = 0; t < 4; ++t)
+      accB[t] = (v4dc){0.0, 0.0, 0.0, 0.0};
+   bool from_lds = false;
+   if ( kb > 0 && blockIdx.x == 0 )
+   {
+      /* the factor of the previous diagonal block moves from its staging block into the matrix (nobody reads that block now) */
+      const double* src = lstage + (long long) (kb - 1) * NB * NB;
+      double* dst = A + (long long) (j0 - NB) * lda + (j0 - NB);
+      for (int e = tid; e < NB * NB; e += 256)
+      {
+         const int r = e >> 6, c = e & 63;
+         if ( c <= r )
+            dst[(long long) r * lda + c] = src[e];
+      }
+   }
+   if ( kb > 0 )
+   {
+      ps_load_tile(Akk - NB, lda, nb, bufA);                    /* P_k: block (kb, kb - 1) */
+      if ( blockIdx.x > 0 )
+         ps_load_tile(Ark - NB, lda, rows, bufB);              /* P_r: block (rb, kb - 1) */
+      __syncthreads();
+      ps_mma<false>(bufA, bufA, wave, lane, acc);               /* P_k P_k^T */
+      if ( blockIdx.x > 0 )
+         ps_mma<false>(bufB, bufA, wave, lane, accB);           /* P_r P_k^T */
+      __syncthreads();
+      /* updated diagonal block -> the tile the factorization reads */
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+         for (int rr = 0; rr < 4; ++rr)
+         {
+            const int row = 16 * wave + lk + 4 * rr, col = 16 * t + lr;
+            double v = 0.0;
+            if ( row < nb && col <= row )
+            {
+               v = -acc[t][rr];
+               v += Akk[(long long) row * lda + col];
+            }
+            bufB[row][col] = v;
+         }
+      __syncthreads();
+      from_lds = true;
+   }
+   pd_ext e2 = ext;
+   e2.from_lds = from_lds ? 1 : 0;
+   e2.nostore = blockIdx.x > 0 ? 1 : 0;
+   e2.Lout = (nS > 1) ? lstage + (long long) kb * NB * NB : NULL;
+   pd_body<NBK>(Akk, lda, nb, j0, dinv + (long long) kb * NB * NB, flag, diag0, regtol, e2);
+   if ( blockIdx.x == 0 )
+      return;
+   /* ---- panel block: B = A_rk - P_r P_k^T (accB), P = B inv(L_kk)^T, forced columns zeroed */
+   __syncthreads();
+#pragma unroll
+   for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+      {
+         const int row = 16 * wave + lk + 4 * rr, col = 16 * t + lr;
+         double v = 0.0;
+         if ( row < rows )
+         {
+            v = -accB[t][rr];
+            v += Ark[(long long) row * lda + col];
+         }
+         bufA[row][col] = v;
+      }
+   __syncthreads();
+   ps_mma<true>(bufA, bufB, wave, lane, acc);
+#pragma unroll
+   for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+      {
+         const int row = 16 * wave + lk + 4 * rr, col = 16 * t + lr;
+         if ( row < rows )
+            Ark[(long long) row * lda + col] = forced[col] != 0.0 ? 0.0 : acc[t][rr];
+      }
+}
+
+template<int NBK>
+static int launch_potrf_step(hipStream_t s, double* A, long long lda, int n, int kb, int nblk, double* dinv, int* flag,
+   const double* diag0, const pd_ext& ext)
+{
+   static bool attr_set = false;
+   if ( !attr_set )
+   {
+      HS_HIP( hipFuncSetAttribute(reinterpret_cast<const void*>(&k_potrf_step<NBK>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            PD_SMEM_BYTES) );
+      attr_set = true;
+   }
+   const int nS = nblk - kb;
+   const int t = nblk - kb - 1;
+   const int nT = kb > 0 ? t * (t + 1) / 2 : 0;
+   hipLaunchKernelGGL((k_potrf_step<NBK>), dim3(nS + nT), dim3(256), PD_SMEM_BYTES, s, A, lda, n, kb, nblk, dinv, flag, diag0, 1e-13, ext);
+   HS_LAUNCH_CHECK();
+   return HS_OK;
 }
 
 template<int NBK>
@@ -382,6 +632,18 @@ __global__ void k_zero_forced_cols(int rows, int nb, double* __restrict__ P, lon
    }
 }
 
+/* test hook (hipsdp_potrf_selfcheck): 1 routes the blocked factorization through the four-launch form */
+static int g_potrf_force_v1 = 0;
+int hs_potrf_force_v1(int on) { const int old = g_potrf_force_v1; g_potrf_force_v1 = on; return old; }
+
+/* doubles the dinv argument of hs_potrf / hs_potrf_psd must hold: the inverses of the ceil(n / 64) diagonal blocks and, for
+ * n > 64, as many staging blocks of the fused block-column kernel */
+long long hs_potrf_dinv_len(int n)
+{
+   const long long nblk = n > 0 ? (n + NB - 1) / NB : 1;
+   return (nblk > 1 ? 2 : 1) * nblk * NB * NB;
+}
+
 int hs_potrf(hipStream_t s, int n, double* A, double* dinv, int* flag, const double* diag0)
 {
    return hs_potrf_psd(s, n, A, dinv, flag, diag0, NULL, 0);
@@ -399,6 +661,23 @@ int hs_potrf_psd(hipStream_t s, int n, double* A, double* dinv, int* flag, const
    const pd_ext* extp = ((diag0 != NULL && regmask != NULL) || ext.set_flag) ? &ext : NULL;
    const long long lda = n;
    const int nblk = (n + NB - 1) / NB;
+   static int v1 = getenv("HIPSDP_POTRF_V1") != NULL ? atoi(getenv("HIPSDP_POTRF_V1")) : 0;
+   if ( nblk > 1 && !v1 && !g_potrf_force_v1 )
+   {
+      /* one launch per block column (k_potrf_step) */
+      pd_ext est = {NULL, NULL, 0.0, NULL, NULL, NULL, 0, rule, (diag0 != NULL) ? regmask : NULL, 0, 0, NULL};
+      for (int b = 0; b < nblk; ++b)
+      {
+         const int nb = (n - b * NB) < NB ? (n - b * NB) : NB;
+         if ( nb <= 16 )
+            HS_CALL( launch_potrf_step<16>(s, A, lda, n, b, nblk, dinv, flag, diag0, est) );
+         else if ( nb <= 32 )
+            HS_CALL( launch_potrf_step<32>(s, A, lda, n, b, nblk, dinv, flag, diag0, est) );
+         else
+            HS_CALL( launch_potrf_step<64>(s, A, lda, n, b, nblk, dinv, flag, diag0, est) );
+      }
+      return HS_OK;
+   }
    for (int b = 0; b < nblk; ++b)
    {
       const int j0 = b * NB;
@@ -417,7 +696,8 @@ int hs_potrf_psd(hipStream_t s, int n, double* A, double* dinv, int* flag, const
          break;
       /* panel: P = A[j1:, j0:j1] * inv(L_jj)^T   (in place: one workgroup column covers all nb columns) */
       double* P = A + (long long) j1 * lda + j0;
-      hs_gemm_args g1 = {rem, nb, nb, HS_KC, HS_KC, P, lda, 0, dj, NB, 0, P, lda, 0, 1.0, 0.0, 1, 0, 1, NULL};
+      /* (the four-launch form keeps the 64 x 64 tile kernel: its summation order is what the fused kernel reproduces bit by bit) */
+      hs_gemm_args g1 = {rem, nb, nb, HS_KC, HS_KC, P, lda, 0, dj, NB, 0, P, lda, 0, 1.0, 0.0, 1, HS_GEMM_TILE64, 1, NULL};
       HS_CALL( hs_dgemm(s, &g1) );
       if ( diag0 != NULL && regmask != NULL )
       {
@@ -428,7 +708,7 @@ int hs_potrf_psd(hipStream_t s, int n, double* A, double* dinv, int* flag, const
       }
       /* trailing update: A22 -= P P^T on the lower triangle */
       double* A22 = A + (long long) j1 * lda + j1;
-      hs_gemm_args g2 = {rem, rem, nb, HS_KC, HS_KC, P, lda, 0, P, lda, 0, A22, lda, 0, -1.0, 1.0, 1, HS_GEMM_LOWER, 1, NULL};
+      hs_gemm_args g2 = {rem, rem, nb, HS_KC, HS_KC, P, lda, 0, P, lda, 0, A22, lda, 0, -1.0, 1.0, 1, HS_GEMM_LOWER | HS_GEMM_TILE64, 1, NULL};
       HS_CALL( hs_dgemm(s, &g2) );
    }
    return HS_OK;
@@ -445,6 +725,24 @@ __global__ void k_copy_block(const double* __restrict__ src, long long lds_, dou
    }
 }
 
+/* all diagonal blocks of Linv in one launch: block b (64 x 64, identity padded in dinv) -> Linv[64 b .., 64 b ..] */
+__global__ void k_copy_diag_blocks(int n, const double* __restrict__ dinv, double* __restrict__ Linv)
+{
+   const int b = blockIdx.x >> 2, part = blockIdx.x & 3;
+   const int i0 = b * NB;
+   const int nb = min(NB, n - i0);
+   for (int e = part * 1024 + threadIdx.x; e < (part + 1) * 1024; e += 256)
+   {
+      const int r = e >> 6, c = e & 63;
+      if ( r < nb && c < nb )
+         Linv[(long long) (i0 + r) * n + i0 + c] = dinv[(long long) b * NB * NB + e];
+   }
+}
+
+/* Linv = L^-1 by recursive doubling: with the inverses of the 64 x 64 diagonal blocks given, level bs = 64, 128, 256, ... joins
+ * neighbouring inverted blocks:  inv [L11 0; L21 L22] = [inv L11, 0; -inv(L22) L21 inv(L11), inv L22].  The pairs of a level are
+ * independent and go through ONE batched product each (plus one for a ragged last pair): 2-4 launches per level, log2(n / 64)
+ * levels, instead of three launches per 64-row block (n = 500: 12 launches instead of 23). */
 int hs_trtri(hipStream_t s, int n, const double* L, const double* dinv, double* Linv, double* tmp)
 {
    if ( n <= 0 )
@@ -452,22 +750,51 @@ int hs_trtri(hipStream_t s, int n, const double* L, const double* dinv, double* 
    const long long ld = n;
    HS_CALL( hs_fill(s, Linv, (long long) n * n, 0.0) );
    const int nblk = (n + NB - 1) / NB;
-   for (int b = 0; b < nblk; ++b)
+   hipLaunchKernelGGL(k_copy_diag_blocks, dim3(4 * nblk), dim3(256), 0, s, n, dinv, Linv);
+   HS_LAUNCH_CHECK();
+   static const bool rowwise = getenv("HIPSDP_TRTRI_V1") != NULL;
+   if ( rowwise )
    {
-      const int i0 = b * NB;
-      const int nb = (n - i0) < NB ? (n - i0) : NB;
-      const double* db = dinv + (long long) b * NB * NB;
-      /* diagonal block */
-      hipLaunchKernelGGL(k_copy_block, dim3(16), dim3(256), 0, s, db, (long long) NB, Linv + (long long) i0 * ld + i0, ld, nb, nb, 1.0);
-      HS_LAUNCH_CHECK();
-      if ( b == 0 )
-         continue;
-      /* tmp[nb x i0] = L[i0:i0+nb, 0:i0] * Linv[0:i0, 0:i0] */
-      hs_gemm_args g1 = {nb, i0, i0, HS_KC, HS_MC, L + (long long) i0 * ld, ld, 0, Linv, ld, 0, tmp, (long long) i0, 0, 1.0, 0.0, 1, 0, 1, NULL};
-      HS_CALL( hs_dgemm(s, &g1) );
-      /* Linv[i0:i0+nb, 0:i0] = - inv(L_bb) * tmp */
-      hs_gemm_args g2 = {nb, i0, nb, HS_KC, HS_MC, db, NB, 0, tmp, (long long) i0, 0, Linv + (long long) i0 * ld, ld, 0, -1.0, 0.0, 1, 0, 1, NULL};
-      HS_CALL( hs_dgemm(s, &g2) );
+      for (int b = 1; b < nblk; ++b)
+      {
+         const int i0 = b * NB;
+         const int nb = (n - i0) < NB ? (n - i0) : NB;
+         const double* db = dinv + (long long) b * NB * NB;
+         /* tmp[nb x i0] = L[i0:i0+nb, 0:i0] * Linv[0:i0, 0:i0] */
+         hs_gemm_args g1 = {nb, i0, i0, HS_KC, HS_MC, L + (long long) i0 * ld, ld, 0, Linv, ld, 0, tmp, (long long) i0, 0, 1.0, 0.0, 1, 0, 1, NULL};
+         HS_CALL( hs_dgemm(s, &g1) );
+         /* Linv[i0:i0+nb, 0:i0] = - inv(L_bb) * tmp */
+         hs_gemm_args g2 = {nb, i0, nb, HS_KC, HS_MC, db, NB, 0, tmp, (long long) i0, 0, Linv + (long long) i0 * ld, ld, 0, -1.0, 0.0, 1, 0, 1, NULL};
+         HS_CALL( hs_dgemm(s, &g2) );
+      }
+      return HS_OK;
+   }
+   for (long long bs = NB; bs < n; bs *= 2)
+   {
+      const long long span = 2 * bs;
+      const int nfull = (int) (n / span);                         /* pairs whose second block has all bs rows */
+      const long long tail = n - (long long) nfull * span;        /* rows after the full pairs */
+      const long long stride = span * (ld + 1);
+      if ( nfull > 0 )
+      {
+         /* tmp_p = L[second, first] Linv[first, first];  Linv[second, first] = - Linv[second, second] tmp_p */
+         hs_gemm_args g1 = {(int) bs, (int) bs, (int) bs, HS_KC, HS_MC, L + bs * ld, ld, stride, Linv, ld, stride, tmp, bs, bs * bs, 1.0, 0.0,
+            nfull, 0, 1, NULL};
+         HS_CALL( hs_dgemm(s, &g1) );
+         hs_gemm_args g2 = {(int) bs, (int) bs, (int) bs, HS_KC, HS_MC, Linv + bs * (ld + 1), ld, stride, tmp, bs, bs * bs, Linv + bs * ld, ld, stride,
+            -1.0, 0.0, nfull, 0, 1, NULL};
+         HS_CALL( hs_dgemm(s, &g2) );
+      }
+      if ( tail > bs )
+      {
+         const long long o = (long long) nfull * span;             /* first row of the ragged pair */
+         const int s2 = (int) (tail - bs);
+         double* tq = tmp + (long long) nfull * bs * bs;
+         hs_gemm_args g1 = {s2, (int) bs, (int) bs, HS_KC, HS_MC, L + (o + bs) * ld + o, ld, 0, Linv + o * (ld + 1), ld, 0, tq, bs, 0, 1.0, 0.0, 1, 0, 1, NULL};
+         HS_CALL( hs_dgemm(s, &g1) );
+         hs_gemm_args g2 = {s2, (int) bs, s2, HS_KC, HS_MC, Linv + (o + bs) * (ld + 1), ld, 0, tq, bs, 0, Linv + (o + bs) * ld + o, ld, 0, -1.0, 0.0, 1, 0, 1, NULL};
+         HS_CALL( hs_dgemm(s, &g2) );
+      }
    }
    return HS_OK;
 }

@@ -464,6 +464,16 @@ int hs_dgemm(hipStream_t stream, const hs_gemm_args* a)
    if ( (a->flags & HS_GEMM_REMAP) && (a->flags & HS_GEMM_LOWER) && a->M != a->N )
       return HS_ERR_ARG;
 
+   /* few tiles, no split-K: the latency-oriented 32 x 32 kernel (dgemm3.hip) */
+   if ( a->splitk <= 1 )
+   {
+      const int r3 = hs_dgemm3_try(stream, a);
+      if ( r3 < 0 )
+         return -r3;
+      if ( r3 == 1 )
+         return HS_OK;
+   }
+
    /* tile choice: big tiles once they fill the chip, small tiles otherwise */
    const long long big = (long long) ((a->M + 127) / 128) * ((a->N + 127) / 128) * (a->splitk > 1 ? a->splitk : a->batch);
    const bool useBig = (big >= 192 || (a->flags & HS_GEMM_XCD)) && !(a->flags & HS_GEMM_TILE64);

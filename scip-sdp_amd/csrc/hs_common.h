@@ -88,6 +88,11 @@ int hs_dgemm(hipStream_t stream, const hs_gemm_args* args);
 int hs_dgemm2_try(hipStream_t stream, const hs_gemm_args* args, int kchunk);
 int hs_dgemm2_enable(int on);
 
+/* latency-oriented 32 x 32 kernel with the K split inside the workgroup (dgemm3.hip) for products of few tiles: 1 launched,
+ * 0 not eligible, < 0 error (negated code); hs_dgemm tries it first for products without split-K */
+int hs_dgemm3_try(hipStream_t stream, const hs_gemm_args* args);
+int hs_dgemm3_enabled(void);
+
 /* choose a split-K factor for a [M x N x K] product so that at least ~2 waves of workgroups exist */
 int hs_dgemm_pick_splitk(int M, int N, int K, int lowerOnly);
 

@@ -114,10 +114,11 @@ int  hs_allgather(void* comm, const double* send, double* recv, long long count_
 /* ---- chol.hip ------------------------------------------------------------------------------------------------- */
 /* In-place blocked Cholesky of the lower triangle of the row-major n x n matrix A (lda = n): A = L L^T, L stored in the
  * lower triangle (upper triangle is left untouched).  dinv receives the inverses of the 64 x 64 diagonal blocks of L
- * (ceil(n/64) * 64 * 64 doubles).  *flag (device int) is set to 1 + index of the first non-positive pivot.
+ * (ceil(n/64) * 64 * 64 doubles; the buffer must hold hs_potrf_dinv_len(n) doubles).  *flag (device int) is set to 1 + index of the first non-positive pivot.
  * diag0 == NULL: strict (definite) mode.  diag0 != NULL (the n original diagonal entries): semidefinite mode, pivots
  * below 1e-13 * diag0[k] are replaced by 1e-13 * diag0[k] and no failure is flagged. */
 int hs_potrf(hipStream_t s, int n, double* A, double* dinv, int* flag, const double* diag0);
+long long hs_potrf_dinv_len(int n);         /* doubles dinv must hold (inverses + staging blocks of the fused block-column kernel) */
 /* set_flag: the (single-launch, n <= 64) factorization stores its result into *flag instead of recording a failure into a
  * cleared flag - for callers where it is the only writer of that flag between two reads */
 int hs_potrf_psd(hipStream_t s, int n, double* A, double* dinv, int* flag, const double* diag0, int* regmask, int set_flag);

@@ -477,7 +477,7 @@ extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int*
          &R.dX, &R.dZ, &R.E, &R.W, &R.T1, &R.Xs, &R.Zs, &R.T2, &R.W2};
       for (double** pm : mats)
          HS_CALL( dalloc(pm, n2) );
-      const long long nd = (long long) ((B.n + 63) / 64) * 64 * 64;
+      const long long nd = hs_potrf_dinv_len(B.n);
       HS_CALL( dalloc(&R.dinvz, nd) );
       HS_CALL( dalloc(&R.dinvx, nd) );
       R.Lp = (((long long) B.n * (B.n + 1) / 2) + 1) & ~1LL;
@@ -513,7 +513,7 @@ extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int*
    HS_CALL( dalloc(&s->rhs2, 2LL * m) );
    HS_CALL( dalloc(&s->Mx, (m1 + 32) * m1) );      /* row padding: the 2 G shard chunks may overhang by < 2 G rows */
    HS_CALL( dalloc(&s->Lm, (long long) m * m) );
-   HS_CALL( dalloc(&s->dinvm, (long long) ((m + 63) / 64) * 64 * 64) );
+   HS_CALL( dalloc(&s->dinvm, hs_potrf_dinv_len(m)) );
    HS_CALL( dalloc(&s->Slp, (long long) q * m1) );
    HS_CALL( dalloc(&s->regmask, m) );
    s->nsc = SC_FIXED_END + 8 * (nblocks > 0 ? nblocks : 1) + 8;
@@ -982,7 +982,9 @@ static int gemm_on(hipStream_t st, double* ws, long long wslen, int layA, int la
 {
    int sk = 1;
    const long long tiles = (long long) ((M + 63) / 64) * ((N + 63) / 64);
-   if ( ws != NULL && tiles <= 160 && tiles >= 4 && K >= 192 )
+   /* few tiles: the 32 x 32 kernel with the K split inside the workgroup takes the product (no slabs, no second launch);
+    * HIPSDP_GEMM_SMALL=0 restores the split-K slabs of the 64 x 64 tile kernel */
+   if ( !hs_dgemm3_enabled() && ws != NULL && tiles <= 160 && tiles >= 4 && K >= 192 )
    {
       sk = (int) ((384 + tiles - 1) / tiles);
       if ( sk > K / 64 ) sk = K / 64;
@@ -1435,12 +1437,27 @@ static int apply_A(hipsdp_solver* s, double* const* Vk, const double* vlp, doubl
    return HS_OK;
 }
 
-/* one Newton direction; results in (dy, dyt, SC_DTAU, SC_DKAPPA), B.dX, B.dZ, s->dx, s->dz */
-static int direction(hipsdp_solver* s, double sigma, double eta, double mu, double rg, bool useE, double etk)
+/* the engine's two queues trade places for a while: everything enqueued through s->stream (and its GEMM workspace) goes to the
+ * second queue */
+struct QueueSwap
+{
+   hipsdp_solver* s;
+   explicit QueueSwap(hipsdp_solver* s_) : s(s_) { std::swap(s->stream, s->stream2); std::swap(s->gws1, s->gws2); }
+   ~QueueSwap() { std::swap(s->stream, s->stream2); std::swap(s->gws1, s->gws2); }
+};
+
+/* one Newton direction; results in (dy, dyt, SC_DTAU, SC_DKAPPA), B.dX, B.dZ, s->dx, s->dz.
+ * part 0: all of it.  part 1: only the right-hand side H_k, hl, A(H) and h = A(H) - eta rp (general path; it needs X, Z^-1 and the
+ * residuals but not the Schur matrix, so the predictor's can run on the second queue beside the factorization of M);
+ * part 2: the rest, after a part-1 call with the same arguments. */
+static int direction(hipsdp_solver* s, double sigma, double eta, double mu, double rg, bool useE, double etk, int part = 0)
 {
    const int m = s->m, m1 = s->m + 1, q = s->q;
    const double sigmu = sigma * mu;
    std::vector<double*> Hs;
+   int fusedA = 0;
+   if ( part != 2 )
+   {
    for (auto& B : s->blk)
    {
       const int n = B.n;
@@ -1459,21 +1476,22 @@ static int direction(hipsdp_solver* s, double sigma, double eta, double mu, doub
    }
    if ( q > 0 )
       HS_CALL( hs_lp_dir(s->stream, q, sigmu, eta, s->x, s->z, s->rd, useE ? s->elp : NULL, s->hl) );
-   const int fusedA = apply_A_small(s, Hs.data(), s->hl, s->AH, 1, eta, s->rp, s->u1);
+   fusedA = part == 1 ? 0 : apply_A_small(s, Hs.data(), s->hl, s->AH, 1, eta, s->rp, s->u1);
    if ( fusedA < 0 )
       return -fusedA;
    if ( fusedA == 0 )
       HS_CALL( apply_A(s, Hs.data(), s->hl, s->AH) );
+   if ( fusedA == 0 && m > 0 )
+   {
+      hipLaunchKernelGGL(k_h, g1d(m), dim3(256), 0, s->stream, m, eta, s->AH, s->rp, s->u1);
+      HS_LAUNCH_CHECK();
+   }
+   if ( part == 1 )
+      return HS_OK;
+   }
    const bool fuse_solve = (fusedA == 1) && m > 0 && m <= 64;      /* single-block factor of M: solve, reductions and closing kernel in one launch */
    if ( m > 0 && !fuse_solve )
-   {
-      if ( fusedA == 0 )
-      {
-         hipLaunchKernelGGL(k_h, g1d(m), dim3(256), 0, s->stream, m, eta, s->AH, s->rp, s->u1);
-         HS_LAUNCH_CHECK();
-      }
       HS_CALL( hs_trsv_sync(s->stream, m, s->Lm, s->dinvm, 1, s->u1, m, 3, s->trsv_ws, &s->trsv_epoch) );
-   }
    /* BH = sum <B_k, H_k> + beta^T hl ; wrp ; bu1 */
    hs_red_batch_begin(s->stream);
    if ( fuse_solve )
@@ -1856,8 +1874,18 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
 
    /* ---- residuals of the current iterate: enqueued at the top of an iteration, or (small problems) already at the end of
     * the previous one together with the step's Cholesky check, so that one read-back serves both */
+   /* The dual residual obeys an exact recurrence: dZ is DEFINED as A^T(dy~) + eta Rd, so after the update (y~, Z) += alpha
+    * (dy~, dZ) the new residual is (1 - alpha eta) Rd whatever the quality of dy (forced pivots included), and likewise for the
+    * LP rows.  The general path (blocks above 64 rows: each pass over A is HBM bound, 1 GB at n = 500 / m = 1000) therefore
+    * scales the residual it has instead of sweeping A again; it is recomputed from scratch at the first iteration and whenever
+    * the certificate residuals are needed (tau -> 0 divides the rounding the recurrence carries).  HIPSDP_RD_RECOMPUTE=1: always. */
+   static const bool rd_recompute = getenv("HIPSDP_RD_RECOMPUTE") != NULL && atoi(getenv("HIPSDP_RD_RECOMPUTE")) != 0;
+   bool rd_have = false;             /* Rd / rd hold the residual of SOME iterate: the current one once rd_pending is worked off */
+   bool rd_pending = false;
+   double rd_scale = 1.0;
    auto enqueue_residuals = [&]() -> int
    {
+      const bool recur = rd_have && !want_cert && !rd_recompute;
       hipLaunchKernelGGL(k_make_ext, g1d(m1), dim3(256), 0, st, m, -s->tau, 1.0, s->y, s->yt);
       HS_LAUNCH_CHECK();
       hs_red_batch_begin(st);         /* the reductions of this phase run in one launch, right before the scalars are read */
@@ -1869,7 +1897,10 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       {
          Block& B = s->blk[k];
          const long long n2 = (long long) B.n * B.n;
-         HS_CALL( pass_AT(s, B, s->yt, -1.0, B.Z, B.Rd) );
+         if ( !recur )
+            HS_CALL( pass_AT(s, B, s->yt, -1.0, B.Z, B.Rd) );
+         else if ( rd_pending )
+            HS_CALL( hs_scale_add(st, n2, rd_scale, B.Rd, 0.0, NULL, B.Rd) );
          HS_CALL( hs_dot(st, n2, B.Rd, B.Rd, s->sc + SC_BLK(k, 0), 0, s->red_ws) );
          HS_CALL( hs_dot(st, n2, B.X, B.Z, s->sc + SC_XZ, 1, s->red_ws) );
          if ( want_cert )
@@ -1888,12 +1919,14 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
                (const double*) NULL, (const double*) NULL, s->rd, (double*) NULL);
             HS_LAUNCH_CHECK();
          }
-         else
+         else if ( !recur )
          {
             const double* v = s->yt;
             HS_CALL( hs_gemv_n(st, q, m1, s->Dext, m1, 1, &v, s->tmpq, q, s->gemv_ws, s->gemv_ws_len) );
             HS_CALL( hs_scale_add(st, q, 1.0, s->tmpq, -1.0, s->z, s->rd) );
          }
+         else if ( rd_pending )
+            HS_CALL( hs_scale_add(st, q, rd_scale, s->rd, 0.0, NULL, s->rd) );
          HS_CALL( hs_dot(st, q, s->rd, s->rd, s->sc + SC_RD2, 1, s->red_ws) );
          HS_CALL( hs_absmax(st, q, s->rd, s->sc + SC_RDLPMAX, 0, s->red_ws) );
          HS_CALL( hs_dot(st, q, s->x, s->z, s->sc + SC_XZ, 1, s->red_ws) );
@@ -1923,6 +1956,7 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       HS_CALL( hs_dot(st, m, s->rp, s->rp, s->sc + SC_RP2, 0, s->red_ws) );
       HS_CALL( hs_dot(st, m, s->AX + 1, s->AX + 1, s->sc + SC_HP2, 0, s->red_ws) );
       HS_CALL( hs_dot(st, m, s->b, s->y, s->sc + SC_DOBJ, 0, s->red_ws) );
+      rd_pending = false;
       return HS_OK;
    };
    bool residuals_ready = false;
@@ -1934,11 +1968,46 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
     * result itself and the flags need no clearing */
    const int setf = (small_all && s->blk.size() == 1) ? 1 : 0;
 
+   /* Overlap on the second queue (blocks of at least 128 rows, HIPSDP_ONEQUEUE / HIPSDP_NO_OVERLAP switch it off):
+    *  - the Z chain of the factorization phase (inverse factor, Z^-1) needs nothing from the residual pass, so it is started at
+    *    the top of the iteration and runs beside the residual kernels and the host's read-back of the termination scalars;
+    *  - the predictor's right-hand side (H_k, A(H), h) needs nothing from the Schur matrix, so it runs beside the latency-bound
+    *    factorization of M (one communicator serves one queue: not with several ranks). */
+   static const bool no_overlap = getenv("HIPSDP_NO_OVERLAP") != NULL;
+   bool zchain_queued = false;
+   auto enqueue_z_chains = [&]() -> int
+   {
+      hipStream_t st2 = s->stream2;
+      for (auto& B : s->blk)
+      {
+         const int n = B.n;
+         const long long n2 = (long long) n * n;
+         if ( n <= 64 )
+            continue;
+         if ( !factors_valid )
+         {
+            HS_CALL( hs_copy(st2, B.Lz, B.Z, n2) );
+            HS_CALL( hs_potrf(st2, n, B.Lz, B.dinvz, s->flags + 0, NULL) );
+         }
+         HS_CALL( hs_trtri(st2, n, B.Lz, B.dinvz, B.LzInv, B.T2) );
+         HS_CALL( gemm_on(st2, s->gws2, s->gws_len, HS_MC, HS_MC, n, n, n, 1.0, B.LzInv, n, B.LzInv, n, 0.0, B.Zinv, n, HS_GEMM_LOWER) );
+         HS_CALL( hs_mirror_lower(st2, B.Zinv, n, n) );
+      }
+      return HS_OK;
+   };
+
    for (it = 0; it <= maxiter; ++it)
    {
       if ( !residuals_ready )
       {
          phase_mark(s, PH_RESID);
+         if ( s->use2 && !no_overlap && !zchain_queued && K > 0 )
+         {
+            HS_HIP( hipMemsetAsync(s->flags, 0, 8 * sizeof(int), st) );
+            HS_CALL( fork2(s) );
+            HS_CALL( enqueue_z_chains() );
+            zchain_queued = true;
+         }
          HS_CALL( enqueue_residuals() );
          HS_CALL( read_scalars(s, hs, NULL) );
       }
@@ -2083,9 +2152,12 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
 
       /* ---- factorizations (the factors of an accepted step are re-used: they were computed by its Cholesky check) */
       phase_mark(s, PH_FACTOR);
-      if ( !(setf && m <= 64) )
-         HS_HIP( hipMemsetAsync(s->flags, 0, 8 * sizeof(int), st) );
-      HS_CALL( fork2(s) );
+      if ( !zchain_queued )
+      {
+         if ( !(setf && m <= 64) )
+            HS_HIP( hipMemsetAsync(s->flags, 0, 8 * sizeof(int), st) );
+         HS_CALL( fork2(s) );
+      }
       for (auto& B : s->blk)
       {
          const int n = B.n;
@@ -2108,7 +2180,9 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
             }
             continue;
          }
-         /* Z chain on the second queue */
+         /* Z chain on the second queue (already under way when it was started at the top of the iteration) */
+         if ( !zchain_queued )
+         {
          if ( !factors_valid )
          {
             HS_CALL( hs_copy(st2, B.Lz, B.Z, n2) );
@@ -2117,6 +2191,7 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
          HS_CALL( hs_trtri(st2, n, B.Lz, B.dinvz, B.LzInv, B.T2) );
          HS_CALL( gemm_on(st2, s->gws2, s->gws_len, HS_MC, HS_MC, n, n, n, 1.0, B.LzInv, n, B.LzInv, n, 0.0, B.Zinv, n, HS_GEMM_LOWER) );
          HS_CALL( hs_mirror_lower(st2, B.Zinv, n, n) );
+         }
          /* X chain on the first */
          if ( !factors_valid )
          {
@@ -2127,6 +2202,7 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
          HS_CALL( hs_trtri(st, n, B.Lx, B.dinvx, B.LxInv, B.T1) );
       }
       HS_CALL( join2(s) );
+      zchain_queued = false;
 
       /* ---- Schur complement (extended by the constant matrix as "variable 0") */
       phase_mark(s, PH_SCHUR);
@@ -2228,6 +2304,16 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       HS_HIP( hipEventRecord(s->ev1, st) );
       hs_comm_phase(2);
       phase_mark(s, PH_MSOLVE);
+      bool predH_queued = false;
+      if ( s->use2 && !no_overlap && s->comm == NULL && !small_problem(s) && m > 0 )
+      {
+         HS_CALL( fork2(s) );
+         {
+            QueueSwap sw(s);
+            HS_CALL( direction(s, 0.0, 1.0, mu, rg, false, 0.0, 1) );
+         }
+         predH_queued = true;
+      }
       if ( m > 0 )
       {
          if ( !schur_small )
@@ -2279,7 +2365,9 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
 
       /* ---- predictor */
       phase_mark(s, PH_PRED);
-      HS_CALL( direction(s, 0.0, 1.0, mu, rg, false, 0.0) );
+      if ( predH_queued )
+         HS_CALL( join2(s) );
+      HS_CALL( direction(s, 0.0, 1.0, mu, rg, false, 0.0, predH_queued ? 2 : 0) );
       HS_CALL( steplen_enqueue(s) );
       HS_CALL( read_scalars(s, hs, hflags) );
       {
@@ -2475,6 +2563,11 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
          s->tau += alpha * dt;
          s->kappa += alpha * dk;
          alpha_last = alpha;
+         /* the residual the next iteration starts from: (1 - alpha eta) times the one this iteration used (general path only:
+          * the single-launch kernels of small problems recompute it inside the fused launches) */
+         rd_have = !small_problem(s);
+         rd_pending = rd_have;
+         rd_scale = 1.0 - alpha * eta;
       }
    }
 

@@ -284,7 +284,7 @@ extern "C" int hipsdp_schur_w(int device, int m1, int n, const double* A, const 
    DevBuf dA, dX, dZ, dG, dT, dM, dD;
    int* dflag = NULL;
    HS_CALL( dA.alloc(m1 * n2) ); HS_CALL( dX.alloc(n2) ); HS_CALL( dZ.alloc(n2) ); HS_CALL( dG.alloc(n2) ); HS_CALL( dT.alloc(n2) );
-   HS_CALL( dM.alloc((long long) m1 * m1) ); HS_CALL( dD.alloc((long long) ((n + 63) / 64) * 4096) );
+   HS_CALL( dM.alloc((long long) m1 * m1) ); HS_CALL( dD.alloc(hs_potrf_dinv_len(n)) );
    HS_HIP( hipMalloc((void**) &dflag, sizeof(int)) );
    HS_HIP( hipMemset(dflag, 0, sizeof(int)) );
    HS_CALL( dA.up(A, m1 * n2) ); HS_CALL( dX.up(X, n2) ); HS_CALL( dZ.up(Z, n2) );
@@ -311,7 +311,7 @@ extern "C" int hipsdp_potrf(int device, int n, double* A, int* fail)
    const long long n2 = (long long) n * n;
    DevBuf dA, dD;
    int* dflag = NULL;
-   HS_CALL( dA.alloc(n2) ); HS_CALL( dD.alloc((long long) ((n + 63) / 64) * 4096) );
+   HS_CALL( dA.alloc(n2) ); HS_CALL( dD.alloc(hs_potrf_dinv_len(n)) );
    HS_HIP( hipMalloc((void**) &dflag, sizeof(int)) );
    HS_HIP( hipMemset(dflag, 0, sizeof(int)) );
    HS_CALL( dA.up(A, n2) );
@@ -326,6 +326,43 @@ extern "C" int hipsdp_potrf(int device, int n, double* A, int* fail)
    return HIPSDP_OK;
 }
 
+int hs_potrf_force_v1(int on);
+
+/* test entry: the blocked factorization in both forms (v1 = 1: diagonal kernel + panel GEMM + mask kernel + trailing GEMM per
+ * block column; 0: one fused launch per block column), optionally in semidefinite mode (diag0 = the matrix diagonal, forced
+ * pivots reported in regmask[n]); dinv: ceil(n / 64) * 4096 doubles (inverses of the diagonal blocks) */
+extern "C" int hipsdp_potrf_ex(int device, int n, double* A, int psd, int v1, double* dinv, int* regmask, int* fail)
+{
+   HS_CALL( pick_device(device) );
+   if ( n <= 0 ) return HIPSDP_ERR_ARG;
+   const long long n2 = (long long) n * n;
+   const long long nd = (long long) ((n + 63) / 64) * 4096;
+   DevBuf dA, dD, dG;
+   int* dint = NULL;
+   HS_CALL( dA.alloc(n2) ); HS_CALL( dD.alloc(hs_potrf_dinv_len(n)) ); HS_CALL( dG.alloc(n) );
+   HS_HIP( hipMalloc((void**) &dint, (size_t) (n + 1) * sizeof(int)) );
+   HS_HIP( hipMemset(dint, 0, (size_t) (n + 1) * sizeof(int)) );
+   HS_HIP( hipMemset(dD.p, 0, (size_t) nd * sizeof(double)) );
+   HS_CALL( dA.up(A, n2) );
+   std::vector<double> dg(n);
+   for (int i = 0; i < n; ++i) dg[i] = A[(long long) i * n + i];
+   HS_CALL( dG.up(dg.data(), n) );
+   const int old = hs_potrf_force_v1(v1);
+   int rc = hs_potrf_psd(0, n, dA.p, dD.p, dint, psd ? dG.p : NULL, psd ? dint + 1 : NULL, 0);
+   (void) hs_potrf_force_v1(old);
+   if ( rc == HS_OK && hipDeviceSynchronize() != hipSuccess ) rc = HS_ERR_HIP;
+   std::vector<int> hint(n + 1, 0);
+   if ( rc == HS_OK && hipMemcpy(hint.data(), dint, (size_t) (n + 1) * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ) rc = HS_ERR_HIP;
+   (void) hipFree(dint);
+   HS_CALL( rc );
+   HS_CALL( dA.down(A, n2) );
+   if ( dinv != NULL ) HS_CALL( dD.down(dinv, nd) );
+   if ( fail != NULL ) *fail = hint[0];
+   if ( regmask != NULL )
+      for (int i = 0; i < n; ++i) regmask[i] = hint[1 + i];
+   return HIPSDP_OK;
+}
+
 extern "C" int hipsdp_potrs(int device, int n, const double* A, int nrhs, double* rhs)
 {
    HS_CALL( pick_device(device) );
@@ -333,7 +370,7 @@ extern "C" int hipsdp_potrs(int device, int n, const double* A, int nrhs, double
    const long long n2 = (long long) n * n;
    DevBuf dA, dD, dR;
    int* dflag = NULL;
-   HS_CALL( dA.alloc(n2) ); HS_CALL( dD.alloc((long long) ((n + 63) / 64) * 4096) ); HS_CALL( dR.alloc((long long) nrhs * n) );
+   HS_CALL( dA.alloc(n2) ); HS_CALL( dD.alloc(hs_potrf_dinv_len(n)) ); HS_CALL( dR.alloc((long long) nrhs * n) );
    HS_HIP( hipMalloc((void**) &dflag, sizeof(int)) );
    HS_HIP( hipMemset(dflag, 0, sizeof(int)) );
    HS_CALL( dA.up(A, n2) ); HS_CALL( dR.up(rhs, (long long) nrhs * n) );
@@ -361,7 +398,7 @@ extern "C" int hipsdp_trtri(int device, int n, const double* A, double* Linv)
    const long long n2 = (long long) n * n;
    DevBuf dA, dD, dL, dT;
    int* dflag = NULL;
-   HS_CALL( dA.alloc(n2) ); HS_CALL( dD.alloc((long long) ((n + 63) / 64) * 4096) ); HS_CALL( dL.alloc(n2) ); HS_CALL( dT.alloc(n2) );
+   HS_CALL( dA.alloc(n2) ); HS_CALL( dD.alloc(hs_potrf_dinv_len(n)) ); HS_CALL( dL.alloc(n2) ); HS_CALL( dT.alloc(n2) );
    HS_HIP( hipMalloc((void**) &dflag, sizeof(int)) );
    HS_HIP( hipMemset(dflag, 0, sizeof(int)) );
    HS_CALL( dA.up(A, n2) );

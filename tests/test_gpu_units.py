@@ -75,6 +75,35 @@ def test_cholesky_inverse_and_solves(gpu, n):
     assert rel(gpu.potrs(S, r), np.linalg.solve(S, r.T).T) <= 1e-11
 
 
+@pytest.mark.parametrize("n", [65, 128, 130, 192, 500, 1000, 1001])
+def test_fused_block_column_cholesky_matches_the_four_launch_form_bitwise(gpu, n):
+    """k_potrf_step (one launch per block column: narrow update, diagonal factorization, panel product, mask and the trailing
+    update of the previous column) performs the same operations in the same order per element as diagonal kernel + panel GEMM +
+    mask kernel + trailing GEMM: identical bits in L, in the inverses of the diagonal blocks, in the forced-pivot mask - definite
+    and semidefinite mode (rank-deficient Schur matrices are where the pivot rule matters)"""
+    G = RNG.standard_normal((n, n))
+    S = G @ G.T + n * np.eye(n)
+    L0, d0, _, f0 = gpu.potrf_ex(S, psd=False, v1=True)
+    L1, d1, _, f1 = gpu.potrf_ex(S, psd=False, v1=False)
+    assert f0 == 0 and f1 == 0
+    assert np.array_equal(np.tril(L0), np.tril(L1)) and np.array_equal(d0, d1)
+    assert rel(np.tril(L1), np.linalg.cholesky(S)) <= 1e-13
+    # semidefinite: rank n // 2 + 3 Gram matrix, scaled rows
+    r = n // 2 + 3
+    H = RNG.standard_normal((n, r))
+    P = H @ H.T
+    L0, d0, m0, _ = gpu.potrf_ex(P, psd=True, v1=True)
+    L1, d1, m1, _ = gpu.potrf_ex(P, psd=True, v1=False)
+    assert np.array_equal(m0, m1) and m1.sum() > 0
+    assert np.array_equal(np.tril(L0), np.tril(L1)) and np.array_equal(d0, d1)
+    Lt = np.tril(L1)
+    assert rel(Lt @ Lt.T, P) <= 1e-9                     # forced pivots are tiny: the factor still reproduces the matrix
+    # an indefinite matrix is flagged at the same pivot
+    S2 = S.copy()
+    S2[n - 3, n - 3] = -1.0
+    assert gpu.potrf_ex(S2, v1=True)[3] == gpu.potrf_ex(S2, v1=False)[3] != 0
+
+
 def test_cholesky_flags_indefinite_matrix(gpu):
     S = np.eye(70)
     S[40, 40] = -1.0
