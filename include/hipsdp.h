@@ -237,6 +237,11 @@ int  hipsdp_lambda_min(int device, int n, const double* W, int steps, double* th
 /* lambda_min(L D L^T), n <= 64, L lower triangular, D symmetric: the small-block step-length kernels; theta[2], resid[2] */
 int  hipsdp_lambda_min_scaled(int device, int n, const double* L, const double* D, int steps, double* theta, double* resid);
 int  hipsdp_syev(int device, int n, const double* A, double* lam, double* V);     /* ascending, eigenvectors as rows */
+/* i-th smallest eigenvalue (1-based) and optionally its unit eigenvector of a symmetric matrix with n <= 64 in one launch through
+ * pinned, device-mapped staging memory of the calling thread (no allocation, no copy engine, no stream synchronisation):
+ * Householder tridiagonalisation in LDS, Sturm multisection, inverse iteration, back-transformation - one eigenpair as DSYEVR
+ * RANGE = 'I' computes it (lapack_interface.c:178-288).  HIPSDP_ERR_ARG for n > 64. */
+int  hipsdp_syevi_small(int device, int n, const double* A, int i, double* eigval, double* eigvec);
 /* PSD projection chain of the warm-start producer (relax_sdp.c:2715-2766 for Z, :3405-3445 for X), fused on the device: sparse
  * lower/upper triangle (row, col, val; both triangles are filled) -> eigen-decomposition -> eigenvalues below minev (by more
  * than epsilon, SCIPisLT) raised to minev -> recombination -> entries with row <= col and |value| > epsilon in row-major order.

@@ -490,17 +490,30 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, long
    for (int t = 0; t < 4; ++t)
       accB[t] = (v4dc){0.0, 0.0, 0.0, 0.0};
    bool from_lds = false;
-   if ( kb > 0 && blockIdx.x == 0 )
+   /* the entries of the diagonal block and of the own block that the updates below are subtracted from: requested first, so
+    * that their latency passes behind the tile loads and the products */
+   double akk[4][4], ark[4][4];
+   if ( kb > 0 )
    {
-      /* the factor of the previous diagonal block moves from its staging block into the matrix (nobody reads that block now) */
-      const double* src = lstage + (long long) (kb - 1) * NB * NB;
-      double* dst = A + (long long) (j0 - NB) * lda + (j0 - NB);
-      for (int e = tid; e < NB * NB; e += 256)
-      {
-         const int r = e >> 6, c = e & 63;
-         if ( c <= r )
-            dst[(long long) r * lda + c] = src[e];
-      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+         for (int rr = 0; rr < 4; ++rr)
+         {
+            const int row = 16 * wave + lk + 4 * rr, col = 16 * t + lr;
+            akk[t][rr] = (row < nb && col <= row) ? Akk[(long long) row * lda + col] : 0.0;
+         }
+   }
+   if ( blockIdx.x > 0 )
+   {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+         for (int rr = 0; rr < 4; ++rr)
+         {
+            const int row = 16 * wave + lk + 4 * rr, col = 16 * t + lr;
+            ark[t][rr] = (row < rows) ? Ark[(long long) row * lda + col] : 0.0;
+         }
    }
    if ( kb > 0 )
    {
@@ -523,7 +536,7 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, long
             if ( row < nb && col <= row )
             {
                v = -acc[t][rr];
-               v += Akk[(long long) row * lda + col];
+               v += akk[t][rr];
             }
             bufB[row][col] = v;
          }
@@ -536,7 +549,22 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, long
    e2.Lout = (nS > 1) ? lstage + (long long) kb * NB * NB : NULL;
    pd_body<NBK>(Akk, lda, nb, j0, dinv + (long long) kb * NB * NB, flag, diag0, regtol, e2);
    if ( blockIdx.x == 0 )
+   {
+      if ( kb > 0 )
+      {
+         /* the factor of the previous diagonal block moves from its staging block into the matrix (nobody reads that block in
+          * this launch) */
+         const double* src = lstage + (long long) (kb - 1) * NB * NB;
+         double* dst = A + (long long) (j0 - NB) * lda + (j0 - NB);
+         for (int e = tid; e < NB * NB; e += 256)
+         {
+            const int r = e >> 6, c = e & 63;
+            if ( c <= r )
+               dst[(long long) r * lda + c] = src[e];
+         }
+      }
       return;
+   }
    /* ---- panel block: B = A_rk - P_r P_k^T (accB), P = B inv(L_kk)^T, forced columns zeroed */
    __syncthreads();
 #pragma unroll
@@ -549,7 +577,7 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, long
          if ( row < rows )
          {
             v = -accB[t][rr];
-            v += Ark[(long long) row * lda + col];
+            v += ark[t][rr];
          }
          bufA[row][col] = v;
       }

@@ -1,0 +1,374 @@
+/* eigi.hip - i-th eigenvalue (and eigenvector) of a small symmetric matrix in ONE launch without a copy engine.
+ *
+ * Reference: SCIPlapackComputeIthEigenvalue (src/sdpi/lapack_interface.c:178-288: DSYEVR with RANGE = 'I', IL = IU = i) as the
+ * callers use it - cons_sdp.c asks for the smallest eigenvalue of blocks of 2-50 rows dozens of times per node (feasibility
+ * checks, eigenvector cuts), solveonevarsdp.c inside its Newton iteration.  A full Jacobi decomposition plus hipMalloc / hipMemcpy
+ * / hipFree per call costs milliseconds there; LAPACK on the host tens of microseconds.  Here, for n <= 64:
+ *   - the matrix goes host -> pinned, device-mapped staging memory (one memcpy of n^2 doubles), the kernel reads it from there and
+ *     writes eigenvalue, eigenvector and a sequence number back to mapped memory; the host polls the number: no hipMalloc, no
+ *     hipMemcpy, no stream synchronisation on the path;
+ *   - one workgroup: Householder tridiagonalisation in LDS (the DSYTD2 recurrence: v, p = tau A v, w = p - (tau/2)(p.v) v,
+ *     A -= v w^T + w v^T; four barriers per column), Sturm-count multisection for exactly the i-th eigenvalue (64 shifts per
+ *     round, one per lane), inverse iteration on the tridiagonal matrix and back-transformation through the reflectors for the
+ *     eigenvector - what DSYEVR does for one eigenpair.
+ * Larger matrices keep the block-Jacobi path (eig.hip). */
+#include "hs_common.h"
+#include "../../include/hipsdp.h"
+#include <cstring>
+#include <cmath>
+
+#define EI_N  64
+#define EI_LD 65
+
+namespace {
+
+__device__ __forceinline__ double ei_wsum(double v)
+{
+#pragma unroll
+   for (int off = 32; off > 0; off >>= 1)
+      v += __shfl_xor(v, off, 64);
+   return v;
+}
+
+__device__ __forceinline__ double ei_quad(double x)
+{
+   x += __shfl_xor(x, 1, 64);
+   x += __shfl_xor(x, 2, 64);
+   return x;
+}
+
+__device__ __forceinline__ double ei_rcp(double t)
+{
+   double r = __builtin_amdgcn_rcp(t);
+   r = fma(fma(-t, r, 1.0), r, r);
+   return r;
+}
+
+/* in: n x n symmetric, in mapped host memory, the triangle at memory positions [j n + i], i >= j, is read; out[0] = eigenvalue, out[1 .. n] = eigenvector,
+ * then the sequence number is stored to *flag (system scope) */
+__global__ void __launch_bounds__(256) k_syevi_small(int n, int ith, int wantvec, const double* __restrict__ in, double* __restrict__ out,
+   unsigned long long seq, unsigned long long* __restrict__ flag)
+{
+   __shared__ double a[EI_N][EI_LD];
+   __shared__ double vv[EI_N], pp[EI_N], ww[EI_N], tau[EI_N], d[EI_N], e[EI_N], e2[EI_N], zz[EI_N];
+   __shared__ double wk[4][EI_N], swp[EI_N];
+   __shared__ double sc[4];
+   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   const int r = tid >> 2, q = tid & 3;
+
+   for (int idx = tid; idx < n * n; idx += 256)
+   {
+      const int i = idx / n, j = idx - i * n;
+      /* DSYEVR is called with UPLO = 'L' on a column-major array (lapack_interface.c:215): it reads memory [j n + i], i >= j */
+      const double v = (j <= i) ? in[(long long) j * n + i] : in[(long long) i * n + j];
+      a[i][j] = v;
+   }
+   __syncthreads();
+
+   /* ---- tridiagonalisation: Q^T A Q = T, reflector k acts on rows / columns k + 1 .. n - 1.  Two barriers per column: the
+    * reflector and the vector w are computed by EVERY wavefront for itself (64-element reductions; all write the same values to
+    * the same LDS words and read back only what they have written themselves), so only the matrix-vector product and the rank-2
+    * update, which all 256 threads share, are separated by barriers. */
+   for (int k = 0; k + 1 < n; ++k)
+   {
+      const int len = n - k - 1;                       /* length of x = a[k + 1 .., k] */
+      double t;
+      {
+         const double xi = (lane < len) ? a[k + 1 + lane][k] : 0.0;
+         const double x0 = __shfl(xi, 0, 64);
+         const double s2 = ei_wsum(lane >= 1 ? xi * xi : 0.0);
+         double beta = x0, scale = 0.0;
+         t = 0.0;
+         if ( s2 > 0.0 )
+         {
+            beta = -copysign(sqrt(x0 * x0 + s2), x0);
+            t = (beta - x0) / beta;
+            scale = 1.0 / (x0 - beta);
+         }
+         if ( lane < len )
+            vv[lane] = (lane == 0) ? 1.0 : xi * scale;
+         if ( lane == 0 )
+         {
+            tau[k] = t;
+            e[k] = beta;
+            d[k] = a[k][k];
+         }
+         __builtin_amdgcn_s_waitcnt(0xc07f);             /* lgkmcnt(0): this wavefront's own LDS writes are done */
+         __builtin_amdgcn_wave_barrier();
+      }
+      if ( t != 0.0 )
+      {
+         /* p = tau A22 v: row r of A22 (r < len), quarter q of its columns */
+         double acc = 0.0;
+         if ( r < len )
+            for (int c = q; c < len; c += 4)
+               acc += a[k + 1 + r][k + 1 + c] * vv[c];
+         acc = ei_quad(acc);
+         if ( r < len && q == 0 )
+            pp[r] = t * acc;
+         __syncthreads();
+         {
+            const double pl = lane < len ? pp[lane] : 0.0, vl = lane < len ? vv[lane] : 0.0;
+            const double pv = ei_wsum(pl * vl);
+            const double al = -0.5 * t * pv;
+            if ( lane < len )
+               ww[lane] = pl + al * vl;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+         }
+         if ( r < len )
+         {
+            const double vr = vv[r], wr = ww[r];
+            for (int c = q; c < len; c += 4)
+               a[k + 1 + r][k + 1 + c] -= vr * ww[c] + wr * vv[c];
+         }
+         /* keep the reflector (v_0 = 1 implied) in the column it annihilated */
+         if ( tid < len )
+            a[k + 1 + tid][k] = vv[tid];
+      }
+      __syncthreads();
+   }
+   if ( tid == 0 )
+   {
+      d[n - 1] = a[n - 1][n - 1];
+      e[n - 1] = 0.0;
+   }
+   __syncthreads();
+   if ( wave != 0 )
+      return;
+
+   /* ---- wavefront 0: i-th eigenvalue of T by Sturm multisection */
+   if ( lane < n )
+      e2[lane] = e[lane] * e[lane];
+   __builtin_amdgcn_wave_barrier();
+   double lo = 1e300, hi = -1e300;
+   for (int i = 0; i < n; ++i)
+   {
+      const double rad = (i > 0 ? fabs(e[i - 1]) : 0.0) + (i + 1 < n ? fabs(e[i]) : 0.0);
+      lo = fmin(lo, d[i] - rad);
+      hi = fmax(hi, d[i] + rad);
+   }
+   const double span0 = fmax(hi - lo, 1e-300);
+   lo -= 1e-12 * span0 + 1e-300;
+   hi += 1e-12 * span0 + 1e-300;
+   const double pivmin = 1e-290;
+   for (int round = 0; round < 16; ++round)
+   {
+      const double x = lo + (hi - lo) * (double) (lane + 1) / 65.0;
+      int cnt = 0;                                     /* eigenvalues below x */
+      double t = d[0] - x;
+      if ( fabs(t) < pivmin ) t = -pivmin;
+      if ( t < 0.0 ) ++cnt;
+      for (int i = 1; i < n; ++i)
+      {
+         t = d[i] - x - e2[i - 1] * ei_rcp(t);
+         if ( fabs(t) < pivmin ) t = -pivmin;
+         if ( !(fabs(t) < 1e290) ) t = (t < 0.0) ? -1e290 : 1e290;
+         if ( t < 0.0 ) ++cnt;
+      }
+      const unsigned long long msk = __ballot(cnt >= ith);
+      const int first = msk ? __ffsll((long long) msk) - 1 : 64;      /* first shift with at least ith eigenvalues below it */
+      const double w = (hi - lo) / 65.0;
+      const double nlo = lo + w * (double) first;
+      const double nhi = (first < 64) ? lo + w * (double) (first + 1) : hi;
+      lo = nlo; hi = nhi;
+      if ( hi - lo <= 2e-16 * fmax(fabs(lo), fabs(hi)) )
+         break;
+   }
+   const double theta = 0.5 * (lo + hi);
+   if ( lane == 0 )
+      out[0] = theta;
+
+   if ( wantvec )
+   {
+      /* inverse iteration on T - theta I (Gaussian elimination with partial pivoting, factored once; lane 0), start vector with
+       * entries of alternating size so that it is not orthogonal to the eigenvector */
+      if ( lane == 0 )
+      {
+         if ( n == 1 )
+            zz[0] = 1.0;
+         else
+         {
+            const double tiny = 1e-14 * fmax(span0, fmax(fabs(theta), 1e-300));
+            double dd = d[0] - theta, du = e[0];
+            for (int i = 0; i < n - 1; ++i)
+            {
+               const double dl = e[i];
+               const double dn = d[i + 1] - theta;
+               const double un = (i + 2 < n) ? e[i + 1] : 0.0;
+               if ( fabs(dd) >= fabs(dl) )
+               {
+                  if ( fabs(dd) < tiny ) dd = tiny;
+                  const double rinv = 1.0 / dd;
+                  const double mlt = dl * rinv;
+                  wk[0][i] = rinv; wk[1][i] = du; wk[2][i] = 0.0; wk[3][i] = mlt; swp[i] = 0.0;
+                  dd = dn - mlt * du;
+                  du = un;
+               }
+               else
+               {
+                  const double rinv = 1.0 / dl;
+                  const double mlt = dd * rinv;
+                  wk[0][i] = rinv; wk[1][i] = dn; wk[2][i] = un; wk[3][i] = mlt; swp[i] = 1.0;
+                  dd = du - mlt * dn;
+                  du = -mlt * un;
+               }
+            }
+            if ( fabs(dd) < tiny ) dd = tiny;
+            wk[0][n - 1] = 1.0 / dd; wk[1][n - 1] = 0.0; wk[2][n - 1] = 0.0;
+            for (int i = 0; i < n; ++i)
+               zz[i] = 1.0 + 0.37 * (double) ((i * 7) % 5);
+            for (int iter = 0; iter < 4; ++iter)
+            {
+               double cur = zz[0];
+               for (int i = 0; i < n - 1; ++i)
+               {
+                  const double nxt = zz[i + 1];
+                  if ( swp[i] == 0.0 )
+                  {
+                     zz[i] = cur;
+                     cur = nxt - wk[3][i] * cur;
+                  }
+                  else
+                  {
+                     zz[i] = nxt;
+                     cur = cur - wk[3][i] * nxt;
+                  }
+               }
+               double x1 = cur * wk[0][n - 1], x2 = 0.0;
+               double nrm = x1 * x1;
+               zz[n - 1] = x1;
+               for (int i = n - 2; i >= 0; --i)
+               {
+                  const double xi = (zz[i] - wk[1][i] * x1 - wk[2][i] * x2) * wk[0][i];
+                  zz[i] = xi;
+                  nrm += xi * xi;
+                  x2 = x1; x1 = xi;
+               }
+               nrm = sqrt(nrm);
+               if ( !(nrm > 0.0) || !(nrm < 1e300) )
+               {
+                  for (int i = 0; i < n; ++i)
+                     zz[i] = (i == 0) ? 1.0 : 0.0;
+                  break;
+               }
+               const double rn = 1.0 / nrm;
+               for (int i = 0; i < n; ++i)
+                  zz[i] *= rn;
+            }
+         }
+      }
+      __builtin_amdgcn_wave_barrier();
+      /* back-transformation x = H_0 H_1 ... H_{n-2} z: reflector k acts on entries k + 1 .. n - 1 */
+      double zi = (lane < n) ? zz[lane] : 0.0;
+      for (int k = n - 2; k >= 0; --k)
+      {
+         const double t = tau[k];
+         if ( t == 0.0 )
+            continue;
+         const bool in = lane > k && lane < n;
+         const double vk = in ? ((lane == k + 1) ? 1.0 : a[lane][k]) : 0.0;
+         const double dot = ei_wsum(vk * zi);
+         zi -= t * dot * vk;
+      }
+      const double nrm = sqrt(ei_wsum(zi * zi));
+      if ( lane < n )
+         out[1 + lane] = nrm > 0.0 ? zi / nrm : zi;
+   }
+   __threadfence_system();
+   __builtin_amdgcn_wave_barrier();
+   if ( lane == 0 )
+   {
+      __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+   }
+}
+
+/* per host thread and device: a stream and the pinned, device-mapped staging memory */
+struct ei_ctx
+{
+   int device;
+   hipStream_t stream;
+   double* hin;  double* din;
+   double* hout; double* dout;          /* [0] eigenvalue, [1 .. 64] eigenvector, then the flag word */
+   unsigned long long seq;
+};
+
+thread_local ei_ctx g_ctx = {-1, NULL, NULL, NULL, NULL, NULL, 0};
+
+int ei_context(int device, ei_ctx** out)
+{
+   if ( g_ctx.device == device && g_ctx.stream != NULL )
+   {
+      *out = &g_ctx;
+      return HS_OK;
+   }
+   if ( g_ctx.stream != NULL )
+   {
+      (void) hipSetDevice(g_ctx.device);
+      (void) hipStreamSynchronize(g_ctx.stream);
+      (void) hipStreamDestroy(g_ctx.stream);
+      (void) hipHostFree(g_ctx.hin);
+      (void) hipHostFree(g_ctx.hout);
+      g_ctx.stream = NULL; g_ctx.device = -1;
+   }
+   HS_HIP( hipSetDevice(device) );
+   HS_HIP( hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking) );
+   HS_HIP( hipHostMalloc((void**) &g_ctx.hin, (size_t) EI_N * EI_N * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) );
+   HS_HIP( hipHostMalloc((void**) &g_ctx.hout, (size_t) (EI_N + 8) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) );
+   HS_HIP( hipHostGetDevicePointer((void**) &g_ctx.din, g_ctx.hin, 0) );
+   HS_HIP( hipHostGetDevicePointer((void**) &g_ctx.dout, g_ctx.hout, 0) );
+   memset(g_ctx.hout, 0, (size_t) (EI_N + 8) * sizeof(double));
+   g_ctx.device = device;
+   g_ctx.seq = 0;
+   *out = &g_ctx;
+   return HS_OK;
+}
+
+}
+
+/* i-th smallest eigenvalue (1-based) of the symmetric n x n matrix A (the triangle at memory positions [j n + i], i >= j, is read:
+ * what DSYEVR 'L' reads from a column-major array), n <= 64; eigvec (n, unit norm) may be NULL.  HIPSDP_ERR_ARG for larger n: the caller takes the full decomposition. */
+extern "C" int hipsdp_syevi_small(int device, int n, const double* A, int i, double* eigval, double* eigvec)
+{
+   int nd = 0;
+   if ( hipGetDeviceCount(&nd) != hipSuccess || nd <= 0 )
+      return HIPSDP_ERR_NODEVICE;
+   if ( device < 0 || device >= nd || n < 1 || n > EI_N || A == NULL || i < 1 || i > n || eigval == NULL )
+      return HIPSDP_ERR_ARG;
+   ei_ctx* c = NULL;
+   HS_CALL( ei_context(device, &c) );
+   HS_HIP( hipSetDevice(device) );
+   memcpy(c->hin, A, (size_t) n * n * sizeof(double));
+   const unsigned long long seq = ++c->seq;
+   volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(c->hout + EI_N + 4);
+   hipLaunchKernelGGL(k_syevi_small, dim3(1), dim3(256), 0, c->stream, n, i, eigvec != NULL ? 1 : 0, c->din, c->dout, seq,
+      reinterpret_cast<unsigned long long*>(c->dout + EI_N + 4));
+   HS_HIP( hipGetLastError() );
+   long long spins = 0;
+   while ( *flag != seq )
+   {
+      if ( (++spins & 0xFFFF) == 0 )
+      {
+         const hipError_t e = hipStreamQuery(c->stream);
+         if ( e == hipSuccess )
+         {
+            if ( *flag == seq )
+               break;
+            HS_HIP( hipStreamSynchronize(c->stream) );
+            if ( *flag != seq )
+               return HIPSDP_ERR_HIP;
+            break;
+         }
+         if ( e != hipErrorNotReady )
+         {
+            hs_record_hip_error(e, "hipStreamQuery(syevi)", __FILE__, __LINE__);
+            return HIPSDP_ERR_HIP;
+         }
+      }
+   }
+   __atomic_thread_fence(__ATOMIC_ACQUIRE);
+   *eigval = c->hout[0];
+   if ( eigvec != NULL )
+      memcpy(eigvec, c->hout + 1, (size_t) n * sizeof(double));
+   return HIPSDP_OK;
+}

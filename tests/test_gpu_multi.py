@@ -143,6 +143,41 @@ def test_spmd_copies_of_a_branch_and_bound_run_over_the_solver_interface(gpu, tm
             assert (r["failed"], r["nodes"], r["calls"], r["iters"]) == (one["failed"], one["nodes"], one["calls"], one["iters"])
 
 
+@pytest.mark.parametrize("slow", [1, 0])
+def test_time_limit_decision_is_collective_when_the_clocks_of_the_copies_disagree(gpu, tmp_path, slow):
+    """Two SPMD copies call SCIPsdpiSolverLoadAndSolve with the same time limit (0.5 s) while ONE copy's clock is already 1 s old.
+    Each process has its own SDPIclock; a copy that returned early on its own reading would leave the other one alone in the next
+    RCCL collective, which has no timeout.  The backend takes rank 0's reading on every copy: slow = 1 -> rank 0 still has time,
+    both solve (identical results); slow = 0 -> rank 0 is out of time, both report the time limit without touching the engine.
+    A second call with a 1 ms limit (expired on both) must report the time limit on both."""
+    outs = [str(tmp_path / ("tl_%d.json" % r)) for r in range(2)]
+    env = dict(os.environ)
+    env.update(HIPSDP_WORLD="2", HIPSDP_COMM_SHM="/hipsdp_tl_%d_%d" % (os.getpid(), slow), HIPSDP_COMM_TIMEOUT="40",
+               HIPSDP_SHARD_MIN_FLOPS="0", SLOW_RANK=str(slow), SLOW_SECONDS="1.0", TIME_LIMIT="0.5")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "spmd_timelimit_worker.py"), outs[r]], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, env=dict(env, HIPSDP_RANK=str(r))) for r in range(2)]
+    logs = []
+    try:
+        for p in procs:
+            o, _ = p.communicate(timeout=150)
+            logs.append(o.decode(errors="replace"))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, "copy %d failed:\n%s" % (r, logs[r][-3000:])
+    res = [json.load(open(o)) for o in outs]
+    first = [r[0] for r in res]
+    if slow == 1:
+        assert all(f["rc"] == 1 and f["solved"] and f["optimal"] and not f["timelim"] for f in first), first
+        assert first[0]["obj"] == first[1]["obj"]
+        assert first[1]["clock"] > 0.5 > 0.0                    # the slow copy really was past the limit
+    else:
+        assert all(f["rc"] == 1 and not f["solved"] and f["timelim"] for f in first), first
+    assert all(r[1]["rc"] == 1 and r[1]["timelim"] and not r[1]["solved"] for r in res), [r[1] for r in res]
+
+
 @pytest.mark.parametrize("load", ["gen", "vars-gen"])
 def test_two_ranks_at_the_bench_size(gpu, tmp_path, load):
     """BASELINE configs[1] (n = 500, m = 1000, the instance generated on the device) solved by two processes: replicated matrices

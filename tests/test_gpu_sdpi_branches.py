@@ -159,3 +159,89 @@ def test_two_solver_instances_on_two_host_threads(gpu):
     assert not errors, errors
     for s in solvers.values():
         s.free()
+
+
+@pytest.mark.parametrize("seed,expect", [(352, [5, 0, 0]), (132, [5, 5, 2])])
+def test_settings_ladder_rescues_what_the_fast_settings_lose(gpu, seed, expect):
+    """The rungs of the backend's ladder (hipsdp_params.settings = 0 / 1 / 2; sdpisolver_sdpa.cpp:1698-1795) on two problems of
+    the stress family (tests/stress_cases.py) that the fast settings end with a numerical failure: seed 352 (2 x 2 block, 64
+    variables, 17 LP rows, planted optimum) is solved by the medium settings, seed 132 (5 x 5 block, 140 variables: far more
+    variables than the matrix space has dimensions) needs a more conservative rung to find its ray.  Engine and oracle climb the
+    same ladder: the fast rung fails on both, both end with the same verdict (the rounding of the two implementations may put the
+    rescue of an ill-posed problem on neighbouring rungs), and the engine's answer is verified on its own."""
+    import ipm_ref
+    import checker
+    import stress_cases
+    core, kind = stress_cases.rand_core(np.random.default_rng(seed))
+    ref = [ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-6, feastol=1e-6, pabstol=1e-5, settings=lv)) for lv in range(3)]
+    assert [r.status for r in ref] == expect
+    ref_final = next(r for r in ref if r.status < 4)
+    s = gpu.Solver(0)
+    s.load_core(core)
+    got = []
+    final = None
+    for lv in range(3):
+        info = s.solve(gaptol=1e-6, feastol=1e-6, pabstol=1e-5, settings=lv)
+        assert info.settings_used == lv
+        got.append(info.status)
+        if info.status < 4 and final is None:
+            final = (lv, info, s.y(), [s.X(k) for k in range(len(core.blocks))], s.lp()[0])
+    s.close()
+    assert got[0] >= 4, got                                    # the fast settings lose it, as in the oracle
+    assert final is not None, got
+    lv, info, y, X, x = final
+    assert info.status == ref_final.status, (got, expect)
+    assert abs(lv - [r.status < 4 for r in ref].index(True)) <= 1
+    if seed == 352:
+        assert got == expect                                   # well-posed problem: rung for rung the same
+    if info.status == 0:
+        assert abs(info.dobj - ref_final.dobj) <= 1e-5 * (1 + abs(ref_final.dobj))
+        ok, det = checker.certificate(core, y, X, x, 1e-5, 1e-5)
+        assert ok, det
+    elif info.status == 2:                                     # y-ray: b^T y < 0, A^T y psd (checksdpi test 2's kind of verdict)
+        assert core.b @ y < 0
+        for A in core.blocks:
+            Zr = np.tensordot(y, A[1:], axes=(0, 0))
+            assert np.linalg.eigvalsh(0.5 * (Zr + Zr.T))[0] >= -1e-6 * abs(core.b @ y)
+        if core.q:
+            assert np.min(core.D @ y) >= -1e-6 * abs(core.b @ y)
+
+
+def test_ladder_at_the_interface_settles_the_hard_nodes_of_example_small(gpu):
+    """example_small has node relaxations whose optimum is not attained (tau -> 0): before the ladder they went to the caller's
+    penalty loop.  Every node through SCIPsdpiSolverLoadAndSolve: optimum -8 (check/testset/short.solu:1), no unresolved node,
+    SettingsUsed reports the rung that solved each node; the restated backend on the numpy IPM walks the same tree."""
+    import bnb
+    import sdpa_io
+    inst = sdpa_io.read_sdpa(os.path.join(GOLDEN, "instances", "example_small.dat-s"))
+    prob = bnb.instance_to_sdpi(inst)
+
+    def run(be):
+        used = []
+
+        def solve(P):
+            rc, _, _ = be.solve(P)
+            assert rc == sdpi_call.SCIP_OKAY
+            used.append(be.settings_used())
+            if be.flag("IsDualInfeasible"):
+                return bnb.NodeResult('infeasible')
+            if be.flag("IsDualUnbounded"):
+                return bnb.NodeResult('unbounded')
+            if not be.flag("IsOptimal"):
+                return bnb.NodeResult('failed')
+            rc, obj, y = be.dual_sol()
+            return bnb.NodeResult('optimal', obj, y)
+        best, y, nodes, failed = bnb.branch_and_bound(prob, inst.intvars, solve)
+        return best, nodes, failed, used
+
+    s = sdpi_call.SdpiSolver(gpu.lib())
+    for par in (1, 2, 3):
+        assert s.set_real(par, 1e-6) == sdpi_call.SCIP_OKAY
+    best, nodes, failed, used = run(s)
+    s.free()
+    rbest, rnodes, rfailed, rused = run(drv.OracleBackend(feastol=1e-6, gaptol=1e-6, ladder=True))
+    assert abs(best + 8.0) <= 1e-5 and abs(rbest + 8.0) <= 1e-5
+    assert failed == 0 and rfailed == 0
+    assert all(u in (sdpi_call.FAST, sdpi_call.MEDIUM, sdpi_call.STABLE) for u in used + rused)
+    print("example_small: rungs used by the HIP backend %s, by the numpy backend %s" % (used, rused))
+    assert abs(nodes - rnodes) <= 2

@@ -97,7 +97,8 @@ def test_slater_check_matches_the_numpy_backend(gpu):
 
 
 @pytest.mark.parametrize("name,optimum", [("example_small.dat-s", -8.0), ("example_tightenmatrices.dat-s", -9.0),
-                                          ("example_TT.dat-s.gz", 2.11803), ("example_CLS.dat-s.gz", 7.1485), ("example_inf.dat-s", None)])
+                                          ("example_TT.dat-s.gz", 2.11803), ("example_CLS.dat-s.gz", 7.1485), ("example_inf.dat-s", None),
+                                          ("example_MkP.dat-s.gz", -95.0)])
 def test_bnb_with_the_full_driver_per_node(gpu, name, optimum):
     """every node goes through the driver: one-variable nodes are decided by the shortcut (device eigenvalues), nodes the
     backend cannot solve acceptably fall back to the penalty formulation like sdpi.c:3437"""
@@ -127,4 +128,7 @@ def test_bnb_with_the_full_driver_per_node(gpu, name, optimum):
         return
     assert best is not None and abs(best - optimum) <= 1e-4 * max(1.0, abs(optimum))
     assert all(abs(y[v] - round(y[v])) <= 1e-9 for v in inst.intvars)
-    assert failed <= 1                 # measured: 0 on all five instances
+    # measured: 0 unresolved nodes on the first five instances.  example_MkP (check/testset/short.solu:7; 105 binaries, one 15 x 15
+    # block, 240 LP rows) has about fifty nodes without interior that go through the penalty formulation; a handful of those stay
+    # unresolved (the numpy backend behind the same driver: 7 of 119 nodes) and are simply branched on
+    assert failed <= (12 if "MkP" in name else 1)

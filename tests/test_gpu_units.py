@@ -271,3 +271,60 @@ def test_small_block_step_length_eigenvalue(gpu, n):
         assert th[0] - rs[0] <= ref + 1e-9 * scale, (th, rs, ref)
         if n <= 25:
             assert abs(th[0] - ref) <= 1e-8 * scale          # full Krylov space (or Jacobi): exact
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 16, 17, 33, 50, 64])
+def test_ith_eigenpair_in_one_launch_matches_dsyevr_range_i(gpu, n):
+    """SCIPlapackComputeIthEigenvalue at the sizes its callers use (cons_sdp.c: blocks of 2-50 rows; lapack_interface.c:178-288):
+    n <= 64 runs k_syevi_small (Householder tridiagonalisation, Sturm multisection for exactly the i-th eigenvalue, inverse
+    iteration + back-transformation) through pinned staging memory.  Every i: eigenvalue against numpy, eigenvector by residual and
+    norm (sign and the basis of a multiple eigenvalue are free, as with DSYEVR)."""
+    lib = gpu.lib()
+    rng = np.random.default_rng(40 + n)
+    G = rng.standard_normal((n, n))
+    A = 0.5 * (G + G.T)
+    if n >= 5:
+        A[2, :] = A[:, 2] = 0.0
+        A[2, 2] = A[3, 3]                      # stress: a decoupled row and (nearly) repeated diagonal entries
+    ev = np.linalg.eigvalsh(A)
+    scale = max(1.0, np.abs(ev).max())
+    for i in range(1, n + 1):
+        val = C.c_double(0.0)
+        vec = np.zeros(n)
+        assert lib.SCIPlapackComputeIthEigenvalue(None, 1, n, _pd(A.copy().reshape(-1)), i, C.byref(val), _pd(vec)) == 1
+        assert abs(val.value - ev[i - 1]) <= 1e-12 * scale * n
+        assert abs(np.linalg.norm(vec) - 1.0) <= 1e-12
+        assert np.linalg.norm(A @ vec - val.value * vec) <= 1e-9 * scale
+        val2 = C.c_double(0.0)
+        assert lib.SCIPlapackComputeIthEigenvalue(None, 0, n, _pd(A.copy().reshape(-1)), i, C.byref(val2), None) == 1
+        assert val2.value == val.value
+    # only the triangle DSYEVR('L') reads from a column-major array (memory [j n + i], i >= j) is used
+    B = np.triu(A) + np.tril(rng.standard_normal((n, n)), -1)
+    val = C.c_double(0.0)
+    assert lib.SCIPlapackComputeIthEigenvalue(None, 0, n, _pd(B.reshape(-1).copy()), 1, C.byref(val), None) == 1
+    assert abs(val.value - ev[0]) <= 1e-12 * scale * n
+    # repeated eigenvalues: 2 I (+) 5 I
+    D = np.diag([2.0] * (n // 2) + [5.0] * (n - n // 2))
+    for i in range(1, n + 1):
+        vec = np.zeros(n)
+        assert lib.SCIPlapackComputeIthEigenvalue(None, 1, n, _pd(D.copy().reshape(-1)), i, C.byref(val), _pd(vec)) == 1
+        assert abs(val.value - np.diag(D)[i - 1]) <= 1e-13 and np.linalg.norm(D @ vec - val.value * vec) <= 1e-10
+
+
+def test_small_eigenvalue_calls_stay_out_of_the_millisecond_regime(gpu):
+    """the path the callers hammer (dozens of calls per node): no allocation, no copy engine, no stream synchronisation - a call
+    at n = 30 must not cost what a hipMalloc + hipMemcpy + full decomposition costs (milliseconds before); the measured numbers
+    are in DESIGN.md (tests/devtools/lapack_small_time.py)"""
+    import time
+    lib = gpu.lib()
+    rng = np.random.default_rng(1)
+    G = rng.standard_normal((30, 30))
+    A = (G + G.T).reshape(-1).copy()
+    val = C.c_double(0.0)
+    for _ in range(5):
+        lib.SCIPlapackComputeIthEigenvalue(None, 0, 30, _pd(A), 1, C.byref(val), None)
+    t0 = time.perf_counter()
+    for _ in range(200):
+        lib.SCIPlapackComputeIthEigenvalue(None, 0, 30, _pd(A), 1, C.byref(val), None)
+    per = (time.perf_counter() - t0) / 200
+    assert per < 5e-4, per
