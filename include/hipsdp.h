@@ -139,6 +139,10 @@ int  hipsdp_get_preoptimal_X(hipsdp_solver* solver, int block, double* X);
 /* smallest eigenvalue of  sum_i A_i^k y_i - A_0^k  for every block, on the device (backs the feasibility check of
  * sdpsolchecker.c:201-257 inside the backend); y: m host values; lmin: nblocks host values */
 int  hipsdp_check_y(hipsdp_solver* solver, const double* y, double* lmin, double* lpviol);
+/* the same against a known tolerance: blocks above 64 rows are certified by one Cholesky factorization of Z(y) + 0.999 tol I
+ * (lmin = -0.999 tol on success: a rigorous lower bound that passes "lmin >= -tol"); the exact eigenvalue is computed only when
+ * that fails */
+int  hipsdp_check_y_tol(hipsdp_solver* solver, const double* y, double tol, double* lmin, double* lpviol);
 
 /* Several ranks making the same calls (SPMD): *flag becomes rank 0's value on every rank, so that decisions taken from a host
  * clock (time limits) are the same everywhere and no rank is left alone in a collective.  One rank / no communicator: no-op. */

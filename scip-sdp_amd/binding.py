@@ -192,11 +192,15 @@ class Solver:
             Xs.append(X)
         return y[:self.m], Xs, x[:self.q]
 
-    def check_y(self, y):
+    def check_y(self, y, tol=0.0):
+        """lambda_min of Z(y) per block (tol > 0: blocks above 64 rows report the certified bound -0.999 tol when it holds)"""
         y = _f64(y)
         lmin = np.zeros(max(1, len(self.ns)))
         viol = C.c_double(0.0)
-        _chk(lib().hipsdp_check_y(self.h, _dp(y), _dp(lmin), C.byref(viol)), "hipsdp_check_y")
+        if tol > 0.0:
+            _chk(lib().hipsdp_check_y_tol(self.h, _dp(y), C.c_double(tol), _dp(lmin), C.byref(viol)), "hipsdp_check_y_tol")
+        else:
+            _chk(lib().hipsdp_check_y(self.h, _dp(y), _dp(lmin), C.byref(viol)), "hipsdp_check_y")
         return lmin[:len(self.ns)], viol.value
 
     def eigencuts(self, block, y, tol, maxcuts):

@@ -560,13 +560,21 @@ extern "C" int hipsdp_set_obj(hipsdp_solver* s, const double* b)
 }
 
 __global__ void k_scatter_coo(long long nnz, int n, const int* __restrict__ var, const int* __restrict__ row,
-   const int* __restrict__ col, const double* __restrict__ val, double* __restrict__ A, int r0, int r1, double* __restrict__ A0)
+   const int* __restrict__ col, const double* __restrict__ val, double* __restrict__ A, int r0, int r1, double* __restrict__ A0,
+   int vmax, int* __restrict__ err)
 {
    const long long n2 = (long long) n * n;
    for (long long e = (long long) blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (long long) gridDim.x * blockDim.x)
    {
       const int r = row[e], c = col[e];
       const int v = var[e];
+      /* the indices are validated here, on the device (10^8 triplets: a host loop costs as much as the upload): an entry out of
+       * range is not written and raises the error flag */
+      if ( v < 0 || v > vmax || r < 0 || r >= n || c < 0 || c >= n )
+      {
+         atomicExch(err, 1);
+         continue;
+      }
       /* matrices sharded by variable: rows this rank does not hold are skipped, the constant matrix goes to its replicated copy */
       double* a = (v == 0) ? A0 : A + (long long) v * n2;
       if ( v != 0 && (v < r0 || v >= r1) )
@@ -585,12 +593,6 @@ extern "C" int hipsdp_add_entries(hipsdp_solver* s, int block, long long nnz, co
       return HIPSDP_OK;
    HS_HIP( hipSetDevice(s->device) );
    Block& B = s->blk[block];
-   for (long long e = 0; e < nnz; ++e)
-      if ( var[e] < 0 || var[e] > s->m || row[e] < 0 || row[e] >= B.n || col[e] < 0 || col[e] >= B.n )
-      {
-         set_err("hipsdp_add_entries: index out of range");
-         return HIPSDP_ERR_ARG;
-      }
    int *dv, *dr, *dc; double* dval;
    HS_CALL( dalloc(&dv, nnz) ); HS_CALL( dalloc(&dr, nnz) ); HS_CALL( dalloc(&dc, nnz) ); HS_CALL( dalloc(&dval, nnz) );
    HS_HIP( hipMemcpyAsync(dv, var, (size_t) nnz * sizeof(int), hipMemcpyHostToDevice, s->stream) );
@@ -598,12 +600,21 @@ extern "C" int hipsdp_add_entries(hipsdp_solver* s, int block, long long nnz, co
    HS_HIP( hipMemcpyAsync(dc, col, (size_t) nnz * sizeof(int), hipMemcpyHostToDevice, s->stream) );
    HS_HIP( hipMemcpyAsync(dval, val, (size_t) nnz * sizeof(double), hipMemcpyHostToDevice, s->stream) );
    long long g = (nnz + 255) / 256; if ( g > 4096 ) g = 4096;
-   hipLaunchKernelGGL(k_scatter_coo, dim3((unsigned) g), dim3(256), 0, s->stream, nnz, B.n, dv, dr, dc, dval, B.A, s->a_r0, s->a_r1, B.A0);
+   int herr = 0;
+   HS_HIP( hipMemsetAsync(s->flags + 6, 0, sizeof(int), s->stream) );
+   hipLaunchKernelGGL(k_scatter_coo, dim3((unsigned) g), dim3(256), 0, s->stream, nnz, B.n, dv, dr, dc, dval, B.A, s->a_r0, s->a_r1, B.A0,
+      s->m, s->flags + 6);
    HS_LAUNCH_CHECK();
+   HS_HIP( hipMemcpyAsync(&herr, s->flags + 6, sizeof(int), hipMemcpyDeviceToHost, s->stream) );
    HS_HIP( hipStreamSynchronize(s->stream) );
    dfree(dv); dfree(dr); dfree(dc); dfree(dval);
    B.apk_valid = false;
    s->solved = false;
+   if ( herr != 0 )
+   {
+      set_err("hipsdp_add_entries: index out of range");
+      return HIPSDP_ERR_ARG;
+   }
    return HIPSDP_OK;
 }
 
@@ -652,24 +663,29 @@ extern "C" int hipsdp_master_add_entries(hipsdp_solver* s, int block, long long 
       return HIPSDP_OK;
    HS_HIP( hipSetDevice(s->device) );
    const int n = s->master_sizes[block];
-   for (long long e = 0; e < nnz; ++e)
-      if ( var[e] < 0 || var[e] >= s->master_slots[block] || row[e] < 0 || row[e] >= n || col[e] < 0 || col[e] >= n )
-      {
-         set_err("hipsdp_master_add_entries: index out of range");
-         return HIPSDP_ERR_ARG;
-      }
    int *dv, *dr, *dc; double* dval;
+   int* derr = NULL;
+   HS_CALL( dalloc(&derr, 1) );
    HS_CALL( dalloc(&dv, nnz) ); HS_CALL( dalloc(&dr, nnz) ); HS_CALL( dalloc(&dc, nnz) ); HS_CALL( dalloc(&dval, nnz) );
    HS_HIP( hipMemcpyAsync(dv, var, (size_t) nnz * sizeof(int), hipMemcpyHostToDevice, s->stream) );
    HS_HIP( hipMemcpyAsync(dr, row, (size_t) nnz * sizeof(int), hipMemcpyHostToDevice, s->stream) );
    HS_HIP( hipMemcpyAsync(dc, col, (size_t) nnz * sizeof(int), hipMemcpyHostToDevice, s->stream) );
    HS_HIP( hipMemcpyAsync(dval, val, (size_t) nnz * sizeof(double), hipMemcpyHostToDevice, s->stream) );
    long long g = (nnz + 255) / 256; if ( g > 4096 ) g = 4096;
+   /* slot 0 of the master copy is a variable like the others: A0 = A, nothing is skipped by the row range */
+   int herr = 0;
+   HS_HIP( hipMemsetAsync(derr, 0, sizeof(int), s->stream) );
    hipLaunchKernelGGL(k_scatter_coo, dim3((unsigned) g), dim3(256), 0, s->stream, nnz, n, dv, dr, dc, dval, s->master_A[block], 0, 2147483647,
-      s->master_A[block]);
+      s->master_A[block], s->master_slots[block] - 1, derr);
    HS_LAUNCH_CHECK();
+   HS_HIP( hipMemcpyAsync(&herr, derr, sizeof(int), hipMemcpyDeviceToHost, s->stream) );
    HS_HIP( hipStreamSynchronize(s->stream) );
-   dfree(dv); dfree(dr); dfree(dc); dfree(dval);
+   dfree(dv); dfree(dr); dfree(dc); dfree(dval); dfree(derr);
+   if ( herr != 0 )
+   {
+      set_err("hipsdp_master_add_entries: index out of range");
+      return HIPSDP_ERR_ARG;
+   }
    return HIPSDP_OK;
 }
 
@@ -2681,7 +2697,24 @@ extern "C" int hipsdp_sync_flag(hipsdp_solver* s, int* flag)
    return rc;
 }
 
+static int check_y_impl(hipsdp_solver* s, const double* y, double tol, double* lmin, double* lpviol);
+
 extern "C" int hipsdp_check_y(hipsdp_solver* s, const double* y, double* lmin, double* lpviol)
+{
+   return check_y_impl(s, y, 0.0, lmin, lpviol);
+}
+
+/* the same check against a known tolerance (what the backend's re-solve loop asks: is lambda_min >= -tol?): blocks above 64 rows
+ * are decided by ONE Cholesky factorization of Z(y) + 0.999 tol I - success proves lambda_min > -0.999 tol and lmin reports that
+ * bound; only a failure (y really is at or beyond the tolerance) pays for the exact eigenvalue.  At an optimum Z(y) is singular
+ * to rounding, i.e. a margin of tol inside the cone: the factorization succeeds and the check costs a pass over A and a Cholesky
+ * instead of 250 Lanczos launches. */
+extern "C" int hipsdp_check_y_tol(hipsdp_solver* s, const double* y, double tol, double* lmin, double* lpviol)
+{
+   return check_y_impl(s, y, tol > 0.0 ? tol : 0.0, lmin, lpviol);
+}
+
+static int check_y_impl(hipsdp_solver* s, const double* y, double tol, double* lmin, double* lpviol)
 {
    if ( s == NULL || !s->shaped ) return HIPSDP_ERR_ARG;
    HS_HIP( hipSetDevice(s->device) );
@@ -2698,8 +2731,14 @@ extern "C" int hipsdp_check_y(hipsdp_solver* s, const double* y, double* lmin, d
    {
       const long long n2 = (long long) B.n * B.n;
       HS_CALL( pass_AT(s, B, s->dyt, 0.0, NULL, B.W) );
-      /* run Lanczos to (numerical) convergence: up to min(n, 250) steps */
-      HS_CALL( hs_lanczos_lmin(st, B.n, B.W, 250, s->sc + SC_BLK(k, 1), s->lan_ws) );
+      /* run Lanczos to (numerical) convergence: up to min(n, 250) steps (not needed where the tolerance certificate decides) */
+      if ( !(tol > 0.0 && B.n > 64) )
+         HS_CALL( hs_lanczos_lmin(st, B.n, B.W, 250, s->sc + SC_BLK(k, 1), s->lan_ws) );
+      else
+      {
+         HS_CALL( hs_fill(st, s->sc + SC_BLK(k, 1), 1, 0.0) );
+         HS_CALL( hs_fill(st, s->sc + SC_BLK(k, 2), 1, 0.0) );
+      }
       ++k;
    }
    HS_CALL( hs_fill(st, s->sc + SC_RATX, 1, 0.0) );
@@ -2725,11 +2764,12 @@ extern "C" int hipsdp_check_y(hipsdp_solver* s, const double* y, double* lmin, d
    {
       Block& B = s->blk[b];
       const int n = B.n;
-      if ( n <= 200 )
+      const bool bytol = tol > 0.0 && n > 64;
+      if ( n <= 200 && !bytol )
          continue;
       const long long n2 = (long long) n * n;
       const double theta = h.v[SC_BLK(b, 1)];
-      const double sigma = lmin[b] - 1e-9 * (1.0 + fabs(theta));
+      const double sigma = bytol ? -0.999 * tol : lmin[b] - 1e-9 * (1.0 + fabs(theta));
       int fl = 0;
       HS_CALL( hs_copy(st, B.T1, B.W, n2) );
       hipLaunchKernelGGL(k_shift_diag, g1d(n), dim3(256), 0, st, n, B.T1, -sigma);

@@ -149,6 +149,16 @@ def test_full_size_c2_properties(gpu):
     assert np.array_equal(s.y(), y1) and info2.iterations == info.iterations    # deterministic reductions
     lmin, viol = s.check_y(y1)
     assert lmin[0] >= -TOL
+    # the check the backend's re-solve loop makes (hipsdp_check_y_tol): a feasible y is certified by one Cholesky factorization of
+    # Z(y) + 0.999 tol I and reports that bound; a y that violates the tolerance gets the exact eigenvalue
+    lmin_t, _ = s.check_y(y1, tol=1e-5)
+    assert abs(lmin_t[0] + 0.999e-5) <= 1e-18
+    ybad = y1.copy()
+    ybad[0] += 0.05
+    lam_exact = np.linalg.eigvalsh(0.5 * ((Z + 0.05 * A[1]) + (Z + 0.05 * A[1]).T))[0]
+    assert lam_exact < -1e-3
+    lmin_b, _ = s.check_y(ybad, tol=1e-5)
+    assert abs(lmin_b[0] - lam_exact) <= 1e-9 * (1 + abs(lam_exact))
     s.close()
 
 
