@@ -66,7 +66,11 @@ def test_example_mkp_through_the_full_driver_numpy_backend():
             return bnb.NodeResult('failed')
         return bnb.NodeResult('optimal', R.objval, R.y)
 
-    best, y, nodes, failed = bnb.branch_and_bound(prob, inst.intvars, solve, maxnodes=1000)
+    # ~500 solves of 15 x 15 / 105-variable problems: BLAS worker threads only get in each other's way at these sizes
+    # (minutes instead of 25 s with one thread per core)
+    from threadpoolctl import threadpool_limits
+    with threadpool_limits(limits=1):
+        best, y, nodes, failed = bnb.branch_and_bound(prob, inst.intvars, solve, maxnodes=1000)
     assert best is not None and abs(best + 95.0) <= 1e-4
     assert all(abs(y[v] - round(y[v])) <= 1e-9 for v in inst.intvars)
     assert failed <= 12 and nodes <= 400
