@@ -110,6 +110,10 @@ int  hipsdp_add_entries(hipsdp_solver* solver, int block, long long nnz, const i
 int  hipsdp_master_define(hipsdp_solver* solver, int nvars, int nblocks, const int* blocksizes, const int* nblockvars);
 int  hipsdp_master_add_entries(hipsdp_solver* solver, int block, long long nnz, const int* slot, const int* row, const int* col,
    const double* val);
+/* the same upload straight from per-slot arrays (slot k: nnz[k] entries row[k][.], col[k][.], val[k][.] - the caller's
+ * sdprow[b][k] / sdpcol[b][k] / sdpval[b][k] of sdpisolver.h:176-233), streamed through pinned staging chunks */
+int  hipsdp_master_add_vars(hipsdp_solver* solver, int block, int nslots, const int* nnz, const int* const* row,
+   const int* const* col, const double* const* val);
 int  hipsdp_master_gather(hipsdp_solver* solver, int engine_block, int master_block, int nactive, const int* slots,
    int nkept, const int* kept);
 /* dense upload of a whole block: A[(m+1) * n * n] host, row-major */

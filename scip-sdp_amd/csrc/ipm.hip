@@ -148,6 +148,8 @@ struct hipsdp_solver
    int a_r0, a_r1;         /* rows of A (0 = constant matrix, i = variable i) this rank holds; [0, m + 1) when replicated */
    hipsdp_params par;
    PhaseClock pc;
+   /* pinned / device staging chunks of hipsdp_master_add_vars (kept until hipsdp_free) */
+   void* stage_h[2]; void* stage_d[2]; hipEvent_t stage_ev[2]; long long stage_cap;
 };
 
 void hs_comm_phase(int phase);      /* multi.hip: the phase the next collectives are booked under */
@@ -343,6 +345,9 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
    s->pc.on = getenv("HIPSDP_PHASES") != NULL && atoi(getenv("HIPSDP_PHASES")) != 0;
    s->pc.open = -1;
    for (int p = 0; p < PH_COUNT; ++p) s->pc.ms[p] = 0.0;
+   s->stage_h[0] = s->stage_h[1] = s->stage_d[0] = s->stage_d[1] = NULL;
+   s->stage_ev[0] = s->stage_ev[1] = NULL;
+   s->stage_cap = 0;
    s->b = s->Dext = s->y = s->x = s->z = s->yt = s->dyt = s->wt = s->AX = s->AH = s->tmpe = s->rp = s->rd = s->tmpq = s->hl = NULL;
    s->beta = s->elp = s->dxa = s->dza = s->dx = s->dz = s->xs = s->zs = s->ys = s->u1 = s->rhs2 = s->u2 = s->dy = s->dya = NULL;
    s->Mx = s->Lm = s->dinvm = s->Slp = s->sc = s->red_ws = s->gemv_ws = s->lan_ws = s->lan_ws2 = s->gws1 = s->gws2 = NULL;
@@ -384,6 +389,12 @@ extern "C" void hipsdp_free(hipsdp_solver** ps)
    s->hsc = NULL;
    for (auto& mk : s->pc.marks) (void) hipEventDestroy(mk.second);
    for (hipEvent_t e : s->pc.pool) (void) hipEventDestroy(e);
+   for (int b = 0; b < 2; ++b)
+   {
+      if ( s->stage_h[b] != NULL ) (void) hipHostFree(s->stage_h[b]);
+      if ( s->stage_d[b] != NULL ) (void) hipFree(s->stage_d[b]);
+      if ( s->stage_ev[b] != NULL ) (void) hipEventDestroy(s->stage_ev[b]);
+   }
    (void) hipStreamSynchronize(s->stream2);
    (void) hipEventDestroy(s->ev0);
    (void) hipEventDestroy(s->ev1);
@@ -684,6 +695,124 @@ extern "C" int hipsdp_master_add_entries(hipsdp_solver* s, int block, long long 
    if ( herr != 0 )
    {
       set_err("hipsdp_master_add_entries: index out of range");
+      return HIPSDP_ERR_ARG;
+   }
+   return HIPSDP_OK;
+}
+
+/* The same upload straight from the caller's per-variable arrays (the layout of sdpisolver.h: sdprow[b][k], sdpcol[b][k],
+ * sdpval[b][k] with sdpnblockvarnonz[b][k] entries each), streamed through two pinned staging chunks: the host fills one chunk
+ * (block copies) while the copy engine moves the other and the scatter kernel consumes it.  No concatenated host copy (2.25 GB
+ * of freshly faulted pageable memory at n = 500, m = 1000) and no pageable H2D transfer. */
+#define HS_STAGE_ENTRIES (4LL << 20)
+static int stage_ensure(hipsdp_solver* s, long long want)
+{
+   long long cap = want < HS_STAGE_ENTRIES ? want : HS_STAGE_ENTRIES;
+   if ( cap < 1024 ) cap = 1024;
+   cap = (cap + 63) & ~63LL;              /* the value array follows three int arrays: keep it 8-byte aligned */
+   if ( s->stage_cap >= cap )
+      return HS_OK;
+   for (int b = 0; b < 2; ++b)
+   {
+      if ( s->stage_h[b] != NULL ) (void) hipHostFree(s->stage_h[b]);
+      if ( s->stage_d[b] != NULL ) (void) hipFree(s->stage_d[b]);
+      s->stage_h[b] = NULL; s->stage_d[b] = NULL;
+      if ( s->stage_ev[b] == NULL )
+         HS_HIP( hipEventCreateWithFlags(&s->stage_ev[b], hipEventDisableTiming) );
+   }
+   s->stage_cap = 0;
+   const size_t bytes = (size_t) cap * (3 * sizeof(int) + sizeof(double));
+   for (int b = 0; b < 2; ++b)
+   {
+      HS_HIP( hipHostMalloc((void**) &s->stage_h[b], bytes, hipHostMallocDefault) );
+      HS_HIP( hipMalloc((void**) &s->stage_d[b], bytes) );
+   }
+   s->stage_cap = cap;
+   return HS_OK;
+}
+
+extern "C" int hipsdp_master_add_vars(hipsdp_solver* s, int block, int nslots, const int* nnz, const int* const* row,
+   const int* const* col, const double* const* val)
+{
+   if ( s == NULL || block < 0 || block >= (int) s->master_A.size() || nslots < 0 || nslots > s->master_slots[block]
+      || (nslots > 0 && (nnz == NULL || row == NULL || col == NULL || val == NULL)) )
+      return HIPSDP_ERR_ARG;
+   long long total = 0;
+   for (int k = 0; k < nslots; ++k)
+   {
+      if ( nnz[k] < 0 )
+         return HIPSDP_ERR_ARG;
+      total += nnz[k];
+   }
+   if ( total == 0 )
+      return HIPSDP_OK;
+   HS_HIP( hipSetDevice(s->device) );
+   HS_CALL( stage_ensure(s, total) );
+   const long long cap = s->stage_cap;
+   const int n = s->master_sizes[block];
+   int* derr = NULL;
+   HS_CALL( dalloc(&derr, 1) );
+   HS_HIP( hipMemsetAsync(derr, 0, sizeof(int), s->stream) );
+   int k = 0;
+   long long off = 0;                  /* entries of slot k already shipped */
+   int set = 0;
+   bool used[2] = {false, false};
+   while ( k < nslots )
+   {
+      if ( used[set] )
+         HS_HIP( hipEventSynchronize(s->stage_ev[set]) );       /* the chunk's previous contents have been consumed */
+      char* hb = (char*) s->stage_h[set];
+      int* hvar = (int*) hb;
+      int* hrow = hvar + cap;
+      int* hcol = hrow + cap;
+      double* hval = (double*) (hcol + cap);
+      long long fill = 0;
+      while ( k < nslots && fill < cap )
+      {
+         const long long left = nnz[k] - off;
+         const long long take = left < cap - fill ? left : cap - fill;
+         if ( take > 0 )
+         {
+            for (long long t = 0; t < take; ++t)
+               hvar[fill + t] = k;
+            memcpy(hrow + fill, row[k] + off, (size_t) take * sizeof(int));
+            memcpy(hcol + fill, col[k] + off, (size_t) take * sizeof(int));
+            memcpy(hval + fill, val[k] + off, (size_t) take * sizeof(double));
+            fill += take;
+            off += take;
+         }
+         if ( off >= nnz[k] )
+         {
+            ++k;
+            off = 0;
+         }
+      }
+      if ( fill == 0 )
+         break;
+      char* db = (char*) s->stage_d[set];
+      int* dvar = (int*) db;
+      int* drow = dvar + cap;
+      int* dcol = drow + cap;
+      double* dval = (double*) (dcol + cap);
+      HS_HIP( hipMemcpyAsync(dvar, hvar, (size_t) fill * sizeof(int), hipMemcpyHostToDevice, s->stream) );
+      HS_HIP( hipMemcpyAsync(drow, hrow, (size_t) fill * sizeof(int), hipMemcpyHostToDevice, s->stream) );
+      HS_HIP( hipMemcpyAsync(dcol, hcol, (size_t) fill * sizeof(int), hipMemcpyHostToDevice, s->stream) );
+      HS_HIP( hipMemcpyAsync(dval, hval, (size_t) fill * sizeof(double), hipMemcpyHostToDevice, s->stream) );
+      long long g = (fill + 255) / 256; if ( g > 4096 ) g = 4096;
+      hipLaunchKernelGGL(k_scatter_coo, dim3((unsigned) g), dim3(256), 0, s->stream, fill, n, dvar, drow, dcol, dval, s->master_A[block], 0,
+         2147483647, s->master_A[block], s->master_slots[block] - 1, derr);
+      HS_LAUNCH_CHECK();
+      HS_HIP( hipEventRecord(s->stage_ev[set], s->stream) );
+      used[set] = true;
+      set ^= 1;
+   }
+   int herr = 0;
+   HS_HIP( hipMemcpyAsync(&herr, derr, sizeof(int), hipMemcpyDeviceToHost, s->stream) );
+   HS_HIP( hipStreamSynchronize(s->stream) );
+   dfree(derr);
+   if ( herr != 0 )
+   {
+      set_err("hipsdp_master_add_vars: index out of range");
       return HIPSDP_ERR_ARG;
    }
    return HIPSDP_OK;
