@@ -156,29 +156,33 @@ SCIP_RETCODE SCIPlapackLinearSolve(BMS_BUFMEM* bufmem, int m, int n, SCIP_Real* 
    SCIP_Real* V;
    SCIP_RETCODE rc;
    SCIP_Real lmax = 0.0;
+   SCIP_Real* res;
    int k;
    int j;
+   int i;
+   int it;
    (void) bufmem;
    if ( m <= 0 || n <= 0 )
       return SCIP_ERROR;
    AtA = (SCIP_Real*) malloc((size_t) n * (size_t) n * sizeof(SCIP_Real));
    Atb = (SCIP_Real*) malloc((size_t) n * sizeof(SCIP_Real));
-   if ( AtA == NULL || Atb == NULL )
+   res = (SCIP_Real*) malloc((size_t) m * sizeof(SCIP_Real));
+   if ( AtA == NULL || Atb == NULL || res == NULL )
    {
-      free(AtA); free(Atb);
+      free(AtA); free(Atb); free(res);
       return SCIP_NOMEMORY;
    }
    /* A col-major [m x n] = row-major At[n][m]; AtA = At At^T: both operands "K contiguous" with K = m */
    if ( hipsdp_dgemm(lapack_device(), 0, 0, n, n, m, 1.0, A, (long long) m, A, (long long) m, 0.0, AtA, (long long) n, 0, 1) != HIPSDP_OK
       || hipsdp_gemv_n(lapack_device(), n, (long long) m, A, 1, b, Atb) != HIPSDP_OK )
    {
-      free(AtA); free(Atb);
+      free(AtA); free(Atb); free(res);
       return SCIP_ERROR;
    }
    rc = decompose(n, AtA, &lam, &V);
    if ( rc != SCIP_OKAY )
    {
-      free(AtA); free(Atb);
+      free(AtA); free(Atb); free(res);
       return rc;
    }
    for (k = 0; k < n; ++k)
@@ -186,17 +190,42 @@ SCIP_RETCODE SCIPlapackLinearSolve(BMS_BUFMEM* bufmem, int m, int n, SCIP_Real* 
          lmax = lam[k];
    for (j = 0; j < n; ++j)
       x[j] = 0.0;
-   for (k = 0; k < n; ++k)
+   /* x = pinv(A^T A) A^T b through the eigenpairs, then two steps of iterative refinement with the residual formed from A itself
+    * (r = b - A x, x += pinv(A^T A) A^T r): the normal equations square the condition number, the refinement brings the error
+    * back to the order cond(A) eps that DGELSD's SVD delivers (lapack_interface.c:712-820) - while cond(A)^2 eps < 1.  The only
+    * caller is the rank-1 heuristic of cons_sdp.c:8158 (tens of rows and columns): these loops stay on the host. */
+   for (it = 0; it < 3; ++it)
    {
-      SCIP_Real coef = 0.0;
-      if ( lam[k] <= 1e-13 * lmax * (SCIP_Real) (m > n ? m : n) )
-         continue;
-      for (j = 0; j < n; ++j)
-         coef += V[(size_t) k * n + j] * Atb[j];
-      coef /= lam[k];
-      for (j = 0; j < n; ++j)
-         x[j] += coef * V[(size_t) k * n + j];
+      if ( it > 0 )
+      {
+         /* Atb := A^T (b - A x), A column-major: A[i + c m] */
+         for (i = 0; i < m; ++i)
+         {
+            SCIP_Real ri = b[i];
+            for (j = 0; j < n; ++j)
+               ri -= A[(size_t) j * m + i] * x[j];
+            res[i] = ri;
+         }
+         for (j = 0; j < n; ++j)
+         {
+            SCIP_Real t = 0.0;
+            for (i = 0; i < m; ++i)
+               t += A[(size_t) j * m + i] * res[i];
+            Atb[j] = t;
+         }
+      }
+      for (k = 0; k < n; ++k)
+      {
+         SCIP_Real coef = 0.0;
+         if ( lam[k] <= 1e-13 * lmax * (SCIP_Real) (m > n ? m : n) )
+            continue;
+         for (j = 0; j < n; ++j)
+            coef += V[(size_t) k * n + j] * Atb[j];
+         coef /= lam[k];
+         for (j = 0; j < n; ++j)
+            x[j] += coef * V[(size_t) k * n + j];
+      }
    }
-   free(AtA); free(Atb); free(lam); free(V);
+   free(AtA); free(Atb); free(lam); free(V); free(res);
    return SCIP_OKAY;
 }

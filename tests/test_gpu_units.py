@@ -215,6 +215,18 @@ def test_sciplapack_eigen_and_gemv(gpu):
     a_cm = A.reshape(-1, order="F").copy()
     assert lib.SCIPlapackLinearSolve(None, 6, 4, _pd(a_cm), _pd(b.copy()), _pd(xs)) == 1
     assert np.allclose(xs, np.linalg.lstsq(A, b, rcond=None)[0], atol=1e-8)
+    # an ill-conditioned system (cond 1e5: the normal equations alone lose 10 of 16 digits): the refinement steps bring the
+    # answer to what DGELSD's SVD gives
+    rng2 = np.random.default_rng(11)
+    U, _ = np.linalg.qr(rng2.standard_normal((12, 5)))
+    W, _ = np.linalg.qr(rng2.standard_normal((5, 5)))
+    A2 = (U * np.array([1.0, 1e-1, 1e-2, 1e-4, 1e-5])) @ W.T
+    b2 = A2 @ rng2.standard_normal(5) + 1e-3 * rng2.standard_normal(12)
+    x2 = np.zeros(5)
+    a2_cm = np.asfortranarray(A2).reshape(-1, order="F").copy()
+    assert lib.SCIPlapackLinearSolve(None, 12, 5, _pd(a2_cm), _pd(b2.copy()), _pd(x2)) == 1
+    xr = np.linalg.lstsq(A2, b2, rcond=None)[0]
+    assert np.linalg.norm(x2 - xr) <= 1e-6 * np.linalg.norm(xr)
 
 
 # flags of hs_gemm_args (csrc/hs_common.h)
