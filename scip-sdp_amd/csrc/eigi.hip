@@ -22,18 +22,38 @@
 
 namespace {
 
+/* lane exchange inside a row of 16 lanes on the data-parallel-primitive path (no LDS crossbar round trip as with ds_bpermute):
+ * CTRL = quad_perm / row_half_mirror / row_mirror pattern */
+template<int CTRL>
+__device__ __forceinline__ double ei_dpp(double v)
+{
+   int lo = __double2loint(v), hi = __double2hiint(v);
+   lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+   return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double ei_lane(double v, int l)
+{
+   const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+   return __hiloint2double(hi, lo);
+}
+
+/* sum over the 64 lanes, result in every lane: four butterfly steps inside the rows of 16 (lane ^ 1, lane ^ 2, mirror of 8,
+ * mirror of 16), then the four row sums are read as scalars and added in a fixed order */
 __device__ __forceinline__ double ei_wsum(double v)
 {
-#pragma unroll
-   for (int off = 32; off > 0; off >>= 1)
-      v += __shfl_xor(v, off, 64);
-   return v;
+   v += ei_dpp<0xB1>(v);              /* quad_perm [1, 0, 3, 2] */
+   v += ei_dpp<0x4E>(v);              /* quad_perm [2, 3, 0, 1] */
+   v += ei_dpp<0x141>(v);             /* row_half_mirror */
+   v += ei_dpp<0x140>(v);             /* row_mirror */
+   return ((ei_lane(v, 0) + ei_lane(v, 16)) + ei_lane(v, 32)) + ei_lane(v, 48);
 }
 
 __device__ __forceinline__ double ei_quad(double x)
 {
-   x += __shfl_xor(x, 1, 64);
-   x += __shfl_xor(x, 2, 64);
+   x += ei_dpp<0xB1>(x);
+   x += ei_dpp<0x4E>(x);
    return x;
 }
 
@@ -75,7 +95,7 @@ __global__ void __launch_bounds__(256) k_syevi_small(int n, int ith, int wantvec
       double t;
       {
          const double xi = (lane < len) ? a[k + 1 + lane][k] : 0.0;
-         const double x0 = __shfl(xi, 0, 64);
+         const double x0 = ei_lane(xi, 0);
          const double s2 = ei_wsum(lane >= 1 ? xi * xi : 0.0);
          double beta = x0, scale = 0.0;
          t = 0.0;
