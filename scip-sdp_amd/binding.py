@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIBPATH = os.path.join(_HERE, "lib", "libhipsdp.so")
+LIBPATH = os.environ.get("HIPSDP_LIB", os.path.join(_HERE, "lib", "libhipsdp.so"))     # HIPSDP_LIB: developer experiments with kernel variants
 
 STATUS_NAMES = {0: "optimal", 1: "dual_infeasible", 2: "dual_unbounded", 3: "both_infeasible", 4: "iterlimit",
                 5: "numeric", 6: "timelimit", 7: "objlimit", -1: "unsolved"}

@@ -34,6 +34,9 @@ typedef const __attribute__((address_space(1))) void* hs_gbl_ptr;
 #ifndef G2_NS
 #define G2_NS   4
 #endif
+#ifndef G2_WGPC
+#define G2_WGPC 2                           /* persistent workgroups per CU (3 needs G2_NS <= 3: 48 KiB of LDS each, and <= 170 VGPRs) */
+#endif
 #define G2_OPSZ (G2_BT * G2_BKS)            /* doubles per operand per stage */
 #define G2_SLOT (2 * G2_OPSZ)
 #define G2_GPS  4                           /* LDS-DMA instructions per wave per stage: 2 per operand */
@@ -112,7 +115,7 @@ __device__ __forceinline__ double g2_frag(const double* __restrict__ slot, int w
 }
 
 template<int LB>
-__global__ void __launch_bounds__(256, 2) hs_dgemm2_kernel(hs_gemm_args p, int kchunk, long long ntile, long long total, int rotdiv)
+__global__ void __launch_bounds__(256, G2_WGPC) hs_dgemm2_kernel(hs_gemm_args p, int kchunk, long long ntile, long long total, int rotdiv)
 {
    extern __shared__ __attribute__((aligned(1024))) double g2_smem[];
    const int tid = threadIdx.x, lane = tid & 63;
@@ -417,7 +420,7 @@ int hs_dgemm2_try(hipStream_t stream, const hs_gemm_args* a, int kchunk)
    const long long total = ntile * nz;
    if ( total < 384 )
       return 0;
-   int grid = 512;                     /* 2 workgroups per CU, 64 per XCD */
+   int grid = 256 * G2_WGPC;           /* G2_WGPC workgroups per CU, 32 G2_WGPC per XCD */
    const int Wx = grid / 8;
    /* rotation of the coordinate the K range depends on (see g2_decode): only when the interleave would pin it */
    int rotdiv = 0;
