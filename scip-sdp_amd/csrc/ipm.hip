@@ -275,7 +275,7 @@ static void free_problem(hipsdp_solver* s)
    }
    s->blk.clear();
    double* ptrs[] = {s->b, s->Dext, s->y, s->x, s->z, s->yt, s->dyt, s->wt, s->AX, s->AH, s->tmpe, s->rp, s->rd, s->tmpq, s->hl,
-      s->beta, s->elp, s->dxa, s->dza, s->dx, s->dz, s->xs, s->zs, s->ys, s->u1, s->rhs2, s->u2, s->dy, s->dya, s->Mx, s->Lm,
+      s->beta, s->elp, s->dxa, s->dza, s->dx, s->dz, s->xs, s->zs, s->ys, s->rhs2, s->u2, s->dy, s->dya, s->Mx, s->Lm,
       s->dinvm, s->Slp, s->sc, s->red_ws, s->gemv_ws, s->lan_ws, s->lan_ws2, s->gws1, s->gws2};
    for (double* p : ptrs) dfree(p);
    hs_schur_ws_free(&s->sws);
@@ -519,9 +519,12 @@ extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int*
    for (double** p : qv) HS_CALL( dalloc(p, q) );
    double** ev[] = {&s->yt, &s->dyt, &s->wt, &s->AX, &s->AH, &s->tmpe};
    for (double** p : ev) HS_CALL( dalloc(p, m1) );
-   double** mv[] = {&s->rp, &s->u1, &s->u2, &s->dy, &s->dya};
+   double** mv[] = {&s->rp, &s->u2, &s->dy, &s->dya};
    for (double** p : mv) HS_CALL( dalloc(p, m) );
-   HS_CALL( dalloc(&s->rhs2, 2LL * m) );
+   /* [g ; b ; h]: the right-hand side of a direction lives behind the two of the tau elimination, so that the predictor's solve
+    * can ride along with them as a third right-hand side (u1 is a view, not an allocation) */
+   HS_CALL( dalloc(&s->rhs2, 3LL * m) );
+   s->u1 = s->rhs2 + 2LL * m;
    HS_CALL( dalloc(&s->Mx, (m1 + 32) * m1) );      /* row padding: the 2 G shard chunks may overhang by < 2 G rows */
    HS_CALL( dalloc(&s->Lm, (long long) m * m) );
    HS_CALL( dalloc(&s->dinvm, hs_potrf_dinv_len(m)) );
@@ -1595,7 +1598,8 @@ struct QueueSwap
  * part 0: all of it.  part 1: only the right-hand side H_k, hl, A(H) and h = A(H) - eta rp (general path; it needs X, Z^-1 and the
  * residuals but not the Schur matrix, so the predictor's can run on the second queue beside the factorization of M);
  * part 2: the rest, after a part-1 call with the same arguments. */
-static int direction(hipsdp_solver* s, double sigma, double eta, double mu, double rg, bool useE, double etk, int part = 0)
+static int direction(hipsdp_solver* s, double sigma, double eta, double mu, double rg, bool useE, double etk, int part = 0,
+   bool u1_solved = false)
 {
    const int m = s->m, m1 = s->m + 1, q = s->q;
    const double sigmu = sigma * mu;
@@ -1635,7 +1639,7 @@ static int direction(hipsdp_solver* s, double sigma, double eta, double mu, doub
       return HS_OK;
    }
    const bool fuse_solve = (fusedA == 1) && m > 0 && m <= 64;      /* single-block factor of M: solve, reductions and closing kernel in one launch */
-   if ( m > 0 && !fuse_solve )
+   if ( m > 0 && !fuse_solve && !u1_solved )
       HS_CALL( hs_trsv_sync(s->stream, m, s->Lm, s->dinvm, 1, s->u1, m, 3, s->trsv_ws, &s->trsv_epoch) );
    /* BH = sum <B_k, H_k> + beta^T hl ; wrp ; bu1 */
    hs_red_batch_begin(s->stream);
@@ -2449,7 +2453,7 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       HS_HIP( hipEventRecord(s->ev1, st) );
       hs_comm_phase(2);
       phase_mark(s, PH_MSOLVE);
-      bool predH_queued = false;
+      bool predH_queued = false, predH_joined = false;
       if ( s->use2 && !no_overlap && s->comm == NULL && !small_problem(s) && m > 0 )
       {
          HS_CALL( fork2(s) );
@@ -2479,7 +2483,16 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
          {
             hipLaunchKernelGGL(k_rhs2, g1d(m), dim3(256), 0, st, m, s->Mx, s->b, s->rhs2);
             HS_LAUNCH_CHECK();
-            HS_CALL( hs_trsv_sync(st, m, s->Lm, s->dinvm, 2, s->rhs2, m, 3, s->trsv_ws, &s->trsv_epoch) );
+            if ( predH_queued )
+            {
+               /* the predictor's right-hand side h (formed on the second queue while M was factored) sits behind g and b: one
+                * solve with three right-hand sides instead of a pair and, later, a single one */
+               HS_CALL( join2(s) );
+               predH_joined = true;
+               HS_CALL( hs_trsv_sync(st, m, s->Lm, s->dinvm, 3, s->rhs2, m, 3, s->trsv_ws, &s->trsv_epoch) );
+            }
+            else
+               HS_CALL( hs_trsv_sync(st, m, s->Lm, s->dinvm, 2, s->rhs2, m, 3, s->trsv_ws, &s->trsv_epoch) );
          }
       }
       if ( m == 0 || m > 64 )
@@ -2510,9 +2523,9 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
 
       /* ---- predictor */
       phase_mark(s, PH_PRED);
-      if ( predH_queued )
+      if ( predH_queued && !predH_joined )
          HS_CALL( join2(s) );
-      HS_CALL( direction(s, 0.0, 1.0, mu, rg, false, 0.0, predH_queued ? 2 : 0) );
+      HS_CALL( direction(s, 0.0, 1.0, mu, rg, false, 0.0, predH_queued ? 2 : 0, predH_joined) );
       HS_CALL( steplen_enqueue(s) );
       HS_CALL( read_scalars(s, hs, hflags) );
       {
