@@ -22,6 +22,11 @@ int hs_gemv_n(hipStream_t s, int R, long long E, const double* A, long long lda,
 int hs_gemv_t(hipStream_t s, int R, long long E, const double* A, long long lda, const double* coef, double sa,
    const double* add, double* out);
 
+/* three linear combinations of the rows in one sweep over A (o_v[e] = sum_i c_v[i] A[i * lda + e]); 1: done, 0: shapes do not
+ * qualify (E, lda even, 16-byte aligned), < 0: error code negated */
+int hs_gemv_t3(hipStream_t s, int R, long long E, const double* A, long long lda, const double* c0, const double* c1, const double* c2,
+   double* o0, double* o1, double* o2);
+
 /* out[slot] = sum_e a[e] * b[e]  (deterministic two-stage; partials in ws, >= 512 doubles) ; accumulate: out[slot] += */
 /* deferred scalar reductions (kernels.hip): between begin and end, reductions over short vectors, scalar fills and scalar
  * copies on that stream are recorded and then executed in order by one launch */

@@ -65,6 +65,8 @@ struct Block
    double *Xs, *Zs;  /* saved iterate for step back-off */
    double *T2, *W2;  /* scratch of the second queue */
    double *Xpre;     /* X of the preoptimal iterate (allocated at the first capture) */
+   double *P2;       /* A^T([1; u2]): the part of dZ that multiplies dtau, the same for predictor and corrector (allocated on first use) */
+   double *pk3;      /* 3 Lp: packed outputs of the three-vector sweep (allocated on first use) */
    double *Apk;      /* (m + 1) x Lp packed lower copy of A for the HBM-bound passes; NULL when memory is short */
    double *pkv;      /* 2 Lp: packed vector in / out */
    long long Lp;
@@ -104,6 +106,7 @@ struct hipsdp_solver
    /* work vectors */
    double *yt, *dyt, *wt, *AX, *AH, *tmpe, *rp, *rd, *tmpq, *hl, *beta, *elp, *dxa, *dza, *dx, *dz, *xs, *zs, *ys;
    double *u1, *rhs2, *u2, *dy, *dya;
+   double *cvec;           /* 2 (m + 1): coefficient vectors [1; u2] and [0; u1] of the split dZ = A^T([0; u1]) - dtau A^T([1; u2]) + eta Rd */
    double *Mx, *Lm, *dinvm, *Slp;
    double *pre_y, *pre_x;  /* preoptimal iterate (params.preoptgap): y and the LP multipliers; X per block in Block::Xpre */
    bool pre_valid;
@@ -270,12 +273,12 @@ static void free_problem(hipsdp_solver* s)
    for (auto& B : s->blk)
    {
       double* ptrs[] = {B.Aown, B.A0sep, B.X, B.Z, B.Rd, B.Lz, B.LzInv, B.Zinv, B.Lx, B.LxInv, B.B, B.H, B.G, B.GZ, B.dXa, B.dZa, B.dX, B.dZ,
-         B.E, B.W, B.T1, B.dinvz, B.dinvx, B.Xs, B.Zs, B.Apkown, B.pkv, B.T2, B.W2, B.Xpre};
+         B.E, B.W, B.T1, B.dinvz, B.dinvx, B.Xs, B.Zs, B.Apkown, B.pkv, B.T2, B.W2, B.Xpre, B.P2, B.pk3};
       for (double* p : ptrs) dfree(p);
    }
    s->blk.clear();
    double* ptrs[] = {s->b, s->Dext, s->y, s->x, s->z, s->yt, s->dyt, s->wt, s->AX, s->AH, s->tmpe, s->rp, s->rd, s->tmpq, s->hl,
-      s->beta, s->elp, s->dxa, s->dza, s->dx, s->dz, s->xs, s->zs, s->ys, s->rhs2, s->u2, s->dy, s->dya, s->Mx, s->Lm,
+      s->beta, s->elp, s->dxa, s->dza, s->dx, s->dz, s->xs, s->zs, s->ys, s->rhs2, s->cvec, s->u2, s->dy, s->dya, s->Mx, s->Lm,
       s->dinvm, s->Slp, s->sc, s->red_ws, s->gemv_ws, s->lan_ws, s->lan_ws2, s->gws1, s->gws2};
    for (double* p : ptrs) dfree(p);
    hs_schur_ws_free(&s->sws);
@@ -291,7 +294,7 @@ static void free_problem(hipsdp_solver* s)
    s->pre_y = s->pre_x = NULL;
    s->pre_valid = false;
    s->b = s->Dext = s->y = s->x = s->z = s->yt = s->dyt = s->wt = s->AX = s->AH = s->tmpe = s->rp = s->rd = s->tmpq = s->hl = NULL;
-   s->beta = s->elp = s->dxa = s->dza = s->dx = s->dz = s->xs = s->zs = s->ys = s->u1 = s->rhs2 = s->u2 = s->dy = s->dya = NULL;
+   s->beta = s->elp = s->dxa = s->dza = s->dx = s->dz = s->xs = s->zs = s->ys = s->u1 = s->rhs2 = s->cvec = s->u2 = s->dy = s->dya = NULL;
    s->Mx = s->Lm = s->dinvm = s->Slp = s->sc = s->red_ws = s->gemv_ws = s->lan_ws = s->lan_ws2 = s->gws1 = s->gws2 = NULL;
    s->flags = NULL;
    s->shaped = false;
@@ -349,7 +352,7 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
    s->stage_ev[0] = s->stage_ev[1] = NULL;
    s->stage_cap = 0;
    s->b = s->Dext = s->y = s->x = s->z = s->yt = s->dyt = s->wt = s->AX = s->AH = s->tmpe = s->rp = s->rd = s->tmpq = s->hl = NULL;
-   s->beta = s->elp = s->dxa = s->dza = s->dx = s->dz = s->xs = s->zs = s->ys = s->u1 = s->rhs2 = s->u2 = s->dy = s->dya = NULL;
+   s->beta = s->elp = s->dxa = s->dza = s->dx = s->dz = s->xs = s->zs = s->ys = s->u1 = s->rhs2 = s->cvec = s->u2 = s->dy = s->dya = NULL;
    s->Mx = s->Lm = s->dinvm = s->Slp = s->sc = s->red_ws = s->gemv_ws = s->lan_ws = s->lan_ws2 = s->gws1 = s->gws2 = NULL;
    hipsdp_default_params(&s->par);
    if ( hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess
@@ -525,6 +528,7 @@ extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int*
     * can ride along with them as a third right-hand side (u1 is a view, not an allocation) */
    HS_CALL( dalloc(&s->rhs2, 3LL * m) );
    s->u1 = s->rhs2 + 2LL * m;
+   HS_CALL( dalloc(&s->cvec, 2LL * m1) );
    HS_CALL( dalloc(&s->Mx, (m1 + 32) * m1) );      /* row padding: the 2 G shard chunks may overhang by < 2 G rows */
    HS_CALL( dalloc(&s->Lm, (long long) m * m) );
    HS_CALL( dalloc(&s->dinvm, hs_potrf_dinv_len(m)) );
@@ -1113,6 +1117,15 @@ __global__ void k_finish_dir(int m, double eta, double rg, double sigmu, double 
    }
 }
 
+/* dZ = P1 - dtau P2 + eta Rd with dtau read from the scalar block (P1 is handed over in dZ) */
+__global__ void k_dz_combine(long long n2, double* __restrict__ dZ, const double* __restrict__ P2, const double* __restrict__ sc, double eta,
+   const double* __restrict__ Rd)
+{
+   const double dtau = sc[SC_DTAU];
+   for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long) gridDim.x * blockDim.x)
+      dZ[i] = (dZ[i] - dtau * P2[i]) + eta * Rd[i];
+}
+
 /* out = Rd + tau * A0  (certificate residual A^T y - Z) */
 __global__ void k_cert(long long n2, double tau, const double* __restrict__ Rd, const double* __restrict__ A0, double* __restrict__ out)
 {
@@ -1598,8 +1611,11 @@ struct QueueSwap
  * part 0: all of it.  part 1: only the right-hand side H_k, hl, A(H) and h = A(H) - eta rp (general path; it needs X, Z^-1 and the
  * residuals but not the Schur matrix, so the predictor's can run on the second queue beside the factorization of M);
  * part 2: the rest, after a part-1 call with the same arguments. */
+/* split: 0 = dZ by one pass with the coefficients [-dtau; dy]; 1 = dZ = P1 - dtau P2 + eta Rd with P1 = A^T([0; u1]) computed here
+ * by one pass and P2 = A^T([1; u2]) from the three-vector sweep of this iteration; 2 = P1 has been computed by that sweep as well
+ * (the predictor: its u1 was solved together with the right-hand sides of the tau elimination) */
 static int direction(hipsdp_solver* s, double sigma, double eta, double mu, double rg, bool useE, double etk, int part = 0,
-   bool u1_solved = false)
+   bool u1_solved = false, int split = 0)
 {
    const int m = s->m, m1 = s->m + 1, q = s->q;
    const double sigmu = sigma * mu;
@@ -1670,7 +1686,22 @@ static int direction(hipsdp_solver* s, double sigma, double eta, double mu, doub
    {
       const int n = B.n;
       const long long n2 = (long long) n * n;
-      HS_CALL( pass_AT(s, B, s->dyt, eta, B.Rd, B.dZ) );
+      if ( split == 0 )
+         HS_CALL( pass_AT(s, B, s->dyt, eta, B.Rd, B.dZ) );
+      else
+      {
+         if ( split == 1 )
+         {
+            if ( &B == &s->blk[0] )
+            {
+               hipLaunchKernelGGL(k_make_ext, g1d(m1), dim3(256), 0, s->stream, m, 0.0, 1.0, s->u1, s->cvec + m1);
+               HS_LAUNCH_CHECK();
+            }
+            HS_CALL( pass_AT(s, B, s->cvec + m1, 0.0, NULL, B.dZ) );
+         }
+         hipLaunchKernelGGL(k_dz_combine, g1d(n2), dim3(256), 0, s->stream, n2, B.dZ, B.P2, s->sc, eta, B.Rd);
+         HS_LAUNCH_CHECK();
+      }
       if ( n <= HS_SMALL_N )
          HS_CALL( hs_dir_block_small(s->stream, n, 1.0, B.X, B.dZ, useE ? B.E : NULL, B.Zinv, sigmu, B.dX) );
       else
@@ -2453,7 +2484,7 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       HS_HIP( hipEventRecord(s->ev1, st) );
       hs_comm_phase(2);
       phase_mark(s, PH_MSOLVE);
-      bool predH_queued = false, predH_joined = false;
+      bool predH_queued = false, predH_joined = false, split_dz = false;
       if ( s->use2 && !no_overlap && s->comm == NULL && !small_problem(s) && m > 0 )
       {
          HS_CALL( fork2(s) );
@@ -2503,11 +2534,52 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       /* B_k = A_0 - sum w_i A_i ; beta = c - D w ; S0 ; b^T M^-1 b */
       hs_red_batch_begin(st);
       HS_CALL( hs_fill_scalar(st, s->sc + SC_S0, 0.0) );
+      /* dZ = A^T([-dtau; u1 - u2 dtau]) + eta Rd is linear in dtau: A^T([0; u1]) - dtau A^T([1; u2]) + eta Rd.  u2 belongs to the
+       * iteration, the predictor's u1 has just been solved with it, so B = A^T(wt), P2 = A^T([1; u2]) and the predictor's
+       * P1 = A^T([0; u1]) come out of ONE sweep over A (three coefficient vectors), the corrector needs one more sweep for its P1:
+       * two sweeps per iteration where B, the predictor's dZ and the corrector's dZ took three - and the dependent chain
+       * B pass -> dtau -> dZ pass loses a link.  Single GPU, packed copy present, predictor solved early (else the old form). */
+      bool split_ok = predH_joined && s->comm == NULL && getenv("HIPSDP_NO_SPLIT_DZ") == NULL;
+      for (auto& B : s->blk)
+         if ( B.Apk == NULL )
+            split_ok = false;
+      if ( split_ok )
+      {
+         hipLaunchKernelGGL(k_make_ext, g1d(m1), dim3(256), 0, st, m, 1.0, 1.0, s->u2, s->cvec);
+         hipLaunchKernelGGL(k_make_ext, g1d(m1), dim3(256), 0, st, m, 0.0, 1.0, s->u1, s->cvec + m1);
+         HS_LAUNCH_CHECK();
+      }
+      split_dz = split_ok;
       for (auto& B : s->blk)
       {
          const int n = B.n;
          const long long n2 = (long long) n * n;
-         HS_CALL( pass_AT(s, B, s->wt, 0.0, NULL, B.B) );
+         bool swept = false;
+         if ( split_ok )
+         {
+            if ( B.P2 == NULL )
+            {
+               HS_CALL( dalloc(&B.P2, n2) );
+               HS_CALL( dalloc(&B.pk3, 3 * B.Lp) );
+            }
+            const int r3 = hs_gemv_t3(st, m1, B.Lp, B.Apk, B.Lp, s->wt, s->cvec, s->cvec + m1, B.pk3, B.pk3 + B.Lp, B.pk3 + 2 * B.Lp);
+            if ( r3 < 0 )
+               return -r3;
+            if ( r3 == 1 )
+            {
+               HS_CALL( hs_unpack_sym(st, n, B.pk3, 0.0, NULL, B.B) );
+               HS_CALL( hs_unpack_sym(st, n, B.pk3 + B.Lp, 0.0, NULL, B.P2) );
+               HS_CALL( hs_unpack_sym(st, n, B.pk3 + 2 * B.Lp, 0.0, NULL, B.dZ) );
+               swept = true;
+            }
+            else
+            {
+               HS_CALL( pass_AT(s, B, s->cvec, 0.0, NULL, B.P2) );
+               HS_CALL( pass_AT(s, B, s->cvec + m1, 0.0, NULL, B.dZ) );
+            }
+         }
+         if ( !swept )
+            HS_CALL( pass_AT(s, B, s->wt, 0.0, NULL, B.B) );
          HS_CALL( gemm(s, HS_KC, HS_MC, n, n, n, 1.0, B.X, n, B.B, n, 0.0, B.T1, n) );
          HS_CALL( gemm(s, HS_KC, HS_MC, n, n, n, 1.0, B.T1, n, B.Zinv, n, 0.0, B.W, n) );
          HS_CALL( hs_dot(st, n2, B.B, B.W, s->sc + SC_S0, 1, s->red_ws) );
@@ -2525,7 +2597,7 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       phase_mark(s, PH_PRED);
       if ( predH_queued && !predH_joined )
          HS_CALL( join2(s) );
-      HS_CALL( direction(s, 0.0, 1.0, mu, rg, false, 0.0, predH_queued ? 2 : 0, predH_joined) );
+      HS_CALL( direction(s, 0.0, 1.0, mu, rg, false, 0.0, predH_queued ? 2 : 0, predH_joined, split_dz ? 2 : 0) );
       HS_CALL( steplen_enqueue(s) );
       HS_CALL( read_scalars(s, hs, hflags) );
       {
@@ -2567,7 +2639,7 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
          HS_CALL( hs_vec_mul(st, q, s->dx, s->dz, s->elp) );
 
       /* ---- corrector */
-      HS_CALL( direction(s, sigma, eta, mu, rg, true, dta * dka) );
+      HS_CALL( direction(s, sigma, eta, mu, rg, true, dta * dka, 0, false, split_dz ? 1 : 0) );
       HS_CALL( steplen_enqueue(s) );
       HS_CALL( read_scalars(s, hs, NULL) );
       const double amax = steplen_host(s, hs);

@@ -1083,6 +1083,61 @@ __global__ void __launch_bounds__(256) k_gemv_t(int R, long long E, const double
    }
 }
 
+/* three linear combinations of the rows in ONE sweep over A: out_v[e] = sum_i coef_v[i] A[i][e], v = 0, 1, 2 (same summation order
+ * per output as k_gemv_t: identical bits).  E even, lda even, 16-byte aligned bases. */
+__global__ void __launch_bounds__(256) k_gemv_t3(int R, long long E, const double* __restrict__ A, long long lda,
+   const double* __restrict__ c0, const double* __restrict__ c1, const double* __restrict__ c2, double* __restrict__ o0,
+   double* __restrict__ o1, double* __restrict__ o2)
+{
+   const long long e = 2 * ((long long) blockIdx.x * blockDim.x + threadIdx.x);
+   if ( e >= E )
+      return;
+   double s00 = 0.0, s01 = 0.0, s10 = 0.0, s11 = 0.0, s20 = 0.0, s21 = 0.0;
+   const double* a = A + e;
+   int i = 0;
+   for (; i + 4 <= R; i += 4)
+   {
+      const dbl2 x0 = *reinterpret_cast<const dbl2*>(a + (long long) (i + 0) * lda);
+      const dbl2 x1 = *reinterpret_cast<const dbl2*>(a + (long long) (i + 1) * lda);
+      const dbl2 x2 = *reinterpret_cast<const dbl2*>(a + (long long) (i + 2) * lda);
+      const dbl2 x3 = *reinterpret_cast<const dbl2*>(a + (long long) (i + 3) * lda);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+      {
+         const dbl2 x = q == 0 ? x0 : (q == 1 ? x1 : (q == 2 ? x2 : x3));
+         const double a0 = c0[i + q], a1 = c1[i + q], a2 = c2[i + q];
+         s00 += a0 * x.x; s01 += a0 * x.y;
+         s10 += a1 * x.x; s11 += a1 * x.y;
+         s20 += a2 * x.x; s21 += a2 * x.y;
+      }
+   }
+   for (; i < R; ++i)
+   {
+      const dbl2 x = *reinterpret_cast<const dbl2*>(a + (long long) i * lda);
+      const double a0 = c0[i], a1 = c1[i], a2 = c2[i];
+      s00 += a0 * x.x; s01 += a0 * x.y;
+      s10 += a1 * x.x; s11 += a1 * x.y;
+      s20 += a2 * x.x; s21 += a2 * x.y;
+   }
+   o0[e] = s00; o0[e + 1] = s01;
+   o1[e] = s10; o1[e + 1] = s11;
+   o2[e] = s20; o2[e + 1] = s21;
+}
+
+/* 1: done in one sweep; 0: shapes / alignment do not qualify (the caller makes three hs_gemv_t calls) */
+int hs_gemv_t3(hipStream_t s, int R, long long E, const double* A, long long lda, const double* c0, const double* c1, const double* c2,
+   double* o0, double* o1, double* o2)
+{
+   if ( E <= 0 || R <= 0 || (E & 1) || (lda & 1) || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(o0) & 15)
+      || (reinterpret_cast<uintptr_t>(o1) & 15) || (reinterpret_cast<uintptr_t>(o2) & 15) )
+      return 0;
+   const long long nthreads = E / 2;
+   hipLaunchKernelGGL(k_gemv_t3, dim3((unsigned) ((nthreads + 255) / 256)), dim3(256), 0, s, R, E, A, lda, c0, c1, c2, o0, o1, o2);
+   if ( hipGetLastError() != hipSuccess )
+      return -HS_ERR_HIP;
+   return 1;
+}
+
 int hs_gemv_t(hipStream_t s, int R, long long E, const double* A, long long lda, const double* coef, double sa,
    const double* add, double* out)
 {
