@@ -313,8 +313,13 @@ def hsd_solve(prob, par=None, start=None):
         def msolve(r):
             if m == 0:
                 return r
+            # each triangular solve is corrected once with the factor itself, as the engine's block solves are (chol.hip, hs_trsv
+            # mode bit 4): the residual of M dy = h is the primal infeasibility the step leaves behind, and on nodes whose
+            # optimum is not attained (tau -> 0) it decides whether the iteration still converges
             w = sla.solve_triangular(Lm, r, lower=True, check_finite=False)
-            return sla.solve_triangular(Lm.T, w, lower=False, check_finite=False)
+            w = w + sla.solve_triangular(Lm, r - Lm @ w, lower=True, check_finite=False)
+            v = sla.solve_triangular(Lm.T, w, lower=False, check_finite=False)
+            return v + sla.solve_triangular(Lm.T, w - Lm.T @ v, lower=False, check_finite=False)
 
         # Stable elimination of (dtau, dkappa).  With w = M^-1 g the direction (1, -w) is the near-null direction of the
         # extended Schur matrix; omega - g^T M^-1 g is evaluated in factored form (a sum of non-negative terms) instead of

@@ -14,41 +14,75 @@
 #define NB 64
 #define HS_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if ( e_ != hipSuccess ) { hs_record_hip_error(e_, "kernel launch", __FILE__, __LINE__); return HS_ERR_HIP; } } while (0)
 
+#ifdef PD_TIMING
+/* development build only (tests/devtools/potrf_phase_time.py): 100 MHz time stamps of the second step workgroup of the launch
+ * whose first column is pd_tj0 */
+__device__ long long pd_tbuf[16];
+__device__ int pd_tj0;
+#define PD_T(idx) do { if ( threadIdx.x == 0 && j0 == pd_tj0 && blockIdx.x == (gridDim.x > 1 ? 1u : 0u) ) pd_tbuf[idx] = wall_clock64(); } while (0)
+extern "C" int hipsdp_debug_pd_timing(int j0, long long* out)
+{
+   if ( out != NULL && hipMemcpyFromSymbol(out, HIP_SYMBOL(pd_tbuf), sizeof(long long) * 16) != hipSuccess )
+      return 1;
+   return hipMemcpyToSymbol(HIP_SYMBOL(pd_tj0), &j0, sizeof(int)) == hipSuccess ? 0 : 1;
+}
+#else
+#define PD_T(idx) do { } while (0)
+#endif
+
 /* Factor the nb x nb diagonal block at A (leading dimension lda), nb <= 64: A_blk = L L^T.  Writes L into the lower
  * triangle of the block and inv(L) (64 x 64, identity-padded) into dinv.  flag: first failing global pivot index + 1.
  *
- * 256 threads.  Factorization: thread t owns row i = t / 4 and the 16 columns j = (t % 4) + 4 jj in registers; column k
- * is published through a double-buffered LDS vector, so a step costs one barrier; a step issues all its LDS reads up
- * front and has no branches in the update; pivots go through v_rsq_f64 + Goldschmidt steps (square root and reciprocal
- * together, no division).  Inverse: the four 16 x 16 diagonal blocks are inverted by one wavefront each (lane c = column
- * c, right-looking), the six off-diagonal blocks X_ij = -X_ii (sum_k L_ik X_kj) are 16 x 16 x 16 products on the matrix
+ * 256 threads, the block in LDS.  The sequential part - 64 pivots - is a register recurrence without barriers and without
+ * LDS traffic: the block is processed in four panels of 16 columns; every wavefront holds the whole panel (lane = row,
+ * 16 registers = the columns of the panel; all four wavefronts do this redundantly, so none waits for another), a column
+ * step reads the pivot and the column through v_readlane (scalar operands of the update), the pivot goes through
+ * v_rsq_f64 + one third-order correction (square root and reciprocal together, no division), and the update of the
+ * remaining columns of the panel folds the scaling in: a_ij -= (a_ik / d) a_jk.  After a panel the trailing 16 x 16
+ * tiles get their rank-16 update on the matrix cores (tiles dealt out to the four wavefronts), one barrier per panel.
+ * [The previous form - two columns per barrier with the pivot columns broadcast through LDS - read 64 KB of LDS per pair of
+ * columns (every thread the 32 column entries of its own columns) and spent 20 of the 25 microseconds of a block there.]
+ * Inverse: the four 16 x 16 diagonal blocks are inverted by one wavefront each (lane c = column c, the rows of L preloaded
+ * into registers), the six off-diagonal blocks X_ij = -X_ii (sum_k L_ik X_kj) are 16 x 16 x 16 products on the matrix
  * cores (the f64 accumulator layout of the inner sum is exactly the B-operand layout of the outer product), one block
  * diagonal per barrier.  All loops are fully unrolled (static register indices). */
-__device__ __forceinline__ void sqrt_and_rsqrt(double d, double* sd, double* isd)
+__device__ __forceinline__ void sqrt_and_rsqrt(double d, double y0, double* sd, double* isd)
 {
-   double y = __builtin_amdgcn_rsq(d);
+   /* y0 = v_rsq_f64(d) carries about 23 bits; y = y0 (1 + e / 2 + 3 e^2 / 8) with e = 1 - d y0^2 leaves 5/16 e^3: below 2^-66 */
+   const double t = d * y0;
+   const double e = fma(-t, y0, 1.0);
+   const double p = fma(0.375, e, 0.5);
+   const double y = fma(y0 * e, p, y0);
+   /* square root with one residual correction: g += (d - g^2) y / 2 */
    double g = d * y;
-   double h = 0.5 * y;
-   double r = fma(-h, g, 0.5);
-   g = fma(g, r, g);
-   h = fma(h, r, h);
-   r = fma(-h, g, 0.5);
-   g = fma(g, r, g);
-   h = fma(h, r, h);
-   /* one residual correction of the square root: g += (d - g^2) * h, and of the reciprocal */
-   g = fma(fma(-g, g, d), h, g);
-   double y2 = 2.0 * h;
-   y2 = fma(fma(-g, y2, 1.0), y2, y2);
+   g = fma(fma(-g, g, d), 0.5 * y, g);
    *sd = g;
-   *isd = y2;
+   *isd = y;
+}
+
+/* LDS written by some lanes of a wavefront is read by other lanes of the same wavefront: the hardware serves a wavefront's
+ * LDS instructions in order, the compiler has to be told (without this it keeps values loaded earlier for the lanes that did
+ * not store themselves) */
+__device__ __forceinline__ void pd_wave_sync()
+{
+   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+   __builtin_amdgcn_wave_barrier();
+   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+/* the value lane src holds, as a wavefront-uniform (scalar) operand */
+__device__ __forceinline__ double pd_lane(double v, int src)
+{
+   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+   return __hiloint2double(hi, lo);
 }
 
 struct __attribute__((aligned(16))) dpair { double x, y; };
 typedef double v4dc __attribute__((ext_vector_type(4)));
 
 #define PD_LD (NB + 2)
-#define PD_COLP (2 * 2 * 4 * 18)
-#define PD_SMEM_BYTES ((PD_COLP + 2 * NB * PD_LD + 3 * NB) * (int) sizeof(double))
+#define PD_SMEM_BYTES ((2 * NB * PD_LD + 4 * NB) * (int) sizeof(double))
 
 /* optional fused inputs / outputs of a single-block factorization (n <= 64; everything NULL for the blocked driver):
  * the matrix is base + alpha * dir (full symmetric storage, ld = lda) and is also stored to Mout; L gets a zero upper
@@ -65,90 +99,65 @@ struct pd_ext
                               * of recording a failure into a flag that somebody cleared beforehand */
    int           rule;      /* 0: forced pivots keep their column, 1: forced columns are zeroed, 2: zeroed when the pivot was <= 0 */
    int*          regmask;   /* semidefinite mode: regmask[j0 + k] = 1 when the pivot of column k was forced (may be NULL) */
-   int           from_lds;  /* 1 (k_potrf_step): the block to factor sits in the LDS tile that later holds inv(L), not in global memory */
+   int           from_lds;  /* 1 (k_potrf_step): the block to factor already sits in the first LDS tile, not in global memory */
    int           nostore;   /* 1 (k_potrf_step, all workgroups but the first): L, inv(L), flag and mask stay in LDS / registers */
    double*       Lout;      /* k_potrf_step: where the owner stores L_kk (64 x 64 staging block, ld 64) instead of the matrix itself: the
                              * other step workgroups of the launch still read the unfactored block from the matrix */
 };
 
-template<int NBK>      /* padded block size actually processed: 16, 32 or 64 (tiny blocks skip the identity padding) */
-__device__ __forceinline__ void pd_body(double* __restrict__ A, long long lda, int nb, int j0,
-   double* __restrict__ dinv, int* __restrict__ flag, const double* __restrict__ diag0, double regtol, const pd_ext& ext)
+/* panel of 16 columns starting at c0 out of the LDS block: lane = row; rows above the panel and the part of the diagonal block
+ * above the diagonal give zeros */
+__device__ __forceinline__ void pd_load_panel(double (&r)[16], const double (*W)[PD_LD], int lane, int c0, bool mine)
 {
-   extern __shared__ __attribute__((aligned(16))) double pd_smem[];
-   double (*colp)[2][4][18] = reinterpret_cast<double (*)[2][4][18]>(pd_smem);            /* columns k, k + 1, permuted: row i at [i & 3][i >> 2]; two buffers */
-   double (*lmT)[PD_LD] = reinterpret_cast<double (*)[PD_LD]>(pd_smem + PD_COLP);          /* lmT[k][i] = L[i][k] (final) */
-   double (*X)[PD_LD] = reinterpret_cast<double (*)[PD_LD]>(pd_smem + PD_COLP + NB * PD_LD);   /* inv(L), row major */
-   double* invd = pd_smem + PD_COLP + 2 * NB * PD_LD;
-   double* d0s = invd + NB;
-   double* forced = d0s + NB;          /* 1.0 where the pivot of the column was forced and its column zeroed (semidefinite mode) */
-   const int tid = threadIdx.x;
-   const int lane = tid & 63;
-   const int wave = tid >> 6;
-   const int i = tid >> 2;
-   const int jc = tid & 3;
-   const int ir = i & 3, iq = i >> 2;
-   double r[16];
 #pragma unroll
-   for (int jj = 0; jj < 16; ++jj)
+   for (int q = 0; q < 8; ++q)
    {
-      const int j = jc + 4 * jj;
-      double v = (i == j) ? 1.0 : 0.0;
-      if ( i < nb && j <= i )
-      {
-         if ( ext.base != NULL )
-         {
-            v = ext.base[(long long) i * lda + j];
-            if ( ext.dir != NULL )
-               v = fma(ext.alpha, ext.dir[(long long) i * lda + j], v);
-            if ( ext.Mout != NULL )
-            {
-               ext.Mout[(long long) i * lda + j] = v;
-               ext.Mout[(long long) j * lda + i] = v;
-            }
-         }
-         else if ( ext.from_lds )
-            v = X[i][j];
-         else
-            v = A[(long long) i * lda + j];
-      }
-      r[jj] = v;
+      dpair u = {0.0, 0.0};
+      if ( mine )
+         u = *reinterpret_cast<const dpair*>(&W[lane][c0 + 2 * q]);
+      r[2 * q] = (lane >= c0 + 2 * q) ? u.x : 0.0;
+      r[2 * q + 1] = (lane >= c0 + 2 * q + 1) ? u.y : 0.0;
    }
-   if ( diag0 != NULL && tid < nb )
-      d0s[tid] = diag0[j0 + tid];
-   int bad = 0;
+}
 
-   /* two columns per barrier: columns k and k + 1 are published together; every thread eliminates column k from
-    * column k + 1 itself (2 x 2 pivot block), then applies the rank-2 update r_ij -= l_ik l_jk + l_i,k+1 l_j,k+1 as two
-    * fused multiply-adds per entry:  with  t0 = l_ik / l_kk,  u = l_i,k+1 / l_k+1,k+1,  l_j,k+1 l_k+1,k+1 = a_j,k+1 - l_jk l_k+1,k:
-    *   r_ij -= (t0 - u l_k+1,k / l_kk) a_jk + u a_j,k+1 */
+/* The 16 pivot steps of one panel (lane = row, r[c] = column c0 + c of the row; rows above the panel hold zeros).
+ * CHECKED = false is the straight recurrence: no branch, nothing but the pivot chain and the updates; it only notes whether a
+ * pivot fell below its threshold thr[k] (0, or regtol * reference diagonal in semidefinite mode; also true for NaN), in which
+ * case the caller reloads the panel and runs the CHECKED form, which replaces such pivots (see below).  isd[k] = 1 / l_kk,
+ * fbits: bit k set where the pivot was forced and its column zeroed. */
+template<bool CHECKED>
+__device__ __forceinline__ bool pd_panel(double (&r)[16], const double (&thr)[16], const double (&dds)[16], int lane, int c0, int nb, int j0,
+   bool psd, double regtol, int rule, double (&isdo)[16], unsigned& fbits, int& bad, double* __restrict__ colb)
+{
+   bool special = false;
+   fbits = 0u;
 #pragma unroll
-   for (int k = 0; k < NBK; k += 2)
+   for (int k = 0; k < 16; ++k)
    {
-      const int buf = (k >> 1) & 1;
-      /* owners publish columns k and k + 1 (rows >= k) */
-      if ( jc == (k & 3) && i >= k )
-         colp[buf][0][ir][iq] = r[k >> 2];
-      if ( jc == ((k + 1) & 3) && i >= k )
-         colp[buf][1][ir][iq] = r[(k + 1) >> 2];
-      __syncthreads();
-      /* everything a step needs from LDS is requested up front (no branches between the reads) */
-      double d0 = colp[buf][0][k & 3][k >> 2];
-      const double a10 = colp[buf][0][(k + 1) & 3][(k + 1) >> 2];
-      double d1 = colp[buf][1][(k + 1) & 3][(k + 1) >> 2];
-      const double ci0 = colp[buf][0][ir][iq];
-      const double ci1 = colp[buf][1][ir][iq];
-      dpair ca[8], cb[8];
+      const int gk = c0 + k;
+      const double a = r[k];
+      double d = pd_lane(a, gk);
+      double y0 = __builtin_amdgcn_rsq(d);
+      double cj[16];
+      if ( k + 2 < 16 )
+      {
+         if ( lane >= c0 && lane < c0 + 16 )
+            colb[lane - c0] = a;
+         pd_wave_sync();
 #pragma unroll
-      for (int q = 0; q < 8; ++q)
-      {
-         ca[q] = *reinterpret_cast<const dpair*>(&colp[buf][0][jc][2 * q]);
-         cb[q] = *reinterpret_cast<const dpair*>(&colp[buf][1][jc][2 * q]);
+         for (int q = (k + 2) / 2; q < 8; ++q)
+         {
+            const dpair u = *reinterpret_cast<const dpair*>(&colb[2 * q]);
+            cj[2 * q] = u.x;
+            cj[2 * q + 1] = u.y;
+         }
       }
-      bool reg0 = false, reg1 = false;
-      if ( k < nb )
+      bool reg = false;
+      if ( !CHECKED )
+         special = special || !(d > thr[k]);
+      else if ( gk < nb )
       {
-         if ( diag0 != NULL )
+         if ( psd )
          {
             /* semidefinite mode (Schur complement with dependent columns): a pivot that cancelled to rounding level is
              * replaced by a small positive one, which keeps the direction alive so that a ray along it can be found; when
@@ -156,108 +165,195 @@ __device__ __forceinline__ void pd_body(double* __restrict__ A, long long lda, i
              * a column that is zero in exact arithmetic, and it is SET to zero: dividing noise by the forced pivot and
              * eliminating with it amplifies the noise exponentially over a run of dependent columns (observed: entries at
              * 1e158 for m = 200 with rank 136) */
-            const double dd = d0s[k];
-            if ( !(d0 > regtol * dd) || !(d0 > 1e-300) )
+            const double dd = dds[k];
+            if ( !(d > regtol * dd) || !(d > 1e-300) )
             {
-               reg0 = (ext.rule == 1) || (ext.rule == 2 && !(d0 > 0.0));
-               d0 = (dd > 1e-280) ? regtol * dd : 1.0;
+               reg = (rule == 1) || (rule == 2 && !(d > 0.0));
+               d = (dd > 1e-280) ? regtol * dd : 1.0;
+               y0 = __builtin_amdgcn_rsq(d);
             }
          }
-         else if ( !(d0 > 0.0) )
+         else if ( !(d > 0.0) )
          {
             if ( bad == 0 )
-               bad = j0 + k + 1;
-            d0 = 1.0;                 /* keep going with a harmless pivot; the caller reads the flag */
+               bad = j0 + gk + 1;
+            d = 1.0;                 /* keep going with a harmless pivot; the caller reads the flag */
+            y0 = 1.0;
          }
       }
-      double sd0, isd0;
-      sqrt_and_rsqrt(d0, &sd0, &isd0);
-      const double e0 = reg0 ? 0.0 : isd0;           /* scale of the sub-column (0: forced pivot) */
-      const double l10 = a10 * e0;
-      d1 = fma(-l10, l10, d1);
-      if ( k + 1 < nb )
-      {
-         if ( diag0 != NULL )
-         {
-            const double dd = d0s[k + 1];
-            if ( !(d1 > regtol * dd) || !(d1 > 1e-300) )
-            {
-               reg1 = (ext.rule == 1) || (ext.rule == 2 && !(d1 > 0.0));
-               d1 = (dd > 1e-280) ? regtol * dd : 1.0;
-            }
-         }
-         else if ( !(d1 > 0.0) )
-         {
-            if ( bad == 0 )
-               bad = j0 + k + 2;
-            d1 = 1.0;
-         }
-      }
-      double sd1, isd1;
-      sqrt_and_rsqrt(d1, &sd1, &isd1);
-      const double e1 = reg1 ? 0.0 : isd1;
-      const double li0 = (i > k) ? ci0 * e0 : 0.0;
-      const double li1 = (i > k + 1) ? fma(-li0, l10, ci1) * e1 : 0.0;
-      const double u = li1 * e1;
-      const double al = fma(-u * l10, e0, li0 * e0);
-      if ( tid == 0 )
-      {
-         forced[k] = reg0 ? 1.0 : 0.0;
-         forced[k + 1] = reg1 ? 1.0 : 0.0;
-         if ( ext.regmask != NULL && !ext.nostore )
-         {
-            if ( k < nb ) ext.regmask[j0 + k] = reg0 ? 1 : 0;
-            if ( k + 1 < nb ) ext.regmask[j0 + k + 1] = reg1 ? 1 : 0;
-         }
-      }
-      if ( jc == (k & 3) )
-      {
-         /* final value of column k in my row */
-         const double lv = (i > k) ? li0 : ((i == k) ? sd0 : 0.0);
-         r[k >> 2] = lv;
-         lmT[k][i] = lv;
-         if ( i == k )
-            invd[k] = isd0;
-      }
-      else if ( jc == ((k + 1) & 3) )
-      {
-         const double lv = (i > k + 1) ? li1 : ((i == k + 1) ? sd1 : 0.0);
-         r[(k + 1) >> 2] = lv;
-         lmT[k + 1][i] = lv;
-         if ( i == k + 1 )
-            invd[k + 1] = isd1;
-      }
-      else if ( jc > ((k + 1) & 3) )
-      {
-         /* the columns k + 2, k + 3 of this group of four (k and k + 1 share a group: k is even) */
-         const double va = ((k >> 2) & 1) ? ca[k >> 3].y : ca[k >> 3].x;
-         const double vb = ((k >> 2) & 1) ? cb[k >> 3].y : cb[k >> 3].x;
-         r[k >> 2] = fma(-u, vb, fma(-al, va, r[k >> 2]));
-      }
+      double sd, isd;
+      sqrt_and_rsqrt(d, y0, &sd, &isd);
+      const double e = reg ? 0.0 : isd;            /* scale of the sub-column (0: forced pivot) */
+      const double t = a * (e * e);
+      /* the column entries a_jk of the diagonal block as wavefront-uniform operands: the first one (it makes the next pivot) through
+       * v_readlane, the others through the wavefront's 16 doubles of LDS (written above, no barrier: LDS serves a wavefront in
+       * order), which costs a fifth of the instructions of 2 x 14 v_readlane + their wait states */
+      if ( k + 1 < 16 )
+         r[k + 1] = fma(-t, pd_lane(a, gk + 1), r[k + 1]);
 #pragma unroll
-      for (int jj = (k >> 2) + 1; jj < 16; ++jj)
+      for (int j = k + 2; j < 16; ++j)
+         r[j] = fma(-t, cj[j], r[j]);
+      /* final value of column gk in my row */
+      r[k] = (lane > gk) ? a * e : ((lane == gk) ? sd : 0.0);
+      isdo[k] = isd;
+      if ( reg )
+         fbits |= 1u << k;
+   }
+   return special;
+}
+
+/* LDS: tile 0 = the block while it is factored, inv(L) afterwards; tile 1 = L; then 1 / l_kk, the reference diagonal, the forced flags */
+template<int NBK>      /* padded block size actually processed: 16, 32 or 64 (tiny blocks skip the identity padding) */
+__device__ __forceinline__ void pd_body(double* __restrict__ A, long long lda, int nb, int j0,
+   double* __restrict__ dinv, int* __restrict__ flag, const double* __restrict__ diag0, double regtol, const pd_ext& ext)
+{
+   extern __shared__ __attribute__((aligned(16))) double pd_smem[];
+   double (*W)[PD_LD] = reinterpret_cast<double (*)[PD_LD]>(pd_smem);                      /* working block, row major */
+   double (*Lm)[PD_LD] = reinterpret_cast<double (*)[PD_LD]>(pd_smem + NB * PD_LD);        /* L, row major */
+   double (*X)[PD_LD] = W;                                                                  /* inv(L), row major (after the factorization) */
+   double* invd = pd_smem + 2 * NB * PD_LD;
+   double* d0s = invd + NB;
+   double* forced = d0s + NB;          /* 1.0 where the pivot of the column was forced and its column zeroed (semidefinite mode) */
+   const int tid = threadIdx.x;
+   const int lane = tid & 63;
+   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+   const int lr = lane & 15, lk = lane >> 4;
+   double* colb = forced + NB + 16 * wave;      /* the wavefront's current pivot column (16 doubles) */
+   {
+      const int i = tid >> 2;
+      const int jc = tid & 3;
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj)
       {
-         const double va = (jj & 1) ? ca[jj >> 1].y : ca[jj >> 1].x;
-         const double vb = (jj & 1) ? cb[jj >> 1].y : cb[jj >> 1].x;
-         r[jj] = fma(-u, vb, fma(-al, va, r[jj]));
+         const int j = jc + 4 * jj;
+         double v = (i == j) ? 1.0 : 0.0;
+         if ( i < nb && j <= i )
+         {
+            if ( ext.base != NULL )
+            {
+               v = ext.base[(long long) i * lda + j];
+               if ( ext.dir != NULL )
+                  v = fma(ext.alpha, ext.dir[(long long) i * lda + j], v);
+               if ( ext.Mout != NULL )
+               {
+                  ext.Mout[(long long) i * lda + j] = v;
+                  ext.Mout[(long long) j * lda + i] = v;
+               }
+            }
+            else if ( ext.from_lds )
+               v = W[i][j];
+            else
+               v = A[(long long) i * lda + j];
+         }
+         W[i][j] = v;
       }
    }
+   if ( diag0 != NULL && tid < nb )
+      d0s[tid] = diag0[j0 + tid];
+   int bad = 0;
    __syncthreads();
+   PD_T(4);
+
+   constexpr int NBLK = NBK / 16;
+#pragma unroll
+   for (int b = 0; b < NBLK; ++b)
+   {
+      const int c0 = 16 * b;
+      if ( b == 2 )
+         PD_T(3);
+      /* the panel: lane = row, r[c] = column c0 + c; rows above the panel idle; within the diagonal block the upper part is not used */
+      double r[16];
+      const bool mine = (lane >= c0 && lane < NBK);
+      pd_load_panel(r, W, lane, c0, mine);
+      double dds[16], thr[16], isdo[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+      {
+         dds[k] = 0.0;
+         thr[k] = 0.0;
+         if ( diag0 != NULL && c0 + k < nb )
+         {
+            dds[k] = d0s[c0 + k];
+            thr[k] = fmax(regtol * dds[k], 1e-300);
+         }
+      }
+      unsigned fbits;
+      if ( pd_panel<false>(r, thr, dds, lane, c0, nb, j0, diag0 != NULL, regtol, ext.rule, isdo, fbits, bad, colb) )
+      {
+         /* rare: a pivot needs the semidefinite treatment or is reported: once more from the unchanged block, with the checks */
+         pd_load_panel(r, W, lane, c0, mine);
+         (void) pd_panel<true>(r, thr, dds, lane, c0, nb, j0, diag0 != NULL, regtol, ext.rule, isdo, fbits, bad, colb);
+      }
+      if ( lane < 16 )
+      {
+         double v = isdo[0];
+#pragma unroll
+         for (int k = 1; k < 16; ++k)
+            v = (lane == k) ? isdo[k] : v;
+         invd[c0 + lane] = v;
+         const bool f = ((fbits >> lane) & 1u) != 0u;
+         forced[c0 + lane] = f ? 1.0 : 0.0;
+         if ( ext.regmask != NULL && !ext.nostore && wave == 0 && c0 + lane < nb )
+            ext.regmask[j0 + c0 + lane] = f ? 1 : 0;
+      }
+      if ( mine )
+      {
+#pragma unroll
+         for (int q = 0; q < 8; ++q)
+         {
+            const dpair u = {r[2 * q], r[2 * q + 1]};
+            *reinterpret_cast<dpair*>(&Lm[lane][c0 + 2 * q]) = u;
+         }
+      }
+      pd_wave_sync();
+      /* rank-16 update of the tiles right of the panel: (i, j), b < j <= i, dealt out to the wavefronts column by column */
+      if ( b + 1 < NBLK )
+      {
+         int idx = 0;
+#pragma unroll
+         for (int j = b + 1; j < NBLK; ++j)
+#pragma unroll
+            for (int i = j; i < NBLK; ++i, ++idx)
+            {
+               if ( (idx & 3) != wave )
+                  continue;
+               v4dc acc = (v4dc){0.0, 0.0, 0.0, 0.0};
+               double pa[4], pb[4], cv[4];
+#pragma unroll
+               for (int sidx = 0; sidx < 4; ++sidx)
+               {
+                  pa[sidx] = Lm[16 * i + lr][c0 + 4 * sidx + lk];
+                  pb[sidx] = Lm[16 * j + lr][c0 + 4 * sidx + lk];
+                  cv[sidx] = W[16 * i + lk + 4 * sidx][16 * j + lr];
+               }
+#pragma unroll
+               for (int sidx = 0; sidx < 4; ++sidx)
+                  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[sidx], pb[sidx], acc, 0, 0, 0);
+#pragma unroll
+               for (int rr = 0; rr < 4; ++rr)
+                  W[16 * i + lk + 4 * rr][16 * j + lr] = cv[rr] - acc[rr];
+            }
+      }
+      __syncthreads();
+   }
+   PD_T(5);
 
    /* write L back */
    if ( !ext.nostore )
    {
-   double* Lw = ext.Lout != NULL ? ext.Lout : A;
-   const long long ldw = ext.Lout != NULL ? NB : lda;
+      double* Lw = ext.Lout != NULL ? ext.Lout : A;
+      const long long ldw = ext.Lout != NULL ? NB : lda;
+      const int i = tid >> 2;
+      const int jc = tid & 3;
 #pragma unroll
-   for (int jj = 0; jj < 16; ++jj)
-   {
-      const int j = jc + 4 * jj;
-      if ( i < nb && j <= i )
-         Lw[(long long) i * ldw + j] = r[jj];
-      else if ( ext.base != NULL && i < nb && j < nb )
-         Lw[(long long) i * ldw + j] = 0.0;
-   }
+      for (int jj = 0; jj < 16; ++jj)
+      {
+         const int j = jc + 4 * jj;
+         if ( i < nb && j <= i )
+            Lw[(long long) i * ldw + j] = (i < NBK) ? Lm[i][j] : ((i == j) ? 1.0 : 0.0);
+         else if ( ext.base != NULL && i < nb && j < nb )
+            Lw[(long long) i * ldw + j] = 0.0;
+      }
    }
    if ( tid == 0 && !ext.nostore )
    {
@@ -267,32 +363,40 @@ __device__ __forceinline__ void pd_body(double* __restrict__ A, long long lda, i
          atomicCAS(flag, 0, bad);
    }
 
-   /* inverse, diagonal 16 x 16 blocks: wavefront w, lane c < 16 solves L_ww x = e_c */
-   constexpr int NBLK = NBK / 16;
+   PD_T(6);
+   /* inverse, diagonal 16 x 16 blocks: wavefront w, lane c < 16 solves L_ww x = e_c; row i of L_ww is read as a whole (all rows
+    * requested before the recurrence starts: the loads are not on its critical path) */
    if ( wave < NBLK && lane < 16 )
    {
       const int base = 16 * wave;
-      double sv[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j)
-         sv[j] = (j == lane) ? 1.0 : 0.0;
+      double lrow[16][16];
+      double iv[16];
 #pragma unroll
       for (int ii = 0; ii < 16; ++ii)
       {
-         const double xi = sv[ii] * invd[base + ii];
-         X[base + ii][base + lane] = xi;
-         if ( ((ii + 1) & 1) && ii + 1 < 16 )
-            sv[ii + 1] -= lmT[base + ii][base + ii + 1] * xi;
+         iv[ii] = invd[base + ii];
 #pragma unroll
-         for (int j = (ii + 2) & ~1; j < 16; j += 2)
+         for (int q = 0; 2 * q < ii; ++q)
          {
-            const dpair l2 = *reinterpret_cast<const dpair*>(&lmT[base + ii][base + j]);
-            sv[j] -= l2.x * xi;
-            sv[j + 1] -= l2.y * xi;
+            const dpair u = *reinterpret_cast<const dpair*>(&Lm[base + ii][base + 2 * q]);
+            lrow[ii][2 * q] = u.x;
+            lrow[ii][2 * q + 1] = u.y;
          }
+      }
+      double xv[16];
+#pragma unroll
+      for (int ii = 0; ii < 16; ++ii)
+      {
+         double acc = (ii == lane) ? 1.0 : 0.0;
+#pragma unroll
+         for (int j = 0; j < ii; ++j)
+            acc = fma(-lrow[ii][j], xv[j], acc);
+         xv[ii] = acc * iv[ii];
+         X[base + ii][base + lane] = xv[ii];
       }
    }
    __syncthreads();
+   PD_T(7);
    /* off-diagonal blocks by block diagonals: block (bi, bj = bi - dd) on wavefront bj */
 #pragma unroll
    for (int dd = 1; dd < NBLK; ++dd)
@@ -300,14 +404,13 @@ __device__ __forceinline__ void pd_body(double* __restrict__ A, long long lda, i
       if ( wave < NBLK - dd )
       {
          const int bj = wave, bi = wave + dd;
-         const int lr = lane & 15, lk = lane >> 4;
          v4dc acc = (v4dc){0.0, 0.0, 0.0, 0.0};
          for (int kb = bj; kb < bi; ++kb)
          {
 #pragma unroll
             for (int sidx = 0; sidx < 4; ++sidx)
             {
-               const double a = lmT[16 * kb + 4 * sidx + lk][16 * bi + lr];       /* L[16 bi + lr][16 kb + 4 s + lk] */
+               const double a = Lm[16 * bi + lr][16 * kb + 4 * sidx + lk];
                const double bv = X[16 * kb + 4 * sidx + lk][16 * bj + lr];
                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc, 0, 0, 0);
             }
@@ -325,6 +428,7 @@ __device__ __forceinline__ void pd_body(double* __restrict__ A, long long lda, i
       }
       __syncthreads();
    }
+   PD_T(8);
    /* inv(L), identity padded, block upper triangle zero */
    if ( !ext.nostore )
    for (int e = tid; e < NB * NB; e += 256)
@@ -433,9 +537,9 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, long
 {
    extern __shared__ __attribute__((aligned(16))) double pd_smem[];
    double* lstage = dinv + (long long) nblk * NB * NB;                                              /* staged L_kk blocks */
-   double (*bufA)[PD_LD] = reinterpret_cast<double (*)[PD_LD]>(pd_smem + PD_COLP);                 /* = lmT of the factorization */
-   double (*bufB)[PD_LD] = reinterpret_cast<double (*)[PD_LD]>(pd_smem + PD_COLP + NB * PD_LD);     /* = X (inverse) */
-   const double* forced = pd_smem + PD_COLP + 2 * NB * PD_LD + 2 * NB;
+   double (*bufA)[PD_LD] = reinterpret_cast<double (*)[PD_LD]>(pd_smem);                 /* tile 0: the block to factor, then inv(L_kk) */
+   double (*bufB)[PD_LD] = reinterpret_cast<double (*)[PD_LD]>(pd_smem + NB * PD_LD);     /* tile 1: L_kk, then the panel block */
+   const double* forced = pd_smem + 2 * NB * PD_LD + 2 * NB;
    const int tid = threadIdx.x, lane = tid & 63;
    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
    const int lr = lane & 15, lk = lane >> 4;
@@ -479,6 +583,7 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, long
    }
 
    /* ---- step workgroup of block row rb */
+   PD_T(0);
    const int rb = kb + (int) blockIdx.x;
    const int r0 = rb * NB;
    const int nb = min(NB, n - j0);
@@ -521,6 +626,7 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, long
       if ( blockIdx.x > 0 )
          ps_load_tile(Ark - NB, lda, rows, bufB);              /* P_r: block (rb, kb - 1) */
       __syncthreads();
+      PD_T(1);
       ps_mma<false>(bufA, bufA, wave, lane, acc);               /* P_k P_k^T */
       if ( blockIdx.x > 0 )
          ps_mma<false>(bufB, bufA, wave, lane, accB);           /* P_r P_k^T */
@@ -538,10 +644,11 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, long
                v = -acc[t][rr];
                v += akk[t][rr];
             }
-            bufB[row][col] = v;
+            bufA[row][col] = v;
          }
       __syncthreads();
       from_lds = true;
+      PD_T(2);
    }
    pd_ext e2 = ext;
    e2.from_lds = from_lds ? 1 : 0;
@@ -566,6 +673,7 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, long
       return;
    }
    /* ---- panel block: B = A_rk - P_r P_k^T (accB), P = B inv(L_kk)^T, forced columns zeroed */
+   PD_T(9);
    __syncthreads();
 #pragma unroll
    for (int t = 0; t < 4; ++t)
@@ -579,10 +687,10 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, long
             v = -accB[t][rr];
             v += ark[t][rr];
          }
-         bufA[row][col] = v;
+         bufB[row][col] = v;
       }
    __syncthreads();
-   ps_mma<true>(bufA, bufB, wave, lane, acc);
+   ps_mma<true>(bufB, bufA, wave, lane, acc);
 #pragma unroll
    for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -592,6 +700,7 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, long
          if ( row < rows )
             Ark[(long long) row * lda + col] = forced[col] != 0.0 ? 0.0 : acc[t][rr];
       }
+   PD_T(10);
 }
 
 template<int NBK>
@@ -838,12 +947,14 @@ __global__ void __launch_bounds__(1024) k_trsv(int n, const double* __restrict__
    double* __restrict__ rhs, long long ldr, int mode)
 {
    __shared__ double xs[NRHS][NB];
+   __shared__ double rho[NRHS][NB];
    __shared__ double red[64][NB + 1];
    const int tid = threadIdx.x;
    const int grp = tid >> 4;       /* 64 row groups */
    const int part = tid & 15;      /* 16 lanes per row, 4 columns each */
    const int nblk = (n + NB - 1) / NB;
    const long long ld = n;
+   const bool refine = (mode & 4) != 0;
 
    if ( mode & 1 )
    {
@@ -871,6 +982,45 @@ __global__ void __launch_bounds__(1024) k_trsv(int n, const double* __restrict__
                xs[k][grp] = sacc;
          }
          __syncthreads();
+         if ( refine )
+         {
+            /* x = inv(L_bb) r leaves a residual r - L_bb x of the order cond(L_bb) * eps * |r| (the inverse is only a right
+             * inverse to rounding); one correction x += inv(L_bb) (r - L_bb x) with the factor itself brings it down to that of a
+             * substitution.  The residual of M dy = h is the primal infeasibility the step leaves behind. */
+            const double* lb = L + (long long) (j0 + (grp < nb ? grp : 0)) * ld + j0;
+            for (int k = 0; k < NRHS; ++k)
+            {
+               double sacc = 0.0;
+#pragma unroll
+               for (int c = 0; c < 4; ++c)
+               {
+                  const int col = 4 * part + c;
+                  if ( col <= grp && grp < nb )
+                     sacc += lb[col] * xs[k][col];
+               }
+               sacc += __shfl_xor(sacc, 1, 64);
+               sacc += __shfl_xor(sacc, 2, 64);
+               sacc += __shfl_xor(sacc, 4, 64);
+               sacc += __shfl_xor(sacc, 8, 64);
+               if ( part == 0 )
+                  rho[k][grp] = (grp < nb) ? rhs[(long long) k * ldr + j0 + grp] - sacc : 0.0;
+            }
+            __syncthreads();
+            for (int k = 0; k < NRHS; ++k)
+            {
+               double sacc = 0.0;
+#pragma unroll
+               for (int c = 0; c < 4; ++c)
+                  sacc += db[grp * NB + 4 * part + c] * rho[k][4 * part + c];
+               sacc += __shfl_xor(sacc, 1, 64);
+               sacc += __shfl_xor(sacc, 2, 64);
+               sacc += __shfl_xor(sacc, 4, 64);
+               sacc += __shfl_xor(sacc, 8, 64);
+               if ( part == 0 )
+                  xs[k][grp] += sacc;
+            }
+            __syncthreads();
+         }
          if ( tid < NB * NRHS )
          {
             const int k = tid / NB, i = tid % NB;
@@ -950,6 +1100,7 @@ __global__ void __launch_bounds__(1024) k_trsv(int n, const double* __restrict__
             __syncthreads();
          }
          /* x_blk = inv(L_bb)^T * (y_blk - s) */
+         double x0[NRHS];
          for (int k = 0; k < NRHS; ++k)
          {
             double sacc = 0.0;
@@ -963,10 +1114,64 @@ __global__ void __launch_bounds__(1024) k_trsv(int n, const double* __restrict__
             sacc += __shfl_xor(sacc, 2, 64);
             sacc += __shfl_xor(sacc, 4, 64);
             sacc += __shfl_xor(sacc, 8, 64);
-            if ( part == 0 && grp < nb )
-               rhs[(long long) k * ldr + j0 + grp] = sacc;
+            x0[k] = sacc;
+            if ( part == 0 )
+            {
+               if ( !refine )
+               {
+                  if ( grp < nb )
+                     rhs[(long long) k * ldr + j0 + grp] = sacc;
+               }
+               else
+                  rho[k][grp] = (grp < nb) ? sacc : 0.0;         /* x0, for the residual */
+            }
          }
          __syncthreads();
+         if ( refine )
+         {
+            /* v - L_bb^T x0 (column grp of the block, rows >= grp), then x = x0 + inv(L_bb)^T (..) */
+            double rv[NRHS];
+            for (int k = 0; k < NRHS; ++k)
+            {
+               double sacc = 0.0;
+#pragma unroll
+               for (int c = 0; c < 4; ++c)
+               {
+                  const int row = 4 * part + c;
+                  if ( row >= grp && row < nb )
+                     sacc += L[(long long) (j0 + row) * ld + j0 + grp] * rho[k][row];
+               }
+               sacc += __shfl_xor(sacc, 1, 64);
+               sacc += __shfl_xor(sacc, 2, 64);
+               sacc += __shfl_xor(sacc, 4, 64);
+               sacc += __shfl_xor(sacc, 8, 64);
+               rv[k] = (grp < nb) ? xs[k][grp] - sacc : 0.0;
+            }
+            __syncthreads();
+            if ( part == 0 )
+            {
+               for (int k = 0; k < NRHS; ++k)
+                  xs[k][grp] = rv[k];
+            }
+            __syncthreads();
+            for (int k = 0; k < NRHS; ++k)
+            {
+               double sacc = 0.0;
+#pragma unroll
+               for (int c = 0; c < 4; ++c)
+               {
+                  const int row = 4 * part + c;
+                  sacc += db[row * NB + grp] * xs[k][row];
+               }
+               sacc += __shfl_xor(sacc, 1, 64);
+               sacc += __shfl_xor(sacc, 2, 64);
+               sacc += __shfl_xor(sacc, 4, 64);
+               sacc += __shfl_xor(sacc, 8, 64);
+               if ( part == 0 && grp < nb )
+                  rhs[(long long) k * ldr + j0 + grp] = x0[k] + sacc;
+            }
+            __syncthreads();
+         }
       }
    }
 }
@@ -1016,9 +1221,10 @@ __device__ __forceinline__ bool trsv_wait(const int* flag, int epoch, int* err)
 
 template<int NRHS>
 __global__ void __launch_bounds__(256) k_trsv_fwd(int n, const double* __restrict__ L, const double* __restrict__ dinv,
-   double* __restrict__ rhs, long long ldr, int* __restrict__ flags, int epoch)
+   double* __restrict__ rhs, long long ldr, int* __restrict__ flags, int epoch, int refine)
 {
    __shared__ double xs[NRHS][NB];
+   __shared__ double x0s[NRHS][NB];
    __shared__ int ok;
    const int b = blockIdx.x;
    const int tid = threadIdx.x;
@@ -1034,6 +1240,21 @@ __global__ void __launch_bounds__(256) k_trsv_fwd(int n, const double* __restric
    const bool rowok = row < nb;
    const double* lrow = L + (long long) (j0 + (rowok ? row : 0)) * ld + 16 * q;
    double lcur[16], lnext[16];
+   /* what the diagonal solve needs of inv(L_bb) and (correction) of L_bb does not depend on the blocks before: requested now,
+    * not when the last of them has arrived */
+   double dbr[16], lbr[16];
+   {
+      const double* db = dinv + (long long) b * NB * NB + row * NB + 16 * q;
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+         dbr[c] = db[c];
+      if ( refine )
+      {
+#pragma unroll
+         for (int c = 0; c < 16; ++c)
+            lbr[c] = (rowok && 16 * q + c <= row) ? lrow[j0 + c] : 0.0;
+      }
+   }
    if ( b > 0 )
    {
 #pragma unroll
@@ -1081,20 +1302,61 @@ __global__ void __launch_bounds__(256) k_trsv_fwd(int n, const double* __restric
          xs[k][row] = rowok ? rhs[(long long) k * ldr + j0 + row] - sacc : 0.0;
    }
    __syncthreads();
-   const double* db = dinv + (long long) b * NB * NB + row * NB + 16 * q;
 #pragma unroll
    for (int k = 0; k < NRHS; ++k)
    {
       double sacc = 0.0;
 #pragma unroll
       for (int c = 0; c < 16; ++c)
-         sacc += db[c] * xs[k][16 * q + c];
+         sacc += dbr[c] * xs[k][16 * q + c];
       sacc += __shfl_xor(sacc, 1, 64);
       sacc += __shfl_xor(sacc, 2, 64);
-      if ( q == 0 && rowok )
+      if ( refine )
+      {
+         if ( q == 0 )
+            x0s[k][row] = rowok ? sacc : 0.0;
+      }
+      else if ( q == 0 && rowok )
          rhs[(long long) k * ldr + j0 + row] = sacc;
    }
    __syncthreads();
+   if ( refine )
+   {
+      /* one correction with the factor itself (see k_trsv): x = x0 + inv(L_bb) (y - L_bb x0) */
+      double rv[NRHS];
+#pragma unroll
+      for (int k = 0; k < NRHS; ++k)
+      {
+         double sacc = 0.0;
+#pragma unroll
+         for (int c = 0; c < 16; ++c)
+            sacc += lbr[c] * x0s[k][16 * q + c];
+         sacc += __shfl_xor(sacc, 1, 64);
+         sacc += __shfl_xor(sacc, 2, 64);
+         rv[k] = rowok ? xs[k][row] - sacc : 0.0;
+      }
+      __syncthreads();
+      if ( q == 0 )
+      {
+#pragma unroll
+         for (int k = 0; k < NRHS; ++k)
+            xs[k][row] = rv[k];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < NRHS; ++k)
+      {
+         double sacc = 0.0;
+#pragma unroll
+         for (int c = 0; c < 16; ++c)
+            sacc += dbr[c] * xs[k][16 * q + c];
+         sacc += __shfl_xor(sacc, 1, 64);
+         sacc += __shfl_xor(sacc, 2, 64);
+         if ( q == 0 && rowok )
+            rhs[(long long) k * ldr + j0 + row] = x0s[k][row] + sacc;
+      }
+      __syncthreads();
+   }
    if ( tid == 0 )
    {
       __threadfence();
@@ -1104,9 +1366,10 @@ __global__ void __launch_bounds__(256) k_trsv_fwd(int n, const double* __restric
 
 template<int NRHS>
 __global__ void __launch_bounds__(256) k_trsv_bwd(int n, const double* __restrict__ L, const double* __restrict__ dinv,
-   double* __restrict__ rhs, long long ldr, int* __restrict__ flags, int epoch)
+   double* __restrict__ rhs, long long ldr, int* __restrict__ flags, int epoch, int refine)
 {
    __shared__ double xs[NRHS][NB];
+   __shared__ double x0s[NRHS][NB];
    __shared__ double red[4][NRHS][NB];
    __shared__ int ok;
    const int nblk = gridDim.x;
@@ -1122,6 +1385,23 @@ __global__ void __launch_bounds__(256) k_trsv_bwd(int n, const double* __restric
 #pragma unroll
    for (int k = 0; k < NRHS; ++k)
       acc[k] = 0.0;
+   /* the diagonal solve's part of inv(L_bb) and (correction) of L_bb: requested before the blocks behind are awaited */
+   double dbr[16], lbr[16];
+   {
+      const double* db = dinv + (long long) b * NB * NB;
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+         dbr[c] = db[(16 * g + c) * NB + col];
+      if ( refine )
+      {
+#pragma unroll
+         for (int c = 0; c < 16; ++c)
+         {
+            const int i = 16 * g + c;
+            lbr[c] = (i >= col && i < nb) ? L[(long long) (j0 + i) * ld + j0 + col] : 0.0;
+         }
+      }
+   }
    /* s[col] = sum over later blocks cb, rows i of the block: L[cb * 64 + i][j0 + col] * x[cb * 64 + i] */
    for (int cb = nblk - 1; cb > b; --cb)
    {
@@ -1168,24 +1448,64 @@ __global__ void __launch_bounds__(256) k_trsv_bwd(int n, const double* __restric
    }
    __syncthreads();
    /* x_b = inv(L_bb)^T v : out[col] = sum_i dinv[i][col] v[i] */
-   const double* db = dinv + (long long) b * NB * NB;
 #pragma unroll
    for (int k = 0; k < NRHS; ++k)
    {
       double sacc = 0.0;
 #pragma unroll
       for (int c = 0; c < 16; ++c)
-         sacc += db[(16 * g + c) * NB + col] * xs[k][16 * g + c];
+         sacc += dbr[c] * xs[k][16 * g + c];
       red[g][k][col] = sacc;
    }
    __syncthreads();
    if ( tid < NB * NRHS )
    {
       const int k = tid / NB, i = tid % NB;
-      if ( i < nb )
-         rhs[(long long) k * ldr + j0 + i] = red[0][k][i] + red[1][k][i] + red[2][k][i] + red[3][k][i];
+      const double v = red[0][k][i] + red[1][k][i] + red[2][k][i] + red[3][k][i];
+      if ( refine )
+         x0s[k][i] = (i < nb) ? v : 0.0;
+      else if ( i < nb )
+         rhs[(long long) k * ldr + j0 + i] = v;
    }
    __syncthreads();
+   if ( refine )
+   {
+      /* one correction with the factor itself (see k_trsv): x = x0 + inv(L_bb)^T (v - L_bb^T x0) */
+#pragma unroll
+      for (int k = 0; k < NRHS; ++k)
+      {
+         double sacc = 0.0;
+#pragma unroll
+         for (int c = 0; c < 16; ++c)
+            sacc += lbr[c] * x0s[k][16 * g + c];
+         red[g][k][col] = sacc;
+      }
+      __syncthreads();
+      if ( tid < NB * NRHS )
+      {
+         const int k = tid / NB, i = tid % NB;
+         const double sacc = red[0][k][i] + red[1][k][i] + red[2][k][i] + red[3][k][i];
+         xs[k][i] = (i < nb) ? xs[k][i] - sacc : 0.0;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < NRHS; ++k)
+      {
+         double sacc = 0.0;
+#pragma unroll
+         for (int c = 0; c < 16; ++c)
+            sacc += dbr[c] * xs[k][16 * g + c];
+         red[g][k][col] = sacc;
+      }
+      __syncthreads();
+      if ( tid < NB * NRHS )
+      {
+         const int k = tid / NB, i = tid % NB;
+         if ( i < nb )
+            rhs[(long long) k * ldr + j0 + i] = x0s[k][i] + (red[0][k][i] + red[1][k][i] + red[2][k][i] + red[3][k][i]);
+      }
+      __syncthreads();
+   }
    if ( tid == 0 )
    {
       __threadfence();
@@ -1208,6 +1528,7 @@ int hs_trsv_sync(hipStream_t s, int n, const double* L, const double* dinv, int 
    if ( nrhs > 4 )
       return HS_ERR_ARG;
    const int nblk = (n + NB - 1) / NB;
+   const int refine = (mode & 4) ? 1 : 0;
    if ( sync_ws == NULL || epoch == NULL || nblk > 512 || nblk < 3 )
       return hs_trsv(s, n, L, dinv, nrhs, rhs, ldr, mode);
    if ( mode & 1 )
@@ -1215,10 +1536,10 @@ int hs_trsv_sync(hipStream_t s, int n, const double* L, const double* dinv, int 
       const int e = ++(*epoch);
       switch ( nrhs )
       {
-      case 1: hipLaunchKernelGGL((k_trsv_fwd<1>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e); break;
-      case 2: hipLaunchKernelGGL((k_trsv_fwd<2>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e); break;
-      case 3: hipLaunchKernelGGL((k_trsv_fwd<3>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e); break;
-      default: hipLaunchKernelGGL((k_trsv_fwd<4>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e); break;
+      case 1: hipLaunchKernelGGL((k_trsv_fwd<1>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e, refine); break;
+      case 2: hipLaunchKernelGGL((k_trsv_fwd<2>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e, refine); break;
+      case 3: hipLaunchKernelGGL((k_trsv_fwd<3>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e, refine); break;
+      default: hipLaunchKernelGGL((k_trsv_fwd<4>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e, refine); break;
       }
       HS_LAUNCH_CHECK();
    }
@@ -1227,10 +1548,10 @@ int hs_trsv_sync(hipStream_t s, int n, const double* L, const double* dinv, int 
       const int e = ++(*epoch);
       switch ( nrhs )
       {
-      case 1: hipLaunchKernelGGL((k_trsv_bwd<1>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e); break;
-      case 2: hipLaunchKernelGGL((k_trsv_bwd<2>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e); break;
-      case 3: hipLaunchKernelGGL((k_trsv_bwd<3>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e); break;
-      default: hipLaunchKernelGGL((k_trsv_bwd<4>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e); break;
+      case 1: hipLaunchKernelGGL((k_trsv_bwd<1>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e, refine); break;
+      case 2: hipLaunchKernelGGL((k_trsv_bwd<2>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e, refine); break;
+      case 3: hipLaunchKernelGGL((k_trsv_bwd<3>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e, refine); break;
+      default: hipLaunchKernelGGL((k_trsv_bwd<4>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e, refine); break;
       }
       HS_LAUNCH_CHECK();
    }

@@ -36,7 +36,7 @@ int hs_red_batch_end_publish(hipStream_t s, int n, const double* src, double* ds
 void hs_red_batch_reset(void);
 int hs_fill_scalar(hipStream_t s, double* p, double v);
 /* single-block solves (m <= 64) and the direction's closing kernel can be part of a batch: see kernels.hip */
-int hs_red_batch_solve(hipStream_t s, int m, const double* dinv, int nrhs, double* vec, long long ld);
+int hs_red_batch_solve(hipStream_t s, int m, const double* dinv, const double* L, int nrhs, double* vec, long long ld);
 struct hs_rb_finish { int m; double eta, rg, sigmu, tau, kappa, etk; const double* u1; const double* u2; double* dy; double* dyt; double* sc;
    int s0, bub, bh, wrp, bu1, dtau, dkappa, den; };
 int hs_red_batch_finish(hipStream_t s, const void* fin, size_t bytes);
@@ -139,6 +139,8 @@ int hs_potrf_small_ext(hipStream_t s, int n, double* L, double* dinv, int* flag,
  * launch; returns 1 if done, 0 if the sizes do not qualify, < 0 on error */
 int hs_schur_small(hipStream_t s, int m1, int nblk, const int* n, const double* const* A, const double* const* X,
    const double* const* Zinv, int q, const double* Dext, const double* x, const double* z, double* Mx, double* Lm, double* diagM);
+/* mode: 1 forward, 2 backward, 3 both; + 4: every 64-wide diagonal solve x = inv(L_bb) r is corrected once with the factor itself
+ * (x += inv(L_bb) (r - L_bb x)), which brings its residual from cond(L_bb) eps |r| down to that of a substitution */
 int hs_trsv(hipStream_t s, int n, const double* L, const double* dinv, int nrhs, double* rhs, long long ldr, int mode);
 /* the same solve with one workgroup per 64-row block (flag hand-off between blocks); sync_ws: hs_trsv_sync_ws(n) ints, zeroed
  * once; *epoch: call counter owned by the caller (start at 0) */

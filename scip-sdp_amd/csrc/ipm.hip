@@ -121,6 +121,7 @@ struct hipsdp_solver
    long long hsc_cap;      /* doubles; kept across re-shapes (pinned allocations are slow) */
    int* trsv_ws;           /* block flags of the multi-workgroup triangular solves */
    int trsv_epoch;
+   bool refine_solves;           /* the triangular solves with M correct themselves once with the factor (hs_trsv mode bit 4) */
    long long gws_len;
    long long gemv_ws_len;
    int* flags;       /* device ints: 0 chol Z, 1 chol X, 2 chol M */
@@ -1050,26 +1051,62 @@ __global__ void k_after_solve2(int m, const double* __restrict__ rhs2, double* _
    }
 }
 
-/* m <= 64 (single-block factor, dinv = inv(L) as 64 x 64): rhs2 = [g ; b] with g = Mx[0, 1:], both solves M x = r as
- * x = inv(L)^T (inv(L) r), then u2 = ub - w and wt = [1, -w]: k_rhs2 + the triangular solves + k_after_solve2 in one launch */
+/* m <= 64 (single-block factor, dinv = inv(L) as 64 x 64, L = the factor as m x m): rhs2 = [g ; b] with g = Mx[0, 1:], both
+ * solves M x = r as x = inv(L)^T (inv(L) r) with each triangular solve corrected once by the factor itself (see RB_SOLVE in
+ * kernels.hip: the residual of these solves is primal infeasibility of the step), then u2 = ub - w and wt = [1, -w]: k_rhs2 + the
+ * triangular solves + k_after_solve2 in one launch */
 __global__ void __launch_bounds__(128) k_solve2_small(int m, const double* __restrict__ Mx, const double* __restrict__ b,
-   const double* __restrict__ dinv, double* __restrict__ rhs2, double* __restrict__ u2, double* __restrict__ wt)
+   const double* __restrict__ dinv, const double* __restrict__ L, double* __restrict__ rhs2, double* __restrict__ u2, double* __restrict__ wt)
 {
-   __shared__ double r[2][64], t[2][64];
+   __shared__ double r[2][64], t[2][64], c[2][64];
    const int k = threadIdx.x >> 6, i = threadIdx.x & 63;
    r[k][i] = (i < m) ? (k == 0 ? Mx[1 + i] : b[i]) : 0.0;
    __syncthreads();
+   /* forward: t = Y r, c = r - L t, t += Y c */
    double acc = 0.0;
    if ( i < m )
       for (int j = 0; j <= i; ++j)
          acc += dinv[i * 64 + j] * r[k][j];
    t[k][i] = acc;
    __syncthreads();
+   double res = 0.0;
+   if ( i < m )
+   {
+      for (int j = 0; j <= i; ++j)
+         res += L[(long long) i * m + j] * t[k][j];
+      res = r[k][i] - res;
+   }
+   c[k][i] = res;
+   __syncthreads();
+   double cor = 0.0;
+   if ( i < m )
+      for (int j = 0; j <= i; ++j)
+         cor += dinv[i * 64 + j] * c[k][j];
+   __syncthreads();
+   t[k][i] = acc + cor;
+   __syncthreads();
+   /* backward: r = Y^T t, c = t - L^T r, r += Y^T c */
    acc = 0.0;
    if ( i < m )
       for (int j = i; j < m; ++j)
          acc += dinv[j * 64 + i] * t[k][j];
    r[k][i] = acc;
+   __syncthreads();
+   res = 0.0;
+   if ( i < m )
+   {
+      for (int j = i; j < m; ++j)
+         res += L[(long long) j * m + i] * r[k][j];
+      res = t[k][i] - res;
+   }
+   c[k][i] = res;
+   __syncthreads();
+   cor = 0.0;
+   if ( i < m )
+      for (int j = i; j < m; ++j)
+         cor += dinv[j * 64 + i] * c[k][j];
+   __syncthreads();
+   r[k][i] = acc + cor;
    __syncthreads();
    if ( i < m )
       rhs2[k * m + i] = r[k][i];
@@ -1614,6 +1651,12 @@ struct QueueSwap
 /* split: 0 = dZ by one pass with the coefficients [-dtau; dy]; 1 = dZ = P1 - dtau P2 + eta Rd with P1 = A^T([0; u1]) computed here
  * by one pass and P2 = A^T([1; u2]) from the three-vector sweep of this iteration; 2 = P1 has been computed by that sweep as well
  * (the predictor: its u1 was solved together with the right-hand sides of the tau elimination) */
+/* mode of the triangular solves with the factor of M: forward + backward, corrected where that is free or asked for */
+static inline int solve_mode(const hipsdp_solver* s)
+{
+   return 3 | (s->refine_solves ? 4 : 0);
+}
+
 static int direction(hipsdp_solver* s, double sigma, double eta, double mu, double rg, bool useE, double etk, int part = 0,
    bool u1_solved = false, int split = 0)
 {
@@ -1656,11 +1699,11 @@ static int direction(hipsdp_solver* s, double sigma, double eta, double mu, doub
    }
    const bool fuse_solve = (fusedA == 1) && m > 0 && m <= 64;      /* single-block factor of M: solve, reductions and closing kernel in one launch */
    if ( m > 0 && !fuse_solve && !u1_solved )
-      HS_CALL( hs_trsv_sync(s->stream, m, s->Lm, s->dinvm, 1, s->u1, m, 3, s->trsv_ws, &s->trsv_epoch) );
+      HS_CALL( hs_trsv_sync(s->stream, m, s->Lm, s->dinvm, 1, s->u1, m, solve_mode(s), s->trsv_ws, &s->trsv_epoch) );
    /* BH = sum <B_k, H_k> + beta^T hl ; wrp ; bu1 */
    hs_red_batch_begin(s->stream);
    if ( fuse_solve )
-      (void) hs_red_batch_solve(s->stream, m, s->dinvm, 1, s->u1, m);
+      (void) hs_red_batch_solve(s->stream, m, s->dinvm, s->Lm, 1, s->u1, m);
    HS_CALL( hs_fill_scalar(s->stream, s->sc + SC_BH, 0.0) );
    for (auto& B : s->blk)
       HS_CALL( hs_dot(s->stream, (long long) B.n * B.n, B.B, B.H, s->sc + SC_BH, 1, s->red_ws) );
@@ -2211,6 +2254,18 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       dinf = sqrt(rd2) / tau / (1.0 + normC);
       dabs = rdmax / tau;
       gap = fabs(dobj - pobj) / tau;
+      /* The triangular solves with the factor of M go block by block as x = inv(L_bb) r, whose residual grows with cond(L_bb)
+       * and ends up as primal infeasibility of the step; each of them is corrected once with the factor itself (hs_trsv mode
+       * bit 4; about 0.3 % of a solve at n = 500, m = 1000).  HIPSDP_REFINE_SOLVES=0 switches the correction off. */
+      {
+         static int forced = -2;
+         if ( forced == -2 )
+         {
+            const char* env = getenv("HIPSDP_REFINE_SOLVES");
+            forced = (env == NULL) ? -1 : (env[0] == '0' ? 0 : 1);
+         }
+         s->refine_solves = (forced != 0);
+      }
       if ( par.verbose )
          printf("hipsdp it %3d mu %.3e pinf %.3e dinf %.3e gap %.3e pobj %.8e dobj %.8e tau %.3e kap %.3e\n", it, mu, pinf, dinf,
             gap, pobj / tau, dobj / tau, tau, kappa);
@@ -2507,7 +2562,7 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
          HS_CALL( hs_potrf_psd(st, m, s->Lm, s->dinvm, s->flags + 2, s->dya, s->regmask, setf) );
          if ( m <= 64 )
          {
-            hipLaunchKernelGGL(k_solve2_small, dim3(1), dim3(128), 0, st, m, s->Mx, s->b, s->dinvm, s->rhs2, s->u2, s->wt);
+            hipLaunchKernelGGL(k_solve2_small, dim3(1), dim3(128), 0, st, m, s->Mx, s->b, s->dinvm, s->Lm, s->rhs2, s->u2, s->wt);
             HS_LAUNCH_CHECK();
          }
          else
@@ -2520,10 +2575,10 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
                 * solve with three right-hand sides instead of a pair and, later, a single one */
                HS_CALL( join2(s) );
                predH_joined = true;
-               HS_CALL( hs_trsv_sync(st, m, s->Lm, s->dinvm, 3, s->rhs2, m, 3, s->trsv_ws, &s->trsv_epoch) );
+               HS_CALL( hs_trsv_sync(st, m, s->Lm, s->dinvm, 3, s->rhs2, m, solve_mode(s), s->trsv_ws, &s->trsv_epoch) );
             }
             else
-               HS_CALL( hs_trsv_sync(st, m, s->Lm, s->dinvm, 2, s->rhs2, m, 3, s->trsv_ws, &s->trsv_epoch) );
+               HS_CALL( hs_trsv_sync(st, m, s->Lm, s->dinvm, 2, s->rhs2, m, solve_mode(s), s->trsv_ws, &s->trsv_epoch) );
          }
       }
       if ( m == 0 || m > 64 )

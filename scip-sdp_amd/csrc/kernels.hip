@@ -543,7 +543,7 @@ __global__ void __launch_bounds__(256) k_reduce_stage2(int nparts, const double*
 #define RB_MAXN  16384
 #define RB_FILL  100
 #define RB_COPY1 101
-#define RB_SOLVE 102      /* out[0:n] <- inv(L)^T inv(L) out[0:n] with a = inv(L) as 64 x 64 (single-block factor, n <= 64); accumulate = number of right-hand sides, c = (const double*) stride in doubles */
+#define RB_SOLVE 102      /* out[0:n] <- inv(L)^T inv(L) out[0:n] with a = inv(L) as 64 x 64, b = L as n x n (single-block factor, n <= 64); accumulate = number of right-hand sides, v = stride in doubles */
 #define RB_FINISH 103     /* the direction's closing element-wise kernel (k_finish_dir of ipm.hip) with its parameters in fin */
 
 struct rb_desc { int kind; int accumulate; long long n; const double* a; const double* b; const double* c; double* out; double v; };
@@ -584,17 +584,26 @@ __global__ void __launch_bounds__(256) k_red_batch(rb_args A)
       case RB_COPY1:     if ( threadIdx.x == 0 ) *D.out = *D.a; break;
       case RB_SOLVE:
       {
-         /* vec <- Linv^T (Linv vec) for `accumulate` right-hand sides, m <= 64: the factor is staged in LDS once (odd pitch:
-          * rows and columns conflict-free), every row of either product is split over four adjacent lanes */
+         /* vec <- inv(L)^T inv(L) vec for `accumulate` right-hand sides, m <= 64, with one correction per triangular solve by the
+          * factor itself: x = Y r (Y = inv(L) as computed) leaves r - L x of the order cond(L) eps |r|, and that residual is the
+          * primal infeasibility the step leaves behind; x += Y (r - L x) brings it down to that of a substitution (on nodes whose
+          * optimum is not attained cond(L) reaches 1e8 and the uncorrected solves stall the iteration at an infeasibility of
+          * 1e-6).  Y sits in the lower triangle of an LDS tile (odd pitch), the strict lower triangle of L transposed above it,
+          * the diagonal of L beside; every row of a product is split over four adjacent lanes. */
          __shared__ double sL[64 * 65];
-         __shared__ double tv[64], tw[64];
+         __shared__ double tv[64], tw[64], tr[64], ldg[64];
          const int m = (int) D.n;
          const long long stride = (long long) D.v;
          const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
          for (int e = threadIdx.x; e < m * m; e += 256)
          {
             const int i = e / m, j = e - i * m;
-            sL[i * 65 + j] = (j <= i) ? D.a[i * 64 + j] : 0.0;
+            if ( j <= i )
+               sL[i * 65 + j] = D.a[i * 64 + j];
+            if ( j < i )
+               sL[j * 65 + i] = D.b[(long long) i * m + j];
+            if ( j == i )
+               ldg[i] = D.b[(long long) i * m + i];
          }
          for (int k = 0; k < D.accumulate; ++k)
          {
@@ -602,6 +611,8 @@ __global__ void __launch_bounds__(256) k_red_batch(rb_args A)
             if ( threadIdx.x < m )
                tv[threadIdx.x] = vec[threadIdx.x];
             __syncthreads();
+            /* forward: tw = Y tv, tr = tv - L tw, tw += Y tr */
+            double x0 = 0.0;
             {
                double acc = 0.0;
                if ( row < m )
@@ -612,10 +623,40 @@ __global__ void __launch_bounds__(256) k_red_batch(rb_args A)
                }
                acc += __shfl_xor(acc, 1, 64);
                acc += __shfl_xor(acc, 2, 64);
+               x0 = acc;
                if ( row < m && part == 0 )
                   tw[row] = acc;
             }
             __syncthreads();
+            {
+               double acc = 0.0;
+               if ( row < m )
+               {
+#pragma unroll 4
+                  for (int j = part; j < row; j += 4)
+                     acc += sL[j * 65 + row] * tw[j];
+               }
+               acc += __shfl_xor(acc, 1, 64);
+               acc += __shfl_xor(acc, 2, 64);
+               if ( row < m && part == 0 )
+                  tr[row] = tv[row] - (acc + ldg[row] * x0);
+            }
+            __syncthreads();
+            {
+               double acc = 0.0;
+               if ( row < m )
+               {
+#pragma unroll 4
+                  for (int j = part; j <= row; j += 4)
+                     acc += sL[row * 65 + j] * tr[j];
+               }
+               acc += __shfl_xor(acc, 1, 64);
+               acc += __shfl_xor(acc, 2, 64);
+               if ( row < m && part == 0 )
+                  tw[row] = x0 + acc;
+            }
+            __syncthreads();
+            /* backward: tv = Y^T tw, tr = tw - L^T tv, result = tv + Y^T tr */
             {
                double acc = 0.0;
                if ( row < m )
@@ -626,8 +667,37 @@ __global__ void __launch_bounds__(256) k_red_batch(rb_args A)
                }
                acc += __shfl_xor(acc, 1, 64);
                acc += __shfl_xor(acc, 2, 64);
+               x0 = acc;
                if ( row < m && part == 0 )
-                  vec[row] = acc;
+                  tv[row] = acc;
+            }
+            __syncthreads();
+            {
+               double acc = 0.0;
+               if ( row < m )
+               {
+#pragma unroll 4
+                  for (int i = row + 1 + part; i < m; i += 4)
+                     acc += sL[row * 65 + i] * tv[i];
+               }
+               acc += __shfl_xor(acc, 1, 64);
+               acc += __shfl_xor(acc, 2, 64);
+               if ( row < m && part == 0 )
+                  tr[row] = tw[row] - (acc + ldg[row] * x0);
+            }
+            __syncthreads();
+            {
+               double acc = 0.0;
+               if ( row < m )
+               {
+#pragma unroll 4
+                  for (int i = row + part; i < m; i += 4)
+                     acc += sL[i * 65 + row] * tr[i];
+               }
+               acc += __shfl_xor(acc, 1, 64);
+               acc += __shfl_xor(acc, 2, 64);
+               if ( row < m && part == 0 )
+                  vec[row] = x0 + acc;
             }
             __syncthreads();
          }
@@ -757,12 +827,12 @@ int hs_copy_scalar(hipStream_t s, double* dst, const double* src)
 }
 
 /* records  vec[k] <- inv(L)^T inv(L) vec[k]  (k < nrhs, vectors ld apart) for a single-block factor (m <= 64, dinv = inv(L) as
- * 64 x 64); 1: recorded, 0: no batch open */
-int hs_red_batch_solve(hipStream_t s, int m, const double* dinv, int nrhs, double* vec, long long ld)
+ * 64 x 64, L = the factor itself as m x m: each triangular solve is corrected once with it); 1: recorded, 0: no batch open */
+int hs_red_batch_solve(hipStream_t s, int m, const double* dinv, const double* L, int nrhs, double* vec, long long ld)
 {
    if ( m > 64 )
       return 0;
-   return rb_record(s, RB_SOLVE, m, dinv, NULL, NULL, vec, nrhs, (double) ld);
+   return rb_record(s, RB_SOLVE, m, dinv, L, NULL, vec, nrhs, (double) ld);
 }
 
 /* records the closing kernel of a direction; the parameter block is copied.  1: recorded, 0: no batch open */

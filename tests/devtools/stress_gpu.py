@@ -52,6 +52,8 @@ def main():
         if msg:
             bad += 1
             print("seed %d: %s :: %s" % (seed0 + t, tag, "; ".join(msg)), flush=True)
+        elif os.environ.get("STRESS_LIST_FAIL") and (info.status >= 4 or ref.status >= 4):
+            print("seed %d: %s :: both fail (gpu %d oracle %d)" % (seed0 + t, tag, info.status, ref.status), flush=True)
     print("%d problems, %d with differences, %.1f s; numerical failures: gpu %d oracle %d" % (count, bad, time.time() - t0, nfail[0], nfail[1]))
     return 1 if bad else 0
 

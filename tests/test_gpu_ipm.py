@@ -50,7 +50,11 @@ def test_engine_matches_oracle_on_reference_cases(gpu, case):
     core = case_core(case)
     ref, g = compare(gpu, core)
     assert g["info"].iterations == ref.iterations
-    assert np.allclose(g["y"], ref.y, atol=1e-7, rtol=1e-7)
+    # test4 is infeasible on both sides with a singular Schur complement ([1 -1; -1 1]): its second pivot is zero in exact
+    # arithmetic, the sign of the rounding residue decides whether the pivot rule zeroes the column, and y along the null
+    # direction follows that coin: the verdict and the iteration count are compared, y only to three digits
+    ytol = 1e-3 if (case["expect"].get("primal"), case["expect"].get("dual")) == ("infeas", "infeas") else 1e-7
+    assert np.allclose(g["y"], ref.y, atol=ytol, rtol=ytol)
     if core.q:
         assert np.allclose(g["lp"][0], ref.x, atol=1e-6, rtol=1e-6)
     for Xg, Xr in zip(g["X"], ref.X):
