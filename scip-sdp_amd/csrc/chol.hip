@@ -33,15 +33,17 @@ extern "C" int hipsdp_debug_pd_timing(int j0, long long* out)
 /* Factor the nb x nb diagonal block at A (leading dimension lda), nb <= 64: A_blk = L L^T.  Writes L into the lower
  * triangle of the block and inv(L) (64 x 64, identity-padded) into dinv.  flag: first failing global pivot index + 1.
  *
- * 256 threads, the block in LDS.  The sequential part - 64 pivots - is a register recurrence without barriers and without
- * LDS traffic: the block is processed in four panels of 16 columns; every wavefront holds the whole panel (lane = row,
- * 16 registers = the columns of the panel; all four wavefronts do this redundantly, so none waits for another), a column
- * step reads the pivot and the column through v_readlane (scalar operands of the update), the pivot goes through
- * v_rsq_f64 + one third-order correction (square root and reciprocal together, no division), and the update of the
- * remaining columns of the panel folds the scaling in: a_ij -= (a_ik / d) a_jk.  After a panel the trailing 16 x 16
- * tiles get their rank-16 update on the matrix cores (tiles dealt out to the four wavefronts), one barrier per panel.
- * [The previous form - two columns per barrier with the pivot columns broadcast through LDS - read 64 KB of LDS per pair of
- * columns (every thread the 32 column entries of its own columns) and spent 20 of the 25 microseconds of a block there.]
+ * 256 threads, the block in LDS.  The sequential part - 64 pivots - is a register recurrence of one wavefront without
+ * barriers: the block is processed in four panels of 16 columns; the wavefront holds the panel as lane = row, 16 registers =
+ * the columns of the panel.  A pivot step: the reciprocal of the pivot (v_rcp_f64 + one third-order correction; the chain from
+ * pivot to pivot runs in wavefront-uniform arithmetic, see pd_panel), the update of the remaining columns of the panel with the
+ * scaling folded in, a_ij -= (a_ik / d) a_jk, where the a_jk are wavefront-uniform operands (the next two columns through
+ * v_readlane, the others through 64 doubles of LDS, applied one step late), and - off the chain - 1 / sqrt(d) (v_rsq_f64 + one
+ * third-order correction) for the stored column.  About 30 instructions per pivot; the loop is bound by their issue.
+ * Meanwhile the other three wavefronts apply the rank-16 update of the panel before to the 16 x 16 tiles behind the next
+ * panel on the matrix cores; the first wavefront updates the tile column of its next panel itself: one barrier per panel.
+ * [History: two columns per barrier with the pivot columns broadcast through LDS read 64 KB of LDS per pair of columns and
+ * took 25 us per block; the recurrence replicated in all four wavefronts 14 us; this form 10 us.]
  * Inverse: the four 16 x 16 diagonal blocks are inverted by one wavefront each (lane c = column c, the rows of L preloaded
  * into registers), the six off-diagonal blocks X_ij = -X_ii (sum_k L_ik X_kj) are 16 x 16 x 16 products on the matrix
  * cores (the f64 accumulator layout of the inner sum is exactly the B-operand layout of the outer product), one block
@@ -82,7 +84,7 @@ struct __attribute__((aligned(16))) dpair { double x, y; };
 typedef double v4dc __attribute__((ext_vector_type(4)));
 
 #define PD_LD (NB + 2)
-#define PD_SMEM_BYTES ((2 * NB * PD_LD + 4 * NB) * (int) sizeof(double))
+#define PD_SMEM_BYTES ((2 * NB * PD_LD + 5 * NB) * (int) sizeof(double))
 
 /* optional fused inputs / outputs of a single-block factorization (n <= 64; everything NULL for the blocked driver):
  * the matrix is base + alpha * dir (full symmetric storage, ld = lda) and is also stored to Mout; L gets a zero upper
@@ -105,8 +107,9 @@ struct pd_ext
                              * other step workgroups of the launch still read the unfactored block from the matrix */
 };
 
-/* panel of 16 columns starting at c0 out of the LDS block: lane = row; rows above the panel and the part of the diagonal block
- * above the diagonal give zeros */
+/* panel of 16 columns starting at c0 out of the LDS block: lane = row; rows above the panel give zeros.  The part of the
+ * diagonal block above the diagonal comes along as it is (zeros or the mirror image, finite either way): the recurrence
+ * carries those entries through without anybody reading them */
 __device__ __forceinline__ void pd_load_panel(double (&r)[16], const double (*W)[PD_LD], int lane, int c0, bool mine)
 {
 #pragma unroll
@@ -115,8 +118,8 @@ __device__ __forceinline__ void pd_load_panel(double (&r)[16], const double (*W)
       dpair u = {0.0, 0.0};
       if ( mine )
          u = *reinterpret_cast<const dpair*>(&W[lane][c0 + 2 * q]);
-      r[2 * q] = (lane >= c0 + 2 * q) ? u.x : 0.0;
-      r[2 * q + 1] = (lane >= c0 + 2 * q + 1) ? u.y : 0.0;
+      r[2 * q] = u.x;
+      r[2 * q + 1] = u.y;
    }
 }
 
@@ -124,33 +127,56 @@ __device__ __forceinline__ void pd_load_panel(double (&r)[16], const double (*W)
  * CHECKED = false is the straight recurrence: no branch, nothing but the pivot chain and the updates; it only notes whether a
  * pivot fell below its threshold thr[k] (0, or regtol * reference diagonal in semidefinite mode; also true for NaN), in which
  * case the caller reloads the panel and runs the CHECKED form, which replaces such pivots (see below).  isd[k] = 1 / l_kk,
- * fbits: bit k set where the pivot was forced and its column zeroed. */
+ * fbits: bit k set where the pivot was forced and its column zeroed.
+ * The chain from pivot to pivot stays in wavefront-uniform arithmetic: the two entries the next pivot is made of, a_{k+1,k} and
+ * a_{k+1,k+1}, are fetched (v_readlane) at the start of the step, when they are final, and d_{k+1} = a_{k+1,k+1} -
+ * (a_{k+1,k} / d_k) a_{k+1,k} is formed by every lane from them - the same operations lane k + 1 applies to its own entry, so
+ * the same bits - instead of being read back from that lane after the update: v_rcp_f64, one third-order step (rc (1 + e + e^2),
+ * e = 1 - d rc) and two operations per pivot, no register-file round trip. */
 template<bool CHECKED>
-__device__ __forceinline__ bool pd_panel(double (&r)[16], const double (&thr)[16], const double (&dds)[16], int lane, int c0, int nb, int j0,
+__device__ __forceinline__ bool pd_panel(double (&r)[16], const double (&thr)[16], const double* __restrict__ d0s, int lane, int c0, int nb, int j0,
    bool psd, double regtol, int rule, double (&isdo)[16], unsigned& fbits, int& bad, double* __restrict__ colb)
 {
    bool special = false;
    fbits = 0u;
+   double cprev[16], tprev = 0.0;
+   double d = pd_lane(r[0], c0);
 #pragma unroll
    for (int k = 0; k < 16; ++k)
    {
       const int gk = c0 + k;
       const double a = r[k];
-      double d = pd_lane(a, gk);
+      /* column entries of the next two rows (scalar operands of their updates) and the diagonal entry of the next row */
+      double sa = 0.0, sb = 0.0, sa2 = 0.0;
+      if ( k + 1 < 16 )
+      {
+         sa = pd_lane(a, gk + 1);
+         sb = pd_lane(r[k + 1], gk + 1);
+      }
+      if ( k + 2 < 16 )
+         sa2 = pd_lane(a, gk + 2);
+      double rc0 = __builtin_amdgcn_rcp(d);
       double y0 = __builtin_amdgcn_rsq(d);
       double cj[16];
-      if ( k + 2 < 16 )
+      if ( k + 3 < 16 )
       {
-         if ( lane >= c0 && lane < c0 + 16 )
-            colb[lane - c0] = a;
+         colb[lane] = a;               /* every row: no lane mask to set up; the rows of the diagonal block are read back */
          pd_wave_sync();
 #pragma unroll
-         for (int q = (k + 2) / 2; q < 8; ++q)
+         for (int q = (k + 3) / 2; q < 8; ++q)
          {
-            const dpair u = *reinterpret_cast<const dpair*>(&colb[2 * q]);
+            const dpair u = *reinterpret_cast<const dpair*>(&colb[c0 + 2 * q]);
             cj[2 * q] = u.x;
             cj[2 * q + 1] = u.y;
          }
+      }
+      /* the updates of the step before, columns k + 2 and up: their column entries came through LDS and have had a whole step
+       * to arrive */
+      if ( k > 0 )
+      {
+#pragma unroll
+         for (int j = k + 2; j < 16; ++j)
+            r[j] = fma(-tprev, cprev[j], r[j]);
       }
       bool reg = false;
       if ( !CHECKED )
@@ -165,12 +191,13 @@ __device__ __forceinline__ bool pd_panel(double (&r)[16], const double (&thr)[16
              * a column that is zero in exact arithmetic, and it is SET to zero: dividing noise by the forced pivot and
              * eliminating with it amplifies the noise exponentially over a run of dependent columns (observed: entries at
              * 1e158 for m = 200 with rank 136) */
-            const double dd = dds[k];
+            const double dd = d0s[gk];
             if ( !(d > regtol * dd) || !(d > 1e-300) )
             {
                reg = (rule == 1) || (rule == 2 && !(d > 0.0));
                d = (dd > 1e-280) ? regtol * dd : 1.0;
                y0 = __builtin_amdgcn_rsq(d);
+               rc0 = __builtin_amdgcn_rcp(d);
             }
          }
          else if ( !(d > 0.0) )
@@ -179,30 +206,94 @@ __device__ __forceinline__ bool pd_panel(double (&r)[16], const double (&thr)[16
                bad = j0 + gk + 1;
             d = 1.0;                 /* keep going with a harmless pivot; the caller reads the flag */
             y0 = 1.0;
+            rc0 = 1.0;
          }
       }
+      /* the multiplier of the update, a_ik / d; square root and 1 / l_kk (for the stored column) follow beside the chain */
+      const double ec = fma(-d, rc0, 1.0);
+      const double rcd = fma(rc0 * ec, 1.0 + ec, rc0);
+      const double t = reg ? 0.0 : a * rcd;
+      const double tu = reg ? 0.0 : sa * rcd;
+      const double dnext = fma(-tu, sa, sb);
       double sd, isd;
-      sqrt_and_rsqrt(d, y0, &sd, &isd);
+      if ( CHECKED )
+         sqrt_and_rsqrt(d, y0, &sd, &isd);
+      else
+      {
+         /* 1 / l_kk only: the pivot row itself gets l_kk = d / sqrt(d) from the scaling of the column */
+         const double tq = d * y0;
+         const double eq = fma(-tq, y0, 1.0);
+         isd = fma(y0 * eq, fma(0.375, eq, 0.5), y0);
+         sd = 0.0;
+      }
       const double e = reg ? 0.0 : isd;            /* scale of the sub-column (0: forced pivot) */
-      const double t = a * (e * e);
-      /* the column entries a_jk of the diagonal block as wavefront-uniform operands: the first one (it makes the next pivot) through
-       * v_readlane, the others through the wavefront's 16 doubles of LDS (written above, no barrier: LDS serves a wavefront in
-       * order), which costs a fifth of the instructions of 2 x 14 v_readlane + their wait states */
+      /* the column entries a_jk of the diagonal block as wavefront-uniform operands: the first two (the next two pivot columns
+       * must be complete when their turn comes) through v_readlane, the others through LDS (written above, no barrier: LDS
+       * serves a wavefront in order) - a fifth of the instructions of 2 x 14 v_readlane + their wait states - and applied
+       * one step later, when the loads have long arrived */
       if ( k + 1 < 16 )
-         r[k + 1] = fma(-t, pd_lane(a, gk + 1), r[k + 1]);
+         r[k + 1] = fma(-t, sa, r[k + 1]);
+      if ( k + 2 < 16 )
+         r[k + 2] = fma(-t, sa2, r[k + 2]);
+      tprev = t;
 #pragma unroll
-      for (int j = k + 2; j < 16; ++j)
-         r[j] = fma(-t, cj[j], r[j]);
-      /* final value of column gk in my row */
-      r[k] = (lane > gk) ? a * e : ((lane == gk) ? sd : 0.0);
+      for (int j = k + 3; j < 16; ++j)
+         cprev[j] = cj[j];
+      /* final value of column gk in my row.  The straight form scales every row: the pivot row gets d / sqrt(d), the rows above
+       * it (upper part of the diagonal block, rows before the panel) carry values nobody reads */
+      if ( CHECKED )
+         r[k] = (lane > gk) ? a * e : ((lane == gk) ? sd : 0.0);
+      else
+         r[k] = a * e;
       isdo[k] = isd;
       if ( reg )
          fbits |= 1u << k;
+      d = dnext;
    }
    return special;
 }
 
-/* LDS: tile 0 = the block while it is factored, inv(L) afterwards; tile 1 = L; then 1 / l_kk, the reference diagonal, the forced flags */
+/* rank-16 update W(i, j) -= P_i P_j^T of nt <= NTMAX tiles of one tile column j (i = i0 .. i0 + nt - 1) with the panel that
+ * starts at column cp: P_j is read once, the accumulators of the tiles advance together (a dependent MFMA waits twice as long
+ * as an independent one) */
+template<int NTMAX>
+__device__ __forceinline__ void pd_update_tiles(double (*W)[PD_LD], const double (*Lm)[PD_LD], int nt, int i0, int j, int cp, int lr, int lk)
+{
+   double pb[4], pa[NTMAX][4], cv[NTMAX][4];
+   v4dc acc[NTMAX];
+#pragma unroll
+   for (int sidx = 0; sidx < 4; ++sidx)
+      pb[sidx] = Lm[16 * j + lr][cp + 4 * sidx + lk];
+#pragma unroll
+   for (int t = 0; t < NTMAX; ++t)
+      if ( t < nt )
+      {
+         acc[t] = (v4dc){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+         for (int sidx = 0; sidx < 4; ++sidx)
+         {
+            pa[t][sidx] = Lm[16 * (i0 + t) + lr][cp + 4 * sidx + lk];
+            cv[t][sidx] = W[16 * (i0 + t) + lk + 4 * sidx][16 * j + lr];
+         }
+      }
+#pragma unroll
+   for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+      for (int t = 0; t < NTMAX; ++t)
+         if ( t < nt )
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[t][sidx], pb[sidx], acc[t], 0, 0, 0);
+#pragma unroll
+   for (int t = 0; t < NTMAX; ++t)
+      if ( t < nt )
+      {
+#pragma unroll
+         for (int rr = 0; rr < 4; ++rr)
+            W[16 * (i0 + t) + lk + 4 * rr][16 * j + lr] = cv[t][rr] - acc[t][rr];
+      }
+}
+
+/* LDS: tile 0 = the block while it is factored, inv(L) afterwards; tile 1 = L; then 64 doubles each: 1 / l_kk, the reference
+ * diagonal, the forced flags, the pivot column of the current step, the pivot thresholds */
 template<int NBK>      /* padded block size actually processed: 16, 32 or 64 (tiny blocks skip the identity padding) */
 __device__ __forceinline__ void pd_body(double* __restrict__ A, long long lda, int nb, int j0,
    double* __restrict__ dinv, int* __restrict__ flag, const double* __restrict__ diag0, double regtol, const pd_ext& ext)
@@ -218,7 +309,9 @@ __device__ __forceinline__ void pd_body(double* __restrict__ A, long long lda, i
    const int lane = tid & 63;
    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
    const int lr = lane & 15, lk = lane >> 4;
-   double* colb = forced + NB + 16 * wave;      /* the wavefront's current pivot column (16 doubles) */
+   double* colb = forced + NB;                  /* the current pivot column of the panel (64 doubles, first wavefront) */
+   double* thrs = colb + NB;                    /* below this a pivot needs the checked form: 0, or regtol * reference diagonal */
+   if ( !ext.from_lds )         /* k_potrf_step hands the block over complete: lower triangle, zeros above, identity padding */
    {
       const int i = tid >> 2;
       const int jc = tid & 3;
@@ -240,16 +333,18 @@ __device__ __forceinline__ void pd_body(double* __restrict__ A, long long lda, i
                   ext.Mout[(long long) j * lda + i] = v;
                }
             }
-            else if ( ext.from_lds )
-               v = W[i][j];
             else
                v = A[(long long) i * lda + j];
          }
          W[i][j] = v;
       }
    }
-   if ( diag0 != NULL && tid < nb )
-      d0s[tid] = diag0[j0 + tid];
+   if ( tid < NB )
+   {
+      const double dd = (diag0 != NULL && tid < nb) ? diag0[j0 + tid] : 0.0;
+      d0s[tid] = dd;
+      thrs[tid] = (diag0 != NULL && tid < nb) ? fmax(regtol * dd, 1e-300) : 0.0;
+   }
    int bad = 0;
    __syncthreads();
    PD_T(4);
@@ -261,80 +356,83 @@ __device__ __forceinline__ void pd_body(double* __restrict__ A, long long lda, i
       const int c0 = 16 * b;
       if ( b == 2 )
          PD_T(3);
-      /* the panel: lane = row, r[c] = column c0 + c; rows above the panel idle; within the diagonal block the upper part is not used */
-      double r[16];
-      const bool mine = (lane >= c0 && lane < NBK);
-      pd_load_panel(r, W, lane, c0, mine);
-      double dds[16], thr[16], isdo[16];
-#pragma unroll
-      for (int k = 0; k < 16; ++k)
+      /* the panel: lane = row, r[c] = column c0 + c; rows above the panel idle; within the diagonal block the upper part is not
+       * used.  One wavefront does it (the loop is bound by its instruction count: about 50 per pivot) and the others
+       * update the tiles behind the next panel meanwhile */
+      if ( wave == 0 )
       {
-         dds[k] = 0.0;
-         thr[k] = 0.0;
-         if ( diag0 != NULL && c0 + k < nb )
+         /* first the tile column this panel lives in gets the update of the panel before it (the other wavefronts take the
+          * tile columns behind it meanwhile: the barrier at the end of the round is the only one) */
+         if constexpr ( NBLK > 1 )
          {
-            dds[k] = d0s[c0 + k];
-            thr[k] = fmax(regtol * dds[k], 1e-300);
+            if ( b > 0 )
+               pd_update_tiles<NBLK - 1>(W, Lm, NBLK - b, b, b, c0 - 16, lr, lk);
          }
-      }
-      unsigned fbits;
-      if ( pd_panel<false>(r, thr, dds, lane, c0, nb, j0, diag0 != NULL, regtol, ext.rule, isdo, fbits, bad, colb) )
-      {
-         /* rare: a pivot needs the semidefinite treatment or is reported: once more from the unchanged block, with the checks */
+         double r[16];
+         const bool mine = (lane >= c0 && lane < NBK);
          pd_load_panel(r, W, lane, c0, mine);
-         (void) pd_panel<true>(r, thr, dds, lane, c0, nb, j0, diag0 != NULL, regtol, ext.rule, isdo, fbits, bad, colb);
-      }
-      if ( lane < 16 )
-      {
-         double v = isdo[0];
-#pragma unroll
-         for (int k = 1; k < 16; ++k)
-            v = (lane == k) ? isdo[k] : v;
-         invd[c0 + lane] = v;
-         const bool f = ((fbits >> lane) & 1u) != 0u;
-         forced[c0 + lane] = f ? 1.0 : 0.0;
-         if ( ext.regmask != NULL && !ext.nostore && wave == 0 && c0 + lane < nb )
-            ext.regmask[j0 + c0 + lane] = f ? 1 : 0;
-      }
-      if ( mine )
-      {
+         if ( b == 2 )
+            PD_T(11);
+         double thr[16], isdo[16];
 #pragma unroll
          for (int q = 0; q < 8; ++q)
          {
-            const dpair u = {r[2 * q], r[2 * q + 1]};
-            *reinterpret_cast<dpair*>(&Lm[lane][c0 + 2 * q]) = u;
+            const dpair u = *reinterpret_cast<const dpair*>(&thrs[c0 + 2 * q]);
+            thr[2 * q] = u.x;
+            thr[2 * q + 1] = u.y;
+         }
+         unsigned fbits;
+         if ( pd_panel<false>(r, thr, d0s, lane, c0, nb, j0, diag0 != NULL, regtol, ext.rule, isdo, fbits, bad, colb) )
+         {
+            /* rare: a pivot needs the semidefinite treatment or is reported: once more from the unchanged block, with the checks */
+            pd_load_panel(r, W, lane, c0, mine);
+            (void) pd_panel<true>(r, thr, d0s, lane, c0, nb, j0, diag0 != NULL, regtol, ext.rule, isdo, fbits, bad, colb);
+         }
+         if ( b == 2 )
+            PD_T(12);
+         if ( lane == 0 )
+         {
+            /* 1 / l_kk of the panel (wavefront-uniform values): one lane stores them */
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+            {
+               const dpair u = {isdo[2 * q], isdo[2 * q + 1]};
+               *reinterpret_cast<dpair*>(&invd[c0 + 2 * q]) = u;
+            }
+         }
+         if ( lane < 16 )
+         {
+            const bool f = ((fbits >> lane) & 1u) != 0u;
+            forced[c0 + lane] = f ? 1.0 : 0.0;
+            if ( ext.regmask != NULL && !ext.nostore && c0 + lane < nb )
+               ext.regmask[j0 + c0 + lane] = f ? 1 : 0;
+         }
+         if ( mine )
+         {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+            {
+               const dpair u = {r[2 * q], r[2 * q + 1]};
+               *reinterpret_cast<dpair*>(&Lm[lane][c0 + 2 * q]) = u;
+            }
          }
       }
-      pd_wave_sync();
-      /* rank-16 update of the tiles right of the panel: (i, j), b < j <= i, dealt out to the wavefronts column by column */
-      if ( b + 1 < NBLK )
+      else if ( b > 0 )
       {
+         /* tiles (i, j), b < j <= i, with the panel before this one: dealt out to the wavefronts 1 - 3 */
          int idx = 0;
 #pragma unroll
          for (int j = b + 1; j < NBLK; ++j)
 #pragma unroll
             for (int i = j; i < NBLK; ++i, ++idx)
-            {
-               if ( (idx & 3) != wave )
-                  continue;
-               v4dc acc = (v4dc){0.0, 0.0, 0.0, 0.0};
-               double pa[4], pb[4], cv[4];
-#pragma unroll
-               for (int sidx = 0; sidx < 4; ++sidx)
-               {
-                  pa[sidx] = Lm[16 * i + lr][c0 + 4 * sidx + lk];
-                  pb[sidx] = Lm[16 * j + lr][c0 + 4 * sidx + lk];
-                  cv[sidx] = W[16 * i + lk + 4 * sidx][16 * j + lr];
-               }
-#pragma unroll
-               for (int sidx = 0; sidx < 4; ++sidx)
-                  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[sidx], pb[sidx], acc, 0, 0, 0);
-#pragma unroll
-               for (int rr = 0; rr < 4; ++rr)
-                  W[16 * i + lk + 4 * rr][16 * j + lr] = cv[rr] - acc[rr];
-            }
+               if ( idx % 3 == wave - 1 )
+                  pd_update_tiles<1>(W, Lm, 1, i, j, c0 - 16, lr, lk);
       }
+      if ( b == 2 )
+         PD_T(13);
       __syncthreads();
+      if ( b == 2 )
+         PD_T(15);
    }
    PD_T(5);
 
@@ -510,24 +608,29 @@ template<bool LOWTRI>
 __device__ __forceinline__ void ps_mma(const double (*Ta)[PD_LD], const double (*Tb)[PD_LD], int wave, int lane, v4dc* acc)
 {
    const int lr = lane & 15, lk = lane >> 4;
-   /* the left operand of the wave (16 rows x 64) is read once and serves the four column tiles; fully unrolled, so that the
-    * LDS reads run ahead of the dependent MFMA chains */
+   /* the left operand of the wave (16 rows x 64) is read once and serves the four column tiles; the four accumulators advance
+    * together (an MFMA that continues an accumulator waits for the one before it: four independent chains keep the pipe full);
+    * each accumulator still sums k in ascending order */
    double a[16];
 #pragma unroll
    for (int sidx = 0; sidx < 16; ++sidx)
       a[sidx] = Ta[16 * wave + lr][4 * sidx + lk];
 #pragma unroll
    for (int t = 0; t < 4; ++t)
-   {
-      v4dc a4 = (v4dc){0.0, 0.0, 0.0, 0.0};
-      /* Tb block lower triangular (LOWTRI): Tb[col][k] = 0 for k beyond the column's 16-block */
+      acc[t] = (v4dc){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int sidx = 0; sidx < (LOWTRI ? 4 * (t + 1) : 16); ++sidx)
+   for (int sidx = 0; sidx < 16; ++sidx)
+   {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
       {
-         const double b = Tb[16 * t + lr][4 * sidx + lk];
-         a4 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[sidx], b, a4, 0, 0, 0);
+         /* Tb block lower triangular (LOWTRI): Tb[col][k] = 0 for k beyond the column's 16-block */
+         if ( !LOWTRI || sidx < 4 * (t + 1) )
+         {
+            const double b = Tb[16 * t + lr][4 * sidx + lk];
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[sidx], b, acc[t], 0, 0, 0);
+         }
       }
-      acc[t] = a4;
    }
 }
 
@@ -638,7 +741,7 @@ __global__ void __launch_bounds__(256) k_potrf_step(double* __restrict__ A, long
          for (int rr = 0; rr < 4; ++rr)
          {
             const int row = 16 * wave + lk + 4 * rr, col = 16 * t + lr;
-            double v = 0.0;
+            double v = (row >= nb && row == col) ? 1.0 : 0.0;       /* identity padding of a ragged last block */
             if ( row < nb && col <= row )
             {
                v = -acc[t][rr];
