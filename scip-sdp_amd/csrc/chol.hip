@@ -1301,16 +1301,25 @@ int hs_trsv(hipStream_t s, int n, const double* L, const double* dinv, int nrhs,
  * accumulates r_b - sum_{c<b} L_bc x_c as the x_c become available, then x_b = inv(L_bb) (..), publishes x_b and raises
  * its flag; backward the same with c > b and transposed blocks.  A block waits only on blocks that are strictly earlier
  * in the dependency order, so any dispatch order terminates; the flags carry the epoch of the call (no reset between
- * calls), the hand-off is release/acquire at agent scope (the acquire refreshes this CU's vector cache), and every spin
+ * calls), the hand-off goes through coherent (sc1) stores and loads (see trsv_publish), and every spin
  * is bounded: on expiry the error word behind the flags is set and the block leaves without publishing (later blocks then
  * expire too, the launch ends, and the interior-point loop stops on the non-finite step it gets).  The next L block is
  * requested before the flag of the current one is awaited. */
 #define TRSV_SPIN_LIMIT (1 << 20)
 
+/* What one block hands to the others - its 64 x NRHS solution entries and its flag - is stored and loaded as relaxed
+ * agent-scope atomics (sc1: served at the device's coherence point), and the stores are waited for (vmcnt) before the flag
+ * goes up.  A release / acquire pair at agent scope would do, but on this device it writes back and invalidates the L2 of an
+ * XCD each time (eight XCDs, one L2 each): that was most of the 5 us a block took. */
+__device__ __forceinline__ void trsv_publish(double* p, double v)
+{
+   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ bool trsv_wait(const int* flag, int epoch, int* err)
 {
    int spins = 0;
-   while ( __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch )
+   while ( __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch )
    {
       if ( ++spins > TRSV_SPIN_LIMIT )
       {
@@ -1378,7 +1387,8 @@ __global__ void __launch_bounds__(256) k_trsv_fwd(int n, const double* __restric
       if ( !ok )
          return;
       if ( tid < NB * NRHS )
-         xs[tid / NB][tid % NB] = rhs[(long long) (tid / NB) * ldr + cb * NB + (tid % NB)];
+         xs[tid / NB][tid % NB] = __hip_atomic_load(&rhs[(long long) (tid / NB) * ldr + cb * NB + (tid % NB)], __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();
 #pragma unroll
       for (int k = 0; k < NRHS; ++k)
@@ -1420,8 +1430,9 @@ __global__ void __launch_bounds__(256) k_trsv_fwd(int n, const double* __restric
             x0s[k][row] = rowok ? sacc : 0.0;
       }
       else if ( q == 0 && rowok )
-         rhs[(long long) k * ldr + j0 + row] = sacc;
+         trsv_publish(&rhs[(long long) k * ldr + j0 + row], sacc);
    }
+   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
    __syncthreads();
    if ( refine )
    {
@@ -1456,15 +1467,13 @@ __global__ void __launch_bounds__(256) k_trsv_fwd(int n, const double* __restric
          sacc += __shfl_xor(sacc, 1, 64);
          sacc += __shfl_xor(sacc, 2, 64);
          if ( q == 0 && rowok )
-            rhs[(long long) k * ldr + j0 + row] = x0s[k][row] + sacc;
+            trsv_publish(&rhs[(long long) k * ldr + j0 + row], x0s[k][row] + sacc);
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
    }
    if ( tid == 0 )
-   {
-      __threadfence();
-      __hip_atomic_store(flags + b, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-   }
+      __hip_atomic_store(flags + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template<int NRHS>
@@ -1525,7 +1534,8 @@ __global__ void __launch_bounds__(256) k_trsv_bwd(int n, const double* __restric
       if ( tid < NB * NRHS )
       {
          const int i = tid % NB;
-         xs[tid / NB][i] = (i < nbc) ? rhs[(long long) (tid / NB) * ldr + i0 + i] : 0.0;
+         xs[tid / NB][i] = (i < nbc) ? __hip_atomic_load(&rhs[(long long) (tid / NB) * ldr + i0 + i], __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_AGENT) : 0.0;
       }
       __syncthreads();
 #pragma unroll
@@ -1568,8 +1578,9 @@ __global__ void __launch_bounds__(256) k_trsv_bwd(int n, const double* __restric
       if ( refine )
          x0s[k][i] = (i < nb) ? v : 0.0;
       else if ( i < nb )
-         rhs[(long long) k * ldr + j0 + i] = v;
+         trsv_publish(&rhs[(long long) k * ldr + j0 + i], v);
    }
+   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
    __syncthreads();
    if ( refine )
    {
@@ -1605,15 +1616,13 @@ __global__ void __launch_bounds__(256) k_trsv_bwd(int n, const double* __restric
       {
          const int k = tid / NB, i = tid % NB;
          if ( i < nb )
-            rhs[(long long) k * ldr + j0 + i] = x0s[k][i] + (red[0][k][i] + red[1][k][i] + red[2][k][i] + red[3][k][i]);
+            trsv_publish(&rhs[(long long) k * ldr + j0 + i], x0s[k][i] + (red[0][k][i] + red[1][k][i] + red[2][k][i] + red[3][k][i]));
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
    }
    if ( tid == 0 )
-   {
-      __threadfence();
-      __hip_atomic_store(flags + b, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-   }
+      __hip_atomic_store(flags + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 /* number of ints of the flag workspace of hs_trsv_sync for an n x n factor (zero it once after allocation) */

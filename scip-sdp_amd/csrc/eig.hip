@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(64) k_tridiag_min(int kmax, const double* __re
  * rows of v = W q_j.  The kernel boundary is the only grid-wide synchronisation; v and the meta scalars alternate
  * between two buffers so that no workgroup reads what another one writes in the same launch.  Launch k ends with the
  * tridiagonal eigenproblem on workgroup 0.  blockIdx.y selects the matrix (X-side / Z-side of a block). */
-struct lanczos_job { const double* W; double* Q; double* v0; double* v1; double* alpha; double* beta; double* meta; double* res; };
+struct lanczos_job { const double* W; double* Q; double* v0; double* v1; double* alpha; double* beta; double* meta; double* res; unsigned long long* sync; };
 struct lanczos_jobs { lanczos_job job[2]; };
 
 __global__ void __launch_bounds__(1024) k_lanczos_fused(int n, int j, int k, lanczos_jobs jobs)
@@ -442,6 +442,180 @@ __global__ void __launch_bounds__(1024) k_lanczos_fused(int n, int j, int k, lan
    else if ( writer && wave == 0 )
    {
       tridiag_min_wave(k, J.alpha, J.beta, meta0, j - 1, last_alpha, last_beta, J.res, T);
+   }
+}
+
+/* ---- the same run in ONE launch -------------------------------------------------------------------------------------- */
+/* All k + 1 rounds of k_lanczos_fused inside one kernel: the workgroups of a matrix meet at a counter in global memory after
+ * every round instead of at a kernel boundary (a round is a few microseconds of work, a launch 11 - 12 us of latency: 17 steps
+ * took 0.2 ms of an iteration's 3 ms outside the Schur complement).  What makes a meeting cheap on this device: the eight XCDs
+ * have an L2 each, and an agent-scope release / acquire pair writes back and invalidates those (a first version with
+ * __threadfence() + acquire loads needed 27 us per round - worse than the launches).  Here nothing that crosses workgroups goes
+ * through a non-coherent cache: the Lanczos basis stays in LDS (every workgroup builds all of it anyway: (k + 2) n doubles, so
+ * n <= about 1000 at 16 steps), and the only data exchanged - the n entries of v = W q_j - are stored and loaded as relaxed
+ * agent-scope atomics (sc1: served at the coherence point), as is the counter; the stores are waited for (vmcnt) before the
+ * workgroup's arrival is counted.  The grid is small (n / 16 workgroups per matrix) and co-resident; the counter only grows
+ * (epoch: arrivals before this launch, kept by the caller); every wait is bounded: on expiry the error word behind the
+ * counter is set, the workgroups leave and the first one reports NaN, which ends the solve as a numerical failure.
+ * Identical arithmetic in identical order: the results are bitwise those of the launch-per-round form. */
+#define LZ_SPIN_LIMIT (1 << 20)
+
+__device__ __forceinline__ bool lz_grid_wait(unsigned long long* cnt, unsigned long long target, int* err, int* okflag)
+{
+   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            /* this wavefront's stores of the round have been acknowledged */
+   __syncthreads();
+   if ( threadIdx.x == 0 )
+   {
+      (void) __hip_atomic_fetch_add(cnt, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int spins = 0, ok = 1;
+      while ( __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target )
+      {
+         if ( ++spins > LZ_SPIN_LIMIT || ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) )
+         {
+            atomicExch(err, 1);
+            ok = 0;
+            break;
+         }
+         __builtin_amdgcn_s_sleep(2);
+      }
+      *okflag = ok;
+   }
+   __syncthreads();
+   return *okflag != 0;
+}
+
+__global__ void __launch_bounds__(1024) k_lanczos_persist(int n, int k, lanczos_jobs jobs, unsigned long long epoch0, unsigned long long epoch1)
+{
+   extern __shared__ __attribute__((aligned(16))) double lz_smem[];
+   __shared__ double sh[16];
+   __shared__ double coef[256];
+   __shared__ double al[256], be[256];
+   __shared__ tridiag_smem T;
+   __shared__ int okflag;
+   double* vs = lz_smem;            /* n: v, then q_j */
+   double* Qs = lz_smem + n;        /* (k + 1) x n: the basis */
+   const lanczos_job J = jobs.job[blockIdx.y];
+   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   const bool writer = blockIdx.x == 0;
+   const int G = gridDim.x;
+   unsigned long long* cnt = J.sync;                        /* round counter, error word behind it */
+   int* err = reinterpret_cast<int*>(J.sync + 1);
+   const unsigned long long base = blockIdx.y == 0 ? epoch0 : epoch1;
+   double scale = 0.0, meta0 = -1.0;
+
+   for (int j = 0; j <= k; ++j)
+   {
+      const double* vin = ((j + 1) & 1) ? J.v1 : J.v0;       /* written in round j - 1 */
+      double* vout = (j & 1) ? J.v1 : J.v0;
+      double* qn = Qs + (long long) j * n;
+      if ( j == 0 )
+      {
+         double sacc = 0.0;
+         for (int i = tid; i < n; i += 1024)
+         {
+            /* fixed pseudo-random start vector: reproducible, not orthogonal to anything in particular */
+            unsigned long long h = (unsigned long long) (i + 1) * 0x9E3779B97F4A7C15ULL;
+            h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ULL; h ^= h >> 32;
+            const double v = 0.5 + (double) (h >> 11) * (1.0 / 9007199254740992.0);
+            vs[i] = v;
+            sacc += v * v;
+         }
+         sacc = bsum1024(sacc, sh);
+         const double inv = 1.0 / sqrt(sacc);
+         for (int i = tid; i < n; i += 1024)
+         {
+            const double qv = vs[i] * inv;
+            vs[i] = qv;
+            qn[i] = qv;
+         }
+      }
+      else
+      {
+         const int jj = j - 1;       /* the step being finished */
+         for (int e = tid; e < n; e += 1024)
+            vs[e] = __hip_atomic_load(&vin[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+         __syncthreads();
+         double aj = 0.0;
+         for (int pass = 0; pass < 2; ++pass)
+         {
+            /* c_i = q_i . v : one wave per i */
+            for (int i = wave; i <= jj; i += 16)
+            {
+               const double* q = Qs + (long long) i * n;
+               double sacc = 0.0;
+               for (int e = lane; e < n; e += 64)
+                  sacc += q[e] * vs[e];
+               sacc = wsum(sacc);
+               if ( lane == 0 )
+                  coef[i] = sacc;
+            }
+            __syncthreads();
+            if ( pass == 0 )
+               aj = coef[jj];
+            /* v -= sum_i c_i q_i */
+            for (int e = tid; e < n; e += 1024)
+            {
+               double sacc = vs[e];
+               for (int i = 0; i <= jj; ++i)
+                  sacc -= coef[i] * Qs[(long long) i * n + e];
+               vs[e] = sacc;
+            }
+            __syncthreads();
+         }
+         double sacc = 0.0;
+         for (int e = tid; e < n; e += 1024)
+            sacc += vs[e] * vs[e];
+         sacc = bsum1024(sacc, sh);
+         const double b = sqrt(sacc);
+         if ( fabs(aj) + b > scale )
+            scale = fabs(aj) + b;
+         const bool broke = (meta0 >= 0.0) || !(b > 1e-13 * scale) || !(b > 1e-300);
+         const double inv = broke ? 0.0 : 1.0 / b;
+         for (int e = tid; e < n; e += 1024)
+         {
+            const double qv = vs[e] * inv;
+            vs[e] = qv;
+            qn[e] = qv;
+         }
+         if ( broke && meta0 < 0.0 )
+            meta0 = (double) jj;
+         if ( tid == 0 )
+         {
+            al[jj] = aj;
+            be[jj] = broke ? 0.0 : b;
+         }
+      }
+      __syncthreads();
+      if ( j < k )
+      {
+         /* my rows of v = W q_j (q_j = 0 after a breakdown: harmless) */
+         const int rows = (n + G - 1) / G;
+         const int r0 = blockIdx.x * rows;
+         const int r1 = min(n, r0 + rows);
+         for (int r = r0 + wave; r < r1; r += 16)
+         {
+            const double* wr = J.W + (long long) r * n;
+            double sacc = 0.0;
+            for (int e = lane; e < n; e += 64)
+               sacc += wr[e] * vs[e];
+            sacc = wsum(sacc);
+            if ( lane == 0 )
+               __hip_atomic_store(&vout[r], sacc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+         }
+         /* everybody's rows before anybody's next round */
+         if ( !lz_grid_wait(cnt, base + (unsigned long long) G * (unsigned long long) (j + 1), err, &okflag) )
+         {
+            if ( writer && tid == 0 )
+            {
+               J.res[0] = __builtin_nan("");
+               J.res[1] = __builtin_nan("");
+               J.res[2] = 0.0;
+            }
+            return;
+         }
+      }
+      else if ( writer && wave == 0 )
+         tridiag_min_wave(k, al, be, meta0, -1, 0.0, 0.0, J.res, T);
    }
 }
 
@@ -677,11 +851,14 @@ static void lanczos_job_init(lanczos_job* J, int n, int maxsteps, const double* 
    J->beta = J->alpha + maxsteps;
    J->meta = J->beta + maxsteps;                       /* 2 x 2 (+ padding) */
    J->res = res;
+   J->sync = NULL;
 }
 
 /* smallest eigenvalue of one or two symmetric n x n matrices (W1 may be NULL); res = {theta, residual bound, steps} */
+static int lz_no_persist = -1;
+
 int hs_lanczos_lmin2(hipStream_t s, int n, const double* W0, const double* W1, int maxsteps, double* res0, double* res1,
-   double* ws0, double* ws1)
+   double* ws0, double* ws1, unsigned long long* epochs, unsigned long long* dsync)
 {
    if ( n <= 0 )
       return HS_ERR_ARG;
@@ -717,6 +894,30 @@ int hs_lanczos_lmin2(hipStream_t s, int n, const double* W0, const double* W1, i
       jobs.job[1] = jobs.job[0];
    int G = (n + 15) / 16;          /* >= 16 rows per workgroup: one per wavefront */
    if ( G > 128 ) G = 128;
+   if ( lz_no_persist < 0 )
+   {
+      const char* env = getenv("HIPSDP_LANCZOS_LAUNCHES");
+      lz_no_persist = (env != NULL && env[0] == '1') ? 1 : 0;
+   }
+   const size_t lds_persist = (size_t) (k + 2) * (size_t) n * sizeof(double);
+   if ( epochs != NULL && dsync != NULL && !lz_no_persist && k <= 250 && lds_persist <= 120 * 1024 )
+   {
+      jobs.job[0].sync = dsync;
+      jobs.job[1].sync = (W1 != NULL) ? dsync + 2 : dsync;
+      /* one launch: the rounds meet at a counter (epochs[0 / 1]: arrivals so far at the counter in ws0 / ws1) */
+      static bool attr2_set = false;
+      if ( !attr2_set )
+      {
+         HS_HIP( hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lanczos_persist), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) );
+         attr2_set = true;
+      }
+      hipLaunchKernelGGL(k_lanczos_persist, dim3(G, nb), dim3(1024), lds_persist, s, n, k, jobs, epochs[0], epochs[1]);
+      HS_LAUNCH_CHECK();
+      epochs[0] += (unsigned long long) G * (unsigned long long) k;
+      if ( nb == 2 )
+         epochs[1] += (unsigned long long) G * (unsigned long long) k;
+      return HS_OK;
+   }
    for (int j = 0; j <= k; ++j)
    {
       hipLaunchKernelGGL(k_lanczos_fused, dim3(G, nb), dim3(1024), (size_t) n * sizeof(double), s, n, j, k, jobs);
@@ -738,7 +939,7 @@ int hs_lmin_scaled_tiny(hipStream_t s, int n, const double* L0, const double* D0
 
 int hs_lanczos_lmin(hipStream_t s, int n, const double* W, int maxsteps, double* res, double* ws)
 {
-   return hs_lanczos_lmin2(s, n, W, NULL, maxsteps, res, NULL, ws, NULL);
+   return hs_lanczos_lmin2(s, n, W, NULL, maxsteps, res, NULL, ws, NULL, NULL, NULL);
 }
 
 /* ---------------------------------------------------------------------------------------------------------------- */
