@@ -446,45 +446,27 @@ __global__ void __launch_bounds__(1024) k_lanczos_fused(int n, int j, int k, lan
 }
 
 /* ---- the same run in ONE launch -------------------------------------------------------------------------------------- */
-/* All k + 1 rounds of k_lanczos_fused inside one kernel: the workgroups of a matrix meet at a counter in global memory after
- * every round instead of at a kernel boundary (a round is a few microseconds of work, a launch 11 - 12 us of latency: 17 steps
- * took 0.2 ms of an iteration's 3 ms outside the Schur complement).  What makes a meeting cheap on this device: the eight XCDs
- * have an L2 each, and an agent-scope release / acquire pair writes back and invalidates those (a first version with
- * __threadfence() + acquire loads needed 27 us per round - worse than the launches).  Here nothing that crosses workgroups goes
- * through a non-coherent cache: the Lanczos basis stays in LDS (every workgroup builds all of it anyway: (k + 2) n doubles, so
- * n <= about 1000 at 16 steps), and the only data exchanged - the n entries of v = W q_j - are stored and loaded as relaxed
- * agent-scope atomics (sc1: served at the coherence point), as is the counter; the stores are waited for (vmcnt) before the
- * workgroup's arrival is counted.  The grid is small (n / 16 workgroups per matrix) and co-resident; the counter only grows
- * (epoch: arrivals before this launch, kept by the caller); every wait is bounded: on expiry the error word behind the
- * counter is set, the workgroups leave and the first one reports NaN, which ends the solve as a numerical failure.
- * Identical arithmetic in identical order: the results are bitwise those of the launch-per-round form. */
-#define LZ_SPIN_LIMIT (1 << 20)
+/* All k + 1 rounds of k_lanczos_fused inside one kernel (a round is a few microseconds of work, a launch 11 - 12 us of
+ * latency: 17 steps took 0.2 ms of an iteration's 3 ms outside the Schur complement).  What makes the hand-over between
+ * workgroups cheap on this device: the eight XCDs have an L2 each, and an agent-scope release / acquire pair writes back and
+ * invalidates those (a first version with __threadfence() + acquire loads needed 27 us per round - worse than the launches).
+ * Here nothing that crosses workgroups goes through a non-coherent cache, and there is no separate synchronisation at all:
+ *  - the Lanczos basis stays in LDS (every workgroup builds all of it anyway: (k + 2) n doubles, so n <= about 850 at 16 steps);
+ *  - the only data exchanged - the n entries of v = W q_j - are stored and loaded as relaxed agent-scope atomics (sc1: served
+ *    at the device's coherence point), and the data is its own signal: an exchange vector is all NaN before it is written,
+ *    and a reader polls each entry it needs until it is a number (one round trip when the entry is already there; a
+ *    counter would cost three: wait for the stores, count, poll).  Three vectors rotate: round j writes vector j mod 3, reads
+ *    j - 1 mod 3 and every workgroup resets its own rows of j + 1 mod 3 to NaN - safe, because whoever has reached round j
+ *    has seen everybody's rows of round j - 1, and those were written after their writers' last read of vector j + 1 mod 3.
+ *    The run ends with exactly one clean vector (k mod 3): the caller rotates the start of the next run onto it (rot).
+ *  - every wait is bounded: on expiry the error word is set, the workgroups leave and the first one reports NaN, which ends
+ *    the solve as a numerical failure (a NaN produced by the arithmetic itself ends the same way).
+ * The grid is small (n / 16 workgroups per matrix) and co-resident.  Identical arithmetic in identical order: the results are
+ * bitwise those of the launch-per-round form. */
+#define LZ_SPIN_LIMIT (1 << 18)
+#define LZ_STRIDE 8192            /* doubles between the exchange vectors (n <= 8192 on this path) */
 
-__device__ __forceinline__ bool lz_grid_wait(unsigned long long* cnt, unsigned long long target, int* err, int* okflag)
-{
-   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            /* this wavefront's stores of the round have been acknowledged */
-   __syncthreads();
-   if ( threadIdx.x == 0 )
-   {
-      (void) __hip_atomic_fetch_add(cnt, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int spins = 0, ok = 1;
-      while ( __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target )
-      {
-         if ( ++spins > LZ_SPIN_LIMIT || ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) )
-         {
-            atomicExch(err, 1);
-            ok = 0;
-            break;
-         }
-         __builtin_amdgcn_s_sleep(2);
-      }
-      *okflag = ok;
-   }
-   __syncthreads();
-   return *okflag != 0;
-}
-
-__global__ void __launch_bounds__(1024) k_lanczos_persist(int n, int k, lanczos_jobs jobs, unsigned long long epoch0, unsigned long long epoch1)
+__global__ void __launch_bounds__(1024) k_lanczos_persist(int n, int k, lanczos_jobs jobs, int rot0, int rot1)
 {
    extern __shared__ __attribute__((aligned(16))) double lz_smem[];
    __shared__ double sh[16];
@@ -498,15 +480,21 @@ __global__ void __launch_bounds__(1024) k_lanczos_persist(int n, int k, lanczos_
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
    const bool writer = blockIdx.x == 0;
    const int G = gridDim.x;
-   unsigned long long* cnt = J.sync;                        /* round counter, error word behind it */
-   int* err = reinterpret_cast<int*>(J.sync + 1);
-   const unsigned long long base = blockIdx.y == 0 ? epoch0 : epoch1;
+   int* err = reinterpret_cast<int*>(J.sync);                /* error word, exchange vectors behind it */
+   double* xv = reinterpret_cast<double*>(J.sync + 2);
+   const int rot = blockIdx.y == 0 ? rot0 : rot1;
+   const int rows = (n + G - 1) / G;
+   const int r0 = blockIdx.x * rows;
+   const int r1 = min(n, r0 + rows);
    double scale = 0.0, meta0 = -1.0;
+   if ( tid == 0 )
+      okflag = 1;
 
    for (int j = 0; j <= k; ++j)
    {
-      const double* vin = ((j + 1) & 1) ? J.v1 : J.v0;       /* written in round j - 1 */
-      double* vout = (j & 1) ? J.v1 : J.v0;
+      const double* vin = xv + (long long) ((rot + j + 2) % 3) * LZ_STRIDE;       /* written in round j - 1 */
+      double* vout = xv + (long long) ((rot + j) % 3) * LZ_STRIDE;
+      double* vnext = xv + (long long) ((rot + j + 1) % 3) * LZ_STRIDE;
       double* qn = Qs + (long long) j * n;
       if ( j == 0 )
       {
@@ -528,13 +516,52 @@ __global__ void __launch_bounds__(1024) k_lanczos_persist(int n, int k, lanczos_
             vs[i] = qv;
             qn[i] = qv;
          }
+         for (int r = r0 + tid; r < r1; r += 1024)
+            __hip_atomic_store(&vnext[r], __builtin_nan(""), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       else
       {
          const int jj = j - 1;       /* the step being finished */
+         bool mine_ok = true;
          for (int e = tid; e < n; e += 1024)
-            vs[e] = __hip_atomic_load(&vin[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+         {
+            double v = __hip_atomic_load(&vin[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int spins = 0;
+            while ( v != v )
+            {
+               if ( ++spins > LZ_SPIN_LIMIT )
+               {
+                  mine_ok = false;
+                  break;
+               }
+               __builtin_amdgcn_s_sleep(1);
+               v = __hip_atomic_load(&vin[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            vs[e] = v;
+         }
+         if ( !mine_ok )
+         {
+            okflag = 0;
+            atomicExch(err, 1);
+         }
          __syncthreads();
+         if ( !okflag )
+         {
+            if ( writer && tid == 0 )
+            {
+               J.res[0] = __builtin_nan("");
+               J.res[1] = __builtin_nan("");
+               J.res[2] = 0.0;
+            }
+            return;
+         }
+         /* everybody's rows of round j - 1 have been seen: my rows of the vector after next can be wiped.  The stores are
+          * acknowledged before this round's rows go out (vmcnt below): who sees those finds the wiped vector wiped */
+         if ( j < k )
+         {
+            for (int r = r0 + tid; r < r1; r += 1024)
+               __hip_atomic_store(&vnext[r], __builtin_nan(""), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+         }
          double aj = 0.0;
          for (int pass = 0; pass < 2; ++pass)
          {
@@ -585,13 +612,11 @@ __global__ void __launch_bounds__(1024) k_lanczos_persist(int n, int k, lanczos_
             be[jj] = broke ? 0.0 : b;
          }
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if ( j < k )
       {
          /* my rows of v = W q_j (q_j = 0 after a breakdown: harmless) */
-         const int rows = (n + G - 1) / G;
-         const int r0 = blockIdx.x * rows;
-         const int r1 = min(n, r0 + rows);
          for (int r = r0 + wave; r < r1; r += 16)
          {
             const double* wr = J.W + (long long) r * n;
@@ -602,21 +627,28 @@ __global__ void __launch_bounds__(1024) k_lanczos_persist(int n, int k, lanczos_
             if ( lane == 0 )
                __hip_atomic_store(&vout[r], sacc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
          }
-         /* everybody's rows before anybody's next round */
-         if ( !lz_grid_wait(cnt, base + (unsigned long long) G * (unsigned long long) (j + 1), err, &okflag) )
-         {
-            if ( writer && tid == 0 )
-            {
-               J.res[0] = __builtin_nan("");
-               J.res[1] = __builtin_nan("");
-               J.res[2] = 0.0;
-            }
-            return;
-         }
       }
       else if ( writer && wave == 0 )
          tridiag_min_wave(k, al, be, meta0, -1, 0.0, 0.0, J.res, T);
    }
+}
+
+/* device words a caller of the one-launch form provides per pair of matrices (hs_lanczos_lmin2's dsync): per matrix an error
+ * word (2 x 8 bytes) and three exchange vectors; hs_lanczos_sync_reset puts them into the state a first run expects */
+long long hs_lanczos_sync_words(void)
+{
+   return 2LL * (2 + 3LL * LZ_STRIDE);
+}
+
+int hs_lanczos_sync_reset(hipStream_t s, unsigned long long* dsync, int* rot)
+{
+   if ( dsync == NULL )
+      return HS_OK;
+   HS_HIP( hipMemsetAsync(dsync, 0xFF, (size_t) hs_lanczos_sync_words() * sizeof(unsigned long long), s) );      /* all NaN */
+   HS_HIP( hipMemsetAsync(dsync, 0, 2 * sizeof(unsigned long long), s) );
+   HS_HIP( hipMemsetAsync(dsync + 2 + 3LL * LZ_STRIDE, 0, 2 * sizeof(unsigned long long), s) );
+   rot[0] = rot[1] = 0;
+   return HS_OK;
 }
 
 long long hs_lanczos_ws(int n, int maxsteps)
@@ -858,7 +890,7 @@ static void lanczos_job_init(lanczos_job* J, int n, int maxsteps, const double* 
 static int lz_no_persist = -1;
 
 int hs_lanczos_lmin2(hipStream_t s, int n, const double* W0, const double* W1, int maxsteps, double* res0, double* res1,
-   double* ws0, double* ws1, unsigned long long* epochs, unsigned long long* dsync)
+   double* ws0, double* ws1, int* rot, unsigned long long* dsync)
 {
    if ( n <= 0 )
       return HS_ERR_ARG;
@@ -900,22 +932,22 @@ int hs_lanczos_lmin2(hipStream_t s, int n, const double* W0, const double* W1, i
       lz_no_persist = (env != NULL && env[0] == '1') ? 1 : 0;
    }
    const size_t lds_persist = (size_t) (k + 2) * (size_t) n * sizeof(double);
-   if ( epochs != NULL && dsync != NULL && !lz_no_persist && k <= 250 && lds_persist <= 120 * 1024 )
+   if ( rot != NULL && dsync != NULL && !lz_no_persist && k >= 3 && k <= 250 && lds_persist <= 120 * 1024 )
    {
+      /* one launch (see k_lanczos_persist); rot[0 / 1]: which of the three exchange vectors of a matrix is the clean one */
       jobs.job[0].sync = dsync;
-      jobs.job[1].sync = (W1 != NULL) ? dsync + 2 : dsync;
-      /* one launch: the rounds meet at a counter (epochs[0 / 1]: arrivals so far at the counter in ws0 / ws1) */
+      jobs.job[1].sync = (W1 != NULL) ? dsync + 2 + 3LL * LZ_STRIDE : dsync;
       static bool attr2_set = false;
       if ( !attr2_set )
       {
          HS_HIP( hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lanczos_persist), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) );
          attr2_set = true;
       }
-      hipLaunchKernelGGL(k_lanczos_persist, dim3(G, nb), dim3(1024), lds_persist, s, n, k, jobs, epochs[0], epochs[1]);
+      hipLaunchKernelGGL(k_lanczos_persist, dim3(G, nb), dim3(1024), lds_persist, s, n, k, jobs, rot[0], rot[1]);
       HS_LAUNCH_CHECK();
-      epochs[0] += (unsigned long long) G * (unsigned long long) k;
+      rot[0] = (rot[0] + k) % 3;
       if ( nb == 2 )
-         epochs[1] += (unsigned long long) G * (unsigned long long) k;
+         rot[1] = (rot[1] + k) % 3;
       return HS_OK;
    }
    for (int j = 0; j <= k; ++j)

@@ -160,11 +160,13 @@ int hs_lanczos_scaled_small(hipStream_t s, int n, int maxsteps, const double* L0
    double* res0, double* res1);
 int hs_lmin_scaled_tiny(hipStream_t s, int n, const double* L0, const double* D0, const double* L1, const double* D1, double* res0,
    double* res1);
-/* epochs, dsync (may be NULL: one launch per Lanczos step): two host counters and four device words (counter + error word
- * per matrix) owned by the caller, zeroed together; with them the whole run is one launch whose workgroups meet at the
- * device counters after every step */
+/* rot, dsync (may be NULL: one launch per Lanczos step): two host integers and hs_lanczos_sync_words() device words owned by
+ * the caller, put into their initial state by hs_lanczos_sync_reset (after allocation, and again after a run that reported
+ * NaN); with them the whole run is one launch whose workgroups hand the product vector over through those words */
 int hs_lanczos_lmin2(hipStream_t s, int n, const double* W0, const double* W1, int maxsteps, double* res0, double* res1,
-   double* ws0, double* ws1, unsigned long long* epochs, unsigned long long* dsync);
+   double* ws0, double* ws1, int* rot, unsigned long long* dsync);
+long long hs_lanczos_sync_words(void);
+int hs_lanczos_sync_reset(hipStream_t s, unsigned long long* dsync, int* rot);
 
 /* Cyclic Jacobi eigen-decomposition of the symmetric n x n matrix A (destroyed): eigenvalues ascending in lam[n],
  * eigenvectors as rows of V (row k = k-th eigenvector).  info (device int) = sweeps used or -1. */

@@ -122,8 +122,8 @@ struct hipsdp_solver
    int* trsv_ws;           /* block flags of the multi-workgroup triangular solves */
    int trsv_epoch;
    bool refine_solves;           /* the triangular solves with M correct themselves once with the factor (hs_trsv mode bit 4) */
-   unsigned long long lan_epochs[2];   /* arrivals so far at the round counters of the persistent Lanczos kernel (eig.hip) */
-   unsigned long long* lan_sync;       /* device: round counter + error word per matrix of a pair */
+   int lan_rot[2];                     /* which exchange vector of the one-launch Lanczos runs is the clean one (eig.hip) */
+   unsigned long long* lan_sync;       /* device: error word + exchange vectors per matrix of a pair */
    long long gws_len;
    long long gemv_ws_len;
    int* flags;       /* device ints: 0 chol Z, 1 chol X, 2 chol M */
@@ -350,7 +350,7 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
    s->regmask = NULL;
    s->trsv_epoch = 0;
    s->lan_sync = NULL;
-   s->lan_epochs[0] = s->lan_epochs[1] = 0ULL;
+   s->lan_rot[0] = s->lan_rot[1] = 0;
    s->last_status = HIPSDP_STATUS_UNSOLVED;
    s->sol_scale = 1.0;
    s->pc.on = getenv("HIPSDP_PHASES") != NULL && atoi(getenv("HIPSDP_PHASES")) != 0;
@@ -560,9 +560,8 @@ extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int*
    HS_CALL( dalloc(&s->lan_ws, hs_lanczos_ws(nmax, 256)) );
    HS_CALL( dalloc(&s->lan_ws2, hs_lanczos_ws(nmax, 256)) );
    if ( s->lan_sync == NULL )
-      HS_HIP( hipMalloc((void**) &s->lan_sync, 4 * sizeof(unsigned long long)) );
-   HS_HIP( hipMemset(s->lan_sync, 0, 4 * sizeof(unsigned long long)) );
-   s->lan_epochs[0] = s->lan_epochs[1] = 0ULL;
+      HS_HIP( hipMalloc((void**) &s->lan_sync, (size_t) hs_lanczos_sync_words() * sizeof(unsigned long long)) );
+   HS_CALL( hs_lanczos_sync_reset(s->stream, s->lan_sync, s->lan_rot) );
    s->gws_len = 8LL * nmax * nmax;
    if ( s->gws_len > 8LL * 1024 * 1024 ) s->gws_len = 8LL * 1024 * 1024;
    HS_CALL( dalloc(&s->gws1, s->gws_len) );
@@ -1813,7 +1812,7 @@ static int steplen_enqueue(hipsdp_solver* s)
                s->sc + SC_BLK(k, 4)) );
       else
          HS_CALL( hs_lanczos_lmin2(st, B.n, B.W, B.W2, s->par.lanczos_steps, s->sc + SC_BLK(k, 1), s->sc + SC_BLK(k, 4), s->lan_ws,
-               s->lan_ws2, s->lan_epochs, s->lan_sync) );
+               s->lan_ws2, s->lan_rot, s->lan_sync) );
       ++k;
    }
    hs_red_batch_begin(s->stream);
@@ -1985,10 +1984,9 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       s->par.lanczos_steps <<= s->par.settings;          /* medium: twice, stable: four times the Lanczos steps */
       if ( s->lan_sync != NULL )
       {
-         /* round counters of the one-launch Lanczos runs: a solve starts them at zero (a run that gave up leaves its error
-          * word set) */
-         HS_HIP( hipMemsetAsync(s->lan_sync, 0, 4 * sizeof(unsigned long long), s->stream) );
-         s->lan_epochs[0] = s->lan_epochs[1] = 0ULL;
+         /* exchange vectors of the one-launch Lanczos runs: a solve starts from their initial state (a run that gave up
+          * leaves them in no particular one) */
+         HS_CALL( hs_lanczos_sync_reset(s->stream, s->lan_sync, s->lan_rot) );
       }
       if ( s->par.lanczos_steps < 4 ) s->par.lanczos_steps = 4;
       if ( s->par.lanczos_steps > 250 ) s->par.lanczos_steps = 250;
