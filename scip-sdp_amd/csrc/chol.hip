@@ -1305,35 +1305,47 @@ int hs_trsv(hipStream_t s, int n, const double* L, const double* dinv, int nrhs,
  * is bounded: on expiry the error word behind the flags is set and the block leaves without publishing (later blocks then
  * expire too, the launch ends, and the interior-point loop stops on the non-finite step it gets).  The next L block is
  * requested before the flag of the current one is awaited. */
-#define TRSV_SPIN_LIMIT (1 << 20)
+#define TRSV_SPIN_LIMIT (1 << 16)
 
-/* What one block hands to the others - its 64 x NRHS solution entries and its flag - is stored and loaded as relaxed
- * agent-scope atomics (sc1: served at the device's coherence point), and the stores are waited for (vmcnt) before the flag
- * goes up.  A release / acquire pair at agent scope would do, but on this device it writes back and invalidates the L2 of an
- * XCD each time (eight XCDs, one L2 each): that was most of the 5 us a block took. */
+/* What one block hands to the others - its 64 x NRHS solution entries - goes through an exchange vector of its own, stored
+ * and loaded as relaxed agent-scope atomics (sc1: served at the device's coherence point), and the data is its own signal:
+ * the vector is all NaN before the launch, a reader polls each entry it needs until it is a number (one round trip when it
+ * is already there).  [Flags with a release / acquire pair at agent scope write back and invalidate the L2 of an XCD each
+ * time - eight XCDs, one L2 each - and even with coherent stores a flag costs three round trips per block: wait for the
+ * stores, raise the flag, poll it.]  Two exchange vectors alternate with the parity of the launch epoch; every block wipes its
+ * own entries of the other one when it starts (the launch before is over, the next one has not begun).  A solution entry
+ * that is NaN by arithmetic lets the readers wait until their bound and ends the launch as a failure, like a dead block. */
 __device__ __forceinline__ void trsv_publish(double* p, double v)
 {
    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ bool trsv_wait(const int* flag, int epoch, int* err)
+__device__ __forceinline__ double trsv_fetch(const double* p, int* ok)
 {
+   double v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
    int spins = 0;
-   while ( __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch )
+   while ( v != v )
    {
       if ( ++spins > TRSV_SPIN_LIMIT )
       {
-         atomicExch(err, 1);
-         return false;
+         *ok = 0;
+         break;
       }
       __builtin_amdgcn_s_sleep(1);
+      v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
    }
-   return true;
+   return v;
+}
+
+/* layout of the workspace (ints): [0] error word, [8 ...] two exchange vectors of 4 x npad doubles (npad = 64 * blocks) */
+__device__ __forceinline__ double* trsv_xvec(int* ws, int gen, int npad)
+{
+   return reinterpret_cast<double*>(ws + 8) + (long long) gen * 4 * npad;
 }
 
 template<int NRHS>
 __global__ void __launch_bounds__(256) k_trsv_fwd(int n, const double* __restrict__ L, const double* __restrict__ dinv,
-   double* __restrict__ rhs, long long ldr, int* __restrict__ flags, int epoch, int refine)
+   double* __restrict__ rhs, long long ldr, int* __restrict__ ws, int epoch, int refine)
 {
    __shared__ double xs[NRHS][NB];
    __shared__ double x0s[NRHS][NB];
@@ -1344,7 +1356,11 @@ __global__ void __launch_bounds__(256) k_trsv_fwd(int n, const double* __restric
    const long long ld = n;
    const int j0 = b * NB;
    const int nb = (n - j0) < NB ? (n - j0) : NB;
-   int* err = flags + gridDim.x;
+   const int npad = gridDim.x * NB;
+   double* xg = trsv_xvec(ws, epoch & 1, npad);
+   trsv_publish(trsv_xvec(ws, (epoch & 1) ^ 1, npad) + (long long) (tid >> 6) * npad + j0 + (tid & 63), __builtin_nan(""));
+   if ( tid == 0 )
+      ok = 1;
    double acc[NRHS];
 #pragma unroll
    for (int k = 0; k < NRHS; ++k)
@@ -1381,15 +1397,15 @@ __global__ void __launch_bounds__(256) k_trsv_fwd(int n, const double* __restric
          for (int c = 0; c < 16; ++c)
             lnext[c] = lrow[(long long) (cb + 1) * NB + c];
       }
-      if ( tid == 0 )
-         ok = trsv_wait(flags + cb, epoch, err) ? 1 : 0;
+      if ( tid < NB * NRHS )
+         xs[tid / NB][tid % NB] = trsv_fetch(xg + (long long) (tid / NB) * npad + cb * NB + (tid % NB), &ok);
       __syncthreads();
       if ( !ok )
+      {
+         if ( tid == 0 )
+            atomicExch(ws, 1);
          return;
-      if ( tid < NB * NRHS )
-         xs[tid / NB][tid % NB] = __hip_atomic_load(&rhs[(long long) (tid / NB) * ldr + cb * NB + (tid % NB)], __ATOMIC_RELAXED,
-            __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();
+      }
 #pragma unroll
       for (int k = 0; k < NRHS; ++k)
       {
@@ -1429,10 +1445,13 @@ __global__ void __launch_bounds__(256) k_trsv_fwd(int n, const double* __restric
          if ( q == 0 )
             x0s[k][row] = rowok ? sacc : 0.0;
       }
-      else if ( q == 0 && rowok )
-         trsv_publish(&rhs[(long long) k * ldr + j0 + row], sacc);
+      else if ( q == 0 )
+      {
+         if ( rowok )
+            rhs[(long long) k * ldr + j0 + row] = sacc;
+         trsv_publish(xg + (long long) k * npad + j0 + row, rowok ? sacc : 0.0);
+      }
    }
-   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
    __syncthreads();
    if ( refine )
    {
@@ -1466,19 +1485,20 @@ __global__ void __launch_bounds__(256) k_trsv_fwd(int n, const double* __restric
             sacc += dbr[c] * xs[k][16 * q + c];
          sacc += __shfl_xor(sacc, 1, 64);
          sacc += __shfl_xor(sacc, 2, 64);
-         if ( q == 0 && rowok )
-            trsv_publish(&rhs[(long long) k * ldr + j0 + row], x0s[k][row] + sacc);
+         if ( q == 0 )
+         {
+            const double xv = x0s[k][row] + sacc;
+            if ( rowok )
+               rhs[(long long) k * ldr + j0 + row] = xv;
+            trsv_publish(xg + (long long) k * npad + j0 + row, rowok ? xv : 0.0);
+         }
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
    }
-   if ( tid == 0 )
-      __hip_atomic_store(flags + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template<int NRHS>
 __global__ void __launch_bounds__(256) k_trsv_bwd(int n, const double* __restrict__ L, const double* __restrict__ dinv,
-   double* __restrict__ rhs, long long ldr, int* __restrict__ flags, int epoch, int refine)
+   double* __restrict__ rhs, long long ldr, int* __restrict__ ws, int epoch, int refine)
 {
    __shared__ double xs[NRHS][NB];
    __shared__ double x0s[NRHS][NB];
@@ -1491,7 +1511,11 @@ __global__ void __launch_bounds__(256) k_trsv_bwd(int n, const double* __restric
    const long long ld = n;
    const int j0 = b * NB;
    const int nb = (n - j0) < NB ? (n - j0) : NB;
-   int* err = flags + nblk;
+   const int npad = nblk * NB;
+   double* xg = trsv_xvec(ws, epoch & 1, npad);
+   trsv_publish(trsv_xvec(ws, (epoch & 1) ^ 1, npad) + (long long) (tid >> 6) * npad + j0 + (tid & 63), __builtin_nan(""));
+   if ( tid == 0 )
+      ok = 1;
    const bool colok = col < nb;
    double acc[NRHS];
 #pragma unroll
@@ -1526,18 +1550,15 @@ __global__ void __launch_bounds__(256) k_trsv_bwd(int n, const double* __restric
          const int i = 16 * g + c;
          lv[c] = (i < nbc && colok) ? L[(long long) (i0 + i) * ld + j0 + col] : 0.0;
       }
-      if ( tid == 0 )
-         ok = trsv_wait(flags + cb, epoch, err) ? 1 : 0;
+      if ( tid < NB * NRHS )
+         xs[tid / NB][tid % NB] = trsv_fetch(xg + (long long) (tid / NB) * npad + i0 + (tid % NB), &ok);
       __syncthreads();
       if ( !ok )
-         return;
-      if ( tid < NB * NRHS )
       {
-         const int i = tid % NB;
-         xs[tid / NB][i] = (i < nbc) ? __hip_atomic_load(&rhs[(long long) (tid / NB) * ldr + i0 + i], __ATOMIC_RELAXED,
-            __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+         if ( tid == 0 )
+            atomicExch(ws, 1);
+         return;
       }
-      __syncthreads();
 #pragma unroll
       for (int k = 0; k < NRHS; ++k)
       {
@@ -1577,10 +1598,13 @@ __global__ void __launch_bounds__(256) k_trsv_bwd(int n, const double* __restric
       const double v = red[0][k][i] + red[1][k][i] + red[2][k][i] + red[3][k][i];
       if ( refine )
          x0s[k][i] = (i < nb) ? v : 0.0;
-      else if ( i < nb )
-         trsv_publish(&rhs[(long long) k * ldr + j0 + i], v);
+      else
+      {
+         if ( i < nb )
+            rhs[(long long) k * ldr + j0 + i] = v;
+         trsv_publish(xg + (long long) k * npad + j0 + i, (i < nb) ? v : 0.0);
+      }
    }
-   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
    __syncthreads();
    if ( refine )
    {
@@ -1615,20 +1639,29 @@ __global__ void __launch_bounds__(256) k_trsv_bwd(int n, const double* __restric
       if ( tid < NB * NRHS )
       {
          const int k = tid / NB, i = tid % NB;
+         const double xv = x0s[k][i] + (red[0][k][i] + red[1][k][i] + red[2][k][i] + red[3][k][i]);
          if ( i < nb )
-            trsv_publish(&rhs[(long long) k * ldr + j0 + i], x0s[k][i] + (red[0][k][i] + red[1][k][i] + red[2][k][i] + red[3][k][i]));
+            rhs[(long long) k * ldr + j0 + i] = xv;
+         trsv_publish(xg + (long long) k * npad + j0 + i, (i < nb) ? xv : 0.0);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
    }
-   if ( tid == 0 )
-      __hip_atomic_store(flags + b, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-/* number of ints of the flag workspace of hs_trsv_sync for an n x n factor (zero it once after allocation) */
+/* number of ints of the workspace of hs_trsv_sync for an n x n factor: an error word and two exchange vectors (see
+ * trsv_xvec); hs_trsv_sync_init once after allocation (and after a launch that gave up) */
 long long hs_trsv_sync_ws(int n)
 {
-   return (long long) (n + NB - 1) / NB + 8;
+   const long long npad = (long long) ((n + NB - 1) / NB) * NB;
+   return 8 + 2 * (2 * 4 * npad);
+}
+
+int hs_trsv_sync_init(hipStream_t s, int n, int* sync_ws, int* epoch)
+{
+   HS_HIP( hipMemsetAsync(sync_ws, 0xFF, (size_t) hs_trsv_sync_ws(n) * sizeof(int), s) );      /* all NaN */
+   HS_HIP( hipMemsetAsync(sync_ws, 0, 8 * sizeof(int), s) );
+   if ( epoch != NULL )
+      *epoch = 0;
+   return HS_OK;
 }
 
 /* the multi-workgroup solve; sync_ws from hs_trsv_sync_ws, *epoch is advanced by the call (start it at 0) */

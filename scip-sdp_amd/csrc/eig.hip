@@ -459,6 +459,7 @@ __global__ void __launch_bounds__(1024) k_lanczos_fused(int n, int j, int k, lan
  *    j - 1 mod 3 and every workgroup resets its own rows of j + 1 mod 3 to NaN - safe, because whoever has reached round j
  *    has seen everybody's rows of round j - 1, and those were written after their writers' last read of vector j + 1 mod 3.
  *    The run ends with exactly one clean vector (k mod 3): the caller rotates the start of the next run onto it (rot).
+ *    Matrices of several sizes take turns on the same vectors: every run wipes nwipe >= n rows, the longest of them.
  *  - every wait is bounded: on expiry the error word is set, the workgroups leave and the first one reports NaN, which ends
  *    the solve as a numerical failure (a NaN produced by the arithmetic itself ends the same way).
  * The grid is small (n / 16 workgroups per matrix) and co-resident.  Identical arithmetic in identical order: the results are
@@ -466,7 +467,7 @@ __global__ void __launch_bounds__(1024) k_lanczos_fused(int n, int j, int k, lan
 #define LZ_SPIN_LIMIT (1 << 18)
 #define LZ_STRIDE 8192            /* doubles between the exchange vectors (n <= 8192 on this path) */
 
-__global__ void __launch_bounds__(1024) k_lanczos_persist(int n, int k, lanczos_jobs jobs, int rot0, int rot1)
+__global__ void __launch_bounds__(1024) k_lanczos_persist(int n, int k, lanczos_jobs jobs, int rot0, int rot1, int nwipe)
 {
    extern __shared__ __attribute__((aligned(16))) double lz_smem[];
    __shared__ double sh[16];
@@ -486,6 +487,11 @@ __global__ void __launch_bounds__(1024) k_lanczos_persist(int n, int k, lanczos_
    const int rows = (n + G - 1) / G;
    const int r0 = blockIdx.x * rows;
    const int r1 = min(n, r0 + rows);
+   /* the rows this workgroup wipes: its share of the longest vector any run on these exchange vectors has (matrices of several
+    * sizes take turns on them: the clean vector a run leaves behind must be clean for the next one's length) */
+   const int wrows = (nwipe + G - 1) / G;
+   const int w0 = blockIdx.x * wrows;
+   const int w1 = min(nwipe, w0 + wrows);
    double scale = 0.0, meta0 = -1.0;
    if ( tid == 0 )
       okflag = 1;
@@ -516,7 +522,7 @@ __global__ void __launch_bounds__(1024) k_lanczos_persist(int n, int k, lanczos_
             vs[i] = qv;
             qn[i] = qv;
          }
-         for (int r = r0 + tid; r < r1; r += 1024)
+         for (int r = w0 + tid; r < w1; r += 1024)
             __hip_atomic_store(&vnext[r], __builtin_nan(""), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       else
@@ -559,7 +565,7 @@ __global__ void __launch_bounds__(1024) k_lanczos_persist(int n, int k, lanczos_
           * acknowledged before this round's rows go out (vmcnt below): who sees those finds the wiped vector wiped */
          if ( j < k )
          {
-            for (int r = r0 + tid; r < r1; r += 1024)
+            for (int r = w0 + tid; r < w1; r += 1024)
                __hip_atomic_store(&vnext[r], __builtin_nan(""), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
          }
          double aj = 0.0;
@@ -890,7 +896,7 @@ static void lanczos_job_init(lanczos_job* J, int n, int maxsteps, const double* 
 static int lz_no_persist = -1;
 
 int hs_lanczos_lmin2(hipStream_t s, int n, const double* W0, const double* W1, int maxsteps, double* res0, double* res1,
-   double* ws0, double* ws1, int* rot, unsigned long long* dsync)
+   double* ws0, double* ws1, int* rot, unsigned long long* dsync, int nwipe)
 {
    if ( n <= 0 )
       return HS_ERR_ARG;
@@ -932,7 +938,7 @@ int hs_lanczos_lmin2(hipStream_t s, int n, const double* W0, const double* W1, i
       lz_no_persist = (env != NULL && env[0] == '1') ? 1 : 0;
    }
    const size_t lds_persist = (size_t) (k + 2) * (size_t) n * sizeof(double);
-   if ( rot != NULL && dsync != NULL && !lz_no_persist && k >= 3 && k <= 250 && lds_persist <= 120 * 1024 )
+   if ( rot != NULL && dsync != NULL && !lz_no_persist && k >= 3 && k <= 250 && lds_persist <= 120 * 1024 && nwipe <= LZ_STRIDE )
    {
       /* one launch (see k_lanczos_persist); rot[0 / 1]: which of the three exchange vectors of a matrix is the clean one */
       jobs.job[0].sync = dsync;
@@ -943,7 +949,7 @@ int hs_lanczos_lmin2(hipStream_t s, int n, const double* W0, const double* W1, i
          HS_HIP( hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lanczos_persist), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) );
          attr2_set = true;
       }
-      hipLaunchKernelGGL(k_lanczos_persist, dim3(G, nb), dim3(1024), lds_persist, s, n, k, jobs, rot[0], rot[1]);
+      hipLaunchKernelGGL(k_lanczos_persist, dim3(G, nb), dim3(1024), lds_persist, s, n, k, jobs, rot[0], rot[1], nwipe > n ? nwipe : n);
       HS_LAUNCH_CHECK();
       rot[0] = (rot[0] + k) % 3;
       if ( nb == 2 )
@@ -971,7 +977,7 @@ int hs_lmin_scaled_tiny(hipStream_t s, int n, const double* L0, const double* D0
 
 int hs_lanczos_lmin(hipStream_t s, int n, const double* W, int maxsteps, double* res, double* ws)
 {
-   return hs_lanczos_lmin2(s, n, W, NULL, maxsteps, res, NULL, ws, NULL, NULL, NULL);
+   return hs_lanczos_lmin2(s, n, W, NULL, maxsteps, res, NULL, ws, NULL, NULL, NULL, 0);
 }
 
 /* ---------------------------------------------------------------------------------------------------------------- */

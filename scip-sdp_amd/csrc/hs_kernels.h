@@ -142,9 +142,11 @@ int hs_schur_small(hipStream_t s, int m1, int nblk, const int* n, const double* 
 /* mode: 1 forward, 2 backward, 3 both; + 4: every 64-wide diagonal solve x = inv(L_bb) r is corrected once with the factor itself
  * (x += inv(L_bb) (r - L_bb x)), which brings its residual from cond(L_bb) eps |r| down to that of a substitution */
 int hs_trsv(hipStream_t s, int n, const double* L, const double* dinv, int nrhs, double* rhs, long long ldr, int mode);
-/* the same solve with one workgroup per 64-row block (flag hand-off between blocks); sync_ws: hs_trsv_sync_ws(n) ints, zeroed
- * once; *epoch: call counter owned by the caller (start at 0) */
+/* the same solve with one workgroup per 64-row block (the blocks hand their parts of the solution over through exchange
+ * vectors in sync_ws); sync_ws: hs_trsv_sync_ws(n) ints, put into their initial state by hs_trsv_sync_init once after
+ * allocation; *epoch: call counter owned by the caller (hs_trsv_sync_init zeroes it) */
 long long hs_trsv_sync_ws(int n);
+int hs_trsv_sync_init(hipStream_t s, int n, int* sync_ws, int* epoch);
 int hs_trsv_sync(hipStream_t s, int n, const double* L, const double* dinv, int nrhs, double* rhs, long long ldr, int mode,
    int* sync_ws, int* epoch);
 
@@ -162,9 +164,10 @@ int hs_lmin_scaled_tiny(hipStream_t s, int n, const double* L0, const double* D0
    double* res1);
 /* rot, dsync (may be NULL: one launch per Lanczos step): two host integers and hs_lanczos_sync_words() device words owned by
  * the caller, put into their initial state by hs_lanczos_sync_reset (after allocation, and again after a run that reported
- * NaN); with them the whole run is one launch whose workgroups hand the product vector over through those words */
+ * NaN); with them the whole run is one launch whose workgroups hand the product vector over through those words; nwipe: the
+ * largest n of all runs that share these words */
 int hs_lanczos_lmin2(hipStream_t s, int n, const double* W0, const double* W1, int maxsteps, double* res0, double* res1,
-   double* ws0, double* ws1, int* rot, unsigned long long* dsync);
+   double* ws0, double* ws1, int* rot, unsigned long long* dsync, int nwipe);
 long long hs_lanczos_sync_words(void);
 int hs_lanczos_sync_reset(hipStream_t s, unsigned long long* dsync, int* rot);
 

@@ -567,7 +567,7 @@ extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int*
    HS_CALL( dalloc(&s->gws1, s->gws_len) );
    HS_CALL( dalloc(&s->gws2, s->gws_len) );
    HS_CALL( dalloc(&s->trsv_ws, hs_trsv_sync_ws(m)) );
-   HS_HIP( hipMemset(s->trsv_ws, 0, (size_t) hs_trsv_sync_ws(m) * sizeof(int)) );
+   HS_CALL( hs_trsv_sync_init(s->stream, m, s->trsv_ws, &s->trsv_epoch) );
    s->trsv_epoch = 0;
    s->sws.T = s->sws.U = s->sws.K = s->sws.V = NULL;
    HS_HIP( hipMemsetAsync(s->Dext, 0, (size_t) ((long long) q * m1 > 0 ? (long long) q * m1 : 1) * sizeof(double), s->stream) );
@@ -1802,7 +1802,10 @@ static int steplen_enqueue(hipsdp_solver* s)
       HS_CALL( gemm_on(st2, s->gws2, s->gws_len, HS_KC, HS_KC, n, n, n, 1.0, B.T2, n, B.LzInv, n, 0.0, B.W2, n) );
    }
    HS_CALL( join2(s) );
-   /* the X-side and the Z-side eigenvalue of a block run in the same launches (one launch per Lanczos step) */
+   /* the X-side and the Z-side eigenvalue of a block run in the same launch */
+   int nmax_blk = 0;
+   for (auto& B : s->blk)
+      if ( B.n > nmax_blk ) nmax_blk = B.n;
    for (auto& B : s->blk)
    {
       if ( B.n <= 16 )
@@ -1812,7 +1815,7 @@ static int steplen_enqueue(hipsdp_solver* s)
                s->sc + SC_BLK(k, 4)) );
       else
          HS_CALL( hs_lanczos_lmin2(st, B.n, B.W, B.W2, s->par.lanczos_steps, s->sc + SC_BLK(k, 1), s->sc + SC_BLK(k, 4), s->lan_ws,
-               s->lan_ws2, s->lan_rot, s->lan_sync) );
+               s->lan_ws2, s->lan_rot, s->lan_sync, nmax_blk) );
       ++k;
    }
    hs_red_batch_begin(s->stream);
@@ -1988,6 +1991,8 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
           * leaves them in no particular one) */
          HS_CALL( hs_lanczos_sync_reset(s->stream, s->lan_sync, s->lan_rot) );
       }
+      if ( s->trsv_ws != NULL && s->m > 2 * 64 )
+         HS_CALL( hs_trsv_sync_init(s->stream, s->m, s->trsv_ws, &s->trsv_epoch) );      /* likewise the triangular solves' */
       if ( s->par.lanczos_steps < 4 ) s->par.lanczos_steps = 4;
       if ( s->par.lanczos_steps > 250 ) s->par.lanczos_steps = 250;
    }

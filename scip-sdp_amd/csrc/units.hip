@@ -378,7 +378,7 @@ extern "C" int hipsdp_potrs(int device, int n, const double* A, int nrhs, double
    int* dsync = NULL;
    int epoch = 0;
    HS_HIP( hipMalloc((void**) &dsync, (size_t) hs_trsv_sync_ws(n) * sizeof(int)) );
-   HS_HIP( hipMemset(dsync, 0, (size_t) hs_trsv_sync_ws(n) * sizeof(int)) );
+   HS_CALL( hs_trsv_sync_init(0, n, dsync, NULL) );
    int rc = hs_potrf(0, n, dA.p, dD.p, dflag, NULL);
    if ( rc == HS_OK ) rc = hs_trsv_sync(0, n, dA.p, dD.p, nrhs, dR.p, n, 3, dsync, &epoch);
    if ( rc == HS_OK && hipDeviceSynchronize() != hipSuccess ) rc = HS_ERR_HIP;

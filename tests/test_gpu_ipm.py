@@ -110,6 +110,29 @@ def test_multi_block_with_lp_rows_and_bounds(gpu):
     assert ok, det
 
 
+def test_blocks_of_several_sizes_above_64_take_turns_on_the_step_length_kernel(gpu):
+    """Blocks with more than 64 rows get their step lengths from the one-launch Lanczos kernel, whose workgroups hand the
+    product vector over through exchange vectors that all blocks of a solver share (eig.hip): a longer block must not find
+    entries a shorter one left behind.  Three sizes in the order long - short - middle, against the oracle."""
+    rng = np.random.default_rng(11)
+    m = 40
+    blocks = []
+    for n in (150, 70, 101):
+        A = rng.standard_normal((m + 1, n, n)) / np.sqrt(n)
+        A = A + A.transpose(0, 2, 1)
+        A[0] = -np.eye(n) * 3.0 + 0.1 * A[0]
+        blocks.append(A)
+    D = np.concatenate([np.eye(m), -np.eye(m)])
+    c = -2.0 * np.ones(2 * m)
+    core = ipm_ref.CoreProblem(rng.standard_normal(m), blocks, D, c)
+    ref, g = compare(gpu, core)
+    assert ref.status == ipm_ref.STATUS_OPTIMAL
+    assert g["info"].iterations == ref.iterations
+    assert np.max(np.abs(g["y"] - ref.y)) <= 1e-6
+    ok, det = checker.certificate(core, g["y"], g["X"], g["lp"][0], TOL, TOL)
+    assert ok, det
+
+
 def test_device_generator_matches_numpy_stream(gpu):
     n, m = 16, 24
     b, A, ys, Xs, Zs = instances.planted_dense(n, m)
