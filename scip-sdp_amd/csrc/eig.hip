@@ -1278,10 +1278,187 @@ __device__ __forceinline__ double rsqrt_nr(double x)
    return 2.0 * h;
 }
 
-/* n <= 16: smallest eigenvalue only, ONE wavefront (np/2 <= 8 rotation pairs, <= 64 two-sided 2 x 2 items: one per lane),
- * no eigenvectors; res = { lambda_min, 0 (exact: no residual bound), n } like the Lanczos result.  The tournament table is
- * built once; the rotation comes from two reciprocal square roots (no division, no sqrt expansion):
- * with d = a_qq - a_pp, b = 2 a_pq, r = hypot(d, b):  cos^2 = (1 + |d| / r) / 2,  sin = sgn(d) b / (2 r cos). */
+#ifdef EIG_TIMING
+__device__ long long lm_tbuf[8];
+#define LM_T(i) do { if ( threadIdx.x == 0 && blockIdx.x == 0 ) lm_tbuf[i] = wall_clock64(); } while (0)
+extern "C" int hipsdp_debug_lm_timing(long long* out)
+{
+   return hipMemcpyFromSymbol(out, HIP_SYMBOL(lm_tbuf), sizeof(long long) * 8) == hipSuccess ? 0 : 1;
+}
+#else
+#define LM_T(i) do { } while (0)
+#endif
+
+/* lane exchange inside a row of 16 lanes on the data-parallel-primitive path (no LDS crossbar round trip as with __shfl) */
+template<int CTRL>
+__device__ __forceinline__ double lm_dpp(double v)
+{
+   int lo = __double2loint(v), hi = __double2hiint(v);
+   lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+   return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lm_lane(double v, int l)
+{
+   const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+   return __hiloint2double(hi, lo);
+}
+/* sums inside the rows of 16 lanes (every lane of a row gets its row's sum) */
+__device__ __forceinline__ double lm_rowsum(double v)
+{
+   v += lm_dpp<0xB1>(v);              /* quad_perm [1, 0, 3, 2] */
+   v += lm_dpp<0x4E>(v);              /* quad_perm [2, 3, 0, 1] */
+   v += lm_dpp<0x141>(v);             /* row_half_mirror */
+   v += lm_dpp<0x140>(v);             /* row_mirror */
+   return v;
+}
+__device__ __forceinline__ double lm_wsum(double v)
+{
+   v = lm_rowsum(v);
+   return ((lm_lane(v, 0) + lm_lane(v, 16)) + lm_lane(v, 32)) + lm_lane(v, 48);
+}
+/* reciprocal to full precision: v_rcp_f64 and two Newton steps */
+__device__ __forceinline__ double lm_rcp(double t)
+{
+   double r = __builtin_amdgcn_rcp(t);
+   r = fma(fma(-t, r, 1.0), r, r);
+   r = fma(fma(-t, r, 1.0), r, r);
+   return r;
+}
+__device__ __forceinline__ double lm_quad(double x)
+{
+   x += lm_dpp<0xB1>(x);
+   x += lm_dpp<0x4E>(x);
+   return x;
+}
+
+/* smallest eigenvalue of the symmetric n x n matrix in a[][] (n <= 16; destroyed), one wavefront of 64 lanes: Householder
+ * tridiagonalisation in LDS (the DSYTD2 recurrence, lane = (row, quarter of the columns)), then Sturm-count multisection on the
+ * tridiagonal matrix (64 shifts per round, one per lane; reciprocal by v_rcp_f64 + a Newton step).  Exact to rounding, like the
+ * Jacobi diagonalisation it replaces (n = 10: 8 reflectors and about 10 rounds instead of 6 - 8 sweeps of 9 rounds with two
+ * barriers each: 28.7 -> about 8 us per launch, twice per iteration of a B&B-sized problem). */
+__device__ double lmin_sym16(double (*a)[17], int n, double* vv, double* ww, double* dd, double* e2, int lane)
+{
+   const int r = lane >> 2, q = lane & 3;
+   for (int k = 0; k + 1 < n; ++k)
+   {
+      const int len = n - k - 1;                       /* length of x = a[k + 1 .., k] */
+      const double xi = (lane < len) ? a[k + 1 + lane][k] : 0.0;
+      const double x0 = lm_lane(xi, 0);
+      const double s2 = lm_lane(lm_rowsum((lane >= 1) ? xi * xi : 0.0), 0);      /* x sits in the first row of lanes */
+      double beta = x0, scale = 0.0, t = 0.0;
+      if ( s2 > 0.0 )
+      {
+         const double h2 = x0 * x0 + s2;
+         beta = -copysign(h2 * rsqrt_nr(h2), x0);
+         t = (beta - x0) * lm_rcp(beta);
+         scale = lm_rcp(x0 - beta);
+      }
+      if ( lane < len )
+         vv[lane] = (lane == 0) ? 1.0 : xi * scale;
+      if ( lane == 0 )
+      {
+         e2[k] = beta * beta;
+         dd[k] = a[k][k];
+      }
+      __syncthreads();
+      if ( t != 0.0 )
+      {
+         /* p = tau A22 v: row r of A22, quarter q of its columns */
+         double acc = 0.0;
+         if ( r < len )
+            for (int c = q; c < len; c += 4)
+               acc += a[k + 1 + r][k + 1 + c] * vv[c];
+         acc = lm_quad(acc);
+         const double pr = t * acc;
+         const double pv = lm_wsum((q == 0 && r < len) ? pr * vv[r] : 0.0);
+         const double wr = (r < len) ? pr - 0.5 * t * pv * vv[r] : 0.0;
+         if ( q == 0 && r < len )
+            ww[r] = wr;
+         __syncthreads();
+         if ( r < len )
+         {
+            const double vr = vv[r];
+            for (int c = q; c < len; c += 4)
+               a[k + 1 + r][k + 1 + c] -= vr * ww[c] + wr * vv[c];
+         }
+         __syncthreads();
+      }
+   }
+   if ( lane == 0 )
+      dd[n - 1] = a[n - 1][n - 1];
+   __syncthreads();
+   LM_T(2);
+   /* smallest eigenvalue of T(dd, e2) by multisection of a Gershgorin interval; the tridiagonal matrix in registers */
+   double dr[16], er[16];
+#pragma unroll
+   for (int i = 0; i < 16; ++i)
+   {
+      dr[i] = (i < n) ? dd[i] : 0.0;
+      er[i] = (i + 1 < n) ? e2[i] : 0.0;
+   }
+   double sr[16];                                       /* |e_i|: lane i computes one, all read them */
+   {
+      const double ev = (lane < 16) ? er[0] : 0.0;
+      double mine = 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+         mine = (lane == i) ? er[i] : mine;
+      (void) ev;
+      const double sq = (mine > 0.0) ? mine * rsqrt_nr(mine) : 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+         sr[i] = lm_lane(sq, i);
+   }
+   double lo = 1e300, hi = -1e300;
+#pragma unroll
+   for (int i = 0; i < 16; ++i)
+   {
+      if ( i < n )
+      {
+         const double rad = (i > 0 ? sr[i - 1] : 0.0) + sr[i];
+         lo = fmin(lo, dr[i] - rad);
+         hi = fmax(hi, dr[i] + rad);
+      }
+   }
+   const double span0 = fmax(hi - lo, 1e-300);
+   lo -= 1e-12 * span0 + 1e-300;
+   hi += 1e-12 * span0 + 1e-300;
+   const double pivmin = 1e-290;
+   LM_T(3);
+   /* every round narrows the interval 65-fold: 10 rounds take it below the rounding level of its ends */
+   for (int round = 0; round < 10; ++round)
+   {
+      const double x = lo + (hi - lo) * (double) (lane + 1) / 65.0;
+      int cnt = 0;                                     /* eigenvalues below x */
+      double t = dr[0] - x;
+      if ( fabs(t) < pivmin ) t = -pivmin;
+      if ( t < 0.0 ) ++cnt;
+#pragma unroll
+      for (int i = 1; i < 16; ++i)
+      {
+         if ( i < n )
+         {
+            t = dr[i] - x - er[i - 1] * rcp_newton(t);
+            if ( fabs(t) < pivmin ) t = -pivmin;
+            if ( !(fabs(t) < 1e290) ) t = (t < 0.0) ? -1e290 : 1e290;
+            if ( t < 0.0 ) ++cnt;
+         }
+      }
+      const unsigned long long msk = __ballot(cnt >= 1);
+      const int first = msk ? __ffsll((long long) msk) - 1 : 64;      /* first shift with an eigenvalue below it */
+      const double w = (hi - lo) / 65.0;
+      const double nlo = lo + w * (double) first;
+      const double nhi = (first < 64) ? lo + w * (double) (first + 1) : hi;
+      lo = nlo; hi = nhi;
+      if ( hi - lo <= 2e-16 * fmax(fabs(lo), fabs(hi)) || hi - lo <= 1e-16 * span0 )
+         break;
+   }
+   return 0.5 * (lo + hi);
+}
+
+/* n <= 16: smallest eigenvalue only, ONE wavefront, no eigenvectors; res = { lambda_min, 0 (exact: no residual bound), n } like
+ * the Lanczos result.  With L given the matrix is L A L^T (the scaled step), formed here. */
 __global__ void __launch_bounds__(64) k_lmin_tiny(int n, const double* __restrict__ A0, const double* __restrict__ A1,
    double* __restrict__ res0, double* __restrict__ res1, const double* __restrict__ L0, const double* __restrict__ L1)
 {
@@ -1289,11 +1466,9 @@ __global__ void __launch_bounds__(64) k_lmin_tiny(int n, const double* __restric
    const double* __restrict__ Lin = blockIdx.x ? L1 : L0;      /* non-NULL: the matrix is L A L^T (the scaled step) */
    double* __restrict__ res = blockIdx.x ? res1 : res0;
    __shared__ double a[16][17];
-   __shared__ double rc[8], rs[8];
-   __shared__ unsigned char tp[15][8], tq[15][8];
+   __shared__ double vv[16], ww[16], dd[16], e2[16];
    const int tid = threadIdx.x;
-   const int np = (n + 1) & ~1;
-   const int half = np / 2;
+   LM_T(0);
    if ( Lin == NULL )
    {
       for (int e = tid; e < 256; e += 64)
@@ -1349,80 +1524,12 @@ __global__ void __launch_bounds__(64) k_lmin_tiny(int n, const double* __restric
          a[r][c] = 0.5 * (st[r][c] + st[c][r]);
       }
    }
-   for (int e = tid; e < (np - 1) * half; e += 64)
-   {
-      const int r = e / half, k = e - r * half;
-      int p, q;
-      jac_pair(np, r, k, &p, &q);
-      tp[r][k] = (unsigned char) p;
-      tq[r][k] = (unsigned char) q;
-   }
    __syncthreads();
-   const int k1 = tid / half, k2 = tid - k1 * half;
-   const bool item = tid < half * half;
-   for (int sweeps = 0; sweeps < 30 && n > 1; ++sweeps)
-   {
-      double off = 0.0, dg = 0.0;
-      for (int e = tid; e < 256; e += 64)
-      {
-         const int r = e >> 4, c = e & 15;
-         const double v = a[r][c];
-         if ( r == c ) dg += v * v; else off += v * v;
-      }
-      for (int o = 32; o > 0; o >>= 1)
-      {
-         off += __shfl_xor(off, o, 64);
-         dg += __shfl_xor(dg, o, 64);
-      }
-      /* |lambda - a_ii| <= ||off||_F: 1e-13 of the diagonal norm is far inside what a step length needs */
-      if ( !(off > 1e-26 * dg) || !(off > 0.0) )
-         break;
-      for (int r = 0; r < np - 1; ++r)
-      {
-         if ( tid < half )
-         {
-            const int p = tp[r][tid], q = tq[r][tid];
-            double c = 1.0, sn = 0.0;
-            if ( q < n )
-            {
-               const double apq = a[p][q], d = a[q][q] - a[p][p];
-               const double b2 = 2.0 * apq;
-               const double h2 = fma(d, d, b2 * b2);
-               if ( fabs(apq) > 1e-300 && h2 > 1e-280 && h2 < 1e280 && fabs(apq) > 1e-19 * (fabs(a[p][p]) + fabs(a[q][q])) )
-               {
-                  const double ir = rsqrt_nr(h2);
-                  const double x = 0.5 * fma(fabs(d), ir, 1.0);
-                  const double ic = rsqrt_nr(x);
-                  c = x * ic;
-                  sn = (d >= 0.0 ? 0.5 : -0.5) * b2 * ir * ic;
-               }
-            }
-            rc[tid] = c;
-            rs[tid] = sn;
-         }
-         __syncthreads();
-         if ( item )
-         {
-            /* the 2 x 2 items of a round are disjoint: read-modify-write in place.  Rows / columns >= n are the zero
-             * padding of a[][] (np <= 16) and rotate with c = 1, s = 0, so they stay zero */
-            const int p = tp[r][k1], q = tq[r][k1], u = tp[r][k2], v = tq[r][k2];
-            const double c1 = rc[k1], s1 = rs[k1], c2 = rc[k2], s2 = rs[k2];
-            const double apu = a[p][u], apv = a[p][v], aqu = a[q][u], aqv = a[q][v];
-            const double bpu = c1 * apu - s1 * aqu, bqu = s1 * apu + c1 * aqu;
-            const double bpv = c1 * apv - s1 * aqv, bqv = s1 * apv + c1 * aqv;
-            a[p][u] = c2 * bpu - s2 * bpv;
-            a[p][v] = s2 * bpu + c2 * bpv;
-            a[q][u] = c2 * bqu - s2 * bqv;
-            a[q][v] = s2 * bqu + c2 * bqv;
-         }
-         __syncthreads();
-      }
-   }
+   LM_T(1);
+   const double lm = (n > 1) ? lmin_sym16(a, n, vv, ww, dd, e2, tid) : a[0][0];
+   LM_T(4);
    if ( tid == 0 )
    {
-      double lm = a[0][0];
-      for (int j = 1; j < n; ++j)
-         lm = fmin(lm, a[j][j]);
       res[0] = lm;
       res[1] = 0.0;
       res[2] = (double) n;

@@ -36,6 +36,32 @@ int main()
       hs_gemm_args g = {n, n, n, HS_KC, HS_MC, S, n, 0, T, n, n2, W, n, n2, 1.0, 0.0, m1, f, 1, NULL};
       printf("batched flags %7d : %.3f ms\n", f, timeit(g, 5));
    }
+   /* the same two products with B K-contiguous (B given as [N][K]): the <0> instance of the persistent kernel */
+   {
+      hs_gemm_args g = {m1 * n, n, n, HS_KC, HS_KC, A, n, 0, S, n, 0, T, n, 0, 1.0, 0.0, 1, 0, 1, NULL};
+      const double ms = timeit(g, 5);
+      printf("stack   B as [N][K]   : %.3f ms  (%.1f TFLOP/s full)\n", ms, 2.0 * m1 * n * (double) n * n / ms * 1e-9);
+      hs_gemm_args g1 = {m1 * n, n, n, HS_KC, HS_MC, A, n, 0, S, n, 0, T, n, 0, 1.0, 0.0, 1, 0, 1, NULL};
+      const double ms1 = timeit(g1, 5);
+      printf("stack   B as [K][N]   : %.3f ms  (%.1f TFLOP/s full)\n", ms1, 2.0 * m1 * n * (double) n * n / ms1 * 1e-9);
+      hs_gemm_args g2 = {n, n, n, HS_KC, HS_KC, S, n, 0, T, n, n2, W, n, n2, 1.0, 0.0, m1, 0, 1, NULL};
+      const double ms2 = timeit(g2, 5);
+      printf("batched B as [N][K]   : %.3f ms  (%.1f TFLOP/s full)\n", ms2, 2.0 * m1 * n * (double) n * n / ms2 * 1e-9);
+      hs_gemm_args g3 = {n, n, n, HS_KC, HS_MC, S, n, 0, T, n, n2, W, n, n2, 1.0, 0.0, m1, 0, 1, NULL};
+      const double ms3 = timeit(g3, 5);
+      printf("batched B as [K][N]   : %.3f ms  (%.1f TFLOP/s full)\n", ms3, 2.0 * m1 * n * (double) n * n / ms3 * 1e-9);
+      /* K four times as long with the same output: how much of the gap is the short K loop */
+      const int n4 = 2000;
+      double* A4; double* S4;
+      CK(hipMalloc(&A4, (size_t) 125000 * n4 * 8)); CK(hipMalloc(&S4, (size_t) n4 * n * 8));
+      CK(hipMemset(A4, 0, (size_t) 125000 * n4 * 8)); CK(hipMemset(S4, 0, (size_t) n4 * n * 8));
+      hs_gemm_args g4 = {125000, n, n4, HS_KC, HS_MC, A4, n4, 0, S4, n, 0, T, n, 0, 1.0, 0.0, 1, 0, 1, NULL};
+      const double ms4 = timeit(g4, 5);
+      printf("125000 x 500 x 2000, B as [K][N] : %.3f ms  (%.1f TFLOP/s)\n", ms4, 2.0 * 125000.0 * n * n4 / ms4 * 1e-9);
+      hs_gemm_args g5 = {125000, n, n4, HS_KC, HS_KC, A4, n4, 0, S4, n4, 0, T, n, 0, 1.0, 0.0, 1, 0, 1, NULL};
+      const double ms5 = timeit(g5, 5);
+      printf("125000 x 500 x 2000, B as [N][K] : %.3f ms  (%.1f TFLOP/s)\n", ms5, 2.0 * 125000.0 * n * n4 / ms5 * 1e-9);
+   }
    /* batched in the transposed formulation: C_j = T_j^T * S^T  (A = T_j in MC layout, B = S as [N][K]) */
    for (int f : {0, HS_GEMM_REMAP})
    {
