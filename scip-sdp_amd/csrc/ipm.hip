@@ -559,15 +559,19 @@ extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int*
    HS_CALL( dalloc(&s->gemv_ws, s->gemv_ws_len) );
    HS_CALL( dalloc(&s->lan_ws, hs_lanczos_ws(nmax, 256)) );
    HS_CALL( dalloc(&s->lan_ws2, hs_lanczos_ws(nmax, 256)) );
-   if ( s->lan_sync == NULL )
-      HS_HIP( hipMalloc((void**) &s->lan_sync, (size_t) hs_lanczos_sync_words() * sizeof(unsigned long long)) );
-   HS_CALL( hs_lanczos_sync_reset(s->stream, s->lan_sync, s->lan_rot) );
+   if ( nmax > 64 )
+   {
+      if ( s->lan_sync == NULL )
+         HS_HIP( hipMalloc((void**) &s->lan_sync, (size_t) hs_lanczos_sync_words() * sizeof(unsigned long long)) );
+      HS_CALL( hs_lanczos_sync_reset(s->stream, s->lan_sync, s->lan_rot) );
+   }
    s->gws_len = 8LL * nmax * nmax;
    if ( s->gws_len > 8LL * 1024 * 1024 ) s->gws_len = 8LL * 1024 * 1024;
    HS_CALL( dalloc(&s->gws1, s->gws_len) );
    HS_CALL( dalloc(&s->gws2, s->gws_len) );
    HS_CALL( dalloc(&s->trsv_ws, hs_trsv_sync_ws(m)) );
-   HS_CALL( hs_trsv_sync_init(s->stream, m, s->trsv_ws, &s->trsv_epoch) );
+   if ( m > 2 * 64 )
+      HS_CALL( hs_trsv_sync_init(s->stream, m, s->trsv_ws, &s->trsv_epoch) );
    s->trsv_epoch = 0;
    s->sws.T = s->sws.U = s->sws.K = s->sws.V = NULL;
    HS_HIP( hipMemsetAsync(s->Dext, 0, (size_t) ((long long) q * m1 > 0 ? (long long) q * m1 : 1) * sizeof(double), s->stream) );
@@ -1985,7 +1989,10 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       if ( s->par.settings < 0 ) s->par.settings = 0;
       if ( s->par.settings > 2 ) s->par.settings = 2;
       s->par.lanczos_steps <<= s->par.settings;          /* medium: twice, stable: four times the Lanczos steps */
-      if ( s->lan_sync != NULL )
+      bool lan_used = false;                  /* blocks with more than 64 rows take their step lengths from the one-launch Lanczos */
+      for (auto& B : s->blk)
+         if ( B.n > 64 ) lan_used = true;
+      if ( s->lan_sync != NULL && lan_used )
       {
          /* exchange vectors of the one-launch Lanczos runs: a solve starts from their initial state (a run that gave up
           * leaves them in no particular one) */
