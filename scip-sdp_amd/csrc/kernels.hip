@@ -1103,6 +1103,20 @@ __global__ void __launch_bounds__(256) k_gemv_t(int R, long long E, const double
          double s0 = 0.0, s1 = 0.0;
          const double* a = A + e;
          int i = 0;
+         /* eight rows requested before the first is used (16 KB per row and workgroup in flight); same summation order */
+         for (; i + 8 <= R; i += 8)
+         {
+            dbl2 x[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+               x[q] = *reinterpret_cast<const dbl2*>(a + (long long) (i + q) * lda);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+            {
+               const double cq = coef[i + q];
+               s0 += cq * x[q].x; s1 += cq * x[q].y;
+            }
+         }
          for (; i + 4 <= R; i += 4)
          {
             const dbl2 x0 = *reinterpret_cast<const dbl2*>(a + (long long) (i + 0) * lda);
@@ -1165,6 +1179,22 @@ __global__ void __launch_bounds__(256) k_gemv_t3(int R, long long E, const doubl
    double s00 = 0.0, s01 = 0.0, s10 = 0.0, s11 = 0.0, s20 = 0.0, s21 = 0.0;
    const double* a = A + e;
    int i = 0;
+   for (; i + 8 <= R; i += 8)
+   {
+      dbl2 xx[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+         xx[q] = *reinterpret_cast<const dbl2*>(a + (long long) (i + q) * lda);
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+      {
+         const dbl2 x = xx[q];
+         const double a0 = c0[i + q], a1 = c1[i + q], a2 = c2[i + q];
+         s00 += a0 * x.x; s01 += a0 * x.y;
+         s10 += a1 * x.x; s11 += a1 * x.y;
+         s20 += a2 * x.x; s21 += a2 * x.y;
+      }
+   }
    for (; i + 4 <= R; i += 4)
    {
       const dbl2 x0 = *reinterpret_cast<const dbl2*>(a + (long long) (i + 0) * lda);
