@@ -944,17 +944,36 @@ int hs_lanczos_lmin2(hipStream_t s, int n, const double* W0, const double* W1, i
       jobs.job[0].sync = dsync;
       jobs.job[1].sync = (W1 != NULL) ? dsync + 2 + 3LL * LZ_STRIDE : dsync;
       static bool attr2_set = false;
+      static int ncu = 0;
       if ( !attr2_set )
       {
          HS_HIP( hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lanczos_persist), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) );
+         int dev = 0;
+         hipDeviceProp_t prop;
+         if ( hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess )
+            ncu = prop.multiProcessorCount;
          attr2_set = true;
       }
-      hipLaunchKernelGGL(k_lanczos_persist, dim3(G, nb), dim3(1024), lds_persist, s, n, k, jobs, rot[0], rot[1], nwipe > n ? nwipe : n);
-      HS_LAUNCH_CHECK();
-      rot[0] = (rot[0] + k) % 3;
-      if ( nb == 2 )
-         rot[1] = (rot[1] + k) % 3;
-      return HS_OK;
+      /* the workgroups wait for each other: all of them must fit on the device at once (a partitioned or smaller device takes
+       * the launch-per-step form) */
+      static size_t occ_lds = 0;
+      static int occ_per_cu = 0;
+      if ( occ_lds != lds_persist )
+      {
+         if ( hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_per_cu, reinterpret_cast<const void*>(&k_lanczos_persist), 1024, lds_persist) != hipSuccess )
+            occ_per_cu = 0;
+         occ_lds = lds_persist;
+      }
+      const int per_cu = occ_per_cu;
+      if ( (long long) per_cu * ncu >= (long long) G * nb )
+      {
+         hipLaunchKernelGGL(k_lanczos_persist, dim3(G, nb), dim3(1024), lds_persist, s, n, k, jobs, rot[0], rot[1], nwipe > n ? nwipe : n);
+         HS_LAUNCH_CHECK();
+         rot[0] = (rot[0] + k) % 3;
+         if ( nb == 2 )
+            rot[1] = (rot[1] + k) % 3;
+         return HS_OK;
+      }
    }
    for (int j = 0; j <= k; ++j)
    {
