@@ -1674,7 +1674,20 @@ int hs_trsv_sync(hipStream_t s, int n, const double* L, const double* dinv, int 
       return HS_ERR_ARG;
    const int nblk = (n + NB - 1) / NB;
    const int refine = (mode & 4) ? 1 : 0;
-   if ( sync_ws == NULL || epoch == NULL || nblk > 512 || nblk < 3 )
+   /* the blocks wait for each other: all workgroups must fit on the device at once (checked once against its CU count) */
+   static int max_blocks = -1;
+   if ( max_blocks < 0 )
+   {
+      int dev = 0, per_cu = 0;
+      hipDeviceProp_t prop;
+      max_blocks = 0;
+      if ( hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess
+         && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_trsv_fwd<4>), 256, 0) == hipSuccess )
+         max_blocks = per_cu * prop.multiProcessorCount;
+      if ( max_blocks > 512 )
+         max_blocks = 512;
+   }
+   if ( sync_ws == NULL || epoch == NULL || nblk > max_blocks || nblk < 3 )
       return hs_trsv(s, n, L, dinv, nrhs, rhs, ldr, mode);
    if ( mode & 1 )
    {
