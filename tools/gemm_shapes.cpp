@@ -62,6 +62,20 @@ int main()
       const double ms5 = timeit(g5, 5);
       printf("125000 x 500 x 2000, B as [N][K] : %.3f ms  (%.1f TFLOP/s)\n", ms5, 2.0 * 125000.0 * n * n4 / ms5 * 1e-9);
    }
+   /* which property of the Schur shape costs the 10 % against a big square: the ragged fourth column tile, or four column tiles
+    * per row panel (reuse of the streamed operand in L2)? */
+   {
+      struct { int M, N, K; } sh[] = {{500500, 500, 500}, {488704, 512, 512}, {244352, 1024, 512}, {122176, 2048, 512}, {61056, 4096, 512},
+         {8192, 4096, 4096}};
+      double* Bb; CK(hipMalloc(&Bb, (size_t) 4096 * 4096 * 8)); CK(hipMemset(Bb, 0, (size_t) 4096 * 4096 * 8));
+      double* Cb; CK(hipMalloc(&Cb, (size_t) 500500 * 512 * 8));
+      for (auto& q : sh)
+      {
+         hs_gemm_args g = {q.M, q.N, q.K, HS_KC, HS_MC, A, q.K, 0, Bb, q.N, 0, Cb, q.N, 0, 1.0, 0.0, 1, 0, 1, NULL};
+         const double ms = timeit(g, 5);
+         printf("plain %7d x %4d x %4d : %.3f ms  %.1f TFLOP/s\n", q.M, q.N, q.K, ms, 2.0 * q.M * (double) q.N * q.K / ms * 1e-9);
+      }
+   }
    /* batched in the transposed formulation: C_j = T_j^T * S^T  (A = T_j in MC layout, B = S as [N][K]) */
    for (int f : {0, HS_GEMM_REMAP})
    {
