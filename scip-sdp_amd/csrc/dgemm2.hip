@@ -246,6 +246,14 @@ __global__ void __launch_bounds__(256, G2_WGPC) hs_dgemm2_kernel(hs_gemm_args p,
 #pragma unroll
       for (int j = 0; j < 4; ++j)
          acc[i][j] = (v4d2){0.0, 0.0, 0.0, 0.0};
+   /* Which 16-row / 16-column slabs of the tile the wavefront (wm, wn) owns.  Triangular operand: the slabs 2 i + wm and 2 j + wn
+    * (interleaved): inside the diagonal band the nonzero slabs then split evenly between the two wavefronts of a pair, and a
+    * band stage takes as long as its busiest wavefront - with contiguous halves one of them had all the work of the first half
+    * of the band (-2.5 % on the two n^3 products of the assembly).  Otherwise the contiguous halves 4 wm + i, 4 wn + j (the
+    * interleaved form costs the Gram product 5 %). */
+   const bool tri_any = (p.flags & (HS_GEMM_A_LOWTRI | HS_GEMM_B_LOWTRI)) != 0;
+   const int sw = tri_any ? 16 : 64;            /* offset of the wavefront's first slab */
+   const int ss = tri_any ? 2 : 1;              /* slab stride */
 
    producer_settle();
    consumer_settle();
@@ -280,26 +288,31 @@ __global__ void __launch_bounds__(256, G2_WGPC) hs_dgemm2_kernel(hs_gemm_args p,
       for (int ks = 0; ks < G2_BKS / 4; ++ks)
       {
          const int kk = ck + 4 * ks;
-         /* B[k][n] = 0 for k < n: column slab j (columns from cn) is zero when kk + 3 < cn */
+         /* B[k][n] = 0 for k < n: column slab c (columns from n0 + 16 c) is zero when kk + 3 < n0 + 16 c */
          int jlim = 4;
          if ( triB )
          {
-            const int d = kk + 3 - (cit.n0 + wn * 64);
-            jlim = d < 0 ? 0 : min(4, d / 16 + 1);
+            const int d = kk + 3 - cit.n0;
+            const int qd = d >> 4;                       /* last nonzero slab (d >= 0) */
+            jlim = (d < 0 || qd < wn) ? 0 : min(4, ((qd - wn) >> 1) + 1);
          }
-         /* A[m][k] = 0 for k > m: row slab i (rows from rm) is zero when kk > rm + 15 */
+         /* A[m][k] = 0 for k > m: row slab r (rows from m0 + 16 r) is zero when kk > m0 + 16 r + 15 */
          int imin = 0;
          if ( triA )
          {
-            const int e = kk - 15 - (cit.m0 + wm * 64);
-            imin = e <= 0 ? 0 : min(4, (e + 15) / 16);
+            const int e = kk - 15 - cit.m0;
+            if ( e > 0 )
+            {
+               const int g = (e + 15) >> 4;              /* first nonzero slab */
+               imin = g <= wm ? 0 : min(4, (g - wm + 1) >> 1);
+            }
          }
          double fa[4], fb[4];
 #pragma unroll
          for (int i = 0; i < 4; ++i)
          {
-            fa[i] = g2_frag<HS_KC>(sa, wm * 64, i, ks, lane);
-            fb[i] = g2_frag<LB>(sb, wn * 64, i, ks, lane);
+            fa[i] = g2_frag<HS_KC>(sa, wm * sw, ss * i, ks, lane);
+            fb[i] = g2_frag<LB>(sb, wn * sw, ss * i, ks, lane);
          }
 #pragma unroll
          for (int i = 0; i < 4; ++i)
@@ -334,11 +347,11 @@ __global__ void __launch_bounds__(256, G2_WGPC) hs_dgemm2_kernel(hs_gemm_args p,
 #pragma unroll
             for (int r = 0; r < 4; ++r)
             {
-               const int row = cit.m0 + wm * 64 + 16 * i + (lane >> 4) + 4 * r;
+               const int row = cit.m0 + wm * sw + 16 * ss * i + (lane >> 4) + 4 * r;
 #pragma unroll
                for (int j = 0; j < 4; ++j)
                {
-                  const int col = cit.n0 + wn * 64 + 16 * j + (lane & 15);
+                  const int col = cit.n0 + wn * sw + 16 * ss * j + (lane & 15);
                   if ( row < p.M && col < p.N )
                   {
                      double* c = C + (long long) row * ldc + col;
