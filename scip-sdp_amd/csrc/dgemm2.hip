@@ -114,7 +114,7 @@ __device__ __forceinline__ double g2_frag(const double* __restrict__ slot, int w
    }
 }
 
-template<int LB>
+template<int LB, int IL>
 __global__ void __launch_bounds__(256, G2_WGPC) hs_dgemm2_kernel(hs_gemm_args p, int kchunk, long long ntile, long long total, int rotdiv)
 {
    extern __shared__ __attribute__((aligned(1024))) double g2_smem[];
@@ -250,10 +250,10 @@ __global__ void __launch_bounds__(256, G2_WGPC) hs_dgemm2_kernel(hs_gemm_args p,
     * (interleaved): inside the diagonal band the nonzero slabs then split evenly between the two wavefronts of a pair, and a
     * band stage takes as long as its busiest wavefront - with contiguous halves one of them had all the work of the first half
     * of the band (-2.5 % on the two n^3 products of the assembly).  Otherwise the contiguous halves 4 wm + i, 4 wn + j (the
-    * interleaved form costs the Gram product 5 %). */
-   const bool tri_any = (p.flags & (HS_GEMM_A_LOWTRI | HS_GEMM_B_LOWTRI)) != 0;
-   const int sw = tri_any ? 16 : 64;            /* offset of the wavefront's first slab */
-   const int ss = tri_any ? 2 : 1;              /* slab stride */
+    * interleaved form costs the Gram product 5 %: its workgroups lose step with each other, and with that their hits in L2 -
+    * 6.9 instead of 4.7 GB of HBM traffic per call; the same happened with the choice as a run-time value, hence IL). */
+   constexpr int sw = IL ? 16 : 64;             /* offset of the wavefront's first slab */
+   constexpr int ss = IL ? 2 : 1;               /* slab stride */
 
    producer_settle();
    consumer_settle();
@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(256, G2_WGPC) hs_dgemm2_kernel(hs_gemm_args p,
          const int kk = ck + 4 * ks;
          /* B[k][n] = 0 for k < n: column slab c (columns from n0 + 16 c) is zero when kk + 3 < n0 + 16 c */
          int jlim = 4;
-         if ( triB )
+         if ( IL && triB )
          {
             const int d = kk + 3 - cit.n0;
             const int qd = d >> 4;                       /* last nonzero slab (d >= 0) */
@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(256, G2_WGPC) hs_dgemm2_kernel(hs_gemm_args p,
          }
          /* A[m][k] = 0 for k > m: row slab r (rows from m0 + 16 r) is zero when kk > m0 + 16 r + 15 */
          int imin = 0;
-         if ( triA )
+         if ( IL && triA )
          {
             const int e = kk - 15 - cit.m0;
             if ( e > 0 )
@@ -445,26 +445,26 @@ int hs_dgemm2_try(hipStream_t stream, const hs_gemm_args* a, int kchunk)
          rotdiv = (int) (Wx / (tm * tn));
    }
    const size_t smem = (size_t) G2_NS * G2_SLOT * sizeof(double);
-   static bool attr_set[2] = {false, false};
-   if ( a->layB == HS_KC )
+   /* triangular operand: the instance with interleaved slab ownership (IL = 1) */
+   const bool il = (a->flags & (HS_GEMM_A_LOWTRI | HS_GEMM_B_LOWTRI)) != 0;
+   static bool attr_set[4] = {false, false, false, false};
+   const int inst = (a->layB == HS_KC ? 0 : 2) + (il ? 1 : 0);
+   const void* fn = inst == 0 ? reinterpret_cast<const void*>(&hs_dgemm2_kernel<HS_KC, 0>)
+      : inst == 1 ? reinterpret_cast<const void*>(&hs_dgemm2_kernel<HS_KC, 1>)
+      : inst == 2 ? reinterpret_cast<const void*>(&hs_dgemm2_kernel<HS_MC, 0>)
+      : reinterpret_cast<const void*>(&hs_dgemm2_kernel<HS_MC, 1>);
+   if ( !attr_set[inst] )
    {
-      if ( !attr_set[0] )
-      {
-         if ( hipFuncSetAttribute(reinterpret_cast<const void*>(&hs_dgemm2_kernel<HS_KC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem) != hipSuccess )
-            return -HS_ERR_HIP;
-         attr_set[0] = true;
-      }
-      hipLaunchKernelGGL((hs_dgemm2_kernel<HS_KC>), dim3(grid), dim3(256), smem, stream, *a, kchunk, ntile, total, rotdiv);
+      if ( hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem) != hipSuccess )
+         return -HS_ERR_HIP;
+      attr_set[inst] = true;
    }
-   else
+   switch ( inst )
    {
-      if ( !attr_set[1] )
-      {
-         if ( hipFuncSetAttribute(reinterpret_cast<const void*>(&hs_dgemm2_kernel<HS_MC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem) != hipSuccess )
-            return -HS_ERR_HIP;
-         attr_set[1] = true;
-      }
-      hipLaunchKernelGGL((hs_dgemm2_kernel<HS_MC>), dim3(grid), dim3(256), smem, stream, *a, kchunk, ntile, total, rotdiv);
+   case 0: hipLaunchKernelGGL((hs_dgemm2_kernel<HS_KC, 0>), dim3(grid), dim3(256), smem, stream, *a, kchunk, ntile, total, rotdiv); break;
+   case 1: hipLaunchKernelGGL((hs_dgemm2_kernel<HS_KC, 1>), dim3(grid), dim3(256), smem, stream, *a, kchunk, ntile, total, rotdiv); break;
+   case 2: hipLaunchKernelGGL((hs_dgemm2_kernel<HS_MC, 0>), dim3(grid), dim3(256), smem, stream, *a, kchunk, ntile, total, rotdiv); break;
+   default: hipLaunchKernelGGL((hs_dgemm2_kernel<HS_MC, 1>), dim3(grid), dim3(256), smem, stream, *a, kchunk, ntile, total, rotdiv); break;
    }
    if ( hipGetLastError() != hipSuccess )
       return -HS_ERR_HIP;
