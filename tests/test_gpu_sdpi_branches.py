@@ -244,3 +244,32 @@ def test_ladder_at_the_interface_settles_the_hard_nodes_of_example_small(gpu):
     assert all(u in (sdpi_call.FAST, sdpi_call.MEDIUM, sdpi_call.STABLE) for u in used + rused)
     print("example_small: rungs used by the HIP backend %s, by the numpy backend %s" % (used, rused))
     assert abs(nodes - rnodes) <= 2
+
+
+def test_node_without_attained_optimum_converges_on_the_fast_settings_like_the_oracle(gpu):
+    """The node lb = (-10, -10, -10), ub = (0, 1, 10) of example_small: its optimum -8 is not attained (tau -> 0 with linear
+    convergence) and the Schur factor reaches cond(L) = 1e8 on the way.  With the triangular solves as x = inv(L_bb) r the residual
+    of M dy = h - the primal infeasibility a step leaves behind - stalled at 1e-6 and the node needed all three rungs of the
+    ladder; with every diagonal-block solve corrected once by the factor itself (chol.hip hs_trsv mode bit 4, RB_SOLVE,
+    k_solve2_small; DESIGN.md, Robustness) the engine follows the oracle: the fast settings, the same number of iterations, no
+    second backend call."""
+    import ipm_ref
+    import bnb
+    import sdpa_io
+    inst = sdpa_io.read_sdpa(os.path.join(GOLDEN, "instances", "example_small.dat-s"))
+    prob = bnb.instance_to_sdpi(inst)
+    node = sdpi_prepare.SdpiProblem(prob.obj, [-10.0, -10.0, -10.0], [0.0, 1.0, 10.0], prob.blocks, prob.lp, isintegral=prob.isintegral)
+    P = sdpi_prepare.prepare(node)
+    b, blk, D, c, maps = sdpi_prepare.to_core(P)
+    ref = ipm_ref.hsd_solve(ipm_ref.CoreProblem(b, blk, D, c), ipm_ref.Params(gaptol=1e-6, feastol=1e-6))
+    assert ref.status == ipm_ref.STATUS_OPTIMAL
+    s = sdpi_call.SdpiSolver(gpu.lib())
+    for par in (1, 2, 3):
+        assert s.set_real(par, 1e-6) == sdpi_call.SCIP_OKAY
+    rc, _, _ = s.solve(P)
+    assert rc == sdpi_call.SCIP_OKAY and s.flag("IsOptimal")
+    assert s.settings_used() == sdpi_call.FAST and s.sdpcalls() == 1
+    assert abs(s.iterations() - ref.iterations) <= 1, (s.iterations(), ref.iterations)
+    rc, obj, y = s.dual_sol()
+    assert abs(obj + 8.0) <= 1e-4
+    s.free()
