@@ -380,7 +380,8 @@ extern "C" int hipsdp_potrs(int device, int n, const double* A, int nrhs, double
    HS_HIP( hipMalloc((void**) &dsync, (size_t) hs_trsv_sync_ws(n) * sizeof(int)) );
    HS_CALL( hs_trsv_sync_init(0, n, dsync, NULL) );
    int rc = hs_potrf(0, n, dA.p, dD.p, dflag, NULL);
-   if ( rc == HS_OK ) rc = hs_trsv_sync(0, n, dA.p, dD.p, nrhs, dR.p, n, 3, dsync, &epoch);
+   /* mode 7: forward + backward, every diagonal-block solve corrected once with the factor itself, as the engine runs them */
+   if ( rc == HS_OK ) rc = hs_trsv_sync(0, n, dA.p, dD.p, nrhs, dR.p, n, 7, dsync, &epoch);
    if ( rc == HS_OK && hipDeviceSynchronize() != hipSuccess ) rc = HS_ERR_HIP;
    (void) hipFree(dsync);
    if ( rc == HS_OK && hipDeviceSynchronize() != hipSuccess ) rc = HS_ERR_HIP;

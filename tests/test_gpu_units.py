@@ -75,6 +75,27 @@ def test_cholesky_inverse_and_solves(gpu, n):
     assert rel(gpu.potrs(S, r), np.linalg.solve(S, r.T).T) <= 1e-11
 
 
+@pytest.mark.parametrize("n", [40, 64, 130, 300, 1000])
+def test_corrected_solves_on_an_ill_conditioned_factor(gpu, n):
+    """hipsdp_potrs runs the triangular solves as the engine does: block by block through the explicit inverses of the 64 x 64
+    diagonal blocks, each solve corrected once with the factor itself (hs_trsv mode bit 4; the single-workgroup kernel for
+    n <= 128, the multi-workgroup kernels above).  Eigenvalues from 1 down to 1e-12: the residual of M x = b stays at the level
+    LAPACK's substitutions leave.  (Norm-wise this also holds without the correction; what the correction buys shows in the
+    interior-point iteration, tests/test_gpu_sdpi_branches.py::test_node_without_attained_optimum_...)"""
+    import scipy.linalg as sla
+    Q, _ = np.linalg.qr(RNG.standard_normal((n, n)))
+    lam = 10.0 ** (-12.0 * np.arange(n) / max(n - 1, 1))
+    M = (Q * lam) @ Q.T
+    M = 0.5 * (M + M.T)
+    b = M @ RNG.standard_normal((2, n)).T
+    x = gpu.potrs(M, b.T.copy()).T
+    c, low = sla.cho_factor(M, lower=True)
+    xr = sla.cho_solve((c, low), b)
+    res = np.linalg.norm(M @ x - b) / np.linalg.norm(b)
+    res_ref = np.linalg.norm(M @ xr - b) / np.linalg.norm(b)
+    assert res <= 20.0 * res_ref + 1e-15, (res, res_ref)
+
+
 @pytest.mark.parametrize("n", [65, 128, 130, 192, 500, 1000, 1001])
 def test_fused_block_column_cholesky_matches_the_four_launch_form_bitwise(gpu, n):
     """k_potrf_step (one launch per block column: narrow update, diagonal factorization, panel product, mask and the trailing
