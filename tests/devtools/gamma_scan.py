@@ -11,10 +11,10 @@ for n, m in ((500, 1000), (1000, 2000)):
     Xs, Zs, ys = bench.planted_pair(n, m, 20240)
     b = s.gen_planted(n, m, 20240, Xs, Zs, ys)
     opt = float(b @ ys)
-    for g in (0.98, 0.99, 0.995, 0.999):
-        s.solve(gaptol=1e-5, feastol=1e-5, gamma=g)
+    for g, ls in ((0.98, 0), (0.99, 0), (0.995, 0), (0.999, 0), (0.98, 40), (0.999, 40), (0.9999, 40)):
+        s.solve(gaptol=1e-5, feastol=1e-5, gamma=g, lanczos_steps=ls)
         t0 = time.time()
-        info = s.solve(gaptol=1e-5, feastol=1e-5, gamma=g)
+        info = s.solve(gaptol=1e-5, feastol=1e-5, gamma=g, lanczos_steps=ls)
         dt = time.time() - t0
-        print("n %d gamma %.3f: status %d iterations %d %.1f ms objective error %.2e" % (n, g, info.status, info.iterations, 1e3 * dt, abs(info.dobj - opt)), flush=True)
+        print("n %d gamma %.4f lanczos steps %d: status %d iterations %d %.1f ms objective error %.2e" % (n, g, ls, info.status, info.iterations, 1e3 * dt, abs(info.dobj - opt)), flush=True)
     s.close()
