@@ -360,10 +360,6 @@ __global__ void __launch_bounds__(256) hs_splitk_reduce_kernel(int M, int N, int
       const int col = (int) (e - (long long) row * N);
       if ( lowerBT > 0 && (row / lowerBT) * lowerBT + lowerBT - 1 < (col / lowerBT) * lowerBT )
          continue;
-      /* lower tiles asked for: of a diagonal tile the entries above the 16-wide slab diagonal are nobody's result (the persistent
-       * kernel does not form them); every caller mirrors the lower triangle afterwards */
-      if ( lowerBT > 0 && (col >> 4) > (row >> 4) )
-         continue;
       if ( lowerBT < 0 && (col / (-lowerBT)) * (-lowerBT) + (-lowerBT) - 1 < (row / (-lowerBT)) * (-lowerBT) )
          continue;
       double s = 0.0;

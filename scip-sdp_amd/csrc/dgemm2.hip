@@ -226,13 +226,6 @@ __global__ void __launch_bounds__(256, G2_WGPC) hs_dgemm2_kernel(hs_gemm_args p,
    g2_item cit;
    int cleft = 0;                       /* stages left in the consumer's item */
    int ck = 0;                          /* K position of the stage being consumed */
-   /* Diagonal tile of a product whose lower tiles only are asked for (Gram product): its upper right quarter is never read, so
-    * the wavefront that owned it takes half of the lower left quarter instead, and the two diagonal quarters leave out the slab
-    * pairs above the diagonal: 10, 8, 8, 10 slab products per K step instead of 16 each.  The wavefronts keep contiguous
-    * halves (no interleaving: see IL below).  wme, wne: the quarter a wavefront works on; mm: bit 4 i + j set = slab pair
-    * (i, j) of that quarter is formed (and stored). */
-   int wme = wm, wne = wn;
-   unsigned mm = 0xFFFFu;
    auto consumer_settle = [&]()
    {
       while ( !cdone )
@@ -244,22 +237,6 @@ __global__ void __launch_bounds__(256, G2_WGPC) hs_dgemm2_kernel(hs_gemm_args p,
             break;
          cpos += Wx;
          cdone = cpos >= lim;
-      }
-      if constexpr ( !IL )
-      {
-      wme = wm; wne = wn; mm = 0xFFFFu;
-      if ( !cdone && (p.flags & HS_GEMM_LOWER) && cit.m0 == cit.n0 )
-      {
-         if ( wm == wn )
-            mm = 0x1u | (0x3u << 4) | (0x7u << 8) | (0xFu << 12);          /* j <= i */
-         else if ( wm == 0 )
-         {
-            wme = 1; wne = 0;
-            mm = 0xCCCCu;                                                    /* j = 2, 3 of the lower left quarter */
-         }
-         else
-            mm = 0x3333u;                                                    /* j = 0, 1 */
-      }
       }
    };
 
@@ -334,14 +311,14 @@ __global__ void __launch_bounds__(256, G2_WGPC) hs_dgemm2_kernel(hs_gemm_args p,
 #pragma unroll
          for (int i = 0; i < 4; ++i)
          {
-            fa[i] = g2_frag<HS_KC>(sa, (IL ? wm : wme) * sw, ss * i, ks, lane);
-            fb[i] = g2_frag<LB>(sb, (IL ? wn : wne) * sw, ss * i, ks, lane);
+            fa[i] = g2_frag<HS_KC>(sa, wm * sw, ss * i, ks, lane);
+            fb[i] = g2_frag<LB>(sb, wn * sw, ss * i, ks, lane);
          }
 #pragma unroll
          for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-               if ( i >= imin && j < jlim && (IL || ((mm >> (4 * i + j)) & 1u)) )
+               if ( i >= imin && j < jlim )
                   acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
       }
       ck += G2_BKS;
@@ -370,12 +347,12 @@ __global__ void __launch_bounds__(256, G2_WGPC) hs_dgemm2_kernel(hs_gemm_args p,
 #pragma unroll
             for (int r = 0; r < 4; ++r)
             {
-               const int row = cit.m0 + (IL ? wm : wme) * sw + 16 * ss * i + (lane >> 4) + 4 * r;
+               const int row = cit.m0 + wm * sw + 16 * ss * i + (lane >> 4) + 4 * r;
 #pragma unroll
                for (int j = 0; j < 4; ++j)
                {
-                  const int col = cit.n0 + (IL ? wn : wne) * sw + 16 * ss * j + (lane & 15);
-                  if ( row < p.M && col < p.N && (IL || ((mm >> (4 * i + j)) & 1u)) )
+                  const int col = cit.n0 + wn * sw + 16 * ss * j + (lane & 15);
+                  if ( row < p.M && col < p.N )
                   {
                      double* c = C + (long long) row * ldc + col;
                      double v = alpha * acc[i][j][r];

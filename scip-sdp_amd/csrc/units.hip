@@ -66,23 +66,12 @@ __global__ void k_unit_fill(long long n, unsigned long long seed, double* __rest
    }
 }
 
-/* lowerN > 0: row-major matrices with lowerN columns of which only the lower triangle at the granularity of 16 x 16 slabs is a
- * result (lower tiles asked for: the persistent kernel does not form the slab pairs above the diagonal) */
-__global__ void k_unit_maxdiff(long long n, const double* __restrict__ a, const double* __restrict__ b, unsigned long long* __restrict__ ndiff,
-   int lowerN)
+__global__ void k_unit_maxdiff(long long n, const double* __restrict__ a, const double* __restrict__ b, unsigned long long* __restrict__ ndiff)
 {
    unsigned long long cnt = 0;
    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x)
-   {
-      if ( lowerN > 0 )
-      {
-         const long long row = i / lowerN, col = i - row * lowerN;
-         if ( (col >> 4) > (row >> 4) )
-            continue;
-      }
       if ( __double_as_longlong(a[i]) != __double_as_longlong(b[i]) )
          ++cnt;
-   }
    if ( cnt )
       atomicAdd(ndiff, cnt);
 }
@@ -145,8 +134,7 @@ extern "C" int hipsdp_dgemm_selfcheck(int device, int M, int N, int K, int layB,
    unsigned long long hn = 0;
    if ( rc == HS_OK )
    {
-      hipLaunchKernelGGL(k_unit_maxdiff, dim3(1024), dim3(256), 0, 0, nc * batch, dC1.p, dC2.p, dn,
-         ((flags & HS_GEMM_LOWER) && batch == 1) ? N : 0);
+      hipLaunchKernelGGL(k_unit_maxdiff, dim3(1024), dim3(256), 0, 0, nc * batch, dC1.p, dC2.p, dn);
       if ( hipMemcpy(&hn, dn, sizeof(hn), hipMemcpyDeviceToHost) != hipSuccess )
          rc = HS_ERR_HIP;
    }
