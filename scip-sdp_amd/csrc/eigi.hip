@@ -57,6 +57,26 @@ __device__ __forceinline__ double ei_quad(double x)
    return x;
 }
 
+/* reciprocal and reciprocal square root to full precision (v_rcp_f64 / v_rsq_f64 and two Newton steps): the scalars of a
+ * reflector without the division and square-root expansions */
+__device__ __forceinline__ double ei_rcp2(double t)
+{
+   double r = __builtin_amdgcn_rcp(t);
+   r = fma(fma(-t, r, 1.0), r, r);
+   r = fma(fma(-t, r, 1.0), r, r);
+   return r;
+}
+__device__ __forceinline__ double ei_rsqrt(double x)
+{
+   double y = __builtin_amdgcn_rsq(x);
+   double h = 0.5 * y, g = x * y;
+   double r = fma(-h, g, 0.5);
+   g = fma(g, r, g); h = fma(h, r, h);
+   r = fma(-h, g, 0.5);
+   h = fma(h, r, h);
+   return 2.0 * h;
+}
+
 __device__ __forceinline__ double ei_rcp(double t)
 {
    double r = __builtin_amdgcn_rcp(t);
@@ -70,7 +90,7 @@ __global__ void __launch_bounds__(256) k_syevi_small(int n, int ith, int wantvec
    unsigned long long seq, unsigned long long* __restrict__ flag)
 {
    __shared__ double a[EI_N][EI_LD];
-   __shared__ double vv[EI_N], pp[EI_N], ww[EI_N], tau[EI_N], d[EI_N], e[EI_N], e2[EI_N], zz[EI_N];
+   __shared__ double vv[EI_N], pp[EI_N], ww[EI_N], tau[EI_N], d[EI_N], e[EI_N], e2[EI_N], zz[EI_N], xc[EI_N];
    __shared__ double wk[4][EI_N], swp[EI_N];
    __shared__ double sc[4];
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -85,72 +105,111 @@ __global__ void __launch_bounds__(256) k_syevi_small(int n, int ith, int wantvec
    }
    __syncthreads();
 
-   /* ---- tridiagonalisation: Q^T A Q = T, reflector k acts on rows / columns k + 1 .. n - 1.  Two barriers per column: the
-    * reflector and the vector w are computed by EVERY wavefront for itself (64-element reductions; all write the same values to
-    * the same LDS words and read back only what they have written themselves), so only the matrix-vector product and the rank-2
-    * update, which all 256 threads share, are separated by barriers. */
+   /* ---- tridiagonalisation: Q^T A Q = T, reflector k acts on rows / columns k + 1 .. n - 1.  The matrix lives in REGISTERS:
+    * thread (r, q) holds row r, columns q + 4 j (16 values); the vectors v and w of a step are kept in LDS under GLOBAL indices
+    * with zeros at the indices the step does not touch, so that the matrix-vector product and the rank-2 update are straight
+    * 16-term loops without predicates and without LDS traffic for the matrix (the LDS form read and wrote every entry of the
+    * trailing block twice per column: 2.4 us per column at n = 64).  Column k leaves the registers through a select chain
+    * (uniform register index) into xc[]; the reflector and the vector w are computed by EVERY wavefront for itself (64-element
+    * reductions; all write the same values to the same LDS words), two barriers per column.  The reflectors go to the LDS
+    * array a[][] (column k below the subdiagonal) for the back-transformation of an eigenvector. */
+   double ar[16];
+#pragma unroll
+   for (int j = 0; j < 16; ++j)
+      ar[j] = (r < n && q + 4 * j < n) ? a[r][q + 4 * j] : 0.0;
+   if ( tid < EI_N )
+   {
+      vv[tid] = 0.0;                                   /* vg: v under global indices */
+      ww[tid] = 0.0;                                   /* wg */
+   }
+   /* column 0 */
+   {
+      double pick = ar[0];
+      if ( q == 0 )
+         xc[r] = pick;                                 /* the current column (global row index) */
+   }
+   __syncthreads();
    for (int k = 0; k + 1 < n; ++k)
    {
-      const int len = n - k - 1;                       /* length of x = a[k + 1 .., k] */
+      const int len = n - k - 1;                       /* length of x = A[k + 1 .., k] */
       double t;
       {
-         const double xi = (lane < len) ? a[k + 1 + lane][k] : 0.0;
+         const double xi = (lane < len) ? xc[k + 1 + lane] : 0.0;
          const double x0 = ei_lane(xi, 0);
          const double s2 = ei_wsum(lane >= 1 ? xi * xi : 0.0);
          double beta = x0, scale = 0.0;
          t = 0.0;
          if ( s2 > 0.0 )
          {
-            beta = -copysign(sqrt(x0 * x0 + s2), x0);
-            t = (beta - x0) / beta;
-            scale = 1.0 / (x0 - beta);
+            const double h2 = x0 * x0 + s2;
+            beta = -copysign(h2 * ei_rsqrt(h2), x0);
+            t = (beta - x0) * ei_rcp2(beta);
+            scale = ei_rcp2(x0 - beta);
          }
          if ( lane < len )
-            vv[lane] = (lane == 0) ? 1.0 : xi * scale;
+            vv[k + 1 + lane] = (lane == 0) ? 1.0 : xi * scale;
          if ( lane == 0 )
          {
+            vv[k] = 0.0;
+            ww[k] = 0.0;
             tau[k] = t;
             e[k] = beta;
-            d[k] = a[k][k];
+            d[k] = xc[k];
          }
          __builtin_amdgcn_s_waitcnt(0xc07f);             /* lgkmcnt(0): this wavefront's own LDS writes are done */
          __builtin_amdgcn_wave_barrier();
       }
       if ( t != 0.0 )
       {
-         /* p = tau A22 v: row r of A22 (r < len), quarter q of its columns */
+         /* p = tau A v over rows > k (v is zero up to k) */
+         double vq[16];
+#pragma unroll
+         for (int j = 0; j < 16; ++j)
+            vq[j] = vv[q + 4 * j];
          double acc = 0.0;
-         if ( r < len )
-            for (int c = q; c < len; c += 4)
-               acc += a[k + 1 + r][k + 1 + c] * vv[c];
+#pragma unroll
+         for (int j = 0; j < 16; ++j)
+            acc += ar[j] * vq[j];
          acc = ei_quad(acc);
-         if ( r < len && q == 0 )
-            pp[r] = t * acc;
+         if ( q == 0 )
+            pp[r] = (r > k) ? t * acc : 0.0;
          __syncthreads();
          {
-            const double pl = lane < len ? pp[lane] : 0.0, vl = lane < len ? vv[lane] : 0.0;
+            const double pl = lane < len ? pp[k + 1 + lane] : 0.0, vl = lane < len ? vv[k + 1 + lane] : 0.0;
             const double pv = ei_wsum(pl * vl);
             const double al = -0.5 * t * pv;
             if ( lane < len )
-               ww[lane] = pl + al * vl;
+               ww[k + 1 + lane] = pl + al * vl;
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
          }
-         if ( r < len )
          {
             const double vr = vv[r], wr = ww[r];
-            for (int c = q; c < len; c += 4)
-               a[k + 1 + r][k + 1 + c] -= vr * ww[c] + wr * vv[c];
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+               ar[j] -= vr * ww[q + 4 * j] + wr * vq[j];
          }
          /* keep the reflector (v_0 = 1 implied) in the column it annihilated */
          if ( tid < len )
-            a[k + 1 + tid][k] = vv[tid];
+            a[k + 1 + tid][k] = vv[k + 1 + tid];
+      }
+      else
+         __syncthreads();                                /* (t is the same in every wavefront) all have read the column */
+      /* the next column leaves the registers (its owner lanes: q == (k + 1) & 3, register (k + 1) >> 2) */
+      {
+         const int jn = (k + 1) >> 2;
+         double pick = 0.0;
+#pragma unroll
+         for (int j = 0; j < 16; ++j)
+            pick = (j == jn) ? ar[j] : pick;
+         if ( q == ((k + 1) & 3) )
+            xc[r] = pick;
       }
       __syncthreads();
    }
    if ( tid == 0 )
    {
-      d[n - 1] = a[n - 1][n - 1];
+      d[n - 1] = xc[n - 1];
       e[n - 1] = 0.0;
    }
    __syncthreads();
