@@ -1357,7 +1357,9 @@ __global__ void __launch_bounds__(256) k_trsv_fwd(int n, const double* __restric
    const int j0 = b * NB;
    const int nb = (n - j0) < NB ? (n - j0) : NB;
    const int npad = gridDim.x * NB;
-   double* xg = trsv_xvec(ws, epoch & 1, npad);
+   /* blockIdx.y: right-hand side(s) of this chain of workgroups (NRHS each); the chains of a launch do not meet */
+   rhs += (long long) blockIdx.y * NRHS * ldr;
+   double* xg = trsv_xvec(ws, epoch & 1, npad) + (long long) blockIdx.y * NRHS * npad;
    trsv_publish(trsv_xvec(ws, (epoch & 1) ^ 1, npad) + (long long) (tid >> 6) * npad + j0 + (tid & 63), __builtin_nan(""));
    if ( tid == 0 )
       ok = 1;
@@ -1512,7 +1514,8 @@ __global__ void __launch_bounds__(256) k_trsv_bwd(int n, const double* __restric
    const int j0 = b * NB;
    const int nb = (n - j0) < NB ? (n - j0) : NB;
    const int npad = nblk * NB;
-   double* xg = trsv_xvec(ws, epoch & 1, npad);
+   rhs += (long long) blockIdx.y * NRHS * ldr;
+   double* xg = trsv_xvec(ws, epoch & 1, npad) + (long long) blockIdx.y * NRHS * npad;
    trsv_publish(trsv_xvec(ws, (epoch & 1) ^ 1, npad) + (long long) (tid >> 6) * npad + j0 + (tid & 63), __builtin_nan(""));
    if ( tid == 0 )
       ok = 1;
@@ -1682,35 +1685,23 @@ int hs_trsv_sync(hipStream_t s, int n, const double* L, const double* dinv, int 
       hipDeviceProp_t prop;
       max_blocks = 0;
       if ( hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess
-         && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_trsv_fwd<4>), 256, 0) == hipSuccess )
+         && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_trsv_bwd<1>), 256, 0) == hipSuccess )
          max_blocks = per_cu * prop.multiProcessorCount;
-      if ( max_blocks > 512 )
-         max_blocks = 512;
    }
-   if ( sync_ws == NULL || epoch == NULL || nblk > max_blocks || nblk < 3 )
+   if ( sync_ws == NULL || epoch == NULL || nblk > 512 || nblk * nrhs > max_blocks || nblk < 3 )
       return hs_trsv(s, n, L, dinv, nrhs, rhs, ldr, mode);
+   /* one chain of workgroups per right-hand side: the chains run side by side (a block's solve for three right-hand sides in
+    * one workgroup took twice as long as for one) */
    if ( mode & 1 )
    {
       const int e = ++(*epoch);
-      switch ( nrhs )
-      {
-      case 1: hipLaunchKernelGGL((k_trsv_fwd<1>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e, refine); break;
-      case 2: hipLaunchKernelGGL((k_trsv_fwd<2>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e, refine); break;
-      case 3: hipLaunchKernelGGL((k_trsv_fwd<3>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e, refine); break;
-      default: hipLaunchKernelGGL((k_trsv_fwd<4>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e, refine); break;
-      }
+      hipLaunchKernelGGL((k_trsv_fwd<1>), dim3(nblk, nrhs), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e, refine);
       HS_LAUNCH_CHECK();
    }
    if ( mode & 2 )
    {
       const int e = ++(*epoch);
-      switch ( nrhs )
-      {
-      case 1: hipLaunchKernelGGL((k_trsv_bwd<1>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e, refine); break;
-      case 2: hipLaunchKernelGGL((k_trsv_bwd<2>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e, refine); break;
-      case 3: hipLaunchKernelGGL((k_trsv_bwd<3>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e, refine); break;
-      default: hipLaunchKernelGGL((k_trsv_bwd<4>), dim3(nblk), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e, refine); break;
-      }
+      hipLaunchKernelGGL((k_trsv_bwd<1>), dim3(nblk, nrhs), dim3(256), 0, s, n, L, dinv, rhs, ldr, sync_ws, e, refine);
       HS_LAUNCH_CHECK();
    }
    return HS_OK;
