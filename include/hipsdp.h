@@ -83,6 +83,9 @@ typedef struct hipsdp_info
    int    chol_fail;        /* number of step halvings forced by a failed Cholesky */
    int    warm_started;     /* 1: the point given with hipsdp_set_start was interior and has been used */
    int    settings_used;    /* the hipsdp_params.settings this solve ran with */
+   double schur_flops_executed; /* FP64 matrix-core flops the assemblies' GEMM launches were ISSUED (whole tiles over the K ranges
+                                 * actually walked: triangular factors, lower tiles, skipped zero slabs) - what MFMA utilisation is
+                                 * measured against; schur_flops is the algorithmic count */
 } hipsdp_info;
 
 const char* hipsdp_last_error(void);
@@ -224,6 +227,11 @@ int  hipsdp_dgemm(int device, int layA, int layB, int M, int N, int K, double al
  * used_v2 = 1 when the persistent kernel accepts the shape, ndiff = elements of C that differ in any bit (must be 0) */
 int  hipsdp_dgemm_selfcheck(int device, int M, int N, int K, int layB, int batch, int splitk, int flags, double beta,
    int* used_v2, long long* ndiff);
+/* the same with a free alpha and, for reps > 0 and beta = 0, the average milliseconds of one product through the tile kernel alone
+ * (ms_tile) and through the default dispatch (ms_fast).  *used: bit 0 the persistent tile kernel took the product, bit 1 the strip
+ * kernel of the two triangular Schur products (alpha = 1, beta = 0 only) */
+int  hipsdp_dgemm_selfcheck2(int device, int M, int N, int K, int layB, int batch, int splitk, int flags, double alpha, double beta,
+   int reps, int* used, long long* ndiff, double* ms_tile, double* ms_fast);
 /* Schur block Mx[(m1) x (m1)] = tr(A_i X A_j Zinv) for i, j = 0..m1-1 */
 int  hipsdp_schur_dense(int device, int m1, int n, const double* A, const double* X, const double* Zinv, double* Mx,
    double ws_gbytes);

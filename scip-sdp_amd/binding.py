@@ -23,7 +23,7 @@ class Info(C.Structure):
                 ("pinf", C.c_double), ("dinf", C.c_double), ("dabs", C.c_double), ("gap", C.c_double), ("mu", C.c_double),
                 ("tau", C.c_double), ("kappa", C.c_double), ("solve_seconds", C.c_double), ("schur_seconds", C.c_double),
                 ("schur_flops", C.c_double), ("schur_calls", C.c_int), ("chol_fail", C.c_int), ("warm_started", C.c_int),
-                ("settings_used", C.c_int)]
+                ("settings_used", C.c_int), ("schur_flops_executed", C.c_double)]
 
 
 _lib = None
@@ -259,6 +259,17 @@ def dgemm_selfcheck(M, N, K, layB=1, batch=1, splitk=1, flags=0, beta=0.0, devic
     _chk(lib().hipsdp_dgemm_selfcheck(device, M, N, K, layB, batch, splitk, flags, C.c_double(beta), C.byref(used), C.byref(nd)),
          "hipsdp_dgemm_selfcheck")
     return used.value, nd.value
+
+
+def dgemm_selfcheck2(M, N, K, layB=1, batch=1, splitk=1, flags=0, alpha=1.0, beta=0.0, reps=0, device=0):
+    """the tile kernel alone against the default dispatch (persistent tile kernel, strip kernel) on the same device-generated
+    operands -> (used bits: 1 persistent tile kernel, 2 strip kernel; differing elements; ms tile; ms default)"""
+    used = C.c_int(0)
+    nd = C.c_longlong(0)
+    t0, t1 = C.c_double(0.0), C.c_double(0.0)
+    _chk(lib().hipsdp_dgemm_selfcheck2(device, M, N, K, layB, batch, splitk, flags, C.c_double(alpha), C.c_double(beta), reps,
+                                       C.byref(used), C.byref(nd), C.byref(t0), C.byref(t1)), "hipsdp_dgemm_selfcheck2")
+    return used.value, nd.value, t0.value, t1.value
 
 
 def potrf(A, device=0):

@@ -810,13 +810,8 @@ template<int NBK>
 static int launch_potrf_step(hipStream_t s, double* A, long long lda, int n, int kb, int nblk, double* dinv, int* flag,
    const double* diag0, const pd_ext& ext)
 {
-   static bool attr_set = false;
-   if ( !attr_set )
-   {
-      HS_HIP( hipFuncSetAttribute(reinterpret_cast<const void*>(&k_potrf_step<NBK>), hipFuncAttributeMaxDynamicSharedMemorySize,
-            PD_SMEM_BYTES) );
-      attr_set = true;
-   }
+   static hs_attr_mask attr_done;
+   HS_CALL( hs_func_max_lds(reinterpret_cast<const void*>(&k_potrf_step<NBK>), PD_SMEM_BYTES, &attr_done) );
    const int nS = nblk - kb;
    const int t = nblk - kb - 1;
    const int nT = kb > 0 ? t * (t + 1) / 2 : 0;
@@ -832,13 +827,8 @@ static int launch_potrf_diag(hipStream_t s, double* Ajj, long long lda, int nb, 
    pd_ext ext = {NULL, NULL, 0.0, NULL, NULL, NULL, 0, 2, NULL};
    if ( extp != NULL )
       ext = *extp;
-   static bool attr_set = false;
-   if ( !attr_set )
-   {
-      HS_HIP( hipFuncSetAttribute(reinterpret_cast<const void*>(&k_potrf_diag<NBK>), hipFuncAttributeMaxDynamicSharedMemorySize,
-            PD_SMEM_BYTES) );
-      attr_set = true;
-   }
+   static hs_attr_mask attr_done;
+   HS_CALL( hs_func_max_lds(reinterpret_cast<const void*>(&k_potrf_diag<NBK>), PD_SMEM_BYTES, &attr_done) );
    hipLaunchKernelGGL((k_potrf_diag<NBK>), dim3(1), dim3(256), PD_SMEM_BYTES, s, Ajj, lda, nb, j0, dj, flag, diag0, 1e-13, ext);
    HS_LAUNCH_CHECK();
    return HS_OK;
@@ -1404,6 +1394,11 @@ __global__ void __launch_bounds__(256) k_trsv_fwd(int n, const double* __restric
       __syncthreads();
       if ( !ok )
       {
+         /* giving up (a block before this one never published: not co-resident, or a NaN by arithmetic): the block's rows of
+          * the right-hand side(s) become NaN, so the interior-point loop sees a non-finite step and ends the solve as a numerical
+          * failure instead of using a silently wrong dy; the blocks behind this one run into their bound the same way */
+         if ( tid < NB * NRHS && (tid % NB) < nb )
+            rhs[(long long) (tid / NB) * ldr + j0 + (tid % NB)] = __builtin_nan("");
          if ( tid == 0 )
             atomicExch(ws, 1);
          return;
@@ -1558,6 +1553,11 @@ __global__ void __launch_bounds__(256) k_trsv_bwd(int n, const double* __restric
       __syncthreads();
       if ( !ok )
       {
+         /* giving up (a block before this one never published: not co-resident, or a NaN by arithmetic): the block's rows of
+          * the right-hand side(s) become NaN, so the interior-point loop sees a non-finite step and ends the solve as a numerical
+          * failure instead of using a silently wrong dy; the blocks behind this one run into their bound the same way */
+         if ( tid < NB * NRHS && (tid % NB) < nb )
+            rhs[(long long) (tid / NB) * ldr + j0 + (tid % NB)] = __builtin_nan("");
          if ( tid == 0 )
             atomicExch(ws, 1);
          return;
@@ -1678,16 +1678,15 @@ int hs_trsv_sync(hipStream_t s, int n, const double* L, const double* dinv, int 
    const int nblk = (n + NB - 1) / NB;
    const int refine = (mode & 4) ? 1 : 0;
    /* the blocks wait for each other: all workgroups must fit on the device at once (checked once against its CU count) */
-   static int max_blocks = -1;
-   if ( max_blocks < 0 )
+   static int per_cu_cached = -1;               /* occupancy of the kernel: a property of the code object, the same on every gfx950 */
+   if ( per_cu_cached < 0 )
    {
-      int dev = 0, per_cu = 0;
-      hipDeviceProp_t prop;
-      max_blocks = 0;
-      if ( hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess
-         && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_trsv_bwd<1>), 256, 0) == hipSuccess )
-         max_blocks = per_cu * prop.multiProcessorCount;
+      int per_cu = 0;
+      if ( hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_trsv_bwd<1>), 256, 0) != hipSuccess )
+         per_cu = 0;
+      per_cu_cached = per_cu;
    }
+   const int max_blocks = per_cu_cached * hs_device_cus();
    if ( sync_ws == NULL || epoch == NULL || nblk > 512 || nblk * nrhs > max_blocks || nblk < 3 )
       return hs_trsv(s, n, L, dinv, nrhs, rhs, ldr, mode);
    /* one chain of workgroups per right-hand side: the chains run side by side (a block's solve for three right-hand sides in

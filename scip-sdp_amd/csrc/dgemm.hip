@@ -250,6 +250,8 @@ __global__ void __launch_bounds__(256, 2) hs_dgemm_kernel(hs_gemm_args p, int kc
       ks0 = max(ks0, (n0 / HS_BK) * HS_BK);
    if ( p.flags & HS_GEMM_A_LOWTRI )
       kend = min(kend, m0 + BT);
+   if ( p.flags & HS_GEMM_A_UPTRI )
+      ks0 = max(ks0, (m0 / HS_BK) * HS_BK);
    const double* A = p.A + (long long) bz * p.strideA;
    const double* B = p.B + (long long) bz * p.strideB;
    C += (long long) bz * p.strideC;
@@ -376,14 +378,9 @@ __global__ void __launch_bounds__(256) hs_splitk_reduce_kernel(int M, int N, int
 template<int BT, int LA, int LB>
 static int launch_cfg(hipStream_t stream, const hs_gemm_args* a, int kchunk)
 {
-   static bool attr_set = false;
+   static hs_attr_mask attr_done;
    const size_t smem = (size_t) 4 * TileGeo<BT>::SZ * sizeof(double);
-   if ( !attr_set )
-   {
-      HS_HIP( hipFuncSetAttribute(reinterpret_cast<const void*>(&hs_dgemm_kernel<BT, LA, LB>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem) );
-      attr_set = true;
-   }
+   HS_CALL( hs_func_max_lds(reinterpret_cast<const void*>(&hs_dgemm_kernel<BT, LA, LB>), (int) smem, &attr_done) );
    dim3 grid((a->M + BT - 1) / BT, (a->N + BT - 1) / BT, a->splitk > 1 ? a->splitk : a->batch);
    if ( a->flags & (HS_GEMM_XCD | HS_GEMM_REMAP) )
    {
@@ -407,6 +404,96 @@ static int launch_lay(hipStream_t stream, const hs_gemm_args* a, int kchunk)
    if ( a->layA == HS_KC && a->layB == HS_MC ) return launch_cfg<BT, HS_KC, HS_MC>(stream, a, kchunk);
    if ( a->layA == HS_MC && a->layB == HS_KC ) return launch_cfg<BT, HS_MC, HS_KC>(stream, a, kchunk);
    return launch_cfg<BT, HS_MC, HS_MC>(stream, a, kchunk);
+}
+
+static thread_local double g_mfma_flops = 0.0;
+double hs_mfma_flops_total(void) { return g_mfma_flops; }
+void hs_mfma_flops_add(double flops) { g_mfma_flops += flops; }
+
+/* see hs_common.h.  BT: tile edge; kstage: K granularity of the kernel's main loop (a tile's K range is walked in whole stages);
+ * kchunk: slice length of a split-K product; slabskip: the persistent kernel's interleaved-slab instance (dgemm2.hip, IL = 1)
+ * issues only the 16 x 16 x 4 products whose operand slabs are not identically zero - the loop below repeats its predicate. */
+double hs_gemm_executed_flops(const hs_gemm_args* a, int BT, int kstage, int kchunk, int slabskip)
+{
+   const long long tm = (a->M + BT - 1) / BT, tn = (a->N + BT - 1) / BT;
+   const int nsl = a->splitk > 1 ? a->splitk : 1;
+   const double per_k = 2.0 * (double) BT * (double) BT;            /* flops of one K step of a whole tile */
+   const bool triA = (a->flags & HS_GEMM_A_LOWTRI) != 0, triB = (a->flags & HS_GEMM_B_LOWTRI) != 0;
+   auto tile_flops = [&](int m0, int n0) -> double
+   {
+      double f = 0.0;
+      for (int sl = 0; sl < nsl; ++sl)
+      {
+         int ks0 = 0, kend = a->K;
+         if ( a->splitk > 1 )
+         {
+            ks0 = sl * kchunk;
+            kend = ks0 + kchunk < a->K ? ks0 + kchunk : a->K;
+         }
+         if ( triB && ks0 < (n0 / 16) * 16 ) ks0 = (n0 / 16) * 16;
+         if ( triA && kend > m0 + BT ) kend = m0 + BT;
+         if ( (a->flags & HS_GEMM_A_UPTRI) && ks0 < (m0 / 16) * 16 ) ks0 = (m0 / 16) * 16;
+         if ( kend <= ks0 )
+            continue;
+         const int stages = (kend - ks0 + kstage - 1) / kstage;
+         if ( !(slabskip && BT == 128 && kstage == 8 && (triA || triB)) )
+         {
+            f += per_k * (double) stages * kstage;
+            continue;
+         }
+         long long mfma = 0;                                     /* 16 x 16 x 4 products issued, all four wavefronts */
+         for (int st = 0; st < stages; ++st)
+         {
+            const int ck = ks0 + st * kstage;
+            const bool bandB = triB && ck < n0 + BT, bandA = triA && ck + kstage > m0;
+            for (int kk = ck; kk < ck + kstage; kk += 4)
+               for (int wm = 0; wm < 2; ++wm)
+                  for (int wn = 0; wn < 2; ++wn)
+                  {
+                     int jlim = 4, imin = 0;
+                     if ( bandB )
+                     {
+                        const int d = kk + 3 - n0, qd = d >> 4;
+                        jlim = (d < 0 || qd < wn) ? 0 : (((qd - wn) >> 1) + 1 < 4 ? ((qd - wn) >> 1) + 1 : 4);
+                     }
+                     if ( bandA )
+                     {
+                        const int e = kk - 15 - m0;
+                        if ( e > 0 )
+                        {
+                           const int g = (e + 15) >> 4;
+                           imin = g <= wm ? 0 : (((g - wm + 1) >> 1) < 4 ? ((g - wm + 1) >> 1) : 4);
+                        }
+                     }
+                     mfma += (4 - imin) * jlim;
+                  }
+         }
+         f += 2048.0 * (double) mfma;
+      }
+      return f;
+   };
+   double per_entry = 0.0;
+   if ( a->flags & HS_GEMM_LOWER )
+      per_entry = (double) (tm * (tm + 1) / 2) * tile_flops(0, 0);
+   else if ( a->flags & HS_GEMM_UPPER )
+   {
+      long long cnt = 0;
+      for (long long ti = 0; ti < tm; ++ti)
+         for (long long tj = 0; tj < tn; ++tj)
+            if ( (tj + 1) * BT > ti * BT )
+               ++cnt;
+      per_entry = (double) cnt * tile_flops(0, 0);
+   }
+   else
+   {
+      /* the K range depends on the row tile only through A_LOWTRI and on the column tile only through B_LOWTRI */
+      const bool depA = triA || (a->flags & HS_GEMM_A_UPTRI);
+      const long long ni = depA ? tm : 1, nj = triB ? tn : 1;
+      for (long long ti = 0; ti < ni; ++ti)
+         for (long long tj = 0; tj < nj; ++tj)
+            per_entry += tile_flops((int) ti * BT, (int) tj * BT) * (double) (depA ? 1 : tm) * (double) (triB ? 1 : tn);
+   }
+   return per_entry * (double) (a->splitk > 1 ? 1 : a->batch);
 }
 
 int hs_dgemm_pick_splitk(int M, int N, int K, int lowerOnly)
@@ -471,7 +558,11 @@ int hs_dgemm(hipStream_t stream, const hs_gemm_args* a)
       if ( r3 < 0 )
          return -r3;
       if ( r3 == 1 )
+      {
+         /* 32 x 32 tiles, K split over the four wavefronts in steps of 4 */
+         hs_mfma_flops_add(2.0 * (double) (((a->M + 31) / 32) * 32) * (double) (((a->N + 31) / 32) * 32) * (double) (((a->K + 15) / 16) * 16) * (double) a->batch);
          return HS_OK;
+      }
    }
 
    /* tile choice: big tiles once they fill the chip, small tiles otherwise */
@@ -497,6 +588,15 @@ int hs_dgemm(hipStream_t stream, const hs_gemm_args* a)
    }
    a = &eff;
 
+   if ( useBig && a->splitk <= 1 )
+   {
+      /* the two triangular products of the Schur assembly: strip kernel (dgemm4.hip), identical results */
+      const int r4 = hs_dgemm4_try(stream, a);
+      if ( r4 < 0 )
+         return -r4;
+      if ( r4 == 1 )
+         return HS_OK;
+   }
    if ( useBig )
    {
       /* the persistent LDS-DMA kernel (dgemm2.hip) takes the shapes it is eligible for: identical results */
@@ -504,10 +604,18 @@ int hs_dgemm(hipStream_t stream, const hs_gemm_args* a)
       if ( r2 < 0 )
          return -r2;
       if ( r2 == 0 )
+      {
          HS_CALL( launch_lay<128>(stream, a, kchunk) );
+         hs_mfma_flops_add(hs_gemm_executed_flops(a, 128, HS_BK, kchunk, 0));
+      }
+      else
+         hs_mfma_flops_add(hs_gemm_executed_flops(a, 128, 8, kchunk, 1));
    }
    else
+   {
       HS_CALL( launch_lay<64>(stream, a, kchunk) );
+      hs_mfma_flops_add(hs_gemm_executed_flops(a, 64, HS_BK, kchunk, 0));
+   }
 
    if ( a->splitk > 1 )
    {

@@ -71,7 +71,7 @@ __device__ __forceinline__ void g2_decode(const hs_gemm_args& p, long long pos, 
       {
          if ( p.flags & HS_GEMM_B_LOWTRI )
             tj = (int) ((tj + (pos / tn) / rotdiv) % tn);
-         else if ( p.flags & HS_GEMM_A_LOWTRI )
+         else if ( p.flags & (HS_GEMM_A_LOWTRI | HS_GEMM_A_UPTRI) )
             ti = (int) ((ti + bz / rotdiv) % tm);
       }
    }
@@ -88,6 +88,8 @@ __device__ __forceinline__ void g2_decode(const hs_gemm_args& p, long long pos, 
       ks0 = max(ks0, (it->n0 / 16) * 16);
    if ( p.flags & HS_GEMM_A_LOWTRI )
       kend = min(kend, it->m0 + G2_BT);
+   if ( p.flags & HS_GEMM_A_UPTRI )
+      ks0 = max(ks0, (it->m0 / 16) * 16);
    it->ks0 = ks0;
    it->kend = kend > ks0 ? kend : ks0;
 }
@@ -384,7 +386,7 @@ static int g2_taken = 0;
 int hs_dgemm2_enable(int on)
 {
    g2_disabled = on ? 0 : 1;
-   return g2_taken;
+   return __atomic_load_n(&g2_taken, __ATOMIC_RELAXED);
 }
 
 int hs_dgemm2_try(hipStream_t stream, const hs_gemm_args* a, int kchunk)
@@ -441,24 +443,20 @@ int hs_dgemm2_try(hipStream_t stream, const hs_gemm_args* a, int kchunk)
    {
       if ( (a->flags & HS_GEMM_B_LOWTRI) && tn > 1 && (Wx % tn) == 0 )
          rotdiv = (int) (Wx / tn);
-      else if ( (a->flags & HS_GEMM_A_LOWTRI) && tm > 1 && (Wx % (tm * tn)) == 0 )
+      else if ( (a->flags & (HS_GEMM_A_LOWTRI | HS_GEMM_A_UPTRI)) && tm > 1 && (Wx % (tm * tn)) == 0 )
          rotdiv = (int) (Wx / (tm * tn));
    }
    const size_t smem = (size_t) G2_NS * G2_SLOT * sizeof(double);
    /* triangular operand: the instance with interleaved slab ownership (IL = 1) */
    const bool il = (a->flags & (HS_GEMM_A_LOWTRI | HS_GEMM_B_LOWTRI)) != 0;
-   static bool attr_set[4] = {false, false, false, false};
+   static hs_attr_mask attr_done[4];
    const int inst = (a->layB == HS_KC ? 0 : 2) + (il ? 1 : 0);
    const void* fn = inst == 0 ? reinterpret_cast<const void*>(&hs_dgemm2_kernel<HS_KC, 0>)
       : inst == 1 ? reinterpret_cast<const void*>(&hs_dgemm2_kernel<HS_KC, 1>)
       : inst == 2 ? reinterpret_cast<const void*>(&hs_dgemm2_kernel<HS_MC, 0>)
       : reinterpret_cast<const void*>(&hs_dgemm2_kernel<HS_MC, 1>);
-   if ( !attr_set[inst] )
-   {
-      if ( hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem) != hipSuccess )
-         return -HS_ERR_HIP;
-      attr_set[inst] = true;
-   }
+   if ( hs_func_max_lds(fn, (int) smem, &attr_done[inst]) != HS_OK )
+      return -HS_ERR_HIP;
    switch ( inst )
    {
    case 0: hipLaunchKernelGGL((hs_dgemm2_kernel<HS_KC, 0>), dim3(grid), dim3(256), smem, stream, *a, kchunk, ntile, total, rotdiv); break;
@@ -468,6 +466,6 @@ int hs_dgemm2_try(hipStream_t stream, const hs_gemm_args* a, int kchunk)
    }
    if ( hipGetLastError() != hipSuccess )
       return -HS_ERR_HIP;
-   ++g2_taken;
+   (void) __atomic_add_fetch(&g2_taken, 1, __ATOMIC_RELAXED);
    return 1;
 }

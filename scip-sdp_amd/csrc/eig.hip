@@ -866,13 +866,8 @@ int hs_lanczos_scaled_small(hipStream_t s, int n, int maxsteps, const double* L0
       return HS_ERR_ARG;
    int k = maxsteps < n ? maxsteps : n;
    if ( k > LS_MAXK ) k = LS_MAXK;
-   static bool attr_set = false;
-   if ( !attr_set )
-   {
-      HS_HIP( hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lanczos_small), hipFuncAttributeMaxDynamicSharedMemorySize,
-            (2 * 64 * 65 + (LS_MAXK + 1) * 64) * (int) sizeof(double)) );
-      attr_set = true;
-   }
+   static hs_attr_mask attr_done;
+   HS_CALL( hs_func_max_lds(reinterpret_cast<const void*>(&k_lanczos_small), (2 * 64 * 65 + (LS_MAXK + 1) * 64) * (int) sizeof(double), &attr_done) );
    const size_t smem = ((size_t) 2 * n * (n | 1) + (size_t) (k + 1) * n) * sizeof(double);
    hipLaunchKernelGGL(k_lanczos_small, dim3(2), dim3(256), smem, s, n, k, D0, D1, res0, res1, L0, L1);
    HS_LAUNCH_CHECK();
@@ -918,12 +913,8 @@ int hs_lanczos_lmin2(hipStream_t s, int n, const double* W0, const double* W1, i
          HS_CALL( hs_lanczos_lmin_unfused(s, n, W1, maxsteps, res1, ws1) );
       return HS_OK;
    }
-   static bool attr_set = false;
-   if ( !attr_set )
-   {
-      HS_HIP( hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lanczos_fused), hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8) );
-      attr_set = true;
-   }
+   static hs_attr_mask attr_done;
+   HS_CALL( hs_func_max_lds(reinterpret_cast<const void*>(&k_lanczos_fused), 8192 * 8, &attr_done) );
    lanczos_jobs jobs;
    lanczos_job_init(&jobs.job[0], n, maxsteps, W0, res0, ws0);
    if ( W1 != NULL )
@@ -943,21 +934,13 @@ int hs_lanczos_lmin2(hipStream_t s, int n, const double* W0, const double* W1, i
       /* one launch (see k_lanczos_persist); rot[0 / 1]: which of the three exchange vectors of a matrix is the clean one */
       jobs.job[0].sync = dsync;
       jobs.job[1].sync = (W1 != NULL) ? dsync + 2 + 3LL * LZ_STRIDE : dsync;
-      static bool attr2_set = false;
-      static int ncu = 0;
-      if ( !attr2_set )
-      {
-         HS_HIP( hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lanczos_persist), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) );
-         int dev = 0;
-         hipDeviceProp_t prop;
-         if ( hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess )
-            ncu = prop.multiProcessorCount;
-         attr2_set = true;
-      }
+      static hs_attr_mask attr2_done;
+      HS_CALL( hs_func_max_lds(reinterpret_cast<const void*>(&k_lanczos_persist), 120 * 1024, &attr2_done) );
+      const int ncu = hs_device_cus();
       /* the workgroups wait for each other: all of them must fit on the device at once (a partitioned or smaller device takes
        * the launch-per-step form) */
-      static size_t occ_lds = 0;
-      static int occ_per_cu = 0;
+      static thread_local size_t occ_lds = 0;
+      static thread_local int occ_per_cu = 0;
       if ( occ_lds != lds_persist )
       {
          if ( hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_per_cu, reinterpret_cast<const void*>(&k_lanczos_persist), 1024, lds_persist) != hipSuccess )

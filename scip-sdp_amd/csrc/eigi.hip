@@ -362,17 +362,33 @@ __global__ void __launch_bounds__(256) k_syevi_small(int n, int ith, int wantvec
    }
 }
 
-/* per host thread and device: a stream and the pinned, device-mapped staging memory */
+/* per host thread and device: a stream and the pinned, device-mapped staging memory.  The object lives in thread-local storage:
+ * its destructor returns stream and pinned memory when the thread ends. */
+#define EI_OUT_DOUBLES (EI_N * EI_N + EI_N + 8)       /* room for a full decomposition: eigenvalues, eigenvectors, flag word */
 struct ei_ctx
 {
    int device;
    hipStream_t stream;
    double* hin;  double* din;
-   double* hout; double* dout;          /* [0] eigenvalue, [1 .. 64] eigenvector, then the flag word */
+   double* hout; double* dout;          /* one eigenpair: [0] eigenvalue, [1 .. 64] eigenvector, flag word at EI_N + 4 */
    unsigned long long seq;
+   ei_ctx() : device(-1), stream(NULL), hin(NULL), din(NULL), hout(NULL), dout(NULL), seq(0) {}
+   void release()
+   {
+      if ( stream != NULL )
+      {
+         (void) hipSetDevice(device);
+         (void) hipStreamSynchronize(stream);
+         (void) hipStreamDestroy(stream);
+      }
+      if ( hin != NULL ) (void) hipHostFree(hin);
+      if ( hout != NULL ) (void) hipHostFree(hout);
+      device = -1; stream = NULL; hin = din = hout = dout = NULL;
+   }
+   ~ei_ctx() { release(); }
 };
 
-thread_local ei_ctx g_ctx = {-1, NULL, NULL, NULL, NULL, NULL, 0};
+thread_local ei_ctx g_ctx;
 
 int ei_context(int device, ei_ctx** out)
 {
@@ -381,24 +397,25 @@ int ei_context(int device, ei_ctx** out)
       *out = &g_ctx;
       return HS_OK;
    }
-   if ( g_ctx.stream != NULL )
+   g_ctx.release();
+   /* built in locals and committed only when complete: a failure half-way leaves no half-initialised context behind */
+   ei_ctx c;
+   c.device = device;
+   hipError_t e = hipSetDevice(device);
+   if ( e == hipSuccess ) e = hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking);
+   if ( e == hipSuccess ) e = hipHostMalloc((void**) &c.hin, (size_t) EI_N * EI_N * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
+   if ( e == hipSuccess ) e = hipHostMalloc((void**) &c.hout, (size_t) EI_OUT_DOUBLES * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
+   if ( e == hipSuccess ) e = hipHostGetDevicePointer((void**) &c.din, c.hin, 0);
+   if ( e == hipSuccess ) e = hipHostGetDevicePointer((void**) &c.dout, c.hout, 0);
+   if ( e != hipSuccess )
    {
-      (void) hipSetDevice(g_ctx.device);
-      (void) hipStreamSynchronize(g_ctx.stream);
-      (void) hipStreamDestroy(g_ctx.stream);
-      (void) hipHostFree(g_ctx.hin);
-      (void) hipHostFree(g_ctx.hout);
-      g_ctx.stream = NULL; g_ctx.device = -1;
+      hs_record_hip_error(e, "ei_context", __FILE__, __LINE__);
+      return e == hipErrorOutOfMemory ? HS_ERR_NOMEM : HS_ERR_HIP;        /* c's destructor releases what had been created */
    }
-   HS_HIP( hipSetDevice(device) );
-   HS_HIP( hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking) );
-   HS_HIP( hipHostMalloc((void**) &g_ctx.hin, (size_t) EI_N * EI_N * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) );
-   HS_HIP( hipHostMalloc((void**) &g_ctx.hout, (size_t) (EI_N + 8) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) );
-   HS_HIP( hipHostGetDevicePointer((void**) &g_ctx.din, g_ctx.hin, 0) );
-   HS_HIP( hipHostGetDevicePointer((void**) &g_ctx.dout, g_ctx.hout, 0) );
-   memset(g_ctx.hout, 0, (size_t) (EI_N + 8) * sizeof(double));
-   g_ctx.device = device;
+   memset(c.hout, 0, (size_t) EI_OUT_DOUBLES * sizeof(double));
+   g_ctx.device = c.device; g_ctx.stream = c.stream; g_ctx.hin = c.hin; g_ctx.din = c.din; g_ctx.hout = c.hout; g_ctx.dout = c.dout;
    g_ctx.seq = 0;
+   c.device = -1; c.stream = NULL; c.hin = c.hout = NULL;                  /* ownership moved */
    *out = &g_ctx;
    return HS_OK;
 }

@@ -37,6 +37,14 @@
 void hs_record_hip_error(hipError_t e, const char* what, const char* file, int line);
 const char* hs_last_error(void);
 
+/* hipFuncAttributeMaxDynamicSharedMemorySize belongs to the (kernel, device) pair, not to the process: `done` is a per-kernel
+ * mask of the devices the attribute has been set on (static storage of the caller, zero-initialised; devices 0..127).  Safe from
+ * several host threads (each with its own current device). */
+struct hs_attr_mask { unsigned long long bits[2]; };
+int hs_func_max_lds(const void* fn, int bytes, hs_attr_mask* done);
+int hs_func_attr_sets(int device);      /* how many (kernel, device) attributes have been set on that device so far */
+int hs_device_cus(void);                /* compute units of the current device (cached per device) */
+
 /* recycling allocator for device blocks of at most 4 MiB (hs_util.cpp); larger requests go to hipMalloc / hipFree */
 int hs_pool_alloc(void** p, size_t bytes);
 void hs_pool_free(void* p);
@@ -51,6 +59,7 @@ void hs_pool_trim(void);
 #define HS_GEMM_LOWER     1   /* compute only tiles that touch the lower triangle (row >= col) of C */
 #define HS_GEMM_A_LOWTRI  2   /* A[m][k] = 0 for k > m (lower triangular left factor): tiles stop at k = m0 + tile */
 #define HS_GEMM_B_LOWTRI  4   /* B[k][n] = 0 for k < n (lower triangular right factor): tiles start at k = n0 */
+#define HS_GEMM_A_UPTRI 256   /* A[m][k] = 0 for k < m (upper triangular left factor): tiles start at k = m0 */
 #define HS_GEMM_XCD       8   /* split-K only: workgroups that share an XCD (blockIdx % 8) walk the same K range, so the
                                * operand panels are fetched from HBM once per XCD and re-used from its L2 */
 #define HS_GEMM_TILE64  128   /* 64 x 64 tiles whatever the size: for products whose N is a narrow column slice (<= 64 columns) */
@@ -88,10 +97,24 @@ int hs_dgemm(hipStream_t stream, const hs_gemm_args* args);
 int hs_dgemm2_try(hipStream_t stream, const hs_gemm_args* args, int kchunk);
 int hs_dgemm2_enable(int on);
 
+/* strip kernel for the two triangular n^3 products of the Schur assembly (dgemm4.hip): 1 launched, 0 not eligible, < 0 error
+ * (negated code); hs_dgemm tries it before the persistent tile kernel.  hs_dgemm4_enable: test hook, returns the previous mode */
+int hs_dgemm4_try(hipStream_t stream, const hs_gemm_args* args);
+int hs_dgemm4_enable(int on);
+double hs_dgemm4_taken(void);          /* products the strip kernel has taken so far (test hook) */
+
 /* latency-oriented 32 x 32 kernel with the K split inside the workgroup (dgemm3.hip) for products of few tiles: 1 launched,
  * 0 not eligible, < 0 error (negated code); hs_dgemm tries it first for products without split-K */
 int hs_dgemm3_try(hipStream_t stream, const hs_gemm_args* args);
 int hs_dgemm3_enabled(void);
+
+/* FP64 matrix-core flops the GEMM launches of the calling host thread have EXECUTED so far (what the MFMA pipes are issued, as
+ * opposed to the algorithmic count 2 M N K): whole tiles (edge tiles are computed padded), over the K range each tile walks
+ * (triangular operands, split-K slices) rounded up to the kernel's K stage, minus the all-zero 16 x 4 slabs the persistent kernel
+ * skips inside the diagonal band.  The engine reads the difference around a Schur assembly (hipsdp_info.schur_flops_executed). */
+double hs_mfma_flops_total(void);
+void   hs_mfma_flops_add(double flops);
+double hs_gemm_executed_flops(const hs_gemm_args* a, int BT, int kstage, int kchunk, int slabskip);
 
 /* choose a split-K factor for a [M x N x K] product so that at least ~2 waves of workgroups exist */
 int hs_dgemm_pick_splitk(int M, int N, int K, int lowerOnly);

@@ -13,7 +13,8 @@ int hs_copy(hipStream_t s, double* dst, const double* src, long long n);
 int hs_axpy(hipStream_t s, long long n, double a, const double* x, double* y);              /* y += a x */
 int hs_scale_add(hipStream_t s, long long n, double a, const double* x, double b, const double* y, double* out); /* out = a x + b y (y may be NULL) */
 int hs_mirror_lower(hipStream_t s, double* A, int n, long long lda);                        /* A[i][j] = A[j][i] for i < j */
-int hs_symmetrize(hipStream_t s, double* A, int n);                                         /* A = (A + A^T) / 2 */
+int hs_symmetrize(hipStream_t s, double* A, int n);
+int hs_transpose(hipStream_t s, int n, const double* src, double* dst);                     /* dst[i][j] = src[j][i], n x n, dst != src */                                         /* A = (A + A^T) / 2 */
 
 /* out[v * ldo + i] = sum_e A[i * lda + e] * V_v[e],  i < R, e < E, v < nv <= 4 (one pass over A for all nv vectors) */
 int hs_gemv_n(hipStream_t s, int R, long long E, const double* A, long long lda, int nv, const double* const* V,

@@ -15,6 +15,49 @@ const char* hs_last_error(void)
    return hs_errbuf;
 }
 
+/* ---- per-device kernel attributes --------------------------------------------------------------------------------------- */
+#define HS_MAXDEV 128
+static int g_attr_sets[HS_MAXDEV];
+static int g_dev_cus[HS_MAXDEV];
+
+int hs_func_max_lds(const void* fn, int bytes, hs_attr_mask* done)
+{
+   int dev = 0;
+   HS_HIP( hipGetDevice(&dev) );
+   if ( dev < 0 || dev >= HS_MAXDEV )
+      return HS_ERR_ARG;
+   const unsigned long long bit = 1ULL << (dev & 63);
+   if ( __atomic_load_n(&done->bits[dev >> 6], __ATOMIC_ACQUIRE) & bit )
+      return HS_OK;
+   /* two threads on the same device may both get here: setting the attribute twice is harmless */
+   HS_HIP( hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) );
+   if ( !(__atomic_fetch_or(&done->bits[dev >> 6], bit, __ATOMIC_ACQ_REL) & bit) )
+      (void) __atomic_add_fetch(&g_attr_sets[dev], 1, __ATOMIC_RELAXED);
+   return HS_OK;
+}
+
+int hs_func_attr_sets(int device)
+{
+   return (device >= 0 && device < HS_MAXDEV) ? __atomic_load_n(&g_attr_sets[device], __ATOMIC_RELAXED) : -1;
+}
+
+int hs_device_cus(void)
+{
+   int dev = 0;
+   if ( hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= HS_MAXDEV )
+      return 0;
+   int c = __atomic_load_n(&g_dev_cus[dev], __ATOMIC_RELAXED);
+   if ( c <= 0 )
+   {
+      hipDeviceProp_t prop;
+      if ( hipGetDeviceProperties(&prop, dev) != hipSuccess )
+         return 0;
+      c = prop.multiProcessorCount;
+      __atomic_store_n(&g_dev_cus[dev], c, __ATOMIC_RELAXED);
+   }
+   return c;
+}
+
 /* ---- small-block device memory pool ------------------------------------------------------------------------------------
  * A branch-and-bound run re-shapes the engine at every node (other fixings -> other sizes), i.e. ~40 hipMalloc / hipFree
  * pairs per node solve, each tens of microseconds: as much as 15 % of a small node solve.  Blocks of at most 4 MiB are

@@ -273,6 +273,9 @@ static void dfree(void* p) { hs_pool_free(p); }
 
 static void free_problem(hipsdp_solver* s)
 {
+   /* blocks go back to a pool that hands them out again without a device synchronisation: nothing may still be running on them */
+   if ( s->stream != NULL ) (void) hipStreamSynchronize(s->stream);
+   if ( s->stream2 != NULL ) (void) hipStreamSynchronize(s->stream2);
    for (auto& B : s->blk)
    {
       double* ptrs[] = {B.Aown, B.A0sep, B.X, B.Z, B.Rd, B.Lz, B.LzInv, B.Zinv, B.Lx, B.LxInv, B.B, B.H, B.G, B.GZ, B.dXa, B.dZa, B.dX, B.dZ,
@@ -1946,6 +1949,11 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       CommOff off(s, alone);
       rc = solve_impl(s, params, info);
    }
+   if ( rc != HIPSDP_OK )          /* error return inside the iteration: whatever it had queued on either queue must not outlive the call */
+   {
+      (void) hipStreamSynchronize(s->stream);
+      (void) hipStreamSynchronize(s->stream2);
+   }
    if ( s->pc.open >= 0 )          /* an error return inside the iteration: close the roctx range, drop the marks */
    {
       phase_mark(s, -1);
@@ -2471,6 +2479,7 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       phase_mark(s, PH_SCHUR);
       hs_comm_phase(0);
       HS_HIP( hipEventRecord(s->ev0, st) );
+      const double mfma_flops_before = hs_mfma_flops_total();
       bool schur_small = false;
       if ( s->comm == NULL && !s->shardA && !s->schur_mode_rows && !s->schur_mode_forced && K > 0 )
       {
@@ -2565,6 +2574,7 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       HS_CALL( hs_mirror_lower(st, s->Mx, m1, m1) );
       }
       HS_HIP( hipEventRecord(s->ev1, st) );
+      info->schur_flops_executed += hs_mfma_flops_total() - mfma_flops_before;
       hs_comm_phase(2);
       phase_mark(s, PH_MSOLVE);
       bool predH_queued = false, predH_joined = false, split_dz = false;
@@ -2885,6 +2895,11 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
    }
 
    phase_mark(s, -1);
+   /* a break above may leave the Z chain of the abandoned iteration running on the second queue (it is started at the top of an
+    * iteration, before the termination decision): it writes B.Lz / B.LzInv / B.Zinv / B.T2 / gws2, so the solve is over - and
+    * its buffers may be re-shaped, freed or read - only when that queue has drained as well */
+   if ( zchain_queued )
+      HS_CALL( join2(s) );
    HS_HIP( hipStreamSynchronize(st) );
    phase_finish(s);
    s->last_status = status;

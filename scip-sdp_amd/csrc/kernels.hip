@@ -322,6 +322,30 @@ int hs_zero_upper(hipStream_t s, double* A, int n)
    return HS_OK;
 }
 
+/* dst = src^T through 32 x 32 LDS tiles (both sides coalesced) */
+__global__ void __launch_bounds__(256) k_transpose(int n, const double* __restrict__ src, double* __restrict__ dst)
+{
+   __shared__ double tile[32][33];
+   const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+   for (int r = ty; r < 32; r += 8)
+      if ( by + r < n && bx + tx < n )
+         tile[r][tx] = src[(long long) (by + r) * n + bx + tx];
+   __syncthreads();
+   for (int r = ty; r < 32; r += 8)
+      if ( bx + r < n && by + tx < n )
+         dst[(long long) (bx + r) * n + by + tx] = tile[tx][r];
+}
+
+int hs_transpose(hipStream_t s, int n, const double* src, double* dst)
+{
+   if ( n <= 0 ) return HS_OK;
+   const int t = (n + 31) / 32;
+   hipLaunchKernelGGL(k_transpose, dim3(t, t), dim3(256), 0, s, n, src, dst);
+   HS_LAUNCH_CHECK();
+   return HS_OK;
+}
+
 int hs_symmetrize(hipStream_t s, double* A, int n)
 {
    if ( n <= 1 ) return HS_OK;
@@ -386,13 +410,8 @@ int hs_dir_block_small(hipStream_t s, int n, double c, const double* X, const do
 {
    if ( n <= 0 ) return HS_OK;
    if ( n > HS_SMALL_N ) return HS_ERR_ARG;
-   static bool attr_set = false;
-   if ( !attr_set )
-   {
-      HS_HIP( hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dir_block_small), hipFuncAttributeMaxDynamicSharedMemorySize,
-            4 * HS_SMALL_N * (HS_SMALL_N + 1) * (int) sizeof(double)) );
-      attr_set = true;
-   }
+   static hs_attr_mask attr_done;
+   HS_CALL( hs_func_max_lds(reinterpret_cast<const void*>(&k_dir_block_small), 4 * HS_SMALL_N * (HS_SMALL_N + 1) * (int) sizeof(double), &attr_done) );
    hipLaunchKernelGGL(k_dir_block_small, dim3(1), dim3(256), (size_t) 4 * n * (n + 1) * sizeof(double), s, n, c, X, R, E, Zinv, s1, out);
    HS_LAUNCH_CHECK();
    return HS_OK;

@@ -13,6 +13,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstring>
+#include <cstdlib>
 #include <cstdio>
 #include <ctime>
 #include <new>
@@ -336,6 +337,40 @@ static unsigned long long job_nonce(void)
       for (const char* p = k; *p; ++p) h = (h ^ (unsigned char) *p) * 1099511628211ULL;
       if ( h == 0 ) h = 1;
       break;
+   }
+   if ( h == 0 )
+   {
+      /* plain HIPSDP_WORLD / HIPSDP_RANK launches (mpirun, a shell loop): the ranks of one job are children of one launcher, so
+       * (parent pid, parent start time) is a value they share and a crashed earlier job does not.  Ranks without a common
+       * parent (each started by hand, parent = init) get 0 and must set HIPSDP_JOB_ID themselves. */
+      const long ppid = (long) getppid();
+      if ( ppid > 1 )
+      {
+         unsigned long long start = 0;
+         char path[64], buf[1024];
+         snprintf(path, sizeof(path), "/proc/%ld/stat", ppid);
+         FILE* f = fopen(path, "r");
+         if ( f != NULL )
+         {
+            const size_t got = fread(buf, 1, sizeof(buf) - 1, f);
+            fclose(f);
+            buf[got] = 0;
+            const char* q = strrchr(buf, ')');             /* the command name may contain blanks: fields are counted behind it */
+            int field = 2;
+            while ( q != NULL && *q != 0 && field < 22 )
+            {
+               q = strchr(q + 1, ' ');
+               ++field;
+            }
+            if ( q != NULL )
+               start = strtoull(q + 1, NULL, 10);
+         }
+         h = 1469598103934665603ULL;
+         h = (h ^ (unsigned long long) ppid) * 1099511628211ULL;
+         h = (h ^ start) * 1099511628211ULL;
+         h = (h ^ 0x70706964ULL) * 1099511628211ULL;
+         if ( h == 0 ) h = 1;
+      }
    }
    return h;
 }

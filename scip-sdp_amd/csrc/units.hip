@@ -90,11 +90,23 @@ __global__ void k_unit_tri(int rows, int cols, long long stride, int batch, doub
    }
 }
 
+/* X[r][c] = 0 for c < r (upper triangular left factor) */
+__global__ void k_unit_tri_upper(int rows, int cols, double* __restrict__ x)
+{
+   const long long per = (long long) rows * cols;
+   for (long long e = (long long) blockIdx.x * blockDim.x + threadIdx.x; e < per; e += (long long) gridDim.x * blockDim.x)
+   {
+      const int r = (int) (e / cols), c = (int) (e - (long long) r * cols);
+      if ( c < r )
+         x[e] = 0.0;
+   }
+}
+
 /* The same product through both GEMM kernels (dgemm.hip, dgemm2.hip) on device-generated operands: the results must agree
  * bit for bit.  A is K-contiguous; layB, batch, splitk and flags as in hs_gemm_args (C packed, ldc = N).  used_v2 = 1 when
  * the persistent kernel accepted the shape; ndiff = number of differing elements of C (over all batch entries). */
-extern "C" int hipsdp_dgemm_selfcheck(int device, int M, int N, int K, int layB, int batch, int splitk, int flags, double beta,
-   int* used_v2, long long* ndiff)
+static int dgemm_selfcheck_impl(int device, int M, int N, int K, int layB, int batch, int splitk, int flags, double alpha, double beta,
+   int reps, int* used, long long* ndiff, double* ms_tile, double* ms_fast)
 {
    HS_CALL( pick_device(device) );
    if ( M <= 0 || N <= 0 || K <= 0 || batch < 1 )
@@ -115,13 +127,44 @@ extern "C" int hipsdp_dgemm_selfcheck(int device, int M, int N, int K, int layB,
       hipLaunchKernelGGL(k_unit_tri, dim3(1024), dim3(256), 0, 0, M, K, 0LL, 1, dA.p);
    if ( (flags & HS_GEMM_B_LOWTRI) && layB == HS_MC )
       hipLaunchKernelGGL(k_unit_tri, dim3(1024), dim3(256), 0, 0, K, N, nb, batch, dB.p);
+   if ( flags & HS_GEMM_A_UPTRI )
+      hipLaunchKernelGGL(k_unit_tri_upper, dim3(1024), dim3(256), 0, 0, M, K, dA.p);
    HS_HIP( hipMemcpy(dC2.p, dC1.p, (size_t) (nc * batch) * sizeof(double), hipMemcpyDeviceToDevice) );
-   hs_gemm_args g = {M, N, K, HS_KC, layB, dA.p, K, 0, dB.p, layB == HS_KC ? (long long) K : (long long) N, sB, dC1.p, N, nc, 1.25, beta,
+   hs_gemm_args g = {M, N, K, HS_KC, layB, dA.p, K, 0, dB.p, layB == HS_KC ? (long long) K : (long long) N, sB, dC1.p, N, nc, alpha, beta,
       batch, flags, splitk, dW.p};
+   hipEvent_t e0 = NULL, e1 = NULL;
+   if ( reps > 0 && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) )
+      return HS_ERR_HIP;
+   auto timed = [&](double* ms) -> int
+   {
+      /* beta = 0 only (the product is repeated on the same C) */
+      if ( reps <= 0 || ms == NULL || beta != 0.0 )
+         return HS_OK;
+      int rc = HS_OK;
+      for (int w = 0; w < 2 && rc == HS_OK; ++w)
+         rc = hs_dgemm(0, &g);
+      (void) hipEventRecord(e0, 0);
+      for (int r = 0; r < reps && rc == HS_OK; ++r)
+         rc = hs_dgemm(0, &g);
+      (void) hipEventRecord(e1, 0);
+      if ( rc == HS_OK && hipEventSynchronize(e1) != hipSuccess )
+         rc = HS_ERR_HIP;
+      float t = 0.f;
+      if ( rc == HS_OK && hipEventElapsedTime(&t, e0, e1) != hipSuccess )
+         rc = HS_ERR_HIP;
+      *ms = (double) t / reps;
+      return rc;
+   };
    int rc = HS_OK;
+   /* reference: the one-tile-per-workgroup kernel (dgemm.hip) alone */
    hs_dgemm2_enable(0);
+   const int g4before = hs_dgemm4_enable(0);
    rc = hs_dgemm(0, &g);
+   if ( rc == HS_OK )
+      rc = timed(ms_tile);
    const int before = hs_dgemm2_enable(1);
+   (void) hs_dgemm4_enable(g4before != 0);          /* -1 (environment not read yet) and 1: on */
+   const double f4before = hs_dgemm4_taken();
    g.C = dC2.p;
    /* the second run must not inherit the slabs of the first: a slice one kernel never writes would go unnoticed */
    if ( splitk > 1 )
@@ -129,6 +172,9 @@ extern "C" int hipsdp_dgemm_selfcheck(int device, int M, int N, int K, int layB,
    if ( rc == HS_OK )
       rc = hs_dgemm(0, &g);
    const int after = hs_dgemm2_enable(1);
+   const double f4after = hs_dgemm4_taken();
+   if ( rc == HS_OK )
+      rc = timed(ms_fast);
    if ( rc == HS_OK && hipDeviceSynchronize() != hipSuccess )
       rc = HS_ERR_HIP;
    unsigned long long hn = 0;
@@ -139,10 +185,30 @@ extern "C" int hipsdp_dgemm_selfcheck(int device, int M, int N, int K, int layB,
          rc = HS_ERR_HIP;
    }
    (void) hipFree(dn);
+   if ( e0 != NULL ) (void) hipEventDestroy(e0);
+   if ( e1 != NULL ) (void) hipEventDestroy(e1);
    HS_CALL( rc );
-   *used_v2 = after - before;
+   *used = (after - before > 0 ? 1 : 0) | (f4after > f4before ? 2 : 0);
    *ndiff = (long long) hn;
    return HIPSDP_OK;
+}
+
+extern "C" int hipsdp_dgemm_selfcheck(int device, int M, int N, int K, int layB, int batch, int splitk, int flags, double beta,
+   int* used_v2, long long* ndiff)
+{
+   int used = 0;
+   HS_CALL( dgemm_selfcheck_impl(device, M, N, K, layB, batch, splitk, flags, 1.25, beta, 0, &used, ndiff, NULL, NULL) );
+   *used_v2 = used & 1;
+   return HIPSDP_OK;
+}
+
+/* the same with a free alpha (the strip kernel of dgemm4.hip takes alpha = 1, beta = 0 only) and, for reps > 0 and beta = 0, the
+ * average time of one product through the tile kernel alone (ms_tile) and through the default dispatch (ms_fast).
+ * *used: bit 0 the persistent tile kernel (dgemm2.hip) took it, bit 1 the strip kernel (dgemm4.hip) */
+extern "C" int hipsdp_dgemm_selfcheck2(int device, int M, int N, int K, int layB, int batch, int splitk, int flags, double alpha, double beta,
+   int reps, int* used, long long* ndiff, double* ms_tile, double* ms_fast)
+{
+   return dgemm_selfcheck_impl(device, M, N, K, layB, batch, splitk, flags, alpha, beta, reps, used, ndiff, ms_tile, ms_fast);
 }
 
 extern "C" int hipsdp_schur_dense(int device, int m1, int n, const double* A, const double* X, const double* Zinv, double* Mx,

@@ -129,6 +129,13 @@ struct SCIP_SDPiSolver
    int                   masternvars;
    int                   masternblocks;
    int                   masternnz;
+   /* the problem whose master copy did NOT fit beside the engine's storage (HIPSDP_ERR_NOMEM): while the caller's arrays keep this
+    * fingerprint the multi-GB attempt is not repeated at every node */
+   SCIP_Bool             masternofit;
+   unsigned long long    nofithash;
+   int                   nofitnvars;
+   int                   nofitnblocks;
+   int                   nofitnnz;
 };
 
 /* ---------------------------------------------------------------------------------------------------------------------- */
@@ -633,6 +640,8 @@ static SCIP_RETCODE loadBlocks(SCIP_SDPISOLVER* s, int nvars, int nsdpblocks, co
    tfp0 = clock();
    fp = sdpFingerprint(nvars, nsdpblocks, sdpblocksizes, sdpnblockvars, sdpnnonz, sdpnblockvarnonz, sdpvar, sdprow, sdpcol, sdpval);
    tfp1 = clock();
+   if ( usemaster && s->masternofit && s->nofithash == fp && s->nofitnvars == nvars && s->nofitnblocks == nsdpblocks && s->nofitnnz == sdpnnonz )
+      usemaster = FALSE;
    if ( usemaster && (! usecache || ! s->mastervalid || s->masterhash != fp || s->masternvars != nvars || s->masternblocks != nsdpblocks
          || s->masternnz != sdpnnonz) )
    {
@@ -649,6 +658,11 @@ static SCIP_RETCODE loadBlocks(SCIP_SDPISOLVER* s, int nvars, int nsdpblocks, co
          /* the master copy does not fit beside the engine's storage: drop it and load this node's blocks directly */
          (void) hipsdp_master_define(s->engine, 0, 0, NULL, NULL);
          usemaster = FALSE;
+         s->masternofit = TRUE;
+         s->nofithash = fp;
+         s->nofitnvars = nvars;
+         s->nofitnblocks = nsdpblocks;
+         s->nofitnnz = sdpnnonz;
          if ( s->sdpinfo )
             printf("hipsdp: no room for the device-resident master copy, loading the node's blocks directly\n");
       }

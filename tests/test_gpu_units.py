@@ -275,6 +275,50 @@ def test_persistent_gemm_matches_tile_gemm_bitwise(gpu, M, N, K, layB, batch, sp
     assert ndiff == 0
 
 
+GEMM_A_UPTRI = 256
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,batch,flags,layB,expect_strip", [
+    (500, 101, GEMM_A_LOWTRI | GEMM_REMAP, 1, 1),       # W_j = G T_j of the Schur assembly: 8 strips of 64 rows per matrix, ragged last strip and slab
+    (500, 101, GEMM_A_LOWTRI | GEMM_REMAP, 0, 1),       # the same with T_j given K contiguous (transposed storage)
+    (500, 101, GEMM_A_UPTRI | GEMM_REMAP, 1, 1),        # T_j^T = R^T A_j: the K range of a strip starts at its first row
+    (500, 101, GEMM_A_UPTRI | GEMM_REMAP, 0, 1),
+    (1000, 40, GEMM_A_LOWTRI | GEMM_REMAP, 1, 1),       # two column tiles of 512 (the second 488 wide)
+    (1000, 40, GEMM_A_UPTRI | GEMM_REMAP, 0, 1),
+    (362, 160, GEMM_A_LOWTRI | GEMM_REMAP, 1, 1),       # 23 column slabs: the wavefronts own 6, 6, 6, 5 of them
+    (362, 160, GEMM_A_UPTRI | GEMM_REMAP, 1, 1),
+    (514, 70, GEMM_A_LOWTRI | GEMM_REMAP, 1, 0),        # 514 columns would fill half of the second strip: not eligible
+    (70, 600, GEMM_A_UPTRI | GEMM_REMAP, 1, 0),         # too narrow
+    (500, 40, GEMM_A_LOWTRI | GEMM_REMAP, 1, 0),        # too few strips (320 < 512)
+])
+def test_strip_gemm_matches_tile_gemm_bitwise(gpu, n, batch, flags, layB, expect_strip):
+    """the strip kernel of the two triangular n^3 products (csrc/dgemm4.hip: one workgroup per CU, 64 x 512 strips, branch-free
+    stages) against the one-tile-per-workgroup kernel on the same device-generated operands: identical bits"""
+    used, ndiff, _, _ = gpu.dgemm_selfcheck2(n, n, n, layB=layB, batch=batch, flags=flags, alpha=1.0, beta=0.0)
+    assert ((used >> 1) & 1) == expect_strip
+    assert ndiff == 0
+
+
+@pytest.mark.gpu
+def test_schur_products_at_bench_shape_against_numpy(gpu):
+    """the two dominant product shapes of the n = 500, m = 1000 assembly through the production dispatch against numpy (the
+    kernels are otherwise compared with each other at this size): the stack product A_stack R (500500 x 500 x 500) and the Gram
+    product W W^T (1001 x 1001 x 250000, lower tiles, K slices)"""
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((500500, 500))
+    R = rng.standard_normal((500, 500))
+    C = gpu.dgemm(A, R)
+    ref = A @ R
+    assert np.max(np.abs(C - ref)) <= 1e-11 * np.max(np.abs(ref))
+    del A, C, ref
+    W = rng.standard_normal((1001, 250000))
+    G = gpu.dgemm(W, W, layB=0, lower_only=True)
+    ref = W @ W.T
+    il = np.tril_indices(1001)
+    assert np.max(np.abs(G[il] - ref[il])) <= 1e-11 * np.max(np.abs(ref))
+
+
 @pytest.mark.parametrize("n", [2, 5, 16, 17, 24, 25, 33, 43, 48, 63, 64])
 def test_small_block_step_length_eigenvalue(gpu, n):
     """lambda_min(L D L^T) by the small-block kernels (one-wavefront Jacobi up to n = 16, single-launch Lanczos with the
