@@ -79,12 +79,14 @@ def planted_pair(n, m, seed):
 
 
 def cpu_baseline(solver, b, n, m, gpu_iterations, budget_iters=None):
-    """CPU restatement (numpy + OpenBLAS threads) of the same algorithm on the same bits: a bounded sample of IPM iterations
-    timed on the host cores, extrapolated to the iteration count of the full solve."""
+    """CPU restatement (numpy / scipy level-3 BLAS on all host cores) of the same algorithm on the same bits, with the Schur assembly
+    in the SAME formulation as the device path (W_j = G A_j R by two DTRMM over stacks, Mx = W W^T by one DSYRK:
+    oracle/ipm_ref.schur_block_w): a bounded sample of IPM iterations timed on the host cores, extrapolated to the iteration count of
+    the full solve."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ipm_ref
     if budget_iters is None:
-        # about 10-30 s of CPU work: 4 iterations at C2 (7.5e11 flop each), 1 at T1 (1.2e13)
+        # about 10-30 s of CPU work: 4 iterations at C2 (5e11 flop each in this formulation), 1 at T1 (8e12)
         budget_iters = 4 if 4.0 * m * n ** 3 + float(m) ** 2 * n ** 2 < 2e12 else 1
     try:
         from threadpoolctl import threadpool_info
@@ -93,17 +95,21 @@ def cpu_baseline(solver, b, n, m, gpu_iterations, budget_iters=None):
         threads = os.cpu_count() or 1
     A = solver.get_block_dense(0)
     core = ipm_ref.CoreProblem(b, [A])
+    par = ipm_ref.Params(gaptol=1e-5, feastol=1e-5, maxiter=budget_iters)
+    par.schur = "W"
     t0 = time.perf_counter()
-    res = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-5, feastol=1e-5, maxiter=budget_iters))
+    res = ipm_ref.hsd_solve(core, par)
     dt = time.perf_counter() - t0
     its = max(1, res.iterations)
     per_iter = dt / its
     solves_per_sec = 1.0 / (per_iter * max(1, gpu_iterations))
+    m1 = m + 1
     return {"value": solves_per_sec, "unit": "solves/s", "cores": int(threads), "kind": "port",
             "iters_per_sec": 1.0 / per_iter,
+            "executed_tflops_of_the_assembly_formulation": (2.0 * m1 * n ** 3 + float(m1) ** 2 * n ** 2) / per_iter / 1e12,
             "sample": "%d IPM iterations of the same n=%d, m=%d instance (A copied back from HBM: identical bits) with "
-                      "oracle/ipm_ref.py on numpy/OpenBLAS, %.1f s; solves/s extrapolated to the %d iterations of the full solve"
-                      % (its, n, m, dt, gpu_iterations)}
+                      "oracle/ipm_ref.py, Schur assembly in the device path's W formulation on level-3 BLAS (DTRMM, DTRMM, DSYRK), %.1f s; "
+                      "solves/s extrapolated to the %d iterations of the full solve" % (its, n, m, dt, gpu_iterations)}
 
 
 def workload_name(n, m):
@@ -122,6 +128,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="skip the t1 / sdpi_boundary / warm_start / phases sub-objects")
     ap.add_argument("--shard-matrices", choices=["auto", "on", "off"], default="auto",
                     help="N > 1: constraint matrices sharded by variable (auto: when the replicated matrices would not fit)")
+    ap.add_argument("--schur-form", choices=["auto", "cols", "rows", "vars"], default="auto",
+                    help="N > 1, how the Schur assembly is sharded: cols = column slices of W_j = G A_j R + all-reduce (default when the "
+                         "matrices fit replicated), rows = row chunks of the Schur matrix + RCCL all-gather (the form BASELINE.json's "
+                         "north_star words), vars = matrices sharded by variable + all-to-all of the W entries (default when they do not fit)")
     ap.add_argument("--master-port", type=int, default=0, help="parent mode: rendezvous port of the ranks (0: pick a free one)")
     ap.add_argument("--launch-dry-run", action="store_true",
                     help="exercise the N-rank launcher without a GPU: the ranks meet over gloo and rank 0 prints a line")
@@ -131,9 +141,43 @@ def parse_args(argv=None):
 # ---- parent mode: `python bench.py --gpus N` without a launcher ---------------------------------------------------------
 
 def visible_gpus():
-    """number of GPUs without initialising one (torch.cuda.device_count() does not create a context on this image)"""
-    import torch
-    return int(torch.cuda.device_count())
+    """Number of GPUs WITHOUT loading the HIP runtime into this process (it is the parent of the ranks: a process that has
+    initialised the GPU must not start the launcher).  The KFD topology in sysfs lists one node per agent; GPU nodes have
+    simd_count > 0.  HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES restrict what a rank will see.  Where sysfs has no KFD tree the
+    count comes from a throw-away child process."""
+    import glob
+    n = 0
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    for f in nodes:
+        try:
+            for ln in open(f):
+                k, _, v = ln.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    n += 1
+                    break
+        except (OSError, ValueError):
+            pass
+    if not nodes:
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], stdout=subprocess.PIPE,
+                               stderr=subprocess.DEVNULL, text=True, timeout=300)
+            n = int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else 0
+        except Exception:
+            n = 0
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
+def hip_runtime_mapped():
+    """whether libamdhip64 is mapped into this process (the parent of the ranks must answer False: tests/test_bench_launcher_cpu.py)"""
+    try:
+        return any("libamdhip64" in ln for ln in open("/proc/self/maps"))
+    except OSError:
+        return False
 
 
 def launch_ranks(args, argv):
@@ -144,6 +188,9 @@ def launch_ranks(args, argv):
     n = args.gpus
     if not args.launch_dry_run:
         have = visible_gpus()
+        if os.environ.get("BENCH_REPORT_MAPS"):            # test hook: what the parent has mapped at the point where it would start the ranks
+            sys.stderr.write("bench.py: parent maps: %s\n" % json.dumps({"hip_mapped": hip_runtime_mapped(), "torch_imported": "torch" in sys.modules,
+                                                                         "visible_gpus": have}))
         if have < n:
             sys.stderr.write("bench.py: --gpus %d asked for, but only %d GPU(s) are visible on this machine: a %d-rank RCCL run "
                              "needs %d devices (one process per GPU); nothing was run\n" % (n, have, n, n))
@@ -198,7 +245,7 @@ def dry_run_rank(args):
         dist.destroy_process_group()
         return 7
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "gpus_arg": args.gpus, "rank_sum": float(t.item()),
+        print(json.dumps({"dry_run": True, "n_gpus": world, "gpus_arg": args.gpus, "rank_sum": float(t.item()), "schur_form": args.schur_form,
                           "local_rank": int(os.environ.get("LOCAL_RANK", "-1")), "master_addr": os.environ.get("MASTER_ADDR")}))
     dist.destroy_process_group()
     return 0
@@ -217,12 +264,21 @@ def run_solves(solver, steps, warmup, barrier, **kw):
 
 
 def schur_summary(infos, n, m, world=1):
+    """roofline of the dominant kernels (the Schur assembly).  frac = EXECUTED matrix-core flops / time / peak: what the engine's GEMM
+    launches issue (whole tiles over the K ranges actually walked - hipsdp_info.schur_flops_executed), i.e. the number MFMA
+    utilisation counters measure; the algorithmic count of SURVEY.md 8(d) (4 m1 n^3 + m1^2 n^2, which the W formulation undercuts)
+    is reported beside it."""
     schur_s = sum(i.schur_seconds for i in infos)
-    schur_fl = sum(i.schur_flops for i in infos)
+    schur_alg = sum(i.schur_flops for i in infos)
+    schur_exe = sum(i.schur_flops_executed for i in infos)
     calls = sum(i.schur_calls for i in infos)
-    ach = schur_fl / max(schur_s, 1e-12) / 1e12
-    return {"achieved": ach, "frac": ach / (FP64_MFMA_PEAK_TFLOPS * world), "avg_assembly_ms": 1e3 * schur_s / max(1, calls),
-            "assemblies": calls, "algorithmic_flops_per_assembly": schur_fl / max(1, calls),
+    peak = FP64_MFMA_PEAK_TFLOPS * world
+    ach = schur_exe / max(schur_s, 1e-12) / 1e12
+    alg = schur_alg / max(schur_s, 1e-12) / 1e12
+    return {"achieved": ach, "frac": ach / peak, "avg_assembly_ms": 1e3 * schur_s / max(1, calls),
+            "assemblies": calls, "executed_flops_per_assembly": schur_exe / max(1, calls),
+            "algorithmic_flops_per_assembly": schur_alg / max(1, calls),
+            "algorithmic_equivalent_tflops": alg, "algorithmic_equivalent_frac": alg / peak,
             "schur_share_of_solve_time": schur_s / max(1e-12, sum(i.solve_seconds for i in infos))}
 
 
@@ -243,7 +299,7 @@ def phase_anatomy(hb, solver):
     return out
 
 
-def bench_t1(hb, seed, barrier):
+def bench_t1(hb, seed, barrier, cpu=False):
     """n = 1000, m = 2000: the size north_star states its 1-GPU target on (>= 10x CPU, >= 30 % FP64-MFMA in the assembly)"""
     n, m = 1000, 2000
     s = hb.Solver(0)
@@ -261,6 +317,11 @@ def bench_t1(hb, seed, barrier):
         pmc = PMC_FROM_PROFILES.get((n, m))
         if pmc is not None:
             out["roofline"]["from_committed_pmc_profile"] = pmc
+        if cpu:
+            try:
+                out["cpu_baseline"] = cpu_baseline(s, b, n, m, int(round(its / len(infos))), budget_iters=1)
+            except Exception as e:
+                out["cpu_baseline"] = {"error": repr(e)}
         return out
     finally:
         s.close()
@@ -375,6 +436,60 @@ def bench_sdpi_boundary(hb, solver, n, m, b, opt):
             "optimal_and_matches_planted_optimum": bool(good)}
 
 
+def bench_bnb(hb, cpu=True):
+    """BASELINE configs[2] / configs[4]: full branch-and-bound over example_TT (truss topology, n=10, m=37, 85 LP rows) and example_CLS
+    (n=43, m=33) with every node relaxation solved by the device engine through SCIPsdpiSolverLoadAndSolve, cold starts and warm starts
+    (child from its parent's (y, Z, X), relax_sdp.c's warmstartipfactor rule with factor 0.5).  The tree search, the .dat-s reader and
+    the sdpi.c-style argument preparation are the test harness (tests/harness: host-side driver code, no arithmetic of the path); node
+    solves per second = node relaxations / wall time inside SCIPsdpiSolverLoadAndSolve.  CPU figure beside it: the same trees with the
+    numpy restatement of the engine (oracle/ipm_ref.py) as node solver."""
+    for d in ("tests", os.path.join("tests", "harness")):
+        if os.path.join(ROOT, d) not in sys.path:
+            sys.path.insert(0, os.path.join(ROOT, d))
+    import bnb
+    import sdpa_io
+    import warm_bnb
+    inst_dir = os.path.join(ROOT, "tests", "golden", "instances")
+    solu = {"example_TT.dat-s.gz": 2.11803, "example_CLS.dat-s.gz": 7.1485}        # check/testset/short.solu
+    out = {"unit": "node SDP solves/s (wall time inside SCIPsdpiSolverLoadAndSolve), tolerance 1e-6, 1 GPU"}
+    for name in sorted(solu):
+        inst = sdpa_io.read_sdpa(os.path.join(inst_dir, name))
+        prob = bnb.instance_to_sdpi(inst)
+        row = {}
+        for label, lam in (("cold", 0.0), ("warm", 0.5)):
+            s, solve, stats = warm_bnb.warm_node_solver(hb.lib(), 1e-6, lam)
+            t0 = time.perf_counter()
+            best, y, nodes, failed = bnb.branch_and_bound(prob, inst.intvars, solve)
+            wall = time.perf_counter() - t0
+            s.free()
+            calls = max(1, stats["calls"])
+            row[label] = {"optimum": best, "matches_short_solu": bool(best is not None and abs(best - solu[name]) <= 1e-4 * max(1.0, abs(solu[name]))),
+                          "nodes": nodes, "node_solves": stats["calls"], "unresolved_nodes": failed,
+                          "ipm_iterations_per_node": stats["iters"] / calls, "warm_started_nodes": stats["warm"],
+                          "node_solves_per_sec": calls / max(stats["wall"], 1e-9), "ms_per_ipm_iteration": 1e3 * stats["time"] / max(1, stats["iters"]),
+                          "engine_seconds": stats["time"], "load_and_solve_seconds": stats["wall"], "tree_wall_seconds": wall}
+        if cpu:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                import ipm_ref                                        # noqa: F401  (the CPU leg: numpy node solver of the harness)
+                solve = bnb.oracle_node_solver(1e-6)
+                cnt = {"calls": 0, "t": 0.0}
+
+                def timed(P, solve=solve, cnt=cnt):
+                    t0 = time.perf_counter()
+                    r = solve(P)
+                    cnt["t"] += time.perf_counter() - t0
+                    cnt["calls"] += 1
+                    return r
+                best, y, nodes, failed = bnb.branch_and_bound(prob, inst.intvars, timed, maxnodes=700)
+                row["cpu_baseline"] = {"kind": "port", "node_solves_per_sec": cnt["calls"] / max(cnt["t"], 1e-9), "node_solves": cnt["calls"],
+                                       "optimum": best, "sample": "the whole tree (at most 700 nodes), cold starts, oracle/ipm_ref.py on numpy as node solver"}
+            except Exception as e:
+                row["cpu_baseline"] = {"error": repr(e)}
+        out[name.split(".")[0]] = row
+    return out
+
+
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
@@ -406,6 +521,15 @@ def main():
     elif torch.cuda.is_available():
         torch.cuda.set_device(0)
 
+    form = args.schur_form
+    if form == "rows":
+        os.environ["HIPSDP_SCHUR"] = "R"                  # read by the engine when it sizes its Schur workspace (csrc/ipm.hip)
+    elif form in ("cols", "vars"):
+        os.environ.pop("HIPSDP_SCHUR", None)
+    if form == "vars":
+        args.shard_matrices = "on"
+    elif form in ("cols", "rows"):
+        args.shard_matrices = "off"
     hb = load_binding()
     if hb.device_count() <= 0:
         raise RuntimeError("bench.py needs an MI355X: no HIP device visible and hipsdp has no CPU path")
@@ -468,14 +592,20 @@ def main():
     pmc = PMC_FROM_PROFILES.get((n, m)) if world == 1 else None
     roofline = {"bound": "mfma", "achieved": roof["achieved"], "peak": FP64_MFMA_PEAK_TFLOPS * world, "unit": "TFLOP/s",
                 "frac": roof["frac"],
-                "frac_is": "ALGORITHMIC rate (4 m1 n^3 + m1^2 n^2 per assembly, SURVEY.md 8(d)) / FP64 matrix peak; the kernels execute "
-                           "fewer flops (triangular factors, lower tiles): see executed_tflops / mfma_busy",
+                "frac_is": "EXECUTED FP64 matrix-core flops of the Schur assembly (counted by the engine from the tiles and K ranges its "
+                           "GEMM launches walk; live in this run) / HIP-event time of the assemblies / FP64 matrix peak - the quantity "
+                           "MFMA-busy counters measure.  algorithmic_equivalent_frac prices the same time with SURVEY.md 8(d)'s "
+                           "4 m1 n^3 + m1^2 n^2 per assembly, which the W formulation (triangular factors, lower tiles) undercuts",
+                "algorithmic_equivalent_frac": roof["algorithmic_equivalent_frac"],
+                "algorithmic_equivalent_tflops": roof["algorithmic_equivalent_tflops"],
                 "traffic": pmc["traffic_bytes_per_assembly"] if pmc else None,
                 "traffic_is": ("quoted from the committed PMC profile, not measured in this run: " + pmc["source"]) if pmc else
                               "not measured for this size / rank count",
-                "executed_tflops": pmc["executed_tflops"] if pmc else None,
-                "mfma_busy": pmc["mfma_busy"] if pmc else None,
-                "kernel": "hs_dgemm2_kernel (Schur assembly: stack GEMM, batched GEMM, K-sliced Gram GEMM + slice reduce)",
+                "pmc_executed_tflops": pmc["executed_tflops"] if pmc else None,
+                "pmc_mfma_busy": pmc["mfma_busy"] if pmc else None,
+                "kernel": "Schur assembly: hs_dgemm2_kernel / hs_dgemm4_kernel (stack and batched n^3 products), hs_dgemm2_kernel (K-sliced Gram "
+                          "product) + slice reduce",
+                "executed_flops_per_assembly": roof["executed_flops_per_assembly"],
                 "algorithmic_flops_per_assembly": roof["algorithmic_flops_per_assembly"],
                 "avg_assembly_ms": roof["avg_assembly_ms"], "assemblies": roof["assemblies"],
                 "schur_share_of_solve_time": roof["schur_share_of_solve_time"]}
@@ -496,9 +626,11 @@ def main():
                                "A resident in HBM" % (workload_name(n, m), n, m),
                    "parallelism": "1 GPU" if world == 1 else
                                   "one node SDP over %d ranks: Schur assembly sharded (%s), passes over A by rows (RCCL all-gather / "
-                                  "all-reduce), everything else replicated" % (world, "W_j formed where A_j lives, all-to-all of the W "
-                                  "entries, all-reduce of the partial Schur matrices" if sharded else "column slices of W_j = G A_j R, "
-                                  "RCCL all-reduce of the partial Schur matrices"),
+                                  "all-reduce), everything else replicated" % (world, "vars: W_j formed where A_j lives, all-to-all of the W "
+                                  "entries, all-reduce of the partial Schur matrices" if sharded else
+                                  ("rows: row chunks of the Schur matrix in the U formulation, RCCL all-gather" if form == "rows" else
+                                   "cols: column slices of W_j = G A_j R, RCCL all-reduce of the partial Schur matrices")),
+                   "schur_form": "vars" if sharded else ("rows" if form == "rows" else "cols"),
                    "matrices": "sharded by variable" if sharded else "replicated",
                    "n": n, "m": m, "seed": args.seed},
         "iters_per_sec": iters / elapsed,
@@ -539,9 +671,14 @@ def main():
         lib.hipsdp_comm_destroy(comm)
     if rank == 0 and world == 1 and not args.no_extras and ok and (n, m) == (500, 1000):
         try:
-            out["t1"] = bench_t1(hb, args.seed, barrier)
+            out["t1"] = bench_t1(hb, args.seed, barrier, cpu=not args.no_cpu)
         except Exception as e:
             out["t1"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not args.no_extras and ok and (n, m) == (500, 1000):
+        try:
+            out["bnb"] = bench_bnb(hb, cpu=not args.no_cpu)
+        except Exception as e:
+            out["bnb"] = {"error": repr(e)}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -99,6 +99,14 @@ void hipsdp_free(hipsdp_solver** solver);
 /* Declares the shape: m variables, nblocks dense SDP blocks of the given sizes, q LP rows.  Allocates the device storage
  * A_k[(m+1) x n_k^2] (row i = vec(A_i), row 0 = constant matrix), zero filled. */
 int  hipsdp_set_shape(hipsdp_solver* solver, int m, int nblocks, const int* blocksizes, int q);
+/* The same with the number of lower-triangular triplets the caller is going to add per block (nnz[k] >= 0; NULL or a negative
+ * entry: unknown).  A block whose count makes the pair formula over nonzeros the cheaper Schur assembly (4 (sum nnz)^2 multiply-adds
+ * against 4 (m + 1) n^3 + (m + 1)^2 n^2; never for n <= 64) is kept SPARSE: no (m + 1) x n^2 array is allocated, the matrices of the
+ * variables stay the triplets of hipsdp_add_entries (what the reference backends hand DSDP / SDPA:
+ * sdpisolver_dsdp.c:1126-1195, sdpisolver_sdpa.cpp:1223-1267), the constant matrix a dense n x n array.  Such a block takes
+ * hipsdp_add_entries only (not hipsdp_set_block_dense / hipsdp_master_gather / hipsdp_gen_planted). */
+int  hipsdp_set_shape2(hipsdp_solver* solver, int m, int nblocks, const int* blocksizes, int q, const long long* nnz);
+int  hipsdp_block_is_sparse(hipsdp_solver* solver, int block);
 /* objective b[m] (host) */
 int  hipsdp_set_obj(hipsdp_solver* solver, const double* b);
 /* Scatter lower-triangular COO entries (row >= col) into block k: entry e belongs to matrix var[e] (0 = constant matrix,

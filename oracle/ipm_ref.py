@@ -54,6 +54,9 @@ class Params:
         # 0 fast, 1 medium, 2 stable - shorter steps, a higher centrality floor, more patient stall tests (same numbers as
         # csrc/ipm.hip: solve_impl)
         self.settings = settings
+        # 'U': Mx = <A_i, X A_j Z^-1> by three full products (default); 'W': the device path's formulation with the triangular
+        # savings (schur_block_w) - the CPU baseline of bench.py
+        self.schur = 'U'
         self.preoptgap = preoptgap    # > 0: keep the first feasible iterate with relative gap below it (Result.pre)
         self.gaptol = gaptol          # relative gap / absolute gap tolerance (relax_sdp.c:70)
         self.feastol = feastol        # residual tolerance (relax_sdp.c:71)
@@ -93,6 +96,28 @@ def schur_block(A, X, Zinv):
     V = Tt.reshape(m1 * n, n) @ X                                          # GEMM2: stack product, V_j = T_j^T X
     Mx = A.reshape(m1, n * n) @ V.reshape(m1, n * n).T                     # GEMM3
     return 0.5 * (Mx + Mx.T)
+
+
+def schur_block_w(A, Lx, Lz):
+    """The same matrix through the W formulation of the device path (csrc/schur.hip: hs_schur_W) with the triangular savings kept,
+    for the CPU baseline of bench.py: X = R R^T (R = chol X), Z^-1 = G^T G (G = inverse of chol Z), W_j = G A_j R,
+    Mx = W W^T over the n^2 entries.  Level-3 BLAS only: two DTRMM over stacks (n^3 m1 each instead of 2 n^3 m1) and one DSYRK
+    (m1^2 n^2 instead of 2 m1^2 n^2).  The row-major stacks are handed to the Fortran routines as their transposes (no copies
+    besides the two the products overwrite):  T^T = R^T A_stack^T,  (W_j^T)_stack^T = G (T_j^T)_stack^T,  <W_i, W_j> = <W_i^T, W_j^T>."""
+    m1, n, _ = A.shape
+    G = sla.solve_triangular(Lz, np.eye(n), lower=True, check_finite=False)          # lower triangular
+    # T = A_stack R:  as Fortran arrays  T^T (n x m1 n) = R^T (upper) * A_stack^T
+    T = np.array(A.reshape(m1 * n, n), order='C', copy=True)
+    Tt_f = sla.blas.dtrmm(1.0, Lx.T, T.T, side=0, lower=0, trans_a=0, overwrite_b=1)   # Lx.T is the F-view of a C-ordered lower R: upper
+    T = Tt_f.T.reshape(m1, n, n)
+    # W_j^T = T_j^T G^T: stack of T_j^T (one memory pass), times G^T from the right:  (stack)^T (n x m1 n) = G (lower) * (T_j^T stack)^T
+    Tt = np.ascontiguousarray(T.transpose(0, 2, 1)).reshape(m1 * n, n)
+    Wt_f = sla.blas.dtrmm(1.0, np.asfortranarray(G), Tt.T, side=0, lower=1, trans_a=0, overwrite_b=1)
+    Wf = Wt_f.T.reshape(m1, n * n)                                                  # row j = vec(W_j^T)
+    # Mx = Wf Wf^T: DSYRK on the F-view a = Wf^T (n^2 x m1): a^T a
+    Mx = sla.blas.dsyrk(1.0, Wf.T, trans=1, lower=1)
+    Mx = np.tril(Mx)
+    return Mx + np.tril(Mx, -1).T
 
 
 import os as _os
@@ -302,8 +327,12 @@ def hsd_solve(prob, par=None, start=None):
             Li = sla.solve_triangular(L, np.eye(L.shape[0]), lower=True, check_finite=False)
             Zinv.append(Li.T @ Li)
         Mx = np.zeros((m + 1, m + 1))
-        for A, Xk, Zi in zip(prob.blocks, X, Zinv):
-            Mx += schur_block(A, Xk, Zi)
+        if getattr(par, 'schur', 'U') == 'W':
+            for A, Lxk, Lzk in zip(prob.blocks, Lx, Lz):
+                Mx += schur_block_w(A, Lxk, Lzk)
+        else:
+            for A, Xk, Zi in zip(prob.blocks, X, Zinv):
+                Mx += schur_block(A, Xk, Zi)
         if q:
             Mx += Dext.T @ ((x / z)[:, None] * Dext)
         g = Mx[0, 1:].copy()

@@ -117,6 +117,17 @@ int  hs_mirror_upper(hipStream_t s, double* A, int n, long long lda);           
 int  hs_allgather_inplace(void* comm, double* buf, long long count_per_rank, int rank, hipStream_t stream);
 int  hs_allgather(void* comm, const double* send, double* recv, long long count_per_rank, hipStream_t stream);
 
+/* ---- sparse.hip: constraint matrices kept as nonzeros (see there) ----------------------------------------------------- */
+struct hs_sparse;
+int  hs_sp_prefers_sparse(int n, int m, long long nnz);
+int  hs_sp_build(hs_sparse** out, int n, int m, long long nnz, const int* var, const int* row, const int* col, const double* val);
+void hs_sp_free(hs_sparse* sp);
+long long hs_sp_nnz(const hs_sparse* sp);
+int  hs_sp_apply_A(hipStream_t s, const hs_sparse* sp, const double* V, double* out_var1);       /* out[v - 1] = <A_v, V>, v = 1 .. m */
+int  hs_sp_apply_AT(hipStream_t s, const hs_sparse* sp, const double* coef, double* out);        /* out += sum_{v >= 1} coef[v] A_v */
+int  hs_sp_schur(hipStream_t s, const hs_sparse* sp, const double* X, const double* Zinv, double* Mx);   /* lower triangle, i, j >= 1 */
+int  hs_sp_expand(hipStream_t s, const hs_sparse* sp, double* A);
+
 /* ---- chol.hip ------------------------------------------------------------------------------------------------- */
 /* In-place blocked Cholesky of the lower triangle of the row-major n x n matrix A (lda = n): A = L L^T, L stored in the
  * lower triangle (upper triangle is left untouched).  dinv receives the inverses of the 64 x 64 diagonal blocks of L

@@ -72,6 +72,18 @@ struct Block
    long long Lp;
    bool apk_valid;
    bool derived_valid;   /* n <= 64: LxInv, LzInv (and Zinv for n <= 32) belong to the current X, Z (written by the fused factorization) */
+   /* SPARSE mode (csrc/sparse.hip): the matrices of the variables are kept as the caller's nonzeros - A is NULL, A0 a dense n x n
+    * array of its own; the triplets are collected on the host (sph) and built into the device structure sp before they are used */
+   bool sparse;
+   bool sp_dirty;
+   hs_sparse* sp;
+   struct SpHost* sph;
+};
+
+struct SpHost
+{
+   std::vector<int> var, row, col;
+   std::vector<double> val;
 };
 
 /* phases of an iteration: roctx ranges for rocprofv3 --marker-trace (always) and, with hipsdp_set_profiling, HIP events on the
@@ -271,6 +283,14 @@ static int dalloc(T** p, long long count)
 
 static void dfree(void* p) { hs_pool_free(p); }
 
+static void free_sparse(Block& B)
+{
+   if ( B.sp != NULL ) hs_sp_free(B.sp);
+   B.sp = NULL;
+   delete B.sph;
+   B.sph = NULL;
+}
+
 static void free_problem(hipsdp_solver* s)
 {
    /* blocks go back to a pool that hands them out again without a device synchronisation: nothing may still be running on them */
@@ -281,6 +301,7 @@ static void free_problem(hipsdp_solver* s)
       double* ptrs[] = {B.Aown, B.A0sep, B.X, B.Z, B.Rd, B.Lz, B.LzInv, B.Zinv, B.Lx, B.LxInv, B.B, B.H, B.G, B.GZ, B.dXa, B.dZa, B.dX, B.dZ,
          B.E, B.W, B.T1, B.dinvz, B.dinvx, B.Xs, B.Zs, B.Apkown, B.pkv, B.T2, B.W2, B.Xpre, B.P2, B.pk3};
       for (double* p : ptrs) dfree(p);
+      free_sparse(B);
    }
    s->blk.clear();
    double* ptrs[] = {s->b, s->Dext, s->y, s->x, s->z, s->yt, s->dyt, s->wt, s->AX, s->AH, s->tmpe, s->rp, s->rd, s->tmpq, s->hl,
@@ -422,7 +443,32 @@ extern "C" void hipsdp_free(hipsdp_solver** ps)
       hs_pool_trim();
 }
 
+/* which storage a block gets: sparse when the caller's nonzero count makes the pair formula the cheaper Schur assembly (never for
+ * matrices sharded by variable: that mode exists for dense matrices that do not fit).  HIPSDP_SPARSE=0: never; =2: whenever a count
+ * is given (tests) */
+static bool block_wants_sparse(const hipsdp_solver* s, int n, int m, long long nnz)
+{
+   static const int mode = getenv("HIPSDP_SPARSE") != NULL ? atoi(getenv("HIPSDP_SPARSE")) : 1;
+   if ( mode == 0 || nnz < 0 || s->shardA_req > 0 )
+      return false;
+   if ( mode == 2 )
+      return m >= 1;
+   return hs_sp_prefers_sparse(n, m, nnz) != 0;
+}
+
 extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int* blocksizes, int q)
+{
+   return hipsdp_set_shape2(s, m, nblocks, blocksizes, q, NULL);
+}
+
+extern "C" int hipsdp_block_is_sparse(hipsdp_solver* s, int block)
+{
+   if ( s == NULL || !s->shaped || block < 0 || block >= (int) s->blk.size() )
+      return 0;
+   return s->blk[block].sparse ? 1 : 0;
+}
+
+extern "C" int hipsdp_set_shape2(hipsdp_solver* s, int m, int nblocks, const int* blocksizes, int q, const long long* nnz)
 {
    g_err[0] = 0;
    if ( s == NULL || m < 0 || nblocks < 0 || q < 0 )
@@ -437,14 +483,22 @@ extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int*
    {
       bool same = true;
       for (int k = 0; k < nblocks; ++k)
-         if ( s->blk[k].n != blocksizes[k] )
+         if ( s->blk[k].n != blocksizes[k] || s->blk[k].sparse != block_wants_sparse(s, blocksizes[k], m, nnz != NULL ? nnz[k] : -1) )
             same = false;
       if ( same )
       {
          const long long m1s = (long long) m + 1;
          for (auto& B : s->blk)
          {
-            HS_HIP( hipMemsetAsync(B.Aown, 0, (size_t) (m1s * B.n * B.n) * sizeof(double), s->stream) );
+            if ( B.sparse )
+            {
+               HS_HIP( hipMemsetAsync(B.A0, 0, (size_t) ((long long) B.n * B.n) * sizeof(double), s->stream) );
+               free_sparse(B);
+               B.sph = new SpHost();
+               B.sp_dirty = true;
+            }
+            else
+               HS_HIP( hipMemsetAsync(B.Aown, 0, (size_t) (m1s * B.n * B.n) * sizeof(double), s->stream) );
             B.apk_valid = false;
             B.derived_valid = false;
          }
@@ -488,11 +542,25 @@ extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int*
       const long long n2 = (long long) B.n * B.n;
       s->blk.push_back(B);
       Block& R = s->blk.back();
+      R.sparse = !s->shardA && block_wants_sparse(s, B.n, m, nnz != NULL ? nnz[k] : -1);
+      if ( R.sparse )
+      {
+         /* no (m + 1) x n^2 array: the variables' matrices stay triplets, the constant matrix gets a dense array of its own */
+         R.sph = new SpHost();
+         R.sp_dirty = true;
+         R.A = NULL;
+         HS_CALL( dalloc(&R.A0sep, n2) );
+         HS_HIP( hipMemsetAsync(R.A0sep, 0, (size_t) n2 * sizeof(double), s->stream) );
+         R.A0 = R.A0sep;
+      }
+      else
+      {
       HS_CALL( dalloc(&R.Aown, arows * n2) );
       HS_HIP( hipMemsetAsync(R.Aown, 0, (size_t) (arows * n2) * sizeof(double), s->stream) );
       R.A = R.Aown - (long long) s->a_r0 * n2;
       R.A0 = R.A;
-      if ( s->a_r0 > 0 || arows == 0 )
+      }
+      if ( !R.sparse && (s->a_r0 > 0 || arows == 0) )
       {
          HS_CALL( dalloc(&R.A0sep, n2) );
          HS_HIP( hipMemsetAsync(R.A0sep, 0, (size_t) n2 * sizeof(double), s->stream) );
@@ -511,7 +579,7 @@ extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int*
       R.pkv = NULL;
       /* the packed copy halves the HBM traffic of the passes; small blocks are launch bound and their passes take one
        * launch less on the full storage */
-      if ( getenv("HIPSDP_NOPACK") == NULL && B.n > 64 )
+      if ( getenv("HIPSDP_NOPACK") == NULL && B.n > 64 && !R.sparse )
       {
          if ( hipMalloc((void**) &R.Apkown, (size_t) ((arows > 0 ? arows : 1) * R.Lp) * sizeof(double)) != hipSuccess )
          {
@@ -629,6 +697,45 @@ extern "C" int hipsdp_add_entries(hipsdp_solver* s, int block, long long nnz, co
       return HIPSDP_OK;
    HS_HIP( hipSetDevice(s->device) );
    Block& B = s->blk[block];
+   if ( B.sparse )
+   {
+      /* variables: collected on the host (built into the device structure before the next use); constant matrix: dense scatter */
+      std::vector<int> cv, cr, cc; std::vector<double> cx;
+      for (long long e = 0; e < nnz; ++e)
+      {
+         if ( var[e] < 0 || var[e] > s->m || row[e] < 0 || row[e] >= B.n || col[e] < 0 || col[e] >= B.n )
+         {
+            set_err("hipsdp_add_entries: index out of range");
+            return HIPSDP_ERR_ARG;
+         }
+         if ( var[e] == 0 )
+         {
+            cv.push_back(0); cr.push_back(row[e]); cc.push_back(col[e]); cx.push_back(val[e]);
+         }
+         else
+         {
+            B.sph->var.push_back(var[e]); B.sph->row.push_back(row[e]); B.sph->col.push_back(col[e]); B.sph->val.push_back(val[e]);
+         }
+      }
+      B.sp_dirty = true;
+      s->solved = false;
+      if ( cv.empty() )
+         return HIPSDP_OK;
+      nnz = (long long) cv.size();
+      int *dv, *dr, *dc; double* dval;
+      HS_CALL( dalloc(&dv, nnz) ); HS_CALL( dalloc(&dr, nnz) ); HS_CALL( dalloc(&dc, nnz) ); HS_CALL( dalloc(&dval, nnz) );
+      HS_HIP( hipMemcpy(dv, cv.data(), (size_t) nnz * sizeof(int), hipMemcpyHostToDevice) );
+      HS_HIP( hipMemcpy(dr, cr.data(), (size_t) nnz * sizeof(int), hipMemcpyHostToDevice) );
+      HS_HIP( hipMemcpy(dc, cc.data(), (size_t) nnz * sizeof(int), hipMemcpyHostToDevice) );
+      HS_HIP( hipMemcpy(dval, cx.data(), (size_t) nnz * sizeof(double), hipMemcpyHostToDevice) );
+      long long g0 = (nnz + 255) / 256; if ( g0 > 4096 ) g0 = 4096;
+      HS_HIP( hipMemsetAsync(s->flags + 6, 0, sizeof(int), s->stream) );
+      hipLaunchKernelGGL(k_scatter_coo, dim3((unsigned) g0), dim3(256), 0, s->stream, nnz, B.n, dv, dr, dc, dval, B.A0, 0, 1, B.A0, 0, s->flags + 6);
+      HS_LAUNCH_CHECK();
+      HS_HIP( hipStreamSynchronize(s->stream) );
+      dfree(dv); dfree(dr); dfree(dc); dfree(dval);
+      return HIPSDP_OK;
+   }
    int *dv, *dr, *dc; double* dval;
    HS_CALL( dalloc(&dv, nnz) ); HS_CALL( dalloc(&dr, nnz) ); HS_CALL( dalloc(&dc, nnz) ); HS_CALL( dalloc(&dval, nnz) );
    HS_HIP( hipMemcpyAsync(dv, var, (size_t) nnz * sizeof(int), hipMemcpyHostToDevice, s->stream) );
@@ -864,9 +971,9 @@ extern "C" int hipsdp_master_gather(hipsdp_solver* s, int engine_block, int mast
    if ( s == NULL || !s->shaped || engine_block < 0 || engine_block >= (int) s->blk.size() || master_block < 0
       || master_block >= (int) s->master_A.size() || nactive < 0 || nactive > s->m || nkept != s->blk[engine_block].n )
       return HIPSDP_ERR_ARG;
-   if ( s->shardA )
+   if ( s->shardA || s->blk[engine_block].sparse )
    {
-      set_err("hipsdp_master_gather: not available with matrices sharded by variable");
+      set_err("hipsdp_master_gather: not available with matrices sharded by variable or kept as nonzeros");
       return HIPSDP_ERR_ARG;
    }
    if ( nactive == 0 )
@@ -901,6 +1008,11 @@ extern "C" int hipsdp_set_block_dense(hipsdp_solver* s, int block, const double*
       return HIPSDP_ERR_ARG;
    HS_HIP( hipSetDevice(s->device) );
    Block& B = s->blk[block];
+   if ( B.sparse )
+   {
+      set_err("hipsdp_set_block_dense: the block is kept as nonzeros (hipsdp_set_shape2 with a count): use hipsdp_add_entries");
+      return HIPSDP_ERR_ARG;
+   }
    const size_t n2b = (size_t) B.n * B.n * sizeof(double);
    if ( s->a_r1 > s->a_r0 )
       HS_HIP( hipMemcpy(B.Aown, A + (size_t) s->a_r0 * B.n * B.n, (size_t) (s->a_r1 - s->a_r0) * n2b, hipMemcpyHostToDevice) );
@@ -929,7 +1041,7 @@ static int pass_AT(hipsdp_solver* s, Block& B, const double* coef, double sa, co
 extern "C" int hipsdp_gen_planted(hipsdp_solver* s, int n, int m, long long seed, const double* Xstar, const double* Zstar,
    const double* ystar, double* b_out)
 {
-   if ( s == NULL || !s->shaped || s->blk.size() != 1 || s->blk[0].n != n || s->m != m || s->q != 0 )
+   if ( s == NULL || !s->shaped || s->blk.size() != 1 || s->blk[0].n != n || s->m != m || s->q != 0 || s->blk[0].sparse )
       return HIPSDP_ERR_ARG;
    HS_HIP( hipSetDevice(s->device) );
    Block& B = s->blk[0];
@@ -977,6 +1089,21 @@ extern "C" int hipsdp_get_block_dense(hipsdp_solver* s, int block, double* A)
       return HIPSDP_ERR_ARG;
    HS_HIP( hipSetDevice(s->device) );
    Block& B = s->blk[block];
+   if ( B.sparse )
+   {
+      /* expanded from the triplets (later entries of the same position win, as in the device structure) */
+      const size_t n2 = (size_t) B.n * B.n;
+      memset(A, 0, (size_t) (s->m + 1) * n2 * sizeof(double));
+      HS_HIP( hipMemcpy(A, B.A0, n2 * sizeof(double), hipMemcpyDeviceToHost) );
+      const SpHost& h = *B.sph;
+      for (size_t e = 0; e < h.var.size(); ++e)
+      {
+         double* a = A + (size_t) h.var[e] * n2;
+         a[(size_t) h.row[e] * B.n + h.col[e]] = h.val[e];
+         a[(size_t) h.col[e] * B.n + h.row[e]] = h.val[e];
+      }
+      return HIPSDP_OK;
+   }
    /* matrices sharded by variable: the rows this rank holds and the constant matrix are written, the rest is left alone */
    const size_t n2b = (size_t) B.n * B.n * sizeof(double);
    if ( s->a_r1 > s->a_r0 )
@@ -1243,7 +1370,7 @@ static int ensure_schur_ws(hipsdp_solver* s)
       return HS_OK;
    const int m1 = s->m + 1;
    long long n2max = 1;
-   for (auto& B : s->blk) { const long long n2 = (long long) B.n * B.n; if ( n2 > n2max ) n2max = n2; }
+   for (auto& B : s->blk) { const long long n2 = (long long) B.n * B.n; if ( !B.sparse && n2 > n2max ) n2max = n2; }
    double budget = s->par.ws_gbytes > 0.0 ? s->par.ws_gbytes : 40.0;
    const char* env = getenv("HIPSDP_WS_GB");
    if ( env != NULL && atof(env) > 0.0 )
@@ -1406,8 +1533,10 @@ static int read_scalars(hipsdp_solver* s, HostScalars& h, int* flags3)
 }
 
 /* the two passes over the constraint matrices of one block; with a packed copy they move half the bytes */
+static int ensure_sparse(hipsdp_solver* s);
 static int ensure_packed(hipsdp_solver* s)
 {
+   HS_CALL( ensure_sparse(s) );
    for (auto& B : s->blk)
    {
       if ( B.Apk != NULL && !B.apk_valid )
@@ -1427,7 +1556,7 @@ int hs_allreduce_sum(void* comm, double* buf, long long count, hipStream_t strea
  * the (packed) n x n partial sums.  Every rank decides from the sizes alone (same decision everywhere). */
 static bool passes_sharded(const hipsdp_solver* s, const Block& B)
 {
-   if ( s->comm == NULL )
+   if ( s->comm == NULL || B.sparse )
       return false;
    if ( s->shardA )
       return true;              /* the only rows there are (hs_var_rows is the row split of the sharded passes) */
@@ -1447,10 +1576,47 @@ static void pass_rows(const hipsdp_solver* s, int* chunk, int* r0, int* r1)
    *r1 = *r0 + c < m1 ? *r0 + c : m1;
 }
 
+/* sparse blocks: the triplets collected since the last build become the device structure */
+static int ensure_sparse(hipsdp_solver* s)
+{
+   for (auto& B : s->blk)
+      if ( B.sparse && (B.sp_dirty || B.sp == NULL) )
+      {
+         if ( B.sp != NULL ) hs_sp_free(B.sp);
+         B.sp = NULL;
+         HS_HIP( hipStreamSynchronize(s->stream) );
+         const SpHost& h = *B.sph;
+         HS_CALL( hs_sp_build(&B.sp, B.n, s->m, (long long) h.var.size(), h.var.data(), h.row.data(), h.col.data(), h.val.data()) );
+         B.sp_dirty = false;
+      }
+   return HS_OK;
+}
+
+/* out = c[0] A0 + sa add (add may be NULL): the dense part of A^T(coef) of a sparse block */
+__global__ void k_sp_base(long long n2, const double* __restrict__ c, const double* __restrict__ A0, double sa, const double* __restrict__ add,
+   double* __restrict__ out)
+{
+   const double c0 = c[0];
+   for (long long e = (long long) blockIdx.x * blockDim.x + threadIdx.x; e < n2; e += (long long) gridDim.x * blockDim.x)
+      out[e] = c0 * A0[e] + (add != NULL ? sa * add[e] : 0.0);
+}
+
+/* Mx[i][0] += v[i] (column 0 of the lower triangle) */
+__global__ void k_add_col0(int m1, const double* __restrict__ v, double* __restrict__ Mx)
+{
+   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m1; i += gridDim.x * blockDim.x)
+      Mx[(long long) i * m1] += v[i];
+}
+
 /* out[m + 1] = <A_i, V>, V symmetric */
 static int pass_A(hipsdp_solver* s, Block& B, const double* V, double* out)
 {
    const int m1 = s->m + 1;
+   if ( B.sparse )
+   {
+      HS_CALL( hs_dot(s->stream, (long long) B.n * B.n, B.A0, V, out, 0, s->red_ws) );
+      return hs_sp_apply_A(s->stream, B.sp, V, out + 1);
+   }
    if ( passes_sharded(s, B) )
    {
       int c, r0, r1;
@@ -1490,6 +1656,12 @@ static int pass_AT(hipsdp_solver* s, Block& B, const double* coef, double sa, co
 {
    const int m1 = s->m + 1;
    const long long n2 = (long long) B.n * B.n;
+   if ( B.sparse )
+   {
+      hipLaunchKernelGGL(k_sp_base, g1d(n2), dim3(256), 0, s->stream, n2, coef, B.A0, sa, add, out);
+      HS_LAUNCH_CHECK();
+      return hs_sp_apply_AT(s->stream, B.sp, coef, out);
+   }
    if ( passes_sharded(s, B) )
    {
       int c, r0, r1;
@@ -2490,7 +2662,9 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
          {
             bn.push_back(B.n); bA.push_back(B.A); bX.push_back(B.X); bZ.push_back(B.Zinv);
          }
-         const int rs = hs_schur_small(st, m1, K, bn.data(), bA.data(), bX.data(), bZ.data(), q, s->Dext, s->x, s->z, s->Mx,
+         bool anysp = false;
+         for (auto& B : s->blk) anysp = anysp || B.sparse;
+         const int rs = anysp ? 0 : hs_schur_small(st, m1, K, bn.data(), bA.data(), bX.data(), bZ.data(), q, s->Dext, s->x, s->z, s->Mx,
             m > 0 ? s->Lm : NULL, s->dya);
          if ( rs < 0 )
             return -rs;
@@ -2507,7 +2681,7 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       {
          /* matrices sharded by variable: W_j where A_j lives, all-to-all of the row ranges, partial Gram matrices summed */
          for (auto& B : s->blk)
-            for (int c0 = 0; c0 < B.n; c0 += s->var_cw)
+            for (int c0 = 0; c0 < B.n && !B.sparse; c0 += s->var_cw)
                HS_CALL( hs_schur_Wvar(st, s->comm, s->rank, s->nranks, m1, B.n, B.A, B.Lx, B.LzInv, s->Mx, &s->sws, c0,
                      B.n - c0 < s->var_cw ? B.n - c0 : s->var_cw) );
          HS_CALL( hs_allreduce_sum(s->comm, s->Mx, (long long) m1 * m1, st) );
@@ -2521,6 +2695,8 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
          for (int g = g0; g < g0 + per; ++g)
             for (auto& B : s->blk)
             {
+               if ( B.sparse )
+                  continue;
                int c0, cw;
                hs_shard_cols(m1, B.n, S, g, &c0, &cw);
                HS_CALL( hs_schur_Wcols(st, m1, B.n, B.A, B.Lx, B.LzInv, s->Mx, &s->sws, c0, cw) );
@@ -2535,6 +2711,8 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
          hs_shard_rows(m1, s->nranks, s->rank, &c, &b1, &b2);
          for (auto& B : s->blk)
          {
+            if ( B.sparse )
+               continue;
             HS_CALL( hs_schur_Urows(st, m1, B.n, B.A, B.X, B.Zinv, s->Mx, &s->sws, b1, b1 + c) );
             HS_CALL( hs_schur_Urows(st, m1, B.n, B.A, B.X, B.Zinv, s->Mx, &s->sws, b2, b2 + c) );
          }
@@ -2560,11 +2738,27 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       {
          for (auto& B : s->blk)
          {
+            if ( B.sparse )
+               continue;
             if ( s->schur_mode_U )
                HS_CALL( hs_schur_U(st, m1, B.n, B.A, B.X, B.Zinv, s->Mx, &s->sws, 0, m1) );
             else
                HS_CALL( hs_schur_W(st, m1, B.n, B.A, B.Lx, B.LzInv, s->Mx, &s->sws) );
          }
+      }
+      /* blocks in sparse mode (csrc/sparse.hip), on every rank alike, behind the exchange of the sharded forms: column 0 from
+       * U_0 = X A_0 Zinv (A_0 is dense) and one gather pass, the pairs of variables from the pair formula over their nonzeros */
+      for (auto& B : s->blk)
+      {
+         if ( !B.sparse )
+            continue;
+         const int n = B.n;
+         HS_CALL( gemm(s, HS_KC, HS_MC, n, n, n, 1.0, B.X, n, B.A0, n, 0.0, B.T1, n) );
+         HS_CALL( gemm(s, HS_KC, HS_MC, n, n, n, 1.0, B.T1, n, B.Zinv, n, 0.0, B.W, n) );
+         HS_CALL( pass_A(s, B, B.W, s->tmpe) );
+         hipLaunchKernelGGL(k_add_col0, g1d(m1), dim3(256), 0, st, m1, s->tmpe, s->Mx);
+         HS_LAUNCH_CHECK();
+         HS_CALL( hs_sp_schur(st, B.sp, B.X, B.Zinv, s->Mx) );
       }
       if ( q > 0 )
       {

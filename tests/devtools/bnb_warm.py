@@ -1,7 +1,7 @@
 """developer script: B&B with warm-started nodes (tests/warm_bnb.py), iteration counts for several interior factors"""
 import sys, os, time, importlib.util
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(ROOT, 'oracle')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, os.path.join(ROOT, 'oracle')); sys.path.insert(0, os.path.join(ROOT, 'tests', 'harness')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 spec = importlib.util.spec_from_file_location('hipsdp_binding', os.path.join(ROOT, 'scip-sdp_amd', 'binding.py'))
 hb = importlib.util.module_from_spec(spec); spec.loader.exec_module(hb)
 import bnb, sdpa_io, warm_bnb

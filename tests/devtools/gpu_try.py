@@ -1,7 +1,7 @@
 """developer smoke script: unit kernels vs numpy, solves vs the oracle (run on the GPU box)"""
 import sys, os, time, importlib.util
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+sys.path.insert(0, os.path.join(ROOT, 'oracle')); sys.path.insert(0, os.path.join(ROOT, 'tests', 'harness'))
 spec = importlib.util.spec_from_file_location('hipsdp_binding', os.path.join(ROOT, 'scip-sdp_amd', 'binding.py'))
 hb = importlib.util.module_from_spec(spec); spec.loader.exec_module(hb)
 import numpy as np

@@ -1,7 +1,7 @@
 """time stamps inside k_lmin_tiny (build of eig.hip with -DEIG_TIMING, HIPSDP_LIB=...): products / tridiagonalisation / setup / multisection"""
 import ctypes as C, importlib.util, os, sys
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
-sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests", "harness")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 spec = importlib.util.spec_from_file_location("hipsdp_binding", os.path.join(ROOT, "scip-sdp_amd", "binding.py"))
 hb = importlib.util.module_from_spec(spec); spec.loader.exec_module(hb)
 import numpy as np, bnb, sdpa_io, sdpi_call

@@ -2,7 +2,7 @@
 """mkp_dbg.py [instance] - developer tool: solve a golden instance on the GPU engine and print the full certificate check"""
 import os, sys, json, types
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests", "harness")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import importlib.util
 spec = importlib.util.spec_from_file_location("hipsdp_binding", os.path.join(ROOT, "scip-sdp_amd", "binding.py"))
 hb = importlib.util.module_from_spec(spec); spec.loader.exec_module(hb)

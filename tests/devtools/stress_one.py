@@ -2,7 +2,7 @@
 """stress_one.py SEED [settings] - developer tool: one problem of the stress family (tests/stress_cases.py) on engine and oracle, verbose"""
 import os, sys, importlib.util
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests", "harness")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 spec = importlib.util.spec_from_file_location("hipsdp_binding", os.path.join(ROOT, "scip-sdp_amd", "binding.py"))
 hb = importlib.util.module_from_spec(spec); spec.loader.exec_module(hb)
 import numpy as np, ipm_ref, stress_cases

@@ -3,7 +3,7 @@ MISDP optima of check/testset/short.solu on the reference's example instances WI
 BASELINE configs 3 and 5).  The node relaxation solver is pluggable: the HIP backend through the SCIPsdpiSolver* boundary
 (tests/test_gpu_bnb.py) or the numpy oracle (CPU test).  Branching: most fractional integer variable, child with the
 rounded-down bound first or second depending on the fraction.  No cuts, no heuristics, no presolve beyond
-oracle/sdpi_prepare.py - this is a parity harness, not a solver."""
+tests/harness/sdpi_prepare.py - this is a parity harness, not a solver."""
 import math
 import numpy as np
 import sdpi_prepare

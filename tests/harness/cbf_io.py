@@ -1,4 +1,4 @@
-"""cbf_io.py - TEST INFRASTRUCTURE (oracle side).  Reader of the subset of the Conic Benchmark Format that SCIP-SDP's
+"""cbf_io.py - TEST INFRASTRUCTURE (harness: host-side driver code, no arithmetic of the path).  Reader of the subset of the Conic Benchmark Format that SCIP-SDP's
 dual-form examples use (format: /root/reference/src/scipsdp/reader_cbf.c:33-80 and the CBF 1 specification it cites):
 
    VER, OBJSENSE MIN|MAX, VAR (cones F, L+, L-, L=), INT, CON (cones L+, L-, L=), PSDCON,
@@ -9,7 +9,7 @@ meaning   min/max  sum_j c_j x_j + c_0   s.t.  sum_j a_ij x_j + b_i  in  K_i   (
 
 PSDVAR / FCOORD / OBJFCOORD (primal-form matrix variables), quadratic cones and rank-1 sections are not read: the reference
 reformulates those inside its reader, which is outside the solver-interface path.  read_cbf returns an SdpiProblem
-(oracle/sdpi_prepare.py) plus the integer variables and the objective constant / sense, i.e. what reader_cbf.c hands to
+(tests/harness/sdpi_prepare.py) plus the integer variables and the objective constant / sense, i.e. what reader_cbf.c hands to
 cons_sdp + the LP rows."""
 import numpy as np
 import sdpi_prepare

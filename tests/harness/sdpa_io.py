@@ -1,4 +1,4 @@
-"""sdpa_io.py - TEST INFRASTRUCTURE (oracle side).  Minimal reader of the SDPA sparse format with SCIP-SDP's '*INTEGER'
+"""sdpa_io.py - TEST INFRASTRUCTURE (harness: host-side driver code, no arithmetic of the path).  Minimal reader of the SDPA sparse format with SCIP-SDP's '*INTEGER'
 extension (format description: /root/reference/sdpa_format.txt:22-61; reference reader: src/scipsdp/reader_sdpa.c).
 
    min b^T y  s.t.  sum_i A_i^k y_i - A_0^k psd (k = SDP blocks),   sum_i d_ri y_i - d_r0 >= 0 (rows of the LP block)

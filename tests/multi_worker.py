@@ -19,7 +19,7 @@ import sys
 # sharded code these tests are about would never execute
 os.environ.setdefault("HIPSDP_SHARD_MIN_FLOPS", "0")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests", "harness"))
 spec = importlib.util.spec_from_file_location("hipsdp_binding", os.path.join(ROOT, "scip-sdp_amd", "binding.py"))
 hb = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(hb)

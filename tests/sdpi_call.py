@@ -1,6 +1,6 @@
 """sdpi_call.py - ctypes marshalling of the 48-argument SCIPsdpiSolverLoadAndSolveWithPenalty call
 (include/sdpisolver_hip.h; reference signature src/sdpi/sdpisolver.h:258-322) for the tests.  The arguments come from
-oracle/sdpi_prepare.prepare(), i.e. they look like what sdpi.c:3399-3405 passes."""
+tests/harness/sdpi_prepare.prepare(), i.e. they look like what sdpi.c:3399-3405 passes."""
 import ctypes as C
 import numpy as np
 

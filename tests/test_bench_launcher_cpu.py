@@ -52,3 +52,31 @@ def test_more_ranks_than_gpus_is_refused_before_anything_runs():
     assert r.returncode == 3
     assert "only %d GPU(s) are visible" % have in r.stderr
     assert r.stdout.strip() == ""
+
+
+def test_the_parent_counts_gpus_without_loading_the_hip_runtime():
+    """the parent of the ranks must not have initialised the GPU when it starts the launcher: it counts devices from the KFD topology
+    in sysfs (or in a throw-away child), so neither libamdhip64 nor torch is in its address space at that point"""
+    r = _run(["--gpus", "64"], _clean_env(BENCH_REPORT_MAPS="1"))
+    assert r.returncode == 3                                # 64 GPUs are not there: refused before anything runs
+    line = [ln for ln in r.stderr.splitlines() if "parent maps:" in ln]
+    assert len(line) == 1, r.stderr
+    rep = json.loads(line[0].split("parent maps:", 1)[1])
+    assert rep["hip_mapped"] is False and rep["torch_imported"] is False
+    assert rep["visible_gpus"] < 64
+
+
+def test_visible_device_variables_restrict_the_count():
+    r = _run(["--gpus", "2"], _clean_env(BENCH_REPORT_MAPS="1", HIP_VISIBLE_DEVICES="0"))
+    assert r.returncode == 3
+    rep = json.loads([ln for ln in r.stderr.splitlines() if "parent maps:" in ln][0].split("parent maps:", 1)[1])
+    assert rep["visible_gpus"] <= 1
+
+
+def test_schur_form_reaches_the_ranks():
+    """--schur-form is part of the command line every rank gets (the scaling run can ask for north_star's rows + all-gather form)"""
+    r = _run(["--gpus", "2", "--launch-dry-run", "--schur-form", "rows"], _clean_env())
+    assert r.returncode == 0, r.stderr
+    assert "--schur-form rows" in r.stderr
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
+    assert out["schur_form"] == "rows"

@@ -64,7 +64,7 @@ def test_bnb_reproduces_short_solu(gpu, name):
     assert failed == 0
 
 
-# dual-form CBF examples (oracle/cbf_io.py): check/testset/short.solu:2,10,11,16
+# dual-form CBF examples (tests/harness/cbf_io.py): check/testset/short.solu:2,10,11,16
 CBF_SOLU = {"example_small_cbf.cbf": -8.0, "example_cbf_dual.cbf": 4.0, "example_multaggr.cbf": -1.0,
             "example_diagzeroimpl.cbf": -1.0}
 

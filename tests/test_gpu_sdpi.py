@@ -1,5 +1,5 @@
 """GPU tests at the drop-in boundary: the reference's SDPI known-answer tests (unittests/src/checksdpi.c) driven through
-SCIPsdpiSolverLoadAndSolve[WithPenalty] of libhipsdp.so with arguments prepared like sdpi.c does (oracle/sdpi_prepare.py),
+SCIPsdpiSolverLoadAndSolve[WithPenalty] of libhipsdp.so with arguments prepared like sdpi.c does (tests/harness/sdpi_prepare.py),
 asserting what solveTest() asserts (checksdpi.c:125-364) at the same EPS = 1e-6."""
 import ctypes as C
 import json

@@ -1,4 +1,4 @@
-"""CPU tests: the oracle (oracle/ipm_ref.py + oracle/sdpi_prepare.py) against the reference's known answers and against
+"""CPU tests: the oracle (oracle/ipm_ref.py + tests/harness/sdpi_prepare.py) against the reference's known answers and against
 algorithm-independent certificates.  This is what pins the oracle (prompt section 3): if these fail, no GPU parity claim
 means anything."""
 import json

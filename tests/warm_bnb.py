@@ -74,7 +74,7 @@ def warm_node_solver(lib, tol, lam, use_objlimit=False):
     s = sdpi_call.SdpiSolver(lib)
     for par in (1, 2, 3):
         assert s.set_real(par, tol) == sdpi_call.SCIP_OKAY
-    stats = dict(calls=0, iters=0, warm=0, time=0.0, cutoff=0)
+    stats = dict(calls=0, iters=0, warm=0, time=0.0, cutoff=0, wall=0.0)
 
     def solve(P):
         prob = P.prob
@@ -85,7 +85,10 @@ def warm_node_solver(lib, tol, lam, use_objlimit=False):
         if use_objlimit:
             cut = getattr(P, "cutoff", np.inf)
             assert s.set_real(4, cut if np.isfinite(cut) else INF) == sdpi_call.SCIP_OKAY
+        import time
+        t0 = time.perf_counter()
         rc, _, _ = s.solve(P, start=start)
+        stats["wall"] += time.perf_counter() - t0
         assert rc == sdpi_call.SCIP_OKAY
         stats["calls"] += 1
         stats["iters"] += s.iterations()
