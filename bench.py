@@ -78,6 +78,30 @@ def planted_pair(n, m, seed):
     return Xs, Zs, ys
 
 
+def host_cpu_share():
+    """cores this process may actually use: the affinity mask, cut by the cgroup's CPU quota (a GPU box hands a job a share of its
+    host cores; BLAS threads beyond it only fight each other)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(solver, b, n, m, gpu_iterations, budget_iters=None):
     """CPU restatement (numpy / scipy level-3 BLAS on all host cores) of the same algorithm on the same bits, with the Schur assembly
     in the SAME formulation as the device path (W_j = G A_j R by two DTRMM over stacks, Mx = W W^T by one DSYRK:
@@ -88,17 +112,22 @@ def cpu_baseline(solver, b, n, m, gpu_iterations, budget_iters=None):
     if budget_iters is None:
         # about 10-30 s of CPU work: 4 iterations at C2 (5e11 flop each in this formulation), 1 at T1 (8e12)
         budget_iters = 4 if 4.0 * m * n ** 3 + float(m) ** 2 * n ** 2 < 2e12 else 1
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count() or 1
+    threads = host_cpu_share()
     A = solver.get_block_dense(0)
     core = ipm_ref.CoreProblem(b, [A])
     par = ipm_ref.Params(gaptol=1e-5, feastol=1e-5, maxiter=budget_iters)
     par.schur = "W"
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=threads)
+    except Exception:
+        limiter = None
     t0 = time.perf_counter()
-    res = ipm_ref.hsd_solve(core, par)
+    try:
+        res = ipm_ref.hsd_solve(core, par)
+    finally:
+        if limiter is not None:
+            limiter.restore_original_limits() if hasattr(limiter, "restore_original_limits") else None
     dt = time.perf_counter() - t0
     its = max(1, res.iterations)
     per_iter = dt / its
@@ -125,6 +154,8 @@ def parse_args(argv=None):
     ap.add_argument("--m", type=int, default=1000)
     ap.add_argument("--seed", type=int, default=20240)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--density", type=float, default=0.1,
+                    help="density of the matrices in the `density` sub-object (SURVEY.md 8(d): 0.1); the headline run is dense")
     ap.add_argument("--no-extras", action="store_true", help="skip the t1 / sdpi_boundary / warm_start / phases sub-objects")
     ap.add_argument("--shard-matrices", choices=["auto", "on", "off"], default="auto",
                     help="N > 1: constraint matrices sharded by variable (auto: when the replicated matrices would not fit)")
@@ -325,6 +356,61 @@ def bench_t1(hb, seed, barrier, cpu=False):
         return out
     finally:
         s.close()
+
+
+def bench_density(hb, n, m, seed, density, barrier):
+    """SURVEY.md 8(d)'s rho = 0.1 variant of the same workload: the matrices A_i have that density (device generator), everything else
+    as in the headline run.  At this density the dense formulation is still the cheaper one (4 (sum nnz)^2 = 6e16 against 7.5e11), so
+    the block stays dense and the time per solve is the headline's; the sparse storage of csrc/sparse.hip takes over where the
+    reference's real instances live (a few nonzeros per matrix): second entry, n = 500, m = 2000, 3 nonzeros per matrix."""
+    out = {}
+    s = hb.Solver(0)
+    try:
+        s.set_shape(m, [n], 0)
+        Xs, Zs, ys = planted_pair(n, m, seed)
+        b = s.gen_planted_density(n, m, seed, density, Xs, Zs, ys)
+        opt = float(b @ ys)
+        infos, el = run_solves(s, 3, 1, barrier)
+        out["dense_block_density_%g" % density] = {
+            "n": n, "m": m, "solves_per_sec": len(infos) / el, "iterations_per_solve": sum(i.iterations for i in infos) / len(infos),
+            "matches_planted_optimum": bool(all(i.status == 0 for i in infos) and abs(infos[-1].dobj - opt) <= 1e-5 * (1 + abs(opt))),
+            "storage": "dense (cost rule: pair formula %.1e multiply-adds against %.1e)" % (
+                4.0 * (density * n * (n + 1) / 2 * m) ** 2, 4.0 * (m + 1) * n ** 3 + float(m + 1) ** 2 * n ** 2)}
+    finally:
+        s.close()
+    # the sparse regime: triplets from the host (6000 of them), kept as nonzeros by the engine
+    rng = np.random.default_rng(seed)
+    n2, m2, k = 500, 2000, 3
+    var = np.repeat(np.arange(1, m2 + 1, dtype=np.int32), k)
+    r = rng.integers(0, n2, size=m2 * k)
+    c = rng.integers(0, n2, size=m2 * k)
+    c[::k] = r[::k]                                                  # one diagonal entry per matrix
+    row, col = np.maximum(r, c).astype(np.int32), np.minimum(r, c).astype(np.int32)
+    key = var.astype(np.int64) * n2 * n2 + row.astype(np.int64) * n2 + col
+    _, first = np.unique(key, return_index=True)
+    var, row, col = var[first], row[first], col[first]
+    val = rng.standard_normal(len(var))
+    Xs, Zs, ys = planted_pair(n2, m2, seed + 1)
+    A0 = -Zs.copy()
+    w = val * ys[var - 1]
+    np.add.at(A0, (row, col), w)
+    off = row != col
+    np.add.at(A0, (col[off], row[off]), w[off])
+    A0 = 0.5 * (A0 + A0.T)
+    b = np.bincount(var - 1, weights=val * Xs[row, col] * np.where(off, 2.0, 1.0), minlength=m2)
+    opt = float(b @ ys)
+    s = hb.Solver(0)
+    try:
+        s.load_sparse(m2, n2, b, (var, row, col, val), A0)
+        infos, el = run_solves(s, 5, 1, barrier)
+        out["sparse_block_3_nonzeros_per_matrix"] = {
+            "n": n2, "m": m2, "kept_as_nonzeros": bool(s.is_sparse(0)), "solves_per_sec": len(infos) / el,
+            "iterations_per_solve": sum(i.iterations for i in infos) / len(infos),
+            "matches_planted_optimum": bool(all(i.status == 0 for i in infos) and abs(infos[-1].dobj - opt) <= 1e-5 * (1 + abs(opt))),
+            "dense_storage_would_be_GB": 8.0 * (m2 + 1) * n2 * n2 / 1e9}
+    finally:
+        s.close()
+    return out
 
 
 def bench_warm_start(solver, n, m, b, barrier, cold_iters):
@@ -675,6 +761,10 @@ def main():
         except Exception as e:
             out["t1"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_extras and ok and (n, m) == (500, 1000):
+        try:
+            out["density"] = bench_density(hb, n, m, args.seed, args.density, barrier)
+        except Exception as e:
+            out["density"] = {"error": repr(e)}
         try:
             out["bnb"] = bench_bnb(hb, cpu=not args.no_cpu)
         except Exception as e:

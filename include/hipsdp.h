@@ -107,6 +107,10 @@ int  hipsdp_set_shape(hipsdp_solver* solver, int m, int nblocks, const int* bloc
  * hipsdp_add_entries only (not hipsdp_set_block_dense / hipsdp_master_gather / hipsdp_gen_planted). */
 int  hipsdp_set_shape2(hipsdp_solver* solver, int m, int nblocks, const int* blocksizes, int q, const long long* nnz);
 int  hipsdp_block_is_sparse(hipsdp_solver* solver, int block);
+/* 0: never keep a block as nonzeros, 1 (default; environment HIPSDP_SPARSE): by the cost rule above, 2: whenever a count is given */
+int  hipsdp_sparse_policy(hipsdp_solver* solver, int mode);
+/* free and total bytes of the device's memory (tests: what a problem allocates) */
+int  hipsdp_mem_info(int device, double* free_bytes, double* total_bytes);
 /* objective b[m] (host) */
 int  hipsdp_set_obj(hipsdp_solver* solver, const double* b);
 /* Scatter lower-triangular COO entries (row >= col) into block k: entry e belongs to matrix var[e] (0 = constant matrix,
@@ -224,6 +228,11 @@ int  hipsdp_comm_create_host(const char* name, int rank, int nranks, long long s
  * returned in b_out[m].  Xstar, Zstar: n x n host arrays; ystar: m host values. */
 int  hipsdp_gen_planted(hipsdp_solver* solver, int n, int m, long long seed, const double* Xstar, const double* Zstar,
    const double* ystar, double* b_out);
+/* the same with matrices of the given density (0 < density <= 1: an off-diagonal entry is nonzero with that probability; SURVEY.md
+ * 8(d) names rho = 0.1).  The storage and the assembly stay the dense ones: below the density where the pair formula over nonzeros
+ * wins (hipsdp_set_shape2) the three GEMMs are the cheaper formulation whatever the zeros */
+int  hipsdp_gen_planted_density(hipsdp_solver* solver, int n, int m, long long seed, double density, const double* Xstar,
+   const double* Zstar, const double* ystar, double* b_out);
 /* copies block k's dense storage A[(m+1) * n * n] back to the host (used to hand identical bits to the CPU baseline) */
 int  hipsdp_get_block_dense(hipsdp_solver* solver, int block, double* A);
 

@@ -59,3 +59,50 @@ def planted_dense(n, m, seed=20240, rank_frac=0.25):
     A[0] = 0.5 * (A[0] + A[0].T)
     b = A[1:].reshape(m, -1) @ Xs.reshape(-1)
     return b, A, ys, Xs, Zs
+
+
+def planted_sparse(n, m, nnz_per_matrix, seed=20240, rank_frac=0.25):
+    """The same planted optimum with SPARSE constraint matrices: A_i (i >= 1) has nnz_per_matrix lower-triangular nonzeros at
+    random positions (one of them on the diagonal), values N(0, 1) - what the reference's instances look like (1-10 nonzeros per
+    matrix) and what both of its backends pass on as triplets (sdpisolver_dsdp.c:1126-1195, sdpisolver_sdpa.cpp:1223-1267).
+    Returns (b[m], coo, A0[n, n], ystar, Xstar, Zstar) with coo = (var[1..m], row, col, val) of the variables' matrices,
+    row >= col; the constant matrix A0 = sum_i A_i y*_i - Z* is dense."""
+    rng = np.random.default_rng(seed)
+    var, row, col, val = [], [], [], []
+    for i in range(1, m + 1):
+        seen = set()
+        d = int(rng.integers(0, n))
+        seen.add((d, d))
+        while len(seen) < nnz_per_matrix:
+            r, c = int(rng.integers(0, n)), int(rng.integers(0, n))
+            seen.add((max(r, c), min(r, c)))
+        for (r, c) in sorted(seen):
+            var.append(i); row.append(r); col.append(c); val.append(float(rng.standard_normal()))
+    var = np.array(var, dtype=np.int32); row = np.array(row, dtype=np.int32); col = np.array(col, dtype=np.int32)
+    val = np.array(val)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    r = max(1, int(round(n * rank_frac)))
+    ev = 1.0 + rng.random(n)
+    Xs = (Q * np.where(np.arange(n) < r, ev, 0.0)) @ Q.T
+    Zs = (Q * np.where(np.arange(n) < r, 0.0, ev)) @ Q.T
+    ys = 2.0 * rng.random(m) - 1.0
+    A0 = -Zs.copy()
+    w = val * ys[var - 1]
+    np.add.at(A0, (row, col), w)
+    off = row != col
+    np.add.at(A0, (col[off], row[off]), w[off])
+    A0 = 0.5 * (A0 + A0.T)
+    # b_i = <A_i, X*>: off-diagonal entries count twice
+    contrib = val * Xs[row, col] * np.where(off, 2.0, 1.0)
+    b = np.bincount(var - 1, weights=contrib, minlength=m)
+    return b, (var, row, col, val), A0, ys, Xs, Zs
+
+
+def coo_to_dense(n, m, coo, A0):
+    """dense [m + 1, n, n] array of a planted_sparse instance (for the dense paths and the oracle)"""
+    var, row, col, val = coo
+    A = np.zeros((m + 1, n, n))
+    A[0] = A0
+    A[var, row, col] = val
+    A[var, col, row] = val
+    return A

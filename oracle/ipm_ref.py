@@ -98,6 +98,24 @@ def schur_block(A, X, Zinv):
     return 0.5 * (Mx + Mx.T)
 
 
+def schur_pairs_sparse(m, coo, X, Zinv):
+    """Schur entries tr(A_i X A_j Zinv), i, j = 1 .. m, from the nonzeros alone - the formula of scip-sdp_amd/csrc/sparse.hip
+    (SDPA's F3 case): with e = (p, q, a) in A_i and f = (r, s, b) in A_j (lower triangles, off-diagonal entries stand for both
+    positions)   sum_e sum_f a b (X_qr Zinv_sp + [p != q] X_pr Zinv_sq + [r != s] X_qs Zinv_rp + [p != q][r != s] X_ps Zinv_rq).
+    Vectorised over all pairs of entries (fine for the sizes the CPU tests use).  Returns the m x m matrix."""
+    var, row, col, val = coo
+    p, q = row[:, None], col[:, None]
+    r, s = row[None, :], col[None, :]
+    w = X[q, r] * Zinv[s, p]
+    w = w + np.where(p != q, X[p, r] * Zinv[s, q], 0.0)
+    w = w + np.where(r != s, X[q, s] * Zinv[r, p], 0.0)
+    w = w + np.where((p != q) & (r != s), X[p, s] * Zinv[r, q], 0.0)
+    w = w * (val[:, None] * val[None, :])
+    M = np.zeros((m, m))
+    np.add.at(M, (var[:, None] - 1 + 0 * var[None, :], 0 * var[:, None] + var[None, :] - 1), w)
+    return M
+
+
 def schur_block_w(A, Lx, Lz):
     """The same matrix through the W formulation of the device path (csrc/schur.hip: hs_schur_W) with the triangular savings kept,
     for the CPU baseline of bench.py: X = R R^T (R = chol X), Z^-1 = G^T G (G = inverse of chol Z), W_j = G A_j R,

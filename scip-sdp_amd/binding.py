@@ -83,10 +83,35 @@ class Solver:
         except Exception:
             pass
 
-    def set_shape(self, m, blocksizes, q):
+    def set_shape(self, m, blocksizes, q, nnz=None):
+        """nnz: lower-triangular triplets the caller is going to add per block (hipsdp_set_shape2: a block whose count makes the
+        pair formula the cheaper Schur assembly is kept as nonzeros)"""
         bs = np.asarray(blocksizes, dtype=np.int32)
-        _chk(lib().hipsdp_set_shape(self.h, m, len(bs), _ip(bs), q), "hipsdp_set_shape")
+        if nnz is None:
+            _chk(lib().hipsdp_set_shape(self.h, m, len(bs), _ip(bs), q), "hipsdp_set_shape")
+        else:
+            cnt = np.ascontiguousarray(nnz, dtype=np.int64)
+            assert len(cnt) == len(bs)
+            _chk(lib().hipsdp_set_shape2(self.h, m, len(bs), _ip(bs), q, cnt.ctypes.data_as(C.POINTER(C.c_longlong))), "hipsdp_set_shape2")
         self.m, self.ns, self.q = m, [int(v) for v in bs], q
+
+    def sparse_policy(self, mode):
+        _chk(lib().hipsdp_sparse_policy(self.h, mode), "hipsdp_sparse_policy")
+
+    def is_sparse(self, k):
+        return bool(lib().hipsdp_block_is_sparse(self.h, k))
+
+    def load_sparse(self, m, n, b, coo, A0):
+        """one block given as triplets of the variables' matrices (var 1 .. m, row >= col) and a dense constant matrix"""
+        var, row, col, val = coo
+        il = np.tril_indices(n)
+        c0 = A0[il]
+        keep = c0 != 0.0
+        self.set_shape(m, [n], 0, nnz=[len(val) + int(keep.sum())])
+        self.set_obj(b)
+        self.add_entries(0, np.concatenate([np.zeros(int(keep.sum()), dtype=np.int32), var]),
+                         np.concatenate([il[0][keep].astype(np.int32), row]), np.concatenate([il[1][keep].astype(np.int32), col]),
+                         np.concatenate([c0[keep], val]))
 
     def set_obj(self, b):
         b = _f64(b)
@@ -120,6 +145,13 @@ class Solver:
         b = np.zeros(m)
         _chk(lib().hipsdp_gen_planted(self.h, n, m, C.c_longlong(seed), _dp(Xstar), _dp(Zstar), _dp(ystar), _dp(b)),
              "hipsdp_gen_planted")
+        return b
+
+    def gen_planted_density(self, n, m, seed, density, Xstar, Zstar, ystar):
+        Xstar, Zstar, ystar = _f64(Xstar), _f64(Zstar), _f64(ystar)
+        b = np.zeros(m)
+        _chk(lib().hipsdp_gen_planted_density(self.h, n, m, C.c_longlong(seed), C.c_double(density), _dp(Xstar), _dp(Zstar), _dp(ystar),
+                                              _dp(b)), "hipsdp_gen_planted_density")
         return b
 
     def get_block_dense(self, k):

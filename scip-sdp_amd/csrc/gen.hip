@@ -28,7 +28,9 @@ __device__ __forceinline__ double counter_normal(unsigned long long seed, unsign
 }
 
 /* A_i = (G_i + G_i^T) / sqrt(2 n), G_i lower triangular with N(0,1) entries drawn at packed index r (r + 1) / 2 + c */
-__global__ void k_gen_dense(int n, int i0, int cnt, unsigned long long seed, double scale, double* __restrict__ A)
+/* density < 1 (rho = 0.1 variant): an off-diagonal entry is kept with that probability (its own counter stream),
+ * the diagonal always; kept entries are scaled by 1 / sqrt(rho) so that the matrices keep their norm */
+__global__ void k_gen_dense(int n, int i0, int cnt, unsigned long long seed, double scale, double density, double* __restrict__ A)
 {
    const long long n2 = (long long) n * n;
    const long long total = (long long) cnt * n2;
@@ -40,12 +42,22 @@ __global__ void k_gen_dense(int n, int i0, int cnt, unsigned long long seed, dou
       const int r = r0 > c0 ? r0 : c0;
       const int c = r0 > c0 ? c0 : r0;
       const unsigned long long idx = (unsigned long long) r * (unsigned long long) (r + 1) / 2ULL + (unsigned long long) c;
-      const double g = counter_normal(seed + (unsigned long long) i, idx);
+      double g = counter_normal(seed + (unsigned long long) i, idx);
+      if ( density < 1.0 && r != c && counter_uniform(seed + 7777777ULL + (unsigned long long) i, idx) >= density )
+         g = 0.0;
       A[(long long) i * n2 + e] = (r == c ? 2.0 : 1.0) * g * scale;
    }
 }
 
 /* the matrices A_i, i0 <= i < i1 (i >= 1), written to A + i n^2 */
+static thread_local double g_gen_density = 1.0;
+
+/* density of the matrices the next hs_gen_dense calls of this thread generate (1: dense) */
+void hs_gen_set_density(double density)
+{
+   g_gen_density = (density > 0.0 && density < 1.0) ? density : 1.0;
+}
+
 int hs_gen_dense(hipStream_t s, int n, int i0, int i1, long long seed, double* A)
 {
    if ( i1 <= i0 )
@@ -53,7 +65,8 @@ int hs_gen_dense(hipStream_t s, int n, int i0, int i1, long long seed, double* A
    const long long total = (long long) (i1 - i0) * n * n;
    long long g = (total + 255) / 256;
    if ( g > 65536 ) g = 65536;
-   hipLaunchKernelGGL(k_gen_dense, dim3((unsigned) g), dim3(256), 0, s, n, i0, i1 - i0, (unsigned long long) seed, 1.0 / sqrt(2.0 * (double) n), A);
+   hipLaunchKernelGGL(k_gen_dense, dim3((unsigned) g), dim3(256), 0, s, n, i0, i1 - i0, (unsigned long long) seed,
+      1.0 / sqrt(2.0 * (double) n * g_gen_density), g_gen_density, A);
    if ( hipGetLastError() != hipSuccess )
       return HS_ERR_HIP;
    return HS_OK;

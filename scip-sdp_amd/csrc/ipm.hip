@@ -109,6 +109,7 @@ struct hipsdp_solver
    hipEvent_t evFork, evJoin;
    bool use2;                    /* false for tiny blocks: they are launch bound and the cross-queue events only add latency */
    int m, q;
+   int sparse_policy;            /* 0: blocks are never kept as nonzeros, 1: when the caller's count makes it cheaper, 2: whenever a count is given */
    std::vector<Block> blk;
    double* b;        /* m */
    double* Dext;     /* q x (m + 1) */
@@ -387,6 +388,8 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
    s->beta = s->elp = s->dxa = s->dza = s->dx = s->dz = s->xs = s->zs = s->ys = s->u1 = s->rhs2 = s->cvec = s->u2 = s->dy = s->dya = NULL;
    s->Mx = s->Lm = s->dinvm = s->Slp = s->sc = s->red_ws = s->gemv_ws = s->lan_ws = s->lan_ws2 = s->gws1 = s->gws2 = NULL;
    hipsdp_default_params(&s->par);
+   s->sparse_policy = getenv("HIPSDP_SPARSE") != NULL ? atoi(getenv("HIPSDP_SPARSE")) : 1;
+   if ( s->sparse_policy < 0 || s->sparse_policy > 2 ) s->sparse_policy = 1;
    if ( hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess
       || hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking) != hipSuccess
       || hipEventCreateWithFlags(&s->evFork, hipEventDisableTiming) != hipSuccess
@@ -448,7 +451,7 @@ extern "C" void hipsdp_free(hipsdp_solver** ps)
  * is given (tests) */
 static bool block_wants_sparse(const hipsdp_solver* s, int n, int m, long long nnz)
 {
-   static const int mode = getenv("HIPSDP_SPARSE") != NULL ? atoi(getenv("HIPSDP_SPARSE")) : 1;
+   const int mode = s->sparse_policy;
    if ( mode == 0 || nnz < 0 || s->shardA_req > 0 )
       return false;
    if ( mode == 2 )
@@ -459,6 +462,29 @@ static bool block_wants_sparse(const hipsdp_solver* s, int n, int m, long long n
 extern "C" int hipsdp_set_shape(hipsdp_solver* s, int m, int nblocks, const int* blocksizes, int q)
 {
    return hipsdp_set_shape2(s, m, nblocks, blocksizes, q, NULL);
+}
+
+extern "C" int hipsdp_sparse_policy(hipsdp_solver* s, int mode)
+{
+   if ( s == NULL || mode < 0 || mode > 2 )
+      return HIPSDP_ERR_ARG;
+   s->sparse_policy = mode;
+   return HIPSDP_OK;
+}
+
+extern "C" int hipsdp_mem_info(int device, double* free_bytes, double* total_bytes)
+{
+   int nd = 0;
+   if ( hipGetDeviceCount(&nd) != hipSuccess || nd <= 0 )
+      return HIPSDP_ERR_NODEVICE;
+   if ( device < 0 || device >= nd )
+      return HIPSDP_ERR_ARG;
+   HS_HIP( hipSetDevice(device) );
+   size_t fr = 0, tot = 0;
+   HS_HIP( hipMemGetInfo(&fr, &tot) );
+   if ( free_bytes != NULL ) *free_bytes = (double) fr;
+   if ( total_bytes != NULL ) *total_bytes = (double) tot;
+   return HIPSDP_OK;
 }
 
 extern "C" int hipsdp_block_is_sparse(hipsdp_solver* s, int block)
@@ -1083,6 +1109,17 @@ extern "C" int hipsdp_gen_planted(hipsdp_solver* s, int n, int m, long long seed
    return HIPSDP_OK;
 }
 
+void hs_gen_set_density(double density);
+
+extern "C" int hipsdp_gen_planted_density(hipsdp_solver* s, int n, int m, long long seed, double density, const double* Xstar,
+   const double* Zstar, const double* ystar, double* b_out)
+{
+   hs_gen_set_density(density);
+   const int rc = hipsdp_gen_planted(s, n, m, seed, Xstar, Zstar, ystar, b_out);
+   hs_gen_set_density(1.0);
+   return rc;
+}
+
 extern "C" int hipsdp_get_block_dense(hipsdp_solver* s, int block, double* A)
 {
    if ( s == NULL || !s->shaped || block < 0 || block >= (int) s->blk.size() )
@@ -1368,6 +1405,13 @@ static int ensure_schur_ws(hipsdp_solver* s)
 {
    if ( s->sws.T != NULL )
       return HS_OK;
+   {
+      /* every block kept as nonzeros: the assembly needs no GEMM workspace (the split-K slabs alone would be 64 (m + 1)^2 doubles) */
+      bool anydense = false;
+      for (auto& B : s->blk) anydense = anydense || !B.sparse;
+      if ( !anydense && !s->blk.empty() )
+         return HS_OK;
+   }
    const int m1 = s->m + 1;
    long long n2max = 1;
    for (auto& B : s->blk) { const long long n2 = (long long) B.n * B.n; if ( !B.sparse && n2 > n2max ) n2max = n2; }

@@ -637,6 +637,10 @@ static SCIP_RETCODE loadBlocks(SCIP_SDPISOLVER* s, int nvars, int nsdpblocks, co
    int k;
    int t;
 
+   /* blocks the engine keeps as nonzeros are loaded directly (a few triplets per matrix: nothing a dense master copy would save) */
+   for (b = 0; b < nsdpblocks; ++b)
+      if ( s->blockmap[b] >= 0 && hipsdp_block_is_sparse(s->engine, s->blockmap[b]) )
+         usemaster = FALSE;
    tfp0 = clock();
    fp = sdpFingerprint(nvars, nsdpblocks, sdpblocksizes, sdpnblockvars, sdpnnonz, sdpnblockvarnonz, sdpvar, sdprow, sdpcol, sdpval);
    tfp1 = clock();
@@ -1116,7 +1120,30 @@ SCIP_RETCODE SCIPsdpiSolverLoadAndSolveWithPenalty(
          HSFREE(s, &engsizes, nsdpblocks);
          return erc;
       }
-      rc = hipsdp_set_shape(s->engine, nengvars, s->nengineblocks, engsizes, q);
+      {
+         /* nonzeros of the variables' matrices per engine block (what the reference backends hand their solver entry by entry:
+          * sdpisolver_dsdp.c:1126-1195, sdpisolver_sdpa.cpp:1223-1267): the engine keeps a block as triplets when that makes the
+          * Schur assembly cheaper than the dense formulation - no (m + 1) x n^2 array for matrices of a few nonzeros each */
+         long long* engnnz = (long long*) calloc((size_t) (nsdpblocks > 0 ? nsdpblocks : 1), sizeof(long long));
+         if ( engnnz != NULL )
+         {
+            int bb;
+            int kk;
+            for (bb = 0; bb < nsdpblocks; ++bb)
+            {
+               const int eb = s->blockmap[bb];
+               if ( eb < 0 )
+                  continue;
+               for (kk = 0; kk < sdpnblockvars[bb]; ++kk)
+                  if ( s->inputtoactive[sdpvar[bb][kk]] > 0 )
+                     engnnz[eb] += sdpnblockvarnonz[bb][kk];
+               if ( s->penalty )
+                  engnnz[eb] += s->compactsize[bb];
+            }
+         }
+         rc = hipsdp_set_shape2(s->engine, nengvars, s->nengineblocks, engsizes, q, engnnz);
+         free(engnnz);
+      }
       HSFREE(s, &engsizes, nsdpblocks);
       if ( rc != HIPSDP_OK )
       {

@@ -195,3 +195,34 @@ def test_eigenvector_cut_restatement_matches_the_sparse_formula():
             ents = [(r, cc, A[1 + i, r, cc]) for r in range(n) for cc in range(r + 1)]
             assert abs(eigcuts_ref.vAv_sparse(ents, v) - co[c, i]) <= 1e-12 * max(1.0, abs(co[c, i]))
         assert abs((co[c] @ y - lh[c]) - ev[c]) <= 1e-10
+
+
+def test_pair_formula_over_nonzeros_equals_the_dense_schur_formula():
+    """oracle/ipm_ref.schur_pairs_sparse (the formula of csrc/sparse.hip, SDPA's F3 case) against the three-product formula on the
+    dense expansion of the same matrices"""
+    import instances
+    rng = np.random.default_rng(4)
+    for n, m, k in ((12, 9, 1), (30, 25, 3), (41, 17, 20)):
+        b, coo, A0, ys, Xs, Zs = instances.planted_sparse(n, m, k, seed=n + m)
+        X = rng.standard_normal((n, n)); X = X @ X.T + n * np.eye(n)
+        Z = rng.standard_normal((n, n)); Z = Z @ Z.T + n * np.eye(n)
+        Zi = np.linalg.inv(Z)
+        M1 = ipm_ref.schur_block(instances.coo_to_dense(n, m, coo, A0), X, Zi)[1:, 1:]
+        M2 = ipm_ref.schur_pairs_sparse(m, coo, X, Zi)
+        assert np.max(np.abs(M1 - M2)) <= 1e-12 * np.max(np.abs(M1))
+        # and the planted optimum is what the oracle finds on the expansion
+        core = ipm_ref.CoreProblem(b, [instances.coo_to_dense(n, m, coo, A0)])
+        r = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-7, feastol=1e-7))
+        if k > 1:
+            assert r.status == 0 and abs(r.dobj - b @ ys) <= 1e-6 * (1 + abs(b @ ys))
+
+
+def test_w_formulation_of_the_cpu_baseline_equals_the_default_schur_formula():
+    rng = np.random.default_rng(2)
+    n, m1 = 37, 23
+    A = rng.standard_normal((m1, n, n)); A = A + A.transpose(0, 2, 1)
+    X = rng.standard_normal((n, n)); X = X @ X.T + n * np.eye(n)
+    Z = rng.standard_normal((n, n)); Z = Z @ Z.T + n * np.eye(n)
+    M1 = ipm_ref.schur_block(A, X, np.linalg.inv(Z))
+    M2 = ipm_ref.schur_block_w(A, np.linalg.cholesky(X), np.linalg.cholesky(Z))
+    assert np.max(np.abs(M1 - M2)) <= 1e-12 * np.max(np.abs(M1))
