@@ -21,6 +21,9 @@
 extern "C" {
 #endif
 
+/* libhipsdp.so is built with hidden visibility: only what this header declares is exported */
+#define HIPSDP_API __attribute__((visibility("default")))
+
 #define HIPSDP_OK             0
 #define HIPSDP_ERR_NODEVICE   1
 #define HIPSDP_ERR_HIP        2
@@ -88,105 +91,105 @@ typedef struct hipsdp_info
                                  * measured against; schur_flops is the algorithmic count */
 } hipsdp_info;
 
-const char* hipsdp_last_error(void);
-const char* hipsdp_version(void);
-int  hipsdp_device_count(void);
-void hipsdp_default_params(hipsdp_params* p);
+HIPSDP_API const char* hipsdp_last_error(void);
+HIPSDP_API const char* hipsdp_version(void);
+HIPSDP_API int  hipsdp_device_count(void);
+HIPSDP_API void hipsdp_default_params(hipsdp_params* p);
 
-int  hipsdp_create(hipsdp_solver** solver, int device);
-void hipsdp_free(hipsdp_solver** solver);
+HIPSDP_API int  hipsdp_create(hipsdp_solver** solver, int device);
+HIPSDP_API void hipsdp_free(hipsdp_solver** solver);
 
 /* Declares the shape: m variables, nblocks dense SDP blocks of the given sizes, q LP rows.  Allocates the device storage
  * A_k[(m+1) x n_k^2] (row i = vec(A_i), row 0 = constant matrix), zero filled. */
-int  hipsdp_set_shape(hipsdp_solver* solver, int m, int nblocks, const int* blocksizes, int q);
+HIPSDP_API int  hipsdp_set_shape(hipsdp_solver* solver, int m, int nblocks, const int* blocksizes, int q);
 /* The same with the number of lower-triangular triplets the caller is going to add per block (nnz[k] >= 0; NULL or a negative
  * entry: unknown).  A block whose count makes the pair formula over nonzeros the cheaper Schur assembly (4 (sum nnz)^2 multiply-adds
  * against 4 (m + 1) n^3 + (m + 1)^2 n^2; never for n <= 64) is kept SPARSE: no (m + 1) x n^2 array is allocated, the matrices of the
  * variables stay the triplets of hipsdp_add_entries (what the reference backends hand DSDP / SDPA:
  * sdpisolver_dsdp.c:1126-1195, sdpisolver_sdpa.cpp:1223-1267), the constant matrix a dense n x n array.  Such a block takes
  * hipsdp_add_entries only (not hipsdp_set_block_dense / hipsdp_master_gather / hipsdp_gen_planted). */
-int  hipsdp_set_shape2(hipsdp_solver* solver, int m, int nblocks, const int* blocksizes, int q, const long long* nnz);
-int  hipsdp_block_is_sparse(hipsdp_solver* solver, int block);
+HIPSDP_API int  hipsdp_set_shape2(hipsdp_solver* solver, int m, int nblocks, const int* blocksizes, int q, const long long* nnz);
+HIPSDP_API int  hipsdp_block_is_sparse(hipsdp_solver* solver, int block);
 /* 0: never keep a block as nonzeros, 1 (default; environment HIPSDP_SPARSE): by the cost rule above, 2: whenever a count is given */
-int  hipsdp_sparse_policy(hipsdp_solver* solver, int mode);
+HIPSDP_API int  hipsdp_sparse_policy(hipsdp_solver* solver, int mode);
 /* free and total bytes of the device's memory (tests: what a problem allocates) */
-int  hipsdp_mem_info(int device, double* free_bytes, double* total_bytes);
+HIPSDP_API int  hipsdp_mem_info(int device, double* free_bytes, double* total_bytes);
 /* objective b[m] (host) */
-int  hipsdp_set_obj(hipsdp_solver* solver, const double* b);
+HIPSDP_API int  hipsdp_set_obj(hipsdp_solver* solver, const double* b);
 /* Scatter lower-triangular COO entries (row >= col) into block k: entry e belongs to matrix var[e] (0 = constant matrix,
  * i = variable i, 1-based) at (row[e], col[e]); both triangles of the dense storage are written.  Host arrays. */
-int  hipsdp_add_entries(hipsdp_solver* solver, int block, long long nnz, const int* var, const int* row, const int* col,
+HIPSDP_API int  hipsdp_add_entries(hipsdp_solver* solver, int block, long long nnz, const int* var, const int* row, const int* col,
    const double* val);
 /* Master copy (optional, for callers that solve many nodes of one problem): the matrices of the variables in ORIGINAL block
  * sizes are uploaded once (COO, lower triangle) and stay in HBM across hipsdp_set_shape calls.  Block b has nblockvars[b] slots,
  * one per variable that appears in it (nblockvars == NULL: nvars slots per block); entries name their slot.  A node's compact
  * block is then filled on the device:  A_engine[a + 1][r][c] = master[slots[a]][kept[r]][kept[c]]  (slots[a] = -1: the
  * a-th active variable does not appear in the block, zeros).  HIPSDP_ERR_NOMEM from define leaves no master copy behind. */
-int  hipsdp_master_define(hipsdp_solver* solver, int nvars, int nblocks, const int* blocksizes, const int* nblockvars);
-int  hipsdp_master_add_entries(hipsdp_solver* solver, int block, long long nnz, const int* slot, const int* row, const int* col,
+HIPSDP_API int  hipsdp_master_define(hipsdp_solver* solver, int nvars, int nblocks, const int* blocksizes, const int* nblockvars);
+HIPSDP_API int  hipsdp_master_add_entries(hipsdp_solver* solver, int block, long long nnz, const int* slot, const int* row, const int* col,
    const double* val);
 /* the same upload straight from per-slot arrays (slot k: nnz[k] entries row[k][.], col[k][.], val[k][.] - the caller's
  * sdprow[b][k] / sdpcol[b][k] / sdpval[b][k] of sdpisolver.h:176-233), streamed through pinned staging chunks */
-int  hipsdp_master_add_vars(hipsdp_solver* solver, int block, int nslots, const int* nnz, const int* const* row,
+HIPSDP_API int  hipsdp_master_add_vars(hipsdp_solver* solver, int block, int nslots, const int* nnz, const int* const* row,
    const int* const* col, const double* const* val);
-int  hipsdp_master_gather(hipsdp_solver* solver, int engine_block, int master_block, int nactive, const int* slots,
+HIPSDP_API int  hipsdp_master_gather(hipsdp_solver* solver, int engine_block, int master_block, int nactive, const int* slots,
    int nkept, const int* kept);
 /* dense upload of a whole block: A[(m+1) * n * n] host, row-major */
-int  hipsdp_set_block_dense(hipsdp_solver* solver, int block, const double* A);
+HIPSDP_API int  hipsdp_set_block_dense(hipsdp_solver* solver, int block, const double* A);
 /* LP rows: Dext[q x (m+1)] host, row-major, column 0 = c (constant), columns 1..m = D */
-int  hipsdp_set_lp(hipsdp_solver* solver, const double* Dext);
+HIPSDP_API int  hipsdp_set_lp(hipsdp_solver* solver, const double* Dext);
 /* device-resident access for generators / benchmarks: pointer to A_k on the device */
-int  hipsdp_block_device_ptr(hipsdp_solver* solver, int block, double** dptr);
+HIPSDP_API int  hipsdp_block_device_ptr(hipsdp_solver* solver, int block, double** dptr);
 
 /* optional warm start (host arrays; X, Z: nblocks dense n_k x n_k matrices; x, z: q) */
-int  hipsdp_set_start(hipsdp_solver* solver, const double* y, const double* const* X, const double* const* Z,
+HIPSDP_API int  hipsdp_set_start(hipsdp_solver* solver, const double* y, const double* const* X, const double* const* Z,
    const double* x, const double* z);
 
-int  hipsdp_solve(hipsdp_solver* solver, const hipsdp_params* params, hipsdp_info* info);
+HIPSDP_API int  hipsdp_solve(hipsdp_solver* solver, const hipsdp_params* params, hipsdp_info* info);
 
 /* solution readback (host arrays).  For STATUS_OPTIMAL the iterate scaled by 1 / tau; for the infeasibility statuses
  * the normalised ray. */
-int  hipsdp_get_y(hipsdp_solver* solver, double* y);
-int  hipsdp_get_X(hipsdp_solver* solver, int block, double* X);
-int  hipsdp_get_Z(hipsdp_solver* solver, int block, double* Z);
-int  hipsdp_get_lp(hipsdp_solver* solver, double* x, double* z);
+HIPSDP_API int  hipsdp_get_y(hipsdp_solver* solver, double* y);
+HIPSDP_API int  hipsdp_get_X(hipsdp_solver* solver, int block, double* X);
+HIPSDP_API int  hipsdp_get_Z(hipsdp_solver* solver, int block, double* Z);
+HIPSDP_API int  hipsdp_get_lp(hipsdp_solver* solver, double* x, double* z);
 /* the preoptimal iterate of the last solve (params.preoptgap > 0): *available = 0 when none was captured; y (m), x (q) and
  * X of a block as hipsdp_get_y / get_lp / get_X return the final ones; any output pointer may be NULL */
-int  hipsdp_get_preoptimal(hipsdp_solver* solver, int* available, double* y, double* x);
-int  hipsdp_get_preoptimal_X(hipsdp_solver* solver, int block, double* X);
+HIPSDP_API int  hipsdp_get_preoptimal(hipsdp_solver* solver, int* available, double* y, double* x);
+HIPSDP_API int  hipsdp_get_preoptimal_X(hipsdp_solver* solver, int block, double* X);
 
 /* smallest eigenvalue of  sum_i A_i^k y_i - A_0^k  for every block, on the device (backs the feasibility check of
  * sdpsolchecker.c:201-257 inside the backend); y: m host values; lmin: nblocks host values */
-int  hipsdp_check_y(hipsdp_solver* solver, const double* y, double* lmin, double* lpviol);
+HIPSDP_API int  hipsdp_check_y(hipsdp_solver* solver, const double* y, double* lmin, double* lpviol);
 /* the same against a known tolerance: blocks above 64 rows are certified by one Cholesky factorization of Z(y) + 0.999 tol I
  * (lmin = -0.999 tol on success: a rigorous lower bound that passes "lmin >= -tol"); the exact eigenvalue is computed only when
  * that fails */
-int  hipsdp_check_y_tol(hipsdp_solver* solver, const double* y, double tol, double* lmin, double* lpviol);
+HIPSDP_API int  hipsdp_check_y_tol(hipsdp_solver* solver, const double* y, double tol, double* lmin, double* lpviol);
 
 /* Several ranks making the same calls (SPMD): *flag becomes rank 0's value on every rank, so that decisions taken from a host
  * clock (time limits) are the same everywhere and no rank is left alone in a collective.  One rank / no communicator: no-op. */
-int  hipsdp_sync_flag(hipsdp_solver* solver, int* flag);
+HIPSDP_API int  hipsdp_sync_flag(hipsdp_solver* solver, int* flag);
 
 /* Phase anatomy of the last hipsdp_solve (profiling on): device milliseconds between HIP events recorded at the phase
  * boundaries of the engine's main stream, summed over the iterations.  phases: 0 residuals + termination read-back,
  * 1 factorizations of X and Z, 2 Schur assembly, 3 Cholesky of M + the two solves + the tau-elimination pass, 4 predictor,
  * 5 corrector, 6 update with its Cholesky check.  The same boundaries are roctx ranges (rocprofv3 --marker-trace), always. */
 #define HIPSDP_NPHASES 7
-int  hipsdp_set_profiling(hipsdp_solver* solver, int on);
-int  hipsdp_get_phase_times(hipsdp_solver* solver, double* ms /* [HIPSDP_NPHASES] */);
-const char* hipsdp_phase_name(int phase);
+HIPSDP_API int  hipsdp_set_profiling(hipsdp_solver* solver, int on);
+HIPSDP_API int  hipsdp_get_phase_times(hipsdp_solver* solver, double* ms /* [HIPSDP_NPHASES] */);
+HIPSDP_API const char* hipsdp_phase_name(int phase);
 
 /* Eigenvector cuts for the LP-based mode (replaces the host loop of cons_sdp.c:896-1010 / :1612-1803 for one block): for every
  * eigenvector v of Z(y) = sum_i A_i y_i - A_0 of block `block` with eigenvalue <= -tol (most negative first, at most maxcuts)
  *     sum_i coefs[c][i] y_i >= lhs[c],   coefs[c][i] = v^T A_i v,  lhs[c] = v^T A_0 v
  * is violated at y by -eigvals[c].  y: m host values (engine variables); coefs: maxcuts x m; vecs: maxcuts x n or NULL. */
-int  hipsdp_eigencuts(hipsdp_solver* solver, int block, const double* y, double tol, int maxcuts, int* ncuts, double* eigvals,
+HIPSDP_API int  hipsdp_eigencuts(hipsdp_solver* solver, int block, const double* y, double tol, int maxcuts, int* ncuts, double* eigvals,
                       double* coefs, double* lhs, double* vecs);
 
 /* multi-GPU: Schur rows are sharded over the ranks of an RCCL communicator (one process per GPU); comm comes from hipsdp_comm_create[_host] */
 /* Small problems (one assembly below HIPSDP_SHARD_MIN_FLOPS, default 2e10 algorithmic flops) are not sharded: every rank solves
  * them alone with the single-rank kernels and rank 0's outcome (status, iterate, preoptimal iterate) is broadcast once per solve. */
-int  hipsdp_set_comm(hipsdp_solver* solver, void* comm, int rank, int nranks);
+HIPSDP_API int  hipsdp_set_comm(hipsdp_solver* solver, void* comm, int rank, int nranks);
 /* Constraint matrices sharded by variable ("A is sharded by variable when it cannot be replicated",
  * n = 4000 / m = 8000 is 1 TB of A): rank g of the communicator holds the matrices of the variables [g c, (g + 1) c),
  * c = ceil((m + 1) / ranks) (index 0 = the constant matrix, which every rank keeps as well); hipsdp_add_entries,
@@ -195,96 +198,99 @@ int  hipsdp_set_comm(hipsdp_solver* solver, void* comm, int rank, int nranks);
  * with one all-to-all per column slice (rank h receives its n / ranks rows of all W_j) and sums the partial Gram matrices.
  * mode 1: shard; -1: shard only when the replicated matrices would take more than 75 % of the device memory; 0: replicate
  * (default).  Call after hipsdp_set_comm and before hipsdp_set_shape; the mode applies to every later hipsdp_set_shape. */
-int  hipsdp_shard_matrices(hipsdp_solver* solver, int mode);
-int  hipsdp_matrices_sharded(hipsdp_solver* solver);       /* what the last hipsdp_set_shape decided: 1 sharded, 0 replicated */
+HIPSDP_API int  hipsdp_shard_matrices(hipsdp_solver* solver, int mode);
+HIPSDP_API int  hipsdp_matrices_sharded(hipsdp_solver* solver);       /* what the last hipsdp_set_shape decided: 1 sharded, 0 replicated */
 /* measurement transport: a communicator of nranks ranks of which only `rank` exists - collectives move nothing, results are
  * meaningless; it times one rank's share of a sharded solve at sizes that need several GPUs (tests/devtools/shard_time.py) */
-int  hipsdp_comm_create_null(int rank, int nranks, void** comm);
+HIPSDP_API int  hipsdp_comm_create_null(int rank, int nranks, void** comm);
 /* host-only helper: column ranges of the sharded assembly, bounds[0 .. nranks]; rank g owns [bounds[g], bounds[g + 1]) */
-int  hipsdp_shard_columns(int m1, int n, int nranks, int* bounds);
-int  hipsdp_comm_create(const void* unique_id_128bytes, int rank, int nranks, void** comm);
-int  hipsdp_comm_unique_id(void* unique_id_128bytes);
-void hipsdp_comm_destroy(void* comm);
+HIPSDP_API int  hipsdp_shard_columns(int m1, int n, int nranks, int* bounds);
+HIPSDP_API int  hipsdp_comm_create(const void* unique_id_128bytes, int rank, int nranks, void** comm);
+HIPSDP_API int  hipsdp_comm_unique_id(void* unique_id_128bytes);
+HIPSDP_API void hipsdp_comm_destroy(void* comm);
 /* what the transport says about itself: *count = ncclCommCount for RCCL; *kind (may be NULL) 0 RCCL, 1 host-staged, 2 measurement */
-int  hipsdp_comm_count(void* comm, int* count, int* kind);
+HIPSDP_API int  hipsdp_comm_count(void* comm, int* count, int* kind);
 /* optional statistics: a HIP event pair around every collective, booked under the phase the engine is in - 0 Schur exchange
  * (all-reduce / all-gather / all-to-all), 1 passes over A, 2 decision scalars and flags, 3 other.  hipsdp_comm_stats waits for
  * the recorded events and returns seconds[4], calls[4], bytes[4] since the last reset (any pointer may be NULL). */
-int  hipsdp_comm_stats_enable(void* comm, int on);
-int  hipsdp_comm_stats(void* comm, double* seconds, long long* calls, double* bytes, int reset);
+HIPSDP_API int  hipsdp_comm_stats_enable(void* comm, int on);
+HIPSDP_API int  hipsdp_comm_stats(void* comm, double* seconds, long long* calls, double* bytes, int reset);
 /* SPMD hosts (N identical processes, one per GPU, making the same calls): the process-wide communicator the environment
  * describes - HIPSDP_WORLD / WORLD_SIZE, HIPSDP_RANK / RANK, and HIPSDP_COMM_FILE=path (RCCL: rank 0 writes the unique id there,
  * the others read it) or HIPSDP_COMM_SHM=/name (host-staged, ranks sharing one device).  *comm = NULL with one rank.  Created at
  * the first call, shared by all solvers of the process, never destroyed.  sdpisolver_hip.c calls it when it creates its engine. */
-int  hipsdp_comm_from_env(int device, void** comm, int* rank, int* nranks);
+HIPSDP_API int  hipsdp_comm_from_env(int device, void** comm, int* rank, int* nranks);
 /* host-staged communicator for several ranks on ONE device (RCCL refuses that): payloads travel through the POSIX
  * shared-memory segment `name` ("/something", unique per job; every rank passes the same name and staging size).  Same
  * collectives, same results; meant for validating the sharded path on a one-GPU machine, not for speed. */
-int  hipsdp_comm_create_host(const char* name, int rank, int nranks, long long staging_bytes, double timeout_seconds, void** comm);
+HIPSDP_API int  hipsdp_comm_create_host(const char* name, int rank, int nranks, long long staging_bytes, double timeout_seconds, void** comm);
 
 /* Synthetic instance of BASELINE.md section 3 generated in HBM.  The solver must have the shape (m, one block of size n,
  * q = 0).  Fills A_1..A_m from the counter stream of oracle/instances.py (seed + i), then plants the optimum the caller
  * supplies: A_0 = sum_i ystar_i A_i - Zstar,  b_i = <A_i, Xstar> (both computed on the device); b is set as objective and
  * returned in b_out[m].  Xstar, Zstar: n x n host arrays; ystar: m host values. */
-int  hipsdp_gen_planted(hipsdp_solver* solver, int n, int m, long long seed, const double* Xstar, const double* Zstar,
+HIPSDP_API int  hipsdp_gen_planted(hipsdp_solver* solver, int n, int m, long long seed, const double* Xstar, const double* Zstar,
    const double* ystar, double* b_out);
 /* the same with matrices of the given density (0 < density <= 1: an off-diagonal entry is nonzero with that probability; SURVEY.md
  * 8(d) names rho = 0.1).  The storage and the assembly stay the dense ones: below the density where the pair formula over nonzeros
  * wins (hipsdp_set_shape2) the three GEMMs are the cheaper formulation whatever the zeros */
-int  hipsdp_gen_planted_density(hipsdp_solver* solver, int n, int m, long long seed, double density, const double* Xstar,
+HIPSDP_API int  hipsdp_gen_planted_density(hipsdp_solver* solver, int n, int m, long long seed, double density, const double* Xstar,
    const double* Zstar, const double* ystar, double* b_out);
 /* copies block k's dense storage A[(m+1) * n * n] back to the host (used to hand identical bits to the CPU baseline) */
-int  hipsdp_get_block_dense(hipsdp_solver* solver, int block, double* A);
+HIPSDP_API int  hipsdp_get_block_dense(hipsdp_solver* solver, int block, double* A);
 
 /* ---- host-buffer dense kernels (unit-level entry points; used by lapack_interface_hip.c and by the parity tests) ---- */
 /* C[M x N] = alpha * op(A) * op(B) + beta * C, row-major; layA/layB: 0 = K contiguous, 1 = M (resp. N) contiguous */
-int  hipsdp_dgemm(int device, int layA, int layB, int M, int N, int K, double alpha, const double* A, long long lda,
+HIPSDP_API int  hipsdp_dgemm(int device, int layA, int layB, int M, int N, int K, double alpha, const double* A, long long lda,
    const double* B, long long ldb, double beta, double* C, long long ldc, int lower_only, int splitk);
 /* both GEMM kernels (one tile per workgroup; persistent with LDS-DMA staging) on the same device-generated operands:
  * used_v2 = 1 when the persistent kernel accepts the shape, ndiff = elements of C that differ in any bit (must be 0) */
-int  hipsdp_dgemm_selfcheck(int device, int M, int N, int K, int layB, int batch, int splitk, int flags, double beta,
+HIPSDP_API int  hipsdp_dgemm_selfcheck(int device, int M, int N, int K, int layB, int batch, int splitk, int flags, double beta,
    int* used_v2, long long* ndiff);
 /* the same with a free alpha and, for reps > 0 and beta = 0, the average milliseconds of one product through the tile kernel alone
  * (ms_tile) and through the default dispatch (ms_fast).  *used: bit 0 the persistent tile kernel took the product, bit 1 the strip
  * kernel of the two triangular Schur products (alpha = 1, beta = 0 only) */
-int  hipsdp_dgemm_selfcheck2(int device, int M, int N, int K, int layB, int batch, int splitk, int flags, double alpha, double beta,
+HIPSDP_API int  hipsdp_dgemm_selfcheck2(int device, int M, int N, int K, int layB, int batch, int splitk, int flags, double alpha, double beta,
    int reps, int* used, long long* ndiff, double* ms_tile, double* ms_fast);
 /* Schur block Mx[(m1) x (m1)] = tr(A_i X A_j Zinv) for i, j = 0..m1-1 */
-int  hipsdp_schur_dense(int device, int m1, int n, const double* A, const double* X, const double* Zinv, double* Mx,
+HIPSDP_API int  hipsdp_schur_dense(int device, int m1, int n, const double* A, const double* X, const double* Zinv, double* Mx,
    double ws_gbytes);
 /* the same matrix through the W formulation (W_j = G A_j R, Mx = W W^T); takes X and Z, factors them on the device */
-int  hipsdp_schur_w(int device, int m1, int n, const double* A, const double* X, const double* Z, double* Mx);
+HIPSDP_API int  hipsdp_schur_w(int device, int m1, int n, const double* A, const double* X, const double* Z, double* Mx);
 /* milliseconds one rank of an nranks-way sharded assembly spends on its share of the Schur matrix (by_columns: column slices
  * of the W formulation, else row chunks of the U formulation); synthetic operands made in HBM */
-int  hipsdp_schur_shard_time(int device, int m1, int n, int nranks, int rank, int by_columns, int reps, double ws_gbytes, double* ms);
+HIPSDP_API int  hipsdp_schur_shard_time(int device, int m1, int n, int nranks, int rank, int by_columns, int reps, double ws_gbytes, double* ms);
 /* the same for one rank of the variable-sharded assembly (hipsdp_shard_matrices): only that rank's rows of A are allocated, the
  * column slices are cw wide, the all-to-all keeps the rank's own piece; *a2a_bytes = bytes the rank would send per assembly */
-int  hipsdp_schur_var_share_time(int device, int m1, int n, int nranks, int rank, int cw, int reps, double* ms, double* a2a_bytes);
-int  hipsdp_potrf(int device, int n, double* A, int* fail);                       /* lower Cholesky in place, row-major */
+HIPSDP_API int  hipsdp_schur_var_share_time(int device, int m1, int n, int nranks, int rank, int cw, int reps, double* ms, double* a2a_bytes);
+HIPSDP_API int  hipsdp_potrf(int device, int n, double* A, int* fail);                       /* lower Cholesky in place, row-major */
 /* both forms of the blocked factorization for the parity tests: v1 = 1 the four-launch form, 0 one launch per block column; psd = 1
  * semidefinite pivot rule with diag0 = diag(A), forced pivots in regmask[n]; dinv[ceil(n / 64) * 4096] (any output may be NULL) */
-int  hipsdp_potrf_ex(int device, int n, double* A, int psd, int v1, double* dinv, int* regmask, int* fail);
-int  hipsdp_potrs(int device, int n, const double* A, int nrhs, double* rhs);     /* factor + solve, rhs[k * n + i] */
-int  hipsdp_trtri(int device, int n, const double* A, double* Linv);              /* A spd -> inverse of its Cholesky factor */
-int  hipsdp_lambda_min(int device, int n, const double* W, int steps, double* theta, double* resid);
+HIPSDP_API int  hipsdp_potrf_ex(int device, int n, double* A, int psd, int v1, double* dinv, int* regmask, int* fail);
+HIPSDP_API int  hipsdp_potrs(int device, int n, const double* A, int nrhs, double* rhs);     /* factor + solve, rhs[k * n + i] */
+HIPSDP_API int  hipsdp_trtri(int device, int n, const double* A, double* Linv);              /* A spd -> inverse of its Cholesky factor */
+HIPSDP_API int  hipsdp_lambda_min(int device, int n, const double* W, int steps, double* theta, double* resid);
 /* lambda_min(L D L^T), n <= 64, L lower triangular, D symmetric: the small-block step-length kernels; theta[2], resid[2] */
-int  hipsdp_lambda_min_scaled(int device, int n, const double* L, const double* D, int steps, double* theta, double* resid);
-int  hipsdp_syev(int device, int n, const double* A, double* lam, double* V);     /* ascending, eigenvectors as rows */
+HIPSDP_API int  hipsdp_lambda_min_scaled(int device, int n, const double* L, const double* D, int steps, double* theta, double* resid);
+HIPSDP_API int  hipsdp_syev(int device, int n, const double* A, double* lam, double* V);     /* ascending, eigenvectors as rows */
 /* i-th smallest eigenvalue (1-based) and optionally its unit eigenvector of a symmetric matrix with n <= 64 in one launch through
  * pinned, device-mapped staging memory of the calling thread (no allocation, no copy engine, no stream synchronisation):
  * Householder tridiagonalisation in LDS, Sturm multisection, inverse iteration, back-transformation - one eigenpair as DSYEVR
  * RANGE = 'I' computes it (lapack_interface.c:178-288).  HIPSDP_ERR_ARG for n > 64. */
-int  hipsdp_syevi_small(int device, int n, const double* A, int i, double* eigval, double* eigvec);
+HIPSDP_API int  hipsdp_syevi_small(int device, int n, const double* A, int i, double* eigval, double* eigvec);
+/* all eigenpairs, n <= 64, the same way (what DSYEVR RANGE = 'A' computes, lapack_interface.c:507-603): eigenvalues by multisection,
+ * eigenvectors by inverse iteration with re-orthogonalisation inside clusters, one launch; hipsdp_syev takes this path for n <= 64 */
+HIPSDP_API int  hipsdp_syev_small(int device, int n, const double* A, double* lam, double* V);
 /* PSD projection chain of the warm-start producer (relax_sdp.c:2715-2766 for Z, :3405-3445 for X), fused on the device: sparse
  * lower/upper triangle (row, col, val; both triangles are filled) -> eigen-decomposition -> eigenvalues below minev (by more
  * than epsilon, SCIPisLT) raised to minev -> recombination -> entries with row <= col and |value| > epsilon in row-major order.
  * mode 0: the reference's literal chain R[i][j] = sum_c V[i][c] lambda_c V[j][c] (V[k][:] = k-th eigenvector; this is what
  * scaleTransposedMatrix + SCIPlapackMatrixMatrixMult(V, TRUE, S, FALSE) evaluate); mode 1: spectral R = sum_k lambda_k v_k v_k^T.
  * cap = length of the output arrays; *nnz_out = entries produced (when it exceeds cap: HIPSDP_ERR_ARG, nothing is written). */
-int  hipsdp_psd_project(int device, int n, int nnz, const int* row, const int* col, const double* val, double minev, double epsilon,
+HIPSDP_API int  hipsdp_psd_project(int device, int n, int nnz, const int* row, const int* col, const double* val, double minev, double epsilon,
    int mode, int cap, int* nnz_out, int* rowout, int* colout, double* valout);
-int  hipsdp_gemv_n(int device, int R, long long E, const double* A, int nv, const double* V, double* out);
-int  hipsdp_gemv_t(int device, int R, long long E, const double* A, const double* coef, double* out);
+HIPSDP_API int  hipsdp_gemv_n(int device, int R, long long E, const double* A, int nv, const double* V, double* out);
+HIPSDP_API int  hipsdp_gemv_t(int device, int R, long long E, const double* A, const double* coef, double* out);
 
 #ifdef __cplusplus
 }

@@ -35,7 +35,11 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIBPATH):
             raise RuntimeError("libhipsdp.so not built (%s); run __graft_entry__.build()" % LIBPATH)
-        _lib = C.CDLL(LIBPATH, mode=C.RTLD_GLOBAL)
+        eng = C.CDLL(LIBPATH, mode=C.RTLD_GLOBAL)
+        # the solver-interface backend (SCIPsdpiSolver*, SCIPlapack*) is a library of its own that needs the engine: symbol lookups
+        # on its handle also find the engine's (dlsym searches the dependencies)
+        sdpi = os.path.join(os.path.dirname(LIBPATH), os.path.basename(LIBPATH).replace("libhipsdp", "libhipsdp_sdpi", 1))
+        _lib = C.CDLL(sdpi, mode=C.RTLD_GLOBAL) if os.path.exists(sdpi) else eng
         _lib.hipsdp_last_error.restype = C.c_char_p
         _lib.hipsdp_version.restype = C.c_char_p
     return _lib

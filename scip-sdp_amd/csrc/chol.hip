@@ -99,7 +99,8 @@ struct pd_ext
    double*       Gram;
    int           set_flag;  /* 1: this launch is the only writer of *flag between two reads: it stores its result (0 = fine) instead
                               * of recording a failure into a flag that somebody cleared beforehand */
-   int           rule;      /* 0: forced pivots keep their column, 1: forced columns are zeroed, 2: zeroed when the pivot was <= 0 */
+   int           rule;      /* 0: forced pivots keep their column, 1: forced columns are zeroed, 2: zeroed when the pivot was <= 0, 3: when it
+                            * was at rounding-noise level, <= 8 eps (k + 1) M_kk */
    int*          regmask;   /* semidefinite mode: regmask[j0 + k] = 1 when the pivot of column k was forced (may be NULL) */
    int           from_lds;  /* 1 (k_potrf_step): the block to factor already sits in the first LDS tile, not in global memory */
    int           nostore;   /* 1 (k_potrf_step, all workgroups but the first): L, inv(L), flag and mask stay in LDS / registers */
@@ -194,7 +195,11 @@ __device__ __forceinline__ bool pd_panel(double (&r)[16], const double (&thr)[16
             const double dd = d0s[gk];
             if ( !(d > regtol * dd) || !(d > 1e-300) )
             {
-               reg = (rule == 1) || (rule == 2 && !(d > 0.0));
+               /* rule 3: "not even positive" is the sign of a rounding-noise number - two implementations of the same algorithm
+                * (this kernel, the oracle) draw it differently, and from there on their iterates differ.  The noise of pivot k of a
+                * matrix with dependent columns is of the order eps k M_kk, so the test is against that level instead of against 0:
+                * both sides then zero the same columns unless the pivot sits within rounding of the threshold itself */
+               reg = (rule == 1) || (rule == 2 && !(d > 0.0)) || (rule == 3 && !(d > 1.78e-15 * (double) (j0 + gk + 1) * dd));
                d = (dd > 1e-280) ? regtol * dd : 1.0;
                y0 = __builtin_amdgcn_rsq(d);
                rc0 = __builtin_amdgcn_rcp(d);
@@ -886,7 +891,7 @@ int hs_potrf_psd(hipStream_t s, int n, double* A, double* dinv, int* flag, const
       return HS_OK;
    if ( diag0 != NULL && regmask == NULL && n > NB )
       return HS_ERR_ARG;
-   static int rule = getenv("HIPSDP_PIVOT_RULE") != NULL ? atoi(getenv("HIPSDP_PIVOT_RULE")) : 2;
+   static int rule = getenv("HIPSDP_PIVOT_RULE") != NULL ? atoi(getenv("HIPSDP_PIVOT_RULE")) : 3;
    pd_ext ext = {NULL, NULL, 0.0, NULL, NULL, NULL, (set_flag && n <= NB) ? 1 : 0, rule, regmask};
    const pd_ext* extp = ((diag0 != NULL && regmask != NULL) || ext.set_flag) ? &ext : NULL;
    const long long lda = n;

@@ -434,8 +434,12 @@ int hs_dgemm4_try(hipStream_t stream, const hs_gemm_args* a)
 {
    if ( g4_mode < 0 )
    {
+      /* Off unless asked for (HIPSDP_GEMM4=1).  Measured at n = 500, m = 1000 inside the solve (profiles/r03_a_*): the same time per
+       * product as the persistent tile kernel (3.13 against 3.10 ms; 69.6 % against 62.5 % matrix-pipe busy, the difference being the
+       * zero slabs of the diagonal band it multiplies) and MORE HBM traffic - 10.1 against 7.0 GB per call: the eight strips of a
+       * batch entry each stream T_j[0 : m0 + 64, :] and four entries in flight per XCD do not fit its 4 MB of L2 */
       const char* env = getenv("HIPSDP_GEMM4");
-      g4_mode = (env != NULL && env[0] == '0') ? 0 : 1;
+      g4_mode = (env != NULL && env[0] == '1') ? 1 : 0;
    }
    if ( !g4_mode )
       return 0;

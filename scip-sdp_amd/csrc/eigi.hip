@@ -86,9 +86,25 @@ __device__ __forceinline__ double ei_rcp(double t)
 
 /* in: n x n symmetric, in mapped host memory, the triangle at memory positions [j n + i], i >= j, is read; out[0] = eigenvalue, out[1 .. n] = eigenvector,
  * then the sequence number is stored to *flag (system scope) */
+/* ALL = true: every eigenpair (out[0 .. n - 1] = eigenvalues ascending, out[EI_N + k n + i] = component i of eigenvector k), what
+ * DSYEVR computes for RANGE = 'A' (lapack_interface.c:507-603): the tridiagonal matrix of the same reduction, then
+ *   - all eigenvalues at once by Sturm-count multisection, four shifts per eigenvalue and round (thread = (eigenvalue, shift));
+ *   - all eigenvectors by inverse iteration on the tridiagonal matrix, one THREAD per eigenvector (Gaussian elimination with partial
+ *     pivoting redone in every one of the three iterations, its U factor in LDS, [row][thread] so that the threads of a wavefront
+ *     touch consecutive words), start vectors that differ from eigenvector to eigenvector;
+ *   - eigenvectors of eigenvalues closer than 1e-3 ||T|| (DSTEIN's criterion) are orthogonalised against each other (classical
+ *     Gram-Schmidt twice, one wavefront per cluster): exactly degenerate eigenvalues get an orthonormal basis of their space out of
+ *     the different start vectors;
+ *   - back-transformation through the reflectors, one wavefront per vector.
+ * Dynamic LDS (ALL only): Z[64][64] (component-major: Z[i * 64 + k] = component i of vector k) and two [64][64] factor arrays (pivot
+ * reciprocals and the first superdiagonal of U; its second superdiagonal is e[i + 1] in the rows that were swapped and 0 elsewhere:
+ * one bit per row in a register). */
+#define EI_ALL_LDS ((EI_N * EI_N + 2 * EI_N * EI_N) * (int) sizeof(double))
+template<bool ALL>
 __global__ void __launch_bounds__(256) k_syevi_small(int n, int ith, int wantvec, const double* __restrict__ in, double* __restrict__ out,
    unsigned long long seq, unsigned long long* __restrict__ flag)
 {
+   extern __shared__ __attribute__((aligned(16))) double ei_dyn[];
    __shared__ double a[EI_N][EI_LD];
    __shared__ double vv[EI_N], pp[EI_N], ww[EI_N], tau[EI_N], d[EI_N], e[EI_N], e2[EI_N], zz[EI_N], xc[EI_N];
    __shared__ double wk[4][EI_N], swp[EI_N];
@@ -213,10 +229,224 @@ __global__ void __launch_bounds__(256) k_syevi_small(int n, int ith, int wantvec
       e[n - 1] = 0.0;
    }
    __syncthreads();
+   if ( ALL )
+   {
+      double* Z = ei_dyn;                              /* [i][k] */
+      double* f0 = Z + EI_N * EI_N;                    /* [i][k]: 1 / pivot of row i of the elimination for vector k */
+      double* f1 = f0 + EI_N * EI_N;                   /* first superdiagonal of U */
+      if ( tid < n )
+         e2[tid] = e[tid] * e[tid];
+      __syncthreads();
+      /* ---- all eigenvalues: thread (k = tid >> 2, s = tid & 3) */
+      double glo = 1e300, ghi = -1e300, tnorm = 0.0;
+      for (int i = 0; i < n; ++i)
+      {
+         const double rad = (i > 0 ? fabs(e[i - 1]) : 0.0) + (i + 1 < n ? fabs(e[i]) : 0.0);
+         glo = fmin(glo, d[i] - rad);
+         ghi = fmax(ghi, d[i] + rad);
+         tnorm = fmax(tnorm, fabs(d[i]) + rad);
+      }
+      const double span0 = fmax(ghi - glo, 1e-300);
+      glo -= 1e-12 * span0 + 1e-300;
+      ghi += 1e-12 * span0 + 1e-300;
+      const double pivmin = 1e-290;
+      {
+         const int k = tid >> 2, sh = tid & 3;
+         double lo = glo, hi = ghi;
+         for (int round = 0; round < 40; ++round)
+         {
+            const double w = (hi - lo) * 0.2;
+            const double x = lo + w * (double) (sh + 1);
+            int cnt = 0;
+            if ( k < n )
+            {
+               double t = d[0] - x;
+               if ( fabs(t) < pivmin ) t = -pivmin;
+               if ( t < 0.0 ) ++cnt;
+               for (int i = 1; i < n; ++i)
+               {
+                  t = d[i] - x - e2[i - 1] * ei_rcp(t);
+                  if ( fabs(t) < pivmin ) t = -pivmin;
+                  if ( !(fabs(t) < 1e290) ) t = (t < 0.0) ? -1e290 : 1e290;
+                  if ( t < 0.0 ) ++cnt;
+               }
+            }
+            /* number of the four shifts with fewer than k + 1 eigenvalues below them = index of the subinterval that holds
+             * eigenvalue k (the counts are monotone in the shift) */
+            int below = (cnt < k + 1) ? 1 : 0;
+            below += __builtin_amdgcn_update_dpp(0, below, 0xB1, 0xf, 0xf, true);
+            below += __builtin_amdgcn_update_dpp(0, below, 0x4E, 0xf, 0xf, true);
+            const double nlo = lo + w * (double) below;
+            const double nhi = (below < 4) ? lo + w * (double) (below + 1) : hi;
+            lo = nlo; hi = nhi;
+            if ( __all(k >= n || hi - lo <= 2e-16 * fmax(fabs(lo), fabs(hi))) )
+               break;
+         }
+         if ( k < n && sh == 0 )
+            zz[k] = 0.5 * (lo + hi);                   /* eigenvalue k */
+      }
+      __syncthreads();
+      if ( tid < n )
+         out[tid] = zz[tid];
+      /* ---- eigenvectors: three rounds of { one step of inverse iteration for every vector (thread k owns vector k),
+       * orthogonalisation inside the clusters }.  Eigenvalue k belongs to the cluster of k - 1
+       * when they are closer than 1e-3 ||T|| (DSTEIN's criterion).  The orthogonalisation has to happen in EVERY round, as in DSTEIN:
+       * the eigenvalues of a cluster differ by a few ulps, so do the amplifications 1 / (lambda_j - theta_k) of its directions, and
+       * vectors that are only orthogonalised at the end have collapsed onto each other by then (seen as 7e-10 in V V^T - I). */
+      const double ortol = 1e-3 * fmax(tnorm, 1e-300);
+      if ( n > 1 )
+      {
+         /* start vectors: a different one for every eigenvector (entries in [0.5, 1.5) from a hash of (i, k)) */
+         for (int idx = tid; idx < n * n; idx += 256)
+         {
+            const int i = idx / n, k = idx - i * n;
+            unsigned h = (unsigned) (i * 2654435761u) ^ (unsigned) ((k + 1) * 40503u);
+            h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+            Z[i * EI_N + k] = 0.5 + (double) (h & 0xFFFF) * (1.0 / 65536.0);
+         }
+      }
+      else if ( tid == 0 )
+         Z[0] = 1.0;
+      __syncthreads();
+      for (int iter = 0; iter < 3 && n > 1; ++iter)
+      {
+         {
+            const int k = tid;                              /* thread k owns vector k */
+            if ( k < n )
+            {
+               const double theta = zz[k];
+               const double tiny = 1e-14 * fmax(span0, fmax(fabs(theta), 1e-300));
+               /* forward elimination of (T - theta I) with partial pivoting, applied to the right-hand side on the way */
+               double dd = d[0] - theta, du = e[0];
+               double cur = Z[k];
+               unsigned long long swapped = 0ULL;           /* bit i: rows i and i + 1 were exchanged */
+               for (int i = 0; i < n - 1; ++i)
+               {
+                  const double dl = e[i];
+                  const double dn = d[i + 1] - theta;
+                  const double un = (i + 2 < n) ? e[i + 1] : 0.0;
+                  const double nxt = Z[(i + 1) * EI_N + k];
+                  /* a subdiagonal entry at rounding level (the tridiagonal matrix of a matrix with few distinct eigenvalues splits
+                   * into small blocks) must not become a pivot: 1 / e would amplify that block by 1e16 and more */
+                  if ( fabs(dd) >= fabs(dl) || fabs(dl) < tiny )
+                  {
+                     if ( fabs(dd) < tiny ) dd = tiny;
+                     const double rinv = ei_rcp2(dd);
+                     const double mlt = dl * rinv;
+                     f0[i * EI_N + k] = rinv; f1[i * EI_N + k] = du;
+                     Z[i * EI_N + k] = cur;
+                     cur = nxt - mlt * cur;
+                     dd = dn - mlt * du;
+                     du = un;
+                  }
+                  else
+                  {
+                     const double rinv = ei_rcp2(dl);
+                     const double mlt = dd * rinv;
+                     f0[i * EI_N + k] = rinv; f1[i * EI_N + k] = dn;
+                     swapped |= 1ULL << i;
+                     Z[i * EI_N + k] = nxt;
+                     cur = cur - mlt * nxt;
+                     dd = du - mlt * dn;
+                     du = -mlt * un;
+                  }
+               }
+               if ( fabs(dd) < tiny ) dd = tiny;
+               double x1 = cur * ei_rcp2(dd), x2 = 0.0;
+               double nrm = x1 * x1;
+               Z[(n - 1) * EI_N + k] = x1;
+               for (int i = n - 2; i >= 0; --i)
+               {
+                  const double u2 = ((swapped >> i) & 1ULL) ? ((i + 2 < n) ? e[i + 1] : 0.0) : 0.0;
+                  const double xi = (Z[i * EI_N + k] - f1[i * EI_N + k] * x1 - u2 * x2) * f0[i * EI_N + k];
+                  Z[i * EI_N + k] = xi;
+                  nrm += xi * xi;
+                  x2 = x1; x1 = xi;
+                  if ( !(nrm < 1e280) )
+                  {
+                     /* rescale on the way (the solution of a nearly singular system is huge by construction) */
+                     const double sc1 = 1e-140;
+                     for (int j = i; j < n; ++j)
+                        Z[j * EI_N + k] *= sc1;
+                     x1 *= sc1; x2 *= sc1; nrm *= sc1 * sc1;
+                  }
+               }
+               double rn = ei_rsqrt(fmax(nrm, 1e-300));
+               if ( !(nrm > 0.0) || !(nrm < 1e300) )
+               {
+                  for (int i = 0; i < n; ++i)
+                     Z[i * EI_N + k] = (i == k) ? 1.0 : 0.0;
+                  rn = 1.0;
+               }
+               for (int i = 0; i < n; ++i)
+                  Z[i * EI_N + k] *= rn;
+            }
+            __syncthreads();
+         }
+         /* clusters: one wavefront per cluster (cluster c goes to wavefront c mod 4), lane = component; classical Gram-Schmidt
+          * against the vectors of the cluster before it, twice */
+         {
+            int cl = -1;
+            int k0 = 0;
+            while ( k0 < n )
+            {
+               int k1 = k0 + 1;
+               while ( k1 < n && zz[k1] - zz[k1 - 1] <= ortol )
+                  ++k1;
+               ++cl;
+               if ( k1 - k0 > 1 && (cl & 3) == wave )
+               {
+                  for (int k = k0; k < k1; ++k)
+                  {
+                     double v = (lane < n) ? Z[lane * EI_N + k] : 0.0;
+                     for (int pass = 0; pass < 2; ++pass)
+                        for (int p = k0; p < k; ++p)
+                        {
+                           const double u = (lane < n) ? Z[lane * EI_N + p] : 0.0;
+                           v -= ei_wsum(u * v) * u;
+                        }
+                     const double nr = ei_wsum(v * v);
+                     v *= ei_rsqrt(fmax(nr, 1e-300));
+                     if ( lane < n )
+                        Z[lane * EI_N + k] = v;
+                     __builtin_amdgcn_s_waitcnt(0xc07f);
+                     __builtin_amdgcn_wave_barrier();
+                  }
+               }
+               k0 = k1;
+            }
+         }
+         __syncthreads();
+      }
+      /* ---- back-transformation x = H_0 H_1 ... H_{n-2} z, one wavefront per vector */
+      for (int k = wave; k < n; k += 4)
+      {
+         double zi = (lane < n) ? Z[lane * EI_N + k] : 0.0;
+         for (int kk = n - 2; kk >= 0; --kk)
+         {
+            const double t = tau[kk];
+            if ( t == 0.0 )
+               continue;
+            const bool in = lane > kk && lane < n;
+            const double vk = in ? ((lane == kk + 1) ? 1.0 : a[lane][kk]) : 0.0;
+            const double dot = ei_wsum(vk * zi);
+            zi -= t * dot * vk;
+         }
+         const double nrm = ei_wsum(zi * zi);
+         if ( lane < n )
+            out[EI_N + (long long) k * n + lane] = nrm > 0.0 ? zi * ei_rsqrt(nrm) : zi;
+      }
+      __threadfence_system();
+      __syncthreads();
+      if ( tid == 0 )
+         __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+   }
    if ( wave != 0 )
       return;
 
    /* ---- wavefront 0: i-th eigenvalue of T by Sturm multisection */
+
    if ( lane < n )
       e2[lane] = e[lane] * e[lane];
    __builtin_amdgcn_wave_barrier();
@@ -364,7 +594,7 @@ __global__ void __launch_bounds__(256) k_syevi_small(int n, int ith, int wantvec
 
 /* per host thread and device: a stream and the pinned, device-mapped staging memory.  The object lives in thread-local storage:
  * its destructor returns stream and pinned memory when the thread ends. */
-#define EI_OUT_DOUBLES (EI_N * EI_N + EI_N + 8)       /* room for a full decomposition: eigenvalues, eigenvectors, flag word */
+#define EI_OUT_DOUBLES (EI_N * EI_N + EI_N + 16)       /* room for a full decomposition: eigenvalues, eigenvectors, flag word */
 struct ei_ctx
 {
    int device;
@@ -437,7 +667,7 @@ extern "C" int hipsdp_syevi_small(int device, int n, const double* A, int i, dou
    memcpy(c->hin, A, (size_t) n * n * sizeof(double));
    const unsigned long long seq = ++c->seq;
    volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(c->hout + EI_N + 4);
-   hipLaunchKernelGGL(k_syevi_small, dim3(1), dim3(256), 0, c->stream, n, i, eigvec != NULL ? 1 : 0, c->din, c->dout, seq,
+   hipLaunchKernelGGL((k_syevi_small<false>), dim3(1), dim3(256), 0, c->stream, n, i, eigvec != NULL ? 1 : 0, c->din, c->dout, seq,
       reinterpret_cast<unsigned long long*>(c->dout + EI_N + 4));
    HS_HIP( hipGetLastError() );
    long long spins = 0;
@@ -466,5 +696,56 @@ extern "C" int hipsdp_syevi_small(int device, int n, const double* A, int i, dou
    *eigval = c->hout[0];
    if ( eigvec != NULL )
       memcpy(eigvec, c->hout + 1, (size_t) n * sizeof(double));
+   return HIPSDP_OK;
+}
+
+/* all eigenpairs of the symmetric n x n matrix A, n <= 64, in one launch through the same staging memory: lam ascending, row k of V =
+ * k-th eigenvector (what SCIPlapackComputeEigenvectorDecomposition returns: lapack_interface.c:507-603).  HIPSDP_ERR_ARG for n > 64. */
+extern "C" int hipsdp_syev_small(int device, int n, const double* A, double* lam, double* V)
+{
+   int nd = 0;
+   if ( hipGetDeviceCount(&nd) != hipSuccess || nd <= 0 )
+      return HIPSDP_ERR_NODEVICE;
+   if ( device < 0 || device >= nd || n < 1 || n > EI_N || A == NULL || lam == NULL )
+      return HIPSDP_ERR_ARG;
+   ei_ctx* c = NULL;
+   HS_CALL( ei_context(device, &c) );
+   HS_HIP( hipSetDevice(device) );
+   static hs_attr_mask attr_done;
+   HS_CALL( hs_func_max_lds(reinterpret_cast<const void*>(&k_syevi_small<true>), EI_ALL_LDS, &attr_done) );
+   memcpy(c->hin, A, (size_t) n * n * sizeof(double));
+   const unsigned long long seq = ++c->seq;
+   /* the flag word sits behind the eigenvalues and the n x n eigenvector array */
+   const long long flagpos = EI_N + (long long) EI_N * EI_N + 4;
+   volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(c->hout + flagpos);
+   hipLaunchKernelGGL((k_syevi_small<true>), dim3(1), dim3(256), EI_ALL_LDS, c->stream, n, 0, 1, c->din, c->dout, seq,
+      reinterpret_cast<unsigned long long*>(c->dout + flagpos));
+   HS_HIP( hipGetLastError() );
+   long long spins = 0;
+   while ( *flag != seq )
+   {
+      if ( (++spins & 0xFFFF) == 0 )
+      {
+         const hipError_t e = hipStreamQuery(c->stream);
+         if ( e == hipSuccess )
+         {
+            if ( *flag == seq )
+               break;
+            HS_HIP( hipStreamSynchronize(c->stream) );
+            if ( *flag != seq )
+               return HIPSDP_ERR_HIP;
+            break;
+         }
+         if ( e != hipErrorNotReady )
+         {
+            hs_record_hip_error(e, "hipStreamQuery(syev_small)", __FILE__, __LINE__);
+            return HIPSDP_ERR_HIP;
+         }
+      }
+   }
+   __atomic_thread_fence(__ATOMIC_ACQUIRE);
+   memcpy(lam, c->hout, (size_t) n * sizeof(double));
+   if ( V != NULL )
+      memcpy(V, c->hout + EI_N, (size_t) n * n * sizeof(double));
    return HIPSDP_OK;
 }

@@ -163,7 +163,7 @@ static int dgemm_selfcheck_impl(int device, int M, int N, int K, int layB, int b
    if ( rc == HS_OK )
       rc = timed(ms_tile);
    const int before = hs_dgemm2_enable(1);
-   (void) hs_dgemm4_enable(g4before != 0);          /* -1 (environment not read yet) and 1: on */
+   (void) hs_dgemm4_enable(1);                      /* the strip kernel is an option of the dispatch (HIPSDP_GEMM4): this check always exercises it */
    const double f4before = hs_dgemm4_taken();
    g.C = dC2.p;
    /* the second run must not inherit the slabs of the first: a slice one kernel never writes would go unnoticed */
@@ -175,6 +175,10 @@ static int dgemm_selfcheck_impl(int device, int M, int N, int K, int layB, int b
    const double f4after = hs_dgemm4_taken();
    if ( rc == HS_OK )
       rc = timed(ms_fast);
+   if ( g4before >= 0 )
+      (void) hs_dgemm4_enable(g4before);
+   else
+      (void) hs_dgemm4_enable(getenv("HIPSDP_GEMM4") != NULL && getenv("HIPSDP_GEMM4")[0] == '1');
    if ( rc == HS_OK && hipDeviceSynchronize() != hipSuccess )
       rc = HS_ERR_HIP;
    unsigned long long hn = 0;
@@ -525,6 +529,11 @@ extern "C" int hipsdp_syev(int device, int n, const double* A, double* lam, doub
 {
    HS_CALL( pick_device(device) );
    if ( n <= 0 ) return HIPSDP_ERR_ARG;
+   /* the sizes the callers of SCIPlapackComputeEigenvectorDecomposition use (blocks of 2-50 rows): tridiagonal reduction, multisection
+    * and inverse iteration in ONE launch through pinned staging memory (eigi.hip); HIPSDP_SYEV_JACOBI=1 keeps the Jacobi path */
+   static const bool jacobi_small = getenv("HIPSDP_SYEV_JACOBI") != NULL && atoi(getenv("HIPSDP_SYEV_JACOBI")) != 0;
+   if ( n <= 64 && !jacobi_small )
+      return hipsdp_syev_small(device, n, A, lam, V);
    const long long n2 = (long long) n * n;
    DevBuf dA, dL, dV, dS;
    HS_CALL( dA.alloc(n2) ); HS_CALL( dL.alloc(n) ); HS_CALL( dV.alloc(n2) ); HS_CALL( dS.alloc(hs_syev_ws(n)) );

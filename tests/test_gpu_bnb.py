@@ -64,6 +64,36 @@ def test_bnb_reproduces_short_solu(gpu, name):
     assert failed == 0
 
 
+def test_first_nodes_of_example_mkp_engine_and_oracle_agree(gpu):
+    """example_MkP (check/testset/short.solu:7, optimum -95; tests/test_gpu_sdpi_driver.py solves it to optimality through the full
+    driver with 0 unresolved nodes): 105 binaries, one 15 x 15 block, 240 LP rows - node Schur matrices of rank <= 120 with m = 105,
+    the regime the noise-level pivot rule of csrc/chol.hip / the oracle's chol_psd was made for.  Most of its nodes have no interior
+    (that is what the driver's penalty formulation is for), so the plain backend call fails on them - on BOTH sides: the first nodes
+    of the best-bound search are solved by the engine and by the oracle, and their outcomes must agree node by node."""
+    inst = sdpa_io.read_sdpa(os.path.join(GOLDEN, "instances", "example_MkP.dat-s.gz"))
+    prob = bnb.instance_to_sdpi(inst)
+    s, solve, stats = hip_node_solver(gpu, 1e-6)
+    ref_solve = bnb.oracle_node_solver(1e-6)
+    seen = []
+
+    def both(P):
+        r = solve(P)
+        if len(seen) < 12:
+            q = ref_solve(P)
+            seen.append((r.status, q.status))
+            if r.status == 'optimal' and q.status == 'optimal':
+                assert abs(r.obj - q.obj) <= 1e-4 * (1 + abs(q.obj))
+        return r
+    best, y, nodes, failed = bnb.branch_and_bound(prob, inst.intvars, both, maxnodes=40)
+    s.free()
+    print("example_MkP, first %d nodes: %d unresolved by the plain call; engine / oracle outcomes of the first %d: %s" %
+          (nodes, failed, len(seen), seen))
+    # the engine side is the whole backend call (settings ladder and re-solve loop included), the oracle side the plain numpy
+    # iteration: the engine may settle a node the plain iteration gives up on, never the other way round
+    assert len(seen) >= 8 and all(a == b or (b == 'failed' and a in ('optimal', 'infeasible')) for a, b in seen)
+    assert best is None or best >= -95.0 - 1e-4
+
+
 # dual-form CBF examples (tests/harness/cbf_io.py): check/testset/short.solu:2,10,11,16
 CBF_SOLU = {"example_small_cbf.cbf": -8.0, "example_cbf_dual.cbf": 4.0, "example_multaggr.cbf": -1.0,
             "example_diagzeroimpl.cbf": -1.0}

@@ -157,6 +157,32 @@ def test_syev_matches_dsyevr_semantics(gpu, n):
     assert np.abs(V @ W @ V.T - np.diag(lam)).max() <= 1e-11 * max(1.0, np.abs(ev).max())
 
 
+@pytest.mark.parametrize("n", [2, 3, 5, 8, 16, 17, 31, 32, 33, 50, 63, 64])
+def test_small_full_decomposition_in_one_launch(gpu, n):
+    """n <= 64: tridiagonal reduction, all eigenvalues by multisection, eigenvectors by inverse iteration with re-orthogonalisation
+    inside clusters, back-transformation - one launch (csrc/eigi.hip, what DSYEVR RANGE = 'A' does: lapack_interface.c:507-603).
+    The spectra a PSD projection meets: random, diagonal input (split tridiagonal matrix), multiples of the identity (one cluster
+    of n equal eigenvalues), low rank (a cluster at zero), pairs closer than the cluster tolerance, graded over 12 orders."""
+    rng = np.random.default_rng(100 + n)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    cases = {"random": (lambda G: G + G.T)(rng.standard_normal((n, n))),
+             "diagonal": np.diag(rng.standard_normal(n)),
+             "identity": 3.5 * np.eye(n),
+             "low_rank": (lambda B: B @ B.T)(rng.standard_normal((n, max(1, n // 4)))),
+             "close_pairs": (Q * np.repeat(np.arange(1, n // 2 + 2, dtype=float), 2)[:n] * (1 + 1e-9 * np.arange(n))) @ Q.T,
+             "graded": (Q * 10.0 ** np.linspace(-6, 6, n)) @ Q.T,
+             "two_clusters": (Q * np.where(np.arange(n) < n // 2, -1.0, 2.0)) @ Q.T}
+    for name, W in cases.items():
+        W = 0.5 * (W + W.T)
+        lam, V = gpu.syev(W)
+        ev = np.linalg.eigvalsh(W)
+        scale = max(1.0, np.abs(ev).max())
+        assert np.abs(lam - ev).max() <= 1e-12 * scale, (name, np.abs(lam - ev).max())
+        assert np.all(np.diff(lam) >= 0.0), name
+        assert np.abs(V @ V.T - np.eye(n)).max() <= 1e-11, (name, np.abs(V @ V.T - np.eye(n)).max())
+        assert np.abs(V @ W @ V.T - np.diag(lam)).max() <= 1e-11 * scale, (name, np.abs(V @ W @ V.T - np.diag(lam)).max())
+
+
 @pytest.mark.parametrize("R,E", [(1, 1), (5, 100), (37, 10000), (300, 40001), (1001, 2500)])
 def test_gemv_passes(gpu, R, E):
     A = RNG.standard_normal((R, E))
