@@ -112,6 +112,9 @@ HIPSDP_API int  hipsdp_set_shape2(hipsdp_solver* solver, int m, int nblocks, con
 HIPSDP_API int  hipsdp_block_is_sparse(hipsdp_solver* solver, int block);
 /* 0: never keep a block as nonzeros, 1 (default; environment HIPSDP_SPARSE): by the cost rule above, 2: whenever a count is given */
 HIPSDP_API int  hipsdp_sparse_policy(hipsdp_solver* solver, int mode);
+/* how many (kernel, device) pairs have had their dynamic-LDS limit raised on that device so far: the attribute
+ * (hipFuncAttributeMaxDynamicSharedMemorySize) belongs to the pair, the engine keeps one bit per device and kernel (tests) */
+HIPSDP_API int  hipsdp_func_attr_sets(int device);
 /* free and total bytes of the device's memory (tests: what a problem allocates) */
 HIPSDP_API int  hipsdp_mem_info(int device, double* free_bytes, double* total_bytes);
 /* objective b[m] (host) */

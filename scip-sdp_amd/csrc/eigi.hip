@@ -749,3 +749,23 @@ extern "C" int hipsdp_syev_small(int device, int n, const double* A, double* lam
       memcpy(V, c->hout + EI_N, (size_t) n * n * sizeof(double));
    return HIPSDP_OK;
 }
+
+/* the same kernel on device buffers, in stream order (no staging memory, no polling): lam[n] ascending, V[n][n] with row k = k-th
+ * eigenvector; scratch: hs_syev_small_scratch() doubles.  For device-side chains that need the decomposition the SCIPlapack entry
+ * point returns (psd.hip: the PSD projection of the warm-start producer) - same eigenvectors, same signs. */
+long long hs_syev_small_scratch(void) { return EI_OUT_DOUBLES; }
+
+int hs_syev_small_dev(hipStream_t st, int n, const double* A, double* lam, double* V, double* scratch)
+{
+   if ( n < 1 || n > EI_N )
+      return HS_ERR_ARG;
+   static hs_attr_mask attr_done;
+   HS_CALL( hs_func_max_lds(reinterpret_cast<const void*>(&k_syevi_small<true>), EI_ALL_LDS, &attr_done) );
+   const long long flagpos = EI_N + (long long) EI_N * EI_N + 4;
+   hipLaunchKernelGGL((k_syevi_small<true>), dim3(1), dim3(256), EI_ALL_LDS, st, n, 0, 1, A, scratch, 1ULL,
+      reinterpret_cast<unsigned long long*>(scratch + flagpos));
+   HS_HIP( hipGetLastError() );
+   HS_HIP( hipMemcpyAsync(lam, scratch, (size_t) n * sizeof(double), hipMemcpyDeviceToDevice, st) );
+   HS_HIP( hipMemcpyAsync(V, scratch + EI_N, (size_t) n * n * sizeof(double), hipMemcpyDeviceToDevice, st) );
+   return HS_OK;
+}

@@ -472,6 +472,11 @@ extern "C" int hipsdp_sparse_policy(hipsdp_solver* s, int mode)
    return HIPSDP_OK;
 }
 
+extern "C" int hipsdp_func_attr_sets(int device)
+{
+   return hs_func_attr_sets(device);
+}
+
 extern "C" int hipsdp_mem_info(int device, double* free_bytes, double* total_bytes)
 {
    int nd = 0;
@@ -1645,6 +1650,28 @@ __global__ void k_sp_base(long long n2, const double* __restrict__ c, const doub
       out[e] = c0 * A0[e] + (add != NULL ? sa * add[e] : 0.0);
 }
 
+/* out[0] = <a, b>: one workgroup, fixed summation order */
+__global__ void __launch_bounds__(1024) k_sp_dot0(long long n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out)
+{
+   __shared__ double part[16];
+   double acc = 0.0;
+   for (long long e = threadIdx.x; e < n; e += 1024)
+      acc += a[e] * b[e];
+#pragma unroll
+   for (int off = 32; off > 0; off >>= 1)
+      acc += __shfl_xor(acc, off, 64);
+   if ( (threadIdx.x & 63) == 0 )
+      part[threadIdx.x >> 6] = acc;
+   __syncthreads();
+   if ( threadIdx.x == 0 )
+   {
+      double t = 0.0;
+      for (int w = 0; w < 16; ++w)
+         t += part[w];
+      out[0] = t;
+   }
+}
+
 /* Mx[i][0] += v[i] (column 0 of the lower triangle) */
 __global__ void k_add_col0(int m1, const double* __restrict__ v, double* __restrict__ Mx)
 {
@@ -1658,7 +1685,10 @@ static int pass_A(hipsdp_solver* s, Block& B, const double* V, double* out)
    const int m1 = s->m + 1;
    if ( B.sparse )
    {
-      HS_CALL( hs_dot(s->stream, (long long) B.n * B.n, B.A0, V, out, 0, s->red_ws) );
+      /* launched at once like the dense pass (hs_dot would be deferred inside a reduction batch, and callers add the result up
+       * with kernels that are not) */
+      hipLaunchKernelGGL(k_sp_dot0, dim3(1), dim3(1024), 0, s->stream, (long long) B.n * B.n, B.A0, V, out);
+      HS_LAUNCH_CHECK();
       return hs_sp_apply_A(s->stream, B.sp, V, out + 1);
    }
    if ( passes_sharded(s, B) )

@@ -155,7 +155,18 @@ extern "C" int hipsdp_psd_project(int device, int n, int nnz, const int* row, co
       int g = (nnz + 255) / 256; if ( g > 1024 ) g = 1024;
       hipLaunchKernelGGL(k_expand_coo, dim3(g), dim3(256), 0, st, nnz, n, drow.p, dcol.p, dval.p, A.p);
    }
-   HS_CALL( hs_syev_jacobi(st, n, A.p, lam.p, V.p, NULL, ws.p) );
+   /* the decomposition SCIPlapackComputeEigenvectorDecomposition returns for this size (the literal chain of mode 0 depends on the
+    * basis: both paths must use the same eigenvectors) */
+   static const bool jacobi_small = getenv("HIPSDP_SYEV_JACOBI") != NULL && atoi(getenv("HIPSDP_SYEV_JACOBI")) != 0;
+   if ( n <= 64 && !jacobi_small )
+   {
+      PoolBuf<double> scr;
+      HS_CALL( scr.alloc(hs_syev_small_scratch()) );
+      HS_CALL( hs_syev_small_dev(st, n, A.p, lam.p, V.p, scr.p) );
+      HS_HIP( hipStreamSynchronize(st) );            /* scr goes back to the pool */
+   }
+   else
+      HS_CALL( hs_syev_jacobi(st, n, A.p, lam.p, V.p, NULL, ws.p) );
    long long g2 = (n2 + 255) / 256; if ( g2 > 4096 ) g2 = 4096;
    hipLaunchKernelGGL(k_clamp_scale, dim3((unsigned) g2), dim3(256), 0, st, n, V.p, lam.p, minev, epsilon, mode, S.p);
    {

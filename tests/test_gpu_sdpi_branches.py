@@ -6,6 +6,7 @@ import os
 import numpy as np
 import pytest
 
+import ipm_ref
 import sdpi_prepare
 import sdpi_call
 import sdpi_driver as drv
@@ -273,3 +274,30 @@ def test_node_without_attained_optimum_converges_on_the_fast_settings_like_the_o
     rc, obj, y = s.dual_sol()
     assert abs(obj + 8.0) <= 1e-4
     s.free()
+
+
+def test_kernel_attributes_are_kept_per_device(gpu):
+    """hipFuncAttributeMaxDynamicSharedMemorySize belongs to the (kernel, device) pair: the engine raises it once per pair (a bit
+    per device in a per-kernel mask, csrc/hs_util.cpp) instead of once per process - a second device in the same process gets its
+    own.  On a one-GPU box: solver instances pinned with HIPSDP_DEVICE=0 raise the limits of the kernels they launch exactly once
+    (the count grows with the first solve and not with later ones or with a second instance), and nothing is booked on device 1."""
+    import instances
+    lib = gpu.lib()
+    b, A, ys, Xs, Zs = instances.planted_dense(150, 200)
+    core = ipm_ref.CoreProblem(b, [A])
+    os.environ["HIPSDP_DEVICE"] = "0"
+    try:
+        counts = []
+        for _ in range(2):
+            s = gpu.Solver(0)
+            s.load_core(core)
+            for _ in range(2):
+                info = s.solve(gaptol=1e-6, feastol=1e-6)
+                assert info.status == 0
+                counts.append(lib.hipsdp_func_attr_sets(0))
+            s.close()
+    finally:
+        os.environ.pop("HIPSDP_DEVICE", None)
+    assert counts[0] > 0
+    assert counts[1] == counts[0] and counts[2] == counts[0] and counts[3] == counts[0]
+    assert lib.hipsdp_func_attr_sets(1) == 0
