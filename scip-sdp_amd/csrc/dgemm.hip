@@ -609,7 +609,7 @@ int hs_dgemm(hipStream_t stream, const hs_gemm_args* a)
          hs_mfma_flops_add(hs_gemm_executed_flops(a, 128, HS_BK, kchunk, 0));
       }
       else
-         hs_mfma_flops_add(hs_gemm_executed_flops(a, 128, 8, kchunk, 1));
+         hs_mfma_flops_add(hs_gemm_executed_flops(a, 128, 8, kchunk, hs_dgemm2_slabskip()));
    }
    else
    {

@@ -40,6 +40,10 @@ typedef const __attribute__((address_space(1))) void* hs_gbl_ptr;
 #define G2_OPSZ (G2_BT * G2_BKS)            /* doubles per operand per stage */
 #define G2_SLOT (2 * G2_OPSZ)
 #define G2_GPS  4                           /* LDS-DMA instructions per wave per stage: 2 per operand */
+#ifndef G2_ABL
+#define G2_ABL  0                           /* developer ablations (tests/devtools/gemm2_abl.sh), wrong results: 1 no C stores, 2 no DMA,
+                                             * 4 no matrix instructions, 8 no drain of the DMA counter in front of the stores */
+#endif
 
 __device__ __attribute__((aligned(16))) double hs_g2_zero[2] = {0.0, 0.0};
 
@@ -69,10 +73,22 @@ __device__ __forceinline__ void g2_decode(const hs_gemm_args& p, long long pos, 
       tj = (int) (t - (long long) ti * tn);
       if ( rotdiv > 0 )
       {
+         /* the rotation advances by one per round of the XCD's workgroups (every workgroup sees all K lengths in turn) and differs
+          * between the workgroups of a round by their index / (Wx / tiles): the two workgroups that share a CU (w and w + Wx / 2 in
+          * dispatch order) then never walk items of the same length at the same time.  Without the second term they ran in lock
+          * step, reached their epilogues together, and the matrix pipe idled while both stored (the 0.5 ms of stores of an
+          * n^3 product of the C2 assembly added to its time instead of hiding behind the partner's matrix instructions). */
          if ( p.flags & HS_GEMM_B_LOWTRI )
-            tj = (int) ((tj + (pos / tn) / rotdiv) % tn);
+         {
+            const long long q = pos / tn;
+            const long long qr = q / rotdiv;
+            tj = (int) ((tj + qr + ((q - qr * rotdiv) * tn) / rotdiv) % tn);
+         }
          else if ( p.flags & (HS_GEMM_A_LOWTRI | HS_GEMM_A_UPTRI) )
-            ti = (int) ((ti + bz / rotdiv) % tm);
+         {
+            const int br = bz / rotdiv;
+            ti = (ti + br + ((bz - br * rotdiv) * tm) / rotdiv) % tm;
+         }
       }
    }
    it->m0 = ti * G2_BT;
@@ -184,16 +200,20 @@ __global__ void __launch_bounds__(256, G2_WGPC) hs_dgemm2_kernel(hs_gemm_args p,
       }
    };
    int gp = 0;                          /* stages issued */
-   auto issue_stage = [&]()
+   /* the four LDS-DMA pieces of the next stage WITHOUT any branch (IL = 0 instances: they sit between the matrix instructions of
+    * the consumer's stage, one basic block); with nothing left to load the pieces read the zero constant - the number of operations
+    * per stage stays four, which is what the counted waits assume */
+   auto issue_loads = [&]() __attribute__((always_inline))
    {
       double* slot = g2_smem + (gp % G2_NS) * G2_SLOT;
+      const bool live = !pdone;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
       {
          const int piece = wave * 2 + i;
-         const double* src = (pk + 2 * ac < pkend) ? pa[i] : hs_g2_zero;
+         const double* src = (live && pk + 2 * ac < pkend) ? pa[i] : hs_g2_zero;
+         if ( !(G2_ABL & 2) )
          __builtin_amdgcn_global_load_lds((hs_gbl_ptr) src, (hs_lds_ptr) (slot + piece * 128), 16, 0, 0);
-         pa[i] += G2_BKS;
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -201,19 +221,25 @@ __global__ void __launch_bounds__(256, G2_WGPC) hs_dgemm2_kernel(hs_gemm_args p,
          const int piece = wave * 2 + i;
          const double* src;
          if ( LB == HS_KC )
-         {
-            src = (pk + 2 * ac < pkend) ? pb[i] : hs_g2_zero;
-            pb[i] += G2_BKS;
-         }
+            src = (live && pk + 2 * ac < pkend) ? pb[i] : hs_g2_zero;
          else
-         {
-            src = (pk + piece < pkend) ? pb[i] : hs_g2_zero;
-            pb[i] += (long long) G2_BKS * p.ldb;
-         }
+            src = (live && pk + piece < pkend) ? pb[i] : hs_g2_zero;
+         if ( !(G2_ABL & 2) )
          __builtin_amdgcn_global_load_lds((hs_gbl_ptr) src, (hs_lds_ptr) (slot + G2_OPSZ + piece * 128), 16, 0, 0);
       }
-      pk += G2_BKS;
+   };
+   auto issue_advance = [&]() __attribute__((always_inline))
+   {
       ++gp;
+      if ( pdone )
+         return;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+      {
+         pa[i] += G2_BKS;
+         pb[i] += (LB == HS_KC) ? (long long) G2_BKS : (long long) G2_BKS * p.ldb;
+      }
+      pk += G2_BKS;
       if ( pk >= pkend )
       {
          ppos += Wx;
@@ -259,48 +285,139 @@ __global__ void __launch_bounds__(256, G2_WGPC) hs_dgemm2_kernel(hs_gemm_args p,
 
    producer_settle();
    consumer_settle();
-#pragma unroll
-   for (int s = 0; s < G2_NS - 1; ++s)
-      if ( !pdone )
-         issue_stage();
-
    int gc = 0;                          /* stage being consumed */
    int landed = 0;                      /* stages [.., landed) are known complete (drained by an epilogue) */
-   while ( !cdone )
+
+   /* the item's tile: alpha acc (+ beta C) -> C or its split-K slab; the accumulators start the next item at zero */
+   auto store_item = [&]()
    {
-      /* stage gc must have landed; newer stages may stay in flight (in-order return) */
-      if ( gc >= landed )
+      if ( IL )
+         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      /* the last matrix instruction was issued as text (tri_mfma) */
+      /* drain the DMA counter first, so that no store sits between a DMA and the wait that retires it */
+      if ( !(G2_ABL & 8) )
       {
-         const int newer = gp - 1 - gc;
-         if ( G2_NS >= 5 && newer >= 3 ) g2_wait_vm<3 * G2_GPS>();
-         else if ( newer >= 2 ) g2_wait_vm<2 * G2_GPS>();
-         else if ( newer == 1 ) g2_wait_vm<G2_GPS>();
-         else g2_wait_vm<0>();
+         g2_wait_vm<0>();
+         landed = gp;
       }
-      __builtin_amdgcn_s_barrier();
-      if ( !pdone )
-         issue_stage();
-      const double* sa = g2_smem + (gc % G2_NS) * G2_SLOT;
-      const double* sb = sa + G2_OPSZ;
-      /* triangular operands: inside the diagonal band of the tile whole 16 x 4 operand slabs are zero; their MFMAs are
-       * skipped (adding a zero product changes nothing, so the result is the same) */
-      const bool triB = (p.flags & HS_GEMM_B_LOWTRI) && ck < cit.n0 + G2_BT;
-      const bool triA = (p.flags & HS_GEMM_A_LOWTRI) && ck + G2_BKS > cit.m0;
-#pragma unroll
-      for (int ks = 0; ks < G2_BKS / 4; ++ks)
+      double* C = p.C;
+      long long ldc = p.ldc;
+      double alpha = p.alpha, beta = p.beta;
+      if ( p.splitk > 1 )
       {
-         const int kk = ck + 4 * ks;
+         C = p.ws + (long long) cit.bz * p.M * p.N;
+         ldc = p.N;
+         alpha = 1.0;
+         beta = 0.0;
+      }
+      else
+         C += (long long) cit.bz * p.strideC;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+      {
+#pragma unroll
+         for (int r = 0; r < 4; ++r)
+         {
+            const int row = cit.m0 + wm * sw + 16 * ss * i + (lane >> 4) + 4 * r;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+               const int col = cit.n0 + wn * sw + 16 * ss * j + (lane & 15);
+               if ( (!(G2_ABL & 1) || acc[i][j][r] == 1.2345e301) && row < p.M && col < p.N )
+               {
+                  double* c = C + (long long) row * ldc + col;
+                  double v = alpha * acc[i][j][r];
+                  if ( beta != 0.0 )
+                     v += beta * (*c);
+                  *c = v;
+               }
+            }
+         }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+         for (int j = 0; j < 4; ++j)
+            acc[i][j] = (v4d2){0.0, 0.0, 0.0, 0.0};
+      cpos += Wx;
+      cdone = cpos >= lim;
+      consumer_settle();
+   };
+
+   /* ---- the stage loop.  A stage is two halves.  First half: the 16 matrix instructions of K step 0 with the fragment reads of
+    * K step 1 between them; then the barrier that frees this stage's ring slot and publishes the next stage; second half: the 16
+    * matrix instructions of K step 1 with the DMA of stage gc + NS (into the slot just freed) and the fragment reads of K step 0
+    * of stage gc + 1 between them.  A v_mfma_f64_16x16x4 occupies the pipe for 64 cycles: what the wave issues meanwhile costs
+    * nothing, whereas reads in front of the matrix instructions (the earlier form of this loop) were paid by every stage: - 10 %
+    * on the Gram product.  Full operands (IL = 0): each half is ONE basic block whose instruction order is pinned by
+    * scheduling groups.  Triangular operands (IL = 1): the matrix instructions of zero slabs inside the diagonal band are skipped
+    * by wave-uniform branches, so the halves are many blocks; the reads and the DMA are issued in front of them and complete
+    * behind them all the same.  (A third form - straight-line halves outside the band, branches inside - gave the register
+    * allocator four versions of the accumulator code and 257 spilled registers.)  Same products in the same order per accumulator
+    * as before. */
+#pragma unroll
+   for (int s = 0; s < G2_NS; ++s)
+   {
+      issue_loads();
+      issue_advance();
+   }
+   double f0a[4], f0b[4], f1a[4], f1b[4];
+   g2_wait_vm<(G2_NS - 1) * G2_GPS>();
+   __builtin_amdgcn_s_barrier();
+#pragma unroll
+   for (int i = 0; i < 4; ++i)
+   {
+      f0a[i] = g2_frag<HS_KC>(g2_smem, wm * sw, ss * i, 0, lane);
+      f0b[i] = g2_frag<LB>(g2_smem + G2_OPSZ, wn * sw, ss * i, 0, lane);
+   }
+   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+   /* tell the compiler that the fragments have landed (the explicit s_waitcnt above it is invisible to its scoreboard: without
+    * this every block that uses them starts with an lgkmcnt(0) of its own, which also waits for the reads issued since) */
+   auto landed_frags = [&](double (&fa)[4], double (&fb)[4])
+   {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+         asm volatile("" : "+v"(fa[i]), "+v"(fb[i]));
+   };
+   landed_frags(f0a, f0b);
+
+   /* triangular operand (IL = 1: B lower triangular, IL = 2: A lower triangular): inside the diagonal band of the tile whole
+    * 16 x 4 operand slabs are zero and their matrix instructions are skipped (adding a zero product changes nothing).  The
+    * nonzero slabs of a wave are a prefix (B) / suffix (A) of its four, so the 16 instructions of a K step are laid out slab
+    * by slab, four blocks of four behind one scalar branch each (a guard per instruction made every one of them a basic block
+    * with a wait of its own; a switch that falls through into the blocks came back from the compiler's CFG structuriser with
+    * copies of the accumulators and 100 spilled registers). */
+   auto tri_mfma = [&](const double (&fa)[4], const double (&fb)[4], int kk, bool tri, bool issue)
+   {
+      /* the instruction as text with the accumulator tied to itself: through the builtin the joins of the skipped and the taken
+       * paths became accumulate-into-another-register forms with copies, and 81 .. 107 spilled registers.  (The compiler's
+       * hazard recogniser does not see an MFMA here: store_item() pads the one read-after-MFMA that could come too early.) */
+#define G2_MFMA(i, j) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(fa[i]), "v"(fb[j]))
+#define G2_ROW(i) { _Pragma("unroll") for (int j = 0; j < 4; ++j) G2_MFMA(i, j); }
+#define G2_COL(j) { _Pragma("unroll") for (int i = 0; i < 4; ++i) G2_MFMA(i, j); }
+      if ( IL == 1 )
+      {
          /* B[k][n] = 0 for k < n: column slab c (columns from n0 + 16 c) is zero when kk + 3 < n0 + 16 c */
          int jlim = 4;
-         if ( IL && triB )
+         if ( tri )
          {
             const int d = kk + 3 - cit.n0;
             const int qd = d >> 4;                       /* last nonzero slab (d >= 0) */
             jlim = (d < 0 || qd < wn) ? 0 : min(4, ((qd - wn) >> 1) + 1);
          }
+         jlim = __builtin_amdgcn_readfirstlane(jlim);         /* uniform by construction; said so, the branches are scalar */
+         if ( jlim >= 4 ) G2_COL(3)
+         if ( issue )
+            issue_loads();                 /* address arithmetic and DMA in the shadow of the block above (when it is not skipped) */
+         if ( jlim >= 3 ) G2_COL(2)
+         if ( jlim >= 2 ) G2_COL(1)
+         if ( jlim >= 1 ) G2_COL(0)
+      }
+      else
+      {
          /* A[m][k] = 0 for k > m: row slab r (rows from m0 + 16 r) is zero when kk > m0 + 16 r + 15 */
          int imin = 0;
-         if ( IL && triA )
+         if ( tri )
          {
             const int e = kk - 15 - cit.m0;
             if ( e > 0 )
@@ -309,72 +426,114 @@ __global__ void __launch_bounds__(256, G2_WGPC) hs_dgemm2_kernel(hs_gemm_args p,
                imin = g <= wm ? 0 : min(4, (g - wm + 1) >> 1);
             }
          }
-         double fa[4], fb[4];
+         imin = __builtin_amdgcn_readfirstlane(imin);
+         if ( imin <= 3 ) G2_ROW(3)
+         if ( issue )
+            issue_loads();
+         if ( imin <= 2 ) G2_ROW(2)
+         if ( imin <= 1 ) G2_ROW(1)
+         if ( imin <= 0 ) G2_ROW(0)
+      }
+#undef G2_MFMA
+#undef G2_ROW
+#undef G2_COL
+   };
+
+   while ( !cdone )
+   {
+      const double* sa = g2_smem + (gc % G2_NS) * G2_SLOT;
+      const double* sn = g2_smem + ((gc + 1) % G2_NS) * G2_SLOT;
+      const bool tri = IL == 1 ? ck < cit.n0 + G2_BT : ck + G2_BKS > cit.m0;      /* stage inside the diagonal band */
+      /* ---- first half */
+      if ( !IL )
+      {
+         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
          for (int i = 0; i < 4; ++i)
          {
-            fa[i] = g2_frag<HS_KC>(sa, wm * sw, ss * i, ks, lane);
-            fb[i] = g2_frag<LB>(sb, wn * sw, ss * i, ks, lane);
+            f1a[i] = g2_frag<HS_KC>(sa, wm * sw, ss * i, 1, lane);
+            f1b[i] = g2_frag<LB>(sa + G2_OPSZ, wn * sw, ss * i, 1, lane);
          }
 #pragma unroll
          for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-               if ( i >= imin && j < jlim )
-                  acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
+               acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0a[i], f0b[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+         for (int q = 0; q < 8; ++q)
+         {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+         }
+         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+         __builtin_amdgcn_sched_barrier(0);
       }
-      ck += G2_BKS;
+      else
+      {
+#pragma unroll
+         for (int i = 0; i < 4; ++i)
+         {
+            f1a[i] = g2_frag<HS_KC>(sa, wm * sw, ss * i, 1, lane);
+            f1b[i] = g2_frag<LB>(sa + G2_OPSZ, wn * sw, ss * i, 1, lane);
+         }
+         tri_mfma(f0a, f0b, ck, tri, false);
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      landed_frags(f1a, f1b);
+      /* stage gc + 1 must have landed; the NS - 2 stages after it may stay in flight (in-order return) */
+      if ( gc + 1 >= landed )
+         g2_wait_vm<(G2_NS - 2) * G2_GPS>();
+      __builtin_amdgcn_s_barrier();
+      /* ---- second half */
+      if ( !IL )
+      {
+         __builtin_amdgcn_sched_barrier(0);
+         issue_loads();
+#pragma unroll
+         for (int i = 0; i < 4; ++i)
+         {
+            f0a[i] = g2_frag<HS_KC>(sn, wm * sw, ss * i, 0, lane);
+            f0b[i] = g2_frag<LB>(sn + G2_OPSZ, wn * sw, ss * i, 0, lane);
+         }
+#pragma unroll
+         for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+               acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1a[i], f1b[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+         for (int q = 0; q < 4; ++q)
+         {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+         }
+#pragma unroll
+         for (int q = 0; q < 8; ++q)
+         {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+         }
+         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+         __builtin_amdgcn_sched_barrier(0);
+      }
+      else
+      {
+#pragma unroll
+         for (int i = 0; i < 4; ++i)
+         {
+            f0a[i] = g2_frag<HS_KC>(sn, wm * sw, ss * i, 0, lane);
+            f0b[i] = g2_frag<LB>(sn + G2_OPSZ, wn * sw, ss * i, 0, lane);
+         }
+         tri_mfma(f1a, f1b, ck + 4, tri, true);
+      }
+      issue_advance();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      landed_frags(f0a, f0b);
+      ck += G2_BKS;
       ++gc;
       if ( --cleft == 0 )
-      {
-         /* epilogue: drain the DMA counter first, so that no store sits between a DMA and the wait that retires it */
-         g2_wait_vm<0>();
-         landed = gp;
-         double* C = p.C;
-         long long ldc = p.ldc;
-         double alpha = p.alpha, beta = p.beta;
-         if ( p.splitk > 1 )
-         {
-            C = p.ws + (long long) cit.bz * p.M * p.N;
-            ldc = p.N;
-            alpha = 1.0;
-            beta = 0.0;
-         }
-         else
-            C += (long long) cit.bz * p.strideC;
-#pragma unroll
-         for (int i = 0; i < 4; ++i)
-         {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-            {
-               const int row = cit.m0 + wm * sw + 16 * ss * i + (lane >> 4) + 4 * r;
-#pragma unroll
-               for (int j = 0; j < 4; ++j)
-               {
-                  const int col = cit.n0 + wn * sw + 16 * ss * j + (lane & 15);
-                  if ( row < p.M && col < p.N )
-                  {
-                     double* c = C + (long long) row * ldc + col;
-                     double v = alpha * acc[i][j][r];
-                     if ( beta != 0.0 )
-                        v += beta * (*c);
-                     *c = v;
-                  }
-               }
-            }
-         }
-#pragma unroll
-         for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-               acc[i][j] = (v4d2){0.0, 0.0, 0.0, 0.0};
-         cpos += Wx;
-         cdone = cpos >= lim;
-         consumer_settle();
-      }
+         store_item();
    }
+   g2_wait_vm<0>();               /* a workgroup without items still has its prologue stages in flight */
 }
 
 /* 1: launched, 0: not eligible (caller uses dgemm.hip), < 0: error code negated */
@@ -387,6 +546,19 @@ int hs_dgemm2_enable(int on)
 {
    g2_disabled = on ? 0 : 1;
    return __atomic_load_n(&g2_taken, __ATOMIC_RELAXED);
+}
+
+/* 1: products with a triangular operand skip the zero slabs inside the diagonal band (instance IL = 1); 0 (HIPSDP_GEMM2_SKIP=0):
+ * they run the straight-line instance over the same K ranges - more matrix instructions, no branches between them */
+int hs_dgemm2_slabskip(void)
+{
+   static int skip = -1;
+   if ( skip < 0 )
+   {
+      const char* env = getenv("HIPSDP_GEMM2_SKIP");
+      skip = (env != NULL && env[0] == '0') ? 0 : 1;
+   }
+   return skip;
 }
 
 int hs_dgemm2_try(hipStream_t stream, const hs_gemm_args* a, int kchunk)
@@ -447,22 +619,32 @@ int hs_dgemm2_try(hipStream_t stream, const hs_gemm_args* a, int kchunk)
          rotdiv = (int) (Wx / (tm * tn));
    }
    const size_t smem = (size_t) G2_NS * G2_SLOT * sizeof(double);
-   /* triangular operand: the instance with interleaved slab ownership (IL = 1) */
-   const bool il = (a->flags & (HS_GEMM_A_LOWTRI | HS_GEMM_B_LOWTRI)) != 0;
-   static hs_attr_mask attr_done[4];
-   const int inst = (a->layB == HS_KC ? 0 : 2) + (il ? 1 : 0);
-   const void* fn = inst == 0 ? reinterpret_cast<const void*>(&hs_dgemm2_kernel<HS_KC, 0>)
-      : inst == 1 ? reinterpret_cast<const void*>(&hs_dgemm2_kernel<HS_KC, 1>)
-      : inst == 2 ? reinterpret_cast<const void*>(&hs_dgemm2_kernel<HS_MC, 0>)
-      : reinterpret_cast<const void*>(&hs_dgemm2_kernel<HS_MC, 1>);
+   /* triangular operand: the instances with interleaved slab ownership that skip the zero slabs of the diagonal band (IL = 1: B,
+    * IL = 2: A; both triangular - not a product of this library - runs without skipping, which is always correct) */
+   const bool triA = (a->flags & HS_GEMM_A_LOWTRI) != 0, triB = (a->flags & HS_GEMM_B_LOWTRI) != 0;
+   const int il = (hs_dgemm2_slabskip() && triA != triB) ? (triB ? 1 : 2) : 0;
+   static hs_attr_mask attr_done[6];
+   const int inst = (a->layB == HS_KC ? 0 : 3) + il;
+   const void* fn = NULL;
+   switch ( inst )
+   {
+   case 0: fn = reinterpret_cast<const void*>(&hs_dgemm2_kernel<HS_KC, 0>); break;
+   case 1: fn = reinterpret_cast<const void*>(&hs_dgemm2_kernel<HS_KC, 1>); break;
+   case 2: fn = reinterpret_cast<const void*>(&hs_dgemm2_kernel<HS_KC, 2>); break;
+   case 3: fn = reinterpret_cast<const void*>(&hs_dgemm2_kernel<HS_MC, 0>); break;
+   case 4: fn = reinterpret_cast<const void*>(&hs_dgemm2_kernel<HS_MC, 1>); break;
+   default: fn = reinterpret_cast<const void*>(&hs_dgemm2_kernel<HS_MC, 2>); break;
+   }
    if ( hs_func_max_lds(fn, (int) smem, &attr_done[inst]) != HS_OK )
       return -HS_ERR_HIP;
    switch ( inst )
    {
    case 0: hipLaunchKernelGGL((hs_dgemm2_kernel<HS_KC, 0>), dim3(grid), dim3(256), smem, stream, *a, kchunk, ntile, total, rotdiv); break;
    case 1: hipLaunchKernelGGL((hs_dgemm2_kernel<HS_KC, 1>), dim3(grid), dim3(256), smem, stream, *a, kchunk, ntile, total, rotdiv); break;
-   case 2: hipLaunchKernelGGL((hs_dgemm2_kernel<HS_MC, 0>), dim3(grid), dim3(256), smem, stream, *a, kchunk, ntile, total, rotdiv); break;
-   default: hipLaunchKernelGGL((hs_dgemm2_kernel<HS_MC, 1>), dim3(grid), dim3(256), smem, stream, *a, kchunk, ntile, total, rotdiv); break;
+   case 2: hipLaunchKernelGGL((hs_dgemm2_kernel<HS_KC, 2>), dim3(grid), dim3(256), smem, stream, *a, kchunk, ntile, total, rotdiv); break;
+   case 3: hipLaunchKernelGGL((hs_dgemm2_kernel<HS_MC, 0>), dim3(grid), dim3(256), smem, stream, *a, kchunk, ntile, total, rotdiv); break;
+   case 4: hipLaunchKernelGGL((hs_dgemm2_kernel<HS_MC, 1>), dim3(grid), dim3(256), smem, stream, *a, kchunk, ntile, total, rotdiv); break;
+   default: hipLaunchKernelGGL((hs_dgemm2_kernel<HS_MC, 2>), dim3(grid), dim3(256), smem, stream, *a, kchunk, ntile, total, rotdiv); break;
    }
    if ( hipGetLastError() != hipSuccess )
       return -HS_ERR_HIP;

@@ -114,6 +114,7 @@ int hs_dgemm3_enabled(void);
  * skips inside the diagonal band.  The engine reads the difference around a Schur assembly (hipsdp_info.schur_flops_executed). */
 double hs_mfma_flops_total(void);
 void   hs_mfma_flops_add(double flops);
+int hs_dgemm2_slabskip(void);
 double hs_gemm_executed_flops(const hs_gemm_args* a, int BT, int kstage, int kchunk, int slabskip);
 
 /* choose a split-K factor for a [M x N x K] product so that at least ~2 waves of workgroups exist */
