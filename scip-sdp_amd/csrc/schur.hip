@@ -550,6 +550,23 @@ int hs_schur_small(hipStream_t s, int m1, int nblk, const int* n, const double* 
 {
    if ( nblk > SS_MAXBLK || m1 > SS_MAXM1 || m1 < 1 || (long long) q * m1 > 2000000LL )
       return 0;
+   {
+      /* the one-launch form does the m1^2 / 2 inner products <A_i, U_j> with scalar arithmetic out of L2: it wins while the launch
+       * count decides (few variables) and loses by 20x at m = 1000 (n = 48: 4.4 ms against 0.2 ms of the GEMM path).  The bound is
+       * on the multiply-adds of those products; measured crossover of the whole iteration (tools/grid_sweep.sh, round 3): n = 16
+       * between m = 100 and 200, n = 32 between 50 and 100, n = 48 at about 20, i.e. 1 - 5e6 (HIPSDP_SCHUR_SMALL_MAXWORK) */
+      static double maxwork = -1.0;
+      if ( maxwork < 0.0 )
+      {
+         const char* env = getenv("HIPSDP_SCHUR_SMALL_MAXWORK");
+         maxwork = env != NULL ? atof(env) : 1.5e6;
+      }
+      double work = 0.0;
+      for (int k = 0; k < nblk; ++k)
+         work += 0.5 * (double) m1 * m1 * (double) n[k] * n[k];
+      if ( work > maxwork )
+         return 0;
+   }
    ss_args B;
    B.nblk = nblk;
    int nmax = 1;
