@@ -42,6 +42,19 @@ struct hs_rb_finish { int m; double eta, rg, sigmu, tau, kappa, etk; const doubl
    int s0, bub, bh, wrp, bu1, dtau, dkappa, den; };
 int hs_red_batch_finish(hipStream_t s, const void* fin, size_t bytes);
 int hs_copy_scalar(hipStream_t s, double* dst, const double* src);
+/* regions in which everything recordable on the stream is recorded (the small single-workgroup kernels of the B&B-sized regime too:
+ * kernels.hip) and everything else launches the records first; regions nest, a read-back (hs_red_batch_end_publish) ends them */
+void hs_red_batch_hold(hipStream_t s);
+int hs_red_batch_release(void);
+int hs_red_batch_flush(void);
+int hs_red_batch_end_all(void);
+int hs_make_ext(hipStream_t s, int m, double s0, double s1, const double* v, double* ext);
+int hs_lp_rows_small(hipStream_t s, int q, int m1, const double* Dext, const double* v, int mode, double eta, double sigmu, const double* x,
+   const double* z, const double* rd, const double* elp, double* out1, double* out2);
+#define HS_AS_MAXBLK 8
+struct hs_as_args { int nblk; int n2[HS_AS_MAXBLK]; const double* A[HS_AS_MAXBLK]; const double* V[HS_AS_MAXBLK]; };
+int hs_apply_A_small(hipStream_t s, int m1, const hs_as_args* B, int q, const double* Dext, const double* vlp, double* out, int epi,
+   double scal, const double* vin, double* vout);
 int hs_axpy3(hipStream_t s, double a, long long n1, const double* x1, double* y1, long long n2, const double* x2, double* y2,
    long long n3, const double* x3, double* y3);
 int hs_dot(hipStream_t s, long long n, const double* a, const double* b, double* out, int accumulate, double* ws);

@@ -1195,16 +1195,6 @@ __global__ void k_flag_nonpositive(int q, const double* __restrict__ x, const do
       atomicExch(flag, 1);
 }
 
-/* ext[0] = s0, ext[1 + i] = s1 * v[i] */
-__global__ void k_make_ext(int m, double s0, double s1, const double* __restrict__ v, double* __restrict__ ext)
-{
-   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-   if ( i == 0 )
-      ext[0] = s0;
-   if ( i < m )
-      ext[1 + i] = s1 * v[i];
-}
-
 /* rp = b * tau - AX[1:] */
 __global__ void k_rp(int m, double tau, const double* __restrict__ b, const double* __restrict__ AX, double* __restrict__ rp)
 {
@@ -1364,6 +1354,7 @@ static inline dim3 g1d(long long n) { long long g = (n + 255) / 256; if ( g < 1 
 static int gemm_on(hipStream_t st, double* ws, long long wslen, int layA, int layB, int M, int N, int K, double alpha,
    const double* A, long long lda, const double* B, long long ldb, double beta, double* C, long long ldc, int flags = 0)
 {
+   (void) hs_red_batch_flush();          /* inside a held region: behind the records */
    int sk = 1;
    const long long tiles = (long long) ((M + 63) / 64) * ((N + 63) / 64);
    /* few tiles: the 32 x 32 kernel with the K split inside the workgroup takes the product (no slabs, no second launch);
@@ -1557,7 +1548,7 @@ static int publish_and_wait(hipsdp_solver* s, int off, int n)
 static int read_scalars(hipsdp_solver* s, HostScalars& h, int* flags3)
 {
    if ( s->comm != NULL || !s->use_publish )
-      HS_CALL( hs_red_batch_end() );      /* recorded reductions must run before the scalars are read */
+      HS_CALL( hs_red_batch_end_all() );  /* recorded operations must run before the scalars are read */
    h.v.resize(s->nsc);
    if ( s->comm != NULL )
    {
@@ -1765,78 +1756,7 @@ static int pass_AT(hipsdp_solver* s, Block& B, const double* coef, double sa, co
    return hs_gemv_t(s->stream, m1, n2, B.A, n2, coef, sa, add, out);
 }
 
-/* small problems: A(V) over all blocks + LP part + the element-wise kernel that always follows, in one launch.
- * epi 0: out only; 1: h[i] = out[1 + i] - eta * rp[i] (k_h); 2: rp[i] = b[i] * tau - out[1 + i] (k_rp) */
-#define AS_MAXBLK 8
-struct as_args { int nblk; int n2[AS_MAXBLK]; const double* A[AS_MAXBLK]; const double* V[AS_MAXBLK]; };
-
-__global__ void __launch_bounds__(256) k_apply_A_small(int m1, as_args B, int q, const double* __restrict__ Dext,
-   const double* __restrict__ vlp, double* __restrict__ out, int epi, double scal, const double* __restrict__ vin,
-   double* __restrict__ vout)
-{
-   __shared__ double sh[4];
-   const int i = blockIdx.x;
-   const int tid = threadIdx.x;
-   double acc = 0.0;
-   for (int k = 0; k < B.nblk; ++k)
-   {
-      const double* a = B.A[k] + (long long) i * B.n2[k];
-      const double* v = B.V[k];
-      for (int e = tid; e < B.n2[k]; e += 256)
-         acc += a[e] * v[e];
-   }
-   for (int r = tid; r < q; r += 256)
-      acc += Dext[(long long) r * m1 + i] * vlp[r];
-   for (int off = 32; off > 0; off >>= 1)
-      acc += __shfl_down(acc, off, 64);
-   if ( (tid & 63) == 0 )
-      sh[tid >> 6] = acc;
-   __syncthreads();
-   if ( tid == 0 )
-   {
-      const double v = sh[0] + sh[1] + sh[2] + sh[3];
-      out[i] = v;
-      if ( i >= 1 )
-      {
-         if ( epi == 1 )
-            vout[i - 1] = v - scal * vin[i - 1];
-         else if ( epi == 2 )
-            vout[i - 1] = vin[i - 1] * scal - v;
-      }
-   }
-}
-
-/* small problems, LP rows: t_r = Dext[r, :] . v, then the element-wise kernels that follow, in one launch (one wavefront per row).
- * mode 0: out1 = t - z (the residual rd);  mode 1: out1 = t + eta * rd (dz), out2 = sigmu / z - x - (x * out1 + elp) / z (dx) */
-__global__ void __launch_bounds__(256) k_lp_rows_small(int q, int m1, const double* __restrict__ Dext, const double* __restrict__ v,
-   int mode, double eta, double sigmu, const double* __restrict__ x, const double* __restrict__ z, const double* __restrict__ rd,
-   const double* __restrict__ elp, double* __restrict__ out1, double* __restrict__ out2)
-{
-   const int lane = threadIdx.x & 63;
-   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-   if ( r >= q )
-      return;
-   const double* d = Dext + (long long) r * m1;
-   double t = 0.0;
-   for (int i = lane; i < m1; i += 64)
-      t += d[i] * v[i];
-   for (int off = 32; off > 0; off >>= 1)
-      t += __shfl_down(t, off, 64);
-   if ( lane == 0 )
-   {
-      if ( mode == 0 )
-         out1[r] = t - z[r];
-      else
-      {
-         const double dzr = t + eta * rd[r];
-         out1[r] = dzr;
-         double tt = x[r] * dzr;
-         if ( elp != NULL )
-            tt += elp[r];
-         out2[r] = sigmu / z[r] - x[r] - tt / z[r];
-      }
-   }
-}
+#define AS_MAXBLK HS_AS_MAXBLK
 
 static bool small_problem(const hipsdp_solver* s)
 {
@@ -1852,13 +1772,35 @@ static bool small_problem(const hipsdp_solver* s)
    return tot <= 8192;
 }
 
+/* B&B-sized problems: runs of small kernels are recorded and executed by one launch (kernels.hip: hs_red_batch_hold).  A region
+ * covers a whole direction, or the step of the iterate with the residual pass behind it; HIPSDP_BATCH=0 switches the regions off
+ * (every kernel its own launch, as before round 3; same arithmetic either way). */
+static bool batch_regions(const hipsdp_solver* s)
+{
+   static int on = -1;
+   if ( on < 0 )
+   {
+      const char* env = getenv("HIPSDP_BATCH");
+      on = (env != NULL && env[0] == '0') ? 0 : 1;
+   }
+   return on != 0 && s->comm == NULL && small_problem(s);
+}
+
+struct BatchRegion
+{
+   bool on;
+   BatchRegion(hipsdp_solver* s, bool want) : on(want) { if ( on ) hs_red_batch_hold(s->stream); }
+   int close() { if ( !on ) return HS_OK; on = false; return hs_red_batch_release(); }
+   ~BatchRegion() { if ( on ) (void) hs_red_batch_release(); }
+};
+
 /* returns 1 when the fused launch was used */
 static int apply_A_small(hipsdp_solver* s, double* const* Vk, const double* vlp, double* out, int epi, double scal,
    const double* vin, double* vout)
 {
    if ( !small_problem(s) )
       return 0;
-   as_args B;
+   hs_as_args B;
    B.nblk = (int) s->blk.size();
    for (int k = 0; k < AS_MAXBLK; ++k)
    {
@@ -1870,9 +1812,9 @@ static int apply_A_small(hipsdp_solver* s, double* const* Vk, const double* vlp,
       B.A[k] = s->blk[k].A;
       B.V[k] = Vk[k];
    }
-   hipLaunchKernelGGL(k_apply_A_small, dim3(s->m + 1), dim3(256), 0, s->stream, s->m + 1, B, s->q, s->Dext, vlp, out, epi, scal, vin, vout);
-   if ( hipGetLastError() != hipSuccess )
-      return -HS_ERR_HIP;
+   const int rc = hs_apply_A_small(s->stream, s->m + 1, &B, s->q, s->Dext, vlp, out, epi, scal, vin, vout);
+   if ( rc != HS_OK )
+      return -rc;
    return 1;
 }
 
@@ -1927,6 +1869,7 @@ static int direction(hipsdp_solver* s, double sigma, double eta, double mu, doub
    const double sigmu = sigma * mu;
    std::vector<double*> Hs;
    int fusedA = 0;
+   BatchRegion region(s, part == 0 && batch_regions(s));
    if ( part != 2 )
    {
    for (auto& B : s->blk)
@@ -1954,6 +1897,7 @@ static int direction(hipsdp_solver* s, double sigma, double eta, double mu, doub
       HS_CALL( apply_A(s, Hs.data(), s->hl, s->AH) );
    if ( fusedA == 0 && m > 0 )
    {
+      HS_CALL( hs_red_batch_flush() );
       hipLaunchKernelGGL(k_h, g1d(m), dim3(256), 0, s->stream, m, eta, s->AH, s->rp, s->u1);
       HS_LAUNCH_CHECK();
    }
@@ -1962,7 +1906,10 @@ static int direction(hipsdp_solver* s, double sigma, double eta, double mu, doub
    }
    const bool fuse_solve = (fusedA == 1) && m > 0 && m <= 64;      /* single-block factor of M: solve, reductions and closing kernel in one launch */
    if ( m > 0 && !fuse_solve && !u1_solved )
+   {
+      HS_CALL( hs_red_batch_flush() );
       HS_CALL( hs_trsv_sync(s->stream, m, s->Lm, s->dinvm, 1, s->u1, m, solve_mode(s), s->trsv_ws, &s->trsv_epoch) );
+   }
    /* BH = sum <B_k, H_k> + beta^T hl ; wrp ; bu1 */
    hs_red_batch_begin(s->stream);
    if ( fuse_solve )
@@ -1984,6 +1931,7 @@ static int direction(hipsdp_solver* s, double sigma, double eta, double mu, doub
    HS_CALL( hs_red_batch_end() );
    if ( !finished )
    {
+      HS_CALL( hs_red_batch_flush() );
       hipLaunchKernelGGL(k_finish_dir, g1d(m > 0 ? m : 1), dim3(256), 0, s->stream, m, eta, rg, sigmu, s->tau, s->kappa, etk,
          s->u1, s->u2, s->dy, s->dyt, s->sc);
       HS_LAUNCH_CHECK();
@@ -2000,11 +1948,12 @@ static int direction(hipsdp_solver* s, double sigma, double eta, double mu, doub
          {
             if ( &B == &s->blk[0] )
             {
-               hipLaunchKernelGGL(k_make_ext, g1d(m1), dim3(256), 0, s->stream, m, 0.0, 1.0, s->u1, s->cvec + m1);
+               HS_CALL( hs_make_ext(s->stream, m, 0.0, 1.0, s->u1, s->cvec + m1) );
                HS_LAUNCH_CHECK();
             }
             HS_CALL( pass_AT(s, B, s->cvec + m1, 0.0, NULL, B.dZ) );
          }
+         HS_CALL( hs_red_batch_flush() );
          hipLaunchKernelGGL(k_dz_combine, g1d(n2), dim3(256), 0, s->stream, n2, B.dZ, B.P2, s->sc, eta, B.Rd);
          HS_LAUNCH_CHECK();
       }
@@ -2023,9 +1972,8 @@ static int direction(hipsdp_solver* s, double sigma, double eta, double mu, doub
    {
       if ( small_problem(s) )
       {
-         hipLaunchKernelGGL(k_lp_rows_small, dim3((q + 3) / 4), dim3(256), 0, s->stream, q, m1, s->Dext, s->dyt, 1, eta, sigmu, s->x, s->z,
-            s->rd, useE ? s->elp : NULL, s->dz, s->dx);
-         HS_LAUNCH_CHECK();
+         HS_CALL( hs_lp_rows_small(s->stream, q, m1, s->Dext, s->dyt, 1, eta, sigmu, s->x, s->z,
+            s->rd, useE ? s->elp : NULL, s->dz, s->dx) );
       }
       else
       {
@@ -2035,7 +1983,7 @@ static int direction(hipsdp_solver* s, double sigma, double eta, double mu, doub
          HS_CALL( hs_lp_dir(s->stream, q, sigmu, 1.0, s->x, s->z, s->dz, useE ? s->elp : NULL, s->dx) );
       }
    }
-   return HS_OK;
+   return region.close();
 }
 
 /* enqueue the step-length estimates for the current direction */
@@ -2391,7 +2339,7 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
    auto enqueue_residuals = [&]() -> int
    {
       const bool recur = rd_have && !want_cert && !rd_recompute;
-      hipLaunchKernelGGL(k_make_ext, g1d(m1), dim3(256), 0, st, m, -s->tau, 1.0, s->y, s->yt);
+      HS_CALL( hs_make_ext(st, m, -s->tau, 1.0, s->y, s->yt) );
       HS_LAUNCH_CHECK();
       hs_red_batch_begin(st);         /* the reductions of this phase run in one launch, right before the scalars are read */
       HS_CALL( hs_fill_scalar(st, s->sc + SC_RD2, 0.0) );
@@ -2410,6 +2358,7 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
          HS_CALL( hs_dot(st, n2, B.X, B.Z, s->sc + SC_XZ, 1, s->red_ws) );
          if ( want_cert )
          {
+            HS_CALL( hs_red_batch_flush() );
             hipLaunchKernelGGL(k_cert, g1d(n2), dim3(256), 0, st, n2, s->tau, B.Rd, B.A0, B.T1);
             HS_LAUNCH_CHECK();
             HS_CALL( hs_dot(st, n2, B.T1, B.T1, s->sc + SC_HD2, 1, s->red_ws) );
@@ -2420,9 +2369,8 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       {
          if ( small_problem(s) )
          {
-            hipLaunchKernelGGL(k_lp_rows_small, dim3((q + 3) / 4), dim3(256), 0, st, q, m1, s->Dext, s->yt, 0, 0.0, 0.0, s->x, s->z,
-               (const double*) NULL, (const double*) NULL, s->rd, (double*) NULL);
-            HS_LAUNCH_CHECK();
+            HS_CALL( hs_lp_rows_small(st, q, m1, s->Dext, s->yt, 0, 0.0, 0.0, s->x, s->z,
+               (const double*) NULL, (const double*) NULL, s->rd, (double*) NULL) );
          }
          else if ( !recur )
          {
@@ -2438,6 +2386,7 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
          if ( want_cert )
          {
             /* rd + tau * c */
+            HS_CALL( hs_red_batch_flush() );
             HS_HIP( hipMemcpy2DAsync(s->tmpq, sizeof(double), s->Dext, (size_t) m1 * sizeof(double), sizeof(double), (size_t) q, hipMemcpyDeviceToDevice, st) );
             HS_CALL( hs_scale_add(st, q, s->tau, s->tmpq, 1.0, s->rd, s->tmpq) );
             HS_CALL( hs_dot(st, q, s->tmpq, s->tmpq, s->sc + SC_HD2, 1, s->red_ws) );
@@ -2454,6 +2403,7 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
          HS_CALL( hs_copy_scalar(st, s->sc + SC_AX0, s->AX) );
          if ( fusedA == 0 )
          {
+            HS_CALL( hs_red_batch_flush() );
             hipLaunchKernelGGL(k_rp, g1d(m > 0 ? m : 1), dim3(256), 0, st, m, s->tau, s->b, s->AX, s->rp);
             HS_LAUNCH_CHECK();
          }
@@ -2906,8 +2856,8 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
             split_ok = false;
       if ( split_ok )
       {
-         hipLaunchKernelGGL(k_make_ext, g1d(m1), dim3(256), 0, st, m, 1.0, 1.0, s->u2, s->cvec);
-         hipLaunchKernelGGL(k_make_ext, g1d(m1), dim3(256), 0, st, m, 0.0, 1.0, s->u1, s->cvec + m1);
+         HS_CALL( hs_make_ext(st, m, 1.0, 1.0, s->u2, s->cvec) );
+         HS_CALL( hs_make_ext(st, m, 0.0, 1.0, s->u1, s->cvec + m1) );
          HS_LAUNCH_CHECK();
       }
       split_dz = split_ok;
@@ -2996,11 +2946,16 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
          const long long n2 = (long long) n * n;
          HS_CALL( gemm(s, HS_KC, HS_MC, n, n, n, 1.0, B.dX, n, B.dZ, n, 0.0, B.E, n) );
       }
-      if ( q > 0 )
-         HS_CALL( hs_vec_mul(st, q, s->dx, s->dz, s->elp) );
+      {
+         /* (B&B-sized: the LP term and the whole corrector direction are one launch) */
+         BatchRegion region(s, batch_regions(s));
+         if ( q > 0 )
+            HS_CALL( hs_vec_mul(st, q, s->dx, s->dz, s->elp) );
 
-      /* ---- corrector */
-      HS_CALL( direction(s, sigma, eta, mu, rg, true, dta * dka, 0, false, split_dz ? 1 : 0) );
+         /* ---- corrector */
+         HS_CALL( direction(s, sigma, eta, mu, rg, true, dta * dka, 0, false, split_dz ? 1 : 0) );
+         HS_CALL( region.close() );
+      }
       HS_CALL( steplen_enqueue(s) );
       HS_CALL( read_scalars(s, hs, NULL) );
       const double amax = steplen_host(s, hs);
@@ -3044,6 +2999,8 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
                std::swap(B.X, B.Xs);
                std::swap(B.Z, B.Zs);
             }
+            if ( batch_regions(s) )
+               hs_red_batch_hold(st);           /* (the read-back below ends the region) */
             HS_CALL( hs_axpy3(st, alpha - applied, m, s->dy, s->y, q, s->dx, s->x, q, s->dz, s->z) );
             applied = alpha;
             s->tau = tau0 + alpha * dt;
@@ -3303,7 +3260,7 @@ static int check_y_impl(hipsdp_solver* s, const double* y, double tol, double* l
    hipStream_t st = s->stream;
    if ( m > 0 )
       HS_HIP( hipMemcpyAsync(s->ys, y, (size_t) m * sizeof(double), hipMemcpyHostToDevice, st) );
-   hipLaunchKernelGGL(k_make_ext, g1d(m1), dim3(256), 0, st, m, -1.0, 1.0, s->ys, s->dyt);
+   HS_CALL( hs_make_ext(st, m, -1.0, 1.0, s->ys, s->dyt) );
    HS_LAUNCH_CHECK();
    HS_CALL( ensure_packed(s) );
    int k = 0;
@@ -3414,7 +3371,7 @@ extern "C" int hipsdp_eigencuts(hipsdp_solver* s, int block, const double* y, do
    hipStream_t st = s->stream;
    if ( m > 0 )
       HS_HIP( hipMemcpyAsync(s->ys, y, (size_t) m * sizeof(double), hipMemcpyHostToDevice, st) );
-   hipLaunchKernelGGL(k_make_ext, g1d(m1), dim3(256), 0, st, m, -1.0, 1.0, s->ys, s->dyt);
+   HS_CALL( hs_make_ext(st, m, -1.0, 1.0, s->ys, s->dyt) );
    HS_LAUNCH_CHECK();
    HS_CALL( ensure_packed(s) );
    HS_CALL( pass_AT(s, B, s->dyt, 0.0, NULL, B.W) );

@@ -10,6 +10,20 @@
  */
 #include "hs_kernels.h"
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+/* recorders of the deferred batch (defined with it below): 1 = recorded; 0 = not recorded, pending records have been launched, the
+ * caller launches its kernel */
+static int hs_rec_dir_block_small(hipStream_t s, int n, double c, const double* X, const double* R, const double* E, const double* Zinv,
+   double s1, double* out);
+static int hs_rec_lp_dir(hipStream_t s, int q, double sigmu, double eta, const double* x, const double* z, const double* r, const double* elp,
+   double* out);
+static int hs_rec_vec_mul(hipStream_t s, long long n, const double* a, const double* b, double* out);
+static int hs_rec_axpy3(hipStream_t s, double a, long long n1, const double* x1, double* y1, long long n2, const double* x2, double* y2,
+   long long n3, const double* x3, double* y3);
+static int hs_rec_gemv_t(hipStream_t s, int R, long long E, const double* A, long long lda, const double* coef, double sa, const double* add,
+   double* out);
 
 struct __attribute__((aligned(16))) dbl2 { double x, y; };
 
@@ -200,6 +214,7 @@ static inline int grid_for(long long n, int block, int cap)
 
 int hs_fill(hipStream_t s, double* p, long long n, double v)
 {
+   (void) hs_red_batch_flush();          /* inside a held region: behind the records */
    if ( n <= 0 ) return HS_OK;
    hipLaunchKernelGGL(k_fill, dim3(grid_for(n, 256, 2048)), dim3(256), 0, s, p, n, v);
    HS_LAUNCH_CHECK();
@@ -208,6 +223,7 @@ int hs_fill(hipStream_t s, double* p, long long n, double v)
 
 int hs_set_identity(hipStream_t s, double* A, int n, double v)
 {
+   (void) hs_red_batch_flush();          /* inside a held region: behind the records */
    if ( n <= 0 ) return HS_OK;
    hipLaunchKernelGGL(k_identity, dim3(grid_for((long long) n * n, 256, 2048)), dim3(256), 0, s, A, n, v);
    HS_LAUNCH_CHECK();
@@ -222,6 +238,7 @@ __global__ void k_copy(long long n, const double* __restrict__ src, double* __re
 
 int hs_copy(hipStream_t s, double* dst, const double* src, long long n)
 {
+   (void) hs_red_batch_flush();          /* inside a held region: behind the records */
    if ( n <= 0 ) return HS_OK;
    if ( n <= (1LL << 16) )
    {
@@ -258,6 +275,8 @@ int hs_axpy3(hipStream_t s, double a, long long n1, const double* x1, double* y1
    if ( n2 < 0 ) n2 = 0;
    if ( n3 < 0 ) n3 = 0;
    if ( n1 + n2 + n3 == 0 ) return HS_OK;
+   if ( hs_rec_axpy3(s, a, n1, x1, y1, n2, x2, y2, n3, x3, y3) )
+      return HS_OK;
    hipLaunchKernelGGL(k_axpy3, dim3(grid_for(n1 + n2 + n3, 256, 2048)), dim3(256), 0, s, a, n1, x1, y1, n2, x2, y2, n3, x3, y3);
    HS_LAUNCH_CHECK();
    return HS_OK;
@@ -265,6 +284,7 @@ int hs_axpy3(hipStream_t s, double a, long long n1, const double* x1, double* y1
 
 int hs_scale_add(hipStream_t s, long long n, double a, const double* x, double b, const double* y, double* out)
 {
+   (void) hs_red_batch_flush();          /* inside a held region: behind the records */
    if ( n <= 0 ) return HS_OK;
    hipLaunchKernelGGL(k_scale_add, dim3(grid_for(n, 256, 2048)), dim3(256), 0, s, n, a, x, b, y, out);
    HS_LAUNCH_CHECK();
@@ -273,11 +293,13 @@ int hs_scale_add(hipStream_t s, long long n, double a, const double* x, double b
 
 int hs_axpy(hipStream_t s, long long n, double a, const double* x, double* y)
 {
+   (void) hs_red_batch_flush();          /* inside a held region: behind the records */
    return hs_scale_add(s, n, a, x, 1.0, y, y);
 }
 
 int hs_mirror_lower(hipStream_t s, double* A, int n, long long lda)
 {
+   (void) hs_red_batch_flush();          /* inside a held region: behind the records */
    if ( n <= 1 ) return HS_OK;
    hipLaunchKernelGGL(k_mirror_lower, dim3(grid_for((long long) n * n, 256, 2048)), dim3(256), 0, s, A, n, lda);
    HS_LAUNCH_CHECK();
@@ -286,6 +308,7 @@ int hs_mirror_lower(hipStream_t s, double* A, int n, long long lda)
 
 int hs_mirror_upper(hipStream_t s, double* A, int n, long long lda)
 {
+   (void) hs_red_batch_flush();          /* inside a held region: behind the records */
    if ( n <= 1 ) return HS_OK;
    hipLaunchKernelGGL(k_mirror_upper, dim3(grid_for((long long) n * n, 256, 2048)), dim3(256), 0, s, A, n, lda);
    HS_LAUNCH_CHECK();
@@ -294,6 +317,7 @@ int hs_mirror_upper(hipStream_t s, double* A, int n, long long lda)
 
 int hs_pack_rows(hipStream_t s, int m1, int n, long long Lp, const double* A, double* Apk)
 {
+   (void) hs_red_batch_flush();          /* inside a held region: behind the records */
    HS_HIP( hipMemsetAsync(Apk, 0, (size_t) m1 * (size_t) Lp * sizeof(double), s) );
    hipLaunchKernelGGL(k_pack_rows, dim3(grid_for((long long) m1 * n * n, 256, 65536)), dim3(256), 0, s, m1, n, Lp, A, Apk);
    HS_LAUNCH_CHECK();
@@ -302,6 +326,7 @@ int hs_pack_rows(hipStream_t s, int m1, int n, long long Lp, const double* A, do
 
 int hs_pack_weighted(hipStream_t s, int n, const double* V, double* pk)
 {
+   (void) hs_red_batch_flush();          /* inside a held region: behind the records */
    hipLaunchKernelGGL(k_pack_weighted, dim3(grid_for((long long) n * n, 256, 2048)), dim3(256), 0, s, n, V, pk);
    HS_LAUNCH_CHECK();
    return HS_OK;
@@ -309,6 +334,7 @@ int hs_pack_weighted(hipStream_t s, int n, const double* V, double* pk)
 
 int hs_unpack_sym(hipStream_t s, int n, const double* pk, double sa, const double* add, double* out)
 {
+   (void) hs_red_batch_flush();          /* inside a held region: behind the records */
    hipLaunchKernelGGL(k_unpack_sym, dim3(grid_for((long long) n * n, 256, 2048)), dim3(256), 0, s, n, pk, sa, add, out);
    HS_LAUNCH_CHECK();
    return HS_OK;
@@ -316,6 +342,7 @@ int hs_unpack_sym(hipStream_t s, int n, const double* pk, double sa, const doubl
 
 int hs_zero_upper(hipStream_t s, double* A, int n)
 {
+   (void) hs_red_batch_flush();          /* inside a held region: behind the records */
    if ( n <= 1 ) return HS_OK;
    hipLaunchKernelGGL(k_zero_upper, dim3(grid_for((long long) n * n, 256, 2048)), dim3(256), 0, s, A, n);
    HS_LAUNCH_CHECK();
@@ -339,6 +366,7 @@ __global__ void __launch_bounds__(256) k_transpose(int n, const double* __restri
 
 int hs_transpose(hipStream_t s, int n, const double* src, double* dst)
 {
+   (void) hs_red_batch_flush();          /* inside a held region: behind the records */
    if ( n <= 0 ) return HS_OK;
    const int t = (n + 31) / 32;
    hipLaunchKernelGGL(k_transpose, dim3(t, t), dim3(256), 0, s, n, src, dst);
@@ -348,6 +376,7 @@ int hs_transpose(hipStream_t s, int n, const double* src, double* dst)
 
 int hs_symmetrize(hipStream_t s, double* A, int n)
 {
+   (void) hs_red_batch_flush();          /* inside a held region: behind the records */
    if ( n <= 1 ) return HS_OK;
    hipLaunchKernelGGL(k_symmetrize, dim3(grid_for((long long) n * n, 256, 2048)), dim3(256), 0, s, A, n);
    HS_LAUNCH_CHECK();
@@ -357,10 +386,9 @@ int hs_symmetrize(hipStream_t s, double* A, int n)
 /* small blocks (n <= 32): the whole chain  out = s1 Zinv - X - sym((c X R + E) Zinv)  in one workgroup, operands in LDS.
  * Same products as the three-launch path (gemm, gemm, k_dirmat), one launch: the B&B-sized problems are bound by the launch
  * count. */
-__global__ void __launch_bounds__(256) k_dir_block_small(int n, double c, const double* __restrict__ X, const double* __restrict__ R,
-   const double* __restrict__ E, const double* __restrict__ Zinv, double s1, double* __restrict__ out)
+__device__ void d_dir_block_small(int n, double c, const double* __restrict__ X, const double* __restrict__ R,
+   const double* __restrict__ E, const double* __restrict__ Zinv, double s1, double* __restrict__ out, double* db_smem)
 {
-   extern __shared__ double db_smem[];
    const int ld = n + 1;
    double* sx = db_smem;
    double* sr = sx + n * ld;
@@ -405,11 +433,20 @@ __global__ void __launch_bounds__(256) k_dir_block_small(int n, double c, const 
    }
 }
 
+__global__ void __launch_bounds__(256) k_dir_block_small(int n, double c, const double* __restrict__ X, const double* __restrict__ R,
+   const double* __restrict__ E, const double* __restrict__ Zinv, double s1, double* __restrict__ out)
+{
+   extern __shared__ double db_smem_k[];
+   d_dir_block_small(n, c, X, R, E, Zinv, s1, out, db_smem_k);
+}
+
 int hs_dir_block_small(hipStream_t s, int n, double c, const double* X, const double* R, const double* E, const double* Zinv,
    double s1, double* out)
 {
    if ( n <= 0 ) return HS_OK;
    if ( n > HS_SMALL_N ) return HS_ERR_ARG;
+   if ( hs_rec_dir_block_small(s, n, c, X, R, E, Zinv, s1, out) )
+      return HS_OK;
    static hs_attr_mask attr_done;
    HS_CALL( hs_func_max_lds(reinterpret_cast<const void*>(&k_dir_block_small), 4 * HS_SMALL_N * (HS_SMALL_N + 1) * (int) sizeof(double), &attr_done) );
    hipLaunchKernelGGL(k_dir_block_small, dim3(1), dim3(256), (size_t) 4 * n * (n + 1) * sizeof(double), s, n, c, X, R, E, Zinv, s1, out);
@@ -419,6 +456,7 @@ int hs_dir_block_small(hipStream_t s, int n, double c, const double* X, const do
 
 int hs_dirmat(hipStream_t s, int n, double s1, const double* Zinv, const double* X, const double* GZ, double* H)
 {
+   (void) hs_red_batch_flush();          /* inside a held region: behind the records */
    if ( n <= 0 ) return HS_OK;
    hipLaunchKernelGGL(k_dirmat, dim3(grid_for((long long) n * n, 256, 2048)), dim3(256), 0, s, n, s1, Zinv, X, GZ, H);
    HS_LAUNCH_CHECK();
@@ -429,6 +467,8 @@ int hs_lp_dir(hipStream_t s, int q, double sigmu, double eta, const double* x, c
    const double* elp, double* out)
 {
    if ( q <= 0 ) return HS_OK;
+   if ( hs_rec_lp_dir(s, q, sigmu, eta, x, z, r, elp, out) )
+      return HS_OK;
    hipLaunchKernelGGL(k_lp_dir, dim3((q + 255) / 256), dim3(256), 0, s, q, sigmu, eta, x, z, r, elp, out);
    HS_LAUNCH_CHECK();
    return HS_OK;
@@ -436,6 +476,7 @@ int hs_lp_dir(hipStream_t s, int q, double sigmu, double eta, const double* x, c
 
 int hs_lp_scale_rows(hipStream_t s, int q, int cols, const double* x, const double* z, const double* D, double* S)
 {
+   (void) hs_red_batch_flush();          /* inside a held region: behind the records */
    if ( q <= 0 ) return HS_OK;
    hipLaunchKernelGGL(k_lp_scale_rows, dim3(grid_for((long long) q * cols, 256, 2048)), dim3(256), 0, s, q, cols, x, z, D, S);
    HS_LAUNCH_CHECK();
@@ -445,6 +486,8 @@ int hs_lp_scale_rows(hipStream_t s, int q, int cols, const double* x, const doub
 int hs_vec_mul(hipStream_t s, long long n, const double* a, const double* b, double* out)
 {
    if ( n <= 0 ) return HS_OK;
+   if ( hs_rec_vec_mul(s, n, a, b, out) )
+      return HS_OK;
    hipLaunchKernelGGL(k_vec_mul, dim3(grid_for(n, 256, 2048)), dim3(256), 0, s, n, a, b, out);
    HS_LAUNCH_CHECK();
    return HS_OK;
@@ -558,49 +601,339 @@ __global__ void __launch_bounds__(256) k_reduce_stage2(int nparts, const double*
  * host reads the scalars.  Between hs_red_batch_begin and hs_red_batch_end such calls (vectors of at most
  * RB_MAXN entries) are only recorded; the end launches ONE single-workgroup kernel that executes the records in order
  * (so accumulation into a common slot keeps its order).  A call that does not fit flushes the records first. */
-#define RB_MAX   28
+#define RB_MAX   24
 #define RB_MAXN  16384
+#define RB_ROWS  64       /* rows / matrices of a staged pass of RB_LPROWS / RB_APPLYA: 64 x 65 resp. 32 x 4 x 65 doubles of LDS */
+#define RB_MATS  32
+#define RB_MAXWORK 16384  /* multiply-adds of one recorded vector operation: above that its multi-workgroup launch is the faster form */
 #define RB_FILL  100
 #define RB_COPY1 101
 #define RB_SOLVE 102      /* out[0:n] <- inv(L)^T inv(L) out[0:n] with a = inv(L) as 64 x 64, b = L as n x n (single-block factor, n <= 64); accumulate = number of right-hand sides, v = stride in doubles */
 #define RB_FINISH 103     /* the direction's closing element-wise kernel (k_finish_dir of ipm.hip) with its parameters in fin */
+/* Round 3: the B&B-sized regime is bound by its launches (example_TT: 37 per iteration, 26 of them a few microseconds of work), so
+ * the small single-workgroup kernels of an iteration can be recorded as well.  Every one of them does the arithmetic of its own
+ * launch in the same order (element-wise kernels: any thread mapping gives the same bits; row sums of the passes: one thread /
+ * one wavefront per output as in the launch; the block reduction of k_apply_A_small is re-enacted by one wavefront with four
+ * accumulators per lane), so iterates do not depend on whether an operation was recorded. */
+#define RB_DIRBLK  110    /* k_dir_block_small: p = X, R, E, Zinv, out; i0 = n; d0 = c, d1 = s1 */
+#define RB_LPDIR   111    /* k_lp_dir: p = x, z, r, elp, out; i0 = q; d0 = sigmu, d1 = eta */
+#define RB_VECMUL  112    /* k_vec_mul: p = a, b, out; i0 = n */
+#define RB_AXPY3   113    /* k_axpy3: p = x1, y1, x2, y2, x3, y3; i0, i1, i2 = lengths; d0 = a */
+#define RB_MAKEEXT 114    /* k_make_ext: p = v, ext; i0 = m; d0 = s0, d1 = s1 */
+#define RB_GEMVT   115    /* k_gemv_t: p = A, coef, add, out; i0 = R, i1 = E, i2 = lda; d0 = sa */
+#define RB_LPROWS  116    /* k_lp_rows_small: p = Dext, v, x, z, rd, elp, out1, out2; i0 = q, i1 = m1, i2 = mode; d0 = eta, d1 = sigmu */
+#define RB_APPLYA  117    /* k_apply_A_small (at most two blocks): p = A0, V0, A1, V1, Dext, vlp, out, vin, vout; i0 = m1, i1 = nblk,
+                           * i2, i3 = n^2 of the blocks, i4 = q, i5 = epi; d0 = scal */
 
-struct rb_desc { int kind; int accumulate; long long n; const double* a; const double* b; const double* c; double* out; double v; };
+struct rb_desc { int kind; int accumulate; int i[6]; double d[4]; const void* p[10]; };
 struct rb_finish { int m; double eta, rg, sigmu, tau, kappa, etk; const double* u1; const double* u2; double* dy; double* dyt; double* sc;
    int s0, bub, bh, wrp, bu1, dtau, dkappa, den; };
 /* pub_*: after the records, copy pub_n doubles to host-visible memory and raise the sequence number there (the host waits for
  * the number instead of a copy + stream synchronisation) */
 struct rb_args { int cnt; rb_desc d[RB_MAX]; rb_finish fin; int pub_n; const double* pub_src; double* pub_dst;
-   unsigned long long pub_seq; unsigned long long* pub_flag; };
-static thread_local struct { bool open; hipStream_t s; rb_args args; } g_rb = {false, NULL, {0, {}}};
+   unsigned long long pub_seq; unsigned long long* pub_flag;
+   unsigned long long* dbg; };         /* developer switch HIPSDP_BATCH_TIMES=1: [kind & 31][2] = wall-clock ticks (100 MHz), records */
+/* hold: depth of the regions (hs_red_batch_hold / _release) inside which begin / end do not launch; smem: dynamic LDS the records need */
+static_assert(sizeof(rb_args) <= 4096, "the records travel as kernel arguments");
+static thread_local struct { bool open; hipStream_t s; int hold; size_t smem; rb_args args; } g_rb = {false, NULL, 0, 0, {0, {}}};
 
 template<int KIND>
 __device__ __forceinline__ double rb_run(const rb_desc& D, double* sh)
 {
    typedef typename RedTraits<KIND>::OP OP;
    double v = OP::id();
-   for (long long i = threadIdx.x; i < D.n; i += 256)
-      v = OP::f(v, red_elem<KIND>(i, D.a, D.b, D.c));
+   const double* a = (const double*) D.p[0];
+   const double* b = (const double*) D.p[1];
+   const double* c = (const double*) D.p[2];
+   double* out = (double*) D.p[3];
+   for (long long i = threadIdx.x; i < D.i[0]; i += 256)
+      v = OP::f(v, red_elem<KIND>(i, a, b, c));
    v = block_reduce_256<OP>(v, sh);
    if ( threadIdx.x == 0 )
-      *D.out = D.accumulate ? OP::f(*D.out, v) : v;
+      *out = D.accumulate ? OP::f(*out, v) : v;
    return v;
+}
+
+/* what lane 0 holds after "for off = 32 .. 1: v += shfl_down(v, off)" over the 64 lanes of a wavefront, computed by ONE thread that
+ * has the 64 lane values in registers: the same additions in the same association (lane l of a level adds lanes l and l + off of the
+ * level before) */
+__device__ __forceinline__ double d_tree64(double (&p)[64])
+{
+#pragma unroll
+   for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int l = 0; l < off; ++l)
+         p[l] += p[l + off];
+   return p[0];
 }
 
 __global__ void __launch_bounds__(256) k_red_batch(rb_args A)
 {
+   extern __shared__ double rb_dyn[];
    __shared__ double sh[4];
    for (int t = 0; t < A.cnt; ++t)
    {
       const rb_desc& D = A.d[t];
+      const unsigned long long t_begin = (A.dbg != NULL) ? wall_clock64() : 0ULL;
       switch ( D.kind )
       {
       case RED_DOT:      rb_run<RED_DOT>(D, sh); break;
       case RED_ABSMAX:   rb_run<RED_ABSMAX>(D, sh); break;
       case RED_RATIOMIN: rb_run<RED_RATIOMIN>(D, sh); break;
       case RED_LPS0:     rb_run<RED_LPS0>(D, sh); break;
-      case RB_FILL:      if ( threadIdx.x == 0 ) *D.out = D.v; break;
-      case RB_COPY1:     if ( threadIdx.x == 0 ) *D.out = *D.a; break;
+      case RB_FILL:      if ( threadIdx.x == 0 ) *(double*) D.p[3] = D.d[0]; break;
+      case RB_COPY1:     if ( threadIdx.x == 0 ) *(double*) D.p[3] = *(const double*) D.p[0]; break;
+      case RB_DIRBLK:
+         d_dir_block_small(D.i[0], D.d[0], (const double*) D.p[0], (const double*) D.p[1], (const double*) D.p[2], (const double*) D.p[3],
+            D.d[1], (double*) D.p[4], rb_dyn);
+         break;
+      case RB_LPDIR:
+      {
+         const double* x = (const double*) D.p[0]; const double* z = (const double*) D.p[1]; const double* r = (const double*) D.p[2];
+         const double* elp = (const double*) D.p[3]; double* out = (double*) D.p[4];
+         const double sigmu = D.d[0], eta = D.d[1];
+         for (int i = threadIdx.x; i < D.i[0]; i += 256)
+         {
+            double t = eta * x[i] * r[i];
+            if ( elp != NULL )
+               t += elp[i];
+            out[i] = sigmu / z[i] - x[i] - t / z[i];
+         }
+         break;
+      }
+      case RB_VECMUL:
+      {
+         const double* a = (const double*) D.p[0]; const double* b = (const double*) D.p[1]; double* out = (double*) D.p[2];
+         for (int i = threadIdx.x; i < D.i[0]; i += 256)
+            out[i] = a[i] * b[i];
+         break;
+      }
+      case RB_AXPY3:
+      {
+         const double a = D.d[0];
+         for (int v = 0; v < 3; ++v)
+         {
+            const double* x = (const double*) D.p[2 * v]; double* y = (double*) D.p[2 * v + 1];
+            for (int i = threadIdx.x; i < D.i[v]; i += 256)
+               y[i] += a * x[i];
+         }
+         break;
+      }
+      case RB_MAKEEXT:
+      {
+         const double* v = (const double*) D.p[0]; double* ext = (double*) D.p[1];
+         if ( threadIdx.x == 0 )
+            ext[0] = D.d[0];
+         for (int i = threadIdx.x; i < D.i[0]; i += 256)
+            ext[1 + i] = D.d[1] * v[i];
+         break;
+      }
+      case RB_GEMVT:
+      {
+         const double* Am = (const double*) D.p[0]; const double* coef = (const double*) D.p[1]; const double* add = (const double*) D.p[2];
+         double* out = (double*) D.p[3];
+         const int R = D.i[0], E = D.i[1];
+         const long long lda = D.i[2];
+         const double sa = D.d[0];
+         /* everything in this kernel waits for memory: eight rows are requested before the first is used (same summation order) */
+         for (int e = threadIdx.x; e < E; e += 256)
+         {
+            double s0 = 0.0;
+            const double* a = Am + e;
+            const double ad = (add != NULL) ? add[e] : 0.0;
+            int i = 0;
+            for (; i + 8 <= R; i += 8)
+            {
+               double x[8], cq[8];
+#pragma unroll
+               for (int u = 0; u < 8; ++u)
+               {
+                  x[u] = a[(long long) (i + u) * lda];
+                  cq[u] = coef[i + u];
+               }
+#pragma unroll
+               for (int u = 0; u < 8; ++u)
+                  s0 += cq[u] * x[u];
+            }
+            for (; i < R; ++i)
+               s0 += coef[i] * a[(long long) i * lda];
+            if ( add != NULL )
+               s0 += sa * ad;
+            out[e] = s0;
+         }
+         break;
+      }
+      case RB_LPROWS:
+      {
+         const double* Dext = (const double*) D.p[0]; const double* v = (const double*) D.p[1]; const double* x = (const double*) D.p[2];
+         const double* z = (const double*) D.p[3]; const double* rd = (const double*) D.p[4]; const double* elp = (const double*) D.p[5];
+         double* out1 = (double*) D.p[6]; double* out2 = (double*) D.p[7];
+         const int q = D.i[0], m1 = D.i[1], mode = D.i[2];
+         const double eta = D.d[0], sigmu = D.d[1];
+         /* the launch gives a row to a wavefront: lane l sums the products i = l, l + 64, .., the lanes are added by the shuffle
+          * tree.  Here: first all lane sums of up to RB_ROWS rows, one per thread and step, into LDS (everything in this kernel waits
+          * for memory: the loads of a step are independent), then one THREAD per row adds its 64 lane sums in the order of the
+          * tree (d_tree64).  8.8 -> 2 us at q = 85 against one wavefront per row and pass. */
+         for (int rb = 0; rb < q; rb += RB_ROWS)
+         {
+            const int nr = min(RB_ROWS, q - rb);
+            if ( m1 <= 64 )
+            {
+               /* at most one product per lane sum: straight-line, the loads of several steps in flight */
+               const int l = threadIdx.x & 63;
+               const bool has = l < m1;
+               const double vl = has ? v[l] : 0.0;
+               const double* dl = Dext + (has ? l : 0);
+               for (int r4 = threadIdx.x >> 6; r4 < nr; r4 += 32)
+               {
+                  double xd[8];
+#pragma unroll
+                  for (int u = 0; u < 8; ++u)
+                     xd[u] = dl[(long long) (rb + min(r4 + 4 * u, nr - 1)) * m1];
+#pragma unroll
+                  for (int u = 0; u < 8; ++u)
+                     if ( r4 + 4 * u < nr )
+                     {
+                        double a = 0.0;
+                        if ( has )
+                           a += xd[u] * vl;
+                        rb_dyn[(r4 + 4 * u) * 65 + l] = a;
+                     }
+               }
+            }
+            else
+            {
+               for (int idx = threadIdx.x; idx < nr * 64; idx += 256)
+               {
+                  const int r = rb + (idx >> 6), l = idx & 63;
+                  const double* dr = Dext + (long long) r * m1;
+                  double a = 0.0;
+                  for (int i = l; i < m1; i += 64)
+                     a += dr[i] * v[i];
+                  rb_dyn[(idx >> 6) * 65 + l] = a;
+               }
+            }
+            __syncthreads();
+            for (int rr = threadIdx.x; rr < nr; rr += 256)
+            {
+               const int r = rb + rr;
+               double pl[64];
+#pragma unroll
+               for (int l = 0; l < 64; ++l)
+                  pl[l] = rb_dyn[rr * 65 + l];        /* (odd pitch: the threads of a wavefront read different banks) */
+               const double t = d_tree64(pl);
+               if ( mode == 0 )
+                  out1[r] = t - z[r];
+               else
+               {
+                  const double dzr = t + eta * rd[r];
+                  out1[r] = dzr;
+                  double tt = x[r] * dzr;
+                  if ( elp != NULL )
+                     tt += elp[r];
+                  out2[r] = sigmu / z[r] - x[r] - tt / z[r];
+               }
+            }
+            __syncthreads();
+         }
+         break;
+      }
+      case RB_APPLYA:
+      {
+         const int m1 = D.i[0], epi = D.i[5];
+         double* out = (double*) D.p[6]; const double* vin = (const double*) D.p[7]; double* vout = (double*) D.p[8];
+         const double scal = D.d[0];
+         /* the launch: thread t of workgroup i sums the products e = t, t + 256, .. of every block and of the LP rows, the wavefronts
+          * reduce by the shuffle tree, thread 0 adds the four results in order.  Here: thread t forms those sums for up to RB_MATS
+          * matrices, one after the other (independent loads), into LDS; then thread (i, g) re-enacts wavefront g of workgroup i from
+          * its 64 values (d_tree64) and the four of a matrix, neighbours in a wavefront, are added in the launch's order */
+         const int nblk = D.i[1], n2a = D.i[2], n2b = D.i[3], q = D.i[4];
+         const double* A0 = (const double*) D.p[0]; const double* V0 = (const double*) D.p[1];
+         const double* A1 = (const double*) D.p[2]; const double* V1 = (const double*) D.p[3];
+         const double* Dext = (const double*) D.p[4]; const double* vlp = (const double*) D.p[5];
+         for (int base = 0; base < m1; base += RB_MATS)
+         {
+            const int nm = min(RB_MATS, m1 - base);
+            const int t = threadIdx.x;
+            if ( nblk == 1 && n2a <= 256 && q <= 256 )
+            {
+               /* at most one product of the block and one of the LP rows per thread and matrix: straight-line, eight matrices in flight */
+               const bool hs = t < n2a, hl = t < q;
+               const double v0 = hs ? V0[t] : 0.0, vl = hl ? vlp[t] : 0.0;
+               const double* ap = A0 + (hs ? t : 0);
+               const double* dp = Dext + (long long) (hl ? t : 0) * m1;
+               for (int ii = 0; ii < nm; ii += 8)
+               {
+                  double xa[8], xd[8];
+#pragma unroll
+                  for (int u = 0; u < 8; ++u)
+                  {
+                     const int i = base + min(ii + u, nm - 1);
+                     xa[u] = ap[(long long) i * n2a];
+                     xd[u] = dp[i];
+                  }
+#pragma unroll
+                  for (int u = 0; u < 8; ++u)
+                     if ( ii + u < nm )
+                     {
+                        double a = 0.0;
+                        if ( hs )
+                           a += xa[u] * v0;
+                        if ( hl )
+                           a += xd[u] * vl;
+                        rb_dyn[((ii + u) * 4 + (t >> 6)) * 65 + (t & 63)] = a;
+                     }
+               }
+            }
+            else
+            for (int ii = 0; ii < nm; ++ii)
+            {
+               const int i = base + ii;
+               double a = 0.0;
+               {
+                  const double* ap = A0 + (long long) i * n2a;
+                  for (int e = t; e < n2a; e += 256)
+                     a += ap[e] * V0[e];
+               }
+               if ( nblk > 1 )
+               {
+                  const double* ap = A1 + (long long) i * n2b;
+                  for (int e = t; e < n2b; e += 256)
+                     a += ap[e] * V1[e];
+               }
+               for (int r = t; r < q; r += 256)
+                  a += Dext[(long long) r * m1 + i] * vlp[r];
+               rb_dyn[(ii * 4 + (t >> 6)) * 65 + (t & 63)] = a;
+            }
+            __syncthreads();
+            for (int jj = threadIdx.x; jj < 4 * ((nm + 15) / 16) * 16; jj += 256)      /* whole quads of threads */
+            {
+               const int ii = min(jj >> 2, nm - 1), g = jj & 3;
+               double pl[64];
+#pragma unroll
+               for (int l = 0; l < 64; ++l)
+                  pl[l] = rb_dyn[(ii * 4 + g) * 65 + l];
+               const double sg = d_tree64(pl);
+               /* sh[0] + sh[1] + sh[2] + sh[3], left to right */
+               const double s1v = __shfl_down(sg, 1, 64), s2v = __shfl_down(sg, 2, 64), s3v = __shfl_down(sg, 3, 64);
+               const double v = ((sg + s1v) + s2v) + s3v;
+               const int i = base + (jj >> 2);
+               if ( g == 0 && (jj >> 2) < nm )
+               {
+                  out[i] = v;
+                  if ( i >= 1 )
+                  {
+                     if ( epi == 1 )
+                        vout[i - 1] = v - scal * vin[i - 1];
+                     else if ( epi == 2 )
+                        vout[i - 1] = vin[i - 1] * scal - v;
+                  }
+               }
+            }
+            __syncthreads();
+         }
+         break;
+      }
       case RB_SOLVE:
       {
          /* vec <- inv(L)^T inv(L) vec for `accumulate` right-hand sides, m <= 64, with one correction per triangular solve by the
@@ -611,22 +944,24 @@ __global__ void __launch_bounds__(256) k_red_batch(rb_args A)
           * the diagonal of L beside; every row of a product is split over four adjacent lanes. */
          __shared__ double sL[64 * 65];
          __shared__ double tv[64], tw[64], tr[64], ldg[64];
-         const int m = (int) D.n;
-         const long long stride = (long long) D.v;
+         const int m = D.i[0];
+         const long long stride = (long long) D.d[0];
+         const double* Da = (const double*) D.p[0];
+         const double* Db = (const double*) D.p[1];
          const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
          for (int e = threadIdx.x; e < m * m; e += 256)
          {
             const int i = e / m, j = e - i * m;
             if ( j <= i )
-               sL[i * 65 + j] = D.a[i * 64 + j];
+               sL[i * 65 + j] = Da[i * 64 + j];
             if ( j < i )
-               sL[j * 65 + i] = D.b[(long long) i * m + j];
+               sL[j * 65 + i] = Db[(long long) i * m + j];
             if ( j == i )
-               ldg[i] = D.b[(long long) i * m + i];
+               ldg[i] = Db[(long long) i * m + i];
          }
          for (int k = 0; k < D.accumulate; ++k)
          {
-            double* vec = D.out + k * stride;
+            double* vec = (double*) D.p[3] + k * stride;
             if ( threadIdx.x < m )
                tv[threadIdx.x] = vec[threadIdx.x];
             __syncthreads();
@@ -748,6 +1083,11 @@ __global__ void __launch_bounds__(256) k_red_batch(rb_args A)
       /* the next record may read what this one wrote (same workgroup, global memory) */
       __threadfence_block();
       __syncthreads();
+      if ( A.dbg != NULL && threadIdx.x == 0 )
+      {
+         atomicAdd(A.dbg + 2 * (D.kind & 31), wall_clock64() - t_begin);
+         atomicAdd(A.dbg + 2 * (D.kind & 31) + 1, 1ULL);
+      }
    }
    if ( A.pub_n > 0 )
    {
@@ -760,13 +1100,49 @@ __global__ void __launch_bounds__(256) k_red_batch(rb_args A)
    }
 }
 
+/* HIPSDP_BATCH_TIMES=1: time per kind of record, printed when the process ends (developer switch) */
+static unsigned long long* g_rb_dbg = NULL;
+static void rb_dbg_report(void)
+{
+   unsigned long long h[64];
+   if ( g_rb_dbg == NULL || hipMemcpy(h, g_rb_dbg, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess )
+      return;
+   for (int k = 0; k < 32; ++k)
+      if ( h[2 * k + 1] > 0 )
+         fprintf(stderr, "batch records of kind %%32 = %2d: %10llu records, %8.3f us each\n", k, h[2 * k + 1],
+            (double) h[2 * k] / (double) h[2 * k + 1] * 0.01);
+}
+static unsigned long long* rb_dbg_buffer(void)
+{
+   static int on = -1;
+   if ( on < 0 )
+   {
+      const char* env = getenv("HIPSDP_BATCH_TIMES");
+      on = (env != NULL && env[0] == '1') ? 1 : 0;
+      if ( on && hipMalloc((void**) &g_rb_dbg, 64 * sizeof(unsigned long long)) == hipSuccess
+         && hipMemset(g_rb_dbg, 0, 64 * sizeof(unsigned long long)) == hipSuccess )
+         atexit(rb_dbg_report);
+      else
+         g_rb_dbg = NULL;
+   }
+   return g_rb_dbg;
+}
+
 static int rb_flush(void)
 {
    if ( g_rb.args.cnt > 0 || g_rb.args.pub_n > 0 )
    {
-      hipLaunchKernelGGL(k_red_batch, dim3(1), dim3(256), 0, g_rb.s, g_rb.args);
+      if ( g_rb.smem > 0 )
+      {
+         static hs_attr_mask attr_done;
+         HS_CALL( hs_func_max_lds(reinterpret_cast<const void*>(&k_red_batch), 4 * HS_SMALL_N * (HS_SMALL_N + 1) * (int) sizeof(double), &attr_done) );
+         static_assert(4 * HS_SMALL_N * (HS_SMALL_N + 1) >= RB_MATS * 4 * 65 && RB_MATS * 4 * 65 >= RB_ROWS * 65, "dynamic LDS of the batch kernel");
+      }
+      g_rb.args.dbg = rb_dbg_buffer();
+      hipLaunchKernelGGL(k_red_batch, dim3(1), dim3(256), g_rb.smem, g_rb.s, g_rb.args);
       g_rb.args.cnt = 0;
       g_rb.args.pub_n = 0;
+      g_rb.smem = 0;
       HS_LAUNCH_CHECK();
    }
    return HS_OK;
@@ -774,26 +1150,63 @@ static int rb_flush(void)
 
 void hs_red_batch_begin(hipStream_t s)
 {
+   if ( g_rb.hold > 0 && g_rb.open && g_rb.s == s )
+      return;                         /* inside a held region: keep recording */
    if ( g_rb.open )
       (void) rb_flush();
    g_rb.open = true;
    g_rb.s = s;
    g_rb.args.cnt = 0;
+   g_rb.smem = 0;
+}
+
+/* A held region: from here to the matching release everything recordable on the stream is recorded - begin / end inside it do
+ * not launch - and whatever is not recordable flushes the records first (hs_red_batch_flush in its wrapper), so the order of the
+ * program is the order of execution.  Regions nest. */
+void hs_red_batch_hold(hipStream_t s)
+{
+   if ( g_rb.hold == 0 )
+      hs_red_batch_begin(s);
+   ++g_rb.hold;
+}
+
+int hs_red_batch_release(void)
+{
+   if ( g_rb.hold > 0 && --g_rb.hold > 0 )
+      return HS_OK;
+   return hs_red_batch_end();
+}
+
+/* launches what is recorded and keeps recording: in front of every launch that is not recorded */
+int hs_red_batch_flush(void)
+{
+   return (g_rb.open && g_rb.hold > 0) ? rb_flush() : HS_OK;
 }
 
 /* drops whatever is recorded (an earlier call may have left a batch open on an error path) */
 void hs_red_batch_reset(void)
 {
    g_rb.open = false;
+   g_rb.hold = 0;
+   g_rb.smem = 0;
    g_rb.args.cnt = 0;
    g_rb.args.pub_n = 0;
 }
 
 int hs_red_batch_end(void)
 {
+   if ( g_rb.hold > 0 )
+      return HS_OK;                   /* the region's release launches */
    const int rc = g_rb.open ? rb_flush() : HS_OK;
    g_rb.open = false;
    return rc;
+}
+
+/* ends every held region and the batch: before the host reads results by any other way than hs_red_batch_end_publish */
+int hs_red_batch_end_all(void)
+{
+   g_rb.hold = 0;
+   return hs_red_batch_end();
 }
 
 /* closes the batch (if one is open) and makes its kernel - or a kernel of its own when nothing is recorded - copy n doubles
@@ -801,7 +1214,11 @@ int hs_red_batch_end(void)
 int hs_red_batch_end_publish(hipStream_t s, int n, const double* src, double* dst, unsigned long long seq, unsigned long long* flag)
 {
    if ( g_rb.open && g_rb.s != s )
+   {
+      g_rb.hold = 0;
       HS_CALL( hs_red_batch_end() );
+   }
+   g_rb.hold = 0;                     /* a read-back ends every region */
    g_rb.s = s;
    g_rb.args.pub_n = n; g_rb.args.pub_src = src; g_rb.args.pub_dst = dst; g_rb.args.pub_seq = seq; g_rb.args.pub_flag = flag;
    if ( !g_rb.open )
@@ -824,8 +1241,43 @@ static int rb_record(hipStream_t s, int kind, long long n, const double* a, cons
    if ( g_rb.args.cnt == RB_MAX )
       (void) rb_flush();
    rb_desc& D = g_rb.args.d[g_rb.args.cnt++];
-   D.kind = kind; D.accumulate = accumulate; D.n = n; D.a = a; D.b = b; D.c = c; D.out = out; D.v = v;
+   memset(&D, 0, sizeof(D));
+   D.kind = kind; D.accumulate = accumulate; D.i[0] = (int) n; D.p[0] = a; D.p[1] = b; D.p[2] = c; D.p[3] = out; D.d[0] = v;
    return 1;
+}
+
+/* a record of the round-3 kinds: NULL when no batch is open on this stream (the caller launches; pending records are flushed first) */
+static rb_desc* rb_record_ext(hipStream_t s, int kind, size_t smem)
+{
+   {
+      /* developer switch HIPSDP_BATCH_SKIP: bit (kind - 110) set = that kind is never recorded */
+      static int skip = -1;
+      if ( skip < 0 )
+         skip = getenv("HIPSDP_BATCH_SKIP") != NULL ? atoi(getenv("HIPSDP_BATCH_SKIP")) : 0;
+      if ( kind >= 110 && ((skip >> (kind - 110)) & 1) )
+      {
+         if ( g_rb.open && g_rb.hold > 0 )
+            (void) rb_flush();
+         return NULL;
+      }
+   }
+   /* only inside a held region: a batch opened by begin alone keeps its round-2 meaning (reductions whose inputs nobody touches
+    * before the read-back; the launches between them are not recorded and run first) */
+   if ( !g_rb.open || g_rb.hold == 0 )
+      return NULL;
+   if ( s != g_rb.s )
+   {
+      (void) rb_flush();
+      return NULL;
+   }
+   if ( g_rb.args.cnt == RB_MAX )
+      (void) rb_flush();
+   rb_desc& D = g_rb.args.d[g_rb.args.cnt++];
+   memset(&D, 0, sizeof(D));
+   D.kind = kind;
+   if ( smem > g_rb.smem )
+      g_rb.smem = smem;
+   return &D;
 }
 
 /* any other kernel launched on the stream while a batch is open must see the records executed first when it depends on
@@ -863,8 +1315,221 @@ int hs_red_batch_finish(hipStream_t s, const void* fin, size_t bytes)
       (void) rb_flush();
    memcpy(&g_rb.args.fin, fin, sizeof(rb_finish));
    rb_desc& D = g_rb.args.d[g_rb.args.cnt++];
-   D.kind = RB_FINISH; D.accumulate = 0; D.n = 0; D.a = NULL; D.b = NULL; D.c = NULL; D.out = NULL; D.v = 0.0;
+   memset(&D, 0, sizeof(D));
+   D.kind = RB_FINISH;
    return 1;
+}
+
+/* ---- recorders of the round-3 kinds.  Not recordable (no batch, other stream, too much work for one workgroup): the records so far
+ * are launched - the caller's kernel must run behind them - and 0 is returned. */
+static int rb_decline(void)
+{
+   if ( g_rb.open && g_rb.hold > 0 )
+      (void) rb_flush();
+   return 0;
+}
+
+static int hs_rec_dir_block_small(hipStream_t s, int n, double c, const double* X, const double* R, const double* E, const double* Zinv,
+   double s1, double* out)
+{
+   rb_desc* D = rb_record_ext(s, RB_DIRBLK, (size_t) 4 * n * (n + 1) * sizeof(double));
+   if ( D == NULL )
+      return 0;
+   D->i[0] = n; D->d[0] = c; D->d[1] = s1; D->p[0] = X; D->p[1] = R; D->p[2] = E; D->p[3] = Zinv; D->p[4] = out;
+   return 1;
+}
+
+static int hs_rec_lp_dir(hipStream_t s, int q, double sigmu, double eta, const double* x, const double* z, const double* r, const double* elp,
+   double* out)
+{
+   if ( q > RB_MAXN )
+      return rb_decline();
+   rb_desc* D = rb_record_ext(s, RB_LPDIR, 0);
+   if ( D == NULL )
+      return 0;
+   D->i[0] = q; D->d[0] = sigmu; D->d[1] = eta; D->p[0] = x; D->p[1] = z; D->p[2] = r; D->p[3] = elp; D->p[4] = out;
+   return 1;
+}
+
+static int hs_rec_vec_mul(hipStream_t s, long long n, const double* a, const double* b, double* out)
+{
+   if ( n > RB_MAXN )
+      return rb_decline();
+   rb_desc* D = rb_record_ext(s, RB_VECMUL, 0);
+   if ( D == NULL )
+      return 0;
+   D->i[0] = (int) n; D->p[0] = a; D->p[1] = b; D->p[2] = out;
+   return 1;
+}
+
+static int hs_rec_axpy3(hipStream_t s, double a, long long n1, const double* x1, double* y1, long long n2, const double* x2, double* y2,
+   long long n3, const double* x3, double* y3)
+{
+   if ( n1 > RB_MAXN || n2 > RB_MAXN || n3 > RB_MAXN )
+      return rb_decline();
+   rb_desc* D = rb_record_ext(s, RB_AXPY3, 0);
+   if ( D == NULL )
+      return 0;
+   D->d[0] = a; D->i[0] = (int) n1; D->i[1] = (int) n2; D->i[2] = (int) n3;
+   D->p[0] = x1; D->p[1] = y1; D->p[2] = x2; D->p[3] = y2; D->p[4] = x3; D->p[5] = y3;
+   return 1;
+}
+
+static int hs_rec_gemv_t(hipStream_t s, int R, long long E, const double* A, long long lda, const double* coef, double sa, const double* add,
+   double* out)
+{
+   if ( E > RB_MAXN || lda > 0x7fffffffLL || (long long) R * E > RB_MAXWORK )
+      return rb_decline();
+   rb_desc* D = rb_record_ext(s, RB_GEMVT, 0);
+   if ( D == NULL )
+      return 0;
+   D->i[0] = R; D->i[1] = (int) E; D->i[2] = (int) lda; D->d[0] = sa; D->p[0] = A; D->p[1] = coef; D->p[2] = add; D->p[3] = out;
+   return 1;
+}
+
+/* ext = [s0; s1 v] (the coefficient vector of a pass over A with the constant matrix in front) */
+__global__ void k_make_ext(int m, double s0, double s1, const double* __restrict__ v, double* __restrict__ ext)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if ( i == 0 )
+      ext[0] = s0;
+   if ( i < m )
+      ext[1 + i] = s1 * v[i];
+}
+
+int hs_make_ext(hipStream_t s, int m, double s0, double s1, const double* v, double* ext)
+{
+   if ( m <= RB_MAXN )
+   {
+      rb_desc* D = rb_record_ext(s, RB_MAKEEXT, 0);
+      if ( D != NULL )
+      {
+         D->i[0] = m; D->d[0] = s0; D->d[1] = s1; D->p[0] = v; D->p[1] = ext;
+         return HS_OK;
+      }
+   }
+   else
+      (void) rb_decline();
+   hipLaunchKernelGGL(k_make_ext, dim3((unsigned) ((m + 1 + 255) / 256)), dim3(256), 0, s, m, s0, s1, v, ext);
+   HS_LAUNCH_CHECK();
+   return HS_OK;
+}
+
+/* small problems, LP rows: t_r = Dext[r, :] . v, then the element-wise kernels that follow, in one launch (one wavefront per row).
+ * mode 0: out1 = t - z (the residual rd);  mode 1: out1 = t + eta * rd (dz), out2 = sigmu / z - x - (x * out1 + elp) / z (dx) */
+__global__ void __launch_bounds__(256) k_lp_rows_small(int q, int m1, const double* __restrict__ Dext, const double* __restrict__ v,
+   int mode, double eta, double sigmu, const double* __restrict__ x, const double* __restrict__ z, const double* __restrict__ rd,
+   const double* __restrict__ elp, double* __restrict__ out1, double* __restrict__ out2)
+{
+   const int lane = threadIdx.x & 63;
+   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+   if ( r >= q )
+      return;
+   const double* d = Dext + (long long) r * m1;
+   double t = 0.0;
+   for (int i = lane; i < m1; i += 64)
+      t += d[i] * v[i];
+   for (int off = 32; off > 0; off >>= 1)
+      t += __shfl_down(t, off, 64);
+   if ( lane == 0 )
+   {
+      if ( mode == 0 )
+         out1[r] = t - z[r];
+      else
+      {
+         const double dzr = t + eta * rd[r];
+         out1[r] = dzr;
+         double tt = x[r] * dzr;
+         if ( elp != NULL )
+            tt += elp[r];
+         out2[r] = sigmu / z[r] - x[r] - tt / z[r];
+      }
+   }
+}
+
+int hs_lp_rows_small(hipStream_t s, int q, int m1, const double* Dext, const double* v, int mode, double eta, double sigmu, const double* x,
+   const double* z, const double* rd, const double* elp, double* out1, double* out2)
+{
+   if ( q <= 0 )
+      return HS_OK;
+   if ( (long long) q * m1 <= RB_MAXWORK )
+   {
+      rb_desc* D = rb_record_ext(s, RB_LPROWS, (size_t) RB_ROWS * 65 * sizeof(double));
+      if ( D != NULL )
+      {
+         D->i[0] = q; D->i[1] = m1; D->i[2] = mode; D->d[0] = eta; D->d[1] = sigmu;
+         D->p[0] = Dext; D->p[1] = v; D->p[2] = x; D->p[3] = z; D->p[4] = rd; D->p[5] = elp; D->p[6] = out1; D->p[7] = out2;
+         return HS_OK;
+      }
+   }
+   else
+      (void) rb_decline();
+   hipLaunchKernelGGL(k_lp_rows_small, dim3((q + 3) / 4), dim3(256), 0, s, q, m1, Dext, v, mode, eta, sigmu, x, z, rd, elp, out1, out2);
+   HS_LAUNCH_CHECK();
+   return HS_OK;
+}
+
+/* small problems: A(V) over all blocks + LP part + the element-wise kernel that always follows, in one launch.
+ * epi 0: out only; 1: h[i] = out[1 + i] - eta * rp[i] (k_h); 2: rp[i] = b[i] * tau - out[1 + i] (k_rp) */
+__global__ void __launch_bounds__(256) k_apply_A_small(int m1, hs_as_args B, int q, const double* __restrict__ Dext,
+   const double* __restrict__ vlp, double* __restrict__ out, int epi, double scal, const double* __restrict__ vin,
+   double* __restrict__ vout)
+{
+   __shared__ double sh[4];
+   const int i = blockIdx.x;
+   const int tid = threadIdx.x;
+   double acc = 0.0;
+   for (int k = 0; k < B.nblk; ++k)
+   {
+      const double* a = B.A[k] + (long long) i * B.n2[k];
+      const double* v = B.V[k];
+      for (int e = tid; e < B.n2[k]; e += 256)
+         acc += a[e] * v[e];
+   }
+   for (int r = tid; r < q; r += 256)
+      acc += Dext[(long long) r * m1 + i] * vlp[r];
+   for (int off = 32; off > 0; off >>= 1)
+      acc += __shfl_down(acc, off, 64);
+   if ( (tid & 63) == 0 )
+      sh[tid >> 6] = acc;
+   __syncthreads();
+   if ( tid == 0 )
+   {
+      const double v = sh[0] + sh[1] + sh[2] + sh[3];
+      out[i] = v;
+      if ( i >= 1 )
+      {
+         if ( epi == 1 )
+            vout[i - 1] = v - scal * vin[i - 1];
+         else if ( epi == 2 )
+            vout[i - 1] = vin[i - 1] * scal - v;
+      }
+   }
+}
+
+int hs_apply_A_small(hipStream_t s, int m1, const hs_as_args* B, int q, const double* Dext, const double* vlp, double* out, int epi,
+   double scal, const double* vin, double* vout)
+{
+   long long tot = q;
+   for (int k = 0; k < B->nblk; ++k)
+      tot += B->n2[k];
+   if ( B->nblk >= 1 && B->nblk <= 2 && tot * m1 <= RB_MAXWORK )
+   {
+      rb_desc* D = rb_record_ext(s, RB_APPLYA, (size_t) RB_MATS * 4 * 65 * sizeof(double));
+      if ( D != NULL )
+      {
+         D->i[0] = m1; D->i[1] = B->nblk; D->i[2] = B->n2[0]; D->i[3] = B->nblk > 1 ? B->n2[1] : 0; D->i[4] = q; D->i[5] = epi;
+         D->d[0] = scal;
+         D->p[0] = B->A[0]; D->p[1] = B->V[0]; D->p[2] = B->nblk > 1 ? B->A[1] : NULL; D->p[3] = B->nblk > 1 ? B->V[1] : NULL;
+         D->p[4] = Dext; D->p[5] = vlp; D->p[6] = out; D->p[7] = vin; D->p[8] = vout;
+         return HS_OK;
+      }
+   }
+   else
+      (void) rb_decline();
+   hipLaunchKernelGGL(k_apply_A_small, dim3(m1), dim3(256), 0, s, m1, *B, q, Dext, vlp, out, epi, scal, vin, vout);
+   HS_LAUNCH_CHECK();
+   return HS_OK;
 }
 
 template<int KIND>
@@ -883,6 +1548,7 @@ static int reduce_launch(hipStream_t s, long long n, const double* a, const doub
       return HS_OK;
    }
    const int g = grid_for(n, 2048, 256);
+   (void) hs_red_batch_flush();
    if ( g == 1 )
    {
       hipLaunchKernelGGL((k_reduce_stage1<KIND>), dim3(1), dim3(256), 0, s, n, a, b, c, ws, out, accumulate, 1);
@@ -1085,6 +1751,7 @@ static int gemv_n_launch(hipStream_t s, int R, long long E, const double* A, lon
 int hs_gemv_n(hipStream_t s, int R, long long E, const double* A, long long lda, int nv, const double* const* V,
    double* out, long long ldo, double* ws, long long wsdoubles)
 {
+   (void) hs_red_batch_flush();          /* inside a held region: behind the records */
    if ( R <= 0 )
       return HS_OK;
    if ( nv < 1 || nv > 4 )
@@ -1247,6 +1914,7 @@ __global__ void __launch_bounds__(256) k_gemv_t3(int R, long long E, const doubl
 int hs_gemv_t3(hipStream_t s, int R, long long E, const double* A, long long lda, const double* c0, const double* c1, const double* c2,
    double* o0, double* o1, double* o2)
 {
+   (void) hs_red_batch_flush();          /* inside a held region: behind the records */
    if ( E <= 0 || R <= 0 || (E & 1) || (lda & 1) || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(o0) & 15)
       || (reinterpret_cast<uintptr_t>(o1) & 15) || (reinterpret_cast<uintptr_t>(o2) & 15) )
       return 0;
@@ -1261,6 +1929,8 @@ int hs_gemv_t(hipStream_t s, int R, long long E, const double* A, long long lda,
    const double* add, double* out)
 {
    if ( E <= 0 )
+      return HS_OK;
+   if ( hs_rec_gemv_t(s, R, E, A, lda, coef, sa, add, out) )
       return HS_OK;
    const bool vec = ((lda & 1) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && R > 0;
    if ( vec )
