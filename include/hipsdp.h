@@ -276,10 +276,11 @@ HIPSDP_API int  hipsdp_lambda_min(int device, int n, const double* W, int steps,
 /* lambda_min(L D L^T), n <= 64, L lower triangular, D symmetric: the small-block step-length kernels; theta[2], resid[2] */
 HIPSDP_API int  hipsdp_lambda_min_scaled(int device, int n, const double* L, const double* D, int steps, double* theta, double* resid);
 HIPSDP_API int  hipsdp_syev(int device, int n, const double* A, double* lam, double* V);     /* ascending, eigenvectors as rows */
-/* i-th smallest eigenvalue (1-based) and optionally its unit eigenvector of a symmetric matrix with n <= 64 in one launch through
+/* i-th smallest eigenvalue (1-based) and optionally its unit eigenvector of a symmetric matrix with n <= 128 in one launch through
  * pinned, device-mapped staging memory of the calling thread (no allocation, no copy engine, no stream synchronisation):
  * Householder tridiagonalisation in LDS, Sturm multisection, inverse iteration, back-transformation - one eigenpair as DSYEVR
- * RANGE = 'I' computes it (lapack_interface.c:178-288).  HIPSDP_ERR_ARG for n > 64. */
+ * RANGE = 'I' computes it (lapack_interface.c:178-288); n <= 64 with the matrix in registers, 64 < n <= 128 in LDS (round 3).
+ * HIPSDP_ERR_ARG for n > 128. */
 HIPSDP_API int  hipsdp_syevi_small(int device, int n, const double* A, int i, double* eigval, double* eigvec);
 /* all eigenpairs, n <= 64, the same way (what DSYEVR RANGE = 'A' computes, lapack_interface.c:507-603): eigenvalues by multisection,
  * eigenvectors by inverse iteration with re-orthogonalisation inside clusters, one launch; hipsdp_syev takes this path for n <= 64 */

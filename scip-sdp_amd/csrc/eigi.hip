@@ -592,6 +592,277 @@ __global__ void __launch_bounds__(256) k_syevi_small(int n, int ith, int wantvec
    }
 }
 
+/* ---- 64 < n <= 128: the same eigenpair, the matrix in LDS --------------------------------------------------------------------
+ * k_syevi_small keeps the matrix in registers (64 x 64 over 256 threads); above 64 rows the full block-Jacobi decomposition was the
+ * only path (2.5 ms per call at n = 65: a cliff, and DSYEVR on the host takes 0.1 - 0.3 ms there).  Here the matrix lives in LDS with
+ * an odd pitch (n = 128: 132 KB), both triangles, and the reduction is the same DSYTD2 recurrence: a pair of threads per row forms
+ * its entry of p = tau A v and applies the rank-2 update to its half of the row; the reflector and w are computed by every
+ * wavefront for itself (two entries per lane), two workgroup barriers per column.  Multisection, inverse iteration and the
+ * back-transformation are those of the small kernel with two entries per lane. */
+#define EM_N 128
+#define EM_FLAG 256                 /* position of the flag word in the output (behind eigenvalue + eigenvector) */
+
+__global__ void __launch_bounds__(256) k_syevi_mid(int n, int ith, int wantvec, const double* __restrict__ in, double* __restrict__ out,
+   unsigned long long seq, unsigned long long* __restrict__ flag)
+{
+   extern __shared__ __attribute__((aligned(16))) double em_a[];
+   __shared__ double vv[EM_N], pp[EM_N], ww[EM_N], tau[EM_N], d[EM_N], e[EM_N], e2[EM_N], zz[EM_N];
+   __shared__ double wk[4][EM_N], swp[EM_N];
+   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   const int ld = n | 1;
+   for (int idx = tid; idx < n * n; idx += 256)
+   {
+      const int i = idx / n, j = idx - i * n;
+      em_a[i * ld + j] = (j <= i) ? in[(long long) j * n + i] : in[(long long) i * n + j];
+   }
+   if ( tid < EM_N )
+   {
+      vv[tid] = 0.0;
+      ww[tid] = 0.0;
+      pp[tid] = 0.0;
+   }
+   __syncthreads();
+
+   for (int k = 0; k + 1 < n; ++k)
+   {
+      const int len = n - k - 1;
+      double t;
+      {
+         const double xa = (lane < len) ? em_a[(k + 1 + lane) * ld + k] : 0.0;
+         const double xb = (lane + 64 < len) ? em_a[(k + 65 + lane) * ld + k] : 0.0;
+         const double x0 = ei_lane(xa, 0);
+         const double s2 = ei_wsum((lane >= 1 ? xa * xa : 0.0) + xb * xb);
+         double beta = x0, scale = 0.0;
+         t = 0.0;
+         if ( s2 > 0.0 )
+         {
+            const double h2 = x0 * x0 + s2;
+            beta = -copysign(h2 * ei_rsqrt(h2), x0);
+            t = (beta - x0) * ei_rcp2(beta);
+            scale = ei_rcp2(x0 - beta);
+         }
+         if ( lane < len )
+            vv[k + 1 + lane] = (lane == 0) ? 1.0 : xa * scale;
+         if ( lane + 64 < len )
+            vv[k + 65 + lane] = xb * scale;
+         if ( lane == 0 )
+         {
+            vv[k] = 0.0;
+            ww[k] = 0.0;
+            tau[k] = t;
+            e[k] = beta;
+            d[k] = em_a[k * ld + k];
+         }
+         __builtin_amdgcn_s_waitcnt(0xc07f);             /* lgkmcnt(0): this wavefront's own LDS writes are done */
+         __builtin_amdgcn_wave_barrier();
+      }
+      if ( t != 0.0 )                                    /* (the same in every wavefront) */
+      {
+         const int row = k + 1 + (tid >> 1), half = tid & 1;
+         {
+            double acc = 0.0;
+            if ( row < n )
+            {
+               /* four partial sums: the loop is a chain of dependent multiply-adds otherwise (16 cycles each) */
+               const double* ar = em_a + row * ld;
+               double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+               int c = k + 1 + half;
+               for (; c + 6 < n; c += 8)
+               {
+                  a0 += ar[c] * vv[c];
+                  a1 += ar[c + 2] * vv[c + 2];
+                  a2 += ar[c + 4] * vv[c + 4];
+                  a3 += ar[c + 6] * vv[c + 6];
+               }
+               for (; c < n; c += 2)
+                  a0 += ar[c] * vv[c];
+               acc = (a0 + a1) + (a2 + a3);
+            }
+            acc += ei_dpp<0xB1>(acc);                   /* the two halves of a row are neighbours */
+            if ( half == 0 && row < n )
+               pp[row] = t * acc;
+         }
+         __syncthreads();
+         {
+            const double pa = (lane < len) ? pp[k + 1 + lane] : 0.0, pb = (lane + 64 < len) ? pp[k + 65 + lane] : 0.0;
+            const double va = (lane < len) ? vv[k + 1 + lane] : 0.0, vb = (lane + 64 < len) ? vv[k + 65 + lane] : 0.0;
+            const double pv = ei_wsum(pa * va + pb * vb);
+            const double al = -0.5 * t * pv;
+            if ( lane < len )
+               ww[k + 1 + lane] = pa + al * va;
+            if ( lane + 64 < len )
+               ww[k + 65 + lane] = pb + al * vb;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+         }
+         if ( row < n )
+         {
+            double* ar = em_a + row * ld;
+            const double vr = vv[row], wr = ww[row];
+#pragma unroll 4
+            for (int c = k + 1 + half; c < n; c += 2)
+               ar[c] -= vr * ww[c] + wr * vv[c];
+         }
+         /* keep the reflector (v_0 = 1 implied) in the column it annihilated: the update does not touch column k */
+         if ( tid < len )
+            em_a[(k + 1 + tid) * ld + k] = vv[k + 1 + tid];
+      }
+      __syncthreads();
+   }
+   if ( tid == 0 )
+   {
+      d[n - 1] = em_a[(n - 1) * ld + n - 1];
+      e[n - 1] = 0.0;
+   }
+   __syncthreads();
+   if ( wave != 0 )
+      return;
+
+   /* ---- wavefront 0: i-th eigenvalue of T by Sturm multisection (64 shifts per round) */
+   for (int i = lane; i < n; i += 64)
+      e2[i] = e[i] * e[i];
+   __builtin_amdgcn_s_waitcnt(0xc07f);
+   __builtin_amdgcn_wave_barrier();
+   double lo = 1e300, hi = -1e300;
+   for (int i = 0; i < n; ++i)
+   {
+      const double rad = (i > 0 ? fabs(e[i - 1]) : 0.0) + (i + 1 < n ? fabs(e[i]) : 0.0);
+      lo = fmin(lo, d[i] - rad);
+      hi = fmax(hi, d[i] + rad);
+   }
+   const double span0 = fmax(hi - lo, 1e-300);
+   lo -= 1e-12 * span0 + 1e-300;
+   hi += 1e-12 * span0 + 1e-300;
+   const double pivmin = 1e-290;
+   for (int round = 0; round < 16; ++round)
+   {
+      const double x = lo + (hi - lo) * (double) (lane + 1) / 65.0;
+      int cnt = 0;                                     /* eigenvalues below x */
+      double t = d[0] - x;
+      if ( fabs(t) < pivmin ) t = -pivmin;
+      if ( t < 0.0 ) ++cnt;
+      for (int i = 1; i < n; ++i)
+      {
+         t = d[i] - x - e2[i - 1] * ei_rcp(t);
+         if ( fabs(t) < pivmin ) t = -pivmin;
+         if ( !(fabs(t) < 1e290) ) t = (t < 0.0) ? -1e290 : 1e290;
+         if ( t < 0.0 ) ++cnt;
+      }
+      const unsigned long long msk = __ballot(cnt >= ith);
+      const int first = msk ? __ffsll((long long) msk) - 1 : 64;      /* first shift with at least ith eigenvalues below it */
+      const double w = (hi - lo) / 65.0;
+      const double nlo = lo + w * (double) first;
+      const double nhi = (first < 64) ? lo + w * (double) (first + 1) : hi;
+      lo = nlo; hi = nhi;
+      if ( hi - lo <= 2e-16 * fmax(fabs(lo), fabs(hi)) )
+         break;
+   }
+   const double theta = 0.5 * (lo + hi);
+   if ( lane == 0 )
+      out[0] = theta;
+
+   if ( wantvec )
+   {
+      /* inverse iteration on T - theta I (Gaussian elimination with partial pivoting, factored once; lane 0) */
+      if ( lane == 0 )
+      {
+         const double tiny = 1e-14 * fmax(span0, fmax(fabs(theta), 1e-300));
+         double dd = d[0] - theta, du = e[0];
+         for (int i = 0; i < n - 1; ++i)
+         {
+            const double dl = e[i];
+            const double dn = d[i + 1] - theta;
+            const double un = (i + 2 < n) ? e[i + 1] : 0.0;
+            if ( fabs(dd) >= fabs(dl) )
+            {
+               if ( fabs(dd) < tiny ) dd = tiny;
+               const double rinv = 1.0 / dd;
+               const double mlt = dl * rinv;
+               wk[0][i] = rinv; wk[1][i] = du; wk[2][i] = 0.0; wk[3][i] = mlt; swp[i] = 0.0;
+               dd = dn - mlt * du;
+               du = un;
+            }
+            else
+            {
+               const double rinv = 1.0 / dl;
+               const double mlt = dd * rinv;
+               wk[0][i] = rinv; wk[1][i] = dn; wk[2][i] = un; wk[3][i] = mlt; swp[i] = 1.0;
+               dd = du - mlt * dn;
+               du = -mlt * un;
+            }
+         }
+         if ( fabs(dd) < tiny ) dd = tiny;
+         wk[0][n - 1] = 1.0 / dd; wk[1][n - 1] = 0.0; wk[2][n - 1] = 0.0;
+         for (int i = 0; i < n; ++i)
+            zz[i] = 1.0 + 0.37 * (double) ((i * 7) % 5);
+         for (int iter = 0; iter < 4; ++iter)
+         {
+            double cur = zz[0];
+            for (int i = 0; i < n - 1; ++i)
+            {
+               const double nxt = zz[i + 1];
+               if ( swp[i] == 0.0 )
+               {
+                  zz[i] = cur;
+                  cur = nxt - wk[3][i] * cur;
+               }
+               else
+               {
+                  zz[i] = nxt;
+                  cur = cur - wk[3][i] * nxt;
+               }
+            }
+            double x1 = cur * wk[0][n - 1], x2 = 0.0;
+            double nrm = x1 * x1;
+            zz[n - 1] = x1;
+            for (int i = n - 2; i >= 0; --i)
+            {
+               const double xi = (zz[i] - wk[1][i] * x1 - wk[2][i] * x2) * wk[0][i];
+               zz[i] = xi;
+               nrm += xi * xi;
+               x2 = x1; x1 = xi;
+            }
+            nrm = sqrt(nrm);
+            if ( !(nrm > 0.0) || !(nrm < 1e300) )
+            {
+               for (int i = 0; i < n; ++i)
+                  zz[i] = (i == 0) ? 1.0 : 0.0;
+               break;
+            }
+            const double rn = 1.0 / nrm;
+            for (int i = 0; i < n; ++i)
+               zz[i] *= rn;
+         }
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      /* back-transformation x = H_0 H_1 ... H_{n-2} z: reflector k acts on entries k + 1 .. n - 1; lane l holds entries l and l + 64 */
+      double za = (lane < n) ? zz[lane] : 0.0, zb = (lane + 64 < n) ? zz[lane + 64] : 0.0;
+      for (int k = n - 2; k >= 0; --k)
+      {
+         const double t = tau[k];
+         if ( t == 0.0 )
+            continue;
+         const int ia = lane, ib = lane + 64;
+         const double va = (ia > k && ia < n) ? ((ia == k + 1) ? 1.0 : em_a[ia * ld + k]) : 0.0;
+         const double vb = (ib > k && ib < n) ? ((ib == k + 1) ? 1.0 : em_a[ib * ld + k]) : 0.0;
+         const double dot = ei_wsum(va * za + vb * zb);
+         za -= t * dot * va;
+         zb -= t * dot * vb;
+      }
+      const double nrm = sqrt(ei_wsum(za * za + zb * zb));
+      if ( lane < n )
+         out[1 + lane] = nrm > 0.0 ? za / nrm : za;
+      if ( lane + 64 < n )
+         out[65 + lane] = nrm > 0.0 ? zb / nrm : zb;
+   }
+   __threadfence_system();
+   __builtin_amdgcn_wave_barrier();
+   if ( lane == 0 )
+      __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+
 /* per host thread and device: a stream and the pinned, device-mapped staging memory.  The object lives in thread-local storage:
  * its destructor returns stream and pinned memory when the thread ends. */
 #define EI_OUT_DOUBLES (EI_N * EI_N + EI_N + 16)       /* room for a full decomposition: eigenvalues, eigenvectors, flag word */
@@ -633,7 +904,7 @@ int ei_context(int device, ei_ctx** out)
    c.device = device;
    hipError_t e = hipSetDevice(device);
    if ( e == hipSuccess ) e = hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking);
-   if ( e == hipSuccess ) e = hipHostMalloc((void**) &c.hin, (size_t) EI_N * EI_N * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
+   if ( e == hipSuccess ) e = hipHostMalloc((void**) &c.hin, (size_t) EM_N * EM_N * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
    if ( e == hipSuccess ) e = hipHostMalloc((void**) &c.hout, (size_t) EI_OUT_DOUBLES * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
    if ( e == hipSuccess ) e = hipHostGetDevicePointer((void**) &c.din, c.hin, 0);
    if ( e == hipSuccess ) e = hipHostGetDevicePointer((void**) &c.dout, c.hout, 0);
@@ -653,22 +924,34 @@ int ei_context(int device, ei_ctx** out)
 }
 
 /* i-th smallest eigenvalue (1-based) of the symmetric n x n matrix A (the triangle at memory positions [j n + i], i >= j, is read:
- * what DSYEVR 'L' reads from a column-major array), n <= 64; eigvec (n, unit norm) may be NULL.  HIPSDP_ERR_ARG for larger n: the caller takes the full decomposition. */
+ * what DSYEVR 'L' reads from a column-major array), n <= 128 (n <= 64: matrix in registers, above: in LDS); eigvec (n, unit norm) may be
+ * NULL.  HIPSDP_ERR_ARG for larger n: the caller takes the full decomposition. */
 extern "C" int hipsdp_syevi_small(int device, int n, const double* A, int i, double* eigval, double* eigvec)
 {
    int nd = 0;
    if ( hipGetDeviceCount(&nd) != hipSuccess || nd <= 0 )
       return HIPSDP_ERR_NODEVICE;
-   if ( device < 0 || device >= nd || n < 1 || n > EI_N || A == NULL || i < 1 || i > n || eigval == NULL )
+   if ( device < 0 || device >= nd || n < 1 || n > EM_N || A == NULL || i < 1 || i > n || eigval == NULL )
       return HIPSDP_ERR_ARG;
    ei_ctx* c = NULL;
    HS_CALL( ei_context(device, &c) );
    HS_HIP( hipSetDevice(device) );
    memcpy(c->hin, A, (size_t) n * n * sizeof(double));
    const unsigned long long seq = ++c->seq;
-   volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(c->hout + EI_N + 4);
-   hipLaunchKernelGGL((k_syevi_small<false>), dim3(1), dim3(256), 0, c->stream, n, i, eigvec != NULL ? 1 : 0, c->din, c->dout, seq,
-      reinterpret_cast<unsigned long long*>(c->dout + EI_N + 4));
+   const int flagpos = (n <= EI_N) ? EI_N + 4 : EM_FLAG;
+   volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(c->hout + flagpos);
+   if ( n <= EI_N )
+      hipLaunchKernelGGL((k_syevi_small<false>), dim3(1), dim3(256), 0, c->stream, n, i, eigvec != NULL ? 1 : 0, c->din, c->dout, seq,
+         reinterpret_cast<unsigned long long*>(c->dout + flagpos));
+   else
+   {
+      /* 64 < n <= 128: the matrix in LDS (k_syevi_mid) */
+      const int smem = n * (n | 1) * (int) sizeof(double);
+      static hs_attr_mask attr_done;
+      HS_CALL( hs_func_max_lds(reinterpret_cast<const void*>(&k_syevi_mid), EM_N * (EM_N + 1) * (int) sizeof(double), &attr_done) );
+      hipLaunchKernelGGL(k_syevi_mid, dim3(1), dim3(256), smem, c->stream, n, i, eigvec != NULL ? 1 : 0, c->din, c->dout, seq,
+         reinterpret_cast<unsigned long long*>(c->dout + flagpos));
+   }
    HS_HIP( hipGetLastError() );
    long long spins = 0;
    while ( *flag != seq )

@@ -3,7 +3,7 @@
  * Every routine moves its (host, column-major) arguments through the hipsdp_* host-buffer kernels of libhipsdp.so:
  *   eigen problems  -> hipsdp_syev   (parallel-order Jacobi on the device; ascending values, eigenvectors as rows - exactly
  *                                     the convention lapack_interface.c:507-603 produces from DSYEVR); one eigenpair of a matrix
- *                                     with n <= 64 -> hipsdp_syevi_small (one launch, tridiagonalisation + bisection)
+ *                                     with n <= 128 -> hipsdp_syevi_small (one launch, tridiagonalisation + bisection)
  *   DGEMV / DGEMM   -> hipsdp_gemv_t / hipsdp_dgemm (FP64 MFMA), with the column-major <-> row-major mapping spelled out
  *   DGELSD          -> minimum-norm least squares through the eigen-decomposition of A^T A (device GEMM + device Jacobi)
  * A symmetric matrix reads the same in row- and column-major order, so no transposition is needed for the eigen calls.
@@ -58,7 +58,7 @@ SCIP_RETCODE SCIPlapackComputeIthEigenvalue(BMS_BUFMEM* bufmem, SCIP_Bool geteig
       return SCIP_ERROR;
    /* the sizes cons_sdp.c and solveonevarsdp.c call this with (blocks of 2-50 rows, dozens of calls per node): one eigenpair in
     * one launch through pinned staging memory, no allocation and no copy on the path */
-   if ( n <= 64 )
+   if ( n <= 128 )
    {
       DEV_CALL( hipsdp_syevi_small(lapack_device(), n, A, i, eigenvalue, (geteigenvectors && eigenvector != NULL) ? eigenvector : NULL) );
       return SCIP_OKAY;

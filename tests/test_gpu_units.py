@@ -376,11 +376,11 @@ def test_small_block_step_length_eigenvalue(gpu, n):
             assert abs(th[0] - ref) <= 1e-8 * scale          # full Krylov space (or Jacobi): exact
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 5, 16, 17, 33, 50, 64])
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 16, 17, 33, 50, 64, 65, 66, 100, 127, 128])
 def test_ith_eigenpair_in_one_launch_matches_dsyevr_range_i(gpu, n):
     """SCIPlapackComputeIthEigenvalue at the sizes its callers use (cons_sdp.c: blocks of 2-50 rows; lapack_interface.c:178-288):
     n <= 64 runs k_syevi_small (Householder tridiagonalisation, Sturm multisection for exactly the i-th eigenvalue, inverse
-    iteration + back-transformation) through pinned staging memory.  Every i: eigenvalue against numpy, eigenvector by residual and
+    iteration + back-transformation) through pinned staging memory, 64 < n <= 128 k_syevi_mid (the same with the matrix in LDS).  Every i: eigenvalue against numpy, eigenvector by residual and
     norm (sign and the basis of a multiple eigenvalue are free, as with DSYEVR)."""
     lib = gpu.lib()
     rng = np.random.default_rng(40 + n)
