@@ -17,6 +17,7 @@
 
 __global__ void k_lmin_tiny(int n, const double* __restrict__ A0, const double* __restrict__ A1, double* __restrict__ res0,
    double* __restrict__ res1, const double* __restrict__ L0, const double* __restrict__ L1);
+__global__ void k_lmin_tiny_multi(hs_step_jobs P);
 
 /* ---------------------------------------------------------------------------------------------------------------- */
 /* Lanczos                                                                                                            */
@@ -703,17 +704,14 @@ __device__ __forceinline__ double quad_sum(double x)
    return x;
 }
 
-__global__ void __launch_bounds__(256) k_lanczos_small(int n, int k, const double* __restrict__ D0, const double* __restrict__ D1,
-   double* __restrict__ res0, double* __restrict__ res1, const double* __restrict__ L0, const double* __restrict__ L1)
+__device__ __forceinline__ void d_lanczos_small(int n, int k, const double* __restrict__ Din, const double* __restrict__ Lin,
+   double* __restrict__ res)
 {
    extern __shared__ double lz2_smem[];
    __shared__ double alpha[LS_MAXK], beta[LS_MAXK], coef[LS_MAXK + 1];
    __shared__ double t1[64], t2[64], v[64];
    __shared__ double shr[4];
    __shared__ tridiag_smem T;
-   const double* __restrict__ Din = blockIdx.x ? D1 : D0;
-   const double* __restrict__ Lin = blockIdx.x ? L1 : L0;
-   double* __restrict__ res = blockIdx.x ? res1 : res0;
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
    const int row = tid >> 2, part = tid & 3;
    const int ld = n | 1;                /* odd row pitch: rows and columns are both conflict-free */
@@ -859,6 +857,23 @@ __global__ void __launch_bounds__(256) k_lanczos_small(int n, int k, const doubl
       tridiag_min_wave(k, alpha, beta, (double) kbreak, -1, 0.0, 0.0, res, T);
 }
 
+__global__ void __launch_bounds__(256) k_lanczos_small(int n, int k, const double* __restrict__ D0, const double* __restrict__ D1,
+   double* __restrict__ res0, double* __restrict__ res1, const double* __restrict__ L0, const double* __restrict__ L1)
+{
+   d_lanczos_small(n, k, blockIdx.x ? D1 : D0, blockIdx.x ? L1 : L0, blockIdx.x ? res1 : res0);
+}
+
+/* the same for SEVERAL blocks in one launch (blockIdx.y = block, blockIdx.x = side): a problem with twenty blocks of fifty rows spent
+ * 39 % of its iteration in forty launches of two workgroups each (tests/devtools/multiblock_time.py) */
+__global__ void __launch_bounds__(256) k_lanczos_small_multi(hs_step_jobs P, int maxsteps)
+{
+   const int job = blockIdx.y;
+   const int n = P.n[job];
+   int k = maxsteps < n ? maxsteps : n;
+   if ( k > LS_MAXK ) k = LS_MAXK;
+   d_lanczos_small(n, k, blockIdx.x ? P.D1[job] : P.D0[job], blockIdx.x ? P.L1[job] : P.L0[job], blockIdx.x ? P.res1[job] : P.res0[job]);
+}
+
 int hs_lanczos_scaled_small(hipStream_t s, int n, int maxsteps, const double* L0, const double* D0, const double* L1, const double* D1,
    double* res0, double* res1)
 {
@@ -870,6 +885,38 @@ int hs_lanczos_scaled_small(hipStream_t s, int n, int maxsteps, const double* L0
    HS_CALL( hs_func_max_lds(reinterpret_cast<const void*>(&k_lanczos_small), (2 * 64 * 65 + (LS_MAXK + 1) * 64) * (int) sizeof(double), &attr_done) );
    const size_t smem = ((size_t) 2 * n * (n | 1) + (size_t) (k + 1) * n) * sizeof(double);
    hipLaunchKernelGGL(k_lanczos_small, dim3(2), dim3(256), smem, s, n, k, D0, D1, res0, res1, L0, L1);
+   HS_LAUNCH_CHECK();
+   return HS_OK;
+}
+
+/* the step-length estimates of all blocks of one size class in one launch: P->n[j] <= 16 everywhere (k_lmin_tiny) or 16 < n <= 64
+ * everywhere (k_lanczos_small); same arithmetic per block as the single launches */
+int hs_steplen_small_multi(hipStream_t s, const hs_step_jobs* P, int maxsteps)
+{
+   if ( P->nblk <= 0 )
+      return HS_OK;
+   if ( P->nblk > HS_STEP_MAXJOBS )
+      return HS_ERR_ARG;
+   int nmax = 0, nmin = 1 << 30;
+   for (int j = 0; j < P->nblk; ++j)
+   {
+      if ( P->n[j] > nmax ) nmax = P->n[j];
+      if ( P->n[j] < nmin ) nmin = P->n[j];
+   }
+   if ( nmin < 1 || nmax > 64 || (nmin <= 16) != (nmax <= 16) )
+      return HS_ERR_ARG;
+   if ( nmax <= 16 )
+   {
+      hipLaunchKernelGGL(k_lmin_tiny_multi, dim3(2, P->nblk), dim3(64), 0, s, *P);
+      HS_LAUNCH_CHECK();
+      return HS_OK;
+   }
+   int k = maxsteps < nmax ? maxsteps : nmax;
+   if ( k > LS_MAXK ) k = LS_MAXK;
+   static hs_attr_mask attr_done;
+   HS_CALL( hs_func_max_lds(reinterpret_cast<const void*>(&k_lanczos_small_multi), (2 * 64 * 65 + (LS_MAXK + 1) * 64) * (int) sizeof(double), &attr_done) );
+   const size_t smem = ((size_t) 2 * nmax * (nmax | 1) + (size_t) (k + 1) * nmax) * sizeof(double);
+   hipLaunchKernelGGL(k_lanczos_small_multi, dim3(2, P->nblk), dim3(256), smem, s, *P, maxsteps);
    HS_LAUNCH_CHECK();
    return HS_OK;
 }
@@ -1461,12 +1508,9 @@ __device__ double lmin_sym16(double (*a)[17], int n, double* vv, double* ww, dou
 
 /* n <= 16: smallest eigenvalue only, ONE wavefront, no eigenvectors; res = { lambda_min, 0 (exact: no residual bound), n } like
  * the Lanczos result.  With L given the matrix is L A L^T (the scaled step), formed here. */
-__global__ void __launch_bounds__(64) k_lmin_tiny(int n, const double* __restrict__ A0, const double* __restrict__ A1,
-   double* __restrict__ res0, double* __restrict__ res1, const double* __restrict__ L0, const double* __restrict__ L1)
+/* Lin non-NULL: the matrix is L A L^T (the scaled step) */
+__device__ __forceinline__ void d_lmin_tiny(int n, const double* __restrict__ Ain, const double* __restrict__ Lin, double* __restrict__ res)
 {
-   const double* __restrict__ Ain = blockIdx.x ? A1 : A0;
-   const double* __restrict__ Lin = blockIdx.x ? L1 : L0;      /* non-NULL: the matrix is L A L^T (the scaled step) */
-   double* __restrict__ res = blockIdx.x ? res1 : res0;
    __shared__ double a[16][17];
    __shared__ double vv[16], ww[16], dd[16], e2[16];
    const int tid = threadIdx.x;
@@ -1536,6 +1580,19 @@ __global__ void __launch_bounds__(64) k_lmin_tiny(int n, const double* __restric
       res[1] = 0.0;
       res[2] = (double) n;
    }
+}
+
+__global__ void __launch_bounds__(64) k_lmin_tiny(int n, const double* __restrict__ A0, const double* __restrict__ A1,
+   double* __restrict__ res0, double* __restrict__ res1, const double* __restrict__ L0, const double* __restrict__ L1)
+{
+   d_lmin_tiny(n, blockIdx.x ? A1 : A0, blockIdx.x ? L1 : L0, blockIdx.x ? res1 : res0);
+}
+
+/* several blocks in one launch (blockIdx.y = block, blockIdx.x = side) */
+__global__ void __launch_bounds__(64) k_lmin_tiny_multi(hs_step_jobs P)
+{
+   const int job = blockIdx.y;
+   d_lmin_tiny(P.n[job], blockIdx.x ? P.D1[job] : P.D0[job], blockIdx.x ? P.L1[job] : P.L0[job], blockIdx.x ? P.res1[job] : P.res0[job]);
 }
 
 /* ---- n > 64: block Jacobi.  The matrix is cut into 32 x 32 blocks; a round of the round-robin tournament over the blocks pairs

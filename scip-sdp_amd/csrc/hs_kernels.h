@@ -183,6 +183,11 @@ int hs_lanczos_lmin(hipStream_t s, int n, const double* W, int maxsteps, double*
 long long hs_lanczos_ws(int n, int maxsteps);
 /* 16 < n <= 64: lambda_min(L0 D0 L0^T), lambda_min(L1 D1 L1^T) by Lanczos with the products, all steps and the tridiagonal
  * problem in one launch */
+/* step-length estimates of several small blocks in one launch (eig.hip): all n[j] <= 16 or all in 17 .. 64 */
+#define HS_STEP_MAXJOBS 32
+struct hs_step_jobs { int nblk; int n[HS_STEP_MAXJOBS]; const double* L0[HS_STEP_MAXJOBS]; const double* D0[HS_STEP_MAXJOBS];
+   const double* L1[HS_STEP_MAXJOBS]; const double* D1[HS_STEP_MAXJOBS]; double* res0[HS_STEP_MAXJOBS]; double* res1[HS_STEP_MAXJOBS]; };
+int hs_steplen_small_multi(hipStream_t s, const hs_step_jobs* P, int maxsteps);
 int hs_lanczos_scaled_small(hipStream_t s, int n, int maxsteps, const double* L0, const double* D0, const double* L1, const double* D1,
    double* res0, double* res1);
 int hs_lmin_scaled_tiny(hipStream_t s, int n, const double* L0, const double* D0, const double* L1, const double* D1, double* res0,

@@ -2007,14 +2007,34 @@ static int steplen_enqueue(hipsdp_solver* s)
    int nmax_blk = 0;
    for (auto& B : s->blk)
       if ( B.n > nmax_blk ) nmax_blk = B.n;
+   /* blocks of at most 64 rows: ONE launch per size class (<= 16: exact, 17 .. 64: Lanczos in LDS) for all of them together - with
+    * twenty blocks of fifty rows the forty two-workgroup launches of an iteration were 39 % of it (round 3) */
+   for (int cls = 0; cls < 2; ++cls)
+   {
+      hs_step_jobs J;
+      J.nblk = 0;
+      int kk = 0;
+      for (auto& B : s->blk)
+      {
+         const bool mine = (cls == 0) ? (B.n <= 16) : (B.n > 16 && B.n <= 64);
+         if ( mine )
+         {
+            const int j = J.nblk++;
+            J.n[j] = B.n; J.L0[j] = B.LxInv; J.D0[j] = B.dX; J.L1[j] = B.LzInv; J.D1[j] = B.dZ;
+            J.res0[j] = s->sc + SC_BLK(kk, 1); J.res1[j] = s->sc + SC_BLK(kk, 4);
+            if ( J.nblk == HS_STEP_MAXJOBS )
+            {
+               HS_CALL( hs_steplen_small_multi(st, &J, s->par.lanczos_steps) );
+               J.nblk = 0;
+            }
+         }
+         ++kk;
+      }
+      HS_CALL( hs_steplen_small_multi(st, &J, s->par.lanczos_steps) );
+   }
    for (auto& B : s->blk)
    {
-      if ( B.n <= 16 )
-         HS_CALL( hs_lmin_scaled_tiny(st, B.n, B.LxInv, B.dX, B.LzInv, B.dZ, s->sc + SC_BLK(k, 1), s->sc + SC_BLK(k, 4)) );
-      else if ( B.n <= 64 )
-         HS_CALL( hs_lanczos_scaled_small(st, B.n, s->par.lanczos_steps, B.LxInv, B.dX, B.LzInv, B.dZ, s->sc + SC_BLK(k, 1),
-               s->sc + SC_BLK(k, 4)) );
-      else
+      if ( B.n > 64 )
          HS_CALL( hs_lanczos_lmin2(st, B.n, B.W, B.W2, s->par.lanczos_steps, s->sc + SC_BLK(k, 1), s->sc + SC_BLK(k, 4), s->lan_ws,
                s->lan_ws2, s->lan_rot, s->lan_sync, nmax_blk) );
       ++k;
