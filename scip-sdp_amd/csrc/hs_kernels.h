@@ -25,6 +25,11 @@ int hs_gemv_t(hipStream_t s, int R, long long E, const double* A, long long lda,
 
 /* three linear combinations of the rows in one sweep over A (o_v[e] = sum_i c_v[i] A[i * lda + e]); 1: done, 0: shapes do not
  * qualify (E, lda even, 16-byte aligned), < 0: error code negated */
+/* the same with a workspace: few entries and many rows are summed in row chunks side by side (kernels.hip); hs_gemv_t_chunks(R, E)
+ * * E doubles are needed for that (0: never split) */
+int hs_gemv_t_chunks(int R, long long E);
+int hs_gemv_t_ws(hipStream_t s, int R, long long E, const double* A, long long lda, const double* coef, double sa,
+   const double* add, double* out, double* ws, long long wsdoubles);
 int hs_gemv_t3(hipStream_t s, int R, long long E, const double* A, long long lda, const double* c0, const double* c1, const double* c2,
    double* o0, double* o1, double* o2);
 

@@ -126,6 +126,8 @@ struct hipsdp_solver
    double pre_scale;       /* 1 / tau at the capture */
    int* regmask;           /* forced pivots of the last factorization of M (semidefinite pivot rule) */
    double *sc, *red_ws, *gemv_ws, *lan_ws, *lan_ws2, *gws1, *gws2;
+   double* gemvt_ws;                   /* row-chunk partial sums of the passes A^T over blocks with few entries (hs_gemv_t_ws) */
+   long long gemvt_ws_len;
    double* hsc;            /* pinned, device-visible host mirror of sc followed by the flags and a sequence number: the last kernel
                             * before a read-back stores the scalars there itself and the host waits for the number */
    double* hsc_dev;        /* device view of hsc */
@@ -316,6 +318,9 @@ static void free_problem(hipsdp_solver* s)
    s->passg = NULL;
    dfree(s->trsv_ws);
    s->trsv_ws = NULL;
+   dfree(s->gemvt_ws);
+   s->gemvt_ws = NULL;
+   s->gemvt_ws_len = 0;
    if ( s->lan_sync != NULL )
       (void) hipFree(s->lan_sync);
    s->lan_sync = NULL;
@@ -387,6 +392,8 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
    s->b = s->Dext = s->y = s->x = s->z = s->yt = s->dyt = s->wt = s->AX = s->AH = s->tmpe = s->rp = s->rd = s->tmpq = s->hl = NULL;
    s->beta = s->elp = s->dxa = s->dza = s->dx = s->dz = s->xs = s->zs = s->ys = s->u1 = s->rhs2 = s->cvec = s->u2 = s->dy = s->dya = NULL;
    s->Mx = s->Lm = s->dinvm = s->Slp = s->sc = s->red_ws = s->gemv_ws = s->lan_ws = s->lan_ws2 = s->gws1 = s->gws2 = NULL;
+   s->gemvt_ws = NULL;
+   s->gemvt_ws_len = 0;
    hipsdp_default_params(&s->par);
    s->sparse_policy = getenv("HIPSDP_SPARSE") != NULL ? atoi(getenv("HIPSDP_SPARSE")) : 1;
    if ( s->sparse_policy < 0 || s->sparse_policy > 2 ) s->sparse_policy = 1;
@@ -659,6 +666,17 @@ extern "C" int hipsdp_set_shape2(hipsdp_solver* s, int m, int nblocks, const int
    HS_CALL( dalloc(&s->red_ws, 1024) );
    s->gemv_ws_len = 8192 + 4LL * 1024 * 4;
    HS_CALL( dalloc(&s->gemv_ws, s->gemv_ws_len) );
+   {
+      long long need = 0;
+      for (auto& B : s->blk)
+      {
+         const long long n2 = (long long) B.n * B.n, lp = (long long) B.n * (B.n + 1) / 2;
+         need = std::max(need, std::max((long long) hs_gemv_t_chunks(m + 1, n2) * n2, (long long) hs_gemv_t_chunks(m + 1, lp) * lp));
+      }
+      s->gemvt_ws_len = need;
+      if ( need > 0 )
+         HS_CALL( dalloc(&s->gemvt_ws, need) );
+   }
    HS_CALL( dalloc(&s->lan_ws, hs_lanczos_ws(nmax, 256)) );
    HS_CALL( dalloc(&s->lan_ws2, hs_lanczos_ws(nmax, 256)) );
    if ( nmax > 64 )
@@ -1750,10 +1768,10 @@ static int pass_AT(hipsdp_solver* s, Block& B, const double* coef, double sa, co
    }
    if ( B.Apk != NULL )
    {
-      HS_CALL( hs_gemv_t(s->stream, m1, B.Lp, B.Apk, B.Lp, coef, 0.0, NULL, B.pkv + B.Lp) );
+      HS_CALL( hs_gemv_t_ws(s->stream, m1, B.Lp, B.Apk, B.Lp, coef, 0.0, NULL, B.pkv + B.Lp, s->gemvt_ws, s->gemvt_ws_len) );
       return hs_unpack_sym(s->stream, B.n, B.pkv + B.Lp, sa, add, out);
    }
-   return hs_gemv_t(s->stream, m1, n2, B.A, n2, coef, sa, add, out);
+   return hs_gemv_t_ws(s->stream, m1, n2, B.A, n2, coef, sa, add, out, s->gemvt_ws, s->gemvt_ws_len);
 }
 
 #define AS_MAXBLK HS_AS_MAXBLK

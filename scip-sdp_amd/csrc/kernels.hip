@@ -1925,6 +1925,95 @@ int hs_gemv_t3(hipStream_t s, int R, long long E, const double* A, long long lda
    return 1;
 }
 
+/* few output entries, many rows (a block of 50 - 300 rows with hundreds of variables: E = 2 500 .. 45 000 entries, 10 .. 90 workgroups
+ * of k_gemv_t, each walking all rows: 1 TB/s): the rows are cut into chunks, workgroup (x, c) forms the partial sums of chunk c, a
+ * second launch adds the chunks in order (and the additive term).  Deterministic; not the summation order of k_gemv_t, which is
+ * why the recorded form (RB_GEMVT, tiny problems) and this one never apply to the same size. */
+__global__ void __launch_bounds__(256) k_gemv_t_part(int R, int rc, long long E, const double* __restrict__ A, long long lda,
+   const double* __restrict__ coef, double* __restrict__ part)
+{
+   const long long e = 2 * ((long long) blockIdx.x * blockDim.x + threadIdx.x);
+   if ( e >= E )
+      return;
+   const int i0 = blockIdx.y * rc;
+   const int i1 = min(R, i0 + rc);
+   double s0 = 0.0, s1 = 0.0;
+   const bool two = e + 1 < E;
+   const double* a = A + e;
+   int i = i0;
+   for (; i + 8 <= i1; i += 8)
+   {
+      double x0[8], x1[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+      {
+         const double* p = a + (long long) (i + q) * lda;
+         x0[q] = p[0];
+         x1[q] = two ? p[1] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+      {
+         const double cq = coef[i + q];
+         s0 += cq * x0[q]; s1 += cq * x1[q];
+      }
+   }
+   for (; i < i1; ++i)
+   {
+      const double* p = a + (long long) i * lda;
+      const double cq = coef[i];
+      s0 += cq * p[0];
+      if ( two )
+         s1 += cq * p[1];
+   }
+   double* o = part + (long long) blockIdx.y * E + e;
+   o[0] = s0;
+   if ( two )
+      o[1] = s1;
+}
+
+__global__ void __launch_bounds__(256) k_gemv_t_comb(int C, long long E, const double* __restrict__ part, double sa,
+   const double* __restrict__ add, double* __restrict__ out)
+{
+   const long long e = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+   if ( e >= E )
+      return;
+   double s0 = 0.0;
+   for (int c = 0; c < C; ++c)
+      s0 += part[(long long) c * E + e];
+   if ( add != NULL )
+      s0 += sa * add[e];
+   out[e] = s0;
+}
+
+/* chunks the split form would use (0: the plain kernel is the right one); workspace: chunks * E doubles */
+int hs_gemv_t_chunks(int R, long long E)
+{
+   if ( E > 65536 || R < 128 || (long long) R * E < (1LL << 20) )
+      return 0;
+   const long long wg = (E + 511) / 512;
+   long long c = (512 + wg - 1) / wg;
+   if ( c > 32 ) c = 32;
+   if ( c > R / 32 ) c = R / 32;
+   return c >= 2 ? (int) c : 0;
+}
+
+int hs_gemv_t_ws(hipStream_t s, int R, long long E, const double* A, long long lda, const double* coef, double sa,
+   const double* add, double* out, double* ws, long long wsdoubles)
+{
+   const int C = hs_gemv_t_chunks(R, E);
+   if ( C == 0 || ws == NULL || (long long) C * E > wsdoubles )
+      return hs_gemv_t(s, R, E, A, lda, coef, sa, add, out);
+   (void) hs_red_batch_flush();
+   int rc = (R + C - 1) / C;
+   rc = (rc + 7) & ~7;
+   const int Cu = (R + rc - 1) / rc;
+   hipLaunchKernelGGL(k_gemv_t_part, dim3((unsigned) ((E + 511) / 512), (unsigned) Cu), dim3(256), 0, s, R, rc, E, A, lda, coef, ws);
+   hipLaunchKernelGGL(k_gemv_t_comb, dim3((unsigned) ((E + 255) / 256)), dim3(256), 0, s, Cu, E, ws, sa, add, out);
+   HS_LAUNCH_CHECK();
+   return HS_OK;
+}
+
 int hs_gemv_t(hipStream_t s, int R, long long E, const double* A, long long lda, const double* coef, double sa,
    const double* add, double* out)
 {
