@@ -13,6 +13,7 @@
  *     eigenvector - what DSYEVR does for one eigenpair.
  * Larger matrices keep the block-Jacobi path (eig.hip). */
 #include "hs_common.h"
+#include "hs_kernels.h"
 #include "../../include/hipsdp.h"
 #include <cstring>
 #include <cmath>
@@ -100,9 +101,11 @@ __device__ __forceinline__ double ei_rcp(double t)
  * reciprocals and the first superdiagonal of U; its second superdiagonal is e[i + 1] in the rows that were swapped and 0 elsewhere:
  * one bit per row in a register). */
 #define EI_ALL_LDS ((EI_N * EI_N + 2 * EI_N * EI_N) * (int) sizeof(double))
+/* the body (flag == NULL: no sequence number, no system-scope fence - the caller is another kernel of the engine, see
+ * k_lmin_exact_multi below; in may then point into LDS) */
 template<bool ALL>
-__global__ void __launch_bounds__(256) k_syevi_small(int n, int ith, int wantvec, const double* __restrict__ in, double* __restrict__ out,
-   unsigned long long seq, unsigned long long* __restrict__ flag)
+__device__ __forceinline__ void d_syevi_small(int n, int ith, int wantvec, const double* in, double* out,
+   unsigned long long seq, unsigned long long* flag, double mtol = 2e-16)
 {
    extern __shared__ __attribute__((aligned(16))) double ei_dyn[];
    __shared__ double a[EI_N][EI_LD];
@@ -481,12 +484,16 @@ __global__ void __launch_bounds__(256) k_syevi_small(int n, int ith, int wantvec
       const double nlo = lo + w * (double) first;
       const double nhi = (first < 64) ? lo + w * (double) (first + 1) : hi;
       lo = nlo; hi = nhi;
-      if ( hi - lo <= 2e-16 * fmax(fabs(lo), fabs(hi)) )
+      if ( hi - lo <= mtol * fmax(fabs(lo), fabs(hi)) )
          break;
    }
    const double theta = 0.5 * (lo + hi);
    if ( lane == 0 )
+   {
       out[0] = theta;
+      if ( flag == NULL && !wantvec )
+         out[1] = 0.5 * (hi - lo);                     /* the eigenvalue lies within this of theta (engine callers: a rigorous bound) */
+   }
 
    if ( wantvec )
    {
@@ -584,12 +591,79 @@ __global__ void __launch_bounds__(256) k_syevi_small(int n, int ith, int wantvec
       if ( lane < n )
          out[1 + lane] = nrm > 0.0 ? zi / nrm : zi;
    }
+   if ( flag == NULL )
+      return;
    __threadfence_system();
    __builtin_amdgcn_wave_barrier();
    if ( lane == 0 )
    {
       __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
    }
+}
+
+template<bool ALL>
+__global__ void __launch_bounds__(256) k_syevi_small(int n, int ith, int wantvec, const double* __restrict__ in, double* __restrict__ out,
+   unsigned long long seq, unsigned long long* __restrict__ flag)
+{
+   d_syevi_small<ALL>(n, ith, wantvec, in, out, seq, flag);
+}
+
+/* ---- step lengths of the engine for blocks of 17 .. 64 rows: lambda_min(L D L^T) EXACTLY instead of by Lanczos -----------------
+ * (L = inverse Cholesky factor of X or Z, D = dX or dZ: the scaled step whose smallest eigenvalue bounds the step length).  The
+ * Lanczos kernel of eig.hip takes 120 us for 24 steps at n = 43 and returns an estimate with a residual bound; the reduction above
+ * gives the eigenvalue itself in about half of that: the workgroup forms W = L D L^T in LDS (two products from LDS, 4 lanes per
+ * row are not needed: 256 threads x n^2 / 256 entries), symmetrises it and runs the i = 1 path of d_syevi_small on it.
+ * blockIdx.x = side (X / Z), blockIdx.y = block; res = {lambda_min, half width of its interval, n} as the other step-length kernels. */
+__global__ void __launch_bounds__(256) k_lmin_exact_multi(hs_step_jobs P)
+{
+   extern __shared__ __attribute__((aligned(16))) double ex_dyn[];
+   const int job = blockIdx.y;
+   const int n = P.n[job];
+   const double* __restrict__ Din = blockIdx.x ? P.D1[job] : P.D0[job];
+   const double* __restrict__ Lin = blockIdx.x ? P.L1[job] : P.L0[job];
+   double* __restrict__ res = blockIdx.x ? P.res1[job] : P.res0[job];
+   const int tid = threadIdx.x;
+   const int ld = n | 1;
+   double* sl = ex_dyn;                 /* n x ld: L (lower triangle, zeros above) */
+   double* sd = sl + n * ld;            /* n x ld: D, then W */
+   double* st = sd + n * ld;            /* n x ld: T = D L^T */
+   for (int e = tid; e < n * n; e += 256)
+   {
+      const int r = e / n, c = e - r * n;
+      sl[r * ld + c] = (c <= r) ? Lin[e] : 0.0;
+      sd[r * ld + c] = Din[e];
+   }
+   __syncthreads();
+   for (int e = tid; e < n * n; e += 256)
+   {
+      const int r = e / n, c = e - r * n;
+      double acc = 0.0;
+      for (int k = 0; k <= c; ++k)                     /* L[c][k] = 0 for k > c */
+         acc += sd[r * ld + k] * sl[c * ld + k];
+      st[r * ld + c] = acc;
+   }
+   __syncthreads();
+   for (int e = tid; e < n * n; e += 256)
+   {
+      const int r = e / n, c = e - r * n;
+      double acc = 0.0;
+      for (int k = 0; k <= r; ++k)
+         acc += sl[r * ld + k] * st[k * ld + c];
+      sd[r * ld + c] = acc;
+   }
+   __syncthreads();
+   /* symmetric part, as an n x n array without pitch (what d_syevi_small reads; it only looks at one triangle) */
+   for (int e = tid; e < n * n; e += 256)
+   {
+      const int r = e / n, c = e - r * n;
+      st[e] = 0.5 * (sd[r * ld + c] + sd[c * ld + r]);
+   }
+   __syncthreads();
+   /* a step length needs nine digits, not sixteen: the multisection stops at a relative width of 1e-10 and hands the half width back
+    * as the residual bound (res[1]), which the host subtracts - five or six rounds instead of nine or ten */
+   d_syevi_small<false>(n, 1, 0, st, res, 0ULL, NULL, 1e-10);
+   if ( tid == 0 )
+      res[2] = (double) n;
 }
 
 /* ---- 64 < n <= 128: the same eigenpair, the matrix in LDS --------------------------------------------------------------------
@@ -1050,5 +1124,25 @@ int hs_syev_small_dev(hipStream_t st, int n, const double* A, double* lam, doubl
    HS_HIP( hipGetLastError() );
    HS_HIP( hipMemcpyAsync(lam, scratch, (size_t) n * sizeof(double), hipMemcpyDeviceToDevice, st) );
    HS_HIP( hipMemcpyAsync(V, scratch + EI_N, (size_t) n * n * sizeof(double), hipMemcpyDeviceToDevice, st) );
+   return HS_OK;
+}
+
+/* lambda_min of the scaled steps of several blocks of 17 .. 64 rows, exactly, in one launch (k_lmin_exact_multi) */
+int hs_lmin_exact_multi(hipStream_t st, const hs_step_jobs* P)
+{
+   if ( P->nblk <= 0 )
+      return HS_OK;
+   int nmax = 0;
+   for (int j = 0; j < P->nblk; ++j)
+   {
+      if ( P->n[j] < 1 || P->n[j] > EI_N )
+         return HS_ERR_ARG;
+      if ( P->n[j] > nmax ) nmax = P->n[j];
+   }
+   static hs_attr_mask attr_done;
+   HS_CALL( hs_func_max_lds(reinterpret_cast<const void*>(&k_lmin_exact_multi), 3 * EI_N * EI_LD * (int) sizeof(double), &attr_done) );
+   const size_t smem = (size_t) 3 * nmax * (nmax | 1) * sizeof(double);
+   hipLaunchKernelGGL(k_lmin_exact_multi, dim3(2, P->nblk), dim3(256), smem, st, *P);
+   HS_HIP( hipGetLastError() );
    return HS_OK;
 }

@@ -193,6 +193,8 @@ long long hs_lanczos_ws(int n, int maxsteps);
 struct hs_step_jobs { int nblk; int n[HS_STEP_MAXJOBS]; const double* L0[HS_STEP_MAXJOBS]; const double* D0[HS_STEP_MAXJOBS];
    const double* L1[HS_STEP_MAXJOBS]; const double* D1[HS_STEP_MAXJOBS]; double* res0[HS_STEP_MAXJOBS]; double* res1[HS_STEP_MAXJOBS]; };
 int hs_steplen_small_multi(hipStream_t s, const hs_step_jobs* P, int maxsteps);
+/* 17 .. 64 rows: the eigenvalue itself (Householder reduction + multisection, eigi.hip) instead of the Lanczos estimate */
+int hs_lmin_exact_multi(hipStream_t st, const hs_step_jobs* P);
 int hs_lanczos_scaled_small(hipStream_t s, int n, int maxsteps, const double* L0, const double* D0, const double* L1, const double* D1,
    double* res0, double* res1);
 int hs_lmin_scaled_tiny(hipStream_t s, int n, const double* L0, const double* D0, const double* L1, const double* D1, double* res0,
