@@ -14,6 +14,7 @@
  * Larger matrices keep the block-Jacobi path (eig.hip). */
 #include "hs_common.h"
 #include "hs_kernels.h"
+#include "hs_lds_product.h"
 #include "../../include/hipsdp.h"
 #include <cstring>
 #include <cmath>
@@ -634,23 +635,10 @@ __global__ void __launch_bounds__(256) k_lmin_exact_multi(hs_step_jobs P)
       sd[r * ld + c] = Din[e];
    }
    __syncthreads();
-   for (int e = tid; e < n * n; e += 256)
-   {
-      const int r = e / n, c = e - r * n;
-      double acc = 0.0;
-      for (int k = 0; k <= c; ++k)                     /* L[c][k] = 0 for k > c */
-         acc += sd[r * ld + k] * sl[c * ld + k];
-      st[r * ld + c] = acc;
-   }
+   /* T = D L^T (second factor given transposed), W = L T: 2 x 5 patches per thread (hs_lds_product.h); the zeros of L are multiplied */
+   db_product<true>(n, ld, sd, sl, [&](int, int, int r, int c, double acc) { st[r * ld + c] = acc; });
    __syncthreads();
-   for (int e = tid; e < n * n; e += 256)
-   {
-      const int r = e / n, c = e - r * n;
-      double acc = 0.0;
-      for (int k = 0; k <= r; ++k)
-         acc += sl[r * ld + k] * st[k * ld + c];
-      sd[r * ld + c] = acc;
-   }
+   db_product(n, ld, sl, st, [&](int, int, int r, int c, double acc) { sd[r * ld + c] = acc; });
    __syncthreads();
    /* symmetric part, as an n x n array without pitch (what d_syevi_small reads; it only looks at one triangle) */
    for (int e = tid; e < n * n; e += 256)
@@ -1135,7 +1123,7 @@ int hs_lmin_exact_multi(hipStream_t st, const hs_step_jobs* P)
    int nmax = 0;
    for (int j = 0; j < P->nblk; ++j)
    {
-      if ( P->n[j] < 1 || P->n[j] > EI_N )
+      if ( P->n[j] < 1 || P->n[j] > HS_SMALL_N )          /* (the products out of LDS give every thread a 2 x 5 patch: hs_lds_product.h) */
          return HS_ERR_ARG;
       if ( P->n[j] > nmax ) nmax = P->n[j];
    }

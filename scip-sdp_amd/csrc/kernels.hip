@@ -386,6 +386,8 @@ int hs_symmetrize(hipStream_t s, double* A, int n)
 /* small blocks (n <= 32): the whole chain  out = s1 Zinv - X - sym((c X R + E) Zinv)  in one workgroup, operands in LDS.
  * Same products as the three-launch path (gemm, gemm, k_dirmat), one launch: the B&B-sized problems are bound by the launch
  * count. */
+#include "hs_lds_product.h"
+
 __device__ void d_dir_block_small(int n, double c, const double* __restrict__ X, const double* __restrict__ R,
    const double* __restrict__ E, const double* __restrict__ Zinv, double s1, double* __restrict__ out, double* db_smem)
 {
@@ -396,35 +398,96 @@ __device__ void d_dir_block_small(int n, double c, const double* __restrict__ X,
    double* sg = sz + n * ld;
    const int tid = threadIdx.x;
    const int n2 = n * n;
-   for (int e = tid; e < n2; e += 256)
+   if ( n2 <= 256 )
    {
-      const int r = e / n, cc = e - r * n;
-      sx[r * ld + cc] = X[e];
-      sr[r * ld + cc] = R[e];
-      sz[r * ld + cc] = Zinv[e];
+      /* at most one entry per thread (n <= 16): nothing to interleave, the short form is the fast one (1.8 us at n = 10) */
+      const int e = tid;
+      const bool in = e < n2;
+      const int r = in ? e / n : 0, cc = in ? e - r * n : 0;
+      const double evv = (in && E != NULL) ? E[e] : 0.0;
+      if ( in )
+      {
+         sx[r * ld + cc] = X[e];
+         sr[r * ld + cc] = R[e];
+         sz[r * ld + cc] = Zinv[e];
+      }
+      __syncthreads();
+      if ( in )
+      {
+         double acc = 0.0;
+         for (int k = 0; k < n; ++k)
+            acc = fma(sx[r * ld + k], sr[k * ld + cc], acc);
+         double g = acc * c;
+         if ( E != NULL )
+            g = __dadd_rn(g, evv);
+         sg[r * ld + cc] = g;
+      }
+      __syncthreads();
+      double gz = 0.0;
+      if ( in )
+      {
+         for (int k = 0; k < n; ++k)
+            gz = fma(sg[r * ld + k], sz[k * ld + cc], gz);
+      }
+      __syncthreads();
+      if ( in )
+         sr[r * ld + cc] = gz;
+      __syncthreads();
+      if ( in )
+         out[e] = s1 * sz[r * ld + cc] - sx[r * ld + cc] - 0.5 * (sr[r * ld + cc] + sr[cc * ld + r]);
+      return;
+   }
+   /* all global loads of the thread first (independent ones in flight together), then the LDS stores: everything in this regime
+    * waits for memory, and a loop of load - store - load pays the latency once per trip */
+   double ev[DB_PR][DB_PC];
+   {
+      const int tc = (n + DB_PC - 1) / DB_PC;
+      const int pr = tid / tc, pc = tid - pr * tc;
+#pragma unroll
+      for (int i = 0; i < DB_PR; ++i)
+#pragma unroll
+         for (int j = 0; j < DB_PC; ++j)
+         {
+            const int r = min(DB_PR * pr + i, n - 1), cc = min(DB_PC * pc + j, n - 1);
+            ev[i][j] = (E != NULL) ? E[r * n + cc] : 0.0;
+         }
+      const int ueff = (n2 + 255) >> 8;
+      double xv[DB_U], rv[DB_U], zv[DB_U];
+#pragma unroll
+      for (int u = 0; u < DB_U; ++u)
+         if ( u < ueff )
+         {
+            const int e = min(tid + 256 * u, n2 - 1);
+            xv[u] = X[e];
+            rv[u] = R[e];
+            zv[u] = Zinv[e];
+         }
+#pragma unroll
+      for (int u = 0; u < DB_U; ++u)
+      {
+         const int e = tid + 256 * u;
+         if ( u < ueff && e < n2 )
+         {
+            const int r = e / n, cc = e - r * n;
+            sx[r * ld + cc] = xv[u];
+            sr[r * ld + cc] = rv[u];
+            sz[r * ld + cc] = zv[u];
+         }
+      }
    }
    __syncthreads();
-   for (int e = tid; e < n2; e += 256)
+   /* G = c X R (+ E): the product is rounded, scaled, then E is added - three roundings, spelled out so that every kernel this body
+    * is compiled into does the same */
+   db_product(n, ld, sx, sr, [&](int i, int j, int r, int cc, double acc)
    {
-      const int r = e / n, cc = e - r * n;
-      double acc = 0.0;
-      for (int k = 0; k < n; ++k)
-         acc += sx[r * ld + k] * sr[k * ld + cc];
-      acc *= c;
+      double g = acc * c;
       if ( E != NULL )
-         acc += E[e];
-      sg[r * ld + cc] = acc;
-   }
+         g = __dadd_rn(g, ev[i][j]);
+      sg[r * ld + cc] = g;
+   });
    __syncthreads();
    /* GZ into sr (R is no longer needed) */
-   for (int e = tid; e < n2; e += 256)
-   {
-      const int r = e / n, cc = e - r * n;
-      double acc = 0.0;
-      for (int k = 0; k < n; ++k)
-         acc += sg[r * ld + k] * sz[k * ld + cc];
-      sr[r * ld + cc] = acc;
-   }
+   db_product(n, ld, sg, sz, [&](int, int, int r, int cc, double acc) { sr[r * ld + cc] = acc; });
    __syncthreads();
    for (int e = tid; e < n2; e += 256)
    {

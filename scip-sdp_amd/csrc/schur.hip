@@ -18,6 +18,7 @@
  * Algorithmic flops per assembly: 4 m1 n^3 + m1^2 n^2.
  */
 #include "hs_kernels.h"
+#include "hs_lds_product.h"
 #include <vector>
 #include <cmath>
 #include <stdlib.h>
@@ -480,23 +481,11 @@ __global__ void __launch_bounds__(256) k_schur_small(int m1, int nmax, ss_args B
          sa[r * ldm + c] = Aj[e];
       }
       __syncthreads();
-      for (int e = tid; e < n2; e += 256)
-      {
-         const int r = e / n, c = e - r * n;
-         double acc = 0.0;
-         for (int t = 0; t < n; ++t)
-            acc += sx[r * ldm + t] * sa[t * ldm + c];
-         st[r * ldm + c] = acc;
-      }
+      /* U_j = (X A_j) Zinv: 2 x 5 patches per thread (hs_lds_product.h; entry by entry the two products were most of the 67 us
+       * of this kernel at n = 43) */
+      db_product(n, ldm, sx, sa, [&](int, int, int r, int c, double acc) { st[r * ldm + c] = acc; });
       __syncthreads();
-      for (int e = tid; e < n2; e += 256)
-      {
-         const int r = e / n, c = e - r * n;
-         double acc = 0.0;
-         for (int t = 0; t < n; ++t)
-            acc += st[r * ldm + t] * sz[t * ldm + c];
-         su[r * ldm + c] = acc;
-      }
+      db_product(n, ldm, st, sz, [&](int, int, int r, int c, double acc) { su[r * ldm + c] = acc; });
       __syncthreads();
       /* <A_i, U_j> for i >= j: one wavefront per i */
       for (int i = j + wave; i < m1; i += 4)
