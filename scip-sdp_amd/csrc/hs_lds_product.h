@@ -35,6 +35,8 @@ __device__ __forceinline__ void db_product(int n, int ld, const double* __restri
 #pragma unroll
       for (int j = 0; j < DB_PC; ++j)
          acc[i][j] = 0.0;
+   /* (four steps of k unrolled: 28 LDS reads in flight; one step at a time waits out the LDS latency n times) */
+#pragma unroll 4
    for (int k = 0; k < n; ++k)
    {
       double av[DB_PR], bv[DB_PC];
