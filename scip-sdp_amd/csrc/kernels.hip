@@ -738,6 +738,7 @@ __global__ void __launch_bounds__(256) k_red_batch(rb_args A)
    {
       const rb_desc& D = A.d[t];
       const unsigned long long t_begin = (A.dbg != NULL) ? wall_clock64() : 0ULL;
+      const unsigned long long c_begin = (A.dbg != NULL) ? clock64() : 0ULL;
       switch ( D.kind )
       {
       case RED_DOT:      rb_run<RED_DOT>(D, sh); break;
@@ -1148,8 +1149,11 @@ __global__ void __launch_bounds__(256) k_red_batch(rb_args A)
       __syncthreads();
       if ( A.dbg != NULL && threadIdx.x == 0 )
       {
-         atomicAdd(A.dbg + 2 * (D.kind & 31), wall_clock64() - t_begin);
+         const unsigned long long dt = wall_clock64() - t_begin;
+         atomicAdd(A.dbg + 2 * (D.kind & 31), dt);
          atomicAdd(A.dbg + 2 * (D.kind & 31) + 1, 1ULL);
+         atomicAdd(A.dbg + 64, dt);                    /* all records: wall-clock ticks and shader-clock cycles */
+         atomicAdd(A.dbg + 65, (unsigned long long) clock64() - c_begin);
       }
    }
    if ( A.pub_n > 0 )
@@ -1167,9 +1171,11 @@ __global__ void __launch_bounds__(256) k_red_batch(rb_args A)
 static unsigned long long* g_rb_dbg = NULL;
 static void rb_dbg_report(void)
 {
-   unsigned long long h[64];
+   unsigned long long h[66];
    if ( g_rb_dbg == NULL || hipMemcpy(h, g_rb_dbg, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess )
       return;
+   if ( h[64] > 0 )
+      fprintf(stderr, "batch records: shader clock while they ran %.0f MHz\n", (double) h[65] / ((double) h[64] * 0.01));
    for (int k = 0; k < 32; ++k)
       if ( h[2 * k + 1] > 0 )
          fprintf(stderr, "batch records of kind %%32 = %2d: %10llu records, %8.3f us each\n", k, h[2 * k + 1],
@@ -1182,8 +1188,8 @@ static unsigned long long* rb_dbg_buffer(void)
    {
       const char* env = getenv("HIPSDP_BATCH_TIMES");
       on = (env != NULL && env[0] == '1') ? 1 : 0;
-      if ( on && hipMalloc((void**) &g_rb_dbg, 64 * sizeof(unsigned long long)) == hipSuccess
-         && hipMemset(g_rb_dbg, 0, 64 * sizeof(unsigned long long)) == hipSuccess )
+      if ( on && hipMalloc((void**) &g_rb_dbg, 66 * sizeof(unsigned long long)) == hipSuccess
+         && hipMemset(g_rb_dbg, 0, 66 * sizeof(unsigned long long)) == hipSuccess )
          atexit(rb_dbg_report);
       else
          g_rb_dbg = NULL;
