@@ -28,11 +28,11 @@ FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X FP64 matrix peak (vendor figure; rocB
 # FP64 matrix rate of the two n^3 products / the Gram product.  Keyed by (n, m), quoted from the committed file named in
 # "source" and labelled as such in the JSON line; one GPU only; None for sizes that were not profiled.
 PMC_FROM_PROFILES = {
-    (500, 1000): {"traffic_bytes_per_assembly": 17.53e9, "mfma_busy": {"n3_products": 0.659, "gram": 0.846},
-                  "executed_tflops": {"n3_products": 43.8, "gram": 58.1},
+    (500, 1000): {"traffic_bytes_per_assembly": 17.52e9, "mfma_busy": {"n3_products": 0.672, "gram": 0.842},
+                  "executed_tflops": {"n3_products": 44.2, "gram": 57.8},
                   "source": "profiles/r03_e_pmc_traffic_c2.txt, profiles/r03_e_pmc_mfma_util.txt"},
-    (1000, 2000): {"traffic_bytes_per_assembly": None, "mfma_busy": {"n3_products": 0.742, "gram": 0.872},
-                   "executed_tflops": {"n3_products": 56.4, "gram": 67.4},
+    (1000, 2000): {"traffic_bytes_per_assembly": None, "mfma_busy": {"n3_products": 0.743, "gram": 0.871},
+                   "executed_tflops": {"n3_products": 56.4, "gram": 67.5},
                    "source": "profiles/r03_e_pmc_mfma_util.txt"},
 }
 WORKLOAD_NAMES = {(500, 1000): "BASELINE configs[1] (C2)", (1000, 2000): "BASELINE.md T1 (north_star target size)",
