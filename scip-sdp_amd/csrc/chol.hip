@@ -299,7 +299,7 @@ __device__ __forceinline__ void pd_update_tiles(double (*W)[PD_LD], const double
 
 /* LDS: tile 0 = the block while it is factored, inv(L) afterwards; tile 1 = L; then 64 doubles each: 1 / l_kk, the reference
  * diagonal, the forced flags, the pivot column of the current step, the pivot thresholds */
-template<int NBK>      /* padded block size actually processed: 16, 32 or 64 (tiny blocks skip the identity padding) */
+template<int NBK>      /* padded block size actually processed: 16, 32, 48 or 64 (small blocks skip the identity padding) */
 __device__ __forceinline__ void pd_body(double* __restrict__ A, long long lda, int nb, int j0,
    double* __restrict__ dinv, int* __restrict__ flag, const double* __restrict__ diag0, double regtol, const pd_ext& ext)
 {
@@ -853,6 +853,8 @@ int hs_potrf_small_ext(hipStream_t s, int n, double* L, double* dinv, int* flag,
       return launch_potrf_diag<16>(s, L, n, n, 0, dinv, flag, NULL, &ext);
    if ( n <= 32 )
       return launch_potrf_diag<32>(s, L, n, n, 0, dinv, flag, NULL, &ext);
+   if ( n <= 48 )
+      return launch_potrf_diag<48>(s, L, n, n, 0, dinv, flag, NULL, &ext);       /* three panels of 16 instead of four (example_CLS: n = 43) */
    return launch_potrf_diag<64>(s, L, n, n, 0, dinv, flag, NULL, &ext);
 }
 
