@@ -148,8 +148,8 @@ def workload_name(n, m):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n", type=int, default=500)
     ap.add_argument("--m", type=int, default=1000)
     ap.add_argument("--seed", type=int, default=20240)
