@@ -383,7 +383,7 @@ int hs_symmetrize(hipStream_t s, double* A, int n)
    return HS_OK;
 }
 
-/* small blocks (n <= 32): the whole chain  out = s1 Zinv - X - sym((c X R + E) Zinv)  in one workgroup, operands in LDS.
+/* small blocks (n <= HS_SMALL_N): the whole chain  out = s1 Zinv - X - sym((c X R + E) Zinv)  in one workgroup, operands in LDS.
  * Same products as the three-launch path (gemm, gemm, k_dirmat), one launch: the B&B-sized problems are bound by the launch
  * count. */
 #include "hs_lds_product.h"
