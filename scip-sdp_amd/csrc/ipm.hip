@@ -2181,6 +2181,12 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       CommOff off(s, alone);
       rc = solve_impl(s, params, info);
    }
+   /* no recorded operation and no held region outlives the call: a normal return has launched everything (the final read-back
+    * ends the regions), an error return may have left records behind, which are dropped */
+   if ( rc == HIPSDP_OK )
+      rc = hs_red_batch_end_all();
+   else
+      hs_red_batch_reset();
    if ( rc != HIPSDP_OK )          /* error return inside the iteration: whatever it had queued on either queue must not outlive the call */
    {
       (void) hipStreamSynchronize(s->stream);
