@@ -4,7 +4,7 @@
 cd $GRAFT_REPO_ROOT
 for n in ${NS:-32 48 64 65 96 128 200 300 400}; do
 for m in ${MS:-50 100 200 500 1000}; do
-timeout -k 10 200 python3 bench.py --n $n --m $m --steps 3 --warmup 1 --no-cpu --no-extras 2>/dev/null | python3 -c "
+timeout -k 10 200 python3 bench.py --n $n --m $m --steps ${STEPS:-3} --warmup ${WARM:-1} --no-cpu --no-extras 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 n=d['config']['n']; m=d['config']['m']; it=d['iterations_per_solve']
