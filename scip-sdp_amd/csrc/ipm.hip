@@ -1696,8 +1696,9 @@ static int pass_A(hipsdp_solver* s, Block& B, const double* V, double* out)
    {
       /* launched at once like the dense pass (hs_dot would be deferred inside a reduction batch, and callers add the result up
        * with kernels that are not) */
-      hipLaunchKernelGGL(k_sp_dot0, dim3(1), dim3(1024), 0, s->stream, (long long) B.n * B.n, B.A0, V, out);
-      HS_LAUNCH_CHECK();
+      /* <A_0, V> (A_0 is dense): the row-dot kernel of the dense pass with one row - split over workgroups and combined in order
+       * (a single workgroup took 73 us for the 250 000 entries of a block of 500 rows) */
+      HS_CALL( hs_gemv_n(s->stream, 1, (long long) B.n * B.n, B.A0, (long long) B.n * B.n, 1, &V, out, 1, s->gemv_ws, s->gemv_ws_len) );
       return hs_sp_apply_A(s->stream, B.sp, V, out + 1);
    }
    if ( passes_sharded(s, B) )
