@@ -20,7 +20,7 @@
 __device__ long long pd_tbuf[16];
 __device__ int pd_tj0;
 #define PD_T(idx) do { if ( threadIdx.x == 0 && j0 == pd_tj0 && blockIdx.x == (gridDim.x > 1 ? 1u : 0u) ) pd_tbuf[idx] = wall_clock64(); } while (0)
-extern "C" int hipsdp_debug_pd_timing(int j0, long long* out)
+extern "C" __attribute__((visibility("default"))) int hipsdp_debug_pd_timing(int j0, long long* out)
 {
    if ( out != NULL && hipMemcpyFromSymbol(out, HIP_SYMBOL(pd_tbuf), sizeof(long long) * 16) != hipSuccess )
       return 1;
