@@ -253,6 +253,10 @@ HIPSDP_API int  hipsdp_dgemm_selfcheck(int device, int M, int N, int K, int layB
 /* the same with a free alpha and, for reps > 0 and beta = 0, the average milliseconds of one product through the tile kernel alone
  * (ms_tile) and through the default dispatch (ms_fast).  *used: bit 0 the persistent tile kernel took the product, bit 1 the strip
  * kernel of the two triangular Schur products (alpha = 1, beta = 0 only) */
+/* unit entry: out[e] = sum_i coef[i] A[i][e] + sa add[e] over R rows of E entries (the pass A^T); split = 1: as the engine calls it
+ * (row chunks side by side when the block has few entries; *chunks = how many, 0 = the plain kernel) */
+HIPSDP_API int  hipsdp_pass_at_unit(int device, int R, long long E, const double* A, const double* coef, double sa, const double* add, int split,
+   double* out, int* chunks);
 HIPSDP_API int  hipsdp_dgemm_selfcheck2(int device, int M, int N, int K, int layB, int batch, int splitk, int flags, double alpha, double beta,
    int reps, int* used, long long* ndiff, double* ms_tile, double* ms_fast);
 /* Schur block Mx[(m1) x (m1)] = tr(A_i X A_j Zinv) for i, j = 0..m1-1 */

@@ -503,8 +503,8 @@ extern "C" int hipsdp_lambda_min(int device, int n, const double* W, int steps, 
    return HIPSDP_OK;
 }
 
-/* lambda_min(L D L^T) as the step-length code computes it for small blocks (n <= 16: one-wavefront Jacobi; 16 < n <= 64:
- * single-launch Lanczos): theta and the residual bound, for the X-side and the Z-side slot at once (same operands) */
+/* lambda_min(L D L^T) as the step-length code computes it for small blocks: theta and the residual bound, for the X-side and the
+ * Z-side slot at once (same operands) */
 extern "C" int hipsdp_lambda_min_scaled(int device, int n, const double* L, const double* D, int steps, double* theta, double* resid)
 {
    HS_CALL( pick_device(device) );
@@ -513,13 +513,25 @@ extern "C" int hipsdp_lambda_min_scaled(int device, int n, const double* L, cons
    DevBuf dL, dD, dR;
    HS_CALL( dL.alloc(n2) ); HS_CALL( dD.alloc(n2) ); HS_CALL( dR.alloc(16) );
    HS_CALL( dL.up(L, n2) ); HS_CALL( dD.up(D, n2) );
-   if ( n <= 16 )
-      HS_CALL( hs_lmin_scaled_tiny(0, n, dL.p, dD.p, dL.p, dD.p, dR.p, dR.p + 8) );
-   else
-      HS_CALL( hs_lanczos_scaled_small(0, n, steps > 0 ? steps : 24, dL.p, dD.p, dL.p, dD.p, dR.p, dR.p + 8) );
+   /* through the launch the engine uses: all blocks of a size class at once (here: the same operands as two blocks, whose results
+    * must agree bit for bit); n <= 16 exact (k_lmin_tiny), 17 .. 48 exact by reduction + multisection (k_lmin_exact_multi), above
+    * Lanczos (k_lanczos_small) */
+   DevBuf dR2;
+   HS_CALL( dR2.alloc(16) );
+   hs_step_jobs J;
+   J.nblk = 2;
+   for (int j = 0; j < 2; ++j)
+   {
+      J.n[j] = n; J.L0[j] = dL.p; J.D0[j] = dD.p; J.L1[j] = dL.p; J.D1[j] = dD.p;
+      J.res0[j] = (j == 0 ? dR.p : dR2.p); J.res1[j] = (j == 0 ? dR.p : dR2.p) + 8;
+   }
+   HS_CALL( hs_steplen_small_multi(0, &J, steps > 0 ? steps : 24) );
    HS_HIP( hipDeviceSynchronize() );
-   double h[16];
+   double h[16], h2[16];
    HS_CALL( dR.down(h, 16) );
+   HS_CALL( dR2.down(h2, 16) );
+   if ( h[0] != h2[0] || h[8] != h2[8] || h[1] != h2[1] || h[9] != h2[9] )
+      return HIPSDP_ERR_NUMERIC;
    theta[0] = h[0]; theta[1] = h[8];
    if ( resid != NULL ) { resid[0] = h[1]; resid[1] = h[9]; }
    return HIPSDP_OK;
@@ -571,3 +583,31 @@ extern "C" int hipsdp_gemv_t(int device, int R, long long E, const double* A, co
    HS_CALL( dO.down(out, E) );
    return HIPSDP_OK;
 }
+
+/* out[e] = sum_i coef[i] A[i][e] + sa add[e] (the pass A^T of the engine): 0 = the plain kernel (one thread walks all rows of its
+ * entries), 1 = as the engine calls it for blocks with few entries (row chunks side by side + a second launch that adds them in
+ * order, when hs_gemv_t_chunks says so: *chunks returns how many).  Two calls with the same operands give the same bits. */
+extern "C" int hipsdp_pass_at_unit(int device, int R, long long E, const double* A, const double* coef, double sa, const double* add, int split,
+   double* out, int* chunks)
+{
+   HS_CALL( pick_device(device) );
+   if ( R <= 0 || E <= 0 || A == NULL || coef == NULL || out == NULL )
+      return HIPSDP_ERR_ARG;
+   DevBuf dA, dc, dadd, dout, dws;
+   const int C = hs_gemv_t_chunks(R, E);
+   if ( chunks != NULL )
+      *chunks = C;
+   HS_CALL( dA.alloc((long long) R * E) ); HS_CALL( dc.alloc(R) ); HS_CALL( dadd.alloc(E) ); HS_CALL( dout.alloc(E) );
+   HS_CALL( dws.alloc((long long) (C > 0 ? C : 1) * E) );
+   HS_CALL( dA.up(A, (long long) R * E) ); HS_CALL( dc.up(coef, R) );
+   if ( add != NULL )
+      HS_CALL( dadd.up(add, E) );
+   if ( split )
+      HS_CALL( hs_gemv_t_ws(0, R, E, dA.p, E, dc.p, sa, add != NULL ? dadd.p : NULL, dout.p, dws.p, (long long) (C > 0 ? C : 1) * E) );
+   else
+      HS_CALL( hs_gemv_t(0, R, E, dA.p, E, dc.p, sa, add != NULL ? dadd.p : NULL, dout.p) );
+   HS_HIP( hipDeviceSynchronize() );
+   HS_CALL( dout.down(out, E) );
+   return HIPSDP_OK;
+}
+
