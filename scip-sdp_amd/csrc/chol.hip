@@ -567,6 +567,16 @@ __global__ void __launch_bounds__(256) k_potrf_diag(double* __restrict__ A, long
    pd_body<NBK>(A, lda, nb, j0, dinv, flag, diag0, regtol, ext);
 }
 
+/* two single-block factorizations of the same size in one launch (blockIdx.x selects): the trial iterates X + alpha dX and
+ * Z + alpha dZ of a small block were two launches of one workgroup each, one behind the other on the same queue */
+struct pd_job { double* A; double* dinv; int* flag; pd_ext ext; };
+template<int NBK>
+__global__ void __launch_bounds__(256) k_potrf_diag_pair(pd_job J0, pd_job J1, long long lda, int nb)
+{
+   const pd_job J = blockIdx.x ? J1 : J0;
+   pd_body<NBK>(J.A, lda, nb, 0, J.dinv, J.flag, NULL, 1e-13, J.ext);
+}
+
 /* ---- one block column of the blocked factorization in ONE launch -------------------------------------------------------
  * Launch kb of hs_potrf_psd (n > 64).  Two kinds of workgroups that do not depend on each other:
  *  - step workgroups (one per 64-row block of block column kb, the first one owns the diagonal block): apply the rank-64 update
@@ -856,6 +866,39 @@ int hs_potrf_small_ext(hipStream_t s, int n, double* L, double* dinv, int* flag,
    if ( n <= 48 )
       return launch_potrf_diag<48>(s, L, n, n, 0, dinv, flag, NULL, &ext);       /* three panels of 16 instead of four (example_CLS: n = 43) */
    return launch_potrf_diag<64>(s, L, n, n, 0, dinv, flag, NULL, &ext);
+}
+
+template<int NBK>
+static int launch_potrf_diag_pair(hipStream_t s, int n, const pd_job& J0, const pd_job& J1)
+{
+   static hs_attr_mask attr_done;
+   HS_CALL( hs_func_max_lds(reinterpret_cast<const void*>(&k_potrf_diag_pair<NBK>), PD_SMEM_BYTES, &attr_done) );
+   hipLaunchKernelGGL((k_potrf_diag_pair<NBK>), dim3(2), dim3(256), PD_SMEM_BYTES, s, J0, J1, (long long) n, n);
+   HS_LAUNCH_CHECK();
+   return HS_OK;
+}
+
+/* hs_potrf_small_ext for two matrices of the same order side by side (index 0 / 1 of every array argument) */
+int hs_potrf_small_ext_pair(hipStream_t s, int n, double* const* L, double* const* dinv, int* const* flag, const double* const* base,
+   const double* const* dir, double alpha, double* const* Mout, double* const* Linv, double* const* Gram, int set_flag)
+{
+   if ( n <= 0 )
+      return HS_OK;
+   if ( n > NB || base[0] == NULL || base[1] == NULL || ((Gram[0] != NULL || Gram[1] != NULL) && n > 32) )
+      return HS_ERR_ARG;
+   pd_job J[2];
+   for (int k = 0; k < 2; ++k)
+   {
+      const pd_ext ext = {base[k], dir[k], alpha, Mout[k], Linv[k], Gram[k], set_flag, 2, NULL};
+      J[k].A = L[k]; J[k].dinv = dinv[k]; J[k].flag = flag[k]; J[k].ext = ext;
+   }
+   if ( n <= 16 )
+      return launch_potrf_diag_pair<16>(s, n, J[0], J[1]);
+   if ( n <= 32 )
+      return launch_potrf_diag_pair<32>(s, n, J[0], J[1]);
+   if ( n <= 48 )
+      return launch_potrf_diag_pair<48>(s, n, J[0], J[1]);
+   return launch_potrf_diag_pair<64>(s, n, J[0], J[1]);
 }
 
 /* the columns of the panel that belong to forced pivots of the diagonal block are zero in exact arithmetic */

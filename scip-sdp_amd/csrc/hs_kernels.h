@@ -163,6 +163,9 @@ int hs_trtri(hipStream_t s, int n, const double* L, const double* dinv, double* 
  * 2: backward only, 3: both */
 /* n <= 64: Cholesky of base + alpha * dir in one launch; optionally stores the matrix (Mout), inv(L) as n x n (Linv) and,
  * for n <= 32, the inverse of the matrix (Gram); L gets a zero upper triangle */
+/* the same for two matrices of the same order in one launch (arrays of two) */
+int hs_potrf_small_ext_pair(hipStream_t s, int n, double* const* L, double* const* dinv, int* const* flag, const double* const* base,
+   const double* const* dir, double alpha, double* const* Mout, double* const* Linv, double* const* Gram, int set_flag);
 int hs_potrf_small_ext(hipStream_t s, int n, double* L, double* dinv, int* flag, const double* base, const double* dir, double alpha,
    double* Mout, double* Linv, double* Gram, int set_flag);
 /* all blocks n <= 32: the extended Schur matrix (SDP blocks + LP part, symmetric), Lm = Mx[1:, 1:] and its diagonal in one

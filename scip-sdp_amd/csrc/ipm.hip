@@ -3039,8 +3039,18 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
             for (auto& B : s->blk)
             {
                const int n = B.n;
-               HS_CALL( hs_potrf_small_ext(st, n, B.Lx, B.dinvx, s->flags + 1, B.X, B.dX, alpha, B.Xs, B.LxInv, NULL, setf) );
-               HS_CALL( hs_potrf_small_ext(st, n, B.Lz, B.dinvz, s->flags + 0, B.Z, B.dZ, alpha, B.Zs, B.LzInv, n <= 32 ? B.Zinv : NULL, setf) );
+               {
+                  /* the Cholesky checks of the trial X and Z: one launch of two workgroups */
+                  double* L2[2] = {B.Lx, B.Lz};
+                  double* di2[2] = {B.dinvx, B.dinvz};
+                  int* fl2[2] = {s->flags + 1, s->flags + 0};
+                  const double* ba2[2] = {B.X, B.Z};
+                  const double* dr2[2] = {B.dX, B.dZ};
+                  double* mo2[2] = {B.Xs, B.Zs};
+                  double* li2[2] = {B.LxInv, B.LzInv};
+                  double* gr2[2] = {NULL, n <= 32 ? B.Zinv : NULL};
+                  HS_CALL( hs_potrf_small_ext_pair(st, n, L2, di2, fl2, ba2, dr2, alpha, mo2, li2, gr2, setf) );
+               }
                std::swap(B.X, B.Xs);
                std::swap(B.Z, B.Zs);
             }
