@@ -1534,6 +1534,29 @@ static int publish_and_wait(hipsdp_solver* s, int off, int n)
    volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(s->hsc + s->hsc_cap - 1);
    HS_CALL( hs_red_batch_end_publish(s->stream, n, s->sc + off, s->hsc_dev + off, seq,
          reinterpret_cast<unsigned long long*>(s->hsc_dev + s->hsc_cap - 1)) );
+   /* developer switch HIPSDP_WAIT_TIMES=1: how long the host waits here in total (at process end): the share of a solve in which the
+    * device is the one being waited for */
+   static int wt = -1;
+   if ( wt < 0 )
+      wt = (getenv("HIPSDP_WAIT_TIMES") != NULL && getenv("HIPSDP_WAIT_TIMES")[0] == '1') ? 1 : 0;
+   const std::chrono::steady_clock::time_point w0 = wt ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+   struct WaitNote
+   {
+      bool on; std::chrono::steady_clock::time_point t0;
+      ~WaitNote()
+      {
+         if ( !on ) return;
+         static double total = 0.0; static long long count = 0; static bool hooked = false;
+         static double* ptot = &total; static long long* pcnt = &count;
+         total += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+         ++count;
+         if ( !hooked )
+         {
+            hooked = true;
+            atexit([]() { fprintf(stderr, "hipsdp: %lld read-backs, the host waited %.3f s in them (%.2f us each)\n", *pcnt, *ptot, 1e6 * *ptot / (double) (*pcnt > 0 ? *pcnt : 1)); });
+         }
+      }
+   } note = {wt != 0, w0};
    long long spins = 0;
    while ( *flag != seq )
    {
