@@ -17,6 +17,20 @@ static_assert(((HS_SMALL_N + DB_PR - 1) / DB_PR) * ((HS_SMALL_N + DB_PC - 1) / D
 template<bool TB = false, class F>
 __device__ __forceinline__ void db_product(int n, int ld, const double* __restrict__ a, const double* __restrict__ b, F&& fin)
 {
+   if ( n * n <= 256 )
+   {
+      /* at most one entry per thread (n <= 16): the patches would leave most of the workgroup idle (n = 10: ten threads) */
+      const int e = (int) threadIdx.x;
+      if ( e < n * n )
+      {
+         const int r = e / n, cc = e - r * n;
+         double acc = 0.0;
+         for (int k = 0; k < n; ++k)
+            acc = fma(a[r * ld + k], TB ? b[cc * ld + k] : b[k * ld + cc], acc);
+         fin(0, 0, r, cc, acc);
+      }
+      return;
+   }
    const int tc = (n + DB_PC - 1) / DB_PC;
    const int pr = (int) threadIdx.x / tc, pc = (int) threadIdx.x - pr * tc;
    const int r0 = DB_PR * pr, c0 = DB_PC * pc;
