@@ -730,12 +730,82 @@ __device__ __forceinline__ double d_tree64(double (&p)[64])
    return p[0];
 }
 
+/* rb_run by ONE wavefront: lane l keeps the partial results of the threads l, 64 + l, 128 + l, 192 + l of the workgroup form, reduces
+ * each as that thread's wavefront would and combines the four in the order thread 0 does - the same bits, no barrier, so up to four
+ * reductions that do not depend on each other run side by side (each one is a round trip to memory: 1.06 us) */
+template<int KIND>
+__device__ __forceinline__ void rb_run_wave(const rb_desc& D)
+{
+   typedef typename RedTraits<KIND>::OP OP;
+   const double* a = (const double*) D.p[0];
+   const double* b = (const double*) D.p[1];
+   const double* c = (const double*) D.p[2];
+   double* out = (double*) D.p[3];
+   const int lane = threadIdx.x & 63;
+   double v[4];
+#pragma unroll
+   for (int g = 0; g < 4; ++g)
+   {
+      double x = OP::id();
+      for (long long i = 64 * g + lane; i < D.i[0]; i += 256)
+         x = OP::f(x, red_elem<KIND>(i, a, b, c));
+      v[g] = x;
+   }
+#pragma unroll
+   for (int g = 0; g < 4; ++g)
+      v[g] = wave_reduce<OP>(v[g]);
+   if ( lane == 0 )
+   {
+      double r = v[0];
+      r = OP::f(r, v[1]); r = OP::f(r, v[2]); r = OP::f(r, v[3]);
+      *out = D.accumulate ? OP::f(*out, r) : r;
+   }
+}
+
 __global__ void __launch_bounds__(256) k_red_batch(rb_args A)
 {
    extern __shared__ double rb_dyn[];
    __shared__ double sh[4];
    for (int t = 0; t < A.cnt; ++t)
    {
+      {
+         /* a run of reductions with distinct results: up to four at a time, one per wavefront */
+         int g = 0;
+         while ( g < 4 && t + g < A.cnt && A.d[t + g].kind <= RED_LPS0 )
+         {
+            bool fresh = true;
+            for (int h = 0; h < g; ++h)
+               fresh = fresh && A.d[t + h].p[3] != A.d[t + g].p[3];
+            if ( !fresh )
+               break;
+            ++g;
+         }
+         if ( g > 1 )
+         {
+            const unsigned long long tg_begin = (A.dbg != NULL) ? wall_clock64() : 0ULL;
+            const int w = threadIdx.x >> 6;
+            if ( w < g )
+            {
+               const rb_desc& G = A.d[t + w];
+               switch ( G.kind )
+               {
+               case RED_DOT:      rb_run_wave<RED_DOT>(G); break;
+               case RED_ABSMAX:   rb_run_wave<RED_ABSMAX>(G); break;
+               case RED_RATIOMIN: rb_run_wave<RED_RATIOMIN>(G); break;
+               default:           rb_run_wave<RED_LPS0>(G); break;
+               }
+            }
+            __threadfence_block();
+            __syncthreads();
+            if ( A.dbg != NULL && threadIdx.x == 0 )
+            {
+               atomicAdd(A.dbg + 2 * 8, wall_clock64() - tg_begin);            /* slot 8: groups of reductions */
+               atomicAdd(A.dbg + 2 * 8 + 1, 1ULL);
+            }
+            t += g - 1;
+            continue;
+         }
+      }
       const rb_desc& D = A.d[t];
       const unsigned long long t_begin = (A.dbg != NULL) ? wall_clock64() : 0ULL;
       const unsigned long long c_begin = (A.dbg != NULL) ? clock64() : 0ULL;
