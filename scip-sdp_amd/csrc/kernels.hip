@@ -771,7 +771,9 @@ __global__ void __launch_bounds__(256) k_red_batch(rb_args A)
       {
          /* a run of reductions with distinct results: up to four at a time, one per wavefront */
          int g = 0;
-         while ( g < 4 && t + g < A.cnt && A.d[t + g].kind <= RED_LPS0 )
+         /* (short vectors only: a wavefront alone takes four times as long over a long one as the workgroup does - 45 instead of 19 us
+          * per batch at n = 128, where the dots run over 16 384 entries) */
+         while ( g < 4 && t + g < A.cnt && A.d[t + g].kind <= RED_LPS0 && A.d[t + g].i[0] <= 1024 )
          {
             bool fresh = true;
             for (int h = 0; h < g; ++h)
