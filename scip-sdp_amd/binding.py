@@ -192,6 +192,16 @@ class Solver:
         _chk(lib().hipsdp_solve(self.h, C.byref(p), C.byref(info)), "hipsdp_solve")
         return info
 
+    def solve_path(self):
+        """1: the last solve ran in the one-launch kernel of csrc/solve1.hip, 0: the general path"""
+        return lib().hipsdp_solve_path(self.h)
+
+    def solve1_trace(self, rows=0):
+        out = np.zeros(64)
+        hist = np.zeros((max(rows, 1), 12))
+        _chk(lib().hipsdp_solve1_trace(self.h, _dp(out), rows, _dp(hist) if rows else None), "hipsdp_solve1_trace")
+        return out, hist[:rows]
+
     def y(self):
         out = np.zeros(self.m)
         _chk(lib().hipsdp_get_y(self.h, _dp(out)), "hipsdp_get_y")

@@ -220,4 +220,40 @@ int hs_syev_small_dev(hipStream_t st, int n, const double* A, double* lam, doubl
 int hs_syev_jacobi(hipStream_t s, int n, double* A, double* lam, double* V, int* info, double* ws);
 long long hs_syev_ws(int n);
 
+/* ---- solve1.hip: a whole node solve of a B&B-sized problem in one launch of one workgroup ------------------------------- */
+#define HS_S1_MAXBLK 8
+/* termination status written to out[0]: the HIPSDP_STATUS_* values of include/hipsdp.h, or -2: declined (too much work for one
+ * compute unit, or the workspace is too small) - nothing was solved, the caller takes the general path */
+#define HS_S1_OPTIMAL 0
+#define HS_S1_DINF 1
+#define HS_S1_DUNB 2
+#define HS_S1_PDINF 3
+#define HS_S1_ITERLIM 4
+#define HS_S1_NUMERIC 5
+#define HS_S1_TIMELIM 6
+#define HS_S1_OBJLIM 7
+#define HS_S1_OUT_DOUBLES 64
+struct hs_solve1_args
+{
+   int m, q, nblk;
+   int n[HS_S1_MAXBLK];
+   const double* A[HS_S1_MAXBLK];          /* dense (m + 1) x n^2 rows */
+   double* X[HS_S1_MAXBLK];                /* n x n: start point in (have_start), final iterate out (unscaled) */
+   double* Z[HS_S1_MAXBLK];
+   double* Xpre[HS_S1_MAXBLK];             /* preoptimal iterate (preoptgap > 0) */
+   const double* b; const double* Dext;
+   double *y, *x, *z, *pre_y, *pre_x;
+   double gaptol, feastol, infeastol, objlimit, timelimit, gamma, pabstol, preoptgap;
+   double elapsed0;                        /* seconds of the time limit already used when the kernel starts */
+   double maxwork;                         /* decline above this many multiply-adds per Schur assembly */
+   int maxiter, settings, have_start, pivot_rule, prof_on, hist_len;
+   double* gws; long long gws_len;         /* workspace in device memory (hs_solve1_ws_doubles) */
+   double* out;                            /* HS_S1_OUT_DOUBLES result scalars (device-visible; pinned host memory works) */
+   double* hist;                           /* optional: 12 doubles per iteration (tests, tools) */
+   unsigned long long seq; unsigned long long* flag;   /* when flag != NULL: *flag = seq once out[] is complete */
+};
+int hs_solve1_fits(int m, int q, int nblk, const int* n);
+long long hs_solve1_ws_doubles(int m, int q, int nblk, const int* n);
+int hs_solve1_launch(hipStream_t st, const hs_solve1_args* a);
+
 #endif

@@ -169,6 +169,13 @@ struct hipsdp_solver
    int a_r0, a_r1;         /* rows of A (0 = constant matrix, i = variable i) this rank holds; [0, m + 1) when replicated */
    hipsdp_params par;
    PhaseClock pc;
+   /* one-launch solve of B&B-sized problems (csrc/solve1.hip) */
+   double* s1_ws;          /* device workspace (cold matrices and nonzero lists that do not fit into LDS) */
+   long long s1_ws_len;
+   double* s1_host;        /* pinned, device-visible: HS_S1_OUT_DOUBLES result scalars, then the sequence word, then the history */
+   double* s1_host_dev;
+   unsigned long long s1_seq;
+   int s1_last;            /* 1: the last solve ran in the single launch */
    /* pinned / device staging chunks of hipsdp_master_add_vars (kept until hipsdp_free) */
    void* stage_h[2]; void* stage_d[2]; hipEvent_t stage_ev[2]; long long stage_cap;
 };
@@ -373,6 +380,7 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
       s->use_publish = !(rb != NULL && rb[0] == 'c');
    }
    s->hsc_cap = 0;
+   s->s1_ws = NULL; s->s1_ws_len = 0; s->s1_host = NULL; s->s1_host_dev = NULL; s->s1_seq = 0; s->s1_last = 0;
    s->trsv_ws = NULL;
    s->pre_y = s->pre_x = NULL;
    s->pre_valid = false;
@@ -432,6 +440,10 @@ extern "C" void hipsdp_free(hipsdp_solver** ps)
    master_free(s);
    if ( s->hsc != NULL ) (void) hipHostFree(s->hsc);
    s->hsc = NULL;
+   if ( s->s1_host != NULL ) (void) hipHostFree(s->s1_host);
+   s->s1_host = NULL;
+   if ( s->s1_ws != NULL ) (void) hipFree(s->s1_ws);
+   s->s1_ws = NULL;
    for (auto& mk : s->pc.marks) (void) hipEventDestroy(mk.second);
    for (hipEvent_t e : s->pc.pool) (void) hipEventDestroy(e);
    for (int b = 0; b < 2; ++b)
@@ -1807,7 +1819,8 @@ static bool small_problem(const hipsdp_solver* s)
    long long tot = 0;
    for (auto& B : s->blk)
    {
-      if ( B.Apk != NULL )
+      /* a block kept as nonzeros (csrc/sparse.hip) has no dense rows A_i: the fused small-problem kernels read A + i n^2 */
+      if ( B.Apk != NULL || B.sparse || B.A == NULL )
          return false;
       tot += (long long) B.n * B.n;
    }
@@ -1842,6 +1855,9 @@ static int apply_A_small(hipsdp_solver* s, double* const* Vk, const double* vlp,
 {
    if ( !small_problem(s) )
       return 0;
+   for (auto& Bk : s->blk)
+      if ( Bk.A == NULL )
+         return 0;
    hs_as_args B;
    B.nblk = (int) s->blk.size();
    for (int k = 0; k < AS_MAXBLK; ++k)
@@ -2227,6 +2243,172 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
    return rc;
 }
 
+/* ---- B&B-sized problems: the whole solve in one launch of one workgroup (csrc/solve1.hip).  Returns HS_OK and *done = true when the
+ * solve ran there; *done = false: not this path's problem (shape, options) or the kernel declined (too much work for one compute
+ * unit) - nothing has been touched and the general path below takes over.  HIPSDP_SOLVE1=0 switches the path off. */
+#define S1_HIST_MAX 256
+static int solve1_try(hipsdp_solver* s, hipsdp_info* info, bool* done)
+{
+   *done = false;
+   s->s1_last = 0;
+   static int on = -1;
+   static double maxwork = 3e6;
+   static int prof = 0;
+   if ( on < 0 )
+   {
+      const char* env = getenv("HIPSDP_SOLVE1");
+      on = (env != NULL && env[0] == '0') ? 0 : 1;
+      if ( getenv("HIPSDP_SOLVE1_MAXWORK") != NULL )
+         maxwork = atof(getenv("HIPSDP_SOLVE1_MAXWORK"));
+      prof = (getenv("HIPSDP_SOLVE1_PROF") != NULL && getenv("HIPSDP_SOLVE1_PROF")[0] == '1') ? 1 : 0;
+   }
+   const hipsdp_params& par = s->par;
+   if ( !on || s->comm != NULL || s->shardA || s->schur_mode_forced || par.verbose || s->pc.on )
+      return HS_OK;
+   if ( getenv("HIPSDP_REFINE_SOLVES") != NULL && getenv("HIPSDP_REFINE_SOLVES")[0] == '0' )
+      return HS_OK;
+   const int K = (int) s->blk.size();
+   int ns[HS_S1_MAXBLK];
+   if ( K < 1 || K > HS_S1_MAXBLK )
+      return HS_OK;
+   for (int k = 0; k < K; ++k)
+   {
+      if ( s->blk[k].sparse || s->blk[k].A == NULL )
+         return HS_OK;
+      ns[k] = s->blk[k].n;
+   }
+   if ( !hs_solve1_fits(s->m, s->q, K, ns) )
+      return HS_OK;
+   hipStream_t st = s->stream;
+   const long long want = hs_solve1_ws_doubles(s->m, s->q, K, ns);
+   if ( s->s1_ws_len < want )
+   {
+      if ( s->s1_ws != NULL )
+      {
+         HS_HIP( hipStreamSynchronize(st) );
+         (void) hipFree(s->s1_ws);
+         s->s1_ws = NULL; s->s1_ws_len = 0;
+      }
+      const long long len = want + want / 2 + 4096;
+      HS_HIP( hipMalloc((void**) &s->s1_ws, (size_t) len * sizeof(double)) );
+      s->s1_ws_len = len;
+   }
+   if ( s->s1_host == NULL )
+   {
+      HS_HIP( hipHostMalloc((void**) &s->s1_host, (size_t) (HS_S1_OUT_DOUBLES + 8 + 12 * S1_HIST_MAX) * sizeof(double),
+            hipHostMallocMapped | hipHostMallocCoherent) );
+      HS_HIP( hipHostGetDevicePointer((void**) &s->s1_host_dev, s->s1_host, 0) );
+      memset(s->s1_host, 0, (size_t) (HS_S1_OUT_DOUBLES + 8) * sizeof(double));
+   }
+   if ( par.preoptgap > 0.0 )
+   {
+      if ( s->pre_y == NULL )
+      {
+         HS_CALL( dalloc(&s->pre_y, s->m) );
+         HS_CALL( dalloc(&s->pre_x, s->q) );
+      }
+      for (auto& B : s->blk)
+         if ( B.Xpre == NULL )
+            HS_CALL( dalloc(&B.Xpre, (long long) B.n * B.n) );
+   }
+   const auto t_begin = std::chrono::steady_clock::now();
+   hs_solve1_args a;
+   memset(&a, 0, sizeof(a));
+   a.m = s->m; a.q = s->q; a.nblk = K;
+   for (int k = 0; k < K; ++k)
+   {
+      Block& B = s->blk[k];
+      a.n[k] = B.n; a.A[k] = B.A; a.X[k] = B.X; a.Z[k] = B.Z; a.Xpre[k] = B.Xpre;
+   }
+   a.b = s->b; a.Dext = s->Dext; a.y = s->y; a.x = s->x; a.z = s->z; a.pre_y = s->pre_y; a.pre_x = s->pre_x;
+   a.gaptol = par.gaptol; a.feastol = par.feastol; a.infeastol = par.infeastol; a.objlimit = par.objlimit; a.timelimit = par.timelimit;
+   a.gamma = par.gamma; a.pabstol = par.pabstol; a.preoptgap = par.preoptgap; a.elapsed0 = 0.0; a.maxwork = maxwork;
+   a.maxiter = par.maxiter; a.settings = par.settings; a.have_start = s->have_start ? 1 : 0;
+   {
+      const char* env = getenv("HIPSDP_PIVOT_RULE");
+      a.pivot_rule = env != NULL ? atoi(env) : 3;
+   }
+   a.prof_on = prof;
+   a.gws = s->s1_ws; a.gws_len = s->s1_ws_len;
+   a.out = s->s1_host_dev;
+   a.hist = getenv("HIPSDP_SOLVE1_HIST") != NULL ? s->s1_host_dev + HS_S1_OUT_DOUBLES + 8 : NULL;
+   a.hist_len = S1_HIST_MAX;
+   a.seq = ++s->s1_seq;
+   a.flag = reinterpret_cast<unsigned long long*>(s->s1_host_dev + HS_S1_OUT_DOUBLES);
+   HS_CALL( hs_solve1_launch(st, &a) );
+   {
+      volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(s->s1_host + HS_S1_OUT_DOUBLES);
+      long long spins = 0;
+      while ( *flag != a.seq )
+      {
+         if ( (++spins & 0x3FFF) == 0 )
+         {
+            const hipError_t e = hipStreamQuery(st);
+            if ( e == hipSuccess )
+            {
+               if ( *flag == a.seq )
+                  break;
+               set_err("the one-launch solve finished without publishing its results");
+               return HS_ERR_HIP;
+            }
+            if ( e != hipErrorNotReady )
+            {
+               hs_record_hip_error(e, "hipStreamQuery(one-launch solve)", __FILE__, __LINE__);
+               return HS_ERR_HIP;
+            }
+         }
+      }
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+   }
+   const double* o = s->s1_host;
+   const int status = (int) o[0];
+   if ( status == -2 )
+      return HS_OK;                              /* declined: the general path takes the problem */
+   /* the iterate is complete in device memory when the kernel has retired (the read-backs use the copy engine) */
+   HS_HIP( hipStreamSynchronize(st) );
+   memset(info, 0, sizeof(*info));
+   s->tau = o[9];
+   s->kappa = o[10];
+   const double pobj = o[2], dobj = o[3];
+   if ( status == HIPSDP_STATUS_DINF || status == HIPSDP_STATUS_DUNB || status == HIPSDP_STATUS_PDINF )
+      s->sol_scale = 1.0 / fmax(fmax(fabs(dobj), fabs(pobj)), 1e-300);
+   else
+      s->sol_scale = 1.0 / s->tau;
+   s->last_status = status;
+   s->solved = true;
+   s->have_start = false;
+   s->pre_valid = o[13] != 0.0;
+   s->pre_scale = o[14];
+   for (auto& B : s->blk)
+      B.derived_valid = false;
+   info->status = status;
+   info->iterations = (int) o[1];
+   info->pobj = pobj * s->sol_scale;
+   info->dobj = dobj * s->sol_scale;
+   info->pinf = o[4]; info->dinf = o[5]; info->dabs = o[6]; info->gap = o[7]; info->mu = o[8];
+   info->tau = s->tau; info->kappa = s->kappa;
+   info->chol_fail = (int) o[11];
+   info->warm_started = (int) o[12];
+   info->settings_used = par.settings;
+   info->schur_calls = info->iterations;
+   for (auto& B : s->blk)
+      info->schur_flops += (double) info->iterations * (4.0 * (s->m + 1) * (double) B.n * B.n * B.n + (double) (s->m + 1) * (s->m + 1) * (double) B.n * B.n);
+   info->solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+   if ( prof )
+   {
+      static const char* const names[12] = {"lists", "start", "residuals", "inverse factors + LP part", "Zinv", "Schur", "chol M + X Rd",
+         "predictor rhs", "predictor step", "corrector rhs", "corrector step", "update"};
+      fprintf(stderr, "hipsdp one-launch solve: %d iterations, %.1f us on the device (%.0f cycles)", info->iterations,
+         o[43] / 100.0, o[17]);
+      for (int i = 0; i < 12; ++i)
+         fprintf(stderr, "%s %s %.0f", i ? "," : ":", names[i], o[18 + i]);
+      fprintf(stderr, " | nnz A %d, LP %d\n", (int) o[40], (int) o[41]);
+   }
+   s->s1_last = 1;
+   *done = true;
+   return HS_OK;
+}
+
 static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info* info)
 {
    g_err[0] = 0;
@@ -2293,6 +2475,12 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
    info->status = HIPSDP_STATUS_UNSOLVED;
    hs_red_batch_reset();
    s->pre_valid = false;
+   {
+      bool done1 = false;
+      HS_CALL( solve1_try(s, info, &done1) );
+      if ( done1 )
+         return HIPSDP_OK;
+   }
    HS_CALL( ensure_schur_ws(s) );
    HS_CALL( ensure_packed(s) );
    {
@@ -3225,6 +3413,22 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
    info->settings_used = settings;
    info->schur_seconds = schur_ms * 1e-3;
    info->solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+   return HIPSDP_OK;
+}
+
+extern "C" int hipsdp_solve_path(hipsdp_solver* s)
+{
+   return (s != NULL && s->solved) ? s->s1_last : 0;
+}
+
+extern "C" int hipsdp_solve1_trace(hipsdp_solver* s, double* out64, int maxrows, double* hist)
+{
+   if ( s == NULL || s->s1_host == NULL )
+      return HIPSDP_ERR_ARG;
+   if ( out64 != NULL )
+      memcpy(out64, s->s1_host, HS_S1_OUT_DOUBLES * sizeof(double));
+   if ( hist != NULL && maxrows > 0 )
+      memcpy(hist, s->s1_host + HS_S1_OUT_DOUBLES + 8, (size_t) (maxrows < S1_HIST_MAX ? maxrows : S1_HIST_MAX) * 12 * sizeof(double));
    return HIPSDP_OK;
 }
 

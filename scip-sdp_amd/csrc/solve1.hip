@@ -1,0 +1,2281 @@
+/* solve1.hip - a whole node solve in ONE launch of ONE workgroup (B&B-sized problems).
+ *
+ * What it replaces: the third-party solve call of the reference's backends - DSDPSetup / DSDPSolve / DSDPComputeX at
+ * src/sdpi/sdpisolver_dsdp.c:1489-1520, SDPA::initializeSolve / solve at src/sdpi/sdpisolver_sdpa.cpp:1600-1670 - for the problem
+ * sizes every instance the reference ships has (example_TT: one 10 x 10 block, 37 variables, 85 LP rows; example_CLS: 43 x 43, 33
+ * variables).  There the reference solves a node in-process with no device hop; the general path of csrc/ipm.hip needs about
+ * twenty dependent launches and three host read-backs per interior-point iteration, i.e. the solve is bound by launch-to-launch
+ * and read-back latency, not by arithmetic.  Here the state of the whole homogeneous self-dual iteration lives in the 160 KiB of
+ * LDS of one compute unit: one launch, termination / stall / certificate decisions on the device, one read-back per solve.
+ *
+ * Algorithm: exactly the iteration of csrc/ipm.hip / oracle/ipm_ref.py (HSD embedding, HKM direction, Mehrotra
+ * predictor-corrector, factored elimination of dtau, semidefinite pivot rule for M, corrected triangular solves, exact
+ * smallest eigenvalues for the step lengths); the summation orders differ, the results agree to rounding.
+ *
+ * Layout of a solve (512 threads = 8 wavefronts on one CU: 256 registers per thread, nothing spills):
+ *   - the constraint matrices are scanned once into two nonzero lists (by variable: p >= q entries of A_i; by position: which
+ *     variables touch entry (r, c)) and the LP rows into row lists and column lists - every instance of the reference has 1-10
+ *     nonzeros per matrix and mostly bound rows; a kernel that finds too much work for one CU declines (status -2) and the
+ *     caller takes the general path;
+ *   - "hot" n x n matrices (X, Z^-1, the two inverse Cholesky factors, dX, dZ, two temporaries) and everything of size m, q,
+ *     m x m always sit in LDS; "cold" ones (Z, Rd, E, B) and the lists go to LDS while it lasts, else to an L2-resident
+ *     workspace (flat addressing: the same code serves both);
+ *   - n x n x n products: 16 x 16 tiles of v_mfma_f64_16x16x4_f64, one wavefront per tile, operands straight from LDS;
+ *   - dependent recurrences (Cholesky, triangular inverse, Householder tridiagonalisation + Sturm multisection, the solves with
+ *     the factor of M) run inside ONE wavefront each, without workgroup barriers, several of them side by side on different
+ *     wavefronts (X side / Z side / blocks; the factorization of M beside the first product of the predictor);
+ *   - Schur complement from the nonzeros: U_j = X A_j Z^-1 as a sum of rank-one terms per nonzero of A_j (several j side by side
+ *     in the scratch region), M_ij = <A_i, U_j> over the nonzeros of A_i.
+ */
+#include "hs_kernels.h"
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <cstdio>
+
+#define S1_NT 512
+#define S1_NW 8
+#define S1_MAXB HS_S1_MAXBLK
+#define S1_MAXM 64
+#define S1_MAXN 64
+#define S1_STATIC_LDS 5632                                  /* bytes kept for the static arrays below */
+#define S1_DYN_LDS (160 * 1024 - S1_STATIC_LDS)
+#define S1_NRED 24
+#define S1_LIGHT_MAX 8                                        /* a matrix with at most this many entries (row >= col) is "light" */
+/* every lambda of the kernel is inlined: a lambda that stays a function keeps what it captures by reference in scratch memory */
+#define S1_INL __attribute__((always_inline))
+#define S1_WSYNC() do { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); } while (0)
+
+/* vectors of length m + 1 and of length q in LDS */
+enum { V_b = 0, V_y, V_rp, V_AX, V_AH, V_g, V_w, V_ub, V_u2, V_u1, V_h, V_dy, V_wt, V_cv, V_dg, V_t1, V_t2, V_t3, V_t4, V_COUNT };
+enum { Q_x = 0, Q_z, Q_rd, Q_beta, Q_hl, Q_dx, Q_dz, Q_elp, Q_sx, Q_COUNT };
+/* partial sums of a phase, one row per wavefront */
+enum { RS_XZ = 0, RS_RD2LP, RS_RDMAX, RS_S0, RS_BH, RS_HD2, RS_RATX, RS_RATZ, RS_NC2, RS_WORK, RS_BLK0, RS_END = RS_BLK0 + S1_MAXB };
+static_assert(RS_END <= S1_NRED, "reduction slots");
+/* scalars in LDS */
+enum { SC_TAU = 0, SC_KAPPA, SC_RP2, SC_HP2, SC_DOBJ, SC_BUB, SC_BU1, SC_WRP, SC_DTAU, SC_DKAPPA, SC_NORMB, SC_NORMC, SC_FAIL, SC_XI,
+       SC_LMIN0, SC_COUNT = SC_LMIN0 + 2 * S1_MAXB };
+
+struct S1Lay
+{
+   int m, m1, q, K;
+   int pm1, pm, VL, QL;
+   int oMx, oLm, oVec, oQ, oR, Rlen, fixedEnd;
+   int n[S1_MAXB], p[S1_MAXB], np[S1_MAXB];
+   int oX[S1_MAXB], oZi[S1_MAXB], oLx[S1_MAXB], oLz[S1_MAXB], odX[S1_MAXB], odZ[S1_MAXB], oT1[S1_MAXB], oT2[S1_MAXB], oEig[S1_MAXB];
+};
+
+/* the part of LDS whose place follows from the shape alone (doubles); returns its length */
+static __host__ __device__ inline int s1_layout(int m, int q, int K, const int* n, S1Lay& L)
+{
+   L.m = m; L.m1 = m + 1; L.q = q; L.K = K;
+   L.pm1 = (m + 1) | 1; L.pm = ((m + 7) & ~7) | 1;          /* Lm: panels of eight columns are read whole */
+   L.VL = (m + 2) & ~1; L.QL = (q + 1) & ~1;
+   int o = 0, sum = 0;
+   for (int k = 0; k < K; ++k)
+   {
+      L.n[k] = n[k]; L.p[k] = n[k] | 1; L.np[k] = n[k] * L.p[k];
+      sum += L.np[k];
+   }
+   for (int k = 0; k < K; ++k) { L.oX[k] = o; o += L.np[k]; }
+   for (int k = 0; k < K; ++k) { L.oZi[k] = o; o += L.np[k]; }
+   for (int k = 0; k < K; ++k) { L.oLx[k] = o; o += L.np[k]; }
+   for (int k = 0; k < K; ++k) { L.oLz[k] = o; o += L.np[k]; }
+   for (int k = 0; k < K; ++k) { L.oEig[k] = o; o += 8 * ((n[k] + 1) & ~1); }
+   L.oMx = o; o += (L.m1 * L.pm1 + 1) & ~1;
+   L.oLm = o; o += (m * L.pm + 1) & ~1;
+   L.oVec = o; o += V_COUNT * L.VL;
+   L.oQ = o; o += Q_COUNT * L.QL;
+   /* scratch region (dX, dZ, T1, T2 of all blocks, contiguous; the Schur phase uses it as a pool of U_j buffers) last, so that
+    * spare LDS can extend it */
+   o = (o + 1) & ~1;
+   L.oR = o;
+   for (int k = 0; k < K; ++k) { L.odX[k] = o; o += L.np[k]; }
+   for (int k = 0; k < K; ++k) { L.odZ[k] = o; o += L.np[k]; }
+   for (int k = 0; k < K; ++k) { L.oT1[k] = o; o += L.np[k]; }
+   for (int k = 0; k < K; ++k) { L.oT2[k] = o; o += L.np[k]; }
+   L.Rlen = 4 * sum;
+   L.fixedEnd = o;
+   return o;
+}
+
+int hs_solve1_fits(int m, int q, int nblk, const int* n)
+{
+   if ( m < 1 || m > S1_MAXM || nblk < 1 || nblk > S1_MAXB || q < 0 || q > 4096 )
+      return 0;
+   for (int k = 0; k < nblk; ++k)
+      if ( n[k] < 1 || n[k] > S1_MAXN )
+         return 0;
+   S1Lay L;
+   const int len = s1_layout(m, q, nblk, n, L);
+   return (long long) len * 8 <= S1_DYN_LDS ? 1 : 0;
+}
+
+/* worst case of everything that may have to live outside LDS: cold matrices, offset arrays, full lists */
+long long hs_solve1_ws_doubles(int m, int q, int nblk, const int* n)
+{
+   const long long m1 = m + 1;
+   long long t = 64;
+   for (int k = 0; k < nblk; ++k)
+   {
+      const long long nn = n[k], np = nn * (nn | 1), n2 = nn * nn, nlow = nn * (nn + 1) / 2;
+      t += 4 * np + 8;
+      t += (m1 + 2) / 2 + 1 + (n2 + 2) / 2 + 1;                      /* voff, poff (ints) */
+      t += 2 * (m1 * nlow + 2) + (m1 * nlow + 2) / 2 + (m1 * nlow + 4) / 4 + 8;      /* vval, pval, vpq (u32), pvar (u16) */
+      t += 2 * ((m1 + 3) / 4 + 2);                                  /* lv, hv */
+   }
+   t += (q + 2) / 2 + 1 + (m1 + 2) / 2 + 1;
+   t += 2 * ((long long) q * m1 + 2) + 2 * (((long long) q * m1 + 4) / 4) + 8;
+   return t + 64;
+}
+
+namespace {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+template<int CTRL>
+__device__ __forceinline__ double s1_dpp(double v)
+{
+   int lo = __double2loint(v), hi = __double2hiint(v);
+   lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+   return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double s1_lane(double v, int l)
+{
+   const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+   return __hiloint2double(hi, lo);
+}
+/* e / n for 0 <= e < 2^20, 1 <= n <= 64 without the integer-division expansion: float reciprocal, one correction step */
+__device__ __forceinline__ int s1_div(int e, int n)
+{
+   int r = (int) ((float) e * __builtin_amdgcn_rcpf((float) n));
+   const int c = e - r * n;
+   if ( c >= n ) ++r;
+   else if ( c < 0 ) --r;
+   return r;
+}
+/* sum within the rows of 16 lanes (every lane of a row gets its row's sum) */
+__device__ __forceinline__ double s1_sum16(double v)
+{
+   v += s1_dpp<0xB1>(v);              /* quad_perm [1, 0, 3, 2] */
+   v += s1_dpp<0x4E>(v);              /* quad_perm [2, 3, 0, 1] */
+   v += s1_dpp<0x141>(v);             /* row_half_mirror */
+   v += s1_dpp<0x140>(v);             /* row_mirror */
+   return v;
+}
+__device__ __forceinline__ double s1_wsum(double v)
+{
+   v = s1_sum16(v);
+   return ((s1_lane(v, 0) + s1_lane(v, 16)) + s1_lane(v, 32)) + s1_lane(v, 48);
+}
+__device__ __forceinline__ double s1_wmax(double v)
+{
+   v = fmax(v, s1_dpp<0xB1>(v));
+   v = fmax(v, s1_dpp<0x4E>(v));
+   v = fmax(v, s1_dpp<0x141>(v));
+   v = fmax(v, s1_dpp<0x140>(v));
+   return fmax(fmax(s1_lane(v, 0), s1_lane(v, 16)), fmax(s1_lane(v, 32), s1_lane(v, 48)));
+}
+__device__ __forceinline__ double s1_wmin(double v)
+{
+   v = fmin(v, s1_dpp<0xB1>(v));
+   v = fmin(v, s1_dpp<0x4E>(v));
+   v = fmin(v, s1_dpp<0x141>(v));
+   v = fmin(v, s1_dpp<0x140>(v));
+   return fmin(fmin(s1_lane(v, 0), s1_lane(v, 16)), fmin(s1_lane(v, 32), s1_lane(v, 48)));
+}
+
+struct S1Blk
+{
+   int n, p, np, G;
+   int oX, oZi, oLx, oLz, odX, odZ, oT1, oT2, oEig;
+   double *Z, *Rd, *E, *B;                                       /* cold matrices, pitch p (flat: LDS or workspace) */
+   int* voff; unsigned* vpq; double* vval;                        /* by variable: entries with row >= col, vpq = row << 16 | col */
+   int* poff; unsigned short* pvar; double* pval;                 /* by position r * n + c (r >= c): the variables that touch it */
+   unsigned short* lv; unsigned short* hv; int nl, nh;            /* variables with few ("light") and many nonzeros in this block */
+};
+
+struct S1Sh
+{
+   S1Lay lay;
+   S1Blk blk[S1_MAXB];
+   int* roff; unsigned short* rcol; double* rval;                 /* LP rows */
+   int* coff; unsigned short* crow; double* cval;                 /* LP columns */
+   double red[S1_NW][S1_NRED];
+   double sc[SC_COUNT];
+   int wtot[S1_NW + 1];
+   int fl[40];
+   long long t_last;
+   double prof[24];
+};
+static_assert(sizeof(S1Sh) <= S1_STATIC_LDS, "static LDS of the one-launch solve");
+
+/* ---- one wavefront: Cholesky of the lower triangle held in LDS (pitch p odd), lane = row, left-looking.  psd: the semidefinite
+ * pivot rule of oracle/ipm_ref.chol_psd / csrc/chol.hip (diag0 = original diagonal).  Returns 0 or 1 + index of the first
+ * non-positive pivot (definite mode). */
+__device__ __forceinline__ int s1_chol(double* L, int n, int p, int lane, bool psd, const double* diag0, int rule)
+{
+   const double regtol = 1e-13;
+   for (int k = 0; k < n; ++k)
+   {
+      double v = 0.0;
+      if ( lane >= k && lane < n )
+      {
+         const double* rl = L + lane * p;
+         const double* rk = L + k * p;
+         /* (eight entries per round: sixteen LDS reads in flight - a read at a time costs its latency, about 100 cycles, per entry) */
+         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+         int j = 0;
+         for (; j + 7 < k; j += 8)
+         {
+            const double a0 = rl[j], a1 = rl[j + 1], a2 = rl[j + 2], a3 = rl[j + 3], a4 = rl[j + 4], a5 = rl[j + 5], a6 = rl[j + 6], a7 = rl[j + 7];
+            const double b0 = rk[j], b1 = rk[j + 1], b2 = rk[j + 2], b3 = rk[j + 3], b4 = rk[j + 4], b5 = rk[j + 5], b6 = rk[j + 6], b7 = rk[j + 7];
+            s0 = fma(a0, b0, s0); s1 = fma(a1, b1, s1); s2 = fma(a2, b2, s2); s3 = fma(a3, b3, s3);
+            s0 = fma(a4, b4, s0); s1 = fma(a5, b5, s1); s2 = fma(a6, b6, s2); s3 = fma(a7, b7, s3);
+         }
+         if ( j + 3 < k )
+         {
+            const double a0 = rl[j], a1 = rl[j + 1], a2 = rl[j + 2], a3 = rl[j + 3];
+            const double b0 = rk[j], b1 = rk[j + 1], b2 = rk[j + 2], b3 = rk[j + 3];
+            s0 = fma(a0, b0, s0); s1 = fma(a1, b1, s1); s2 = fma(a2, b2, s2); s3 = fma(a3, b3, s3);
+            j += 4;
+         }
+         {
+            const double a0 = (j < k) ? rl[j] : 0.0, a1 = (j + 1 < k) ? rl[j + 1] : 0.0, a2 = (j + 2 < k) ? rl[j + 2] : 0.0;
+            const double b0 = (j < k) ? rk[j] : 0.0, b1 = (j + 1 < k) ? rk[j + 1] : 0.0, b2 = (j + 2 < k) ? rk[j + 2] : 0.0;
+            s0 = fma(a0, b0, s0); s1 = fma(a1, b1, s1); s2 = fma(a2, b2, s2);
+         }
+         v = rl[k] - ((s0 + s1) + (s2 + s3));
+      }
+      double d = s1_lane(v, k);
+      bool zero = false;
+      if ( psd )
+      {
+         const double mkk = diag0[k];
+         if ( !(d > regtol * mkk) || !(d > 1e-300) )
+         {
+            zero = (rule == 1) || (rule == 2 && !(d > 0.0)) || (rule == 3 && !(d > 1.78e-15 * (double) (k + 1) * mkk));
+            d = (mkk > 1e-280) ? regtol * mkk : 1.0;
+         }
+      }
+      else if ( !(d > 0.0) )
+         return k + 1;
+      const double sd = sqrt(d);
+      const double rs = 1.0 / sd;
+      if ( lane == k )
+         L[k * p + k] = sd;
+      else if ( lane > k && lane < n )
+         L[lane * p + k] = zero ? 0.0 : v * rs;
+      S1_WSYNC();
+   }
+   return 0;
+}
+
+/* reciprocal square root and reciprocal to full precision: v_rsq_f64 / v_rcp_f64 and two Newton steps (a few instructions instead
+ * of the division and square-root expansions - the single-wavefront recurrences are bound by their instruction count) */
+__device__ __forceinline__ double s1_rsqrt(double x)
+{
+   double r = __builtin_amdgcn_rsq(x);
+   double e = fma(-x * r, r, 1.0);
+   r = fma(0.5 * r, e, r);
+   e = fma(-x * r, r, 1.0);
+   r = fma(0.5 * r, e, r);
+   return r;
+}
+__device__ __forceinline__ double s1_rcp(double t)
+{
+   double r = __builtin_amdgcn_rcp(t);
+   r = fma(fma(-t, r, 1.0), r, r);
+   r = fma(fma(-t, r, 1.0), r, r);
+   return r;
+}
+
+/* ---- one wavefront: Cholesky in panels of eight columns.  The matrix (lower triangle, LDS, pitch p) is factored in place; before a
+ * panel is touched the finished columns are applied to it on the matrix cores (16 x 16 x 4 tiles: a few dozen instructions
+ * where the dot products entry by entry take thousands), then the panel lives in eight registers per lane (lane = row) and the
+ * pivots run as a register recurrence - the entries of the pivot row come by v_readlane, no LDS round trip inside a panel.
+ * psd: semidefinite pivot rule of oracle/ipm_ref.chol_psd (dg0 = this lane's original diagonal entry).  keepdiag = false: the
+ * stored factor has a ZERO diagonal and zero upper triangle (what the substitutions below want), the diagonal entry of row
+ * `lane` is returned in mydiag.  Returns 0 or 1 + index of the first non-positive pivot (definite mode). */
+__device__ __forceinline__ int s1_cholp(double* A, int n, int p, int lane, bool psd, double dg0, int rule, bool keepdiag, double& mydiag)
+{
+   const double regtol = 1e-13;
+   const int lr = lane & 15, kq = lane >> 4;
+   mydiag = 1.0;
+   for (int k0 = 0; k0 < n; k0 += 8)
+   {
+      if ( k0 > 0 )
+      {
+         for (int T = k0 >> 4; 16 * T < n; ++T)
+         {
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+            const int ar = 16 * T + lr, br = k0 + lr;
+            const bool aok = ar < n, bok = (lr < 8) && (br < n);
+            const double* pa = A + ar * p + kq;
+            const double* pb = A + br * p + kq;
+            for (int kk = 0; kk < k0; kk += 8)
+            {
+               const double a0 = aok ? pa[kk] : 0.0, b0 = bok ? pb[kk] : 0.0;
+               const double a1 = aok ? pa[kk + 4] : 0.0, b1 = bok ? pb[kk + 4] : 0.0;
+               acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+               acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+            {
+               const int row = 16 * T + kq + 4 * r;
+               if ( lr < 8 && row < n && row >= k0 + lr && k0 + lr < n )
+                  A[row * p + k0 + lr] -= acc[r];
+            }
+         }
+         S1_WSYNC();
+      }
+      double a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+         a[u] = (lane >= k0 + u && lane < n && k0 + u < n) ? A[lane * p + k0 + u] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+      {
+         const int k = k0 + u;
+         if ( k < n )
+         {
+#pragma unroll
+            for (int v = 0; v < u; ++v)
+               a[u] = fma(-a[v], s1_lane(a[v], k), a[u]);
+            double d = s1_lane(a[u], k);
+            bool zero = false;
+            if ( psd )
+            {
+               const double mkk = s1_lane(dg0, k);
+               if ( !(d > regtol * mkk) || !(d > 1e-300) )
+               {
+                  zero = (rule == 1) || (rule == 2 && !(d > 0.0)) || (rule == 3 && !(d > 1.78e-15 * (double) (k + 1) * mkk));
+                  d = (mkk > 1e-280) ? regtol * mkk : 1.0;
+               }
+            }
+            else if ( !(d > 0.0) )
+               return k + 1;
+            const double rs = s1_rsqrt(d);
+            const double sd = d * rs;
+            if ( lane == k )
+               mydiag = sd;
+            a[u] = (lane > k) ? (zero ? 0.0 : a[u] * rs) : ((lane == k && keepdiag) ? sd : 0.0);
+         }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+         if ( lane < n && k0 + u < n )
+            A[lane * p + k0 + u] = a[u];
+      S1_WSYNC();
+   }
+   return 0;
+}
+
+/* ---- one wavefront: x = (L L^T)^-1 r for one or two right-hand sides by forward and backward substitution, lane = row.  L as
+ * s1_cholp(keepdiag = false) leaves it (strictly lower, zero diagonal and upper triangle, pitch p >= 8 ceil(m / 8)), dinv = 1 /
+ * (diagonal entry of this lane's row).  In: x0, x1 = this lane's entries of the right-hand sides; out: of the solutions.  The
+ * columns of eight steps are loaded ahead of the recurrence, whose steps are a multiply, a v_readlane pair and a multiply-add. */
+__device__ __forceinline__ void s1_llt_solve(const double* L, int m, int p, int lane, double dinv, bool two, double& x0, double& x1)
+{
+   double a0 = (lane < m) ? x0 : 0.0, a1 = (lane < m && two) ? x1 : 0.0;
+   for (int k0 = 0; k0 < m; k0 += 8)
+   {
+      double c[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+         c[u] = (lane < m) ? L[lane * p + k0 + u] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+         if ( k0 + u < m )
+         {
+            const double y0 = s1_lane(a0 * dinv, k0 + u);
+            a0 = fma(-c[u], y0, a0);
+            if ( two )
+            {
+               const double y1 = s1_lane(a1 * dinv, k0 + u);
+               a1 = fma(-c[u], y1, a1);
+            }
+         }
+   }
+   a0 *= dinv; a1 *= dinv;
+   for (int k0 = (m - 1) & ~7; k0 >= 0; k0 -= 8)
+   {
+      double c[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+         c[u] = (lane < m && k0 + u < m) ? L[(k0 + u) * p + lane] : 0.0;
+#pragma unroll
+      for (int u = 7; u >= 0; --u)
+         if ( k0 + u < m )
+         {
+            const double y0 = s1_lane(a0 * dinv, k0 + u);
+            a0 = fma(-c[u], y0, a0);
+            if ( two )
+            {
+               const double y1 = s1_lane(a1 * dinv, k0 + u);
+               a1 = fma(-c[u], y1, a1);
+            }
+         }
+   }
+   x0 = a0 * dinv;
+   x1 = a1 * dinv;
+}
+
+/* ---- one wavefront: Li = L^-1 (lower), lane = column; in place when Li == L */
+__device__ __forceinline__ void s1_trinv(const double* L, double* Li, int n, int p, int lane)
+{
+   for (int i = 0; i < n; ++i)
+   {
+      const double* ri = L + i * p;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      {
+         /* uniform trip count (entries above the lane's column are masked): eight entries per round, the reads in flight together */
+         const double* cl = Li + lane;
+         int k = 0;
+         for (; k + 7 < i; k += 8)
+         {
+            double a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+            {
+               a[u] = ri[k + u];
+               b[u] = (k + u >= lane) ? cl[(k + u) * p] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u += 4)
+            {
+               s0 = fma(a[u], b[u], s0); s1 = fma(a[u + 1], b[u + 1], s1); s2 = fma(a[u + 2], b[u + 2], s2); s3 = fma(a[u + 3], b[u + 3], s3);
+            }
+         }
+         {
+            double a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+            {
+               const bool in = (k + u < i);
+               a[u] = in ? ri[k + u] : 0.0;
+               b[u] = (in && k + u >= lane) ? cl[(k + u) * p] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u += 4)
+            {
+               s0 = fma(a[u], b[u], s0); s1 = fma(a[u + 1], b[u + 1], s1); s2 = fma(a[u + 2], b[u + 2], s2); s3 = fma(a[u + 3], b[u + 3], s3);
+            }
+         }
+      }
+      const double rd = s1_rcp(ri[i]);
+      const double val = (lane == i) ? rd : -((s0 + s1) + (s2 + s3)) * rd;
+      __builtin_amdgcn_wave_barrier();
+      if ( lane <= i )
+         Li[i * p + lane] = val;
+      S1_WSYNC();
+   }
+}
+
+/* ---- one wavefront: smallest eigenvalue of the symmetric n x n matrix whose LOWER triangle is in W (LDS, pitch p odd; destroyed):
+ * Householder tridiagonalisation (lane = row), Sturm multisection with 64 shifts per round.  Returns min(lambda_min, 0) to a
+ * relative accuracy of 1e-11 (from below), NaN when the matrix is not finite.  scr: 4 * n doubles of LDS. */
+__device__ __forceinline__ double s1_lmin(double* W, int n, int p, int lane, double* scr)
+{
+   double* dd = scr;
+   double* ee = scr + n;
+   double* vv = scr + 2 * n;
+   double* ww = scr + 3 * n;
+   const bool small = n <= 16;                  /* the rows sit in the first 16 lanes: reductions inside one DPP row */
+   for (int k = 0; k + 2 < n; ++k)
+   {
+      const double xa = (lane > k && lane < n) ? W[lane * p + k] : 0.0;
+      const double x0 = s1_lane(xa, k + 1);
+      const double s2 = small ? s1_lane(s1_sum16(lane > k + 1 ? xa * xa : 0.0), 0) : s1_wsum(lane > k + 1 ? xa * xa : 0.0);
+      if ( lane == 0 )
+         dd[k] = W[k * p + k];
+      if ( !(s2 > 1e-290) )
+      {
+         if ( lane == 0 )
+            ee[k] = x0;
+         if ( s2 != s2 )
+            return s2;
+         continue;
+      }
+      const double h2 = x0 * x0 + s2;
+      const double rh = s1_rsqrt(h2);
+      const double beta = -copysign(h2 * rh, x0);
+      const double t = (x0 - beta) * copysign(rh, x0);          /* (beta - x0) / beta with 1 / beta = -sign(x0) / sqrt(h2) */
+      const double scale = s1_rcp(x0 - beta);
+      const double vl = (lane == k + 1) ? 1.0 : xa * scale;          /* lanes > k */
+      if ( lane > k && lane < n )
+         vv[lane] = vl;
+      if ( lane == 0 )
+         ee[k] = beta;
+      S1_WSYNC();
+      /* p = t A v over the trailing block (rows, columns k + 1 .. n - 1), lower storage */
+      double pl = 0.0;
+      if ( lane > k && lane < n )
+      {
+         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+         int c = k + 1;
+         for (; c + 3 < n; c += 4)
+         {
+            double ev[4], vc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+            {
+               ev[u] = W[(c + u <= lane) ? lane * p + c + u : (c + u) * p + lane];
+               vc[u] = vv[c + u];
+            }
+            a0 = fma(ev[0], vc[0], a0); a1 = fma(ev[1], vc[1], a1); a2 = fma(ev[2], vc[2], a2); a3 = fma(ev[3], vc[3], a3);
+         }
+         {
+            double ev[3], vc[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+            {
+               const bool in = (c + u < n);
+               ev[u] = in ? W[(c + u <= lane) ? lane * p + c + u : (c + u) * p + lane] : 0.0;
+               vc[u] = in ? vv[c + u] : 0.0;
+            }
+            a0 = fma(ev[0], vc[0], a0); a1 = fma(ev[1], vc[1], a1); a2 = fma(ev[2], vc[2], a2);
+         }
+         pl = t * ((a0 + a1) + (a2 + a3));
+      }
+      const double pvl = (lane > k && lane < n) ? pl * vl : 0.0;
+      const double pv = small ? s1_lane(s1_sum16(pvl), 0) : s1_wsum(pvl);
+      const double al = -0.5 * t * pv;
+      const double wl = pl + al * vl;
+      if ( lane > k && lane < n )
+         ww[lane] = wl;
+      S1_WSYNC();
+      if ( lane > k && lane < n )
+      {
+         double* rl = W + lane * p;
+         int c = k + 1;
+         for (; c + 3 <= lane; c += 4)
+         {
+            double r4[4], w4[4], v4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+            {
+               r4[u] = rl[c + u]; w4[u] = ww[c + u]; v4[u] = vv[c + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+               rl[c + u] = r4[u] - (vl * w4[u] + wl * v4[u]);
+         }
+         for (; c <= lane; ++c)
+            rl[c] -= vl * ww[c] + wl * vv[c];
+      }
+      S1_WSYNC();
+   }
+   if ( lane == 0 )
+   {
+      if ( n >= 2 )
+      {
+         dd[n - 2] = W[(n - 2) * p + n - 2];
+         ee[n - 2] = W[(n - 1) * p + n - 2];
+      }
+      dd[n - 1] = W[(n - 1) * p + n - 1];
+      ee[n - 1] = 0.0;
+   }
+   S1_WSYNC();
+   /* scale to norm one, Gershgorin interval */
+   double nrm = 0.0, glo = 1e300;
+   for (int i = lane; i < n; i += 64)
+   {
+      const double rad = (i > 0 ? fabs(ee[i - 1]) : 0.0) + fabs(ee[i]);
+      nrm = fmax(nrm, fabs(dd[i]) + rad);
+      glo = fmin(glo, dd[i] - rad);
+   }
+   {
+      double bad = 0.0;
+      for (int i = lane; i < n; i += 64)
+         if ( !(fabs(dd[i]) < 1e300) || !(fabs(ee[i]) < 1e300) )
+            bad = 1.0;
+      if ( s1_wmax(bad) > 0.0 )
+         return nan("");
+   }
+   nrm = s1_wmax(nrm);
+   glo = s1_wmin(glo);
+   if ( !(glo < 0.0) || !(nrm > 0.0) )
+      return 0.0;
+   const double sinv = 1.0 / nrm;
+   /* e2 into ww, scaled diagonal into vv */
+   for (int i = lane; i < n; i += 64)
+   {
+      vv[i] = dd[i] * sinv;
+      const double es = ee[i] * sinv;
+      ww[i] = es * es;
+   }
+   S1_WSYNC();
+   double lo = glo * sinv * (1.0 + 1e-12) - 1e-300, hi = 0.0;
+   /* is there an eigenvalue below zero at all?  (lane 0's shift of the first round is placed at 0) */
+   bool first = true;
+   for (int round = 0; round < 14; ++round)
+   {
+      const double wdt = (hi - lo) / 65.0;
+      double x = lo + wdt * (double) (lane + 1);
+      if ( first )
+         x = (lane == 63) ? 0.0 : lo + (hi - lo) * (double) (lane + 1) / 64.0;
+      /* Sturm sequence in product form, rescaled every fourth step; a sign change = an eigenvalue below x */
+      double pp = 1.0, pc = vv[0] - x;
+      bool posc = pc > 0.0;
+      bool below = !posc;
+#pragma unroll 8
+      for (int i = 1; i < n; ++i)
+      {
+         const double pn = fma(vv[i] - x, pc, -ww[i - 1] * pp);
+         const bool posn = (pn > 0.0) || (pn == 0.0 && !posc);
+         below = below || (posn != posc);
+         pp = pc; pc = pn; posc = posn;
+         if ( (i & 3) == 3 )
+         {
+            const int ex = -max(__builtin_amdgcn_frexp_exp(pc), __builtin_amdgcn_frexp_exp(pp));
+            if ( ex > -1000 && ex < 1000 )
+            {
+               pc = ldexp(pc, ex);
+               pp = ldexp(pp, ex);
+            }
+         }
+      }
+      const unsigned long long msk = __ballot(below);
+      if ( first )
+      {
+         first = false;
+         if ( !(msk >> 63) )
+            return 0.0;                                     /* nothing below zero */
+         const int f = __ffsll((long long) msk) - 1;        /* first shift with an eigenvalue below it */
+         const double w64 = (hi - lo) / 64.0;
+         const double nlo = (f == 0) ? lo : lo + w64 * (double) f;
+         const double nhi = (f == 63) ? 0.0 : lo + w64 * (double) (f + 1);
+         lo = nlo; hi = nhi;
+      }
+      else
+      {
+         const int f = msk ? __ffsll((long long) msk) - 1 : 64;
+         const double nlo = lo + wdt * (double) f;
+         const double nhi = (f < 64) ? lo + wdt * (double) (f + 1) : hi;
+         lo = nlo; hi = nhi;
+      }
+      if ( hi - lo <= 1e-11 * fabs(lo) || fabs(lo) < 1e-15 )
+         break;
+   }
+   return lo * nrm;
+}
+
+/* ---- n x n x n product on the matrix cores: wavefront `wave` of the subset [w0, w0 + nw) takes the 16 x 16 tiles tbase + t with
+ * (tbase + t) % nw == wave - w0.  la(i, k), lb(k, j): operand entries (called only inside the matrix); ep(i, j, value). */
+template<class LA, class LB, class EP>
+__device__ __forceinline__ void s1_mm(int n, int wave, int lane, int w0, int nw, int& tbase, LA la, LB lb, EP ep)
+{
+   const int nt = (n + 15) >> 4;
+   const int ntile = nt * nt;
+   if ( wave >= w0 && wave < w0 + nw )
+   {
+      const int lr = lane & 15, kq = lane >> 4;
+      for (int t = 0; t < ntile; ++t)
+      {
+         if ( (tbase + t) % nw != wave - w0 )
+            continue;
+         const int ti = t / nt, tj = t - ti * nt;
+         const int ri = 16 * ti + lr, cj = 16 * tj + lr;
+         v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 2
+         for (int kk = 0; kk < n; kk += 8)
+         {
+            const int k0 = kk + kq, k1 = kk + 4 + kq;
+            const double a0 = (ri < n && k0 < n) ? la(ri, k0) : 0.0;
+            const double b0 = (cj < n && k0 < n) ? lb(k0, cj) : 0.0;
+            const double a1 = (ri < n && k1 < n) ? la(ri, k1) : 0.0;
+            const double b1 = (cj < n && k1 < n) ? lb(k1, cj) : 0.0;
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
+         }
+#pragma unroll
+         for (int r = 0; r < 4; ++r)
+         {
+            const int row = 16 * ti + kq + 4 * r;
+            if ( row < n && cj < n )
+               ep(row, cj, acc0[r] + acc1[r]);
+         }
+      }
+   }
+   tbase += ntile;
+}
+
+/* exclusive prefix sums of the counts a[0 .. len) in place, a[len] = total (all threads; contains barriers) */
+__device__ __forceinline__ void s1_exscan(int* a, int len, S1Sh& sh, int tid)
+{
+   const int lane = tid & 63, wave = tid >> 6;
+   const int chunk = (len + S1_NT - 1) / S1_NT;
+   const int i0 = tid * chunk;
+   int s = 0;
+   for (int i = i0; i < i0 + chunk && i < len; ++i)
+      s += a[i];
+   int incl = s;
+#pragma unroll
+   for (int off = 1; off < 64; off <<= 1)
+   {
+      const int u = __shfl_up(incl, off, 64);
+      if ( lane >= off )
+         incl += u;
+   }
+   if ( lane == 63 )
+      sh.wtot[wave] = incl;
+   __syncthreads();
+   int base = 0;
+   for (int w = 0; w < wave; ++w)
+      base += sh.wtot[w];
+   int run = base + incl - s;
+   for (int i = i0; i < i0 + chunk && i < len; ++i)
+   {
+      const int t = a[i];
+      a[i] = run;
+      run += t;
+   }
+   if ( tid == S1_NT - 1 )
+      a[len] = run;
+   __syncthreads();
+}
+
+#define S1_STAMP(id) do { if ( P.prof_on && tid == 0 ) { const long long t_ = clock64(); sh.prof[id] += (double) (t_ - sh.t_last); sh.t_last = t_; } } while (0)
+
+__global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
+{
+   extern __shared__ __attribute__((aligned(16))) double sm[];
+   __shared__ S1Sh sh;
+   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+   const int m = P.m, m1 = P.m + 1, q = P.q, K = P.nblk;
+   const long long t_start = clock64();
+   const long long w_start = wall_clock64();
+
+   /* ---- layout */
+   if ( tid == 0 )
+   {
+      s1_layout(m, q, K, P.n, sh.lay);
+      for (int i = 0; i < 24; ++i)
+         sh.prof[i] = 0.0;
+      sh.t_last = t_start;
+   }
+   __syncthreads();
+   const S1Lay& L = sh.lay;
+   const int pm1 = L.pm1, pm = L.pm, VL = L.VL, QL = L.QL;
+   double* const Mx = sm + L.oMx;
+   double* const Lm = sm + L.oLm;
+#define VEC(id) (sm + L.oVec + (id) * VL)
+#define QV(id) (sm + L.oQ + (id) * QL)
+   double* const out = P.out;
+
+   /* ---- flexible part: offset arrays first (their sizes follow from the shape), the counts decide the rest */
+   if ( tid == 0 )
+   {
+      int ldsleft = (int) (S1_DYN_LDS / 8) - L.fixedEnd;
+      double* lp = sm + L.fixedEnd;
+      double* gp = P.gws;
+      /* (1) the pool of U_j buffers of the Schur phase: up to 16 of the largest block */
+      int npmax = 0;
+      for (int k = 0; k < K; ++k) npmax = max(npmax, L.np[k]);
+      int Rlen = L.Rlen;
+      {
+         const int want = S1_NW * npmax - Rlen;
+         if ( want > 0 )
+         {
+            const int ext = min(want, max(0, ldsleft / 2)) & ~1;
+            Rlen += ext; lp += ext; ldsleft -= ext;
+         }
+      }
+      sh.lay.Rlen = Rlen;
+      auto take = [&](long long cnt) S1_INL -> double*
+      {
+         cnt = (cnt + 1) & ~1LL;
+         double* r;
+         if ( cnt <= ldsleft ) { r = lp; lp += cnt; ldsleft -= (int) cnt; }
+         else { r = gp; gp += cnt; }
+         return r;
+      };
+      for (int k = 0; k < K; ++k)
+      {
+         S1Blk& B = sh.blk[k];
+         B.n = L.n[k]; B.p = L.p[k]; B.np = L.np[k];
+         B.oX = L.oX[k]; B.oZi = L.oZi[k]; B.oLx = L.oLx[k]; B.oLz = L.oLz[k]; B.odX = L.odX[k]; B.odZ = L.odZ[k];
+         B.oT1 = L.oT1[k]; B.oT2 = L.oT2[k]; B.oEig = L.oEig[k];
+         int G = S1_NW;
+         while ( G > 1 && G * B.np > Rlen ) G >>= 1;
+         B.G = G;
+      }
+      /* (2) cold matrices */
+      for (int k = 0; k < K; ++k)
+      {
+         S1Blk& B = sh.blk[k];
+         B.Z = take(B.np); B.Rd = take(B.np); B.E = take(B.np); B.B = take(B.np);
+      }
+      /* (3) offset arrays */
+      sh.roff = (int*) take((q + 2) / 2 + 1);
+      sh.coff = (int*) take((m1 + 2) / 2 + 1);
+      for (int k = 0; k < K; ++k)
+      {
+         S1Blk& B = sh.blk[k];
+         B.voff = (int*) take((m1 + 2) / 2 + 1);
+         B.poff = (int*) take((B.n * B.n + 2) / 2 + 1);
+      }
+      sh.fl[0] = ldsleft;
+      *(double**) &sh.sc[0] = lp;               /* (handed to the second allocation step below) */
+      *(double**) &sh.sc[1] = gp;
+   }
+   __syncthreads();
+
+   /* ---- counts: LP rows / columns, entries by variable / by position */
+   for (int r = wave; r < q; r += S1_NW)
+   {
+      int cnt = 0;
+      for (int c0 = 0; c0 < m1; c0 += 64)
+      {
+         const int c = c0 + lane;
+         const bool nz = c < m1 && P.Dext[(long long) r * m1 + c] != 0.0;
+         cnt += __popcll(__ballot(nz));
+      }
+      if ( lane == 0 ) sh.roff[r] = cnt;
+   }
+   for (int c = wave; c < m1; c += S1_NW)
+   {
+      int cnt = 0;
+      for (int r0 = 0; r0 < q; r0 += 64)
+      {
+         const int r = r0 + lane;
+         const bool nz = r < q && P.Dext[(long long) r * m1 + c] != 0.0;
+         cnt += __popcll(__ballot(nz));
+      }
+      if ( lane == 0 ) sh.coff[c] = cnt;
+   }
+   for (int k = 0; k < K; ++k)
+   {
+      const S1Blk& B = sh.blk[k];
+      const int n = B.n, n2 = n * n;
+      const double* A = P.A[k];
+      for (int i = wave; i < m1; i += S1_NW)
+      {
+         int cnt = 0;
+         for (int e0 = 0; e0 < n2; e0 += 64)
+         {
+            const int e = e0 + lane;
+            const int r = s1_div(e, n), c = e - r * n;
+            const bool nz = e < n2 && r >= c && A[(long long) i * n2 + e] != 0.0;
+            cnt += __popcll(__ballot(nz));
+         }
+         if ( lane == 0 ) B.voff[i] = cnt;
+      }
+      for (int e = tid; e < n2; e += S1_NT)
+      {
+         const int r = s1_div(e, n), c = e - r * n;
+         int cnt = 0;
+         if ( r >= c )
+            for (int i = 0; i < m1; ++i)
+               cnt += (A[(long long) i * n2 + e] != 0.0) ? 1 : 0;
+         B.poff[e] = cnt;
+      }
+   }
+   __syncthreads();
+   s1_exscan(sh.roff, q, sh, tid);
+   s1_exscan(sh.coff, m1, sh, tid);
+   for (int k = 0; k < K; ++k)
+   {
+      s1_exscan(sh.blk[k].voff, m1, sh, tid);
+      s1_exscan(sh.blk[k].poff, sh.blk[k].n * sh.blk[k].n, sh, tid);
+   }
+   if ( tid == 0 )
+   {
+      int ldsleft = sh.fl[0];
+      double* lp = *(double**) &sh.sc[0];
+      double* gp = *(double**) &sh.sc[1];
+      auto take = [&](long long cnt) S1_INL -> double*
+      {
+         cnt = (cnt + 1) & ~1LL;
+         double* r;
+         if ( cnt <= ldsleft ) { r = lp; lp += cnt; ldsleft -= (int) cnt; }
+         else { r = gp; gp += cnt; }
+         return r;
+      };
+      const int nnzD = sh.roff[q];
+      sh.rval = take(nnzD); sh.cval = take(nnzD);
+      sh.rcol = (unsigned short*) take((nnzD + 3) / 4); sh.crow = (unsigned short*) take((nnzD + 3) / 4);
+      double work = 0.0;
+      int nnzA = 0;
+      for (int k = 0; k < K; ++k)
+      {
+         S1Blk& B = sh.blk[k];
+         const int nz = B.voff[m1];
+         nnzA += nz;
+         B.vval = take(nz); B.pval = take(nz);
+         B.vpq = (unsigned*) take((nz + 1) / 2); B.pvar = (unsigned short*) take((nz + 3) / 4);
+         B.lv = (unsigned short*) take((m1 + 3) / 4); B.hv = (unsigned short*) take((m1 + 3) / 4);
+         /* light variables go through the pair formula (a thread per pair), heavy ones through U_j = X A_j Zinv */
+         int nl = 0, nh = 0, nzh = 0;
+         for (int i = 0; i < m1; ++i)
+         {
+            const int c = B.voff[i + 1] - B.voff[i];
+            if ( c == 0 )
+               continue;
+            if ( c <= S1_LIGHT_MAX ) B.lv[nl++] = (unsigned short) i;
+            else { B.hv[nh++] = (unsigned short) i; nzh += c; }
+         }
+         B.nl = nl; B.nh = nh;
+         work += 2.0 * (double) nzh * (double) (B.n * B.n) + 2.0 * (double) nz * (double) nh + 32.0 * (double) nl * (double) nl;
+      }
+      sh.fl[1] = (work > P.maxwork) ? 1 : 0;
+      sh.fl[2] = nnzA; sh.fl[3] = nnzD;
+      sh.fl[4] = ((long long) (gp - P.gws) > P.gws_len) ? 1 : 0;
+   }
+   __syncthreads();
+   if ( sh.fl[1] || sh.fl[4] )
+   {
+      /* more work than one compute unit should take (dense matrices), or a workspace that is too small: decline */
+      if ( tid == 0 )
+      {
+         out[0] = -2.0; out[40] = (double) sh.fl[2]; out[41] = (double) sh.fl[3];
+         __threadfence_system();
+         if ( P.flag != NULL )
+            __hip_atomic_store(P.flag, P.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      return;
+   }
+
+   /* ---- fill the lists */
+   for (int r = wave; r < q; r += S1_NW)
+   {
+      int run = sh.roff[r];
+      for (int c0 = 0; c0 < m1; c0 += 64)
+      {
+         const int c = c0 + lane;
+         const double v = c < m1 ? P.Dext[(long long) r * m1 + c] : 0.0;
+         const unsigned long long msk = __ballot(v != 0.0);
+         if ( v != 0.0 )
+         {
+            const int pos = run + __popcll(msk & ((1ULL << lane) - 1ULL));
+            sh.rcol[pos] = (unsigned short) c;
+            sh.rval[pos] = v;
+         }
+         run += __popcll(msk);
+      }
+   }
+   for (int c = wave; c < m1; c += S1_NW)
+   {
+      int run = sh.coff[c];
+      for (int r0 = 0; r0 < q; r0 += 64)
+      {
+         const int r = r0 + lane;
+         const double v = r < q ? P.Dext[(long long) r * m1 + c] : 0.0;
+         const unsigned long long msk = __ballot(v != 0.0);
+         if ( v != 0.0 )
+         {
+            const int pos = run + __popcll(msk & ((1ULL << lane) - 1ULL));
+            sh.crow[pos] = (unsigned short) r;
+            sh.cval[pos] = v;
+         }
+         run += __popcll(msk);
+      }
+   }
+   for (int k = 0; k < K; ++k)
+   {
+      const S1Blk& B = sh.blk[k];
+      const int n = B.n, n2 = n * n;
+      const double* A = P.A[k];
+      for (int i = wave; i < m1; i += S1_NW)
+      {
+         int run = B.voff[i];
+         for (int e0 = 0; e0 < n2; e0 += 64)
+         {
+            const int e = e0 + lane;
+            const int r = s1_div(e, n), c = e - r * n;
+            const double v = (e < n2 && r >= c) ? A[(long long) i * n2 + e] : 0.0;
+            const unsigned long long msk = __ballot(v != 0.0);
+            if ( v != 0.0 )
+            {
+               const int pos = run + __popcll(msk & ((1ULL << lane) - 1ULL));
+               B.vpq[pos] = ((unsigned) r << 16) | (unsigned) c;
+               B.vval[pos] = v;
+            }
+            run += __popcll(msk);
+         }
+      }
+      for (int e = tid; e < n2; e += S1_NT)
+      {
+         const int r = s1_div(e, n), c = e - r * n;
+         if ( r < c )
+            continue;
+         int pos = B.poff[e];
+         for (int i = 0; i < m1; ++i)
+         {
+            const double v = A[(long long) i * n2 + e];
+            if ( v != 0.0 )
+            {
+               B.pvar[pos] = (unsigned short) i;
+               B.pval[pos] = v;
+               ++pos;
+            }
+         }
+      }
+   }
+   /* objective, norms */
+   if ( tid < m )
+      VEC(V_b)[tid] = P.b[tid];
+   __syncthreads();
+   {
+      double c2 = 0.0;
+      for (int k = 0; k < K; ++k)
+      {
+         const S1Blk& B = sh.blk[k];
+         const int n = B.n, n2 = n * n;
+         for (int e = tid; e < n2; e += S1_NT)
+         {
+            const int t = B.poff[e];
+            if ( t < B.poff[e + 1] && B.pvar[t] == 0 )
+            {
+               const int r = s1_div(e, n), c = e - r * n;
+               c2 += (r == c ? 1.0 : 2.0) * B.pval[t] * B.pval[t];
+            }
+         }
+      }
+      for (int r = tid; r < q; r += S1_NT)
+      {
+         const int t = sh.roff[r];
+         if ( t < sh.roff[r + 1] && sh.rcol[t] == 0 )
+            c2 += sh.rval[t] * sh.rval[t];
+      }
+      c2 = s1_wsum(c2);
+      if ( lane == 0 )
+         sh.red[wave][RS_NC2] = c2;
+      if ( wave == 0 )
+      {
+         const double bb = (lane < m) ? VEC(V_b)[lane] : 0.0;
+         const double nb2 = s1_wsum(bb * bb);
+         if ( lane == 0 )
+            sh.sc[SC_NORMB] = sqrt(nb2);
+      }
+   }
+   __syncthreads();
+   if ( tid == 0 )
+   {
+      double c2 = 0.0;
+      for (int w = 0; w < S1_NW; ++w)
+         c2 += sh.red[w][RS_NC2];
+      sh.sc[SC_NORMC] = sqrt(c2);
+   }
+   __syncthreads();
+   const double normb = sh.sc[SC_NORMB], normC = sh.sc[SC_NORMC];
+   S1_STAMP(0);
+
+   /* ---- starting point */
+   long long Nsum = q;
+   for (int k = 0; k < K; ++k)
+      Nsum += L.n[k];
+   const double N1 = (double) (Nsum + 1);
+   int warm = 0;
+   auto trial_factor = [&](double alpha, bool fromglobal) S1_INL -> int
+   {
+      /* LxI <- X + alpha dXs (dXs in E), LzI <- Z + alpha dZs (dZs in B), then their Cholesky factors in place; returns the
+       * failure flags (1: Z, 2: X).  fromglobal: the caller's start matrices, symmetrised, into X and Z as well. */
+      for (int k = 0; k < K; ++k)
+      {
+         const S1Blk& B = sh.blk[k];
+         const int n = B.n, p = B.p;
+         for (int e = tid; e < n * n; e += S1_NT)
+         {
+            const int r = s1_div(e, n), c = e - r * n;
+            double xv, zv;
+            if ( fromglobal )
+            {
+               xv = 0.5 * (P.X[k][(long long) r * n + c] + P.X[k][(long long) c * n + r]);
+               zv = 0.5 * (P.Z[k][(long long) r * n + c] + P.Z[k][(long long) c * n + r]);
+               sm[B.oX + r * p + c] = xv;
+               B.Z[r * p + c] = zv;
+            }
+            else
+            {
+               xv = sm[B.oX + r * p + c];
+               zv = B.Z[r * p + c];
+               if ( alpha != 0.0 )
+               {
+                  xv = fma(alpha, B.E[r * p + c], xv);
+                  zv = fma(alpha, B.B[r * p + c], zv);
+               }
+            }
+            sm[B.oLx + r * p + c] = xv;
+            sm[B.oLz + r * p + c] = zv;
+         }
+      }
+      __syncthreads();
+      for (int t = wave; t < 2 * K; t += S1_NW)
+      {
+         const S1Blk& B = sh.blk[t >> 1];
+         double dummy;
+         const int f = s1_cholp(sm + ((t & 1) ? B.oLz : B.oLx), B.n, B.p, lane, false, 1.0, 0, true, dummy);
+         if ( lane == 0 )
+            sh.fl[8 + t] = f;
+      }
+      __syncthreads();
+      int ff = 0;
+      for (int t = 0; t < 2 * K; ++t)
+         if ( sh.fl[8 + t] != 0 )
+            ff |= (t & 1) ? 1 : 2;
+      return ff;
+   };
+   if ( P.have_start )
+   {
+      if ( tid < m ) VEC(V_y)[tid] = P.y[tid];
+      for (int r = tid; r < q; r += S1_NT)
+      {
+         QV(Q_x)[r] = P.x[r];
+         QV(Q_z)[r] = P.z[r];
+      }
+      const int ff = trial_factor(0.0, true);
+      /* interior?  mean complementarity */
+      double xz = 0.0, bad = 0.0;
+      for (int k = 0; k < K; ++k)
+      {
+         const S1Blk& B = sh.blk[k];
+         const int n = B.n, p = B.p;
+         for (int e = tid; e < n * n; e += S1_NT)
+         {
+            const int r = s1_div(e, n), c = e - r * n;
+            xz += sm[B.oX + r * p + c] * B.Z[r * p + c];
+         }
+      }
+      for (int r = tid; r < q; r += S1_NT)
+      {
+         const double xv = QV(Q_x)[r], zv = QV(Q_z)[r];
+         xz += xv * zv;
+         if ( !(xv > 0.0) || !(zv > 0.0) )
+            bad = 1.0;
+      }
+      xz = s1_wsum(xz);
+      bad = s1_wmax(bad);
+      if ( lane == 0 )
+      {
+         sh.red[wave][RS_XZ] = xz;
+         sh.red[wave][RS_RDMAX] = bad;
+      }
+      __syncthreads();
+      double sxz = 0.0, sbad = 0.0;
+      for (int w = 0; w < S1_NW; ++w)
+      {
+         sxz += sh.red[w][RS_XZ];
+         sbad = fmax(sbad, sh.red[w][RS_RDMAX]);
+      }
+      const double mu0 = sxz / (double) (Nsum > 0 ? Nsum : 1);
+      warm = (ff == 0 && sbad == 0.0 && mu0 > 0.0 && mu0 < 1e300) ? 1 : 0;
+      __syncthreads();
+      if ( warm && tid == 0 )
+      {
+         sh.sc[SC_TAU] = 1.0;
+         sh.sc[SC_KAPPA] = mu0;
+      }
+   }
+   if ( !warm )
+   {
+      const double xi = fmax(1.0, sqrt(fmax(fmax(normb, normC), 1.0)));
+      if ( tid < m ) VEC(V_y)[tid] = 0.0;
+      for (int r = tid; r < q; r += S1_NT)
+      {
+         QV(Q_x)[r] = xi;
+         QV(Q_z)[r] = xi;
+      }
+      for (int k = 0; k < K; ++k)
+      {
+         const S1Blk& B = sh.blk[k];
+         const int n = B.n, p = B.p;
+         for (int e = tid; e < n * n; e += S1_NT)
+         {
+            const int r = s1_div(e, n), c = e - r * n;
+            const double v = (r == c) ? xi : 0.0;
+            sm[B.oX + r * p + c] = v;
+            B.Z[r * p + c] = v;
+         }
+      }
+      if ( tid == 0 )
+      {
+         sh.sc[SC_TAU] = 1.0;
+         sh.sc[SC_KAPPA] = xi * xi;
+      }
+   }
+   __syncthreads();
+
+   /* ---- parameters of the settings ladder (oracle/ipm_ref.py: Params.settings; csrc/ipm.hip: solve_impl) */
+   const int settings = P.settings < 0 ? 0 : (P.settings > 2 ? 2 : P.settings);
+   const double gamma_eff = settings == 0 ? P.gamma : fmin(P.gamma, settings == 1 ? 0.9 : 0.75);
+   const int stall_lim = settings == 0 ? 3 : (settings == 1 ? 5 : 8);
+   const int nobest_lim = settings == 0 ? 6 : (settings == 1 ? 10 : 15);
+   const double sigma_floor = settings == 0 ? 1e-8 : (settings == 1 ? 1e-4 : 1e-2);
+   const int maxiter = P.maxiter;
+
+   int status = HS_S1_ITERLIM;
+   int it = 0, certwait = 0, nstall = 0, sincebest = 0, chol_fail = 0, pre_valid = 0;
+   double lastmu = 1e300, alpha_last = 1.0, bestmerit = 1e300, pre_scale = 0.0;
+   double mu = 0, pinf = 0, dinf = 0, dabs_ = 0, gap = 0, pobj = 0, dobj = 0;
+   bool factors_valid = (warm != 0);
+   S1_STAMP(1);
+
+   /* ---- helpers of the iteration (all threads call them; they contain no barrier unless stated) */
+   /* out(r, c) for r >= c: sum over the variables that touch the position of coefficient x value */
+   auto pass_AT = [&](const S1Blk& B, const double* cv, auto epi) S1_INL
+   {
+      const int n = B.n, n2 = n * n;
+      for (int e = tid; e < n2; e += S1_NT)
+      {
+         const int r = s1_div(e, n), c = e - r * n;
+         if ( r < c )
+            continue;
+         double s = 0.0;
+         const int t1 = B.poff[e + 1];
+         for (int t = B.poff[e]; t < t1; ++t)
+            s = fma(B.pval[t], cv[B.pvar[t]], s);
+         epi(r, c, s);
+      }
+   };
+   /* outv[i] = sum_k <A_i^k, V_k> + (Dext^T xv)_i, V_k symmetric at LDS offset offs[k] (16 lanes per variable) */
+   auto pass_A = [&](bool ofdX, const double* xv, double* outv) S1_INL
+   {
+      const int gid = tid >> 4, l16 = tid & 15;
+      for (int i = gid; i < m1; i += S1_NT / 16)
+      {
+         double s = 0.0;
+         for (int k = 0; k < K; ++k)
+         {
+            const S1Blk& B = sh.blk[k];
+            const double* V = sm + (ofdX ? B.odX : B.oX);
+            const int t1 = B.voff[i + 1];
+            for (int t = B.voff[i] + l16; t < t1; t += 16)
+            {
+               const unsigned pq = B.vpq[t];
+               const int pp = (int) (pq >> 16), qq = (int) (pq & 0xffffu);
+               s = fma(B.vval[t] * (pp == qq ? 1.0 : 2.0), V[pp * B.p + qq], s);
+            }
+         }
+         {
+            const int t1 = sh.coff[i + 1];
+            for (int t = sh.coff[i] + l16; t < t1; t += 16)
+               s = fma(sh.cval[t], xv[sh.crow[t]], s);
+         }
+         s = s1_sum16(s);
+         if ( l16 == 0 )
+            outv[i] = s;
+      }
+   };
+   auto lp_row = [&](int r, const double* cv) S1_INL -> double
+   {
+      double s = 0.0;
+      const int t1 = sh.roff[r + 1];
+      for (int t = sh.roff[r]; t < t1; ++t)
+         s = fma(sh.rval[t], cv[sh.rcol[t]], s);
+      return s;
+   };
+   auto red_sum = [&](int slot) S1_INL -> double
+   {
+      double s = 0.0;
+#pragma unroll
+      for (int w = 0; w < S1_NW; ++w)
+         s += sh.red[w][slot];
+      return s;
+   };
+   /* wavefront 0: the solves with the factor of M, each triangular solve corrected once with the factor itself (oracle: msolve).
+    * r0, r1: right-hand sides (r1 may be NULL), results in o0, o1; t0..t3: scratch vectors */
+   /* wavefront 0: x = M^-1 r for one or two right-hand sides (LDS vectors) by substitution with the factor of M; mdinv: this
+    * lane's 1 / diagonal entry of the factor.  [The oracle corrects each triangular solve once with the factor itself because the
+    * engine's general path solves with explicit inverses of diagonal blocks; a substitution has the small residual by itself.] */
+   double mdinv = 1.0;
+   auto msolve2 = [&](const double* r0, const double* r1, double* o0, double* o1) S1_INL
+   {
+      const bool two = (r1 != NULL);
+      double x0 = (lane < m) ? r0[lane] : 0.0;
+      double x1 = (two && lane < m) ? r1[lane] : 0.0;
+      s1_llt_solve(Lm, m, pm, lane, mdinv, two, x0, x1);
+      if ( lane < m )
+      {
+         o0[lane] = x0;
+         if ( two ) o1[lane] = x1;
+      }
+      S1_WSYNC();
+   };
+
+   double sigma = 0.0, eta = 1.0;
+   /* H (or dX) = sigmu Zinv - X - sym(T2) into dX, LP part into `lpout` from `rlp` (rd for the right-hand side, dz for the step) */
+   auto dir_matrix = [&](double sigmu, double etalp, const double* rlp, bool useE, double* lpout) S1_INL
+   {
+      for (int k = 0; k < K; ++k)
+      {
+         const S1Blk& B = sh.blk[k];
+         const int n = B.n, p = B.p;
+         for (int e = tid; e < n * n; e += S1_NT)
+         {
+            const int r = s1_div(e, n), c = e - r * n;
+            sm[B.odX + r * p + c] = sigmu * sm[B.oZi + r * p + c] - sm[B.oX + r * p + c]
+               - 0.5 * (sm[B.oT2 + r * p + c] + sm[B.oT2 + c * p + r]);
+         }
+      }
+      for (int r = tid; r < q; r += S1_NT)
+      {
+         const double xv = QV(Q_x)[r], zv = QV(Q_z)[r];
+         lpout[r] = sigmu / zv - xv - (etalp * xv * rlp[r] + (useE ? QV(Q_elp)[r] : 0.0)) / zv;
+      }
+   };
+   /* wavefront 0, after A(H) is known: h, u1 = M^-1 h, dtau, dkappa, dy, coefficient vector [-dtau; dy] */
+   auto finish_dir = [&](double sigmu, double etk, double rg) S1_INL
+   {
+      const double tau = sh.sc[SC_TAU], kappa = sh.sc[SC_KAPPA];
+      if ( lane < m )
+         VEC(V_h)[lane] = VEC(V_AH)[lane + 1] - eta * VEC(V_rp)[lane];
+      S1_WSYNC();
+      msolve2(VEC(V_h), NULL, VEC(V_u1), NULL);
+      const double u1 = lane < m ? VEC(V_u1)[lane] : 0.0;
+      const double bu1 = s1_wsum(lane < m ? VEC(V_b)[lane] * u1 : 0.0);
+      const double wrp = s1_wsum(lane < m ? VEC(V_w)[lane] * VEC(V_rp)[lane] : 0.0);
+      const double S0 = red_sum(RS_S0);
+      const double BH = red_sum(RS_BH);
+      const double den = S0 + kappa / tau + sh.sc[SC_BUB];
+      const double num = -eta * rg + (sigmu - tau * kappa - etk) / tau - BH - eta * wrp + bu1;
+      const double dtau = num / den;
+      const double dkappa = (sigmu - tau * kappa - etk - kappa * dtau) / tau;
+      if ( lane < m )
+      {
+         const double dy = u1 - VEC(V_u2)[lane] * dtau;
+         VEC(V_dy)[lane] = dy;
+         VEC(V_cv)[lane + 1] = dy;
+      }
+      if ( lane == 0 )
+      {
+         VEC(V_cv)[0] = -dtau;
+         sh.sc[SC_DTAU] = dtau;
+         sh.sc[SC_DKAPPA] = dkappa;
+      }
+   };
+   /* partial sums <B, H> + beta^T hl of this thread's share -> RS_BH */
+   auto bh_partials = [&]() S1_INL
+   {
+      double s = 0.0;
+      for (int k = 0; k < K; ++k)
+      {
+         const S1Blk& B = sh.blk[k];
+         const int n = B.n, p = B.p;
+         for (int e = tid; e < n * n; e += S1_NT)
+         {
+            const int r = s1_div(e, n), c = e - r * n;
+            s = fma(B.B[r * p + c], sm[B.odX + r * p + c], s);
+         }
+      }
+      for (int r = tid; r < q; r += S1_NT)
+         s = fma(QV(Q_beta)[r], QV(Q_hl)[r], s);
+      s = s1_wsum(s);
+      if ( lane == 0 )
+         sh.red[wave][RS_BH] = s;
+   };
+   /* dZ = A^T([-dtau; dy]) + eta Rd, dz likewise */
+   auto make_dZ = [&]() S1_INL
+   {
+      const double* cv = VEC(V_cv);
+      for (int k = 0; k < K; ++k)
+      {
+         const S1Blk& B = sh.blk[k];
+         const int p = B.p;
+         pass_AT(B, cv, [&](int r, int c, double s) S1_INL
+         {
+            const double v = fma(eta, B.Rd[r * p + c], s);
+            sm[B.odZ + r * p + c] = v;
+            sm[B.odZ + c * p + r] = v;
+         });
+      }
+      for (int r = tid; r < q; r += S1_NT)
+         QV(Q_dz)[r] = fma(eta, QV(Q_rd)[r], lp_row(r, cv));
+   };
+   /* step lengths: (a) T1 = LxI dX, T2 = LzI dZ (+ LP ratio tests; save = true: dX, dZ are copied to E, B first), (b) dX <- T1 LxI^T,
+    * dZ <- T2 LzI^T, (c) their smallest eigenvalues, one wavefront each.  Returns the largest step that keeps everything
+    * non-negative.  Contains barriers. */
+   auto steplen = [&](bool save) S1_INL -> double
+   {
+      {
+         int tb = 0;
+         for (int k = 0; k < K; ++k)
+         {
+            const S1Blk& B = sh.blk[k];
+            const int n = B.n, p = B.p;
+            const double* Lx = sm + B.oLx; const double* Lz = sm + B.oLz;
+            const double* dX = sm + B.odX; const double* dZ = sm + B.odZ;
+            double* T1 = sm + B.oT1; double* T2 = sm + B.oT2;
+            s1_mm(n, wave, lane, 0, S1_NW, tb,
+               [&](int i, int kk) S1_INL { return kk <= i ? Lx[i * p + kk] : 0.0; }, [&](int kk, int j) S1_INL { return dX[kk * p + j]; },
+               [&](int i, int j, double v) S1_INL { T1[i * p + j] = v; });
+            s1_mm(n, wave, lane, 0, S1_NW, tb,
+               [&](int i, int kk) S1_INL { return kk <= i ? Lz[i * p + kk] : 0.0; }, [&](int kk, int j) S1_INL { return dZ[kk * p + j]; },
+               [&](int i, int j, double v) S1_INL { T2[i * p + j] = v; });
+            if ( save )
+               for (int e = tid; e < n * n; e += S1_NT)
+               {
+                  const int r = s1_div(e, n), c = e - r * n;
+                  B.E[r * p + c] = dX[r * p + c];
+                  B.B[r * p + c] = dZ[r * p + c];
+               }
+         }
+         double rx = 1e300, rz = 1e300;
+         for (int r = tid; r < q; r += S1_NT)
+         {
+            const double dxv = QV(Q_dx)[r], dzv = QV(Q_dz)[r];
+            if ( dxv < 0.0 ) rx = fmin(rx, -QV(Q_x)[r] / dxv);
+            if ( dzv < 0.0 ) rz = fmin(rz, -QV(Q_z)[r] / dzv);
+         }
+         rx = s1_wmin(rx); rz = s1_wmin(rz);
+         if ( lane == 0 )
+         {
+            sh.red[wave][RS_RATX] = rx;
+            sh.red[wave][RS_RATZ] = rz;
+         }
+      }
+      __syncthreads();
+      {
+         int tb = 0;
+         for (int k = 0; k < K; ++k)
+         {
+            const S1Blk& B = sh.blk[k];
+            const int n = B.n, p = B.p;
+            const double* Lx = sm + B.oLx; const double* Lz = sm + B.oLz;
+            double* dX = sm + B.odX; double* dZ = sm + B.odZ;
+            const double* T1 = sm + B.oT1; const double* T2 = sm + B.oT2;
+            s1_mm(n, wave, lane, 0, S1_NW, tb,
+               [&](int i, int kk) S1_INL { return T1[i * p + kk]; }, [&](int kk, int j) S1_INL { return kk <= j ? Lx[j * p + kk] : 0.0; },
+               [&](int i, int j, double v) S1_INL { dX[i * p + j] = v; });
+            s1_mm(n, wave, lane, 0, S1_NW, tb,
+               [&](int i, int kk) S1_INL { return T2[i * p + kk]; }, [&](int kk, int j) S1_INL { return kk <= j ? Lz[j * p + kk] : 0.0; },
+               [&](int i, int j, double v) S1_INL { dZ[i * p + j] = v; });
+         }
+      }
+      __syncthreads();
+      for (int t = wave; t < 2 * K; t += S1_NW)
+      {
+         const S1Blk& B = sh.blk[t >> 1];
+         const double lm = s1_lmin(sm + ((t & 1) ? B.odZ : B.odX), B.n, B.p, lane, sm + B.oEig + (t & 1) * 4 * ((B.n + 1) & ~1));
+         if ( lane == 0 )
+            sh.sc[SC_LMIN0 + t] = lm;
+      }
+      __syncthreads();
+      double a = 1e300;
+      for (int t = 0; t < 2 * K; ++t)
+      {
+         const double lm = sh.sc[SC_LMIN0 + t];
+         if ( lm != lm )
+            a = nan("");
+         else if ( lm < 0.0 )
+            a = fmin(a, -1.0 / lm);
+      }
+      double rx = 1e300, rz = 1e300;
+      for (int w = 0; w < S1_NW; ++w)
+      {
+         rx = fmin(rx, sh.red[w][RS_RATX]);
+         rz = fmin(rz, sh.red[w][RS_RATZ]);
+      }
+      a = fmin(a, fmin(rx, rz));
+      const double tau = sh.sc[SC_TAU], kappa = sh.sc[SC_KAPPA], dtau = sh.sc[SC_DTAU], dkappa = sh.sc[SC_DKAPPA];
+      if ( dtau < 0.0 ) a = fmin(a, -tau / dtau);
+      if ( dkappa < 0.0 ) a = fmin(a, -kappa / dkappa);
+      return a;
+   };
+
+   for (it = 0; it <= maxiter; ++it)
+   {
+      /* ================= residuals */
+      {
+         const double tau = sh.sc[SC_TAU];
+         if ( tid < m1 )
+            VEC(V_cv)[tid] = (tid == 0) ? -tau : VEC(V_y)[tid - 1];
+      }
+      __syncthreads();
+      {
+         const double* cv = VEC(V_cv);
+         double xz = 0.0;
+         for (int k = 0; k < K; ++k)
+         {
+            const S1Blk& B = sh.blk[k];
+            const int p = B.p;
+            double r2 = 0.0;
+            pass_AT(B, cv, [&](int r, int c, double s) S1_INL
+            {
+               const double zv = B.Z[r * p + c];
+               const double v = s - zv;
+               B.Rd[r * p + c] = v;
+               B.Rd[c * p + r] = v;
+               const double wgt = (r == c) ? 1.0 : 2.0;
+               r2 = fma(wgt * v, v, r2);
+               xz = fma(wgt * sm[B.oX + r * p + c], zv, xz);
+            });
+            r2 = s1_wsum(r2);
+            if ( lane == 0 )
+               sh.red[wave][RS_BLK0 + k] = r2;
+         }
+         double r2lp = 0.0, rmax = 0.0;
+         for (int r = tid; r < q; r += S1_NT)
+         {
+            const double zv = QV(Q_z)[r];
+            const double v = lp_row(r, cv) - zv;
+            QV(Q_rd)[r] = v;
+            QV(Q_sx)[r] = QV(Q_x)[r] / zv;
+            r2lp = fma(v, v, r2lp);
+            rmax = fmax(rmax, fabs(v));
+            xz = fma(QV(Q_x)[r], zv, xz);
+         }
+         xz = s1_wsum(xz); r2lp = s1_wsum(r2lp); rmax = s1_wmax(rmax);
+         if ( lane == 0 )
+         {
+            sh.red[wave][RS_XZ] = xz;
+            sh.red[wave][RS_RD2LP] = r2lp;
+            sh.red[wave][RS_RDMAX] = rmax;
+         }
+         pass_A(false, QV(Q_x), VEC(V_AX));
+      }
+      __syncthreads();
+      if ( wave == 0 )
+      {
+         const double tau = sh.sc[SC_TAU];
+         const double ax = lane < m ? VEC(V_AX)[lane + 1] : 0.0;
+         const double bv = lane < m ? VEC(V_b)[lane] : 0.0;
+         const double rp = bv * tau - ax;
+         if ( lane < m )
+            VEC(V_rp)[lane] = rp;
+         const double rp2 = s1_wsum(lane < m ? rp * rp : 0.0);
+         const double hp2 = s1_wsum(ax * ax);
+         const double dob = s1_wsum(lane < m ? bv * VEC(V_y)[lane] : 0.0);
+         if ( lane == 0 )
+         {
+            sh.sc[SC_RP2] = rp2; sh.sc[SC_HP2] = hp2; sh.sc[SC_DOBJ] = dob;
+         }
+      }
+      __syncthreads();
+      const double tau = sh.sc[SC_TAU], kappa = sh.sc[SC_KAPPA];
+      pobj = VEC(V_AX)[0];
+      dobj = sh.sc[SC_DOBJ];
+      const double rg = pobj - dobj - kappa;
+      mu = (red_sum(RS_XZ) + tau * kappa) / N1;
+      double rd2 = red_sum(RS_RD2LP);
+      double rdmax = 0.0;
+      for (int w = 0; w < S1_NW; ++w)
+         rdmax = fmax(rdmax, sh.red[w][RS_RDMAX]);
+      for (int k = 0; k < K; ++k)
+      {
+         const double bk = red_sum(RS_BLK0 + k);
+         rd2 += bk;
+         rdmax = fmax(rdmax, sqrt(bk));
+      }
+      const double rpn = sqrt(sh.sc[SC_RP2]);
+      pinf = rpn / tau / (1.0 + normb);
+      const double pabs = rpn / tau;
+      const bool pabsok = P.pabstol <= 0.0 || pabs <= P.pabstol;
+      dinf = sqrt(rd2) / tau / (1.0 + normC);
+      dabs_ = rdmax / tau;
+      gap = fabs(dobj - pobj) / tau;
+      if ( P.hist != NULL && tid == 0 && it < P.hist_len )
+      {
+         double* h = P.hist + 12 * it;
+         h[0] = it; h[1] = mu; h[2] = pinf; h[3] = dinf; h[4] = gap; h[5] = tau; h[6] = kappa; h[7] = pobj; h[8] = dobj;
+      }
+      S1_STAMP(2);
+      if ( !(fabs(mu) < 1e300) || !(pinf < 1e300) || !(dinf < 1e300) )
+      {
+         status = HS_S1_NUMERIC;
+         break;
+      }
+      /* preoptimal iterate (capture rule of sdpisolver_dsdp.c:323-358) */
+      if ( P.preoptgap > 0.0 && !pre_valid && pinf <= P.feastol && dabs_ <= P.feastol
+         && gap / (1.0 + 0.5 * fabs(pobj / tau) + 0.5 * fabs(dobj / tau)) < P.preoptgap )
+      {
+         if ( tid < m ) P.pre_y[tid] = VEC(V_y)[tid];
+         for (int r = tid; r < q; r += S1_NT)
+            P.pre_x[r] = QV(Q_x)[r];
+         for (int k = 0; k < K; ++k)
+         {
+            const S1Blk& B = sh.blk[k];
+            const int n = B.n, p = B.p;
+            for (int e = tid; e < n * n; e += S1_NT)
+            {
+               const int r = s1_div(e, n), c = e - r * n;
+               P.Xpre[k][e] = sm[B.oX + r * p + c];
+            }
+         }
+         pre_scale = 1.0 / tau;
+         pre_valid = 1;
+      }
+      if ( P.objlimit < 1e20 && pinf <= P.feastol && pobj / tau > P.objlimit + P.gaptol )
+      {
+         status = HS_S1_OBJLIM;
+         break;
+      }
+      if ( pinf <= P.feastol && pabsok && dabs_ <= P.feastol && gap <= P.gaptol )
+      {
+         status = HS_S1_OPTIMAL;
+         break;
+      }
+      const bool certzone = (tau < 1e-2 * fmin(1.0, kappa)) || (mu / (tau * tau) > 1e10);
+      if ( certzone )
+      {
+         /* Farkas certificates: || A^T y - Z || = || Rd + tau A_0 || and || A(X, x) || relative to the objective they certify */
+         double h2 = 0.0;
+         for (int k = 0; k < K; ++k)
+         {
+            const S1Blk& B = sh.blk[k];
+            const int n = B.n, p = B.p;
+            for (int e = tid; e < n * n; e += S1_NT)
+            {
+               const int r = s1_div(e, n), c = e - r * n;
+               if ( r < c )
+                  continue;
+               const int t = B.poff[e];
+               const double a0 = (t < B.poff[e + 1] && B.pvar[t] == 0) ? B.pval[t] : 0.0;
+               const double v = fma(tau, a0, B.Rd[r * p + c]);
+               h2 = fma((r == c ? 1.0 : 2.0) * v, v, h2);
+            }
+         }
+         for (int r = tid; r < q; r += S1_NT)
+         {
+            const int t = sh.roff[r];
+            const double c0 = (t < sh.roff[r + 1] && sh.rcol[t] == 0) ? sh.rval[t] : 0.0;
+            const double v = fma(tau, c0, QV(Q_rd)[r]);
+            h2 = fma(v, v, h2);
+         }
+         h2 = s1_wsum(h2);
+         if ( lane == 0 )
+            sh.red[wave][RS_HD2] = h2;
+         __syncthreads();
+         const double hd = sqrt(red_sum(RS_HD2));
+         const double hp = sqrt(sh.sc[SC_HP2]);
+         const double big = fmax(fabs(dobj), fabs(pobj));
+         const bool cand_dunb = dobj < -1e-3 * big;
+         const bool cand_dinf = pobj > 1e-3 * big;
+         const bool ok_dunb = cand_dunb && hd <= P.infeastol * (-dobj);
+         const bool ok_dinf = cand_dinf && hp <= P.infeastol * pobj;
+         if ( (ok_dunb || ok_dinf) && (ok_dunb || !cand_dunb || certwait >= 5) && (ok_dinf || !cand_dinf || certwait >= 5) )
+         {
+            status = (ok_dunb && ok_dinf) ? HS_S1_PDINF : (ok_dunb ? HS_S1_DUNB : HS_S1_DINF);
+            break;
+         }
+         if ( ok_dunb || ok_dinf )
+            ++certwait;
+      }
+      if ( it == maxiter )
+         break;
+      if ( mu > 0.9 * lastmu && alpha_last < 1e-2 )
+      {
+         if ( ++nstall >= stall_lim )
+         {
+            status = HS_S1_NUMERIC;
+            break;
+         }
+      }
+      else
+         nstall = 0;
+      lastmu = mu;
+      if ( !certzone )
+      {
+         double merit = fmax(fmax(pinf / P.feastol, dabs_ / P.feastol), gap / P.gaptol);
+         if ( P.pabstol > 0.0 )
+            merit = fmax(merit, pabs / P.pabstol);
+         if ( merit < 0.9 * bestmerit )
+         {
+            bestmerit = merit;
+            sincebest = 0;
+         }
+         else if ( ++sincebest >= nobest_lim )
+         {
+            status = HS_S1_NUMERIC;
+            break;
+         }
+      }
+      if ( P.timelimit > 0.0 )
+      {
+         /* s_memrealtime: 100 MHz */
+         const double el = (double) (wall_clock64() - w_start) * 1e-8 + P.elapsed0;
+         int over = (el > P.timelimit) ? 1 : 0;
+         over = __builtin_amdgcn_readfirstlane(over);
+         if ( tid == 0 )
+            sh.fl[5] = over;
+         __syncthreads();
+         if ( sh.fl[5] )
+         {
+            status = HS_S1_TIMELIM;
+            break;
+         }
+      }
+
+      /* ================= factorizations */
+      if ( !factors_valid )
+      {
+         const int ff = trial_factor(0.0, false);
+         if ( ff != 0 )
+         {
+            status = HS_S1_NUMERIC;
+            break;
+         }
+      }
+      /* inverse factors in place (one wavefront per matrix, from wavefront 0 up); LP part of the Schur matrix by the threads at
+       * the other end: thread NT - 1 - i owns row i of Mx (lower part), zeroes it and adds its rows' contributions */
+      for (int t = wave; t < 2 * K; t += S1_NW)
+      {
+         const S1Blk& B = sh.blk[t >> 1];
+         double* Lp = sm + ((t & 1) ? B.oLz : B.oLx);
+         s1_trinv(Lp, Lp, B.n, B.p, lane);
+      }
+      if ( wave == S1_NW - 1 )
+      {
+         /* LP part of the Schur matrix, D^T diag(x / z) D, lower triangle; it also clears Mx.  Lane l owns the rows l + 1 (and l + 65):
+          * it walks the LP rows its variable appears in and adds their entries up to its own column.  Row 0 (the constant
+          * column, present in almost every bound row) has one entry, Mx[0][0]: a reduction over the wavefront. */
+         const double* sx = QV(Q_sx);
+         for (int i = lane + 1; i < m1; i += 64)
+         {
+            double* row = Mx + i * pm1;
+            for (int j = 0; j <= i; ++j)
+               row[j] = 0.0;
+            const int t1 = sh.coff[i + 1];
+            for (int t = sh.coff[i]; t < t1; ++t)
+            {
+               const int r = sh.crow[t];
+               const double sv = sh.cval[t] * sx[r];
+               const int u1 = sh.roff[r + 1];
+               for (int u = sh.roff[r]; u < u1; ++u)
+               {
+                  const int j = sh.rcol[u];
+                  if ( j > i )
+                     break;
+                  row[j] = fma(sv, sh.rval[u], row[j]);
+               }
+            }
+         }
+         double s00 = 0.0;
+         const int t1 = sh.coff[1];
+         for (int t = sh.coff[0] + lane; t < t1; t += 64)
+         {
+            const double cv0 = sh.cval[t];
+            s00 = fma(cv0 * sx[sh.crow[t]], cv0, s00);
+         }
+         s00 = s1_wsum(s00);
+         if ( lane == 0 )
+            Mx[0] = s00;
+      }
+      __syncthreads();
+      S1_STAMP(3);
+      {
+         int tb = 0;
+         for (int k = 0; k < K; ++k)
+         {
+            const S1Blk& B = sh.blk[k];
+            const int p = B.p;
+            const double* Lz = sm + B.oLz;
+            double* Zi = sm + B.oZi;
+            s1_mm(B.n, wave, lane, 0, S1_NW, tb,
+               [&](int i, int kk) S1_INL { return kk >= i ? Lz[kk * p + i] : 0.0; }, [&](int kk, int j) S1_INL { return kk >= j ? Lz[kk * p + j] : 0.0; },
+               [&](int i, int j, double v) S1_INL { Zi[i * p + j] = v; });
+         }
+      }
+      __syncthreads();
+      S1_STAMP(4);
+
+      /* ================= Schur complement from the nonzeros: U_j = X A_j Zinv (G of them side by side), Mx[i][j] += <A_i, U_j> */
+      for (int k = 0; k < K; ++k)
+      {
+         const S1Blk& B = sh.blk[k];
+         const int n = B.n, p = B.p, n2 = n * n, G = B.G;
+         const int gsz = S1_NT / G;
+         const int g = tid / gsz, tig = tid - g * gsz;
+         double* U = sm + L.oR + g * B.np;
+         const double* X = sm + B.oX;
+         const double* Zi = sm + B.oZi;
+         /* heavy variables j: U_j = X A_j Zinv as a sum of rank-one terms per nonzero, then <A_i, U_j> for every i (a heavy i only
+          * from j on: the pair of two heavy variables is formed once) */
+         const int nh = B.nh;
+         for (int h0 = 0; h0 < nh; h0 += G)
+         {
+            const int j = (h0 + g < nh) ? (int) B.hv[h0 + g] : -1;
+            if ( j >= 0 )
+            {
+               const int t0 = B.voff[j], t1 = B.voff[j + 1];
+               for (int e = tig; e < n2; e += gsz)
+               {
+                  const int r = s1_div(e, n), c = e - r * n;
+                  double s0 = 0.0;
+                  for (int t = t0; t < t1; ++t)
+                  {
+                     const unsigned pq = B.vpq[t];
+                     const int pp = (int) (pq >> 16), qq = (int) (pq & 0xffffu);
+                     const double a = B.vval[t];
+                     double term = X[r * p + pp] * Zi[qq * p + c];
+                     if ( pp != qq )
+                        term = fma(X[r * p + qq], Zi[pp * p + c], term);
+                     s0 = fma(a, term, s0);
+                  }
+                  U[r * p + c] = s0;
+               }
+            }
+            __syncthreads();
+            if ( j >= 0 )
+            {
+               for (int i = tig; i < m1; i += gsz)
+               {
+                  const int t0 = B.voff[i], t1 = B.voff[i + 1];
+                  if ( t1 == t0 || (t1 - t0 > S1_LIGHT_MAX && i < j) )
+                     continue;
+                  double s0 = 0.0;
+                  for (int t = t0; t < t1; ++t)
+                  {
+                     const unsigned pq = B.vpq[t];
+                     const int pp = (int) (pq >> 16), qq = (int) (pq & 0xffffu);
+                     double term = U[pp * p + qq];
+                     if ( pp != qq )
+                        term += U[qq * p + pp];
+                     s0 = fma(B.vval[t], term, s0);
+                  }
+                  Mx[(i >= j) ? i * pm1 + j : j * pm1 + i] += s0;
+               }
+            }
+            __syncthreads();
+         }
+         /* pairs of light variables: a thread per pair, the pair formula over their nonzeros (SDPA's F3 case; csrc/sparse.hip:
+          * k_sp_schur) - e = (p, q, a) in A_i, f = (r, s, b) in A_j, lower triangles standing for both positions:
+          * a b (X_qr Zi_sp + [p != q] X_pr Zi_sq + [r != s] X_qs Zi_rp + [p != q][r != s] X_ps Zi_rq) */
+         const int nl = B.nl;
+         for (int t = tid; t < nl * nl; t += S1_NT)
+         {
+            const int ia = s1_div(t, nl), ib = t - ia * nl;
+            if ( ib > ia )
+               continue;
+            const int i = B.lv[ia], j = B.lv[ib];
+            const int e0 = B.voff[i], e1 = B.voff[i + 1], f0 = B.voff[j], f1 = B.voff[j + 1];
+            double s0 = 0.0;
+            for (int e = e0; e < e1; ++e)
+            {
+               const unsigned pq = B.vpq[e];
+               const int pp = (int) (pq >> 16), qq = (int) (pq & 0xffffu);
+               const double a = B.vval[e];
+               double se = 0.0;
+               for (int f = f0; f < f1; ++f)
+               {
+                  const unsigned rs = B.vpq[f];
+                  const int rr = (int) (rs >> 16), ss = (int) (rs & 0xffffu);
+                  double term = X[qq * p + rr] * Zi[ss * p + pp];
+                  if ( pp != qq )
+                     term = fma(X[pp * p + rr], Zi[ss * p + qq], term);
+                  if ( rr != ss )
+                  {
+                     term = fma(X[qq * p + ss], Zi[rr * p + pp], term);
+                     if ( pp != qq )
+                        term = fma(X[pp * p + ss], Zi[rr * p + qq], term);
+                  }
+                  se = fma(B.vval[f], term, se);
+               }
+               s0 = fma(a, se, s0);
+            }
+            Mx[i * pm1 + j] += s0;
+         }
+      }
+      __syncthreads();
+      S1_STAMP(5);
+
+      /* ================= factorization of M and the two solves (wavefront 0) beside the first product of the predictor,
+       * T1 = X Rd (the others) */
+      if ( wave == 0 )
+      {
+         /* lower triangle of M into Lm (zero above the diagonal, out to the padded width), lane = row */
+         double dg0 = 1.0;
+         if ( lane < m )
+         {
+            const double* src = Mx + (lane + 1) * pm1 + 1;
+            double* dst = Lm + lane * pm;
+            for (int j = 0; j < pm - 1; ++j)
+               dst[j] = (j <= lane) ? src[j] : 0.0;
+            dg0 = src[lane];
+            VEC(V_g)[lane] = Mx[(lane + 1) * pm1];
+         }
+         S1_WSYNC();
+         double mdiag;
+         (void) s1_cholp(Lm, m, pm, lane, true, dg0, P.pivot_rule, false, mdiag);
+         mdinv = s1_rcp(mdiag);
+         msolve2(VEC(V_g), VEC(V_b), VEC(V_w), VEC(V_ub));
+         if ( lane < m )
+         {
+            const double w = VEC(V_w)[lane], ub = VEC(V_ub)[lane];
+            VEC(V_u2)[lane] = ub - w;
+            VEC(V_wt)[lane + 1] = -w;
+         }
+         const double bub = s1_wsum(lane < m ? VEC(V_b)[lane] * VEC(V_ub)[lane] : 0.0);
+         if ( lane == 0 )
+         {
+            VEC(V_wt)[0] = 1.0;
+            sh.sc[SC_BUB] = bub;
+         }
+      }
+      {
+         int tb = 0;
+         const int w0 = (S1_NW > 1) ? 1 : 0, nw = S1_NW - w0;
+         for (int k = 0; k < K; ++k)
+         {
+            const S1Blk& B = sh.blk[k];
+            const int p = B.p;
+            const double* X = sm + B.oX;
+            const double* Rd = B.Rd;
+            double* T1 = sm + B.oT1;
+            s1_mm(B.n, wave, lane, w0, nw, tb,
+               [&](int i, int kk) S1_INL { return X[i * p + kk]; }, [&](int kk, int j) S1_INL { return Rd[kk * p + j]; },
+               [&](int i, int j, double v) S1_INL { T1[i * p + j] = v; });
+         }
+      }
+      __syncthreads();
+      S1_STAMP(6);
+      {
+         double u2bad = 0.0;
+         if ( tid < m && !(fabs(VEC(V_u2)[tid]) < 1e300) )
+            u2bad = 1.0;
+         if ( __syncthreads_or(u2bad != 0.0) )
+         {
+            status = HS_S1_NUMERIC;
+            break;
+         }
+      }
+      /* B_k = A_0 - sum w_i A_i, beta = c - D w; T2 = T1 Zinv */
+      sigma = 0.0; eta = 1.0;
+      {
+         const double* wt = VEC(V_wt);
+         for (int k = 0; k < K; ++k)
+         {
+            const S1Blk& B = sh.blk[k];
+            const int p = B.p;
+            pass_AT(B, wt, [&](int r, int c, double s) S1_INL
+            {
+               B.B[r * p + c] = s;
+               B.B[c * p + r] = s;
+            });
+         }
+         for (int r = tid; r < q; r += S1_NT)
+            QV(Q_beta)[r] = lp_row(r, wt);
+         int tb = 0;
+         for (int k = 0; k < K; ++k)
+         {
+            const S1Blk& B = sh.blk[k];
+            const int p = B.p;
+            const double* T1 = sm + B.oT1; const double* Zi = sm + B.oZi;
+            double* T2 = sm + B.oT2;
+            s1_mm(B.n, wave, lane, 0, S1_NW, tb,
+               [&](int i, int kk) S1_INL { return T1[i * p + kk]; }, [&](int kk, int j) S1_INL { return Zi[kk * p + j]; },
+               [&](int i, int j, double v) S1_INL { T2[i * p + j] = v; });
+         }
+      }
+      __syncthreads();
+      /* H of the predictor -> dX, hl; T1 = X B */
+      {
+         dir_matrix(0.0, 1.0, QV(Q_rd), false, QV(Q_hl));
+         int tb = 0;
+         for (int k = 0; k < K; ++k)
+         {
+            const S1Blk& B = sh.blk[k];
+            const int p = B.p;
+            const double* X = sm + B.oX; const double* Bm = B.B;
+            double* T1 = sm + B.oT1;
+            s1_mm(B.n, wave, lane, 0, S1_NW, tb,
+               [&](int i, int kk) S1_INL { return X[i * p + kk]; }, [&](int kk, int j) S1_INL { return Bm[kk * p + j]; },
+               [&](int i, int j, double v) S1_INL { T1[i * p + j] = v; });
+         }
+      }
+      __syncthreads();
+      /* A(H), <B, H>; T2 = T1 Zinv */
+      {
+         pass_A(true, QV(Q_hl), VEC(V_AH));
+         bh_partials();
+         int tb = 0;
+         for (int k = 0; k < K; ++k)
+         {
+            const S1Blk& B = sh.blk[k];
+            const int p = B.p;
+            const double* T1 = sm + B.oT1; const double* Zi = sm + B.oZi;
+            double* T2 = sm + B.oT2;
+            s1_mm(B.n, wave, lane, 0, S1_NW, tb,
+               [&](int i, int kk) S1_INL { return T1[i * p + kk]; }, [&](int kk, int j) S1_INL { return Zi[kk * p + j]; },
+               [&](int i, int j, double v) S1_INL { T2[i * p + j] = v; });
+         }
+      }
+      __syncthreads();
+      /* S0 = sum <B, X B Zinv> + sum (x / z) beta^2 (factored form: a sum of non-negative terms) */
+      {
+         double s = 0.0;
+         for (int k = 0; k < K; ++k)
+         {
+            const S1Blk& B = sh.blk[k];
+            const int n = B.n, p = B.p;
+            for (int e = tid; e < n * n; e += S1_NT)
+            {
+               const int r = s1_div(e, n), c = e - r * n;
+               s = fma(B.B[r * p + c], sm[B.oT2 + r * p + c], s);
+            }
+         }
+         for (int r = tid; r < q; r += S1_NT)
+         {
+            const double be = QV(Q_beta)[r];
+            s = fma(QV(Q_sx)[r] * be, be, s);
+         }
+         s = s1_wsum(s);
+         if ( lane == 0 )
+            sh.red[wave][RS_S0] = s;
+      }
+      __syncthreads();
+      if ( wave == 0 )
+         finish_dir(0.0, 0.0, rg);
+      __syncthreads();
+      S1_STAMP(7);
+      double dta = sh.sc[SC_DTAU], dka = sh.sc[SC_DKAPPA];
+      if ( !(fabs(dta) < 1e300) || !(fabs(dka) < 1e300) )
+      {
+         status = HS_S1_NUMERIC;
+         break;
+      }
+      make_dZ();
+      __syncthreads();
+      {
+         int tb = 0;
+         for (int k = 0; k < K; ++k)
+         {
+            const S1Blk& B = sh.blk[k];
+            const int p = B.p;
+            const double* X = sm + B.oX; const double* dZ = sm + B.odZ;
+            double* T1 = sm + B.oT1;
+            s1_mm(B.n, wave, lane, 0, S1_NW, tb,
+               [&](int i, int kk) S1_INL { return X[i * p + kk]; }, [&](int kk, int j) S1_INL { return dZ[kk * p + j]; },
+               [&](int i, int j, double v) S1_INL { T1[i * p + j] = v; });
+         }
+      }
+      __syncthreads();
+      {
+         int tb = 0;
+         for (int k = 0; k < K; ++k)
+         {
+            const S1Blk& B = sh.blk[k];
+            const int p = B.p;
+            const double* T1 = sm + B.oT1; const double* Zi = sm + B.oZi;
+            double* T2 = sm + B.oT2;
+            s1_mm(B.n, wave, lane, 0, S1_NW, tb,
+               [&](int i, int kk) S1_INL { return T1[i * p + kk]; }, [&](int kk, int j) S1_INL { return Zi[kk * p + j]; },
+               [&](int i, int j, double v) S1_INL { T2[i * p + j] = v; });
+         }
+      }
+      __syncthreads();
+      dir_matrix(0.0, 1.0, QV(Q_dz), false, QV(Q_dx));          /* dXa, dxa */
+      __syncthreads();
+      /* second-order terms E = dXa dZa, elp = dxa dza; then the predictor's step length */
+      {
+         int tb = 0;
+         for (int k = 0; k < K; ++k)
+         {
+            const S1Blk& B = sh.blk[k];
+            const int p = B.p;
+            const double* dX = sm + B.odX; const double* dZ = sm + B.odZ;
+            double* E = B.E;
+            s1_mm(B.n, wave, lane, 0, S1_NW, tb,
+               [&](int i, int kk) S1_INL { return dX[i * p + kk]; }, [&](int kk, int j) S1_INL { return dZ[kk * p + j]; },
+               [&](int i, int j, double v) S1_INL { E[i * p + j] = v; });
+         }
+         for (int r = tid; r < q; r += S1_NT)
+            QV(Q_elp)[r] = QV(Q_dx)[r] * QV(Q_dz)[r];
+      }
+      const double aa = fmin(1.0, steplen(false));
+      S1_STAMP(8);
+      if ( !(aa == aa) )
+      {
+         status = HS_S1_NUMERIC;
+         break;
+      }
+      sigma = (1.0 - aa) * (1.0 - aa) * (1.0 - aa);
+      sigma = fmin(1.0, fmax(sigma_floor, sigma));
+      eta = 1.0 - sigma;
+      const double sigmu = sigma * mu;
+      const double etk = dta * dka;
+
+      /* ================= corrector */
+      {
+         int tb = 0;
+         for (int k = 0; k < K; ++k)
+         {
+            const S1Blk& B = sh.blk[k];
+            const int p = B.p;
+            const double* X = sm + B.oX; const double* Rd = B.Rd; const double* E = B.E;
+            double* T1 = sm + B.oT1;
+            const double et = eta;
+            s1_mm(B.n, wave, lane, 0, S1_NW, tb,
+               [&](int i, int kk) S1_INL { return X[i * p + kk]; }, [&](int kk, int j) S1_INL { return Rd[kk * p + j]; },
+               [&](int i, int j, double v) S1_INL { T1[i * p + j] = fma(et, v, E[i * p + j]); });
+         }
+      }
+      __syncthreads();
+      {
+         int tb = 0;
+         for (int k = 0; k < K; ++k)
+         {
+            const S1Blk& B = sh.blk[k];
+            const int p = B.p;
+            const double* T1 = sm + B.oT1; const double* Zi = sm + B.oZi;
+            double* T2 = sm + B.oT2;
+            s1_mm(B.n, wave, lane, 0, S1_NW, tb,
+               [&](int i, int kk) S1_INL { return T1[i * p + kk]; }, [&](int kk, int j) S1_INL { return Zi[kk * p + j]; },
+               [&](int i, int j, double v) S1_INL { T2[i * p + j] = v; });
+         }
+      }
+      __syncthreads();
+      dir_matrix(sigmu, eta, QV(Q_rd), true, QV(Q_hl));
+      __syncthreads();
+      pass_A(true, QV(Q_hl), VEC(V_AH));
+      bh_partials();
+      __syncthreads();
+      if ( wave == 0 )
+         finish_dir(sigmu, etk, rg);
+      __syncthreads();
+      S1_STAMP(9);
+      const double dt = sh.sc[SC_DTAU], dk = sh.sc[SC_DKAPPA];
+      if ( !(fabs(dt) < 1e300) || !(fabs(dk) < 1e300) )
+      {
+         status = HS_S1_NUMERIC;
+         break;
+      }
+      make_dZ();
+      __syncthreads();
+      {
+         int tb = 0;
+         for (int k = 0; k < K; ++k)
+         {
+            const S1Blk& B = sh.blk[k];
+            const int p = B.p;
+            const double* X = sm + B.oX; const double* dZ = sm + B.odZ; const double* E = B.E;
+            double* T1 = sm + B.oT1;
+            s1_mm(B.n, wave, lane, 0, S1_NW, tb,
+               [&](int i, int kk) S1_INL { return X[i * p + kk]; }, [&](int kk, int j) S1_INL { return dZ[kk * p + j]; },
+               [&](int i, int j, double v) S1_INL { T1[i * p + j] = v + E[i * p + j]; });
+         }
+      }
+      __syncthreads();
+      {
+         int tb = 0;
+         for (int k = 0; k < K; ++k)
+         {
+            const S1Blk& B = sh.blk[k];
+            const int p = B.p;
+            const double* T1 = sm + B.oT1; const double* Zi = sm + B.oZi;
+            double* T2 = sm + B.oT2;
+            s1_mm(B.n, wave, lane, 0, S1_NW, tb,
+               [&](int i, int kk) S1_INL { return T1[i * p + kk]; }, [&](int kk, int j) S1_INL { return Zi[kk * p + j]; },
+               [&](int i, int j, double v) S1_INL { T2[i * p + j] = v; });
+         }
+      }
+      __syncthreads();
+      dir_matrix(sigmu, 1.0, QV(Q_dz), true, QV(Q_dx));
+      __syncthreads();
+      const double amax = steplen(true);
+      S1_STAMP(10);
+      double alpha = fmin(1.0, gamma_eff * amax);
+      if ( !(alpha == alpha) || !(fabs(alpha) < 1e300) )
+      {
+         status = HS_S1_NUMERIC;
+         break;
+      }
+      if ( P.hist != NULL && tid == 0 && it < P.hist_len )
+      {
+         double* h = P.hist + 12 * it;
+         h[9] = aa; h[10] = alpha; h[11] = dt;
+      }
+
+      /* ================= step, with a Cholesky check of the new X and Z (halved on failure) */
+      bool accepted = false;
+      for (int attempt = 0; attempt < 8; ++attempt)
+      {
+         const int ff = trial_factor(alpha, false);
+         if ( ff == 0 )
+         {
+            accepted = true;
+            break;
+         }
+         alpha *= 0.5;
+         ++chol_fail;
+      }
+      if ( !accepted )
+      {
+         status = HS_S1_NUMERIC;
+         factors_valid = false;
+         break;
+      }
+      for (int k = 0; k < K; ++k)
+      {
+         const S1Blk& B = sh.blk[k];
+         const int n = B.n, p = B.p;
+         for (int e = tid; e < n * n; e += S1_NT)
+         {
+            const int r = s1_div(e, n), c = e - r * n;
+            sm[B.oX + r * p + c] = fma(alpha, B.E[r * p + c], sm[B.oX + r * p + c]);
+            B.Z[r * p + c] = fma(alpha, B.B[r * p + c], B.Z[r * p + c]);
+         }
+      }
+      if ( tid < m )
+         VEC(V_y)[tid] = fma(alpha, VEC(V_dy)[tid], VEC(V_y)[tid]);
+      for (int r = tid; r < q; r += S1_NT)
+      {
+         QV(Q_x)[r] = fma(alpha, QV(Q_dx)[r], QV(Q_x)[r]);
+         QV(Q_z)[r] = fma(alpha, QV(Q_dz)[r], QV(Q_z)[r]);
+      }
+      __syncthreads();
+      if ( tid == 0 )
+      {
+         sh.sc[SC_TAU] = tau + alpha * dt;
+         sh.sc[SC_KAPPA] = kappa + alpha * dk;
+      }
+      factors_valid = true;
+      alpha_last = alpha;
+      __syncthreads();
+      S1_STAMP(11);
+   }
+
+   /* ---- results: the iterate as it is (the caller scales by 1 / tau or normalises the ray), one block of scalars */
+   __syncthreads();
+   if ( tid < m ) P.y[tid] = VEC(V_y)[tid];
+   for (int r = tid; r < q; r += S1_NT)
+   {
+      P.x[r] = QV(Q_x)[r];
+      P.z[r] = QV(Q_z)[r];
+   }
+   for (int k = 0; k < K; ++k)
+   {
+      const S1Blk& B = sh.blk[k];
+      const int n = B.n, p = B.p;
+      for (int e = tid; e < n * n; e += S1_NT)
+      {
+         const int r = s1_div(e, n), c = e - r * n;
+         P.X[k][e] = sm[B.oX + r * p + c];
+         P.Z[k][e] = B.Z[r * p + c];
+      }
+   }
+   __threadfence_system();
+   __syncthreads();
+   if ( tid == 0 )
+   {
+      out[1] = (double) it; out[2] = pobj; out[3] = dobj; out[4] = pinf; out[5] = dinf; out[6] = dabs_; out[7] = gap; out[8] = mu;
+      out[9] = sh.sc[SC_TAU]; out[10] = sh.sc[SC_KAPPA]; out[11] = (double) chol_fail; out[12] = (double) warm;
+      out[13] = (double) pre_valid; out[14] = pre_scale; out[15] = normb; out[16] = normC;
+      out[17] = (double) (clock64() - t_start);
+      out[43] = (double) (wall_clock64() - w_start);
+      for (int i = 0; i < 16; ++i)
+         out[18 + i] = sh.prof[i];
+      out[40] = (double) sh.fl[2]; out[41] = (double) sh.fl[3];
+      out[42] = (double) (((size_t) (void*) sh.blk[0].vval) >> 32);
+      out[0] = (double) status;
+      __threadfence_system();
+      if ( P.flag != NULL )
+         __hip_atomic_store(P.flag, P.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+   }
+}
+
+}
+
+static hs_attr_mask s1_attr_done;
+
+int hs_solve1_launch(hipStream_t st, const hs_solve1_args* a)
+{
+   HS_CALL( hs_func_max_lds(reinterpret_cast<const void*>(&k_solve1), S1_DYN_LDS, &s1_attr_done) );
+   hipLaunchKernelGGL(k_solve1, dim3(1), dim3(S1_NT), S1_DYN_LDS, st, *a);
+   if ( hipGetLastError() != hipSuccess )
+      return HS_ERR_HIP;
+   return HS_OK;
+}
