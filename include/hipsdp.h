@@ -153,8 +153,8 @@ HIPSDP_API int  hipsdp_solve(hipsdp_solver* solver, const hipsdp_params* params,
 /* B&B-sized problems (every block <= 64 rows, m <= 64, few nonzeros per matrix) are solved by ONE launch of one workgroup
  * (csrc/solve1.hip; HIPSDP_SOLVE1=0 switches it off).  hipsdp_solve_path: 1 when the last solve ran there, 0 the general path.
  * hipsdp_solve1_trace: scalars of the last one-launch solve - out[0..63] (status, iterations, ..., device cycles per phase; see
- * csrc/solve1.hip) and, with HIPSDP_SOLVE1_HIST=1 in the environment, up to maxrows rows of 12 doubles per iteration
- * (it, mu, pinf, dinf, gap, tau, kappa, pobj, dobj, predictor step, step, dtau) - what the parity tests compare with the oracle's
+ * csrc/solve1.hip) and, with HIPSDP_SOLVE1_HIST=1 in the environment, up to maxrows rows of 16 doubles per iteration
+ * (it, mu, pinf, dinf, gap, tau, kappa, pobj, dobj, predictor step, step, dtau, residual of the linearised primal equation, forced pivots, |dy|, |h|) - what the parity tests compare with the oracle's
  * history.  Either pointer may be NULL. */
 HIPSDP_API int  hipsdp_solve_path(hipsdp_solver* solver);
 HIPSDP_API int  hipsdp_solve1_trace(hipsdp_solver* solver, double* out64, int maxrows, double* hist);

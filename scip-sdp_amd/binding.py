@@ -198,7 +198,7 @@ class Solver:
 
     def solve1_trace(self, rows=0):
         out = np.zeros(64)
-        hist = np.zeros((max(rows, 1), 12))
+        hist = np.zeros((max(rows, 1), 16))
         _chk(lib().hipsdp_solve1_trace(self.h, _dp(out), rows, _dp(hist) if rows else None), "hipsdp_solve1_trace")
         return out, hist[:rows]
 

@@ -2251,10 +2251,9 @@ static int solve1_try(hipsdp_solver* s, hipsdp_info* info, bool* done)
 {
    *done = false;
    s->s1_last = 0;
-   static int on = -1;
-   static double maxwork = 3e6;
-   static int prof = 0;
-   if ( on < 0 )
+   /* (read at every solve: tests and tools switch the path between two solves of one process) */
+   int on = 1, prof = 0;
+   double maxwork = 3e6;
    {
       const char* env = getenv("HIPSDP_SOLVE1");
       on = (env != NULL && env[0] == '0') ? 0 : 1;
@@ -2295,7 +2294,7 @@ static int solve1_try(hipsdp_solver* s, hipsdp_info* info, bool* done)
    }
    if ( s->s1_host == NULL )
    {
-      HS_HIP( hipHostMalloc((void**) &s->s1_host, (size_t) (HS_S1_OUT_DOUBLES + 8 + 12 * S1_HIST_MAX) * sizeof(double),
+      HS_HIP( hipHostMalloc((void**) &s->s1_host, (size_t) (HS_S1_OUT_DOUBLES + 8 + 16 * S1_HIST_MAX) * sizeof(double),
             hipHostMallocMapped | hipHostMallocCoherent) );
       HS_HIP( hipHostGetDevicePointer((void**) &s->s1_host_dev, s->s1_host, 0) );
       memset(s->s1_host, 0, (size_t) (HS_S1_OUT_DOUBLES + 8) * sizeof(double));
@@ -2329,6 +2328,7 @@ static int solve1_try(hipsdp_solver* s, hipsdp_info* info, bool* done)
       a.pivot_rule = env != NULL ? atoi(env) : 3;
    }
    a.prof_on = prof;
+   a.refine = (getenv("HIPSDP_SOLVE1_REFINE") != NULL && getenv("HIPSDP_SOLVE1_REFINE")[0] == '1') ? 1 : 0;
    a.gws = s->s1_ws; a.gws_len = s->s1_ws_len;
    a.out = s->s1_host_dev;
    a.hist = getenv("HIPSDP_SOLVE1_HIST") != NULL ? s->s1_host_dev + HS_S1_OUT_DOUBLES + 8 : NULL;
@@ -3428,7 +3428,7 @@ extern "C" int hipsdp_solve1_trace(hipsdp_solver* s, double* out64, int maxrows,
    if ( out64 != NULL )
       memcpy(out64, s->s1_host, HS_S1_OUT_DOUBLES * sizeof(double));
    if ( hist != NULL && maxrows > 0 )
-      memcpy(hist, s->s1_host + HS_S1_OUT_DOUBLES + 8, (size_t) (maxrows < S1_HIST_MAX ? maxrows : S1_HIST_MAX) * 12 * sizeof(double));
+      memcpy(hist, s->s1_host + HS_S1_OUT_DOUBLES + 8, (size_t) (maxrows < S1_HIST_MAX ? maxrows : S1_HIST_MAX) * 16 * sizeof(double));
    return HIPSDP_OK;
 }
 

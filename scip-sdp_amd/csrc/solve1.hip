@@ -41,7 +41,7 @@
 #define S1_STATIC_LDS 5632                                  /* bytes kept for the static arrays below */
 #define S1_DYN_LDS (160 * 1024 - S1_STATIC_LDS)
 #define S1_NRED 24
-#define S1_LIGHT_MAX 8                                        /* a matrix with at most this many entries (row >= col) is "light" */
+#define S1_LIGHT_MAX 24                                       /* a matrix with at most this many entries (both triangles) is "light" */
 /* every lambda of the kernel is inlined: a lambda that stays a function keeps what it captures by reference in scratch memory */
 #define S1_INL __attribute__((always_inline))
 #define S1_WSYNC() do { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); } while (0)
@@ -121,8 +121,9 @@ long long hs_solve1_ws_doubles(int m, int q, int nblk, const int* n)
       const long long nn = n[k], np = nn * (nn | 1), n2 = nn * nn, nlow = nn * (nn + 1) / 2;
       t += 4 * np + 8;
       t += (m1 + 2) / 2 + 1 + (n2 + 2) / 2 + 1;                      /* voff, poff (ints) */
-      t += 2 * (m1 * nlow + 2) + (m1 * nlow + 2) / 2 + (m1 * nlow + 4) / 4 + 8;      /* vval, pval, vpq (u32), pvar (u16) */
+      t += (m1 * n2 + 2) + (m1 * nlow + 2) + (m1 * n2 + 2) / 2 + (m1 * nlow + 4) / 4 + 8;      /* vval, pval, vpq (u32), pvar (u16) */
       t += 2 * ((m1 + 3) / 4 + 2);                                  /* lv, hv */
+      t += (m1 + 2) / 2 + 2 + (m1 * S1_LIGHT_MAX + 3) / 4 + 2 + (m1 * S1_LIGHT_MAX + 2) / 2 + 2 + m1 * S1_LIGHT_MAX * nn + 4;      /* lro, lrp, lre, Tc */
    }
    t += (q + 2) / 2 + 1 + (m1 + 2) / 2 + 1;
    t += 2 * ((long long) q * m1 + 2) + 2 * (((long long) q * m1 + 4) / 4) + 8;
@@ -191,9 +192,12 @@ struct S1Blk
    int n, p, np, G;
    int oX, oZi, oLx, oLz, odX, odZ, oT1, oT2, oEig;
    double *Z, *Rd, *E, *B;                                       /* cold matrices, pitch p (flat: LDS or workspace) */
-   int* voff; unsigned* vpq; double* vval;                        /* by variable: entries with row >= col, vpq = row << 16 | col */
+   int* voff; unsigned* vpq; double* vval;                        /* by variable: ALL entries (both triangles) in row-major order, vpq = row << 16 | col */
    int* poff; unsigned short* pvar; double* pval;                 /* by position r * n + c (r >= c): the variables that touch it */
    unsigned short* lv; unsigned short* hv; int nl, nh;            /* variables with few ("light") and many nonzeros in this block */
+   /* rows of the light matrices: variable lv[a] has the row slots lro[a] .. lro[a + 1]; slot s is row lrp[s] of its matrix, whose
+    * entries are the lre[s] & 63 entries from lre[s] >> 6 on of the variable-major list; Tc[s * n + c] = (A_j Zinv)[row][c] */
+   int* lro; unsigned short* lrp; int* lre; double* Tc; int nrs;
 };
 
 struct S1Sh
@@ -298,11 +302,12 @@ __device__ __forceinline__ double s1_rcp(double t)
  * psd: semidefinite pivot rule of oracle/ipm_ref.chol_psd (dg0 = this lane's original diagonal entry).  keepdiag = false: the
  * stored factor has a ZERO diagonal and zero upper triangle (what the substitutions below want), the diagonal entry of row
  * `lane` is returned in mydiag.  Returns 0 or 1 + index of the first non-positive pivot (definite mode). */
-__device__ __forceinline__ int s1_cholp(double* A, int n, int p, int lane, bool psd, double dg0, int rule, bool keepdiag, double& mydiag)
+__device__ __forceinline__ int s1_cholp(double* A, int n, int p, int lane, bool psd, double dg0, int rule, bool keepdiag, double& mydiag, int& nforced)
 {
    const double regtol = 1e-13;
    const int lr = lane & 15, kq = lane >> 4;
    mydiag = 1.0;
+   nforced = 0;
    for (int k0 = 0; k0 < n; k0 += 8)
    {
       if ( k0 > 0 )
@@ -353,6 +358,7 @@ __device__ __forceinline__ int s1_cholp(double* A, int n, int p, int lane, bool 
                {
                   zero = (rule == 1) || (rule == 2 && !(d > 0.0)) || (rule == 3 && !(d > 1.78e-15 * (double) (k + 1) * mkk));
                   d = (mkk > 1e-280) ? regtol * mkk : 1.0;
+                  nforced += zero ? 65536 : 1;
                }
             }
             else if ( !(d > 0.0) )
@@ -377,50 +383,101 @@ __device__ __forceinline__ int s1_cholp(double* A, int n, int p, int lane, bool 
  * s1_cholp(keepdiag = false) leaves it (strictly lower, zero diagonal and upper triangle, pitch p >= 8 ceil(m / 8)), dinv = 1 /
  * (diagonal entry of this lane's row).  In: x0, x1 = this lane's entries of the right-hand sides; out: of the solutions.  The
  * columns of eight steps are loaded ahead of the recurrence, whose steps are a multiply, a v_readlane pair and a multiply-add. */
-__device__ __forceinline__ void s1_llt_solve(const double* L, int m, int p, int lane, double dinv, bool two, double& x0, double& x1)
+__device__ __forceinline__ void s1_llt_solve(const double* L, int m, int p, int lane, double dinv, double diag, bool two, bool refine,
+   double& x0, double& x1)
 {
-   double a0 = (lane < m) ? x0 : 0.0, a1 = (lane < m && two) ? x1 : 0.0;
-   for (int k0 = 0; k0 < m; k0 += 8)
+   const double r0 = (lane < m) ? x0 : 0.0, r1 = (lane < m && two) ? x1 : 0.0;
+   /* forward substitution of (a0, a1) in place: on return a = L^-1 a */
+   auto fwd = [&](double& a0, double& a1) S1_INL
    {
-      double c[8];
+      for (int k0 = 0; k0 < m; k0 += 8)
+      {
+         double c[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-         c[u] = (lane < m) ? L[lane * p + k0 + u] : 0.0;
+         for (int u = 0; u < 8; ++u)
+            c[u] = (lane < m) ? L[lane * p + k0 + u] : 0.0;
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-         if ( k0 + u < m )
-         {
-            const double y0 = s1_lane(a0 * dinv, k0 + u);
-            a0 = fma(-c[u], y0, a0);
-            if ( two )
+         for (int u = 0; u < 8; ++u)
+            if ( k0 + u < m )
             {
-               const double y1 = s1_lane(a1 * dinv, k0 + u);
-               a1 = fma(-c[u], y1, a1);
+               const double y0 = s1_lane(a0 * dinv, k0 + u);
+               a0 = fma(-c[u], y0, a0);
+               if ( two )
+               {
+                  const double y1 = s1_lane(a1 * dinv, k0 + u);
+                  a1 = fma(-c[u], y1, a1);
+               }
             }
-         }
-   }
-   a0 *= dinv; a1 *= dinv;
-   for (int k0 = (m - 1) & ~7; k0 >= 0; k0 -= 8)
+      }
+      a0 *= dinv; a1 *= dinv;
+   };
+   auto bwd = [&](double& a0, double& a1) S1_INL
    {
-      double c[8];
+      for (int k0 = (m - 1) & ~7; k0 >= 0; k0 -= 8)
+      {
+         double c[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-         c[u] = (lane < m && k0 + u < m) ? L[(k0 + u) * p + lane] : 0.0;
+         for (int u = 0; u < 8; ++u)
+            c[u] = (lane < m && k0 + u < m) ? L[(k0 + u) * p + lane] : 0.0;
 #pragma unroll
-      for (int u = 7; u >= 0; --u)
-         if ( k0 + u < m )
-         {
-            const double y0 = s1_lane(a0 * dinv, k0 + u);
-            a0 = fma(-c[u], y0, a0);
-            if ( two )
+         for (int u = 7; u >= 0; --u)
+            if ( k0 + u < m )
             {
-               const double y1 = s1_lane(a1 * dinv, k0 + u);
-               a1 = fma(-c[u], y1, a1);
+               const double y0 = s1_lane(a0 * dinv, k0 + u);
+               a0 = fma(-c[u], y0, a0);
+               if ( two )
+               {
+                  const double y1 = s1_lane(a1 * dinv, k0 + u);
+                  a1 = fma(-c[u], y1, a1);
+               }
             }
-         }
+      }
+      a0 *= dinv; a1 *= dinv;
+   };
+   /* products with the factor for the correction step: o = L w (trans = false) or L^T w */
+   auto lmul = [&](bool trans, double w0, double w1, double& o0, double& o1) S1_INL
+   {
+      double s0 = diag * w0, s1 = diag * w1;
+      for (int k0 = 0; k0 < m; k0 += 8)
+      {
+         double c[8];
+#pragma unroll
+         for (int u = 0; u < 8; ++u)
+            c[u] = (lane < m && k0 + u < m) ? (trans ? L[(k0 + u) * p + lane] : L[lane * p + k0 + u]) : 0.0;
+#pragma unroll
+         for (int u = 0; u < 8; ++u)
+            if ( k0 + u < m )
+            {
+               s0 = fma(c[u], s1_lane(w0, k0 + u), s0);
+               if ( two )
+                  s1 = fma(c[u], s1_lane(w1, k0 + u), s1);
+            }
+      }
+      o0 = s0; o1 = s1;
+   };
+   double a0 = r0, a1 = r1;
+   fwd(a0, a1);
+   if ( refine )
+   {
+      /* each triangular solve corrected once with the factor itself (oracle/ipm_ref.py: msolve) */
+      double t0, t1;
+      lmul(false, a0, a1, t0, t1);
+      double d0 = r0 - t0, d1 = r1 - t1;
+      fwd(d0, d1);
+      a0 += d0; a1 += d1;
    }
-   x0 = a0 * dinv;
-   x1 = a1 * dinv;
+   const double w0 = a0, w1 = a1;
+   bwd(a0, a1);
+   if ( refine )
+   {
+      double t0, t1;
+      lmul(true, a0, a1, t0, t1);
+      double d0 = w0 - t0, d1 = w1 - t1;
+      bwd(d0, d1);
+      a0 += d0; a1 += d1;
+   }
+   x0 = a0;
+   x1 = a1;
 }
 
 /* ---- one wavefront: Li = L^-1 (lower), lane = column; in place when Li == L */
@@ -680,6 +737,19 @@ __device__ __forceinline__ void s1_mm(int n, int wave, int lane, int w0, int nw,
          const int ti = t / nt, tj = t - ti * nt;
          const int ri = 16 * ti + lr, cj = 16 * tj + lr;
          v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#ifdef S1_NO_MFMA
+         /* (developer switch: the same tile with scalar multiply-adds, for accuracy comparisons) */
+         for (int k = 0; k < n; ++k)
+         {
+            const double b = (cj < n) ? lb(k, cj) : 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+            {
+               const int row = 16 * ti + kq + 4 * r;
+               acc0[r] = fma((row < n) ? la(row, k) : 0.0, b, acc0[r]);
+            }
+         }
+#else
 #pragma unroll 2
          for (int kk = 0; kk < n; kk += 8)
          {
@@ -691,6 +761,7 @@ __device__ __forceinline__ void s1_mm(int n, int wave, int lane, int w0, int nw,
             acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
          }
+#endif
 #pragma unroll
          for (int r = 0; r < 4; ++r)
          {
@@ -859,7 +930,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          {
             const int e = e0 + lane;
             const int r = s1_div(e, n), c = e - r * n;
-            const bool nz = e < n2 && r >= c && A[(long long) i * n2 + e] != 0.0;
+            const bool nz = e < n2 && A[(long long) i * n2 + e] != 0.0;
             cnt += __popcll(__ballot(nz));
          }
          if ( lane == 0 ) B.voff[i] = cnt;
@@ -903,10 +974,11 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       for (int k = 0; k < K; ++k)
       {
          S1Blk& B = sh.blk[k];
-         const int nz = B.voff[m1];
-         nnzA += nz;
-         B.vval = take(nz); B.pval = take(nz);
-         B.vpq = (unsigned*) take((nz + 1) / 2); B.pvar = (unsigned short*) take((nz + 3) / 4);
+         const int nz = B.voff[m1];                       /* entries of all matrices, both triangles */
+         const int nzl = B.poff[B.n * B.n];                /* entries with row >= col */
+         nnzA += nzl;
+         B.vval = take(nz); B.pval = take(nzl);
+         B.vpq = (unsigned*) take((nz + 1) / 2); B.pvar = (unsigned short*) take((nzl + 3) / 4);
          B.lv = (unsigned short*) take((m1 + 3) / 4); B.hv = (unsigned short*) take((m1 + 3) / 4);
          /* light variables go through the pair formula (a thread per pair), heavy ones through U_j = X A_j Zinv */
          int nl = 0, nh = 0, nzh = 0;
@@ -919,7 +991,16 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
             else { B.hv[nh++] = (unsigned short) i; nzh += c; }
          }
          B.nl = nl; B.nh = nh;
-         work += 2.0 * (double) nzh * (double) (B.n * B.n) + 2.0 * (double) nz * (double) nh + 32.0 * (double) nl * (double) nl;
+         B.lro = (int*) take((nl + 2) / 2 + 1);
+         int nzlight = 0;
+         for (int a = 0; a < nl; ++a)
+            nzlight += B.voff[B.lv[a] + 1] - B.voff[B.lv[a]];
+         B.lrp = (unsigned short*) take((nzlight + 3) / 4 + 1);
+         B.lre = (int*) take((nzlight + 2) / 2 + 1);
+         B.Tc = take((long long) nzlight * B.n + 2);
+         B.nrs = 0;
+         work += (double) nzh * (double) B.n + (double) nh * (double) B.n * (double) (B.n * B.n) + (double) nz * (double) nh
+            + 0.5 * (double) (nz - nzh) * (double) (nz - nzh) * 1.5;
       }
       sh.fl[1] = (work > P.maxwork) ? 1 : 0;
       sh.fl[2] = nnzA; sh.fl[3] = nnzD;
@@ -986,7 +1067,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          {
             const int e = e0 + lane;
             const int r = s1_div(e, n), c = e - r * n;
-            const double v = (e < n2 && r >= c) ? A[(long long) i * n2 + e] : 0.0;
+            const double v = (e < n2) ? A[(long long) i * n2 + e] : 0.0;
             const unsigned long long msk = __ballot(v != 0.0);
             if ( v != 0.0 )
             {
@@ -1014,6 +1095,49 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
             }
          }
       }
+   }
+   __syncthreads();
+   /* row slots of the light matrices */
+   for (int k = 0; k < K; ++k)
+   {
+      S1Blk& B = sh.blk[k];
+      for (int a = tid; a < B.nl; a += S1_NT)
+      {
+         const int i = B.lv[a];
+         int cnt = 0, prev = -1;
+         for (int t = B.voff[i]; t < B.voff[i + 1]; ++t)
+         {
+            const int pp = (int) (B.vpq[t] >> 16);
+            if ( pp != prev ) { ++cnt; prev = pp; }
+         }
+         B.lro[a] = cnt;
+      }
+      __syncthreads();
+      s1_exscan(B.lro, B.nl, sh, tid);
+      for (int a = tid; a < B.nl; a += S1_NT)
+      {
+         const int i = B.lv[a];
+         int sidx = B.lro[a] - 1, prev = -1, start = 0, len = 0;
+         for (int t = B.voff[i]; t < B.voff[i + 1]; ++t)
+         {
+            const int pp = (int) (B.vpq[t] >> 16);
+            if ( pp != prev )
+            {
+               if ( prev >= 0 )
+                  B.lre[sidx] = (start << 6) | len;
+               ++sidx;
+               B.lrp[sidx] = (unsigned short) pp;
+               start = t; len = 0;
+               prev = pp;
+            }
+            ++len;
+         }
+         if ( prev >= 0 )
+            B.lre[sidx] = (start << 6) | len;
+      }
+      if ( tid == 0 )
+         B.nrs = B.lro[B.nl];
+      __syncthreads();
    }
    /* objective, norms */
    if ( tid < m )
@@ -1107,8 +1231,8 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       for (int t = wave; t < 2 * K; t += S1_NW)
       {
          const S1Blk& B = sh.blk[t >> 1];
-         double dummy;
-         const int f = s1_cholp(sm + ((t & 1) ? B.oLz : B.oLx), B.n, B.p, lane, false, 1.0, 0, true, dummy);
+         double dummy; int nfd;
+         const int f = s1_cholp(sm + ((t & 1) ? B.oLz : B.oLx), B.n, B.p, lane, false, 1.0, 0, true, dummy, nfd);
          if ( lane == 0 )
             sh.fl[8 + t] = f;
       }
@@ -1247,7 +1371,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
             {
                const unsigned pq = B.vpq[t];
                const int pp = (int) (pq >> 16), qq = (int) (pq & 0xffffu);
-               s = fma(B.vval[t] * (pp == qq ? 1.0 : 2.0), V[pp * B.p + qq], s);
+               s = fma(B.vval[t], V[pp * B.p + qq], s);
             }
          }
          {
@@ -1281,13 +1405,13 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
    /* wavefront 0: x = M^-1 r for one or two right-hand sides (LDS vectors) by substitution with the factor of M; mdinv: this
     * lane's 1 / diagonal entry of the factor.  [The oracle corrects each triangular solve once with the factor itself because the
     * engine's general path solves with explicit inverses of diagonal blocks; a substitution has the small residual by itself.] */
-   double mdinv = 1.0;
+   double mdinv = 1.0, mdiagv = 1.0;
    auto msolve2 = [&](const double* r0, const double* r1, double* o0, double* o1) S1_INL
    {
       const bool two = (r1 != NULL);
       double x0 = (lane < m) ? r0[lane] : 0.0;
       double x1 = (two && lane < m) ? r1[lane] : 0.0;
-      s1_llt_solve(Lm, m, pm, lane, mdinv, two, x0, x1);
+      s1_llt_solve(Lm, m, pm, lane, mdinv, mdiagv, two, P.refine != 0, x0, x1);
       if ( lane < m )
       {
          o0[lane] = x0;
@@ -1569,7 +1693,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       gap = fabs(dobj - pobj) / tau;
       if ( P.hist != NULL && tid == 0 && it < P.hist_len )
       {
-         double* h = P.hist + 12 * it;
+         double* h = P.hist + 16 * it;
          h[0] = it; h[1] = mu; h[2] = pinf; h[3] = dinf; h[4] = gap; h[5] = tau; h[6] = kappa; h[7] = pobj; h[8] = dobj;
       }
       S1_STAMP(2);
@@ -1773,67 +1897,105 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       S1_STAMP(4);
 
       /* ================= Schur complement from the nonzeros: U_j = X A_j Zinv (G of them side by side), Mx[i][j] += <A_i, U_j> */
+      /* Schur complement from the nonzeros, in the association of the dense formula: T_j = A_j Zinv (row p of T_j: sum over the
+       * entries of row p of A_j), U_j = X T_j (sum over the non-empty rows), M_ij = sum over the entries (a, b) of A_i of
+       * A_i[a][b] U_j[b][a] - zeros skipped, nothing else changed.  [The pair formula of csrc/sparse.hip, a b (X_qr Zinv_sp + ...),
+       * and a sum of rank-one terms a X[:, p] Zinv[q, :] are the same numbers in exact arithmetic but leave the linearised primal
+       * equation violated 300 times more on nodes without an optimum (tau -> 0, cond(Z) 1e5: 2e-7 against 5e-10, measured on
+       * example_TT's infeasible nodes with tests/devtools/solve1_node.py): Zinv is almost of rank one there, the differences
+       * Zinv[q][c] - Zinv[q'][c] a constraint matrix asks for must be formed BEFORE they meet X, as the products X dZ Zinv of the
+       * direction form them.] */
       for (int k = 0; k < K; ++k)
       {
          const S1Blk& B = sh.blk[k];
-         const int n = B.n, p = B.p, n2 = n * n, G = B.G;
-         const int gsz = S1_NT / G;
-         const int g = tid / gsz, tig = tid - g * gsz;
-         double* U = sm + L.oR + g * B.np;
+         const int n = B.n, p = B.p, n2 = n * n;
          const double* X = sm + B.oX;
          const double* Zi = sm + B.oZi;
-         /* heavy variables j: U_j = X A_j Zinv as a sum of rank-one terms per nonzero, then <A_i, U_j> for every i (a heavy i only
-          * from j on: the pair of two heavy variables is formed once) */
+         /* heavy variables j: T_j and U_j as whole matrices in the scratch region (two buffers per j, G2 of them side by side) */
          const int nh = B.nh;
-         for (int h0 = 0; h0 < nh; h0 += G)
+         if ( nh > 0 )
          {
-            const int j = (h0 + g < nh) ? (int) B.hv[h0 + g] : -1;
-            if ( j >= 0 )
+            int G2 = B.G >> 1;
+            if ( G2 < 1 ) G2 = 1;
+            const int gsz = S1_NT / G2;
+            const int g = tid / gsz, tig = tid - g * gsz;
+            double* T = sm + L.oR + (2 * g) * B.np;
+            double* U = T + B.np;
+            for (int h0 = 0; h0 < nh; h0 += G2)
             {
-               const int t0 = B.voff[j], t1 = B.voff[j + 1];
-               for (int e = tig; e < n2; e += gsz)
+               const int j = (h0 + g < nh) ? (int) B.hv[h0 + g] : -1;
+               if ( j >= 0 )
                {
-                  const int r = s1_div(e, n), c = e - r * n;
-                  double s0 = 0.0;
-                  for (int t = t0; t < t1; ++t)
+                  /* T = A_j Zinv: thread c owns column c and walks the entries in row-major order */
+                  const int t0 = B.voff[j], t1 = B.voff[j + 1];
+                  for (int c = tig; c < n; c += gsz)
                   {
-                     const unsigned pq = B.vpq[t];
-                     const int pp = (int) (pq >> 16), qq = (int) (pq & 0xffffu);
-                     const double a = B.vval[t];
-                     double term = X[r * p + pp] * Zi[qq * p + c];
-                     if ( pp != qq )
-                        term = fma(X[r * p + qq], Zi[pp * p + c], term);
-                     s0 = fma(a, term, s0);
+                     for (int r = 0; r < n; ++r)
+                        T[r * p + c] = 0.0;
+                     for (int t = t0; t < t1; ++t)
+                     {
+                        const unsigned pq = B.vpq[t];
+                        const int pp = (int) (pq >> 16), qq = (int) (pq & 0xffffu);
+                        T[pp * p + c] = fma(B.vval[t], Zi[qq * p + c], T[pp * p + c]);
+                     }
                   }
-                  U[r * p + c] = s0;
                }
-            }
-            __syncthreads();
-            if ( j >= 0 )
-            {
-               for (int i = tig; i < m1; i += gsz)
-               {
-                  const int t0 = B.voff[i], t1 = B.voff[i + 1];
-                  if ( t1 == t0 || (t1 - t0 > S1_LIGHT_MAX && i < j) )
-                     continue;
-                  double s0 = 0.0;
-                  for (int t = t0; t < t1; ++t)
+               __syncthreads();
+               if ( j >= 0 )
+                  for (int e = tig; e < n2; e += gsz)
                   {
-                     const unsigned pq = B.vpq[t];
-                     const int pp = (int) (pq >> 16), qq = (int) (pq & 0xffffu);
-                     double term = U[pp * p + qq];
-                     if ( pp != qq )
-                        term += U[qq * p + pp];
-                     s0 = fma(B.vval[t], term, s0);
+                     const int r = s1_div(e, n), c = e - r * n;
+                     double s0 = 0.0;
+                     for (int kk = 0; kk < n; ++kk)
+                        s0 = fma(X[r * p + kk], T[kk * p + c], s0);
+                     U[r * p + c] = s0;
                   }
-                  Mx[(i >= j) ? i * pm1 + j : j * pm1 + i] += s0;
-               }
+               __syncthreads();
+               if ( j >= 0 )
+                  for (int i = tig; i < m1; i += gsz)
+                  {
+                     const int t0 = B.voff[i], t1 = B.voff[i + 1];
+                     if ( t1 == t0 || (t1 - t0 > S1_LIGHT_MAX && i < j) )
+                        continue;
+                     double s0 = 0.0;
+                     for (int t = t0; t < t1; ++t)
+                     {
+                        const unsigned pq = B.vpq[t];
+                        const int pp = (int) (pq >> 16), qq = (int) (pq & 0xffffu);
+                        s0 = fma(B.vval[t], U[qq * p + pp], s0);
+                     }
+                     Mx[(i >= j) ? i * pm1 + j : j * pm1 + i] += s0;
+                  }
+               __syncthreads();
             }
-            __syncthreads();
          }
-         /* pairs of light variables: a thread per pair, the pair formula over their nonzeros (SDPA's F3 case; csrc/sparse.hip:
-          * k_sp_schur) - e = (p, q, a) in A_i, f = (r, s, b) in A_j, lower triangles standing for both positions:
-          * a b (X_qr Zi_sp + [p != q] X_pr Zi_sq + [r != s] X_qs Zi_rp + [p != q][r != s] X_ps Zi_rq) */
+      }
+      /* light matrices: (a) T_j = A_j Zinv, only the non-empty rows, for all of them at once ... */
+      for (int k = 0; k < K; ++k)
+      {
+         const S1Blk& B = sh.blk[k];
+         const int n = B.n, p = B.p;
+         const double* Zi = sm + B.oZi;
+         const int nrs = B.nrs;
+         for (int idx = tid; idx < nrs * n; idx += S1_NT)
+         {
+            const int sl = s1_div(idx, n), c = idx - sl * n;
+            const int packed = B.lre[sl];
+            const int e0 = packed >> 6, len = packed & 63;
+            double tacc = 0.0;
+            for (int e = e0; e < e0 + len; ++e)
+               tacc = fma(B.vval[e], Zi[(int) (B.vpq[e] & 0xffffu) * p + c], tacc);
+            B.Tc[idx] = tacc;
+         }
+      }
+      __syncthreads();
+      /* ... (b) a thread per pair i >= j: M_ij = sum over the entries (a, b) of A_i of A_i[a][b] (X T_j)[b][a], the product with X
+       * over the non-empty rows of T_j only */
+      for (int k = 0; k < K; ++k)
+      {
+         const S1Blk& B = sh.blk[k];
+         const int n = B.n, p = B.p;
+         const double* X = sm + B.oX;
          const int nl = B.nl;
          for (int t = tid; t < nl * nl; t += S1_NT)
          {
@@ -1841,32 +2003,19 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
             if ( ib > ia )
                continue;
             const int i = B.lv[ia], j = B.lv[ib];
-            const int e0 = B.voff[i], e1 = B.voff[i + 1], f0 = B.voff[j], f1 = B.voff[j + 1];
-            double s0 = 0.0;
+            const int e0 = B.voff[i], e1 = B.voff[i + 1];
+            const int s0i = B.lro[ib], s1i = B.lro[ib + 1];
+            double acc = 0.0;
             for (int e = e0; e < e1; ++e)
             {
-               const unsigned pq = B.vpq[e];
-               const int pp = (int) (pq >> 16), qq = (int) (pq & 0xffffu);
-               const double a = B.vval[e];
-               double se = 0.0;
-               for (int f = f0; f < f1; ++f)
-               {
-                  const unsigned rs = B.vpq[f];
-                  const int rr = (int) (rs >> 16), ss = (int) (rs & 0xffffu);
-                  double term = X[qq * p + rr] * Zi[ss * p + pp];
-                  if ( pp != qq )
-                     term = fma(X[pp * p + rr], Zi[ss * p + qq], term);
-                  if ( rr != ss )
-                  {
-                     term = fma(X[qq * p + ss], Zi[rr * p + pp], term);
-                     if ( pp != qq )
-                        term = fma(X[pp * p + ss], Zi[rr * p + qq], term);
-                  }
-                  se = fma(B.vval[f], term, se);
-               }
-               s0 = fma(a, se, s0);
+               const unsigned ab = B.vpq[e];
+               const int aa_ = (int) (ab >> 16), bb_ = (int) (ab & 0xffffu);
+               double u = 0.0;
+               for (int sl = s0i; sl < s1i; ++sl)
+                  u = fma(X[bb_ * p + (int) B.lrp[sl]], B.Tc[sl * n + aa_], u);
+               acc = fma(B.vval[e], u, acc);
             }
-            Mx[i * pm1 + j] += s0;
+            Mx[i * pm1 + j] += acc;
          }
       }
       __syncthreads();
@@ -1889,8 +2038,12 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          }
          S1_WSYNC();
          double mdiag;
-         (void) s1_cholp(Lm, m, pm, lane, true, dg0, P.pivot_rule, false, mdiag);
+         int nforced;
+         (void) s1_cholp(Lm, m, pm, lane, true, dg0, P.pivot_rule, false, mdiag, nforced);
+         if ( lane == 0 )
+            sh.fl[6] = nforced;
          mdinv = s1_rcp(mdiag);
+         mdiagv = mdiag;
          msolve2(VEC(V_g), VEC(V_b), VEC(V_w), VEC(V_ub));
          if ( lane < m )
          {
@@ -2165,6 +2318,33 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       __syncthreads();
       dir_matrix(sigmu, 1.0, QV(Q_dz), true, QV(Q_dx));
       __syncthreads();
+      if ( P.hist != NULL )
+      {
+         /* diagnostic: how well the direction satisfies the linearised primal equation A(dX, dx) = eta rp + b dtau */
+         pass_A(true, QV(Q_dx), VEC(V_t1));
+         __syncthreads();
+         if ( wave == 0 )
+         {
+            const double e = (lane < m) ? VEC(V_t1)[lane + 1] - eta * VEC(V_rp)[lane] - VEC(V_b)[lane] * dt : 0.0;
+            const double e2 = s1_wsum(e * e);
+            const double dy2 = s1_wsum(lane < m ? VEC(V_dy)[lane] * VEC(V_dy)[lane] : 0.0);
+            /* residual of the solve itself: M dy - h + (b - g) dtau with the assembled matrix (lower triangle of Mx) */
+            double rs = 0.0;
+            if ( lane < m )
+            {
+               for (int j = 0; j < m; ++j)
+                  rs = fma((j <= lane) ? Mx[(lane + 1) * pm1 + j + 1] : Mx[(j + 1) * pm1 + lane + 1], VEC(V_dy)[j], rs);
+               rs = rs - VEC(V_h)[lane] + (VEC(V_b)[lane] - VEC(V_g)[lane]) * dt;
+            }
+            const double h2 = s1_wsum(rs * rs);
+            if ( lane == 0 && it < P.hist_len )
+            {
+               double* hh = P.hist + 16 * it;
+               hh[12] = sqrt(e2); hh[13] = (double) sh.fl[6]; hh[14] = sqrt(dy2); hh[15] = sqrt(h2);
+            }
+         }
+         __syncthreads();
+      }
       const double amax = steplen(true);
       S1_STAMP(10);
       double alpha = fmin(1.0, gamma_eff * amax);
@@ -2175,7 +2355,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       }
       if ( P.hist != NULL && tid == 0 && it < P.hist_len )
       {
-         double* h = P.hist + 12 * it;
+         double* h = P.hist + 16 * it;
          h[9] = aa; h[10] = alpha; h[11] = dt;
       }
 

@@ -67,7 +67,7 @@ for name, core, tol in problems():
     info = s.solve(gaptol=tol, feastol=tol, pabstol=10 * tol)
     path = s.solve_path()
     y = s.y()
-    out, hist = (s.solve1_trace(256) if path else (np.zeros(64), np.zeros((0, 12))))
+    out, hist = (s.solve1_trace(256) if path else (np.zeros(64), np.zeros((0, 16))))
     s.close()
     worst = 0.0; where = None
     if path:
