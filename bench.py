@@ -13,6 +13,7 @@ non-zero when any rank failed.  Rank 0 prints ONE JSON line.  The oracle (oracle
 cpu_baseline().
 """
 import argparse
+import ctypes as C
 import importlib.util
 import json
 import os
@@ -544,6 +545,8 @@ def bench_bnb(hb, cpu=True):
         row = {}
         for label, lam in (("cold", 0.0), ("warm", 0.5)):
             s, solve, stats = warm_bnb.warm_node_solver(hb.lib(), 1e-6, lam)
+            hb.lib().hipsdp_solve1_solves.restype = C.c_longlong
+            one0 = hb.lib().hipsdp_solve1_solves()
             t0 = time.perf_counter()
             best, y, nodes, failed = bnb.branch_and_bound(prob, inst.intvars, solve)
             wall = time.perf_counter() - t0
@@ -553,7 +556,10 @@ def bench_bnb(hb, cpu=True):
                           "nodes": nodes, "node_solves": stats["calls"], "unresolved_nodes": failed,
                           "ipm_iterations_per_node": stats["iters"] / calls, "warm_started_nodes": stats["warm"],
                           "node_solves_per_sec": calls / max(stats["wall"], 1e-9), "ms_per_ipm_iteration": 1e3 * stats["time"] / max(1, stats["iters"]),
-                          "engine_seconds": stats["time"], "load_and_solve_seconds": stats["wall"], "tree_wall_seconds": wall}
+                          "engine_seconds": stats["time"], "load_and_solve_seconds": stats["wall"], "tree_wall_seconds": wall,
+                          # engine solves (re-solves of the tolerance loop and ladder rungs included) that ran as ONE launch of one
+                          # workgroup (csrc/solve1.hip); the rest took the general path (dense matrices: example_CLS)
+                          "one_launch_engine_solves": int(hb.lib().hipsdp_solve1_solves() - one0)}
         if cpu:
             try:
                 sys.path.insert(0, os.path.join(ROOT, "oracle"))

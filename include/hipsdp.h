@@ -157,6 +157,7 @@ HIPSDP_API int  hipsdp_solve(hipsdp_solver* solver, const hipsdp_params* params,
  * (it, mu, pinf, dinf, gap, tau, kappa, pobj, dobj, predictor step, step, dtau, residual of the linearised primal equation, forced pivots, |dy|, |h|) - what the parity tests compare with the oracle's
  * history.  Either pointer may be NULL. */
 HIPSDP_API int  hipsdp_solve_path(hipsdp_solver* solver);
+HIPSDP_API long long hipsdp_solve1_solves(void);      /* solves of this process served by the one launch so far */
 HIPSDP_API int  hipsdp_solve1_trace(hipsdp_solver* solver, double* out64, int maxrows, double* hist);
 
 /* solution readback (host arrays).  For STATUS_OPTIMAL the iterate scaled by 1 / tau; for the infeasibility statuses

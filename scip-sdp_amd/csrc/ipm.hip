@@ -2247,6 +2247,7 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
  * solve ran there; *done = false: not this path's problem (shape, options) or the kernel declined (too much work for one compute
  * unit) - nothing has been touched and the general path below takes over.  HIPSDP_SOLVE1=0 switches the path off. */
 #define S1_HIST_MAX 256
+static long long g_solve1_solves = 0;      /* solves of this process that ran in the one launch (bench.py reports the share) */
 static int solve1_try(hipsdp_solver* s, hipsdp_info* info, bool* done)
 {
    *done = false;
@@ -2402,9 +2403,13 @@ static int solve1_try(hipsdp_solver* s, hipsdp_info* info, bool* done)
          o[43] / 100.0, o[17]);
       for (int i = 0; i < 12; ++i)
          fprintf(stderr, "%s %s %.0f", i ? "," : ":", names[i], o[18 + i]);
+      fprintf(stderr, " | sub");
+      for (int i = 12; i < 22; ++i)
+         fprintf(stderr, " %.0f", o[18 + i]);
       fprintf(stderr, " | nnz A %d, LP %d\n", (int) o[40], (int) o[41]);
    }
    s->s1_last = 1;
+   (void) __sync_add_and_fetch(&g_solve1_solves, 1);
    *done = true;
    return HS_OK;
 }
@@ -3414,6 +3419,11 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
    info->schur_seconds = schur_ms * 1e-3;
    info->solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
    return HIPSDP_OK;
+}
+
+extern "C" long long hipsdp_solve1_solves(void)
+{
+   return __sync_add_and_fetch(&g_solve1_solves, 0);
 }
 
 extern "C" int hipsdp_solve_path(hipsdp_solver* s)

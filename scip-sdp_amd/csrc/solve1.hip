@@ -531,10 +531,214 @@ __device__ __forceinline__ void s1_trinv(const double* L, double* Li, int n, int
    }
 }
 
+template<int CTRL>
+__device__ __forceinline__ double s1_dppz(double v)
+{
+   int lo = __double2loint(v), hi = __double2hiint(v);
+   lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+   return __hiloint2double(hi, lo);
+}
+
+/* ---- one wavefront: min(lambda_min, 0) of the symmetric tridiagonal matrix with diagonal d_i and off-diagonal e_i (coupling i and
+ * i + 1) held by lane i, n <= 64: Sturm multisection, 64 shifts per round, to a relative accuracy of 1e-10 (from below); NaN when
+ * an entry is not finite.  The sequence runs in product form out of REGISTERS: d_i and e_i^2 reach all lanes by v_readlane (an LDS
+ * read per step cost its latency, 100 cycles, per step: 2700 cycles per round at n = 10, now about 500). */
+template<bool SMALL>
+__device__ __forceinline__ double s1_sturm_min(double dl, double el, int n, int lane, double* tprof)
+{
+   if ( lane >= n ) { dl = 0.0; el = 0.0; }
+   if ( lane == n - 1 ) el = 0.0;
+   double eprev = __shfl_up(el, 1, 64);
+   if ( lane == 0 ) eprev = 0.0;
+   const double rad = fabs(eprev) + fabs(el);
+   const double bad = (!(fabs(dl) < 1e300) || !(fabs(el) < 1e300)) ? 1.0 : 0.0;
+   if ( s1_wmax(bad) > 0.0 )
+      return nan("");
+   const double nrm = s1_wmax((lane < n) ? fabs(dl) + rad : 0.0);
+   const double glo = s1_wmin((lane < n) ? dl - rad : 1e300);
+   if ( !(glo < 0.0) || !(nrm > 0.0) )
+      return 0.0;
+   const double sinv = 1.0 / nrm;
+   const double ds = dl * sinv;
+   const double e2 = (el * sinv) * (el * sinv);
+   if ( tprof != NULL && lane == 0 )
+      tprof[1] -= (double) clock64();
+   double lo = glo * sinv * (1.0 + 1e-12) - 1e-300, hi = 0.0;
+   const double d0 = s1_lane(ds, 0);
+   /* SMALL (n <= 16): the whole matrix as wavefront-uniform values, the steps unrolled - three multiply-adds and a compare per step */
+   double dsv[16], e2v[16];
+   if ( SMALL )
+   {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+      {
+         dsv[i] = s1_lane(ds, i);
+         e2v[i] = s1_lane(e2, i);
+      }
+   }
+   bool first = true;
+   for (int round = 0; round < 14; ++round)
+   {
+      const double wdt = (hi - lo) / 65.0;
+      double x = lo + wdt * (double) (lane + 1);
+      if ( first )
+         x = (lane == 63) ? 0.0 : lo + (hi - lo) * (double) (lane + 1) / 64.0;
+      /* p_0 = 1, p_1 = d_0 - x, p_{i+1} = (d_i - x) p_i - e_{i-1}^2 p_{i-1}: a sign change = an eigenvalue below x (an exact zero
+       * counts as negative); rescaled every eighth step */
+      double pp = 1.0, pc = d0 - x;
+      bool posc = pc > 0.0;
+      bool below = !posc;
+      if ( SMALL )
+      {
+#pragma unroll
+         for (int i = 1; i < 16; ++i)
+            if ( i < n )
+            {
+               const double pn = fma(dsv[i] - x, pc, -e2v[i - 1] * pp);
+               const bool posn = pn > 0.0;
+               below = below || (posn != posc);
+               pp = pc; pc = pn; posc = posn;
+               if ( i == 8 )
+               {
+                  const int ex = -max(__builtin_amdgcn_frexp_exp(pc), __builtin_amdgcn_frexp_exp(pp));
+                  if ( ex > -1000 && ex < 1000 )
+                  {
+                     pc = ldexp(pc, ex);
+                     pp = ldexp(pp, ex);
+                  }
+               }
+            }
+      }
+      else
+      for (int i = 1; i < n; ++i)
+      {
+         const double di = s1_lane(ds, i), ei = s1_lane(e2, i - 1);
+         const double pn = fma(di - x, pc, -ei * pp);
+         const bool posn = pn > 0.0;
+         below = below || (posn != posc);
+         pp = pc; pc = pn; posc = posn;
+         if ( (i & 7) == 7 )
+         {
+            const int ex = -max(__builtin_amdgcn_frexp_exp(pc), __builtin_amdgcn_frexp_exp(pp));
+            if ( ex > -1000 && ex < 1000 )
+            {
+               pc = ldexp(pc, ex);
+               pp = ldexp(pp, ex);
+            }
+         }
+      }
+      const unsigned long long msk = __ballot(below);
+      if ( first )
+      {
+         first = false;
+         if ( !(msk >> 63) )
+            return 0.0;                                     /* nothing below zero */
+         const int f = __ffsll((long long) msk) - 1;        /* first shift with an eigenvalue below it */
+         const double w64 = (hi - lo) / 64.0;
+         const double nlo = (f == 0) ? lo : lo + w64 * (double) f;
+         const double nhi = (f == 63) ? 0.0 : lo + w64 * (double) (f + 1);
+         lo = nlo; hi = nhi;
+      }
+      else
+      {
+         const int f = msk ? __ffsll((long long) msk) - 1 : 64;
+         const double nlo = lo + wdt * (double) f;
+         const double nhi = (f < 64) ? lo + wdt * (double) (f + 1) : hi;
+         lo = nlo; hi = nhi;
+      }
+      if ( tprof != NULL && lane == 0 )
+         tprof[2] += 1.0;
+      if ( hi - lo <= 1e-10 * fabs(lo) || fabs(lo) < 1e-15 )
+         break;
+   }
+   if ( tprof != NULL && lane == 0 )
+      tprof[1] += (double) clock64();
+   return lo * nrm;
+}
+
+/* ---- the same for n <= 16 with the matrix in registers: lane = row, sixteen registers = its columns, the reduction fully unrolled.
+ * The entries of the reflector and of w reach the lanes by v_readlane; no LDS access after the rows are loaded (the LDS form
+ * below waits out six LDS round trips per column: 3100 cycles per column at n = 10, this one about 1000). */
+__device__ __forceinline__ double s1_lmin16(const double* W, int n, int p, int lane, double* tprof)
+{
+   double a[16];
+#pragma unroll
+   for (int j = 0; j < 16; ++j)
+      a[j] = (lane < n && j < n) ? W[lane * p + j] : 0.0;
+   double dreg = 0.0, ereg = 0.0;
+#pragma unroll
+   for (int k = 0; k < 14; ++k)
+   {
+      if ( k + 2 < n )
+      {
+         const double xa = (lane > k) ? a[k] : 0.0;
+         const double x0 = s1_lane(xa, k + 1);
+         const double s2 = s1_lane(s1_sum16(lane > k + 1 ? xa * xa : 0.0), 0);
+         if ( lane == k )
+            dreg = a[k];
+         if ( s2 != s2 )
+            return s2;
+         if ( !(s2 > 1e-290) )
+         {
+            if ( lane == k )
+               ereg = x0;
+         }
+         else
+         {
+            const double h2 = x0 * x0 + s2;
+            const double rh = s1_rsqrt(h2);
+            const double beta = -copysign(h2 * rh, x0);
+            const double t = (x0 - beta) * copysign(rh, x0);
+            const double scale = s1_rcp(x0 - beta);
+            const double vl = (lane == k + 1) ? 1.0 : ((lane > k + 1) ? xa * scale : 0.0);
+            if ( lane == k )
+               ereg = beta;
+            double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+            for (int j = k + 1; j < 16; j += 2)
+            {
+               acc0 = fma(a[j], s1_lane(vl, j), acc0);
+               if ( j + 1 < 16 )
+                  acc1 = fma(a[j + 1], s1_lane(vl, j + 1), acc1);
+            }
+            const double pl = (lane > k) ? t * (acc0 + acc1) : 0.0;
+            const double pv = s1_lane(s1_sum16(pl * vl), 0);
+            const double wl = fma(-0.5 * t * pv, vl, pl);
+#pragma unroll
+            for (int j = k + 1; j < 16; ++j)
+               a[j] -= vl * s1_lane(wl, j) + wl * s1_lane(vl, j);
+         }
+      }
+   }
+   /* the rest of the diagonal and the last off-diagonal entry: a[lane], a[lane - 1] of the own row */
+   double own = 0.0, left = 0.0;
+#pragma unroll
+   for (int j = 0; j < 16; ++j)
+   {
+      if ( j == lane ) own = a[j];
+      if ( j + 1 == lane ) left = a[j];
+   }
+   if ( lane + 2 >= n )
+      dreg = own;
+   if ( n >= 2 )
+   {
+      const double elast = s1_lane(left, n - 1);
+      if ( lane == n - 2 )
+         ereg = elast;
+   }
+   if ( tprof != NULL && lane == 0 )
+      tprof[0] -= (double) clock64();
+   const double r = s1_sturm_min<true>(dreg, ereg, n, lane, tprof);
+   if ( tprof != NULL && lane == 0 )
+      tprof[0] += (double) clock64();
+   return r;
+}
+
 /* ---- one wavefront: smallest eigenvalue of the symmetric n x n matrix whose LOWER triangle is in W (LDS, pitch p odd; destroyed):
  * Householder tridiagonalisation (lane = row), Sturm multisection with 64 shifts per round.  Returns min(lambda_min, 0) to a
  * relative accuracy of 1e-11 (from below), NaN when the matrix is not finite.  scr: 4 * n doubles of LDS. */
-__device__ __forceinline__ double s1_lmin(double* W, int n, int p, int lane, double* scr)
+__device__ __forceinline__ double s1_lmin(double* W, int n, int p, int lane, double* scr, double* tprof)
 {
    double* dd = scr;
    double* ee = scr + n;
@@ -636,88 +840,10 @@ __device__ __forceinline__ double s1_lmin(double* W, int n, int p, int lane, dou
       ee[n - 1] = 0.0;
    }
    S1_WSYNC();
-   /* scale to norm one, Gershgorin interval */
-   double nrm = 0.0, glo = 1e300;
-   for (int i = lane; i < n; i += 64)
-   {
-      const double rad = (i > 0 ? fabs(ee[i - 1]) : 0.0) + fabs(ee[i]);
-      nrm = fmax(nrm, fabs(dd[i]) + rad);
-      glo = fmin(glo, dd[i] - rad);
-   }
-   {
-      double bad = 0.0;
-      for (int i = lane; i < n; i += 64)
-         if ( !(fabs(dd[i]) < 1e300) || !(fabs(ee[i]) < 1e300) )
-            bad = 1.0;
-      if ( s1_wmax(bad) > 0.0 )
-         return nan("");
-   }
-   nrm = s1_wmax(nrm);
-   glo = s1_wmin(glo);
-   if ( !(glo < 0.0) || !(nrm > 0.0) )
-      return 0.0;
-   const double sinv = 1.0 / nrm;
-   /* e2 into ww, scaled diagonal into vv */
-   for (int i = lane; i < n; i += 64)
-   {
-      vv[i] = dd[i] * sinv;
-      const double es = ee[i] * sinv;
-      ww[i] = es * es;
-   }
-   S1_WSYNC();
-   double lo = glo * sinv * (1.0 + 1e-12) - 1e-300, hi = 0.0;
-   /* is there an eigenvalue below zero at all?  (lane 0's shift of the first round is placed at 0) */
-   bool first = true;
-   for (int round = 0; round < 14; ++round)
-   {
-      const double wdt = (hi - lo) / 65.0;
-      double x = lo + wdt * (double) (lane + 1);
-      if ( first )
-         x = (lane == 63) ? 0.0 : lo + (hi - lo) * (double) (lane + 1) / 64.0;
-      /* Sturm sequence in product form, rescaled every fourth step; a sign change = an eigenvalue below x */
-      double pp = 1.0, pc = vv[0] - x;
-      bool posc = pc > 0.0;
-      bool below = !posc;
-#pragma unroll 8
-      for (int i = 1; i < n; ++i)
-      {
-         const double pn = fma(vv[i] - x, pc, -ww[i - 1] * pp);
-         const bool posn = (pn > 0.0) || (pn == 0.0 && !posc);
-         below = below || (posn != posc);
-         pp = pc; pc = pn; posc = posn;
-         if ( (i & 3) == 3 )
-         {
-            const int ex = -max(__builtin_amdgcn_frexp_exp(pc), __builtin_amdgcn_frexp_exp(pp));
-            if ( ex > -1000 && ex < 1000 )
-            {
-               pc = ldexp(pc, ex);
-               pp = ldexp(pp, ex);
-            }
-         }
-      }
-      const unsigned long long msk = __ballot(below);
-      if ( first )
-      {
-         first = false;
-         if ( !(msk >> 63) )
-            return 0.0;                                     /* nothing below zero */
-         const int f = __ffsll((long long) msk) - 1;        /* first shift with an eigenvalue below it */
-         const double w64 = (hi - lo) / 64.0;
-         const double nlo = (f == 0) ? lo : lo + w64 * (double) f;
-         const double nhi = (f == 63) ? 0.0 : lo + w64 * (double) (f + 1);
-         lo = nlo; hi = nhi;
-      }
-      else
-      {
-         const int f = msk ? __ffsll((long long) msk) - 1 : 64;
-         const double nlo = lo + wdt * (double) f;
-         const double nhi = (f < 64) ? lo + wdt * (double) (f + 1) : hi;
-         lo = nlo; hi = nhi;
-      }
-      if ( hi - lo <= 1e-11 * fabs(lo) || fabs(lo) < 1e-15 )
-         break;
-   }
-   return lo * nrm;
+   /* the tridiagonal matrix into the lanes (lane i: d_i, e_i), then the multisection */
+   const double dl = (lane < n) ? dd[lane] : 0.0;
+   const double el = (lane < n) ? ee[lane] : 0.0;
+   return s1_sturm_min<false>(dl, el, n, lane, tprof);
 }
 
 /* ---- n x n x n product on the matrix cores: wavefront `wave` of the subset [w0, w0 + nw) takes the 16 x 16 tiles tbase + t with
@@ -1552,6 +1678,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          }
       }
       __syncthreads();
+      S1_STAMP(16);
       {
          int tb = 0;
          for (int k = 0; k < K; ++k)
@@ -1570,14 +1697,19 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          }
       }
       __syncthreads();
+      S1_STAMP(17);
       for (int t = wave; t < 2 * K; t += S1_NW)
       {
          const S1Blk& B = sh.blk[t >> 1];
-         const double lm = s1_lmin(sm + ((t & 1) ? B.odZ : B.odX), B.n, B.p, lane, sm + B.oEig + (t & 1) * 4 * ((B.n + 1) & ~1));
+         double* Wm = sm + ((t & 1) ? B.odZ : B.odX);
+         double* tpr = (P.prof_on && t == 0) ? &sh.prof[19] : (double*) NULL;
+         const double lm = (B.n <= 16) ? s1_lmin16(Wm, B.n, B.p, lane, tpr)
+            : s1_lmin(Wm, B.n, B.p, lane, sm + B.oEig + (t & 1) * 4 * ((B.n + 1) & ~1), tpr);
          if ( lane == 0 )
             sh.sc[SC_LMIN0 + t] = lm;
       }
       __syncthreads();
+      S1_STAMP(18);
       double a = 1e300;
       for (int t = 0; t < 2 * K; ++t)
       {
@@ -2182,6 +2314,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       }
       make_dZ();
       __syncthreads();
+      S1_STAMP(12);
       {
          int tb = 0;
          for (int k = 0; k < K; ++k)
@@ -2196,6 +2329,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          }
       }
       __syncthreads();
+      S1_STAMP(13);
       {
          int tb = 0;
          for (int k = 0; k < K; ++k)
@@ -2210,8 +2344,10 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          }
       }
       __syncthreads();
+      S1_STAMP(14);
       dir_matrix(0.0, 1.0, QV(Q_dz), false, QV(Q_dx));          /* dXa, dxa */
       __syncthreads();
+      S1_STAMP(15);
       /* second-order terms E = dXa dZa, elp = dxa dza; then the predictor's step length */
       {
          int tb = 0;
@@ -2436,7 +2572,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       out[13] = (double) pre_valid; out[14] = pre_scale; out[15] = normb; out[16] = normC;
       out[17] = (double) (clock64() - t_start);
       out[43] = (double) (wall_clock64() - w_start);
-      for (int i = 0; i < 16; ++i)
+      for (int i = 0; i < 22; ++i)
          out[18 + i] = sh.prof[i];
       out[40] = (double) sh.fl[2]; out[41] = (double) sh.fl[3];
       out[42] = (double) (((size_t) (void*) sh.blk[0].vval) >> 32);

@@ -1,6 +1,7 @@
-/* units.hip - host-buffer entry points around single device kernels.  They serve two callers: lapack_interface_hip.c (the
- * SCIPlapack* surface of src/sdpi/lapack_interface.h:50-127 takes host arrays) and the per-kernel parity tests in tests/.
- * Each call: H2D, kernel(s) on the default stream, D2H.  Nothing here has a CPU code path. */
+/* units.hip - TEST entry points around single device kernels for the per-kernel parity tests in tests/ (self-checks of the GEMM
+ * kernels, single factorizations, single Schur assemblies, ...).  Each call: H2D, kernel(s) on the default stream, D2H, with
+ * per-call allocations - fine for tests, not for the product: what lapack_interface_hip.c calls (hipsdp_dgemm, hipsdp_gemv_*,
+ * hipsdp_syev) lives in host_entries.hip.  Nothing here has a CPU code path. */
 #include "hs_kernels.h"
 #include "../../include/hipsdp.h"
 #include <vector>
@@ -32,27 +33,6 @@ int pick_device(int device)
 
 long long span(int rows, int cols, long long ld) { return rows <= 0 ? 0 : (long long) (rows - 1) * ld + cols; }
 
-}
-
-extern "C" int hipsdp_dgemm(int device, int layA, int layB, int M, int N, int K, double alpha, const double* A, long long lda,
-   const double* B, long long ldb, double beta, double* C, long long ldc, int lower_only, int splitk)
-{
-   HS_CALL( pick_device(device) );
-   const long long na = layA == HS_KC ? span(M, K, lda) : span(K, M, lda);
-   const long long nb = layB == HS_KC ? span(N, K, ldb) : span(K, N, ldb);
-   const long long nc = span(M, N, ldc);
-   DevBuf dA, dB, dC, dW;
-   HS_CALL( dA.alloc(na) ); HS_CALL( dB.alloc(nb) ); HS_CALL( dC.alloc(nc) );
-   HS_CALL( dA.up(A, na) ); HS_CALL( dB.up(B, nb) ); HS_CALL( dC.up(C, nc) );
-   if ( splitk <= 0 )
-      splitk = hs_dgemm_pick_splitk(M, N, K, lower_only);
-   if ( splitk > 1 )
-      HS_CALL( dW.alloc((long long) splitk * M * N) );
-   hs_gemm_args g = {M, N, K, layA, layB, dA.p, lda, 0, dB.p, ldb, 0, dC.p, ldc, 0, alpha, beta, 1, lower_only ? HS_GEMM_LOWER : 0, splitk, dW.p};
-   HS_CALL( hs_dgemm(0, &g) );
-   HS_HIP( hipDeviceSynchronize() );
-   HS_CALL( dC.down(C, nc) );
-   return HIPSDP_OK;
 }
 
 /* fills with reproducible values in [-0.5, 0.5) */
@@ -534,53 +514,6 @@ extern "C" int hipsdp_lambda_min_scaled(int device, int n, const double* L, cons
       return HIPSDP_ERR_NUMERIC;
    theta[0] = h[0]; theta[1] = h[8];
    if ( resid != NULL ) { resid[0] = h[1]; resid[1] = h[9]; }
-   return HIPSDP_OK;
-}
-
-extern "C" int hipsdp_syev(int device, int n, const double* A, double* lam, double* V)
-{
-   HS_CALL( pick_device(device) );
-   if ( n <= 0 ) return HIPSDP_ERR_ARG;
-   /* the sizes the callers of SCIPlapackComputeEigenvectorDecomposition use (blocks of 2-50 rows): tridiagonal reduction, multisection
-    * and inverse iteration in ONE launch through pinned staging memory (eigi.hip); HIPSDP_SYEV_JACOBI=1 keeps the Jacobi path */
-   static const bool jacobi_small = getenv("HIPSDP_SYEV_JACOBI") != NULL && atoi(getenv("HIPSDP_SYEV_JACOBI")) != 0;
-   if ( n <= 64 && !jacobi_small )
-      return hipsdp_syev_small(device, n, A, lam, V);
-   const long long n2 = (long long) n * n;
-   DevBuf dA, dL, dV, dS;
-   HS_CALL( dA.alloc(n2) ); HS_CALL( dL.alloc(n) ); HS_CALL( dV.alloc(n2) ); HS_CALL( dS.alloc(hs_syev_ws(n)) );
-   HS_CALL( dA.up(A, n2) );
-   HS_CALL( hs_syev_jacobi(0, n, dA.p, dL.p, dV.p, NULL, dS.p) );
-   HS_HIP( hipDeviceSynchronize() );
-   HS_CALL( dL.down(lam, n) );
-   if ( V != NULL ) HS_CALL( dV.down(V, n2) );
-   return HIPSDP_OK;
-}
-
-extern "C" int hipsdp_gemv_n(int device, int R, long long E, const double* A, int nv, const double* V, double* out)
-{
-   HS_CALL( pick_device(device) );
-   if ( nv < 1 || nv > 4 ) return HIPSDP_ERR_ARG;
-   DevBuf dA, dV, dO, dS;
-   HS_CALL( dA.alloc(R * E) ); HS_CALL( dV.alloc(nv * E) ); HS_CALL( dO.alloc((long long) nv * R) ); HS_CALL( dS.alloc(65536) );
-   HS_CALL( dA.up(A, R * E) ); HS_CALL( dV.up(V, nv * E) );
-   const double* vp[4];
-   for (int v = 0; v < 4; ++v) vp[v] = dV.p + (long long) (v < nv ? v : 0) * E;
-   HS_CALL( hs_gemv_n(0, R, E, dA.p, E, nv, vp, dO.p, R, dS.p, 65536) );
-   HS_HIP( hipDeviceSynchronize() );
-   HS_CALL( dO.down(out, (long long) nv * R) );
-   return HIPSDP_OK;
-}
-
-extern "C" int hipsdp_gemv_t(int device, int R, long long E, const double* A, const double* coef, double* out)
-{
-   HS_CALL( pick_device(device) );
-   DevBuf dA, dC, dO;
-   HS_CALL( dA.alloc(R * E) ); HS_CALL( dC.alloc(R) ); HS_CALL( dO.alloc(E) );
-   HS_CALL( dA.up(A, R * E) ); HS_CALL( dC.up(coef, R) );
-   HS_CALL( hs_gemv_t(0, R, E, dA.p, E, dC.p, 0.0, NULL, dO.p) );
-   HS_HIP( hipDeviceSynchronize() );
-   HS_CALL( dO.down(out, E) );
    return HIPSDP_OK;
 }
 

@@ -26,6 +26,70 @@ static int lapack_device(void)
    return e != NULL ? atoi(e) : 0;
 }
 
+/* ---- size cutoff inside SCIP-SDP ("a size cutoff below which the host path is kept (typical
+ * cons_sdp blocks are 2-50; PCIe latency dominates there)").  SCIP-SDP always links LAPACK / BLAS (INSTALL:7-12), so the build
+ * inside SCIP-SDP (-DHIPSDP_WITH_SCIP) keeps the host routine wherever a device round trip (20-50 us before the first flop) cannot
+ * win: measured on the GPU box (profiles/r04_lapack_small_sizes.txt) the one-launch device kernels take 14-540 us for one
+ * eigenpair and 32-530 us for all of them at n <= 128 / 64 against 2-330 us of DSYEVR, a product of host arrays pays the PCIe
+ * transfer of its operands (a matrix-vector product never earns it back, a matrix-matrix product from about 2 M N K = 10^8).
+ * HIPSDP_LAPACK_CUTOFF=<n> moves the eigen cutoff (0: always the device).  The stand-alone library has no host LAPACK to call:
+ * there every size goes to the device. */
+#ifdef HIPSDP_WITH_SCIP
+#ifndef HIPSDP_LAPACK_INT
+#define HIPSDP_LAPACK_INT int
+#endif
+typedef HIPSDP_LAPACK_INT lint;
+extern void dsyevr_(char* jobz, char* range, char* uplo, lint* n, double* a, lint* lda, double* vl, double* vu, lint* il, lint* iu,
+   double* abstol, lint* m, double* w, double* z, lint* ldz, lint* isuppz, double* work, lint* lwork, lint* iwork, lint* liwork, lint* info);
+extern void dgemv_(char* trans, lint* m, lint* n, double* alpha, double* a, lint* lda, double* x, lint* incx, double* beta, double* y,
+   lint* incy);
+extern void dgemm_(char* transa, char* transb, lint* m, lint* n, lint* k, double* alpha, double* a, lint* lda, double* b, lint* ldb,
+   double* beta, double* c, lint* ldc);
+
+static int host_eigen_cutoff(void)
+{
+   const char* e = getenv("HIPSDP_LAPACK_CUTOFF");
+   return e != NULL ? atoi(e) : 128;
+}
+
+/* eigenpairs il .. iu (1-based, ascending) of the symmetric matrix A (copied: DSYEVR destroys its argument); vectors (may be NULL):
+ * (iu - il + 1) x n, one eigenvector per row - the convention of lapack_interface.c:178-288, 507-603 */
+static SCIP_RETCODE host_syevr(int n, const SCIP_Real* A, int il, int iu, SCIP_Real* values, SCIP_Real* vectors)
+{
+   char jobz = vectors != NULL ? 'V' : 'N', range = 'I', uplo = 'L';
+   lint N = n, LDA = n, IL = il, IU = iu, M = 0, LDZ = n, LWORK = -1, LIWORK = -1, INFO = 0, iwq = 0;
+   double vl = 0.0, vu = 0.0, abstol = 0.0, wq = 0.0;
+   double* a = (double*) malloc((size_t) n * (size_t) n * sizeof(double));
+   double* w = (double*) malloc((size_t) n * sizeof(double));
+   lint* isuppz = (lint*) malloc(2 * (size_t) n * sizeof(lint));
+   double* work = NULL;
+   lint* iwork = NULL;
+   SCIP_RETCODE rc = SCIP_OKAY;
+   if ( a == NULL || w == NULL || isuppz == NULL )
+      rc = SCIP_NOMEMORY;
+   if ( rc == SCIP_OKAY )
+   {
+      memcpy(a, A, (size_t) n * (size_t) n * sizeof(double));
+      dsyevr_(&jobz, &range, &uplo, &N, a, &LDA, &vl, &vu, &IL, &IU, &abstol, &M, w, vectors, &LDZ, isuppz, &wq, &LWORK, &iwq, &LIWORK, &INFO);
+      LWORK = (lint) wq; LIWORK = iwq;
+      work = (double*) malloc((size_t) (LWORK > 1 ? LWORK : 1) * sizeof(double));
+      iwork = (lint*) malloc((size_t) (LIWORK > 1 ? LIWORK : 1) * sizeof(lint));
+      if ( INFO != 0 || work == NULL || iwork == NULL )
+         rc = INFO != 0 ? SCIP_ERROR : SCIP_NOMEMORY;
+   }
+   if ( rc == SCIP_OKAY )
+   {
+      dsyevr_(&jobz, &range, &uplo, &N, a, &LDA, &vl, &vu, &IL, &IU, &abstol, &M, w, vectors, &LDZ, isuppz, work, &LWORK, iwork, &LIWORK, &INFO);
+      if ( INFO != 0 || M != (lint) (iu - il + 1) )
+         rc = SCIP_ERROR;
+      else
+         memcpy(values, w, (size_t) (iu - il + 1) * sizeof(double));
+   }
+   free(a); free(w); free(isuppz); free(work); free(iwork);
+   return rc;
+}
+#endif
+
 #define DEV_CALL(x) do { if ( (x) != HIPSDP_OK ) return SCIP_ERROR; } while (0)
 
 /* full decomposition into freshly allocated arrays (caller frees) */
@@ -56,6 +120,10 @@ SCIP_RETCODE SCIPlapackComputeIthEigenvalue(BMS_BUFMEM* bufmem, SCIP_Bool geteig
    (void) bufmem;
    if ( n <= 0 || i < 1 || i > n || A == NULL || eigenvalue == NULL )
       return SCIP_ERROR;
+#ifdef HIPSDP_WITH_SCIP
+   if ( n <= host_eigen_cutoff() )
+      return host_syevr(n, A, i, i, eigenvalue, (geteigenvectors && eigenvector != NULL) ? eigenvector : NULL);
+#endif
    /* the sizes cons_sdp.c and solveonevarsdp.c call this with (blocks of 2-50 rows, dozens of calls per node): one eigenpair in
     * one launch through pinned staging memory, no allocation and no copy on the path */
    if ( n <= 128 )
@@ -91,6 +159,20 @@ SCIP_RETCODE SCIPlapackComputeEigenvectorsNegative(BMS_BUFMEM* bufmem, int n, SC
    (void) bufmem;
    if ( n <= 0 || A == NULL || neigenvalues == NULL || eigenvalues == NULL || eigenvectors == NULL )
       return SCIP_ERROR;
+#ifdef HIPSDP_WITH_SCIP
+   if ( n <= host_eigen_cutoff() )
+   {
+      lam = (SCIP_Real*) malloc((size_t) n * sizeof(SCIP_Real));
+      V = (SCIP_Real*) malloc((size_t) n * (size_t) n * sizeof(SCIP_Real));
+      rc = (lam == NULL || V == NULL) ? SCIP_NOMEMORY : host_syevr(n, A, 1, n, lam, V);
+      if ( rc != SCIP_OKAY )
+      {
+         free(lam); free(V);
+         return rc;
+      }
+   }
+   else
+#endif
    rc = decompose(n, A, &lam, &V);
    if ( rc != SCIP_OKAY )
       return rc;
@@ -112,6 +194,10 @@ SCIP_RETCODE SCIPlapackComputeEigenvectorDecomposition(BMS_BUFMEM* bufmem, int n
    (void) bufmem;
    if ( n <= 0 || A == NULL || eigenvalues == NULL || eigenvectors == NULL )
       return SCIP_ERROR;
+#ifdef HIPSDP_WITH_SCIP
+   if ( n <= host_eigen_cutoff() )
+      return host_syevr(n, A, 1, n, eigenvalues, eigenvectors);
+#endif
    DEV_CALL( hipsdp_syev(lapack_device(), n, A, eigenvalues, eigenvectors) );
    return SCIP_OKAY;
 }
@@ -122,6 +208,16 @@ SCIP_RETCODE SCIPlapackMatrixVectorMult(int nrows, int ncols, SCIP_Real* matrix,
 {
    if ( nrows <= 0 || ncols <= 0 )
       return SCIP_ERROR;
+#ifdef HIPSDP_WITH_SCIP
+   {
+      /* host arrays in, host array out, 2 flops per 8 bytes: the transfer alone costs more than DGEMV (lapack_interface.c:607-650) */
+      char trans = 'N';
+      lint M = nrows, N = ncols, one = 1;
+      double alpha = 1.0, beta = 0.0;
+      dgemv_(&trans, &M, &N, &alpha, matrix, &M, vector, &one, &beta, result, &one);
+      return SCIP_OKAY;
+   }
+#endif
    DEV_CALL( hipsdp_gemv_t(lapack_device(), ncols, (long long) nrows, matrix, vector, result) );
    return SCIP_OKAY;
 }
@@ -141,6 +237,16 @@ SCIP_RETCODE SCIPlapackMatrixMatrixMult(int nrowsA, int ncolsA, SCIP_Real* matri
    const int Kb = transposeB ? ncolsB : nrowsB;
    if ( K != Kb || M <= 0 || N <= 0 || K <= 0 )
       return SCIP_ERROR;
+#ifdef HIPSDP_WITH_SCIP
+   if ( 2.0 * (double) M * (double) N * (double) K < 1e8 )
+   {
+      char ta = transposeA ? 'T' : 'N', tb = transposeB ? 'T' : 'N';
+      lint m_ = M, n_ = N, k_ = K, lda = nrowsA, ldb = nrowsB, ldc = M;
+      double alpha = 1.0, beta = 0.0;
+      dgemm_(&ta, &tb, &m_, &n_, &k_, &alpha, matrixA, &lda, matrixB, &ldb, &beta, result, &ldc);
+      return SCIP_OKAY;
+   }
+#endif
    DEV_CALL( hipsdp_dgemm(lapack_device(), transposeB ? 1 : 0, transposeA ? 0 : 1, N, M, K, 1.0,
          matrixB, (long long) (transposeB ? N : K), matrixA, (long long) (transposeA ? K : M), 0.0, result, (long long) M, 0, 1) );
    return SCIP_OKAY;

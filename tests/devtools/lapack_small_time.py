@@ -10,7 +10,8 @@ hb = importlib.util.module_from_spec(spec); spec.loader.exec_module(hb)
 lib = hb.lib()
 PD = C.POINTER(C.c_double)
 pd = lambda a: a.ctypes.data_as(PD)
-print("%5s %22s %22s %22s %16s" % ("n", "IthEigenvalue(1) us", "IthEigenvalue+vec us", "EigenvectorDecomp us", "numpy eigvalsh us"))
+print("%5s %20s %20s %20s %16s %14s %14s %14s %14s" % ("n", "IthEigenvalue(1) us", "IthEigenvalue+vec us", "EigenvectorDecomp us", "numpy eigvalsh us",
+      "MatMatMult us", "numpy A@B us", "MatVecMult us", "numpy A@x us"))
 for n in (2, 5, 10, 16, 20, 30, 43, 50, 64, 65, 100, 128):
     rng = np.random.default_rng(n)
     G = rng.standard_normal((n, n)); A = (G + G.T)
@@ -26,4 +27,9 @@ for n in (2, 5, 10, 16, 20, 30, 43, 50, 64, 65, 100, 128):
     t2 = timeit(lambda: lib.SCIPlapackComputeIthEigenvalue(None, 1, n, pd(a), 1, C.byref(val), pd(vec)))
     t3 = timeit(lambda: lib.SCIPlapackComputeEigenvectorDecomposition(None, n, pd(a.copy()), pd(lam), pd(V)))
     t4 = timeit(lambda: np.linalg.eigvalsh(A))
-    print("%5d %22.1f %22.1f %22.1f %16.1f" % (n, t1, t2, t3, t4))
+    Bm = rng.standard_normal((n, n)); bflat = Bm.reshape(-1).copy(); cres = np.zeros(n * n); xv = rng.standard_normal(n); yv = np.zeros(n)
+    t5 = timeit(lambda: lib.SCIPlapackMatrixMatrixMult(n, n, pd(a), 0, n, n, pd(bflat), 0, pd(cres)))
+    t6 = timeit(lambda: A @ Bm)
+    t7 = timeit(lambda: lib.SCIPlapackMatrixVectorMult(n, n, pd(a), pd(xv), pd(yv)))
+    t8 = timeit(lambda: A @ xv)
+    print("%5d %20.1f %20.1f %20.1f %16.1f %14.1f %14.1f %14.1f %14.1f" % (n, t1, t2, t3, t4, t5, t6, t7, t8))

@@ -1,0 +1,271 @@
+"""GPU: the one-launch node solve of B&B-sized problems (csrc/solve1.hip) against the oracle - the whole interior-point solve in one
+kernel, what the reference's backends do in-process (sdpisolver_dsdp.c:1489-1520 DSDPSetup / DSDPSolve / DSDPComputeX,
+sdpisolver_sdpa.cpp:1600-1670).  Every test checks that the path under test really ran (Solver.solve_path()), compares status,
+iteration count and - iteration by iteration - mu, the residuals, the gap, tau and kappa with oracle/ipm_ref.py, and the same
+problems through the general path (HIPSDP_SOLVE1=0) give the same answers."""
+import json
+import os
+import numpy as np
+import pytest
+
+import bnb
+import checker
+import instances
+import ipm_ref
+import sdpa_io
+import sdpi_call
+import sdpi_prepare
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+CASES = json.load(open(os.path.join(GOLDEN, "checksdpi_cases.json")))["cases"]
+
+
+def case_core(case):
+    blocks = [dict(n=b["n"], vars={int(k): [tuple(e) for e in v] for k, v in b["vars"].items()},
+                   const=[tuple(e) for e in b["const"]]) for b in case["blocks"]]
+    lp = [(l, r, {int(k): v for k, v in row.items()}) for (l, r, row) in case["lp"]]
+    P = sdpi_prepare.prepare(sdpi_prepare.SdpiProblem(case["obj"], case["lb"], case["ub"], blocks, lp))
+    b, blk, D, c, maps = sdpi_prepare.to_core(P)
+    return ipm_ref.CoreProblem(b, blk, D, c)
+
+
+def instance_core(name):
+    inst = sdpa_io.read_sdpa(os.path.join(GOLDEN, "instances", name))
+    D, c = sdpa_io.lp_dense(inst)
+    return ipm_ref.CoreProblem(inst.obj, sdpa_io.dense_blocks(inst), D, c)
+
+
+def random_sparse_core(seed):
+    """1-3 blocks of 2-13 rows, 3-29 variables with three nonzeros per matrix and block, 0-19 LP rows; strictly feasible on both sides"""
+    rng = np.random.default_rng(seed)
+    m = int(rng.integers(3, 30))
+    sizes = [int(rng.integers(2, 14)) for _ in range(int(rng.integers(1, 4)))]
+    q = int(rng.integers(0, 20))
+    ystar = rng.standard_normal(m)
+    blocks = []
+    for n in sizes:
+        A = np.zeros((m + 1, n, n))
+        for i in range(1, m + 1):
+            for _ in range(3):
+                r, c = rng.integers(0, n, 2)
+                v = rng.standard_normal()
+                A[i, r, c] += v
+                if r != c:
+                    A[i, c, r] += v
+        Zs = rng.standard_normal((n, n))
+        Zs = Zs @ Zs.T + 0.5 * np.eye(n)
+        A[0] = np.tensordot(ystar, A[1:], axes=(0, 0)) - Zs
+        blocks.append(A)
+    D = rng.standard_normal((q, m)) * (rng.random((q, m)) < 0.3)
+    c = D @ ystar - rng.random(q) - 0.1
+    b = sum(np.array([np.trace(A[i]) for i in range(1, m + 1)]) for A in blocks) + (D.T @ np.ones(q) if q else 0.0)
+    return ipm_ref.CoreProblem(b, blocks, D, c)
+
+
+def solve_one_launch(hb, core, monkeypatch, rows=128, **kw):
+    monkeypatch.setenv("HIPSDP_SOLVE1", "1")
+    monkeypatch.setenv("HIPSDP_SOLVE1_HIST", "1")
+    s = hb.Solver(0)
+    s.load_core(core)
+    info = s.solve(**kw)
+    out = dict(info=info, path=s.solve_path(), y=s.y(), X=[s.X(k) for k in range(len(core.blocks))], lp=s.lp())
+    out["trace"], out["hist"] = s.solve1_trace(rows) if out["path"] else (None, None)
+    s.close()
+    return out
+
+
+def solve_general(hb, core, monkeypatch, **kw):
+    monkeypatch.setenv("HIPSDP_SOLVE1", "0")
+    s = hb.Solver(0)
+    s.load_core(core)
+    info = s.solve(**kw)
+    out = dict(info=info, path=s.solve_path(), y=s.y())
+    s.close()
+    return out
+
+
+def assert_history_matches(g, ref, upto_last=2, rtol=1e-5):
+    """mu, pinf, dinf, gap, tau, kappa of every iteration but the last `upto_last` (where the residuals sit at the rounding floor)"""
+    h = g["hist"]
+    for r in range(max(0, min(len(ref.history), g["info"].iterations + 1) - upto_last)):
+        for j in range(1, 7):
+            a, b = h[r, j], ref.history[r][j]
+            assert abs(a - b) <= rtol * abs(b) + 1e-11, (r, j, a, b)
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c["blocks"]], ids=[c["name"] for c in CASES if c["blocks"]])
+def test_reference_cases_in_one_launch(gpu, case, monkeypatch):
+    core = case_core(case)
+    ref = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-6, feastol=1e-6, pabstol=1e-5))
+    g = solve_one_launch(gpu, core, monkeypatch, gaptol=1e-6, feastol=1e-6, pabstol=1e-5)
+    assert g["path"] == 1
+    assert g["info"].status == ref.status and g["info"].iterations == ref.iterations
+    assert_history_matches(g, ref)
+    assert np.allclose(g["y"], ref.y, atol=1e-7, rtol=1e-7)
+    for Xg, Xr in zip(g["X"], ref.X):
+        assert np.allclose(Xg, Xr, atol=1e-6, rtol=1e-6)
+    if core.q:
+        assert np.allclose(g["lp"][0], ref.x, atol=1e-6, rtol=1e-6)
+    if ref.status in (ipm_ref.STATUS_DINF, ipm_ref.STATUS_PDINF):
+        assert checker.farkas_dual_infeasible(core, g["X"], g["lp"][0], 1e-6)[0]
+    gen = solve_general(gpu, core, monkeypatch, gaptol=1e-6, feastol=1e-6, pabstol=1e-5)
+    assert gen["path"] == 0 and gen["info"].status == ref.status and gen["info"].iterations == ref.iterations
+
+
+@pytest.mark.parametrize("name", ["example_small.dat-s", "example_TT.dat-s.gz", "example_inf.dat-s", "example_tightenmatrices.dat-s"])
+def test_reference_instances_in_one_launch(gpu, name, monkeypatch):
+    core = instance_core(name)
+    ref = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-6, feastol=1e-6, pabstol=1e-5))
+    g = solve_one_launch(gpu, core, monkeypatch, gaptol=1e-6, feastol=1e-6, pabstol=1e-5)
+    assert g["path"] == 1
+    assert g["info"].status == ref.status == 0 and g["info"].iterations == ref.iterations
+    assert_history_matches(g, ref)
+    assert np.max(np.abs(g["y"] - ref.y)) <= 1e-7 * (1 + np.max(np.abs(ref.y)))
+    ok, det = checker.certificate(core, g["y"], g["X"], g["lp"][0], 1e-5, 1e-5)
+    assert ok, det
+    # one read-back: the device reports its own cycles, and the host's wall time of the call is not far above them
+    assert g["trace"][43] > 0 and g["info"].solve_seconds < 20e-3
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_sparse_problems_in_one_launch(gpu, seed, monkeypatch):
+    core = random_sparse_core(100 + seed)
+    ref = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-6, feastol=1e-6, pabstol=1e-5))
+    g = solve_one_launch(gpu, core, monkeypatch, gaptol=1e-6, feastol=1e-6, pabstol=1e-5)
+    assert g["path"] == 1
+    assert g["info"].status == ref.status
+    assert abs(g["info"].iterations - ref.iterations) <= (0 if ref.status == 0 else 1)
+    if ref.status == 0:
+        assert_history_matches(g, ref)
+        # (random sparse matrices can be linearly dependent: y is then not unique - the objective and the optimality certificate are)
+        assert abs(g["info"].dobj - ref.dobj) <= 1e-6 * (1 + abs(ref.dobj))
+        ok, det = checker.certificate(core, g["y"], g["X"], g["lp"][0], 1e-5, 1e-5)
+        assert ok, det
+
+
+def test_dense_matrices_are_declined_and_solved_by_the_general_path(gpu, monkeypatch):
+    """43 x 43 block with 33 DENSE matrices (example_CLS) and a dense planted block: more work per Schur assembly than one compute
+    unit should take - the kernel counts the nonzeros, declines, and the call is served by the general path with the same answer"""
+    for core in (instance_core("example_CLS.dat-s.gz"), ipm_ref.CoreProblem(*(lambda t: (t[0], [t[1]]))(instances.planted_dense(40, 30)))):
+        ref = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-6, feastol=1e-6, pabstol=1e-5))
+        g = solve_one_launch(gpu, core, monkeypatch, gaptol=1e-6, feastol=1e-6, pabstol=1e-5)
+        assert g["path"] == 0
+        assert g["info"].status == ref.status == 0 and g["info"].iterations == ref.iterations
+
+
+def test_small_dense_block_runs_in_one_launch(gpu, monkeypatch):
+    """dense matrices of a few rows go through the whole-matrix form of the assembly (T_j and U_j in the scratch region)"""
+    b, A, ys, Xs, Zs = instances.planted_dense(8, 12)
+    core = ipm_ref.CoreProblem(b, [A])
+    ref = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-5, feastol=1e-5, pabstol=1e-4))
+    g = solve_one_launch(gpu, core, monkeypatch, gaptol=1e-5, feastol=1e-5, pabstol=1e-4)
+    assert g["path"] == 1 and g["info"].status == ref.status == 0 and g["info"].iterations == ref.iterations
+    assert_history_matches(g, ref, rtol=1e-4)
+    assert abs(g["info"].dobj - b @ ys) <= 1e-4 * (1 + abs(b @ ys))
+
+
+def test_warm_start_in_one_launch(gpu, monkeypatch):
+    core = random_sparse_core(7)
+    cold = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-6, feastol=1e-6))
+    assert cold.status == 0
+    # the optimum pushed into the interior, as relax_sdp.c builds its warm-start points
+    lam = 0.5
+    X0 = [(1 - lam) * Xk + lam * np.eye(Xk.shape[0]) for Xk in cold.X]
+    Z0 = [(1 - lam) * Zk + lam * np.eye(Zk.shape[0]) for Zk in cold.Z]
+    x0 = (1 - lam) * cold.x + lam
+    z0 = (1 - lam) * cold.z + lam
+    st = ipm_ref.warm_start_point(core, cold.y, X0, Z0, x0, z0)
+    ref = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-6, feastol=1e-6), start=st)
+    monkeypatch.setenv("HIPSDP_SOLVE1", "1")
+    s = gpu.Solver(0)
+    s.load_core(core)
+    s.set_start(cold.y, X0, Z0, x0, z0)
+    info = s.solve(gaptol=1e-6, feastol=1e-6)
+    assert s.solve_path() == 1 and info.warm_started == 1
+    assert info.status == ref.status == 0 and info.iterations == ref.iterations
+    assert np.max(np.abs(s.y() - ref.y)) <= 1e-6
+    # a start point that is not interior: cold start, same result as without one
+    s.load_core(core)
+    s.set_start(cold.y, [-Xk for Xk in X0], Z0, x0, z0)
+    info2 = s.solve(gaptol=1e-6, feastol=1e-6)
+    assert s.solve_path() == 1 and info2.warm_started == 0 and info2.iterations == cold.iterations
+    s.close()
+
+
+def test_preoptimal_iterate_and_limits_in_one_launch(gpu, monkeypatch):
+    core = instance_core("example_TT.dat-s.gz")
+    ref = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-7, feastol=1e-6, preoptgap=1e-2))
+    monkeypatch.setenv("HIPSDP_SOLVE1", "1")
+    s = gpu.Solver(0)
+    s.load_core(core)
+    info = s.solve(gaptol=1e-7, feastol=1e-6, preoptgap=1e-2)
+    assert s.solve_path() == 1 and info.status == 0 and info.iterations == ref.iterations
+    pre = s.preoptimal()
+    assert pre is not None and ref.pre is not None
+    assert np.allclose(pre[0], ref.pre["y"], atol=1e-7, rtol=1e-6)
+    assert np.allclose(pre[1][0], ref.pre["X"][0], atol=1e-6, rtol=1e-6)
+    assert np.allclose(pre[2], ref.pre["x"], atol=1e-6, rtol=1e-6)
+    # objective limit: the lower bound passes the limit long before the optimum (0.1645) is reached
+    s.load_core(core)
+    info = s.solve(gaptol=1e-7, feastol=1e-6, objlimit=-1.0)
+    assert s.solve_path() == 1 and info.status == 7 and info.iterations <= ref.iterations
+    # iteration limit
+    s.load_core(core)
+    info = s.solve(gaptol=1e-7, feastol=1e-6, maxiter=4)
+    assert s.solve_path() == 1 and info.status == 4 and info.iterations == 4
+    # time limit on the device clock: a limit no solve can keep
+    s.load_core(core)
+    info = s.solve(gaptol=1e-7, feastol=1e-6, timelimit=1e-7)
+    assert s.solve_path() == 1 and info.status == 6
+    s.close()
+
+
+def test_settings_ladder_values_reach_the_kernel(gpu, monkeypatch):
+    core = instance_core("example_TT.dat-s.gz")
+    for settings in (1, 2):
+        par = ipm_ref.Params(gaptol=1e-6, feastol=1e-6, settings=settings)
+        ref = ipm_ref.hsd_solve(core, par)
+        g = solve_one_launch(gpu, core, monkeypatch, gaptol=1e-6, feastol=1e-6, settings=settings)
+        assert g["path"] == 1 and g["info"].settings_used == settings
+        assert g["info"].status == ref.status == 0 and g["info"].iterations == ref.iterations
+
+
+def test_whole_tree_of_example_tt_both_paths_node_by_node(gpu, monkeypatch):
+    """BASELINE config 3 without SCIP: every node of the B&B tree of example_TT (569 nodes: optimal, infeasible, cut off) through
+    SCIPsdpiSolverLoadAndSolve twice - one-launch kernel and general path.  Same outcome at every node, iteration counts within one,
+    optimum of check/testset/short.solu.  (The nodes without an optimum, tau -> 0, are what separates a Schur assembly in the
+    association of the dense formula from the pair formula: DESIGN.md.)"""
+    inst = sdpa_io.read_sdpa(os.path.join(GOLDEN, "instances", "example_TT.dat-s.gz"))
+    prob = bnb.instance_to_sdpi(inst)
+    sa, sb = sdpi_call.SdpiSolver(gpu.lib()), sdpi_call.SdpiSolver(gpu.lib())
+    for s in (sa, sb):
+        for p in (1, 2, 3):
+            assert s.set_real(p, 1e-6) == sdpi_call.SCIP_OKAY
+    tot = dict(a=0, b=0, n=0, diff=0)
+
+    def outcome(s):
+        if s.flag("IsDualInfeasible"):
+            return 'infeasible', None
+        if not s.flag("IsOptimal"):
+            return 'failed', None
+        rc, obj, y = s.dual_sol()
+        return 'optimal', (obj, y)
+
+    def solve(P):
+        monkeypatch.setenv("HIPSDP_SOLVE1", "1")
+        sa.solve(P)
+        ia, oa = sa.iterations(), outcome(sa)
+        monkeypatch.setenv("HIPSDP_SOLVE1", "0")
+        sb.solve(P)
+        ib, ob = sb.iterations(), outcome(sb)
+        tot['a'] += ia; tot['b'] += ib; tot['n'] += 1
+        if oa[0] != ob[0] or abs(ia - ib) > 1 or (oa[0] == 'optimal' and abs(oa[1][0] - ob[1][0]) > 1e-5 * (1 + abs(ob[1][0]))):
+            tot['diff'] += 1
+        return bnb.NodeResult(oa[0]) if oa[0] != 'optimal' else bnb.NodeResult('optimal', oa[1][0], oa[1][1])
+    best, y, nodes, failed = bnb.branch_and_bound(prob, inst.intvars, solve)
+    sa.free(); sb.free()
+    print("example_TT: %d nodes, iterations one-launch %d / general %d, differing nodes %d" % (nodes, tot['a'], tot['b'], tot['diff']))
+    assert abs(best - 2.11803) <= 1e-4 and failed == 0
+    assert tot['diff'] == 0
+    assert abs(tot['a'] - tot['b']) <= 0.005 * tot['b']
