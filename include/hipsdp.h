@@ -280,6 +280,10 @@ HIPSDP_API int  hipsdp_schur_shard_time(int device, int m1, int n, int nranks, i
 /* the same for one rank of the variable-sharded assembly (hipsdp_shard_matrices): only that rank's rows of A are allocated, the
  * column slices are cw wide, the all-to-all keeps the rank's own piece; *a2a_bytes = bytes the rank would send per assembly */
 HIPSDP_API int  hipsdp_schur_var_share_time(int device, int m1, int n, int nranks, int rank, int cw, int reps, double* ms, double* a2a_bytes);
+/* sparse block mode: Schur entries of matrices given as triplets (var 1 .. m, row >= col) exactly as the engine assembles them
+ * (csrc/sparse.hip); Mx (m + 1) x (m + 1), lower triangle of rows / columns 1 .. m */
+HIPSDP_API int  hipsdp_schur_sparse_unit(int device, int n, int m, long long nnz, const int* var, const int* row, const int* col,
+   const double* val, const double* X, const double* Zinv, double* Mx);
 HIPSDP_API int  hipsdp_potrf(int device, int n, double* A, int* fail);                       /* lower Cholesky in place, row-major */
 /* both forms of the blocked factorization for the parity tests: v1 = 1 the four-launch form, 0 one launch per block column; psd = 1
  * semidefinite pivot rule with diag0 = diag(A), forced pivots in regmask[n]; dinv[ceil(n / 64) * 4096] (any output may be NULL) */

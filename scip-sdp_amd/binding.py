@@ -288,6 +288,18 @@ def schur_dense(A, X, Zinv, ws_gbytes=0.0, device=0):
     return Mx
 
 
+def schur_sparse_unit(n, m, coo, X, Zinv, device=0):
+    """(m + 1) x (m + 1) array whose lower triangle of rows / columns 1 .. m holds tr(A_i X A_j Zinv) as csrc/sparse.hip assembles it"""
+    var, row, col, val = coo
+    var = np.ascontiguousarray(var, dtype=np.int32); row = np.ascontiguousarray(row, dtype=np.int32)
+    col = np.ascontiguousarray(col, dtype=np.int32); val = _f64(val)
+    X = _f64(X); Zinv = _f64(Zinv)
+    Mx = np.zeros((m + 1, m + 1))
+    _chk(lib().hipsdp_schur_sparse_unit(device, n, m, C.c_longlong(len(val)), _ip(var), _ip(row), _ip(col), _dp(val), _dp(X), _dp(Zinv), _dp(Mx)),
+         "hipsdp_schur_sparse_unit")
+    return Mx
+
+
 def schur_w(A, X, Z, device=0):
     A = _f64(A)
     m1, n = A.shape[0], A.shape[1]

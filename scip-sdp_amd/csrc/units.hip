@@ -544,3 +544,28 @@ extern "C" int hipsdp_pass_at_unit(int device, int R, long long E, const double*
    return HIPSDP_OK;
 }
 
+/* unit entry of the sparse block mode (csrc/sparse.hip): the Schur entries tr(A_i X A_j Zinv), i, j = 1 .. m, of matrices given as
+ * triplets (var 1 .. m, row >= col), assembled by hs_sp_schur exactly as the engine calls it; Mx: (m + 1) x (m + 1), only the lower
+ * triangle of the rows / columns 1 .. m is written (the rest is returned zero) */
+extern "C" int hipsdp_schur_sparse_unit(int device, int n, int m, long long nnz, const int* var, const int* row, const int* col,
+   const double* val, const double* X, const double* Zinv, double* Mx)
+{
+   HS_CALL( pick_device(device) );
+   if ( n <= 0 || m <= 0 || nnz < 0 || X == NULL || Zinv == NULL || Mx == NULL )
+      return HIPSDP_ERR_ARG;
+   hs_sparse* sp = NULL;
+   HS_CALL( hs_sp_build(&sp, n, m, nnz, var, row, col, val) );
+   const long long n2 = (long long) n * n, mm = (long long) (m + 1) * (m + 1);
+   DevBuf dX, dZ, dM;
+   int rc = dX.alloc(n2);
+   if ( rc == HS_OK ) rc = dZ.alloc(n2);
+   if ( rc == HS_OK ) rc = dM.alloc(mm);
+   if ( rc == HS_OK ) rc = dX.up(X, n2);
+   if ( rc == HS_OK ) rc = dZ.up(Zinv, n2);
+   if ( rc == HS_OK && hipMemset(dM.p, 0, (size_t) mm * sizeof(double)) != hipSuccess ) rc = HS_ERR_HIP;
+   if ( rc == HS_OK ) rc = hs_sp_schur(0, sp, dX.p, dZ.p, dM.p);
+   if ( rc == HS_OK && hipDeviceSynchronize() != hipSuccess ) rc = HS_ERR_HIP;
+   if ( rc == HS_OK ) rc = dM.down(Mx, mm);
+   hs_sp_free(sp);
+   return rc;
+}

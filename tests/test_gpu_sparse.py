@@ -43,19 +43,38 @@ def test_sparse_block_matches_the_dense_block_and_the_oracle(gpu, n, m, k):
     assert np.max(np.abs(y_s - ref.y)) <= 1e-6 * (1 + np.max(np.abs(ref.y)))
 
 
-def test_schur_entries_of_the_pair_formula_against_the_oracle(gpu):
-    """one assembly: after a solve of one iteration the engine's X and Z are read back and the oracle's pair formula
-    (ipm_ref.schur_pairs_sparse) and dense formula agree with each other on them - and the solves above agree with the dense
-    path to 1e-7, which they could not if an entry of the Schur matrix were off"""
-    n, m, k = 70, 40, 4
+@pytest.mark.parametrize("n,m,k", [(70, 40, 4), (96, 120, 3), (130, 60, 9)])
+def test_schur_entries_of_the_sparse_assembly_against_the_oracle(gpu, n, m, k):
+    """the kernels of csrc/sparse.hip themselves (hipsdp_schur_sparse_unit runs hs_sp_schur as the engine calls it), entry by entry
+    against the oracle's pair formula and against the dense three-product formula on the expanded matrices"""
     b, coo, A0, ys, Xs, Zs = instances.planted_sparse(n, m, k, seed=9)
     rng = np.random.default_rng(1)
     X = rng.standard_normal((n, n)); X = X @ X.T + n * np.eye(n)
     Z = rng.standard_normal((n, n)); Z = Z @ Z.T + n * np.eye(n)
-    Zi = np.linalg.inv(Z)
+    Zi = np.linalg.inv(Z); Zi = 0.5 * (Zi + Zi.T)
+    Mg = gpu.schur_sparse_unit(n, m, coo, X, Zi)[1:, 1:]
     M1 = ipm_ref.schur_block(instances.coo_to_dense(n, m, coo, A0), X, Zi)[1:, 1:]
     M2 = ipm_ref.schur_pairs_sparse(m, coo, X, Zi)
-    assert np.max(np.abs(M1 - M2)) <= 1e-12 * np.max(np.abs(M1))
+    il = np.tril_indices(m)
+    scale = np.max(np.abs(M1))
+    assert np.max(np.abs(M1 - M2)) <= 1e-12 * scale
+    assert np.max(np.abs(Mg[il] - M2[il])) <= 1e-12 * scale
+    assert np.max(np.abs(Mg[il] - M1[il])) <= 1e-12 * scale
+
+
+@pytest.mark.parametrize("n,m,k,policy", [(70, 40, 4, 2), (88, 60, 3, 2), (40, 30, 3, 2), (64, 50, 2, 2)])
+def test_sparse_blocks_of_at_most_90_rows_are_solved_by_the_engine(gpu, n, m, k, policy):
+    """blocks of at most 90 rows kept as nonzeros (policy 2 forces it at any size; the default policy does it from 65 rows on when the
+    caller's count makes it the cheaper assembly): such a block has no dense rows A_i, so none of the fused small-problem kernels
+    (which read A + i n^2) may take it (advisor finding of round 3: small_problem() did not exclude them)"""
+    b, coo, A0, ys, Xs, Zs = instances.planted_sparse(n, m, k, seed=300 + n)
+    sp, info, y, X = _solve(gpu, n, m, b, coo, A0, policy, tol=1e-6)
+    assert sp
+    core = ipm_ref.CoreProblem(b, [instances.coo_to_dense(n, m, coo, A0)])
+    ref = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-6, feastol=1e-6))
+    assert info.status == ref.status == 0 and info.iterations == ref.iterations
+    assert abs(info.dobj - float(b @ ys)) <= 1e-5 * (1 + abs(float(b @ ys)))
+    assert np.max(np.abs(y - ref.y)) <= 1e-6 * (1 + np.max(np.abs(ref.y)))
 
 
 def test_three_nonzeros_per_matrix_n500_m2000_takes_megabytes_not_gigabytes(gpu):
