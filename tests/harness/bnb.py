@@ -163,3 +163,32 @@ def oracle_node_solver(tol=1e-6):
             y[v] = r.y[k]
         return NodeResult('optimal', float(P.prob.obj @ y), y)
     return solve
+
+
+def cpu_c_node_solver(tol=1e-6, stats=None):
+    """the same with the plain-C restatement of the iteration (oracle/cpu_ref.c) as node solver: the compiled CPU figure beside the
+    device numbers (bench.py); stats (dict) collects calls / iterations / seconds inside the C solve"""
+    import time
+    import ipm_ref
+    import cpu_ref
+
+    def solve(P):
+        b, blk, D, c, maps = sdpi_prepare.to_core(P)
+        core = ipm_ref.CoreProblem(b, blk, D, c)
+        t0 = time.perf_counter()
+        info, yv = cpu_ref.solve(core, gaptol=tol, feastol=tol)
+        if stats is not None:
+            stats["seconds"] = stats.get("seconds", 0.0) + time.perf_counter() - t0
+            stats["calls"] = stats.get("calls", 0) + 1
+            stats["iters"] = stats.get("iters", 0) + info.iterations
+        if info.status in (ipm_ref.STATUS_DINF, ipm_ref.STATUS_PDINF):
+            return NodeResult('infeasible')
+        if info.status == ipm_ref.STATUS_DUNB:
+            return NodeResult('unbounded')
+        if info.status != ipm_ref.STATUS_OPTIMAL:
+            return NodeResult('failed')
+        y = np.array(P.lb, dtype=float)
+        for k, v in enumerate(maps["active"]):
+            y[v] = yv[k]
+        return NodeResult('optimal', float(P.prob.obj @ y), y)
+    return solve
