@@ -284,6 +284,14 @@ HIPSDP_API int  hipsdp_schur_var_share_time(int device, int m1, int n, int nrank
  * (csrc/sparse.hip); Mx (m + 1) x (m + 1), lower triangle of rows / columns 1 .. m */
 HIPSDP_API int  hipsdp_schur_sparse_unit(int device, int n, int m, long long nnz, const int* var, const int* row, const int* col,
    const double* val, const double* X, const double* Zinv, double* Mx);
+/* measured FP64 matrix peak of the device: a chip-filling launch of register-only v_mfma_f64_16x16x4_f64 for about ms milliseconds;
+ * *tflops by HIP events, *ghz = shader clocks per wall tick inside the kernel (bench.py prices its roofline against this as well) */
+HIPSDP_API int  hipsdp_mfma_peak(int device, double ms, double* tflops, double* ghz);
+/* shader frequency DURING the Schur assemblies of a solve: with sampling on, one-thread kernels right before and right after every
+ * assembly read the shader-clock and the 100 MHz counters on the engine's stream; *ghz = sum of clock differences / sum of time
+ * differences over the assemblies of the last solve (0 when none was sampled) */
+HIPSDP_API int  hipsdp_set_clock_sampling(hipsdp_solver* solver, int on);
+HIPSDP_API int  hipsdp_get_assembly_clock(hipsdp_solver* solver, double* ghz);
 HIPSDP_API int  hipsdp_potrf(int device, int n, double* A, int* fail);                       /* lower Cholesky in place, row-major */
 /* both forms of the blocked factorization for the parity tests: v1 = 1 the four-launch form, 0 one launch per block column; psd = 1
  * semidefinite pivot rule with diag0 = diag(A), forced pivots in regmask[n]; dinv[ceil(n / 64) * 4096] (any output may be NULL) */

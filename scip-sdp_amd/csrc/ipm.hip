@@ -169,6 +169,8 @@ struct hipsdp_solver
    int a_r0, a_r1;         /* rows of A (0 = constant matrix, i = variable i) this rank holds; [0, m + 1) when replicated */
    hipsdp_params par;
    PhaseClock pc;
+   /* shader clock during the Schur assemblies (hipsdp_set_clock_sampling): 4 words per assembly */
+   bool clk_on; unsigned long long* clk_buf; int clk_n; double clk_ghz;
    /* one-launch solve of B&B-sized problems (csrc/solve1.hip) */
    double* s1_ws;          /* device workspace (cold matrices and nonzero lists that do not fit into LDS) */
    long long s1_ws_len;
@@ -380,6 +382,7 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
       s->use_publish = !(rb != NULL && rb[0] == 'c');
    }
    s->hsc_cap = 0;
+   s->clk_on = false; s->clk_buf = NULL; s->clk_n = 0; s->clk_ghz = 0.0;
    s->s1_ws = NULL; s->s1_ws_len = 0; s->s1_host = NULL; s->s1_host_dev = NULL; s->s1_seq = 0; s->s1_last = 0;
    s->trsv_ws = NULL;
    s->pre_y = s->pre_x = NULL;
@@ -444,6 +447,8 @@ extern "C" void hipsdp_free(hipsdp_solver** ps)
    s->s1_host = NULL;
    if ( s->s1_ws != NULL ) (void) hipFree(s->s1_ws);
    s->s1_ws = NULL;
+   if ( s->clk_buf != NULL ) (void) hipFree(s->clk_buf);
+   s->clk_buf = NULL;
    for (auto& mk : s->pc.marks) (void) hipEventDestroy(mk.second);
    for (hipEvent_t e : s->pc.pool) (void) hipEventDestroy(e);
    for (int b = 0; b < 2; ++b)
@@ -2243,6 +2248,30 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
    return rc;
 }
 
+#define CLK_MAX_ASSEMBLIES 256
+__global__ void k_clock_sample(unsigned long long* __restrict__ out)
+{
+   out[0] = clock64();
+   out[1] = wall_clock64();
+}
+
+extern "C" int hipsdp_set_clock_sampling(hipsdp_solver* s, int on)
+{
+   if ( s == NULL ) return HIPSDP_ERR_ARG;
+   HS_HIP( hipSetDevice(s->device) );
+   if ( on && s->clk_buf == NULL )
+      HS_HIP( hipMalloc((void**) &s->clk_buf, (size_t) CLK_MAX_ASSEMBLIES * 4 * sizeof(unsigned long long)) );
+   s->clk_on = on != 0;
+   return HIPSDP_OK;
+}
+
+extern "C" int hipsdp_get_assembly_clock(hipsdp_solver* s, double* ghz)
+{
+   if ( s == NULL || ghz == NULL ) return HIPSDP_ERR_ARG;
+   *ghz = s->clk_ghz;
+   return HIPSDP_OK;
+}
+
 /* ---- B&B-sized problems: the whole solve in one launch of one workgroup (csrc/solve1.hip).  Returns HS_OK and *done = true when the
  * solve ran there; *done = false: not this path's problem (shape, options) or the kernel declined (too much work for one compute
  * unit) - nothing has been touched and the general path below takes over.  HIPSDP_SOLVE1=0 switches the path off. */
@@ -2287,7 +2316,8 @@ static int solve1_try(hipsdp_solver* s, hipsdp_info* info, bool* done)
       {
          HS_HIP( hipStreamSynchronize(st) );
          (void) hipFree(s->s1_ws);
-         s->s1_ws = NULL; s->s1_ws_len = 0;
+         s->clk_on = false; s->clk_buf = NULL; s->clk_n = 0; s->clk_ghz = 0.0;
+   s->s1_ws = NULL; s->s1_ws_len = 0;
       }
       const long long len = want + want / 2 + 4096;
       HS_HIP( hipMalloc((void**) &s->s1_ws, (size_t) len * sizeof(double)) );
@@ -2480,6 +2510,8 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
    info->status = HIPSDP_STATUS_UNSOLVED;
    hs_red_batch_reset();
    s->pre_valid = false;
+   s->clk_n = 0;
+   s->clk_ghz = 0.0;
    {
       bool done1 = false;
       HS_CALL( solve1_try(s, info, &done1) );
@@ -2935,6 +2967,12 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       /* ---- Schur complement (extended by the constant matrix as "variable 0") */
       phase_mark(s, PH_SCHUR);
       hs_comm_phase(0);
+      const bool clk_this = s->clk_on && s->clk_buf != NULL && s->clk_n < CLK_MAX_ASSEMBLIES;
+      if ( clk_this )
+      {
+         hipLaunchKernelGGL(k_clock_sample, dim3(1), dim3(1), 0, st, s->clk_buf + 4 * s->clk_n);
+         HS_LAUNCH_CHECK();
+      }
       HS_HIP( hipEventRecord(s->ev0, st) );
       const double mfma_flops_before = hs_mfma_flops_total();
       bool schur_small = false;
@@ -3053,6 +3091,12 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       HS_CALL( hs_mirror_lower(st, s->Mx, m1, m1) );
       }
       HS_HIP( hipEventRecord(s->ev1, st) );
+      if ( clk_this )
+      {
+         hipLaunchKernelGGL(k_clock_sample, dim3(1), dim3(1), 0, st, s->clk_buf + 4 * s->clk_n + 2);
+         HS_LAUNCH_CHECK();
+         ++s->clk_n;
+      }
       info->schur_flops_executed += hs_mfma_flops_total() - mfma_flops_before;
       hs_comm_phase(2);
       phase_mark(s, PH_MSOLVE);
@@ -3397,6 +3441,18 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
    if ( zchain_queued )
       HS_CALL( join2(s) );
    HS_HIP( hipStreamSynchronize(st) );
+   if ( s->clk_on && s->clk_n > 0 )
+   {
+      std::vector<unsigned long long> h((size_t) 4 * s->clk_n);
+      HS_HIP( hipMemcpy(h.data(), s->clk_buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) );
+      double dc = 0.0, dw = 0.0;
+      for (int a = 0; a < s->clk_n; ++a)
+      {
+         dc += (double) (h[4 * a + 2] - h[4 * a]);
+         dw += (double) (h[4 * a + 3] - h[4 * a + 1]);
+      }
+      s->clk_ghz = dw > 0.0 ? dc / (dw * 10.0) : 0.0;
+   }
    phase_finish(s);
    s->last_status = status;
    s->solved = true;

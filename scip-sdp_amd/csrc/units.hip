@@ -569,3 +569,83 @@ extern "C" int hipsdp_schur_sparse_unit(int device, int n, int m, long long nnz,
    hs_sp_free(sp);
    return rc;
 }
+
+/* ---- measured FP64 matrix peak of THIS device ("peak values are measured on the box"): every wavefront of a
+ * chip-filling launch issues independent v_mfma_f64_16x16x4_f64 out of registers, nothing else - no memory traffic, no barriers -
+ * for about `ms` milliseconds; *tflops = matrix flops / HIP-event time, *ghz = shader clocks / 100 MHz ticks inside the kernel (the
+ * frequency the firmware grants under pure matrix load).  The roofline of bench.py is priced against the vendor figure AND this. */
+typedef double up_v4d __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_mfma_peak(long long iters, double* __restrict__ sink, unsigned long long* __restrict__ clk)
+{
+   up_v4d a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0, a4 = a0, a5 = a0, a6 = a0, a7 = a0;
+   const double x = 1.0 + 1e-9 * (double) threadIdx.x, y = 1.0 - 1e-9 * (double) threadIdx.x;
+   unsigned long long c0 = 0, w0 = 0;
+   if ( blockIdx.x == 0 && threadIdx.x == 0 )
+   {
+      c0 = clock64();
+      w0 = wall_clock64();
+   }
+   /* (tied inline asm: with the builtin the register allocator moved the 64 accumulator registers between the two register files in
+    * every trip - 128 copies around 8 matrix instructions, 60 % of the rate) */
+#define UP_MFMA(acc, p, q) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(p), "v"(q))
+   for (long long i = 0; i < iters; ++i)
+   {
+      UP_MFMA(a0, x, y); UP_MFMA(a1, y, x); UP_MFMA(a2, x, x); UP_MFMA(a3, y, y);
+      UP_MFMA(a4, x, y); UP_MFMA(a5, y, x); UP_MFMA(a6, x, x); UP_MFMA(a7, y, y);
+   }
+   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+   if ( blockIdx.x == 0 && threadIdx.x == 0 )
+   {
+      clk[0] = clock64() - c0;
+      clk[1] = wall_clock64() - w0;
+   }
+   const up_v4d t = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+   if ( t[0] + t[1] + t[2] + t[3] == 12345.678 )          /* (never: keeps the accumulators alive) */
+      sink[threadIdx.x] = t[0];
+}
+
+extern "C" int hipsdp_mfma_peak(int device, double ms, double* tflops, double* ghz)
+{
+   HS_CALL( pick_device(device) );
+   if ( !(ms > 0.0) ) ms = 20.0;
+   DevBuf sink, clk;
+   HS_CALL( sink.alloc(256) ); HS_CALL( clk.alloc(2) );
+   const int cus = hs_device_cus() > 0 ? hs_device_cus() : 256;
+   hipEvent_t e0, e1;
+   HS_HIP( hipEventCreate(&e0) ); HS_HIP( hipEventCreate(&e1) );
+   double best = 0.0, bestghz = 0.0;
+   /* one, two and four workgroups of four wavefronts per compute unit: the best of them is the figure (which occupancy feeds the
+    * matrix pipes best is the device's business) */
+   for (int wgpc = 1; wgpc <= 4; wgpc *= 2)
+   {
+      const int grid = cus * wgpc;
+      long long iters = 20000;
+      float t = 0.f;
+      for (int pass = 0; pass < 3; ++pass)                         /* pass 0 warms up and calibrates the trip count */
+      {
+         HS_HIP( hipEventRecord(e0, 0) );
+         hipLaunchKernelGGL(k_mfma_peak, dim3(grid), dim3(256), 0, 0, iters, sink.p, reinterpret_cast<unsigned long long*>(clk.p));
+         HS_HIP( hipEventRecord(e1, 0) );
+         HS_HIP( hipEventSynchronize(e1) );
+         HS_HIP( hipEventElapsedTime(&t, e0, e1) );
+         if ( pass == 0 && t > 0.f )
+         {
+            iters = (long long) ((double) iters * ms / (double) t);
+            if ( iters < 1000 ) iters = 1000;
+         }
+      }
+      unsigned long long h[2] = {0, 0};
+      HS_HIP( hipMemcpy(h, clk.p, sizeof(h), hipMemcpyDeviceToHost) );
+      const double flops = (double) iters * 8.0 * 2048.0 * 4.0 * (double) grid;      /* 2048 flops per instruction, 4 wavefronts per workgroup */
+      const double tf = flops / ((double) t * 1e-3) / 1e12;
+      if ( tf > best )
+      {
+         best = tf;
+         bestghz = h[1] > 0 ? (double) h[0] / ((double) h[1] * 10.0) : 0.0;      /* wall ticks are 10 ns */
+      }
+   }
+   (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+   if ( tflops != NULL ) *tflops = best;
+   if ( ghz != NULL ) *ghz = bestghz;
+   return HIPSDP_OK;
+}
