@@ -101,6 +101,11 @@ struct hs_schur_ws
    long long n2;           /* doubles per matrix the allocation was sized for */
    long long kws_len;
    int       full;         /* 1: T and U hold all m1 matrices (hs_schur_W usable) */
+   /* variable-sharded form, overlapped exchange: second send / receive buffers and the events of the two-slice pipeline */
+   double*   U2;
+   double*   V2;
+   void*     evP[2];       /* hipEvent_t: the products of a slice are in its send buffer */
+   void*     evX[2];       /* hipEvent_t: the exchange of a slice has arrived */
 };
 int  hs_schur_ws_alloc(hs_schur_ws* w, int m1, long long n2max, double budget_gb);
 void hs_schur_ws_free(hs_schur_ws* w);
@@ -126,6 +131,14 @@ void hs_shard_cols(int m1, int n, int nranks, int rank, int* c_begin, int* c_wid
 int  hs_schur_Wvar(hipStream_t s, void* comm, int rank, int nranks, int m1, int n, const double* A, const double* R, const double* G,
    double* Mx, hs_schur_ws* w, int c0, int cw);
 int  hs_schur_ws_alloc_var(hs_schur_ws* w, int m1, int nranks, int n, int cwmax);
+/* the second pair of buffers + events for hs_schur_Wvar_all(overlap); HS_ERR_NOMEM leaves the in-order form usable */
+int  hs_schur_ws_alloc_var_overlap(hs_schur_ws* w);
+/* all column slices of one block: slice after slice as hs_schur_Wvar does (overlap = 0), or - overlap = 1, second buffers present -
+ * as a two-slice pipeline: the all-to-all of slice s runs on the communication queue `sc` behind an event while the compute queue
+ * forms the products of slice s + 1; the Gram update of slice s waits for its exchange.  Same kernels, same arguments, same order
+ * of the updates of Mx: bit-identical to the in-order form. */
+int  hs_schur_Wvar_all(hipStream_t s, hipStream_t sc, void* comm, int rank, int nranks, int m1, int n, const double* A, const double* R,
+   const double* G, double* Mx, hs_schur_ws* w, int cwmax, int overlap);
 void hs_var_rows(int m1, int nranks, int rank, int* r0, int* r1);            /* rows of A (variables) a rank owns */
 void hs_var_wrows(int n, int nranks, int rank, int* q0, int* q1);            /* rows of the W_j a rank receives */
 int  hs_alltoall(void* comm, const double* send, double* recv, const long long* cnt, hipStream_t stream);

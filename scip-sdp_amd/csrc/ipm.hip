@@ -165,6 +165,7 @@ struct hipsdp_solver
    int shard_passes;       /* -1: by size (>= 64 MB per pass), 0 / 1: HIPSDP_SHARD_PASSES */
    int shardA_req;         /* hipsdp_shard_matrices: 0 replicated (default), 1 by variable, -1 by size against the free memory */
    int var_cw;             /* matrices sharded by variable: columns per slice of the Schur assembly */
+   bool var_overlap;       /* ... and the all-to-all of a slice runs on the second queue beside the products of the next one */
    bool shardA;            /* decided by set_shape: this problem's constraint matrices are sharded by variable */
    int a_r0, a_r1;         /* rows of A (0 = constant matrix, i = variable i) this rank holds; [0, m + 1) when replicated */
    hipsdp_params par;
@@ -372,7 +373,8 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
    s->Mgather = NULL;
    s->schur_mode_rows = false;
    s->schur_mode_cols = false; s->schur_sim_shards = 0;
-   s->sws.T = s->sws.U = s->sws.K = s->sws.V = NULL;
+   s->sws.T = s->sws.U = s->sws.K = s->sws.V = s->sws.U2 = s->sws.V2 = NULL;
+   s->sws.evP[0] = s->sws.evP[1] = s->sws.evX[0] = s->sws.evX[1] = NULL;
    s->flags = NULL;
    s->hsc = NULL;
    s->hsc_dev = NULL;
@@ -710,7 +712,8 @@ extern "C" int hipsdp_set_shape2(hipsdp_solver* s, int m, int nblocks, const int
    if ( m > 2 * 64 )
       HS_CALL( hs_trsv_sync_init(s->stream, m, s->trsv_ws, &s->trsv_epoch) );
    s->trsv_epoch = 0;
-   s->sws.T = s->sws.U = s->sws.K = s->sws.V = NULL;
+   s->sws.T = s->sws.U = s->sws.K = s->sws.V = s->sws.U2 = s->sws.V2 = NULL;
+   s->sws.evP[0] = s->sws.evP[1] = s->sws.evX[0] = s->sws.evX[1] = NULL;
    HS_HIP( hipMemsetAsync(s->Dext, 0, (size_t) ((long long) q * m1 > 0 ? (long long) q * m1 : 1) * sizeof(double), s->stream) );
    HS_HIP( hipMemsetAsync(s->b, 0, (size_t) (m > 0 ? m : 1) * sizeof(double), s->stream) );
    HS_HIP( hipStreamSynchronize(s->stream) );
@@ -1469,7 +1472,9 @@ static int ensure_schur_ws(hipsdp_solver* s)
        * doubles.  The widest slice that fits the budget (a multiple of 128, or all n columns); same numbers on every rank. */
       int nmaxb = 1;
       for (auto& B : s->blk) if ( B.n > nmaxb ) nmaxb = B.n;
-      const double per_col = 3.0 * 8.0 * (double) ((m1 + s->nranks - 1) / s->nranks + 1) * (double) nmaxb;
+      /* overlapped exchange (default; HIPSDP_VAR_OVERLAP=0: slice after slice): a second send and a second receive buffer */
+      static const bool var_overlap = !(getenv("HIPSDP_VAR_OVERLAP") != NULL && getenv("HIPSDP_VAR_OVERLAP")[0] == '0');
+      const double per_col = (var_overlap ? 5.0 : 3.0) * 8.0 * (double) ((m1 + s->nranks - 1) / s->nranks + 1) * (double) nmaxb;
       long long cw = (long long) (budget * 1e9 / per_col);
       const char* ecw = getenv("HIPSDP_VAR_SLICE");          /* test hook: force narrow slices */
       if ( ecw != NULL && atoi(ecw) > 0 )
@@ -1479,6 +1484,9 @@ static int ensure_schur_ws(hipsdp_solver* s)
       if ( cw > nmaxb ) cw = nmaxb;
       s->var_cw = (int) cw;
       HS_CALL( hs_schur_ws_alloc_var(&s->sws, m1, s->nranks, nmaxb, (int) cw) );
+      s->var_overlap = false;
+      if ( var_overlap && cw < nmaxb )                /* (one slice: nothing to overlap with) */
+         s->var_overlap = (hs_schur_ws_alloc_var_overlap(&s->sws) == HS_OK);
       s->schur_mode_U = false; s->schur_mode_rows = false; s->schur_mode_forced = true;
       return HS_OK;
    }
@@ -3004,9 +3012,9 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       {
          /* matrices sharded by variable: W_j where A_j lives, all-to-all of the row ranges, partial Gram matrices summed */
          for (auto& B : s->blk)
-            for (int c0 = 0; c0 < B.n && !B.sparse; c0 += s->var_cw)
-               HS_CALL( hs_schur_Wvar(st, s->comm, s->rank, s->nranks, m1, B.n, B.A, B.Lx, B.LzInv, s->Mx, &s->sws, c0,
-                     B.n - c0 < s->var_cw ? B.n - c0 : s->var_cw) );
+            if ( !B.sparse )
+               HS_CALL( hs_schur_Wvar_all(st, s->stream2, s->comm, s->rank, s->nranks, m1, B.n, B.A, B.Lx, B.LzInv, s->Mx, &s->sws, s->var_cw,
+                     s->var_overlap ? 1 : 0) );
          HS_CALL( hs_allreduce_sum(s->comm, s->Mx, (long long) m1 * m1, st) );
       }
       else if ( s->schur_mode_cols )

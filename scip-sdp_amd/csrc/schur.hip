@@ -25,7 +25,8 @@
 
 int hs_schur_ws_alloc(hs_schur_ws* w, int m1, long long n2max, double budget_gb)
 {
-   w->T = w->U = w->K = w->V = NULL;
+   w->T = w->U = w->K = w->V = w->U2 = w->V2 = NULL;
+   w->evP[0] = w->evP[1] = w->evX[0] = w->evX[1] = NULL;
    w->capT = w->capV = 0;
    const double need_full = 2.0 * 8.0 * (double) m1 * (double) n2max;
    long long cols = m1;
@@ -72,7 +73,15 @@ void hs_schur_ws_free(hs_schur_ws* w)
    hs_pool_free(w->U);
    hs_pool_free(w->K);
    hs_pool_free(w->V);
-   w->T = w->U = w->K = w->V = NULL;
+   hs_pool_free(w->U2);
+   hs_pool_free(w->V2);
+   for (int i = 0; i < 2; ++i)
+   {
+      if ( w->evP[i] != NULL ) (void) hipEventDestroy((hipEvent_t) w->evP[i]);
+      if ( w->evX[i] != NULL ) (void) hipEventDestroy((hipEvent_t) w->evX[i]);
+      w->evP[i] = w->evX[i] = NULL;
+   }
+   w->T = w->U = w->K = w->V = w->U2 = w->V2 = NULL;
 }
 
 int hs_schur_U(hipStream_t s, int m1, int n, const double* A, const double* X, const double* Zinv, double* Mx,
@@ -241,7 +250,8 @@ void hs_var_wrows(int n, int nranks, int rank, int* q0, int* q1)
 
 int hs_schur_ws_alloc_var(hs_schur_ws* w, int m1, int nranks, int n, int cwmax)
 {
-   w->T = w->U = w->K = w->V = NULL;
+   w->T = w->U = w->K = w->V = w->U2 = w->V2 = NULL;
+   w->evP[0] = w->evP[1] = w->evX[0] = w->evX[1] = NULL;
    w->full = 0; w->chunk_cols = 0; w->n2 = 0;
    const long long cj = (m1 + nranks - 1) / nranks;
    long long rowsmax = 1;
@@ -273,24 +283,53 @@ int hs_schur_ws_alloc_var(hs_schur_ws* w, int m1, int nranks, int n, int cwmax)
    return HS_OK;
 }
 
-int hs_schur_Wvar(hipStream_t s, void* comm, int rank, int nranks, int m1, int n, const double* A, const double* R, const double* G,
-   double* Mx, hs_schur_ws* w, int c0, int cw)
+int hs_schur_ws_alloc_var_overlap(hs_schur_ws* w)
 {
-   if ( cw <= 0 )
-      return HS_OK;
+   if ( w->U == NULL || w->V == NULL )
+      return HS_ERR_ARG;
+   if ( hs_pool_alloc((void**) &w->U2, (size_t) w->capT * sizeof(double)) != HS_OK
+      || hs_pool_alloc((void**) &w->V2, (size_t) w->capV * sizeof(double)) != HS_OK )
+   {
+      hs_pool_free(w->U2); hs_pool_free(w->V2);
+      w->U2 = w->V2 = NULL;
+      return HS_ERR_NOMEM;
+   }
+   for (int i = 0; i < 2; ++i)
+   {
+      hipEvent_t e = NULL;
+      HS_HIP( hipEventCreateWithFlags(&e, hipEventDisableTiming) );
+      w->evP[i] = (void*) e;
+      HS_HIP( hipEventCreateWithFlags(&e, hipEventDisableTiming) );
+      w->evX[i] = (void*) e;
+   }
+   return HS_OK;
+}
+
+namespace {
+
+/* the three stages of one column slice [c0, c0 + cw) of the variable-sharded assembly */
+struct WvarSlice
+{
+   int rank, nranks, m1, n, c0, cw, r0, r1, cj;
+   long long n2, nk, Kme;
+   long long cnt[64 * 64];
+};
+
+int wvar_setup(WvarSlice& q, const hs_schur_ws* w, int rank, int nranks, int m1, int n, int c0, int cw)
+{
    if ( nranks < 1 || nranks > 64 || w->V == NULL || c0 < 0 || c0 + cw > n )
       return HS_ERR_ARG;
-   const long long n2 = (long long) n * n;
-   const long long nk = (long long) n * cw;
-   int r0, r1, p0, p1;
-   hs_var_rows(m1, nranks, rank, &r0, &r1);
+   q.rank = rank; q.nranks = nranks; q.m1 = m1; q.n = n; q.c0 = c0; q.cw = cw;
+   q.n2 = (long long) n * n;
+   q.nk = (long long) n * cw;
+   int p0, p1;
+   hs_var_rows(m1, nranks, rank, &q.r0, &q.r1);
    hs_var_wrows(n, nranks, rank, &p0, &p1);
-   const int cj = r1 - r0;
-   const long long Kme = (long long) (p1 - p0) * cw;
-   if ( (long long) cj * nk > w->capT || (long long) m1 * Kme > w->capV || (long long) cj * n > 2000000000LL || nk > 2000000000LL
-      || Kme > 2000000000LL )
+   q.cj = q.r1 - q.r0;
+   q.Kme = (long long) (p1 - p0) * cw;
+   if ( (long long) q.cj * q.nk > w->capT || (long long) m1 * q.Kme > w->capV || (long long) q.cj * n > 2000000000LL || q.nk > 2000000000LL
+      || q.Kme > 2000000000LL )
       return HS_ERR_ARG;
-   long long cnt[64 * 64];
    for (int src = 0; src < nranks; ++src)
    {
       int a0, a1;
@@ -299,29 +338,40 @@ int hs_schur_Wvar(hipStream_t s, void* comm, int rank, int nranks, int m1, int n
       {
          int q0, q1;
          hs_var_wrows(n, nranks, dst, &q0, &q1);
-         cnt[src * nranks + dst] = (long long) (a1 - a0) * (q1 - q0) * cw;
+         q.cnt[src * nranks + dst] = (long long) (a1 - a0) * (q1 - q0) * cw;
       }
    }
-   if ( cj > 0 )
+   return HS_OK;
+}
+
+/* T_j[:, slice] = A_j R, then W_j[rows of rank h, slice] = G T_j into the send buffer, piece by piece */
+int wvar_products(hipStream_t s, const WvarSlice& q, const double* A, const double* R, const double* G, hs_schur_ws* w, double* send)
+{
+   const int n = q.n, cw = q.cw, c0 = q.c0, cj = q.cj;
+   if ( cj <= 0 )
+      return HS_OK;
+   hs_gemm_args g1 = {cj * n, cw, n - c0, HS_KC, HS_MC, A + (long long) q.r0 * q.n2 + c0, n, 0, R + (long long) c0 * n + c0, n, 0, w->T, cw, 0,
+      1.0, 0.0, 1, HS_GEMM_B_LOWTRI, 1, NULL};
+   HS_CALL( hs_dgemm(s, &g1) );
+   for (int h = 0; h < q.nranks; ++h)
    {
-      /* T_j[:, slice] = A_j[:, c0:] R[c0:, slice] for the own j (R lower triangular: the product starts at k = c0) */
-      hs_gemm_args g1 = {cj * n, cw, n - c0, HS_KC, HS_MC, A + (long long) r0 * n2 + c0, n, 0, R + (long long) c0 * n + c0, n, 0, w->T, cw, 0,
-         1.0, 0.0, 1, HS_GEMM_B_LOWTRI, 1, NULL};
-      HS_CALL( hs_dgemm(s, &g1) );
-      /* W_j[q0:q1, slice] = G[q0:q1, 0:q1] T_j[0:q1, slice], written where the piece for rank h starts in the send buffer */
-      for (int h = 0; h < nranks; ++h)
-      {
-         int q0, q1;
-         hs_var_wrows(n, nranks, h, &q0, &q1);
-         if ( q1 <= q0 )
-            continue;
-         const long long piece = (long long) (q1 - q0) * cw;
-         hs_gemm_args g2 = {q1 - q0, cw, q1, HS_KC, HS_MC, G + (long long) q0 * n, n, 0, w->T, cw, nk, w->U + (long long) cj * q0 * cw, cw, piece,
-            1.0, 0.0, cj, HS_GEMM_REMAP, 1, NULL};
-         HS_CALL( hs_dgemm(s, &g2) );
-      }
+      int q0, q1;
+      hs_var_wrows(n, q.nranks, h, &q0, &q1);
+      if ( q1 <= q0 )
+         continue;
+      const long long piece = (long long) (q1 - q0) * cw;
+      hs_gemm_args g2 = {q1 - q0, cw, q1, HS_KC, HS_MC, G + (long long) q0 * n, n, 0, w->T, cw, q.nk, send + (long long) cj * q0 * cw, cw, piece,
+         1.0, 0.0, cj, HS_GEMM_REMAP, 1, NULL};
+      HS_CALL( hs_dgemm(s, &g2) );
    }
-   HS_CALL( hs_alltoall(comm, w->U, w->V, cnt, s) );
+   return HS_OK;
+}
+
+/* Mx += V V^T over this rank's rows of all W_j (lower tiles) */
+int wvar_gram(hipStream_t s, const WvarSlice& q, hs_schur_ws* w, const double* recv, double* Mx)
+{
+   const int m1 = q.m1;
+   const long long Kme = q.Kme;
    if ( Kme <= 0 )
       return HS_OK;
    int flags = HS_GEMM_LOWER;
@@ -338,9 +388,63 @@ int hs_schur_Wvar(hipStream_t s, void* comm, int rank, int nranks, int m1, int n
       sk = hs_dgemm_pick_splitk(m1, m1, (int) Kme, 1);
       while ( sk > 1 && (long long) sk * m1 * m1 > w->kws_len ) --sk;
    }
-   hs_gemm_args g3 = {m1, m1, (int) Kme, HS_KC, HS_KC, w->V, Kme, 0, w->V, Kme, 0, Mx, m1, 0, 1.0, 1.0, 1, flags, sk, w->K};
-   HS_CALL( hs_dgemm(s, &g3) );
-   return HS_OK;
+   hs_gemm_args g3 = {m1, m1, (int) Kme, HS_KC, HS_KC, recv, Kme, 0, recv, Kme, 0, Mx, m1, 0, 1.0, 1.0, 1, flags, sk, w->K};
+   return hs_dgemm(s, &g3);
+}
+
+}
+
+int hs_schur_Wvar(hipStream_t s, void* comm, int rank, int nranks, int m1, int n, const double* A, const double* R, const double* G,
+   double* Mx, hs_schur_ws* w, int c0, int cw)
+{
+   if ( cw <= 0 )
+      return HS_OK;
+   WvarSlice q;
+   HS_CALL( wvar_setup(q, w, rank, nranks, m1, n, c0, cw) );
+   HS_CALL( wvar_products(s, q, A, R, G, w, w->U) );
+   HS_CALL( hs_alltoall(comm, w->U, w->V, q.cnt, s) );
+   return wvar_gram(s, q, w, w->V, Mx);
+}
+
+int hs_schur_Wvar_all(hipStream_t s, hipStream_t sc, void* comm, int rank, int nranks, int m1, int n, const double* A, const double* R,
+   const double* G, double* Mx, hs_schur_ws* w, int cwmax, int overlap)
+{
+   if ( cwmax <= 0 )
+      return HS_ERR_ARG;
+   const int nslices = (n + cwmax - 1) / cwmax;
+   if ( !overlap || nslices < 2 || w->U2 == NULL || w->V2 == NULL || sc == NULL || w->evP[0] == NULL )
+   {
+      for (int c0 = 0; c0 < n; c0 += cwmax)
+         HS_CALL( hs_schur_Wvar(s, comm, rank, nranks, m1, n, A, R, G, Mx, w, c0, n - c0 < cwmax ? n - c0 : cwmax) );
+      return HS_OK;
+   }
+   /* two-slice pipeline.  Compute queue s: products(0), [products(t + 1), wait exchange(t), Gram(t)] ...; communication queue sc:
+    * [wait products(t), all-to-all(t)] ...  Buffers alternate with the slice parity; the queue orders make every reuse safe: the
+    * send buffer of slice t + 2 is written after Gram(t) was enqueued, which waited for exchange(t); the receive buffer of slice
+    * t + 2 is written by an exchange that waits for products(t + 2), enqueued behind Gram(t) which read it.  The Gram updates hit Mx
+    * in slice order, as in the in-order form: same bits. */
+   static thread_local WvarSlice tq[2];        /* host bookkeeping of the two slices in flight */
+   double* sendb[2] = {w->U, w->U2};
+   double* recvb[2] = {w->V, w->V2};
+   for (int t = 0; t < nslices; ++t)
+   {
+      const int b = t & 1;
+      const int c0 = t * cwmax, cw = n - c0 < cwmax ? n - c0 : cwmax;
+      HS_CALL( wvar_setup(tq[b], w, rank, nranks, m1, n, c0, cw) );
+      HS_CALL( wvar_products(s, tq[b], A, R, G, w, sendb[b]) );
+      HS_HIP( hipEventRecord((hipEvent_t) w->evP[b], s) );
+      HS_HIP( hipStreamWaitEvent(sc, (hipEvent_t) w->evP[b], 0) );
+      HS_CALL( hs_alltoall(comm, sendb[b], recvb[b], tq[b].cnt, sc) );
+      HS_HIP( hipEventRecord((hipEvent_t) w->evX[b], sc) );
+      if ( t >= 1 )
+      {
+         HS_HIP( hipStreamWaitEvent(s, (hipEvent_t) w->evX[b ^ 1], 0) );
+         HS_CALL( wvar_gram(s, tq[b ^ 1], w, recvb[b ^ 1], Mx) );
+      }
+   }
+   const int bl = (nslices - 1) & 1;
+   HS_HIP( hipStreamWaitEvent(s, (hipEvent_t) w->evX[bl], 0) );
+   return wvar_gram(s, tq[bl], w, recvb[bl], Mx);
 }
 
 void hs_shard_cols(int m1, int n, int nranks, int rank, int* c_begin, int* c_width)

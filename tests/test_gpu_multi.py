@@ -84,6 +84,24 @@ def test_matrices_sharded_by_variable_reproduce_the_single_rank_solve(gpu, tmp_p
         assert np.max(np.abs(np.array(r["y"]) - np.array(many[0]["y"]))) <= 1e-12 * max(1.0, np.max(np.abs(y1)))
 
 
+@pytest.mark.parametrize("world,n,m,q,slice_cols", [(2, 70, 130, 0, 16), (3, 80, 50, 7, 24), (4, 96, 40, 0, 32)])
+def test_overlapped_exchange_of_the_variable_sharded_assembly_is_bit_identical_to_the_in_order_form(gpu, tmp_path, world, n, m, q, slice_cols):
+    """several column slices per assembly: by default the all-to-all of slice s runs on the communication queue behind an event while
+    the compute queue forms the products of slice s + 1, and the Gram update of slice s waits for its exchange (csrc/schur.hip:
+    hs_schur_Wvar_all; SURVEY.md section 7.3: the exchange "must be overlapped").  HIPSDP_VAR_OVERLAP=0 issues everything in order
+    on one queue.  Same kernels, same arguments, same order of the updates: the two runs must agree in every bit on every rank."""
+    env = {"HIPSDP_TEST_STAGING": str(1 << 20), "HIPSDP_VAR_SLICE": str(slice_cols)}
+    over = run_world(tmp_path, world, n, m, q, "ov%d" % world, env=dict(env, HIPSDP_VAR_OVERLAP="1"), load="vars-dense")
+    inord = run_world(tmp_path, world, n, m, q, "io%d" % world, env=dict(env, HIPSDP_VAR_OVERLAP="0"), load="vars-dense")
+    one = run_world(tmp_path, 1, n, m, q, "o1", load="dense")[0]
+    for a, b in zip(over, inord):
+        assert a["status"] == b["status"] == 0 and a["iterations"] == b["iterations"] == one["iterations"]
+        assert np.array_equal(np.array(a["y"]), np.array(b["y"]))
+        assert a["xtrace"] == b["xtrace"]
+    y1 = np.array(one["y"])
+    assert np.max(np.abs(np.array(over[0]["y"]) - y1)) <= 1e-8 * max(1.0, np.max(np.abs(y1)))
+
+
 def test_matrices_sharded_by_variable_at_a_size_that_uses_the_mfma_tile_kernels(gpu, tmp_path):
     """n = 300, m = 400 on two ranks: the three products of hs_schur_Wvar run on the persistent 128-tile FP64-MFMA kernel, the
     instance is generated on the device by rows, the packed copies hold a rank's rows only"""
