@@ -712,7 +712,7 @@ def main():
             lib.hipsdp_get_assembly_clock(solver.h, C.byref(ghz))
             lib.hipsdp_set_clock_sampling(solver.h, 0)
             tf, pg = C.c_double(0.0), C.c_double(0.0)
-            lib.hipsdp_mfma_peak(C.c_int(local_rank if world > 1 else 0), C.c_double(20.0), C.byref(tf), C.byref(pg))
+            hb.ulib().hipsdp_mfma_peak(C.c_int(local_rank if world > 1 else 0), C.c_double(20.0), C.byref(tf), C.byref(pg))
             measured = {"assembly_clock_ghz": ghz.value, "measured_peak_tflops": tf.value, "measured_peak_clock_ghz": pg.value}
         except Exception as e:                                     # pragma: no cover
             measured = {"error": repr(e)}

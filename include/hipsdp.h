@@ -252,55 +252,17 @@ HIPSDP_API int  hipsdp_gen_planted_density(hipsdp_solver* solver, int n, int m, 
 /* copies block k's dense storage A[(m+1) * n * n] back to the host (used to hand identical bits to the CPU baseline) */
 HIPSDP_API int  hipsdp_get_block_dense(hipsdp_solver* solver, int block, double* A);
 
-/* ---- host-buffer dense kernels (unit-level entry points; used by lapack_interface_hip.c and by the parity tests) ---- */
+/* ---- host-buffer entry points behind the SCIPlapack* surface (src/sdpi/lapack_interface_hip.c; csrc/host_entries.hip, eigi.hip,
+ * psd.hip): every calling thread owns a context per device (own stream, pinned mapped staging, grow-only device pool) - no
+ * hipMalloc / hipFree / device-wide synchronisation per call ---- */
 /* C[M x N] = alpha * op(A) * op(B) + beta * C, row-major; layA/layB: 0 = K contiguous, 1 = M (resp. N) contiguous */
 HIPSDP_API int  hipsdp_dgemm(int device, int layA, int layB, int M, int N, int K, double alpha, const double* A, long long lda,
    const double* B, long long ldb, double beta, double* C, long long ldc, int lower_only, int splitk);
-/* both GEMM kernels (one tile per workgroup; persistent with LDS-DMA staging) on the same device-generated operands:
- * used_v2 = 1 when the persistent kernel accepts the shape, ndiff = elements of C that differ in any bit (must be 0) */
-HIPSDP_API int  hipsdp_dgemm_selfcheck(int device, int M, int N, int K, int layB, int batch, int splitk, int flags, double beta,
-   int* used_v2, long long* ndiff);
-/* the same with a free alpha and, for reps > 0 and beta = 0, the average milliseconds of one product through the tile kernel alone
- * (ms_tile) and through the default dispatch (ms_fast).  *used: bit 0 the persistent tile kernel took the product, bit 1 the strip
- * kernel of the two triangular Schur products (alpha = 1, beta = 0 only) */
-/* unit entry: out[e] = sum_i coef[i] A[i][e] + sa add[e] over R rows of E entries (the pass A^T); split = 1: as the engine calls it
- * (row chunks side by side when the block has few entries; *chunks = how many, 0 = the plain kernel) */
-HIPSDP_API int  hipsdp_pass_at_unit(int device, int R, long long E, const double* A, const double* coef, double sa, const double* add, int split,
-   double* out, int* chunks);
-HIPSDP_API int  hipsdp_dgemm_selfcheck2(int device, int M, int N, int K, int layB, int batch, int splitk, int flags, double alpha, double beta,
-   int reps, int* used, long long* ndiff, double* ms_tile, double* ms_fast);
-/* Schur block Mx[(m1) x (m1)] = tr(A_i X A_j Zinv) for i, j = 0..m1-1 */
-HIPSDP_API int  hipsdp_schur_dense(int device, int m1, int n, const double* A, const double* X, const double* Zinv, double* Mx,
-   double ws_gbytes);
-/* the same matrix through the W formulation (W_j = G A_j R, Mx = W W^T); takes X and Z, factors them on the device */
-HIPSDP_API int  hipsdp_schur_w(int device, int m1, int n, const double* A, const double* X, const double* Z, double* Mx);
-/* milliseconds one rank of an nranks-way sharded assembly spends on its share of the Schur matrix (by_columns: column slices
- * of the W formulation, else row chunks of the U formulation); synthetic operands made in HBM */
-HIPSDP_API int  hipsdp_schur_shard_time(int device, int m1, int n, int nranks, int rank, int by_columns, int reps, double ws_gbytes, double* ms);
-/* the same for one rank of the variable-sharded assembly (hipsdp_shard_matrices): only that rank's rows of A are allocated, the
- * column slices are cw wide, the all-to-all keeps the rank's own piece; *a2a_bytes = bytes the rank would send per assembly */
-HIPSDP_API int  hipsdp_schur_var_share_time(int device, int m1, int n, int nranks, int rank, int cw, int reps, double* ms, double* a2a_bytes);
-/* sparse block mode: Schur entries of matrices given as triplets (var 1 .. m, row >= col) exactly as the engine assembles them
- * (csrc/sparse.hip); Mx (m + 1) x (m + 1), lower triangle of rows / columns 1 .. m */
-HIPSDP_API int  hipsdp_schur_sparse_unit(int device, int n, int m, long long nnz, const int* var, const int* row, const int* col,
-   const double* val, const double* X, const double* Zinv, double* Mx);
-/* measured FP64 matrix peak of the device: a chip-filling launch of register-only v_mfma_f64_16x16x4_f64 for about ms milliseconds;
- * *tflops by HIP events, *ghz = shader clocks per wall tick inside the kernel (bench.py prices its roofline against this as well) */
-HIPSDP_API int  hipsdp_mfma_peak(int device, double ms, double* tflops, double* ghz);
 /* shader frequency DURING the Schur assemblies of a solve: with sampling on, one-thread kernels right before and right after every
  * assembly read the shader-clock and the 100 MHz counters on the engine's stream; *ghz = sum of clock differences / sum of time
  * differences over the assemblies of the last solve (0 when none was sampled) */
 HIPSDP_API int  hipsdp_set_clock_sampling(hipsdp_solver* solver, int on);
 HIPSDP_API int  hipsdp_get_assembly_clock(hipsdp_solver* solver, double* ghz);
-HIPSDP_API int  hipsdp_potrf(int device, int n, double* A, int* fail);                       /* lower Cholesky in place, row-major */
-/* both forms of the blocked factorization for the parity tests: v1 = 1 the four-launch form, 0 one launch per block column; psd = 1
- * semidefinite pivot rule with diag0 = diag(A), forced pivots in regmask[n]; dinv[ceil(n / 64) * 4096] (any output may be NULL) */
-HIPSDP_API int  hipsdp_potrf_ex(int device, int n, double* A, int psd, int v1, double* dinv, int* regmask, int* fail);
-HIPSDP_API int  hipsdp_potrs(int device, int n, const double* A, int nrhs, double* rhs);     /* factor + solve, rhs[k * n + i] */
-HIPSDP_API int  hipsdp_trtri(int device, int n, const double* A, double* Linv);              /* A spd -> inverse of its Cholesky factor */
-HIPSDP_API int  hipsdp_lambda_min(int device, int n, const double* W, int steps, double* theta, double* resid);
-/* lambda_min(L D L^T), n <= 64, L lower triangular, D symmetric: the small-block step-length kernels; theta[2], resid[2] */
-HIPSDP_API int  hipsdp_lambda_min_scaled(int device, int n, const double* L, const double* D, int steps, double* theta, double* resid);
 HIPSDP_API int  hipsdp_syev(int device, int n, const double* A, double* lam, double* V);     /* ascending, eigenvectors as rows */
 /* i-th smallest eigenvalue (1-based) and optionally its unit eigenvector of a symmetric matrix with n <= 128 in one launch through
  * pinned, device-mapped staging memory of the calling thread (no allocation, no copy engine, no stream synchronisation):

@@ -45,6 +45,22 @@ def lib():
     return _lib
 
 
+_ulib = None
+
+
+def ulib():
+    """libhipsdp_units.so: the engine's objects plus the TEST / BENCH entry points of csrc/units.hip (include/hipsdp_units.h) - a library
+    of its own, loaded beside the product libraries with local symbol scope (its copy of the engine is self-contained)"""
+    global _ulib
+    if _ulib is None:
+        path = os.path.join(os.path.dirname(LIBPATH), "libhipsdp_units.so")
+        if not os.path.exists(path):
+            raise RuntimeError("libhipsdp_units.so not built (%s); run __graft_entry__.build()" % path)
+        _ulib = C.CDLL(path, mode=C.RTLD_LOCAL)
+        _ulib.hipsdp_last_error.restype = C.c_char_p
+    return _ulib
+
+
 def _chk(rc, what):
     if rc != 0:
         raise RuntimeError("%s failed: rc=%d (%s)" % (what, rc, lib().hipsdp_last_error().decode()))
@@ -283,7 +299,7 @@ def schur_dense(A, X, Zinv, ws_gbytes=0.0, device=0):
     X = _f64(X)
     Zinv = _f64(Zinv)
     Mx = np.zeros((m1, m1))
-    _chk(lib().hipsdp_schur_dense(device, m1, n, _dp(A), _dp(X), _dp(Zinv), _dp(Mx), C.c_double(ws_gbytes)),
+    _chk(ulib().hipsdp_schur_dense(device, m1, n, _dp(A), _dp(X), _dp(Zinv), _dp(Mx), C.c_double(ws_gbytes)),
          "hipsdp_schur_dense")
     return Mx
 
@@ -295,7 +311,7 @@ def schur_sparse_unit(n, m, coo, X, Zinv, device=0):
     col = np.ascontiguousarray(col, dtype=np.int32); val = _f64(val)
     X = _f64(X); Zinv = _f64(Zinv)
     Mx = np.zeros((m + 1, m + 1))
-    _chk(lib().hipsdp_schur_sparse_unit(device, n, m, C.c_longlong(len(val)), _ip(var), _ip(row), _ip(col), _dp(val), _dp(X), _dp(Zinv), _dp(Mx)),
+    _chk(ulib().hipsdp_schur_sparse_unit(device, n, m, C.c_longlong(len(val)), _ip(var), _ip(row), _ip(col), _dp(val), _dp(X), _dp(Zinv), _dp(Mx)),
          "hipsdp_schur_sparse_unit")
     return Mx
 
@@ -306,7 +322,7 @@ def schur_w(A, X, Z, device=0):
     X = _f64(X)
     Z = _f64(Z)
     Mx = np.zeros((m1, m1))
-    _chk(lib().hipsdp_schur_w(device, m1, n, _dp(A), _dp(X), _dp(Z), _dp(Mx)), "hipsdp_schur_w")
+    _chk(ulib().hipsdp_schur_w(device, m1, n, _dp(A), _dp(X), _dp(Z), _dp(Mx)), "hipsdp_schur_w")
     return Mx
 
 
@@ -314,7 +330,7 @@ def dgemm_selfcheck(M, N, K, layB=1, batch=1, splitk=1, flags=0, beta=0.0, devic
     """both GEMM kernels on the same device-generated operands -> (used_v2, number of elements of C differing in any bit)"""
     used = C.c_int(0)
     nd = C.c_longlong(0)
-    _chk(lib().hipsdp_dgemm_selfcheck(device, M, N, K, layB, batch, splitk, flags, C.c_double(beta), C.byref(used), C.byref(nd)),
+    _chk(ulib().hipsdp_dgemm_selfcheck(device, M, N, K, layB, batch, splitk, flags, C.c_double(beta), C.byref(used), C.byref(nd)),
          "hipsdp_dgemm_selfcheck")
     return used.value, nd.value
 
@@ -325,7 +341,7 @@ def dgemm_selfcheck2(M, N, K, layB=1, batch=1, splitk=1, flags=0, alpha=1.0, bet
     used = C.c_int(0)
     nd = C.c_longlong(0)
     t0, t1 = C.c_double(0.0), C.c_double(0.0)
-    _chk(lib().hipsdp_dgemm_selfcheck2(device, M, N, K, layB, batch, splitk, flags, C.c_double(alpha), C.c_double(beta), reps,
+    _chk(ulib().hipsdp_dgemm_selfcheck2(device, M, N, K, layB, batch, splitk, flags, C.c_double(alpha), C.c_double(beta), reps,
                                        C.byref(used), C.byref(nd), C.byref(t0), C.byref(t1)), "hipsdp_dgemm_selfcheck2")
     return used.value, nd.value, t0.value, t1.value
 
@@ -333,7 +349,7 @@ def dgemm_selfcheck2(M, N, K, layB=1, batch=1, splitk=1, flags=0, alpha=1.0, bet
 def potrf(A, device=0):
     L = _f64(A).copy()
     fail = C.c_int(0)
-    _chk(lib().hipsdp_potrf(device, L.shape[0], _dp(L), C.byref(fail)), "hipsdp_potrf")
+    _chk(ulib().hipsdp_potrf(device, L.shape[0], _dp(L), C.byref(fail)), "hipsdp_potrf")
     return np.tril(L), fail.value
 
 
@@ -344,7 +360,7 @@ def potrf_ex(A, psd=False, v1=False, device=0):
     dinv = np.zeros(((n + 63) // 64) * 4096)
     mask = np.zeros(n, dtype=np.int32)
     fail = C.c_int(0)
-    _chk(lib().hipsdp_potrf_ex(device, n, _dp(L), int(psd), int(v1), _dp(dinv), _ip(mask), C.byref(fail)), "hipsdp_potrf_ex")
+    _chk(ulib().hipsdp_potrf_ex(device, n, _dp(L), int(psd), int(v1), _dp(dinv), _ip(mask), C.byref(fail)), "hipsdp_potrf_ex")
     return L, dinv, mask, fail.value
 
 
@@ -352,14 +368,14 @@ def potrs(A, rhs, device=0):
     A = _f64(A)
     r = _f64(rhs).copy()
     r2 = r.reshape(-1, A.shape[0])
-    _chk(lib().hipsdp_potrs(device, A.shape[0], _dp(A), r2.shape[0], _dp(r2)), "hipsdp_potrs")
+    _chk(ulib().hipsdp_potrs(device, A.shape[0], _dp(A), r2.shape[0], _dp(r2)), "hipsdp_potrs")
     return r2.reshape(r.shape)
 
 
 def trtri(A, device=0):
     A = _f64(A)
     Li = np.zeros_like(A)
-    _chk(lib().hipsdp_trtri(device, A.shape[0], _dp(A), _dp(Li)), "hipsdp_trtri")
+    _chk(ulib().hipsdp_trtri(device, A.shape[0], _dp(A), _dp(Li)), "hipsdp_trtri")
     return Li
 
 
@@ -367,7 +383,7 @@ def lambda_min(W, steps=0, device=0):
     W = _f64(W)
     th = C.c_double(0.0)
     rs = C.c_double(0.0)
-    _chk(lib().hipsdp_lambda_min(device, W.shape[0], _dp(W), steps, C.byref(th), C.byref(rs)), "hipsdp_lambda_min")
+    _chk(ulib().hipsdp_lambda_min(device, W.shape[0], _dp(W), steps, C.byref(th), C.byref(rs)), "hipsdp_lambda_min")
     return th.value, rs.value
 
 

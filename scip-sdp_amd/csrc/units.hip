@@ -4,6 +4,7 @@
  * hipsdp_syev) lives in host_entries.hip.  Nothing here has a CPU code path. */
 #include "hs_kernels.h"
 #include "../../include/hipsdp.h"
+#include "../../include/hipsdp_units.h"
 #include <vector>
 #include <cstring>
 #include <cstdlib>

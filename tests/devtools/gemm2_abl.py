@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 spec = importlib.util.spec_from_file_location("hipsdp_binding", os.path.join(ROOT, "scip-sdp_amd", "binding.py"))
 hb = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(hb)
-lib = hb.lib()
+lib = hb.ulib()
 B_LOWTRI, A_LOWTRI, REMAP, LOWER = 4, 2, 16, 1
 
 

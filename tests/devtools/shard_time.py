@@ -8,7 +8,7 @@ hb = importlib.util.module_from_spec(spec); spec.loader.exec_module(hb)
 var = len(sys.argv) > 1 and sys.argv[1] == "var"
 n = int(sys.argv[1]) if len(sys.argv) > 1 and not var else 500
 m = int(sys.argv[2]) if len(sys.argv) > 2 and not var else 1000
-lib = hb.lib()
+lib = hb.ulib()
 if len(sys.argv) > 1 and sys.argv[1] == "var":
     # one rank's share of the variable-sharded assembly (matrices sharded by variable): only that rank's rows of A are allocated
     n, m, G, cw = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])

@@ -352,7 +352,7 @@ def test_small_block_step_length_eigenvalue(gpu, n):
     Lanczos, Ritz value and its residual bound): theta - resid <= lambda_min <= theta + resid, both slots of the launch and both
     blocks of the job table agree"""
     import ctypes as C
-    lib = gpu.lib()
+    lib = gpu.ulib()
     rng = np.random.default_rng(n)
     for trial in range(5):
         L = np.tril(rng.standard_normal((n, n))) + 2.0 * np.eye(n)
@@ -439,7 +439,7 @@ def test_pass_AT_in_row_chunks_matches_the_plain_kernel(gpu, R, E):
     """hs_gemv_t_ws: blocks with few entries and many rows are summed in row chunks side by side (two launches) instead of one thread
     per pair of entries walking all rows.  Against numpy and against the plain kernel (another summation order: 1e-13 relative), and
     twice with the same bits; the last two shapes do not split (too little work / too many entries)."""
-    lib = gpu.lib()
+    lib = gpu.ulib()
     rng = np.random.default_rng(R + E)
     A = rng.standard_normal((R, E))
     coef = rng.standard_normal(R)

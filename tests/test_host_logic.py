@@ -27,6 +27,15 @@ def test_library_exports_every_declared_symbol(hb):
     assert len([n for n in names if n.startswith("SCIPsdpiSolver")]) == 53      # sdpisolver.h:79-724
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
+    # the test / bench entry points (include/hipsdp_units.h) live in a library of their own and NOT in the product library
+    unit_names = declared_symbols("hipsdp_units.h", "hipsdp_")
+    ulib = hb.ulib()
+    assert not [n for n in unit_names if not hasattr(ulib, n)]
+    import subprocess
+    exported = subprocess.run(["nm", "-D", "--defined-only", hb.LIBPATH], stdout=subprocess.PIPE, text=True).stdout
+    product = set(re.findall(r"\b(hipsdp_\w+)\b", exported))
+    assert not (product & set(unit_names)), sorted(product & set(unit_names))
+    assert product == set(declared_symbols("hipsdp.h", "hipsdp_")), sorted(product ^ set(declared_symbols("hipsdp.h", "hipsdp_")))
 
 
 def test_name_and_static_answers(hb):
