@@ -81,7 +81,7 @@ static __host__ __device__ inline int s1_layout(int m, int q, int K, const int* 
    for (int k = 0; k < K; ++k) { L.oZi[k] = o; o += L.np[k]; }
    for (int k = 0; k < K; ++k) { L.oLx[k] = o; o += L.np[k]; }
    for (int k = 0; k < K; ++k) { L.oLz[k] = o; o += L.np[k]; }
-   for (int k = 0; k < K; ++k) { L.oEig[k] = o; o += 8 * ((n[k] + 1) & ~1); }
+   for (int k = 0; k < K; ++k) { L.oEig[k] = o; o += 8 * ((n[k] + 1) & ~1) + 64; }
    L.oMx = o; o += (L.m1 * L.pm1 + 1) & ~1;
    L.oLm = o; o += (m * L.pm + 1) & ~1;
    L.oVec = o; o += V_COUNT * L.VL;
@@ -545,7 +545,7 @@ __device__ __forceinline__ double s1_dppz(double v)
  * an entry is not finite.  The sequence runs in product form out of REGISTERS: d_i and e_i^2 reach all lanes by v_readlane (an LDS
  * read per step cost its latency, 100 cycles, per step: 2700 cycles per round at n = 10, now about 500). */
 template<bool SMALL>
-__device__ __forceinline__ double s1_sturm_min(double dl, double el, int n, int lane, double* tprof)
+__device__ __forceinline__ double s1_sturm_min(double dl, double el, int n, int lane, double* bc, double* tprof)
 {
    if ( lane >= n ) { dl = 0.0; el = 0.0; }
    if ( lane == n - 1 ) el = 0.0;
@@ -559,31 +559,42 @@ __device__ __forceinline__ double s1_sturm_min(double dl, double el, int n, int 
    const double glo = s1_wmin((lane < n) ? dl - rad : 1e300);
    if ( !(glo < 0.0) || !(nrm > 0.0) )
       return 0.0;
-   const double sinv = 1.0 / nrm;
+   const double sinv = s1_rcp(nrm);
    const double ds = dl * sinv;
    const double e2 = (el * sinv) * (el * sinv);
    if ( tprof != NULL && lane == 0 )
       tprof[1] -= (double) clock64();
    double lo = glo * sinv * (1.0 + 1e-12) - 1e-300, hi = 0.0;
    const double d0 = s1_lane(ds, 0);
-   /* SMALL (n <= 16): the whole matrix as wavefront-uniform values, the steps unrolled - three multiply-adds and a compare per step */
+   /* SMALL (n <= 16): every lane holds the whole matrix in VECTOR registers (written to LDS once, read back by all lanes), padded to
+    * 16 rows with rows that cannot change a sign (diagonal 4 > |x| + 1, no coupling): the 15 steps are straight-line code, three
+    * arithmetic instructions and a compare each.  [Broadcast by v_readlane made the entries wavefront-uniform SCALAR values: the
+    * kernel has none to spare, every step then re-read its two entries from spill lanes - 26 instructions and a branch per step.] */
    double dsv[16], e2v[16];
    if ( SMALL )
    {
+      if ( lane < 16 )
+      {
+         bc[lane] = (lane < n) ? ds : 4.0;
+         bc[16 + lane] = (lane + 1 < n) ? e2 : 0.0;
+      }
+      S1_WSYNC();
 #pragma unroll
       for (int i = 0; i < 16; ++i)
       {
-         dsv[i] = s1_lane(ds, i);
-         e2v[i] = s1_lane(e2, i);
+         dsv[i] = bc[i];
+         e2v[i] = bc[16 + i];
       }
    }
    bool first = true;
+   const double flane1 = (double) (lane + 1);
    for (int round = 0; round < 14; ++round)
    {
-      const double wdt = (hi - lo) / 65.0;
-      double x = lo + wdt * (double) (lane + 1);
+      /* (multiplications by the rounded reciprocals: an FP64 division is 30 dependent instructions, two per round were a quarter of it) */
+      const double wdt = (hi - lo) * (1.0 / 65.0);
+      double x = lo + wdt * flane1;
       if ( first )
-         x = (lane == 63) ? 0.0 : lo + (hi - lo) * (double) (lane + 1) / 64.0;
+         x = (lane == 63) ? 0.0 : lo + (hi - lo) * flane1 * (1.0 / 64.0);
       /* p_0 = 1, p_1 = d_0 - x, p_{i+1} = (d_i - x) p_i - e_{i-1}^2 p_{i-1}: a sign change = an eigenvalue below x (an exact zero
        * counts as negative); rescaled every eighth step */
       double pp = 1.0, pc = d0 - x;
@@ -591,24 +602,24 @@ __device__ __forceinline__ double s1_sturm_min(double dl, double el, int n, int 
       bool below = !posc;
       if ( SMALL )
       {
+         pc = dsv[0] - x;
+         posc = pc > 0.0;
+         below = !posc;
 #pragma unroll
          for (int i = 1; i < 16; ++i)
-            if ( i < n )
+         {
+            const double pn = fma(dsv[i] - x, pc, -e2v[i - 1] * pp);
+            const bool posn = pn > 0.0;
+            below = below || (posn != posc);
+            pp = pc; pc = pn; posc = posn;
+            if ( i == 8 )
             {
-               const double pn = fma(dsv[i] - x, pc, -e2v[i - 1] * pp);
-               const bool posn = pn > 0.0;
-               below = below || (posn != posc);
-               pp = pc; pc = pn; posc = posn;
-               if ( i == 8 )
-               {
-                  const int ex = -max(__builtin_amdgcn_frexp_exp(pc), __builtin_amdgcn_frexp_exp(pp));
-                  if ( ex > -1000 && ex < 1000 )
-                  {
-                     pc = ldexp(pc, ex);
-                     pp = ldexp(pp, ex);
-                  }
-               }
+               const int ex = -max(__builtin_amdgcn_frexp_exp(pc), __builtin_amdgcn_frexp_exp(pp));
+               const bool okx = ex > -1000 && ex < 1000;
+               pc = okx ? ldexp(pc, ex) : pc;
+               pp = okx ? ldexp(pp, ex) : pp;
             }
+         }
       }
       else
       for (int i = 1; i < n; ++i)
@@ -635,7 +646,7 @@ __device__ __forceinline__ double s1_sturm_min(double dl, double el, int n, int 
          if ( !(msk >> 63) )
             return 0.0;                                     /* nothing below zero */
          const int f = __ffsll((long long) msk) - 1;        /* first shift with an eigenvalue below it */
-         const double w64 = (hi - lo) / 64.0;
+         const double w64 = (hi - lo) * (1.0 / 64.0);
          const double nlo = (f == 0) ? lo : lo + w64 * (double) f;
          const double nhi = (f == 63) ? 0.0 : lo + w64 * (double) (f + 1);
          lo = nlo; hi = nhi;
@@ -660,7 +671,7 @@ __device__ __forceinline__ double s1_sturm_min(double dl, double el, int n, int 
 /* ---- the same for n <= 16 with the matrix in registers: lane = row, sixteen registers = its columns, the reduction fully unrolled.
  * The entries of the reflector and of w reach the lanes by v_readlane; no LDS access after the rows are loaded (the LDS form
  * below waits out six LDS round trips per column: 3100 cycles per column at n = 10, this one about 1000). */
-__device__ __forceinline__ double s1_lmin16(const double* W, int n, int p, int lane, double* tprof)
+__device__ __forceinline__ double s1_lmin16(const double* W, int n, int p, int lane, double* bc, double* tprof)
 {
    double a[16];
 #pragma unroll
@@ -691,23 +702,35 @@ __device__ __forceinline__ double s1_lmin16(const double* W, int n, int p, int l
             const double beta = -copysign(h2 * rh, x0);
             const double t = (x0 - beta) * copysign(rh, x0);
             const double scale = s1_rcp(x0 - beta);
+            /* the reflector (zero in the lanes up to k) and, below, w reach all lanes through 16 doubles of LDS: one write, the
+             * sixteen entries read back as vector registers (v_readlane would make them scalar values, of which the kernel has none
+             * to spare).  Entries up to k are zero, so the sums and the update run over all sixteen columns without guards. */
             const double vl = (lane == k + 1) ? 1.0 : ((lane > k + 1) ? xa * scale : 0.0);
             if ( lane == k )
                ereg = beta;
+            if ( lane < 16 )
+               bc[lane] = vl;
+            S1_WSYNC();
+            double vv[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+               vv[j] = bc[j];
             double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
-            for (int j = k + 1; j < 16; j += 2)
+            for (int j = 0; j < 16; j += 2)
             {
-               acc0 = fma(a[j], s1_lane(vl, j), acc0);
-               if ( j + 1 < 16 )
-                  acc1 = fma(a[j + 1], s1_lane(vl, j + 1), acc1);
+               acc0 = fma(a[j], vv[j], acc0);
+               acc1 = fma(a[j + 1], vv[j + 1], acc1);
             }
             const double pl = (lane > k) ? t * (acc0 + acc1) : 0.0;
             const double pv = s1_lane(s1_sum16(pl * vl), 0);
             const double wl = fma(-0.5 * t * pv, vl, pl);
+            if ( lane < 16 )
+               bc[16 + lane] = wl;
+            S1_WSYNC();
 #pragma unroll
-            for (int j = k + 1; j < 16; ++j)
-               a[j] -= vl * s1_lane(wl, j) + wl * s1_lane(vl, j);
+            for (int j = 0; j < 16; ++j)
+               a[j] -= fma(vl, bc[16 + j], wl * vv[j]);
          }
       }
    }
@@ -729,7 +752,7 @@ __device__ __forceinline__ double s1_lmin16(const double* W, int n, int p, int l
    }
    if ( tprof != NULL && lane == 0 )
       tprof[0] -= (double) clock64();
-   const double r = s1_sturm_min<true>(dreg, ereg, n, lane, tprof);
+   const double r = s1_sturm_min<true>(dreg, ereg, n, lane, bc, tprof);
    if ( tprof != NULL && lane == 0 )
       tprof[0] += (double) clock64();
    return r;
@@ -843,7 +866,7 @@ __device__ __forceinline__ double s1_lmin(double* W, int n, int p, int lane, dou
    /* the tridiagonal matrix into the lanes (lane i: d_i, e_i), then the multisection */
    const double dl = (lane < n) ? dd[lane] : 0.0;
    const double el = (lane < n) ? ee[lane] : 0.0;
-   return s1_sturm_min<false>(dl, el, n, lane, tprof);
+   return s1_sturm_min<false>(dl, el, n, lane, scr, tprof);
 }
 
 /* ---- n x n x n product on the matrix cores: wavefront `wave` of the subset [w0, w0 + nw) takes the 16 x 16 tiles tbase + t with
@@ -1703,8 +1726,9 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          const S1Blk& B = sh.blk[t >> 1];
          double* Wm = sm + ((t & 1) ? B.odZ : B.odX);
          double* tpr = (P.prof_on && t == 0) ? &sh.prof[19] : (double*) NULL;
-         const double lm = (B.n <= 16) ? s1_lmin16(Wm, B.n, B.p, lane, tpr)
-            : s1_lmin(Wm, B.n, B.p, lane, sm + B.oEig + (t & 1) * 4 * ((B.n + 1) & ~1), tpr);
+         double* escr = sm + B.oEig + (t & 1) * (4 * ((B.n + 1) & ~1) + 32);
+         const double lm = (B.n <= 16) ? s1_lmin16(Wm, B.n, B.p, lane, escr, tpr)
+            : s1_lmin(Wm, B.n, B.p, lane, escr, tpr);
          if ( lane == 0 )
             sh.sc[SC_LMIN0 + t] = lm;
       }
