@@ -2367,7 +2367,6 @@ static int solve1_try(hipsdp_solver* s, hipsdp_info* info, bool* done)
       a.pivot_rule = env != NULL ? atoi(env) : 3;
    }
    a.prof_on = prof;
-   a.refine = (getenv("HIPSDP_SOLVE1_REFINE") != NULL && getenv("HIPSDP_SOLVE1_REFINE")[0] == '1') ? 1 : 0;
    a.gws = s->s1_ws; a.gws_len = s->s1_ws_len;
    a.out = s->s1_host_dev;
    a.hist = getenv("HIPSDP_SOLVE1_HIST") != NULL ? s->s1_host_dev + HS_S1_OUT_DOUBLES + 8 : NULL;

@@ -148,6 +148,20 @@ __device__ __forceinline__ double s1_lane(double v, int l)
    return __hiloint2double(hi, lo);
 }
 /* e / n for 0 <= e < 2^20, 1 <= n <= 64 without the integer-division expansion: float reciprocal, one correction step */
+/* a value every lane computed identically, moved to scalar registers (the kernel keeps dozens of such loop-carried values; as vector
+ * registers they take two each for the whole solve, as scalars they are spilled 64 to a vector register) */
+__device__ __forceinline__ double s1_uni(double v)
+{
+#ifdef S1_NO_UNI
+   return v;
+#else
+   int lo = __double2loint(v), hi = __double2hiint(v);
+   lo = __builtin_amdgcn_readfirstlane(lo);
+   hi = __builtin_amdgcn_readfirstlane(hi);
+   return __hiloint2double(hi, lo);
+#endif
+}
+
 __device__ __forceinline__ int s1_div(int e, int n)
 {
    int r = (int) ((float) e * __builtin_amdgcn_rcpf((float) n));
@@ -346,9 +360,6 @@ __device__ __forceinline__ int s1_cholp(double* A, int n, int p, int lane, bool 
          const int k = k0 + u;
          if ( k < n )
          {
-#pragma unroll
-            for (int v = 0; v < u; ++v)
-               a[u] = fma(-a[v], s1_lane(a[v], k), a[u]);
             double d = s1_lane(a[u], k);
             bool zero = false;
             if ( psd )
@@ -367,7 +378,13 @@ __device__ __forceinline__ int s1_cholp(double* A, int n, int p, int lane, bool 
             const double sd = d * rs;
             if ( lane == k )
                mydiag = sd;
-            a[u] = (lane > k) ? (zero ? 0.0 : a[u] * rs) : ((lane == k && keepdiag) ? sd : 0.0);
+            const double lu = (lane > k) ? (zero ? 0.0 : a[u] * rs) : 0.0;
+            a[u] = (lane == k && keepdiag) ? sd : lu;
+            /* the later columns of the panel take this column's term at once (independent multiply-adds; taken column by column
+             * when its pivot comes they were a chain of up to seven dependent ones in front of every pivot) */
+#pragma unroll
+            for (int v = u + 1; v < 8; ++v)
+               a[v] = fma(-lu, s1_lane(lu, (k0 + v) & 63), a[v]);
          }
       }
 #pragma unroll
@@ -380,104 +397,88 @@ __device__ __forceinline__ int s1_cholp(double* A, int n, int p, int lane, bool 
 }
 
 /* ---- one wavefront: x = (L L^T)^-1 r for one or two right-hand sides by forward and backward substitution, lane = row.  L as
- * s1_cholp(keepdiag = false) leaves it (strictly lower, zero diagonal and upper triangle, pitch p >= 8 ceil(m / 8)), dinv = 1 /
- * (diagonal entry of this lane's row).  In: x0, x1 = this lane's entries of the right-hand sides; out: of the solutions.  The
- * columns of eight steps are loaded ahead of the recurrence, whose steps are a multiply, a v_readlane pair and a multiply-add. */
-__device__ __forceinline__ void s1_llt_solve(const double* L, int m, int p, int lane, double dinv, double diag, bool two, bool refine,
-   double& x0, double& x1)
+ * s1_cholp(keepdiag = false) leaves it: strictly lower, ZERO diagonal, upper triangle and padding columns (pitch p >= 8 ceil(m / 8)
+ * + 1, so no step needs a mask or a bound), dinv = 1 / (diagonal entry of this lane's row).  In: x0, x1 = this lane's entries of
+ * the right-hand sides; out: of the solutions.  The entries of eight steps are loaded - unconditionally, one block ahead - before
+ * the recurrence needs them; a step is a multiply, a v_readlane pair and a multiply-add, straight-line code.  [A first form with
+ * guarded loads and a run-time "two right-hand sides" flag spent three quarters of its instructions on branches and exec masks:
+ * 220 cycles per step.] */
+template<bool TWO>
+__device__ __forceinline__ void s1_llt_solve(const double* L, int m, int p, int lane, double dinv, double& x0, double& x1)
 {
-   const double r0 = (lane < m) ? x0 : 0.0, r1 = (lane < m && two) ? x1 : 0.0;
-   /* forward substitution of (a0, a1) in place: on return a = L^-1 a */
-   auto fwd = [&](double& a0, double& a1) S1_INL
+   const int rl = (lane < m) ? lane : 0;
+   const bool live = lane < m;
+   double a0 = live ? x0 : 0.0, a1 = (live && TWO) ? x1 : 0.0;
+   const int nb = (m + 7) >> 3;
    {
-      for (int k0 = 0; k0 < m; k0 += 8)
+      const double* row = L + rl * p;
+      double cn[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+         cn[u] = row[u];
+      for (int b = 0; b < nb; ++b)
       {
+         const int k0 = 8 * b;
          double c[8];
 #pragma unroll
          for (int u = 0; u < 8; ++u)
-            c[u] = (lane < m) ? L[lane * p + k0 + u] : 0.0;
+            c[u] = live ? cn[u] : 0.0;
+         if ( b + 1 < nb )
+         {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+               cn[u] = row[k0 + 8 + u];
+         }
 #pragma unroll
          for (int u = 0; u < 8; ++u)
-            if ( k0 + u < m )
-            {
-               const double y0 = s1_lane(a0 * dinv, k0 + u);
-               a0 = fma(-c[u], y0, a0);
-               if ( two )
-               {
-                  const double y1 = s1_lane(a1 * dinv, k0 + u);
-                  a1 = fma(-c[u], y1, a1);
-               }
-            }
+         {
+            const double t0 = a0 * dinv, t1 = a1 * dinv;
+            const double y0 = s1_lane(t0, k0 + u);
+            const double y1 = TWO ? s1_lane(t1, k0 + u) : 0.0;
+            a0 = fma(-c[u], y0, a0);
+            if ( TWO )
+               a1 = fma(-c[u], y1, a1);
+         }
       }
-      a0 *= dinv; a1 *= dinv;
-   };
-   auto bwd = [&](double& a0, double& a1) S1_INL
+   }
+   a0 *= dinv; a1 *= dinv;
    {
-      for (int k0 = (m - 1) & ~7; k0 >= 0; k0 -= 8)
+      /* rows k0 .. k0 + 7 of the factor, this lane's column; rows past m - 1 are clamped to row 0, whose entries are all zero */
+      const double* col = L + rl;
+      double cn[8];
       {
+         const int k0 = 8 * (nb - 1);
+#pragma unroll
+         for (int u = 0; u < 8; ++u)
+            cn[u] = col[((k0 + u < m) ? k0 + u : 0) * p];
+      }
+      for (int b = nb - 1; b >= 0; --b)
+      {
+         const int k0 = 8 * b;
          double c[8];
 #pragma unroll
          for (int u = 0; u < 8; ++u)
-            c[u] = (lane < m && k0 + u < m) ? L[(k0 + u) * p + lane] : 0.0;
+            c[u] = live ? cn[u] : 0.0;
+         if ( b > 0 )
+         {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+               cn[u] = col[(k0 - 8 + u) * p];
+         }
 #pragma unroll
          for (int u = 7; u >= 0; --u)
-            if ( k0 + u < m )
-            {
-               const double y0 = s1_lane(a0 * dinv, k0 + u);
-               a0 = fma(-c[u], y0, a0);
-               if ( two )
-               {
-                  const double y1 = s1_lane(a1 * dinv, k0 + u);
-                  a1 = fma(-c[u], y1, a1);
-               }
-            }
+         {
+            const double t0 = a0 * dinv, t1 = a1 * dinv;
+            const double y0 = s1_lane(t0, (k0 + u) & 63);
+            const double y1 = TWO ? s1_lane(t1, (k0 + u) & 63) : 0.0;
+            a0 = fma(-c[u], y0, a0);
+            if ( TWO )
+               a1 = fma(-c[u], y1, a1);
+         }
       }
-      a0 *= dinv; a1 *= dinv;
-   };
-   /* products with the factor for the correction step: o = L w (trans = false) or L^T w */
-   auto lmul = [&](bool trans, double w0, double w1, double& o0, double& o1) S1_INL
-   {
-      double s0 = diag * w0, s1 = diag * w1;
-      for (int k0 = 0; k0 < m; k0 += 8)
-      {
-         double c[8];
-#pragma unroll
-         for (int u = 0; u < 8; ++u)
-            c[u] = (lane < m && k0 + u < m) ? (trans ? L[(k0 + u) * p + lane] : L[lane * p + k0 + u]) : 0.0;
-#pragma unroll
-         for (int u = 0; u < 8; ++u)
-            if ( k0 + u < m )
-            {
-               s0 = fma(c[u], s1_lane(w0, k0 + u), s0);
-               if ( two )
-                  s1 = fma(c[u], s1_lane(w1, k0 + u), s1);
-            }
-      }
-      o0 = s0; o1 = s1;
-   };
-   double a0 = r0, a1 = r1;
-   fwd(a0, a1);
-   if ( refine )
-   {
-      /* each triangular solve corrected once with the factor itself (oracle/ipm_ref.py: msolve) */
-      double t0, t1;
-      lmul(false, a0, a1, t0, t1);
-      double d0 = r0 - t0, d1 = r1 - t1;
-      fwd(d0, d1);
-      a0 += d0; a1 += d1;
    }
-   const double w0 = a0, w1 = a1;
-   bwd(a0, a1);
-   if ( refine )
-   {
-      double t0, t1;
-      lmul(true, a0, a1, t0, t1);
-      double d0 = w0 - t0, d1 = w1 - t1;
-      bwd(d0, d1);
-      a0 += d0; a1 += d1;
-   }
-   x0 = a0;
-   x1 = a1;
+   x0 = a0 * dinv;
+   x1 = a1 * dinv;
 }
 
 /* ---- one wavefront: Li = L^-1 (lower), lane = column; in place when Li == L */
@@ -529,6 +530,288 @@ __device__ __forceinline__ void s1_trinv(const double* L, double* Li, int n, int
          Li[i * p + lane] = val;
       S1_WSYNC();
    }
+}
+
+/* ==== blocks of at most S1U_MAXN rows: the whole matrix in the registers of EVERY lane ====
+ * The recurrences of a small block (Cholesky factor, its inverse, the Householder reduction to tridiagonal form) are chains of
+ * dependent steps; spread over the lanes of a wavefront each step pays a cross-lane reduction, a broadcast through LDS or
+ * v_readlane and the waits between them - 1500 to 2200 cycles per column at n = 10, whatever the arithmetic.  Here every lane
+ * holds the lower triangle (at most 55 doubles, indices fixed at compile time) and all lanes do the same arithmetic: no
+ * communication at all, the instruction count is the flop count (n^3 / 3 for factor + inverse, 2 n^3 / 3 for the reduction) and
+ * independent multiply-adds issue back to back.  Instantiated for NP = 4, 6, 8, 10 rows; a smaller block is padded. */
+#define S1U_IX(i, j) ((i) * ((i) + 1) / 2 + (j))
+#ifndef S1U_MAXN
+#define S1U_MAXN 10                                           /* (12 fits the registers only with 500 spills) */
+#endif
+
+/* W (LDS, full symmetric n x n, pitch p) -> inverse of its Cholesky factor, lower triangle, in place.  Returns 0, or 1 + the index
+ * of the first pivot that is not positive (nothing stored then). */
+template<int NP>
+__device__ __forceinline__ int s1u_chol_inv(double* W, int n, int p, int lane)
+{
+   double a[NP * (NP + 1) / 2];
+#pragma unroll
+   for (int i = 0; i < NP; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j)
+         a[S1U_IX(i, j)] = (i < n) ? W[i * p + j] : ((i == j) ? 1.0 : 0.0);
+#pragma unroll
+   for (int k = 0; k < NP; ++k)
+   {
+      double d = a[S1U_IX(k, k)];
+#pragma unroll
+      for (int v = 0; v < k; ++v)
+         d = fma(-a[S1U_IX(k, v)], a[S1U_IX(k, v)], d);
+      if ( !(d > 0.0) )
+         return k + 1;
+      const double rs = s1_rsqrt(d);
+      a[S1U_IX(k, k)] = rs;                               /* 1 / (diagonal entry of the factor) */
+#pragma unroll
+      for (int i = k + 1; i < NP; ++i)
+      {
+         double sv = a[S1U_IX(i, k)];
+#pragma unroll
+         for (int v = 0; v < k; ++v)
+            sv = fma(-a[S1U_IX(i, v)], a[S1U_IX(k, v)], sv);
+         a[S1U_IX(i, k)] = sv * rs;
+      }
+   }
+   /* inverse in place, row by row: Li[i][j] = -(sum_{k = j}^{i - 1} L[i][k] Li[k][j]) / L[i][i] */
+#pragma unroll
+   for (int i = 1; i < NP; ++i)
+   {
+      const double rd = a[S1U_IX(i, i)];
+#pragma unroll
+      for (int j = 0; j < i; ++j)
+      {
+         double sv = a[S1U_IX(i, j)] * a[S1U_IX(j, j)];
+#pragma unroll
+         for (int k = j + 1; k < i; ++k)
+            sv = fma(a[S1U_IX(i, k)], a[S1U_IX(k, j)], sv);
+         a[S1U_IX(i, j)] = -sv * rd;
+      }
+   }
+   if ( lane == 0 )
+   {
+#pragma unroll
+      for (int i = 0; i < NP; ++i)
+#pragma unroll
+         for (int j = 0; j <= i; ++j)
+            if ( i < n )
+               W[i * p + j] = a[S1U_IX(i, j)];
+   }
+   S1_WSYNC();
+   return 0;
+}
+
+__device__ __forceinline__ int s1u_chol_inv_n(double* W, int n, int p, int lane)
+{
+   if ( n <= 4 ) return s1u_chol_inv<4>(W, n, p, lane);
+   if ( n <= 6 ) return s1u_chol_inv<6>(W, n, p, lane);
+#if S1U_MAXN > 8
+   if ( n <= 8 ) return s1u_chol_inv<8>(W, n, p, lane);
+#endif
+#if S1U_MAXN > 10
+   if ( n <= 10 ) return s1u_chol_inv<10>(W, n, p, lane);
+   return s1u_chol_inv<12>(W, n, p, lane);
+#elif S1U_MAXN > 8
+   return s1u_chol_inv<10>(W, n, p, lane);
+#else
+   return s1u_chol_inv<8>(W, n, p, lane);
+#endif
+}
+
+/* min(lambda_min, 0) of the symmetric matrix whose lower triangle is in W (LDS, pitch p; not changed), to a relative accuracy of
+ * 1e-10 from below; NaN when an entry is not finite.  Householder reduction as in s1_lmin16 (same formulas), then Sturm
+ * multisection in product form with lane = shift, 64 shifts per round. */
+template<int NP>
+__device__ __forceinline__ double s1u_lmin(const double* W, int n, int p, int lane, double* tprof)
+{
+   double a[NP * (NP + 1) / 2];
+#pragma unroll
+   for (int i = 0; i < NP; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j)
+         a[S1U_IX(i, j)] = (i < n) ? W[i * p + j] : 0.0;
+   double d[NP], e[NP];
+#pragma unroll
+   for (int k = 0; k + 2 < NP; ++k)
+   {
+      if ( k + 2 < n )
+      {
+         const double x0 = a[S1U_IX(k + 1, k)];
+         double s2a = 0.0, s2b = 0.0;
+#pragma unroll
+         for (int i = k + 2; i < NP; i += 2)
+         {
+            s2a = fma(a[S1U_IX(i, k)], a[S1U_IX(i, k)], s2a);
+            if ( i + 1 < NP )
+               s2b = fma(a[S1U_IX(i + 1, k)], a[S1U_IX(i + 1, k)], s2b);
+         }
+         const double s2 = s2a + s2b;
+         if ( s2 != s2 )
+            return s2;
+         if ( s2 > 1e-290 )
+         {
+            const double h2 = x0 * x0 + s2;
+            const double rh = s1_rsqrt(h2);
+            const double beta = -copysign(h2 * rh, x0);
+            const double t = (x0 - beta) * copysign(rh, x0);
+            const double scale = s1_rcp(x0 - beta);
+            double v[NP], w[NP];
+            v[k + 1] = 1.0;
+#pragma unroll
+            for (int i = k + 2; i < NP; ++i)
+               v[i] = a[S1U_IX(i, k)] * scale;
+            a[S1U_IX(k + 1, k)] = beta;
+            /* p = t A v over the trailing block, pv = p^T v, w = p - (t pv / 2) v */
+            double pva = 0.0, pvb = 0.0;
+#pragma unroll
+            for (int i = k + 1; i < NP; ++i)
+            {
+               double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+               for (int j = k + 1; j < NP; ++j)
+               {
+                  const double aij = (j <= i) ? a[S1U_IX(i, j)] : a[S1U_IX(j, i)];
+                  if ( (j - k) & 1 )
+                     acc0 = fma(aij, v[j], acc0);
+                  else
+                     acc1 = fma(aij, v[j], acc1);
+               }
+               w[i] = t * (acc0 + acc1);
+               if ( (i - k) & 1 )
+                  pva = fma(w[i], v[i], pva);
+               else
+                  pvb = fma(w[i], v[i], pvb);
+            }
+            const double hf = -0.5 * t * (pva + pvb);
+#pragma unroll
+            for (int i = k + 1; i < NP; ++i)
+               w[i] = fma(hf, v[i], w[i]);
+#pragma unroll
+            for (int i = k + 1; i < NP; ++i)
+#pragma unroll
+               for (int j = k + 1; j <= i; ++j)
+                  a[S1U_IX(i, j)] = fma(-w[i], v[j], fma(-v[i], w[j], a[S1U_IX(i, j)]));
+         }
+      }
+   }
+#pragma unroll
+   for (int k = 0; k < NP; ++k)
+   {
+      d[k] = a[S1U_IX(k, k)];
+      e[k] = (k + 1 < NP) ? a[S1U_IX(k + 1, k)] : 0.0;
+   }
+   if ( tprof != NULL && lane == 0 )
+      tprof[0] -= (double) clock64();
+   /* Gershgorin bounds, scaling to norm one, padding rows that cannot change a sign */
+   double nrm = 0.0, glo = 1e300;
+   bool bad = false;
+#pragma unroll
+   for (int i = 0; i < NP; ++i)
+   {
+      const double rad = ((i > 0) ? fabs(e[i - 1]) : 0.0) + fabs(e[i]);
+      nrm = fmax(nrm, fabs(d[i]) + rad);
+      glo = fmin(glo, d[i] - rad);
+      bad = bad || !(fabs(d[i]) < 1e300) || !(fabs(e[i]) < 1e300);
+   }
+   double res;
+   if ( bad )
+      res = nan("");
+   else if ( !(glo < 0.0) || !(nrm > 0.0) )
+      res = 0.0;
+   else
+   {
+      const double sinv = s1_rcp(nrm);
+      double dsv[NP], e2v[NP];
+#pragma unroll
+      for (int i = 0; i < NP; ++i)
+      {
+         dsv[i] = (i < n) ? d[i] * sinv : 4.0;
+         e2v[i] = (i + 1 < n) ? (e[i] * sinv) * (e[i] * sinv) : 0.0;
+      }
+      double lo = glo * sinv * (1.0 + 1e-12) - 1e-300, hi = 0.0;
+      bool first = true;
+      const double flane1 = (double) (lane + 1);
+      res = 0.0;
+      bool done = false;
+      for (int round = 0; round < 14 && !done; ++round)
+      {
+         const double wdt = (hi - lo) * (1.0 / 65.0);
+         double x = lo + wdt * flane1;
+         if ( first )
+            x = (lane == 63) ? 0.0 : lo + (hi - lo) * flane1 * (1.0 / 64.0);
+         double pp = 1.0, pc = dsv[0] - x;
+         bool posc = pc > 0.0;
+         bool below = !posc;
+#pragma unroll
+         for (int i = 1; i < NP; ++i)
+         {
+            const double pn = fma(dsv[i] - x, pc, -e2v[i - 1] * pp);
+            const bool posn = pn > 0.0;
+            below = below || (posn != posc);
+            pp = pc; pc = pn; posc = posn;
+            if ( i == 8 && NP > 9 )
+            {
+               const int ex = -max(__builtin_amdgcn_frexp_exp(pc), __builtin_amdgcn_frexp_exp(pp));
+               const bool okx = ex > -1000 && ex < 1000;
+               pc = okx ? ldexp(pc, ex) : pc;
+               pp = okx ? ldexp(pp, ex) : pp;
+            }
+         }
+         const unsigned long long msk = __ballot(below);
+         if ( first )
+         {
+            first = false;
+            if ( !(msk >> 63) )
+            {
+               lo = 0.0;                                    /* nothing below zero */
+               done = true;
+            }
+            else
+            {
+               const int f = __ffsll((long long) msk) - 1;
+               const double w64 = (hi - lo) * (1.0 / 64.0);
+               const double nlo = (f == 0) ? lo : lo + w64 * (double) f;
+               const double nhi = (f == 63) ? 0.0 : lo + w64 * (double) (f + 1);
+               lo = nlo; hi = nhi;
+            }
+         }
+         else
+         {
+            const int f = msk ? __ffsll((long long) msk) - 1 : 64;
+            const double nlo = lo + wdt * (double) f;
+            const double nhi = (f < 64) ? lo + wdt * (double) (f + 1) : hi;
+            lo = nlo; hi = nhi;
+         }
+         if ( tprof != NULL && lane == 0 )
+            tprof[2] += 1.0;
+         if ( hi - lo <= 1e-10 * fabs(lo) || fabs(lo) < 1e-15 )
+            done = true;
+      }
+      res = lo * nrm;
+   }
+   if ( tprof != NULL && lane == 0 )
+      tprof[0] += (double) clock64();
+   return res;
+}
+
+__device__ __forceinline__ double s1u_lmin_n(const double* W, int n, int p, int lane, double* tprof)
+{
+   if ( n <= 4 ) return s1u_lmin<4>(W, n, p, lane, tprof);
+   if ( n <= 6 ) return s1u_lmin<6>(W, n, p, lane, tprof);
+#if S1U_MAXN > 8
+   if ( n <= 8 ) return s1u_lmin<8>(W, n, p, lane, tprof);
+#endif
+#if S1U_MAXN > 10
+   if ( n <= 10 ) return s1u_lmin<10>(W, n, p, lane, tprof);
+   return s1u_lmin<12>(W, n, p, lane, tprof);
+#elif S1U_MAXN > 8
+   return s1u_lmin<10>(W, n, p, lane, tprof);
+#else
+   return s1u_lmin<8>(W, n, p, lane, tprof);
+#endif
 }
 
 template<int CTRL>
@@ -980,10 +1263,11 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
    __syncthreads();
    const S1Lay& L = sh.lay;
    const int pm1 = L.pm1, pm = L.pm, VL = L.VL, QL = L.QL;
+   const int oVec = L.oVec, oQ = L.oQ;
    double* const Mx = sm + L.oMx;
    double* const Lm = sm + L.oLm;
-#define VEC(id) (sm + L.oVec + (id) * VL)
-#define QV(id) (sm + L.oQ + (id) * QL)
+#define VEC(id) (sm + oVec + (id) * VL)
+#define QV(id) (sm + oQ + (id) * QL)
    double* const out = P.out;
 
    /* ---- flexible part: offset arrays first (their sizes follow from the shape), the counts decide the rest */
@@ -1334,7 +1618,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       sh.sc[SC_NORMC] = sqrt(c2);
    }
    __syncthreads();
-   const double normb = sh.sc[SC_NORMB], normC = sh.sc[SC_NORMC];
+   const double normb = s1_uni(sh.sc[SC_NORMB]), normC = s1_uni(sh.sc[SC_NORMC]);
    S1_STAMP(0);
 
    /* ---- starting point */
@@ -1343,6 +1627,44 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       Nsum += L.n[k];
    const double N1 = (double) (Nsum + 1);
    int warm = 0;
+   /* LP part of the Schur matrix (one wavefront; needs x / z in Q_sx) */
+   auto lp_schur = [&]() S1_INL
+   {
+      /* LP part of the Schur matrix, D^T diag(x / z) D, lower triangle; it also clears Mx.  Lane l owns the rows l + 1 (and l + 65):
+       * it walks the LP rows its variable appears in and adds their entries up to its own column.  Row 0 (the constant
+       * column, present in almost every bound row) has one entry, Mx[0][0]: a reduction over the wavefront. */
+      const double* sx = QV(Q_sx);
+      for (int i = lane + 1; i < m1; i += 64)
+      {
+         double* row = Mx + i * pm1;
+         for (int j = 0; j <= i; ++j)
+            row[j] = 0.0;
+         const int t1 = sh.coff[i + 1];
+         for (int t = sh.coff[i]; t < t1; ++t)
+         {
+            const int r = sh.crow[t];
+            const double sv = sh.cval[t] * sx[r];
+            const int u1 = sh.roff[r + 1];
+            for (int u = sh.roff[r]; u < u1; ++u)
+            {
+               const int j = sh.rcol[u];
+               if ( j > i )
+                  break;
+               row[j] = fma(sv, sh.rval[u], row[j]);
+            }
+         }
+      }
+      double s00 = 0.0;
+      const int t1 = sh.coff[1];
+      for (int t = sh.coff[0] + lane; t < t1; t += 64)
+      {
+         const double cv0 = sh.cval[t];
+         s00 = fma(cv0 * sx[sh.crow[t]], cv0, s00);
+      }
+      s00 = s1_wsum(s00);
+      if ( lane == 0 )
+         Mx[0] = s00;
+   };
    auto trial_factor = [&](double alpha, bool fromglobal) S1_INL -> int
    {
       /* LxI <- X + alpha dXs (dXs in E), LzI <- Z + alpha dZs (dZs in B), then their Cholesky factors in place; returns the
@@ -1376,12 +1698,28 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
             sm[B.oLz + r * p + c] = zv;
          }
       }
+      for (int r = tid; r < q; r += S1_NT)
+      {
+         double xv = QV(Q_x)[r], zv = QV(Q_z)[r];
+         if ( alpha != 0.0 )
+         {
+            xv = fma(alpha, QV(Q_dx)[r], xv);
+            zv = fma(alpha, QV(Q_dz)[r], zv);
+         }
+         QV(Q_sx)[r] = xv / zv;
+      }
       __syncthreads();
+      /* (the LP part of the next Schur matrix rides along on the last wavefront: Mx is free between the corrector and the next
+       * assembly, and a trial that fails repeats it) */
+      if ( wave == S1_NW - 1 )
+         lp_schur();
       for (int t = wave; t < 2 * K; t += S1_NW)
       {
          const S1Blk& B = sh.blk[t >> 1];
          double dummy; int nfd;
-         const int f = s1_cholp(sm + ((t & 1) ? B.oLz : B.oLx), B.n, B.p, lane, false, 1.0, 0, true, dummy, nfd);
+         /* (blocks of at most S1U_MAXN rows: factor and inverse factor in one go, every lane for itself) */
+         const int f = (B.n <= S1U_MAXN) ? s1u_chol_inv_n(sm + ((t & 1) ? B.oLz : B.oLx), B.n, B.p, lane)
+            : s1_cholp(sm + ((t & 1) ? B.oLz : B.oLx), B.n, B.p, lane, false, 1.0, 0, true, dummy, nfd);
          if ( lane == 0 )
             sh.fl[8 + t] = f;
       }
@@ -1479,6 +1817,9 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
    const int nobest_lim = settings == 0 ? 6 : (settings == 1 ? 10 : 15);
    const double sigma_floor = settings == 0 ? 1e-8 : (settings == 1 ? 1e-4 : 1e-2);
    const int maxiter = P.maxiter;
+   bool anybig = false;
+   for (int k = 0; k < K; ++k)
+      anybig = anybig || (L.n[k] > S1U_MAXN);
 
    int status = HS_S1_ITERLIM;
    int it = 0, certwait = 0, nstall = 0, sincebest = 0, chol_fail = 0, pre_valid = 0;
@@ -1549,18 +1890,20 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          s += sh.red[w][slot];
       return s;
    };
-   /* wavefront 0: the solves with the factor of M, each triangular solve corrected once with the factor itself (oracle: msolve).
-    * r0, r1: right-hand sides (r1 may be NULL), results in o0, o1; t0..t3: scratch vectors */
-   /* wavefront 0: x = M^-1 r for one or two right-hand sides (LDS vectors) by substitution with the factor of M; mdinv: this
-    * lane's 1 / diagonal entry of the factor.  [The oracle corrects each triangular solve once with the factor itself because the
-    * engine's general path solves with explicit inverses of diagonal blocks; a substitution has the small residual by itself.] */
-   double mdinv = 1.0, mdiagv = 1.0;
+   /* wavefront 0: x = M^-1 r for one or two right-hand sides (LDS vectors; r1 may be NULL) by substitution with the factor of M;
+    * mdinv: this lane's 1 / diagonal entry of the factor.  [The oracle corrects each triangular solve once with the factor itself
+    * because the engine's general path solves with explicit inverses of diagonal blocks; a substitution has the small residual by
+    * itself.] */
+   double mdinv = 1.0;
    auto msolve2 = [&](const double* r0, const double* r1, double* o0, double* o1) S1_INL
    {
       const bool two = (r1 != NULL);
       double x0 = (lane < m) ? r0[lane] : 0.0;
       double x1 = (two && lane < m) ? r1[lane] : 0.0;
-      s1_llt_solve(Lm, m, pm, lane, mdinv, mdiagv, two, P.refine != 0, x0, x1);
+      if ( two )
+         s1_llt_solve<true>(Lm, m, pm, lane, mdinv, x0, x1);
+      else
+         s1_llt_solve<false>(Lm, m, pm, lane, mdinv, x0, x1);
       if ( lane < m )
       {
          o0[lane] = x0;
@@ -1727,8 +2070,8 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          double* Wm = sm + ((t & 1) ? B.odZ : B.odX);
          double* tpr = (P.prof_on && t == 0) ? &sh.prof[19] : (double*) NULL;
          double* escr = sm + B.oEig + (t & 1) * (4 * ((B.n + 1) & ~1) + 32);
-         const double lm = (B.n <= 16) ? s1_lmin16(Wm, B.n, B.p, lane, escr, tpr)
-            : s1_lmin(Wm, B.n, B.p, lane, escr, tpr);
+         const double lm = (B.n <= S1U_MAXN) ? s1u_lmin_n(Wm, B.n, B.p, lane, tpr)
+            : ((B.n <= 16) ? s1_lmin16(Wm, B.n, B.p, lane, escr, tpr) : s1_lmin(Wm, B.n, B.p, lane, escr, tpr));
          if ( lane == 0 )
             sh.sc[SC_LMIN0 + t] = lm;
       }
@@ -1793,7 +2136,6 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
             const double zv = QV(Q_z)[r];
             const double v = lp_row(r, cv) - zv;
             QV(Q_rd)[r] = v;
-            QV(Q_sx)[r] = QV(Q_x)[r] / zv;
             r2lp = fma(v, v, r2lp);
             rmax = fmax(rmax, fabs(v));
             xz = fma(QV(Q_x)[r], zv, xz);
@@ -1826,10 +2168,10 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       }
       __syncthreads();
       const double tau = sh.sc[SC_TAU], kappa = sh.sc[SC_KAPPA];
-      pobj = VEC(V_AX)[0];
-      dobj = sh.sc[SC_DOBJ];
+      pobj = s1_uni(VEC(V_AX)[0]);
+      dobj = s1_uni(sh.sc[SC_DOBJ]);
       const double rg = pobj - dobj - kappa;
-      mu = (red_sum(RS_XZ) + tau * kappa) / N1;
+      mu = s1_uni((red_sum(RS_XZ) + tau * kappa) / N1);
       double rd2 = red_sum(RS_RD2LP);
       double rdmax = 0.0;
       for (int w = 0; w < S1_NW; ++w)
@@ -1841,12 +2183,12 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          rdmax = fmax(rdmax, sqrt(bk));
       }
       const double rpn = sqrt(sh.sc[SC_RP2]);
-      pinf = rpn / tau / (1.0 + normb);
+      pinf = s1_uni(rpn / tau / (1.0 + normb));
       const double pabs = rpn / tau;
       const bool pabsok = P.pabstol <= 0.0 || pabs <= P.pabstol;
-      dinf = sqrt(rd2) / tau / (1.0 + normC);
-      dabs_ = rdmax / tau;
-      gap = fabs(dobj - pobj) / tau;
+      dinf = s1_uni(sqrt(rd2) / tau / (1.0 + normC));
+      dabs_ = s1_uni(rdmax / tau);
+      gap = s1_uni(fabs(dobj - pobj) / tau);
       if ( P.hist != NULL && tid == 0 && it < P.hist_len )
       {
          double* h = P.hist + 16 * it;
@@ -1875,7 +2217,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
                P.Xpre[k][e] = sm[B.oX + r * p + c];
             }
          }
-         pre_scale = 1.0 / tau;
+         pre_scale = s1_uni(1.0 / tau);
          pre_valid = 1;
       }
       if ( P.objlimit < 1e20 && pinf <= P.feastol && pobj / tau > P.objlimit + P.gaptol )
@@ -1954,7 +2296,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
             merit = fmax(merit, pabs / P.pabstol);
          if ( merit < 0.9 * bestmerit )
          {
-            bestmerit = merit;
+            bestmerit = s1_uni(merit);
             sincebest = 0;
          }
          else if ( ++sincebest >= nobest_lim )
@@ -1989,52 +2331,19 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
             break;
          }
       }
-      /* inverse factors in place (one wavefront per matrix, from wavefront 0 up); LP part of the Schur matrix by the threads at
-       * the other end: thread NT - 1 - i owns row i of Mx (lower part), zeroes it and adds its rows' contributions */
-      for (int t = wave; t < 2 * K; t += S1_NW)
+      /* inverse factors in place for the blocks above S1U_MAXN rows (one wavefront per matrix; the smaller ones were inverted with
+       * their factorization); then Zinv = LzI^T LzI */
+      if ( anybig )
       {
-         const S1Blk& B = sh.blk[t >> 1];
-         double* Lp = sm + ((t & 1) ? B.oLz : B.oLx);
-         s1_trinv(Lp, Lp, B.n, B.p, lane);
-      }
-      if ( wave == S1_NW - 1 )
-      {
-         /* LP part of the Schur matrix, D^T diag(x / z) D, lower triangle; it also clears Mx.  Lane l owns the rows l + 1 (and l + 65):
-          * it walks the LP rows its variable appears in and adds their entries up to its own column.  Row 0 (the constant
-          * column, present in almost every bound row) has one entry, Mx[0][0]: a reduction over the wavefront. */
-         const double* sx = QV(Q_sx);
-         for (int i = lane + 1; i < m1; i += 64)
+         for (int t = wave; t < 2 * K; t += S1_NW)
          {
-            double* row = Mx + i * pm1;
-            for (int j = 0; j <= i; ++j)
-               row[j] = 0.0;
-            const int t1 = sh.coff[i + 1];
-            for (int t = sh.coff[i]; t < t1; ++t)
-            {
-               const int r = sh.crow[t];
-               const double sv = sh.cval[t] * sx[r];
-               const int u1 = sh.roff[r + 1];
-               for (int u = sh.roff[r]; u < u1; ++u)
-               {
-                  const int j = sh.rcol[u];
-                  if ( j > i )
-                     break;
-                  row[j] = fma(sv, sh.rval[u], row[j]);
-               }
-            }
+            const S1Blk& B = sh.blk[t >> 1];
+            double* Lp = sm + ((t & 1) ? B.oLz : B.oLx);
+            if ( B.n > S1U_MAXN )
+               s1_trinv(Lp, Lp, B.n, B.p, lane);
          }
-         double s00 = 0.0;
-         const int t1 = sh.coff[1];
-         for (int t = sh.coff[0] + lane; t < t1; t += 64)
-         {
-            const double cv0 = sh.cval[t];
-            s00 = fma(cv0 * sx[sh.crow[t]], cv0, s00);
-         }
-         s00 = s1_wsum(s00);
-         if ( lane == 0 )
-            Mx[0] = s00;
+         __syncthreads();
       }
-      __syncthreads();
       S1_STAMP(3);
       {
          int tb = 0;
@@ -2195,12 +2504,15 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          S1_WSYNC();
          double mdiag;
          int nforced;
+         long long tq0 = 0;
+         if ( P.prof_on ) tq0 = clock64();
          (void) s1_cholp(Lm, m, pm, lane, true, dg0, P.pivot_rule, false, mdiag, nforced);
          if ( lane == 0 )
             sh.fl[6] = nforced;
          mdinv = s1_rcp(mdiag);
-         mdiagv = mdiag;
+         if ( P.prof_on && lane == 0 ) { const long long tq1 = clock64(); sh.prof[20] += (double) (tq1 - tq0); tq0 = tq1; }
          msolve2(VEC(V_g), VEC(V_b), VEC(V_w), VEC(V_ub));
+         if ( P.prof_on && lane == 0 ) { const long long tq1 = clock64(); sh.prof[21] += (double) (tq1 - tq0); }
          if ( lane < m )
          {
             const double w = VEC(V_w)[lane], ub = VEC(V_ub)[lane];
@@ -2330,7 +2642,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          finish_dir(0.0, 0.0, rg);
       __syncthreads();
       S1_STAMP(7);
-      double dta = sh.sc[SC_DTAU], dka = sh.sc[SC_DKAPPA];
+      const double dta = sh.sc[SC_DTAU], dka = sh.sc[SC_DKAPPA];
       if ( !(fabs(dta) < 1e300) || !(fabs(dka) < 1e300) )
       {
          status = HS_S1_NUMERIC;
@@ -2563,7 +2875,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          sh.sc[SC_KAPPA] = kappa + alpha * dk;
       }
       factors_valid = true;
-      alpha_last = alpha;
+      alpha_last = s1_uni(alpha);
       __syncthreads();
       S1_STAMP(11);
    }
