@@ -2297,7 +2297,7 @@ static int solve1_try(hipsdp_solver* s, hipsdp_info* info, bool* done)
       on = (env != NULL && env[0] == '0') ? 0 : 1;
       if ( getenv("HIPSDP_SOLVE1_MAXWORK") != NULL )
          maxwork = atof(getenv("HIPSDP_SOLVE1_MAXWORK"));
-      prof = (getenv("HIPSDP_SOLVE1_PROF") != NULL && getenv("HIPSDP_SOLVE1_PROF")[0] == '1') ? 1 : 0;
+      prof = getenv("HIPSDP_SOLVE1_PROF") != NULL ? atoi(getenv("HIPSDP_SOLVE1_PROF")) : 0;
    }
    const hipsdp_params& par = s->par;
    if ( !on || s->comm != NULL || s->shardA || s->schur_mode_forced || par.verbose || s->pc.on )
@@ -2369,7 +2369,7 @@ static int solve1_try(hipsdp_solver* s, hipsdp_info* info, bool* done)
    a.prof_on = prof;
    a.gws = s->s1_ws; a.gws_len = s->s1_ws_len;
    a.out = s->s1_host_dev;
-   a.hist = getenv("HIPSDP_SOLVE1_HIST") != NULL ? s->s1_host_dev + HS_S1_OUT_DOUBLES + 8 : NULL;
+   a.hist = (getenv("HIPSDP_SOLVE1_HIST") != NULL && getenv("HIPSDP_SOLVE1_HIST")[0] != '0') ? s->s1_host_dev + HS_S1_OUT_DOUBLES + 8 : NULL;
    a.hist_len = S1_HIST_MAX;
    a.seq = ++s->s1_seq;
    a.flag = reinterpret_cast<unsigned long long*>(s->s1_host_dev + HS_S1_OUT_DOUBLES);

@@ -50,7 +50,7 @@
 enum { V_b = 0, V_y, V_rp, V_AX, V_AH, V_g, V_w, V_ub, V_u2, V_u1, V_h, V_dy, V_wt, V_cv, V_dg, V_t1, V_t2, V_t3, V_t4, V_COUNT };
 enum { Q_x = 0, Q_z, Q_rd, Q_beta, Q_hl, Q_dx, Q_dz, Q_elp, Q_sx, Q_COUNT };
 /* partial sums of a phase, one row per wavefront */
-enum { RS_XZ = 0, RS_RD2LP, RS_RDMAX, RS_S0, RS_BH, RS_HD2, RS_RATX, RS_RATZ, RS_NC2, RS_WORK, RS_BLK0, RS_END = RS_BLK0 + S1_MAXB };
+enum { RS_XZ = 0, RS_RD2LP, RS_RDMAX, RS_S0, RS_BH, RS_HD2, RS_RATX, RS_RATZ, RS_NC2, RS_WORK, RS_RP2, RS_HP2, RS_DOB, RS_BLK0, RS_END = RS_BLK0 + S1_MAXB };
 static_assert(RS_END <= S1_NRED, "reduction slots");
 /* scalars in LDS */
 enum { SC_TAU = 0, SC_KAPPA, SC_RP2, SC_HP2, SC_DOBJ, SC_BUB, SC_BU1, SC_WRP, SC_DTAU, SC_DKAPPA, SC_NORMB, SC_NORMC, SC_FAIL, SC_XI,
@@ -1164,7 +1164,7 @@ __device__ __forceinline__ void s1_mm(int n, int wave, int lane, int w0, int nw,
       const int lr = lane & 15, kq = lane >> 4;
       for (int t = 0; t < ntile; ++t)
       {
-         if ( (tbase + t) % nw != wave - w0 )
+         if ( (tbase + t) % nw != w0 + nw - 1 - wave )
             continue;
          const int ti = t / nt, tj = t - ti * nt;
          const int ri = 16 * ti + lr, cj = 16 * tj + lr;
@@ -1206,6 +1206,56 @@ __device__ __forceinline__ void s1_mm(int n, int wave, int lane, int w0, int nw,
    tbase += ntile;
 }
 
+
+/* two products of the same shape at once, D1 = A1 B1 and D2 = A2 B2, with one epilogue ep(i, j, d1, d2).  Used for sym(T Zinv): the
+ * second product is Zinv T^T, i.e. the transposed tile in the same lanes, so that H = sigma mu Zinv - X - sym(T Zinv) leaves the
+ * product's epilogue instead of a phase of its own. */
+template<class LA, class LB, class LA2, class LB2, class EP>
+__device__ __forceinline__ void s1_mm2(int n, int wave, int lane, int w0, int nw, int& tbase, LA la, LB lb, LA2 la2, LB2 lb2, EP ep)
+{
+   const int nt = (n + 15) >> 4;
+   const int ntile = nt * nt;
+   if ( wave >= w0 && wave < w0 + nw )
+   {
+      const int lr = lane & 15, kq = lane >> 4;
+      for (int t = 0; t < ntile; ++t)
+      {
+         if ( (tbase + t) % nw != w0 + nw - 1 - wave )
+            continue;
+         const int ti = t / nt, tj = t - ti * nt;
+         const int ri = 16 * ti + lr, cj = 16 * tj + lr;
+         v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+         v4d bcc0 = {0.0, 0.0, 0.0, 0.0}, bcc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 2
+         for (int kk = 0; kk < n; kk += 8)
+         {
+            const int k0 = kk + kq, k1 = kk + 4 + kq;
+            const bool ra0 = ri < n && k0 < n, rb0 = cj < n && k0 < n, ra1 = ri < n && k1 < n, rb1 = cj < n && k1 < n;
+            const double a0 = ra0 ? la(ri, k0) : 0.0;
+            const double b0 = rb0 ? lb(k0, cj) : 0.0;
+            const double a1 = ra1 ? la(ri, k1) : 0.0;
+            const double b1 = rb1 ? lb(k1, cj) : 0.0;
+            const double c0 = ra0 ? la2(ri, k0) : 0.0;
+            const double d0 = rb0 ? lb2(k0, cj) : 0.0;
+            const double c1 = ra1 ? la2(ri, k1) : 0.0;
+            const double d1 = rb1 ? lb2(k1, cj) : 0.0;
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
+            bcc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(c0, d0, bcc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
+            bcc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(c1, d1, bcc1, 0, 0, 0);
+         }
+#pragma unroll
+         for (int r = 0; r < 4; ++r)
+         {
+            const int row = 16 * ti + kq + 4 * r;
+            if ( row < n && cj < n )
+               ep(row, cj, acc0[r] + acc1[r], bcc0[r] + bcc1[r]);
+         }
+      }
+   }
+   tbase += ntile;
+}
+
 /* exclusive prefix sums of the counts a[0 .. len) in place, a[len] = total (all threads; contains barriers) */
 __device__ __forceinline__ void s1_exscan(int* a, int len, S1Sh& sh, int tid)
 {
@@ -1241,6 +1291,17 @@ __device__ __forceinline__ void s1_exscan(int* a, int len, S1Sh& sh, int tid)
    __syncthreads();
 }
 
+/* pointers to the lists and cold matrices: they live in LDS while it lasts, else in the workspace in global memory, and are kept as
+ * generic pointers.  A generic load counts on both memory counters and the compiler waits for ALL outstanding loads before every
+ * use; when everything is in LDS (every B&B-sized instance of the reference) the iteration is compiled with LDS-typed pointers. */
+template<bool AL, class T> struct S1Ptr { typedef T* type; };
+template<class T> struct S1Ptr<true, T> { typedef __attribute__((address_space(3))) T* type; };
+template<bool AL, class T> __device__ __forceinline__ typename S1Ptr<AL, T>::type s1_lp(T* p) { return (typename S1Ptr<AL, T>::type) p; }
+#define LP(x) s1_lp<AL>(x)
+
+/* developer profile (prof_on == 2, history buffer given): in iteration 3 every wavefront notes when it reaches each barrier - which
+ * wavefront a phase waits for, and how long the others idle */
+#define S1_BAR() do { if ( P.prof_on == 2 && P.hist != NULL && it == 3 && lane == 0 && nbar < 60 ) P.hist[2048 + 8 * nbar + wave] = (double) clock64(); ++nbar; __syncthreads(); } while (0)
 #define S1_STAMP(id) do { if ( P.prof_on && tid == 0 ) { const long long t_ = clock64(); sh.prof[id] += (double) (t_ - sh.t_last); sh.t_last = t_; } } while (0)
 
 __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
@@ -1438,6 +1499,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       sh.fl[1] = (work > P.maxwork) ? 1 : 0;
       sh.fl[2] = nnzA; sh.fl[3] = nnzD;
       sh.fl[4] = ((long long) (gp - P.gws) > P.gws_len) ? 1 : 0;
+      sh.fl[30] = (gp == P.gws) ? 1 : 0;                   /* nothing went to global memory */
    }
    __syncthreads();
    if ( sh.fl[1] || sh.fl[4] )
@@ -1620,6 +1682,9 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
    __syncthreads();
    const double normb = s1_uni(sh.sc[SC_NORMB]), normC = s1_uni(sh.sc[SC_NORMC]);
    S1_STAMP(0);
+   auto body = [&](auto ALtag) S1_INL
+   {
+   constexpr bool AL = decltype(ALtag)::value;
 
    /* ---- starting point */
    long long Nsum = q;
@@ -1627,6 +1692,11 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       Nsum += L.n[k];
    const double N1 = (double) (Nsum + 1);
    int warm = 0;
+   int it = 0, nbar = 0;
+   /* (thread index rotated by `off`: independent tasks of a phase start at different wavefronts - a loop that starts at thread 0
+    * puts a block of 10 rows, 85 LP rows and the tile of a product all on wavefronts 0 and 1 while the other six wait at the
+    * barrier; the products' tiles are dealt out from the last wavefront down) */
+   auto tro = [&](int off) S1_INL -> int { const int t = tid - off; return t < 0 ? t + S1_NT : t; };
    /* LP part of the Schur matrix (one wavefront; needs x / z in Q_sx) */
    auto lp_schur = [&]() S1_INL
    {
@@ -1639,27 +1709,27 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          double* row = Mx + i * pm1;
          for (int j = 0; j <= i; ++j)
             row[j] = 0.0;
-         const int t1 = sh.coff[i + 1];
-         for (int t = sh.coff[i]; t < t1; ++t)
+         const int t1 = LP(sh.coff)[i + 1];
+         for (int t = LP(sh.coff)[i]; t < t1; ++t)
          {
-            const int r = sh.crow[t];
-            const double sv = sh.cval[t] * sx[r];
-            const int u1 = sh.roff[r + 1];
-            for (int u = sh.roff[r]; u < u1; ++u)
+            const int r = LP(sh.crow)[t];
+            const double sv = LP(sh.cval)[t] * sx[r];
+            const int u1 = LP(sh.roff)[r + 1];
+            for (int u = LP(sh.roff)[r]; u < u1; ++u)
             {
-               const int j = sh.rcol[u];
+               const int j = LP(sh.rcol)[u];
                if ( j > i )
                   break;
-               row[j] = fma(sv, sh.rval[u], row[j]);
+               row[j] = fma(sv, LP(sh.rval)[u], row[j]);
             }
          }
       }
       double s00 = 0.0;
-      const int t1 = sh.coff[1];
-      for (int t = sh.coff[0] + lane; t < t1; t += 64)
+      const int t1 = LP(sh.coff)[1];
+      for (int t = LP(sh.coff)[0] + lane; t < t1; t += 64)
       {
-         const double cv0 = sh.cval[t];
-         s00 = fma(cv0 * sx[sh.crow[t]], cv0, s00);
+         const double cv0 = LP(sh.cval)[t];
+         s00 = fma(cv0 * sx[LP(sh.crow)[t]], cv0, s00);
       }
       s00 = s1_wsum(s00);
       if ( lane == 0 )
@@ -1682,23 +1752,23 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
                xv = 0.5 * (P.X[k][(long long) r * n + c] + P.X[k][(long long) c * n + r]);
                zv = 0.5 * (P.Z[k][(long long) r * n + c] + P.Z[k][(long long) c * n + r]);
                sm[B.oX + r * p + c] = xv;
-               B.Z[r * p + c] = zv;
+               LP(B.Z)[r * p + c] = zv;
             }
             else
             {
                xv = sm[B.oX + r * p + c];
-               zv = B.Z[r * p + c];
+               zv = LP(B.Z)[r * p + c];
                if ( alpha != 0.0 )
                {
-                  xv = fma(alpha, B.E[r * p + c], xv);
-                  zv = fma(alpha, B.B[r * p + c], zv);
+                  xv = fma(alpha, LP(B.E)[r * p + c], xv);
+                  zv = fma(alpha, LP(B.B)[r * p + c], zv);
                }
             }
             sm[B.oLx + r * p + c] = xv;
             sm[B.oLz + r * p + c] = zv;
          }
       }
-      for (int r = tid; r < q; r += S1_NT)
+      for (int r = tro(128); r < q; r += S1_NT)
       {
          double xv = QV(Q_x)[r], zv = QV(Q_z)[r];
          if ( alpha != 0.0 )
@@ -1708,7 +1778,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          }
          QV(Q_sx)[r] = xv / zv;
       }
-      __syncthreads();
+      S1_BAR();
       /* (the LP part of the next Schur matrix rides along on the last wavefront: Mx is free between the corrector and the next
        * assembly, and a trial that fails repeats it) */
       if ( wave == S1_NW - 1 )
@@ -1723,7 +1793,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          if ( lane == 0 )
             sh.fl[8 + t] = f;
       }
-      __syncthreads();
+      S1_BAR();
       int ff = 0;
       for (int t = 0; t < 2 * K; ++t)
          if ( sh.fl[8 + t] != 0 )
@@ -1738,6 +1808,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          QV(Q_x)[r] = P.x[r];
          QV(Q_z)[r] = P.z[r];
       }
+      __syncthreads();
       const int ff = trial_factor(0.0, true);
       /* interior?  mean complementarity */
       double xz = 0.0, bad = 0.0;
@@ -1748,7 +1819,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          for (int e = tid; e < n * n; e += S1_NT)
          {
             const int r = s1_div(e, n), c = e - r * n;
-            xz += sm[B.oX + r * p + c] * B.Z[r * p + c];
+            xz += sm[B.oX + r * p + c] * LP(B.Z)[r * p + c];
          }
       }
       for (int r = tid; r < q; r += S1_NT)
@@ -1799,7 +1870,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
             const int r = s1_div(e, n), c = e - r * n;
             const double v = (r == c) ? xi : 0.0;
             sm[B.oX + r * p + c] = v;
-            B.Z[r * p + c] = v;
+            LP(B.Z)[r * p + c] = v;
          }
       }
       if ( tid == 0 )
@@ -1822,7 +1893,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       anybig = anybig || (L.n[k] > S1U_MAXN);
 
    int status = HS_S1_ITERLIM;
-   int it = 0, certwait = 0, nstall = 0, sincebest = 0, chol_fail = 0, pre_valid = 0;
+   int certwait = 0, nstall = 0, sincebest = 0, chol_fail = 0, pre_valid = 0;
    double lastmu = 1e300, alpha_last = 1.0, bestmerit = 1e300, pre_scale = 0.0;
    double mu = 0, pinf = 0, dinf = 0, dabs_ = 0, gap = 0, pobj = 0, dobj = 0;
    bool factors_valid = (warm != 0);
@@ -1830,25 +1901,25 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
 
    /* ---- helpers of the iteration (all threads call them; they contain no barrier unless stated) */
    /* out(r, c) for r >= c: sum over the variables that touch the position of coefficient x value */
-   auto pass_AT = [&](const S1Blk& B, const double* cv, auto epi) S1_INL
+   auto pass_AT = [&](const S1Blk& B, const double* cv, int toff, auto epi) S1_INL
    {
       const int n = B.n, n2 = n * n;
-      for (int e = tid; e < n2; e += S1_NT)
+      for (int e = tro(toff); e < n2; e += S1_NT)
       {
          const int r = s1_div(e, n), c = e - r * n;
          if ( r < c )
             continue;
          double s = 0.0;
-         const int t1 = B.poff[e + 1];
-         for (int t = B.poff[e]; t < t1; ++t)
-            s = fma(B.pval[t], cv[B.pvar[t]], s);
+         const int t1 = LP(B.poff)[e + 1];
+         for (int t = LP(B.poff)[e]; t < t1; ++t)
+            s = fma(LP(B.pval)[t], cv[LP(B.pvar)[t]], s);
          epi(r, c, s);
       }
    };
    /* outv[i] = sum_k <A_i^k, V_k> + (Dext^T xv)_i, V_k symmetric at LDS offset offs[k] (16 lanes per variable) */
-   auto pass_A = [&](bool ofdX, const double* xv, double* outv) S1_INL
+   auto pass_A = [&](bool ofdX, const double* xv, double* outv, int toff, auto epi) S1_INL
    {
-      const int gid = tid >> 4, l16 = tid & 15;
+      const int gid = tro(toff) >> 4, l16 = tid & 15;
       for (int i = gid; i < m1; i += S1_NT / 16)
       {
          double s = 0.0;
@@ -1856,30 +1927,34 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          {
             const S1Blk& B = sh.blk[k];
             const double* V = sm + (ofdX ? B.odX : B.oX);
-            const int t1 = B.voff[i + 1];
-            for (int t = B.voff[i] + l16; t < t1; t += 16)
+            const int t1 = LP(B.voff)[i + 1];
+            for (int t = LP(B.voff)[i] + l16; t < t1; t += 16)
             {
-               const unsigned pq = B.vpq[t];
+               const unsigned pq = LP(B.vpq)[t];
                const int pp = (int) (pq >> 16), qq = (int) (pq & 0xffffu);
-               s = fma(B.vval[t], V[pp * B.p + qq], s);
+               s = fma(LP(B.vval)[t], V[pp * B.p + qq], s);
             }
          }
          {
-            const int t1 = sh.coff[i + 1];
-            for (int t = sh.coff[i] + l16; t < t1; t += 16)
-               s = fma(sh.cval[t], xv[sh.crow[t]], s);
+            const int t1 = LP(sh.coff)[i + 1];
+            for (int t = LP(sh.coff)[i] + l16; t < t1; t += 16)
+               s = fma(LP(sh.cval)[t], xv[LP(sh.crow)[t]], s);
          }
          s = s1_sum16(s);
          if ( l16 == 0 )
+         {
             outv[i] = s;
+            epi(i, s);
+         }
       }
    };
+   auto no_epi = [](int, double) S1_INL {};
    auto lp_row = [&](int r, const double* cv) S1_INL -> double
    {
       double s = 0.0;
-      const int t1 = sh.roff[r + 1];
-      for (int t = sh.roff[r]; t < t1; ++t)
-         s = fma(sh.rval[t], cv[sh.rcol[t]], s);
+      const int t1 = LP(sh.roff)[r + 1];
+      for (int t = LP(sh.roff)[r]; t < t1; ++t)
+         s = fma(LP(sh.rval)[t], cv[LP(sh.rcol)[t]], s);
       return s;
    };
    auto red_sum = [&](int slot) S1_INL -> double
@@ -1913,21 +1988,23 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
    };
 
    double sigma = 0.0, eta = 1.0;
-   /* H (or dX) = sigmu Zinv - X - sym(T2) into dX, LP part into `lpout` from `rlp` (rd for the right-hand side, dz for the step) */
+   /* H (or dX) = sigmu Zinv - X - sym(T1 Zinv) into dX: the product and its transpose (Zinv T1^T) side by side, H from the epilogue;
+    * LP part into `lpout` from `rlp` (rd for the right-hand side, dz for the step).  All threads; no barrier. */
    auto dir_matrix = [&](double sigmu, double etalp, const double* rlp, bool useE, double* lpout) S1_INL
    {
+      int tb = 0;
       for (int k = 0; k < K; ++k)
       {
          const S1Blk& B = sh.blk[k];
-         const int n = B.n, p = B.p;
-         for (int e = tid; e < n * n; e += S1_NT)
-         {
-            const int r = s1_div(e, n), c = e - r * n;
-            sm[B.odX + r * p + c] = sigmu * sm[B.oZi + r * p + c] - sm[B.oX + r * p + c]
-               - 0.5 * (sm[B.oT2 + r * p + c] + sm[B.oT2 + c * p + r]);
-         }
+         const int p = B.p;
+         const double* T1 = sm + B.oT1; const double* Zi = sm + B.oZi; const double* X = sm + B.oX;
+         double* dX = sm + B.odX;
+         s1_mm2(B.n, wave, lane, 0, S1_NW, tb,
+            [&](int i, int kk) S1_INL { return T1[i * p + kk]; }, [&](int kk, int j) S1_INL { return Zi[kk * p + j]; },
+            [&](int i, int kk) S1_INL { return Zi[i * p + kk]; }, [&](int kk, int j) S1_INL { return T1[j * p + kk]; },
+            [&](int i, int j, double v1, double v2) S1_INL { dX[i * p + j] = sigmu * Zi[i * p + j] - X[i * p + j] - 0.5 * (v1 + v2); });
       }
-      for (int r = tid; r < q; r += S1_NT)
+      for (int r = tid; r < q; r += S1_NT)                /* (the tiles of the product are on the last wavefronts) */
       {
          const double xv = QV(Q_x)[r], zv = QV(Q_z)[r];
          lpout[r] = sigmu / zv - xv - (etalp * xv * rlp[r] + (useE ? QV(Q_elp)[r] : 0.0)) / zv;
@@ -1974,10 +2051,10 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          for (int e = tid; e < n * n; e += S1_NT)
          {
             const int r = s1_div(e, n), c = e - r * n;
-            s = fma(B.B[r * p + c], sm[B.odX + r * p + c], s);
+            s = fma(LP(B.B)[r * p + c], sm[B.odX + r * p + c], s);
          }
       }
-      for (int r = tid; r < q; r += S1_NT)
+      for (int r = tro(320); r < q; r += S1_NT)
          s = fma(QV(Q_beta)[r], QV(Q_hl)[r], s);
       s = s1_wsum(s);
       if ( lane == 0 )
@@ -1991,14 +2068,14 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       {
          const S1Blk& B = sh.blk[k];
          const int p = B.p;
-         pass_AT(B, cv, [&](int r, int c, double s) S1_INL
+         pass_AT(B, cv, 0, [&](int r, int c, double s) S1_INL
          {
-            const double v = fma(eta, B.Rd[r * p + c], s);
+            const double v = fma(eta, LP(B.Rd)[r * p + c], s);
             sm[B.odZ + r * p + c] = v;
             sm[B.odZ + c * p + r] = v;
          });
       }
-      for (int r = tid; r < q; r += S1_NT)
+      for (int r = tro(128); r < q; r += S1_NT)
          QV(Q_dz)[r] = fma(eta, QV(Q_rd)[r], lp_row(r, cv));
    };
    /* step lengths: (a) T1 = LxI dX, T2 = LzI dZ (+ LP ratio tests; save = true: dX, dZ are copied to E, B first), (b) dX <- T1 LxI^T,
@@ -2022,15 +2099,15 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
                [&](int i, int kk) S1_INL { return kk <= i ? Lz[i * p + kk] : 0.0; }, [&](int kk, int j) S1_INL { return dZ[kk * p + j]; },
                [&](int i, int j, double v) S1_INL { T2[i * p + j] = v; });
             if ( save )
-               for (int e = tid; e < n * n; e += S1_NT)
+               for (int e = tro(128); e < n * n; e += S1_NT)
                {
                   const int r = s1_div(e, n), c = e - r * n;
-                  B.E[r * p + c] = dX[r * p + c];
-                  B.B[r * p + c] = dZ[r * p + c];
+                  LP(B.E)[r * p + c] = dX[r * p + c];
+                  LP(B.B)[r * p + c] = dZ[r * p + c];
                }
          }
          double rx = 1e300, rz = 1e300;
-         for (int r = tid; r < q; r += S1_NT)
+         for (int r = tro(256); r < q; r += S1_NT)
          {
             const double dxv = QV(Q_dx)[r], dzv = QV(Q_dz)[r];
             if ( dxv < 0.0 ) rx = fmin(rx, -QV(Q_x)[r] / dxv);
@@ -2043,7 +2120,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
             sh.red[wave][RS_RATZ] = rz;
          }
       }
-      __syncthreads();
+      S1_BAR();
       S1_STAMP(16);
       {
          int tb = 0;
@@ -2062,7 +2139,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
                [&](int i, int j, double v) S1_INL { dZ[i * p + j] = v; });
          }
       }
-      __syncthreads();
+      S1_BAR();
       S1_STAMP(17);
       for (int t = wave; t < 2 * K; t += S1_NW)
       {
@@ -2075,7 +2152,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          if ( lane == 0 )
             sh.sc[SC_LMIN0 + t] = lm;
       }
-      __syncthreads();
+      S1_BAR();
       S1_STAMP(18);
       double a = 1e300;
       for (int t = 0; t < 2 * K; ++t)
@@ -2099,15 +2176,13 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       return a;
    };
 
+   if ( tid < m1 )
+      VEC(V_cv)[tid] = (tid == 0) ? -sh.sc[SC_TAU] : VEC(V_y)[tid - 1];
+   S1_BAR();
    for (it = 0; it <= maxiter; ++it)
    {
-      /* ================= residuals */
-      {
-         const double tau = sh.sc[SC_TAU];
-         if ( tid < m1 )
-            VEC(V_cv)[tid] = (tid == 0) ? -tau : VEC(V_y)[tid - 1];
-      }
-      __syncthreads();
+      nbar = 0;
+      /* ================= residuals (V_cv = [-tau; y] comes from the start or from the update of the last iteration) */
       {
          const double* cv = VEC(V_cv);
          double xz = 0.0;
@@ -2116,12 +2191,12 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
             const S1Blk& B = sh.blk[k];
             const int p = B.p;
             double r2 = 0.0;
-            pass_AT(B, cv, [&](int r, int c, double s) S1_INL
+            pass_AT(B, cv, 0, [&](int r, int c, double s) S1_INL
             {
-               const double zv = B.Z[r * p + c];
+               const double zv = LP(B.Z)[r * p + c];
                const double v = s - zv;
-               B.Rd[r * p + c] = v;
-               B.Rd[c * p + r] = v;
+               LP(B.Rd)[r * p + c] = v;
+               LP(B.Rd)[c * p + r] = v;
                const double wgt = (r == c) ? 1.0 : 2.0;
                r2 = fma(wgt * v, v, r2);
                xz = fma(wgt * sm[B.oX + r * p + c], zv, xz);
@@ -2131,7 +2206,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
                sh.red[wave][RS_BLK0 + k] = r2;
          }
          double r2lp = 0.0, rmax = 0.0;
-         for (int r = tid; r < q; r += S1_NT)
+         for (int r = tro(128); r < q; r += S1_NT)
          {
             const double zv = QV(Q_z)[r];
             const double v = lp_row(r, cv) - zv;
@@ -2147,29 +2222,34 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
             sh.red[wave][RS_RD2LP] = r2lp;
             sh.red[wave][RS_RDMAX] = rmax;
          }
-         pass_A(false, QV(Q_x), VEC(V_AX));
-      }
-      __syncthreads();
-      if ( wave == 0 )
-      {
-         const double tau = sh.sc[SC_TAU];
-         const double ax = lane < m ? VEC(V_AX)[lane + 1] : 0.0;
-         const double bv = lane < m ? VEC(V_b)[lane] : 0.0;
-         const double rp = bv * tau - ax;
-         if ( lane < m )
-            VEC(V_rp)[lane] = rp;
-         const double rp2 = s1_wsum(lane < m ? rp * rp : 0.0);
-         const double hp2 = s1_wsum(ax * ax);
-         const double dob = s1_wsum(lane < m ? bv * VEC(V_y)[lane] : 0.0);
-         if ( lane == 0 )
+         /* A(X, x), and with it rp = b tau - A(X, x), its norm, the norm of A(X, x) and b^T y */
          {
-            sh.sc[SC_RP2] = rp2; sh.sc[SC_HP2] = hp2; sh.sc[SC_DOBJ] = dob;
+            const double tau0 = sh.sc[SC_TAU];
+            double rp2 = 0.0, hp2 = 0.0, dob = 0.0;
+            pass_A(false, QV(Q_x), VEC(V_AX), 256, [&](int i, double ax) S1_INL
+            {
+               if ( i > 0 )
+               {
+                  const double bv = VEC(V_b)[i - 1];
+                  const double rp = bv * tau0 - ax;
+                  VEC(V_rp)[i - 1] = rp;
+                  rp2 = fma(rp, rp, rp2);
+                  hp2 = fma(ax, ax, hp2);
+                  dob = fma(bv, VEC(V_y)[i - 1], dob);
+               }
+            });
+            rp2 = s1_wsum(rp2); hp2 = s1_wsum(hp2); dob = s1_wsum(dob);
+            if ( lane == 0 )
+            {
+               sh.red[wave][RS_RP2] = rp2; sh.red[wave][RS_HP2] = hp2; sh.red[wave][RS_DOB] = dob;
+            }
          }
       }
-      __syncthreads();
+      S1_BAR();
       const double tau = sh.sc[SC_TAU], kappa = sh.sc[SC_KAPPA];
+      const double hp2sum = red_sum(RS_HP2);
       pobj = s1_uni(VEC(V_AX)[0]);
-      dobj = s1_uni(sh.sc[SC_DOBJ]);
+      dobj = s1_uni(red_sum(RS_DOB));
       const double rg = pobj - dobj - kappa;
       mu = s1_uni((red_sum(RS_XZ) + tau * kappa) / N1);
       double rd2 = red_sum(RS_RD2LP);
@@ -2182,7 +2262,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          rd2 += bk;
          rdmax = fmax(rdmax, sqrt(bk));
       }
-      const double rpn = sqrt(sh.sc[SC_RP2]);
+      const double rpn = sqrt(red_sum(RS_RP2));
       pinf = s1_uni(rpn / tau / (1.0 + normb));
       const double pabs = rpn / tau;
       const bool pabsok = P.pabstol <= 0.0 || pabs <= P.pabstol;
@@ -2244,25 +2324,25 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
                const int r = s1_div(e, n), c = e - r * n;
                if ( r < c )
                   continue;
-               const int t = B.poff[e];
-               const double a0 = (t < B.poff[e + 1] && B.pvar[t] == 0) ? B.pval[t] : 0.0;
-               const double v = fma(tau, a0, B.Rd[r * p + c]);
+               const int t = LP(B.poff)[e];
+               const double a0 = (t < LP(B.poff)[e + 1] && LP(B.pvar)[t] == 0) ? LP(B.pval)[t] : 0.0;
+               const double v = fma(tau, a0, LP(B.Rd)[r * p + c]);
                h2 = fma((r == c ? 1.0 : 2.0) * v, v, h2);
             }
          }
          for (int r = tid; r < q; r += S1_NT)
          {
-            const int t = sh.roff[r];
-            const double c0 = (t < sh.roff[r + 1] && sh.rcol[t] == 0) ? sh.rval[t] : 0.0;
+            const int t = LP(sh.roff)[r];
+            const double c0 = (t < LP(sh.roff)[r + 1] && LP(sh.rcol)[t] == 0) ? LP(sh.rval)[t] : 0.0;
             const double v = fma(tau, c0, QV(Q_rd)[r]);
             h2 = fma(v, v, h2);
          }
          h2 = s1_wsum(h2);
          if ( lane == 0 )
             sh.red[wave][RS_HD2] = h2;
-         __syncthreads();
+         S1_BAR();
          const double hd = sqrt(red_sum(RS_HD2));
-         const double hp = sqrt(sh.sc[SC_HP2]);
+         const double hp = sqrt(hp2sum);
          const double big = fmax(fabs(dobj), fabs(pobj));
          const bool cand_dunb = dobj < -1e-3 * big;
          const bool cand_dinf = pobj > 1e-3 * big;
@@ -2313,7 +2393,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          over = __builtin_amdgcn_readfirstlane(over);
          if ( tid == 0 )
             sh.fl[5] = over;
-         __syncthreads();
+         S1_BAR();
          if ( sh.fl[5] )
          {
             status = HS_S1_TIMELIM;
@@ -2342,7 +2422,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
             if ( B.n > S1U_MAXN )
                s1_trinv(Lp, Lp, B.n, B.p, lane);
          }
-         __syncthreads();
+         S1_BAR();
       }
       S1_STAMP(3);
       {
@@ -2358,7 +2438,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
                [&](int i, int j, double v) S1_INL { Zi[i * p + j] = v; });
          }
       }
-      __syncthreads();
+      S1_BAR();
       S1_STAMP(4);
 
       /* ================= Schur complement from the nonzeros: U_j = X A_j Zinv (G of them side by side), Mx[i][j] += <A_i, U_j> */
@@ -2388,24 +2468,24 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
             double* U = T + B.np;
             for (int h0 = 0; h0 < nh; h0 += G2)
             {
-               const int j = (h0 + g < nh) ? (int) B.hv[h0 + g] : -1;
+               const int j = (h0 + g < nh) ? (int) LP(B.hv)[h0 + g] : -1;
                if ( j >= 0 )
                {
                   /* T = A_j Zinv: thread c owns column c and walks the entries in row-major order */
-                  const int t0 = B.voff[j], t1 = B.voff[j + 1];
+                  const int t0 = LP(B.voff)[j], t1 = LP(B.voff)[j + 1];
                   for (int c = tig; c < n; c += gsz)
                   {
                      for (int r = 0; r < n; ++r)
                         T[r * p + c] = 0.0;
                      for (int t = t0; t < t1; ++t)
                      {
-                        const unsigned pq = B.vpq[t];
+                        const unsigned pq = LP(B.vpq)[t];
                         const int pp = (int) (pq >> 16), qq = (int) (pq & 0xffffu);
-                        T[pp * p + c] = fma(B.vval[t], Zi[qq * p + c], T[pp * p + c]);
+                        T[pp * p + c] = fma(LP(B.vval)[t], Zi[qq * p + c], T[pp * p + c]);
                      }
                   }
                }
-               __syncthreads();
+               S1_BAR();
                if ( j >= 0 )
                   for (int e = tig; e < n2; e += gsz)
                   {
@@ -2415,23 +2495,23 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
                         s0 = fma(X[r * p + kk], T[kk * p + c], s0);
                      U[r * p + c] = s0;
                   }
-               __syncthreads();
+               S1_BAR();
                if ( j >= 0 )
                   for (int i = tig; i < m1; i += gsz)
                   {
-                     const int t0 = B.voff[i], t1 = B.voff[i + 1];
+                     const int t0 = LP(B.voff)[i], t1 = LP(B.voff)[i + 1];
                      if ( t1 == t0 || (t1 - t0 > S1_LIGHT_MAX && i < j) )
                         continue;
                      double s0 = 0.0;
                      for (int t = t0; t < t1; ++t)
                      {
-                        const unsigned pq = B.vpq[t];
+                        const unsigned pq = LP(B.vpq)[t];
                         const int pp = (int) (pq >> 16), qq = (int) (pq & 0xffffu);
-                        s0 = fma(B.vval[t], U[qq * p + pp], s0);
+                        s0 = fma(LP(B.vval)[t], U[qq * p + pp], s0);
                      }
                      Mx[(i >= j) ? i * pm1 + j : j * pm1 + i] += s0;
                   }
-               __syncthreads();
+               S1_BAR();
             }
          }
       }
@@ -2445,15 +2525,15 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          for (int idx = tid; idx < nrs * n; idx += S1_NT)
          {
             const int sl = s1_div(idx, n), c = idx - sl * n;
-            const int packed = B.lre[sl];
+            const int packed = LP(B.lre)[sl];
             const int e0 = packed >> 6, len = packed & 63;
             double tacc = 0.0;
             for (int e = e0; e < e0 + len; ++e)
-               tacc = fma(B.vval[e], Zi[(int) (B.vpq[e] & 0xffffu) * p + c], tacc);
-            B.Tc[idx] = tacc;
+               tacc = fma(LP(B.vval)[e], Zi[(int) (LP(B.vpq)[e] & 0xffffu) * p + c], tacc);
+            LP(B.Tc)[idx] = tacc;
          }
       }
-      __syncthreads();
+      S1_BAR();
       /* ... (b) a thread per pair i >= j: M_ij = sum over the entries (a, b) of A_i of A_i[a][b] (X T_j)[b][a], the product with X
        * over the non-empty rows of T_j only */
       for (int k = 0; k < K; ++k)
@@ -2462,28 +2542,66 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          const int n = B.n, p = B.p;
          const double* X = sm + B.oX;
          const int nl = B.nl;
-         for (int t = tid; t < nl * nl; t += S1_NT)
+         const int npair = (nl * (nl + 1)) >> 1;
+         for (int t = tid; t < npair; t += S1_NT)
          {
-            const int ia = s1_div(t, nl), ib = t - ia * nl;
-            if ( ib > ia )
-               continue;
-            const int i = B.lv[ia], j = B.lv[ib];
-            const int e0 = B.voff[i], e1 = B.voff[i + 1];
-            const int s0i = B.lro[ib], s1i = B.lro[ib + 1];
+            /* pair number t -> (ia, ib), ib <= ia: ia = floor((sqrt(8 t + 1) - 1) / 2), corrected for the rounding of the root */
+            int ia = (int) ((sqrtf(8.0f * (float) t + 1.0f) - 1.0f) * 0.5f);
+            if ( ((ia + 1) * (ia + 2)) >> 1 <= t ) ++ia;
+            if ( (ia * (ia + 1)) >> 1 > t ) --ia;
+            const int ib = t - ((ia * (ia + 1)) >> 1);
+            const int i = LP(B.lv)[ia], j = LP(B.lv)[ib];
+            const int e0 = LP(B.voff)[i], e1 = LP(B.voff)[i + 1];
+            const int s0i = LP(B.lro)[ib], ns = LP(B.lro)[ib + 1] - s0i;
             double acc = 0.0;
-            for (int e = e0; e < e1; ++e)
+            if ( ns <= 4 )
             {
-               const unsigned ab = B.vpq[e];
-               const int aa_ = (int) (ab >> 16), bb_ = (int) (ab & 0xffffu);
-               double u = 0.0;
-               for (int sl = s0i; sl < s1i; ++sl)
-                  u = fma(X[bb_ * p + (int) B.lrp[sl]], B.Tc[sl * n + aa_], u);
-               acc = fma(B.vval[e], u, acc);
+               /* the usual case, at most four non-empty rows in A_j: their row numbers and the rows of T_j fixed before the loop
+                * over the entries of A_i, so that the eight loads of an entry are independent of each other (slots past ns read
+                * slot 0 with a zero factor: u + 0 x = u exactly); same operations in the same order as the general loop */
+               const int r0 = (int) LP(B.lrp)[s0i];
+               const int r1 = (ns > 1) ? (int) LP(B.lrp)[s0i + 1] : r0;
+               const int r2 = (ns > 2) ? (int) LP(B.lrp)[s0i + 2] : r0;
+               const int r3 = (ns > 3) ? (int) LP(B.lrp)[s0i + 3] : r0;
+               auto T0 = LP(B.Tc) + s0i * n;
+               auto T1 = (ns > 1) ? T0 + n : T0;
+               auto T2 = (ns > 2) ? T0 + 2 * n : T0;
+               auto T3 = (ns > 3) ? T0 + 3 * n : T0;
+               /* (position and value of the next entry are requested before this one's eight loads: one round trip per entry) */
+               unsigned abn = (e0 < e1) ? LP(B.vpq)[e0] : 0u;
+               double vn = (e0 < e1) ? LP(B.vval)[e0] : 0.0;
+               for (int e = e0; e < e1; ++e)
+               {
+                  const unsigned ab = abn;
+                  const double ve = vn;
+                  const int en = (e + 1 < e1) ? e + 1 : e;
+                  abn = LP(B.vpq)[en];
+                  vn = LP(B.vval)[en];
+                  const int aa_ = (int) (ab >> 16), bb_ = (int) (ab & 0xffffu);
+                  const double* xr = X + bb_ * p;
+                  const double x0 = xr[r0], x1 = (ns > 1) ? xr[r1] : 0.0, x2 = (ns > 2) ? xr[r2] : 0.0, x3 = (ns > 3) ? xr[r3] : 0.0;
+                  const double t0 = T0[aa_], t1 = T1[aa_], t2 = T2[aa_], t3 = T3[aa_];
+                  double u = fma(x0, t0, 0.0);
+                  u = fma(x1, t1, u);
+                  u = fma(x2, t2, u);
+                  u = fma(x3, t3, u);
+                  acc = fma(ve, u, acc);
+               }
             }
+            else
+               for (int e = e0; e < e1; ++e)
+               {
+                  const unsigned ab = LP(B.vpq)[e];
+                  const int aa_ = (int) (ab >> 16), bb_ = (int) (ab & 0xffffu);
+                  double u = 0.0;
+                  for (int sl = s0i; sl < s0i + ns; ++sl)
+                     u = fma(X[bb_ * p + (int) LP(B.lrp)[sl]], LP(B.Tc)[sl * n + aa_], u);
+                  acc = fma(LP(B.vval)[e], u, acc);
+               }
             Mx[i * pm1 + j] += acc;
          }
       }
-      __syncthreads();
+      S1_BAR();
       S1_STAMP(5);
 
       /* ================= factorization of M and the two solves (wavefront 0) beside the first product of the predictor,
@@ -2513,12 +2631,17 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          if ( P.prof_on && lane == 0 ) { const long long tq1 = clock64(); sh.prof[20] += (double) (tq1 - tq0); tq0 = tq1; }
          msolve2(VEC(V_g), VEC(V_b), VEC(V_w), VEC(V_ub));
          if ( P.prof_on && lane == 0 ) { const long long tq1 = clock64(); sh.prof[21] += (double) (tq1 - tq0); }
+         bool u2bad = false;
          if ( lane < m )
          {
             const double w = VEC(V_w)[lane], ub = VEC(V_ub)[lane];
             VEC(V_u2)[lane] = ub - w;
             VEC(V_wt)[lane + 1] = -w;
+            u2bad = !(fabs(ub - w) < 1e300);
          }
+         const unsigned long long anybad = __ballot(u2bad);
+         if ( lane == 0 )
+            sh.fl[7] = (anybad != 0ULL) ? 1 : 0;
          const double bub = s1_wsum(lane < m ? VEC(V_b)[lane] * VEC(V_ub)[lane] : 0.0);
          if ( lane == 0 )
          {
@@ -2534,26 +2657,21 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
             const S1Blk& B = sh.blk[k];
             const int p = B.p;
             const double* X = sm + B.oX;
-            const double* Rd = B.Rd;
+            auto Rd = LP(B.Rd);
             double* T1 = sm + B.oT1;
             s1_mm(B.n, wave, lane, w0, nw, tb,
                [&](int i, int kk) S1_INL { return X[i * p + kk]; }, [&](int kk, int j) S1_INL { return Rd[kk * p + j]; },
                [&](int i, int j, double v) S1_INL { T1[i * p + j] = v; });
          }
       }
-      __syncthreads();
+      S1_BAR();
       S1_STAMP(6);
+      if ( sh.fl[7] )
       {
-         double u2bad = 0.0;
-         if ( tid < m && !(fabs(VEC(V_u2)[tid]) < 1e300) )
-            u2bad = 1.0;
-         if ( __syncthreads_or(u2bad != 0.0) )
-         {
-            status = HS_S1_NUMERIC;
-            break;
-         }
+         status = HS_S1_NUMERIC;
+         break;
       }
-      /* B_k = A_0 - sum w_i A_i, beta = c - D w; T2 = T1 Zinv */
+      /* B_k = A_0 - sum w_i A_i, beta = c - D w; H of the predictor = -X - sym(X Rd Zinv) -> dX, hl */
       sigma = 0.0; eta = 1.0;
       {
          const double* wt = VEC(V_wt);
@@ -2561,72 +2679,47 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          {
             const S1Blk& B = sh.blk[k];
             const int p = B.p;
-            pass_AT(B, wt, [&](int r, int c, double s) S1_INL
+            pass_AT(B, wt, 256, [&](int r, int c, double s) S1_INL
             {
-               B.B[r * p + c] = s;
-               B.B[c * p + r] = s;
+               LP(B.B)[r * p + c] = s;
+               LP(B.B)[c * p + r] = s;
             });
          }
-         for (int r = tid; r < q; r += S1_NT)
+         for (int r = tro(128); r < q; r += S1_NT)
             QV(Q_beta)[r] = lp_row(r, wt);
-         int tb = 0;
-         for (int k = 0; k < K; ++k)
-         {
-            const S1Blk& B = sh.blk[k];
-            const int p = B.p;
-            const double* T1 = sm + B.oT1; const double* Zi = sm + B.oZi;
-            double* T2 = sm + B.oT2;
-            s1_mm(B.n, wave, lane, 0, S1_NW, tb,
-               [&](int i, int kk) S1_INL { return T1[i * p + kk]; }, [&](int kk, int j) S1_INL { return Zi[kk * p + j]; },
-               [&](int i, int j, double v) S1_INL { T2[i * p + j] = v; });
-         }
-      }
-      __syncthreads();
-      /* H of the predictor -> dX, hl; T1 = X B */
-      {
          dir_matrix(0.0, 1.0, QV(Q_rd), false, QV(Q_hl));
-         int tb = 0;
-         for (int k = 0; k < K; ++k)
-         {
-            const S1Blk& B = sh.blk[k];
-            const int p = B.p;
-            const double* X = sm + B.oX; const double* Bm = B.B;
-            double* T1 = sm + B.oT1;
-            s1_mm(B.n, wave, lane, 0, S1_NW, tb,
-               [&](int i, int kk) S1_INL { return X[i * p + kk]; }, [&](int kk, int j) S1_INL { return Bm[kk * p + j]; },
-               [&](int i, int j, double v) S1_INL { T1[i * p + j] = v; });
-         }
       }
-      __syncthreads();
-      /* A(H), <B, H>; T2 = T1 Zinv */
+      S1_BAR();
+      /* A(H), <B, H>; T1 = X B */
       {
-         pass_A(true, QV(Q_hl), VEC(V_AH));
+         pass_A(true, QV(Q_hl), VEC(V_AH), 128, no_epi);
          bh_partials();
          int tb = 0;
          for (int k = 0; k < K; ++k)
          {
             const S1Blk& B = sh.blk[k];
             const int p = B.p;
-            const double* T1 = sm + B.oT1; const double* Zi = sm + B.oZi;
-            double* T2 = sm + B.oT2;
+            const double* X = sm + B.oX; auto Bm = LP(B.B);
+            double* T1 = sm + B.oT1;
             s1_mm(B.n, wave, lane, 0, S1_NW, tb,
-               [&](int i, int kk) S1_INL { return T1[i * p + kk]; }, [&](int kk, int j) S1_INL { return Zi[kk * p + j]; },
-               [&](int i, int j, double v) S1_INL { T2[i * p + j] = v; });
+               [&](int i, int kk) S1_INL { return X[i * p + kk]; }, [&](int kk, int j) S1_INL { return Bm[kk * p + j]; },
+               [&](int i, int j, double v) S1_INL { T1[i * p + j] = v; });
          }
       }
-      __syncthreads();
-      /* S0 = sum <B, X B Zinv> + sum (x / z) beta^2 (factored form: a sum of non-negative terms) */
+      S1_BAR();
+      /* S0 = sum <B, X B Zinv> + sum (x / z) beta^2 (factored form: a sum of non-negative terms): the entries of X B Zinv are summed
+       * up as the product's epilogue delivers them */
       {
          double s = 0.0;
+         int tb = 0;
          for (int k = 0; k < K; ++k)
          {
             const S1Blk& B = sh.blk[k];
-            const int n = B.n, p = B.p;
-            for (int e = tid; e < n * n; e += S1_NT)
-            {
-               const int r = s1_div(e, n), c = e - r * n;
-               s = fma(B.B[r * p + c], sm[B.oT2 + r * p + c], s);
-            }
+            const int p = B.p;
+            const double* T1 = sm + B.oT1; const double* Zi = sm + B.oZi; auto Bm = LP(B.B);
+            s1_mm(B.n, wave, lane, 0, S1_NW, tb,
+               [&](int i, int kk) S1_INL { return T1[i * p + kk]; }, [&](int kk, int j) S1_INL { return Zi[kk * p + j]; },
+               [&](int i, int j, double v) S1_INL { s = fma(Bm[i * p + j], v, s); });
          }
          for (int r = tid; r < q; r += S1_NT)
          {
@@ -2637,10 +2730,10 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          if ( lane == 0 )
             sh.red[wave][RS_S0] = s;
       }
-      __syncthreads();
+      S1_BAR();
       if ( wave == 0 )
          finish_dir(0.0, 0.0, rg);
-      __syncthreads();
+      S1_BAR();
       S1_STAMP(7);
       const double dta = sh.sc[SC_DTAU], dka = sh.sc[SC_DKAPPA];
       if ( !(fabs(dta) < 1e300) || !(fabs(dka) < 1e300) )
@@ -2649,7 +2742,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          break;
       }
       make_dZ();
-      __syncthreads();
+      S1_BAR();
       S1_STAMP(12);
       {
          int tb = 0;
@@ -2664,25 +2757,10 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
                [&](int i, int j, double v) S1_INL { T1[i * p + j] = v; });
          }
       }
-      __syncthreads();
+      S1_BAR();
       S1_STAMP(13);
-      {
-         int tb = 0;
-         for (int k = 0; k < K; ++k)
-         {
-            const S1Blk& B = sh.blk[k];
-            const int p = B.p;
-            const double* T1 = sm + B.oT1; const double* Zi = sm + B.oZi;
-            double* T2 = sm + B.oT2;
-            s1_mm(B.n, wave, lane, 0, S1_NW, tb,
-               [&](int i, int kk) S1_INL { return T1[i * p + kk]; }, [&](int kk, int j) S1_INL { return Zi[kk * p + j]; },
-               [&](int i, int j, double v) S1_INL { T2[i * p + j] = v; });
-         }
-      }
-      __syncthreads();
-      S1_STAMP(14);
       dir_matrix(0.0, 1.0, QV(Q_dz), false, QV(Q_dx));          /* dXa, dxa */
-      __syncthreads();
+      S1_BAR();
       S1_STAMP(15);
       /* second-order terms E = dXa dZa, elp = dxa dza; then the predictor's step length */
       {
@@ -2692,12 +2770,12 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
             const S1Blk& B = sh.blk[k];
             const int p = B.p;
             const double* dX = sm + B.odX; const double* dZ = sm + B.odZ;
-            double* E = B.E;
+            auto E = LP(B.E);
             s1_mm(B.n, wave, lane, 0, S1_NW, tb,
                [&](int i, int kk) S1_INL { return dX[i * p + kk]; }, [&](int kk, int j) S1_INL { return dZ[kk * p + j]; },
                [&](int i, int j, double v) S1_INL { E[i * p + j] = v; });
          }
-         for (int r = tid; r < q; r += S1_NT)
+         for (int r = tro(64); r < q; r += S1_NT)
             QV(Q_elp)[r] = QV(Q_dx)[r] * QV(Q_dz)[r];
       }
       const double aa = fmin(1.0, steplen(false));
@@ -2720,7 +2798,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          {
             const S1Blk& B = sh.blk[k];
             const int p = B.p;
-            const double* X = sm + B.oX; const double* Rd = B.Rd; const double* E = B.E;
+            const double* X = sm + B.oX; auto Rd = LP(B.Rd); auto E = LP(B.E);
             double* T1 = sm + B.oT1;
             const double et = eta;
             s1_mm(B.n, wave, lane, 0, S1_NW, tb,
@@ -2728,29 +2806,15 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
                [&](int i, int j, double v) S1_INL { T1[i * p + j] = fma(et, v, E[i * p + j]); });
          }
       }
-      __syncthreads();
-      {
-         int tb = 0;
-         for (int k = 0; k < K; ++k)
-         {
-            const S1Blk& B = sh.blk[k];
-            const int p = B.p;
-            const double* T1 = sm + B.oT1; const double* Zi = sm + B.oZi;
-            double* T2 = sm + B.oT2;
-            s1_mm(B.n, wave, lane, 0, S1_NW, tb,
-               [&](int i, int kk) S1_INL { return T1[i * p + kk]; }, [&](int kk, int j) S1_INL { return Zi[kk * p + j]; },
-               [&](int i, int j, double v) S1_INL { T2[i * p + j] = v; });
-         }
-      }
-      __syncthreads();
+      S1_BAR();
       dir_matrix(sigmu, eta, QV(Q_rd), true, QV(Q_hl));
-      __syncthreads();
-      pass_A(true, QV(Q_hl), VEC(V_AH));
+      S1_BAR();
+      pass_A(true, QV(Q_hl), VEC(V_AH), 128, no_epi);
       bh_partials();
-      __syncthreads();
+      S1_BAR();
       if ( wave == 0 )
          finish_dir(sigmu, etk, rg);
-      __syncthreads();
+      S1_BAR();
       S1_STAMP(9);
       const double dt = sh.sc[SC_DTAU], dk = sh.sc[SC_DKAPPA];
       if ( !(fabs(dt) < 1e300) || !(fabs(dk) < 1e300) )
@@ -2759,42 +2823,28 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          break;
       }
       make_dZ();
-      __syncthreads();
+      S1_BAR();
       {
          int tb = 0;
          for (int k = 0; k < K; ++k)
          {
             const S1Blk& B = sh.blk[k];
             const int p = B.p;
-            const double* X = sm + B.oX; const double* dZ = sm + B.odZ; const double* E = B.E;
+            const double* X = sm + B.oX; const double* dZ = sm + B.odZ; auto E = LP(B.E);
             double* T1 = sm + B.oT1;
             s1_mm(B.n, wave, lane, 0, S1_NW, tb,
                [&](int i, int kk) S1_INL { return X[i * p + kk]; }, [&](int kk, int j) S1_INL { return dZ[kk * p + j]; },
                [&](int i, int j, double v) S1_INL { T1[i * p + j] = v + E[i * p + j]; });
          }
       }
-      __syncthreads();
-      {
-         int tb = 0;
-         for (int k = 0; k < K; ++k)
-         {
-            const S1Blk& B = sh.blk[k];
-            const int p = B.p;
-            const double* T1 = sm + B.oT1; const double* Zi = sm + B.oZi;
-            double* T2 = sm + B.oT2;
-            s1_mm(B.n, wave, lane, 0, S1_NW, tb,
-               [&](int i, int kk) S1_INL { return T1[i * p + kk]; }, [&](int kk, int j) S1_INL { return Zi[kk * p + j]; },
-               [&](int i, int j, double v) S1_INL { T2[i * p + j] = v; });
-         }
-      }
-      __syncthreads();
+      S1_BAR();
       dir_matrix(sigmu, 1.0, QV(Q_dz), true, QV(Q_dx));
-      __syncthreads();
+      S1_BAR();
       if ( P.hist != NULL )
       {
          /* diagnostic: how well the direction satisfies the linearised primal equation A(dX, dx) = eta rp + b dtau */
-         pass_A(true, QV(Q_dx), VEC(V_t1));
-         __syncthreads();
+         pass_A(true, QV(Q_dx), VEC(V_t1), 0, no_epi);
+         S1_BAR();
          if ( wave == 0 )
          {
             const double e = (lane < m) ? VEC(V_t1)[lane + 1] - eta * VEC(V_rp)[lane] - VEC(V_b)[lane] * dt : 0.0;
@@ -2815,7 +2865,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
                hh[12] = sqrt(e2); hh[13] = (double) sh.fl[6]; hh[14] = sqrt(dy2); hh[15] = sqrt(h2);
             }
          }
-         __syncthreads();
+         S1_BAR();
       }
       const double amax = steplen(true);
       S1_STAMP(10);
@@ -2857,26 +2907,33 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          for (int e = tid; e < n * n; e += S1_NT)
          {
             const int r = s1_div(e, n), c = e - r * n;
-            sm[B.oX + r * p + c] = fma(alpha, B.E[r * p + c], sm[B.oX + r * p + c]);
-            B.Z[r * p + c] = fma(alpha, B.B[r * p + c], B.Z[r * p + c]);
+            sm[B.oX + r * p + c] = fma(alpha, LP(B.E)[r * p + c], sm[B.oX + r * p + c]);
+            LP(B.Z)[r * p + c] = fma(alpha, LP(B.B)[r * p + c], LP(B.Z)[r * p + c]);
          }
       }
-      if ( tid < m )
-         VEC(V_y)[tid] = fma(alpha, VEC(V_dy)[tid], VEC(V_y)[tid]);
-      for (int r = tid; r < q; r += S1_NT)
       {
-         QV(Q_x)[r] = fma(alpha, QV(Q_dx)[r], QV(Q_x)[r]);
-         QV(Q_z)[r] = fma(alpha, QV(Q_dz)[r], QV(Q_z)[r]);
-      }
-      __syncthreads();
-      if ( tid == 0 )
-      {
-         sh.sc[SC_TAU] = tau + alpha * dt;
-         sh.sc[SC_KAPPA] = kappa + alpha * dk;
+         const double taun = tau + alpha * dt;
+         if ( tid < m )
+         {
+            const double yn = fma(alpha, VEC(V_dy)[tid], VEC(V_y)[tid]);
+            VEC(V_y)[tid] = yn;
+            VEC(V_cv)[tid + 1] = yn;
+         }
+         for (int r = tro(256); r < q; r += S1_NT)
+         {
+            QV(Q_x)[r] = fma(alpha, QV(Q_dx)[r], QV(Q_x)[r]);
+            QV(Q_z)[r] = fma(alpha, QV(Q_dz)[r], QV(Q_z)[r]);
+         }
+         if ( tid == 0 )
+         {
+            VEC(V_cv)[0] = -taun;
+            sh.sc[SC_TAU] = taun;
+            sh.sc[SC_KAPPA] = kappa + alpha * dk;
+         }
       }
       factors_valid = true;
       alpha_last = s1_uni(alpha);
-      __syncthreads();
+      S1_BAR();
       S1_STAMP(11);
    }
 
@@ -2896,7 +2953,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       {
          const int r = s1_div(e, n), c = e - r * n;
          P.X[k][e] = sm[B.oX + r * p + c];
-         P.Z[k][e] = B.Z[r * p + c];
+         P.Z[k][e] = LP(B.Z)[r * p + c];
       }
    }
    __threadfence_system();
@@ -2917,6 +2974,11 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       if ( P.flag != NULL )
          __hip_atomic_store(P.flag, P.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
    }
+   };
+   if ( sh.fl[30] )
+      body(std::true_type{});
+   else
+      body(std::false_type{});
 }
 
 }

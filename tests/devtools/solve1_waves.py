@@ -1,0 +1,37 @@
+"""developer script: which wavefront each phase of the one-launch solve waits for.  HIPSDP_SOLVE1_PROF=2 makes every wavefront note
+the clock when it reaches each barrier of iteration 3; printed per barrier: the time from the previous barrier's release to the
+arrival of each of the eight wavefronts (cycles).
+usage: python tests/devtools/solve1_waves.py [instance]"""
+import sys, os, importlib.util
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests', 'harness'), os.path.join(ROOT, 'tests')]
+os.environ["HIPSDP_SOLVE1_HIST"] = "1"
+os.environ["HIPSDP_SOLVE1_PROF"] = "2"
+import numpy as np
+spec = importlib.util.spec_from_file_location('hipsdp_binding', os.path.join(ROOT, 'scip-sdp_amd', 'binding.py'))
+hb = importlib.util.module_from_spec(spec); spec.loader.exec_module(hb)
+import ipm_ref, sdpa_io
+
+name = sys.argv[1] if len(sys.argv) > 1 else "example_TT.dat-s.gz"
+inst = sdpa_io.read_sdpa(os.path.join(ROOT, 'tests', 'golden', 'instances', name))
+D, c = sdpa_io.lp_dense(inst)
+core = ipm_ref.CoreProblem(inst.obj, sdpa_io.dense_blocks(inst), D, c)
+s = hb.Solver(0)
+s.load_core(core)
+info = s.solve(gaptol=1e-6, feastol=1e-6, pabstol=1e-5)
+assert s.solve_path() == 1
+out, hist = s.solve1_trace(256)
+s.close()
+st = hist.reshape(-1)[2048:2048 + 480].reshape(60, 8)
+prev = None
+tot = 0.0
+print("barrier  wait-for  " + " ".join("w%d" % w for w in range(8)))
+for b in range(60):
+    if st[b].max() == 0:
+        break
+    if prev is not None:
+        d = st[b] - prev
+        print("%3d  %7.0f   %s" % (b, d.max(), " ".join("%6.0f" % v for v in d)))
+        tot += d.max()
+    prev = st[b].max()
+print("sum of the phases of iteration 3: %.0f cycles; %d iterations" % (tot, info.iterations))
