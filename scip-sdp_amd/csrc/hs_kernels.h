@@ -256,6 +256,7 @@ struct hs_solve1_args
    double* Xpre[HS_S1_MAXBLK];             /* preoptimal iterate (preoptgap > 0) */
    const double* b; const double* Dext;
    double *y, *x, *z, *pre_y, *pre_x;
+   double *hy, *hx, *hz;               /* optional: y, x, z once more into pinned host memory (the caller's read-backs of a node need no copy) */
    double gaptol, feastol, infeastol, objlimit, timelimit, gamma, pabstol, preoptgap;
    double elapsed0;                        /* seconds of the time limit already used when the kernel starts */
    double maxwork;                         /* decline above this many multiply-adds per Schur assembly */

@@ -177,6 +177,14 @@ struct hipsdp_solver
    long long s1_ws_len;
    double* s1_host;        /* pinned, device-visible: HS_S1_OUT_DOUBLES result scalars, then the sequence word, then the history */
    double* s1_host_dev;
+   bool s1_sol_host;       /* y, x, z of the last solve are in s1_host too (offset S1_SOL_OFF): hipsdp_get_y / get_lp copy from there */
+   bool zero_b, zero_D;    /* set_shape (same shape again) owes b / Dext their zeros: paid by set_obj / set_lp overwriting them, or before the next use */
+   /* staging arena of the small uploads of a node (objective, LP rows, gather indices, triplets of the constant matrices, start
+    * point): pinned, device-visible; a setter copies its data there and queues an asynchronous copy or a kernel that reads the
+    * arena directly - nothing waits.  stage_pending: something queued on `stream` has not been waited for yet (every entry point
+    * that touches device data outside that queue calls stage_sync first).  The offset returns to 0 when the queue has drained
+    * (set_shape, end of a solve). */
+   char* arena_h; char* arena_d; size_t arena_cap, stage_off; bool stage_pending;
    unsigned long long s1_seq;
    int s1_last;            /* 1: the last solve ran in the single launch */
    /* pinned / device staging chunks of hipsdp_master_add_vars (kept until hipsdp_free) */
@@ -296,6 +304,79 @@ static int dalloc(T** p, long long count)
 
 static void dfree(void* p) { hs_pool_free(p); }
 
+#define STAGE_BYTES (2u << 20)
+/* room for `bytes` in the staging arena: host address (NULL: does not fit - the caller takes its blocking path), *dev = the same
+ * bytes as the device sees them */
+static void* stage_take(hipsdp_solver* s, size_t bytes, void** dev)
+{
+   if ( getenv("HIPSDP_NO_STAGING") != NULL )
+      return NULL;
+   if ( s->arena_h == NULL )
+   {
+      void* h = NULL; void* d = NULL;
+      if ( hipHostMalloc(&h, STAGE_BYTES, hipHostMallocMapped) != hipSuccess )
+         return NULL;
+      if ( hipHostGetDevicePointer(&d, h, 0) != hipSuccess )
+      {
+         (void) hipHostFree(h);
+         return NULL;
+      }
+      s->arena_h = (char*) h; s->arena_d = (char*) d; s->arena_cap = STAGE_BYTES; s->stage_off = 0;
+   }
+   const size_t off = (s->stage_off + 63) & ~(size_t) 63;
+   if ( off + bytes > s->arena_cap )
+      return NULL;
+   s->stage_off = off + bytes;
+   if ( dev != NULL )
+      *dev = s->arena_d + off;
+   return s->arena_h + off;
+}
+/* host -> device of a small array through the arena, queued on the solver's stream; falls back to a blocking copy */
+static int stage_upload(hipsdp_solver* s, void* dst, const void* src, size_t bytes)
+{
+   if ( bytes == 0 )
+      return HIPSDP_OK;
+   void* h = stage_take(s, bytes, NULL);
+   if ( h == NULL )
+   {
+      HS_HIP( hipStreamSynchronize(s->stream) );
+      HS_HIP( hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) );
+      return HIPSDP_OK;
+   }
+   memcpy(h, src, bytes);
+   HS_HIP( hipMemcpyAsync(dst, h, bytes, hipMemcpyHostToDevice, s->stream) );
+   s->stage_pending = true;
+   return HIPSDP_OK;
+}
+/* before anything outside the solver's stream touches device data: wait for what the setters queued */
+static int flush_zeros(hipsdp_solver* s)
+{
+   if ( s->zero_b )
+   {
+      HS_HIP( hipMemsetAsync(s->b, 0, (size_t) (s->m > 0 ? s->m : 1) * sizeof(double), s->stream) );
+      s->zero_b = false; s->stage_pending = true;
+   }
+   if ( s->zero_D )
+   {
+      const long long cnt = (long long) s->q * (s->m + 1);
+      HS_HIP( hipMemsetAsync(s->Dext, 0, (size_t) (cnt > 0 ? cnt : 1) * sizeof(double), s->stream) );
+      s->zero_D = false; s->stage_pending = true;
+   }
+   return HIPSDP_OK;
+}
+static int stage_sync(hipsdp_solver* s)
+{
+   if ( s != NULL && (s->zero_b || s->zero_D) )
+      HS_CALL( flush_zeros(s) );
+   if ( s != NULL && s->stage_pending )
+   {
+      HS_HIP( hipStreamSynchronize(s->stream) );
+      s->stage_pending = false;
+      s->stage_off = 0;
+   }
+   return HIPSDP_OK;
+}
+
 static void free_sparse(Block& B)
 {
    if ( B.sp != NULL ) hs_sp_free(B.sp);
@@ -385,7 +466,8 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
    }
    s->hsc_cap = 0;
    s->clk_on = false; s->clk_buf = NULL; s->clk_n = 0; s->clk_ghz = 0.0;
-   s->s1_ws = NULL; s->s1_ws_len = 0; s->s1_host = NULL; s->s1_host_dev = NULL; s->s1_seq = 0; s->s1_last = 0;
+   s->s1_ws = NULL; s->s1_ws_len = 0; s->s1_host = NULL; s->s1_host_dev = NULL; s->s1_seq = 0; s->s1_last = 0; s->s1_sol_host = false; s->zero_b = false; s->zero_D = false;
+   s->arena_h = NULL; s->arena_d = NULL; s->arena_cap = 0; s->stage_off = 0; s->stage_pending = false;
    s->trsv_ws = NULL;
    s->pre_y = s->pre_x = NULL;
    s->pre_valid = false;
@@ -447,6 +529,8 @@ extern "C" void hipsdp_free(hipsdp_solver** ps)
    s->hsc = NULL;
    if ( s->s1_host != NULL ) (void) hipHostFree(s->s1_host);
    s->s1_host = NULL;
+   if ( s->arena_h != NULL ) (void) hipHostFree(s->arena_h);
+   s->arena_h = NULL; s->arena_d = NULL; s->arena_cap = 0;
    if ( s->s1_ws != NULL ) (void) hipFree(s->s1_ws);
    s->s1_ws = NULL;
    if ( s->clk_buf != NULL ) (void) hipFree(s->clk_buf);
@@ -532,6 +616,8 @@ extern "C" int hipsdp_set_shape2(hipsdp_solver* s, int m, int nblocks, const int
       return HIPSDP_ERR_ARG;
    HS_HIP( hipSetDevice(s->device) );
    HS_HIP( hipStreamSynchronize(s->stream) );
+   s->stage_pending = false; s->stage_off = 0;
+   s->zero_b = false; s->zero_D = false; s->s1_sol_host = false;
    /* The same shape again (the next node of a tree with the same fixings pattern, a re-load of the same problem): every
     * allocation is kept - the constraint matrices (GBs at the bench sizes), their packed copy and the Schur workspace cost tens
     * of milliseconds to free and allocate again - and only the contents are reset to what a fresh shape has. */
@@ -559,9 +645,9 @@ extern "C" int hipsdp_set_shape2(hipsdp_solver* s, int m, int nblocks, const int
             B.apk_valid = false;
             B.derived_valid = false;
          }
-         HS_HIP( hipMemsetAsync(s->Dext, 0, (size_t) ((long long) q * m1s > 0 ? (long long) q * m1s : 1) * sizeof(double), s->stream) );
-         HS_HIP( hipMemsetAsync(s->b, 0, (size_t) (m > 0 ? m : 1) * sizeof(double), s->stream) );
-         HS_HIP( hipStreamSynchronize(s->stream) );
+         /* (b and Dext are cleared when they are next used - unless set_obj / set_lp, which replace them whole, come first) */
+         s->zero_b = true; s->zero_D = true;
+         s->stage_pending = true;                 /* (no wait here: what follows is queued behind the clears) */
          s->have_start = false;
          s->solved = false;
          s->pre_valid = false;
@@ -727,7 +813,8 @@ extern "C" int hipsdp_set_obj(hipsdp_solver* s, const double* b)
    if ( s == NULL || !s->shaped ) return HIPSDP_ERR_ARG;
    HS_HIP( hipSetDevice(s->device) );
    if ( s->m > 0 )
-      HS_HIP( hipMemcpy(s->b, b, (size_t) s->m * sizeof(double), hipMemcpyHostToDevice) );
+      HS_CALL( stage_upload(s, s->b, b, (size_t) s->m * sizeof(double)) );
+   s->zero_b = false;
    s->solved = false;
    return HIPSDP_OK;
 }
@@ -805,6 +892,40 @@ extern "C" int hipsdp_add_entries(hipsdp_solver* s, int block, long long nnz, co
       dfree(dv); dfree(dr); dfree(dc); dfree(dval);
       return HIPSDP_OK;
    }
+   if ( nnz <= 16384 )
+   {
+      /* a few triplets (the constant matrix of a node): indices checked here, the triplets through the arena, no wait */
+      bool ok = true;
+      for (long long e = 0; e < nnz; ++e)
+         if ( var[e] < 0 || var[e] > s->m || row[e] < 0 || row[e] >= B.n || col[e] < 0 || col[e] >= B.n )
+            ok = false;
+      if ( !ok )
+      {
+         set_err("hipsdp_add_entries: index out of range");
+         return HIPSDP_ERR_ARG;
+      }
+      void* dvp = NULL;
+      char* h = (char*) stage_take(s, (size_t) nnz * (3 * sizeof(int) + sizeof(double)) + 64, &dvp);
+      if ( h != NULL )
+      {
+         /* values first (8-byte aligned), then the three index arrays */
+         memcpy(h, val, (size_t) nnz * sizeof(double));
+         int* hi = (int*) (h + (size_t) nnz * sizeof(double));
+         memcpy(hi, var, (size_t) nnz * sizeof(int));
+         memcpy(hi + nnz, row, (size_t) nnz * sizeof(int));
+         memcpy(hi + 2 * nnz, col, (size_t) nnz * sizeof(int));
+         const double* dval = (const double*) dvp;
+         const int* di = (const int*) ((const char*) dvp + (size_t) nnz * sizeof(double));
+         long long g = (nnz + 255) / 256; if ( g > 4096 ) g = 4096;
+         hipLaunchKernelGGL(k_scatter_coo, dim3((unsigned) g), dim3(256), 0, s->stream, nnz, B.n, di, di + nnz, di + 2 * nnz, dval, B.A,
+            s->a_r0, s->a_r1, B.A0, s->m, s->flags + 6);
+         HS_LAUNCH_CHECK();
+         s->stage_pending = true;
+         B.apk_valid = false;
+         s->solved = false;
+         return HIPSDP_OK;
+      }
+   }
    int *dv, *dr, *dc; double* dval;
    HS_CALL( dalloc(&dv, nnz) ); HS_CALL( dalloc(&dr, nnz) ); HS_CALL( dalloc(&dc, nnz) ); HS_CALL( dalloc(&dval, nnz) );
    HS_HIP( hipMemcpyAsync(dv, var, (size_t) nnz * sizeof(int), hipMemcpyHostToDevice, s->stream) );
@@ -838,6 +959,7 @@ extern "C" int hipsdp_master_define(hipsdp_solver* s, int nvars, int nblocks, co
    if ( s == NULL || nvars < 0 || nblocks < 0 )
       return HIPSDP_ERR_ARG;
    HS_HIP( hipSetDevice(s->device) );
+   HS_CALL( stage_sync(s) );
    HS_HIP( hipStreamSynchronize(s->stream) );
    master_free(s);
    s->master_nvars = nvars;
@@ -874,6 +996,7 @@ extern "C" int hipsdp_master_add_entries(hipsdp_solver* s, int block, long long 
    if ( nnz == 0 )
       return HIPSDP_OK;
    HS_HIP( hipSetDevice(s->device) );
+   HS_CALL( stage_sync(s) );
    const int n = s->master_sizes[block];
    int *dv, *dr, *dc; double* dval;
    int* derr = NULL;
@@ -948,6 +1071,7 @@ extern "C" int hipsdp_master_add_vars(hipsdp_solver* s, int block, int nslots, c
    if ( total == 0 )
       return HIPSDP_OK;
    HS_HIP( hipSetDevice(s->device) );
+   HS_CALL( stage_sync(s) );
    HS_CALL( stage_ensure(s, total) );
    const long long cap = s->stage_cap;
    const int n = s->master_sizes[block];
@@ -1055,17 +1179,35 @@ extern "C" int hipsdp_master_gather(hipsdp_solver* s, int engine_block, int mast
    for (int r = 0; r < nkept; ++r)
       if ( kept[r] < 0 || kept[r] >= N )
          return HIPSDP_ERR_ARG;
-   int *dact, *dkept;
-   HS_CALL( dalloc(&dact, nactive) ); HS_CALL( dalloc(&dkept, nkept) );
-   HS_HIP( hipMemcpyAsync(dact, activevars, (size_t) nactive * sizeof(int), hipMemcpyHostToDevice, s->stream) );
-   HS_HIP( hipMemcpyAsync(dkept, kept, (size_t) nkept * sizeof(int), hipMemcpyHostToDevice, s->stream) );
    Block& B = s->blk[engine_block];
    long long g = ((long long) nactive * nkept * nkept + 255) / 256; if ( g > 65536 ) g = 65536;
-   hipLaunchKernelGGL(k_master_gather, dim3((unsigned) g), dim3(256), 0, s->stream, nactive, nkept, N, dact, dkept,
-      s->master_A[master_block], B.A);
-   HS_LAUNCH_CHECK();
-   HS_HIP( hipStreamSynchronize(s->stream) );
-   dfree(dact); dfree(dkept);
+   {
+      /* the two index lists through the arena: the kernel reads them there, nothing is copied and nothing waited for */
+      void* dv = NULL;
+      int* hidx = (int*) stage_take(s, (size_t) (nactive + nkept) * sizeof(int), &dv);
+      if ( hidx != NULL )
+      {
+         memcpy(hidx, activevars, (size_t) nactive * sizeof(int));
+         memcpy(hidx + nactive, kept, (size_t) nkept * sizeof(int));
+         const int* didx = (const int*) dv;
+         hipLaunchKernelGGL(k_master_gather, dim3((unsigned) g), dim3(256), 0, s->stream, nactive, nkept, N, didx, didx + nactive,
+            s->master_A[master_block], B.A);
+         HS_LAUNCH_CHECK();
+         s->stage_pending = true;
+      }
+      else
+      {
+         int *dact, *dkept;
+         HS_CALL( dalloc(&dact, nactive) ); HS_CALL( dalloc(&dkept, nkept) );
+         HS_HIP( hipMemcpyAsync(dact, activevars, (size_t) nactive * sizeof(int), hipMemcpyHostToDevice, s->stream) );
+         HS_HIP( hipMemcpyAsync(dkept, kept, (size_t) nkept * sizeof(int), hipMemcpyHostToDevice, s->stream) );
+         hipLaunchKernelGGL(k_master_gather, dim3((unsigned) g), dim3(256), 0, s->stream, nactive, nkept, N, dact, dkept,
+            s->master_A[master_block], B.A);
+         HS_LAUNCH_CHECK();
+         HS_HIP( hipStreamSynchronize(s->stream) );
+         dfree(dact); dfree(dkept);
+      }
+   }
    B.apk_valid = false;
    s->solved = false;
    return HIPSDP_OK;
@@ -1076,6 +1218,7 @@ extern "C" int hipsdp_set_block_dense(hipsdp_solver* s, int block, const double*
    if ( s == NULL || !s->shaped || block < 0 || block >= (int) s->blk.size() )
       return HIPSDP_ERR_ARG;
    HS_HIP( hipSetDevice(s->device) );
+   HS_CALL( stage_sync(s) );
    Block& B = s->blk[block];
    if ( B.sparse )
    {
@@ -1097,7 +1240,8 @@ extern "C" int hipsdp_set_lp(hipsdp_solver* s, const double* Dext)
    if ( s == NULL || !s->shaped ) return HIPSDP_ERR_ARG;
    HS_HIP( hipSetDevice(s->device) );
    if ( s->q > 0 )
-      HS_HIP( hipMemcpy(s->Dext, Dext, (size_t) s->q * (s->m + 1) * sizeof(double), hipMemcpyHostToDevice) );
+      HS_CALL( stage_upload(s, s->Dext, Dext, (size_t) s->q * (s->m + 1) * sizeof(double)) );
+   s->zero_D = false;
    s->solved = false;
    return HIPSDP_OK;
 }
@@ -1113,6 +1257,7 @@ extern "C" int hipsdp_gen_planted(hipsdp_solver* s, int n, int m, long long seed
    if ( s == NULL || !s->shaped || s->blk.size() != 1 || s->blk[0].n != n || s->m != m || s->q != 0 || s->blk[0].sparse )
       return HIPSDP_ERR_ARG;
    HS_HIP( hipSetDevice(s->device) );
+   HS_CALL( stage_sync(s) );
    Block& B = s->blk[0];
    const long long n2 = (long long) n * n;
    const int m1 = m + 1;
@@ -1168,6 +1313,7 @@ extern "C" int hipsdp_get_block_dense(hipsdp_solver* s, int block, double* A)
    if ( s == NULL || !s->shaped || block < 0 || block >= (int) s->blk.size() )
       return HIPSDP_ERR_ARG;
    HS_HIP( hipSetDevice(s->device) );
+   HS_CALL( stage_sync(s) );
    Block& B = s->blk[block];
    if ( B.sparse )
    {
@@ -1197,6 +1343,7 @@ extern "C" int hipsdp_block_device_ptr(hipsdp_solver* s, int block, double** dpt
 {
    if ( s == NULL || !s->shaped || block < 0 || block >= (int) s->blk.size() )
       return HIPSDP_ERR_ARG;
+   HS_CALL( stage_sync(s) );
    *dptr = s->blk[block].Aown;
    return HIPSDP_OK;
 }
@@ -1207,19 +1354,20 @@ extern "C" int hipsdp_set_start(hipsdp_solver* s, const double* y, const double*
    if ( s == NULL || !s->shaped ) return HIPSDP_ERR_ARG;
    HS_HIP( hipSetDevice(s->device) );
    if ( s->m > 0 )
-      HS_HIP( hipMemcpy(s->y, y, (size_t) s->m * sizeof(double), hipMemcpyHostToDevice) );
+      HS_CALL( stage_upload(s, s->y, y, (size_t) s->m * sizeof(double)) );
    for (size_t k = 0; k < s->blk.size(); ++k)
    {
       const size_t bytes = (size_t) s->blk[k].n * s->blk[k].n * sizeof(double);
-      HS_HIP( hipMemcpy(s->blk[k].X, X[k], bytes, hipMemcpyHostToDevice) );
-      HS_HIP( hipMemcpy(s->blk[k].Z, Z[k], bytes, hipMemcpyHostToDevice) );
+      HS_CALL( stage_upload(s, s->blk[k].X, X[k], bytes) );
+      HS_CALL( stage_upload(s, s->blk[k].Z, Z[k], bytes) );
    }
    if ( s->q > 0 )
    {
-      HS_HIP( hipMemcpy(s->x, x, (size_t) s->q * sizeof(double), hipMemcpyHostToDevice) );
-      HS_HIP( hipMemcpy(s->z, z, (size_t) s->q * sizeof(double), hipMemcpyHostToDevice) );
+      HS_CALL( stage_upload(s, s->x, x, (size_t) s->q * sizeof(double)) );
+      HS_CALL( stage_upload(s, s->z, z, (size_t) s->q * sizeof(double)) );
    }
    s->have_start = true;
+   s->s1_sol_host = false;
    return HIPSDP_OK;
 }
 
@@ -2228,6 +2376,7 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
    if ( s == NULL || !s->shaped || info == NULL )
       return HIPSDP_ERR_ARG;
    HS_HIP( hipSetDevice(s->device) );
+   HS_CALL( flush_zeros(s) );
    const bool alone = replicate_small(s);
    int rc;
    {
@@ -2267,6 +2416,7 @@ extern "C" int hipsdp_set_clock_sampling(hipsdp_solver* s, int on)
 {
    if ( s == NULL ) return HIPSDP_ERR_ARG;
    HS_HIP( hipSetDevice(s->device) );
+   HS_CALL( stage_sync(s) );
    if ( on && s->clk_buf == NULL )
       HS_HIP( hipMalloc((void**) &s->clk_buf, (size_t) CLK_MAX_ASSEMBLIES * 4 * sizeof(unsigned long long)) );
    s->clk_on = on != 0;
@@ -2284,11 +2434,14 @@ extern "C" int hipsdp_get_assembly_clock(hipsdp_solver* s, double* ghz)
  * solve ran there; *done = false: not this path's problem (shape, options) or the kernel declined (too much work for one compute
  * unit) - nothing has been touched and the general path below takes over.  HIPSDP_SOLVE1=0 switches the path off. */
 #define S1_HIST_MAX 256
+#define S1_SOL_OFF (HS_S1_OUT_DOUBLES + 8 + 16 * S1_HIST_MAX)       /* y (64), x (4096), z (4096) */
+#define S1_HOST_DOUBLES (S1_SOL_OFF + 64 + 2 * 4096)
 static long long g_solve1_solves = 0;      /* solves of this process that ran in the one launch (bench.py reports the share) */
 static int solve1_try(hipsdp_solver* s, hipsdp_info* info, bool* done)
 {
    *done = false;
    s->s1_last = 0;
+   s->s1_sol_host = false;
    /* (read at every solve: tests and tools switch the path between two solves of one process) */
    int on = 1, prof = 0;
    double maxwork = 3e6;
@@ -2333,7 +2486,7 @@ static int solve1_try(hipsdp_solver* s, hipsdp_info* info, bool* done)
    }
    if ( s->s1_host == NULL )
    {
-      HS_HIP( hipHostMalloc((void**) &s->s1_host, (size_t) (HS_S1_OUT_DOUBLES + 8 + 16 * S1_HIST_MAX) * sizeof(double),
+      HS_HIP( hipHostMalloc((void**) &s->s1_host, (size_t) S1_HOST_DOUBLES * sizeof(double),
             hipHostMallocMapped | hipHostMallocCoherent) );
       HS_HIP( hipHostGetDevicePointer((void**) &s->s1_host_dev, s->s1_host, 0) );
       memset(s->s1_host, 0, (size_t) (HS_S1_OUT_DOUBLES + 8) * sizeof(double));
@@ -2371,6 +2524,7 @@ static int solve1_try(hipsdp_solver* s, hipsdp_info* info, bool* done)
    a.out = s->s1_host_dev;
    a.hist = (getenv("HIPSDP_SOLVE1_HIST") != NULL && getenv("HIPSDP_SOLVE1_HIST")[0] != '0') ? s->s1_host_dev + HS_S1_OUT_DOUBLES + 8 : NULL;
    a.hist_len = S1_HIST_MAX;
+   a.hy = s->s1_host_dev + S1_SOL_OFF; a.hx = a.hy + 64; a.hz = a.hx + 4096;
    a.seq = ++s->s1_seq;
    a.flag = reinterpret_cast<unsigned long long*>(s->s1_host_dev + HS_S1_OUT_DOUBLES);
    HS_CALL( hs_solve1_launch(st, &a) );
@@ -2446,6 +2600,7 @@ static int solve1_try(hipsdp_solver* s, hipsdp_info* info, bool* done)
       fprintf(stderr, " | nnz A %d, LP %d\n", (int) o[40], (int) o[41]);
    }
    s->s1_last = 1;
+   s->s1_sol_host = true;
    (void) __sync_add_and_fetch(&g_solve1_solves, 1);
    *done = true;
    return HS_OK;
@@ -2523,8 +2678,12 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       bool done1 = false;
       HS_CALL( solve1_try(s, info, &done1) );
       if ( done1 )
+      {
+         s->stage_pending = false; s->stage_off = 0;           /* (the kernel has retired, and with it everything queued before it) */
          return HIPSDP_OK;
+      }
    }
+   HS_CALL( stage_sync(s) );                                  /* the general path uses both queues */
    HS_CALL( ensure_schur_ws(s) );
    HS_CALL( ensure_packed(s) );
    {
@@ -3510,7 +3669,16 @@ extern "C" int hipsdp_solve1_trace(hipsdp_solver* s, double* out64, int maxrows,
 static int read_scaled(hipsdp_solver* s, const double* d, long long n, double scale, double* out)
 {
    if ( n <= 0 ) return HIPSDP_OK;
+   if ( s->s1_sol_host && s->s1_host != NULL && (d == s->y || d == s->x || d == s->z) )
+   {
+      /* the one-launch solve left y, x, z in pinned memory as well */
+      const double* h = s->s1_host + S1_SOL_OFF + (d == s->y ? 0 : (d == s->x ? 64 : 64 + 4096));
+      for (long long i = 0; i < n; ++i)
+         out[i] = h[i] * scale;
+      return HIPSDP_OK;
+   }
    HS_HIP( hipSetDevice(s->device) );
+   HS_CALL( stage_sync(s) );
    HS_HIP( hipMemcpy(out, d, (size_t) n * sizeof(double), hipMemcpyDeviceToHost) );
    for (long long i = 0; i < n; ++i)
       out[i] *= scale;
@@ -3576,6 +3744,7 @@ extern "C" int hipsdp_sync_flag(hipsdp_solver* s, int* flag)
    if ( s->comm == NULL || s->nranks < 2 )
       return HIPSDP_OK;
    HS_HIP( hipSetDevice(s->device) );
+   HS_CALL( stage_sync(s) );
    int* d = NULL;
    HS_CALL( dalloc(&d, 1) );
    int rc = HS_OK;
@@ -3610,6 +3779,7 @@ static int check_y_impl(hipsdp_solver* s, const double* y, double tol, double* l
 {
    if ( s == NULL || !s->shaped ) return HIPSDP_ERR_ARG;
    HS_HIP( hipSetDevice(s->device) );
+   HS_CALL( stage_sync(s) );
    CommOff off(s, replicate_small(s));
    const int m = s->m, m1 = m + 1, q = s->q;
    hipStream_t st = s->stream;
@@ -3718,6 +3888,7 @@ extern "C" int hipsdp_eigencuts(hipsdp_solver* s, int block, const double* y, do
    if ( eigvals == NULL || coefs == NULL || lhs == NULL )
       return HIPSDP_ERR_ARG;
    HS_HIP( hipSetDevice(s->device) );
+   HS_CALL( stage_sync(s) );
    CommOff off(s, replicate_small(s));
    const int m = s->m, m1 = m + 1;
    Block& B = s->blk[block];
@@ -3811,6 +3982,7 @@ extern "C" int hipsdp_set_comm(hipsdp_solver* s, void* comm, int rank, int nrank
    if ( s->sws.T != NULL )
    {
       HS_HIP( hipSetDevice(s->device) );
+      HS_CALL( stage_sync(s) );
       HS_HIP( hipStreamSynchronize(s->stream) );
       hs_schur_ws_free(&s->sws);
    }

@@ -33,8 +33,10 @@
 #include <cstring>
 #include <cstdio>
 
+#ifndef S1_NT
 #define S1_NT 512
 #define S1_NW 8
+#endif
 #define S1_MAXB HS_S1_MAXBLK
 #define S1_MAXM 64
 #define S1_MAXN 64
@@ -307,6 +309,13 @@ __device__ __forceinline__ double s1_rcp(double t)
    r = fma(fma(-t, r, 1.0), r, r);
    r = fma(fma(-t, r, 1.0), r, r);
    return r;
+}
+
+/* square root of a non-negative number through the reciprocal square root (the library square root and the FP64 division expand to
+ * 25-35 instructions each; the scalar bookkeeping of an iteration - every wavefront does it for itself - had twenty of them) */
+__device__ __forceinline__ double s1_sqrt(double x)
+{
+   return (x > 0.0) ? x * s1_rsqrt(x) : 0.0;
 }
 
 /* ---- one wavefront: Cholesky in panels of eight columns.  The matrix (lower triangle, LDS, pitch p) is factored in place; before a
@@ -1696,7 +1705,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
    /* (thread index rotated by `off`: independent tasks of a phase start at different wavefronts - a loop that starts at thread 0
     * puts a block of 10 rows, 85 LP rows and the tile of a product all on wavefronts 0 and 1 while the other six wait at the
     * barrier; the products' tiles are dealt out from the last wavefront down) */
-   auto tro = [&](int off) S1_INL -> int { const int t = tid - off; return t < 0 ? t + S1_NT : t; };
+   auto tro = [&](int off) S1_INL -> int { const int t = tid - (off & (S1_NT - 1)); return t < 0 ? t + S1_NT : t; };
    /* LP part of the Schur matrix (one wavefront; needs x / z in Q_sx) */
    auto lp_schur = [&]() S1_INL
    {
@@ -1888,6 +1897,8 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
    const int nobest_lim = settings == 0 ? 6 : (settings == 1 ? 10 : 15);
    const double sigma_floor = settings == 0 ? 1e-8 : (settings == 1 ? 1e-4 : 1e-2);
    const int maxiter = P.maxiter;
+   const double iN1 = 1.0 / N1, inormb1 = 1.0 / (1.0 + normb), inormC1 = 1.0 / (1.0 + normC);
+   const double ifeastol = 1.0 / P.feastol, igaptol = 1.0 / P.gaptol, ipabstol = (P.pabstol > 0.0) ? 1.0 / P.pabstol : 0.0;
    bool anybig = false;
    for (int k = 0; k < K; ++k)
       anybig = anybig || (L.n[k] > S1U_MAXN);
@@ -2023,10 +2034,11 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       const double wrp = s1_wsum(lane < m ? VEC(V_w)[lane] * VEC(V_rp)[lane] : 0.0);
       const double S0 = red_sum(RS_S0);
       const double BH = red_sum(RS_BH);
-      const double den = S0 + kappa / tau + sh.sc[SC_BUB];
-      const double num = -eta * rg + (sigmu - tau * kappa - etk) / tau - BH - eta * wrp + bu1;
-      const double dtau = num / den;
-      const double dkappa = (sigmu - tau * kappa - etk - kappa * dtau) / tau;
+      const double it_ = s1_rcp(tau);
+      const double den = S0 + kappa * it_ + sh.sc[SC_BUB];
+      const double num = -eta * rg + (sigmu - tau * kappa - etk) * it_ - BH - eta * wrp + bu1;
+      const double dtau = num * s1_rcp(den);
+      const double dkappa = (sigmu - tau * kappa - etk - kappa * dtau) * it_;
       if ( lane < m )
       {
          const double dy = u1 - VEC(V_u2)[lane] * dtau;
@@ -2110,8 +2122,8 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          for (int r = tro(256); r < q; r += S1_NT)
          {
             const double dxv = QV(Q_dx)[r], dzv = QV(Q_dz)[r];
-            if ( dxv < 0.0 ) rx = fmin(rx, -QV(Q_x)[r] / dxv);
-            if ( dzv < 0.0 ) rz = fmin(rz, -QV(Q_z)[r] / dzv);
+            if ( dxv < 0.0 ) rx = fmin(rx, -QV(Q_x)[r] * s1_rcp(dxv));
+            if ( dzv < 0.0 ) rz = fmin(rz, -QV(Q_z)[r] * s1_rcp(dzv));
          }
          rx = s1_wmin(rx); rz = s1_wmin(rz);
          if ( lane == 0 )
@@ -2161,7 +2173,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          if ( lm != lm )
             a = nan("");
          else if ( lm < 0.0 )
-            a = fmin(a, -1.0 / lm);
+            a = fmin(a, -s1_rcp(lm));
       }
       double rx = 1e300, rz = 1e300;
       for (int w = 0; w < S1_NW; ++w)
@@ -2171,8 +2183,8 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       }
       a = fmin(a, fmin(rx, rz));
       const double tau = sh.sc[SC_TAU], kappa = sh.sc[SC_KAPPA], dtau = sh.sc[SC_DTAU], dkappa = sh.sc[SC_DKAPPA];
-      if ( dtau < 0.0 ) a = fmin(a, -tau / dtau);
-      if ( dkappa < 0.0 ) a = fmin(a, -kappa / dkappa);
+      if ( dtau < 0.0 ) a = fmin(a, -tau * s1_rcp(dtau));
+      if ( dkappa < 0.0 ) a = fmin(a, -kappa * s1_rcp(dkappa));
       return a;
    };
 
@@ -2251,7 +2263,8 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       pobj = s1_uni(VEC(V_AX)[0]);
       dobj = s1_uni(red_sum(RS_DOB));
       const double rg = pobj - dobj - kappa;
-      mu = s1_uni((red_sum(RS_XZ) + tau * kappa) / N1);
+      const double itau = s1_rcp(tau);
+      mu = s1_uni((red_sum(RS_XZ) + tau * kappa) * iN1);
       double rd2 = red_sum(RS_RD2LP);
       double rdmax = 0.0;
       for (int w = 0; w < S1_NW; ++w)
@@ -2260,15 +2273,15 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       {
          const double bk = red_sum(RS_BLK0 + k);
          rd2 += bk;
-         rdmax = fmax(rdmax, sqrt(bk));
+         rdmax = fmax(rdmax, s1_sqrt(bk));
       }
-      const double rpn = sqrt(red_sum(RS_RP2));
-      pinf = s1_uni(rpn / tau / (1.0 + normb));
-      const double pabs = rpn / tau;
+      const double rpn = s1_sqrt(red_sum(RS_RP2));
+      pinf = s1_uni(rpn * itau * inormb1);
+      const double pabs = rpn * itau;
       const bool pabsok = P.pabstol <= 0.0 || pabs <= P.pabstol;
-      dinf = s1_uni(sqrt(rd2) / tau / (1.0 + normC));
-      dabs_ = s1_uni(rdmax / tau);
-      gap = s1_uni(fabs(dobj - pobj) / tau);
+      dinf = s1_uni(s1_sqrt(rd2) * itau * inormC1);
+      dabs_ = s1_uni(rdmax * itau);
+      gap = s1_uni(fabs(dobj - pobj) * itau);
       if ( P.hist != NULL && tid == 0 && it < P.hist_len )
       {
          double* h = P.hist + 16 * it;
@@ -2300,7 +2313,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          pre_scale = s1_uni(1.0 / tau);
          pre_valid = 1;
       }
-      if ( P.objlimit < 1e20 && pinf <= P.feastol && pobj / tau > P.objlimit + P.gaptol )
+      if ( P.objlimit < 1e20 && pinf <= P.feastol && pobj * itau > P.objlimit + P.gaptol )
       {
          status = HS_S1_OBJLIM;
          break;
@@ -2310,7 +2323,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          status = HS_S1_OPTIMAL;
          break;
       }
-      const bool certzone = (tau < 1e-2 * fmin(1.0, kappa)) || (mu / (tau * tau) > 1e10);
+      const bool certzone = (tau < 1e-2 * fmin(1.0, kappa)) || (mu * itau * itau > 1e10);
       if ( certzone )
       {
          /* Farkas certificates: || A^T y - Z || = || Rd + tau A_0 || and || A(X, x) || relative to the objective they certify */
@@ -2341,8 +2354,8 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          if ( lane == 0 )
             sh.red[wave][RS_HD2] = h2;
          S1_BAR();
-         const double hd = sqrt(red_sum(RS_HD2));
-         const double hp = sqrt(hp2sum);
+         const double hd = s1_sqrt(red_sum(RS_HD2));
+         const double hp = s1_sqrt(hp2sum);
          const double big = fmax(fabs(dobj), fabs(pobj));
          const bool cand_dunb = dobj < -1e-3 * big;
          const bool cand_dinf = pobj > 1e-3 * big;
@@ -2371,9 +2384,9 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       lastmu = mu;
       if ( !certzone )
       {
-         double merit = fmax(fmax(pinf / P.feastol, dabs_ / P.feastol), gap / P.gaptol);
+         double merit = fmax(fmax(pinf * ifeastol, dabs_ * ifeastol), gap * igaptol);
          if ( P.pabstol > 0.0 )
-            merit = fmax(merit, pabs / P.pabstol);
+            merit = fmax(merit, pabs * ipabstol);
          if ( merit < 0.9 * bestmerit )
          {
             bestmerit = s1_uni(merit);
@@ -2939,11 +2952,16 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
 
    /* ---- results: the iterate as it is (the caller scales by 1 / tau or normalises the ray), one block of scalars */
    __syncthreads();
-   if ( tid < m ) P.y[tid] = VEC(V_y)[tid];
+   if ( tid < m )
+   {
+      P.y[tid] = VEC(V_y)[tid];
+      if ( P.hy != NULL ) P.hy[tid] = VEC(V_y)[tid];
+   }
    for (int r = tid; r < q; r += S1_NT)
    {
       P.x[r] = QV(Q_x)[r];
       P.z[r] = QV(Q_z)[r];
+      if ( P.hx != NULL ) { P.hx[r] = QV(Q_x)[r]; P.hz[r] = QV(Q_z)[r]; }
    }
    for (int k = 0; k < K; ++k)
    {
