@@ -185,6 +185,8 @@ struct hipsdp_solver
     * that touches device data outside that queue calls stage_sync first).  The offset returns to 0 when the queue has drained
     * (set_shape, end of a solve). */
    char* arena_h; char* arena_d; size_t arena_cap, stage_off; bool stage_pending;
+   int m_alloc, q_alloc;   /* what the vectors and matrices indexed by variables / LP rows were allocated for (>= m, q: set_shape2) */
+   int ncmd;               /* commands of the node's setters waiting in the arena (run by ONE launch before the solve, see NodeCmd) */
    unsigned long long s1_seq;
    int s1_last;            /* 1: the last solve ran in the single launch */
    /* pinned / device staging chunks of hipsdp_master_add_vars (kept until hipsdp_free) */
@@ -305,8 +307,86 @@ static int dalloc(T** p, long long count)
 static void dfree(void* p) { hs_pool_free(p); }
 
 #define STAGE_BYTES (2u << 20)
+/* ---- the setters of a node, deferred.  A B&B node is loaded by five or six small calls (clear, objective, gather of the active
+ * matrices from the master copy, triplets of the constant matrix, LP rows, start point).  As separate copies and launches they
+ * cost 4-6 us of host time each and as much again on the device's queue, one behind the other - a tenth of the solve of such a
+ * node.  Instead each call leaves its data and a command in the pinned arena, and ONE launch of one workgroup runs the commands in
+ * order just before the solve (or before anything else touches the device data: stage_sync).  Large operands keep the direct path. */
+enum { NC_ZERO = 1, NC_COPY = 2, NC_GATHER = 3, NC_SCATTER = 4 };
+struct NodeCmd
+{
+   int op, i0, i1, i2, i3, i4, pad0, pad1;
+   long long n;
+   double* dst;                 /* ZERO, COPY: destination; GATHER, SCATTER: the block's matrices */
+   double* dst2;                /* SCATTER: the constant matrix */
+   const double* src;           /* COPY: data; GATHER: master copy; SCATTER: values */
+   const int* idx;              /* GATHER: active slots then kept indices; SCATTER: var, row, col */
+   long long pad2;
+};
+#define NC_MAX 48
+#define NC_BYTES (NC_MAX * sizeof(NodeCmd))
+#define NC_LIMIT 65536           /* elements a deferred command may touch */
+
+__global__ void __launch_bounds__(1024) k_node_cmds(const NodeCmd* __restrict__ cmds, int ncmd)
+{
+   __shared__ NodeCmd sc[NC_MAX];
+   {
+      const long long* src = reinterpret_cast<const long long*>(cmds);
+      long long* dst = reinterpret_cast<long long*>(sc);
+      const int words = ncmd * (int) (sizeof(NodeCmd) / sizeof(long long));
+      for (int i = threadIdx.x; i < words; i += blockDim.x)
+         dst[i] = src[i];
+   }
+   __syncthreads();
+   for (int c = 0; c < ncmd; ++c)
+   {
+      const NodeCmd& q = sc[c];
+      if ( q.op == NC_ZERO )
+      {
+         for (long long e = threadIdx.x; e < q.n; e += blockDim.x)
+            q.dst[e] = 0.0;
+      }
+      else if ( q.op == NC_COPY )
+      {
+         for (long long e = threadIdx.x; e < q.n; e += blockDim.x)
+            q.dst[e] = q.src[e];
+      }
+      else if ( q.op == NC_GATHER )
+      {
+         /* (k_master_gather) i0 = active variables, i1 = kept rows, i2 = order of the master matrices */
+         const int nactive = q.i0, nk = q.i1, N = q.i2;
+         const int* act = q.idx; const int* kept = q.idx + nactive;
+         const long long nk2 = (long long) nk * nk, total = (long long) nactive * nk2;
+         for (long long e = threadIdx.x; e < total; e += blockDim.x)
+         {
+            const long long a = e / nk2;
+            const long long rc = e - a * nk2;
+            const int r = (int) (rc / nk), cc = (int) (rc - (long long) r * nk);
+            q.dst[(a + 1) * nk2 + rc] = act[a] >= 0 ? q.src[((long long) act[a] * N + kept[r]) * N + kept[cc]] : 0.0;
+         }
+      }
+      else if ( q.op == NC_SCATTER )
+      {
+         /* (k_scatter_coo, indices checked by the host) i0 = order of the block, i1, i2 = the rows of A this rank holds */
+         const int n = q.i0, r0 = q.i1, r1 = q.i2;
+         const long long n2 = (long long) n * n;
+         const int* var = q.idx; const int* row = q.idx + q.n; const int* col = q.idx + 2 * q.n;
+         for (long long e = threadIdx.x; e < q.n; e += blockDim.x)
+         {
+            const int v = var[e], r = row[e], cc = col[e];
+            if ( v != 0 && (v < r0 || v >= r1) )
+               continue;
+            double* a = (v == 0) ? q.dst2 : q.dst + (long long) v * n2;
+            a[(long long) r * n + cc] = q.src[e];
+            a[(long long) cc * n + r] = q.src[e];
+         }
+      }
+      __syncthreads();
+   }
+}
+
 /* room for `bytes` in the staging arena: host address (NULL: does not fit - the caller takes its blocking path), *dev = the same
- * bytes as the device sees them */
+ * bytes as the device sees them.  The first NC_BYTES of the arena hold the command list. */
 static void* stage_take(hipsdp_solver* s, size_t bytes, void** dev)
 {
    if ( getenv("HIPSDP_NO_STAGING") != NULL )
@@ -321,8 +401,10 @@ static void* stage_take(hipsdp_solver* s, size_t bytes, void** dev)
          (void) hipHostFree(h);
          return NULL;
       }
-      s->arena_h = (char*) h; s->arena_d = (char*) d; s->arena_cap = STAGE_BYTES; s->stage_off = 0;
+      s->arena_h = (char*) h; s->arena_d = (char*) d; s->arena_cap = STAGE_BYTES; s->stage_off = 0; s->ncmd = 0;
    }
+   if ( s->stage_off < NC_BYTES )
+      s->stage_off = NC_BYTES;
    const size_t off = (s->stage_off + 63) & ~(size_t) 63;
    if ( off + bytes > s->arena_cap )
       return NULL;
@@ -331,36 +413,81 @@ static void* stage_take(hipsdp_solver* s, size_t bytes, void** dev)
       *dev = s->arena_d + off;
    return s->arena_h + off;
 }
-/* host -> device of a small array through the arena, queued on the solver's stream; falls back to a blocking copy */
+/* launch the waiting commands (no wait) */
+static int flush_cmds(hipsdp_solver* s)
+{
+   if ( s->ncmd > 0 )
+   {
+      hipLaunchKernelGGL(k_node_cmds, dim3(1), dim3(1024), 0, s->stream, reinterpret_cast<const NodeCmd*>(s->arena_d), s->ncmd);
+      HS_LAUNCH_CHECK();
+      s->ncmd = 0;
+      s->stage_pending = true;
+   }
+   return HIPSDP_OK;
+}
+/* a slot for one more command (NULL: the arena is not available, the caller takes its direct path) */
+static NodeCmd* cmd_new(hipsdp_solver* s)
+{
+   if ( s->arena_h == NULL && stage_take(s, 0, NULL) == NULL )
+      return NULL;
+   if ( s->ncmd >= NC_MAX )
+   {
+      /* (never in practice: the list is read when the kernel runs, so it must have run before the slots are written again) */
+      if ( flush_cmds(s) != HIPSDP_OK || hipStreamSynchronize(s->stream) != hipSuccess )
+         return NULL;
+   }
+   NodeCmd* q = reinterpret_cast<NodeCmd*>(s->arena_h) + s->ncmd;
+   memset(q, 0, sizeof(*q));
+   ++s->ncmd;
+   return q;
+}
+/* host -> device of a small array: data and a copy command into the arena; falls back to a blocking copy */
 static int stage_upload(hipsdp_solver* s, void* dst, const void* src, size_t bytes)
 {
    if ( bytes == 0 )
       return HIPSDP_OK;
-   void* h = stage_take(s, bytes, NULL);
-   if ( h == NULL )
+   void* dv = NULL;
+   void* h = (bytes <= NC_LIMIT * sizeof(double)) ? stage_take(s, bytes, &dv) : NULL;
+   NodeCmd* q = (h != NULL) ? cmd_new(s) : NULL;
+   if ( q == NULL )
    {
+      HS_CALL( flush_cmds(s) );
       HS_HIP( hipStreamSynchronize(s->stream) );
       HS_HIP( hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) );
       return HIPSDP_OK;
    }
    memcpy(h, src, bytes);
-   HS_HIP( hipMemcpyAsync(dst, h, bytes, hipMemcpyHostToDevice, s->stream) );
-   s->stage_pending = true;
+   q->op = NC_COPY; q->n = (long long) (bytes / sizeof(double)); q->dst = (double*) dst; q->src = (const double*) dv;
    return HIPSDP_OK;
 }
 /* before anything outside the solver's stream touches device data: wait for what the setters queued */
+/* clear `count` doubles, in order with the waiting commands */
+static int stage_zero(hipsdp_solver* s, double* dst, long long count)
+{
+   if ( count <= 0 )
+      return HIPSDP_OK;
+   NodeCmd* q = (count <= NC_LIMIT) ? cmd_new(s) : NULL;
+   if ( q != NULL )
+   {
+      q->op = NC_ZERO; q->n = count; q->dst = dst;
+      return HIPSDP_OK;
+   }
+   HS_CALL( flush_cmds(s) );
+   HS_HIP( hipMemsetAsync(dst, 0, (size_t) count * sizeof(double), s->stream) );
+   s->stage_pending = true;
+   return HIPSDP_OK;
+}
 static int flush_zeros(hipsdp_solver* s)
 {
    if ( s->zero_b )
    {
-      HS_HIP( hipMemsetAsync(s->b, 0, (size_t) (s->m > 0 ? s->m : 1) * sizeof(double), s->stream) );
-      s->zero_b = false; s->stage_pending = true;
+      HS_CALL( stage_zero(s, s->b, s->m) );
+      s->zero_b = false;
    }
    if ( s->zero_D )
    {
-      const long long cnt = (long long) s->q * (s->m + 1);
-      HS_HIP( hipMemsetAsync(s->Dext, 0, (size_t) (cnt > 0 ? cnt : 1) * sizeof(double), s->stream) );
-      s->zero_D = false; s->stage_pending = true;
+      HS_CALL( stage_zero(s, s->Dext, (long long) s->q * (s->m + 1)) );
+      s->zero_D = false;
    }
    return HIPSDP_OK;
 }
@@ -368,6 +495,8 @@ static int stage_sync(hipsdp_solver* s)
 {
    if ( s != NULL && (s->zero_b || s->zero_D) )
       HS_CALL( flush_zeros(s) );
+   if ( s != NULL && s->ncmd > 0 )
+      HS_CALL( flush_cmds(s) );
    if ( s != NULL && s->stage_pending )
    {
       HS_HIP( hipStreamSynchronize(s->stream) );
@@ -467,7 +596,7 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
    s->hsc_cap = 0;
    s->clk_on = false; s->clk_buf = NULL; s->clk_n = 0; s->clk_ghz = 0.0;
    s->s1_ws = NULL; s->s1_ws_len = 0; s->s1_host = NULL; s->s1_host_dev = NULL; s->s1_seq = 0; s->s1_last = 0; s->s1_sol_host = false; s->zero_b = false; s->zero_D = false;
-   s->arena_h = NULL; s->arena_d = NULL; s->arena_cap = 0; s->stage_off = 0; s->stage_pending = false;
+   s->arena_h = NULL; s->arena_d = NULL; s->arena_cap = 0; s->stage_off = 0; s->stage_pending = false; s->ncmd = 0; s->m_alloc = 0; s->q_alloc = 0;
    s->trsv_ws = NULL;
    s->pre_y = s->pre_x = NULL;
    s->pre_valid = false;
@@ -615,14 +744,24 @@ extern "C" int hipsdp_set_shape2(hipsdp_solver* s, int m, int nblocks, const int
    if ( s == NULL || m < 0 || nblocks < 0 || q < 0 )
       return HIPSDP_ERR_ARG;
    HS_HIP( hipSetDevice(s->device) );
-   HS_HIP( hipStreamSynchronize(s->stream) );
-   s->stage_pending = false; s->stage_off = 0;
+   /* (nothing of an earlier load or solve may still be queued: the arena starts over, buffers may go back to the pool) */
+   if ( s->ncmd > 0 )
+      HS_CALL( flush_cmds(s) );
+   if ( hipStreamQuery(s->stream) != hipSuccess )
+      HS_HIP( hipStreamSynchronize(s->stream) );
+   if ( s->stream2 != NULL && hipStreamQuery(s->stream2) != hipSuccess )
+      HS_HIP( hipStreamSynchronize(s->stream2) );
+   s->stage_pending = false; s->stage_off = 0; s->ncmd = 0;
    s->zero_b = false; s->zero_D = false; s->s1_sol_host = false;
    /* The same shape again (the next node of a tree with the same fixings pattern, a re-load of the same problem): every
     * allocation is kept - the constraint matrices (GBs at the bench sizes), their packed copy and the Schur workspace cost tens
     * of milliseconds to free and allocate again - and only the contents are reset to what a fresh shape has. */
-   if ( s->shaped && s->m == m && s->q == q && (int) s->blk.size() == nblocks && !s->shardA && s->shardA_req == 0
-      && getenv("HIPSDP_NO_SHAPE_REUSE") == NULL )
+   /* B&B: the nodes of a tree differ in the number of active variables and LP rows by a few (fixings, tightened bounds).  Small
+    * shapes are allocated with some room (m_alloc, q_alloc below), and a shape with the same blocks that fits into it takes the
+    * same path: nothing is freed or allocated - sixty pool operations and a dozen clears per node otherwise. */
+   const bool fits = s->shaped && (int) s->blk.size() == nblocks && !s->shardA && s->shardA_req == 0
+      && ((s->m == m && s->q == q) || (m <= s->m_alloc && q <= s->q_alloc && s->comm == NULL));
+   if ( fits && getenv("HIPSDP_NO_SHAPE_REUSE") == NULL )
    {
       bool same = true;
       for (int k = 0; k < nblocks; ++k)
@@ -631,17 +770,27 @@ extern "C" int hipsdp_set_shape2(hipsdp_solver* s, int m, int nblocks, const int
       if ( same )
       {
          const long long m1s = (long long) m + 1;
+         if ( s->m != m || s->q != q )
+         {
+            /* what depends on the counts themselves */
+            hs_schur_ws_free(&s->sws);
+            s->sws.T = s->sws.U = s->sws.K = s->sws.V = s->sws.U2 = s->sws.V2 = NULL;
+            s->sws.evP[0] = s->sws.evP[1] = s->sws.evX[0] = s->sws.evX[1] = NULL;
+            s->m = m; s->q = q;
+            s->a_r0 = 0; s->a_r1 = (int) m1s;
+            s->u1 = s->rhs2 + 2LL * m;
+         }
          for (auto& B : s->blk)
          {
             if ( B.sparse )
             {
-               HS_HIP( hipMemsetAsync(B.A0, 0, (size_t) ((long long) B.n * B.n) * sizeof(double), s->stream) );
+               HS_CALL( stage_zero(s, B.A0, (long long) B.n * B.n) );
                free_sparse(B);
                B.sph = new SpHost();
                B.sp_dirty = true;
             }
             else
-               HS_HIP( hipMemsetAsync(B.Aown, 0, (size_t) (m1s * B.n * B.n) * sizeof(double), s->stream) );
+               HS_CALL( stage_zero(s, B.Aown, m1s * B.n * B.n) );
             B.apk_valid = false;
             B.derived_valid = false;
          }
@@ -658,6 +807,11 @@ extern "C" int hipsdp_set_shape2(hipsdp_solver* s, int m, int nblocks, const int
    s->m = m;
    s->q = q;
    const long long m1 = m + 1;
+   /* room for the neighbouring shapes of a tree (see above); large problems are allocated exactly */
+   const bool roomy = (m <= 112) && s->comm == NULL && s->shardA_req == 0;
+   const int mA = roomy ? m + 16 : m, qA = roomy ? q + 32 : q;
+   const long long m1A = (long long) mA + 1;
+   s->m_alloc = mA; s->q_alloc = qA;
    int nmax = 1;
    /* Constraint matrices sharded by variable (several ranks only): asked for, or - left to the sizes - when the replicated
     * matrices with their packed copy would take more than 75 % of the device memory.  Every rank decides from the same numbers. */
@@ -674,6 +828,7 @@ extern "C" int hipsdp_set_shape2(hipsdp_solver* s, int m, int nblocks, const int
          hs_var_rows((int) m1, s->nranks, s->rank, &s->a_r0, &s->a_r1);
    }
    const long long arows = s->a_r1 - s->a_r0;
+   const long long arowsA = s->shardA ? arows : m1A;
    for (int k = 0; k < nblocks; ++k)
    {
       Block B;
@@ -698,8 +853,8 @@ extern "C" int hipsdp_set_shape2(hipsdp_solver* s, int m, int nblocks, const int
       }
       else
       {
-      HS_CALL( dalloc(&R.Aown, arows * n2) );
-      HS_HIP( hipMemsetAsync(R.Aown, 0, (size_t) (arows * n2) * sizeof(double), s->stream) );
+      HS_CALL( dalloc(&R.Aown, arowsA * n2) );
+      HS_HIP( hipMemsetAsync(R.Aown, 0, (size_t) (arowsA * n2) * sizeof(double), s->stream) );
       R.A = R.Aown - (long long) s->a_r0 * n2;
       R.A0 = R.A;
       }
@@ -724,7 +879,7 @@ extern "C" int hipsdp_set_shape2(hipsdp_solver* s, int m, int nblocks, const int
        * launch less on the full storage */
       if ( getenv("HIPSDP_NOPACK") == NULL && B.n > 64 && !R.sparse )
       {
-         if ( hipMalloc((void**) &R.Apkown, (size_t) ((arows > 0 ? arows : 1) * R.Lp) * sizeof(double)) != hipSuccess )
+         if ( hipMalloc((void**) &R.Apkown, (size_t) ((arowsA > 0 ? arowsA : 1) * R.Lp) * sizeof(double)) != hipSuccess )
          {
             (void) hipGetLastError();
             R.Apkown = NULL;              /* not enough memory for the packed copy: the passes use the full storage */
@@ -737,25 +892,25 @@ extern "C" int hipsdp_set_shape2(hipsdp_solver* s, int m, int nblocks, const int
          }
       }
    }
-   HS_CALL( dalloc(&s->b, m) );
-   HS_CALL( dalloc(&s->Dext, (long long) q * m1) );
-   HS_CALL( dalloc(&s->y, m) ); HS_CALL( dalloc(&s->ys, m) );
+   HS_CALL( dalloc(&s->b, mA) );
+   HS_CALL( dalloc(&s->Dext, (long long) qA * m1A) );
+   HS_CALL( dalloc(&s->y, mA) ); HS_CALL( dalloc(&s->ys, mA) );
    double** qv[] = {&s->x, &s->z, &s->rd, &s->tmpq, &s->hl, &s->beta, &s->elp, &s->dxa, &s->dza, &s->dx, &s->dz, &s->xs, &s->zs};
-   for (double** p : qv) HS_CALL( dalloc(p, q) );
+   for (double** p : qv) HS_CALL( dalloc(p, qA) );
    double** ev[] = {&s->yt, &s->dyt, &s->wt, &s->AX, &s->AH, &s->tmpe};
-   for (double** p : ev) HS_CALL( dalloc(p, m1) );
+   for (double** p : ev) HS_CALL( dalloc(p, m1A) );
    double** mv[] = {&s->rp, &s->u2, &s->dy, &s->dya};
-   for (double** p : mv) HS_CALL( dalloc(p, m) );
+   for (double** p : mv) HS_CALL( dalloc(p, mA) );
    /* [g ; b ; h]: the right-hand side of a direction lives behind the two of the tau elimination, so that the predictor's solve
     * can ride along with them as a third right-hand side (u1 is a view, not an allocation) */
-   HS_CALL( dalloc(&s->rhs2, 3LL * m) );
+   HS_CALL( dalloc(&s->rhs2, 3LL * mA) );
    s->u1 = s->rhs2 + 2LL * m;
-   HS_CALL( dalloc(&s->cvec, 2LL * m1) );
-   HS_CALL( dalloc(&s->Mx, (m1 + 32) * m1) );      /* row padding: the 2 G shard chunks may overhang by < 2 G rows */
-   HS_CALL( dalloc(&s->Lm, (long long) m * m) );
-   HS_CALL( dalloc(&s->dinvm, hs_potrf_dinv_len(m)) );
-   HS_CALL( dalloc(&s->Slp, (long long) q * m1) );
-   HS_CALL( dalloc(&s->regmask, m) );
+   HS_CALL( dalloc(&s->cvec, 2LL * m1A) );
+   HS_CALL( dalloc(&s->Mx, (m1A + 32) * m1A) );    /* row padding: the 2 G shard chunks may overhang by < 2 G rows */
+   HS_CALL( dalloc(&s->Lm, (long long) mA * mA) );
+   HS_CALL( dalloc(&s->dinvm, hs_potrf_dinv_len(mA)) );
+   HS_CALL( dalloc(&s->Slp, (long long) qA * m1A) );
+   HS_CALL( dalloc(&s->regmask, mA) );
    s->nsc = SC_FIXED_END + 8 * (nblocks > 0 ? nblocks : 1) + 8;
    HS_CALL( dalloc(&s->sc, s->nsc + 4) );          /* the 8 int flags live behind the scalars: one read-back covers both */
    s->flags = reinterpret_cast<int*>(s->sc + s->nsc);
@@ -776,7 +931,7 @@ extern "C" int hipsdp_set_shape2(hipsdp_solver* s, int m, int nblocks, const int
       for (auto& B : s->blk)
       {
          const long long n2 = (long long) B.n * B.n, lp = (long long) B.n * (B.n + 1) / 2;
-         need = std::max(need, std::max((long long) hs_gemv_t_chunks(m + 1, n2) * n2, (long long) hs_gemv_t_chunks(m + 1, lp) * lp));
+         need = std::max(need, std::max((long long) hs_gemv_t_chunks(mA + 1, n2) * n2, (long long) hs_gemv_t_chunks(mA + 1, lp) * lp));
       }
       s->gemvt_ws_len = need;
       if ( need > 0 )
@@ -794,7 +949,7 @@ extern "C" int hipsdp_set_shape2(hipsdp_solver* s, int m, int nblocks, const int
    if ( s->gws_len > 8LL * 1024 * 1024 ) s->gws_len = 8LL * 1024 * 1024;
    HS_CALL( dalloc(&s->gws1, s->gws_len) );
    HS_CALL( dalloc(&s->gws2, s->gws_len) );
-   HS_CALL( dalloc(&s->trsv_ws, hs_trsv_sync_ws(m)) );
+   HS_CALL( dalloc(&s->trsv_ws, hs_trsv_sync_ws(mA)) );
    if ( m > 2 * 64 )
       HS_CALL( hs_trsv_sync_init(s->stream, m, s->trsv_ws, &s->trsv_epoch) );
    s->trsv_epoch = 0;
@@ -879,6 +1034,7 @@ extern "C" int hipsdp_add_entries(hipsdp_solver* s, int block, long long nnz, co
          return HIPSDP_OK;
       nnz = (long long) cv.size();
       int *dv, *dr, *dc; double* dval;
+      HS_CALL( flush_cmds(s) );
       HS_CALL( dalloc(&dv, nnz) ); HS_CALL( dalloc(&dr, nnz) ); HS_CALL( dalloc(&dc, nnz) ); HS_CALL( dalloc(&dval, nnz) );
       HS_HIP( hipMemcpy(dv, cv.data(), (size_t) nnz * sizeof(int), hipMemcpyHostToDevice) );
       HS_HIP( hipMemcpy(dr, cr.data(), (size_t) nnz * sizeof(int), hipMemcpyHostToDevice) );
@@ -916,17 +1072,27 @@ extern "C" int hipsdp_add_entries(hipsdp_solver* s, int block, long long nnz, co
          memcpy(hi + 2 * nnz, col, (size_t) nnz * sizeof(int));
          const double* dval = (const double*) dvp;
          const int* di = (const int*) ((const char*) dvp + (size_t) nnz * sizeof(double));
-         long long g = (nnz + 255) / 256; if ( g > 4096 ) g = 4096;
-         hipLaunchKernelGGL(k_scatter_coo, dim3((unsigned) g), dim3(256), 0, s->stream, nnz, B.n, di, di + nnz, di + 2 * nnz, dval, B.A,
-            s->a_r0, s->a_r1, B.A0, s->m, s->flags + 6);
-         HS_LAUNCH_CHECK();
-         s->stage_pending = true;
+         NodeCmd* q = cmd_new(s);
+         if ( q != NULL )
+         {
+            q->op = NC_SCATTER; q->n = nnz; q->i0 = B.n; q->i1 = s->a_r0; q->i2 = s->a_r1; q->idx = di; q->src = dval; q->dst = B.A; q->dst2 = B.A0;
+         }
+         else
+         {
+            long long g = (nnz + 255) / 256; if ( g > 4096 ) g = 4096;
+            HS_CALL( flush_cmds(s) );
+            hipLaunchKernelGGL(k_scatter_coo, dim3((unsigned) g), dim3(256), 0, s->stream, nnz, B.n, di, di + nnz, di + 2 * nnz, dval, B.A,
+               s->a_r0, s->a_r1, B.A0, s->m, s->flags + 6);
+            HS_LAUNCH_CHECK();
+            s->stage_pending = true;
+         }
          B.apk_valid = false;
          s->solved = false;
          return HIPSDP_OK;
       }
    }
    int *dv, *dr, *dc; double* dval;
+   HS_CALL( flush_cmds(s) );
    HS_CALL( dalloc(&dv, nnz) ); HS_CALL( dalloc(&dr, nnz) ); HS_CALL( dalloc(&dc, nnz) ); HS_CALL( dalloc(&dval, nnz) );
    HS_HIP( hipMemcpyAsync(dv, var, (size_t) nnz * sizeof(int), hipMemcpyHostToDevice, s->stream) );
    HS_HIP( hipMemcpyAsync(dr, row, (size_t) nnz * sizeof(int), hipMemcpyHostToDevice, s->stream) );
@@ -1190,14 +1356,24 @@ extern "C" int hipsdp_master_gather(hipsdp_solver* s, int engine_block, int mast
          memcpy(hidx, activevars, (size_t) nactive * sizeof(int));
          memcpy(hidx + nactive, kept, (size_t) nkept * sizeof(int));
          const int* didx = (const int*) dv;
-         hipLaunchKernelGGL(k_master_gather, dim3((unsigned) g), dim3(256), 0, s->stream, nactive, nkept, N, didx, didx + nactive,
-            s->master_A[master_block], B.A);
-         HS_LAUNCH_CHECK();
-         s->stage_pending = true;
+         NodeCmd* q = ((long long) nactive * nkept * nkept <= NC_LIMIT) ? cmd_new(s) : NULL;
+         if ( q != NULL )
+         {
+            q->op = NC_GATHER; q->i0 = nactive; q->i1 = nkept; q->i2 = N; q->idx = didx; q->src = s->master_A[master_block]; q->dst = B.A;
+         }
+         else
+         {
+            HS_CALL( flush_cmds(s) );
+            hipLaunchKernelGGL(k_master_gather, dim3((unsigned) g), dim3(256), 0, s->stream, nactive, nkept, N, didx, didx + nactive,
+               s->master_A[master_block], B.A);
+            HS_LAUNCH_CHECK();
+            s->stage_pending = true;
+         }
       }
       else
       {
          int *dact, *dkept;
+         HS_CALL( flush_cmds(s) );
          HS_CALL( dalloc(&dact, nactive) ); HS_CALL( dalloc(&dkept, nkept) );
          HS_HIP( hipMemcpyAsync(dact, activevars, (size_t) nactive * sizeof(int), hipMemcpyHostToDevice, s->stream) );
          HS_HIP( hipMemcpyAsync(dkept, kept, (size_t) nkept * sizeof(int), hipMemcpyHostToDevice, s->stream) );
@@ -2354,8 +2530,8 @@ static int sync_outcome(hipsdp_solver* s, int rc, hipsdp_info* info)
    {
       if ( s->pre_y == NULL )
       {
-         HS_CALL( dalloc(&s->pre_y, m) );
-         HS_CALL( dalloc(&s->pre_x, q) );
+         HS_CALL( dalloc(&s->pre_y, s->m_alloc > m ? s->m_alloc : m) );
+         HS_CALL( dalloc(&s->pre_x, s->q_alloc > q ? s->q_alloc : q) );
       }
       if ( m > 0 ) HS_CALL( hs_bcast_doubles(s->comm, s->pre_y, m, st) );
       if ( q > 0 ) HS_CALL( hs_bcast_doubles(s->comm, s->pre_x, q, st) );
@@ -2377,6 +2553,7 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       return HIPSDP_ERR_ARG;
    HS_HIP( hipSetDevice(s->device) );
    HS_CALL( flush_zeros(s) );
+   HS_CALL( flush_cmds(s) );
    const bool alone = replicate_small(s);
    int rc;
    {
@@ -2495,8 +2672,8 @@ static int solve1_try(hipsdp_solver* s, hipsdp_info* info, bool* done)
    {
       if ( s->pre_y == NULL )
       {
-         HS_CALL( dalloc(&s->pre_y, s->m) );
-         HS_CALL( dalloc(&s->pre_x, s->q) );
+         HS_CALL( dalloc(&s->pre_y, s->m_alloc > s->m ? s->m_alloc : s->m) );
+         HS_CALL( dalloc(&s->pre_x, s->q_alloc > s->q ? s->q_alloc : s->q) );
       }
       for (auto& B : s->blk)
          if ( B.Xpre == NULL )
@@ -2974,8 +3151,8 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       {
          if ( s->pre_y == NULL )
          {
-            HS_CALL( dalloc(&s->pre_y, m) );
-            HS_CALL( dalloc(&s->pre_x, q) );
+            HS_CALL( dalloc(&s->pre_y, s->m_alloc > m ? s->m_alloc : m) );
+            HS_CALL( dalloc(&s->pre_x, s->q_alloc > q ? s->q_alloc : q) );
          }
          if ( m > 0 ) HS_CALL( hs_copy(st, s->pre_y, s->y, m) );
          if ( q > 0 ) HS_CALL( hs_copy(st, s->pre_x, s->x, q) );
