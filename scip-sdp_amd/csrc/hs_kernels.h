@@ -246,6 +246,82 @@ long long hs_syev_ws(int n);
 #define HS_S1_TIMELIM 6
 #define HS_S1_OBJLIM 7
 #define HS_S1_OUT_DOUBLES 64
+/* ---- the deferred setters of a node (csrc/ipm.hip: stage_*, flush_cmds): commands in pinned memory, run in order by one workgroup -
+ * the first thing the one-launch solve does, or a launch of their own before anything else touches the device data */
+enum { NC_ZERO = 1, NC_COPY = 2, NC_GATHER = 3, NC_SCATTER = 4 };
+struct NodeCmd
+{
+   int op, i0, i1, i2, i3, i4, pad0, pad1;
+   long long n;
+   double* dst;                 /* ZERO, COPY: destination; GATHER, SCATTER: the block's matrices */
+   double* dst2;                /* SCATTER: the constant matrix */
+   const double* src;           /* COPY: data; GATHER: master copy; SCATTER: values */
+   const int* idx;              /* GATHER: active slots then kept indices; SCATTER: var, row, col */
+   long long pad2;
+};
+#define NC_MAX 48
+#define NC_BYTES (NC_MAX * sizeof(NodeCmd))
+#define NC_LIMIT 65536           /* elements a deferred command may touch */
+#ifdef __HIPCC__
+/* all threads of ONE workgroup; sc: NC_MAX commands of LDS */
+__device__ __forceinline__ void hs_run_node_cmds(const NodeCmd* __restrict__ cmds, int ncmd, NodeCmd* sc)
+{
+   {
+      const long long* src = reinterpret_cast<const long long*>(cmds);
+      long long* dst = reinterpret_cast<long long*>(sc);
+      const int words = ncmd * (int) (sizeof(NodeCmd) / sizeof(long long));
+      for (int i = threadIdx.x; i < words; i += blockDim.x)
+         dst[i] = src[i];
+   }
+   __syncthreads();
+   for (int c = 0; c < ncmd; ++c)
+   {
+      const NodeCmd& q = sc[c];
+      if ( q.op == NC_ZERO )
+      {
+         for (long long e = threadIdx.x; e < q.n; e += blockDim.x)
+            q.dst[e] = 0.0;
+      }
+      else if ( q.op == NC_COPY )
+      {
+         for (long long e = threadIdx.x; e < q.n; e += blockDim.x)
+            q.dst[e] = q.src[e];
+      }
+      else if ( q.op == NC_GATHER )
+      {
+         /* (k_master_gather) i0 = active variables, i1 = kept rows, i2 = order of the master matrices */
+         const int nactive = q.i0, nk = q.i1, N = q.i2;
+         const int* act = q.idx; const int* kept = q.idx + nactive;
+         const long long nk2 = (long long) nk * nk, total = (long long) nactive * nk2;
+         for (long long e = threadIdx.x; e < total; e += blockDim.x)
+         {
+            const long long a = e / nk2;
+            const long long rc = e - a * nk2;
+            const int r = (int) (rc / nk), cc = (int) (rc - (long long) r * nk);
+            q.dst[(a + 1) * nk2 + rc] = act[a] >= 0 ? q.src[((long long) act[a] * N + kept[r]) * N + kept[cc]] : 0.0;
+         }
+      }
+      else if ( q.op == NC_SCATTER )
+      {
+         /* (k_scatter_coo, indices checked by the host) i0 = order of the block, i1, i2 = the rows of A this rank holds */
+         const int n = q.i0, r0 = q.i1, r1 = q.i2;
+         const long long n2 = (long long) n * n;
+         const int* var = q.idx; const int* row = q.idx + q.n; const int* col = q.idx + 2 * q.n;
+         for (long long e = threadIdx.x; e < q.n; e += blockDim.x)
+         {
+            const int v = var[e], r = row[e], cc = col[e];
+            if ( v != 0 && (v < r0 || v >= r1) )
+               continue;
+            double* a = (v == 0) ? q.dst2 : q.dst + (long long) v * n2;
+            a[(long long) r * n + cc] = q.src[e];
+            a[(long long) cc * n + r] = q.src[e];
+         }
+      }
+      __syncthreads();
+   }
+}
+#endif
+
 struct hs_solve1_args
 {
    int m, q, nblk;
@@ -256,6 +332,7 @@ struct hs_solve1_args
    double* Xpre[HS_S1_MAXBLK];             /* preoptimal iterate (preoptgap > 0) */
    const double* b; const double* Dext;
    double *y, *x, *z, *pre_y, *pre_x;
+   const void* cmds; int ncmd;         /* deferred setters of the node (NodeCmd list in pinned memory), run before anything else */
    double *hy, *hx, *hz;               /* optional: y, x, z once more into pinned host memory (the caller's read-backs of a node need no copy) */
    double gaptol, feastol, infeastol, objlimit, timelimit, gamma, pabstol, preoptgap;
    double elapsed0;                        /* seconds of the time limit already used when the kernel starts */

@@ -312,77 +312,10 @@ static void dfree(void* p) { hs_pool_free(p); }
  * cost 4-6 us of host time each and as much again on the device's queue, one behind the other - a tenth of the solve of such a
  * node.  Instead each call leaves its data and a command in the pinned arena, and ONE launch of one workgroup runs the commands in
  * order just before the solve (or before anything else touches the device data: stage_sync).  Large operands keep the direct path. */
-enum { NC_ZERO = 1, NC_COPY = 2, NC_GATHER = 3, NC_SCATTER = 4 };
-struct NodeCmd
-{
-   int op, i0, i1, i2, i3, i4, pad0, pad1;
-   long long n;
-   double* dst;                 /* ZERO, COPY: destination; GATHER, SCATTER: the block's matrices */
-   double* dst2;                /* SCATTER: the constant matrix */
-   const double* src;           /* COPY: data; GATHER: master copy; SCATTER: values */
-   const int* idx;              /* GATHER: active slots then kept indices; SCATTER: var, row, col */
-   long long pad2;
-};
-#define NC_MAX 48
-#define NC_BYTES (NC_MAX * sizeof(NodeCmd))
-#define NC_LIMIT 65536           /* elements a deferred command may touch */
-
 __global__ void __launch_bounds__(1024) k_node_cmds(const NodeCmd* __restrict__ cmds, int ncmd)
 {
    __shared__ NodeCmd sc[NC_MAX];
-   {
-      const long long* src = reinterpret_cast<const long long*>(cmds);
-      long long* dst = reinterpret_cast<long long*>(sc);
-      const int words = ncmd * (int) (sizeof(NodeCmd) / sizeof(long long));
-      for (int i = threadIdx.x; i < words; i += blockDim.x)
-         dst[i] = src[i];
-   }
-   __syncthreads();
-   for (int c = 0; c < ncmd; ++c)
-   {
-      const NodeCmd& q = sc[c];
-      if ( q.op == NC_ZERO )
-      {
-         for (long long e = threadIdx.x; e < q.n; e += blockDim.x)
-            q.dst[e] = 0.0;
-      }
-      else if ( q.op == NC_COPY )
-      {
-         for (long long e = threadIdx.x; e < q.n; e += blockDim.x)
-            q.dst[e] = q.src[e];
-      }
-      else if ( q.op == NC_GATHER )
-      {
-         /* (k_master_gather) i0 = active variables, i1 = kept rows, i2 = order of the master matrices */
-         const int nactive = q.i0, nk = q.i1, N = q.i2;
-         const int* act = q.idx; const int* kept = q.idx + nactive;
-         const long long nk2 = (long long) nk * nk, total = (long long) nactive * nk2;
-         for (long long e = threadIdx.x; e < total; e += blockDim.x)
-         {
-            const long long a = e / nk2;
-            const long long rc = e - a * nk2;
-            const int r = (int) (rc / nk), cc = (int) (rc - (long long) r * nk);
-            q.dst[(a + 1) * nk2 + rc] = act[a] >= 0 ? q.src[((long long) act[a] * N + kept[r]) * N + kept[cc]] : 0.0;
-         }
-      }
-      else if ( q.op == NC_SCATTER )
-      {
-         /* (k_scatter_coo, indices checked by the host) i0 = order of the block, i1, i2 = the rows of A this rank holds */
-         const int n = q.i0, r0 = q.i1, r1 = q.i2;
-         const long long n2 = (long long) n * n;
-         const int* var = q.idx; const int* row = q.idx + q.n; const int* col = q.idx + 2 * q.n;
-         for (long long e = threadIdx.x; e < q.n; e += blockDim.x)
-         {
-            const int v = var[e], r = row[e], cc = col[e];
-            if ( v != 0 && (v < r0 || v >= r1) )
-               continue;
-            double* a = (v == 0) ? q.dst2 : q.dst + (long long) v * n2;
-            a[(long long) r * n + cc] = q.src[e];
-            a[(long long) cc * n + r] = q.src[e];
-         }
-      }
-      __syncthreads();
-   }
+   hs_run_node_cmds(cmds, ncmd, sc);
 }
 
 /* room for `bytes` in the staging arena: host address (NULL: does not fit - the caller takes its blocking path), *dev = the same
@@ -2553,7 +2486,8 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
       return HIPSDP_ERR_ARG;
    HS_HIP( hipSetDevice(s->device) );
    HS_CALL( flush_zeros(s) );
-   HS_CALL( flush_cmds(s) );
+   if ( s->comm != NULL )
+      HS_CALL( flush_cmds(s) );                   /* (one rank alone: the one-launch solve runs the waiting commands itself) */
    const bool alone = replicate_small(s);
    int rc;
    {
@@ -2704,6 +2638,8 @@ static int solve1_try(hipsdp_solver* s, hipsdp_info* info, bool* done)
    a.hy = s->s1_host_dev + S1_SOL_OFF; a.hx = a.hy + 64; a.hz = a.hx + 4096;
    a.seq = ++s->s1_seq;
    a.flag = reinterpret_cast<unsigned long long*>(s->s1_host_dev + HS_S1_OUT_DOUBLES);
+   a.cmds = s->arena_d; a.ncmd = s->ncmd;         /* the node's setters: run by the same launch */
+   s->ncmd = 0;
    HS_CALL( hs_solve1_launch(st, &a) );
    {
       volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(s->s1_host + HS_S1_OUT_DOUBLES);

@@ -1322,6 +1322,13 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
    const long long t_start = clock64();
    const long long w_start = wall_clock64();
 
+   /* ---- the node's deferred setters (objective, LP rows, gather of the active matrices, constant matrix, start point) */
+   if ( P.ncmd > 0 )
+   {
+      hs_run_node_cmds(reinterpret_cast<const NodeCmd*>(P.cmds), P.ncmd, reinterpret_cast<NodeCmd*>(sm));
+      __syncthreads();
+   }
+
    /* ---- layout */
    if ( tid == 0 )
    {
@@ -2617,22 +2624,24 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       S1_BAR();
       S1_STAMP(5);
 
+      /* lower triangle of M into Lm (zero above the diagonal, out to the padded width) and its first column into g: all threads
+       * (one wavefront copying row by row took 5000 cycles in front of the factorization) */
+      {
+         const int wd = pm - 1;
+         for (int e = tid; e < m * wd; e += S1_NT)
+         {
+            const int r = s1_div(e, wd), j = e - r * wd;
+            Lm[r * pm + j] = (j <= r) ? Mx[(r + 1) * pm1 + 1 + j] : 0.0;
+         }
+         if ( tid < m )
+            VEC(V_g)[tid] = Mx[(tid + 1) * pm1];
+      }
+      S1_BAR();
       /* ================= factorization of M and the two solves (wavefront 0) beside the first product of the predictor,
        * T1 = X Rd (the others) */
       if ( wave == 0 )
       {
-         /* lower triangle of M into Lm (zero above the diagonal, out to the padded width), lane = row */
-         double dg0 = 1.0;
-         if ( lane < m )
-         {
-            const double* src = Mx + (lane + 1) * pm1 + 1;
-            double* dst = Lm + lane * pm;
-            for (int j = 0; j < pm - 1; ++j)
-               dst[j] = (j <= lane) ? src[j] : 0.0;
-            dg0 = src[lane];
-            VEC(V_g)[lane] = Mx[(lane + 1) * pm1];
-         }
-         S1_WSYNC();
+         const double dg0 = (lane < m) ? Lm[lane * pm + lane] : 1.0;
          double mdiag;
          int nforced;
          long long tq0 = 0;
