@@ -98,9 +98,42 @@ def schur_block(A, X, Zinv):
     return 0.5 * (Mx + Mx.T)
 
 
+def schur_rows_sparse(m, n, coo, X, Zinv):
+    """Schur entries tr(A_i X A_j Zinv), i, j = 1 .. m, from the nonzeros in the association of the dense formula - what
+    scip-sdp_amd/csrc/sparse.hip (k_sp_trows, k_sp_schur) and csrc/solve1.hip compute since round 4: T_j = A_j Zinv restricted to the
+    non-empty rows of A_j, then M_ij = sum over the entries (a, b) of A_i (both triangles) of A_i[a][b] sum_p X[b][p] T_j[p][a].
+    coo: lower-triangular triplets (var 1 .. m, row >= col, val).  Plain loops (small cases only).  Returns the m x m matrix."""
+    var, row, col, val = coo
+    full = [[] for _ in range(m + 1)]
+    for v, r, c, x in zip(var, row, col, val):
+        full[int(v)].append((int(r), int(c), float(x)))
+        if r != c:
+            full[int(v)].append((int(c), int(r), float(x)))
+    T = []
+    for j in range(1, m + 1):
+        rows = {}
+        for (p_, q_, x) in sorted(full[j]):
+            rows.setdefault(p_, np.zeros(n))
+            rows[p_] = rows[p_] + x * Zinv[q_, :]
+        T.append(sorted(rows.items()))
+    M = np.zeros((m, m))
+    for i in range(1, m + 1):
+        ents = sorted(full[i])
+        for j in range(1, m + 1):
+            acc = 0.0
+            for (a, b_, x) in ents:
+                u = 0.0
+                for (p_, trow) in T[j - 1]:
+                    u += X[b_, p_] * trow[a]
+                acc += x * u
+            M[i - 1, j - 1] = acc
+    return M
+
+
 def schur_pairs_sparse(m, coo, X, Zinv):
-    """Schur entries tr(A_i X A_j Zinv), i, j = 1 .. m, from the nonzeros alone - the formula of scip-sdp_amd/csrc/sparse.hip
-    (SDPA's F3 case): with e = (p, q, a) in A_i and f = (r, s, b) in A_j (lower triangles, off-diagonal entries stand for both
+    """Schur entries tr(A_i X A_j Zinv), i, j = 1 .. m, from the nonzeros alone by the PAIR formula (SDPA's F3 case; what
+    scip-sdp_amd/csrc/sparse.hip used in rounds 2-3 - the same numbers in exact arithmetic, but see schur_rows_sparse and DESIGN.md
+    7.3): with e = (p, q, a) in A_i and f = (r, s, b) in A_j (lower triangles, off-diagonal entries stand for both
     positions)   sum_e sum_f a b (X_qr Zinv_sp + [p != q] X_pr Zinv_sq + [r != s] X_qs Zinv_rp + [p != q][r != s] X_ps Zinv_rq).
     Vectorised over all pairs of entries (fine for the sizes the CPU tests use).  Returns the m x m matrix."""
     var, row, col, val = coo

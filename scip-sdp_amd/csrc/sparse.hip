@@ -7,13 +7,18 @@
  * of an SPMD run and the ranks of a sharded one must agree to the last bit, so no floating-point atomics).  The constant matrix
  * stays a dense n x n array (it is dense after fixings / in planted instances, and k_cert wants it dense).
  *
- * Schur complement of such a block - SDPA's F3 formula (Fujisawa, Kojima, Nakata 1997): with e = (p, q, a) in A_i, f = (r, s, b) in A_j
+ * Schur complement of such a block, from the nonzeros but IN THE ASSOCIATION OF THE DENSE FORMULA (round 4):
  *
- *      Mx[i][j] = tr(A_i X A_j Zinv) = sum_e sum_f a b ( X_qr Zinv_sp + [p != q] X_pr Zinv_sq + [r != s] X_qs Zinv_rp
- *                                                        + [p != q][r != s] X_ps Zinv_rq )
+ *      T_j = A_j Zinv          only the non-empty rows of A_j: row p of T_j = sum over the entries (p, q) of A_j[p][q] Zinv[q][:]
+ *      Mx[i][j] = tr(A_i X A_j Zinv) = sum over the entries (a, b) of A_i:  A_i[a][b] * sum over the non-empty rows p of A_j: X[b][p] T_j[p][a]
  *
- * 4 nnz_i nnz_j multiply-adds per pair instead of the 4 n^3 / m + n^2 of the dense formulation: the engine takes it when
- * 4 (sum nnz)^2 is the smaller number (hs_sp_prefers_sparse).  Row / column 0 of the extended matrix (constant matrix as
+ * Rounds 2 and 3 used SDPA's F3 pair formula (Fujisawa, Kojima, Nakata 1997), sum_e sum_f a b (X_qr Zinv_sp + ...): the same number
+ * in exact arithmetic, the same count of multiply-adds (about nnz_i nnz_j per pair) - but on nodes without an optimum (tau -> 0, Zinv
+ * almost of rank one) the assembled matrix then differs from the operator the direction applies by 300 times more than with the
+ * association above, the primal residual stalls at 1e-7 and the node goes to the settings ladder (found with the one-launch
+ * solve on example_TT's infeasible nodes).  The differences of entries of Zinv a constraint matrix asks for are formed first, as the
+ * products X dZ Zinv of the direction form them.  The engine keeps a block as nonzeros when 4 (sum nnz)^2 is smaller than the dense
+ * count (hs_sp_prefers_sparse).  Row / column 0 of the extended matrix (constant matrix as
  * "variable 0") comes from U_0 = X A_0 Zinv (two dense n^3 products) and one gather pass <A_i, U_0>.
  */
 #include "hs_kernels.h"
@@ -37,6 +42,18 @@ struct hs_sparse
    int*       pcol;
    int*       pvar;        /* variable (1-based) of an entry */
    double*    pval;
+   /* FULL symmetric entries by variable, row-major (the two-stage Schur assembly): entries of variable v are [foff[v - 1], foff[v]),
+    * entry e = (frow[e], fcol[e], fval[e]); the non-empty rows of variable v are the slots [soff[v - 1], soff[v]): slot s is row
+    * srow[s] with the entries [sent[s], sent[s + 1]); Tc: nslots x n doubles of workspace, Tc[s][c] = (A_v Zinv)[srow[s]][c] */
+   long long  nfull, nslots;
+   int*       foff;
+   int*       frow;
+   int*       fcol;
+   double*    fval;
+   int*       soff;
+   int*       srow;
+   int*       sent;
+   double*    Tc;
 };
 
 namespace {
@@ -59,6 +76,8 @@ void hs_sp_free(hs_sparse* sp)
       return;
    hs_pool_free(sp->voff); hs_pool_free(sp->vrow); hs_pool_free(sp->vcol); hs_pool_free(sp->vval);
    hs_pool_free(sp->poff); hs_pool_free(sp->prow); hs_pool_free(sp->pcol); hs_pool_free(sp->pvar); hs_pool_free(sp->pval);
+   hs_pool_free(sp->foff); hs_pool_free(sp->frow); hs_pool_free(sp->fcol); hs_pool_free(sp->fval);
+   hs_pool_free(sp->soff); hs_pool_free(sp->srow); hs_pool_free(sp->sent); hs_pool_free(sp->Tc);
    delete sp;
 }
 
@@ -141,7 +160,49 @@ int hs_sp_build(hs_sparse** out, int n, int m, long long nnz, const int* var, co
    sp->n = n; sp->m = m; sp->nnz = nz; sp->npos = npos;
    sp->voff = sp->vrow = sp->vcol = sp->poff = sp->prow = sp->pcol = sp->pvar = NULL;
    sp->vval = sp->pval = NULL;
+   sp->foff = sp->frow = sp->fcol = sp->soff = sp->srow = sp->sent = NULL;
+   sp->fval = sp->Tc = NULL;
+   /* full entries (both triangles) by variable, row-major, and the row slots */
+   std::vector<int> foff((size_t) m + 1, 0), frow, fcol, soff((size_t) m + 1, 0), srow, sent;
+   std::vector<double> fval;
+   {
+      std::vector<std::pair<std::pair<int, int>, double> > ent;
+      for (int v = 1; v <= m; ++v)
+      {
+         ent.clear();
+         for (int e = voff[v - 1]; e < voff[v]; ++e)
+         {
+            ent.push_back(std::make_pair(std::make_pair(hr[e], hc[e]), hx[e]));
+            if ( hr[e] != hc[e] )
+               ent.push_back(std::make_pair(std::make_pair(hc[e], hr[e]), hx[e]));
+         }
+         std::sort(ent.begin(), ent.end(), [](const std::pair<std::pair<int, int>, double>& a, const std::pair<std::pair<int, int>, double>& b) {
+            return a.first < b.first; });
+         for (size_t k = 0; k < ent.size(); ++k)
+         {
+            if ( k == 0 || ent[k].first.first != ent[k - 1].first.first )
+            {
+               srow.push_back(ent[k].first.first);
+               sent.push_back((int) frow.size());
+            }
+            frow.push_back(ent[k].first.first); fcol.push_back(ent[k].first.second); fval.push_back(ent[k].second);
+         }
+         foff[v] = (int) frow.size();
+         soff[v] = (int) srow.size();
+      }
+      sent.push_back((int) frow.size());
+   }
+   sp->nfull = (long long) frow.size();
+   sp->nslots = (long long) srow.size();
    int rc = sp_upload(&sp->voff, voff);
+   if ( rc == HS_OK ) rc = sp_upload(&sp->foff, foff);
+   if ( rc == HS_OK ) rc = sp_upload(&sp->frow, frow);
+   if ( rc == HS_OK ) rc = sp_upload(&sp->fcol, fcol);
+   if ( rc == HS_OK ) rc = sp_upload(&sp->fval, fval);
+   if ( rc == HS_OK ) rc = sp_upload(&sp->soff, soff);
+   if ( rc == HS_OK ) rc = sp_upload(&sp->srow, srow);
+   if ( rc == HS_OK ) rc = sp_upload(&sp->sent, sent);
+   if ( rc == HS_OK ) rc = hs_pool_alloc((void**) &sp->Tc, (size_t) ((sp->nslots > 0 ? sp->nslots : 1) * (long long) n) * sizeof(double));
    if ( rc == HS_OK ) rc = sp_upload(&sp->vrow, hr);
    if ( rc == HS_OK ) rc = sp_upload(&sp->vcol, hc);
    if ( rc == HS_OK ) rc = sp_upload(&sp->vval, hx);
@@ -224,11 +285,28 @@ int hs_sp_apply_AT(hipStream_t s, const hs_sparse* sp, const double* coef, doubl
    return HS_OK;
 }
 
-/* Mx[i][j] += tr(A_i X A_j Zinv) for 1 <= j <= i <= m (lower triangle, ld = m + 1; row / column 0 is not touched).  One wavefront
- * per pair: its lanes split the nnz_i x nnz_j products, summed in a fixed order. */
-__global__ void __launch_bounds__(256) k_sp_schur(int m, int n, const int* __restrict__ voff, const int* __restrict__ vrow,
-   const int* __restrict__ vcol, const double* __restrict__ vval, const double* __restrict__ X, const double* __restrict__ Zinv,
-   double* __restrict__ Mx, long long npairs)
+/* (a) Tc[s][c] = sum over the entries of slot s of value * Zinv[col][c]: one thread per (slot, column), entries in order */
+__global__ void __launch_bounds__(256) k_sp_trows(long long nslots, int n, const int* __restrict__ sent, const int* __restrict__ fcol,
+   const double* __restrict__ fval, const double* __restrict__ Zinv, double* __restrict__ Tc)
+{
+   const long long total = nslots * n;
+   for (long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long) gridDim.x * blockDim.x)
+   {
+      const long long sl = t / n;
+      const int c = (int) (t - sl * n);
+      double acc = 0.0;
+      for (int e = sent[sl]; e < sent[sl + 1]; ++e)
+         acc = fma(fval[e], Zinv[(long long) fcol[e] * n + c], acc);
+      Tc[t] = acc;
+   }
+}
+
+/* (b) Mx[i][j] += sum over the entries (a, b) of A_i of A_i[a][b] * (sum over the row slots of A_j of X[b][row] Tc[slot][a]) for
+ * 1 <= j <= i <= m (lower triangle, ld = m + 1; row / column 0 is not touched).  One wavefront per pair: its lanes split the
+ * entries of A_i, partial sums added in a fixed order. */
+__global__ void __launch_bounds__(256) k_sp_schur(int m, int n, const int* __restrict__ foff, const int* __restrict__ frow,
+   const int* __restrict__ fcol, const double* __restrict__ fval, const int* __restrict__ soff, const int* __restrict__ srow,
+   const double* __restrict__ Tc, const double* __restrict__ X, double* __restrict__ Mx, long long npairs)
 {
    const int lane = threadIdx.x & 63;
    const int m1 = m + 1;
@@ -239,19 +317,15 @@ __global__ void __launch_bounds__(256) k_sp_schur(int m, int n, const int* __res
       while ( (i + 1) * (i + 2) / 2 <= pr ) ++i;
       while ( i * (i + 1) / 2 > pr ) --i;
       const long long j = pr - i * (i + 1) / 2;
-      const int a0 = voff[i], a1 = voff[i + 1], b0 = voff[j], b1 = voff[j + 1];
-      const int na = a1 - a0, nb = b1 - b0;
-      const long long tot = (long long) na * nb;
+      const int a0 = foff[i], a1 = foff[i + 1], s0 = soff[j], s1 = soff[j + 1];
       double acc = 0.0;
-      for (long long t = lane; t < tot; t += 64)
+      for (int e = a0 + lane; e < a1; e += 64)
       {
-         const int ea = a0 + (int) (t / nb), eb = b0 + (int) (t % nb);
-         const int p = vrow[ea], q = vcol[ea], r = vrow[eb], c = vcol[eb];
-         double w = X[(long long) q * n + r] * Zinv[(long long) c * n + p];
-         if ( p != q ) w += X[(long long) p * n + r] * Zinv[(long long) c * n + q];
-         if ( r != c ) w += X[(long long) q * n + c] * Zinv[(long long) r * n + p];
-         if ( p != q && r != c ) w += X[(long long) p * n + c] * Zinv[(long long) r * n + q];
-         acc += vval[ea] * vval[eb] * w;
+         const int a = frow[e], b = fcol[e];
+         double u = 0.0;
+         for (int sl = s0; sl < s1; ++sl)
+            u = fma(X[(long long) b * n + srow[sl]], Tc[(long long) sl * n + a], u);
+         acc = fma(fval[e], u, acc);
       }
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1)
@@ -261,12 +335,12 @@ __global__ void __launch_bounds__(256) k_sp_schur(int m, int n, const int* __res
    }
 }
 
-/* the same sum by ONE THREAD per pair of variables, its element pairs in order: with a handful of nonzeros per matrix (3: nine
- * element pairs) a wavefront per pair has 9 of 64 lanes at work and pays the decoding of the pair index and a six-step reduction
- * for every one of the m (m + 1) / 2 pairs (0.94 ms at m = 2000); taken when the average number of element pairs is below 32 */
-__global__ void __launch_bounds__(256) k_sp_schur_t(int m, int n, const int* __restrict__ voff, const int* __restrict__ vrow,
-   const int* __restrict__ vcol, const double* __restrict__ vval, const double* __restrict__ X, const double* __restrict__ Zinv,
-   double* __restrict__ Mx, long long npairs)
+/* the same sum by ONE THREAD per pair of variables, its entries in order: with a handful of nonzeros per matrix a wavefront per
+ * pair has a few of 64 lanes at work and pays the decoding of the pair index and a six-step reduction for every one of the
+ * m (m + 1) / 2 pairs; taken when the average number of entries per matrix is small */
+__global__ void __launch_bounds__(256) k_sp_schur_t(int m, int n, const int* __restrict__ foff, const int* __restrict__ frow,
+   const int* __restrict__ fcol, const double* __restrict__ fval, const int* __restrict__ soff, const int* __restrict__ srow,
+   const double* __restrict__ Tc, const double* __restrict__ X, double* __restrict__ Mx, long long npairs)
 {
    const int m1 = m + 1;
    for (long long pr = (long long) blockIdx.x * blockDim.x + threadIdx.x; pr < npairs; pr += (long long) gridDim.x * blockDim.x)
@@ -275,21 +349,15 @@ __global__ void __launch_bounds__(256) k_sp_schur_t(int m, int n, const int* __r
       while ( (i + 1) * (i + 2) / 2 <= pr ) ++i;
       while ( i * (i + 1) / 2 > pr ) --i;
       const long long j = pr - i * (i + 1) / 2;
-      const int a0 = voff[i], a1 = voff[i + 1], b0 = voff[j], b1 = voff[j + 1];
+      const int a0 = foff[i], a1 = foff[i + 1], s0 = soff[j], s1 = soff[j + 1];
       double acc = 0.0;
-      for (int ea = a0; ea < a1; ++ea)
+      for (int e = a0; e < a1; ++e)
       {
-         const int p = vrow[ea], q = vcol[ea];
-         const double va = vval[ea];
-         for (int eb = b0; eb < b1; ++eb)
-         {
-            const int r = vrow[eb], c = vcol[eb];
-            double w = X[(long long) q * n + r] * Zinv[(long long) c * n + p];
-            if ( p != q ) w += X[(long long) p * n + r] * Zinv[(long long) c * n + q];
-            if ( r != c ) w += X[(long long) q * n + c] * Zinv[(long long) r * n + p];
-            if ( p != q && r != c ) w += X[(long long) p * n + c] * Zinv[(long long) r * n + q];
-            acc += va * vval[eb] * w;
-         }
+         const int a = frow[e], b = fcol[e];
+         double u = 0.0;
+         for (int sl = s0; sl < s1; ++sl)
+            u = fma(X[(long long) b * n + srow[sl]], Tc[(long long) sl * n + a], u);
+         acc = fma(fval[e], u, acc);
       }
       Mx[(i + 1) * m1 + (j + 1)] += acc;
    }
@@ -300,27 +368,33 @@ int hs_sp_schur(hipStream_t s, const hs_sparse* sp, const double* X, const doubl
    if ( sp->m <= 0 )
       return HS_OK;
    const long long npairs = (long long) sp->m * (sp->m + 1) / 2;
+   if ( sp->nslots > 0 )
    {
-      const double avg = (double) sp->nnz / (double) sp->m;
-      if ( avg * avg < 32.0 )
+      long long blocks = (sp->nslots * sp->n + 255) / 256;
+      if ( blocks > 65536 ) blocks = 65536;
+      hipLaunchKernelGGL(k_sp_trows, dim3((unsigned) blocks), dim3(256), 0, s, sp->nslots, sp->n, sp->sent, sp->fcol, sp->fval, Zinv, sp->Tc);
+      HS_HIP( hipGetLastError() );
+   }
+   {
+      const double avg = (double) sp->nfull / (double) sp->m;
+      if ( avg < 24.0 )
       {
          long long blocks = (npairs + 255) / 256;
          if ( blocks > 65536 ) blocks = 65536;
-         hipLaunchKernelGGL(k_sp_schur_t, dim3((unsigned) blocks), dim3(256), 0, s, sp->m, sp->n, sp->voff, sp->vrow, sp->vcol, sp->vval, X, Zinv, Mx,
-            npairs);
+         hipLaunchKernelGGL(k_sp_schur_t, dim3((unsigned) blocks), dim3(256), 0, s, sp->m, sp->n, sp->foff, sp->frow, sp->fcol, sp->fval,
+            sp->soff, sp->srow, sp->Tc, X, Mx, npairs);
          HS_HIP( hipGetLastError() );
          return HS_OK;
       }
    }
    long long blocks = (npairs + 3) / 4;
    if ( blocks > 65536 ) blocks = 65536;
-   hipLaunchKernelGGL(k_sp_schur, dim3((unsigned) blocks), dim3(256), 0, s, sp->m, sp->n, sp->voff, sp->vrow, sp->vcol, sp->vval, X, Zinv, Mx,
-      npairs);
+   hipLaunchKernelGGL(k_sp_schur, dim3((unsigned) blocks), dim3(256), 0, s, sp->m, sp->n, sp->foff, sp->frow, sp->fcol, sp->fval,
+      sp->soff, sp->srow, sp->Tc, X, Mx, npairs);
    HS_HIP( hipGetLastError() );
    return HS_OK;
 }
 
-/* dense expansion of the variables' matrices: A[v n^2 + ..] for v = 1 .. m (the caller has zeroed A); row 0 is not touched */
 __global__ void k_sp_expand(long long nnz, int n, const int* __restrict__ pvar_by_var, const int* __restrict__ voff, int m,
    const int* __restrict__ vrow, const int* __restrict__ vcol, const double* __restrict__ vval, double* __restrict__ A)
 {

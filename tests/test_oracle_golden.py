@@ -198,8 +198,8 @@ def test_eigenvector_cut_restatement_matches_the_sparse_formula():
 
 
 def test_pair_formula_over_nonzeros_equals_the_dense_schur_formula():
-    """oracle/ipm_ref.schur_pairs_sparse (the formula of csrc/sparse.hip, SDPA's F3 case) against the three-product formula on the
-    dense expansion of the same matrices"""
+    """oracle/ipm_ref.schur_pairs_sparse (SDPA's F3 case) and schur_rows_sparse (the two-stage sum of csrc/sparse.hip) against the
+    three-product formula on the dense expansion of the same matrices"""
     import instances
     rng = np.random.default_rng(4)
     for n, m, k in ((12, 9, 1), (30, 25, 3), (41, 17, 20)):
@@ -210,6 +210,8 @@ def test_pair_formula_over_nonzeros_equals_the_dense_schur_formula():
         M1 = ipm_ref.schur_block(instances.coo_to_dense(n, m, coo, A0), X, Zi)[1:, 1:]
         M2 = ipm_ref.schur_pairs_sparse(m, coo, X, Zi)
         assert np.max(np.abs(M1 - M2)) <= 1e-12 * np.max(np.abs(M1))
+        M3 = ipm_ref.schur_rows_sparse(m, n, coo, X, Zi)             # the association csrc/sparse.hip uses since round 4
+        assert np.max(np.abs(M1 - M3)) <= 1e-12 * np.max(np.abs(M1))
         # and the planted optimum is what the oracle finds on the expansion
         core = ipm_ref.CoreProblem(b, [instances.coo_to_dense(n, m, coo, A0)])
         r = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-7, feastol=1e-7))
