@@ -329,23 +329,33 @@ __device__ __forceinline__ int s1_cholp(double* A, int n, int p, int lane, bool 
 {
    const double regtol = 1e-13;
    const int lr = lane & 15, kq = lane >> 4;
+   /* semidefinite rule: one comparison per pivot in the usual case (the threshold of this lane's row, never below 1e-300) */
+   const double thr = fmax(regtol * dg0, 1e-300);
    mydiag = 1.0;
    nforced = 0;
    for (int k0 = 0; k0 < n; k0 += 8)
    {
       if ( k0 > 0 )
       {
+         /* panel -= (finished columns) (their rows k0 .. k0 + 7)^T, 16-row tiles on the matrix cores.  All loads unconditional
+          * with clamped indices (rows past n and the unused half of the B operand only reach entries that are not written
+          * back), the accumulators start from the panel itself and take the NEGATIVE products, so that the result is stored
+          * without a read behind the matrix instructions. */
+         const int nm1 = n - 1;
          for (int T = k0 >> 4; 16 * T < n; ++T)
          {
-            v4d acc = {0.0, 0.0, 0.0, 0.0};
-            const int ar = 16 * T + lr, br = k0 + lr;
-            const bool aok = ar < n, bok = (lr < 8) && (br < n);
+            const int ar = min(16 * T + lr, nm1), br = min(k0 + lr, nm1);
             const double* pa = A + ar * p + kq;
             const double* pb = A + br * p + kq;
+            const int cc = min(k0 + lr, nm1);
+            v4d acc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+               acc[r] = A[min(16 * T + kq + 4 * r, nm1) * p + cc];
             for (int kk = 0; kk < k0; kk += 8)
             {
-               const double a0 = aok ? pa[kk] : 0.0, b0 = bok ? pb[kk] : 0.0;
-               const double a1 = aok ? pa[kk + 4] : 0.0, b1 = bok ? pb[kk + 4] : 0.0;
+               const double a0 = -pa[kk], b0 = pb[kk];
+               const double a1 = -pa[kk + 4], b1 = pb[kk + 4];
                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
             }
@@ -354,7 +364,7 @@ __device__ __forceinline__ int s1_cholp(double* A, int n, int p, int lane, bool 
             {
                const int row = 16 * T + kq + 4 * r;
                if ( lr < 8 && row < n && row >= k0 + lr && k0 + lr < n )
-                  A[row * p + k0 + lr] -= acc[r];
+                  A[row * p + k0 + lr] = acc[r];
             }
          }
          S1_WSYNC();
@@ -373,9 +383,9 @@ __device__ __forceinline__ int s1_cholp(double* A, int n, int p, int lane, bool 
             bool zero = false;
             if ( psd )
             {
-               const double mkk = s1_lane(dg0, k);
-               if ( !(d > regtol * mkk) || !(d > 1e-300) )
+               if ( !(d > s1_lane(thr, k)) )
                {
+                  const double mkk = s1_lane(dg0, k);
                   zero = (rule == 1) || (rule == 2 && !(d > 0.0)) || (rule == 3 && !(d > 1.78e-15 * (double) (k + 1) * mkk));
                   d = (mkk > 1e-280) ? regtol * mkk : 1.0;
                   nforced += zero ? 65536 : 1;
@@ -384,10 +394,10 @@ __device__ __forceinline__ int s1_cholp(double* A, int n, int p, int lane, bool 
             else if ( !(d > 0.0) )
                return k + 1;
             const double rs = s1_rsqrt(d);
-            const double sd = d * rs;
+            const double sd = d * rs;                        /* (d may be the replacement of a forced pivot) */
             if ( lane == k )
                mydiag = sd;
-            const double lu = (lane > k) ? (zero ? 0.0 : a[u] * rs) : 0.0;
+            const double lu = (lane > k && !zero) ? a[u] * rs : 0.0;
             a[u] = (lane == k && keepdiag) ? sd : lu;
             /* the later columns of the panel take this column's term at once (independent multiply-adds; taken column by column
              * when its pivot comes they were a chain of up to seven dependent ones in front of every pivot) */
