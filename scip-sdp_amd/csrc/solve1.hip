@@ -1321,6 +1321,7 @@ template<bool AL, class T> __device__ __forceinline__ typename S1Ptr<AL, T>::typ
 /* developer profile (prof_on == 2, history buffer given): in iteration 3 every wavefront notes when it reaches each barrier - which
  * wavefront a phase waits for, and how long the others idle */
 #define S1_BAR() do { if ( P.prof_on == 2 && P.hist != NULL && it == 3 && lane == 0 && nbar < 60 ) P.hist[2048 + 8 * nbar + wave] = (double) clock64(); ++nbar; __syncthreads(); } while (0)
+#define S1_SETUP_STAMP(i) do { if ( P.prof_on == 2 && P.hist != NULL && tid == 0 ) P.hist[2048 + 480 + (i)] = (double) (clock64() - t_start); } while (0)
 #define S1_STAMP(id) do { if ( P.prof_on && tid == 0 ) { const long long t_ = clock64(); sh.prof[id] += (double) (t_ - sh.t_last); sh.t_last = t_; } } while (0)
 
 __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
@@ -1336,7 +1337,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
    if ( P.ncmd > 0 )
    {
       hs_run_node_cmds(reinterpret_cast<const NodeCmd*>(P.cmds), P.ncmd, reinterpret_cast<NodeCmd*>(sm));
-      __syncthreads();
+      __syncthreads(); S1_SETUP_STAMP(0);
    }
 
    /* ---- layout */
@@ -1347,7 +1348,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          sh.prof[i] = 0.0;
       sh.t_last = t_start;
    }
-   __syncthreads();
+   __syncthreads(); S1_SETUP_STAMP(1);
    const S1Lay& L = sh.lay;
    const int pm1 = L.pm1, pm = L.pm, VL = L.VL, QL = L.QL;
    const int oVec = L.oVec, oQ = L.oQ;
@@ -1409,11 +1410,52 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          B.voff = (int*) take((m1 + 2) / 2 + 1);
          B.poff = (int*) take((B.n * B.n + 2) / 2 + 1);
       }
+      /* (4) the caller's dense arrays once into LDS, at its top, when half of what is left holds them: the passes below read
+       * every entry three times in chains of dependent loads - 700 ns each from L2, 40 ns from LDS (the lists of example_TT took
+       * 50 us of the 1.2 ms of a solve) */
+      {
+         long long need = (long long) q * m1;
+         for (int k = 0; k < K; ++k)
+            need += (long long) m1 * L.n[k] * L.n[k];
+         need = (need + 1) & ~1LL;
+         sh.fl[31] = -1; sh.fl[32] = 0;
+         if ( need > 0 && need <= (ldsleft / 4) * 3 )
+         {
+            /* (should the lists then not fit below it, the second allocation step gives the area up again: lists in global
+             * memory would cost every iteration what this saves once) */
+            sh.fl[31] = (int) (S1_DYN_LDS / 8) - (int) need;
+            sh.fl[32] = (int) need;
+            ldsleft -= (int) need;
+         }
+      }
       sh.fl[0] = ldsleft;
       *(double**) &sh.sc[0] = lp;               /* (handed to the second allocation step below) */
       *(double**) &sh.sc[1] = gp;
    }
-   __syncthreads();
+   __syncthreads(); S1_SETUP_STAMP(2);
+   const double* Dsrc = P.Dext;
+   const double* Asrc[S1_MAXB];
+   for (int k = 0; k < K; ++k)
+      Asrc[k] = P.A[k];
+   if ( sh.fl[31] >= 0 )
+   {
+      double* dst = sm + sh.fl[31];
+      const long long nd = (long long) q * m1;
+      for (long long e = tid; e < nd; e += S1_NT)
+         dst[e] = P.Dext[e];
+      Dsrc = dst;
+      dst += nd;
+      for (int k = 0; k < K; ++k)
+      {
+         const long long na = (long long) m1 * L.n[k] * L.n[k];
+         const double* src = P.A[k];
+         for (long long e = tid; e < na; e += S1_NT)
+            dst[e] = src[e];
+         Asrc[k] = dst;
+         dst += na;
+      }
+      __syncthreads(); S1_SETUP_STAMP(3);
+   }
 
    /* ---- counts: LP rows / columns, entries by variable / by position */
    for (int r = wave; r < q; r += S1_NW)
@@ -1422,7 +1464,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       for (int c0 = 0; c0 < m1; c0 += 64)
       {
          const int c = c0 + lane;
-         const bool nz = c < m1 && P.Dext[(long long) r * m1 + c] != 0.0;
+         const bool nz = c < m1 && Dsrc[(long long) r * m1 + c] != 0.0;
          cnt += __popcll(__ballot(nz));
       }
       if ( lane == 0 ) sh.roff[r] = cnt;
@@ -1433,7 +1475,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       for (int r0 = 0; r0 < q; r0 += 64)
       {
          const int r = r0 + lane;
-         const bool nz = r < q && P.Dext[(long long) r * m1 + c] != 0.0;
+         const bool nz = r < q && Dsrc[(long long) r * m1 + c] != 0.0;
          cnt += __popcll(__ballot(nz));
       }
       if ( lane == 0 ) sh.coff[c] = cnt;
@@ -1442,7 +1484,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
    {
       const S1Blk& B = sh.blk[k];
       const int n = B.n, n2 = n * n;
-      const double* A = P.A[k];
+      const double* A = Asrc[k];
       for (int i = wave; i < m1; i += S1_NW)
       {
          int cnt = 0;
@@ -1465,7 +1507,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          B.poff[e] = cnt;
       }
    }
-   __syncthreads();
+   __syncthreads(); S1_SETUP_STAMP(4);
    s1_exscan(sh.roff, q, sh, tid);
    s1_exscan(sh.coff, m1, sh, tid);
    for (int k = 0; k < K; ++k)
@@ -1475,9 +1517,12 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
    }
    if ( tid == 0 )
    {
+      for (int attempt = 0; attempt < 2; ++attempt)
+      {
       int ldsleft = sh.fl[0];
       double* lp = *(double**) &sh.sc[0];
       double* gp = *(double**) &sh.sc[1];
+      double* const gp0 = gp;
       auto take = [&](long long cnt) S1_INL -> double*
       {
          cnt = (cnt + 1) & ~1LL;
@@ -1526,8 +1571,21 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       sh.fl[2] = nnzA; sh.fl[3] = nnzD;
       sh.fl[4] = ((long long) (gp - P.gws) > P.gws_len) ? 1 : 0;
       sh.fl[30] = (gp == P.gws) ? 1 : 0;                   /* nothing went to global memory */
+      if ( gp == gp0 || sh.fl[31] < 0 )
+         break;
+      /* a list went to global memory while the staged copy of the caller's arrays holds LDS: give that area up (the passes that
+       * fill the lists read the caller's arrays again) and allocate once more */
+      sh.fl[0] += sh.fl[32];
+      sh.fl[31] = -1;
+      }
    }
-   __syncthreads();
+   __syncthreads(); S1_SETUP_STAMP(5);
+   if ( sh.fl[31] < 0 )
+   {
+      Dsrc = P.Dext;
+      for (int k = 0; k < K; ++k)
+         Asrc[k] = P.A[k];
+   }
    if ( sh.fl[1] || sh.fl[4] )
    {
       /* more work than one compute unit should take (dense matrices), or a workspace that is too small: decline */
@@ -1548,7 +1606,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       for (int c0 = 0; c0 < m1; c0 += 64)
       {
          const int c = c0 + lane;
-         const double v = c < m1 ? P.Dext[(long long) r * m1 + c] : 0.0;
+         const double v = c < m1 ? Dsrc[(long long) r * m1 + c] : 0.0;
          const unsigned long long msk = __ballot(v != 0.0);
          if ( v != 0.0 )
          {
@@ -1565,7 +1623,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       for (int r0 = 0; r0 < q; r0 += 64)
       {
          const int r = r0 + lane;
-         const double v = r < q ? P.Dext[(long long) r * m1 + c] : 0.0;
+         const double v = r < q ? Dsrc[(long long) r * m1 + c] : 0.0;
          const unsigned long long msk = __ballot(v != 0.0);
          if ( v != 0.0 )
          {
@@ -1580,7 +1638,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
    {
       const S1Blk& B = sh.blk[k];
       const int n = B.n, n2 = n * n;
-      const double* A = P.A[k];
+      const double* A = Asrc[k];
       for (int i = wave; i < m1; i += S1_NW)
       {
          int run = B.voff[i];
@@ -1617,7 +1675,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          }
       }
    }
-   __syncthreads();
+   __syncthreads(); S1_SETUP_STAMP(6);
    /* row slots of the light matrices */
    for (int k = 0; k < K; ++k)
    {
@@ -1633,7 +1691,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          }
          B.lro[a] = cnt;
       }
-      __syncthreads();
+      __syncthreads(); S1_SETUP_STAMP(7);
       s1_exscan(B.lro, B.nl, sh, tid);
       for (int a = tid; a < B.nl; a += S1_NT)
       {
@@ -1658,12 +1716,12 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       }
       if ( tid == 0 )
          B.nrs = B.lro[B.nl];
-      __syncthreads();
+      __syncthreads(); S1_SETUP_STAMP(8);
    }
    /* objective, norms */
    if ( tid < m )
       VEC(V_b)[tid] = P.b[tid];
-   __syncthreads();
+   __syncthreads(); S1_SETUP_STAMP(9);
    {
       double c2 = 0.0;
       for (int k = 0; k < K; ++k)
@@ -1697,7 +1755,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
             sh.sc[SC_NORMB] = sqrt(nb2);
       }
    }
-   __syncthreads();
+   __syncthreads(); S1_SETUP_STAMP(10);
    if ( tid == 0 )
    {
       double c2 = 0.0;
@@ -1705,7 +1763,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          c2 += sh.red[w][RS_NC2];
       sh.sc[SC_NORMC] = sqrt(c2);
    }
-   __syncthreads();
+   __syncthreads(); S1_SETUP_STAMP(11);
    const double normb = s1_uni(sh.sc[SC_NORMB]), normC = s1_uni(sh.sc[SC_NORMC]);
    S1_STAMP(0);
    auto body = [&](auto ALtag) S1_INL

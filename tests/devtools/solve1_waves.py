@@ -35,3 +35,5 @@ for b in range(60):
         tot += d.max()
     prev = st[b].max()
 print("sum of the phases of iteration 3: %.0f cycles; %d iterations" % (tot, info.iterations))
+su = hist.reshape(-1)[2048 + 480:2048 + 480 + 16]
+print("setup stamps (cycles since kernel start):", " ".join("%.0f" % v for v in su))
