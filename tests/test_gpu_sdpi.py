@@ -371,3 +371,37 @@ def test_preoptimal_solution_through_the_solver_interface(gpu):
         M[cc, rr] = vv
     assert np.linalg.eigvalsh(M)[0] > 0.0 and np.max(np.abs(M - np.array([[0.2, 0.4], [0.4, 0.8]]))) <= 0.1
     s.free()
+
+
+def test_deferred_setters_give_the_results_of_the_direct_ones(gpu, monkeypatch):
+    """A sequence of different random nodes through ONE backend (shapes change from node to node: buffers allocated with room are
+    re-used, the setters of a node wait as commands in the pinned arena for the launch of the solve) against a second backend with
+    HIPSDP_NO_STAGING=1 and HIPSDP_NO_SHAPE_REUSE=1 (every setter copies and waits, every shape allocates anew): same status, same
+    iteration count, objective and y to the last bit - the arithmetic of the solve does not depend on how its data arrived."""
+    sa, sb = new_solver(gpu), new_solver(gpu)
+    rng = np.random.default_rng(77)
+    done = 0
+    for t in range(30):
+        prob = _random_node(rng, nvars=int(rng.integers(4, 12)), sizes=[int(rng.integers(2, 7)), int(rng.integers(2, 9))],
+                            nlp=int(rng.integers(0, 6)), nfixed=int(rng.integers(0, 3)))
+        P = sdpi_prepare.prepare(prob)
+        if P.status != 'ok':
+            continue
+        monkeypatch.delenv("HIPSDP_NO_STAGING", raising=False)
+        monkeypatch.delenv("HIPSDP_NO_SHAPE_REUSE", raising=False)
+        rca, _, _ = sa.solve(P)
+        monkeypatch.setenv("HIPSDP_NO_STAGING", "1")
+        monkeypatch.setenv("HIPSDP_NO_SHAPE_REUSE", "1")
+        rcb, _, _ = sb.solve(P)
+        assert rca == rcb == sdpi_call.SCIP_OKAY
+        assert sa.flag("IsOptimal") == sb.flag("IsOptimal") and sa.flag("IsDualInfeasible") == sb.flag("IsDualInfeasible")
+        assert sa.iterations() == sb.iterations()
+        if sa.flag("IsOptimal"):
+            _, oa, ya = sa.dual_sol()
+            _, ob, yb = sb.dual_sol()
+            assert oa == ob and np.array_equal(ya, yb)
+        done += 1
+    monkeypatch.delenv("HIPSDP_NO_STAGING", raising=False)
+    monkeypatch.delenv("HIPSDP_NO_SHAPE_REUSE", raising=False)
+    sa.free(); sb.free()
+    assert done >= 15
