@@ -2556,12 +2556,18 @@ static int solve1_try(hipsdp_solver* s, hipsdp_info* info, bool* done)
    /* (read at every solve: tests and tools switch the path between two solves of one process) */
    int on = 1, prof = 0;
    double maxwork = 3e6;
+   /* largest block the kernel is offered by default: measured with sparse matrices (tests/devtools/solve1_sizes.py) it wins up to
+    * 16 rows (0.195 against 0.280 ms per iteration), ties at 24 and loses at 32 (0.62 against 0.43: the step lengths of a block of
+    * more than 16 rows are a one-wavefront tridiagonalisation out of LDS); it RUNS up to 64 rows (HIPSDP_SOLVE1_MAXN=64, tests) */
+   int maxn = 24;
    {
       const char* env = getenv("HIPSDP_SOLVE1");
       on = (env != NULL && env[0] == '0') ? 0 : 1;
       if ( getenv("HIPSDP_SOLVE1_MAXWORK") != NULL )
          maxwork = atof(getenv("HIPSDP_SOLVE1_MAXWORK"));
       prof = getenv("HIPSDP_SOLVE1_PROF") != NULL ? atoi(getenv("HIPSDP_SOLVE1_PROF")) : 0;
+      if ( getenv("HIPSDP_SOLVE1_MAXN") != NULL )
+         maxn = atoi(getenv("HIPSDP_SOLVE1_MAXN"));
    }
    const hipsdp_params& par = s->par;
    if ( !on || s->comm != NULL || s->shardA || s->schur_mode_forced || par.verbose || s->pc.on )
@@ -2574,7 +2580,7 @@ static int solve1_try(hipsdp_solver* s, hipsdp_info* info, bool* done)
       return HS_OK;
    for (int k = 0; k < K; ++k)
    {
-      if ( s->blk[k].sparse || s->blk[k].A == NULL )
+      if ( s->blk[k].sparse || s->blk[k].A == NULL || s->blk[k].n > maxn )
          return HS_OK;
       ns[k] = s->blk[k].n;
    }

@@ -63,6 +63,30 @@ def random_sparse_core(seed):
     return ipm_ref.CoreProblem(b, blocks, D, c)
 
 
+def sized_sparse_core(sizes, m, q, seed):
+    """given block sizes: m variables with three nonzeros per matrix and block (the constant matrices come out dense), q LP rows"""
+    rng = np.random.default_rng(seed)
+    ystar = rng.standard_normal(m)
+    blocks = []
+    for n in sizes:
+        A = np.zeros((m + 1, n, n))
+        for i in range(1, m + 1):
+            for _ in range(3):
+                r, c = rng.integers(0, n, 2)
+                v = rng.standard_normal()
+                A[i, r, c] += v
+                if r != c:
+                    A[i, c, r] += v
+        Zs = rng.standard_normal((n, n))
+        Zs = Zs @ Zs.T + 0.5 * np.eye(n)
+        A[0] = np.tensordot(ystar, A[1:], axes=(0, 0)) - Zs
+        blocks.append(A)
+    D = rng.standard_normal((q, m)) * (rng.random((q, m)) < 0.3)
+    c = D @ ystar - rng.random(q) - 0.1
+    b = sum(np.array([np.trace(A[i]) for i in range(1, m + 1)]) for A in blocks) + (D.T @ np.ones(q) if q else 0.0)
+    return ipm_ref.CoreProblem(b, blocks, D, c)
+
+
 def solve_one_launch(hb, core, monkeypatch, rows=128, **kw):
     monkeypatch.setenv("HIPSDP_SOLVE1", "1")
     monkeypatch.setenv("HIPSDP_SOLVE1_HIST", "1")
@@ -142,6 +166,33 @@ def test_random_sparse_problems_in_one_launch(gpu, seed, monkeypatch):
         assert abs(g["info"].dobj - ref.dobj) <= 1e-6 * (1 + abs(ref.dobj))
         ok, det = checker.certificate(core, g["y"], g["X"], g["lp"][0], 1e-5, 1e-5)
         assert ok, det
+
+
+@pytest.mark.parametrize("sizes,m,q", [([16], 40, 40), ([24], 40, 40), ([28], 44, 10), ([32], 48, 40), ([20, 20], 50, 20),
+                                       ([12, 12, 12], 40, 40), ([9] * 8, 60, 100), ([17, 3, 11, 2], 64, 30)])
+def test_blocks_up_to_the_limits_of_the_kernel_in_one_launch(gpu, sizes, m, q, monkeypatch):
+    """By default the kernel is offered blocks of at most 24 rows (above that the general path is faster: tests/devtools/
+    solve1_sizes.py); it RUNS whatever fits its LDS - here with HIPSDP_SOLVE1_MAXN=64: blocks of 16 < n <= 32 rows (step lengths by
+    the one-wavefront LDS tridiagonalisation, panel Cholesky + in-place inverse instead of the whole-matrix-per-lane forms, several
+    tiles per product), eight blocks, m = 64: same iterations as the oracle, iterate by iterate."""
+    monkeypatch.setenv("HIPSDP_SOLVE1_MAXN", "64")
+    core = sized_sparse_core(sizes, m, q, 5)
+    ref = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-6, feastol=1e-6, pabstol=1e-5))
+    g = solve_one_launch(gpu, core, monkeypatch, gaptol=1e-6, feastol=1e-6, pabstol=1e-5)
+    assert g["path"] == 1
+    assert g["info"].status == ref.status == 0
+    assert g["info"].iterations == ref.iterations
+    assert_history_matches(g, ref)
+    assert abs(g["info"].dobj - ref.dobj) <= 1e-6 * (1 + abs(ref.dobj))
+    ok, det = checker.certificate(core, g["y"], g["X"], g["lp"][0], 1e-5, 1e-5)
+    assert ok, det
+
+
+def test_blocks_above_24_rows_take_the_general_path_by_default(gpu, monkeypatch):
+    monkeypatch.delenv("HIPSDP_SOLVE1_MAXN", raising=False)
+    core = sized_sparse_core([28], 44, 10, 5)
+    g = solve_one_launch(gpu, core, monkeypatch, gaptol=1e-6, feastol=1e-6, pabstol=1e-5)
+    assert g["path"] == 0 and g["info"].status == 0
 
 
 def test_dense_matrices_are_declined_and_solved_by_the_general_path(gpu, monkeypatch):
