@@ -1174,7 +1174,15 @@ __device__ __forceinline__ double s1_lmin(double* W, int n, int p, int lane, dou
 /* ---- n x n x n product on the matrix cores: wavefront `wave` of the subset [w0, w0 + nw) takes the 16 x 16 tiles tbase + t with
  * (tbase + t) % nw == wave - w0.  la(i, k), lb(k, j): operand entries (called only inside the matrix); ep(i, j, value). */
 template<class LA, class LB, class EP>
+__device__ __forceinline__ void s1_mmk(int n, int nk, int wave, int lane, int w0, int nw, int& tbase, LA la, LB lb, EP ep);
+template<class LA, class LB, class EP>
 __device__ __forceinline__ void s1_mm(int n, int wave, int lane, int w0, int nw, int& tbase, LA la, LB lb, EP ep)
+{
+   s1_mmk(n, n, wave, lane, w0, nw, tbase, la, lb, ep);
+}
+/* (n x n result, inner dimension nk) */
+template<class LA, class LB, class EP>
+__device__ __forceinline__ void s1_mmk(int n, int nk, int wave, int lane, int w0, int nw, int& tbase, LA la, LB lb, EP ep)
 {
    const int nt = (n + 15) >> 4;
    const int ntile = nt * nt;
@@ -1190,7 +1198,7 @@ __device__ __forceinline__ void s1_mm(int n, int wave, int lane, int w0, int nw,
          v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #ifdef S1_NO_MFMA
          /* (developer switch: the same tile with scalar multiply-adds, for accuracy comparisons) */
-         for (int k = 0; k < n; ++k)
+         for (int k = 0; k < nk; ++k)
          {
             const double b = (cj < n) ? lb(k, cj) : 0.0;
 #pragma unroll
@@ -1201,14 +1209,19 @@ __device__ __forceinline__ void s1_mm(int n, int wave, int lane, int w0, int nw,
             }
          }
 #else
+         /* (operands loaded unconditionally at clamped indices and masked afterwards: a guarded load is a branch around it - four
+          * per K step, most of the time of a tile) */
+         const int ric = min(ri, n - 1), cjc = min(cj, n - 1);
 #pragma unroll 2
-         for (int kk = 0; kk < n; kk += 8)
+         for (int kk = 0; kk < nk; kk += 8)
          {
             const int k0 = kk + kq, k1 = kk + 4 + kq;
-            const double a0 = (ri < n && k0 < n) ? la(ri, k0) : 0.0;
-            const double b0 = (cj < n && k0 < n) ? lb(k0, cj) : 0.0;
-            const double a1 = (ri < n && k1 < n) ? la(ri, k1) : 0.0;
-            const double b1 = (cj < n && k1 < n) ? lb(k1, cj) : 0.0;
+            const int k0c = min(k0, nk - 1), k1c = min(k1, nk - 1);
+            const double a0l = la(ric, k0c), b0l = lb(k0c, cjc), a1l = la(ric, k1c), b1l = lb(k1c, cjc);
+            const double a0 = (ri < n && k0 < nk) ? a0l : 0.0;
+            const double b0 = (cj < n && k0 < nk) ? b0l : 0.0;
+            const double a1 = (ri < n && k1 < nk) ? a1l : 0.0;
+            const double b1 = (cj < n && k1 < nk) ? b1l : 0.0;
             acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
          }
@@ -1250,14 +1263,17 @@ __device__ __forceinline__ void s1_mm2(int n, int wave, int lane, int w0, int nw
          {
             const int k0 = kk + kq, k1 = kk + 4 + kq;
             const bool ra0 = ri < n && k0 < n, rb0 = cj < n && k0 < n, ra1 = ri < n && k1 < n, rb1 = cj < n && k1 < n;
-            const double a0 = ra0 ? la(ri, k0) : 0.0;
-            const double b0 = rb0 ? lb(k0, cj) : 0.0;
-            const double a1 = ra1 ? la(ri, k1) : 0.0;
-            const double b1 = rb1 ? lb(k1, cj) : 0.0;
-            const double c0 = ra0 ? la2(ri, k0) : 0.0;
-            const double d0 = rb0 ? lb2(k0, cj) : 0.0;
-            const double c1 = ra1 ? la2(ri, k1) : 0.0;
-            const double d1 = rb1 ? lb2(k1, cj) : 0.0;
+            const int ric = min(ri, n - 1), cjc = min(cj, n - 1), k0c = min(k0, n - 1), k1c = min(k1, n - 1);
+            const double a0l = la(ric, k0c), b0l = lb(k0c, cjc), a1l = la(ric, k1c), b1l = lb(k1c, cjc);
+            const double c0l = la2(ric, k0c), d0l = lb2(k0c, cjc), c1l = la2(ric, k1c), d1l = lb2(k1c, cjc);
+            const double a0 = ra0 ? a0l : 0.0;
+            const double b0 = rb0 ? b0l : 0.0;
+            const double a1 = ra1 ? a1l : 0.0;
+            const double b1 = rb1 ? b1l : 0.0;
+            const double c0 = ra0 ? c0l : 0.0;
+            const double d0 = rb0 ? d0l : 0.0;
+            const double c1 = ra1 ? c1l : 0.0;
+            const double d1 = rb1 ? d1l : 0.0;
             acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
             bcc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(c0, d0, bcc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
@@ -1676,6 +1692,34 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       }
    }
    __syncthreads(); S1_SETUP_STAMP(6);
+   /* which form of the LP part of the Schur matrix (lp_schur): walking the nonzeros costs what the busiest lane does - the entries of
+    * all LP rows its variable appears in, about 40 cycles each -, the product about 800 cycles per eight LP rows and tile */
+   {
+      int mine = 0;
+      for (int i = tid + 1; i < m1; i += S1_NT)
+      {
+         int c = 0;
+         for (int t = sh.coff[i]; t < sh.coff[i + 1]; ++t)
+            c += sh.roff[sh.crow[t] + 1] - sh.roff[sh.crow[t]];
+         mine = max(mine, c);
+      }
+      for (int off = 32; off > 0; off >>= 1)
+         mine = max(mine, __shfl_xor(mine, off, 64));
+      if ( lane == 0 )
+         sh.wtot[wave] = mine;
+   }
+   __syncthreads();
+   if ( tid == 0 )
+   {
+      int worst = 0;
+      for (int w = 0; w < S1_NW; ++w)
+         worst = max(worst, sh.wtot[w]);
+      const int nt1 = (m1 + 15) >> 4;
+      const int nwv = S1_NW - ((2 * K < S1_NW - 1) ? 2 * K : S1_NW - 1);
+      const double mmcost = (double) ((nt1 * nt1 + nwv - 1) / nwv) * (double) ((q + 7) >> 3) * 800.0;
+      sh.fl[33] = (sh.fl[31] >= 0 && mmcost < 40.0 * (double) worst + 2000.0) ? 1 : 0;
+   }
+   __syncthreads();
    /* row slots of the light matrices */
    for (int k = 0; k < K; ++k)
    {
@@ -1781,13 +1825,30 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
     * puts a block of 10 rows, 85 LP rows and the tile of a product all on wavefronts 0 and 1 while the other six wait at the
     * barrier; the products' tiles are dealt out from the last wavefront down) */
    auto tro = [&](int off) S1_INL -> int { const int t = tid - (off & (S1_NT - 1)); return t < 0 ? t + S1_NT : t; };
-   /* LP part of the Schur matrix (one wavefront; needs x / z in Q_sx) */
-   auto lp_schur = [&]() S1_INL
+   /* LP part of the Schur matrix, D^T diag(x / z) D (needs x / z in Q_sx); it also clears Mx.  Two forms.
+    * (a) When the dense copy of the caller's LP rows that the setup staged in LDS is still there and the cost model of the setup
+    * prefers it (sh.fl[33]: dense rows - cuts): a product on
+    * the matrix cores, (m + 1) x (m + 1) with inner dimension q, lower triangle written; wavefronts w0 .. NW - 1.
+    * (b) Otherwise one wavefront walks the nonzeros: lane l owns the rows l + 1 (and l + 65) of Mx, it walks the LP rows its variable
+    * appears in and adds their entries up to its own column; row 0 (the constant column, present in almost every bound row) has one
+    * entry, Mx[0][0]: a reduction over the wavefront.  [Form (b) alone until the end of round 4: 7 400 cycles on example_TT's
+    * bound rows, hidden beside the trial factorization - and 129 000 on 85 rows of density 0.3: eigenvector cuts are DENSE rows.
+    * Form (a) from global memory: 26 000 cycles, the latency of 44 dependent-by-issue global loads per tile.] */
+   auto lp_schur = [&](int w0) S1_INL
    {
-      /* LP part of the Schur matrix, D^T diag(x / z) D, lower triangle; it also clears Mx.  Lane l owns the rows l + 1 (and l + 65):
-       * it walks the LP rows its variable appears in and adds their entries up to its own column.  Row 0 (the constant
-       * column, present in almost every bound row) has one entry, Mx[0][0]: a reduction over the wavefront. */
       const double* sx = QV(Q_sx);
+      if ( sh.fl[33] )
+      {
+         const double* Dl = sm + sh.fl[31];
+         int tb = 0;
+         s1_mmk(m1, q, wave, lane, w0, S1_NW - w0, tb,
+            [&](int i, int kk) S1_INL { return Dl[kk * m1 + i] * sx[kk]; },
+            [&](int kk, int j) S1_INL { return Dl[kk * m1 + j]; },
+            [&](int i, int j, double v) S1_INL { if ( j <= i ) Mx[i * pm1 + j] = v; });
+         return;
+      }
+      if ( wave != S1_NW - 1 )
+         return;
       for (int i = lane + 1; i < m1; i += 64)
       {
          double* row = Mx + i * pm1;
@@ -1865,8 +1926,10 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       S1_BAR();
       /* (the LP part of the next Schur matrix rides along on the last wavefront: Mx is free between the corrector and the next
        * assembly, and a trial that fails repeats it) */
-      if ( wave == S1_NW - 1 )
-         lp_schur();
+      {
+         const int w0 = (2 * K < S1_NW - 1) ? 2 * K : S1_NW - 1;
+         lp_schur(w0);
+      }
       for (int t = wave; t < 2 * K; t += S1_NW)
       {
          const S1Blk& B = sh.blk[t >> 1];
@@ -2180,10 +2243,10 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
             const double* dX = sm + B.odX; const double* dZ = sm + B.odZ;
             double* T1 = sm + B.oT1; double* T2 = sm + B.oT2;
             s1_mm(n, wave, lane, 0, S1_NW, tb,
-               [&](int i, int kk) S1_INL { return kk <= i ? Lx[i * p + kk] : 0.0; }, [&](int kk, int j) S1_INL { return dX[kk * p + j]; },
+               [&](int i, int kk) S1_INL { const double v_ = Lx[i * p + kk]; return kk <= i ? v_ : 0.0; }, [&](int kk, int j) S1_INL { return dX[kk * p + j]; },
                [&](int i, int j, double v) S1_INL { T1[i * p + j] = v; });
             s1_mm(n, wave, lane, 0, S1_NW, tb,
-               [&](int i, int kk) S1_INL { return kk <= i ? Lz[i * p + kk] : 0.0; }, [&](int kk, int j) S1_INL { return dZ[kk * p + j]; },
+               [&](int i, int kk) S1_INL { const double v_ = Lz[i * p + kk]; return kk <= i ? v_ : 0.0; }, [&](int kk, int j) S1_INL { return dZ[kk * p + j]; },
                [&](int i, int j, double v) S1_INL { T2[i * p + j] = v; });
             if ( save )
                for (int e = tro(128); e < n * n; e += S1_NT)
@@ -2219,10 +2282,10 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
             double* dX = sm + B.odX; double* dZ = sm + B.odZ;
             const double* T1 = sm + B.oT1; const double* T2 = sm + B.oT2;
             s1_mm(n, wave, lane, 0, S1_NW, tb,
-               [&](int i, int kk) S1_INL { return T1[i * p + kk]; }, [&](int kk, int j) S1_INL { return kk <= j ? Lx[j * p + kk] : 0.0; },
+               [&](int i, int kk) S1_INL { return T1[i * p + kk]; }, [&](int kk, int j) S1_INL { const double v_ = Lx[j * p + kk]; return kk <= j ? v_ : 0.0; },
                [&](int i, int j, double v) S1_INL { dX[i * p + j] = v; });
             s1_mm(n, wave, lane, 0, S1_NW, tb,
-               [&](int i, int kk) S1_INL { return T2[i * p + kk]; }, [&](int kk, int j) S1_INL { return kk <= j ? Lz[j * p + kk] : 0.0; },
+               [&](int i, int kk) S1_INL { return T2[i * p + kk]; }, [&](int kk, int j) S1_INL { const double v_ = Lz[j * p + kk]; return kk <= j ? v_ : 0.0; },
                [&](int i, int j, double v) S1_INL { dZ[i * p + j] = v; });
          }
       }
@@ -2522,7 +2585,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
             const double* Lz = sm + B.oLz;
             double* Zi = sm + B.oZi;
             s1_mm(B.n, wave, lane, 0, S1_NW, tb,
-               [&](int i, int kk) S1_INL { return kk >= i ? Lz[kk * p + i] : 0.0; }, [&](int kk, int j) S1_INL { return kk >= j ? Lz[kk * p + j] : 0.0; },
+               [&](int i, int kk) S1_INL { const double v_ = Lz[kk * p + i]; return kk >= i ? v_ : 0.0; }, [&](int kk, int j) S1_INL { const double v_ = Lz[kk * p + j]; return kk >= j ? v_ : 0.0; },
                [&](int i, int j, double v) S1_INL { Zi[i * p + j] = v; });
          }
       }

@@ -13,9 +13,15 @@ hb = importlib.util.module_from_spec(spec); spec.loader.exec_module(hb)
 import ipm_ref, sdpa_io
 
 name = sys.argv[1] if len(sys.argv) > 1 else "example_TT.dat-s.gz"
-inst = sdpa_io.read_sdpa(os.path.join(ROOT, 'tests', 'golden', 'instances', name))
-D, c = sdpa_io.lp_dense(inst)
-core = ipm_ref.CoreProblem(inst.obj, sdpa_io.dense_blocks(inst), D, c)
+if name.startswith("random:"):
+    # random:<n,n,...>:<m>:<q>  - sparse variable matrices (three nonzeros each), dense constant matrices, LP rows of density 0.3
+    import test_gpu_solve1
+    _, ns, m_, q_ = name.split(":")
+    core = test_gpu_solve1.sized_sparse_core([int(v) for v in ns.split(",")], int(m_), int(q_), 5)
+else:
+    inst = sdpa_io.read_sdpa(os.path.join(ROOT, 'tests', 'golden', 'instances', name))
+    D, c = sdpa_io.lp_dense(inst)
+    core = ipm_ref.CoreProblem(inst.obj, sdpa_io.dense_blocks(inst), D, c)
 s = hb.Solver(0)
 s.load_core(core)
 info = s.solve(gaptol=1e-6, feastol=1e-6, pabstol=1e-5)
