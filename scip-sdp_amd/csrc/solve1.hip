@@ -1326,6 +1326,18 @@ __device__ __forceinline__ void s1_exscan(int* a, int len, S1Sh& sh, int tid)
    __syncthreads();
 }
 
+/* LP part of the Schur matrix as a product (see lp_schur in the kernel): a function of its own - it is the rare case (dense LP rows),
+ * and inlined its registers are added to what the iteration keeps alive around the whole-matrix-per-lane recurrences */
+__device__ __attribute__((noinline)) void s1_lp_schur_mm(const double* Dl, const double* sx, double* Mx, int m1, int q, int pm1, int wave,
+   int lane, int w0)
+{
+   int tb = 0;
+   s1_mmk(m1, q, wave, lane, w0, S1_NW - w0, tb,
+      [&](int i, int kk) S1_INL { return Dl[kk * m1 + i] * sx[kk]; },
+      [&](int kk, int j) S1_INL { return Dl[kk * m1 + j]; },
+      [&](int i, int j, double v) S1_INL { if ( j <= i ) Mx[i * pm1 + j] = v; });
+}
+
 /* pointers to the lists and cold matrices: they live in LDS while it lasts, else in the workspace in global memory, and are kept as
  * generic pointers.  A generic load counts on both memory counters and the compiler waits for ALL outstanding loads before every
  * use; when everything is in LDS (every B&B-sized instance of the reference) the iteration is compiled with LDS-typed pointers. */
@@ -1839,12 +1851,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       const double* sx = QV(Q_sx);
       if ( sh.fl[33] )
       {
-         const double* Dl = sm + sh.fl[31];
-         int tb = 0;
-         s1_mmk(m1, q, wave, lane, w0, S1_NW - w0, tb,
-            [&](int i, int kk) S1_INL { return Dl[kk * m1 + i] * sx[kk]; },
-            [&](int kk, int j) S1_INL { return Dl[kk * m1 + j]; },
-            [&](int i, int j, double v) S1_INL { if ( j <= i ) Mx[i * pm1 + j] = v; });
+         s1_lp_schur_mm(sm + sh.fl[31], sx, Mx, m1, q, pm1, wave, lane, w0);
          return;
       }
       if ( wave != S1_NW - 1 )
