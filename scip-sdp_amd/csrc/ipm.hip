@@ -2675,8 +2675,9 @@ static int solve1_try(hipsdp_solver* s, hipsdp_info* info, bool* done)
    const int status = (int) o[0];
    if ( status == -2 )
       return HS_OK;                              /* declined: the general path takes the problem */
-   /* the iterate is complete in device memory when the kernel has retired (the read-backs use the copy engine) */
-   HS_HIP( hipStreamSynchronize(st) );
+   /* the result block, y, x and z are in pinned memory, published before the sequence word; X and Z in device memory are complete
+    * when the kernel has retired - whoever reads them waits for the queue first (stage_sync), this call does not */
+   s->stage_pending = true;
    memset(info, 0, sizeof(*info));
    s->tau = o[9];
    s->kappa = o[10];
@@ -2798,7 +2799,7 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       HS_CALL( solve1_try(s, info, &done1) );
       if ( done1 )
       {
-         s->stage_pending = false; s->stage_off = 0;           /* (the kernel has retired, and with it everything queued before it) */
+         s->stage_off = 0;                                      /* (the kernel ran the commands and read their data at its start) */
          return HIPSDP_OK;
       }
    }
