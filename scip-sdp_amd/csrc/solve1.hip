@@ -71,7 +71,9 @@ struct S1Lay
 static __host__ __device__ inline int s1_layout(int m, int q, int K, const int* n, S1Lay& L)
 {
    L.m = m; L.m1 = m + 1; L.q = q; L.K = K;
-   L.pm1 = (m + 1) | 1; L.pm = ((m + 7) & ~7) | 1;          /* Lm: panels of eight columns are read whole */
+   /* the factor of M overwrites M in place (rows / columns 1 .. m of the extended matrix): the pitch covers column 0 and whole panels
+    * of eight columns (the substitutions read them unmasked; the padding stays zero from the start of the solve) */
+   L.pm1 = (((m + 7) & ~7) + 1) | 1; L.pm = L.pm1;
    L.VL = (m + 2) & ~1; L.QL = (q + 1) & ~1;
    int o = 0, sum = 0;
    for (int k = 0; k < K; ++k)
@@ -85,7 +87,7 @@ static __host__ __device__ inline int s1_layout(int m, int q, int K, const int* 
    for (int k = 0; k < K; ++k) { L.oLz[k] = o; o += L.np[k]; }
    for (int k = 0; k < K; ++k) { L.oEig[k] = o; o += 8 * ((n[k] + 1) & ~1) + 64; }
    L.oMx = o; o += (L.m1 * L.pm1 + 1) & ~1;
-   L.oLm = o; o += (m * L.pm + 1) & ~1;
+   L.oLm = L.oMx + L.pm1 + 1;
    L.oVec = o; o += V_COUNT * L.VL;
    L.oQ = o; o += Q_COUNT * L.QL;
    /* scratch region (dX, dZ, T1, T2 of all blocks, contiguous; the Schur phase uses it as a pool of U_j buffers) last, so that
@@ -1385,6 +1387,10 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
 #define VEC(id) (sm + oVec + (id) * VL)
 #define QV(id) (sm + oQ + (id) * QL)
    double* const out = P.out;
+   /* (the extended Schur matrix starts from zeros: its upper triangle and the padding columns are never written and are read -
+    * unmasked - by the substitutions with the factor that overwrites it) */
+   for (int e = tid; e < m1 * pm1; e += S1_NT)
+      Mx[e] = 0.0;
 
    /* ---- flexible part: offset arrays first (their sizes follow from the shape), the counts decide the rest */
    if ( tid == 0 )
@@ -2762,23 +2768,13 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       S1_BAR();
       S1_STAMP(5);
 
-      /* lower triangle of M into Lm (zero above the diagonal, out to the padded width) and its first column into g: all threads
-       * (one wavefront copying row by row took 5000 cycles in front of the factorization) */
-      {
-         const int wd = pm - 1;
-         for (int e = tid; e < m * wd; e += S1_NT)
-         {
-            const int r = s1_div(e, wd), j = e - r * wd;
-            Lm[r * pm + j] = (j <= r) ? Mx[(r + 1) * pm1 + 1 + j] : 0.0;
-         }
-         if ( tid < m )
-            VEC(V_g)[tid] = Mx[(tid + 1) * pm1];
-      }
-      S1_BAR();
       /* ================= factorization of M and the two solves (wavefront 0) beside the first product of the predictor,
        * T1 = X Rd (the others) */
       if ( wave == 0 )
       {
+         /* (the factor overwrites M where it stands; its first column, g, is taken out first) */
+         if ( lane < m )
+            VEC(V_g)[lane] = Mx[(lane + 1) * pm1];
          const double dg0 = (lane < m) ? Lm[lane * pm + lane] : 1.0;
          double mdiag;
          int nforced;
@@ -3010,14 +3006,8 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
             const double e = (lane < m) ? VEC(V_t1)[lane + 1] - eta * VEC(V_rp)[lane] - VEC(V_b)[lane] * dt : 0.0;
             const double e2 = s1_wsum(e * e);
             const double dy2 = s1_wsum(lane < m ? VEC(V_dy)[lane] * VEC(V_dy)[lane] : 0.0);
-            /* residual of the solve itself: M dy - h + (b - g) dtau with the assembled matrix (lower triangle of Mx) */
-            double rs = 0.0;
-            if ( lane < m )
-            {
-               for (int j = 0; j < m; ++j)
-                  rs = fma((j <= lane) ? Mx[(lane + 1) * pm1 + j + 1] : Mx[(j + 1) * pm1 + lane + 1], VEC(V_dy)[j], rs);
-               rs = rs - VEC(V_h)[lane] + (VEC(V_b)[lane] - VEC(V_g)[lane]) * dt;
-            }
+            /* (the residual of the solve itself cannot be formed any more: the factor has overwritten M) */
+            const double rs = 0.0;
             const double h2 = s1_wsum(rs * rs);
             if ( lane == 0 && it < P.hist_len )
             {
