@@ -2545,8 +2545,8 @@ extern "C" int hipsdp_get_assembly_clock(hipsdp_solver* s, double* ghz)
  * solve ran there; *done = false: not this path's problem (shape, options) or the kernel declined (too much work for one compute
  * unit) - nothing has been touched and the general path below takes over.  HIPSDP_SOLVE1=0 switches the path off. */
 #define S1_HIST_MAX 256
-#define S1_SOL_OFF (HS_S1_OUT_DOUBLES + 8 + 16 * S1_HIST_MAX)       /* y (64), x (4096), z (4096) */
-#define S1_HOST_DOUBLES (S1_SOL_OFF + 64 + 2 * 4096)
+#define S1_SOL_OFF (HS_S1_OUT_DOUBLES + 8 + 16 * S1_HIST_MAX)       /* y (128), x (4096), z (4096) */
+#define S1_HOST_DOUBLES (S1_SOL_OFF + 128 + 2 * 4096)
 static long long g_solve1_solves = 0;      /* solves of this process that ran in the one launch (bench.py reports the share) */
 static int solve1_try(hipsdp_solver* s, hipsdp_info* info, bool* done)
 {
@@ -2641,7 +2641,7 @@ static int solve1_try(hipsdp_solver* s, hipsdp_info* info, bool* done)
    a.out = s->s1_host_dev;
    a.hist = (getenv("HIPSDP_SOLVE1_HIST") != NULL && getenv("HIPSDP_SOLVE1_HIST")[0] != '0') ? s->s1_host_dev + HS_S1_OUT_DOUBLES + 8 : NULL;
    a.hist_len = S1_HIST_MAX;
-   a.hy = s->s1_host_dev + S1_SOL_OFF; a.hx = a.hy + 64; a.hz = a.hx + 4096;
+   a.hy = s->s1_host_dev + S1_SOL_OFF; a.hx = a.hy + 128; a.hz = a.hx + 4096;
    a.seq = ++s->s1_seq;
    a.flag = reinterpret_cast<unsigned long long*>(s->s1_host_dev + HS_S1_OUT_DOUBLES);
    a.cmds = s->arena_d; a.ncmd = s->ncmd;         /* the node's setters: run by the same launch */
@@ -3792,7 +3792,7 @@ static int read_scaled(hipsdp_solver* s, const double* d, long long n, double sc
    if ( s->s1_sol_host && s->s1_host != NULL && (d == s->y || d == s->x || d == s->z) )
    {
       /* the one-launch solve left y, x, z in pinned memory as well */
-      const double* h = s->s1_host + S1_SOL_OFF + (d == s->y ? 0 : (d == s->x ? 64 : 64 + 4096));
+      const double* h = s->s1_host + S1_SOL_OFF + (d == s->y ? 0 : (d == s->x ? 128 : 128 + 4096));
       for (long long i = 0; i < n; ++i)
          out[i] = h[i] * scale;
       return HIPSDP_OK;

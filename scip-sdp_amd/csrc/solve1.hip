@@ -38,7 +38,7 @@
 #define S1_NW 8
 #endif
 #define S1_MAXB HS_S1_MAXBLK
-#define S1_MAXM 64
+#define S1_MAXM 128                                         /* (above 64: two rows per lane in the factorization of M and the substitutions) */
 #define S1_MAXN 64
 #define S1_STATIC_LDS 5632                                  /* bytes kept for the static arrays below */
 #define S1_DYN_LDS (160 * 1024 - S1_STATIC_LDS)
@@ -500,6 +500,195 @@ __device__ __forceinline__ void s1_llt_solve(const double* L, int m, int p, int 
    }
    x0 = a0 * dinv;
    x1 = a1 * dinv;
+}
+
+/* ==== 64 < m <= 128: the factor of M and the substitutions with TWO rows per lane (lane and lane + 64) ====
+ * Functions of their own (the common case m <= 64 keeps its registers); results go through LDS vectors. */
+
+/* s1_cholp(psd = true, keepdiag = false) for 64 < n <= 128; dg: the original diagonal (LDS, n entries), dinv_out: 1 / (diagonal
+ * entries of the factor) (LDS, n entries); returns the forced-pivot counter */
+__device__ __attribute__((noinline)) int s1_cholp2(double* A, int n, int p, int lane, const double* dg, int rule, double* dinv_out)
+{
+   const double regtol = 1e-13;
+   const int lr = lane & 15, kq = lane >> 4;
+   const bool has1 = lane + 64 < n;
+   const double dg0 = dg[lane], dg1 = has1 ? dg[lane + 64] : 1.0;
+   const double thr0 = fmax(regtol * dg0, 1e-300), thr1 = fmax(regtol * dg1, 1e-300);
+   double diag0 = 1.0, diag1 = 1.0;
+   int nforced = 0;
+   for (int k0 = 0; k0 < n; k0 += 8)
+   {
+      if ( k0 > 0 )
+      {
+         const int nm1 = n - 1;
+         for (int T = k0 >> 4; 16 * T < n; ++T)
+         {
+            const int ar = min(16 * T + lr, nm1), br = min(k0 + lr, nm1);
+            const double* pa = A + ar * p + kq;
+            const double* pb = A + br * p + kq;
+            const int cc = min(k0 + lr, nm1);
+            v4d acc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+               acc[r] = A[min(16 * T + kq + 4 * r, nm1) * p + cc];
+            for (int kk = 0; kk < k0; kk += 8)
+            {
+               const double a0 = -pa[kk], b0 = pb[kk];
+               const double a1 = -pa[kk + 4], b1 = pb[kk + 4];
+               acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+               acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+            {
+               const int row = 16 * T + kq + 4 * r;
+               if ( lr < 8 && row < n && row >= k0 + lr && k0 + lr < n )
+                  A[row * p + k0 + lr] = acc[r];
+            }
+         }
+         S1_WSYNC();
+      }
+      const bool hi = k0 >= 64;                           /* (a panel lies in one half: 64 is a multiple of 8) */
+      double a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+      {
+         a[u] = (lane >= k0 + u && k0 + u < n) ? A[lane * p + k0 + u] : 0.0;
+         b[u] = (has1 && lane + 64 >= k0 + u && k0 + u < n) ? A[(lane + 64) * p + k0 + u] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+      {
+         const int k = k0 + u;
+         if ( k < n )
+         {
+            const int kl = k & 63;
+            double d = hi ? s1_lane(b[u], kl) : s1_lane(a[u], kl);
+            bool zero = false;
+            if ( !(d > (hi ? s1_lane(thr1, kl) : s1_lane(thr0, kl))) )
+            {
+               const double mkk = hi ? s1_lane(dg1, kl) : s1_lane(dg0, kl);
+               zero = (rule == 1) || (rule == 2 && !(d > 0.0)) || (rule == 3 && !(d > 1.78e-15 * (double) (k + 1) * mkk));
+               d = (mkk > 1e-280) ? regtol * mkk : 1.0;
+               nforced += zero ? 65536 : 1;
+            }
+            const double rs = s1_rsqrt(d);
+            const double sd = d * rs;
+            if ( lane == kl )
+            {
+               if ( hi ) diag1 = sd; else diag0 = sd;
+            }
+            const double lua = (!hi && lane > k && !zero) ? a[u] * rs : 0.0;
+            const double lub = ((!hi || lane + 64 > k) && !zero) ? b[u] * rs : 0.0;
+            a[u] = lua; b[u] = lub;
+#pragma unroll
+            for (int v = u + 1; v < 8; ++v)
+            {
+               const double piv = hi ? s1_lane(lub, (k0 + v) & 63) : s1_lane(lua, (k0 + v) & 63);
+               a[v] = fma(-lua, piv, a[v]);
+               b[v] = fma(-lub, piv, b[v]);
+            }
+         }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+         if ( k0 + u < n )
+         {
+            A[lane * p + k0 + u] = a[u];
+            if ( has1 )
+               A[(lane + 64) * p + k0 + u] = b[u];
+         }
+      S1_WSYNC();
+   }
+   dinv_out[lane] = s1_rcp(diag0);
+   if ( has1 )
+      dinv_out[lane + 64] = s1_rcp(diag1);
+   S1_WSYNC();
+   return nforced;
+}
+
+/* s1_llt_solve for 64 < m <= 128: right-hand sides r0 (and r1) and results o0 (o1) are LDS vectors, dinv the vector s1_cholp2 left */
+template<bool TWO>
+__device__ __attribute__((noinline)) void s1_llt_solve2(const double* L, int m, int p, int lane, const double* dinv, const double* r0,
+   const double* r1, double* o0, double* o1)
+{
+   const bool has1 = lane + 64 < m;
+   const int rh = has1 ? lane + 64 : 0;
+   const double di0 = dinv[lane], di1 = has1 ? dinv[lane + 64] : 1.0;
+   double a0 = r0[lane], a0h = has1 ? r0[lane + 64] : 0.0;
+   double a1 = TWO ? r1[lane] : 0.0, a1h = (TWO && has1) ? r1[lane + 64] : 0.0;
+   const int nb = (m + 7) >> 3;
+   {
+      const double* row = L + lane * p;
+      const double* rowh = L + rh * p;
+      for (int b = 0; b < nb; ++b)
+      {
+         const int k0 = 8 * b;
+         const bool hi = k0 >= 64;
+         double c[8], ch[8];
+#pragma unroll
+         for (int u = 0; u < 8; ++u)
+         {
+            c[u] = row[k0 + u];
+            const double v = rowh[k0 + u];
+            ch[u] = has1 ? v : 0.0;
+         }
+#pragma unroll
+         for (int u = 0; u < 8; ++u)
+         {
+            const int kl = (k0 + u) & 63;
+            const double t0 = hi ? a0h * di1 : a0 * di0, t1 = hi ? a1h * di1 : a1 * di0;
+            const double y0 = s1_lane(t0, kl);
+            const double y1 = TWO ? s1_lane(t1, kl) : 0.0;
+            a0 = fma(-c[u], y0, a0); a0h = fma(-ch[u], y0, a0h);
+            if ( TWO )
+            {
+               a1 = fma(-c[u], y1, a1); a1h = fma(-ch[u], y1, a1h);
+            }
+         }
+      }
+   }
+   a0 *= di0; a0h *= di1; a1 *= di0; a1h *= di1;
+   {
+      /* rows k0 .. k0 + 7 of the factor, columns lane and lane + 64; rows past m - 1 are clamped to row 0, which is all zero */
+      const double* col = L + lane;
+      const double* colh = L + rh;
+      for (int b = nb - 1; b >= 0; --b)
+      {
+         const int k0 = 8 * b;
+         const bool hi = k0 >= 64;
+         double c[8], ch[8];
+#pragma unroll
+         for (int u = 0; u < 8; ++u)
+         {
+            const int rr = (k0 + u < m) ? k0 + u : 0;
+            c[u] = col[rr * p];
+            const double v = colh[rr * p];
+            ch[u] = has1 ? v : 0.0;
+         }
+#pragma unroll
+         for (int u = 7; u >= 0; --u)
+         {
+            const int kl = (k0 + u) & 63;
+            const double t0 = hi ? a0h * di1 : a0 * di0, t1 = hi ? a1h * di1 : a1 * di0;
+            const double y0 = s1_lane(t0, kl);
+            const double y1 = TWO ? s1_lane(t1, kl) : 0.0;
+            a0 = fma(-c[u], y0, a0); a0h = fma(-ch[u], y0, a0h);
+            if ( TWO )
+            {
+               a1 = fma(-c[u], y1, a1); a1h = fma(-ch[u], y1, a1h);
+            }
+         }
+      }
+   }
+   o0[lane] = a0 * di0;
+   if ( has1 ) o0[lane + 64] = a0h * di1;
+   if ( TWO )
+   {
+      o1[lane] = a1 * di0;
+      if ( has1 ) o1[lane + 64] = a1h * di1;
+   }
+   S1_WSYNC();
 }
 
 /* ---- one wavefront: Li = L^-1 (lower), lane = column; in place when Li == L */
@@ -1811,8 +2000,10 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          sh.red[wave][RS_NC2] = c2;
       if ( wave == 0 )
       {
-         const double bb = (lane < m) ? VEC(V_b)[lane] : 0.0;
-         const double nb2 = s1_wsum(bb * bb);
+         double bsq = 0.0;
+         for (int i = lane; i < m; i += 64)
+            bsq = fma(VEC(V_b)[i], VEC(V_b)[i], bsq);
+         const double nb2 = s1_wsum(bsq);
          if ( lane == 0 )
             sh.sc[SC_NORMB] = sqrt(nb2);
       }
@@ -2135,6 +2326,14 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
    auto msolve2 = [&](const double* r0, const double* r1, double* o0, double* o1) S1_INL
    {
       const bool two = (r1 != NULL);
+      if ( m > 64 )
+      {
+         if ( two )
+            s1_llt_solve2<true>(Lm, m, pm, lane, VEC(V_dg), r0, r1, o0, o1);
+         else
+            s1_llt_solve2<false>(Lm, m, pm, lane, VEC(V_dg), r0, r1, o0, o1);
+         return;
+      }
       double x0 = (lane < m) ? r0[lane] : 0.0;
       double x1 = (two && lane < m) ? r1[lane] : 0.0;
       if ( two )
@@ -2176,13 +2375,18 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
    auto finish_dir = [&](double sigmu, double etk, double rg) S1_INL
    {
       const double tau = sh.sc[SC_TAU], kappa = sh.sc[SC_KAPPA];
-      if ( lane < m )
-         VEC(V_h)[lane] = VEC(V_AH)[lane + 1] - eta * VEC(V_rp)[lane];
+      for (int i = lane; i < m; i += 64)
+         VEC(V_h)[i] = VEC(V_AH)[i + 1] - eta * VEC(V_rp)[i];
       S1_WSYNC();
       msolve2(VEC(V_h), NULL, VEC(V_u1), NULL);
-      const double u1 = lane < m ? VEC(V_u1)[lane] : 0.0;
-      const double bu1 = s1_wsum(lane < m ? VEC(V_b)[lane] * u1 : 0.0);
-      const double wrp = s1_wsum(lane < m ? VEC(V_w)[lane] * VEC(V_rp)[lane] : 0.0);
+      double bu1 = 0.0, wrp = 0.0;
+      for (int i = lane; i < m; i += 64)
+      {
+         bu1 = fma(VEC(V_b)[i], VEC(V_u1)[i], bu1);
+         wrp = fma(VEC(V_w)[i], VEC(V_rp)[i], wrp);
+      }
+      bu1 = s1_wsum(bu1);
+      wrp = s1_wsum(wrp);
       const double S0 = red_sum(RS_S0);
       const double BH = red_sum(RS_BH);
       const double it_ = s1_rcp(tau);
@@ -2190,11 +2394,11 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       const double num = -eta * rg + (sigmu - tau * kappa - etk) * it_ - BH - eta * wrp + bu1;
       const double dtau = num * s1_rcp(den);
       const double dkappa = (sigmu - tau * kappa - etk - kappa * dtau) * it_;
-      if ( lane < m )
+      for (int i = lane; i < m; i += 64)
       {
-         const double dy = u1 - VEC(V_u2)[lane] * dtau;
-         VEC(V_dy)[lane] = dy;
-         VEC(V_cv)[lane + 1] = dy;
+         const double dy = VEC(V_u1)[i] - VEC(V_u2)[i] * dtau;
+         VEC(V_dy)[i] = dy;
+         VEC(V_cv)[i + 1] = dy;
       }
       if ( lane == 0 )
       {
@@ -2773,14 +2977,25 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       if ( wave == 0 )
       {
          /* (the factor overwrites M where it stands; its first column, g, is taken out first) */
-         if ( lane < m )
-            VEC(V_g)[lane] = Mx[(lane + 1) * pm1];
+         for (int i = lane; i < m; i += 64)
+         {
+            VEC(V_g)[i] = Mx[(i + 1) * pm1];
+            if ( m > 64 )
+               VEC(V_dg)[i] = Lm[i * pm + i];
+         }
          const double dg0 = (lane < m) ? Lm[lane * pm + lane] : 1.0;
          double mdiag;
          int nforced;
          long long tq0 = 0;
          if ( P.prof_on ) tq0 = clock64();
-         (void) s1_cholp(Lm, m, pm, lane, true, dg0, P.pivot_rule, false, mdiag, nforced);
+         if ( m > 64 )
+         {
+            S1_WSYNC();
+            nforced = s1_cholp2(Lm, m, pm, lane, VEC(V_dg), P.pivot_rule, VEC(V_dg));
+            mdiag = 1.0;
+         }
+         else
+            (void) s1_cholp(Lm, m, pm, lane, true, dg0, P.pivot_rule, false, mdiag, nforced);
          if ( lane == 0 )
             sh.fl[6] = nforced;
          mdinv = s1_rcp(mdiag);
@@ -2788,17 +3003,19 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          msolve2(VEC(V_g), VEC(V_b), VEC(V_w), VEC(V_ub));
          if ( P.prof_on && lane == 0 ) { const long long tq1 = clock64(); sh.prof[21] += (double) (tq1 - tq0); }
          bool u2bad = false;
-         if ( lane < m )
+         double bubp = 0.0;
+         for (int i = lane; i < m; i += 64)
          {
-            const double w = VEC(V_w)[lane], ub = VEC(V_ub)[lane];
-            VEC(V_u2)[lane] = ub - w;
-            VEC(V_wt)[lane + 1] = -w;
-            u2bad = !(fabs(ub - w) < 1e300);
+            const double w = VEC(V_w)[i], ub = VEC(V_ub)[i];
+            VEC(V_u2)[i] = ub - w;
+            VEC(V_wt)[i + 1] = -w;
+            u2bad = u2bad || !(fabs(ub - w) < 1e300);
+            bubp = fma(VEC(V_b)[i], ub, bubp);
          }
          const unsigned long long anybad = __ballot(u2bad);
          if ( lane == 0 )
             sh.fl[7] = (anybad != 0ULL) ? 1 : 0;
-         const double bub = s1_wsum(lane < m ? VEC(V_b)[lane] * VEC(V_ub)[lane] : 0.0);
+         const double bub = s1_wsum(bubp);
          if ( lane == 0 )
          {
             VEC(V_wt)[0] = 1.0;
@@ -3003,9 +3220,15 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          S1_BAR();
          if ( wave == 0 )
          {
-            const double e = (lane < m) ? VEC(V_t1)[lane + 1] - eta * VEC(V_rp)[lane] - VEC(V_b)[lane] * dt : 0.0;
-            const double e2 = s1_wsum(e * e);
-            const double dy2 = s1_wsum(lane < m ? VEC(V_dy)[lane] * VEC(V_dy)[lane] : 0.0);
+            double e2p = 0.0, dy2p = 0.0;
+            for (int i = lane; i < m; i += 64)
+            {
+               const double e = VEC(V_t1)[i + 1] - eta * VEC(V_rp)[i] - VEC(V_b)[i] * dt;
+               e2p = fma(e, e, e2p);
+               dy2p = fma(VEC(V_dy)[i], VEC(V_dy)[i], dy2p);
+            }
+            const double e2 = s1_wsum(e2p);
+            const double dy2 = s1_wsum(dy2p);
             /* (the residual of the solve itself cannot be formed any more: the factor has overwritten M) */
             const double rs = 0.0;
             const double h2 = s1_wsum(rs * rs);

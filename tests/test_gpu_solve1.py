@@ -137,7 +137,8 @@ def test_reference_cases_in_one_launch(gpu, case, monkeypatch):
     assert gen["path"] == 0 and gen["info"].status == ref.status and gen["info"].iterations == ref.iterations
 
 
-@pytest.mark.parametrize("name", ["example_small.dat-s", "example_TT.dat-s.gz", "example_inf.dat-s", "example_tightenmatrices.dat-s"])
+@pytest.mark.parametrize("name", ["example_small.dat-s", "example_TT.dat-s.gz", "example_inf.dat-s", "example_tightenmatrices.dat-s",
+                                  "example_MkP.dat-s.gz"])
 def test_reference_instances_in_one_launch(gpu, name, monkeypatch):
     core = instance_core(name)
     ref = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-6, feastol=1e-6, pabstol=1e-5))
@@ -169,12 +170,14 @@ def test_random_sparse_problems_in_one_launch(gpu, seed, monkeypatch):
 
 
 @pytest.mark.parametrize("sizes,m,q", [([16], 40, 40), ([24], 40, 40), ([28], 44, 10), ([32], 48, 40), ([20, 20], 50, 20),
-                                       ([12, 12, 12], 40, 40), ([9] * 8, 60, 100), ([17, 3, 11, 2], 64, 30)])
+                                       ([12, 12, 12], 40, 40), ([9] * 8, 60, 100), ([17, 3, 11, 2], 64, 30),
+                                       ([12], 65, 20), ([10, 9], 90, 60), ([14, 8], 104, 12)])
 def test_blocks_up_to_the_limits_of_the_kernel_in_one_launch(gpu, sizes, m, q, monkeypatch):
     """By default the kernel is offered blocks of at most 24 rows (above that the general path is faster: tests/devtools/
     solve1_sizes.py); it RUNS whatever fits its LDS - here with HIPSDP_SOLVE1_MAXN=64: blocks of 16 < n <= 32 rows (step lengths by
     the one-wavefront LDS tridiagonalisation, panel Cholesky + in-place inverse instead of the whole-matrix-per-lane forms, several
-    tiles per product), eight blocks, m = 64: same iterations as the oracle, iterate by iterate."""
+    tiles per product), eight blocks, m = 64, and 64 < m <= 108 (two rows per lane in the factorization of M and the substitutions,
+    lists partly outside LDS): same iterations as the oracle, iterate by iterate."""
     monkeypatch.setenv("HIPSDP_SOLVE1_MAXN", "64")
     core = sized_sparse_core(sizes, m, q, 5)
     ref = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-6, feastol=1e-6, pabstol=1e-5))
