@@ -171,7 +171,7 @@ struct hipsdp_solver
    hipsdp_params par;
    PhaseClock pc;
    /* shader clock during the Schur assemblies (hipsdp_set_clock_sampling): 4 words per assembly */
-   bool clk_on; unsigned long long* clk_buf; int clk_n; double clk_ghz;
+   bool clk_on; unsigned long long* clk_buf; int clk_n; double clk_ghz; hipStream_t clk_stream;
    /* one-launch solve of B&B-sized problems (csrc/solve1.hip) */
    double* s1_ws;          /* device workspace (cold matrices and nonzero lists that do not fit into LDS) */
    long long s1_ws_len;
@@ -527,7 +527,7 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
       s->use_publish = !(rb != NULL && rb[0] == 'c');
    }
    s->hsc_cap = 0;
-   s->clk_on = false; s->clk_buf = NULL; s->clk_n = 0; s->clk_ghz = 0.0;
+   s->clk_on = false; s->clk_buf = NULL; s->clk_n = 0; s->clk_ghz = 0.0; s->clk_stream = NULL;
    s->s1_ws = NULL; s->s1_ws_len = 0; s->s1_host = NULL; s->s1_host_dev = NULL; s->s1_seq = 0; s->s1_last = 0; s->s1_sol_host = false; s->zero_b = false; s->zero_D = false;
    s->arena_h = NULL; s->arena_d = NULL; s->arena_cap = 0; s->stage_off = 0; s->stage_pending = false; s->ncmd = 0; s->m_alloc = 0; s->q_alloc = 0;
    s->trsv_ws = NULL;
@@ -597,6 +597,8 @@ extern "C" void hipsdp_free(hipsdp_solver** ps)
    s->s1_ws = NULL;
    if ( s->clk_buf != NULL ) (void) hipFree(s->clk_buf);
    s->clk_buf = NULL;
+   if ( s->clk_stream != NULL ) (void) hipStreamDestroy(s->clk_stream);
+   s->clk_stream = NULL;
    for (auto& mk : s->pc.marks) (void) hipEventDestroy(mk.second);
    for (hipEvent_t e : s->pc.pool) (void) hipEventDestroy(e);
    for (int b = 0; b < 2; ++b)
@@ -2517,10 +2519,30 @@ extern "C" int hipsdp_solve(hipsdp_solver* s, const hipsdp_params* params, hipsd
 }
 
 #define CLK_MAX_ASSEMBLIES 256
-__global__ void k_clock_sample(unsigned long long* __restrict__ out)
+/* Shader clock DURING an assembly: one thread on a queue of its own counts its cycles (clock64) and the 100 MHz wall ticks from the
+ * moment the assembly is queued until a flag says it is over - ONE thread, one counter.  [First form: one (clock64, wall clock) pair
+ * from a launch before and one from a launch after the assembly - they land on different XCDs, whose cycle counters are not
+ * aligned: 1.98, 2.37 GHz and garbage on some boxes.  Second: 20 us of spinning right behind the assembly - the idle device is
+ * back at 2.44 GHz by then.]  out[0]: flag (set by k_clock_stop behind the assembly), out[2], out[3]: cycles, ticks. */
+__global__ void k_clock_window(unsigned long long* __restrict__ out)
 {
-   out[0] = clock64();
-   out[1] = wall_clock64();
+   const unsigned long long w0 = wall_clock64();
+   const unsigned long long c0 = clock64();
+   unsigned long long w1 = w0;
+   /* (at most 0.2 s: an exit every wave reaches) */
+   while ( __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ULL && w1 - w0 < 20000000ULL )
+   {
+      __builtin_amdgcn_s_sleep(32);
+      w1 = wall_clock64();
+   }
+   const unsigned long long c1 = clock64();
+   w1 = wall_clock64();
+   out[2] = c1 - c0;
+   out[3] = w1 - w0;
+}
+__global__ void k_clock_stop(unsigned long long* __restrict__ out)
+{
+   __hip_atomic_store(out, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 extern "C" int hipsdp_set_clock_sampling(hipsdp_solver* s, int on)
@@ -2530,6 +2552,8 @@ extern "C" int hipsdp_set_clock_sampling(hipsdp_solver* s, int on)
    HS_CALL( stage_sync(s) );
    if ( on && s->clk_buf == NULL )
       HS_HIP( hipMalloc((void**) &s->clk_buf, (size_t) CLK_MAX_ASSEMBLIES * 4 * sizeof(unsigned long long)) );
+   if ( on && s->clk_stream == NULL )
+      HS_HIP( hipStreamCreateWithFlags(&s->clk_stream, hipStreamNonBlocking) );
    s->clk_on = on != 0;
    return HIPSDP_OK;
 }
@@ -2594,8 +2618,7 @@ static int solve1_try(hipsdp_solver* s, hipsdp_info* info, bool* done)
       {
          HS_HIP( hipStreamSynchronize(st) );
          (void) hipFree(s->s1_ws);
-         s->clk_on = false; s->clk_buf = NULL; s->clk_n = 0; s->clk_ghz = 0.0;
-   s->s1_ws = NULL; s->s1_ws_len = 0;
+         s->s1_ws = NULL; s->s1_ws_len = 0;
       }
       const long long len = want + want / 2 + 4096;
       HS_HIP( hipMalloc((void**) &s->s1_ws, (size_t) len * sizeof(double)) );
@@ -3253,13 +3276,17 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       /* ---- Schur complement (extended by the constant matrix as "variable 0") */
       phase_mark(s, PH_SCHUR);
       hs_comm_phase(0);
-      const bool clk_this = s->clk_on && s->clk_buf != NULL && s->clk_n < CLK_MAX_ASSEMBLIES;
+      const bool clk_this = s->clk_on && s->clk_buf != NULL && s->clk_stream != NULL && s->clk_n < CLK_MAX_ASSEMBLIES;
+      HS_HIP( hipEventRecord(s->ev0, st) );
       if ( clk_this )
       {
-         hipLaunchKernelGGL(k_clock_sample, dim3(1), dim3(1), 0, st, s->clk_buf + 4 * s->clk_n);
+         /* the counting thread starts when the assembly may start (behind the event) on its own queue */
+         HS_HIP( hipMemsetAsync(s->clk_buf + 4 * s->clk_n, 0, 4 * sizeof(unsigned long long), st) );
+         HS_HIP( hipEventRecord(s->ev0, st) );
+         HS_HIP( hipStreamWaitEvent(s->clk_stream, s->ev0, 0) );
+         hipLaunchKernelGGL(k_clock_window, dim3(1), dim3(1), 0, s->clk_stream, s->clk_buf + 4 * s->clk_n);
          HS_LAUNCH_CHECK();
       }
-      HS_HIP( hipEventRecord(s->ev0, st) );
       const double mfma_flops_before = hs_mfma_flops_total();
       bool schur_small = false;
       if ( s->comm == NULL && !s->shardA && !s->schur_mode_rows && !s->schur_mode_forced && K > 0 )
@@ -3379,7 +3406,7 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       HS_HIP( hipEventRecord(s->ev1, st) );
       if ( clk_this )
       {
-         hipLaunchKernelGGL(k_clock_sample, dim3(1), dim3(1), 0, st, s->clk_buf + 4 * s->clk_n + 2);
+         hipLaunchKernelGGL(k_clock_stop, dim3(1), dim3(1), 0, st, s->clk_buf + 4 * s->clk_n);
          HS_LAUNCH_CHECK();
          ++s->clk_n;
       }
@@ -3729,13 +3756,15 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
    HS_HIP( hipStreamSynchronize(st) );
    if ( s->clk_on && s->clk_n > 0 )
    {
+      if ( s->clk_stream != NULL )
+         HS_HIP( hipStreamSynchronize(s->clk_stream) );
       std::vector<unsigned long long> h((size_t) 4 * s->clk_n);
       HS_HIP( hipMemcpy(h.data(), s->clk_buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) );
       double dc = 0.0, dw = 0.0;
       for (int a = 0; a < s->clk_n; ++a)
       {
-         dc += (double) (h[4 * a + 2] - h[4 * a]);
-         dw += (double) (h[4 * a + 3] - h[4 * a + 1]);
+         dc += (double) h[4 * a + 2];
+         dw += (double) h[4 * a + 3];
       }
       s->clk_ghz = dw > 0.0 ? dc / (dw * 10.0) : 0.0;
    }
