@@ -1925,8 +1925,22 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       const int nwv = S1_NW - ((2 * K < S1_NW - 1) ? 2 * K : S1_NW - 1);
       const double mmcost = (double) ((nt1 * nt1 + nwv - 1) / nwv) * (double) ((q + 7) >> 3) * 800.0;
       sh.fl[33] = (sh.fl[31] >= 0 && mmcost < 40.0 * (double) worst + 2000.0) ? 1 : 0;
+      /* many dense LP rows whose dense copy did not fit LDS: walking their nonzeros on one wavefront would take longer than the whole
+       * iteration of the general path - decline */
+      sh.fl[34] = (!sh.fl[33] && 40.0 * (double) worst > 4e5) ? 1 : 0;
    }
    __syncthreads();
+   if ( sh.fl[34] )
+   {
+      if ( tid == 0 )
+      {
+         out[0] = -2.0; out[40] = (double) sh.fl[2]; out[41] = (double) sh.fl[3];
+         __threadfence_system();
+         if ( P.flag != NULL )
+            __hip_atomic_store(P.flag, P.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      return;
+   }
    /* row slots of the light matrices */
    for (int k = 0; k < K; ++k)
    {

@@ -323,3 +323,26 @@ def test_whole_tree_of_example_tt_both_paths_node_by_node(gpu, monkeypatch):
     assert abs(best - 2.11803) <= 1e-4 and failed == 0
     assert tot['diff'] == 0
     assert abs(tot['a'] - tot['b']) <= 0.005 * tot['b']
+
+
+def test_many_dense_lp_rows_beyond_lds_are_declined(gpu, monkeypatch):
+    """600 dense LP rows (cuts) over 60 variables: their dense copy does not fit LDS beside the rest, and walking 36 000 nonzeros per
+    variable on one wavefront would cost more than the general path's whole iteration - the kernel declines, the general path solves"""
+    rng = np.random.default_rng(3)
+    m, n, q = 60, 8, 600
+    ystar = rng.standard_normal(m)
+    A = np.zeros((m + 1, n, n))
+    for i in range(1, m + 1):
+        r, c = rng.integers(0, n, 2)
+        A[i, r, c] += 1.0
+        A[i, c, r] += 1.0 if r != c else 0.0
+    Zs = rng.standard_normal((n, n)); Zs = Zs @ Zs.T + 0.5 * np.eye(n)
+    A[0] = np.tensordot(ystar, A[1:], axes=(0, 0)) - Zs
+    D = rng.standard_normal((q, m))
+    c = D @ ystar - rng.random(q) - 0.1
+    b = np.array([np.trace(A[i]) for i in range(1, m + 1)]) + D.T @ np.ones(q)
+    core = ipm_ref.CoreProblem(b, [A], D, c)
+    ref = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-6, feastol=1e-6, pabstol=1e-5))
+    g = solve_one_launch(gpu, core, monkeypatch, gaptol=1e-6, feastol=1e-6, pabstol=1e-5)
+    assert g["path"] == 0
+    assert g["info"].status == ref.status and abs(g["info"].iterations - ref.iterations) <= 1
