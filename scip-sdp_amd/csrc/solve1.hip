@@ -1900,7 +1900,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
    }
    __syncthreads(); S1_SETUP_STAMP(6);
    /* which form of the LP part of the Schur matrix (lp_schur): walking the nonzeros costs what the busiest lane does - the entries of
-    * all LP rows its variable appears in, about 40 cycles each -, the product about 800 cycles per eight LP rows and tile */
+    * all LP rows its variable appears in, about 500 cycles each -, the product about 800 cycles per eight LP rows and tile */
    {
       int mine = 0;
       for (int i = tid + 1; i < m1; i += S1_NT)
@@ -1923,11 +1923,12 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          worst = max(worst, sh.wtot[w]);
       const int nt1 = (m1 + 15) >> 4;
       const int nwv = S1_NW - ((2 * K < S1_NW - 1) ? 2 * K : S1_NW - 1);
-      const double mmcost = (double) ((nt1 * nt1 + nwv - 1) / nwv) * (double) ((q + 7) >> 3) * 800.0;
-      sh.fl[33] = (sh.fl[31] >= 0 && mmcost < 40.0 * (double) worst + 2000.0) ? 1 : 0;
-      /* many dense LP rows whose dense copy did not fit LDS: walking their nonzeros on one wavefront would take longer than the whole
-       * iteration of the general path - decline */
-      sh.fl[34] = (!sh.fl[33] && 40.0 * (double) worst > 4e5) ? 1 : 0;
+      /* (a K step of a tile: about 800 cycles out of LDS, 2400 out of global memory - the latency of its four loads) */
+      const double mmcost = (double) ((nt1 * nt1 + nwv - 1) / nwv) * (double) ((q + 7) >> 3) * (sh.fl[31] >= 0 ? 800.0 : 2400.0);
+      const double rowcost = 500.0 * (double) worst + 3000.0;        /* (three dependent LDS round trips per entry) */
+      sh.fl[33] = (mmcost < rowcost) ? (sh.fl[31] >= 0 ? 1 : 2) : 0;
+      /* neither form affordable (hundreds of dense LP rows): longer than the whole iteration of the general path - decline */
+      sh.fl[34] = (fmin(mmcost, rowcost) > 2e6) ? 1 : 0;
    }
    __syncthreads();
    if ( sh.fl[34] )
@@ -2050,7 +2051,8 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
    auto tro = [&](int off) S1_INL -> int { const int t = tid - (off & (S1_NT - 1)); return t < 0 ? t + S1_NT : t; };
    /* LP part of the Schur matrix, D^T diag(x / z) D (needs x / z in Q_sx); it also clears Mx.  Two forms.
     * (a) When the dense copy of the caller's LP rows that the setup staged in LDS is still there and the cost model of the setup
-    * prefers it (sh.fl[33]: dense rows - cuts): a product on
+    * prefers it (sh.fl[33] = 1: dense rows - cuts; = 2: the same from the caller's array in global memory when that is still cheaper
+    * than walking the nonzeros): a product on
     * the matrix cores, (m + 1) x (m + 1) with inner dimension q, lower triangle written; wavefronts w0 .. NW - 1.
     * (b) Otherwise one wavefront walks the nonzeros: lane l owns the rows l + 1 (and l + 65) of Mx, it walks the LP rows its variable
     * appears in and adds their entries up to its own column; row 0 (the constant column, present in almost every bound row) has one
@@ -2062,7 +2064,7 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       const double* sx = QV(Q_sx);
       if ( sh.fl[33] )
       {
-         s1_lp_schur_mm(sm + sh.fl[31], sx, Mx, m1, q, pm1, wave, lane, w0);
+         s1_lp_schur_mm(sh.fl[33] == 1 ? sm + sh.fl[31] : P.Dext, sx, Mx, m1, q, pm1, wave, lane, w0);
          return;
       }
       if ( wave != S1_NW - 1 )
@@ -2841,13 +2843,19 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          /* heavy variables j: T_j and U_j as whole matrices in the scratch region.  While the dense copy of the caller's matrices that
           * the setup staged in LDS is still there (sh.fl[31] >= 0): T_j = A_j Zinv and U_j = X T_j as products on the matrix cores,
           * then <A_i, U_j^T> for every i, sixteen lanes per variable (a dense constant matrix - the usual case of a cost matrix -
-          * of 10 rows: 41 000 -> 9 000 cycles).  Otherwise from the lists (two buffers per j, G2 of them side by side). */
+          * of 10 rows: 41 000 -> 7 200 cycles; before, from the lists: a thread per column of T_j walking all entries). */
          const int nh = B.nh;
-         if ( nh > 0 && sh.fl[31] >= 0 )
+         if ( nh > 0 )
          {
-            const double* Ast = sm + sh.fl[31] + q * m1;
-            for (int kb = 0; kb < k; ++kb)
-               Ast += m1 * sh.blk[kb].n * sh.blk[kb].n;
+            /* (the dense matrices: the staged copy in LDS, else the caller's array in global memory - a tile asks for a few
+             * fragments only) */
+            const double* Ast = P.A[k];
+            if ( sh.fl[31] >= 0 )
+            {
+               Ast = sm + sh.fl[31] + q * m1;
+               for (int kb = 0; kb < k; ++kb)
+                  Ast += m1 * sh.blk[kb].n * sh.blk[kb].n;
+            }
             double* T = sm + L.oR;
             double* U = T + B.np;
             for (int h0 = 0; h0 < nh; ++h0)
@@ -2887,62 +2895,6 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
                         Mx[(i >= j) ? i * pm1 + j : j * pm1 + i] += s0;
                   }
                }
-               S1_BAR();
-            }
-         }
-         else if ( nh > 0 )
-         {
-            int G2 = B.G >> 1;
-            if ( G2 < 1 ) G2 = 1;
-            const int gsz = S1_NT / G2;
-            const int g = tid / gsz, tig = tid - g * gsz;
-            double* T = sm + L.oR + (2 * g) * B.np;
-            double* U = T + B.np;
-            for (int h0 = 0; h0 < nh; h0 += G2)
-            {
-               const int j = (h0 + g < nh) ? (int) LP(B.hv)[h0 + g] : -1;
-               if ( j >= 0 )
-               {
-                  /* T = A_j Zinv: thread c owns column c and walks the entries in row-major order */
-                  const int t0 = LP(B.voff)[j], t1 = LP(B.voff)[j + 1];
-                  for (int c = tig; c < n; c += gsz)
-                  {
-                     for (int r = 0; r < n; ++r)
-                        T[r * p + c] = 0.0;
-                     for (int t = t0; t < t1; ++t)
-                     {
-                        const unsigned pq = LP(B.vpq)[t];
-                        const int pp = (int) (pq >> 16), qq = (int) (pq & 0xffffu);
-                        T[pp * p + c] = fma(LP(B.vval)[t], Zi[qq * p + c], T[pp * p + c]);
-                     }
-                  }
-               }
-               S1_BAR();
-               if ( j >= 0 )
-                  for (int e = tig; e < n2; e += gsz)
-                  {
-                     const int r = s1_div(e, n), c = e - r * n;
-                     double s0 = 0.0;
-                     for (int kk = 0; kk < n; ++kk)
-                        s0 = fma(X[r * p + kk], T[kk * p + c], s0);
-                     U[r * p + c] = s0;
-                  }
-               S1_BAR();
-               if ( j >= 0 )
-                  for (int i = tig; i < m1; i += gsz)
-                  {
-                     const int t0 = LP(B.voff)[i], t1 = LP(B.voff)[i + 1];
-                     if ( t1 == t0 || (t1 - t0 > S1_LIGHT_MAX && i < j) )
-                        continue;
-                     double s0 = 0.0;
-                     for (int t = t0; t < t1; ++t)
-                     {
-                        const unsigned pq = LP(B.vpq)[t];
-                        const int pp = (int) (pq >> 16), qq = (int) (pq & 0xffffu);
-                        s0 = fma(LP(B.vval)[t], U[qq * p + pp], s0);
-                     }
-                     Mx[(i >= j) ? i * pm1 + j : j * pm1 + i] += s0;
-                  }
                S1_BAR();
             }
          }

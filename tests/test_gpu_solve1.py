@@ -326,10 +326,11 @@ def test_whole_tree_of_example_tt_both_paths_node_by_node(gpu, monkeypatch):
 
 
 def test_many_dense_lp_rows_beyond_lds_are_declined(gpu, monkeypatch):
-    """600 dense LP rows (cuts) over 60 variables: their dense copy does not fit LDS beside the rest, and walking 36 000 nonzeros per
-    variable on one wavefront would cost more than the general path's whole iteration - the kernel declines, the general path solves"""
+    """3000 dense LP rows over 60 variables: neither form of the LP part of the Schur matrix is affordable on one compute unit (the
+    product from global memory: 2.7 million cycles per iteration by the cost model of the setup) - the kernel declines, the general
+    path solves"""
     rng = np.random.default_rng(3)
-    m, n, q = 60, 8, 600
+    m, n, q = 60, 8, 3000
     ystar = rng.standard_normal(m)
     A = np.zeros((m + 1, n, n))
     for i in range(1, m + 1):
