@@ -2580,10 +2580,12 @@ static int solve1_try(hipsdp_solver* s, hipsdp_info* info, bool* done)
    /* (read at every solve: tests and tools switch the path between two solves of one process) */
    int on = 1, prof = 0;
    double maxwork = 3e6;
-   /* largest block the kernel is offered by default: measured with sparse matrices (tests/devtools/solve1_sizes.py) it wins up to
-    * 16 rows (0.195 against 0.280 ms per iteration), ties at 24 and loses at 32 (0.62 against 0.43: the step lengths of a block of
-    * more than 16 rows are a one-wavefront tridiagonalisation out of LDS); it RUNS up to 64 rows (HIPSDP_SOLVE1_MAXN=64, tests) */
-   int maxn = 24;
+   /* largest block the kernel is offered (HIPSDP_SOLVE1_MAXN): whatever fits its LDS - one block of 36 rows, two of 30, eight of 12.
+    * Measured with sparse variable matrices, dense constant matrices and LP rows of density 0.3 (tests/devtools/solve1_sizes.py) it
+    * is ahead of the general path at every such size: 16 rows 0.124 against 0.281 ms per iteration, 24: 0.233 / 0.360, 32: 0.360 /
+    * 0.422, two of 30: 0.449 / 0.572.  [Mid-round it lost at 32 rows, 0.62 against 0.43 - a dense constant matrix went through
+    * scalar loops of one wavefront and dense LP rows through a walk of their nonzeros - and the default was 24.] */
+   int maxn = 64;
    {
       const char* env = getenv("HIPSDP_SOLVE1");
       on = (env != NULL && env[0] == '0') ? 0 : 1;

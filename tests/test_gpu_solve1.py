@@ -173,12 +173,10 @@ def test_random_sparse_problems_in_one_launch(gpu, seed, monkeypatch):
                                        ([12, 12, 12], 40, 40), ([9] * 8, 60, 100), ([17, 3, 11, 2], 64, 30),
                                        ([12], 65, 20), ([10, 9], 90, 60), ([14, 8], 104, 12)])
 def test_blocks_up_to_the_limits_of_the_kernel_in_one_launch(gpu, sizes, m, q, monkeypatch):
-    """By default the kernel is offered blocks of at most 24 rows (above that the general path is faster: tests/devtools/
-    solve1_sizes.py); it RUNS whatever fits its LDS - here with HIPSDP_SOLVE1_MAXN=64: blocks of 16 < n <= 32 rows (step lengths by
+    """The kernel runs whatever fits its LDS: blocks of 16 < n <= 32 rows (step lengths by
     the one-wavefront LDS tridiagonalisation, panel Cholesky + in-place inverse instead of the whole-matrix-per-lane forms, several
     tiles per product), eight blocks, m = 64, and 64 < m <= 108 (two rows per lane in the factorization of M and the substitutions,
     lists partly outside LDS): same iterations as the oracle, iterate by iterate."""
-    monkeypatch.setenv("HIPSDP_SOLVE1_MAXN", "64")
     core = sized_sparse_core(sizes, m, q, 5)
     ref = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-6, feastol=1e-6, pabstol=1e-5))
     g = solve_one_launch(gpu, core, monkeypatch, gaptol=1e-6, feastol=1e-6, pabstol=1e-5)
@@ -191,11 +189,15 @@ def test_blocks_up_to_the_limits_of_the_kernel_in_one_launch(gpu, sizes, m, q, m
     assert ok, det
 
 
-def test_blocks_above_24_rows_take_the_general_path_by_default(gpu, monkeypatch):
-    monkeypatch.delenv("HIPSDP_SOLVE1_MAXN", raising=False)
+def test_block_size_switch_of_the_kernel(gpu, monkeypatch):
+    """HIPSDP_SOLVE1_MAXN limits the blocks the kernel is offered (default: whatever fits)"""
     core = sized_sparse_core([28], 44, 10, 5)
+    monkeypatch.setenv("HIPSDP_SOLVE1_MAXN", "24")
     g = solve_one_launch(gpu, core, monkeypatch, gaptol=1e-6, feastol=1e-6, pabstol=1e-5)
     assert g["path"] == 0 and g["info"].status == 0
+    monkeypatch.delenv("HIPSDP_SOLVE1_MAXN", raising=False)
+    g = solve_one_launch(gpu, core, monkeypatch, gaptol=1e-6, feastol=1e-6, pabstol=1e-5)
+    assert g["path"] == 1 and g["info"].status == 0
 
 
 def test_dense_matrices_are_declined_and_solved_by_the_general_path(gpu, monkeypatch):
