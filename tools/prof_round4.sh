@@ -25,3 +25,5 @@ cd $R
 python3 tests/devtools/bnb_rate.py > $out/bnb_rate.txt 2>&1
 cat $out/bnb_rate.txt
 head -5 $out/bnb_kernel_stats.csv
+python3 tests/devtools/solve1_sizes.py > $out/solve1_sizes.txt 2>&1
+cat $out/solve1_sizes.txt
