@@ -602,6 +602,71 @@ def bench_bnb(hb, cpu=True):
     return out
 
 
+def bench_bnb_sizes(hb):
+    """ms per interior-point iteration of ONE node solve on both paths of the engine - one-launch kernel (csrc/solve1.hip) and general
+    path (HIPSDP_SOLVE1=0) - over the sizes the one-launch kernel is offered: sparse variable matrices (three nonzeros per matrix and
+    block), dense constant matrices, LP rows of density 0.3 (synthetic, seeded), and the root node of example_MkP.  Best of three solves,
+    engine time / iterations.  Both paths give the same iteration counts and objective (checked here)."""
+    import numpy as np
+    for d in ("tests", os.path.join("tests", "harness"), "oracle"):
+        if os.path.join(ROOT, d) not in sys.path:
+            sys.path.insert(0, os.path.join(ROOT, d))
+    import ipm_ref
+    import sdpa_io
+
+    def core_of(sizes, m, q, seed):
+        rng = np.random.default_rng(seed)
+        ystar = rng.standard_normal(m)
+        blocks = []
+        for n in sizes:
+            A = np.zeros((m + 1, n, n))
+            for i in range(1, m + 1):
+                for _ in range(3):
+                    r, c = rng.integers(0, n, 2)
+                    v = rng.standard_normal()
+                    A[i, r, c] += v
+                    if r != c:
+                        A[i, c, r] += v
+            Zs = rng.standard_normal((n, n)); Zs = Zs @ Zs.T + 0.5 * np.eye(n)
+            A[0] = np.tensordot(ystar, A[1:], axes=(0, 0)) - Zs
+            blocks.append(A)
+        D = rng.standard_normal((q, m)) * (rng.random((q, m)) < 0.3)
+        c = D @ ystar - rng.random(q) - 0.1
+        b = sum(np.array([np.trace(A[i]) for i in range(1, m + 1)]) for A in blocks) + (D.T @ np.ones(q) if q else 0.0)
+        return ipm_ref.CoreProblem(b, blocks, D, c)
+
+    cases = [("blocks %s, m %d, q %d" % (sz, m, q), core_of(sz, m, q, 5)) for sz, m, q in
+             [([10], 37, 85), ([16], 40, 40), ([24], 40, 40), ([32], 48, 40), ([12, 12, 12], 40, 40), ([30, 30], 50, 20)]]
+    inst = sdpa_io.read_sdpa(os.path.join(ROOT, "tests", "golden", "instances", "example_MkP.dat-s.gz"))
+    D, c = sdpa_io.lp_dense(inst)
+    cases.append(("example_MkP root (n 15, m 105, q 240)", ipm_ref.CoreProblem(inst.obj, sdpa_io.dense_blocks(inst), D, c)))
+    rows = []
+    keep = os.environ.get("HIPSDP_SOLVE1")
+    try:
+        for name, core in cases:
+            row = {"case": name}
+            for label, path in (("one_launch", "1"), ("general", "0")):
+                os.environ["HIPSDP_SOLVE1"] = path
+                s = hb.Solver(0)
+                s.load_core(core)
+                best = None
+                for _ in range(3):
+                    info = s.solve(gaptol=1e-6, feastol=1e-6)
+                    best = info.solve_seconds if best is None else min(best, info.solve_seconds)
+                row[label] = {"ms_per_ipm_iteration": 1e3 * best / max(1, info.iterations), "iterations": info.iterations, "status": info.status,
+                              "dobj": info.dobj, "took_one_launch_path": bool(s.solve_path())}
+                s.close()
+            row["same_iterations_and_objective"] = bool(row["one_launch"]["iterations"] == row["general"]["iterations"]
+                                                        and abs(row["one_launch"]["dobj"] - row["general"]["dobj"]) <= 1e-7 * (1 + abs(row["general"]["dobj"])))
+            rows.append(row)
+    finally:
+        if keep is None:
+            os.environ.pop("HIPSDP_SOLVE1", None)
+        else:
+            os.environ["HIPSDP_SOLVE1"] = keep
+    return rows
+
+
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
@@ -817,6 +882,10 @@ def main():
             out["density"] = {"error": repr(e)}
         try:
             out["bnb"] = bench_bnb(hb, cpu=not args.no_cpu)
+            try:
+                out["bnb"]["one_launch_against_general_path"] = bench_bnb_sizes(hb)
+            except Exception as e:
+                out["bnb"]["one_launch_against_general_path"] = {"error": repr(e)}
         except Exception as e:
             out["bnb"] = {"error": repr(e)}
     if dist is not None:
