@@ -2984,6 +2984,10 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
                }
             Mx[i * pm1 + j] += acc;
          }
+         /* (the lists of light variables differ from block to block - a dense constant matrix is heavy in a block of 8 rows and
+          * light in one of 2 -, so the same entry of Mx is another thread's in the next block: one block after the other) */
+         if ( k + 1 < K )
+            S1_BAR();
       }
       S1_BAR();
       S1_STAMP(5);
