@@ -263,9 +263,40 @@ struct NodeCmd
 #define NC_BYTES (NC_MAX * sizeof(NodeCmd))
 #define NC_LIMIT 65536           /* elements a deferred command may touch */
 #ifdef __HIPCC__
-/* all threads of ONE workgroup; sc: NC_MAX commands of LDS */
-__device__ __forceinline__ void hs_run_node_cmds(const NodeCmd* __restrict__ cmds, int ncmd, NodeCmd* sc)
+/* all threads of ONE workgroup; sc: NC_MAX commands of LDS.  stage != NULL: `staged` bytes (a multiple of 16) of LDS that take the
+ * first `staged` bytes of the arena - the command list and everything the commands read from pinned memory - in ONE pipelined pass
+ * over PCIe; the commands then read their data and index arrays out of LDS.  (Read where the commands use them, every element is a
+ * PCIe round trip of its own in a chain per thread - the gather reads three indices per entry -: 12 us for the six commands of a
+ * node of example_TT, 4 us this way.)  sc is not used then. */
+__device__ __forceinline__ void hs_run_node_cmds(const NodeCmd* __restrict__ cmds, int ncmd, NodeCmd* sc, double* stage = NULL, long long staged = 0)
 {
+   const char* const arena = reinterpret_cast<const char*>(cmds);
+   if ( stage != NULL )
+   {
+      typedef double nc_v2 __attribute__((ext_vector_type(2)));
+      const nc_v2* src = reinterpret_cast<const nc_v2*>(cmds);
+      nc_v2* dst = reinterpret_cast<nc_v2*>(stage);
+      const int n16 = (int) (staged >> 4);
+      for (int b = threadIdx.x; b < n16; b += 4 * blockDim.x)
+      {
+         nc_v2 v[4];
+#pragma unroll
+         for (int u = 0; u < 4; ++u)
+         {
+            const int i = b + u * (int) blockDim.x;
+            v[u] = src[i < n16 ? i : n16 - 1];
+         }
+#pragma unroll
+         for (int u = 0; u < 4; ++u)
+         {
+            const int i = b + u * (int) blockDim.x;
+            if ( i < n16 )
+               dst[i] = v[u];
+         }
+      }
+      sc = reinterpret_cast<NodeCmd*>(stage);
+   }
+   else
    {
       const long long* src = reinterpret_cast<const long long*>(cmds);
       long long* dst = reinterpret_cast<long long*>(sc);
@@ -274,6 +305,14 @@ __device__ __forceinline__ void hs_run_node_cmds(const NodeCmd* __restrict__ cmd
          dst[i] = src[i];
    }
    __syncthreads();
+   /* an address inside the staged part of the arena -> its copy in LDS */
+   auto loc = [&](const void* p) -> const void*
+   {
+      const char* c = reinterpret_cast<const char*>(p);
+      if ( stage != NULL && c >= arena && c < arena + staged )
+         return reinterpret_cast<const char*>(stage) + (c - arena);
+      return p;
+   };
    for (int c = 0; c < ncmd; ++c)
    {
       const NodeCmd& q = sc[c];
@@ -284,14 +323,15 @@ __device__ __forceinline__ void hs_run_node_cmds(const NodeCmd* __restrict__ cmd
       }
       else if ( q.op == NC_COPY )
       {
+         const double* src = reinterpret_cast<const double*>(loc(q.src));
          for (long long e = threadIdx.x; e < q.n; e += blockDim.x)
-            q.dst[e] = q.src[e];
+            q.dst[e] = src[e];
       }
       else if ( q.op == NC_GATHER )
       {
          /* (k_master_gather) i0 = active variables, i1 = kept rows, i2 = order of the master matrices */
          const int nactive = q.i0, nk = q.i1, N = q.i2;
-         const int* act = q.idx; const int* kept = q.idx + nactive;
+         const int* act = reinterpret_cast<const int*>(loc(q.idx)); const int* kept = act + nactive;
          const long long nk2 = (long long) nk * nk, total = (long long) nactive * nk2;
          for (long long e = threadIdx.x; e < total; e += blockDim.x)
          {
@@ -306,15 +346,16 @@ __device__ __forceinline__ void hs_run_node_cmds(const NodeCmd* __restrict__ cmd
          /* (k_scatter_coo, indices checked by the host) i0 = order of the block, i1, i2 = the rows of A this rank holds */
          const int n = q.i0, r0 = q.i1, r1 = q.i2;
          const long long n2 = (long long) n * n;
-         const int* var = q.idx; const int* row = q.idx + q.n; const int* col = q.idx + 2 * q.n;
+         const int* var = reinterpret_cast<const int*>(loc(q.idx)); const int* row = var + q.n; const int* col = var + 2 * q.n;
+         const double* val = reinterpret_cast<const double*>(loc(q.src));
          for (long long e = threadIdx.x; e < q.n; e += blockDim.x)
          {
             const int v = var[e], r = row[e], cc = col[e];
             if ( v != 0 && (v < r0 || v >= r1) )
                continue;
             double* a = (v == 0) ? q.dst2 : q.dst + (long long) v * n2;
-            a[(long long) r * n + cc] = q.src[e];
-            a[(long long) cc * n + r] = q.src[e];
+            a[(long long) r * n + cc] = val[e];
+            a[(long long) cc * n + r] = val[e];
          }
       }
       __syncthreads();
@@ -333,6 +374,7 @@ struct hs_solve1_args
    const double* b; const double* Dext;
    double *y, *x, *z, *pre_y, *pre_x;
    const void* cmds; int ncmd;         /* deferred setters of the node (NodeCmd list in pinned memory), run before anything else */
+   long long cmd_bytes;                /* bytes of the arena behind cmds that hold the list and the data of its commands (multiple of 16) */
    double *hy, *hx, *hz;               /* optional: y, x, z once more into pinned host memory (the caller's read-backs of a node need no copy) */
    double gaptol, feastol, infeastol, objlimit, timelimit, gamma, pabstol, preoptgap;
    double elapsed0;                        /* seconds of the time limit already used when the kernel starts */

@@ -2670,6 +2670,11 @@ static int solve1_try(hipsdp_solver* s, hipsdp_info* info, bool* done)
    a.seq = ++s->s1_seq;
    a.flag = reinterpret_cast<unsigned long long*>(s->s1_host_dev + HS_S1_OUT_DOUBLES);
    a.cmds = s->arena_d; a.ncmd = s->ncmd;         /* the node's setters: run by the same launch */
+   if ( s->ncmd > 0 )
+   {
+      const size_t used = s->stage_off > NC_BYTES ? s->stage_off : NC_BYTES;
+      a.cmd_bytes = (long long) ((used + 15) & ~(size_t) 15);         /* (the arena's size is a multiple of 16) */
+   }
    s->ncmd = 0;
    HS_CALL( hs_solve1_launch(st, &a) );
    {

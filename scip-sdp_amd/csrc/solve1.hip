@@ -1517,6 +1517,55 @@ __device__ __forceinline__ void s1_exscan(int* a, int len, S1Sh& sh, int tid)
    __syncthreads();
 }
 
+/* the same by ONE wavefront (no barrier): independent scans run side by side on different wavefronts */
+__device__ __forceinline__ void s1_exscan_wave(int* a, int len, int lane)
+{
+   const int chunk = (len + 63) >> 6;
+   const int i0 = lane * chunk;
+   int s = 0;
+   for (int i = i0; i < i0 + chunk && i < len; ++i)
+      s += a[i];
+   int incl = s;
+#pragma unroll
+   for (int off = 1; off < 64; off <<= 1)
+   {
+      const int u = __shfl_up(incl, off, 64);
+      if ( lane >= off )
+         incl += u;
+   }
+   int run = incl - s;
+   for (int i = i0; i < i0 + chunk && i < len; ++i)
+   {
+      const int t = a[i];
+      a[i] = run;
+      run += t;
+   }
+   if ( lane == 63 )
+      a[len] = incl;
+}
+
+/* global -> LDS, four loads in flight per thread (a loop of load, store waits out the 700 ns of an L2 round trip per element) */
+__device__ __forceinline__ void s1_copy_in(double* dst, const double* __restrict__ src, long long n, int tid)
+{
+   for (long long b = tid; b < n; b += 4 * S1_NT)
+   {
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+      {
+         const long long i = b + u * S1_NT;
+         v[u] = src[i < n ? i : n - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+      {
+         const long long i = b + u * S1_NT;
+         if ( i < n )
+            dst[i] = v[u];
+      }
+   }
+}
+
 /* LP part of the Schur matrix as a product (see lp_schur in the kernel): a function of its own - it is the rare case (dense LP rows),
  * and inlined its registers are added to what the iteration keeps alive around the whole-matrix-per-lane recurrences */
 __device__ __attribute__((noinline)) void s1_lp_schur_mm(const double* Dl, const double* sx, double* Mx, int m1, int q, int pm1, int wave,
@@ -1555,7 +1604,9 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
    /* ---- the node's deferred setters (objective, LP rows, gather of the active matrices, constant matrix, start point) */
    if ( P.ncmd > 0 )
    {
-      hs_run_node_cmds(reinterpret_cast<const NodeCmd*>(P.cmds), P.ncmd, reinterpret_cast<NodeCmd*>(sm));
+      const bool staged = P.cmd_bytes >= (long long) NC_BYTES && P.cmd_bytes <= (long long) S1_DYN_LDS;
+      hs_run_node_cmds(reinterpret_cast<const NodeCmd*>(P.cmds), P.ncmd, reinterpret_cast<NodeCmd*>(sm), staged ? sm : (double*) NULL,
+         staged ? P.cmd_bytes : 0);
       __syncthreads(); S1_SETUP_STAMP(0);
    }
 
@@ -1664,16 +1715,13 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
    {
       double* dst = sm + sh.fl[31];
       const long long nd = (long long) q * m1;
-      for (long long e = tid; e < nd; e += S1_NT)
-         dst[e] = P.Dext[e];
+      s1_copy_in(dst, P.Dext, nd, tid);
       Dsrc = dst;
       dst += nd;
       for (int k = 0; k < K; ++k)
       {
          const long long na = (long long) m1 * L.n[k] * L.n[k];
-         const double* src = P.A[k];
-         for (long long e = tid; e < na; e += S1_NT)
-            dst[e] = src[e];
+         s1_copy_in(dst, P.A[k], na, tid);
          Asrc[k] = dst;
          dst += na;
       }
@@ -1731,18 +1779,24 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
       }
    }
    __syncthreads(); S1_SETUP_STAMP(4);
-   s1_exscan(sh.roff, q, sh, tid);
-   s1_exscan(sh.coff, m1, sh, tid);
-   for (int k = 0; k < K; ++k)
+   /* (one wavefront per array, side by side) */
+   for (int t = wave; t < 2 + 2 * K; t += S1_NW)
    {
-      s1_exscan(sh.blk[k].voff, m1, sh, tid);
-      s1_exscan(sh.blk[k].poff, sh.blk[k].n * sh.blk[k].n, sh, tid);
+      if ( t == 0 ) s1_exscan_wave(sh.roff, q, lane);
+      else if ( t == 1 ) s1_exscan_wave(sh.coff, m1, lane);
+      else if ( t & 1 ) s1_exscan_wave(sh.blk[(t - 2) >> 1].poff, sh.blk[(t - 2) >> 1].n * sh.blk[(t - 2) >> 1].n, lane);
+      else s1_exscan_wave(sh.blk[(t - 2) >> 1].voff, m1, lane);
    }
-   if ( tid == 0 )
+   __syncthreads();
+   /* second allocation step, by wavefront 0: the sizes are wavefront-uniform values (every lane computes them), lane 0 notes the
+    * results; the variables are sorted into light and heavy ones 64 at a time (as a loop of one thread over the counts in LDS
+    * this step took 26 000 cycles of the 130 000 of the setup of example_TT) */
+   if ( wave == 0 )
    {
+      int fl0 = sh.fl[0], fl31 = sh.fl[31];
       for (int attempt = 0; attempt < 2; ++attempt)
       {
-      int ldsleft = sh.fl[0];
+      int ldsleft = fl0;
       double* lp = *(double**) &sh.sc[0];
       double* gp = *(double**) &sh.sc[1];
       double* const gp0 = gp;
@@ -1755,51 +1809,78 @@ __global__ void __launch_bounds__(S1_NT) k_solve1(const hs_solve1_args P)
          return r;
       };
       const int nnzD = sh.roff[q];
-      sh.rval = take(nnzD); sh.cval = take(nnzD);
-      sh.rcol = (unsigned short*) take((nnzD + 3) / 4); sh.crow = (unsigned short*) take((nnzD + 3) / 4);
+      {
+         double* const rval = take(nnzD); double* const cval = take(nnzD);
+         unsigned short* const rcol = (unsigned short*) take((nnzD + 3) / 4); unsigned short* const crow = (unsigned short*) take((nnzD + 3) / 4);
+         if ( lane == 0 )
+         {
+            sh.rval = rval; sh.cval = cval; sh.rcol = rcol; sh.crow = crow;
+         }
+      }
       double work = 0.0;
       int nnzA = 0;
       for (int k = 0; k < K; ++k)
       {
          S1Blk& B = sh.blk[k];
-         const int nz = B.voff[m1];                       /* entries of all matrices, both triangles */
-         const int nzl = B.poff[B.n * B.n];                /* entries with row >= col */
+         const int bn = B.n;
+         const int* const voff = B.voff;
+         const int nz = voff[m1];                          /* entries of all matrices, both triangles */
+         const int nzl = B.poff[bn * bn];                  /* entries with row >= col */
          nnzA += nzl;
-         B.vval = take(nz); B.pval = take(nzl);
-         B.vpq = (unsigned*) take((nz + 1) / 2); B.pvar = (unsigned short*) take((nzl + 3) / 4);
-         B.lv = (unsigned short*) take((m1 + 3) / 4); B.hv = (unsigned short*) take((m1 + 3) / 4);
-         /* light variables go through the pair formula (a thread per pair), heavy ones through U_j = X A_j Zinv */
-         int nl = 0, nh = 0, nzh = 0;
-         for (int i = 0; i < m1; ++i)
+         double* const vval = take(nz); double* const pval = take(nzl);
+         unsigned* const vpq = (unsigned*) take((nz + 1) / 2); unsigned short* const pvar = (unsigned short*) take((nzl + 3) / 4);
+         unsigned short* const lv = (unsigned short*) take((m1 + 3) / 4); unsigned short* const hv = (unsigned short*) take((m1 + 3) / 4);
+         /* light variables go through the pair formula (a thread per pair), heavy ones through U_j = X A_j Zinv; both lists ascending */
+         int nl = 0, nh = 0, nzh = 0, nzlight = 0;
+         for (int i0 = 0; i0 < m1; i0 += 64)
          {
-            const int c = B.voff[i + 1] - B.voff[i];
-            if ( c == 0 )
-               continue;
-            if ( c <= S1_LIGHT_MAX ) B.lv[nl++] = (unsigned short) i;
-            else { B.hv[nh++] = (unsigned short) i; nzh += c; }
+            const int i = i0 + lane;
+            const int c = (i < m1) ? voff[i + 1] - voff[i] : 0;
+            const bool isl = c > 0 && c <= S1_LIGHT_MAX, ish = c > S1_LIGHT_MAX;
+            const unsigned long long ml = __ballot(isl), mh = __ballot(ish);
+            const unsigned long long below = (1ULL << lane) - 1ULL;
+            if ( isl ) lv[nl + __popcll(ml & below)] = (unsigned short) i;
+            if ( ish ) hv[nh + __popcll(mh & below)] = (unsigned short) i;
+            nl += __popcll(ml); nh += __popcll(mh);
+            nzh += ish ? c : 0; nzlight += isl ? c : 0;
          }
-         B.nl = nl; B.nh = nh;
-         B.lro = (int*) take((nl + 2) / 2 + 1);
-         int nzlight = 0;
-         for (int a = 0; a < nl; ++a)
-            nzlight += B.voff[B.lv[a] + 1] - B.voff[B.lv[a]];
-         B.lrp = (unsigned short*) take((nzlight + 3) / 4 + 1);
-         B.lre = (int*) take((nzlight + 2) / 2 + 1);
-         B.Tc = take((long long) nzlight * B.n + 2);
-         B.nrs = 0;
-         work += (double) nzh * (double) B.n + (double) nh * (double) B.n * (double) (B.n * B.n) + (double) nz * (double) nh
+         for (int off = 32; off > 0; off >>= 1)
+         {
+            nzh += __shfl_xor(nzh, off, 64);
+            nzlight += __shfl_xor(nzlight, off, 64);
+         }
+         int* const lro = (int*) take((nl + 2) / 2 + 1);
+         unsigned short* const lrp = (unsigned short*) take((nzlight + 3) / 4 + 1);
+         int* const lre = (int*) take((nzlight + 2) / 2 + 1);
+         double* const Tc = take((long long) nzlight * bn + 2);
+         if ( lane == 0 )
+         {
+            B.vval = vval; B.pval = pval; B.vpq = vpq; B.pvar = pvar; B.lv = lv; B.hv = hv;
+            B.nl = nl; B.nh = nh;
+            B.lro = lro; B.lrp = lrp; B.lre = lre; B.Tc = Tc;
+            B.nrs = 0;
+         }
+         work += (double) nzh * (double) bn + (double) nh * (double) bn * (double) (bn * bn) + (double) nz * (double) nh
             + 0.5 * (double) (nz - nzh) * (double) (nz - nzh) * 1.5;
       }
-      sh.fl[1] = (work > P.maxwork) ? 1 : 0;
-      sh.fl[2] = nnzA; sh.fl[3] = nnzD;
-      sh.fl[4] = ((long long) (gp - P.gws) > P.gws_len) ? 1 : 0;
-      sh.fl[30] = (gp == P.gws) ? 1 : 0;                   /* nothing went to global memory */
-      if ( gp == gp0 || sh.fl[31] < 0 )
+      if ( lane == 0 )
+      {
+         sh.fl[1] = (work > P.maxwork) ? 1 : 0;
+         sh.fl[2] = nnzA; sh.fl[3] = nnzD;
+         sh.fl[4] = ((long long) (gp - P.gws) > P.gws_len) ? 1 : 0;
+         sh.fl[30] = (gp == P.gws) ? 1 : 0;                   /* nothing went to global memory */
+      }
+      if ( gp == gp0 || fl31 < 0 )
          break;
       /* a list went to global memory while the staged copy of the caller's arrays holds LDS: give that area up (the passes that
        * fill the lists read the caller's arrays again) and allocate once more */
-      sh.fl[0] += sh.fl[32];
-      sh.fl[31] = -1;
+      fl0 += sh.fl[32];
+      fl31 = -1;
+      }
+      if ( lane == 0 )
+      {
+         sh.fl[0] = fl0;
+         sh.fl[31] = fl31;
       }
    }
    __syncthreads(); S1_SETUP_STAMP(5);
