@@ -270,8 +270,8 @@ HIPSDP_API int  hipsdp_syev(int device, int n, const double* A, double* lam, dou
  * RANGE = 'I' computes it (lapack_interface.c:178-288); n <= 64 with the matrix in registers, 64 < n <= 128 in LDS (round 3).
  * HIPSDP_ERR_ARG for n > 128. */
 HIPSDP_API int  hipsdp_syevi_small(int device, int n, const double* A, int i, double* eigval, double* eigvec);
-/* all eigenpairs, n <= 64, the same way (what DSYEVR RANGE = 'A' computes, lapack_interface.c:507-603): eigenvalues by multisection,
- * eigenvectors by inverse iteration with re-orthogonalisation inside clusters, one launch; hipsdp_syev takes this path for n <= 64 */
+/* all eigenpairs, n <= 128, the same way (what DSYEVR RANGE = 'A' computes, lapack_interface.c:507-603): eigenvalues by multisection,
+ * eigenvectors by inverse iteration with re-orthogonalisation inside clusters, one launch; hipsdp_syev takes this path for n <= 128 */
 HIPSDP_API int  hipsdp_syev_small(int device, int n, const double* A, double* lam, double* V);
 /* PSD projection chain of the warm-start producer (relax_sdp.c:2715-2766 for Z, :3405-3445 for X), fused on the device: sparse
  * lower/upper triangle (row, col, val; both triangles are filled) -> eigen-decomposition -> eigenvalues below minev (by more

@@ -52,6 +52,16 @@ __device__ __forceinline__ double ei_wsum(double v)
    return ((ei_lane(v, 0) + ei_lane(v, 16)) + ei_lane(v, 32)) + ei_lane(v, 48);
 }
 
+/* sum over the 16 lanes of a row, result in every lane of the row */
+__device__ __forceinline__ double ei_sum16(double v)
+{
+   v += ei_dpp<0xB1>(v);
+   v += ei_dpp<0x4E>(v);
+   v += ei_dpp<0x141>(v);
+   v += ei_dpp<0x140>(v);
+   return v;
+}
+
 __device__ __forceinline__ double ei_quad(double x)
 {
    x += ei_dpp<0xB1>(x);
@@ -664,15 +674,14 @@ __global__ void __launch_bounds__(256) k_lmin_exact_multi(hs_step_jobs P)
 #define EM_N 128
 #define EM_FLAG 256                 /* position of the flag word in the output (behind eigenvalue + eigenvector) */
 
-__global__ void __launch_bounds__(256) k_syevi_mid(int n, int ith, int wantvec, const double* __restrict__ in, double* __restrict__ out,
-   unsigned long long seq, unsigned long long* __restrict__ flag)
+/* the reduction (the first 256 threads of the workgroup work, all pass the barriers): the matrix from `in` into em_a (pitch n | 1), tridiagonal matrix in d / e, the
+ * scalar factors of the reflectors in tau, reflector k (v_0 = 1 implied) in column k of em_a below the subdiagonal */
+__device__ __forceinline__ void em_tridiag(int n, const double* __restrict__ in, double* em_a, double* vv, double* pp, double* ww, double* tau,
+   double* d, double* e)
 {
-   extern __shared__ __attribute__((aligned(16))) double em_a[];
-   __shared__ double vv[EM_N], pp[EM_N], ww[EM_N], tau[EM_N], d[EM_N], e[EM_N], e2[EM_N], zz[EM_N];
-   __shared__ double wk[4][EM_N], swp[EM_N];
-   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   const int tid = threadIdx.x, lane = tid & 63;
    const int ld = n | 1;
-   for (int idx = tid; idx < n * n; idx += 256)
+   for (int idx = tid; idx < n * n; idx += (int) blockDim.x)
    {
       const int i = idx / n, j = idx - i * n;
       em_a[i * ld + j] = (j <= i) ? in[(long long) j * n + i] : in[(long long) i * n + j];
@@ -777,6 +786,17 @@ __global__ void __launch_bounds__(256) k_syevi_mid(int n, int ith, int wantvec, 
       e[n - 1] = 0.0;
    }
    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) k_syevi_mid(int n, int ith, int wantvec, const double* __restrict__ in, double* __restrict__ out,
+   unsigned long long seq, unsigned long long* __restrict__ flag)
+{
+   extern __shared__ __attribute__((aligned(16))) double em_a[];
+   __shared__ double vv[EM_N], pp[EM_N], ww[EM_N], tau[EM_N], d[EM_N], e[EM_N], e2[EM_N], zz[EM_N];
+   __shared__ double wk[4][EM_N], swp[EM_N];
+   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   const int ld = n | 1;
+   em_tridiag(n, in, em_a, vv, pp, ww, tau, d, e);
    if ( wave != 0 )
       return;
 
@@ -925,6 +945,488 @@ __global__ void __launch_bounds__(256) k_syevi_mid(int n, int ith, int wantvec, 
 }
 
 
+/* ---- 64 < n <= 128: ALL eigenpairs in one launch ---------------------------------------------------------------------------------
+ * The phases of k_syevi_small<true> with two entries per lane, laid out for what 160 KB of LDS hold: the reduction needs the matrix
+ * there (132 KB at n = 128), the inverse iteration the eigenvectors of T.  So after the reduction the reflectors move to device
+ * memory, transposed (reflector k contiguous: the back-transformation reads it with one coalesced load per half), and the array
+ * becomes Z[i][k] (component i of vector k, the same odd pitch: thread-per-vector and lane-per-component accesses are both conflict
+ * free).  The two factor arrays of the thread-per-vector elimination (pivot reciprocals, first superdiagonal of U) live in device
+ * memory as [row][vector]: written once per round in the forward sweep (nobody waits for a store), read in the backward sweep eight
+ * rows ahead of the recurrence that uses them.  All eigenvalues by multisection as in the small kernel (thread = eigenvalue x one of
+ * four shifts), in two passes of 64 eigenvalues.  scratch: 3 * 128 * 128 doubles of device memory.
+ * out: [0, n) eigenvalues ascending, [EM_N + k n + i] component i of eigenvector k, flag word behind them. */
+#define EM_NT 512                   /* threads of k_syev_mid */
+#define EM_ALL_FLAG (EM_N + EM_N * EM_N + 4)
+#define EM_ALL_OUT (EM_N + EM_N * EM_N + 16)
+__global__ void __launch_bounds__(EM_NT) k_syev_mid(int n, const double* __restrict__ in, double* __restrict__ out, double* __restrict__ scratch,
+   unsigned long long seq, unsigned long long* __restrict__ flag)
+{
+   extern __shared__ __attribute__((aligned(16))) double em_a[];
+   __shared__ double vv[EM_N + 8], pp[EM_N], ww[EM_N + 8], tau[EM_N], d[EM_N], e[EM_N], zz[EM_N];
+   __shared__ double cbuf[2][EM_NT / 64][EM_N];            /* corrections of the wavefronts that share a large cluster */
+   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   const int ld = n | 1;
+   /* developer aid: phase ends in ticks of the 100 MHz counter behind the flag word (HIPSDP_SYEV_STAMPS=1 prints them) */
+   const long long w0 = wall_clock64();
+#define EM_STAMP(j) do { if ( tid == 0 ) out[EM_ALL_FLAG + 2 + (j)] = (double) (wall_clock64() - w0); } while (0)
+   em_tridiag(n, in, em_a, vv, pp, ww, tau, d, e);
+   EM_STAMP(0);
+
+   /* ---- the reflectors leave LDS: Vt[k][i] = entry i of reflector k (i > k + 1; entry k + 1 is the implied 1) */
+   double* __restrict__ Vt = scratch;
+   double* __restrict__ G0 = scratch + EM_N * EM_N;        /* [i][k]: 1 / pivot of row i of the elimination for vector k */
+   double* __restrict__ G1 = G0 + EM_N * EM_N;             /* first superdiagonal of U */
+   for (int idx = tid; idx < n * n; idx += EM_NT)
+   {
+      const int k = idx / n, i = idx - k * n;
+      Vt[k * EM_N + i] = (i > k + 1) ? em_a[i * ld + k] : 0.0;
+   }
+   __syncthreads();
+   double* Z = em_a;                                        /* [i][k], pitch ld */
+
+   /* ---- all eigenvalues: thread (k = tid >> 2 (+ 64 in the second pass), s = tid & 3) */
+   double glo = 1e300, ghi = -1e300, tnorm = 0.0;
+   for (int i = 0; i < n; ++i)
+   {
+      const double rad = (i > 0 ? fabs(e[i - 1]) : 0.0) + (i + 1 < n ? fabs(e[i]) : 0.0);
+      glo = fmin(glo, d[i] - rad);
+      ghi = fmax(ghi, d[i] + rad);
+      tnorm = fmax(tnorm, fabs(d[i]) + rad);
+   }
+   const double span0 = fmax(ghi - glo, 1e-300);
+   glo -= 1e-12 * span0 + 1e-300;
+   ghi += 1e-12 * span0 + 1e-300;
+   /* Sturm counts in product form on the matrix scaled to norm 1 (p_0 = 1, p_1 = d_0 - x, p_{i+1} = (d_i - x) p_i - e_{i-1}^2 p_{i-1};
+    * a sign change = an eigenvalue below x, a zero takes the sign opposite to its predecessor; rescaled every fourth step): two
+    * dependent operations per step where the quotient form of the small kernel has a division - 260 cycles per step, 640 us for the
+    * 128 eigenvalues of a 128 x 128 matrix */
+   const double sinv = 1.0 / fmax(tnorm, 1e-300);
+   double* ds = vv;                                         /* (free since the reduction) */
+   double* es = ww;
+   if ( tid < n )
+   {
+      ds[tid] = d[tid] * sinv;
+      es[tid] = (e[tid] * sinv) * (e[tid] * sinv);
+   }
+   __syncthreads();
+   if ( tid < 8 )
+   {
+      ds[n + tid] = 4.0;                                    /* rows behind the matrix: no coupling, no sign change (|x| <= 1) */
+      es[n - 1 + tid] = 0.0;
+   }
+   __syncthreads();
+   {
+      const int k = tid >> 2, sh = tid & 3;                 /* thread = (eigenvalue, one of four shifts) */
+      const int nb = (n - 1 + 3) >> 2;                      /* blocks of four steps i = 1 + 4 b .. 4 + 4 b */
+      double lo = glo * sinv, hi = ghi * sinv;
+      for (int round = 0; round < 40; ++round)
+      {
+         const double w = (hi - lo) * 0.2;
+         const double x = lo + w * (double) (sh + 1);
+         int cnt = 0;
+         if ( k < n )
+         {
+            double pp_ = 1.0, pc = ds[0] - x;
+            if ( pc == 0.0 ) pc = -1e-290;
+            bool posc = pc > 0.0;
+            cnt = posc ? 0 : 1;
+            /* the entries of the next block are on their way while the four steps of this one run */
+            double dn[4], en[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+            {
+               dn[u] = ds[1 + u];
+               en[u] = es[u];
+            }
+            for (int b = 0; b < nb; ++b)
+            {
+               double dc[4], ec[4];
+#pragma unroll
+               for (int u = 0; u < 4; ++u)
+               {
+                  dc[u] = dn[u];
+                  ec[u] = en[u];
+               }
+               const int nx = (b + 1 < nb) ? 5 + 4 * b : 1;
+#pragma unroll
+               for (int u = 0; u < 4; ++u)
+               {
+                  dn[u] = ds[nx + u];
+                  en[u] = es[nx - 1 + u];
+               }
+#pragma unroll
+               for (int u = 0; u < 4; ++u)
+               {
+                  double pn = fma(dc[u] - x, pc, -ec[u] * pp_);
+                  if ( pn == 0.0 ) pn = -copysign(1e-290, pc);
+                  const bool posn = pn > 0.0;
+                  cnt += (posn != posc) ? 1 : 0;
+                  pp_ = pc; pc = pn; posc = posn;
+               }
+               const int ex = -max(__builtin_amdgcn_frexp_exp(pc), __builtin_amdgcn_frexp_exp(pp_));
+               pc = ldexp(pc, ex);
+               pp_ = ldexp(pp_, ex);
+            }
+         }
+         int below = (cnt < k + 1) ? 1 : 0;
+         below += __builtin_amdgcn_update_dpp(0, below, 0xB1, 0xf, 0xf, true);
+         below += __builtin_amdgcn_update_dpp(0, below, 0x4E, 0xf, 0xf, true);
+         const double nlo = lo + w * (double) below;
+         const double nhi = (below < 4) ? lo + w * (double) (below + 1) : hi;
+         lo = nlo; hi = nhi;
+         /* (to two ulps of the eigenvalue - an interval cannot get shorter than one -, but not below half an ulp of the norm: 24
+          * rounds instead of all 40) */
+         if ( __all(k >= n || hi - lo <= 4.5e-16 * fmax(fmax(fabs(lo), fabs(hi)), 0.25)) )
+            break;
+      }
+      if ( k < n && sh == 0 )
+         zz[k] = 0.5 * (lo + hi) * tnorm;
+   }
+   __syncthreads();
+   EM_STAMP(1);
+   if ( tid < n )
+      out[tid] = zz[tid];
+
+   /* ---- eigenvectors of T: three rounds of { one step of inverse iteration per vector (thread k owns vector k), orthogonalisation
+    * inside the clusters } - see k_syevi_small for why in every round */
+   const double ortol = 1e-3 * fmax(tnorm, 1e-300);
+   for (int idx = tid; idx < n * n; idx += EM_NT)
+   {
+      const int i = idx / n, k = idx - i * n;
+      unsigned h = (unsigned) (i * 2654435761u) ^ (unsigned) ((k + 1) * 40503u);
+      h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+      Z[i * ld + k] = 0.5 + (double) (h & 0xFFFF) * (1.0 / 65536.0);
+   }
+   __syncthreads();
+   for (int iter = 0; iter < 3; ++iter)
+   {
+      {
+         const int k = tid;
+         if ( k < n )
+         {
+            const double theta = zz[k];
+            const double tiny = 1e-14 * fmax(span0, fmax(fabs(theta), 1e-300));
+            double dd = d[0] - theta, du = e[0];
+            double cur = Z[k];
+            unsigned long long swlo = 0ULL, swhi = 0ULL;     /* bit i (of 128): rows i and i + 1 were exchanged */
+            for (int i = 0; i < n - 1; ++i)
+            {
+               const double dl = e[i];
+               const double dn = d[i + 1] - theta;
+               const double un = (i + 2 < n) ? e[i + 1] : 0.0;
+               const double nxt = Z[(i + 1) * ld + k];
+               if ( fabs(dd) >= fabs(dl) || fabs(dl) < tiny )
+               {
+                  if ( fabs(dd) < tiny ) dd = tiny;
+                  const double rinv = ei_rcp2(dd);
+                  const double mlt = dl * rinv;
+                  G0[i * EM_N + k] = rinv; G1[i * EM_N + k] = du;
+                  Z[i * ld + k] = cur;
+                  cur = nxt - mlt * cur;
+                  dd = dn - mlt * du;
+                  du = un;
+               }
+               else
+               {
+                  const double rinv = ei_rcp2(dl);
+                  const double mlt = dd * rinv;
+                  G0[i * EM_N + k] = rinv; G1[i * EM_N + k] = dn;
+                  if ( i < 64 ) swlo |= 1ULL << i; else swhi |= 1ULL << (i - 64);
+                  Z[i * ld + k] = nxt;
+                  cur = cur - mlt * nxt;
+                  dd = du - mlt * dn;
+                  du = -mlt * un;
+               }
+            }
+            if ( fabs(dd) < tiny ) dd = tiny;
+            double x1 = cur * ei_rcp2(dd), x2 = 0.0;
+            double nrm = x1 * x1;
+            Z[(n - 1) * ld + k] = x1;
+            /* backward sweep, the factors of eight rows on their way while the recurrence runs */
+            for (int i0 = n - 2; i0 >= 0; i0 -= 8)
+            {
+               double g0[8], g1[8];
+#pragma unroll
+               for (int u = 0; u < 8; ++u)
+               {
+                  const int i = (i0 - u >= 0) ? i0 - u : 0;
+                  g0[u] = G0[i * EM_N + k];
+                  g1[u] = G1[i * EM_N + k];
+               }
+#pragma unroll
+               for (int u = 0; u < 8; ++u)
+               {
+                  const int i = i0 - u;
+                  if ( i >= 0 )
+                  {
+                     const bool sw = (i < 64) ? ((swlo >> i) & 1ULL) : ((swhi >> (i - 64)) & 1ULL);
+                     const double u2 = sw ? ((i + 2 < n) ? e[i + 1] : 0.0) : 0.0;
+                     const double xi = (Z[i * ld + k] - g1[u] * x1 - u2 * x2) * g0[u];
+                     Z[i * ld + k] = xi;
+                     nrm += xi * xi;
+                     x2 = x1; x1 = xi;
+                     if ( !(nrm < 1e280) )
+                     {
+                        const double sc1 = 1e-140;
+                        for (int j = i; j < n; ++j)
+                           Z[j * ld + k] *= sc1;
+                        x1 *= sc1; x2 *= sc1; nrm *= sc1 * sc1;
+                     }
+                  }
+               }
+            }
+            double rn = ei_rsqrt(fmax(nrm, 1e-300));
+            if ( !(nrm > 0.0) || !(nrm < 1e300) )
+            {
+               for (int i = 0; i < n; ++i)
+                  Z[i * ld + k] = (i == k) ? 1.0 : 0.0;
+               rn = 1.0;
+            }
+            for (int i = 0; i < n; ++i)
+               Z[i * ld + k] *= rn;
+         }
+         __syncthreads();
+         EM_STAMP(2 + 2 * iter);
+      }
+      /* clusters: one wavefront per cluster (cluster c goes to wavefront c mod 8).  Layout: the four rows of 16 lanes of the wavefront
+       * work on four vectors p of the cluster at a time, lane l of a row holds the components l + 16 j (j < 8): a dot product is
+       * eight multiply-adds and ONE reduction over 16 lanes for the four of them (lane = component over the whole wavefront: a
+       * 64-lane reduction of 25 instructions per dot product - 1.04 ms per round for the 96 zero eigenvalues of a rank-32 matrix of
+       * order 128, the whole decomposition slower than the Jacobi iteration).  Classical Gram-Schmidt against the vectors of the
+       * cluster before k, twice. */
+      {
+         const int l16 = lane & 15, row = lane >> 4;
+         int cl = -1;
+         int k0 = 0;
+         while ( k0 < n )
+         {
+            int k1 = k0 + 1;
+            while ( k1 < n && zz[k1] - zz[k1 - 1] <= ortol )
+               ++k1;
+            ++cl;
+            if ( k1 - k0 >= 16 )
+            {
+               /* a large cluster (the zero eigenvalues of a low-rank matrix): ALL wavefronts share it - the groups of four earlier
+                * vectors go round the wavefronts, the corrections meet in LDS (alone, one wavefront needed 600 us per round for
+                * 96 vectors: the decomposition of a rank-32 matrix of order 128 took as long as the Jacobi iteration) */
+               for (int k = k0; k < k1; ++k)
+               {
+                  double v[8];
+#pragma unroll
+                  for (int j = 0; j < 8; ++j)
+                  {
+                     const int i = l16 + 16 * j;
+                     v[j] = (i < n) ? Z[i * ld + k] : 0.0;
+                  }
+                  /* (one pass in the first two rounds - it only has to keep the vectors from collapsing onto each other before the
+                   * next amplification -, two in the last) */
+                  for (int pass = 0; pass < (iter == 2 ? 2 : 1); ++pass)
+                  {
+                     double corr[8];
+#pragma unroll
+                     for (int j = 0; j < 8; ++j)
+                        corr[j] = 0.0;
+                     for (int p0 = k0 + 4 * wave; p0 < k; p0 += 4 * (EM_NT / 64))
+                     {
+                        const int p = p0 + row;
+                        double u[8];
+                        double dt = 0.0;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                        {
+                           const int i = l16 + 16 * j;
+                           u[j] = (i < n && p < k) ? Z[i * ld + (p < k ? p : k0)] : 0.0;
+                           dt = fma(u[j], v[j], dt);
+                        }
+                        dt = ei_sum16(dt);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                           corr[j] = fma(dt, u[j], corr[j]);
+                     }
+#pragma unroll
+                     for (int j = 0; j < 8; ++j)
+                     {
+                        double c = corr[j];
+                        c += __shfl_xor(c, 16, 64);
+                        c += __shfl_xor(c, 32, 64);
+                        if ( row == 0 )
+                           cbuf[pass][wave][l16 + 16 * j] = c;
+                     }
+                     __syncthreads();
+#pragma unroll
+                     for (int j = 0; j < 8; ++j)
+                     {
+                        double c = 0.0;
+#pragma unroll
+                        for (int w = 0; w < EM_NT / 64; ++w)
+                           c += cbuf[pass][w][l16 + 16 * j];
+                        v[j] -= c;
+                     }
+                  }
+                  double nr = 0.0;
+#pragma unroll
+                  for (int j = 0; j < 8; ++j)
+                     nr = fma(v[j], v[j], nr);
+                  nr = ei_sum16(nr);
+                  const double rs = ei_rsqrt(fmax(nr, 1e-300));
+                  if ( wave == 0 && row == 0 )
+                  {
+#pragma unroll
+                     for (int j = 0; j < 8; ++j)
+                     {
+                        const int i = l16 + 16 * j;
+                        if ( i < n )
+                           Z[i * ld + k] = v[j] * rs;
+                     }
+                  }
+                  __syncthreads();
+               }
+            }
+            else if ( k1 - k0 > 1 && (cl & 7) == wave )
+            {
+               for (int k = k0; k < k1; ++k)
+               {
+                  double v[8];
+#pragma unroll
+                  for (int j = 0; j < 8; ++j)
+                  {
+                     const int i = l16 + 16 * j;
+                     v[j] = (i < n) ? Z[i * ld + k] : 0.0;
+                  }
+                  for (int pass = 0; pass < 2; ++pass)
+                  {
+                     double corr[8];
+#pragma unroll
+                     for (int j = 0; j < 8; ++j)
+                        corr[j] = 0.0;
+                     for (int p0 = k0; p0 < k; p0 += 4)
+                     {
+                        const int p = p0 + row;
+                        double u[8];
+                        double dt = 0.0;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                        {
+                           const int i = l16 + 16 * j;
+                           u[j] = (i < n && p < k) ? Z[i * ld + (p < k ? p : k0)] : 0.0;
+                           dt = fma(u[j], v[j], dt);
+                        }
+                        dt = ei_sum16(dt);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                           corr[j] = fma(dt, u[j], corr[j]);
+                     }
+                     /* the four rows' corrections together (every row ends with the same vector) */
+#pragma unroll
+                     for (int j = 0; j < 8; ++j)
+                     {
+                        double c = corr[j];
+                        c += __shfl_xor(c, 16, 64);
+                        c += __shfl_xor(c, 32, 64);
+                        v[j] -= c;
+                     }
+                  }
+                  double nr = 0.0;
+#pragma unroll
+                  for (int j = 0; j < 8; ++j)
+                     nr = fma(v[j], v[j], nr);
+                  nr = ei_sum16(nr);
+                  const double rs = ei_rsqrt(fmax(nr, 1e-300));
+                  if ( row == 0 )
+                  {
+#pragma unroll
+                     for (int j = 0; j < 8; ++j)
+                     {
+                        const int i = l16 + 16 * j;
+                        if ( i < n )
+                           Z[i * ld + k] = v[j] * rs;
+                     }
+                  }
+                  __builtin_amdgcn_s_waitcnt(0xc07f);
+                  __builtin_amdgcn_wave_barrier();
+               }
+            }
+            k0 = k1;
+         }
+      }
+      __syncthreads();
+      EM_STAMP(3 + 2 * iter);
+   }
+   /* ---- back-transformation x = H_0 H_1 ... H_{n-2} z in the same layout: a wavefront takes four vectors at a time (one per row of 16
+    * lanes, lane l: components l + 16 j), a reflector costs eight multiply-adds, one 16-lane reduction and eight more for the four of
+    * them (one vector per wavefront with a 64-lane reduction per reflector: 460 cycles each, 775 us at n = 128); the reflectors from
+    * device memory, two ahead */
+   {
+      const int l16 = lane & 15, row = lane >> 4;
+      for (int k0 = 4 * wave; k0 < n; k0 += 32)
+      {
+         const int k = k0 + row;
+         double z[8];
+#pragma unroll
+         for (int j = 0; j < 8; ++j)
+         {
+            const int i = l16 + 16 * j;
+            z[j] = (i < n && k < n) ? Z[i * ld + k] : 0.0;
+         }
+         for (int kk0 = n - 2; kk0 >= 0; kk0 -= 2)
+         {
+            double r0[8], r1[8];
+            const int kb = (kk0 - 1 >= 0) ? kk0 - 1 : 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+            {
+               r0[j] = Vt[kk0 * EM_N + l16 + 16 * j];
+               r1[j] = Vt[kb * EM_N + l16 + 16 * j];
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+            {
+               const int kk = kk0 - r;
+               if ( kk < 0 )
+                  continue;
+               const double t = tau[kk];
+               if ( t == 0.0 )
+                  continue;
+               double vr[8];
+               double dot = 0.0;
+#pragma unroll
+               for (int j = 0; j < 8; ++j)
+               {
+                  const int i = l16 + 16 * j;
+                  const double rv = r ? r1[j] : r0[j];
+                  vr[j] = (i > kk && i < n) ? ((i == kk + 1) ? 1.0 : rv) : 0.0;
+                  dot = fma(vr[j], z[j], dot);
+               }
+               dot = t * ei_sum16(dot);
+#pragma unroll
+               for (int j = 0; j < 8; ++j)
+                  z[j] = fma(-dot, vr[j], z[j]);
+            }
+         }
+         double nrm = 0.0;
+#pragma unroll
+         for (int j = 0; j < 8; ++j)
+            nrm = fma(z[j], z[j], nrm);
+         nrm = ei_sum16(nrm);
+         const double rs = nrm > 0.0 ? ei_rsqrt(nrm) : 1.0;
+#pragma unroll
+         for (int j = 0; j < 8; ++j)
+         {
+            const int i = l16 + 16 * j;
+            if ( k < n && i < n )
+               out[EM_N + (long long) k * n + i] = z[j] * rs;
+         }
+      }
+   }
+   __syncthreads();
+   EM_STAMP(8);
+#undef EM_STAMP
+   __threadfence_system();
+   __syncthreads();
+   if ( tid == 0 )
+      __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 /* per host thread and device: a stream and the pinned, device-mapped staging memory.  The object lives in thread-local storage:
  * its destructor returns stream and pinned memory when the thread ends. */
 #define EI_OUT_DOUBLES (EI_N * EI_N + EI_N + 16)       /* room for a full decomposition: eigenvalues, eigenvectors, flag word */
@@ -934,8 +1436,9 @@ struct ei_ctx
    hipStream_t stream;
    double* hin;  double* din;
    double* hout; double* dout;          /* one eigenpair: [0] eigenvalue, [1 .. 64] eigenvector, flag word at EI_N + 4 */
+   double* dscr;                        /* device memory of the full decomposition above 64 rows (k_syev_mid), allocated at its first call */
    unsigned long long seq;
-   ei_ctx() : device(-1), stream(NULL), hin(NULL), din(NULL), hout(NULL), dout(NULL), seq(0) {}
+   ei_ctx() : device(-1), stream(NULL), hin(NULL), din(NULL), hout(NULL), dout(NULL), dscr(NULL), seq(0) {}
    void release()
    {
       if ( stream != NULL )
@@ -946,7 +1449,8 @@ struct ei_ctx
       }
       if ( hin != NULL ) (void) hipHostFree(hin);
       if ( hout != NULL ) (void) hipHostFree(hout);
-      device = -1; stream = NULL; hin = din = hout = dout = NULL;
+      if ( dscr != NULL ) (void) hipFree(dscr);
+      device = -1; stream = NULL; hin = din = hout = dout = dscr = NULL;
    }
    ~ei_ctx() { release(); }
 };
@@ -967,7 +1471,7 @@ int ei_context(int device, ei_ctx** out)
    hipError_t e = hipSetDevice(device);
    if ( e == hipSuccess ) e = hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking);
    if ( e == hipSuccess ) e = hipHostMalloc((void**) &c.hin, (size_t) EM_N * EM_N * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
-   if ( e == hipSuccess ) e = hipHostMalloc((void**) &c.hout, (size_t) EI_OUT_DOUBLES * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
+   if ( e == hipSuccess ) e = hipHostMalloc((void**) &c.hout, (size_t) EM_ALL_OUT * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent);
    if ( e == hipSuccess ) e = hipHostGetDevicePointer((void**) &c.din, c.hin, 0);
    if ( e == hipSuccess ) e = hipHostGetDevicePointer((void**) &c.dout, c.hout, 0);
    if ( e != hipSuccess )
@@ -975,7 +1479,7 @@ int ei_context(int device, ei_ctx** out)
       hs_record_hip_error(e, "ei_context", __FILE__, __LINE__);
       return e == hipErrorOutOfMemory ? HS_ERR_NOMEM : HS_ERR_HIP;        /* c's destructor releases what had been created */
    }
-   memset(c.hout, 0, (size_t) EI_OUT_DOUBLES * sizeof(double));
+   memset(c.hout, 0, (size_t) EM_ALL_OUT * sizeof(double));
    g_ctx.device = c.device; g_ctx.stream = c.stream; g_ctx.hin = c.hin; g_ctx.din = c.din; g_ctx.hout = c.hout; g_ctx.dout = c.dout;
    g_ctx.seq = 0;
    c.device = -1; c.stream = NULL; c.hin = c.hout = NULL;                  /* ownership moved */
@@ -1044,27 +1548,42 @@ extern "C" int hipsdp_syevi_small(int device, int n, const double* A, int i, dou
    return HIPSDP_OK;
 }
 
-/* all eigenpairs of the symmetric n x n matrix A, n <= 64, in one launch through the same staging memory: lam ascending, row k of V =
- * k-th eigenvector (what SCIPlapackComputeEigenvectorDecomposition returns: lapack_interface.c:507-603).  HIPSDP_ERR_ARG for n > 64. */
+/* all eigenpairs of the symmetric n x n matrix A, n <= 128, in one launch through the same staging memory: lam ascending, row k of V =
+ * k-th eigenvector (what SCIPlapackComputeEigenvectorDecomposition returns: lapack_interface.c:507-603).  n <= 64: matrix in
+ * registers (k_syevi_small<true>), above: in LDS (k_syev_mid).  HIPSDP_ERR_ARG for n > 128. */
 extern "C" int hipsdp_syev_small(int device, int n, const double* A, double* lam, double* V)
 {
    int nd = 0;
    if ( hipGetDeviceCount(&nd) != hipSuccess || nd <= 0 )
       return HIPSDP_ERR_NODEVICE;
-   if ( device < 0 || device >= nd || n < 1 || n > EI_N || A == NULL || lam == NULL )
+   if ( device < 0 || device >= nd || n < 1 || n > EM_N || A == NULL || lam == NULL )
       return HIPSDP_ERR_ARG;
    ei_ctx* c = NULL;
    HS_CALL( ei_context(device, &c) );
    HS_HIP( hipSetDevice(device) );
-   static hs_attr_mask attr_done;
-   HS_CALL( hs_func_max_lds(reinterpret_cast<const void*>(&k_syevi_small<true>), EI_ALL_LDS, &attr_done) );
+   const bool mid = n > EI_N;
+   /* the flag word sits behind the eigenvalues and the eigenvector array */
+   const long long vecpos = mid ? EM_N : EI_N;
+   const long long flagpos = mid ? (long long) EM_ALL_FLAG : EI_N + (long long) EI_N * EI_N + 4;
+   if ( mid && c->dscr == NULL )
+      HS_HIP( hipMalloc((void**) &c->dscr, (size_t) 3 * EM_N * EM_N * sizeof(double)) );      /* (once per thread and device) */
    memcpy(c->hin, A, (size_t) n * n * sizeof(double));
    const unsigned long long seq = ++c->seq;
-   /* the flag word sits behind the eigenvalues and the n x n eigenvector array */
-   const long long flagpos = EI_N + (long long) EI_N * EI_N + 4;
    volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(c->hout + flagpos);
-   hipLaunchKernelGGL((k_syevi_small<true>), dim3(1), dim3(256), EI_ALL_LDS, c->stream, n, 0, 1, c->din, c->dout, seq,
-      reinterpret_cast<unsigned long long*>(c->dout + flagpos));
+   if ( mid )
+   {
+      static hs_attr_mask attr_mid;
+      HS_CALL( hs_func_max_lds(reinterpret_cast<const void*>(&k_syev_mid), EM_N * (EM_N + 1) * (int) sizeof(double), &attr_mid) );
+      hipLaunchKernelGGL(k_syev_mid, dim3(1), dim3(EM_NT), (size_t) n * (n | 1) * sizeof(double), c->stream, n, c->din, c->dout, c->dscr, seq,
+         reinterpret_cast<unsigned long long*>(c->dout + flagpos));
+   }
+   else
+   {
+      static hs_attr_mask attr_done;
+      HS_CALL( hs_func_max_lds(reinterpret_cast<const void*>(&k_syevi_small<true>), EI_ALL_LDS, &attr_done) );
+      hipLaunchKernelGGL((k_syevi_small<true>), dim3(1), dim3(256), EI_ALL_LDS, c->stream, n, 0, 1, c->din, c->dout, seq,
+         reinterpret_cast<unsigned long long*>(c->dout + flagpos));
+   }
    HS_HIP( hipGetLastError() );
    long long spins = 0;
    while ( *flag != seq )
@@ -1091,19 +1610,40 @@ extern "C" int hipsdp_syev_small(int device, int n, const double* A, double* lam
    __atomic_thread_fence(__ATOMIC_ACQUIRE);
    memcpy(lam, c->hout, (size_t) n * sizeof(double));
    if ( V != NULL )
-      memcpy(V, c->hout + EI_N, (size_t) n * n * sizeof(double));
+      memcpy(V, c->hout + vecpos, (size_t) n * n * sizeof(double));
+   if ( mid )
+   {
+      static const bool stamps = getenv("HIPSDP_SYEV_STAMPS") != NULL && atoi(getenv("HIPSDP_SYEV_STAMPS")) != 0;
+      if ( stamps )
+      {
+         const double* t = c->hout + EM_ALL_FLAG + 2;
+         fprintf(stderr, "hipsdp syev n = %d, us since kernel start: reduction %.0f, eigenvalues %.0f, rounds %.0f %.0f | %.0f %.0f | %.0f %.0f, back-transformation %.0f\n",
+            n, t[0] * 0.01, t[1] * 0.01, t[2] * 0.01, t[3] * 0.01, t[4] * 0.01, t[5] * 0.01, t[6] * 0.01, t[7] * 0.01, t[8] * 0.01);
+      }
+   }
    return HIPSDP_OK;
 }
 
-/* the same kernel on device buffers, in stream order (no staging memory, no polling): lam[n] ascending, V[n][n] with row k = k-th
- * eigenvector; scratch: hs_syev_small_scratch() doubles.  For device-side chains that need the decomposition the SCIPlapack entry
- * point returns (psd.hip: the PSD projection of the warm-start producer) - same eigenvectors, same signs. */
-long long hs_syev_small_scratch(void) { return EI_OUT_DOUBLES; }
+/* the same kernels on device buffers, in stream order (no staging memory, no polling): lam[n] ascending, V[n][n] with row k = k-th
+ * eigenvector; scratch: hs_syev_small_scratch(n) doubles.  For device-side chains that need the decomposition the SCIPlapack entry
+ * point returns (psd.hip: the PSD projection of the warm-start producer) - same eigenvectors, same signs.  n <= 128. */
+long long hs_syev_small_scratch(int n) { return n <= EI_N ? (long long) EI_OUT_DOUBLES : (long long) EM_ALL_OUT + 3LL * EM_N * EM_N; }
 
 int hs_syev_small_dev(hipStream_t st, int n, const double* A, double* lam, double* V, double* scratch)
 {
-   if ( n < 1 || n > EI_N )
+   if ( n < 1 || n > EM_N )
       return HS_ERR_ARG;
+   if ( n > EI_N )
+   {
+      static hs_attr_mask attr_mid;
+      HS_CALL( hs_func_max_lds(reinterpret_cast<const void*>(&k_syev_mid), EM_N * (EM_N + 1) * (int) sizeof(double), &attr_mid) );
+      hipLaunchKernelGGL(k_syev_mid, dim3(1), dim3(EM_NT), (size_t) n * (n | 1) * sizeof(double), st, n, A, scratch, scratch + EM_ALL_OUT, 1ULL,
+         reinterpret_cast<unsigned long long*>(scratch + EM_ALL_FLAG));
+      HS_HIP( hipGetLastError() );
+      HS_HIP( hipMemcpyAsync(lam, scratch, (size_t) n * sizeof(double), hipMemcpyDeviceToDevice, st) );
+      HS_HIP( hipMemcpyAsync(V, scratch + EM_N, (size_t) n * n * sizeof(double), hipMemcpyDeviceToDevice, st) );
+      return HS_OK;
+   }
    static hs_attr_mask attr_done;
    HS_CALL( hs_func_max_lds(reinterpret_cast<const void*>(&k_syevi_small<true>), EI_ALL_LDS, &attr_done) );
    const long long flagpos = EI_N + (long long) EI_N * EI_N + 4;

@@ -183,10 +183,11 @@ extern "C" int hipsdp_syev(int device, int n, const double* A, double* lam, doub
 {
    if ( n <= 0 || A == NULL || lam == NULL )
       return HIPSDP_ERR_ARG;
-   /* the sizes the callers of SCIPlapackComputeEigenvectorDecomposition use (blocks of 2-50 rows): tridiagonal reduction, multisection
-    * and inverse iteration in ONE launch through pinned staging memory (eigi.hip); HIPSDP_SYEV_JACOBI=1 keeps the Jacobi path */
+   /* the sizes the callers of SCIPlapackComputeEigenvectorDecomposition use (blocks of 2-50 rows, and up to 128): tridiagonal
+    * reduction, multisection and inverse iteration in ONE launch through pinned staging memory (eigi.hip); HIPSDP_SYEV_JACOBI=1 keeps
+    * the Jacobi path */
    static const bool jacobi_small = getenv("HIPSDP_SYEV_JACOBI") != NULL && atoi(getenv("HIPSDP_SYEV_JACOBI")) != 0;
-   if ( n <= 64 && !jacobi_small )
+   if ( n <= 128 && !jacobi_small )
       return hipsdp_syev_small(device, n, A, lam, V);
    /* above: block Jacobi on the device (eig.hip), operands copied by the copy engine on the context's stream */
    const long long n2 = even((long long) n * n), nl = even(n), nws = even(hs_syev_ws(n));

@@ -224,8 +224,8 @@ int hs_lanczos_lmin2(hipStream_t s, int n, const double* W0, const double* W1, i
 long long hs_lanczos_sync_words(void);
 int hs_lanczos_sync_reset(hipStream_t s, unsigned long long* dsync, int* rot);
 
-/* eigi.hip: n <= 64, all eigenpairs in one launch on device buffers (same results as hipsdp_syev_small) */
-long long hs_syev_small_scratch(void);
+/* eigi.hip: n <= 128, all eigenpairs in one launch on device buffers (same results as hipsdp_syev_small) */
+long long hs_syev_small_scratch(int n);
 int hs_syev_small_dev(hipStream_t st, int n, const double* A, double* lam, double* V, double* scratch);
 
 /* Cyclic Jacobi eigen-decomposition of the symmetric n x n matrix A (destroyed): eigenvalues ascending in lam[n],

@@ -158,10 +158,10 @@ extern "C" int hipsdp_psd_project(int device, int n, int nnz, const int* row, co
    /* the decomposition SCIPlapackComputeEigenvectorDecomposition returns for this size (the literal chain of mode 0 depends on the
     * basis: both paths must use the same eigenvectors) */
    static const bool jacobi_small = getenv("HIPSDP_SYEV_JACOBI") != NULL && atoi(getenv("HIPSDP_SYEV_JACOBI")) != 0;
-   if ( n <= 64 && !jacobi_small )
+   if ( n <= 128 && !jacobi_small )
    {
       PoolBuf<double> scr;
-      HS_CALL( scr.alloc(hs_syev_small_scratch()) );
+      HS_CALL( scr.alloc(hs_syev_small_scratch(n)) );
       HS_CALL( hs_syev_small_dev(st, n, A.p, lam.p, V.p, scr.p) );
       HS_HIP( hipStreamSynchronize(st) );            /* scr goes back to the pool */
    }

@@ -183,6 +183,30 @@ def test_small_full_decomposition_in_one_launch(gpu, n):
         assert np.abs(V @ W @ V.T - np.diag(lam)).max() <= 1e-11 * scale, (name, np.abs(V @ W @ V.T - np.diag(lam)).max())
 
 
+@pytest.mark.parametrize("n", [65, 66, 80, 100, 127, 128])
+def test_mid_full_decomposition_in_one_launch(gpu, n):
+    """64 < n <= 128: the same in one launch with the matrix in LDS (k_syev_mid: reflectors and factor arrays in device memory, the
+    eigenvectors of the tridiagonal matrix in the LDS the matrix leaves) - the spectra of the test above."""
+    rng = np.random.default_rng(100 + n)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    cases = {"random": (lambda G: G + G.T)(rng.standard_normal((n, n))),
+             "diagonal": np.diag(rng.standard_normal(n)),
+             "identity": 3.5 * np.eye(n),
+             "low_rank": (lambda B: B @ B.T)(rng.standard_normal((n, max(1, n // 4)))),
+             "close_pairs": (Q * np.repeat(np.arange(1, n // 2 + 2, dtype=float), 2)[:n] * (1 + 1e-9 * np.arange(n))) @ Q.T,
+             "graded": (Q * 10.0 ** np.linspace(-6, 6, n)) @ Q.T,
+             "two_clusters": (Q * np.where(np.arange(n) < n // 2, -1.0, 2.0)) @ Q.T}
+    for name, W in cases.items():
+        W = 0.5 * (W + W.T)
+        lam, V = gpu.syev(W)
+        ev = np.linalg.eigvalsh(W)
+        scale = max(1.0, np.abs(ev).max())
+        assert np.abs(lam - ev).max() <= 1e-12 * scale, (name, np.abs(lam - ev).max())
+        assert np.all(np.diff(lam) >= 0.0), name
+        assert np.abs(V @ V.T - np.eye(n)).max() <= 1e-11, (name, np.abs(V @ V.T - np.eye(n)).max())
+        assert np.abs(V @ W @ V.T - np.diag(lam)).max() <= 1e-11 * scale, (name, np.abs(V @ W @ V.T - np.diag(lam)).max())
+
+
 @pytest.mark.parametrize("R,E", [(1, 1), (5, 100), (37, 10000), (300, 40001), (1001, 2500)])
 def test_gemv_passes(gpu, R, E):
     A = RNG.standard_normal((R, E))
