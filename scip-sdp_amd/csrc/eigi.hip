@@ -1427,6 +1427,24 @@ __global__ void __launch_bounds__(EM_NT) k_syev_mid(int n, const double* __restr
       __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+/* from how many rows on the full decomposition takes k_syev_mid (HIPSDP_SYEV_MID_FROM, read once; both entry points use the same
+ * rule: the literal PSD projection chain depends on the basis).  Default 10: written for 64 < n <= 128, the kernel turned out to be
+ * ahead of k_syevi_small<true> - whose matrix sits in registers, but whose counts are in quotient form and whose reductions span
+ * 64 lanes - from 10 rows on (16: 104 against 121 us per call, 33: 188 / 236, 48: 277 / 369, 64: 389 / 538), level below. */
+static int em_mid_from(void)
+{
+   static int from = -1;
+   if ( from < 0 )
+   {
+      const char* env = getenv("HIPSDP_SYEV_MID_FROM");
+      int v = env != NULL ? atoi(env) : 10;
+      if ( v < 2 ) v = 2;
+      if ( v > EI_N + 1 ) v = EI_N + 1;
+      from = v;
+   }
+   return from;
+}
+
 /* per host thread and device: a stream and the pinned, device-mapped staging memory.  The object lives in thread-local storage:
  * its destructor returns stream and pinned memory when the thread ends. */
 #define EI_OUT_DOUBLES (EI_N * EI_N + EI_N + 16)       /* room for a full decomposition: eigenvalues, eigenvectors, flag word */
@@ -1561,7 +1579,7 @@ extern "C" int hipsdp_syev_small(int device, int n, const double* A, double* lam
    ei_ctx* c = NULL;
    HS_CALL( ei_context(device, &c) );
    HS_HIP( hipSetDevice(device) );
-   const bool mid = n > EI_N;
+   const bool mid = n >= em_mid_from();
    /* the flag word sits behind the eigenvalues and the eigenvector array */
    const long long vecpos = mid ? EM_N : EI_N;
    const long long flagpos = mid ? (long long) EM_ALL_FLAG : EI_N + (long long) EI_N * EI_N + 4;
@@ -1627,13 +1645,13 @@ extern "C" int hipsdp_syev_small(int device, int n, const double* A, double* lam
 /* the same kernels on device buffers, in stream order (no staging memory, no polling): lam[n] ascending, V[n][n] with row k = k-th
  * eigenvector; scratch: hs_syev_small_scratch(n) doubles.  For device-side chains that need the decomposition the SCIPlapack entry
  * point returns (psd.hip: the PSD projection of the warm-start producer) - same eigenvectors, same signs.  n <= 128. */
-long long hs_syev_small_scratch(int n) { return n <= EI_N ? (long long) EI_OUT_DOUBLES : (long long) EM_ALL_OUT + 3LL * EM_N * EM_N; }
+long long hs_syev_small_scratch(int n) { return n < em_mid_from() ? (long long) EI_OUT_DOUBLES : (long long) EM_ALL_OUT + 3LL * EM_N * EM_N; }
 
 int hs_syev_small_dev(hipStream_t st, int n, const double* A, double* lam, double* V, double* scratch)
 {
    if ( n < 1 || n > EM_N )
       return HS_ERR_ARG;
-   if ( n > EI_N )
+   if ( n >= em_mid_from() )
    {
       static hs_attr_mask attr_mid;
       HS_CALL( hs_func_max_lds(reinterpret_cast<const void*>(&k_syev_mid), EM_N * (EM_N + 1) * (int) sizeof(double), &attr_mid) );

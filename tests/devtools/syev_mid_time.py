@@ -6,7 +6,7 @@ import numpy as np
 spec = importlib.util.spec_from_file_location('hipsdp_binding', os.path.join(ROOT, 'scip-sdp_amd', 'binding.py'))
 hb = importlib.util.module_from_spec(spec); spec.loader.exec_module(hb)
 rng = np.random.default_rng(1)
-sizes = (32, 64, 65, 80, 96, 100, 112, 128)
+sizes = tuple(int(v) for v in sys.argv[1].split(',')) if len(sys.argv) > 1 else (32, 64, 65, 80, 96, 100, 112, 128)
 mats = {}
 for n in sizes:
     G = rng.standard_normal((n, n)); mats[n] = G + G.T
