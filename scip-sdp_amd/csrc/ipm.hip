@@ -4005,8 +4005,9 @@ static int check_y_impl(hipsdp_solver* s, const double* y, double tol, double* l
       double l0 = 0.0;
       int rc = dalloc(&lam, n);
       if ( rc == HS_OK ) rc = dalloc(&V, n2);
-      if ( rc == HS_OK ) rc = dalloc(&ws, hs_syev_ws(n));
-      if ( rc == HS_OK ) rc = hs_syev_jacobi(st, n, B.W, lam, V, NULL, ws);
+      /* (up to 128 rows: tridiagonal reduction, multisection, inverse iteration in one launch, eigi.hip; block Jacobi above) */
+      if ( rc == HS_OK ) rc = dalloc(&ws, n <= 128 ? hs_syev_small_scratch(n) : hs_syev_ws(n));
+      if ( rc == HS_OK ) rc = n <= 128 ? hs_syev_small_dev(st, n, B.W, lam, V, ws) : hs_syev_jacobi(st, n, B.W, lam, V, NULL, ws);
       if ( rc == HS_OK && (hipMemcpyAsync(&l0, lam, sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess
             || hipStreamSynchronize(st) != hipSuccess) )
          rc = HS_ERR_HIP;
@@ -4030,7 +4031,7 @@ __global__ void k_outer_row(int n, const double* __restrict__ V, int row, double
 /* Eigenvector cuts of one block at the point y (LP-based mode of the reference: cons_sdp.c:896-1010 produceCutFromEigenvector,
  * :1612-1803 separateSol): every eigenvector v of Z(y) = sum_i A_i y_i - A_0 with eigenvalue <= -tol gives the valid inequality
  *    sum_i (v^T A_i v) y_i >= v^T A_0 v.
- * Z(y) (one pass over A), its eigen-decomposition (Jacobi) and the coefficients <A_i, v v^T> (one pass over A per cut) are
+ * Z(y) (one pass over A), its eigen-decomposition (one launch up to 128 rows, block Jacobi above) and the coefficients <A_i, v v^T> (one pass over A per cut) are
  * formed on the device.  The most negative eigenvalues come first; at most maxcuts cuts.
  * eigvals[maxcuts], coefs[maxcuts x m], lhs[maxcuts], vecs[maxcuts x n] (may be NULL) are host arrays. */
 extern "C" int hipsdp_eigencuts(hipsdp_solver* s, int block, const double* y, double tol, int maxcuts, int* ncuts, double* eigvals,
@@ -4061,9 +4062,9 @@ extern "C" int hipsdp_eigencuts(hipsdp_solver* s, int block, const double* y, do
    std::vector<double> hlam(n), hout;
    int rc = dalloc(&lam, n);
    if ( rc == HS_OK ) rc = dalloc(&V, n2);
-   if ( rc == HS_OK ) rc = dalloc(&ws, hs_syev_ws(n));
+   if ( rc == HS_OK ) rc = dalloc(&ws, n <= 128 ? hs_syev_small_scratch(n) : hs_syev_ws(n));
    if ( rc == HS_OK ) rc = dalloc(&out, m1);
-   if ( rc == HS_OK ) rc = hs_syev_jacobi(st, n, B.W, lam, V, NULL, ws);
+   if ( rc == HS_OK ) rc = n <= 128 ? hs_syev_small_dev(st, n, B.W, lam, V, ws) : hs_syev_jacobi(st, n, B.W, lam, V, NULL, ws);
    if ( rc == HS_OK && (hipMemcpyAsync(hlam.data(), lam, (size_t) n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess
          || hipStreamSynchronize(st) != hipSuccess) )
       rc = HS_ERR_HIP;
