@@ -111,6 +111,58 @@ __device__ __forceinline__ double ei_rcp(double t)
  * Dynamic LDS (ALL only): Z[64][64] (component-major: Z[i * 64 + k] = component i of vector k) and two [64][64] factor arrays (pivot
  * reciprocals and the first superdiagonal of U; its second superdiagonal is e[i + 1] in the rows that were swapped and 0 elsewhere:
  * one bit per row in a register). */
+/* Number of eigenvalues below x of the symmetric tridiagonal matrix scaled to norm <= 1: ds[i] = d_i / norm, es[i] = (e_i / norm)^2,
+ * both padded behind the matrix (ds: eight entries 4.0, es: zeros from n - 1 on: rows without coupling that cannot change a sign
+ * while |x| <= 1); nb = (n - 1 + 3) >> 2 blocks of four steps.  Sturm sequence in PRODUCT form: p_0 = 1, p_1 = d_0 - x,
+ * p_{i+1} = (d_i - x) p_i - e_{i-1}^2 p_{i-1}; a sign change = an eigenvalue below x, a zero takes the sign opposite to its
+ * predecessor; rescaled every fourth step; the entries of the next block are on their way while the four steps of this one run.
+ * Two dependent operations per step where the quotient form t_i = d_i - x - e_{i-1}^2 / t_{i-1} has a division: 260 cycles per step
+ * (the division in double precision is a chain of a dozen dependent instructions) against about 60. */
+__device__ __forceinline__ int ei_sturm_count(const double* ds, const double* es, int nb, double x)
+{
+   double pp_ = 1.0, pc = ds[0] - x;
+   if ( pc == 0.0 ) pc = -1e-290;
+   bool posc = pc > 0.0;
+   int cnt = posc ? 0 : 1;
+   double dn[4], en[4];
+#pragma unroll
+   for (int u = 0; u < 4; ++u)
+   {
+      dn[u] = ds[1 + u];
+      en[u] = es[u];
+   }
+   for (int b = 0; b < nb; ++b)
+   {
+      double dc[4], ec[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+      {
+         dc[u] = dn[u];
+         ec[u] = en[u];
+      }
+      const int nx = (b + 1 < nb) ? 5 + 4 * b : 1;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+      {
+         dn[u] = ds[nx + u];
+         en[u] = es[nx - 1 + u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+      {
+         double pn = fma(dc[u] - x, pc, -ec[u] * pp_);
+         if ( pn == 0.0 ) pn = -copysign(1e-290, pc);
+         const bool posn = pn > 0.0;
+         cnt += (posn != posc) ? 1 : 0;
+         pp_ = pc; pc = pn; posc = posn;
+      }
+      const int ex = -max(__builtin_amdgcn_frexp_exp(pc), __builtin_amdgcn_frexp_exp(pp_));
+      pc = ldexp(pc, ex);
+      pp_ = ldexp(pp_, ex);
+   }
+   return cnt;
+}
+
 #define EI_ALL_LDS ((EI_N * EI_N + 2 * EI_N * EI_N) * (int) sizeof(double))
 /* the body (flag == NULL: no sequence number, no system-scope fence - the caller is another kernel of the engine, see
  * k_lmin_exact_multi below; in may then point into LDS) */
@@ -120,7 +172,7 @@ __device__ __forceinline__ void d_syevi_small(int n, int ith, int wantvec, const
 {
    extern __shared__ __attribute__((aligned(16))) double ei_dyn[];
    __shared__ double a[EI_N][EI_LD];
-   __shared__ double vv[EI_N], pp[EI_N], ww[EI_N], tau[EI_N], d[EI_N], e[EI_N], e2[EI_N], zz[EI_N], xc[EI_N];
+   __shared__ double vv[EI_N], pp[EI_N + 8], ww[EI_N], tau[EI_N], d[EI_N], e[EI_N], e2[EI_N], zz[EI_N], xc[EI_N + 8];
    __shared__ double wk[4][EI_N], swp[EI_N];
    __shared__ double sc[4];
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -459,45 +511,57 @@ __device__ __forceinline__ void d_syevi_small(int n, int ith, int wantvec, const
    if ( wave != 0 )
       return;
 
-   /* ---- wavefront 0: i-th eigenvalue of T by Sturm multisection */
-
-   if ( lane < n )
-      e2[lane] = e[lane] * e[lane];
-   __builtin_amdgcn_wave_barrier();
-   double lo = 1e300, hi = -1e300;
+   /* ---- wavefront 0: i-th eigenvalue of T by Sturm multisection, 64 shifts per round, counts in product form on the matrix scaled
+    * to norm 1 (ei_sturm_count) */
+   double lo = 1e300, hi = -1e300, tnorm = 0.0;
    for (int i = 0; i < n; ++i)
    {
       const double rad = (i > 0 ? fabs(e[i - 1]) : 0.0) + (i + 1 < n ? fabs(e[i]) : 0.0);
       lo = fmin(lo, d[i] - rad);
       hi = fmax(hi, d[i] + rad);
+      tnorm = fmax(tnorm, fabs(d[i]) + rad);
    }
    const double span0 = fmax(hi - lo, 1e-300);
    lo -= 1e-12 * span0 + 1e-300;
    hi += 1e-12 * span0 + 1e-300;
-   const double pivmin = 1e-290;
+   tnorm = fmax(tnorm, 1e-300);
+   const double sinv = 1.0 / tnorm;
+   double* ds = pp;                                    /* (free since the reduction) */
+   double* es = xc;
+   if ( lane < n )
+   {
+      ds[lane] = d[lane] * sinv;
+      es[lane] = (e[lane] * sinv) * (e[lane] * sinv);
+   }
+   __builtin_amdgcn_s_waitcnt(0xc07f);
+   __builtin_amdgcn_wave_barrier();
+   if ( lane < 8 )
+   {
+      ds[n + lane] = 4.0;
+      es[n - 1 + lane] = 0.0;
+   }
+   __builtin_amdgcn_s_waitcnt(0xc07f);
+   __builtin_amdgcn_wave_barrier();
+   lo *= sinv; hi *= sinv;
+   const int nb = (n - 1 + 3) >> 2;
+   /* the search ends at two ulps of the eigenvalue (an interval cannot get shorter than one: the test "2e-16 relative" never fired
+    * and all 16 rounds ran) or at the caller's relative width; without a caller's width not below half an ulp of the norm */
+   const double rtol = fmax(mtol, 4.5e-16);
+   const double rfloor = (mtol <= 4.5e-16) ? 0.25 : 0.0;
    for (int round = 0; round < 16; ++round)
    {
       const double x = lo + (hi - lo) * (double) (lane + 1) / 65.0;
-      int cnt = 0;                                     /* eigenvalues below x */
-      double t = d[0] - x;
-      if ( fabs(t) < pivmin ) t = -pivmin;
-      if ( t < 0.0 ) ++cnt;
-      for (int i = 1; i < n; ++i)
-      {
-         t = d[i] - x - e2[i - 1] * ei_rcp(t);
-         if ( fabs(t) < pivmin ) t = -pivmin;
-         if ( !(fabs(t) < 1e290) ) t = (t < 0.0) ? -1e290 : 1e290;
-         if ( t < 0.0 ) ++cnt;
-      }
+      const int cnt = ei_sturm_count(ds, es, nb, x);   /* eigenvalues below x */
       const unsigned long long msk = __ballot(cnt >= ith);
       const int first = msk ? __ffsll((long long) msk) - 1 : 64;      /* first shift with at least ith eigenvalues below it */
       const double w = (hi - lo) / 65.0;
       const double nlo = lo + w * (double) first;
       const double nhi = (first < 64) ? lo + w * (double) (first + 1) : hi;
       lo = nlo; hi = nhi;
-      if ( hi - lo <= mtol * fmax(fabs(lo), fabs(hi)) )
+      if ( hi - lo <= rtol * fmax(fmax(fabs(lo), fabs(hi)), rfloor) )
          break;
    }
+   lo *= tnorm; hi *= tnorm;
    const double theta = 0.5 * (lo + hi);
    if ( lane == 0 )
    {
@@ -792,7 +856,7 @@ __global__ void __launch_bounds__(256) k_syevi_mid(int n, int ith, int wantvec, 
    unsigned long long seq, unsigned long long* __restrict__ flag)
 {
    extern __shared__ __attribute__((aligned(16))) double em_a[];
-   __shared__ double vv[EM_N], pp[EM_N], ww[EM_N], tau[EM_N], d[EM_N], e[EM_N], e2[EM_N], zz[EM_N];
+   __shared__ double vv[EM_N + 8], pp[EM_N], ww[EM_N + 8], tau[EM_N], d[EM_N], e[EM_N], zz[EM_N];
    __shared__ double wk[4][EM_N], swp[EM_N];
    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
    const int ld = n | 1;
@@ -800,45 +864,52 @@ __global__ void __launch_bounds__(256) k_syevi_mid(int n, int ith, int wantvec, 
    if ( wave != 0 )
       return;
 
-   /* ---- wavefront 0: i-th eigenvalue of T by Sturm multisection (64 shifts per round) */
-   for (int i = lane; i < n; i += 64)
-      e2[i] = e[i] * e[i];
-   __builtin_amdgcn_s_waitcnt(0xc07f);
-   __builtin_amdgcn_wave_barrier();
-   double lo = 1e300, hi = -1e300;
+   /* ---- wavefront 0: i-th eigenvalue of T by Sturm multisection (64 shifts per round, counts in product form: ei_sturm_count) */
+   double lo = 1e300, hi = -1e300, tnorm = 0.0;
    for (int i = 0; i < n; ++i)
    {
       const double rad = (i > 0 ? fabs(e[i - 1]) : 0.0) + (i + 1 < n ? fabs(e[i]) : 0.0);
       lo = fmin(lo, d[i] - rad);
       hi = fmax(hi, d[i] + rad);
+      tnorm = fmax(tnorm, fabs(d[i]) + rad);
    }
    const double span0 = fmax(hi - lo, 1e-300);
    lo -= 1e-12 * span0 + 1e-300;
    hi += 1e-12 * span0 + 1e-300;
-   const double pivmin = 1e-290;
+   tnorm = fmax(tnorm, 1e-300);
+   const double sinv = 1.0 / tnorm;
+   double* ds = vv;                                    /* (free since the reduction) */
+   double* es = ww;
+   for (int i = lane; i < n; i += 64)
+   {
+      ds[i] = d[i] * sinv;
+      es[i] = (e[i] * sinv) * (e[i] * sinv);
+   }
+   __builtin_amdgcn_s_waitcnt(0xc07f);
+   __builtin_amdgcn_wave_barrier();
+   if ( lane < 8 )
+   {
+      ds[n + lane] = 4.0;
+      es[n - 1 + lane] = 0.0;
+   }
+   __builtin_amdgcn_s_waitcnt(0xc07f);
+   __builtin_amdgcn_wave_barrier();
+   lo *= sinv; hi *= sinv;
+   const int nb = (n - 1 + 3) >> 2;
    for (int round = 0; round < 16; ++round)
    {
       const double x = lo + (hi - lo) * (double) (lane + 1) / 65.0;
-      int cnt = 0;                                     /* eigenvalues below x */
-      double t = d[0] - x;
-      if ( fabs(t) < pivmin ) t = -pivmin;
-      if ( t < 0.0 ) ++cnt;
-      for (int i = 1; i < n; ++i)
-      {
-         t = d[i] - x - e2[i - 1] * ei_rcp(t);
-         if ( fabs(t) < pivmin ) t = -pivmin;
-         if ( !(fabs(t) < 1e290) ) t = (t < 0.0) ? -1e290 : 1e290;
-         if ( t < 0.0 ) ++cnt;
-      }
+      const int cnt = ei_sturm_count(ds, es, nb, x);   /* eigenvalues below x */
       const unsigned long long msk = __ballot(cnt >= ith);
       const int first = msk ? __ffsll((long long) msk) - 1 : 64;      /* first shift with at least ith eigenvalues below it */
       const double w = (hi - lo) / 65.0;
       const double nlo = lo + w * (double) first;
       const double nhi = (first < 64) ? lo + w * (double) (first + 1) : hi;
       lo = nlo; hi = nhi;
-      if ( hi - lo <= 2e-16 * fmax(fabs(lo), fabs(hi)) )
+      if ( hi - lo <= 4.5e-16 * fmax(fmax(fabs(lo), fabs(hi)), 0.25) )
          break;
    }
+   lo *= tnorm; hi *= tnorm;
    const double theta = 0.5 * (lo + hi);
    if ( lane == 0 )
       out[0] = theta;
@@ -1023,51 +1094,7 @@ __global__ void __launch_bounds__(EM_NT) k_syev_mid(int n, const double* __restr
       {
          const double w = (hi - lo) * 0.2;
          const double x = lo + w * (double) (sh + 1);
-         int cnt = 0;
-         if ( k < n )
-         {
-            double pp_ = 1.0, pc = ds[0] - x;
-            if ( pc == 0.0 ) pc = -1e-290;
-            bool posc = pc > 0.0;
-            cnt = posc ? 0 : 1;
-            /* the entries of the next block are on their way while the four steps of this one run */
-            double dn[4], en[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-            {
-               dn[u] = ds[1 + u];
-               en[u] = es[u];
-            }
-            for (int b = 0; b < nb; ++b)
-            {
-               double dc[4], ec[4];
-#pragma unroll
-               for (int u = 0; u < 4; ++u)
-               {
-                  dc[u] = dn[u];
-                  ec[u] = en[u];
-               }
-               const int nx = (b + 1 < nb) ? 5 + 4 * b : 1;
-#pragma unroll
-               for (int u = 0; u < 4; ++u)
-               {
-                  dn[u] = ds[nx + u];
-                  en[u] = es[nx - 1 + u];
-               }
-#pragma unroll
-               for (int u = 0; u < 4; ++u)
-               {
-                  double pn = fma(dc[u] - x, pc, -ec[u] * pp_);
-                  if ( pn == 0.0 ) pn = -copysign(1e-290, pc);
-                  const bool posn = pn > 0.0;
-                  cnt += (posn != posc) ? 1 : 0;
-                  pp_ = pc; pc = pn; posc = posn;
-               }
-               const int ex = -max(__builtin_amdgcn_frexp_exp(pc), __builtin_amdgcn_frexp_exp(pp_));
-               pc = ldexp(pc, ex);
-               pp_ = ldexp(pp_, ex);
-            }
-         }
+         const int cnt = (k < n) ? ei_sturm_count(ds, es, nb, x) : 0;
          int below = (cnt < k + 1) ? 1 : 0;
          below += __builtin_amdgcn_update_dpp(0, below, 0xB1, 0xf, 0xf, true);
          below += __builtin_amdgcn_update_dpp(0, below, 0x4E, 0xf, 0xf, true);
