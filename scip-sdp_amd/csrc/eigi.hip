@@ -737,10 +737,14 @@ __global__ void __launch_bounds__(256) k_lmin_exact_multi(hs_step_jobs P)
  * back-transformation are those of the small kernel with two entries per lane. */
 #define EM_N 128
 #define EM_FLAG 256                 /* position of the flag word in the output (behind eigenvalue + eigenvector) */
+#define EM_NT 512                   /* threads of the two kernels for n <= 128 */
 
-/* the reduction (the first 256 threads of the workgroup work, all pass the barriers): the matrix from `in` into em_a (pitch n | 1), tridiagonal matrix in d / e, the
- * scalar factors of the reflectors in tau, reflector k (v_0 = 1 implied) in column k of em_a below the subdiagonal */
-__device__ __forceinline__ void em_tridiag(int n, const double* __restrict__ in, double* em_a, double* vv, double* pp, double* ww, double* tau,
+/* the reduction (512 threads, EM_TPR = 2 or 4 per row of the trailing block; contains barriers): the matrix from `in` into em_a
+ * (pitch n | 1), tridiagonal matrix in d / e, the scalar factors of the reflectors in tau, reflector k (v_0 = 1 implied) in column k
+ * of em_a below the subdiagonal.  Four threads per row up to 112 rows (n = 100: one eigenvalue 340 -> 291 us), two above (at
+ * n = 128 four were 5 % slower: eight wavefronts at three barriers per column instead of four). */
+template<int EM_TPR>
+__device__ __forceinline__ void em_tridiag_t(int n, const double* __restrict__ in, double* em_a, double* vv, double* pp, double* ww, double* tau,
    double* d, double* e)
 {
    const int tid = threadIdx.x, lane = tid & 63;
@@ -793,7 +797,7 @@ __device__ __forceinline__ void em_tridiag(int n, const double* __restrict__ in,
       }
       if ( t != 0.0 )                                    /* (the same in every wavefront) */
       {
-         const int row = k + 1 + (tid >> 1), half = tid & 1;
+         const int row = k + 1 + tid / EM_TPR, part = tid % EM_TPR;
          {
             double acc = 0.0;
             if ( row < n )
@@ -801,20 +805,23 @@ __device__ __forceinline__ void em_tridiag(int n, const double* __restrict__ in,
                /* four partial sums: the loop is a chain of dependent multiply-adds otherwise (16 cycles each) */
                const double* ar = em_a + row * ld;
                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-               int c = k + 1 + half;
-               for (; c + 6 < n; c += 8)
+               int c = k + 1 + part;
+               for (; c + 3 * EM_TPR < n; c += 4 * EM_TPR)
                {
                   a0 += ar[c] * vv[c];
-                  a1 += ar[c + 2] * vv[c + 2];
-                  a2 += ar[c + 4] * vv[c + 4];
-                  a3 += ar[c + 6] * vv[c + 6];
+                  a1 += ar[c + EM_TPR] * vv[c + EM_TPR];
+                  a2 += ar[c + 2 * EM_TPR] * vv[c + 2 * EM_TPR];
+                  a3 += ar[c + 3 * EM_TPR] * vv[c + 3 * EM_TPR];
                }
-               for (; c < n; c += 2)
+               for (; c < n; c += EM_TPR)
                   a0 += ar[c] * vv[c];
                acc = (a0 + a1) + (a2 + a3);
             }
-            acc += ei_dpp<0xB1>(acc);                   /* the two halves of a row are neighbours */
-            if ( half == 0 && row < n )
+            if ( EM_TPR == 4 )
+               acc = ei_quad(acc);                      /* the parts of a row are neighbours */
+            else
+               acc += ei_dpp<0xB1>(acc);
+            if ( part == 0 && row < n )
                pp[row] = t * acc;
          }
          __syncthreads();
@@ -835,7 +842,7 @@ __device__ __forceinline__ void em_tridiag(int n, const double* __restrict__ in,
             double* ar = em_a + row * ld;
             const double vr = vv[row], wr = ww[row];
 #pragma unroll 4
-            for (int c = k + 1 + half; c < n; c += 2)
+            for (int c = k + 1 + part; c < n; c += EM_TPR)
                ar[c] -= vr * ww[c] + wr * vv[c];
          }
          /* keep the reflector (v_0 = 1 implied) in the column it annihilated: the update does not touch column k */
@@ -852,7 +859,16 @@ __device__ __forceinline__ void em_tridiag(int n, const double* __restrict__ in,
    __syncthreads();
 }
 
-__global__ void __launch_bounds__(256) k_syevi_mid(int n, int ith, int wantvec, const double* __restrict__ in, double* __restrict__ out,
+__device__ __forceinline__ void em_tridiag(int n, const double* __restrict__ in, double* em_a, double* vv, double* pp, double* ww, double* tau,
+   double* d, double* e)
+{
+   if ( n <= 112 )
+      em_tridiag_t<4>(n, in, em_a, vv, pp, ww, tau, d, e);
+   else
+      em_tridiag_t<2>(n, in, em_a, vv, pp, ww, tau, d, e);
+}
+
+__global__ void __launch_bounds__(EM_NT) k_syevi_mid(int n, int ith, int wantvec, const double* __restrict__ in, double* __restrict__ out,
    unsigned long long seq, unsigned long long* __restrict__ flag)
 {
    extern __shared__ __attribute__((aligned(16))) double em_a[];
@@ -1026,7 +1042,6 @@ __global__ void __launch_bounds__(256) k_syevi_mid(int n, int ith, int wantvec, 
  * rows ahead of the recurrence that uses them.  All eigenvalues by multisection as in the small kernel (thread = eigenvalue x one of
  * four shifts), in two passes of 64 eigenvalues.  scratch: 3 * 128 * 128 doubles of device memory.
  * out: [0, n) eigenvalues ascending, [EM_N + k n + i] component i of eigenvector k, flag word behind them. */
-#define EM_NT 512                   /* threads of k_syev_mid */
 #define EM_ALL_FLAG (EM_N + EM_N * EM_N + 4)
 #define EM_ALL_OUT (EM_N + EM_N * EM_N + 16)
 __global__ void __launch_bounds__(EM_NT) k_syev_mid(int n, const double* __restrict__ in, double* __restrict__ out, double* __restrict__ scratch,
@@ -1560,7 +1575,7 @@ extern "C" int hipsdp_syevi_small(int device, int n, const double* A, int i, dou
       const int smem = n * (n | 1) * (int) sizeof(double);
       static hs_attr_mask attr_done;
       HS_CALL( hs_func_max_lds(reinterpret_cast<const void*>(&k_syevi_mid), EM_N * (EM_N + 1) * (int) sizeof(double), &attr_done) );
-      hipLaunchKernelGGL(k_syevi_mid, dim3(1), dim3(256), smem, c->stream, n, i, eigvec != NULL ? 1 : 0, c->din, c->dout, seq,
+      hipLaunchKernelGGL(k_syevi_mid, dim3(1), dim3(EM_NT), smem, c->stream, n, i, eigvec != NULL ? 1 : 0, c->din, c->dout, seq,
          reinterpret_cast<unsigned long long*>(c->dout + flagpos));
    }
    HS_HIP( hipGetLastError() );
