@@ -1044,6 +1044,248 @@ __global__ void __launch_bounds__(EM_NT) k_syevi_mid(int n, int ith, int wantvec
  * out: [0, n) eigenvalues ascending, [EM_N + k n + i] component i of eigenvector k, flag word behind them. */
 #define EM_ALL_FLAG (EM_N + EM_N * EM_N + 4)
 #define EM_ALL_OUT (EM_N + EM_N * EM_N + 16)
+/* the two phases of k_syev_mid that work in the 16-lane layout (lane l of a row of 16 holds the components l + 16 j, j < NJ): NJ = 4
+ * serves matrices of up to 64 rows with half the instructions of NJ = 8, and so on down to NJ = 1 for 16 rows (n = 43 of rank 5:
+ * 550 -> 390 us per decomposition with NJ = 4) */
+template<int NJ>
+__device__ __forceinline__ void em_clusters(int n, int ld, int iter, double ortol, double* Z, const double* zz, double (*cbuf)[EM_NT / 64][EM_N])
+{
+   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   /* clusters: one wavefront per cluster (cluster c goes to wavefront c mod 8).  Layout: the four rows of 16 lanes of the wavefront
+    * work on four vectors p of the cluster at a time, lane l of a row holds the components l + 16 j (j < 8): a dot product is
+    * eight multiply-adds and ONE reduction over 16 lanes for the four of them (lane = component over the whole wavefront: a
+    * 64-lane reduction of 25 instructions per dot product - 1.04 ms per round for the 96 zero eigenvalues of a rank-32 matrix of
+    * order 128, the whole decomposition slower than the Jacobi iteration).  Classical Gram-Schmidt against the vectors of the
+    * cluster before k, twice. */
+   {
+      const int l16 = lane & 15, row = lane >> 4;
+      int cl = -1;
+      int k0 = 0;
+      while ( k0 < n )
+      {
+         int k1 = k0 + 1;
+         while ( k1 < n && zz[k1] - zz[k1 - 1] <= ortol )
+            ++k1;
+         ++cl;
+         if ( k1 - k0 >= 16 )
+         {
+            /* a large cluster (the zero eigenvalues of a low-rank matrix): ALL wavefronts share it - the groups of four earlier
+             * vectors go round the wavefronts, the corrections meet in LDS (alone, one wavefront needed 600 us per round for
+             * 96 vectors: the decomposition of a rank-32 matrix of order 128 took as long as the Jacobi iteration) */
+            for (int k = k0; k < k1; ++k)
+            {
+               double v[NJ];
+#pragma unroll
+               for (int j = 0; j < NJ; ++j)
+               {
+                  const int i = l16 + 16 * j;
+                  v[j] = (i < n) ? Z[i * ld + k] : 0.0;
+               }
+               /* (one pass in the first two rounds - it only has to keep the vectors from collapsing onto each other before the
+                * next amplification -, two in the last) */
+               for (int pass = 0; pass < (iter == 2 ? 2 : 1); ++pass)
+               {
+                  double corr[NJ];
+#pragma unroll
+                  for (int j = 0; j < NJ; ++j)
+                     corr[j] = 0.0;
+                  for (int p0 = k0 + 4 * wave; p0 < k; p0 += 4 * (EM_NT / 64))
+                  {
+                     const int p = p0 + row;
+                     double u[NJ];
+                     double dt = 0.0;
+#pragma unroll
+                     for (int j = 0; j < NJ; ++j)
+                     {
+                        const int i = l16 + 16 * j;
+                        u[j] = (i < n && p < k) ? Z[i * ld + (p < k ? p : k0)] : 0.0;
+                        dt = fma(u[j], v[j], dt);
+                     }
+                     dt = ei_sum16(dt);
+#pragma unroll
+                     for (int j = 0; j < NJ; ++j)
+                        corr[j] = fma(dt, u[j], corr[j]);
+                  }
+#pragma unroll
+                  for (int j = 0; j < NJ; ++j)
+                  {
+                     double c = corr[j];
+                     c += __shfl_xor(c, 16, 64);
+                     c += __shfl_xor(c, 32, 64);
+                     if ( row == 0 )
+                        cbuf[pass][wave][l16 + 16 * j] = c;
+                  }
+                  __syncthreads();
+#pragma unroll
+                  for (int j = 0; j < NJ; ++j)
+                  {
+                     double c = 0.0;
+#pragma unroll
+                     for (int w = 0; w < EM_NT / 64; ++w)
+                        c += cbuf[pass][w][l16 + 16 * j];
+                     v[j] -= c;
+                  }
+               }
+               double nr = 0.0;
+#pragma unroll
+               for (int j = 0; j < NJ; ++j)
+                  nr = fma(v[j], v[j], nr);
+               nr = ei_sum16(nr);
+               const double rs = ei_rsqrt(fmax(nr, 1e-300));
+               if ( wave == 0 && row == 0 )
+               {
+#pragma unroll
+                  for (int j = 0; j < NJ; ++j)
+                  {
+                     const int i = l16 + 16 * j;
+                     if ( i < n )
+                        Z[i * ld + k] = v[j] * rs;
+                  }
+               }
+               __syncthreads();
+            }
+         }
+         else if ( k1 - k0 > 1 && (cl & 7) == wave )
+         {
+            for (int k = k0; k < k1; ++k)
+            {
+               double v[NJ];
+#pragma unroll
+               for (int j = 0; j < NJ; ++j)
+               {
+                  const int i = l16 + 16 * j;
+                  v[j] = (i < n) ? Z[i * ld + k] : 0.0;
+               }
+               for (int pass = 0; pass < 2; ++pass)
+               {
+                  double corr[NJ];
+#pragma unroll
+                  for (int j = 0; j < NJ; ++j)
+                     corr[j] = 0.0;
+                  for (int p0 = k0; p0 < k; p0 += 4)
+                  {
+                     const int p = p0 + row;
+                     double u[NJ];
+                     double dt = 0.0;
+#pragma unroll
+                     for (int j = 0; j < NJ; ++j)
+                     {
+                        const int i = l16 + 16 * j;
+                        u[j] = (i < n && p < k) ? Z[i * ld + (p < k ? p : k0)] : 0.0;
+                        dt = fma(u[j], v[j], dt);
+                     }
+                     dt = ei_sum16(dt);
+#pragma unroll
+                     for (int j = 0; j < NJ; ++j)
+                        corr[j] = fma(dt, u[j], corr[j]);
+                  }
+                  /* the four rows' corrections together (every row ends with the same vector) */
+#pragma unroll
+                  for (int j = 0; j < NJ; ++j)
+                  {
+                     double c = corr[j];
+                     c += __shfl_xor(c, 16, 64);
+                     c += __shfl_xor(c, 32, 64);
+                     v[j] -= c;
+                  }
+               }
+               double nr = 0.0;
+#pragma unroll
+               for (int j = 0; j < NJ; ++j)
+                  nr = fma(v[j], v[j], nr);
+               nr = ei_sum16(nr);
+               const double rs = ei_rsqrt(fmax(nr, 1e-300));
+               if ( row == 0 )
+               {
+#pragma unroll
+                  for (int j = 0; j < NJ; ++j)
+                  {
+                     const int i = l16 + 16 * j;
+                     if ( i < n )
+                        Z[i * ld + k] = v[j] * rs;
+                  }
+               }
+               __builtin_amdgcn_s_waitcnt(0xc07f);
+               __builtin_amdgcn_wave_barrier();
+            }
+         }
+         k0 = k1;
+      }
+   }
+}
+
+template<int NJ>
+__device__ __forceinline__ void em_backtransform(int n, int ld, const double* Z, const double* __restrict__ Vt, const double* tau, double* __restrict__ out)
+{
+   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   /* ---- back-transformation x = H_0 H_1 ... H_{n-2} z in the same layout: a wavefront takes four vectors at a time (one per row of 16
+    * lanes, lane l: components l + 16 j), a reflector costs eight multiply-adds, one 16-lane reduction and eight more for the four of
+    * them (one vector per wavefront with a 64-lane reduction per reflector: 460 cycles each, 775 us at n = 128); the reflectors from
+    * device memory, two ahead */
+   {
+      const int l16 = lane & 15, row = lane >> 4;
+      for (int k0 = 4 * wave; k0 < n; k0 += 32)
+      {
+         const int k = k0 + row;
+         double z[NJ];
+#pragma unroll
+         for (int j = 0; j < NJ; ++j)
+         {
+            const int i = l16 + 16 * j;
+            z[j] = (i < n && k < n) ? Z[i * ld + k] : 0.0;
+         }
+         for (int kk0 = n - 2; kk0 >= 0; kk0 -= 2)
+         {
+            double r0[NJ], r1[NJ];
+            const int kb = (kk0 - 1 >= 0) ? kk0 - 1 : 0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+            {
+               r0[j] = Vt[kk0 * EM_N + l16 + 16 * j];
+               r1[j] = Vt[kb * EM_N + l16 + 16 * j];
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+            {
+               const int kk = kk0 - r;
+               if ( kk < 0 )
+                  continue;
+               const double t = tau[kk];
+               if ( t == 0.0 )
+                  continue;
+               double vr[NJ];
+               double dot = 0.0;
+#pragma unroll
+               for (int j = 0; j < NJ; ++j)
+               {
+                  const int i = l16 + 16 * j;
+                  const double rv = r ? r1[j] : r0[j];
+                  vr[j] = (i > kk && i < n) ? ((i == kk + 1) ? 1.0 : rv) : 0.0;
+                  dot = fma(vr[j], z[j], dot);
+               }
+               dot = t * ei_sum16(dot);
+#pragma unroll
+               for (int j = 0; j < NJ; ++j)
+                  z[j] = fma(-dot, vr[j], z[j]);
+            }
+         }
+         double nrm = 0.0;
+#pragma unroll
+         for (int j = 0; j < NJ; ++j)
+            nrm = fma(z[j], z[j], nrm);
+         nrm = ei_sum16(nrm);
+         const double rs = nrm > 0.0 ? ei_rsqrt(nrm) : 1.0;
+#pragma unroll
+         for (int j = 0; j < NJ; ++j)
+         {
+            const int i = l16 + 16 * j;
+            if ( k < n && i < n )
+               out[EM_N + (long long) k * n + i] = z[j] * rs;
+         }
+      }
+   }
+}
+
 __global__ void __launch_bounds__(EM_NT) k_syev_mid(int n, const double* __restrict__ in, double* __restrict__ out, double* __restrict__ scratch,
    unsigned long long seq, unsigned long long* __restrict__ flag)
 {
@@ -1230,236 +1472,25 @@ __global__ void __launch_bounds__(EM_NT) k_syev_mid(int n, const double* __restr
          __syncthreads();
          EM_STAMP(2 + 2 * iter);
       }
-      /* clusters: one wavefront per cluster (cluster c goes to wavefront c mod 8).  Layout: the four rows of 16 lanes of the wavefront
-       * work on four vectors p of the cluster at a time, lane l of a row holds the components l + 16 j (j < 8): a dot product is
-       * eight multiply-adds and ONE reduction over 16 lanes for the four of them (lane = component over the whole wavefront: a
-       * 64-lane reduction of 25 instructions per dot product - 1.04 ms per round for the 96 zero eigenvalues of a rank-32 matrix of
-       * order 128, the whole decomposition slower than the Jacobi iteration).  Classical Gram-Schmidt against the vectors of the
-       * cluster before k, twice. */
-      {
-         const int l16 = lane & 15, row = lane >> 4;
-         int cl = -1;
-         int k0 = 0;
-         while ( k0 < n )
-         {
-            int k1 = k0 + 1;
-            while ( k1 < n && zz[k1] - zz[k1 - 1] <= ortol )
-               ++k1;
-            ++cl;
-            if ( k1 - k0 >= 16 )
-            {
-               /* a large cluster (the zero eigenvalues of a low-rank matrix): ALL wavefronts share it - the groups of four earlier
-                * vectors go round the wavefronts, the corrections meet in LDS (alone, one wavefront needed 600 us per round for
-                * 96 vectors: the decomposition of a rank-32 matrix of order 128 took as long as the Jacobi iteration) */
-               for (int k = k0; k < k1; ++k)
-               {
-                  double v[8];
-#pragma unroll
-                  for (int j = 0; j < 8; ++j)
-                  {
-                     const int i = l16 + 16 * j;
-                     v[j] = (i < n) ? Z[i * ld + k] : 0.0;
-                  }
-                  /* (one pass in the first two rounds - it only has to keep the vectors from collapsing onto each other before the
-                   * next amplification -, two in the last) */
-                  for (int pass = 0; pass < (iter == 2 ? 2 : 1); ++pass)
-                  {
-                     double corr[8];
-#pragma unroll
-                     for (int j = 0; j < 8; ++j)
-                        corr[j] = 0.0;
-                     for (int p0 = k0 + 4 * wave; p0 < k; p0 += 4 * (EM_NT / 64))
-                     {
-                        const int p = p0 + row;
-                        double u[8];
-                        double dt = 0.0;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                        {
-                           const int i = l16 + 16 * j;
-                           u[j] = (i < n && p < k) ? Z[i * ld + (p < k ? p : k0)] : 0.0;
-                           dt = fma(u[j], v[j], dt);
-                        }
-                        dt = ei_sum16(dt);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                           corr[j] = fma(dt, u[j], corr[j]);
-                     }
-#pragma unroll
-                     for (int j = 0; j < 8; ++j)
-                     {
-                        double c = corr[j];
-                        c += __shfl_xor(c, 16, 64);
-                        c += __shfl_xor(c, 32, 64);
-                        if ( row == 0 )
-                           cbuf[pass][wave][l16 + 16 * j] = c;
-                     }
-                     __syncthreads();
-#pragma unroll
-                     for (int j = 0; j < 8; ++j)
-                     {
-                        double c = 0.0;
-#pragma unroll
-                        for (int w = 0; w < EM_NT / 64; ++w)
-                           c += cbuf[pass][w][l16 + 16 * j];
-                        v[j] -= c;
-                     }
-                  }
-                  double nr = 0.0;
-#pragma unroll
-                  for (int j = 0; j < 8; ++j)
-                     nr = fma(v[j], v[j], nr);
-                  nr = ei_sum16(nr);
-                  const double rs = ei_rsqrt(fmax(nr, 1e-300));
-                  if ( wave == 0 && row == 0 )
-                  {
-#pragma unroll
-                     for (int j = 0; j < 8; ++j)
-                     {
-                        const int i = l16 + 16 * j;
-                        if ( i < n )
-                           Z[i * ld + k] = v[j] * rs;
-                     }
-                  }
-                  __syncthreads();
-               }
-            }
-            else if ( k1 - k0 > 1 && (cl & 7) == wave )
-            {
-               for (int k = k0; k < k1; ++k)
-               {
-                  double v[8];
-#pragma unroll
-                  for (int j = 0; j < 8; ++j)
-                  {
-                     const int i = l16 + 16 * j;
-                     v[j] = (i < n) ? Z[i * ld + k] : 0.0;
-                  }
-                  for (int pass = 0; pass < 2; ++pass)
-                  {
-                     double corr[8];
-#pragma unroll
-                     for (int j = 0; j < 8; ++j)
-                        corr[j] = 0.0;
-                     for (int p0 = k0; p0 < k; p0 += 4)
-                     {
-                        const int p = p0 + row;
-                        double u[8];
-                        double dt = 0.0;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                        {
-                           const int i = l16 + 16 * j;
-                           u[j] = (i < n && p < k) ? Z[i * ld + (p < k ? p : k0)] : 0.0;
-                           dt = fma(u[j], v[j], dt);
-                        }
-                        dt = ei_sum16(dt);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                           corr[j] = fma(dt, u[j], corr[j]);
-                     }
-                     /* the four rows' corrections together (every row ends with the same vector) */
-#pragma unroll
-                     for (int j = 0; j < 8; ++j)
-                     {
-                        double c = corr[j];
-                        c += __shfl_xor(c, 16, 64);
-                        c += __shfl_xor(c, 32, 64);
-                        v[j] -= c;
-                     }
-                  }
-                  double nr = 0.0;
-#pragma unroll
-                  for (int j = 0; j < 8; ++j)
-                     nr = fma(v[j], v[j], nr);
-                  nr = ei_sum16(nr);
-                  const double rs = ei_rsqrt(fmax(nr, 1e-300));
-                  if ( row == 0 )
-                  {
-#pragma unroll
-                     for (int j = 0; j < 8; ++j)
-                     {
-                        const int i = l16 + 16 * j;
-                        if ( i < n )
-                           Z[i * ld + k] = v[j] * rs;
-                     }
-                  }
-                  __builtin_amdgcn_s_waitcnt(0xc07f);
-                  __builtin_amdgcn_wave_barrier();
-               }
-            }
-            k0 = k1;
-         }
-      }
+      if ( n <= 16 )
+         em_clusters<1>(n, ld, iter, ortol, Z, zz, cbuf);
+      else if ( n <= 32 )
+         em_clusters<2>(n, ld, iter, ortol, Z, zz, cbuf);
+      else if ( n <= 64 )
+         em_clusters<4>(n, ld, iter, ortol, Z, zz, cbuf);
+      else
+         em_clusters<8>(n, ld, iter, ortol, Z, zz, cbuf);
       __syncthreads();
       EM_STAMP(3 + 2 * iter);
    }
-   /* ---- back-transformation x = H_0 H_1 ... H_{n-2} z in the same layout: a wavefront takes four vectors at a time (one per row of 16
-    * lanes, lane l: components l + 16 j), a reflector costs eight multiply-adds, one 16-lane reduction and eight more for the four of
-    * them (one vector per wavefront with a 64-lane reduction per reflector: 460 cycles each, 775 us at n = 128); the reflectors from
-    * device memory, two ahead */
-   {
-      const int l16 = lane & 15, row = lane >> 4;
-      for (int k0 = 4 * wave; k0 < n; k0 += 32)
-      {
-         const int k = k0 + row;
-         double z[8];
-#pragma unroll
-         for (int j = 0; j < 8; ++j)
-         {
-            const int i = l16 + 16 * j;
-            z[j] = (i < n && k < n) ? Z[i * ld + k] : 0.0;
-         }
-         for (int kk0 = n - 2; kk0 >= 0; kk0 -= 2)
-         {
-            double r0[8], r1[8];
-            const int kb = (kk0 - 1 >= 0) ? kk0 - 1 : 0;
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-            {
-               r0[j] = Vt[kk0 * EM_N + l16 + 16 * j];
-               r1[j] = Vt[kb * EM_N + l16 + 16 * j];
-            }
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-            {
-               const int kk = kk0 - r;
-               if ( kk < 0 )
-                  continue;
-               const double t = tau[kk];
-               if ( t == 0.0 )
-                  continue;
-               double vr[8];
-               double dot = 0.0;
-#pragma unroll
-               for (int j = 0; j < 8; ++j)
-               {
-                  const int i = l16 + 16 * j;
-                  const double rv = r ? r1[j] : r0[j];
-                  vr[j] = (i > kk && i < n) ? ((i == kk + 1) ? 1.0 : rv) : 0.0;
-                  dot = fma(vr[j], z[j], dot);
-               }
-               dot = t * ei_sum16(dot);
-#pragma unroll
-               for (int j = 0; j < 8; ++j)
-                  z[j] = fma(-dot, vr[j], z[j]);
-            }
-         }
-         double nrm = 0.0;
-#pragma unroll
-         for (int j = 0; j < 8; ++j)
-            nrm = fma(z[j], z[j], nrm);
-         nrm = ei_sum16(nrm);
-         const double rs = nrm > 0.0 ? ei_rsqrt(nrm) : 1.0;
-#pragma unroll
-         for (int j = 0; j < 8; ++j)
-         {
-            const int i = l16 + 16 * j;
-            if ( k < n && i < n )
-               out[EM_N + (long long) k * n + i] = z[j] * rs;
-         }
-      }
-   }
+   if ( n <= 16 )
+      em_backtransform<1>(n, ld, Z, Vt, tau, out);
+   else if ( n <= 32 )
+      em_backtransform<2>(n, ld, Z, Vt, tau, out);
+   else if ( n <= 64 )
+      em_backtransform<4>(n, ld, Z, Vt, tau, out);
+   else
+      em_backtransform<8>(n, ld, Z, Vt, tau, out);
    __syncthreads();
    EM_STAMP(8);
 #undef EM_STAMP
