@@ -1302,8 +1302,11 @@ __global__ void __launch_bounds__(EM_NT) k_syev_mid(int n, const double* __restr
 
    /* ---- the reflectors leave LDS: Vt[k][i] = entry i of reflector k (i > k + 1; entry k + 1 is the implied 1) */
    double* __restrict__ Vt = scratch;
-   double* __restrict__ G0 = scratch + EM_N * EM_N;        /* [i][k]: 1 / pivot of row i of the elimination for vector k */
-   double* __restrict__ G1 = G0 + EM_N * EM_N;             /* first superdiagonal of U */
+   /* the two factor arrays of the elimination, [i][k] with pitch gs: behind Z in LDS when n <= 64 (the launch asks for the room),
+    * else in device memory */
+   const int gs = (n <= 64) ? 64 : EM_N;
+   double* __restrict__ G0 = (n <= 64) ? em_a + n * ld : scratch + EM_N * EM_N;      /* 1 / pivot of row i of the elimination for vector k */
+   double* __restrict__ G1 = G0 + (n <= 64 ? n * 64 : EM_N * EM_N);                  /* first superdiagonal of U */
    for (int idx = tid; idx < n * n; idx += EM_NT)
    {
       const int k = idx / n, i = idx - k * n;
@@ -1344,22 +1347,30 @@ __global__ void __launch_bounds__(EM_NT) k_syev_mid(int n, const double* __restr
    }
    __syncthreads();
    {
-      const int k = tid >> 2, sh = tid & 3;                 /* thread = (eigenvalue, one of four shifts) */
+      /* thread = (eigenvalue, one of S shifts): S = 4, 8 or 16 - what the 512 threads allow for n eigenvalues (2.3, 3.2 or 4.1 bits
+       * per round) */
+      const int lgS = (n > 64) ? 2 : ((n > 32) ? 3 : 4), S = 1 << lgS;
+      const int k = tid >> lgS, sh = tid & (S - 1);
       const int nb = (n - 1 + 3) >> 2;                      /* blocks of four steps i = 1 + 4 b .. 4 + 4 b */
+      const double rS1 = 1.0 / (double) (S + 1);
       double lo = glo * sinv, hi = ghi * sinv;
       for (int round = 0; round < 40; ++round)
       {
-         const double w = (hi - lo) * 0.2;
+         const double w = (hi - lo) * rS1;
          const double x = lo + w * (double) (sh + 1);
          const int cnt = (k < n) ? ei_sturm_count(ds, es, nb, x) : 0;
+         /* number of the S shifts with fewer than k + 1 eigenvalues below them = index of the subinterval that holds eigenvalue k */
          int below = (cnt < k + 1) ? 1 : 0;
          below += __builtin_amdgcn_update_dpp(0, below, 0xB1, 0xf, 0xf, true);
          below += __builtin_amdgcn_update_dpp(0, below, 0x4E, 0xf, 0xf, true);
+         if ( lgS >= 3 )
+            below += __builtin_amdgcn_update_dpp(0, below, 0x141, 0xf, 0xf, true);
+         if ( lgS >= 4 )
+            below += __builtin_amdgcn_update_dpp(0, below, 0x140, 0xf, 0xf, true);
          const double nlo = lo + w * (double) below;
-         const double nhi = (below < 4) ? lo + w * (double) (below + 1) : hi;
+         const double nhi = (below < S) ? lo + w * (double) (below + 1) : hi;
          lo = nlo; hi = nhi;
-         /* (to two ulps of the eigenvalue - an interval cannot get shorter than one -, but not below half an ulp of the norm: 24
-          * rounds instead of all 40) */
+         /* (to two ulps of the eigenvalue - an interval cannot get shorter than one -, but not below half an ulp of the norm) */
          if ( __all(k >= n || hi - lo <= 4.5e-16 * fmax(fmax(fabs(lo), fabs(hi)), 0.25)) )
             break;
       }
@@ -1374,6 +1385,9 @@ __global__ void __launch_bounds__(EM_NT) k_syev_mid(int n, const double* __restr
    /* ---- eigenvectors of T: three rounds of { one step of inverse iteration per vector (thread k owns vector k), orthogonalisation
     * inside the clusters } - see k_syevi_small for why in every round */
    const double ortol = 1e-3 * fmax(tnorm, 1e-300);
+   /* (without two eigenvalues that close the orthogonalisation phase - every thread walking the list of eigenvalues, two barriers -
+    * is skipped: 8 us per round at n = 43) */
+   const int clustered = __syncthreads_or((tid > 0 && tid < n && zz[tid] - zz[tid - 1] <= ortol) ? 1 : 0);
    for (int idx = tid; idx < n * n; idx += EM_NT)
    {
       const int i = idx / n, k = idx - i * n;
@@ -1404,7 +1418,7 @@ __global__ void __launch_bounds__(EM_NT) k_syev_mid(int n, const double* __restr
                   if ( fabs(dd) < tiny ) dd = tiny;
                   const double rinv = ei_rcp2(dd);
                   const double mlt = dl * rinv;
-                  G0[i * EM_N + k] = rinv; G1[i * EM_N + k] = du;
+                  G0[i * gs + k] = rinv; G1[i * gs + k] = du;
                   Z[i * ld + k] = cur;
                   cur = nxt - mlt * cur;
                   dd = dn - mlt * du;
@@ -1414,7 +1428,7 @@ __global__ void __launch_bounds__(EM_NT) k_syev_mid(int n, const double* __restr
                {
                   const double rinv = ei_rcp2(dl);
                   const double mlt = dd * rinv;
-                  G0[i * EM_N + k] = rinv; G1[i * EM_N + k] = dn;
+                  G0[i * gs + k] = rinv; G1[i * gs + k] = dn;
                   if ( i < 64 ) swlo |= 1ULL << i; else swhi |= 1ULL << (i - 64);
                   Z[i * ld + k] = nxt;
                   cur = cur - mlt * nxt;
@@ -1434,8 +1448,8 @@ __global__ void __launch_bounds__(EM_NT) k_syev_mid(int n, const double* __restr
                for (int u = 0; u < 8; ++u)
                {
                   const int i = (i0 - u >= 0) ? i0 - u : 0;
-                  g0[u] = G0[i * EM_N + k];
-                  g1[u] = G1[i * EM_N + k];
+                  g0[u] = G0[i * gs + k];
+                  g1[u] = G1[i * gs + k];
                }
 #pragma unroll
                for (int u = 0; u < 8; ++u)
@@ -1472,15 +1486,18 @@ __global__ void __launch_bounds__(EM_NT) k_syev_mid(int n, const double* __restr
          __syncthreads();
          EM_STAMP(2 + 2 * iter);
       }
-      if ( n <= 16 )
-         em_clusters<1>(n, ld, iter, ortol, Z, zz, cbuf);
-      else if ( n <= 32 )
-         em_clusters<2>(n, ld, iter, ortol, Z, zz, cbuf);
-      else if ( n <= 64 )
-         em_clusters<4>(n, ld, iter, ortol, Z, zz, cbuf);
-      else
-         em_clusters<8>(n, ld, iter, ortol, Z, zz, cbuf);
-      __syncthreads();
+      if ( clustered )
+      {
+         if ( n <= 16 )
+            em_clusters<1>(n, ld, iter, ortol, Z, zz, cbuf);
+         else if ( n <= 32 )
+            em_clusters<2>(n, ld, iter, ortol, Z, zz, cbuf);
+         else if ( n <= 64 )
+            em_clusters<4>(n, ld, iter, ortol, Z, zz, cbuf);
+         else
+            em_clusters<8>(n, ld, iter, ortol, Z, zz, cbuf);
+         __syncthreads();
+      }
       EM_STAMP(3 + 2 * iter);
    }
    if ( n <= 16 )
@@ -1498,6 +1515,12 @@ __global__ void __launch_bounds__(EM_NT) k_syev_mid(int n, const double* __restr
    __syncthreads();
    if ( tid == 0 )
       __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+/* dynamic LDS of k_syev_mid: the matrix / the eigenvectors of T, and up to 64 rows the two factor arrays of the inverse iteration */
+static size_t em_all_lds(int n)
+{
+   return ((size_t) n * (n | 1) + (n <= 64 ? (size_t) 2 * n * 64 : 0)) * sizeof(double);
 }
 
 /* from how many rows on the full decomposition takes k_syev_mid (HIPSDP_SYEV_MID_FROM, read once; both entry points use the same
@@ -1665,7 +1688,7 @@ extern "C" int hipsdp_syev_small(int device, int n, const double* A, double* lam
    {
       static hs_attr_mask attr_mid;
       HS_CALL( hs_func_max_lds(reinterpret_cast<const void*>(&k_syev_mid), EM_N * (EM_N + 1) * (int) sizeof(double), &attr_mid) );
-      hipLaunchKernelGGL(k_syev_mid, dim3(1), dim3(EM_NT), (size_t) n * (n | 1) * sizeof(double), c->stream, n, c->din, c->dout, c->dscr, seq,
+      hipLaunchKernelGGL(k_syev_mid, dim3(1), dim3(EM_NT), em_all_lds(n), c->stream, n, c->din, c->dout, c->dscr, seq,
          reinterpret_cast<unsigned long long*>(c->dout + flagpos));
    }
    else
@@ -1728,7 +1751,7 @@ int hs_syev_small_dev(hipStream_t st, int n, const double* A, double* lam, doubl
    {
       static hs_attr_mask attr_mid;
       HS_CALL( hs_func_max_lds(reinterpret_cast<const void*>(&k_syev_mid), EM_N * (EM_N + 1) * (int) sizeof(double), &attr_mid) );
-      hipLaunchKernelGGL(k_syev_mid, dim3(1), dim3(EM_NT), (size_t) n * (n | 1) * sizeof(double), st, n, A, scratch, scratch + EM_ALL_OUT, 1ULL,
+      hipLaunchKernelGGL(k_syev_mid, dim3(1), dim3(EM_NT), em_all_lds(n), st, n, A, scratch, scratch + EM_ALL_OUT, 1ULL,
          reinterpret_cast<unsigned long long*>(scratch + EM_ALL_FLAG));
       HS_HIP( hipGetLastError() );
       HS_HIP( hipMemcpyAsync(lam, scratch, (size_t) n * sizeof(double), hipMemcpyDeviceToDevice, st) );
