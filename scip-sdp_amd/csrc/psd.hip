@@ -14,6 +14,7 @@
 #include "hs_kernels.h"
 #include "../../include/hipsdp.h"
 #include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -115,6 +116,36 @@ __global__ void __launch_bounds__(64) k_write_rows(int n, const double* __restri
    }
 }
 
+/* pinned, device-mapped staging of the calling thread for the sizes the warm-start producer meets (blocks of up to 128 rows): the
+ * kernels read the triplets and write the result there - with pageable arrays every one of the seven copies of a call blocks for
+ * 15-20 us, 120 us of the 200 a projection of order 10 took */
+#define PSD_PIN_ENTRIES 32768
+struct PsdPin
+{
+   char* h; char* d; int device;
+   PsdPin() : h(NULL), d(NULL), device(-1) {}
+   ~PsdPin() { if ( h != NULL ) (void) hipHostFree(h); }
+   /* layout: [in rows | in cols | in vals | total | out rows | out cols | out vals] */
+   static size_t bytes() { return (size_t) PSD_PIN_ENTRIES * (4 * sizeof(int) + 2 * sizeof(double)) + 64; }
+   bool get(int dev)
+   {
+      if ( h != NULL && device == dev )
+         return true;
+      if ( h != NULL ) { (void) hipHostFree(h); h = NULL; d = NULL; }
+      void* hp = NULL; void* dp = NULL;
+      if ( hipHostMalloc(&hp, bytes(), hipHostMallocMapped) != hipSuccess )
+         return false;
+      if ( hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess )
+      {
+         (void) hipHostFree(hp);
+         return false;
+      }
+      h = (char*) hp; d = (char*) dp; device = dev;
+      return true;
+   }
+};
+thread_local PsdPin g_pin;
+
 template<class T> struct PoolBuf
 {
    T* p;
@@ -145,25 +176,57 @@ extern "C" int hipsdp_psd_project(int device, int n, int nnz, const int* row, co
    HS_CALL( A.alloc(n2) ); HS_CALL( lam.alloc(n) ); HS_CALL( V.alloc(n2) ); HS_CALL( S.alloc(n2) ); HS_CALL( ws.alloc(hs_syev_ws(n)) );
    HS_CALL( drow.alloc(nnz) ); HS_CALL( dcol.alloc(nnz) ); HS_CALL( dval.alloc(nnz) );
    HS_CALL( cnt.alloc(n) ); HS_CALL( off.alloc(n + 1) );
-   HS_CALL( orow.alloc(cap) ); HS_CALL( ocol.alloc(cap) ); HS_CALL( oval.alloc(cap) );
+   /* small operands: triplets and result through the thread's pinned staging memory (no copy of a call blocks) */
+   const bool pinned = nnz <= PSD_PIN_ENTRIES && cap <= PSD_PIN_ENTRIES && g_pin.get(device);
+   int *pin_total = NULL, *pin_orow = NULL, *pin_ocol = NULL;
+   double* pin_oval = NULL;
+   const int *in_row = NULL, *in_col = NULL;
+   const double* in_val = NULL;
+   int *out_row = NULL, *out_col = NULL;
+   double* out_val = NULL;
+   if ( pinned )
+   {
+      const size_t E = PSD_PIN_ENTRIES;
+      char* h = g_pin.h; char* d = g_pin.d;
+      if ( nnz > 0 )
+      {
+         memcpy(h, row, (size_t) nnz * sizeof(int));
+         memcpy(h + E * sizeof(int), col, (size_t) nnz * sizeof(int));
+         memcpy(h + 2 * E * sizeof(int), val, (size_t) nnz * sizeof(double));
+      }
+      in_row = (const int*) d; in_col = (const int*) (d + E * sizeof(int)); in_val = (const double*) (d + 2 * E * sizeof(int));
+      const size_t o0 = 2 * E * sizeof(int) + E * sizeof(double);
+      pin_total = (int*) (h + o0);
+      pin_orow = (int*) (h + o0 + 64); out_row = (int*) (d + o0 + 64);
+      pin_ocol = (int*) (h + o0 + 64 + E * sizeof(int)); out_col = (int*) (d + o0 + 64 + E * sizeof(int));
+      pin_oval = (double*) (h + o0 + 64 + 2 * E * sizeof(int)); out_val = (double*) (d + o0 + 64 + 2 * E * sizeof(int));
+   }
+   else
+   {
+      HS_CALL( orow.alloc(cap) ); HS_CALL( ocol.alloc(cap) ); HS_CALL( oval.alloc(cap) );
+      out_row = orow.p; out_col = ocol.p; out_val = oval.p;
+   }
    HS_HIP( hipMemsetAsync(A.p, 0, (size_t) n2 * sizeof(double), st) );
    if ( nnz > 0 )
    {
-      HS_HIP( hipMemcpyAsync(drow.p, row, (size_t) nnz * sizeof(int), hipMemcpyHostToDevice, st) );
-      HS_HIP( hipMemcpyAsync(dcol.p, col, (size_t) nnz * sizeof(int), hipMemcpyHostToDevice, st) );
-      HS_HIP( hipMemcpyAsync(dval.p, val, (size_t) nnz * sizeof(double), hipMemcpyHostToDevice, st) );
+      if ( !pinned )
+      {
+         HS_HIP( hipMemcpyAsync(drow.p, row, (size_t) nnz * sizeof(int), hipMemcpyHostToDevice, st) );
+         HS_HIP( hipMemcpyAsync(dcol.p, col, (size_t) nnz * sizeof(int), hipMemcpyHostToDevice, st) );
+         HS_HIP( hipMemcpyAsync(dval.p, val, (size_t) nnz * sizeof(double), hipMemcpyHostToDevice, st) );
+         in_row = drow.p; in_col = dcol.p; in_val = dval.p;
+      }
       int g = (nnz + 255) / 256; if ( g > 1024 ) g = 1024;
-      hipLaunchKernelGGL(k_expand_coo, dim3(g), dim3(256), 0, st, nnz, n, drow.p, dcol.p, dval.p, A.p);
+      hipLaunchKernelGGL(k_expand_coo, dim3(g), dim3(256), 0, st, nnz, n, in_row, in_col, in_val, A.p);
    }
    /* the decomposition SCIPlapackComputeEigenvectorDecomposition returns for this size (the literal chain of mode 0 depends on the
     * basis: both paths must use the same eigenvectors) */
    static const bool jacobi_small = getenv("HIPSDP_SYEV_JACOBI") != NULL && atoi(getenv("HIPSDP_SYEV_JACOBI")) != 0;
+   PoolBuf<double> scr;                              /* (lives to the end of the call: no wait in the middle of the chain) */
    if ( n <= 128 && !jacobi_small )
    {
-      PoolBuf<double> scr;
       HS_CALL( scr.alloc(hs_syev_small_scratch(n)) );
       HS_CALL( hs_syev_small_dev(st, n, A.p, lam.p, V.p, scr.p) );
-      HS_HIP( hipStreamSynchronize(st) );            /* scr goes back to the pool */
    }
    else
       HS_CALL( hs_syev_jacobi(st, n, A.p, lam.p, V.p, NULL, ws.p) );
@@ -176,16 +239,31 @@ extern "C" int hipsdp_psd_project(int device, int n, int nnz, const int* row, co
    }
    hipLaunchKernelGGL(k_row_counts, dim3(n), dim3(256), 0, st, n, A.p, epsilon, cnt.p);
    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, n, cnt.p, off.p);
-   hipLaunchKernelGGL(k_write_rows, dim3(n), dim3(64), 0, st, n, A.p, epsilon, off.p, cap, orow.p, ocol.p, oval.p);
+   hipLaunchKernelGGL(k_write_rows, dim3(n), dim3(64), 0, st, n, A.p, epsilon, off.p, cap, out_row, out_col, out_val);
    if ( hipGetLastError() != hipSuccess )
       return HIPSDP_ERR_HIP;
    int total = 0;
-   HS_HIP( hipMemcpyAsync(&total, off.p + n, sizeof(int), hipMemcpyDeviceToHost, st) );
-   HS_HIP( hipStreamSynchronize(st) );
+   if ( pinned )
+   {
+      HS_HIP( hipMemcpyAsync(pin_total, off.p + n, sizeof(int), hipMemcpyDeviceToHost, st) );      /* (pinned destination: no staging) */
+      HS_HIP( hipStreamSynchronize(st) );
+      total = *pin_total;
+   }
+   else
+   {
+      HS_HIP( hipMemcpyAsync(&total, off.p + n, sizeof(int), hipMemcpyDeviceToHost, st) );
+      HS_HIP( hipStreamSynchronize(st) );
+   }
    *nnz_out = total;
    if ( total > cap )
       return HIPSDP_ERR_ARG;             /* the needed length is in *nnz_out */
-   if ( total > 0 )
+   if ( total > 0 && pinned )
+   {
+      memcpy(rowout, pin_orow, (size_t) total * sizeof(int));
+      memcpy(colout, pin_ocol, (size_t) total * sizeof(int));
+      memcpy(valout, pin_oval, (size_t) total * sizeof(double));
+   }
+   else if ( total > 0 )
    {
       HS_HIP( hipMemcpy(rowout, orow.p, (size_t) total * sizeof(int), hipMemcpyDeviceToHost) );
       HS_HIP( hipMemcpy(colout, ocol.p, (size_t) total * sizeof(int), hipMemcpyDeviceToHost) );
