@@ -187,6 +187,8 @@ struct hipsdp_solver
    char* arena_h; char* arena_d; size_t arena_cap, stage_off; bool stage_pending;
    int m_alloc, q_alloc;   /* what the vectors and matrices indexed by variables / LP rows were allocated for (>= m, q: set_shape2) */
    int ncmd;               /* commands of the node's setters waiting in the arena (run by ONE launch before the solve, see NodeCmd) */
+   hipEvent_t cmd_ev;      /* recorded behind a flushed command list: the launch reads the list from the arena when it RUNS, so the */
+   bool cmd_inflight;      /* slots must not be written again before it has (cmd_new waits for the event) */
    unsigned long long s1_seq;
    int s1_last;            /* 1: the last solve ran in the single launch */
    /* pinned / device staging chunks of hipsdp_master_add_vars (kept until hipsdp_free) */
@@ -355,6 +357,11 @@ static int flush_cmds(hipsdp_solver* s)
       HS_LAUNCH_CHECK();
       s->ncmd = 0;
       s->stage_pending = true;
+      /* the kernel fetches the list when it runs, not when it is queued: whoever writes slot 0 next waits for this event */
+      if ( s->cmd_ev == NULL )
+         HS_HIP( hipEventCreateWithFlags(&s->cmd_ev, hipEventDisableTiming) );
+      HS_HIP( hipEventRecord(s->cmd_ev, s->stream) );
+      s->cmd_inflight = true;
    }
    return HIPSDP_OK;
 }
@@ -363,11 +370,14 @@ static NodeCmd* cmd_new(hipsdp_solver* s)
 {
    if ( s->arena_h == NULL && stage_take(s, 0, NULL) == NULL )
       return NULL;
-   if ( s->ncmd >= NC_MAX )
+   if ( s->ncmd >= NC_MAX && flush_cmds(s) != HIPSDP_OK )
+      return NULL;
+   if ( s->cmd_inflight )
    {
-      /* (never in practice: the list is read when the kernel runs, so it must have run before the slots are written again) */
-      if ( flush_cmds(s) != HIPSDP_OK || hipStreamSynchronize(s->stream) != hipSuccess )
+      /* a flushed list may not have been fetched yet (large gathers / clears flush in the middle of a node's setters) */
+      if ( hipEventSynchronize(s->cmd_ev) != hipSuccess )
          return NULL;
+      s->cmd_inflight = false;
    }
    NodeCmd* q = reinterpret_cast<NodeCmd*>(s->arena_h) + s->ncmd;
    memset(q, 0, sizeof(*q));
@@ -435,6 +445,7 @@ static int stage_sync(hipsdp_solver* s)
       HS_HIP( hipStreamSynchronize(s->stream) );
       s->stage_pending = false;
       s->stage_off = 0;
+      s->cmd_inflight = false;
    }
    return HIPSDP_OK;
 }
@@ -529,7 +540,7 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
    s->hsc_cap = 0;
    s->clk_on = false; s->clk_buf = NULL; s->clk_n = 0; s->clk_ghz = 0.0; s->clk_stream = NULL;
    s->s1_ws = NULL; s->s1_ws_len = 0; s->s1_host = NULL; s->s1_host_dev = NULL; s->s1_seq = 0; s->s1_last = 0; s->s1_sol_host = false; s->zero_b = false; s->zero_D = false;
-   s->arena_h = NULL; s->arena_d = NULL; s->arena_cap = 0; s->stage_off = 0; s->stage_pending = false; s->ncmd = 0; s->m_alloc = 0; s->q_alloc = 0;
+   s->arena_h = NULL; s->arena_d = NULL; s->arena_cap = 0; s->stage_off = 0; s->stage_pending = false; s->ncmd = 0; s->cmd_ev = NULL; s->cmd_inflight = false; s->m_alloc = 0; s->q_alloc = 0;
    s->trsv_ws = NULL;
    s->pre_y = s->pre_x = NULL;
    s->pre_valid = false;
@@ -592,6 +603,8 @@ extern "C" void hipsdp_free(hipsdp_solver** ps)
    if ( s->s1_host != NULL ) (void) hipHostFree(s->s1_host);
    s->s1_host = NULL;
    if ( s->arena_h != NULL ) (void) hipHostFree(s->arena_h);
+   if ( s->cmd_ev != NULL ) (void) hipEventDestroy(s->cmd_ev);
+   s->cmd_ev = NULL;
    s->arena_h = NULL; s->arena_d = NULL; s->arena_cap = 0;
    if ( s->s1_ws != NULL ) (void) hipFree(s->s1_ws);
    s->s1_ws = NULL;
@@ -686,7 +699,7 @@ extern "C" int hipsdp_set_shape2(hipsdp_solver* s, int m, int nblocks, const int
       HS_HIP( hipStreamSynchronize(s->stream) );
    if ( s->stream2 != NULL && hipStreamQuery(s->stream2) != hipSuccess )
       HS_HIP( hipStreamSynchronize(s->stream2) );
-   s->stage_pending = false; s->stage_off = 0; s->ncmd = 0;
+   s->stage_pending = false; s->stage_off = 0; s->ncmd = 0; s->cmd_inflight = false;
    s->zero_b = false; s->zero_D = false; s->s1_sol_host = false;
    /* The same shape again (the next node of a tree with the same fixings pattern, a re-load of the same problem): every
     * allocation is kept - the constraint matrices (GBs at the bench sizes), their packed copy and the Schur workspace cost tens

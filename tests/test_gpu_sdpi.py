@@ -405,3 +405,38 @@ def test_deferred_setters_give_the_results_of_the_direct_ones(gpu, monkeypatch):
     monkeypatch.delenv("HIPSDP_NO_SHAPE_REUSE", raising=False)
     sa.free(); sb.free()
     assert done >= 15
+
+
+def test_deferred_setters_with_operands_above_the_command_limit(gpu, monkeypatch):
+    """a gather of nactive * nkept^2 > NC_LIMIT (65536) entries and the clearing of more than NC_LIMIT doubles flush the
+    waiting command list in the MIDDLE of a node's setters (objective copy pending -> flush -> further commands into slot 0).  The
+    launch reads the list when it runs: the next command must not be written before it has.  Blocks of 44-60 rows with 34-48
+    variables (one-launch path declines nothing here that matters: the data path is the same), a second small block so that the
+    shape re-use path clears mixed sizes; against a backend with every setter blocking: same bits."""
+    sa, sb = new_solver(gpu), new_solver(gpu)
+    rng = np.random.default_rng(4711)
+    done = 0
+    for t in range(12):
+        prob = _random_node(rng, nvars=int(rng.integers(34, 48)), sizes=[int(rng.integers(44, 60)), int(rng.integers(2, 9))],
+                            nlp=int(rng.integers(0, 6)), nfixed=int(rng.integers(0, 3)))
+        P = sdpi_prepare.prepare(prob)
+        if P.status != 'ok':
+            continue
+        monkeypatch.delenv("HIPSDP_NO_STAGING", raising=False)
+        monkeypatch.delenv("HIPSDP_NO_SHAPE_REUSE", raising=False)
+        rca, _, _ = sa.solve(P)
+        monkeypatch.setenv("HIPSDP_NO_STAGING", "1")
+        monkeypatch.setenv("HIPSDP_NO_SHAPE_REUSE", "1")
+        rcb, _, _ = sb.solve(P)
+        assert rca == rcb == sdpi_call.SCIP_OKAY
+        assert sa.flag("IsOptimal") == sb.flag("IsOptimal") and sa.flag("IsDualInfeasible") == sb.flag("IsDualInfeasible")
+        assert sa.iterations() == sb.iterations()
+        if sa.flag("IsOptimal"):
+            _, oa, ya = sa.dual_sol()
+            _, ob, yb = sb.dual_sol()
+            assert oa == ob and np.array_equal(ya, yb)
+        done += 1
+    monkeypatch.delenv("HIPSDP_NO_STAGING", raising=False)
+    monkeypatch.delenv("HIPSDP_NO_SHAPE_REUSE", raising=False)
+    sa.free(); sb.free()
+    assert done >= 6
