@@ -23,6 +23,10 @@ HIPSDP_API int  hipsdp_pass_at_unit(int device, int R, long long E, const double
    double* out, int* chunks);
 HIPSDP_API int  hipsdp_dgemm_selfcheck2(int device, int M, int N, int K, int layB, int batch, int splitk, int flags, double alpha, double beta,
    int reps, int* used, long long* ndiff, double* ms_tile, double* ms_fast);
+/* the same, also returning the largest absolute difference of the two results and the number of elements that differ between
+ * TWO runs of the default dispatch (must be 0) */
+HIPSDP_API int  hipsdp_dgemm_selfcheck3(int device, int M, int N, int K, int layB, int batch, int splitk, int flags, double alpha, double beta,
+   int reps, int* used, long long* ndiff, double* maxdiff, long long* nrepro, double* ms_tile, double* ms_fast);
 /* Schur block Mx[(m1) x (m1)] = tr(A_i X A_j Zinv) for i, j = 0..m1-1 */
 HIPSDP_API int  hipsdp_schur_dense(int device, int m1, int n, const double* A, const double* X, const double* Zinv, double* Mx,
    double ws_gbytes);

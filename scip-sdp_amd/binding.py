@@ -346,6 +346,17 @@ def dgemm_selfcheck2(M, N, K, layB=1, batch=1, splitk=1, flags=0, alpha=1.0, bet
     return used.value, nd.value, t0.value, t1.value
 
 
+def dgemm_selfcheck3(M, N, K, layB=1, batch=1, splitk=1, flags=0, alpha=1.0, beta=0.0, reps=0, device=0):
+    """as dgemm_selfcheck2, with the largest absolute difference of the two results and the number of elements that differ between
+    two runs of the default dispatch -> (used bits, differing elements, max |difference|, not reproduced, ms tile, ms default)"""
+    used = C.c_int(0)
+    nd, nr = C.c_longlong(0), C.c_longlong(0)
+    md, t0, t1 = C.c_double(0.0), C.c_double(0.0), C.c_double(0.0)
+    _chk(ulib().hipsdp_dgemm_selfcheck3(device, M, N, K, layB, batch, splitk, flags, C.c_double(alpha), C.c_double(beta), reps,
+                                       C.byref(used), C.byref(nd), C.byref(md), C.byref(nr), C.byref(t0), C.byref(t1)), "hipsdp_dgemm_selfcheck3")
+    return used.value, nd.value, md.value, nr.value, t0.value, t1.value
+
+
 def potrf(A, device=0):
     L = _f64(A).copy()
     fail = C.c_int(0)

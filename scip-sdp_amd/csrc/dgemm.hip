@@ -436,6 +436,14 @@ double hs_gemm_executed_flops(const hs_gemm_args* a, int BT, int kstage, int kch
          if ( kend <= ks0 )
             continue;
          const int stages = (kend - ks0 + kstage - 1) / kstage;
+         if ( slabskip == 2 && BT == 128 && kstage == 8 && hs_dgemm2_tri5_eligible(a) )
+         {
+            /* paired-band kernel (hs_dgemm5_kernel): the band of 16 stages as 8 double stages of 36 matrix instructions per
+             * wavefront, whatever part of it lies inside the K range; full stages outside it */
+            const int nfull = triB ? (a->K > n0 + BT ? (a->K - n0 - BT + kstage - 1) / kstage : 0) : m0 / kstage;
+            f += 2048.0 * 4.0 * (8.0 * 36.0 + 32.0 * (double) nfull);
+            continue;
+         }
          if ( !(slabskip && BT == 128 && kstage == 8 && (triA || triB)) )
          {
             f += per_k * (double) stages * kstage;
@@ -588,15 +596,6 @@ int hs_dgemm(hipStream_t stream, const hs_gemm_args* a)
    }
    a = &eff;
 
-   if ( useBig && a->splitk <= 1 )
-   {
-      /* the two triangular products of the Schur assembly: strip kernel (dgemm4.hip), identical results */
-      const int r4 = hs_dgemm4_try(stream, a);
-      if ( r4 < 0 )
-         return -r4;
-      if ( r4 == 1 )
-         return HS_OK;
-   }
    if ( useBig )
    {
       /* the persistent LDS-DMA kernel (dgemm2.hip) takes the shapes it is eligible for: identical results */

@@ -97,12 +97,6 @@ int hs_dgemm(hipStream_t stream, const hs_gemm_args* args);
 int hs_dgemm2_try(hipStream_t stream, const hs_gemm_args* args, int kchunk);
 int hs_dgemm2_enable(int on);
 
-/* strip kernel for the two triangular n^3 products of the Schur assembly (dgemm4.hip): 1 launched, 0 not eligible, < 0 error
- * (negated code); hs_dgemm tries it before the persistent tile kernel.  hs_dgemm4_enable: test hook, returns the previous mode */
-int hs_dgemm4_try(hipStream_t stream, const hs_gemm_args* args);
-int hs_dgemm4_enable(int on);
-double hs_dgemm4_taken(void);          /* products the strip kernel has taken so far (test hook) */
-
 /* latency-oriented 32 x 32 kernel with the K split inside the workgroup (dgemm3.hip) for products of few tiles: 1 launched,
  * 0 not eligible, < 0 error (negated code); hs_dgemm tries it first for products without split-K */
 int hs_dgemm3_try(hipStream_t stream, const hs_gemm_args* args);
@@ -114,7 +108,8 @@ int hs_dgemm3_enabled(void);
  * skips inside the diagonal band.  The engine reads the difference around a Schur assembly (hipsdp_info.schur_flops_executed). */
 double hs_mfma_flops_total(void);
 void   hs_mfma_flops_add(double flops);
-int hs_dgemm2_slabskip(void);
+int hs_dgemm2_slabskip(void);            /* 0: no skipping of zero slabs, 1: skipping instances of round 3, 2: paired-band kernel (default) */
+int hs_dgemm2_tri5_eligible(const hs_gemm_args* a);
 double hs_gemm_executed_flops(const hs_gemm_args* a, int BT, int kstage, int kchunk, int slabskip);
 
 /* choose a split-K factor for a [M x N x K] product so that at least ~2 waves of workgroups exist */

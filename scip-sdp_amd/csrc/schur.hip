@@ -126,33 +126,12 @@ int hs_schur_W(hipStream_t s, int m1, int n, const double* A, const double* R, c
    const long long rows = (long long) m1 * n;
    if ( !w->full || n2 > 2000000000LL || rows > 2000000000LL )
       return HS_ERR_ARG;
-   /* HIPSDP_SCHUR_LEFT=1: both products with the triangular factor on the left (measured at n = 500, m = 1000 inside the solve:
-    * 10.93 ms per assembly against 10.60 for the form below - the K-contiguous right operand of the second product costs more than
-    * the strip kernel gains on the first; kept for shapes where A_stack R has few rows) */
-   static const bool leftform = getenv("HIPSDP_SCHUR_LEFT") != NULL && atoi(getenv("HIPSDP_SCHUR_LEFT")) != 0;
-   if ( leftform && w->kws_len >= n2 && (n & 1) == 0 )
-   {
-      /* Both n^3 products with the triangular factor on the LEFT (strip kernel, dgemm4.hip).  A_j is symmetric, so
-       * T_j^T = (A_j R)^T = R^T A_j: the first product is formed transposed - same multiplications in the same order, the same bits -
-       * and the second one takes T_j in that storage (K contiguous right operand).  R^T goes to the split-K slabs (free until GEMM3). */
-      double* Rt = w->K;
-      HS_CALL( hs_transpose(s, n, R, Rt) );
-      /* GEMM1: T_j^T = R^T * A_j, R^T upper triangular, batched over the m1 matrices */
-      hs_gemm_args g1 = {n, n, n, HS_KC, HS_MC, Rt, n, 0, A, n, n2, w->T, n, n2, 1.0, 0.0, m1, HS_GEMM_A_UPTRI | HS_GEMM_REMAP, 1, NULL};
-      HS_CALL( hs_dgemm(s, &g1) );
-      /* GEMM2: W_j = G * T_j, G lower triangular; T_j is read as [N][K] from its transposed storage */
-      hs_gemm_args g2 = {n, n, n, HS_KC, HS_KC, G, n, 0, w->T, n, n2, w->U, n, n2, 1.0, 0.0, m1, HS_GEMM_A_LOWTRI | HS_GEMM_REMAP, 1, NULL};
-      HS_CALL( hs_dgemm(s, &g2) );
-   }
-   else
-   {
-      /* GEMM1: T = A_stack * R, R lower triangular */
-      hs_gemm_args g1 = {(int) rows, n, n, HS_KC, HS_MC, A, n, 0, R, n, 0, w->T, n, 0, 1.0, 0.0, 1, HS_GEMM_B_LOWTRI, 1, NULL};   /* measured: the XCD remap costs 45 % on this shape */
-      HS_CALL( hs_dgemm(s, &g1) );
-      /* GEMM2: W_j = G * T_j, G lower triangular */
-      hs_gemm_args g2 = {n, n, n, HS_KC, HS_MC, G, n, 0, w->T, n, n2, w->U, n, n2, 1.0, 0.0, m1, HS_GEMM_A_LOWTRI | HS_GEMM_REMAP, 1, NULL};
-      HS_CALL( hs_dgemm(s, &g2) );
-   }
+   /* GEMM1: T = A_stack * R, R lower triangular */
+   hs_gemm_args g1 = {(int) rows, n, n, HS_KC, HS_MC, A, n, 0, R, n, 0, w->T, n, 0, 1.0, 0.0, 1, HS_GEMM_B_LOWTRI, 1, NULL};   /* measured: the XCD remap costs 45 % on this shape */
+   HS_CALL( hs_dgemm(s, &g1) );
+   /* GEMM2: W_j = G * T_j, G lower triangular */
+   hs_gemm_args g2 = {n, n, n, HS_KC, HS_MC, G, n, 0, w->T, n, n2, w->U, n, n2, 1.0, 0.0, m1, HS_GEMM_A_LOWTRI | HS_GEMM_REMAP, 1, NULL};
+   HS_CALL( hs_dgemm(s, &g2) );
    /* GEMM3: Mx += W W^T on the lower tiles */
    int flags = HS_GEMM_LOWER;
    int sk;

@@ -57,6 +57,20 @@ __global__ void k_unit_maxdiff(long long n, const double* __restrict__ a, const 
       atomicAdd(ndiff, cnt);
 }
 
+/* max |a - b| (non-negative doubles order like their bit patterns) */
+__global__ void k_unit_maxabsdiff(long long n, const double* __restrict__ a, const double* __restrict__ b, unsigned long long* __restrict__ out)
+{
+   double m = 0.0;
+   for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long) gridDim.x * blockDim.x)
+   {
+      const double d = fabs(a[i] - b[i]);
+      if ( !(d <= m) )            /* a NaN counts as the largest difference */
+         m = (d != d) ? 1e300 : d;
+   }
+   if ( m > 0.0 )
+      atomicMax(out, (unsigned long long) __double_as_longlong(m));
+}
+
 /* zero the part of an operand that a triangular flag declares zero: mode 0: X[r][c] = 0 for c > r (rows x cols, K contiguous A:
  * k > m), mode 1: X[r][c] = 0 for r < c (B stored [K][N]: k < n) - the same predicate, kept apart for readability */
 __global__ void k_unit_tri(int rows, int cols, long long stride, int batch, double* __restrict__ x)
@@ -87,7 +101,7 @@ __global__ void k_unit_tri_upper(int rows, int cols, double* __restrict__ x)
  * bit for bit.  A is K-contiguous; layB, batch, splitk and flags as in hs_gemm_args (C packed, ldc = N).  used_v2 = 1 when
  * the persistent kernel accepted the shape; ndiff = number of differing elements of C (over all batch entries). */
 static int dgemm_selfcheck_impl(int device, int M, int N, int K, int layB, int batch, int splitk, int flags, double alpha, double beta,
-   int reps, int* used, long long* ndiff, double* ms_tile, double* ms_fast)
+   int reps, int* used, long long* ndiff, double* ms_tile, double* ms_fast, double* maxdiff = NULL, long long* nrepro = NULL)
 {
    HS_CALL( pick_device(device) );
    if ( M <= 0 || N <= 0 || K <= 0 || batch < 1 )
@@ -139,13 +153,10 @@ static int dgemm_selfcheck_impl(int device, int M, int N, int K, int layB, int b
    int rc = HS_OK;
    /* reference: the one-tile-per-workgroup kernel (dgemm.hip) alone */
    hs_dgemm2_enable(0);
-   const int g4before = hs_dgemm4_enable(0);
    rc = hs_dgemm(0, &g);
    if ( rc == HS_OK )
       rc = timed(ms_tile);
    const int before = hs_dgemm2_enable(1);
-   (void) hs_dgemm4_enable(1);                      /* the strip kernel is an option of the dispatch (HIPSDP_GEMM4): this check always exercises it */
-   const double f4before = hs_dgemm4_taken();
    g.C = dC2.p;
    /* the second run must not inherit the slabs of the first: a slice one kernel never writes would go unnoticed */
    if ( splitk > 1 )
@@ -153,13 +164,8 @@ static int dgemm_selfcheck_impl(int device, int M, int N, int K, int layB, int b
    if ( rc == HS_OK )
       rc = hs_dgemm(0, &g);
    const int after = hs_dgemm2_enable(1);
-   const double f4after = hs_dgemm4_taken();
    if ( rc == HS_OK )
       rc = timed(ms_fast);
-   if ( g4before >= 0 )
-      (void) hs_dgemm4_enable(g4before);
-   else
-      (void) hs_dgemm4_enable(getenv("HIPSDP_GEMM4") != NULL && getenv("HIPSDP_GEMM4")[0] == '1');
    if ( rc == HS_OK && hipDeviceSynchronize() != hipSuccess )
       rc = HS_ERR_HIP;
    unsigned long long hn = 0;
@@ -169,11 +175,51 @@ static int dgemm_selfcheck_impl(int device, int M, int N, int K, int layB, int b
       if ( hipMemcpy(&hn, dn, sizeof(hn), hipMemcpyDeviceToHost) != hipSuccess )
          rc = HS_ERR_HIP;
    }
+   if ( rc == HS_OK && nrepro != NULL )
+   {
+      /* the default dispatch once more into a third array: the same bits whichever workgroup computed which tile */
+      DevBuf dC3;
+      unsigned long long hr = 0;
+      rc = dC3.alloc(nc * batch);
+      if ( rc == HS_OK && hipMemcpy(dC3.p, dC1.p, (size_t) (nc * batch) * sizeof(double), hipMemcpyDeviceToDevice) != hipSuccess )
+         rc = HS_ERR_HIP;
+      if ( rc == HS_OK && beta != 0.0 )
+      {
+         /* (beta != 0: C1 holds the tile kernel's result, not the input - regenerate the input) */
+         hipLaunchKernelGGL(k_unit_fill, dim3(1024), dim3(256), 0, 0, nc * batch, 37ULL, dC3.p);
+         hipLaunchKernelGGL(k_unit_fill, dim3(1024), dim3(256), 0, 0, nc * batch, 37ULL, dC2.p);
+         g.C = dC2.p;
+         rc = hs_dgemm(0, &g);
+      }
+      g.C = dC3.p;
+      if ( rc == HS_OK )
+         rc = hs_dgemm(0, &g);
+      if ( rc == HS_OK && hipMemset(dn, 0, sizeof(unsigned long long)) != hipSuccess )
+         rc = HS_ERR_HIP;
+      if ( rc == HS_OK )
+      {
+         hipLaunchKernelGGL(k_unit_maxdiff, dim3(1024), dim3(256), 0, 0, nc * batch, dC2.p, dC3.p, dn);
+         if ( hipMemcpy(&hr, dn, sizeof(hr), hipMemcpyDeviceToHost) != hipSuccess )
+            rc = HS_ERR_HIP;
+      }
+      *nrepro = (long long) hr;
+      g.C = dC2.p;
+   }
+   if ( rc == HS_OK && maxdiff != NULL )
+   {
+      unsigned long long bits = 0;
+      if ( hipMemset(dn, 0, sizeof(unsigned long long)) != hipSuccess )
+         rc = HS_ERR_HIP;
+      hipLaunchKernelGGL(k_unit_maxabsdiff, dim3(1024), dim3(256), 0, 0, nc * batch, dC1.p, dC2.p, dn);
+      if ( rc == HS_OK && hipMemcpy(&bits, dn, sizeof(bits), hipMemcpyDeviceToHost) != hipSuccess )
+         rc = HS_ERR_HIP;
+      memcpy(maxdiff, &bits, sizeof(double));
+   }
    (void) hipFree(dn);
    if ( e0 != NULL ) (void) hipEventDestroy(e0);
    if ( e1 != NULL ) (void) hipEventDestroy(e1);
    HS_CALL( rc );
-   *used = (after - before > 0 ? 1 : 0) | (f4after > f4before ? 2 : 0);
+   *used = after - before > 0 ? 1 : 0;
    *ndiff = (long long) hn;
    return HIPSDP_OK;
 }
@@ -187,13 +233,20 @@ extern "C" int hipsdp_dgemm_selfcheck(int device, int M, int N, int K, int layB,
    return HIPSDP_OK;
 }
 
-/* the same with a free alpha (the strip kernel of dgemm4.hip takes alpha = 1, beta = 0 only) and, for reps > 0 and beta = 0, the
- * average time of one product through the tile kernel alone (ms_tile) and through the default dispatch (ms_fast).
- * *used: bit 0 the persistent tile kernel (dgemm2.hip) took it, bit 1 the strip kernel (dgemm4.hip) */
+/* the same with a free alpha and, for reps > 0 and beta = 0, the average time of one product through the tile kernel alone
+ * (ms_tile) and through the default dispatch (ms_fast).  *used: bit 0 a persistent kernel of dgemm2.hip took it */
 extern "C" int hipsdp_dgemm_selfcheck2(int device, int M, int N, int K, int layB, int batch, int splitk, int flags, double alpha, double beta,
    int reps, int* used, long long* ndiff, double* ms_tile, double* ms_fast)
 {
    return dgemm_selfcheck_impl(device, M, N, K, layB, batch, splitk, flags, alpha, beta, reps, used, ndiff, ms_tile, ms_fast);
+}
+
+/* the same with the largest absolute difference between the two results (entries are sums of K products of values in
+ * [-0.5, 0.5): the paired-band kernel of the triangular products sums the band in another order than the tile kernel) */
+extern "C" int hipsdp_dgemm_selfcheck3(int device, int M, int N, int K, int layB, int batch, int splitk, int flags, double alpha, double beta,
+   int reps, int* used, long long* ndiff, double* maxdiff, long long* nrepro, double* ms_tile, double* ms_fast)
+{
+   return dgemm_selfcheck_impl(device, M, N, K, layB, batch, splitk, flags, alpha, beta, reps, used, ndiff, ms_tile, ms_fast, maxdiff, nrepro);
 }
 
 extern "C" int hipsdp_schur_dense(int device, int m1, int n, const double* A, const double* X, const double* Zinv, double* Mx,

@@ -306,9 +306,7 @@ GEMM_LOWER, GEMM_A_LOWTRI, GEMM_B_LOWTRI, GEMM_XCD, GEMM_REMAP, GEMM_NOFAST = 1,
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K,layB,batch,splitk,flags,beta,expect_v2", [
-    (50000, 500, 500, 1, 1, 1, GEMM_B_LOWTRI, 0.0, 1),                  # stack product of the Schur assembly (A_j R), K tail of 4
-    (50000, 500, 500, 1, 1, 1, 0, 0.0, 1),                              # the same without the triangular clipping
-    (500, 500, 500, 1, 40, 1, GEMM_A_LOWTRI | GEMM_REMAP, 0.0, 1),      # batched product G T_j
+    (50000, 500, 500, 1, 1, 1, 0, 0.0, 1),                              # stack product without the triangular clipping
     (1001, 1001, 30000, 0, 1, 14, GEMM_LOWER | GEMM_XCD | GEMM_NOFAST, 1.0, 1),   # Gram product W W^T in K slices, ragged last tile
     (3000, 2500, 500, 1, 1, 1, 0, 0.5, 1),                              # beta != 0
     (2900, 2600, 330, 0, 1, 1, 0, 0.0, 1),                              # both K contiguous, ragged tiles, K tail of 2
@@ -325,29 +323,30 @@ def test_persistent_gemm_matches_tile_gemm_bitwise(gpu, M, N, K, layB, batch, sp
     assert ndiff == 0
 
 
-GEMM_A_UPTRI = 256
-
-
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,batch,flags,layB,expect_strip", [
-    (500, 101, GEMM_A_LOWTRI | GEMM_REMAP, 1, 1),       # W_j = G T_j of the Schur assembly: 8 strips of 64 rows per matrix, ragged last strip and slab
-    (500, 101, GEMM_A_LOWTRI | GEMM_REMAP, 0, 1),       # the same with T_j given K contiguous (transposed storage)
-    (500, 101, GEMM_A_UPTRI | GEMM_REMAP, 1, 1),        # T_j^T = R^T A_j: the K range of a strip starts at its first row
-    (500, 101, GEMM_A_UPTRI | GEMM_REMAP, 0, 1),
-    (1000, 40, GEMM_A_LOWTRI | GEMM_REMAP, 1, 1),       # two column tiles of 512 (the second 488 wide)
-    (1000, 40, GEMM_A_UPTRI | GEMM_REMAP, 0, 1),
-    (362, 160, GEMM_A_LOWTRI | GEMM_REMAP, 1, 1),       # 23 column slabs: the wavefronts own 6, 6, 6, 5 of them
-    (362, 160, GEMM_A_UPTRI | GEMM_REMAP, 1, 1),
-    (514, 70, GEMM_A_LOWTRI | GEMM_REMAP, 1, 0),        # 514 columns would fill half of the second strip: not eligible
-    (70, 600, GEMM_A_UPTRI | GEMM_REMAP, 1, 0),         # too narrow
-    (500, 40, GEMM_A_LOWTRI | GEMM_REMAP, 1, 0),        # too few strips (320 < 512)
+@pytest.mark.parametrize("M,N,K,layB,batch,flags,alpha,beta", [
+    (50000, 500, 500, 1, 1, GEMM_B_LOWTRI, 1.25, 0.0),                  # stack product of the Schur assembly (A_j R): last column tile 116 wide, K tail of 4
+    (50000, 500, 500, 1, 1, GEMM_B_LOWTRI, 1.0, 0.0),                   # alpha = 1: the store path the assembly takes
+    (500, 500, 500, 1, 40, GEMM_A_LOWTRI | GEMM_REMAP, 1.0, 0.0),       # batched product G T_j, T_j row-contiguous
+    (500, 500, 500, 0, 40, GEMM_A_LOWTRI | GEMM_REMAP, 1.25, 0.0),      # T_j given K contiguous (transposed storage)
+    (40000, 256, 384, 1, 1, GEMM_B_LOWTRI, 1.0, 0.5),                   # K > N (column slice of a sharded assembly), beta != 0
+    (50000, 372, 500, 1, 1, GEMM_B_LOWTRI, 1.0, 0.0),                   # ragged last column tile, the band of the last tile cut by K
+    (30001, 1000, 1000, 1, 1, GEMM_B_LOWTRI, 1.0, 0.0),                 # eight column tiles, odd M (clamped rows)
+    (1000, 1000, 1000, 1, 16, GEMM_A_LOWTRI | GEMM_REMAP, 1.0, 0.0),    # eight row tiles per matrix: up to 112 full stages in front of the band
+    (362, 362, 362, 1, 160, GEMM_A_LOWTRI | GEMM_REMAP, 1.0, 0.0),      # three row tiles, the last 106 rows: band cut by K
+    (6000, 130, 130, 1, 6, GEMM_B_LOWTRI, 1.0, 0.0),                    # batched right-triangular product, second column tile 2 wide
 ])
-def test_strip_gemm_matches_tile_gemm_bitwise(gpu, n, batch, flags, layB, expect_strip):
-    """the strip kernel of the two triangular n^3 products (csrc/dgemm4.hip: one workgroup per CU, 64 x 512 strips, branch-free
-    stages) against the one-tile-per-workgroup kernel on the same device-generated operands: identical bits"""
-    used, ndiff, _, _ = gpu.dgemm_selfcheck2(n, n, n, layB=layB, batch=batch, flags=flags, alpha=1.0, beta=0.0)
-    assert ((used >> 1) & 1) == expect_strip
-    assert ndiff == 0
+def test_paired_band_gemm_matches_tile_gemm(gpu, M, N, K, layB, batch, flags, alpha, beta):
+    """the two triangular n^3 products through the paired-band kernel (csrc/dgemm2.hip: hs_dgemm5_kernel - double stages (d, 15 - d)
+    inside the diagonal band, list entries taken dynamically) against the one-tile-per-workgroup kernel on the same
+    device-generated operands.  The band is summed in another order of K, so the results agree to rounding, not bit for bit:
+    entries are sums of at most K products of numbers in [-0.5, 0.5), |difference| <= 1e-15 K is 5-10 ulp of the largest of them.
+    A second call must reproduce the first bit for bit (which workgroup computes a tile must not matter)."""
+    used, ndiff, maxdiff, nrepro, _, _ = gpu.dgemm_selfcheck3(M, N, K, layB=layB, batch=batch, flags=flags, alpha=alpha, beta=beta)
+    assert used == 1
+    assert nrepro == 0
+    assert maxdiff <= 1e-15 * K
+    assert ndiff > 0 or K <= 136           # (really another summation order: the test would otherwise not exercise the new kernel)
 
 
 @pytest.mark.gpu
