@@ -23,6 +23,10 @@ HIPSDP_API int  hipsdp_pass_at_unit(int device, int R, long long E, const double
    double* out, int* chunks);
 HIPSDP_API int  hipsdp_dgemm_selfcheck2(int device, int M, int N, int K, int layB, int batch, int splitk, int flags, double alpha, double beta,
    int reps, int* used, long long* ndiff, double* ms_tile, double* ms_fast);
+HIPSDP_API int  hipsdp_gram_plan_info(int device, int M, long long K, int nslab, int* no, int* nd, int* nitems, double* span);
+/* Gram product W W^T (lower triangle) through the K-sliced tile kernels and through the Gram kernel of csrc/gram.hip */
+HIPSDP_API int  hipsdp_gram_selfcheck(int device, int M, long long K, int reps, int* used, double* maxdiff, long long* nrepro, double* ms_tile,
+   double* ms_gram);
 /* the same, also returning the largest absolute difference of the two results and the number of elements that differ between
  * TWO runs of the default dispatch (must be 0) */
 HIPSDP_API int  hipsdp_dgemm_selfcheck3(int device, int M, int N, int K, int layB, int batch, int splitk, int flags, double alpha, double beta,

@@ -357,6 +357,17 @@ def dgemm_selfcheck3(M, N, K, layB=1, batch=1, splitk=1, flags=0, alpha=1.0, bet
     return used.value, nd.value, md.value, nr.value, t0.value, t1.value
 
 
+def gram_selfcheck(M, K, reps=0, device=0):
+    """W W^T on the lower triangle through the K-sliced tile kernels and through the Gram kernel (csrc/gram.hip)
+    -> (Gram kernel took it, max |difference| over the lower triangle, elements not reproduced by a second run, ms tile path, ms Gram kernel)"""
+    used = C.c_int(0)
+    nr = C.c_longlong(0)
+    md, t0, t1 = C.c_double(0.0), C.c_double(0.0), C.c_double(0.0)
+    _chk(ulib().hipsdp_gram_selfcheck(device, M, C.c_longlong(K), reps, C.byref(used), C.byref(md), C.byref(nr), C.byref(t0), C.byref(t1)),
+         "hipsdp_gram_selfcheck")
+    return used.value, md.value, nr.value, t0.value, t1.value
+
+
 def potrf(A, device=0):
     L = _f64(A).copy()
     fail = C.c_int(0)

@@ -561,6 +561,9 @@ __global__ void __launch_bounds__(256, G2_WGPC) hs_dgemm2_kernel(hs_gemm_args p,
  * Everything else as above: persistent workgroups, XCD-contiguous interleaved items, LDS-DMA ring of 4 slots, counted waits,
  * two halves per (double) stage with the next half's fragment reads and the ring's DMA between the matrix instructions. */
 #define G5_NS 4
+#ifndef G5_DESC
+#define G5_DESC 1
+#endif
 #ifndef G5_ABL
 #define G5_ABL 0                            /* developer ablations (wrong results): 1 no C stores, 2 no DMA, 4 no matrix instructions */
 #endif
@@ -716,18 +719,15 @@ __global__ void __launch_bounds__(256, 2) hs_dgemm5_kernel(hs_gemm_args p, long 
    auto stage_begin = [&](int slotidx) __attribute__((always_inline))
    {
       rq_slot = g2_smem + slotidx * G2_SLOT;
+      /* both kinds: the full stages first, then the band.  TRI = 1 walks its full stages from the END of the K range down to the
+       * band: the column tiles of a row panel, taken by four workgroups of the XCD within a few microseconds of each other, then
+       * read the same columns of A at the same time (G5_DESC=0: ascending from the band's end) */
+      const int j = pidx - pnfull;
+      const int pj = (j & 1) ? 15 - (j >> 1) : (j >> 1);
       if ( TRI == 1 )
-      {
-         const int j = pidx;
-         const int pj = (j & 1) ? 15 - (j >> 1) : (j >> 1);
-         rq_K0 = pkb + 8 * (j < 16 ? pj : j);
-      }
+         rq_K0 = j < 0 ? pkb + G2_BT + 8 * (G5_DESC ? pnfull - 1 - pidx : pidx) : pkb + 8 * pj;
       else
-      {
-         const int j = pidx - pnfull;
-         const int pj = (j & 1) ? 15 - (j >> 1) : (j >> 1);
          rq_K0 = j < 0 ? 8 * pidx : pkb + 8 * pj;
-      }
    };
    auto stage_piece = [&](int k) __attribute__((always_inline))
    {
@@ -1179,17 +1179,11 @@ __global__ void __launch_bounds__(256, 2) hs_dgemm5_kernel(hs_gemm_args p, long 
       /* the item after this one into nxt (the requests for it start four stages before this one ends) */
       decode_next(__builtin_amdgcn_readfirstlane((int) g5_q[(gi + 1) & 3]));
       if ( TRI == 1 )
-      {
          cnfull = p.K > cn0 + G2_BT ? (p.K - cn0 - G2_BT + G2_BKS - 1) / G2_BKS : 0;
-         run_band();
-         run_full(cnfull);
-      }
       else
-      {
          cnfull = cm0 / G2_BKS;
-         run_full(cnfull);
-         run_band();
-      }
+      run_full(cnfull);
+      run_band();
       store_item();
       cm0 = nm0; cn0 = nn0; cbz = nbz; cvalid = nvalid;
       ++gi;

@@ -113,6 +113,24 @@ int hs_schur_U(hipStream_t s, int m1, int n, const double* A, const double* X, c
    return HS_OK;
 }
 
+/* Mx += V V^T (lower triangle) through the Gram kernel (gram.hip) when it takes the shape: *done = 1 */
+static int schur_gram(hipStream_t s, int m1, long long K, const double* V, long long ldv, double* Mx, hs_schur_ws* w, int* done)
+{
+   *done = 0;
+   long long nslab = w->kws_len / ((long long) m1 * m1);
+   if ( nslab > 64 ) nslab = 64;
+   double executed = 0.0;
+   const int r = hs_gram_try(s, m1, K, V, ldv, Mx, m1, 1.0, 1.0, w->K, (int) nslab, &executed);
+   if ( r < 0 )
+      return -r;
+   if ( r == 1 )
+   {
+      hs_mfma_flops_add(executed);
+      *done = 1;
+   }
+   return HS_OK;
+}
+
 /* smallest m1 for which the Gram product runs in XCD-walked K slices (below: plain split-K over the lower tiles) */
 static int hs_syrk_min_m1(void)
 {
@@ -133,6 +151,12 @@ int hs_schur_W(hipStream_t s, int m1, int n, const double* A, const double* R, c
    hs_gemm_args g2 = {n, n, n, HS_KC, HS_MC, G, n, 0, w->T, n, n2, w->U, n, n2, 1.0, 0.0, m1, HS_GEMM_A_LOWTRI | HS_GEMM_REMAP, 1, NULL};
    HS_CALL( hs_dgemm(s, &g2) );
    /* GEMM3: Mx += W W^T on the lower tiles */
+   {
+      int done = 0;
+      HS_CALL( schur_gram(s, m1, n2, w->U, n2, Mx, w, &done) );
+      if ( done )
+         return HS_OK;
+   }
    int flags = HS_GEMM_LOWER;
    int sk;
    /* measured (tools/syrk_threshold.sh): the XCD-walked slices win by 8-10 % for n >= 256 at every m1 >= 256, and for n = 128 from
@@ -182,6 +206,12 @@ int hs_schur_Wcols(hipStream_t s, int m1, int n, const double* A, const double* 
    HS_CALL( hs_dgemm(s, &g1) );
    hs_gemm_args g2 = {n, cw, n, HS_KC, HS_MC, G, n, 0, w->T, cw, nk, w->U, cw, nk, 1.0, 0.0, m1, HS_GEMM_A_LOWTRI | HS_GEMM_REMAP | narrow, 1, NULL};
    HS_CALL( hs_dgemm(s, &g2) );
+   {
+      int done = 0;
+      HS_CALL( schur_gram(s, m1, nk, w->U, nk, Mx, w, &done) );
+      if ( done )
+         return HS_OK;
+   }
    int flags = HS_GEMM_LOWER;
    int sk;
    if ( m1 >= 256 && nk >= 16384 )
@@ -353,6 +383,12 @@ int wvar_gram(hipStream_t s, const WvarSlice& q, hs_schur_ws* w, const double* r
    const long long Kme = q.Kme;
    if ( Kme <= 0 )
       return HS_OK;
+   {
+      int done = 0;
+      HS_CALL( schur_gram(s, m1, Kme, recv, Kme, Mx, w, &done) );
+      if ( done )
+         return HS_OK;
+   }
    int flags = HS_GEMM_LOWER;
    int sk;
    if ( m1 >= 256 && Kme >= 16384 )

@@ -249,6 +249,122 @@ extern "C" int hipsdp_dgemm_selfcheck3(int device, int M, int N, int K, int layB
    return dgemm_selfcheck_impl(device, M, N, K, layB, batch, splitk, flags, alpha, beta, reps, used, ndiff, ms_tile, ms_fast, maxdiff, nrepro);
 }
 
+/* lower triangle: max |a - b| over r >= c, and the number of elements there whose bits differ */
+__global__ void k_unit_lowdiff(int M, const double* __restrict__ a, const double* __restrict__ b, unsigned long long* __restrict__ out)
+{
+   double m = 0.0;
+   unsigned long long cnt = 0;
+   const long long MM = (long long) M * M;
+   for (long long e = (long long) blockIdx.x * blockDim.x + threadIdx.x; e < MM; e += (long long) gridDim.x * blockDim.x)
+   {
+      const int r = (int) (e / M), c = (int) (e - (long long) r * M);
+      if ( c > r )
+         continue;
+      const double d = fabs(a[e] - b[e]);
+      if ( !(d <= m) )
+         m = (d != d) ? 1e300 : d;
+      if ( __double_as_longlong(a[e]) != __double_as_longlong(b[e]) )
+         ++cnt;
+   }
+   if ( m > 0.0 )
+      atomicMax(out, (unsigned long long) __double_as_longlong(m));
+   if ( cnt )
+      atomicAdd(out + 1, cnt);
+}
+
+/* The Gram product of the Schur assembly, C = W W^T + C on the lower triangle with W [M][K] generated on the device, through the
+ * K-sliced tile kernels (hs_dgemm, HS_GEMM_LOWER | HS_GEMM_XCD) and through the Gram kernel (gram.hip): *used = 1 when the Gram
+ * kernel took the shape, *maxdiff = largest difference over the lower triangle, *nrepro = elements of the lower triangle that
+ * differ between two runs of the Gram kernel (must be 0); reps > 0: average times of the two paths */
+extern "C" int hipsdp_gram_selfcheck(int device, int M, long long K, int reps, int* used, double* maxdiff, long long* nrepro, double* ms_tile,
+   double* ms_gram)
+{
+   HS_CALL( pick_device(device) );
+   if ( M <= 0 || K <= 0 || used == NULL || maxdiff == NULL || nrepro == NULL )
+      return HIPSDP_ERR_ARG;
+   const long long MM = (long long) M * M;
+   const long long tm = (M + 127) / 128;
+   int sk = hs_dgemm_pick_xcd_slices(tm * (tm + 1) / 2, K);
+   const int nslab = 64;
+   DevBuf dW, dC1, dC2, dC3, dS;
+   unsigned long long* dn = NULL;
+   HS_CALL( dW.alloc((long long) M * K) ); HS_CALL( dC1.alloc(MM) ); HS_CALL( dC2.alloc(MM) ); HS_CALL( dC3.alloc(MM) ); HS_CALL( dS.alloc((long long) nslab * MM) );
+   HS_HIP( hipMalloc((void**) &dn, 2 * sizeof(unsigned long long)) );
+   hipLaunchKernelGGL(k_unit_fill, dim3(1024), dim3(256), 0, 0, (long long) M * K, 11ULL, dW.p);
+   hipLaunchKernelGGL(k_unit_fill, dim3(1024), dim3(256), 0, 0, MM, 37ULL, dC1.p);
+   hipLaunchKernelGGL(k_unit_fill, dim3(1024), dim3(256), 0, 0, MM, 37ULL, dC2.p);
+   hipLaunchKernelGGL(k_unit_fill, dim3(1024), dim3(256), 0, 0, MM, 37ULL, dC3.p);
+   hipLaunchKernelGGL(k_unit_fill, dim3(1024), dim3(256), 0, 0, (long long) nslab * MM, 51ULL, dS.p);
+   hs_gemm_args g3 = {M, M, (int) K, HS_KC, HS_KC, dW.p, K, 0, dW.p, K, 0, dC1.p, M, 0, 1.0, 1.0, 1, HS_GEMM_LOWER | HS_GEMM_XCD | HS_GEMM_NOFAST, sk, dS.p};
+   int rc = hs_dgemm(0, &g3);
+   int r2 = 0;
+   double ex = 0.0;
+   if ( rc == HS_OK )
+   {
+      hipLaunchKernelGGL(k_unit_fill, dim3(1024), dim3(256), 0, 0, (long long) nslab * MM, 52ULL, dS.p);
+      r2 = hs_gram_try(0, M, K, dW.p, K, dC2.p, M, 1.0, 1.0, dS.p, nslab, &ex);
+      if ( r2 < 0 ) rc = -r2;
+   }
+   if ( rc == HS_OK && r2 == 1 )
+   {
+      hipLaunchKernelGGL(k_unit_fill, dim3(1024), dim3(256), 0, 0, (long long) nslab * MM, 53ULL, dS.p);
+      r2 = hs_gram_try(0, M, K, dW.p, K, dC3.p, M, 1.0, 1.0, dS.p, nslab, &ex);
+      if ( r2 < 0 ) rc = -r2;
+   }
+   *used = r2 == 1 ? 1 : 0;
+   *maxdiff = 0.0; *nrepro = 0;
+   unsigned long long h[2] = {0, 0};
+   if ( rc == HS_OK && r2 == 1 )
+   {
+      if ( hipMemset(dn, 0, 2 * sizeof(unsigned long long)) != hipSuccess ) rc = HS_ERR_HIP;
+      hipLaunchKernelGGL(k_unit_lowdiff, dim3(1024), dim3(256), 0, 0, M, dC1.p, dC2.p, dn);
+      if ( rc == HS_OK && hipMemcpy(h, dn, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess ) rc = HS_ERR_HIP;
+      memcpy(maxdiff, &h[0], sizeof(double));
+      if ( rc == HS_OK && hipMemset(dn, 0, 2 * sizeof(unsigned long long)) != hipSuccess ) rc = HS_ERR_HIP;
+      hipLaunchKernelGGL(k_unit_lowdiff, dim3(1024), dim3(256), 0, 0, M, dC2.p, dC3.p, dn);
+      if ( rc == HS_OK && hipMemcpy(h, dn, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess ) rc = HS_ERR_HIP;
+      *nrepro = (long long) h[1];
+   }
+   if ( rc == HS_OK && reps > 0 && ms_tile != NULL && ms_gram != NULL )
+   {
+      hipEvent_t e0, e1;
+      HS_HIP( hipEventCreate(&e0) ); HS_HIP( hipEventCreate(&e1) );
+      for (int which = 0; which < 2 && rc == HS_OK; ++which)
+      {
+         for (int it = -2; it < reps && rc == HS_OK; ++it)
+         {
+            if ( it == 0 )
+               (void) hipEventRecord(e0, 0);
+            if ( which == 0 )
+               rc = hs_dgemm(0, &g3);
+            else if ( r2 == 1 )
+            {
+               const int r = hs_gram_try(0, M, K, dW.p, K, dC2.p, M, 1.0, 1.0, dS.p, nslab, &ex);
+               if ( r < 0 ) rc = -r;
+            }
+         }
+         (void) hipEventRecord(e1, 0);
+         float t = 0.f;
+         if ( rc == HS_OK && (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t, e0, e1) != hipSuccess) )
+            rc = HS_ERR_HIP;
+         *(which == 0 ? ms_tile : ms_gram) = (double) t / reps;
+      }
+      (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+   }
+   if ( rc == HS_OK && hipDeviceSynchronize() != hipSuccess )
+      rc = HS_ERR_HIP;
+   (void) hipFree(dn);
+   return rc;
+}
+
+/* how csrc/gram.hip cuts the Gram product of a shape: partial tiles per off-diagonal / diagonal tile, items, estimated time in units
+ * of one off-diagonal tile over all of K */
+extern "C" int hipsdp_gram_plan_info(int device, int M, long long K, int nslab, int* no, int* nd, int* nitems, double* span)
+{
+   HS_CALL( pick_device(device) );
+   return hs_gram_plan_info(M, K, nslab, no, nd, nitems, span) ? HIPSDP_OK : HIPSDP_ERR_ARG;
+}
+
 extern "C" int hipsdp_schur_dense(int device, int m1, int n, const double* A, const double* X, const double* Zinv, double* Mx,
    double ws_gbytes)
 {

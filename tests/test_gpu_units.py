@@ -350,6 +350,28 @@ def test_paired_band_gemm_matches_tile_gemm(gpu, M, N, K, layB, batch, flags, al
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,K,expect_gram", [
+    (1001, 120000, 1),       # the tile count of the bench shape (36 lower tiles, ragged last tile): 15 / 11 K slices, one item per workgroup
+    (401, 250000, None),     # 4 x 4 tiles: the diagonal tiles are 40 % of the items
+    (700, 120000, None),
+    (1024, 65536, None),     # whole tiles
+    (1001, 30000, None),     # short K: taken only if the plan's estimate beats the tile kernel's by 3 % (csrc/gram.hip: gr_plan)
+    (2001, 20000, 0),        # 136 tiles: more than one item per workgroup - left to the K-sliced tile kernel
+    (200, 40000, 0),         # below the sizes the kernel is offered
+])
+def test_gram_kernel_matches_the_k_sliced_tile_kernels(gpu, M, K, expect_gram):
+    """Mx += W W^T on the lower triangle through csrc/gram.hip (diagonal tiles with nine accumulators per wavefront from one operand
+    image, tiles cut into K slices by a plan made on the host, one item per workgroup) against the K-sliced tile kernels on the same
+    device-generated W: the two sum K in different slices, so they agree to rounding (entries are sums of K products of numbers in
+    [-0.5, 0.5): the diagonal is about K / 12); a second run of the Gram kernel reproduces the first bit for bit"""
+    used, maxdiff, nrepro, _, _ = gpu.gram_selfcheck(M, K)
+    assert expect_gram is None or used == expect_gram
+    if used:
+        assert nrepro == 0
+        assert maxdiff <= 1e-15 * K
+
+
+@pytest.mark.gpu
 def test_schur_products_at_bench_shape_against_numpy(gpu):
     """the two dominant product shapes of the n = 500, m = 1000 assembly through the production dispatch against numpy (the
     kernels are otherwise compared with each other at this size): the stack product A_stack R (500500 x 500 x 500) and the Gram
