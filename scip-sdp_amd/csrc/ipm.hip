@@ -17,6 +17,7 @@
 #include <rocprofiler-sdk-roctx/roctx.h>
 #include <vector>
 #include <utility>
+#include <functional>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -1825,12 +1826,16 @@ int hs_bcast_ints(void* comm, int* buf, long long count, hipStream_t stream);
 /* Read-back without a copy engine and without a stream synchronisation: a kernel stores n doubles of sc to the host mirror
  * and then a sequence number; the host polls the number (coherent pinned memory).  The stream is queried now and then so
  * that a failed launch cannot leave the host spinning. */
-static int publish_and_wait(hipsdp_solver* s, int off, int n)
+static int publish_and_wait(hipsdp_solver* s, int off, int n, const std::function<int()>* between = NULL)
 {
    const unsigned long long seq = ++s->pub_seq;
    volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(s->hsc + s->hsc_cap - 1);
    HS_CALL( hs_red_batch_end_publish(s->stream, n, s->sc + off, s->hsc_dev + off, seq,
          reinterpret_cast<unsigned long long*>(s->hsc_dev + s->hsc_cap - 1)) );
+   /* work that does not depend on what the host is about to read goes into the queue now: the device runs it while the scalars
+    * travel, the host decides and the next launches arrive */
+   if ( between != NULL )
+      HS_CALL( (*between)() );
    /* developer switch HIPSDP_WAIT_TIMES=1: how long the host waits here in total (at process end): the share of a solve in which the
     * device is the one being waited for */
    static int wt = -1;
@@ -1883,7 +1888,7 @@ static int publish_and_wait(hipsdp_solver* s, int off, int n)
    return HS_OK;
 }
 
-static int read_scalars(hipsdp_solver* s, HostScalars& h, int* flags3)
+static int read_scalars(hipsdp_solver* s, HostScalars& h, int* flags3, const std::function<int()>* between = NULL)
 {
    if ( s->comm != NULL || !s->use_publish )
       HS_CALL( hs_red_batch_end_all() );  /* recorded operations must run before the scalars are read */
@@ -1897,11 +1902,13 @@ static int read_scalars(hipsdp_solver* s, HostScalars& h, int* flags3)
    if ( s->comm == NULL && s->use_publish )
    {
       /* the batch kernel (or a one-block kernel when the batch is empty) stores the scalars to the host mirror itself */
-      HS_CALL( publish_and_wait(s, 0, s->nsc + 4) );
+      HS_CALL( publish_and_wait(s, 0, s->nsc + 4, between) );
    }
    else
    {
       HS_HIP( hipMemcpyAsync(s->hsc, s->sc, (size_t) (s->nsc + (flags3 != NULL ? 4 : 0)) * sizeof(double), hipMemcpyDeviceToHost, s->stream) );
+      if ( between != NULL )
+         HS_CALL( (*between)() );
       HS_HIP( hipStreamSynchronize(s->stream) );
    }
    memcpy(h.v.data(), s->hsc, (size_t) s->nsc * sizeof(double));
@@ -3073,6 +3080,31 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       return HS_OK;
    };
 
+   /* round 5: the X chain of the factorization phase (triangular inverse of the factor of X) does not depend on the termination
+    * scalars either: it is queued behind the kernel that publishes them and runs while the host waits, decides and launches (a
+    * solve that ends here has run it in vain: 0.1 ms at n = 500) */
+   bool xchain_queued = false;
+   const std::function<int()> enqueue_x_chains = [&]() -> int
+   {
+      if ( xchain_queued )
+         return HS_OK;
+      for (auto& B : s->blk)
+      {
+         const int n = B.n;
+         if ( n <= 64 )
+            continue;
+         if ( !factors_valid )
+         {
+            HS_CALL( hs_copy(st, B.Lx, B.X, (long long) n * n) );
+            HS_CALL( hs_potrf(st, n, B.Lx, B.dinvx, s->flags + 1, NULL) );
+         }
+         HS_CALL( hs_zero_upper(st, B.Lx, n) );
+         HS_CALL( hs_trtri(st, n, B.Lx, B.dinvx, B.LxInv, B.T1) );
+      }
+      xchain_queued = true;
+      return HS_OK;
+   };
+
    for (it = 0; it <= maxiter; ++it)
    {
       if ( !residuals_ready )
@@ -3086,7 +3118,7 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
             zchain_queued = true;
          }
          HS_CALL( enqueue_residuals() );
-         HS_CALL( read_scalars(s, hs, NULL) );
+         HS_CALL( read_scalars(s, hs, NULL, (zchain_queued && s->comm == NULL) ? &enqueue_x_chains : NULL) );
       }
       residuals_ready = false;
 
@@ -3281,7 +3313,9 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
          HS_CALL( gemm_on(st2, s->gws2, s->gws_len, HS_MC, HS_MC, n, n, n, 1.0, B.LzInv, n, B.LzInv, n, 0.0, B.Zinv, n, HS_GEMM_LOWER) );
          HS_CALL( hs_mirror_lower(st2, B.Zinv, n, n) );
          }
-         /* X chain on the first */
+         /* X chain on the first (already queued behind the read-back when the Z chain was started at the top of the iteration) */
+         if ( !xchain_queued )
+         {
          if ( !factors_valid )
          {
             HS_CALL( hs_copy(st, B.Lx, B.X, n2) );
@@ -3289,9 +3323,11 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
          }
          HS_CALL( hs_zero_upper(st, B.Lx, n) );
          HS_CALL( hs_trtri(st, n, B.Lx, B.dinvx, B.LxInv, B.T1) );
+         }
       }
       HS_CALL( join2(s) );
       zchain_queued = false;
+      xchain_queued = false;
 
       /* ---- Schur complement (extended by the constant matrix as "variable 0") */
       phase_mark(s, PH_SCHUR);
