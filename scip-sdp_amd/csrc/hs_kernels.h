@@ -388,5 +388,7 @@ struct hs_solve1_args
 int hs_solve1_fits(int m, int q, int nblk, const int* n);
 long long hs_solve1_ws_doubles(int m, int q, int nblk, const int* n);
 int hs_solve1_launch(hipStream_t st, const hs_solve1_args* a);
+int hs_solve1_class(const hs_solve1_args* a);
+int hs_solve1_debug_counts(unsigned int* out2);
 
 #endif

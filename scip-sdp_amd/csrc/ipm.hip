@@ -2592,6 +2592,7 @@ extern "C" int hipsdp_get_assembly_clock(hipsdp_solver* s, double* ghz)
 #define S1_SOL_OFF (HS_S1_OUT_DOUBLES + 8 + 16 * S1_HIST_MAX)       /* y (128), x (4096), z (4096) */
 #define S1_HOST_DOUBLES (S1_SOL_OFF + 128 + 2 * 4096)
 static long long g_solve1_solves = 0;      /* solves of this process that ran in the one launch (bench.py reports the share) */
+static long long g_solve1_fallbacks = 0;   /* ... that the kernel gave up on numerically and the general path solved again */
 static int solve1_try(hipsdp_solver* s, hipsdp_info* info, bool* done)
 {
    *done = false;
@@ -2725,6 +2726,20 @@ static int solve1_try(hipsdp_solver* s, hipsdp_info* info, bool* done)
    const int status = (int) o[0];
    if ( status == -2 )
       return HS_OK;                              /* declined: the general path takes the problem */
+   /* A numerical failure of the kernel on a cold start is not final: on 4 of 400 random shapes with cond(M) around 1e14
+    * one path gives up where the other converges (profiles/r04_c_solve1_fuzz.txt) - their last steps differ in how the solves with M
+    * are corrected.  The general path solves the problem again from its own start before the caller escalates its settings (a
+    * warm start is consumed by the kernel: its verdict stands).  HIPSDP_SOLVE1_NO_FALLBACK=1 keeps the kernel's failure. */
+   if ( status == HIPSDP_STATUS_NUMERIC && (int) o[12] == 0 )
+   {
+      const bool nofb = getenv("HIPSDP_SOLVE1_NO_FALLBACK") != NULL && getenv("HIPSDP_SOLVE1_NO_FALLBACK")[0] == '1';    /* (read at every solve, like the other switches of this path) */
+      if ( !nofb )
+      {
+         HS_HIP( hipStreamSynchronize(st) );     /* (the kernel may still be writing its last X and Z) */
+         (void) __sync_add_and_fetch(&g_solve1_fallbacks, 1);
+         return HS_OK;
+      }
+   }
    /* the result block, y, x and z are in pinned memory, published before the sequence word; X and Z in device memory are complete
     * when the kernel has retired - whoever reads them waits for the queue first (stage_sync), this call does not */
    s->stage_pending = true;
@@ -3848,9 +3863,21 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
    return HIPSDP_OK;
 }
 
+extern "C" long long hipsdp_solve1_fallbacks(void)
+{
+   return __sync_add_and_fetch(&g_solve1_fallbacks, 0);
+}
+
 extern "C" long long hipsdp_solve1_solves(void)
 {
    return __sync_add_and_fetch(&g_solve1_solves, 0);
+}
+
+extern "C" int hipsdp_solve1_debug_counts(unsigned int* counts2)
+{
+   if ( counts2 == NULL )
+      return 0;
+   return hs_solve1_debug_counts(counts2);
 }
 
 extern "C" int hipsdp_solve_path(hipsdp_solver* s)
