@@ -35,15 +35,31 @@ static int lapack_device(void)
  * HIPSDP_LAPACK_CUTOFF=<n> moves the eigen cutoff (0: always the device).  The stand-alone library has no host LAPACK to call:
  * there every size goes to the device. */
 #ifdef HIPSDP_WITH_SCIP
-#ifndef HIPSDP_LAPACK_INT
-#define HIPSDP_LAPACK_INT int
+/* Fortran name mangling and integer width exactly as the file this one replaces selects them (lapack_interface.c:50-70): F77_FUNC from
+ * SCIP-SDP's configf77.h, LAPACKINTTYPE = long long with -DLAPACKLONG, OpenBLAS' blasint with -DOPENBLAS, else int - an ILP64 BLAS
+ * linked with the flags SCIP-SDP is built with gets the integers it expects.  -DHIPSDP_LAPACK_INT=<type> overrides the width and a
+ * predefined F77_FUNC the mangling (tests/test_lapack_host_branch_cpu.py links scipy's OpenBLAS, whose symbols are scipy_dgemm_ ...). */
+#ifndef F77_FUNC
+#include "sdpi/configf77.h"
 #endif
+#ifdef HIPSDP_LAPACK_INT
 typedef HIPSDP_LAPACK_INT lint;
-extern void dsyevr_(char* jobz, char* range, char* uplo, lint* n, double* a, lint* lda, double* vl, double* vu, lint* il, lint* iu,
+#elif defined(LAPACKLONG)
+typedef long long int lint;
+#elif defined(OPENBLAS)
+#include <cblas.h>
+typedef blasint lint;
+#else
+typedef int lint;
+#endif
+#define hs_dsyevr F77_FUNC(dsyevr, DSYEVR)
+#define hs_dgemv  F77_FUNC(dgemv, DGEMV)
+#define hs_dgemm  F77_FUNC(dgemm, DGEMM)
+extern void hs_dsyevr(char* jobz, char* range, char* uplo, lint* n, double* a, lint* lda, double* vl, double* vu, lint* il, lint* iu,
    double* abstol, lint* m, double* w, double* z, lint* ldz, lint* isuppz, double* work, lint* lwork, lint* iwork, lint* liwork, lint* info);
-extern void dgemv_(char* trans, lint* m, lint* n, double* alpha, double* a, lint* lda, double* x, lint* incx, double* beta, double* y,
+extern void hs_dgemv(char* trans, lint* m, lint* n, double* alpha, double* a, lint* lda, double* x, lint* incx, double* beta, double* y,
    lint* incy);
-extern void dgemm_(char* transa, char* transb, lint* m, lint* n, lint* k, double* alpha, double* a, lint* lda, double* b, lint* ldb,
+extern void hs_dgemm(char* transa, char* transb, lint* m, lint* n, lint* k, double* alpha, double* a, lint* lda, double* b, lint* ldb,
    double* beta, double* c, lint* ldc);
 
 static int host_eigen_cutoff(void)
@@ -70,7 +86,7 @@ static SCIP_RETCODE host_syevr(int n, const SCIP_Real* A, int il, int iu, SCIP_R
    if ( rc == SCIP_OKAY )
    {
       memcpy(a, A, (size_t) n * (size_t) n * sizeof(double));
-      dsyevr_(&jobz, &range, &uplo, &N, a, &LDA, &vl, &vu, &IL, &IU, &abstol, &M, w, vectors, &LDZ, isuppz, &wq, &LWORK, &iwq, &LIWORK, &INFO);
+      hs_dsyevr(&jobz, &range, &uplo, &N, a, &LDA, &vl, &vu, &IL, &IU, &abstol, &M, w, vectors, &LDZ, isuppz, &wq, &LWORK, &iwq, &LIWORK, &INFO);
       LWORK = (lint) wq; LIWORK = iwq;
       work = (double*) malloc((size_t) (LWORK > 1 ? LWORK : 1) * sizeof(double));
       iwork = (lint*) malloc((size_t) (LIWORK > 1 ? LIWORK : 1) * sizeof(lint));
@@ -79,7 +95,7 @@ static SCIP_RETCODE host_syevr(int n, const SCIP_Real* A, int il, int iu, SCIP_R
    }
    if ( rc == SCIP_OKAY )
    {
-      dsyevr_(&jobz, &range, &uplo, &N, a, &LDA, &vl, &vu, &IL, &IU, &abstol, &M, w, vectors, &LDZ, isuppz, work, &LWORK, iwork, &LIWORK, &INFO);
+      hs_dsyevr(&jobz, &range, &uplo, &N, a, &LDA, &vl, &vu, &IL, &IU, &abstol, &M, w, vectors, &LDZ, isuppz, work, &LWORK, iwork, &LIWORK, &INFO);
       if ( INFO != 0 || M != (lint) (iu - il + 1) )
          rc = SCIP_ERROR;
       else
@@ -214,7 +230,7 @@ SCIP_RETCODE SCIPlapackMatrixVectorMult(int nrows, int ncols, SCIP_Real* matrix,
       char trans = 'N';
       lint M = nrows, N = ncols, one = 1;
       double alpha = 1.0, beta = 0.0;
-      dgemv_(&trans, &M, &N, &alpha, matrix, &M, vector, &one, &beta, result, &one);
+      hs_dgemv(&trans, &M, &N, &alpha, matrix, &M, vector, &one, &beta, result, &one);
       return SCIP_OKAY;
    }
 #endif
@@ -243,7 +259,7 @@ SCIP_RETCODE SCIPlapackMatrixMatrixMult(int nrowsA, int ncolsA, SCIP_Real* matri
       char ta = transposeA ? 'T' : 'N', tb = transposeB ? 'T' : 'N';
       lint m_ = M, n_ = N, k_ = K, lda = nrowsA, ldb = nrowsB, ldc = M;
       double alpha = 1.0, beta = 0.0;
-      dgemm_(&ta, &tb, &m_, &n_, &k_, &alpha, matrixA, &lda, matrixB, &ldb, &beta, result, &ldc);
+      hs_dgemm(&ta, &tb, &m_, &n_, &k_, &alpha, matrixA, &lda, matrixB, &ldb, &beta, result, &ldc);
       return SCIP_OKAY;
    }
 #endif

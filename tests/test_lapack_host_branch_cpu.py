@@ -1,0 +1,159 @@
+"""The branch of lapack_interface_hip.c that an integrator actually runs (missing #4): compiled inside SCIP-SDP
+(-DHIPSDP_WITH_SCIP) every SCIPlapack* eigen call with n <= 128, every matrix-vector product and every matrix-matrix product below
+1e8 flops goes to the host's DSYEVR / DGEMV / DGEMM - SCIP-SDP always links LAPACK, and a device round trip cannot win at the sizes
+cons_sdp.c calls these with (profiles/r04_d_lapack_small_sizes.txt).  Here that build is compiled against the
+REFERENCE's lapack_interface.h (with the test-only SCIP type stand-ins of tests/scip_stubs/), linked with scipy's bundled OpenBLAS
+(symbols scipy_dsyevr_ ... through the same F77_FUNC hook SCIP-SDP's configf77.h provides; LP64) and a stub libhipsdp whose device
+entry points fail, and the DSYEVR-semantics the callers rely on are executed through the seven symbols: i-th eigenvalue 1-based
+(lapack_interface.c:178-288), eigenvectors as ROWS, the negative range with its tolerance (:398-503), the full decomposition
+(:507-603), DGEMV (:607-650), DGEMM with the four transpose combinations and the vector of unittests/src/checklapack.c:80-119."""
+import ctypes as C
+import glob
+import os
+import subprocess
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/src"
+
+
+def _openblas():
+    try:
+        import scipy
+    except ImportError:
+        return None
+    g = glob.glob(os.path.join(os.path.dirname(scipy.__file__), "..", "scipy.libs", "libscipy_openblas*.so"))
+    return os.path.abspath(g[0]) if g else None
+
+
+@pytest.fixture(scope="module")
+def hostlib(tmp_path_factory):
+    if not os.path.exists(os.path.join(REF, "sdpi", "lapack_interface.h")):
+        pytest.skip("reference tree not present")
+    blas = _openblas()
+    if blas is None:
+        pytest.skip("no OpenBLAS with scipy_-prefixed LAPACK symbols in this image")
+    nm = subprocess.run(["nm", "-D", blas], stdout=subprocess.PIPE, text=True).stdout
+    for sym in ("scipy_dsyevr_", "scipy_dgemv_", "scipy_dgemm_"):
+        assert (" T " + sym + "\n") in nm, "symbol %s missing in %s" % (sym, blas)
+    out = str(tmp_path_factory.mktemp("hostlapack") / "liblapack_host_branch.so")
+    cmd = ["gcc", "-std=c99", "-O1", "-shared", "-fPIC", "-Wall", "-Werror=implicit-function-declaration", "-DHIPSDP_WITH_SCIP",
+           "-DF77_FUNC(name,NAME)=scipy_ ## name ## _", "-DHIPSDP_LAPACK_INT=int",
+           "-I" + os.path.join(ROOT, "tests", "scip_stubs"), "-I" + REF, "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "scip-sdp_amd", "src", "sdpi", "lapack_interface_hip.c"),
+           os.path.join(ROOT, "tests", "scip_stubs", "hipsdp_stub.c"), blas, "-Wl,-rpath," + os.path.dirname(blas), "-lm", "-o", out]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    assert "warning" not in r.stdout, r.stdout
+    return C.CDLL(out)
+
+
+def _pd(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _sym(n, seed):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((n, n))
+    return 0.5 * (A + A.T)
+
+
+SCIP_OKAY = 1
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 17, 64, 128])
+def test_ith_eigenvalue_is_one_based_and_the_vector_belongs_to_it(hostlib, n):
+    A = _sym(n, 100 + n)
+    lam = np.linalg.eigvalsh(A)
+    for i in sorted({1, (n + 1) // 2, n}):
+        val = C.c_double(0.0)
+        vec = np.zeros(n)
+        a = np.asfortranarray(A).reshape(-1, order="F").copy()
+        assert hostlib.SCIPlapackComputeIthEigenvalue(None, 1, n, _pd(a), i, C.byref(val), _pd(vec)) == SCIP_OKAY
+        assert abs(val.value - lam[i - 1]) <= 1e-12 * (1 + abs(lam).max())
+        assert abs(np.linalg.norm(vec) - 1.0) <= 1e-12
+        assert np.linalg.norm(A @ vec - val.value * vec) <= 1e-10 * (1 + abs(lam).max())
+        assert np.array_equal(a, np.asfortranarray(A).reshape(-1, order="F"))           # the caller's matrix is left alone
+        val2 = C.c_double(0.0)
+        assert hostlib.SCIPlapackComputeIthEigenvalueAlternative(None, 0, n, _pd(a), i, C.byref(val2), None) == SCIP_OKAY
+        assert val2.value == val.value
+    assert hostlib.hipsdp_stub_calls() == 0
+
+
+@pytest.mark.parametrize("n", [3, 10, 43, 128])
+def test_full_decomposition_ascending_with_eigenvectors_as_rows(hostlib, n):
+    A = _sym(n, 200 + n)
+    vals = np.zeros(n)
+    vecs = np.zeros(n * n)
+    a = A.reshape(-1).copy()
+    assert hostlib.SCIPlapackComputeEigenvectorDecomposition(None, n, _pd(a), _pd(vals), _pd(vecs)) == SCIP_OKAY
+    V = vecs.reshape(n, n)                       # row k = eigenvector k (lapack_interface.h:99-108)
+    assert np.all(np.diff(vals) >= 0)
+    assert np.max(np.abs(vals - np.linalg.eigvalsh(A))) <= 1e-12 * (1 + abs(vals).max())
+    assert np.max(np.abs(V @ V.T - np.eye(n))) <= 1e-12
+    assert np.max(np.abs(V.T @ np.diag(vals) @ V - A)) <= 1e-11 * (1 + abs(vals).max())
+    assert hostlib.hipsdp_stub_calls() == 0
+
+
+def test_negative_eigenpairs_up_to_the_tolerance(hostlib):
+    n = 12
+    rng = np.random.default_rng(7)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    lam = np.array([-3.0, -1.5, -1e-3, -1e-9, 0.0, 1e-9, 0.2, 0.5, 1.0, 2.0, 3.0, 4.0])
+    A = (Q * lam) @ Q.T
+    A = 0.5 * (A + A.T)
+    cnt = C.c_int(-1)
+    vals = np.zeros(n)
+    vecs = np.zeros(n * n)
+    tol = 1e-6
+    assert hostlib.SCIPlapackComputeEigenvectorsNegative(None, n, _pd(A.reshape(-1).copy()), C.c_double(tol), C.byref(cnt), _pd(vals), _pd(vecs)) == SCIP_OKAY
+    assert cnt.value == 3                        # -3, -1.5, -1e-3 lie at or below -tol; -1e-9 does not
+    assert np.max(np.abs(vals[:3] - lam[:3])) <= 1e-12
+    V = vecs.reshape(n, n)[:3]
+    for k in range(3):
+        assert np.linalg.norm(A @ V[k] - vals[k] * V[k]) <= 1e-11
+    assert hostlib.hipsdp_stub_calls() == 0
+
+
+def test_matrix_vector_product_of_a_column_major_matrix(hostlib):
+    rng = np.random.default_rng(3)
+    for (r, c) in [(1, 1), (4, 7), (50, 33)]:
+        M = rng.standard_normal((r, c))
+        x = rng.standard_normal(c)
+        y = np.zeros(r)
+        assert hostlib.SCIPlapackMatrixVectorMult(r, c, _pd(np.asfortranarray(M).reshape(-1, order="F").copy()), _pd(x), _pd(y)) == SCIP_OKAY
+        assert np.max(np.abs(y - M @ x)) <= 1e-13 * (1 + np.abs(M @ x).max())
+    assert hostlib.hipsdp_stub_calls() == 0
+
+
+def test_matrix_matrix_product_golden_vector_and_all_transpose_combinations(hostlib):
+    # unittests/src/checklapack.c:80-119: A = [1 3; 2 4], B^T with B = [5 7; 6 8] column-major -> C = [26 30; 38 44]
+    A = np.array([1.0, 2.0, 3.0, 4.0]); B = np.array([5.0, 6.0, 7.0, 8.0]); Cm = np.ones(4)
+    assert hostlib.SCIPlapackMatrixMatrixMult(2, 2, _pd(A), 0, 2, 2, _pd(B), 1, _pd(Cm)) == SCIP_OKAY
+    assert np.allclose(Cm, [26.0, 38.0, 30.0, 44.0], atol=1e-12)
+    rng = np.random.default_rng(4)
+    for ta in (0, 1):
+        for tb in (0, 1):
+            M, N, K = 5, 7, 4
+            Am = rng.standard_normal((K, M) if ta else (M, K))
+            Bm = rng.standard_normal((N, K) if tb else (K, N))
+            out = np.zeros(M * N)
+            assert hostlib.SCIPlapackMatrixMatrixMult(Am.shape[0], Am.shape[1], _pd(np.asfortranarray(Am).reshape(-1, order="F").copy()), ta,
+                                                      Bm.shape[0], Bm.shape[1], _pd(np.asfortranarray(Bm).reshape(-1, order="F").copy()), tb,
+                                                      _pd(out)) == SCIP_OKAY
+            ref = (Am.T if ta else Am) @ (Bm.T if tb else Bm)
+            assert np.max(np.abs(out.reshape(N, M).T - ref)) <= 1e-13 * (1 + np.abs(ref).max())
+    # inner dimensions that do not match are refused before any library is called
+    assert hostlib.SCIPlapackMatrixMatrixMult(2, 3, _pd(np.zeros(6)), 0, 2, 2, _pd(np.zeros(4)), 0, _pd(np.zeros(4))) != SCIP_OKAY
+    assert hostlib.hipsdp_stub_calls() == 0
+
+
+def test_sizes_above_the_cutoff_go_to_the_device(hostlib):
+    """n = 129 > the default cutoff of 128: the device entry point is called (the stub fails, the interface reports SCIP_ERROR)"""
+    n = 129
+    A = _sym(n, 9)
+    val = C.c_double(0.0)
+    before = hostlib.hipsdp_stub_calls()
+    assert hostlib.SCIPlapackComputeIthEigenvalue(None, 0, n, _pd(A.reshape(-1).copy()), 1, C.byref(val), None) != SCIP_OKAY
+    assert hostlib.hipsdp_stub_calls() == before + 1
