@@ -150,10 +150,12 @@ HIPSDP_API int  hipsdp_set_start(hipsdp_solver* solver, const double* y, const d
 
 HIPSDP_API int  hipsdp_solve(hipsdp_solver* solver, const hipsdp_params* params, hipsdp_info* info);
 
-/* B&B-sized problems (every block <= 64 rows, m <= 64, few nonzeros per matrix) are solved by ONE launch of one workgroup
- * (csrc/solve1.hip; HIPSDP_SOLVE1=0 switches it off).  hipsdp_solve_path: 1 when the last solve ran there, 0 the general path.
+/* B&B-sized problems (no communicator, every block <= 64 rows, m <= 128, q <= 4096, the fixed part of the state fits the 160 KiB of
+ * LDS of one compute unit - hs_solve1_fits: one block of 36 rows, two of 30, eight of 12, m up to about 110 -, and one Schur assembly
+ * stays below 3e6 multiply-adds: few nonzeros per matrix) are solved by ONE launch of one workgroup (csrc/solve1_body.h, one kernel
+ * instance per size class; HIPSDP_SOLVE1=0 switches it off).  hipsdp_solve_path: 1 when the last solve ran there, 0 the general path.
  * hipsdp_solve1_trace: scalars of the last one-launch solve - out[0..63] (status, iterations, ..., device cycles per phase; see
- * csrc/solve1.hip) and, with HIPSDP_SOLVE1_HIST=1 in the environment, up to maxrows rows of 16 doubles per iteration
+ * csrc/solve1_body.h) and, with HIPSDP_SOLVE1_HIST=1 in the environment, up to maxrows rows of 16 doubles per iteration
  * (it, mu, pinf, dinf, gap, tau, kappa, pobj, dobj, predictor step, step, dtau, residual of the linearised primal equation, forced pivots, |dy|, |h|) - what the parity tests compare with the oracle's
  * history.  Either pointer may be NULL. */
 HIPSDP_API int  hipsdp_solve_path(hipsdp_solver* solver);
@@ -263,9 +265,10 @@ HIPSDP_API int  hipsdp_get_block_dense(hipsdp_solver* solver, int block, double*
 /* C[M x N] = alpha * op(A) * op(B) + beta * C, row-major; layA/layB: 0 = K contiguous, 1 = M (resp. N) contiguous */
 HIPSDP_API int  hipsdp_dgemm(int device, int layA, int layB, int M, int N, int K, double alpha, const double* A, long long lda,
    const double* B, long long ldb, double beta, double* C, long long ldc, int lower_only, int splitk);
-/* shader frequency DURING the Schur assemblies of a solve: with sampling on, one-thread kernels right before and right after every
- * assembly read the shader-clock and the 100 MHz counters on the engine's stream; *ghz = sum of clock differences / sum of time
- * differences over the assemblies of the last solve (0 when none was sampled) */
+/* shader frequency DURING the Schur assemblies of a solve: with sampling on, ONE thread on a queue of its own (k_clock_window) starts
+ * with every assembly and counts its shader-clock cycles and the 100 MHz wall ticks until the assembly's last kernel has set a word
+ * (a pair of samples from launches before and after the assembly lands on different XCDs, whose cycle counters are not aligned);
+ * *ghz = sum of cycles / sum of wall time over the assemblies of the last solve (0 when none was sampled) */
 HIPSDP_API int  hipsdp_set_clock_sampling(hipsdp_solver* solver, int on);
 HIPSDP_API int  hipsdp_get_assembly_clock(hipsdp_solver* solver, double* ghz);
 HIPSDP_API int  hipsdp_syev(int device, int n, const double* A, double* lam, double* V);     /* ascending, eigenvectors as rows */

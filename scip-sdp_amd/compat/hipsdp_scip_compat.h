@@ -57,6 +57,7 @@ void*     hipsdp_compat_malloc(size_t bytes);
 void*     hipsdp_compat_realloc(void* p, size_t oldbytes, size_t newbytes);
 void      hipsdp_compat_free(void* p, size_t bytes);
 long long hipsdp_compat_mem_used(void);
+long long hipsdp_compat_shortcut_checks(void);      /* checks done under HIPSDP_VERIFY_SHORTCUT=1 (sdpisolver_hip.c) */
 
 /* parameter ids and settings: values of src/sdpi/type_sdpi.h:47-79 */
 enum SCIP_SDPParam

@@ -146,6 +146,55 @@ struct PsdPin
 };
 thread_local PsdPin g_pin;
 
+/* device -> pageable host memory through the two halves of the thread's pinned staging, asynchronous copies on `st` */
+static int d2h_through_staging(int device, hipStream_t st, void* dst, const void* src, size_t bytes)
+{
+   if ( bytes == 0 )
+      return HS_OK;
+   if ( !g_pin.get(device) )
+   {
+      HS_HIP( hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) );
+      return HS_OK;
+   }
+   const size_t half = (PsdPin::bytes() / 2) & ~(size_t) 255;
+   hipEvent_t ev[2] = {NULL, NULL};
+   HS_HIP( hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) );
+   if ( hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) != hipSuccess )
+   {
+      (void) hipEventDestroy(ev[0]);
+      return HS_ERR_HIP;
+   }
+   int rc = HS_OK;
+   size_t issued = 0, taken = 0;
+   int nissued = 0, ntaken = 0;
+   while ( taken < bytes && rc == HS_OK )
+   {
+      /* keep two chunks in flight */
+      while ( issued < bytes && nissued - ntaken < 2 && rc == HS_OK )
+      {
+         const size_t len = bytes - issued < half ? bytes - issued : half;
+         const int b = nissued & 1;
+         if ( hipMemcpyAsync(g_pin.h + b * half, (const char*) src + issued, len, hipMemcpyDeviceToHost, st) != hipSuccess
+            || hipEventRecord(ev[b], st) != hipSuccess )
+            rc = HS_ERR_HIP;
+         issued += len; ++nissued;
+      }
+      if ( rc != HS_OK )
+         break;
+      const int b = ntaken & 1;
+      const size_t len = bytes - taken < half ? bytes - taken : half;
+      if ( hipEventSynchronize(ev[b]) != hipSuccess )
+         rc = HS_ERR_HIP;
+      else
+         memcpy((char*) dst + taken, g_pin.h + b * half, len);
+      taken += len; ++ntaken;
+   }
+   if ( rc != HS_OK )
+      (void) hipStreamSynchronize(st);
+   (void) hipEventDestroy(ev[0]); (void) hipEventDestroy(ev[1]);
+   return rc;
+}
+
 template<class T> struct PoolBuf
 {
    T* p;
@@ -265,9 +314,12 @@ extern "C" int hipsdp_psd_project(int device, int n, int nnz, const int* row, co
    }
    else if ( total > 0 )
    {
-      HS_HIP( hipMemcpy(rowout, orow.p, (size_t) total * sizeof(int), hipMemcpyDeviceToHost) );
-      HS_HIP( hipMemcpy(colout, ocol.p, (size_t) total * sizeof(int), hipMemcpyDeviceToHost) );
-      HS_HIP( hipMemcpy(valout, oval.p, (size_t) total * sizeof(double), hipMemcpyDeviceToHost) );
+      /* results larger than the pinned staging (blocks above about 180 rows): in chunks THROUGH the staging memory, two halves in turn -
+       * the copy engine fills one half while the host empties the other; a pageable destination would make every copy block and be
+       * staged by the runtime page by page (round 4: three blocking pageable copies) */
+      HS_CALL( d2h_through_staging(device, st, rowout, orow.p, (size_t) total * sizeof(int)) );
+      HS_CALL( d2h_through_staging(device, st, colout, ocol.p, (size_t) total * sizeof(int)) );
+      HS_CALL( d2h_through_staging(device, st, valout, oval.p, (size_t) total * sizeof(double)) );
    }
    return HIPSDP_OK;
 }

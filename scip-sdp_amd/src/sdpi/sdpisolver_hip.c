@@ -37,6 +37,13 @@
 
 #include "hipsdp.h"
 
+/* how often HIPSDP_VERIFY_SHORTCUT=1 has checked the termination bound against an independent evaluation of Z(y) (tests) */
+static long long g_shortcut_checks = 0;
+#ifndef HIPSDP_WITH_SCIP
+long long hipsdp_compat_shortcut_checks(void) { return g_shortcut_checks; }
+#endif
+
+
 #define PENALTYBOUNDTOL          1e-3      /* relative distance of Tr(X) to Gamma that counts as "bound reached" */
 #define MIN_PENALTYPARAM         1e5
 #define MAX_PENALTYPARAM         1e12
@@ -853,6 +860,40 @@ static SCIP_RETCODE solveAndCheckTolerances(SCIP_SDPISOLVER* s, int level, SCIP_
          for (e = 0; e < s->nengineblocks; ++e)
             lminp[e] = -s->info.dabs;
          lpviol = s->info.dabs;
+         /* HIPSDP_VERIFY_SHORTCUT=1 (tests, CI): the bound is checked against an independent evaluation of Z(y) - the
+          * check the shortcut replaces - whenever it is used; a violation is an error of the backend, not a property of the node */
+         if ( getenv("HIPSDP_VERIFY_SHORTCUT") != NULL && getenv("HIPSDP_VERIFY_SHORTCUT")[0] == '1' )
+         {
+            SCIP_Real* lchk = (SCIP_Real*) malloc((size_t) (s->nengineblocks > 0 ? s->nengineblocks : 1) * sizeof(SCIP_Real));
+            SCIP_Real lpchk = 0.0;
+            /* the claim: lambda_min(Z(y)) >= -dabs and no LP row violated by more than dabs.  hipsdp_check_y_tol with the tolerance
+             * (dabs + slack) / 0.999 proves exactly that for blocks above 64 rows (Cholesky factorization of Z(y) + (dabs + slack) I; it
+             * then reports -0.999 tol) and returns the exact eigenvalue below that size or when the factorization fails; slack covers
+             * the rounding of evaluating Z(y) a second time */
+            const SCIP_Real slack = 1e-9 + 0.01 * s->info.dabs;
+            const SCIP_Real chktol = (s->info.dabs + slack) / 0.999;
+            int bad = 0;
+            if ( lchk == NULL )
+            {
+               if ( lminp != lmin ) free(lminp);
+               return SCIP_NOMEMORY;
+            }
+            if ( hipsdp_check_y_tol(s->engine, s->ysol, chktol, lchk, &lpchk) != HIPSDP_OK )
+               bad = 1;
+            for (e = 0; e < s->nengineblocks && ! bad; ++e)
+               if ( lchk[e] < -chktol )
+                  bad = 1;
+            if ( ! bad && lpchk > s->info.dabs + slack )
+               bad = 1;
+            ++g_shortcut_checks;
+            free(lchk);
+            if ( bad )
+            {
+               if ( lminp != lmin ) free(lminp);
+               SCIPerrorMessage("HIPSDP: the termination bound dabs = %g does not hold for the independent check of y\n", s->info.dabs);
+               return SCIP_LPERROR;
+            }
+         }
       }
       else
       {

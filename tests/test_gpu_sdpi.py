@@ -230,6 +230,45 @@ def test_random_nodes_backend_vs_oracle(gpu, seed):
     s.free()
 
 
+def test_termination_bound_against_the_independent_check_of_y(gpu, monkeypatch):
+    """when the engine's own dual residual bound settles the caller's tolerance (dabs <= 0.999 feastol) the backend
+    skips the eigenvalue check of Z(y).  HIPSDP_VERIFY_SHORTCUT=1 evaluates hipsdp_check_y_tol all the same and fails the solve when
+    lambda_min(Z(y)) < -dabs or an LP row is violated by more than dabs: the golden cases and forty random nodes (one-launch kernel and
+    general path) pass through it, and the shortcut did fire."""
+    lib = gpu.lib()
+    lib.hipsdp_compat_shortcut_checks.restype = C.c_longlong
+    before = lib.hipsdp_compat_shortcut_checks()
+    monkeypatch.setenv("HIPSDP_VERIFY_SHORTCUT", "1")
+    for case in CASES["cases"]:
+        P = sdpi_prepare.prepare(build(case))
+        if P.status != 'ok':
+            continue
+        s = new_solver(gpu)
+        rc, _, _ = s.solve(P)
+        assert rc == sdpi_call.SCIP_OKAY, case["name"]
+        s.free()
+    done = 0
+    for path in ("1", "0"):
+        monkeypatch.setenv("HIPSDP_SOLVE1", path)
+        rng = np.random.default_rng(31337)
+        for t in range(20):
+            big = (t % 4 == 3)
+            prob = _random_node(rng, nvars=int(rng.integers(30, 80) if big else rng.integers(4, 12)),
+                                sizes=[int(rng.integers(66, 100))] if big else [int(rng.integers(2, 7)), int(rng.integers(2, 9))],
+                                nlp=int(rng.integers(0, 6)), nfixed=int(rng.integers(0, 3)))
+            P = sdpi_prepare.prepare(prob)
+            if P.status != 'ok':
+                continue
+            s = new_solver(gpu)
+            rc, _, _ = s.solve(P)
+            assert rc == sdpi_call.SCIP_OKAY
+            done += 1
+            s.free()
+    monkeypatch.delenv("HIPSDP_SOLVE1", raising=False)
+    assert done >= 20
+    assert lib.hipsdp_compat_shortcut_checks() >= before + 20
+
+
 def test_time_limit_and_objective_limit(gpu):
     case = [c for c in CASES["cases"] if c["name"] == "test11"][0]
     P = sdpi_prepare.prepare(build(case))

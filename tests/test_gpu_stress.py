@@ -13,6 +13,11 @@ from stress_cases import rand_core
 pytestmark = pytest.mark.gpu
 
 
+# engine and oracle within ONE iteration of each other (was two); the problems on which the last iterates sit at the
+# tolerance and the two stop two iterations apart are listed by family and seed
+ITERATIONS_OFF_BY_TWO = set()
+
+
 def run(gpu, seed, monkeypatch, family):
     if family == "mid":
         monkeypatch.setenv("STRESS_BIG", "1")
@@ -32,7 +37,7 @@ def run(gpu, seed, monkeypatch, family):
     if info.status >= 4 and ref.status >= 4:
         return
     assert info.status == ref.status, tag
-    assert abs(info.iterations - ref.iterations) <= 2, tag
+    assert abs(info.iterations - ref.iterations) <= (2 if (family, seed) in ITERATIONS_OFF_BY_TWO else 1), tag
     if ref.status == ipm_ref.STATUS_OPTIMAL:
         assert abs(info.dobj - ref.dobj) <= 1e-5 * (1 + abs(ref.dobj)), tag
         # (y is unique only while the variables do not outnumber the dimensions of the matrix space)
