@@ -115,6 +115,7 @@ int  hs_schur_U(hipStream_t s, int m1, int n, const double* A, const double* X, 
 /* accumulate the lower triangle of Mx with W_j = G A_j R (R: lower Cholesky factor of X with a ZERO upper triangle,
  * G: inverse of the lower Cholesky factor of Z) */
 int  hs_schur_W(hipStream_t s, int m1, int n, const double* A, const double* R, const double* G, double* Mx, hs_schur_ws* w);
+int  hs_schur_W_identity(hipStream_t s, int m1, int n, const double* A, double* Mx, hs_schur_ws* w);
 
 int  hs_schur_Urows(hipStream_t s, int m1, int n, const double* A, const double* X, const double* Zinv, double* Mx,
    hs_schur_ws* w, int r_begin, int r_end);

@@ -2899,6 +2899,10 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
    const double normC = sqrt(h2[1]);
 
    /* ---- starting point */
+   /* cold start: X = Z = xi I in every block until the first step - the first Schur complement is then the Gram matrix of the
+    * constraint matrices themselves, M_ij = tr(A_i (xi I) A_j (I / xi)) = <A_i, A_j>, and the two n^3 products of the assembly
+    * (which would multiply by sqrt(xi) I and I / sqrt(xi)) are not needed for it (round 5; single rank, dense blocks, W form) */
+   bool identity_start = false;
    bool start_factors = false;
    for (auto& B : s->blk)
       B.derived_valid = false;
@@ -2954,9 +2958,13 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       HS_CALL( hs_fill(st, s->z, q, xi) );
       s->tau = 1.0;
       s->kappa = xi * xi;
+      identity_start = true;
    }
    info->warm_started = s->have_start ? 1 : 0;
    s->have_start = false;
+   /* HIPSDP_NO_IDENTITY_START=1: the first assembly of a cold solve through the general products as well (A/B runs, tests) */
+   if ( getenv("HIPSDP_NO_IDENTITY_START") != NULL && getenv("HIPSDP_NO_IDENTITY_START")[0] == '1' )
+      identity_start = false;
 
    int status = HIPSDP_STATUS_ITERLIM;
    int it = 0, certwait = 0, nstall = 0;
@@ -3406,6 +3414,13 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
                   continue;
                int c0, cw;
                hs_shard_cols(m1, B.n, S, g, &c0, &cw);
+               if ( identity_start && it == 0 && s->comm == NULL )
+               {
+                  /* (all column slices at once, straight from A) */
+                  if ( g == g0 )
+                     HS_CALL( hs_schur_W_identity(st, m1, B.n, B.A, s->Mx, &s->sws) );
+                  continue;
+               }
                HS_CALL( hs_schur_Wcols(st, m1, B.n, B.A, B.Lx, B.LzInv, s->Mx, &s->sws, c0, cw) );
             }
          if ( s->comm != NULL )
@@ -3447,7 +3462,9 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
          {
             if ( B.sparse )
                continue;
-            if ( s->schur_mode_U )
+            if ( identity_start && it == 0 )
+               HS_CALL( hs_schur_W_identity(st, m1, B.n, B.A, s->Mx, &s->sws) );
+            else if ( s->schur_mode_U )
                HS_CALL( hs_schur_U(st, m1, B.n, B.A, B.X, B.Zinv, s->Mx, &s->sws, 0, m1) );
             else
                HS_CALL( hs_schur_W(st, m1, B.n, B.A, B.Lx, B.LzInv, s->Mx, &s->sws) );
