@@ -116,6 +116,7 @@ int  hs_schur_U(hipStream_t s, int m1, int n, const double* A, const double* X, 
  * G: inverse of the lower Cholesky factor of Z) */
 int  hs_schur_W(hipStream_t s, int m1, int n, const double* A, const double* R, const double* G, double* Mx, hs_schur_ws* w);
 int  hs_schur_W_identity(hipStream_t s, int m1, int n, const double* A, double* Mx, hs_schur_ws* w);
+int  hs_schur_W_identity_range(hipStream_t s, int m1, int n, const double* A, long long k0, long long k1, double* Mx, hs_schur_ws* w);
 
 int  hs_schur_Urows(hipStream_t s, int m1, int n, const double* A, const double* X, const double* Zinv, double* Mx,
    hs_schur_ws* w, int r_begin, int r_end);

@@ -3354,6 +3354,7 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
 
       /* ---- Schur complement (extended by the constant matrix as "variable 0") */
       phase_mark(s, PH_SCHUR);
+      bool gram_only_used = false;
       hs_comm_phase(0);
       const bool clk_this = s->clk_on && s->clk_buf != NULL && s->clk_stream != NULL && s->clk_n < CLK_MAX_ASSEMBLIES;
       HS_HIP( hipEventRecord(s->ev0, st) );
@@ -3414,11 +3415,18 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
                   continue;
                int c0, cw;
                hs_shard_cols(m1, B.n, S, g, &c0, &cw);
-               if ( identity_start && it == 0 && s->comm == NULL )
+               if ( identity_start && it == 0 )
                {
-                  /* (all column slices at once, straight from A) */
+                  /* (all column slices of this rank at once, straight from A; several ranks: the n^2 entries of the matrices in equal
+                   * ranges, the partial Gram matrices are summed below like the slices' ones) */
                   if ( g == g0 )
-                     HS_CALL( hs_schur_W_identity(st, m1, B.n, B.A, s->Mx, &s->sws) );
+                  {
+                     const long long n2 = (long long) B.n * B.n;
+                     const int G = s->comm != NULL ? s->nranks : 1, r = s->comm != NULL ? s->rank : 0;
+                     const long long k0 = ((n2 * r / G) / 8) * 8, k1 = r == G - 1 ? n2 : ((n2 * (r + 1) / G) / 8) * 8;
+                     HS_CALL( hs_schur_W_identity_range(st, m1, B.n, B.A, k0, k1, s->Mx, &s->sws) );
+                  }
+                  gram_only_used = true;
                   continue;
                }
                HS_CALL( hs_schur_Wcols(st, m1, B.n, B.A, B.Lx, B.LzInv, s->Mx, &s->sws, c0, cw) );
@@ -3463,7 +3471,10 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
             if ( B.sparse )
                continue;
             if ( identity_start && it == 0 )
+            {
                HS_CALL( hs_schur_W_identity(st, m1, B.n, B.A, s->Mx, &s->sws) );
+               gram_only_used = true;
+            }
             else if ( s->schur_mode_U )
                HS_CALL( hs_schur_U(st, m1, B.n, B.A, B.X, B.Zinv, s->Mx, &s->sws, 0, m1) );
             else
@@ -3622,8 +3633,10 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
          if ( hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess )
             schur_ms += ms;
          info->schur_calls++;
+         /* (the assembly at the cold start is the Gram product alone: the count of SURVEY.md 8(d) without its n^3 part) */
+         const bool gram_only = gram_only_used;
          for (auto& B : s->blk)
-            info->schur_flops += 4.0 * m1 * (double) B.n * B.n * B.n + (double) m1 * m1 * (double) B.n * B.n;
+            info->schur_flops += (gram_only && !B.sparse ? 0.0 : 4.0 * m1 * (double) B.n * B.n * B.n) + (double) m1 * m1 * (double) B.n * B.n;
       }
       if ( hflags[0] != 0 || hflags[1] != 0 || hflags[2] != 0 )
       {

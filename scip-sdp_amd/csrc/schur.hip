@@ -140,33 +140,41 @@ static int hs_syrk_min_m1(void)
 
 /* The same assembly at the cold start X = Z = xi I: M_ij = tr(A_i X A_j Z^-1) = <A_i, A_j>, i.e. the Gram matrix of the rows of A itself - the
  * two n^3 products would multiply by sqrt(xi) I and by I / sqrt(xi).  Mx += A A^T on the lower tiles, no workspace but the slabs. */
-int hs_schur_W_identity(hipStream_t s, int m1, int n, const double* A, double* Mx, hs_schur_ws* w)
+int hs_schur_W_identity_range(hipStream_t s, int m1, int n, const double* A, long long k0, long long k1, double* Mx, hs_schur_ws* w)
 {
    const long long n2 = (long long) n * n;
-   if ( n2 > 2000000000LL )
+   const long long K = k1 - k0;
+   if ( n2 > 2000000000LL || k0 < 0 || k1 > n2 || (k0 & 1) )
       return HS_ERR_ARG;
+   if ( K <= 0 )
+      return HS_OK;
    {
       int done = 0;
-      HS_CALL( schur_gram(s, m1, n2, A, n2, Mx, w, &done) );
+      HS_CALL( schur_gram(s, m1, K, A + k0, n2, Mx, w, &done) );
       if ( done )
          return HS_OK;
    }
    int flags = HS_GEMM_LOWER;
    int sk;
-   if ( m1 >= hs_syrk_min_m1() && n2 >= 16384 && (n2 >= 50000 || m1 >= 900) )
+   if ( m1 >= hs_syrk_min_m1() && K >= 16384 && (K >= 50000 || m1 >= 900) )
    {
       const long long tm = (m1 + 127) / 128;
-      sk = hs_dgemm_pick_xcd_slices(tm * (tm + 1) / 2, n2);
+      sk = hs_dgemm_pick_xcd_slices(tm * (tm + 1) / 2, K);
       while ( sk > 2 && (long long) sk * m1 * m1 > w->kws_len ) --sk;
       flags |= HS_GEMM_XCD | HS_GEMM_NOFAST;
    }
    else
    {
-      sk = hs_dgemm_pick_splitk(m1, m1, (int) n2, 1);
+      sk = hs_dgemm_pick_splitk(m1, m1, (int) K, 1);
       while ( sk > 1 && (long long) sk * m1 * m1 > w->kws_len ) --sk;
    }
-   hs_gemm_args g3 = {m1, m1, (int) n2, HS_KC, HS_KC, A, n2, 0, A, n2, 0, Mx, m1, 0, 1.0, 1.0, 1, flags, sk, w->K};
+   hs_gemm_args g3 = {m1, m1, (int) K, HS_KC, HS_KC, A + k0, n2, 0, A + k0, n2, 0, Mx, m1, 0, 1.0, 1.0, 1, flags, sk, w->K};
    return hs_dgemm(s, &g3);
+}
+
+int hs_schur_W_identity(hipStream_t s, int m1, int n, const double* A, double* Mx, hs_schur_ws* w)
+{
+   return hs_schur_W_identity_range(s, m1, n, A, 0, (long long) n * n, Mx, w);
 }
 
 int hs_schur_W(hipStream_t s, int m1, int n, const double* A, const double* R, const double* G, double* Mx, hs_schur_ws* w)
