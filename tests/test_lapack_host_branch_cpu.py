@@ -42,7 +42,7 @@ def hostlib(tmp_path_factory):
            "-DF77_FUNC(name,NAME)=scipy_ ## name ## _", "-DHIPSDP_LAPACK_INT=int",
            "-I" + os.path.join(ROOT, "tests", "scip_stubs"), "-I" + REF, "-I" + os.path.join(ROOT, "include"),
            os.path.join(ROOT, "scip-sdp_amd", "src", "sdpi", "lapack_interface_hip.c"),
-           os.path.join(ROOT, "tests", "scip_stubs", "hipsdp_stub.c"), blas, "-Wl,-rpath," + os.path.dirname(blas), "-lm", "-o", out]
+           os.path.join(ROOT, "tests", "scip_stubs", "hipsdp_stub.c"), blas, "-Wl,-rpath," + os.path.dirname(blas), "-Wl,-Bsymbolic", "-lm", "-o", out]   # (-Bsymbolic: calls between the seven symbols stay inside this library even when libhipsdp_sdpi.so is loaded globally by another test)
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout
     assert "warning" not in r.stdout, r.stdout
