@@ -91,6 +91,41 @@ def test_engine_matches_oracle_on_planted_blocks(gpu, n, m):
     assert abs(g["info"].dobj - b @ ys) <= TOL * (1 + abs(b @ ys))
 
 
+@pytest.mark.parametrize("n,m,two_blocks", [(100, 200, False), (150, 320, False), (96, 260, True)])
+def test_first_assembly_of_a_cold_solve_is_the_gram_matrix_of_the_constraint_matrices(gpu, monkeypatch, n, m, two_blocks):
+    """At the cold start X = Z = xi I the Schur complement is M_ij = tr(A_i X A_j Z^-1) = <A_i, A_j>: the engine's first assembly runs the
+    Gram product on the rows of A alone (csrc/schur.hip: hs_schur_W_identity) instead of multiplying by sqrt(xi) I and I / sqrt(xi)
+    first.  With HIPSDP_NO_IDENTITY_START=1 the same solve takes the general products in that iteration too: the same iteration
+    count, the same objective and y to rounding - and both agree with the oracle, which knows nothing of the shortcut."""
+    b, A, ys, Xs, Zs = instances.planted_dense(n, m)
+    blocks = [A]
+    if two_blocks:
+        # a second dense block that keeps the problem strictly feasible on both sides: Z_2(y*) = Zs2 > 0, X_2 = I
+        rng = np.random.default_rng(11)
+        n2 = 70
+        A2 = rng.standard_normal((m + 1, n2, n2)) / np.sqrt(2.0 * n2)
+        A2 = A2 + A2.transpose(0, 2, 1)
+        Zs2 = rng.standard_normal((n2, n2)); Zs2 = Zs2 @ Zs2.T / n2 + 0.5 * np.eye(n2)
+        A2[0] = np.tensordot(ys, A2[1:], axes=(0, 0)) - Zs2
+        blocks.append(A2)
+        b = b + np.array([np.trace(A2[i]) for i in range(1, m + 1)])
+    core = ipm_ref.CoreProblem(b, blocks)
+    monkeypatch.delenv("HIPSDP_NO_IDENTITY_START", raising=False)
+    g1 = gpu_solve(gpu, core, gaptol=1e-6, feastol=1e-6)
+    monkeypatch.setenv("HIPSDP_NO_IDENTITY_START", "1")
+    g2 = gpu_solve(gpu, core, gaptol=1e-6, feastol=1e-6)
+    monkeypatch.delenv("HIPSDP_NO_IDENTITY_START", raising=False)
+    assert g1["info"].status == 0 and g2["info"].status == 0
+    assert g1["info"].iterations == g2["info"].iterations
+    assert abs(g1["info"].dobj - g2["info"].dobj) <= 1e-11 * (1 + abs(g2["info"].dobj))
+    assert np.max(np.abs(g1["y"] - g2["y"])) <= 1e-9 * (1 + np.max(np.abs(g2["y"])))
+    # the first assembly executes the Gram product only: fewer matrix-core flops than with the two n^3 products
+    assert g1["info"].schur_flops_executed < g2["info"].schur_flops_executed
+    ref = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-6, feastol=1e-6))
+    assert ref.status == 0 and ref.iterations == g1["info"].iterations
+    assert np.max(np.abs(g1["y"] - ref.y)) <= 1e-6
+
+
 def test_multi_block_with_lp_rows_and_bounds(gpu):
     rng = np.random.default_rng(7)
     m = 12
