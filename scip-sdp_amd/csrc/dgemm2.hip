@@ -561,6 +561,10 @@ __global__ void __launch_bounds__(256, G2_WGPC) hs_dgemm2_kernel(hs_gemm_args p,
  * Everything else as above: persistent workgroups, XCD-contiguous interleaved items, LDS-DMA ring of 4 slots, counted waits,
  * two halves per (double) stage with the next half's fragment reads and the ring's DMA between the matrix instructions. */
 #define G5_NS 4
+/* private bits of hs_gemm_args.flags, set by the launcher only */
+#define G5_F_NT    (1 << 30)               /* result tiles are stored non-temporally */
+#define G5_F_SETS  (1 << 29)               /* list order: g5_decode_sets */
+#define G5_F_PAIRS (1 << 28)               /* list entries are taken two at a time */
 #ifndef G5_DESC
 #define G5_DESC 1
 #endif
@@ -632,6 +636,66 @@ __device__ __forceinline__ bool g5_decode(const hs_gemm_args& p, long long idx, 
    return ok;
 }
 
+/* The same list in SETS (G5_F_SETS): the small triangular operand (n x n: R or G) is read by every item and the large one is
+ * streamed, so what the 64 workgroups of an XCD hold in its 4 MB L2 decides how often either is fetched again.  nv panels of the
+ * small operand (column tiles for TRI = 1, row tiles for TRI = 2), ranked by K length (rank 0 the longest): set k = the ranks
+ * {2k, nv - 1 - 2k, 2k + 1, nv - 2 - 2k} - two long/short pairs, at most about half of the small operand (2.2 of 4.5 MB at
+ * n = 1000).  The XCD's list (whole groups of the natural order: Tx is a multiple of G) is walked set by set; inside a set the
+ * four items that share a panel of the streamed operand (same row tile / same batch entry and column tile) are consecutive
+ * entries, taken by four workgroups within a few microseconds.  The last entries of the list by decreasing K length as above. */
+template<int TRI>
+__device__ __forceinline__ bool g5_decode_sets(long long idx, long long base, long long Tx, int tm, int tn, long long ntile, int tailwant,
+   int* om0, int* on0, int* obz)
+{
+   const bool ok = idx < Tx;
+   if ( !ok )
+      idx = 0;
+   const int nv = TRI == 1 ? tn : tm;
+   const long long U = TRI == 1 ? Tx / tn : (Tx / ntile) * tn;       /* panels of the streamed operand in this list */
+   const int nset = (nv + 3) >> 2;
+   const int szl = nv - 4 * (nset - 1);                             /* members of the last set */
+   long long ngt = tailwant / szl;
+   if ( ngt > U ) ngt = U;
+   const long long tstart = Tx - ngt * szl;
+   long long g;
+   int r;
+   if ( idx >= tstart )
+   {
+      /* tail: class by class (rank ascending = K length descending) over the last ngt panels of the last set */
+      const long long q = idx - tstart;
+      const int cl = (int) (q / ngt);
+      g = U - ngt + (q - (long long) cl * ngt);
+      const int k = nset - 1;
+      r = cl < ((szl + 1) >> 1) ? 2 * k + cl : nv - 1 - 2 * k - (szl - 1 - cl);
+   }
+   else
+   {
+      const int k = (int) (idx / (4 * U));
+      const long long rem = idx - 4 * U * k;
+      const int sz = nv - 4 * k < 4 ? nv - 4 * k : 4;
+      g = rem / sz;
+      const int j = (int) (rem - g * sz);
+      const int q = 2 * k + (j >> 1);
+      r = (j & 1) ? nv - 1 - q : q;
+   }
+   long long pos;
+   if ( TRI == 1 )
+      pos = base + g * tn + r;
+   else
+   {
+      const long long bl = g / tn;
+      const int tj = (int) (g - bl * tn);
+      pos = base + bl * ntile + (long long) (nv - 1 - r) * tn + tj;
+   }
+   const long long bz = pos / ntile;
+   const int t = (int) (pos - bz * ntile);
+   const int ti = t / tn, tj = t - ti * tn;
+   *om0 = ok ? ti * G2_BT : 0;
+   *on0 = ok ? tj * G2_BT : 0;
+   *obz = ok ? (int) bz : 0;
+   return ok;
+}
+
 #define G5_UNI(x) __builtin_amdgcn_readfirstlane(x)        /* wave-uniform by construction: keep it in a scalar register */
 
 template<int LB, int TRI>
@@ -646,7 +710,13 @@ __global__ void __launch_bounds__(256, 2) hs_dgemm5_kernel(hs_gemm_args p, long 
 
    const int xcd = blockIdx.x & 7;
    const int Wx = gridDim.x >> 3;
-   const long long T8 = (total + 7) / 8;
+   const bool sets = (p.flags & G5_F_SETS) != 0;
+   long long T8 = (total + 7) / 8;
+   if ( sets )
+   {
+      const long long G = TRI == 1 ? (long long) tn : ntile;       /* whole groups per XCD (total is a multiple of G) */
+      T8 = ((T8 + G - 1) / G) * G;
+   }
    const long long base = (long long) xcd * T8;
    const long long Tx = base >= total ? 0 : (base + T8 > total ? total - base : T8);
    const int tailwant = 3 * Wx;
@@ -667,7 +737,8 @@ __global__ void __launch_bounds__(256, 2) hs_dgemm5_kernel(hs_gemm_args p, long 
       int dm0 = 0, dn0 = 0, dbz = 0;
       /* (past the end of the list: item (0, 0, 0) with an empty K range - every request then reads the zero constant - and a stage
        * count that is never reached; no early return: the compiler then keeps the state behind it in scratch memory) */
-      nvalid = g5_decode<TRI>(p, idx, base, Tx, tm, tn, ntile, tailwant, &dm0, &dn0, &dbz);
+      nvalid = sets ? g5_decode_sets<TRI>(idx, base, Tx, tm, tn, ntile, tailwant, &dm0, &dn0, &dbz)
+         : g5_decode<TRI>(p, idx, base, Tx, tm, tn, ntile, tailwant, &dm0, &dn0, &dbz);
       nm0 = G5_UNI(dm0); nn0 = G5_UNI(dn0); nbz = G5_UNI(dbz);
       const double* A = p.A + (long long) nbz * p.strideA;
       const double* B = p.B + (long long) nbz * p.strideB;
@@ -774,6 +845,8 @@ __global__ void __launch_bounds__(256, 2) hs_dgemm5_kernel(hs_gemm_args p, long 
    bool cvalid = false;
    int cnfull = 0;
    int gi = 0;                            /* number of the consumer's item among those this workgroup has taken */
+   const bool pairs = (p.flags & G5_F_PAIRS) != 0;      /* list entries are taken two at a time (a long and a short item: equal work) */
+   unsigned int lastq = 0;
 
    v4d2 acc[NI][NJ];
 #pragma unroll
@@ -885,7 +958,20 @@ __global__ void __launch_bounds__(256, 2) hs_dgemm5_kernel(hs_gemm_args p, long 
       {
          /* interior tile, nothing to add to: one address per row of four-row groups, the columns as immediate offsets */
          double* c0 = C + (long long) row0 * ldc + col0;
-         if ( alpha == 1.0 )
+         if ( p.flags & G5_F_NT )
+         {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+               for (int r = 0; r < 4; ++r)
+               {
+                  double* cr = c0 + (long long) (16 * i + 4 * r) * ldc;
+#pragma unroll
+                  for (int j = 0; j < NJ; ++j)
+                     __builtin_nontemporal_store(alpha * acc[i][j][r], cr + 16 * j);
+               }
+         }
+         else if ( alpha == 1.0 )
          {
 #pragma unroll
             for (int i = 0; i < NI; ++i)
@@ -1073,7 +1159,10 @@ __global__ void __launch_bounds__(256, 2) hs_dgemm5_kernel(hs_gemm_args p, long 
             /* (everything requested so far, and the atomic of the previous double stage) */
             g2_wait_vm<0>();
             if ( wave == 0 && lane == 0 )
+            {
                g5_q[(gi + 2) & 3] = taken;
+               lastq = taken;
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
          }
          else if ( d < 7 )
@@ -1123,7 +1212,14 @@ __global__ void __launch_bounds__(256, 2) hs_dgemm5_kernel(hs_gemm_args p, long 
             stage_end();
             /* one thread takes the list entry of the item after the next; the value is collected at the next double stage's wait */
             if ( d == 0 && wave == 0 && lane == 0 )
-               taken = atomicAdd(ctr + xcd, 1u);
+            {
+               if ( !pairs )
+                  taken = atomicAdd(ctr + xcd, 1u);
+               else if ( (gi & 1) == 0 )
+                  taken = atomicAdd(ctr + xcd, 2u);
+               else
+                  taken = lastq + 1;
+            }
             if ( d < 7 )
             {
                read_frags(l0, nlo, 0, nlt0, nlt1);
@@ -1157,8 +1253,8 @@ __global__ void __launch_bounds__(256, 2) hs_dgemm5_kernel(hs_gemm_args p, long 
    /* ---- prologue: the workgroup takes its first two list entries; the first item into cur, four stages requested */
    if ( tid == 0 )
    {
-      const unsigned int e0 = atomicAdd(ctr + xcd, 1u);
-      const unsigned int e1 = atomicAdd(ctr + xcd, 1u);
+      const unsigned int e0 = atomicAdd(ctr + xcd, pairs ? 2u : 1u);
+      const unsigned int e1 = pairs ? e0 + 1 : atomicAdd(ctr + xcd, 1u);
       g5_q[0] = e0;
       g5_q[1] = e1;
    }
@@ -1346,11 +1442,20 @@ int hs_dgemm2_try(hipStream_t stream, const hs_gemm_args* a, int kchunk)
       unsigned int* ctr = g5_counters(stream);
       if ( ctr == NULL || hipMemsetAsync(ctr, 0, 64, stream) != hipSuccess )
          return -HS_ERR_HIP;
+      /* list order and store policy (HIPSDP_GEMM_ORDER=0: the natural order, entries taken one by one, plain stores - round 5's
+       * first form): entries in sets of the small operand's panels, taken two at a time, result tiles stored non-temporally.  The
+       * same products per tile either way: only which workgroup computes a tile, and when, changes */
+      hs_gemm_args a5 = *a;
+      {
+         static const int order = getenv("HIPSDP_GEMM_ORDER") != NULL ? atoi(getenv("HIPSDP_GEMM_ORDER")) : 1;
+         if ( order )
+            a5.flags |= G5_F_NT | G5_F_SETS | G5_F_PAIRS;
+      }
       switch ( inst5 )
       {
-      case 0: hipLaunchKernelGGL((hs_dgemm5_kernel<HS_MC, 1>), dim3(grid), dim3(256), smem5, stream, *a, ntile, total, ctr); break;
-      case 1: hipLaunchKernelGGL((hs_dgemm5_kernel<HS_MC, 2>), dim3(grid), dim3(256), smem5, stream, *a, ntile, total, ctr); break;
-      default: hipLaunchKernelGGL((hs_dgemm5_kernel<HS_KC, 2>), dim3(grid), dim3(256), smem5, stream, *a, ntile, total, ctr); break;
+      case 0: hipLaunchKernelGGL((hs_dgemm5_kernel<HS_MC, 1>), dim3(grid), dim3(256), smem5, stream, a5, ntile, total, ctr); break;
+      case 1: hipLaunchKernelGGL((hs_dgemm5_kernel<HS_MC, 2>), dim3(grid), dim3(256), smem5, stream, a5, ntile, total, ctr); break;
+      default: hipLaunchKernelGGL((hs_dgemm5_kernel<HS_KC, 2>), dim3(grid), dim3(256), smem5, stream, a5, ntile, total, ctr); break;
       }
       if ( hipGetLastError() != hipSuccess )
          return -HS_ERR_HIP;

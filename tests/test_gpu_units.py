@@ -335,6 +335,17 @@ def test_persistent_gemm_matches_tile_gemm_bitwise(gpu, M, N, K, layB, batch, sp
     (1000, 1000, 1000, 1, 16, GEMM_A_LOWTRI | GEMM_REMAP, 1.0, 0.0),    # eight row tiles per matrix: up to 112 full stages in front of the band
     (362, 362, 362, 1, 160, GEMM_A_LOWTRI | GEMM_REMAP, 1.0, 0.0),      # three row tiles, the last 106 rows: band cut by K
     (6000, 130, 130, 1, 6, GEMM_B_LOWTRI, 1.0, 0.0),                    # batched right-triangular product, second column tile 2 wide
+    # the list order in sets of four panels of the triangular operand (g5_decode_sets): 5, 6, 7 and 9 panels leave last sets of 1, 2, 3, 1
+    (20000, 640, 640, 1, 1, GEMM_B_LOWTRI, 1.0, 0.0),
+    (20000, 700, 700, 1, 1, GEMM_B_LOWTRI, 1.0, 0.0),
+    (20000, 896, 896, 1, 1, GEMM_B_LOWTRI, 1.0, 0.0),
+    (12000, 1100, 1100, 1, 1, GEMM_B_LOWTRI, 1.0, 0.0),
+    (640, 640, 640, 1, 24, GEMM_A_LOWTRI | GEMM_REMAP, 1.0, 0.0),
+    (760, 760, 760, 1, 16, GEMM_A_LOWTRI | GEMM_REMAP, 1.0, 0.0),
+    (896, 896, 896, 1, 12, GEMM_A_LOWTRI | GEMM_REMAP, 1.0, 0.0),
+    (1100, 1100, 1100, 1, 9, GEMM_A_LOWTRI | GEMM_REMAP, 1.0, 0.0),
+    (100, 100, 100, 1, 500, GEMM_A_LOWTRI | GEMM_REMAP, 1.0, 0.0),      # one panel
+    (250, 250, 250, 1, 120, GEMM_A_LOWTRI | GEMM_REMAP, 1.0, 0.0),      # two panels, lists shorter than the re-ordered tail
 ])
 def test_paired_band_gemm_matches_tile_gemm(gpu, M, N, K, layB, batch, flags, alpha, beta):
     """the two triangular n^3 products through the paired-band kernel (csrc/dgemm2.hip: hs_dgemm5_kernel - double stages (d, 15 - d)
