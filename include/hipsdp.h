@@ -150,8 +150,8 @@ HIPSDP_API int  hipsdp_set_start(hipsdp_solver* solver, const double* y, const d
 
 HIPSDP_API int  hipsdp_solve(hipsdp_solver* solver, const hipsdp_params* params, hipsdp_info* info);
 
-/* B&B-sized problems (no communicator, every block <= 64 rows, m <= 128, q <= 4096, the fixed part of the state fits the 160 KiB of
- * LDS of one compute unit - hs_solve1_fits: one block of 36 rows, two of 30, eight of 12, m up to about 110 -, and one Schur assembly
+/* B&B-sized problems (no communicator, every block <= 64 rows, m <= 108 (HIPSDP_SOLVE1_MAXM; 128 fit), q <= 4096, the fixed part of the state fits the 160 KiB of
+ * LDS of one compute unit - hs_solve1_fits: one block of 36 rows, two of 30, eight of 12 -, and one Schur assembly
  * stays below 3e6 multiply-adds: few nonzeros per matrix) are solved by ONE launch of one workgroup (csrc/solve1_body.h, one kernel
  * instance per size class; HIPSDP_SOLVE1=0 switches it off).  hipsdp_solve_path: 1 when the last solve ran there, 0 the general path.
  * hipsdp_solve1_trace: scalars of the last one-launch solve - out[0..63] (status, iterations, ..., device cycles per phase; see

@@ -2607,7 +2607,14 @@ static int solve1_try(hipsdp_solver* s, hipsdp_info* info, bool* done)
     * 0.422, two of 30: 0.449 / 0.572.  [Mid-round it lost at 32 rows, 0.62 against 0.43 - a dense constant matrix went through
     * scalar loops of one wavefront and dense LP rows through a walk of their nonzeros - and the default was 24.] */
    int maxn = 64;
+   /* most variables the kernel is offered (HIPSDP_SOLVE1_MAXM): with the Schur matrix as a packed triangle m = 128 fits its LDS, but
+    * the factorization of M is one workgroup's (the panel recurrence one wavefront's) and grows with m^3 - against the general path
+    * (tests/devtools/solve1_mbig.py, ms per iteration): m = 70: 0.227 / 0.393, 90: 0.330 / 0.426, 105: 0.424 / 0.453 (example_MkP's
+    * root, two nonzeros per matrix: 0.235 / 0.450), 110: 0.520 / 0.501, 120: 0.465 / 0.436, 128: 0.541 / 0.476 */
+   int maxm = 108;
    {
+      if ( getenv("HIPSDP_SOLVE1_MAXM") != NULL )
+         maxm = atoi(getenv("HIPSDP_SOLVE1_MAXM"));
       const char* env = getenv("HIPSDP_SOLVE1");
       on = (env != NULL && env[0] == '0') ? 0 : 1;
       if ( getenv("HIPSDP_SOLVE1_MAXWORK") != NULL )
@@ -2623,7 +2630,7 @@ static int solve1_try(hipsdp_solver* s, hipsdp_info* info, bool* done)
       return HS_OK;
    const int K = (int) s->blk.size();
    int ns[HS_S1_MAXBLK];
-   if ( K < 1 || K > HS_S1_MAXBLK )
+   if ( K < 1 || K > HS_S1_MAXBLK || s->m > maxm )
       return HS_OK;
    for (int k = 0; k < K; ++k)
    {

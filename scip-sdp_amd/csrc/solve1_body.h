@@ -87,6 +87,7 @@ struct S1Lay
 {
    int m, m1, q, K;
    int pm1, pm, VL, QL;
+   int packedM;            /* m > 64: the extended Schur matrix as a packed lower triangle (row i at i (i + 1) / 2) */
    int oMx, oLm, oVec, oQ, oR, Rlen, fixedEnd;
    int n[S1_MAXB], p[S1_MAXB], np[S1_MAXB];
    int oX[S1_MAXB], oZi[S1_MAXB], oLx[S1_MAXB], oLz[S1_MAXB], odX[S1_MAXB], odZ[S1_MAXB], oT1[S1_MAXB], oT2[S1_MAXB], oEig[S1_MAXB];
@@ -111,7 +112,10 @@ static __host__ __device__ inline int s1_layout(int m, int q, int K, const int* 
    for (int k = 0; k < K; ++k) { L.oLx[k] = o; o += L.np[k]; }
    for (int k = 0; k < K; ++k) { L.oLz[k] = o; o += L.np[k]; }
    for (int k = 0; k < K; ++k) { L.oEig[k] = o; o += 8 * ((n[k] + 1) & ~1) + 64; }
-   L.oMx = o; o += (L.m1 * L.pm1 + 1) & ~1;
+   /* m > 64 (the instance with two rows per lane): M as a packed lower triangle - 45 instead of 96 KB at m = 105, so that the
+    * lists of such a problem find room in LDS again; sixteen doubles behind it for the unmasked reads past the end of the last rows */
+   L.packedM = m > 64 ? 1 : 0;
+   L.oMx = o; o += L.packedM ? (L.m1 * (L.m1 + 1) / 2 + 16 + 1) & ~1 : (L.m1 * L.pm1 + 1) & ~1;
    L.oLm = L.oMx + L.pm1 + 1;
    L.oVec = o; o += V_COUNT * L.VL;
    L.oQ = o; o += Q_COUNT * L.QL;
@@ -538,34 +542,117 @@ __device__ __forceinline__ void s1_llt_solve(const double* L, int m, int p, int 
 }
 
 /* ==== 64 < m <= 128: the factor of M and the substitutions with TWO rows per lane (lane and lane + 64) ====
- * Functions of their own (the common case m <= 64 keeps its registers); results go through LDS vectors. */
+ * Functions of their own (the common case m <= 64 keeps its registers); results go through LDS vectors.  The matrix is the PACKED
+ * lower triangle of the extended Schur matrix Mx (m + 1 rows, row i at i (i + 1) / 2): entry (i, j), j <= i, of M itself is
+ * Mx[S1_PKROW(i) + j] - row i + 1, column j + 1 of the extended matrix.  Nothing above the diagonal exists: loads that would reach
+ * there are clamped to an entry that does and masked (or their results discarded), stores never go there.  The code of a panel
+ * and of a block of substitution steps exists twice, for columns below and from 64 on (HI): which of a lane's two rows holds the
+ * pivot is then known at compile time - with run-time selects the panel was 250 branches, 10 000 cycles. */
+#define S1_PKROW(i) ((((i) + 1) * ((i) + 2) >> 1) + 1)
+typedef __attribute__((address_space(3))) double s1_ldsd;
+
+/* the eight columns k0 .. k0 + 7 of the panel as a register recurrence (one wavefront); a: rows lane, b: rows lane + 64.  HI: the
+ * panel's columns are 64 and up - rows below 64 have no entries there */
+template<bool HI>
+__device__ __forceinline__ void s1_cholp2_cols(s1_ldsd* A, int n, int k0, int lane, bool has1, int r0, int r1, double thr, double dgx,
+   int rule, double& diag, int& nforced)
+{
+   const double regtol = 1e-13;
+   const int rowb = has1 ? lane + 64 : lane;           /* (the row r1 points to) */
+   double a[8], b[8];
+#pragma unroll
+   for (int u = 0; u < 8; ++u)
+   {
+      const int col = k0 + u;
+      /* (loads under their masks: with unconditional loads from clamped columns and a select behind them the factor came out
+       * wrong - not understood; the masked form is what the one-wavefront version had) */
+      a[u] = (!HI && lane >= col && col < n) ? A[r0 + col] : 0.0;
+      b[u] = (has1 && rowb >= col && col < n) ? A[r1 + col] : 0.0;
+   }
+#pragma unroll
+   for (int u = 0; u < 8; ++u)
+   {
+      const int k = k0 + u;
+      if ( k < n )
+      {
+         const int kl = HI ? k - 64 : k;
+         double d = s1_lane(HI ? b[u] : a[u], kl);
+         bool zero = false;
+         if ( !(d > s1_lane(thr, kl)) )
+         {
+            const double mkk = s1_lane(dgx, kl);
+            zero = (rule == 1) || (rule == 2 && !(d > 0.0)) || (rule == 3 && !(d > 1.78e-15 * (double) (k + 1) * mkk));
+            d = (mkk > 1e-280) ? regtol * mkk : 1.0;
+            nforced += zero ? 65536 : 1;
+         }
+         const double rs = s1_rsqrt(d);
+         const double sd = d * rs;
+         diag = (lane == kl) ? sd : diag;
+         const double lua = (!HI && lane > k && !zero) ? a[u] * rs : 0.0;
+         const double lub = ((!HI || lane + 64 > k) && !zero) ? b[u] * rs : 0.0;
+         a[u] = lua; b[u] = lub;
+#pragma unroll
+         for (int v = u + 1; v < 8; ++v)
+         {
+            const double piv = s1_lane(HI ? lub : lua, HI ? k0 + v - 64 : k0 + v);
+            if ( !HI )
+               a[v] = fma(-lua, piv, a[v]);
+            b[v] = fma(-lub, piv, b[v]);
+         }
+      }
+   }
+   /* (the diagonal entry is stored as ZERO - what the substitutions want -, nothing is stored past it) */
+#pragma unroll
+   for (int u = 0; u < 8; ++u)
+   {
+      const int col = k0 + u;
+      if ( col < n )
+      {
+         if ( !HI && lane >= col )
+            A[r0 + col] = a[u];
+         if ( has1 && rowb >= col )
+            A[r1 + col] = b[u];
+      }
+   }
+}
 
 /* s1_cholp(psd = true, keepdiag = false) for 64 < n <= 128; dg: the original diagonal (LDS, n entries), dinv_out: 1 / (diagonal
  * entries of the factor) (LDS, n entries); returns the forced-pivot counter */
-__device__ __attribute__((noinline)) int s1_cholp2(double* A, int n, int p, int lane, const double* dg, int rule, double* dinv_out)
+/* ALL wavefronts of the workgroup call it: the panel update in front of every panel (16-row tiles on the matrix cores, independent
+ * of each other) is dealt out tile by tile, the eight columns of the panel are a register recurrence of wavefront 0; two workgroup
+ * barriers per panel.  [One wavefront doing both: 227 000 cycles at m = 105, of which the tile updates were 60 000.]  The return
+ * value and dinv_out are wavefront 0's. */
+__device__ __attribute__((noinline)) int s1_cholp2(double* Ag, int n_, int wave_, int lane, const double* dg, int rule_, double* dinv_out)
 {
+   /* (the arguments of a function that is not inlined arrive in vector registers: said to be uniform, the loops and the tests
+    * on them are scalar branches instead of execution masks) */
+   const int n = __builtin_amdgcn_readfirstlane(n_), wave = __builtin_amdgcn_readfirstlane(wave_), rule = __builtin_amdgcn_readfirstlane(rule_);
    const double regtol = 1e-13;
+   s1_ldsd* A = (s1_ldsd*) Ag;
    const int lr = lane & 15, kq = lane >> 4;
    const bool has1 = lane + 64 < n;
    const double dg0 = dg[lane], dg1 = has1 ? dg[lane + 64] : 1.0;
    const double thr0 = fmax(regtol * dg0, 1e-300), thr1 = fmax(regtol * dg1, 1e-300);
    double diag0 = 1.0, diag1 = 1.0;
    int nforced = 0;
+   const int r0 = S1_PKROW(lane), r1 = S1_PKROW(has1 ? lane + 64 : lane);
    for (int k0 = 0; k0 < n; k0 += 8)
    {
       if ( k0 > 0 )
       {
+         /* (rows above the panel and the columns of a row past its diagonal read whatever follows in the packed array: such
+          * entries only reach accumulator rows / columns that are not stored) */
          const int nm1 = n - 1;
-         for (int T = k0 >> 4; 16 * T < n; ++T)
+         for (int T = (k0 >> 4) + wave; 16 * T < n; T += S1_NW)
          {
             const int ar = min(16 * T + lr, nm1), br = min(k0 + lr, nm1);
-            const double* pa = A + ar * p + kq;
-            const double* pb = A + br * p + kq;
+            const s1_ldsd* pa = A + S1_PKROW(ar) + kq;
+            const s1_ldsd* pb = A + S1_PKROW(br) + kq;
             const int cc = min(k0 + lr, nm1);
             v4d acc;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-               acc[r] = A[min(16 * T + kq + 4 * r, nm1) * p + cc];
+               acc[r] = A[S1_PKROW(min(16 * T + kq + 4 * r, nm1)) + cc];
             for (int kk = 0; kk < k0; kk += 8)
             {
                const double a0 = -pa[kk], b0 = pb[kk];
@@ -578,142 +665,110 @@ __device__ __attribute__((noinline)) int s1_cholp2(double* A, int n, int p, int 
             {
                const int row = 16 * T + kq + 4 * r;
                if ( lr < 8 && row < n && row >= k0 + lr && k0 + lr < n )
-                  A[row * p + k0 + lr] = acc[r];
+                  A[S1_PKROW(row) + k0 + lr] = acc[r];
             }
          }
-         S1_WSYNC();
+         __syncthreads();
       }
-      const bool hi = k0 >= 64;                           /* (a panel lies in one half: 64 is a multiple of 8) */
-      double a[8], b[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
+      if ( wave == 0 )
       {
-         a[u] = (lane >= k0 + u && k0 + u < n) ? A[lane * p + k0 + u] : 0.0;
-         b[u] = (has1 && lane + 64 >= k0 + u && k0 + u < n) ? A[(lane + 64) * p + k0 + u] : 0.0;
+         /* (a panel lies in one half: 64 is a multiple of 8) */
+         if ( k0 >= 64 )
+            s1_cholp2_cols<true>(A, n, k0, lane, has1, r0, r1, thr1, dg1, rule, diag1, nforced);
+         else
+            s1_cholp2_cols<false>(A, n, k0, lane, has1, r0, r1, thr0, dg0, rule, diag0, nforced);
       }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-      {
-         const int k = k0 + u;
-         if ( k < n )
-         {
-            const int kl = k & 63;
-            double d = hi ? s1_lane(b[u], kl) : s1_lane(a[u], kl);
-            bool zero = false;
-            if ( !(d > (hi ? s1_lane(thr1, kl) : s1_lane(thr0, kl))) )
-            {
-               const double mkk = hi ? s1_lane(dg1, kl) : s1_lane(dg0, kl);
-               zero = (rule == 1) || (rule == 2 && !(d > 0.0)) || (rule == 3 && !(d > 1.78e-15 * (double) (k + 1) * mkk));
-               d = (mkk > 1e-280) ? regtol * mkk : 1.0;
-               nforced += zero ? 65536 : 1;
-            }
-            const double rs = s1_rsqrt(d);
-            const double sd = d * rs;
-            if ( lane == kl )
-            {
-               if ( hi ) diag1 = sd; else diag0 = sd;
-            }
-            const double lua = (!hi && lane > k && !zero) ? a[u] * rs : 0.0;
-            const double lub = ((!hi || lane + 64 > k) && !zero) ? b[u] * rs : 0.0;
-            a[u] = lua; b[u] = lub;
-#pragma unroll
-            for (int v = u + 1; v < 8; ++v)
-            {
-               const double piv = hi ? s1_lane(lub, (k0 + v) & 63) : s1_lane(lua, (k0 + v) & 63);
-               a[v] = fma(-lua, piv, a[v]);
-               b[v] = fma(-lub, piv, b[v]);
-            }
-         }
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-         if ( k0 + u < n )
-         {
-            A[lane * p + k0 + u] = a[u];
-            if ( has1 )
-               A[(lane + 64) * p + k0 + u] = b[u];
-         }
-      S1_WSYNC();
+      __syncthreads();
    }
-   dinv_out[lane] = s1_rcp(diag0);
-   if ( has1 )
-      dinv_out[lane + 64] = s1_rcp(diag1);
-   S1_WSYNC();
+   if ( wave == 0 )
+   {
+      dinv_out[lane] = s1_rcp(diag0);
+      if ( has1 )
+         dinv_out[lane + 64] = s1_rcp(diag1);
+   }
+   __syncthreads();
    return nforced;
+}
+
+/* eight steps of a substitution with two rows per lane: c / ch = this lane's entries of the factor for the steps k0 .. k0 + 7 (rows
+ * lane / lane + 64; forward: of its rows, backward: of its columns), a* = the right-hand sides being reduced.  HI: the steps are
+ * 64 and up - the values come from the upper rows, and (forward) the lower rows are done, (backward) both halves take part */
+template<bool TWO, bool HI, bool DOWN>
+__device__ __forceinline__ void s1_llt_steps2(const double* c, const double* ch, int k0, double di0, double di1, double& a0, double& a0h,
+   double& a1, double& a1h)
+{
+#pragma unroll
+   for (int uu = 0; uu < 8; ++uu)
+   {
+      const int u = DOWN ? uu : 7 - uu;
+      const int kl = HI ? k0 + u - 64 : k0 + u;
+      const double t0 = HI ? a0h * di1 : a0 * di0, t1 = HI ? a1h * di1 : a1 * di0;
+      const double y0 = s1_lane(t0, kl);
+      const double y1 = TWO ? s1_lane(t1, kl) : 0.0;
+      a0 = fma(-c[u], y0, a0); a0h = fma(-ch[u], y0, a0h);
+      if ( TWO )
+      {
+         a1 = fma(-c[u], y1, a1); a1h = fma(-ch[u], y1, a1h);
+      }
+   }
 }
 
 /* s1_llt_solve for 64 < m <= 128: right-hand sides r0 (and r1) and results o0 (o1) are LDS vectors, dinv the vector s1_cholp2 left */
 template<bool TWO>
-__device__ __attribute__((noinline)) void s1_llt_solve2(const double* L, int m, int p, int lane, const double* dinv, const double* r0,
+__device__ __attribute__((noinline)) void s1_llt_solve2(const double* Lg, int m_, int lane, const double* dinv, const double* r0,
    const double* r1, double* o0, double* o1)
 {
+   const int m = __builtin_amdgcn_readfirstlane(m_);
+   const s1_ldsd* L = (const s1_ldsd*) Lg;
    const bool has1 = lane + 64 < m;
-   const int rh = has1 ? lane + 64 : 0;
+   const int rh = has1 ? lane + 64 : lane;
    const double di0 = dinv[lane], di1 = has1 ? dinv[lane + 64] : 1.0;
    double a0 = r0[lane], a0h = has1 ? r0[lane + 64] : 0.0;
    double a1 = TWO ? r1[lane] : 0.0, a1h = (TWO && has1) ? r1[lane + 64] : 0.0;
    const int nb = (m + 7) >> 3;
    {
-      const double* row = L + lane * p;
-      const double* rowh = L + rh * p;
+      /* this lane's rows, columns k0 .. k0 + 7: only the strictly lower part exists */
+      const s1_ldsd* row = L + S1_PKROW(lane);
+      const s1_ldsd* rowh = L + S1_PKROW(rh);
       for (int b = 0; b < nb; ++b)
       {
          const int k0 = 8 * b;
-         const bool hi = k0 >= 64;
          double c[8], ch[8];
 #pragma unroll
          for (int u = 0; u < 8; ++u)
          {
-            c[u] = row[k0 + u];
-            const double v = rowh[k0 + u];
-            ch[u] = has1 ? v : 0.0;
+            const double v = row[min(k0 + u, lane)];
+            c[u] = (k0 + u < lane) ? v : 0.0;
+            const double vh = rowh[min(k0 + u, rh)];
+            ch[u] = (has1 && k0 + u < rh) ? vh : 0.0;
          }
-#pragma unroll
-         for (int u = 0; u < 8; ++u)
-         {
-            const int kl = (k0 + u) & 63;
-            const double t0 = hi ? a0h * di1 : a0 * di0, t1 = hi ? a1h * di1 : a1 * di0;
-            const double y0 = s1_lane(t0, kl);
-            const double y1 = TWO ? s1_lane(t1, kl) : 0.0;
-            a0 = fma(-c[u], y0, a0); a0h = fma(-ch[u], y0, a0h);
-            if ( TWO )
-            {
-               a1 = fma(-c[u], y1, a1); a1h = fma(-ch[u], y1, a1h);
-            }
-         }
+         if ( k0 >= 64 )
+            s1_llt_steps2<TWO, true, true>(c, ch, k0, di0, di1, a0, a0h, a1, a1h);
+         else
+            s1_llt_steps2<TWO, false, true>(c, ch, k0, di0, di1, a0, a0h, a1, a1h);
       }
    }
    a0 *= di0; a0h *= di1; a1 *= di0; a1h *= di1;
    {
-      /* rows k0 .. k0 + 7 of the factor, columns lane and lane + 64; rows past m - 1 are clamped to row 0, which is all zero */
-      const double* col = L + lane;
-      const double* colh = L + rh;
+      /* rows k0 .. k0 + 7 of the factor, columns lane and lane + 64: entry (row, column) exists for row > column */
       for (int b = nb - 1; b >= 0; --b)
       {
          const int k0 = 8 * b;
-         const bool hi = k0 >= 64;
          double c[8], ch[8];
 #pragma unroll
          for (int u = 0; u < 8; ++u)
          {
             const int rr = (k0 + u < m) ? k0 + u : 0;
-            c[u] = col[rr * p];
-            const double v = colh[rr * p];
-            ch[u] = has1 ? v : 0.0;
+            const s1_ldsd* rp = L + S1_PKROW(rr);
+            const double v = rp[min(lane, rr)];
+            c[u] = rr > lane ? v : 0.0;
+            const double vh = rp[min(rh, rr)];
+            ch[u] = (has1 && rr > rh) ? vh : 0.0;
          }
-#pragma unroll
-         for (int u = 7; u >= 0; --u)
-         {
-            const int kl = (k0 + u) & 63;
-            const double t0 = hi ? a0h * di1 : a0 * di0, t1 = hi ? a1h * di1 : a1 * di0;
-            const double y0 = s1_lane(t0, kl);
-            const double y1 = TWO ? s1_lane(t1, kl) : 0.0;
-            a0 = fma(-c[u], y0, a0); a0h = fma(-ch[u], y0, a0h);
-            if ( TWO )
-            {
-               a1 = fma(-c[u], y1, a1); a1h = fma(-ch[u], y1, a1h);
-            }
-         }
+         if ( k0 >= 64 )
+            s1_llt_steps2<TWO, true, false>(c, ch, k0, di0, di1, a0, a0h, a1, a1h);
+         else
+            s1_llt_steps2<TWO, false, false>(c, ch, k0, di0, di1, a0, a0h, a1, a1h);
       }
    }
    o0[lane] = a0 * di0;
@@ -1603,14 +1658,18 @@ __device__ __forceinline__ void s1_copy_in(double* dst, const double* __restrict
 
 /* LP part of the Schur matrix as a product (see lp_schur in the kernel): a function of its own - it is the rare case (dense LP rows),
  * and inlined its registers are added to what the iteration keeps alive around the whole-matrix-per-lane recurrences */
-__device__ __attribute__((noinline)) void s1_lp_schur_mm(const double* Dl, const double* sx, double* Mx, int m1, int q, int pm1, int wave,
-   int lane, int w0)
+__device__ __attribute__((noinline)) void s1_lp_schur_mm(const double* Dl, const double* sx, double* Mx, int m1_, int q_, int pm1_, bool mpk_,
+   int wave_, int lane, int w0_)
 {
+   /* (arguments arrive in vector registers: said to be uniform, the tile loops are scalar) */
+   const int m1 = __builtin_amdgcn_readfirstlane(m1_), q = __builtin_amdgcn_readfirstlane(q_), pm1 = __builtin_amdgcn_readfirstlane(pm1_);
+   const int wave = __builtin_amdgcn_readfirstlane(wave_), w0 = __builtin_amdgcn_readfirstlane(w0_);
+   const bool mpk = __builtin_amdgcn_readfirstlane((int) mpk_) != 0;
    int tb = 0;
    s1_mmk(m1, q, wave, lane, w0, S1_NW - w0, tb,
       [&](int i, int kk) S1_INL { return Dl[kk * m1 + i] * sx[kk]; },
       [&](int kk, int j) S1_INL { return Dl[kk * m1 + j]; },
-      [&](int i, int j, double v) S1_INL { if ( j <= i ) Mx[i * pm1 + j] = v; });
+      [&](int i, int j, double v) S1_INL { if ( j <= i ) Mx[(mpk ? (i * (i + 1)) >> 1 : i * pm1) + j] = v; });
 }
 
 /* pointers to the lists and cold matrices: they live in LDS while it lasts, else in the workspace in global memory, and are kept as
@@ -1675,12 +1734,15 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
    const int oVec = L.oVec, oQ = L.oQ;
    double* const Mx = sm + L.oMx;
    double* const Lm = sm + L.oLm;
+   /* row i of the extended Schur matrix starts at Mx + MROW(i): a packed lower triangle in the instance for m > 64 */
+   const bool mpk = S1_MBIG && L.packedM;
+#define MROW(i) (mpk ? ((i) * ((i) + 1)) >> 1 : (i) * pm1)
 #define VEC(id) (sm + oVec + (id) * VL)
 #define QV(id) (sm + oQ + (id) * QL)
    double* const out = P.out;
    /* (the extended Schur matrix starts from zeros: its upper triangle and the padding columns are never written and are read -
     * unmasked - by the substitutions with the factor that overwrites it) */
-   for (int e = tid; e < m1 * pm1; e += S1_NT)
+   for (int e = tid; e < (mpk ? (m1 * (m1 + 1) >> 1) + 16 : m1 * pm1); e += S1_NT)
       Mx[e] = 0.0;
 
    /* ---- flexible part: offset arrays first (their sizes follow from the shape), the counts decide the rest */
@@ -2196,14 +2258,14 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
       const double* sx = QV(Q_sx);
       if ( sh.fl[33] )
       {
-         s1_lp_schur_mm(sh.fl[33] == 1 ? sm + sh.fl[31] : P.Dext, sx, Mx, m1, q, pm1, wave, lane, w0);
+         s1_lp_schur_mm(sh.fl[33] == 1 ? sm + sh.fl[31] : P.Dext, sx, Mx, m1, q, pm1, mpk, wave, lane, w0);
          return;
       }
       if ( wave != S1_NW - 1 )
          return;
       for (int i = lane + 1; i < m1; i += 64)
       {
-         double* row = Mx + i * pm1;
+         double* row = Mx + MROW(i);
          for (int j = 0; j <= i; ++j)
             row[j] = 0.0;
          const int t1 = LP(sh.coff)[i + 1];
@@ -2477,9 +2539,9 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
       if ( S1_MBIG && m > 64 )
       {
          if ( two )
-            s1_llt_solve2<true>(Lm, m, pm, lane, VEC(V_dg), r0, r1, o0, o1);
+            s1_llt_solve2<true>(Mx, m, lane, VEC(V_dg), r0, r1, o0, o1);
          else
-            s1_llt_solve2<false>(Lm, m, pm, lane, VEC(V_dg), r0, r1, o0, o1);
+            s1_llt_solve2<false>(Mx, m, lane, VEC(V_dg), r0, r1, o0, o1);
          return;
       }
       double x0 = (lane < m) ? r0[lane] : 0.0;
@@ -3024,7 +3086,7 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
                      }
                      s0 = s1_sum16(s0);
                      if ( l16 == 0 )
-                        Mx[(i >= j) ? i * pm1 + j : j * pm1 + i] += s0;
+                        Mx[(i >= j) ? MROW(i) + j : MROW(j) + i] += s0;
                   }
                }
                S1_BAR();
@@ -3114,7 +3176,7 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
                      u = fma(X[bb_ * p + (int) LP(B.lrp)[sl]], LP(B.Tc)[sl * n + aa_], u);
                   acc = fma(LP(B.vval)[e], u, acc);
                }
-            Mx[i * pm1 + j] += acc;
+            Mx[MROW(i) + j] += acc;
          }
          /* (the lists of light variables differ from block to block - a dense constant matrix is heavy in a block of 8 rows and
           * light in one of 2 -, so the same entry of Mx is another thread's in the next block: one block after the other) */
@@ -3126,28 +3188,34 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
 
       /* ================= factorization of M and the two solves (wavefront 0) beside the first product of the predictor,
        * T1 = X Rd (the others) */
+      /* (64 < m: the factorization is the work of all wavefronts - s1_cholp2 -, the product X Rd comes first) */
+      const bool coop = S1_MBIG && m > 64;
+      double mdiag = 1.0;
+      int nforced = 0;
+      long long tq0 = 0;
       if ( wave == 0 )
       {
          /* (the factor overwrites M where it stands; its first column, g, is taken out first) */
          for (int i = lane; i < m; i += 64)
          {
-            VEC(V_g)[i] = Mx[(i + 1) * pm1];
-            if ( S1_MBIG && m > 64 )
-               VEC(V_dg)[i] = Lm[i * pm + i];
+            VEC(V_g)[i] = Mx[MROW(i + 1)];
+            if ( coop )
+               VEC(V_dg)[i] = Mx[MROW(i + 1) + i + 1];
          }
-         const double dg0 = (lane < m) ? Lm[lane * pm + lane] : 1.0;
-         double mdiag;
-         int nforced;
-         long long tq0 = 0;
          if ( P.prof_on ) tq0 = clock64();
-         if ( S1_MBIG && m > 64 )
+      }
+      if ( coop )
+      {
+         __syncthreads();
+         nforced = s1_cholp2(Mx, m, wave, lane, VEC(V_dg), P.pivot_rule, VEC(V_dg));
+      }
+      if ( wave == 0 )
+      {
+         if ( !coop )
          {
-            S1_WSYNC();
-            nforced = s1_cholp2(Lm, m, pm, lane, VEC(V_dg), P.pivot_rule, VEC(V_dg));
-            mdiag = 1.0;
-         }
-         else
+            const double dg0 = (lane < m) ? Lm[lane * pm + lane] : 1.0;
             (void) s1_cholp(Lm, m, pm, lane, true, dg0, P.pivot_rule, false, mdiag, nforced);
+         }
          if ( lane == 0 )
             sh.fl[6] = nforced;
          mdinv = s1_rcp(mdiag);

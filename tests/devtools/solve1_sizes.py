@@ -9,26 +9,8 @@ hb = importlib.util.module_from_spec(spec); spec.loader.exec_module(hb)
 import ipm_ref
 
 
-def core_of(sizes, m, q, seed):
-    rng = np.random.default_rng(seed)
-    ystar = rng.standard_normal(m)
-    blocks = []
-    for n in sizes:
-        A = np.zeros((m + 1, n, n))
-        for i in range(1, m + 1):
-            for _ in range(3):
-                r, c = rng.integers(0, n, 2)
-                v = rng.standard_normal()
-                A[i, r, c] += v
-                if r != c:
-                    A[i, c, r] += v
-        Zs = rng.standard_normal((n, n)); Zs = Zs @ Zs.T + 0.5 * np.eye(n)
-        A[0] = np.tensordot(ystar, A[1:], axes=(0, 0)) - Zs
-        blocks.append(A)
-    D = rng.standard_normal((q, m)) * (rng.random((q, m)) < 0.3)
-    c = D @ ystar - rng.random(q) - 0.1
-    b = sum(np.array([np.trace(A[i]) for i in range(1, m + 1)]) for A in blocks) + (D.T @ np.ones(q) if q else 0.0)
-    return ipm_ref.CoreProblem(b, blocks, D, c)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from solve1_sizes_lib import core_of
 
 
 for sizes, m, q in [([10], 37, 85), ([16], 40, 40), ([24], 40, 40), ([32], 48, 40), ([48], 60, 40), ([64], 64, 64), ([12, 12, 12], 40, 40),
