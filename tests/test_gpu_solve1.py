@@ -172,12 +172,13 @@ def test_random_sparse_problems_in_one_launch(gpu, seed, monkeypatch):
 
 @pytest.mark.parametrize("sizes,m,q", [([16], 40, 40), ([24], 40, 40), ([28], 44, 10), ([32], 48, 40), ([20, 20], 50, 20),
                                        ([12, 12, 12], 40, 40), ([9] * 8, 60, 100), ([17, 3, 11, 2], 64, 30),
-                                       ([12], 65, 20), ([10, 9], 90, 60), ([14, 8], 104, 12)])
+                                       ([12], 65, 20), ([10, 9], 90, 60), ([14, 8], 104, 12), ([15], 70, 100), ([15], 105, 240)])
 def test_blocks_up_to_the_limits_of_the_kernel_in_one_launch(gpu, sizes, m, q, monkeypatch):
     """The kernel runs whatever fits its LDS: blocks of 16 < n <= 32 rows (step lengths by
     the one-wavefront LDS tridiagonalisation, panel Cholesky + in-place inverse instead of the whole-matrix-per-lane forms, several
-    tiles per product), eight blocks, m = 64, and 64 < m <= 108 (two rows per lane in the factorization of M and the substitutions,
-    lists partly outside LDS): same iterations as the oracle, iterate by iterate."""
+    tiles per product), eight blocks, m = 64, and 64 < m <= 108 (the Schur matrix as a packed lower triangle, factored by all
+    wavefronts - tile updates dealt out, the panel recurrence with two rows per lane -, two rows per lane in the substitutions;
+    the last two cases with LP rows of density 0.3: a dense M): same iterations as the oracle, iterate by iterate."""
     core = sized_sparse_core(sizes, m, q, 5)
     ref = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-6, feastol=1e-6, pabstol=1e-5))
     g = solve_one_launch(gpu, core, monkeypatch, gaptol=1e-6, feastol=1e-6, pabstol=1e-5)
@@ -190,6 +191,24 @@ def test_blocks_up_to_the_limits_of_the_kernel_in_one_launch(gpu, sizes, m, q, m
     assert ok, det
 
 
+def test_variable_limit_of_the_kernel(gpu, monkeypatch):
+    """m = 128 fits the kernel's LDS since the Schur matrix is a packed triangle, but above m = 108 the general path is the faster
+    one (csrc/ipm.hip: solve1_try) and gets the problem; HIPSDP_SOLVE1_MAXM=128 offers it to the kernel all the same - same iterates"""
+    core = sized_sparse_core([16], 120, 100, 5)
+    ref = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-6, feastol=1e-6, pabstol=1e-5))
+    g = solve_one_launch(gpu, core, monkeypatch, gaptol=1e-6, feastol=1e-6, pabstol=1e-5)
+    assert g["path"] == 0
+    assert g["info"].status == ref.status == 0
+    monkeypatch.setenv("HIPSDP_SOLVE1_MAXM", "128")
+    g = solve_one_launch(gpu, core, monkeypatch, gaptol=1e-6, feastol=1e-6, pabstol=1e-5)
+    assert g["path"] == 1
+    assert g["info"].status == 0
+    assert g["info"].iterations == ref.iterations
+    assert_history_matches(g, ref)
+    assert abs(g["info"].dobj - ref.dobj) <= 1e-6 * (1 + abs(ref.dobj))
+
+
+@pytest.mark.gpu
 def test_block_size_switch_of_the_kernel(gpu, monkeypatch):
     """HIPSDP_SOLVE1_MAXN limits the blocks the kernel is offered (default: whatever fits)"""
     core = sized_sparse_core([28], 44, 10, 5)
