@@ -178,6 +178,10 @@ __device__ __forceinline__ double s1_dpp(double v)
    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
    return __hiloint2double(hi, lo);
 }
+/* a loaded value is needed HERE, whatever the selects behind it say: without it the compiler sinks a load whose value is only used
+ * under a condition into a branch of its own - eight loads of a panel or of a block of substitution steps then wait for LDS one
+ * after the other (19 branches and 16 full waits per block of s1_llt_solve2, 1000 cycles) instead of being in flight together */
+#define S1_PIN(x) asm volatile("" : "+v"(x))
 __device__ __forceinline__ double s1_lane(double v, int l)
 {
    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
@@ -411,9 +415,19 @@ __device__ __forceinline__ int s1_cholp(double* A, int n, int p, int lane, bool 
          S1_WSYNC();
       }
       double a[8];
+      {
+         /* (all eight loads in flight together, from a row that exists: S1_PIN) */
+         const double* rowp = A + min(lane, n - 1) * p + k0;
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-         a[u] = (lane >= k0 + u && lane < n && k0 + u < n) ? A[lane * p + k0 + u] : 0.0;
+         for (int u = 0; u < 8; ++u)
+            a[u] = rowp[u];
+#pragma unroll
+         for (int u = 0; u < 8; ++u)
+            S1_PIN(a[u]);
+#pragma unroll
+         for (int u = 0; u < 8; ++u)
+            a[u] = (lane >= k0 + u && lane < n && k0 + u < n) ? a[u] : 0.0;
+      }
 #pragma unroll
       for (int u = 0; u < 8; ++u)
       {
@@ -564,10 +578,21 @@ __device__ __forceinline__ void s1_cholp2_cols(s1_ldsd* A, int n, int k0, int la
    for (int u = 0; u < 8; ++u)
    {
       const int col = k0 + u;
-      /* (loads under their masks: with unconditional loads from clamped columns and a select behind them the factor came out
-       * wrong - not understood; the masked form is what the one-wavefront version had) */
-      a[u] = (!HI && lane >= col && col < n) ? A[r0 + col] : 0.0;
-      b[u] = (has1 && rowb >= col && col < n) ? A[r1 + col] : 0.0;
+      /* (from columns that exist, all in flight together - S1_PIN -, masked behind) */
+      a[u] = HI ? 0.0 : A[r0 + min(col, lane)];
+      b[u] = A[r1 + min(col, rowb)];
+   }
+#pragma unroll
+   for (int u = 0; u < 8; ++u)
+   {
+      S1_PIN(a[u]); S1_PIN(b[u]);
+   }
+#pragma unroll
+   for (int u = 0; u < 8; ++u)
+   {
+      const int col = k0 + u;
+      a[u] = (!HI && lane >= col && col < n) ? a[u] : 0.0;
+      b[u] = (has1 && rowb >= col && col < n) ? b[u] : 0.0;
    }
 #pragma unroll
    for (int u = 0; u < 8; ++u)
@@ -737,10 +762,19 @@ __device__ __attribute__((noinline)) void s1_llt_solve2(const double* Lg, int m_
 #pragma unroll
          for (int u = 0; u < 8; ++u)
          {
-            const double v = row[min(k0 + u, lane)];
-            c[u] = (k0 + u < lane) ? v : 0.0;
-            const double vh = rowh[min(k0 + u, rh)];
-            ch[u] = (has1 && k0 + u < rh) ? vh : 0.0;
+            c[u] = row[min(k0 + u, lane)];
+            ch[u] = rowh[min(k0 + u, rh)];
+         }
+#pragma unroll
+         for (int u = 0; u < 8; ++u)
+         {
+            S1_PIN(c[u]); S1_PIN(ch[u]);
+         }
+#pragma unroll
+         for (int u = 0; u < 8; ++u)
+         {
+            c[u] = (k0 + u < lane) ? c[u] : 0.0;
+            ch[u] = (has1 && k0 + u < rh) ? ch[u] : 0.0;
          }
          if ( k0 >= 64 )
             s1_llt_steps2<TWO, true, true>(c, ch, k0, di0, di1, a0, a0h, a1, a1h);
@@ -760,10 +794,20 @@ __device__ __attribute__((noinline)) void s1_llt_solve2(const double* Lg, int m_
          {
             const int rr = (k0 + u < m) ? k0 + u : 0;
             const s1_ldsd* rp = L + S1_PKROW(rr);
-            const double v = rp[min(lane, rr)];
-            c[u] = rr > lane ? v : 0.0;
-            const double vh = rp[min(rh, rr)];
-            ch[u] = (has1 && rr > rh) ? vh : 0.0;
+            c[u] = rp[min(lane, rr)];
+            ch[u] = rp[min(rh, rr)];
+         }
+#pragma unroll
+         for (int u = 0; u < 8; ++u)
+         {
+            S1_PIN(c[u]); S1_PIN(ch[u]);
+         }
+#pragma unroll
+         for (int u = 0; u < 8; ++u)
+         {
+            const int rr = (k0 + u < m) ? k0 + u : 0;
+            c[u] = rr > lane ? c[u] : 0.0;
+            ch[u] = (has1 && rr > rh) ? ch[u] : 0.0;
          }
          if ( k0 >= 64 )
             s1_llt_steps2<TWO, true, false>(c, ch, k0, di0, di1, a0, a0h, a1, a1h);
