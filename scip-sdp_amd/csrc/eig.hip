@@ -1616,7 +1616,9 @@ __global__ void __launch_bounds__(64) k_lmin_tiny_multi(hs_step_jobs P)
  * coordinates stay unit vectors and are dropped by the final sort. */
 #define BJ_B 32
 #define BJ_M 64
-#define BJ_T 512            /* threads of the subproblem workgroup */
+#ifndef BJ_T
+#define BJ_T 1024           /* threads of the subproblem workgroup */
+#endif
 
 /* reciprocal square root: v_rsq_f64 seed + two coupled Newton steps (no division, no sqrt expansion) */
 __device__ __forceinline__ double bj_rsqrt(double x)
@@ -1628,6 +1630,15 @@ __device__ __forceinline__ double bj_rsqrt(double x)
    r = fma(-h, g, 0.5);
    h = fma(h, r, h);
    return 2.0 * h;
+}
+
+/* reciprocal: v_rcp_f64 seed + two Newton steps */
+__device__ __forceinline__ double bj_rcp(double t)
+{
+   double r = __builtin_amdgcn_rcp(t);
+   r = fma(fma(-t, r, 1.0), r, r);
+   r = fma(fma(-t, r, 1.0), r, r);
+   return r;
 }
 
 __global__ void k_bjac_pad(int n, int N, const double* __restrict__ A, double* __restrict__ Ap, double* __restrict__ Vtp)
@@ -1712,7 +1723,11 @@ __global__ void __launch_bounds__(BJ_T) k_bjac_sub(int N, int nbp, int r, const 
                /* the small-angle rotation from two reciprocal square roots: with d = a_qq - a_pp, b = 2 a_pq, r = hypot(d, b)
                 * cos^2 = (1 + |d| / r) / 2,  sin = sgn(d) b / (2 r cos)  (scaled by 1 / max(|d|, |b|) against overflow) */
                double d = aqq - app, b = 2.0 * apq;
+#ifdef BJ_DIV
                const double sc = 1.0 / fmax(fabs(d), fabs(b));
+#else
+               const double sc = bj_rcp(fmax(fabs(d), fabs(b)));      /* (only scales d and b against overflow: no division expansion) */
+#endif
                d *= sc; b *= sc;
                const double ir = bj_rsqrt(d * d + b * b);
                const double c2 = 0.5 + 0.5 * fabs(d) * ir;
@@ -1761,58 +1776,74 @@ __global__ void __launch_bounds__(BJ_T) k_bjac_sub(int N, int nbp, int r, const 
 __global__ void __launch_bounds__(256) k_bjac_apply(int N, int nbp, int r, int mode, double* __restrict__ Ap, double* __restrict__ Vtp,
    const double* __restrict__ J)
 {
+   /* both operands with the summation index contiguous and an odd pitch: the fragments of the matrix instruction (lane & 15 = row
+    * or column, lane >> 4 = position in the K step) are read without bank conflicts */
    __shared__ double L[BJ_M][BJ_M + 1];     /* [i][k] */
-   __shared__ double R[BJ_M][BJ_M + 4];     /* [k][j] */
+   __shared__ double Rt[BJ_M][BJ_M + 1];    /* [j][k] */
+   typedef double bj_v4 __attribute__((ext_vector_type(4)));
    const int tid = threadIdx.x;
    int P, Q;
    jac_pair(nbp, r, blockIdx.x, &P, &Q);
    const double* Jk = J + (long long) blockIdx.x * BJ_M * BJ_M;
    double* M = (mode == 0 && blockIdx.z == 1) ? Vtp : Ap;
    const int c0 = blockIdx.y * BJ_M;
-   for (int e = tid; e < BJ_M * BJ_M; e += 256)
    {
-      const int i = e / BJ_M, j = e % BJ_M;
-      if ( mode == 0 )
+      /* all 32 loads of a thread in flight before the first LDS write (a loop of load - write pairs was sixteen round trips) */
+      double vj[16], vm[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
       {
-         L[i][j] = Jk[e];                                                   /* J[i][k] */
-         R[i][j] = M[(long long) bj_grow(P, Q, i) * N + c0 + j];            /* strip[k][j] */
+         const int e = tid + 256 * q;
+         const int i = e / BJ_M, j = e % BJ_M;
+         vj[q] = Jk[e];
+         vm[q] = mode == 0 ? M[(long long) bj_grow(P, Q, i) * N + c0 + j] : M[(long long) (c0 + i) * N + bj_grow(P, Q, j)];
       }
-      else
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
       {
-         L[i][j] = M[(long long) (c0 + i) * N + bj_grow(P, Q, j)];          /* strip[i][k] */
-         R[j][i] = Jk[e];                                                   /* R[k][j] = J[j][k] */
+         const int e = tid + 256 * q;
+         const int i = e / BJ_M, j = e % BJ_M;
+         if ( mode == 0 )
+         {
+            L[i][j] = vj[q];                                                /* J[i][k] */
+            Rt[j][i] = vm[q];                                               /* strip[k][j] */
+         }
+         else
+         {
+            L[i][j] = vm[q];                                                /* strip[i][k] */
+            Rt[i][j] = vj[q];                                               /* (J^T)[k][j] = J[j][k] */
+         }
       }
    }
    __syncthreads();
-   const int ti = tid / 16, tj = tid % 16;
-   double acc[4][4];
+   /* wavefront w: rows 16 w .. 16 w + 15 of the product, four column tiles (four independent accumulator chains), K = 64 in 16 steps
+    * of v_mfma_f64_16x16x4 (the 64 x 64 x 64 product was 1024 multiply-adds per thread on the vector pipe: 12.7 us per launch) */
+   const int lane = tid & 63, w = tid >> 6, lr = lane & 15, lk = lane >> 4;
+   bj_v4 acc[4];
 #pragma unroll
-   for (int x = 0; x < 4; ++x)
+   for (int t = 0; t < 4; ++t)
+      acc[t] = (bj_v4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int y = 0; y < 4; ++y) acc[x][y] = 0.0;
-#pragma unroll 8
-   for (int k = 0; k < BJ_M; ++k)
+   for (int ks = 0; ks < 16; ++ks)
    {
-      double l[4], rr[4];
+      const double a = L[16 * w + lr][4 * ks + lk];
 #pragma unroll
-      for (int x = 0; x < 4; ++x) l[x] = L[4 * ti + x][k];
-#pragma unroll
-      for (int y = 0; y < 4; ++y) rr[y] = R[k][4 * tj + y];
-#pragma unroll
-      for (int x = 0; x < 4; ++x)
-#pragma unroll
-         for (int y = 0; y < 4; ++y) acc[x][y] = fma(l[x], rr[y], acc[x][y]);
+      for (int t = 0; t < 4; ++t)
+      {
+         const double bb = Rt[16 * t + lr][4 * ks + lk];
+         acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[t], 0, 0, 0);
+      }
    }
 #pragma unroll
-   for (int x = 0; x < 4; ++x)
+   for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int y = 0; y < 4; ++y)
+      for (int rr = 0; rr < 4; ++rr)
       {
-         const int i = 4 * ti + x, j = 4 * tj + y;
+         const int i = 16 * w + lk + 4 * rr, j = 16 * t + lr;
          if ( mode == 0 )
-            M[(long long) bj_grow(P, Q, i) * N + c0 + j] = acc[x][y];
+            M[(long long) bj_grow(P, Q, i) * N + c0 + j] = acc[t][rr];
          else
-            M[(long long) (c0 + i) * N + bj_grow(P, Q, j)] = acc[x][y];
+            M[(long long) (c0 + i) * N + bj_grow(P, Q, j)] = acc[t][rr];
       }
 }
 
@@ -1869,13 +1900,46 @@ __global__ void __launch_bounds__(256) k_bjac_sort(int n, int N, const double* _
          V[(long long) rank * n + c] = Vtp[(long long) i * N + c];
 }
 
+/* perm[rank of the i-th diagonal entry among the first n, descending] = i */
+__global__ void __launch_bounds__(256) k_bjac_rank(int n, int N, const double* __restrict__ Ap, int* __restrict__ perm)
+{
+   __shared__ int rank_s;
+   const int i = blockIdx.x;
+   const double di = Ap[(long long) i * N + i];
+   if ( threadIdx.x == 0 ) rank_s = 0;
+   __syncthreads();
+   int cnt = 0;
+   for (int j = threadIdx.x; j < n; j += blockDim.x)
+   {
+      const double dj = Ap[(long long) j * N + j];
+      if ( dj > di || (dj == di && j < i) )
+         ++cnt;
+   }
+   atomicAdd(&rank_s, cnt);
+   __syncthreads();
+   if ( threadIdx.x == 0 ) perm[rank_s] = i;
+}
+
+/* A2 = P A P^T, Vt2 = P Vt on the first n coordinates (the padding stays where it is) */
+__global__ void k_bjac_permute(int n, int N, const int* __restrict__ perm, const double* __restrict__ Ap, const double* __restrict__ Vtp,
+   double* __restrict__ A2, double* __restrict__ Vt2)
+{
+   for (long long e = (long long) blockIdx.x * blockDim.x + threadIdx.x; e < (long long) N * N; e += (long long) gridDim.x * blockDim.x)
+   {
+      const int r = (int) (e / N), c = (int) (e % N);
+      const int pr = r < n ? perm[r] : r, pc = c < n ? perm[c] : c;
+      A2[e] = Ap[(long long) pr * N + pc];
+      Vt2[e] = Vtp[(long long) pr * N + c];
+   }
+}
+
 #define BJ_OFFBLOCKS 256
 static int bj_padded(int n) { const int nb = (n + BJ_B - 1) / BJ_B; return ((nb + 1) & ~1) * BJ_B; }
 
 long long hs_syev_ws(int n)
 {
    const long long N = bj_padded(n);
-   return 2 * N * N + (N / BJ_M) * BJ_M * BJ_M + 2 * BJ_OFFBLOCKS + 64;
+   return 4 * N * N + (N / BJ_M) * BJ_M * BJ_M + 2 * BJ_OFFBLOCKS + N + 64;
 }
 
 int hs_syev_jacobi(hipStream_t s, int n, double* A, double* lam, double* V, int* info, double* ws)
@@ -1895,6 +1959,9 @@ int hs_syev_jacobi(hipStream_t s, int n, double* A, double* lam, double* V, int*
       double* Vtp = Ap + (long long) N * N;
       double* J = Vtp + (long long) N * N;
       double* part = J + (long long) (nbp / 2) * BJ_M * BJ_M;
+      double* Ap2 = part + 2 * BJ_OFFBLOCKS + 32;                     /* second pair of arrays: target of the permutations below */
+      double* Vtp2 = Ap2 + (long long) N * N;
+      int* perm = reinterpret_cast<int*>(Vtp2 + (long long) N * N);
       long long pg = ((long long) N * N + 255) / 256; if ( pg > 4096 ) pg = 4096;
       hipLaunchKernelGGL(k_bjac_pad, dim3((unsigned) pg), dim3(256), 0, s, n, N, A, Ap, Vtp);
       HS_LAUNCH_CHECK();
@@ -1903,6 +1970,8 @@ int hs_syev_jacobi(hipStream_t s, int n, double* A, double* lam, double* V, int*
       if ( tol < 1e-30 ) tol = 1e-30;
       double prev = 1e300;
       int sweeps_b = 0;
+      int nperm = 0, lastperm = -3;
+      const bool bjsort = !(getenv("HIPSDP_BJ_SORT") != NULL && getenv("HIPSDP_BJ_SORT")[0] == '0');
       int inner0 = 1, inner = 1;               /* inner sweeps of a subproblem: first outer sweep (dense subproblems), later ones */
       if ( getenv("HIPSDP_BJ_INNER") != NULL )
          (void) sscanf(getenv("HIPSDP_BJ_INNER"), "%d,%d", &inner0, &inner);
@@ -1921,7 +1990,26 @@ int hs_syev_jacobi(hipStream_t s, int n, double* A, double* lam, double* V, int*
             break;
          if ( off <= 1e-24 * dg && off > 0.25 * prev )
             break;                                      /* at the noise floor: no longer shrinking */
+         const double prev0 = prev;
          prev = off;
+         /* Multiple eigenvalues (the n - rank equal ones of a low-rank matrix - what the PSD projection of a warm start meets): the
+          * cyclic method converges quadratically only when the diagonal entries that belong to one eigenvalue sit next to each other;
+          * scattered among the others they made the tail linear (off^2 / diag^2 from 1e-17 down by 0.6 per sweep: 25 sweeps at
+          * n = 200, the limit of 40 at n = 500 with 1e-11 still off the diagonal).  So when the diagonal entries are close to the
+          * eigenvalues and a sweep has NOT brought the quadratic drop (a matrix with separated eigenvalues never comes here), the
+          * coordinates are sorted by their diagonal entries, and once more three sweeps later if it is still slow:
+          * A <- P A P^T, Vt <- P Vt.  What remains behind that is the second convergence phase every Jacobi method has on such a
+          * matrix - the perturbation inside the eigenspace is a dense matrix of its own - at 0.1 per sweep instead of 0.6. */
+         if ( bjsort && nperm < 2 && off <= 1e-8 * dg && off > 1e-2 * prev0 && sweeps_b >= lastperm + 3 )
+         {
+            lastperm = sweeps_b;
+            hipLaunchKernelGGL(k_bjac_rank, dim3(n), dim3(256), 0, s, n, N, Ap, perm);
+            hipLaunchKernelGGL(k_bjac_permute, dim3((unsigned) pg), dim3(256), 0, s, n, N, perm, Ap, Vtp, Ap2, Vtp2);
+            HS_LAUNCH_CHECK();
+            double* t = Ap; Ap = Ap2; Ap2 = t;
+            t = Vtp; Vtp = Vtp2; Vtp2 = t;
+            ++nperm;
+         }
          for (int r = -1; r < nbp - 1; ++r)
          {
             /* r = -1: the pairs inside the blocks (pairing of round 0); r >= 0: the cross pairs of the block pairs of round r */
