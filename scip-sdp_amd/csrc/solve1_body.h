@@ -178,10 +178,6 @@ __device__ __forceinline__ double s1_dpp(double v)
    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
    return __hiloint2double(hi, lo);
 }
-/* a loaded value is needed HERE, whatever the selects behind it say: without it the compiler sinks a load whose value is only used
- * under a condition into a branch of its own - eight loads of a panel or of a block of substitution steps then wait for LDS one
- * after the other (19 branches and 16 full waits per block of s1_llt_solve2, 1000 cycles) instead of being in flight together */
-#define S1_PIN(x) asm volatile("" : "+v"(x))
 __device__ __forceinline__ double s1_lane(double v, int l)
 {
    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
@@ -415,19 +411,9 @@ __device__ __forceinline__ int s1_cholp(double* A, int n, int p, int lane, bool 
          S1_WSYNC();
       }
       double a[8];
-      {
-         /* (all eight loads in flight together, from a row that exists: S1_PIN) */
-         const double* rowp = A + min(lane, n - 1) * p + k0;
 #pragma unroll
-         for (int u = 0; u < 8; ++u)
-            a[u] = rowp[u];
-#pragma unroll
-         for (int u = 0; u < 8; ++u)
-            S1_PIN(a[u]);
-#pragma unroll
-         for (int u = 0; u < 8; ++u)
-            a[u] = (lane >= k0 + u && lane < n && k0 + u < n) ? a[u] : 0.0;
-      }
+      for (int u = 0; u < 8; ++u)
+         a[u] = (lane >= k0 + u && lane < n && k0 + u < n) ? A[lane * p + k0 + u] : 0.0;
 #pragma unroll
       for (int u = 0; u < 8; ++u)
       {
@@ -578,21 +564,13 @@ __device__ __forceinline__ void s1_cholp2_cols(s1_ldsd* A, int n, int k0, int la
    for (int u = 0; u < 8; ++u)
    {
       const int col = k0 + u;
-      /* (from columns that exist, all in flight together - S1_PIN -, masked behind) */
-      a[u] = HI ? 0.0 : A[r0 + min(col, lane)];
-      b[u] = A[r1 + min(col, rowb)];
-   }
-#pragma unroll
-   for (int u = 0; u < 8; ++u)
-   {
-      S1_PIN(a[u]); S1_PIN(b[u]);
-   }
-#pragma unroll
-   for (int u = 0; u < 8; ++u)
-   {
-      const int col = k0 + u;
-      a[u] = (!HI && lane >= col && col < n) ? a[u] : 0.0;
-      b[u] = (has1 && rowb >= col && col < n) ? b[u] : 0.0;
+      /* (loads under their masks.  Unconditional loads from clamped columns with a select behind them: wrong factors; the same with
+       * the loaded values pinned by an empty asm in front of the selects: right on every test and 6 % faster at m = 105 - the
+       * compiler sinks a masked load into a branch of its own with a full LDS wait -, but the -DS1_DEBUG build of that source then
+       * walked other iterates than the release build, whatever the poison value: a difference in generated code, not a read of
+       * uninitialised memory.  A form whose debug build disagrees is not shipped) */
+      a[u] = (!HI && lane >= col && col < n) ? A[r0 + col] : 0.0;
+      b[u] = (has1 && rowb >= col && col < n) ? A[r1 + col] : 0.0;
    }
 #pragma unroll
    for (int u = 0; u < 8; ++u)
@@ -762,19 +740,10 @@ __device__ __attribute__((noinline)) void s1_llt_solve2(const double* Lg, int m_
 #pragma unroll
          for (int u = 0; u < 8; ++u)
          {
-            c[u] = row[min(k0 + u, lane)];
-            ch[u] = rowh[min(k0 + u, rh)];
-         }
-#pragma unroll
-         for (int u = 0; u < 8; ++u)
-         {
-            S1_PIN(c[u]); S1_PIN(ch[u]);
-         }
-#pragma unroll
-         for (int u = 0; u < 8; ++u)
-         {
-            c[u] = (k0 + u < lane) ? c[u] : 0.0;
-            ch[u] = (has1 && k0 + u < rh) ? ch[u] : 0.0;
+            const double v = row[min(k0 + u, lane)];
+            c[u] = (k0 + u < lane) ? v : 0.0;
+            const double vh = rowh[min(k0 + u, rh)];
+            ch[u] = (has1 && k0 + u < rh) ? vh : 0.0;
          }
          if ( k0 >= 64 )
             s1_llt_steps2<TWO, true, true>(c, ch, k0, di0, di1, a0, a0h, a1, a1h);
@@ -794,20 +763,10 @@ __device__ __attribute__((noinline)) void s1_llt_solve2(const double* Lg, int m_
          {
             const int rr = (k0 + u < m) ? k0 + u : 0;
             const s1_ldsd* rp = L + S1_PKROW(rr);
-            c[u] = rp[min(lane, rr)];
-            ch[u] = rp[min(rh, rr)];
-         }
-#pragma unroll
-         for (int u = 0; u < 8; ++u)
-         {
-            S1_PIN(c[u]); S1_PIN(ch[u]);
-         }
-#pragma unroll
-         for (int u = 0; u < 8; ++u)
-         {
-            const int rr = (k0 + u < m) ? k0 + u : 0;
-            c[u] = rr > lane ? c[u] : 0.0;
-            ch[u] = (has1 && rr > rh) ? ch[u] : 0.0;
+            const double v = rp[min(lane, rr)];
+            c[u] = rr > lane ? v : 0.0;
+            const double vh = rp[min(rh, rr)];
+            ch[u] = (has1 && rr > rh) ? vh : 0.0;
          }
          if ( k0 >= 64 )
             s1_llt_steps2<TWO, true, false>(c, ch, k0, di0, di1, a0, a0h, a1, a1h);
@@ -2500,6 +2459,8 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
       anybig = anybig || (!S1_ALLU && L.n[k] > S1U_MAXN);
 
    int status = HS_S1_ITERLIM;
+
+   int numwhere = 0;             /* source line of the test that gave up numerically (out[44]; developer trace) */
    int certwait = 0, nstall = 0, sincebest = 0, chol_fail = 0, pre_valid = 0;
    double lastmu = 1e300, alpha_last = 1.0, bestmerit = 1e300, pre_scale = 0.0;
    double mu = 0, pinf = 0, dinf = 0, dabs_ = 0, gap = 0, pobj = 0, dobj = 0;
@@ -2899,7 +2860,7 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
       S1_STAMP(2);
       if ( !(fabs(mu) < 1e300) || !(pinf < 1e300) || !(dinf < 1e300) )
       {
-         status = HS_S1_NUMERIC;
+         status = HS_S1_NUMERIC; numwhere = __LINE__;
          break;
       }
       /* preoptimal iterate (capture rule of sdpisolver_dsdp.c:323-358) */
@@ -2984,7 +2945,7 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
       {
          if ( ++nstall >= stall_lim )
          {
-            status = HS_S1_NUMERIC;
+            status = HS_S1_NUMERIC; numwhere = __LINE__;
             break;
          }
       }
@@ -3003,7 +2964,7 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
          }
          else if ( ++sincebest >= nobest_lim )
          {
-            status = HS_S1_NUMERIC;
+            status = HS_S1_NUMERIC; numwhere = __LINE__;
             break;
          }
       }
@@ -3029,7 +2990,7 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
          const int ff = trial_factor(0.0, false);
          if ( ff != 0 )
          {
-            status = HS_S1_NUMERIC;
+            status = HS_S1_NUMERIC; numwhere = __LINE__;
             break;
          }
       }
@@ -3305,7 +3266,7 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
       S1_STAMP(6);
       if ( sh.fl[7] )
       {
-         status = HS_S1_NUMERIC;
+         status = HS_S1_NUMERIC; numwhere = __LINE__;
          break;
       }
       /* B_k = A_0 - sum w_i A_i, beta = c - D w; H of the predictor = -X - sym(X Rd Zinv) -> dX, hl */
@@ -3375,7 +3336,7 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
       const double dta = sh.sc[SC_DTAU], dka = sh.sc[SC_DKAPPA];
       if ( !(fabs(dta) < 1e300) || !(fabs(dka) < 1e300) )
       {
-         status = HS_S1_NUMERIC;
+         status = HS_S1_NUMERIC; numwhere = __LINE__;
          break;
       }
       make_dZ();
@@ -3419,7 +3380,7 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
       S1_STAMP(8);
       if ( !(aa == aa) )
       {
-         status = HS_S1_NUMERIC;
+         status = HS_S1_NUMERIC; numwhere = __LINE__;
          break;
       }
       sigma = (1.0 - aa) * (1.0 - aa) * (1.0 - aa);
@@ -3456,7 +3417,7 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
       const double dt = sh.sc[SC_DTAU], dk = sh.sc[SC_DKAPPA];
       if ( !(fabs(dt) < 1e300) || !(fabs(dk) < 1e300) )
       {
-         status = HS_S1_NUMERIC;
+         status = HS_S1_NUMERIC; numwhere = __LINE__;
          break;
       }
       make_dZ();
@@ -3509,7 +3470,7 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
       double alpha = fmin(1.0, gamma_eff * amax);
       if ( !(alpha == alpha) || !(fabs(alpha) < 1e300) )
       {
-         status = HS_S1_NUMERIC;
+         status = HS_S1_NUMERIC; numwhere = __LINE__;
          break;
       }
       if ( P.hist != NULL && tid == 0 && it < P.hist_len )
@@ -3533,7 +3494,7 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
       }
       if ( !accepted )
       {
-         status = HS_S1_NUMERIC;
+         status = HS_S1_NUMERIC; numwhere = __LINE__;
          factors_valid = false;
          break;
       }
@@ -3611,6 +3572,7 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
          out[18 + i] = sh.prof[i];
       out[40] = (double) sh.fl[2]; out[41] = (double) sh.fl[3];
       out[42] = (double) (((size_t) (void*) sh.blk[0].vval) >> 32);
+      out[44] = (double) numwhere;
       out[0] = (double) status;
       __threadfence_system();
       if ( P.flag != NULL )

@@ -23,6 +23,8 @@ for seed in [int(a) for a in sys.argv[1:]]:
         print("  HIPSDP_SOLVE1=%s: path %d status %d it %d dobj %.10g" % (path, s.solve_path(), info.status, info.iterations, info.dobj))
         if path == "1" and s.solve_path() == 1:
             out, hist = s.solve1_trace(40)
+            if info.status == 5:
+                print("   the kernel gave up at csrc/solve1_body.h:%d" % int(out[44]))
             print("   it        mu      pinf      dinf       gap       tau     kappa | pred.step   step      dtau   lin.res   forced      |dy|  || oracle: mu pinf dinf gap tau")
             for r in hist[:info.iterations + 1]:
                 it = int(r[0])
