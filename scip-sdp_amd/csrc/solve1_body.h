@@ -559,18 +559,20 @@ __device__ __forceinline__ void s1_cholp2_cols(s1_ldsd* A, int n, int k0, int la
 {
    const double regtol = 1e-13;
    const int rowb = has1 ? lane + 64 : lane;           /* (the row r1 points to) */
+   const int zi = ((n + 1) * (n + 2)) >> 1;            /* first of the sixteen zeros behind the packed triangle */
    double a[8], b[8];
 #pragma unroll
    for (int u = 0; u < 8; ++u)
    {
       const int col = k0 + u;
-      /* (loads under their masks.  Unconditional loads from clamped columns with a select behind them: wrong factors; the same with
-       * the loaded values pinned by an empty asm in front of the selects: right on every test and 6 % faster at m = 105 - the
-       * compiler sinks a masked load into a branch of its own with a full LDS wait -, but the -DS1_DEBUG build of that source then
-       * walked other iterates than the release build, whatever the poison value: a difference in generated code, not a read of
-       * uninitialised memory.  A form whose debug build disagrees is not shipped) */
-      a[u] = (!HI && lane >= col && col < n) ? A[r0 + col] : 0.0;
-      b[u] = (has1 && rowb >= col && col < n) ? A[r1 + col] : 0.0;
+      /* Every load unconditional, its ADDRESS selected between the entry and a zero behind the triangle: nothing to mask, the
+       * same values exactly, and nothing for the compiler to sink - a load under a mask (`cond ? A[i] : 0.0`) became a branch of
+       * its own with a full LDS wait, sixteen in a row per panel.  [Two other forms on the way: loads from clamped columns with a
+       * select behind them gave wrong factors; the same with the values pinned by an empty asm was right on every test and as
+       * fast as this one, but - inlined into the kernel through s1_cholp as well - its -DS1_DEBUG build walked other iterates
+       * than the release build, whatever the poison value: not shipped.  DESIGN 7.6] */
+      a[u] = HI ? 0.0 : A[(lane >= col && col < n) ? r0 + col : zi];
+      b[u] = A[(has1 && rowb >= col && col < n) ? r1 + col : zi];
    }
 #pragma unroll
    for (int u = 0; u < 8; ++u)
@@ -729,10 +731,9 @@ __device__ __attribute__((noinline)) void s1_llt_solve2(const double* Lg, int m_
    double a0 = r0[lane], a0h = has1 ? r0[lane + 64] : 0.0;
    double a1 = TWO ? r1[lane] : 0.0, a1h = (TWO && has1) ? r1[lane + 64] : 0.0;
    const int nb = (m + 7) >> 3;
+   const int zi = ((m + 1) * (m + 2)) >> 1;            /* first of the sixteen zeros behind the packed triangle */
    {
       /* this lane's rows, columns k0 .. k0 + 7: only the strictly lower part exists */
-      const s1_ldsd* row = L + S1_PKROW(lane);
-      const s1_ldsd* rowh = L + S1_PKROW(rh);
       for (int b = 0; b < nb; ++b)
       {
          const int k0 = 8 * b;
@@ -740,10 +741,9 @@ __device__ __attribute__((noinline)) void s1_llt_solve2(const double* Lg, int m_
 #pragma unroll
          for (int u = 0; u < 8; ++u)
          {
-            const double v = row[min(k0 + u, lane)];
-            c[u] = (k0 + u < lane) ? v : 0.0;
-            const double vh = rowh[min(k0 + u, rh)];
-            ch[u] = (has1 && k0 + u < rh) ? vh : 0.0;
+            /* (unconditional loads, the address selected between the entry and a zero behind the triangle: see s1_cholp2_cols) */
+            c[u] = L[(k0 + u < lane) ? S1_PKROW(lane) + k0 + u : zi];
+            ch[u] = L[(has1 && k0 + u < rh) ? S1_PKROW(rh) + k0 + u : zi];
          }
          if ( k0 >= 64 )
             s1_llt_steps2<TWO, true, true>(c, ch, k0, di0, di1, a0, a0h, a1, a1h);
@@ -762,11 +762,8 @@ __device__ __attribute__((noinline)) void s1_llt_solve2(const double* Lg, int m_
          for (int u = 0; u < 8; ++u)
          {
             const int rr = (k0 + u < m) ? k0 + u : 0;
-            const s1_ldsd* rp = L + S1_PKROW(rr);
-            const double v = rp[min(lane, rr)];
-            c[u] = rr > lane ? v : 0.0;
-            const double vh = rp[min(rh, rr)];
-            ch[u] = (has1 && rr > rh) ? vh : 0.0;
+            c[u] = L[rr > lane ? S1_PKROW(rr) + lane : zi];
+            ch[u] = L[(has1 && rr > rh) ? S1_PKROW(rr) + rh : zi];
          }
          if ( k0 >= 64 )
             s1_llt_steps2<TWO, true, false>(c, ch, k0, di0, di1, a0, a0h, a1, a1h);
