@@ -1934,6 +1934,21 @@ __global__ void k_bjac_permute(int n, int N, const int* __restrict__ perm, const
 }
 
 #define BJ_OFFBLOCKS 256
+/* the convergence test of a sweep reads two sums back: into PINNED memory of the calling thread.  [Into a stack array the copy is
+ * staged by the runtime and blocks: 150-290 us per sweep where the kernels of a sweep at n = 200 take 450 - a quarter of every
+ * decomposition above 128 rows, 3 of the 13.6 ms of a PSD projection at n = 200.] */
+static double* bj_readback_buffer()
+{
+   static thread_local double* buf = NULL;
+   if ( buf == NULL )
+   {
+      void* p = NULL;
+      if ( hipHostMalloc(&p, 2 * BJ_OFFBLOCKS * sizeof(double), hipHostMallocPortable) != hipSuccess )
+         return NULL;
+      buf = static_cast<double*>(p);
+   }
+   return buf;
+}
 static int bj_padded(int n) { const int nb = (n + BJ_B - 1) / BJ_B; return ((nb + 1) & ~1) * BJ_B; }
 
 long long hs_syev_ws(int n)
@@ -1975,12 +1990,14 @@ int hs_syev_jacobi(hipStream_t s, int n, double* A, double* lam, double* V, int*
       int inner0 = 1, inner = 1;               /* inner sweeps of a subproblem: first outer sweep (dense subproblems), later ones */
       if ( getenv("HIPSDP_BJ_INNER") != NULL )
          (void) sscanf(getenv("HIPSDP_BJ_INNER"), "%d,%d", &inner0, &inner);
+      double* const h = bj_readback_buffer();
+      if ( h == NULL )
+         return HS_ERR_HIP;
       for (sweeps_b = 0; sweeps_b < 40; ++sweeps_b)
       {
-         double h[2 * BJ_OFFBLOCKS];
          hipLaunchKernelGGL(k_bjac_offnorm, dim3(BJ_OFFBLOCKS), dim3(256), 0, s, N, Ap, part);
          HS_LAUNCH_CHECK();
-         HS_HIP( hipMemcpyAsync(h, part, sizeof(h), hipMemcpyDeviceToHost, s) );
+         HS_HIP( hipMemcpyAsync(h, part, 2 * BJ_OFFBLOCKS * sizeof(double), hipMemcpyDeviceToHost, s) );
          HS_HIP( hipStreamSynchronize(s) );
          double off = 0.0, dg = 0.0;
          for (int b = 0; b < BJ_OFFBLOCKS; ++b) { off += h[2 * b]; dg += h[2 * b + 1]; }
@@ -2039,9 +2056,11 @@ int hs_syev_jacobi(hipStream_t s, int n, double* A, double* lam, double* V, int*
       const long long work = 2LL * half * half;
       int grid = (int) ((work + 255) / 256);
       if ( grid > 4096 ) grid = 4096;
+      double* const h = bj_readback_buffer();
+      if ( h == NULL )
+         return HS_ERR_HIP;
       for (sweeps = 0; sweeps < 30; ++sweeps)
       {
-         double h[2];
          hipLaunchKernelGGL(k_jacobi_offnorm, dim3(1), dim3(1024), 0, s, n, A, nrm);
          HS_LAUNCH_CHECK();
          HS_HIP( hipMemcpyAsync(h, nrm, 2 * sizeof(double), hipMemcpyDeviceToHost, s) );
