@@ -2899,11 +2899,11 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       HS_HIP( hipMemcpy2DAsync(s->tmpq, sizeof(double), s->Dext, (size_t) m1 * sizeof(double), sizeof(double), (size_t) q, hipMemcpyDeviceToDevice, st) );
       HS_CALL( hs_dot(st, q, s->tmpq, s->tmpq, s->sc + 1, 1, s->red_ws) );
    }
-   double h2[2];
-   HS_HIP( hipMemcpyAsync(h2, s->sc, 2 * sizeof(double), hipMemcpyDeviceToHost, st) );
+   /* (into the pinned mirror of the scalars: a copy into a stack variable is staged by the runtime and blocks) */
+   HS_HIP( hipMemcpyAsync(s->hsc, s->sc, 2 * sizeof(double), hipMemcpyDeviceToHost, st) );
    HS_HIP( hipStreamSynchronize(st) );
-   const double normb = sqrt(h2[0]);
-   const double normC = sqrt(h2[1]);
+   const double normb = sqrt(s->hsc[0]);
+   const double normC = sqrt(s->hsc[1]);
 
    /* ---- starting point */
    /* cold start: X = Z = xi I in every block until the first step - the first Schur complement is then the Gram matrix of the
@@ -2939,9 +2939,11 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       }
       int f4[4];
       double xz = 0.0;
-      HS_HIP( hipMemcpyAsync(f4, s->flags, 4 * sizeof(int), hipMemcpyDeviceToHost, st) );
-      HS_HIP( hipMemcpyAsync(&xz, s->sc + SC_XZ, sizeof(double), hipMemcpyDeviceToHost, st) );
+      HS_HIP( hipMemcpyAsync(s->hsc + 4, s->flags, 4 * sizeof(int), hipMemcpyDeviceToHost, st) );
+      HS_HIP( hipMemcpyAsync(s->hsc + 8, s->sc + SC_XZ, sizeof(double), hipMemcpyDeviceToHost, st) );
       HS_HIP( hipStreamSynchronize(st) );
+      memcpy(f4, s->hsc + 4, sizeof(f4));
+      xz = s->hsc[8];
       const double mu0 = xz / (double) (N > 0 ? N : 1);
       if ( f4[0] == 0 && f4[1] == 0 && f4[3] == 0 && std::isfinite(mu0) && mu0 > 0.0 )
       {
