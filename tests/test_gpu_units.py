@@ -369,6 +369,9 @@ def test_persistent_gemm_matches_tile_gemm_bitwise(gpu, M, N, K, layB, batch, sp
     (760, 760, 760, 1, 16, GEMM_A_LOWTRI | GEMM_REMAP, 1.0, 0.0),
     (896, 896, 896, 1, 12, GEMM_A_LOWTRI | GEMM_REMAP, 1.0, 0.0),
     (1100, 1100, 1100, 1, 9, GEMM_A_LOWTRI | GEMM_REMAP, 1.0, 0.0),
+    (6000, 2048, 2048, 1, 1, GEMM_B_LOWTRI, 1.0, 0.0),                  # sixteen panels: four whole sets (n = 2000 is BASELINE configs[3])
+    (2048, 2048, 2048, 1, 3, GEMM_A_LOWTRI | GEMM_REMAP, 1.0, 0.0),
+    (3000, 4100, 4100, 1, 1, GEMM_B_LOWTRI, 1.0, 0.0),                  # 33 panels, the last set a single one
     (100, 100, 100, 1, 500, GEMM_A_LOWTRI | GEMM_REMAP, 1.0, 0.0),      # one panel
     (250, 250, 250, 1, 120, GEMM_A_LOWTRI | GEMM_REMAP, 1.0, 0.0),      # two panels, lists shorter than the re-ordered tail
 ])
