@@ -651,7 +651,9 @@ __device__ __forceinline__ bool g5_decode_sets(long long idx, long long base, lo
    if ( !ok )
       idx = 0;
    const int nv = TRI == 1 ? tn : tm;
-   const long long U = TRI == 1 ? Tx / tn : (Tx / ntile) * tn;       /* panels of the streamed operand in this list */
+   long long U = TRI == 1 ? Tx / tn : (Tx / ntile) * tn;             /* panels of the streamed operand in this list */
+   if ( U < 1 )
+      U = 1;                    /* (an XCD whose share is empty: nothing below is used, but nothing divides by zero either) */
    const int nset = (nv + 3) >> 2;
    const int szl = nv - 4 * (nset - 1);                             /* members of the last set */
    long long ngt = tailwant / szl;

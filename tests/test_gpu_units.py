@@ -372,6 +372,7 @@ def test_persistent_gemm_matches_tile_gemm_bitwise(gpu, M, N, K, layB, batch, sp
     (6000, 2048, 2048, 1, 1, GEMM_B_LOWTRI, 1.0, 0.0),                  # sixteen panels: four whole sets (n = 2000 is BASELINE configs[3])
     (2048, 2048, 2048, 1, 3, GEMM_A_LOWTRI | GEMM_REMAP, 1.0, 0.0),
     (3000, 4100, 4100, 1, 1, GEMM_B_LOWTRI, 1.0, 0.0),                  # 33 panels, the last set a single one
+    (1000, 1000, 1000, 1, 7, GEMM_A_LOWTRI | GEMM_REMAP, 1.0, 0.0),     # 7 x 64 items in whole batch entries: the eighth XCD's share is empty
     (100, 100, 100, 1, 500, GEMM_A_LOWTRI | GEMM_REMAP, 1.0, 0.0),      # one panel
     (250, 250, 250, 1, 120, GEMM_A_LOWTRI | GEMM_REMAP, 1.0, 0.0),      # two panels, lists shorter than the re-ordered tail
 ])
