@@ -366,7 +366,8 @@ __device__ __forceinline__ double s1_sqrt(double x)
  * psd: semidefinite pivot rule of oracle/ipm_ref.chol_psd (dg0 = this lane's original diagonal entry).  keepdiag = false: the
  * stored factor has a ZERO diagonal and zero upper triangle (what the substitutions below want), the diagonal entry of row
  * `lane` is returned in mydiag.  Returns 0 or 1 + index of the first non-positive pivot (definite mode). */
-__device__ __forceinline__ int s1_cholp(double* A, int n, int p, int lane, bool psd, double dg0, int rule, bool keepdiag, double& mydiag, int& nforced)
+__device__ __forceinline__ int s1_cholp(double* A, int n, int p, int lane, bool psd, double dg0, int rule, bool keepdiag, double& mydiag, int& nforced,
+   const double* zp)
 {
    const double regtol = 1e-13;
    const int lr = lane & 15, kq = lane >> 4;
@@ -411,9 +412,19 @@ __device__ __forceinline__ int s1_cholp(double* A, int n, int p, int lane, bool 
          S1_WSYNC();
       }
       double a[8];
+#if S1_MBIG
+      /* (the instance for m > 64 keeps the loads under their masks: with unconditional loads in THIS function its -DS1_DEBUG
+       * build walked other iterates than its release build on blocks of 11-14 rows - DESIGN 7.6) */
 #pragma unroll
       for (int u = 0; u < 8; ++u)
          a[u] = (lane >= k0 + u && lane < n && k0 + u < n) ? A[lane * p + k0 + u] : 0.0;
+#else
+      /* unconditional loads, the ADDRESS selected between the entry and zp - an LDS word that holds 0.0 and is never written: a
+       * load under a mask becomes a branch of its own with a full LDS wait, eight in a row here (see s1_cholp2_cols) */
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+         a[u] = *((lane >= k0 + u && lane < n && k0 + u < n) ? (const double*) (A + lane * p + k0 + u) : zp);
+#endif
 #pragma unroll
       for (int u = 0; u < 8; ++u)
       {
@@ -1737,6 +1748,9 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
    /* row i of the extended Schur matrix starts at Mx + MROW(i): a packed lower triangle in the instance for m > 64 */
    const bool mpk = S1_MBIG && L.packedM;
 #define MROW(i) (mpk ? ((i) * ((i) + 1)) >> 1 : (i) * pm1)
+   /* an LDS word that holds 0.0 from the start of the solve and is never written: entry (0, 1) of the full extended matrix (its
+    * upper triangle), the first spare word behind the packed one */
+   const double* const zsrc = mpk ? Mx + ((m1 * (m1 + 1)) >> 1) : Mx + 1;
 #define VEC(id) (sm + oVec + (id) * VL)
 #define QV(id) (sm + oQ + (id) * QL)
    double* const out = P.out;
@@ -2350,7 +2364,7 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
          double dummy; int nfd;
          /* (blocks of at most S1U_MAXN rows: factor and inverse factor in one go, every lane for itself) */
          const int f = (S1_ALLU || B.n <= S1U_MAXN) ? s1u_chol_inv_n(sm + ((t & 1) ? B.oLz : B.oLx), B.n, B.p, lane)
-            : s1_cholp(sm + ((t & 1) ? B.oLz : B.oLx), B.n, B.p, lane, false, 1.0, 0, true, dummy, nfd);
+            : s1_cholp(sm + ((t & 1) ? B.oLz : B.oLx), B.n, B.p, lane, false, 1.0, 0, true, dummy, nfd, zsrc);
          if ( lane == 0 )
             sh.fl[8 + t] = f;
       }
@@ -3216,7 +3230,7 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
          if ( !coop )
          {
             const double dg0 = (lane < m) ? Lm[lane * pm + lane] : 1.0;
-            (void) s1_cholp(Lm, m, pm, lane, true, dg0, P.pivot_rule, false, mdiag, nforced);
+            (void) s1_cholp(Lm, m, pm, lane, true, dg0, P.pivot_rule, false, mdiag, nforced, zsrc);
          }
          if ( lane == 0 )
             sh.fl[6] = nforced;
