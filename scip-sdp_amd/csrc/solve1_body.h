@@ -1394,6 +1394,20 @@ __device__ __forceinline__ double s1_lmin(double* W, int n, int p, int lane, dou
       {
          double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
          int c = k + 1;
+         /* (eight columns per round trip to LDS - sixteen loads in flight - where four were: the same sums in the same order, the
+          * second four go to the accumulators after the first) */
+         for (; c + 7 < n; c += 8)
+         {
+            double ev[8], vc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+            {
+               ev[u] = W[(c + u <= lane) ? lane * p + c + u : (c + u) * p + lane];
+               vc[u] = vv[c + u];
+            }
+            a0 = fma(ev[0], vc[0], a0); a1 = fma(ev[1], vc[1], a1); a2 = fma(ev[2], vc[2], a2); a3 = fma(ev[3], vc[3], a3);
+            a0 = fma(ev[4], vc[4], a0); a1 = fma(ev[5], vc[5], a1); a2 = fma(ev[6], vc[6], a2); a3 = fma(ev[7], vc[7], a3);
+         }
          for (; c + 3 < n; c += 4)
          {
             double ev[4], vc[4];
@@ -1429,6 +1443,18 @@ __device__ __forceinline__ double s1_lmin(double* W, int n, int p, int lane, dou
       {
          double* rl = W + lane * p;
          int c = k + 1;
+         for (; c + 7 <= lane; c += 8)
+         {
+            double r8[8], w8[8], v8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+            {
+               r8[u] = rl[c + u]; w8[u] = ww[c + u]; v8[u] = vv[c + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+               rl[c + u] = r8[u] - (vl * w8[u] + wl * v8[u]);
+         }
          for (; c + 3 <= lane; c += 4)
          {
             double r4[4], w4[4], v4[4];
