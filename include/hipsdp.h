@@ -161,6 +161,7 @@ HIPSDP_API int  hipsdp_solve(hipsdp_solver* solver, const hipsdp_params* params,
 HIPSDP_API int  hipsdp_solve_path(hipsdp_solver* solver);
 HIPSDP_API long long hipsdp_solve1_solves(void);      /* solves of this process served by the one launch so far */
 HIPSDP_API long long hipsdp_solve1_fallbacks(void);   /* cold solves the one-launch kernel gave up on numerically and the general path solved again */
+HIPSDP_API long long hipsdp_solve1_fallbacks_warm(void);   /* ... of these: warm-started solves, retried on the general path from the caller's start point */
 /* library built with -DS1_DEBUG (developer build of the one-launch kernel: NaN-poisoned LDS and workspace, full fences, wave-uniformity
  * checks; csrc/solve1_body.h): counts[0] = values declared wave-uniform that were not, counts[1] = solves the kernel ran.  Returns 1
  * in such a build, 0 in a release build (counts zero) */

@@ -12,14 +12,14 @@
  *    of 32.  Both operands are the same 128 rows of W: only one operand image is loaded.  The code is the same for all wavefronts:
  *    the B fragment of accumulator k comes from an LDS address that depends on w, its A fragment is chosen between the two row
  *    slabs by a wave-uniform select;
- *  - the HOST cuts the product into items (tile, K range) once per shape and writes them as eight lists, one per XCD, into a small
- *    table; the 64 workgroups of an XCD TAKE entries of their list one by one (atomic counter).  Two forms, the one with the
- *    shorter estimated time is taken (gr_plan): (A) few tiles: every tile in equal K slices, the diagonal tiles in fewer, longer
- *    ones (m = 1000: 28 x 15 + 8 x 9 = 492 items, one per workgroup, where 36 x 14 whole tiles were 504), sorted by their start in
- *    K so that an XCD's workgroups read the same rows of W at about the same K (once from HBM, then from that XCD's L2, as
- *    before); (B) many tiles: K in 8 ranges, one per XCD, each in S sub-slices, an XCD's list in sub-slice order - whoever finishes a
- *    cheap diagonal item takes the next entry.  Partial tiles go to slabs and are summed in slab order by a second kernel
- *    (bitwise reproducible: which workgroup computes an item does not matter).
+ *  - the HOST cuts the product into items (tile, K range) once per shape and deals them out as STATIC lists, one per workgroup
+ *    (items g.off[wg] .. g.off[wg + 1] of a small table in device memory; longest-processing-time scheduling within each XCD's
+ *    share, gr_make_plan) - the kernel contains no atomic and takes nothing dynamically.  Every tile is cut into equal K slices,
+ *    the diagonal tiles into fewer, longer ones (m = 1000: 28 x 15 + 8 x 9 = 492 items, one per workgroup, where 36 x 14 whole
+ *    tiles were 504), sorted by their start in K so that an XCD's workgroups read the same rows of W at about the same K (once
+ *    from HBM, then from that XCD's L2, as before).  Plans with more than one item per workgroup are built by the same code but
+ *    not taken by default (the lists of an XCD's workgroups drift apart in K, gr_plan).  Partial tiles go to slabs and are
+ *    summed in slab order by a second kernel (bitwise reproducible: the order of the sum is fixed by the plan).
  * Stage loop, LDS images and counted waits as in dgemm2.hip (two halves per stage, the DMA placed by hand behind the first matrix
  * instructions of the second half); no request crosses an item boundary.
  */
@@ -571,6 +571,8 @@ GramPlan* gr_plan(int M, long long K, int nslab)
          || hipMalloc((void**) &doff, 513 * sizeof(int)) != hipSuccess
          || hipMemcpy(doff, best->off.data(), 513 * sizeof(int), hipMemcpyHostToDevice) != hipSuccess )
       {
+         if ( d != NULL ) (void) hipFree(d);
+         if ( doff != NULL ) (void) hipFree(doff);
          delete best;
          return NULL;
       }

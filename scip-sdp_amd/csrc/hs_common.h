@@ -98,8 +98,8 @@ int hs_dgemm2_try(hipStream_t stream, const hs_gemm_args* args, int kchunk);
 int hs_dgemm2_enable(int on);
 
 /* the Gram product of the Schur assembly (gram.hip): C (M x M, lower triangle) = alpha W W^T + beta C with W [M][K] K contiguous,
- * through nslab >= 8 slabs of M x M doubles at ws; diagonal tiles at 9 / 16 of the matrix instructions, list entries taken
- * dynamically per XCD.  1: done, 0: not eligible (the caller takes hs_dgemm with HS_GEMM_LOWER), < 0: error code negated */
+ * through nslab >= 8 slabs of M x M doubles at ws; diagonal tiles at 9 / 16 of the matrix instructions, a static list of items per
+ * workgroup built on the host (no atomics).  1: done, 0: not eligible (the caller takes hs_dgemm with HS_GEMM_LOWER), < 0: error code negated */
 int hs_gram_try(hipStream_t stream, int M, long long K, const double* W, long long ldw, double* C, long long ldc, double alpha, double beta,
    double* ws, int nslab, double* executed);
 int hs_gram_enable(int on);

@@ -382,6 +382,7 @@ struct hs_solve1_args
    double elapsed0;                        /* seconds of the time limit already used when the kernel starts */
    double maxwork;                         /* decline above this many multiply-adds per Schur assembly */
    int maxiter, settings, have_start, pivot_rule, prof_on, hist_len;
+   int keep_on_fail;                       /* 1: on a numerical failure leave y, x, z, X, Z as they were handed in (the general path retries from them) */
    double* gws; long long gws_len;         /* workspace in device memory (hs_solve1_ws_doubles) */
    double* out;                            /* HS_S1_OUT_DOUBLES result scalars (device-visible; pinned host memory works) */
    double* hist;                           /* optional: 16 doubles per iteration (tests, tools) */

@@ -2593,6 +2593,7 @@ extern "C" int hipsdp_get_assembly_clock(hipsdp_solver* s, double* ghz)
 #define S1_HOST_DOUBLES (S1_SOL_OFF + 128 + 2 * 4096)
 static long long g_solve1_solves = 0;      /* solves of this process that ran in the one launch (bench.py reports the share) */
 static long long g_solve1_fallbacks = 0;   /* ... that the kernel gave up on numerically and the general path solved again */
+static long long g_solve1_fallbacks_warm = 0;   /* ... of these: warm-started solves (retried from the caller's start) */
 static int solve1_try(hipsdp_solver* s, hipsdp_info* info, bool* done)
 {
    *done = false;
@@ -2690,6 +2691,8 @@ static int solve1_try(hipsdp_solver* s, hipsdp_info* info, bool* done)
       a.pivot_rule = env != NULL ? atoi(env) : 3;
    }
    a.prof_on = prof;
+   const int nofb = (getenv("HIPSDP_SOLVE1_NO_FALLBACK") != NULL && getenv("HIPSDP_SOLVE1_NO_FALLBACK")[0] == '1') ? 1 : 0;    /* (read at every solve, like the other switches of this path) */
+   a.keep_on_fail = nofb ? 0 : 1;
    a.gws = s->s1_ws; a.gws_len = s->s1_ws_len;
    a.out = s->s1_host_dev;
    a.hist = (getenv("HIPSDP_SOLVE1_HIST") != NULL && getenv("HIPSDP_SOLVE1_HIST")[0] != '0') ? s->s1_host_dev + HS_S1_OUT_DOUBLES + 8 : NULL;
@@ -2733,19 +2736,19 @@ static int solve1_try(hipsdp_solver* s, hipsdp_info* info, bool* done)
    const int status = (int) o[0];
    if ( status == -2 )
       return HS_OK;                              /* declined: the general path takes the problem */
-   /* A numerical failure of the kernel on a cold start is not final: on 4 of 400 random shapes with cond(M) around 1e14
-    * one path gives up where the other converges (profiles/r04_c_solve1_fuzz.txt) - their last steps differ in how the solves with M
-    * are corrected.  The general path solves the problem again from its own start before the caller escalates its settings (a
-    * warm start is consumed by the kernel: its verdict stands).  HIPSDP_SOLVE1_NO_FALLBACK=1 keeps the kernel's failure. */
-   if ( status == HIPSDP_STATUS_NUMERIC && (int) o[12] == 0 )
+   /* A numerical failure of the kernel is not final: on about 1 % of random shapes with cond(M) around
+    * 1e14 one path gives up where the other converges (profiles/r04_c_solve1_fuzz.txt) - their last steps differ in how the solves
+    * with M are corrected.  The general path solves the problem again before the caller escalates its settings, FROM THE SAME START:
+    * with keep_on_fail the kernel has left y, x, z, X, Z in device memory as the node's setters wrote them (a caller's start point
+    * stays in place and have_start stays as it was; without one the general path starts cold as it always does).
+    * HIPSDP_SOLVE1_NO_FALLBACK=1 keeps the kernel's failure (and its last iterate). */
+   if ( status == HIPSDP_STATUS_NUMERIC && nofb == 0 )
    {
-      const bool nofb = getenv("HIPSDP_SOLVE1_NO_FALLBACK") != NULL && getenv("HIPSDP_SOLVE1_NO_FALLBACK")[0] == '1';    /* (read at every solve, like the other switches of this path) */
-      if ( !nofb )
-      {
-         HS_HIP( hipStreamSynchronize(st) );     /* (the kernel may still be writing its last X and Z) */
-         (void) __sync_add_and_fetch(&g_solve1_fallbacks, 1);
-         return HS_OK;
-      }
+      HS_HIP( hipStreamSynchronize(st) );
+      (void) __sync_add_and_fetch(&g_solve1_fallbacks, 1);
+      if ( (int) o[12] != 0 )
+         (void) __sync_add_and_fetch(&g_solve1_fallbacks_warm, 1);
+      return HS_OK;
    }
    /* the result block, y, x and z are in pinned memory, published before the sequence word; X and Z in device memory are complete
     * when the kernel has retired - whoever reads them waits for the queue first (stage_sync), this call does not */
@@ -3114,7 +3117,11 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
 
    /* round 5: the X chain of the factorization phase (triangular inverse of the factor of X) does not depend on the termination
     * scalars either: it is queued behind the kernel that publishes them and runs while the host waits, decides and launches (a
-    * solve that ends here has run it in vain: 0.1 ms at n = 500) */
+    * solve that ends here has run it in vain: 0.1 ms at n = 500).
+    * INVARIANT: the chain is speculative - when the solve ends at this read-back, B.Lx, B.dinvx, B.LxInv, B.T1 and
+    * flags[1] already hold the factors of the FINAL X.  Lx, LxInv, dinvx and T1 are therefore UNDEFINED after solve_impl returns
+    * (nothing reads them: every getter works from X, Z, y; the next solve refactors).  The chain's time is charged to PH_RESID, not
+    * PH_FACTOR, in the phase anatomy (bench.py says so next to those two figures). */
    bool xchain_queued = false;
    const std::function<int()> enqueue_x_chains = [&]() -> int
    {
@@ -3905,6 +3912,11 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
 extern "C" long long hipsdp_solve1_fallbacks(void)
 {
    return __sync_add_and_fetch(&g_solve1_fallbacks, 0);
+}
+
+extern "C" long long hipsdp_solve1_fallbacks_warm(void)
+{
+   return __sync_add_and_fetch(&g_solve1_fallbacks_warm, 0);
 }
 
 extern "C" long long hipsdp_solve1_solves(void)

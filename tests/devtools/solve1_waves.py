@@ -43,3 +43,8 @@ for b in range(60):
 print("sum of the phases of iteration 3: %.0f cycles; %d iterations" % (tot, info.iterations))
 su = hist.reshape(-1)[2048 + 480:2048 + 480 + 16]
 print("setup stamps (cycles since kernel start):", " ".join("%.0f" % v for v in su))
+# per-solve sums of the stamped sections (S1_STAMP ids 1 .. 18: cycles of thread 0 between two stamps, summed over the iterations;
+# 19: Sturm multisection of the first step-length task, 20: factorization of M, 21: the two solves behind it)
+pr = out[18:40]
+print("stamp sums per iteration (cycles):", " ".join("%d:%.0f" % (i, pr[i] / max(1, info.iterations)) for i in range(22) if pr[i] != 0))
+print("kernel cycles %.0f, wall %.1f us, iterations %d" % (out[17], out[43] * 1e-2, info.iterations))

@@ -527,3 +527,18 @@ def test_w_formulation_in_slices_when_the_workspace_is_small(gpu):
         alt = gpu_solve(gpu, core, gaptol=1e-6, feastol=1e-6, ws_gbytes=gb)
         assert alt["info"].status == 0 and alt["info"].iterations == base["info"].iterations
         assert np.max(np.abs(alt["y"] - base["y"])) <= 1e-8
+
+
+def test_identity_start_assembly_with_a_chunked_workspace_smaller_than_two_slabs(gpu):
+    """with a chunked workspace (budget below the whole T, W pair) the split-K slabs hold sk m1 cols doubles, and
+    for m1 > 8 cols that is less than the two m1 x m1 slabs the XCD-sliced Gram product of the cold start's first assembly
+    (M = A A^T) asked for: the product must then go straight into M.  m1 = 1101, cols = 128: 16 * 1101 * 128 < 2 * 1101^2."""
+    b, A, ys, Xs, Zs = instances.planted_dense(128, 1100)
+    core = ipm_ref.CoreProblem(b, [A])
+    base = gpu_solve(gpu, core, gaptol=1e-6, feastol=1e-6)
+    alt = gpu_solve(gpu, core, gaptol=1e-6, feastol=1e-6, ws_gbytes=0.01)
+    assert base["info"].status == 0 and alt["info"].status == 0
+    assert alt["info"].iterations == base["info"].iterations
+    assert np.max(np.abs(alt["y"] - base["y"])) <= 1e-7
+    opt = float(b @ ys)
+    assert abs(alt["info"].dobj - opt) <= 1e-5 * (1 + abs(opt))

@@ -150,10 +150,29 @@ def test_matrix_matrix_product_golden_vector_and_all_transpose_combinations(host
 
 
 def test_sizes_above_the_cutoff_go_to_the_device(hostlib):
-    """n = 129 > the default cutoff of 128: the device entry point is called (the stub fails, the interface reports SCIP_ERROR)"""
-    n = 129
-    A = _sym(n, 9)
+    """The cutoffs follow the measured crossover (lapack_interface_hip.c, host_eigen_cutoff): one eigenpair stays on the host up to 512
+    rows, a full decomposition up to 400; above, the device entry point is called (the stub fails, the interface reports SCIP_ERROR)"""
     val = C.c_double(0.0)
+    # one eigenpair at n = 300: host (DSYEVR RANGE = 'I'), checked against numpy
+    n = 300
+    A = _sym(n, 9)
     before = hostlib.hipsdp_stub_calls()
+    assert hostlib.SCIPlapackComputeIthEigenvalue(None, 0, n, _pd(A.reshape(-1).copy()), 3, C.byref(val), None) == SCIP_OKAY
+    assert abs(val.value - np.linalg.eigvalsh(A)[2]) <= 1e-10 * (1 + np.abs(A).max() * n)
+    assert hostlib.hipsdp_stub_calls() == before
+    # one eigenpair at n = 513: device
+    n = 513
+    A = _sym(n, 10)
     assert hostlib.SCIPlapackComputeIthEigenvalue(None, 0, n, _pd(A.reshape(-1).copy()), 1, C.byref(val), None) != SCIP_OKAY
     assert hostlib.hipsdp_stub_calls() == before + 1
+    # full decomposition: n = 400 host, n = 401 device
+    for n, host in ((400, True), (401, False)):
+        A = _sym(n, 11)
+        lam = np.zeros(n); V = np.zeros(n * n)
+        before = hostlib.hipsdp_stub_calls()
+        rc = hostlib.SCIPlapackComputeEigenvectorDecomposition(None, n, _pd(A.reshape(-1).copy()), _pd(lam), _pd(V))
+        if host:
+            assert rc == SCIP_OKAY and hostlib.hipsdp_stub_calls() == before
+            assert np.max(np.abs(lam - np.linalg.eigvalsh(A))) <= 1e-10 * (1 + np.abs(A).max() * n)
+        else:
+            assert rc != SCIP_OKAY and hostlib.hipsdp_stub_calls() == before + 1
