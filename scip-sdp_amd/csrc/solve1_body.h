@@ -70,14 +70,6 @@
 #ifndef S1_MBIG
 #define S1_MBIG 1
 #endif
-/* round 6: the factorization of M and the substitutions with the diagonal block of a panel in every lane (s1_cholp_r, s1_llt_solve_b);
- * the instances for m <= 64 */
-#ifndef S1_CHOLR
-#define S1_CHOLR (!S1_MBIG)
-#endif
-#ifndef S1_BLKSOLVE
-#define S1_BLKSOLVE (!S1_MBIG)
-#endif
 #define S1_ALLU  (S1_NCLS <= 10)
 #define S1_ALL16 (S1_NCLS <= 16)
 
@@ -94,7 +86,7 @@ enum { SC_TAU = 0, SC_KAPPA, SC_RP2, SC_HP2, SC_DOBJ, SC_BUB, SC_BU1, SC_WRP, SC
 struct S1Lay
 {
    int m, m1, q, K;
-   int pm1, pm, VL, QL, mrows;
+   int pm1, pm, VL, QL;
    int packedM;            /* m > 64: the extended Schur matrix as a packed lower triangle (row i at i (i + 1) / 2) */
    int oMx, oLm, oVec, oQ, oR, Rlen, fixedEnd;
    int n[S1_MAXB], p[S1_MAXB], np[S1_MAXB];
@@ -108,8 +100,7 @@ static __host__ __device__ inline int s1_layout(int m, int q, int K, const int* 
    /* the factor of M overwrites M in place (rows / columns 1 .. m of the extended matrix): the pitch covers column 0 and whole panels
     * of eight columns (the substitutions read them unmasked; the padding stays zero from the start of the solve) */
    L.pm1 = (((m + 7) & ~7) + 1) | 1; L.pm = L.pm1;
-   /* (m <= 64: vectors cover whole panels of eight - the blocked substitutions read entries k0 .. k0 + 7 of them unmasked) */
-   L.VL = m > 64 ? (m + 2) & ~1 : ((m + 7) & ~7) + 2; L.QL = (q + 1) & ~1;
+   L.VL = (m + 2) & ~1; L.QL = (q + 1) & ~1;
    int o = 0, sum = 0;
    for (int k = 0; k < K; ++k)
    {
@@ -124,10 +115,7 @@ static __host__ __device__ inline int s1_layout(int m, int q, int K, const int* 
    /* m > 64 (the instance with two rows per lane): M as a packed lower triangle - 45 instead of 96 KB at m = 105, so that the
     * lists of such a problem find room in LDS again; sixteen doubles behind it for the unmasked reads past the end of the last rows */
    L.packedM = m > 64 ? 1 : 0;
-   /* (m <= 64: rows up to the end of the last panel of eight exist and stay zero - s1_cholp_r and s1_llt_solve_b read the rows of a
-    * panel's diagonal block unmasked) */
-   L.mrows = L.packedM ? L.m1 : ((m + 7) & ~7) + 1;
-   L.oMx = o; o += L.packedM ? (L.m1 * (L.m1 + 1) / 2 + 16 + 1) & ~1 : (L.mrows * L.pm1 + 1) & ~1;
+   L.oMx = o; o += L.packedM ? (L.m1 * (L.m1 + 1) / 2 + 16 + 1) & ~1 : (L.m1 * L.pm1 + 1) & ~1;
    L.oLm = L.oMx + L.pm1 + 1;
    L.oVec = o; o += V_COUNT * L.VL;
    L.oQ = o; o += Q_COUNT * L.QL;
@@ -377,9 +365,12 @@ __device__ __forceinline__ double s1_sqrt(double x)
  * pivots run as a register recurrence - the entries of the pivot row come by v_readlane, no LDS round trip inside a panel.
  * psd: semidefinite pivot rule of oracle/ipm_ref.chol_psd (dg0 = this lane's original diagonal entry).  keepdiag = false: the
  * stored factor has a ZERO diagonal and zero upper triangle (what the substitutions below want), the diagonal entry of row
- * `lane` is returned in mydiag.  Returns 0 or 1 + index of the first non-positive pivot (definite mode). */
+ * `lane` is returned in mydiag.  Returns 0 or 1 + index of the first non-positive pivot (definite mode).  hook(j) is called before
+ * panel j = 1, 2, .. is touched (default: nothing). */
+struct S1NoHook { __device__ __forceinline__ void operator()(int) const {} };
+template<class HOOK = S1NoHook>
 __device__ __forceinline__ int s1_cholp(double* A, int n, int p, int lane, bool psd, double dg0, int rule, bool keepdiag, double& mydiag, int& nforced,
-   const double* zp)
+   const double* zp, HOOK hook = HOOK())
 {
    const double regtol = 1e-13;
    const int lr = lane & 15, kq = lane >> 4;
@@ -389,6 +380,9 @@ __device__ __forceinline__ int s1_cholp(double* A, int n, int p, int lane, bool 
    nforced = 0;
    for (int k0 = 0; k0 < n; k0 += 8)
    {
+      /* (the caller's hook between two panels: the factorization of M meets the other wavefronts at workgroup barriers there) */
+      if ( k0 > 0 )
+         hook(k0 >> 3);
       if ( k0 > 0 )
       {
          /* panel -= (finished columns) (their rows k0 .. k0 + 7)^T, 16-row tiles on the matrix cores.  All loads unconditional
@@ -558,247 +552,6 @@ __device__ __forceinline__ void s1_llt_solve(const double* L, int m, int p, int 
             if ( TWO )
                a1 = fma(-c[u], y1, a1);
          }
-      }
-   }
-   x0 = a0 * dinv;
-   x1 = a1 * dinv;
-}
-
-/* ---- round 6: the same two recurrences with the 8 x 8 DIAGONAL BLOCK of a panel in the registers of EVERY lane ------------------
- * In s1_cholp every pivot of a panel is a chain "v_readlane of the pivot row's entry -> test -> reciprocal square root -> scale ->
- * v_readlane of the scaled entry -> multiply-add into the next column", and in s1_llt_solve every step is "multiply -> v_readlane ->
- * multiply-add": the value that the next step needs sits in ONE lane and reaches the others through scalar registers (two
- * v_readlane_b32 per double, their hazards, and in this kernel scalar registers that are spilled into vector lanes).  Measured on
- * example_TT (m = 37, profiles/r06_a_solve1_wave_profile.txt): 650 cycles per column of the factorization, 110 per substitution step,
- * 44 000 cycles of the 175 000 of an iteration.
- * Here the 36 entries of the panel's diagonal block (28 + the 8 reciprocal diagonal entries in the substitutions) are read by every
- * lane from LDS (uniform addresses: broadcast reads, no conflicts) and every lane runs the block's recurrence for itself: no cross-lane
- * traffic inside a panel, independent multiply-adds, and the own row of a lane follows with multiply-adds whose second factors are
- * already in its registers.  The operations each ENTRY sees, and their order, are exactly those of s1_cholp / s1_llt_solve - every
- * lane computes for the rows of the diagonal block what the lanes that own those rows compute for themselves -: the results are the
- * same bits (tests/test_gpu_solve1.py: the tree of example_TT node by node, the fuzz slice). */
-#define S1D_IX(i, j) ((i) * ((i) + 1) / 2 + (j))
-
-/* s1_cholp with the panel recurrence in every lane; dgv: LDS vector with the original diagonal (semidefinite mode).  The rows
- * n .. 8 ceil(n / 8) - 1 of A and the entries of dgv there must exist (zero rows, any finite numbers): the diagonal block of the last
- * panel is read whole. */
-__device__ __forceinline__ int s1_cholp_r(double* A, int n, int p, int lane, bool psd, const double* dgv, int rule, bool keepdiag, double& mydiag,
-   int& nforced, const double* zp)
-{
-   const double regtol = 1e-13;
-   const int lr = lane & 15, kq = lane >> 4;
-   mydiag = 1.0;
-   nforced = 0;
-   const int nm1 = n - 1;
-   for (int k0 = 0; k0 < n; k0 += 8)
-   {
-      if ( k0 > 0 )
-      {
-         for (int T = k0 >> 4; 16 * T < n; ++T)
-         {
-            const int ar = min(16 * T + lr, nm1), br = min(k0 + lr, nm1);
-            const double* pa = A + ar * p + kq;
-            const double* pb = A + br * p + kq;
-            const int cc = min(k0 + lr, nm1);
-            v4d acc;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-               acc[r] = A[min(16 * T + kq + 4 * r, nm1) * p + cc];
-            for (int kk = 0; kk < k0; kk += 8)
-            {
-               const double a0 = -pa[kk], b0 = pb[kk];
-               const double a1 = -pa[kk + 4], b1 = pb[kk + 4];
-               acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
-               acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-            {
-               const int row = 16 * T + kq + 4 * r;
-               if ( lr < 8 && row < n && row >= k0 + lr && k0 + lr < n )
-                  A[row * p + k0 + lr] = acc[r];
-            }
-         }
-         S1_WSYNC();
-      }
-      double a[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-         a[u] = *((lane >= k0 + u && lane < n && k0 + u < n) ? (const double*) (A + lane * p + k0 + u) : zp);
-      /* the diagonal block (rows past the matrix: clamped loads, replaced by zeros) and the original diagonal of its rows */
-      double D[36], dgk[8];
-      {
-         const double* Ad = A + k0 * p + k0;
-#pragma unroll
-         for (int i = 0; i < 8; ++i)
-         {
-#pragma unroll
-            for (int j = 0; j <= i; ++j)
-               D[S1D_IX(i, j)] = Ad[i * p + j];
-            dgk[i] = psd ? dgv[k0 + i] : 1.0;
-         }
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-      {
-         const int k = k0 + u;
-         if ( k < n )
-         {
-            double d = D[S1D_IX(u, u)];
-            bool zero = false;
-            if ( psd )
-            {
-               const double mkk = dgk[u];
-               if ( !(d > fmax(regtol * mkk, 1e-300)) )
-               {
-                  zero = (rule == 1) || (rule == 2 && !(d > 0.0)) || (rule == 3 && !(d > 1.78e-15 * (double) (k + 1) * mkk));
-                  d = (mkk > 1e-280) ? regtol * mkk : 1.0;
-                  nforced += zero ? 65536 : 1;
-               }
-            }
-            else if ( !(d > 0.0) )
-               return k + 1;
-            const double rs = s1_rsqrt(d);
-            const double sd = d * rs;
-            /* column u of the block, then its term in the later columns (every lane, same numbers) */
-#pragma unroll
-            for (int v = u + 1; v < 8; ++v)
-               D[S1D_IX(v, u)] = zero ? 0.0 : D[S1D_IX(v, u)] * rs;
-#pragma unroll
-            for (int v = u + 1; v < 8; ++v)
-#pragma unroll
-               for (int w = u + 1; w <= v; ++w)
-                  D[S1D_IX(v, w)] = fma(-D[S1D_IX(v, u)], D[S1D_IX(w, u)], D[S1D_IX(v, w)]);
-            /* this lane's own row */
-            if ( lane == k )
-               mydiag = sd;
-            const double lu = (lane > k && !zero) ? a[u] * rs : 0.0;
-            a[u] = (lane == k && keepdiag) ? sd : lu;
-#pragma unroll
-            for (int v = u + 1; v < 8; ++v)
-               a[v] = fma(-lu, D[S1D_IX(v, u)], a[v]);
-         }
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-         if ( lane < n && k0 + u < n )
-            A[lane * p + k0 + u] = a[u];
-      S1_WSYNC();
-   }
-   return 0;
-}
-
-/* s1_llt_solve in blocks of eight steps: the lanes exchange their right-hand-side entries through xb0 / xb1 (LDS, 8 ceil(m / 8)
- * doubles each), every lane solves the 8 x 8 diagonal block for itself and applies the eight solution entries to its own row.
- * dvv: LDS vector with 1 / (diagonal entry) of every row; dinv = this lane's. */
-template<bool TWO>
-__device__ __forceinline__ void s1_llt_solve_b(const double* L, int m, int p, int lane, double dinv, const double* dvv, double* xb0, double* xb1,
-   double& x0, double& x1)
-{
-   /* The factor has 8 nb rows (zero rows behind row m - 1), dvv and the exchange vectors 8 nb entries (zeros behind entry m - 1):
-    * nothing is clamped or masked.  A lane past the matrix follows row 0 (all zero) forwards and column 0 backwards; it stores nothing. */
-   const int nb = (m + 7) >> 3;
-   const bool inpan = lane < 8 * nb;
-   const int rl = inpan ? lane : 0;
-   const bool live = lane < m;
-   double a0 = live ? x0 : 0.0, a1 = (live && TWO) ? x1 : 0.0;
-   {
-      const double* row = L + rl * p;
-      for (int b = 0; b < nb; ++b)
-      {
-         const int k0 = 8 * b;
-         double c[8];
-#pragma unroll
-         for (int u = 0; u < 8; ++u)
-            c[u] = row[k0 + u];
-         if ( inpan )
-         {
-            xb0[lane] = a0;
-            if ( TWO ) xb1[lane] = a1;
-         }
-         S1_WSYNC();
-         const double* Ld = L + k0 * p + k0;
-         double ld[28], dv[8], y0[8], y1[8];
-#pragma unroll
-         for (int u = 0; u < 8; ++u)
-         {
-            dv[u] = dvv[k0 + u];
-            y0[u] = xb0[k0 + u];
-            y1[u] = TWO ? xb1[k0 + u] : 0.0;
-#pragma unroll
-            for (int v = 0; v < u; ++v)
-               ld[S1D_IX(u, v) - u] = Ld[u * p + v];
-         }
-#pragma unroll
-         for (int u = 0; u < 8; ++u)
-         {
-            double s0 = y0[u], s1 = y1[u];
-#pragma unroll
-            for (int v = 0; v < u; ++v)
-            {
-               s0 = fma(-ld[S1D_IX(u, v) - u], y0[v], s0);
-               if ( TWO ) s1 = fma(-ld[S1D_IX(u, v) - u], y1[v], s1);
-            }
-            y0[u] = s0 * dv[u];
-            if ( TWO ) y1[u] = s1 * dv[u];
-         }
-#pragma unroll
-         for (int u = 0; u < 8; ++u)
-         {
-            a0 = fma(-c[u], y0[u], a0);
-            if ( TWO ) a1 = fma(-c[u], y1[u], a1);
-         }
-         __builtin_amdgcn_wave_barrier();
-      }
-   }
-   a0 *= dinv; a1 *= dinv;
-   {
-      const double* col = L + rl;
-      for (int b = nb - 1; b >= 0; --b)
-      {
-         const int k0 = 8 * b;
-         double c[8];
-#pragma unroll
-         for (int u = 0; u < 8; ++u)
-            c[u] = col[(k0 + u) * p];
-         if ( inpan )
-         {
-            xb0[lane] = a0;
-            if ( TWO ) xb1[lane] = a1;
-         }
-         S1_WSYNC();
-         const double* Ld = L + k0 * p + k0;
-         double ld[28], dv[8], y0[8], y1[8];
-#pragma unroll
-         for (int u = 0; u < 8; ++u)
-         {
-            dv[u] = dvv[k0 + u];
-            y0[u] = xb0[k0 + u];
-            y1[u] = TWO ? xb1[k0 + u] : 0.0;
-#pragma unroll
-            for (int v = 0; v < u; ++v)
-               ld[S1D_IX(u, v) - u] = Ld[u * p + v];
-         }
-#pragma unroll
-         for (int u = 7; u >= 0; --u)
-         {
-            double s0 = y0[u], s1 = y1[u];
-#pragma unroll
-            for (int v = 7; v > u; --v)
-            {
-               s0 = fma(-ld[S1D_IX(v, u) - v], y0[v], s0);
-               if ( TWO ) s1 = fma(-ld[S1D_IX(v, u) - v], y1[v], s1);
-            }
-            y0[u] = s0 * dv[u];
-            if ( TWO ) y1[u] = s1 * dv[u];
-         }
-#pragma unroll
-         for (int u = 7; u >= 0; --u)
-         {
-            a0 = fma(-c[u], y0[u], a0);
-            if ( TWO ) a1 = fma(-c[u], y1[u], a1);
-         }
-         __builtin_amdgcn_wave_barrier();
       }
    }
    x0 = a0 * dinv;
@@ -2035,7 +1788,7 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
    double* const out = P.out;
    /* (the extended Schur matrix starts from zeros: its upper triangle and the padding columns are never written and are read -
     * unmasked - by the substitutions with the factor that overwrites it) */
-   for (int e = tid; e < (mpk ? (m1 * (m1 + 1) >> 1) + 16 : L.mrows * pm1); e += S1_NT)
+   for (int e = tid; e < (mpk ? (m1 * (m1 + 1) >> 1) + 16 : m1 * pm1); e += S1_NT)
       Mx[e] = 0.0;
 
    /* ---- flexible part: offset arrays first (their sizes follow from the shape), the counts decide the rest */
@@ -2775,10 +2528,14 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
       }
    };
    /* outv[i] = sum_k <A_i^k, V_k> + (Dext^T xv)_i, V_k symmetric at LDS offset offs[k] (16 lanes per variable) */
-   auto pass_A = [&](bool ofdX, const double* xv, double* outv, int toff, auto epi) S1_INL
+   /* (wfrom > 0: only the wavefronts wfrom .. take part - the others are busy elsewhere; same sums, other owners) */
+   auto pass_A_from = [&](int wfrom, bool ofdX, const double* xv, double* outv, int toff, auto epi) S1_INL
    {
-      const int gid = tro(toff) >> 4, l16 = tid & 15;
-      for (int i = gid; i < m1; i += S1_NT / 16)
+      const int nthr = S1_NT - 64 * wfrom;
+      int trot = tid - 64 * wfrom - (toff % nthr);
+      if ( trot < 0 ) trot += nthr;
+      const int gid = (wfrom == 0 ? tro(toff) : trot) >> 4, l16 = tid & 15;
+      for (int i = (wave >= wfrom ? gid : m1); i < m1; i += nthr / 16)
       {
          double s = 0.0;
          for (int k = 0; k < K; ++k)
@@ -2806,6 +2563,7 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
          }
       }
    };
+   auto pass_A = [&](bool ofdX, const double* xv, double* outv, int toff, auto epi) S1_INL { pass_A_from(0, ofdX, xv, outv, toff, epi); };
    auto no_epi = [](int, double) S1_INL {};
    auto lp_row = [&](int r, const double* cv) S1_INL -> double
    {
@@ -2841,18 +2599,10 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
       }
       double x0 = (lane < m) ? r0[lane] : 0.0;
       double x1 = (two && lane < m) ? r1[lane] : 0.0;
-#if S1_BLKSOLVE
-      /* (1 / diagonal of every row in V_dg since the factorization; V_t2, V_t3: the exchange vectors) */
-      if ( two )
-         s1_llt_solve_b<true>(Lm, m, pm, lane, mdinv, VEC(V_dg), VEC(V_t2), VEC(V_t3), x0, x1);
-      else
-         s1_llt_solve_b<false>(Lm, m, pm, lane, mdinv, VEC(V_dg), VEC(V_t2), VEC(V_t3), x0, x1);
-#else
       if ( two )
          s1_llt_solve<true>(Lm, m, pm, lane, mdinv, x0, x1);
       else
          s1_llt_solve<false>(Lm, m, pm, lane, mdinv, x0, x1);
-#endif
       if ( lane < m )
       {
          o0[lane] = x0;
@@ -2864,7 +2614,7 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
    double sigma = 0.0, eta = 1.0;
    /* H (or dX) = sigmu Zinv - X - sym(T1 Zinv) into dX: the product and its transpose (Zinv T1^T) side by side, H from the epilogue;
     * LP part into `lpout` from `rlp` (rd for the right-hand side, dz for the step).  All threads; no barrier. */
-   auto dir_matrix = [&](double sigmu, double etalp, const double* rlp, bool useE, double* lpout) S1_INL
+   auto dir_matrix_from = [&](int wfrom, double sigmu, double etalp, const double* rlp, bool useE, double* lpout) S1_INL
    {
       int tb = 0;
       for (int k = 0; k < K; ++k)
@@ -2873,25 +2623,30 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
          const int p = B.p;
          const double* T1 = sm + B.oT1; const double* Zi = sm + B.oZi; const double* X = sm + B.oX;
          double* dX = sm + B.odX;
-         s1_mm2(B.n, wave, lane, 0, S1_NW, tb,
+         s1_mm2(B.n, wave, lane, wfrom, S1_NW - wfrom, tb,
             [&](int i, int kk) S1_INL { return T1[i * p + kk]; }, [&](int kk, int j) S1_INL { return Zi[kk * p + j]; },
             [&](int i, int kk) S1_INL { return Zi[i * p + kk]; }, [&](int kk, int j) S1_INL { return T1[j * p + kk]; },
             [&](int i, int j, double v1, double v2) S1_INL { dX[i * p + j] = sigmu * Zi[i * p + j] - X[i * p + j] - 0.5 * (v1 + v2); });
       }
-      for (int r = tid; r < q; r += S1_NT)                /* (the tiles of the product are on the last wavefronts) */
+      for (int r = (wave >= wfrom ? tid - 64 * wfrom : q); r < q; r += S1_NT - 64 * wfrom)                /* (the tiles of the product are on the last wavefronts) */
       {
          const double xv = QV(Q_x)[r], zv = QV(Q_z)[r];
          lpout[r] = sigmu / zv - xv - (etalp * xv * rlp[r] + (useE ? QV(Q_elp)[r] : 0.0)) / zv;
       }
    };
+   auto dir_matrix = [&](double sigmu, double etalp, const double* rlp, bool useE, double* lpout) S1_INL { dir_matrix_from(0, sigmu, etalp, rlp, useE, lpout); };
    /* wavefront 0, after A(H) is known: h, u1 = M^-1 h, dtau, dkappa, dy, coefficient vector [-dtau; dy] */
-   auto finish_dir = [&](double sigmu, double etk, double rg) S1_INL
+   /* (solved: u1 = M^-1 h is there already - the predictor's, solved beside the two right-hand sides of the tau elimination) */
+   auto finish_dir = [&](double sigmu, double etk, double rg, bool solved) S1_INL
    {
       const double tau = sh.sc[SC_TAU], kappa = sh.sc[SC_KAPPA];
-      for (int i = lane; i < m; i += 64)
-         VEC(V_h)[i] = VEC(V_AH)[i + 1] - eta * VEC(V_rp)[i];
-      S1_WSYNC();
-      msolve2(VEC(V_h), NULL, VEC(V_u1), NULL);
+      if ( !solved )
+      {
+         for (int i = lane; i < m; i += 64)
+            VEC(V_h)[i] = VEC(V_AH)[i + 1] - eta * VEC(V_rp)[i];
+         S1_WSYNC();
+         msolve2(VEC(V_h), NULL, VEC(V_u1), NULL);
+      }
       double bu1 = 0.0, wrp = 0.0;
       for (int i = lane; i < m; i += 64)
       {
@@ -3489,13 +3244,103 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
       S1_BAR();
       S1_STAMP(5);
 
-      /* ================= factorization of M and the two solves (wavefront 0) beside the first product of the predictor,
-       * T1 = X Rd (the others) */
-      /* (64 < m: the factorization is the work of all wavefronts - s1_cholp2 -, the product X Rd comes first) */
+      /* ================= factorization of M (wavefront 0) beside the predictor's right-hand side (the others), then the THREE solves
+       * with the factor on three wavefronts.
+       * Round 6 (m <= 64).  A wave-serial section of this kernel costs its instruction count times eight cycles whatever the
+       * dependencies (profiles/r06_solve1_diag_block_attempt.txt), so what shortens the iteration is giving the other wavefronts the
+       * work that does not need M while wavefront 0 factors it, and giving every right-hand side a wavefront of its own:
+       *   wavefront 0:  g = column 0 of Mx | panel 0 | panel 1 | panel 2 | panels 3 .. | 1 / diagonal -> V_dg || w = M^-1 g, wt
+       *   the others:   T1 = X Rd          | H = -X - sym(T1 Zinv), hl | A(H) | h = A(H) - rp     || ub = M^-1 b, b^T ub (wavefront 1)
+       *                                                                                              || u1 = M^-1 h (wavefront 2)
+       * (`|`: a workgroup barrier - wavefront 0 passes them between its panels through the hook of s1_cholp, where it arrives later
+       * than the others; `||`: the barrier behind the factorization.)  Before: the factorization and a solve with two right-hand
+       * sides on wavefront 0 (35 000 cycles at example_TT) while the others formed T1 and waited, H and A(H) as phases of their own
+       * behind it, and the predictor's solve alone on wavefront 0 in finish_dir (7 500).  Every number is computed by the same
+       * operations in the same order as before - only by other lanes -: same bits.
+       * (64 < m, the other instance: the factorization is the work of all wavefronts - s1_cholp2 -, the product X Rd comes first.) */
       const bool coop = S1_MBIG && m > 64;
+      const bool shadow = !S1_MBIG;
       double mdiag = 1.0;
       int nforced = 0;
       long long tq0 = 0;
+      sigma = 0.0; eta = 1.0;
+      if ( shadow )
+      {
+         const int NSY = 3;
+         if ( wave == 0 )
+         {
+            for (int i = lane; i < m; i += 64)
+               VEC(V_g)[i] = Mx[MROW(i + 1)];
+            if ( lane == 0 )
+               sh.fl[7] = 0;
+            if ( P.prof_on ) tq0 = clock64();
+            const double dg0 = (lane < m) ? Lm[lane * pm + lane] : 1.0;
+            int nsy = 0;
+            (void) s1_cholp(Lm, m, pm, lane, true, dg0, P.pivot_rule, false, mdiag, nforced, zsrc,
+               [&](int) S1_INL { if ( nsy < NSY ) { S1_BAR(); ++nsy; } });
+            for (; nsy < NSY; ++nsy)
+               S1_BAR();
+            if ( lane == 0 )
+               sh.fl[6] = nforced;
+            mdinv = s1_rcp(mdiag);
+            if ( lane < m )
+               VEC(V_dg)[lane] = mdinv;
+            if ( P.prof_on && lane == 0 ) { const long long tq1 = clock64(); sh.prof[20] += (double) (tq1 - tq0); tq0 = tq1; }
+         }
+         else
+         {
+            {
+               int tb = 0;
+               for (int k = 0; k < K; ++k)
+               {
+                  const S1Blk& B = sh.blk[k];
+                  const int p = B.p;
+                  const double* X = sm + B.oX;
+                  auto Rd = LP(B.Rd);
+                  double* T1 = sm + B.oT1;
+                  s1_mm(B.n, wave, lane, 1, S1_NW - 1, tb,
+                     [&](int i, int kk) S1_INL { return X[i * p + kk]; }, [&](int kk, int j) S1_INL { return Rd[kk * p + j]; },
+                     [&](int i, int j, double v) S1_INL { T1[i * p + j] = v; });
+               }
+            }
+            S1_BAR();
+            dir_matrix_from(1, 0.0, 1.0, QV(Q_rd), false, QV(Q_hl));
+            S1_BAR();
+            pass_A_from(1, true, QV(Q_hl), VEC(V_AH), 128, no_epi);
+            S1_BAR();
+            if ( wave == 1 )
+               for (int i = lane; i < m; i += 64)
+                  VEC(V_h)[i] = VEC(V_AH)[i + 1] - eta * VEC(V_rp)[i];
+         }
+         S1_BAR();
+         if ( wave == 0 )
+         {
+            msolve2(VEC(V_g), NULL, VEC(V_w), NULL);
+            for (int i = lane; i < m; i += 64)
+               VEC(V_wt)[i + 1] = -VEC(V_w)[i];
+            if ( lane == 0 )
+               VEC(V_wt)[0] = 1.0;
+            if ( P.prof_on && lane == 0 ) { const long long tq1 = clock64(); sh.prof[21] += (double) (tq1 - tq0); }
+         }
+         else if ( wave == 1 )
+         {
+            mdinv = (lane < m) ? VEC(V_dg)[lane] : 1.0;
+            msolve2(VEC(V_b), NULL, VEC(V_ub), NULL);
+            double bubp = 0.0;
+            for (int i = lane; i < m; i += 64)
+               bubp = fma(VEC(V_b)[i], VEC(V_ub)[i], bubp);
+            const double bub = s1_wsum(bubp);
+            if ( lane == 0 )
+               sh.sc[SC_BUB] = bub;
+         }
+         else if ( wave == 2 )
+         {
+            mdinv = (lane < m) ? VEC(V_dg)[lane] : 1.0;
+            msolve2(VEC(V_h), NULL, VEC(V_u1), NULL);
+         }
+      }
+      else
+      {
       if ( wave == 0 )
       {
          /* (the factor overwrites M where it stands; its first column, g, is taken out first) */
@@ -3517,26 +3362,11 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
          if ( !coop )
          {
             const double dg0 = (lane < m) ? Lm[lane * pm + lane] : 1.0;
-#if S1_CHOLR
-            if ( lane < ((m + 7) & ~7) )
-               VEC(V_dg)[lane] = dg0;                    /* (dg0 = 1 behind the matrix) */
-            S1_WSYNC();
-            (void) s1_cholp_r(Lm, m, pm, lane, true, VEC(V_dg), P.pivot_rule, false, mdiag, nforced, zsrc);
-#else
             (void) s1_cholp(Lm, m, pm, lane, true, dg0, P.pivot_rule, false, mdiag, nforced, zsrc);
-#endif
          }
          if ( lane == 0 )
             sh.fl[6] = nforced;
          mdinv = s1_rcp(mdiag);
-#if S1_BLKSOLVE
-         if ( !coop )
-         {
-            if ( lane < ((m + 7) & ~7) )
-               VEC(V_dg)[lane] = (lane < m) ? mdinv : 0.0;
-            S1_WSYNC();
-         }
-#endif
          if ( P.prof_on && lane == 0 ) { const long long tq1 = clock64(); sh.prof[20] += (double) (tq1 - tq0); tq0 = tq1; }
          msolve2(VEC(V_g), VEC(V_b), VEC(V_w), VEC(V_ub));
          if ( P.prof_on && lane == 0 ) { const long long tq1 = clock64(); sh.prof[21] += (double) (tq1 - tq0); }
@@ -3575,16 +3405,24 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
                [&](int i, int j, double v) S1_INL { T1[i * p + j] = v; });
          }
       }
+      }
       S1_BAR();
       S1_STAMP(6);
-      if ( sh.fl[7] )
+      if ( !shadow && sh.fl[7] )
       {
          status = HS_S1_NUMERIC; numwhere = __LINE__;
          break;
       }
-      /* B_k = A_0 - sum w_i A_i, beta = c - D w; H of the predictor = -X - sym(X Rd Zinv) -> dX, hl */
-      sigma = 0.0; eta = 1.0;
+      /* B_k = A_0 - sum w_i A_i, beta = c - D w; H of the predictor = -X - sym(X Rd Zinv) -> dX, hl (shadow: H is there already; u2 =
+       * ub - w and the test of its entries are the work of this phase) */
       {
+         if ( shadow && tid < m )
+         {
+            const double w = VEC(V_w)[tid], ub = VEC(V_ub)[tid];
+            VEC(V_u2)[tid] = ub - w;
+            if ( !(fabs(ub - w) < 1e300) )
+               sh.fl[7] = 1;
+         }
          const double* wt = VEC(V_wt);
          for (int k = 0; k < K; ++k)
          {
@@ -3598,12 +3436,19 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
          }
          for (int r = tro(128); r < q; r += S1_NT)
             QV(Q_beta)[r] = lp_row(r, wt);
-         dir_matrix(0.0, 1.0, QV(Q_rd), false, QV(Q_hl));
+         if ( !shadow )
+            dir_matrix(0.0, 1.0, QV(Q_rd), false, QV(Q_hl));
       }
       S1_BAR();
+      if ( shadow && sh.fl[7] )
+      {
+         status = HS_S1_NUMERIC; numwhere = __LINE__;
+         break;
+      }
       /* A(H), <B, H>; T1 = X B */
       {
-         pass_A(true, QV(Q_hl), VEC(V_AH), 128, no_epi);
+         if ( !shadow )
+            pass_A(true, QV(Q_hl), VEC(V_AH), 128, no_epi);
          bh_partials();
          int tb = 0;
          for (int k = 0; k < K; ++k)
@@ -3643,7 +3488,7 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
       }
       S1_BAR();
       if ( wave == 0 )
-         finish_dir(0.0, 0.0, rg);
+         finish_dir(0.0, 0.0, rg, shadow);
       S1_BAR();
       S1_STAMP(7);
       const double dta = sh.sc[SC_DTAU], dka = sh.sc[SC_DKAPPA];
@@ -3724,7 +3569,7 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
       bh_partials();
       S1_BAR();
       if ( wave == 0 )
-         finish_dir(sigmu, etk, rg);
+         finish_dir(sigmu, etk, rg, false);
       S1_BAR();
       S1_STAMP(9);
       const double dt = sh.sc[SC_DTAU], dk = sh.sc[SC_DKAPPA];
