@@ -3785,6 +3785,20 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       }
       else
       {
+         /* Round 6: one rank - the rest of the step (y, x, z, tau, kappa) is applied optimistically behind the Cholesky check of the
+          * new X and Z, and the residual pass of the NEXT iterate (the sweep A(X), the scaled dual residual, the reductions) and the
+          * chains of its factorization phase are queued behind that: ONE read-back returns the check's flags and the termination
+          * scalars of the next iteration, where there were two with an idle device between them (profiles/r06_a_iter_sequence.txt:
+          * 50 us waiting for the flags, then 200 us of small kernels arriving one launch at a time).  A failed check - rare: the
+          * step lengths are Lanczos estimates with a safety factor - halves the step as before; the optimistic part is taken back by
+          * a correcting axpy and the dual residual is recomputed from scratch at the next pass (its recurrence was applied in place). */
+         const bool optimistic = (s->comm == NULL) && getenv("HIPSDP_NO_OPTIMISTIC") == NULL;
+         /* (test hook, tests/test_gpu_ipm.py: HIPSDP_TEST_OVERSTEP=<factor> lengthens the step of iteration 2 beyond the boundary of the
+          * cone, so that the rarely taken road - failed check, step halved, optimistic part taken back - is driven) */
+         if ( it == 2 && getenv("HIPSDP_TEST_OVERSTEP") != NULL )
+            alpha = amax * atof(getenv("HIPSDP_TEST_OVERSTEP"));
+         const double tau0 = s->tau, kappa0 = s->kappa;
+         double applied = 0.0;
          for (int attempt = 0; attempt < 8; ++attempt)
          {
             HS_HIP( hipMemsetAsync(s->flags, 0, 8 * sizeof(int), st) );
@@ -3810,6 +3824,52 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
             HS_CALL( join2(s) );
             if ( K == 0 )
                break;
+            if ( optimistic )
+            {
+               /* (blocks of at most 64 rows: their trial iterate sits in Xs / Zs - swapped in now, back on a failure) */
+               for (auto& B : s->blk)
+                  if ( B.n <= 64 )
+                  {
+                     std::swap(B.X, B.Xs);
+                     std::swap(B.Z, B.Zs);
+                  }
+               HS_CALL( hs_axpy3(st, alpha - applied, m, s->dy, s->y, q, s->dx, s->x, q, s->dz, s->z) );
+               applied = alpha;
+               s->tau = tau0 + alpha * dt;
+               s->kappa = kappa0 + alpha * dk;
+               factors_valid = true;                    /* (what the chains below test: the check has produced the factors) */
+               if ( s->use2 && !no_overlap && !zchain_queued )
+               {
+                  HS_CALL( fork2(s) );
+                  HS_CALL( enqueue_z_chains() );
+                  zchain_queued = true;
+               }
+               if ( attempt == 0 )
+               {
+                  rd_have = !small_problem(s);
+                  rd_pending = rd_have;
+                  rd_scale = 1.0 - alpha * eta;
+               }
+               HS_CALL( enqueue_residuals() );
+               HS_CALL( read_scalars(s, hs, hflags, (zchain_queued && s->comm == NULL) ? &enqueue_x_chains : NULL) );
+               if ( hflags[0] == 0 && hflags[1] == 0 )
+                  break;
+               /* the step was too long: everything queued behind the check ran on an iterate that is given up */
+               for (auto& B : s->blk)
+                  if ( B.n <= 64 )
+                  {
+                     std::swap(B.X, B.Xs);
+                     std::swap(B.Z, B.Zs);
+                  }
+               factors_valid = false;
+               zchain_queued = false;
+               xchain_queued = false;
+               rd_have = false;
+               rd_pending = false;
+               alpha *= 0.5;
+               info->chol_fail++;
+               continue;
+            }
             if ( s->comm != NULL )
                HS_CALL( hs_bcast_ints(s->comm, s->flags, 3, st) );
             if ( s->comm == NULL && s->use_publish )
@@ -3829,6 +3889,12 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
          {
             if ( par.verbose )
                printf("hipsdp: no step length down to %g keeps X and Z positive definite\n", alpha);
+            if ( optimistic && applied != 0.0 )
+            {
+               HS_CALL( hs_axpy3(st, -applied, m, s->dy, s->y, q, s->dx, s->x, q, s->dz, s->z) );
+               s->tau = tau0;
+               s->kappa = kappa0;
+            }
             for (auto& B : s->blk)
             {
                const long long n2 = (long long) B.n * B.n;
@@ -3846,21 +3912,29 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
             if ( B.n <= 64 )
             {
                /* accept the trial iterate: its factors, inverse factors (and inverse) are those of the fused factorization */
-               std::swap(B.X, B.Xs);
-               std::swap(B.Z, B.Zs);
+               if ( !optimistic )
+               {
+                  std::swap(B.X, B.Xs);
+                  std::swap(B.Z, B.Zs);
+               }
                B.derived_valid = true;
             }
          }
          factors_valid = (K > 0);
-         HS_CALL( hs_axpy3(st, alpha, m, s->dy, s->y, q, s->dx, s->x, q, s->dz, s->z) );
-         s->tau += alpha * dt;
-         s->kappa += alpha * dk;
          alpha_last = alpha;
-         /* the residual the next iteration starts from: (1 - alpha eta) times the one this iteration used (general path only:
-          * the single-launch kernels of small problems recompute it inside the fused launches) */
-         rd_have = !small_problem(s);
-         rd_pending = rd_have;
-         rd_scale = 1.0 - alpha * eta;
+         if ( optimistic && K > 0 )
+            residuals_ready = true;                /* (applied, queued and read above) */
+         else
+         {
+            HS_CALL( hs_axpy3(st, alpha, m, s->dy, s->y, q, s->dx, s->x, q, s->dz, s->z) );
+            s->tau += alpha * dt;
+            s->kappa += alpha * dk;
+            /* the residual the next iteration starts from: (1 - alpha eta) times the one this iteration used (general path only:
+             * the single-launch kernels of small problems recompute it inside the fused launches) */
+            rd_have = !small_problem(s);
+            rd_pending = rd_have;
+            rd_scale = 1.0 - alpha * eta;
+         }
       }
    }
 

@@ -431,6 +431,40 @@ def test_preoptimal_iterate_matches_the_oracle(gpu):
         s.close()
 
 
+@pytest.mark.parametrize("sizes", [(100,), (70, 20)])
+def test_failed_cholesky_check_takes_the_optimistic_step_back(gpu, sizes, monkeypatch):
+    """Round 6: on the general path the rest of the step and the residual pass of the next iterate are queued behind the Cholesky check
+    of the new X and Z, one read-back for both (csrc/ipm.hip, "optimistic").  A step beyond the boundary of the cone - forced here in
+    iteration 2 (HIPSDP_TEST_OVERSTEP) - fails the check: the step is halved, the optimistic part taken back, the dual residual
+    recomputed.  Same optimum, same iteration count and the same number of failed checks as the form that reads the flags first
+    (HIPSDP_NO_OPTIMISTIC=1); blocks of at most 64 rows keep their trial iterate in a second buffer that is swapped in and back."""
+    rng = np.random.default_rng(23)
+    m = 40
+    blocks = []
+    for n in sizes:
+        A = rng.standard_normal((m + 1, n, n))
+        A = A + A.transpose(0, 2, 1)
+        A[0] = -np.eye(n) * 3.0 + 0.1 * A[0]
+        blocks.append(A)
+    D = np.concatenate([np.eye(m), -np.eye(m)])
+    c = np.concatenate([-2.0 * np.ones(m), -2.0 * np.ones(m)])
+    core = ipm_ref.CoreProblem(rng.standard_normal(m), blocks, D, c)
+    monkeypatch.setenv("HIPSDP_SOLVE1", "0")
+    plain = gpu_solve(gpu, core, gaptol=1e-6, feastol=1e-6)
+    assert plain["info"].status == 0 and plain["info"].chol_fail == 0
+    monkeypatch.setenv("HIPSDP_TEST_OVERSTEP", "1.6")
+    opt = gpu_solve(gpu, core, gaptol=1e-6, feastol=1e-6)
+    monkeypatch.setenv("HIPSDP_NO_OPTIMISTIC", "1")
+    old = gpu_solve(gpu, core, gaptol=1e-6, feastol=1e-6)
+    assert opt["info"].status == 0 and old["info"].status == 0
+    assert opt["info"].chol_fail >= 1 and opt["info"].chol_fail == old["info"].chol_fail
+    assert opt["info"].iterations == old["info"].iterations
+    assert abs(opt["info"].dobj - plain["info"].dobj) <= 1e-6 * (1 + abs(plain["info"].dobj))
+    assert np.max(np.abs(opt["y"] - old["y"])) <= 1e-7
+    ok, det = checker.certificate(core, opt["y"], opt["X"], opt["lp"][0], TOL, TOL)
+    assert ok, det
+
+
 @pytest.mark.parametrize("mode", ["K3", "R", "U"])
 def test_sharded_forms_with_several_blocks_and_lp_rows(gpu, mode, monkeypatch):
     """blocks of different sizes (70 crosses the 64 boundary, 20 leaves slices of the column form empty) plus LP rows: the
