@@ -106,6 +106,8 @@ struct hs_schur_ws
    double*   V2;
    void*     evP[2];       /* hipEvent_t: the products of a slice are in its send buffer */
    void*     evX[2];       /* hipEvent_t: the exchange of a slice has arrived */
+   void*     ev_g2;        /* hipEvent_t or NULL: hs_schur_W waits for it between its first and its second product (the inverse factor of Z
+                            * is formed on another queue while A_stack R runs; set and cleared by the caller around the call) */
 };
 int  hs_schur_ws_alloc(hs_schur_ws* w, int m1, long long n2max, double budget_gb);
 void hs_schur_ws_free(hs_schur_ws* w);

@@ -529,7 +529,7 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
    s->schur_mode_rows = false;
    s->schur_mode_cols = false; s->schur_sim_shards = 0;
    s->sws.T = s->sws.U = s->sws.K = s->sws.V = s->sws.U2 = s->sws.V2 = NULL;
-   s->sws.evP[0] = s->sws.evP[1] = s->sws.evX[0] = s->sws.evX[1] = NULL;
+   s->sws.evP[0] = s->sws.evP[1] = s->sws.evX[0] = s->sws.evX[1] = NULL; s->sws.ev_g2 = NULL;
    s->flags = NULL;
    s->hsc = NULL;
    s->hsc_dev = NULL;
@@ -724,7 +724,7 @@ extern "C" int hipsdp_set_shape2(hipsdp_solver* s, int m, int nblocks, const int
             /* what depends on the counts themselves */
             hs_schur_ws_free(&s->sws);
             s->sws.T = s->sws.U = s->sws.K = s->sws.V = s->sws.U2 = s->sws.V2 = NULL;
-            s->sws.evP[0] = s->sws.evP[1] = s->sws.evX[0] = s->sws.evX[1] = NULL;
+            s->sws.evP[0] = s->sws.evP[1] = s->sws.evX[0] = s->sws.evX[1] = NULL; s->sws.ev_g2 = NULL;
             s->m = m; s->q = q;
             s->a_r0 = 0; s->a_r1 = (int) m1s;
             s->u1 = s->rhs2 + 2LL * m;
@@ -903,7 +903,7 @@ extern "C" int hipsdp_set_shape2(hipsdp_solver* s, int m, int nblocks, const int
       HS_CALL( hs_trsv_sync_init(s->stream, m, s->trsv_ws, &s->trsv_epoch) );
    s->trsv_epoch = 0;
    s->sws.T = s->sws.U = s->sws.K = s->sws.V = s->sws.U2 = s->sws.V2 = NULL;
-   s->sws.evP[0] = s->sws.evP[1] = s->sws.evX[0] = s->sws.evX[1] = NULL;
+   s->sws.evP[0] = s->sws.evP[1] = s->sws.evX[0] = s->sws.evX[1] = NULL; s->sws.ev_g2 = NULL;
    HS_HIP( hipMemsetAsync(s->Dext, 0, (size_t) ((long long) q * m1 > 0 ? (long long) q * m1 : 1) * sizeof(double), s->stream) );
    HS_HIP( hipMemsetAsync(s->b, 0, (size_t) (m > 0 ? m : 1) * sizeof(double), s->stream) );
    HS_HIP( hipStreamSynchronize(s->stream) );
@@ -3138,8 +3138,14 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
             HS_CALL( hs_potrf(st, n, B.Lx, B.dinvx, s->flags + 1, NULL) );
          }
          HS_CALL( hs_zero_upper(st, B.Lx, n) );
-         HS_CALL( hs_trtri(st, n, B.Lx, B.dinvx, B.LxInv, B.T1) );
       }
+      /* round 6: the inverse factor of X is not an operand of the assembly (W_j = G A_j R takes R = Lx itself) - it goes to the second
+       * queue behind the Z chain and runs beside the first product of the assembly instead of in front of it (75 us at n = 500);
+       * the first queue meets the second one again before anything reads LxInv */
+      HS_CALL( fork2(s) );
+      for (auto& B : s->blk)
+         if ( B.n > 64 )
+            HS_CALL( hs_trtri(s->stream2, B.n, B.Lx, B.dinvx, B.LxInv, B.T1) );
       xchain_queued = true;
       return HS_OK;
    };
@@ -3364,7 +3370,21 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
          HS_CALL( hs_trtri(st, n, B.Lx, B.dinvx, B.LxInv, B.T1) );
          }
       }
-      HS_CALL( join2(s) );
+      /* round 6: every block above 64 rows, one rank, the W formulation: the chains of the second queue (inverse factor of Z - the G of
+       * W_j = G A_j R -, inverse factor of X) are awaited between the first and the second product of the assembly, not in front of
+       * it */
+      bool defer_join = s->use2 && !no_overlap && s->comm == NULL && !s->shardA && !s->schur_mode_cols && !s->schur_mode_rows
+         && !s->schur_mode_U && !s->schur_mode_forced && K > 0 && !(identity_start && it == 0) && getenv("HIPSDP_NO_DEFER_JOIN") == NULL;
+      for (auto& B : s->blk)
+         if ( B.n <= 64 || B.sparse )
+            defer_join = false;
+      if ( defer_join )
+      {
+         HS_HIP( hipEventRecord(s->evJoin, s->stream2) );
+         s->sws.ev_g2 = (void*) s->evJoin;
+      }
+      else
+         HS_CALL( join2(s) );
       zchain_queued = false;
       xchain_queued = false;
 
@@ -3517,6 +3537,12 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
          HS_CALL( gemm(s, HS_MC, HS_MC, m1, m1, q, 1.0, s->Dext, m1, s->Slp, m1, 1.0, s->Mx, m1, HS_GEMM_LOWER) );
       }
       HS_CALL( hs_mirror_lower(st, s->Mx, m1, m1) );
+      }
+      if ( defer_join )
+      {
+         /* (the first queue has waited for the event inside hs_schur_W; once more for whoever follows, and the hook is taken out) */
+         s->sws.ev_g2 = NULL;
+         HS_CALL( join2(s) );
       }
       HS_HIP( hipEventRecord(s->ev1, st) );
       if ( clk_this )
