@@ -109,17 +109,46 @@ def host_cpu_share():
 
 
 def cpu_baseline(solver, b, n, m, gpu_iterations, budget_iters=None):
-    """CPU restatement (numpy / scipy level-3 BLAS on all host cores) of the same algorithm on the same bits, with the Schur assembly
-    in the SAME formulation as the device path (W_j = G A_j R by two DTRMM over stacks, Mx = W W^T by one DSYRK:
-    oracle/ipm_ref.schur_block_w): a bounded sample of IPM iterations timed on the host cores, extrapolated to the iteration count of
-    the full solve."""
+    """The same algorithm on the same bits on the host cores: oracle/cpu_ref_dense.c - the C restatement of oracle/ipm_ref.py for one dense
+    block, Schur assembly in the device path's W formulation (W_j = G A_j R by two DTRMM, Mx = W W^T as DGEMM panels), OpenMP over
+    independent pieces, scipy's bundled OpenBLAS single-threaded underneath (kind "own C restatement + OpenBLAS").  budget_iters = None:
+    the WHOLE solve is timed (the bench size: about 10 s); a number: that many iterations are timed and the solves/s are extrapolated to
+    the iteration count of the device's solve (n = 1000 / m = 2000: 8e12 flop per iteration).  Without an OpenBLAS in the image: the numpy
+    port of rounds 1-5 (kind "port")."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import ipm_ref
-    if budget_iters is None:
-        # about 10-30 s of CPU work: 4 iterations at C2 (5e11 flop each in this formulation), 1 at T1 (8e12)
-        budget_iters = 4 if 4.0 * m * n ** 3 + float(m) ** 2 * n ** 2 < 2e12 else 1
     threads = host_cpu_share()
     A = solver.get_block_dense(0)
+    m1 = m + 1
+    try:
+        import cpu_ref_dense
+        cpu_ref_dense.build()
+    except Exception:
+        cpu_ref_dense = None
+    if cpu_ref_dense is not None:
+        full = budget_iters is None
+        info, _y = cpu_ref_dense.solve(b, A, gaptol=1e-5, feastol=1e-5, maxiter=(200 if full else budget_iters), threads=threads)
+        its = max(1, info.iterations)
+        per_iter = info.total_seconds / its
+        if full:
+            solves_per_sec = 1.0 / info.total_seconds
+            sample = ("one complete solve of the same n=%d, m=%d instance (A copied back from HBM: identical bits): %d iterations, status %d, "
+                      "objective %.9g, %.1f s of which %.1f s Schur assembly; nothing extrapolated" %
+                      (n, m, info.iterations, info.status, info.dobj, info.total_seconds, info.schur_seconds))
+        else:
+            solves_per_sec = 1.0 / (per_iter * max(1, gpu_iterations))
+            sample = ("%d IPM iterations of the same n=%d, m=%d instance (A copied back from HBM: identical bits), %.1f s of which %.1f s "
+                      "Schur assembly; solves/s extrapolated to the %d iterations of the device's solve" %
+                      (its, n, m, info.total_seconds, info.schur_seconds, gpu_iterations))
+        return {"value": solves_per_sec, "unit": "solves/s", "cores": int(threads), "kind": "own C restatement + OpenBLAS",
+                "blas": cpu_ref_dense.blas_name() + " (single-threaded calls under OpenMP, %d threads)" % threads,
+                "source": "oracle/cpu_ref_dense.c", "iterations": int(info.iterations), "extrapolated": (not full),
+                "iters_per_sec": 1.0 / per_iter,
+                "executed_tflops_of_the_assembly_formulation":
+                    (2.0 * m1 * n ** 3 + float(m1) ** 2 * n ** 2) * its / max(info.schur_seconds, 1e-9) / 1e12,
+                "sample": sample}
+    import ipm_ref
+    if budget_iters is None:
+        budget_iters = 4 if 4.0 * m * n ** 3 + float(m) ** 2 * n ** 2 < 2e12 else 1
     core = ipm_ref.CoreProblem(b, [A])
     par = ipm_ref.Params(gaptol=1e-5, feastol=1e-5, maxiter=budget_iters)
     par.schur = "W"
@@ -128,13 +157,11 @@ def cpu_baseline(solver, b, n, m, gpu_iterations, budget_iters=None):
     except Exception:
         threadpool_limits = None
     if threadpool_limits is not None:
-        # (a context manager: the limit ends with the block on every threadpoolctl version - advisor finding of round 3)
         with threadpool_limits(limits=threads):
             t0 = time.perf_counter()
             res = ipm_ref.hsd_solve(core, par)
             dt = time.perf_counter() - t0
     else:
-        # no limiter: the BLAS runs with its own default thread count, which is what gets reported
         threads = os.cpu_count() or threads
         t0 = time.perf_counter()
         res = ipm_ref.hsd_solve(core, par)
@@ -142,13 +169,11 @@ def cpu_baseline(solver, b, n, m, gpu_iterations, budget_iters=None):
     its = max(1, res.iterations)
     per_iter = dt / its
     solves_per_sec = 1.0 / (per_iter * max(1, gpu_iterations))
-    m1 = m + 1
     return {"value": solves_per_sec, "unit": "solves/s", "cores": int(threads), "kind": "port",
-            "iters_per_sec": 1.0 / per_iter,
+            "iters_per_sec": 1.0 / per_iter, "extrapolated": True,
             "executed_tflops_of_the_assembly_formulation": (2.0 * m1 * n ** 3 + float(m1) ** 2 * n ** 2) / per_iter / 1e12,
-            "sample": "%d IPM iterations of the same n=%d, m=%d instance (A copied back from HBM: identical bits) with "
-                      "oracle/ipm_ref.py, Schur assembly in the device path's W formulation on level-3 BLAS (DTRMM, DTRMM, DSYRK), %.1f s; "
-                      "solves/s extrapolated to the %d iterations of the full solve" % (its, n, m, dt, gpu_iterations)}
+            "sample": "%d IPM iterations of the same n=%d, m=%d instance with oracle/ipm_ref.py on numpy (no OpenBLAS to link the C "
+                      "restatement against), %.1f s; solves/s extrapolated to the %d iterations of the full solve" % (its, n, m, dt, gpu_iterations)}
 
 
 def workload_name(n, m):
@@ -360,7 +385,7 @@ def bench_t1(hb, seed, barrier, cpu=False):
             out["roofline"]["from_committed_pmc_profile"] = pmc
         if cpu:
             try:
-                out["cpu_baseline"] = cpu_baseline(s, b, n, m, int(round(its / len(infos))), budget_iters=1)
+                out["cpu_baseline"] = cpu_baseline(s, b, n, m, int(round(its / len(infos))), budget_iters=2)
             except Exception as e:
                 out["cpu_baseline"] = {"error": repr(e)}
         return out

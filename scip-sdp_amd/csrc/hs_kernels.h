@@ -108,6 +108,9 @@ struct hs_schur_ws
    void*     evX[2];       /* hipEvent_t: the exchange of a slice has arrived */
    void*     ev_g2;        /* hipEvent_t or NULL: hs_schur_W waits for it between its first and its second product (the inverse factor of Z
                             * is formed on another queue while A_stack R runs; set and cleared by the caller around the call) */
+   int       (*after_g1)(void*);   /* or NULL: called by hs_schur_W when its first product is in the queue (the caller puts work of its
+                                    * own into other queues there - it may set ev_g2); once, then cleared */
+   void*     after_g1_arg;
 };
 int  hs_schur_ws_alloc(hs_schur_ws* w, int m1, long long n2max, double budget_gb);
 void hs_schur_ws_free(hs_schur_ws* w);

@@ -529,7 +529,7 @@ extern "C" int hipsdp_create(hipsdp_solver** out, int device)
    s->schur_mode_rows = false;
    s->schur_mode_cols = false; s->schur_sim_shards = 0;
    s->sws.T = s->sws.U = s->sws.K = s->sws.V = s->sws.U2 = s->sws.V2 = NULL;
-   s->sws.evP[0] = s->sws.evP[1] = s->sws.evX[0] = s->sws.evX[1] = NULL; s->sws.ev_g2 = NULL;
+   s->sws.evP[0] = s->sws.evP[1] = s->sws.evX[0] = s->sws.evX[1] = NULL; s->sws.ev_g2 = NULL; s->sws.after_g1 = NULL; s->sws.after_g1_arg = NULL;
    s->flags = NULL;
    s->hsc = NULL;
    s->hsc_dev = NULL;
@@ -724,7 +724,7 @@ extern "C" int hipsdp_set_shape2(hipsdp_solver* s, int m, int nblocks, const int
             /* what depends on the counts themselves */
             hs_schur_ws_free(&s->sws);
             s->sws.T = s->sws.U = s->sws.K = s->sws.V = s->sws.U2 = s->sws.V2 = NULL;
-            s->sws.evP[0] = s->sws.evP[1] = s->sws.evX[0] = s->sws.evX[1] = NULL; s->sws.ev_g2 = NULL;
+            s->sws.evP[0] = s->sws.evP[1] = s->sws.evX[0] = s->sws.evX[1] = NULL; s->sws.ev_g2 = NULL; s->sws.after_g1 = NULL; s->sws.after_g1_arg = NULL;
             s->m = m; s->q = q;
             s->a_r0 = 0; s->a_r1 = (int) m1s;
             s->u1 = s->rhs2 + 2LL * m;
@@ -903,7 +903,7 @@ extern "C" int hipsdp_set_shape2(hipsdp_solver* s, int m, int nblocks, const int
       HS_CALL( hs_trsv_sync_init(s->stream, m, s->trsv_ws, &s->trsv_epoch) );
    s->trsv_epoch = 0;
    s->sws.T = s->sws.U = s->sws.K = s->sws.V = s->sws.U2 = s->sws.V2 = NULL;
-   s->sws.evP[0] = s->sws.evP[1] = s->sws.evX[0] = s->sws.evX[1] = NULL; s->sws.ev_g2 = NULL;
+   s->sws.evP[0] = s->sws.evP[1] = s->sws.evX[0] = s->sws.evX[1] = NULL; s->sws.ev_g2 = NULL; s->sws.after_g1 = NULL; s->sws.after_g1_arg = NULL;
    HS_HIP( hipMemsetAsync(s->Dext, 0, (size_t) ((long long) q * m1 > 0 ? (long long) q * m1 : 1) * sizeof(double), s->stream) );
    HS_HIP( hipMemsetAsync(s->b, 0, (size_t) (m > 0 ? m : 1) * sizeof(double), s->stream) );
    HS_HIP( hipStreamSynchronize(s->stream) );
@@ -3138,15 +3138,37 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
             HS_CALL( hs_potrf(st, n, B.Lx, B.dinvx, s->flags + 1, NULL) );
          }
          HS_CALL( hs_zero_upper(st, B.Lx, n) );
+         HS_CALL( hs_trtri(st, n, B.Lx, B.dinvx, B.LxInv, B.T1) );
       }
-      /* round 6: the inverse factor of X is not an operand of the assembly (W_j = G A_j R takes R = Lx itself) - it goes to the second
-       * queue behind the Z chain and runs beside the first product of the assembly instead of in front of it (75 us at n = 500);
-       * the first queue meets the second one again before anything reads LxInv */
-      HS_CALL( fork2(s) );
-      for (auto& B : s->blk)
-         if ( B.n > 64 )
-            HS_CALL( hs_trtri(s->stream2, B.n, B.Lx, B.dinvx, B.LxInv, B.T1) );
       xchain_queued = true;
+      return HS_OK;
+   };
+   /* round 6: every block above 64 rows, one rank, the W formulation (W_j = G A_j R): the inverse factor of X is not an operand of the
+    * assembly (R = Lx itself) and G = LzInv is the operand of its SECOND product only.  The chains of the second queue are then
+    * awaited between the first and the second product (hs_schur_ws.ev_g2), and the inverse factor of X is put into the second queue
+    * when the first product has been launched (hs_schur_ws.after_g1) - 75 us of device time and as much of the host's launching that
+    * stood between the termination decision and the assembly (profiles/r06_*_iter_sequence.txt). */
+   auto defer_possible = [&]() -> bool
+   {
+      if ( !(s->use2 && !no_overlap && s->comm == NULL && !s->shardA && !s->schur_mode_cols && !s->schur_mode_rows
+            && !s->schur_mode_U && !s->schur_mode_forced && K > 0 && getenv("HIPSDP_NO_DEFER_JOIN") == NULL) )
+         return false;
+      for (auto& B : s->blk)
+         if ( B.n <= 64 || B.sparse )
+            return false;
+      return true;
+   };
+   struct AfterG1 { hipsdp_solver* s; };
+   AfterG1 after_g1_arg = {s};
+   auto after_g1_fn = [](void* p) -> int
+   {
+      hipsdp_solver* s = static_cast<AfterG1*>(p)->s;
+      HS_HIP( hipEventRecord(s->evFork, s->stream) );              /* (behind hs_zero_upper of Lx and the first product) */
+      HS_HIP( hipStreamWaitEvent(s->stream2, s->evFork, 0) );
+      for (auto& B : s->blk)
+         HS_CALL( hs_trtri(s->stream2, B.n, B.Lx, B.dinvx, B.LxInv, B.T1) );
+      HS_HIP( hipEventRecord(s->evJoin, s->stream2) );
+      s->sws.ev_g2 = (void*) s->evJoin;
       return HS_OK;
    };
 
@@ -3163,7 +3185,7 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
             zchain_queued = true;
          }
          HS_CALL( enqueue_residuals() );
-         HS_CALL( read_scalars(s, hs, NULL, (zchain_queued && s->comm == NULL) ? &enqueue_x_chains : NULL) );
+         HS_CALL( read_scalars(s, hs, NULL, (zchain_queued && s->comm == NULL && !(factors_valid && defer_possible())) ? &enqueue_x_chains : NULL) );
       }
       residuals_ready = false;
 
@@ -3318,6 +3340,7 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
 
       /* ---- factorizations (the factors of an accepted step are re-used: they were computed by its Cholesky check) */
       phase_mark(s, PH_FACTOR);
+      const bool defer_join = defer_possible() && !(identity_start && it == 0) && !xchain_queued;
       if ( !zchain_queued )
       {
          if ( !(setf && m <= 64) )
@@ -3367,21 +3390,15 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
             HS_CALL( hs_potrf(st, n, B.Lx, B.dinvx, s->flags + 1, NULL) );
          }
          HS_CALL( hs_zero_upper(st, B.Lx, n) );
-         HS_CALL( hs_trtri(st, n, B.Lx, B.dinvx, B.LxInv, B.T1) );
+         if ( !defer_join )
+            HS_CALL( hs_trtri(st, n, B.Lx, B.dinvx, B.LxInv, B.T1) );
          }
       }
-      /* round 6: every block above 64 rows, one rank, the W formulation: the chains of the second queue (inverse factor of Z - the G of
-       * W_j = G A_j R -, inverse factor of X) are awaited between the first and the second product of the assembly, not in front of
-       * it */
-      bool defer_join = s->use2 && !no_overlap && s->comm == NULL && !s->shardA && !s->schur_mode_cols && !s->schur_mode_rows
-         && !s->schur_mode_U && !s->schur_mode_forced && K > 0 && !(identity_start && it == 0) && getenv("HIPSDP_NO_DEFER_JOIN") == NULL;
-      for (auto& B : s->blk)
-         if ( B.n <= 64 || B.sparse )
-            defer_join = false;
       if ( defer_join )
       {
-         HS_HIP( hipEventRecord(s->evJoin, s->stream2) );
-         s->sws.ev_g2 = (void*) s->evJoin;
+         /* (the inverse factor of X follows the first product into the second queue; the event is recorded behind it) */
+         s->sws.after_g1 = after_g1_fn;
+         s->sws.after_g1_arg = &after_g1_arg;
       }
       else
          HS_CALL( join2(s) );
@@ -3540,8 +3557,9 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
       }
       if ( defer_join )
       {
-         /* (the first queue has waited for the event inside hs_schur_W; once more for whoever follows, and the hook is taken out) */
+         /* (the first queue has waited for the event inside hs_schur_W; once more for whoever follows, and the hooks are taken out) */
          s->sws.ev_g2 = NULL;
+         s->sws.after_g1 = NULL;
          HS_CALL( join2(s) );
       }
       HS_HIP( hipEventRecord(s->ev1, st) );
@@ -3877,7 +3895,7 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
                   rd_scale = 1.0 - alpha * eta;
                }
                HS_CALL( enqueue_residuals() );
-               HS_CALL( read_scalars(s, hs, hflags, (zchain_queued && s->comm == NULL) ? &enqueue_x_chains : NULL) );
+               HS_CALL( read_scalars(s, hs, hflags, (zchain_queued && s->comm == NULL && !defer_possible()) ? &enqueue_x_chains : NULL) );
                if ( hflags[0] == 0 && hflags[1] == 0 )
                   break;
                /* the step was too long: everything queued behind the check ran on an iterate that is given up */

@@ -26,6 +26,15 @@ static int hs_rec_gemv_t(hipStream_t s, int R, long long E, const double* A, lon
    double* out);
 
 struct __attribute__((aligned(16))) dbl2 { double x, y; };
+/* 16 bytes of a row that is read once per sweep (the constraint matrices): the load does not allocate in the caches, so that what the
+ * sweep runs beside - the factorization of M on the other queue, the vectors of the sweep itself - stays in L2 */
+__device__ __forceinline__ dbl2 load_stream2(const double* p)
+{
+   typedef double gv2 __attribute__((ext_vector_type(2)));
+   const gv2 t = __builtin_nontemporal_load(reinterpret_cast<const gv2*>(p));
+   dbl2 r; r.x = t.x; r.y = t.y;
+   return r;
+}
 
 static inline int hs_launch_ok(void)
 {
@@ -1747,8 +1756,12 @@ __global__ void __launch_bounds__(256) k_gemv_n(int R, long long E, const double
 
    if ( VEC )
    {
-      /* chunk and e0 are even, all bases 16-byte aligned */
-      for (long long e = e0 + 2 * threadIdx.x; e + 1 < e1; e += 512)
+      /* chunk and e0 are even, all bases 16-byte aligned.  [Round 6, measured and not kept: four 16-byte pieces of the row in flight
+       * per thread as non-allocating loads - 185 against 169 us per sweep at the bench size, and a block column of the factorization of
+       * M on the other queue waited 130 us for compute units beside it (profiles/r06_sweep_streaming_loads.txt).  The column sweeps
+       * k_gemv_t / k_gemv_t3 do take the non-allocating loads: 155 -> 145 us.] */
+      long long e = e0 + 2 * threadIdx.x;
+      for (; e + 1 < e1; e += 512)
       {
          const dbl2 x = *reinterpret_cast<const dbl2*>(a + e);
 #pragma unroll
@@ -1936,7 +1949,7 @@ __global__ void __launch_bounds__(256) k_gemv_t(int R, long long E, const double
             dbl2 x[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q)
-               x[q] = *reinterpret_cast<const dbl2*>(a + (long long) (i + q) * lda);
+               x[q] = load_stream2(a + (long long) (i + q) * lda);
 #pragma unroll
             for (int q = 0; q < 8; ++q)
             {
@@ -2011,7 +2024,7 @@ __global__ void __launch_bounds__(256) k_gemv_t3(int R, long long E, const doubl
       dbl2 xx[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q)
-         xx[q] = *reinterpret_cast<const dbl2*>(a + (long long) (i + q) * lda);
+         xx[q] = load_stream2(a + (long long) (i + q) * lda);
 #pragma unroll
       for (int q = 0; q < 8; ++q)
       {

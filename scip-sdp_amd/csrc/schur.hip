@@ -28,6 +28,7 @@ int hs_schur_ws_alloc(hs_schur_ws* w, int m1, long long n2max, double budget_gb)
    w->T = w->U = w->K = w->V = w->U2 = w->V2 = NULL;
    w->evP[0] = w->evP[1] = w->evX[0] = w->evX[1] = NULL;
    w->ev_g2 = NULL;
+   w->after_g1 = NULL; w->after_g1_arg = NULL;
    w->capT = w->capV = 0;
    const double need_full = 2.0 * 8.0 * (double) m1 * (double) n2max;
    long long cols = m1;
@@ -198,6 +199,12 @@ int hs_schur_W(hipStream_t s, int m1, int n, const double* A, const double* R, c
    /* GEMM1: T = A_stack * R, R lower triangular */
    hs_gemm_args g1 = {(int) rows, n, n, HS_KC, HS_MC, A, n, 0, R, n, 0, w->T, n, 0, 1.0, 0.0, 1, HS_GEMM_B_LOWTRI, 1, NULL};   /* measured: the XCD remap costs 45 % on this shape */
    HS_CALL( hs_dgemm(s, &g1) );
+   if ( w->after_g1 != NULL )
+   {
+      int (*f)(void*) = w->after_g1;
+      w->after_g1 = NULL;
+      HS_CALL( f(w->after_g1_arg) );
+   }
    if ( w->ev_g2 != NULL )
       HS_HIP( hipStreamWaitEvent(s, (hipEvent_t) w->ev_g2, 0) );
    /* GEMM2: W_j = G * T_j, G lower triangular */
@@ -303,6 +310,7 @@ int hs_schur_ws_alloc_var(hs_schur_ws* w, int m1, int nranks, int n, int cwmax)
    w->T = w->U = w->K = w->V = w->U2 = w->V2 = NULL;
    w->evP[0] = w->evP[1] = w->evX[0] = w->evX[1] = NULL;
    w->ev_g2 = NULL;
+   w->after_g1 = NULL; w->after_g1_arg = NULL;
    w->full = 0; w->chunk_cols = 0; w->n2 = 0;
    const long long cj = (m1 + nranks - 1) / nranks;
    long long rowsmax = 1;
