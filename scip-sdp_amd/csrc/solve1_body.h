@@ -54,7 +54,16 @@
  * Results must be the release build's bit for bit. */
 #define S1_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); } while (0)
 #else
-#define S1_WSYNC() do { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); } while (0)
+/* Release form: the hardware serves a wavefront's LDS instructions in order, so lanes that exchange data through LDS need the wait for
+ * the LDS counter and nothing else - but the COMPILER has to be told as well that memory changes hands here (as pd_wave_sync of
+ * chol.hip tells it): without the two wavefront-scope fences nothing forbids it to keep a value loaded before the exchange, or to move
+ * a load across it.  Round 6 (profiles/r06_solve1_debug_release_root_cause.txt): the variant of commit f33223b
+ * whose debug build walked other iterates than its release build does so with -ffp-contract=off as well (not contraction), its release
+ * build gives the same bits with the full hardware fences of the debug form (not a missing hardware ordering) - and its DEBUG build gives
+ * other bits on the same five shapes depending on which form of this macro it uses: what varied was the freedom this macro left the
+ * compiler.  The fences below take it away; they emit no instruction. */
+#define S1_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); \
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #endif
 
 /* ---- size classes (round 5).  The kernel is compiled once per class, each instance with the code of its class only (rounds 4's
