@@ -1319,12 +1319,65 @@ __global__ void __launch_bounds__(1024) k_trsv(int n, const double* __restrict__
    }
 }
 
+/* x = (L L^T)^-1 r for a single-block factor (n <= 64) by substitution in the oracle's order, one right-hand side per wavefront
+ * (hs_kernels.h: hs_wl_msolve) */
+__global__ void __launch_bounds__(256) k_msolve_sub64(int n, const double* __restrict__ L, double* __restrict__ rhs, long long ldr)
+{
+   __shared__ double sL[64 * 65];
+   for (int e = threadIdx.x; e < n * n; e += blockDim.x)
+   {
+      const int i = e / n, j = e - i * n;
+      if ( j <= i )
+         sL[i * 65 + j] = L[(long long) i * n + j];
+   }
+   __syncthreads();
+   const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+   double* v = rhs + (long long) k * ldr;
+   const double x = hs_wl_msolve(sL, n, lane, lane < n ? v[lane] : 0.0);
+   if ( lane < n )
+      v[lane] = x;
+}
+
+/* the same for 64 < n <= 128: two rows per lane, the factor (zeros above the diagonal) in 129 KB of dynamic LDS */
+__global__ void __launch_bounds__(256) k_msolve_sub128(int n, const double* __restrict__ L, double* __restrict__ rhs, long long ldr)
+{
+   extern __shared__ __attribute__((aligned(16))) double sL2[];
+   for (int e = threadIdx.x; e < n * n; e += blockDim.x)
+   {
+      const int i = e / n, j = e - i * n;
+      sL2[i * 129 + j] = (j <= i) ? L[(long long) i * n + j] : 0.0;
+   }
+   __syncthreads();
+   const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+   double* v = rhs + (long long) k * ldr;
+   double x[2] = {v[lane], lane + 64 < n ? v[lane + 64] : 0.0};
+   hs_wl2_msolve<129>(sL2, n, lane, x);
+   v[lane] = x[0];
+   if ( lane + 64 < n )
+      v[lane + 64] = x[1];
+}
+
 int hs_trsv(hipStream_t s, int n, const double* L, const double* dinv, int nrhs, double* rhs, long long ldr, int mode)
 {
    if ( n <= 0 || nrhs <= 0 )
       return HS_OK;
    if ( nrhs > 4 )
       return HS_ERR_ARG;
+   if ( n <= 64 && mode == 7 && hs_small_solve_by_substitution() )
+   {
+      hipLaunchKernelGGL(k_msolve_sub64, dim3(1), dim3(64 * nrhs), 0, s, n, L, rhs, ldr);
+      HS_LAUNCH_CHECK();
+      return HS_OK;
+   }
+   if ( n <= 128 && mode == 7 && hs_small_solve_by_substitution() )
+   {
+      static hs_attr_mask attr_done;
+      const int smem = 128 * 129 * (int) sizeof(double);
+      HS_CALL( hs_func_max_lds(reinterpret_cast<const void*>(&k_msolve_sub128), smem, &attr_done) );
+      hipLaunchKernelGGL(k_msolve_sub128, dim3(1), dim3(64 * nrhs), smem, s, n, L, rhs, ldr);
+      HS_LAUNCH_CHECK();
+      return HS_OK;
+   }
    switch ( nrhs )
    {
    case 1: hipLaunchKernelGGL((k_trsv<1>), dim3(1), dim3(1024), 0, s, n, L, dinv, rhs, ldr, mode); break;

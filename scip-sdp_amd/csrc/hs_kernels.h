@@ -370,6 +370,155 @@ __device__ __forceinline__ void hs_run_node_cmds(const NodeCmd* __restrict__ cmd
 }
 #endif
 
+#ifdef __HIPCC__
+/* ---- one wavefront: x = (L L^T)^-1 r for a single-block factor (m <= 64) in the ORACLE's order (oracle/ipm_ref.py: msolve) - forward
+ * substitution, one correction with the factor itself, backward substitution, one correction - where the default multiplies by an
+ * explicitly inverted factor (with the same corrections).  An option (HIPSDP_SMALL_SOLVE=subst, kernels.hip:
+ * hs_small_solve_by_substitution), built in round 6 to test whether the inverted blocks are why the general path parts from the oracle
+ * on singular Schur complements; they are not.
+ * sL: LDS image of L, row i at sL + 65 i (entries j <= i valid, the diagonal included); lane = row; r, result: this lane's entry. */
+__device__ __forceinline__ double hs_wl_bcast(double v, int src)
+{
+   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+   return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double hs_wl_fwd(const double* sL, int m, int lane, double di, double x)
+{
+   const bool live = lane < m;
+   const double* row = sL + (live ? lane : 0) * 65;
+   double a = live ? x : 0.0;
+   for (int k = 0; k < m; ++k)
+   {
+      const double y = hs_wl_bcast(a * di, k);
+      const double c = row[k];
+      if ( live && lane > k )
+         a = fma(-c, y, a);
+   }
+   return a * di;
+}
+__device__ __forceinline__ double hs_wl_bwd(const double* sL, int m, int lane, double di, double x)
+{
+   const bool live = lane < m;
+   const int col = live ? lane : 0;
+   double a = live ? x : 0.0;
+   for (int k = m - 1; k >= 0; --k)
+   {
+      const double y = hs_wl_bcast(a * di, k);
+      const double c = sL[k * 65 + col];
+      if ( live && lane < k )
+         a = fma(-c, y, a);
+   }
+   return a * di;
+}
+/* (L w)_lane and (L^T v)_lane */
+__device__ __forceinline__ double hs_wl_mulL(const double* sL, int m, int lane, double w)
+{
+   const bool live = lane < m;
+   const double* row = sL + (live ? lane : 0) * 65;
+   double acc = 0.0;
+   for (int j = 0; j < m; ++j)
+   {
+      const double wj = hs_wl_bcast(w, j);
+      const double c = row[j];
+      if ( live && j <= lane )
+         acc = fma(c, wj, acc);
+   }
+   return acc;
+}
+__device__ __forceinline__ double hs_wl_mulLt(const double* sL, int m, int lane, double v)
+{
+   const bool live = lane < m;
+   const int col = live ? lane : 0;
+   double acc = 0.0;
+   for (int j = 0; j < m; ++j)
+   {
+      const double vj = hs_wl_bcast(v, j);
+      const double c = sL[j * 65 + col];
+      if ( live && j >= lane )
+         acc = fma(c, vj, acc);
+   }
+   return acc;
+}
+/* the same for 64 < m <= 128: two rows per lane (lane and lane + 64), L at pitch P (odd) in LDS; x[0], x[1]: this lane's two entries */
+template<int P>
+__device__ __forceinline__ void hs_wl2_fwd(const double* sL, int m, int lane, const double (&di)[2], double (&a)[2])
+{
+   const int r0 = lane, r1 = lane + 64;
+   const bool l1 = r1 < m;
+   const double* row0 = sL + r0 * P;
+   const double* row1 = sL + (l1 ? r1 : 0) * P;
+   for (int k = 0; k < m; ++k)
+   {
+      const double y = (k < 64) ? hs_wl_bcast(a[0] * di[0], k) : hs_wl_bcast(a[1] * di[1], k - 64);
+      const double c0 = row0[k], c1 = row1[k];
+      if ( r0 > k ) a[0] = fma(-c0, y, a[0]);
+      if ( l1 && r1 > k ) a[1] = fma(-c1, y, a[1]);
+   }
+   a[0] *= di[0]; a[1] *= di[1];
+}
+template<int P>
+__device__ __forceinline__ void hs_wl2_bwd(const double* sL, int m, int lane, const double (&di)[2], double (&a)[2])
+{
+   const int r0 = lane, r1 = lane + 64;
+   const bool l1 = r1 < m;
+   const int c1col = l1 ? r1 : 0;
+   for (int k = m - 1; k >= 0; --k)
+   {
+      const double y = (k < 64) ? hs_wl_bcast(a[0] * di[0], k) : hs_wl_bcast(a[1] * di[1], k - 64);
+      const double c0 = sL[k * P + r0], c1 = sL[k * P + c1col];
+      if ( r0 < k ) a[0] = fma(-c0, y, a[0]);
+      if ( l1 && r1 < k ) a[1] = fma(-c1, y, a[1]);
+   }
+   a[0] *= di[0]; a[1] *= di[1];
+}
+template<int P, bool TRANS>
+__device__ __forceinline__ void hs_wl2_mul(const double* sL, int m, int lane, const double (&w)[2], double (&out)[2])
+{
+   const int r0 = lane, r1 = lane + 64;
+   const bool l1 = r1 < m;
+   const int q1 = l1 ? r1 : 0;
+   double s0 = 0.0, s1 = 0.0;
+   for (int j = 0; j < m; ++j)
+   {
+      const double wj = (j < 64) ? hs_wl_bcast(w[0], j) : hs_wl_bcast(w[1], j - 64);
+      const double c0 = TRANS ? sL[j * P + r0] : sL[r0 * P + j];
+      const double c1 = TRANS ? sL[j * P + q1] : sL[q1 * P + j];
+      if ( TRANS ? j >= r0 : j <= r0 ) s0 = fma(c0, wj, s0);
+      if ( l1 && (TRANS ? j >= r1 : j <= r1) ) s1 = fma(c1, wj, s1);
+   }
+   out[0] = s0; out[1] = s1;
+}
+/* sL must hold zeros above the diagonal (the transposed accesses of rows past a lane's own are masked, the others read them) */
+template<int P>
+__device__ __forceinline__ void hs_wl2_msolve(const double* sL, int m, int lane, double (&x)[2])
+{
+   const int r1 = lane + 64;
+   double di[2] = {1.0 / sL[lane * P + lane], r1 < m ? 1.0 / sL[r1 * P + r1] : 0.0};
+   double r[2] = {x[0], r1 < m ? x[1] : 0.0}, w[2] = {r[0], r[1]}, t[2], c[2];
+   hs_wl2_fwd<P>(sL, m, lane, di, w);
+   hs_wl2_mul<P, false>(sL, m, lane, w, t);
+   c[0] = r[0] - t[0]; c[1] = r[1] - t[1];
+   hs_wl2_fwd<P>(sL, m, lane, di, c);
+   w[0] += c[0]; w[1] += c[1];
+   double v[2] = {w[0], w[1]};
+   hs_wl2_bwd<P>(sL, m, lane, di, v);
+   hs_wl2_mul<P, true>(sL, m, lane, v, t);
+   c[0] = w[0] - t[0]; c[1] = w[1] - t[1];
+   hs_wl2_bwd<P>(sL, m, lane, di, c);
+   x[0] = v[0] + c[0]; x[1] = v[1] + c[1];
+}
+__device__ __forceinline__ double hs_wl_msolve(const double* sL, int m, int lane, double r)
+{
+   const double di = lane < m ? 1.0 / sL[lane * 65 + lane] : 0.0;
+   double w = hs_wl_fwd(sL, m, lane, di, r);
+   w += hs_wl_fwd(sL, m, lane, di, r - hs_wl_mulL(sL, m, lane, w));
+   double v = hs_wl_bwd(sL, m, lane, di, w);
+   v += hs_wl_bwd(sL, m, lane, di, w - hs_wl_mulLt(sL, m, lane, v));
+   return v;
+}
+#endif
+
 struct hs_solve1_args
 {
    int m, q, nblk;
@@ -393,6 +542,7 @@ struct hs_solve1_args
    double* hist;                           /* optional: 16 doubles per iteration (tests, tools) */
    unsigned long long seq; unsigned long long* flag;   /* when flag != NULL: *flag = seq once out[] is complete */
 };
+int hs_small_solve_by_substitution(void);
 int hs_solve1_fits(int m, int q, int nblk, const int* n);
 long long hs_solve1_ws_doubles(int m, int q, int nblk, const int* n);
 int hs_solve1_launch(hipStream_t st, const hs_solve1_args* a);

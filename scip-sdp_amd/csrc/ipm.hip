@@ -1543,11 +1543,41 @@ __global__ void k_after_solve2(int m, const double* __restrict__ rhs2, double* _
  * kernels.hip: the residual of these solves is primal infeasibility of the step), then u2 = ub - w and wt = [1, -w]: k_rhs2 + the
  * triangular solves + k_after_solve2 in one launch */
 __global__ void __launch_bounds__(128) k_solve2_small(int m, const double* __restrict__ Mx, const double* __restrict__ b,
-   const double* __restrict__ dinv, const double* __restrict__ L, double* __restrict__ rhs2, double* __restrict__ u2, double* __restrict__ wt)
+   const double* __restrict__ dinv, const double* __restrict__ L, double* __restrict__ rhs2, double* __restrict__ u2, double* __restrict__ wt,
+   int subst)
 {
    __shared__ double r[2][64], t[2][64], c[2][64];
+   __shared__ double sL[64 * 65];
    const int k = threadIdx.x >> 6, i = threadIdx.x & 63;
    r[k][i] = (i < m) ? (k == 0 ? Mx[1 + i] : b[i]) : 0.0;
+   if ( subst )
+   {
+      /* round 6 (HIPSDP_SMALL_SOLVE=subst): substitution with the factor itself in the oracle's order, one right-hand side per wavefront */
+      for (int e = threadIdx.x; e < m * m; e += 128)
+      {
+         const int ii = e / m, jj = e - ii * m;
+         if ( jj <= ii )
+            sL[ii * 65 + jj] = L[(long long) ii * m + jj];
+      }
+      __syncthreads();
+      const double x = hs_wl_msolve(sL, m, i, r[k][i]);
+      __syncthreads();
+      r[k][i] = x;
+      __syncthreads();
+      if ( i < m )
+         rhs2[k * m + i] = x;
+      if ( k == 0 )
+      {
+         if ( i == 0 )
+            wt[0] = 1.0;
+         if ( i < m )
+         {
+            u2[i] = r[1][i] - r[0][i];
+            wt[1 + i] = -r[0][i];
+         }
+      }
+      return;
+   }
    __syncthreads();
    /* forward: t = Y r, c = r - L t, t += Y c */
    double acc = 0.0;
@@ -3595,7 +3625,7 @@ static int solve_impl(hipsdp_solver* s, const hipsdp_params* params, hipsdp_info
          HS_CALL( hs_potrf_psd(st, m, s->Lm, s->dinvm, s->flags + 2, s->dya, s->regmask, setf) );
          if ( m <= 64 )
          {
-            hipLaunchKernelGGL(k_solve2_small, dim3(1), dim3(128), 0, st, m, s->Mx, s->b, s->dinvm, s->Lm, s->rhs2, s->u2, s->wt);
+            hipLaunchKernelGGL(k_solve2_small, dim3(1), dim3(128), 0, st, m, s->Mx, s->b, s->dinvm, s->Lm, s->rhs2, s->u2, s->wt, hs_small_solve_by_substitution());
             HS_LAUNCH_CHECK();
          }
          else

@@ -1094,6 +1094,28 @@ __global__ void __launch_bounds__(256) k_red_batch(rb_args A)
          const double* Da = (const double*) D.p[0];
          const double* Db = (const double*) D.p[1];
          const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
+         if ( D.i[1] )
+         {
+            /* round 6 (HIPSDP_SMALL_SOLVE=subst): substitution with the factor itself in the oracle's order (hs_kernels.h: hs_wl_msolve),
+             * one right-hand side per wavefront */
+            for (int e = threadIdx.x; e < m * m; e += 256)
+            {
+               const int i = e / m, j = e - i * m;
+               if ( j <= i )
+                  sL[i * 65 + j] = Db[(long long) i * m + j];
+            }
+            __syncthreads();
+            const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+            for (int k = wv; k < D.accumulate; k += 4)
+            {
+               double* vec = (double*) D.p[3] + k * stride;
+               const double x = hs_wl_msolve(sL, m, ln, ln < m ? vec[ln] : 0.0);
+               if ( ln < m )
+                  vec[ln] = x;
+            }
+            __syncthreads();
+            break;
+         }
          for (int e = threadIdx.x; e < m * m; e += 256)
          {
             const int i = e / m, j = e - i * m;
@@ -1447,13 +1469,29 @@ int hs_copy_scalar(hipStream_t s, double* dst, const double* src)
    return hs_copy(s, dst, src, 1);
 }
 
+/* HIPSDP_SMALL_SOLVE=subst: the solves with the factor of M for m <= 128 substitute in the oracle's order (hs_kernels.h: hs_wl_msolve,
+ * hs_wl2_msolve; chol.hip: k_msolve_sub64 / 128) instead of multiplying by explicitly inverted diagonal blocks with one correction per
+ * triangular solve (the default since round 2).  Round 6 built it to test the reading that the general path parts from the oracle on
+ * singular Schur complements BECAUSE of the inverted blocks - it does not hold up: on 27 fuzz shapes where the
+ * one-launch kernel and the general path disagree, status agreement WITH THE ORACLE is 20 of 27 either way, and on a fresh slice of 400
+ * shapes the two paths disagree on 6 (substitution) against 4 (inverse) - profiles/r06_small_solve_substitution.txt.  Kept as a switch
+ * (read at every call: tests flip it), not as the default. */
+int hs_small_solve_by_substitution(void)
+{
+   const char* e = getenv("HIPSDP_SMALL_SOLVE");
+   return (e != NULL && e[0] == 's') ? 1 : 0;
+}
+
 /* records  vec[k] <- inv(L)^T inv(L) vec[k]  (k < nrhs, vectors ld apart) for a single-block factor (m <= 64, dinv = inv(L) as
  * 64 x 64, L = the factor itself as m x m: each triangular solve is corrected once with it); 1: recorded, 0: no batch open */
 int hs_red_batch_solve(hipStream_t s, int m, const double* dinv, const double* L, int nrhs, double* vec, long long ld)
 {
    if ( m > 64 )
       return 0;
-   return rb_record(s, RB_SOLVE, m, dinv, L, NULL, vec, nrhs, (double) ld);
+   if ( !rb_record(s, RB_SOLVE, m, dinv, L, NULL, vec, nrhs, (double) ld) )
+      return 0;
+   g_rb.args.d[g_rb.args.cnt - 1].i[1] = hs_small_solve_by_substitution();
+   return 1;
 }
 
 /* records the closing kernel of a direction; the parameter block is copied.  1: recorded, 0: no batch open */

@@ -431,6 +431,28 @@ def test_preoptimal_iterate_matches_the_oracle(gpu):
         s.close()
 
 
+@pytest.mark.parametrize("n,m", [(12, 30), (20, 64), (16, 100), (24, 128)])
+def test_solves_with_m_by_substitution_in_the_oracles_order(gpu, n, m, monkeypatch):
+    """HIPSDP_SMALL_SOLVE=subst (round 6): on the general path the solves with the factor of M for m <= 128 substitute with the factor itself
+    in the oracle's order (msolve of oracle/ipm_ref.py: forward, one correction, backward, one correction; one lane per row, two rows per
+    lane above 64) instead of multiplying by inverted diagonal blocks.  Same status and iteration count as the oracle and as the default,
+    objective to 1e-6 (y too where it is unique)."""
+    b, A, ys, Xs, Zs = instances.planted_dense(n, min(m, n * (n + 1) // 2 - 1))
+    core = ipm_ref.CoreProblem(b, [A])
+    ref = ipm_ref.hsd_solve(core, ipm_ref.Params(gaptol=1e-6, feastol=1e-6))
+    monkeypatch.setenv("HIPSDP_SOLVE1", "0")
+    dflt = gpu_solve(gpu, core, gaptol=1e-6, feastol=1e-6)
+    monkeypatch.setenv("HIPSDP_SMALL_SOLVE", "subst")
+    sub = gpu_solve(gpu, core, gaptol=1e-6, feastol=1e-6)
+    assert ref.status == 0 and dflt["info"].status == 0 and sub["info"].status == 0
+    assert sub["info"].iterations == ref.iterations == dflt["info"].iterations
+    # (objectives: with m close to the dimension of the matrix space the optimal y is not unique to this accuracy)
+    assert abs(sub["info"].dobj - ref.dobj) <= 1e-6 * (1 + abs(ref.dobj)) and abs(sub["info"].dobj - dflt["info"].dobj) <= 1e-6 * (1 + abs(ref.dobj))
+    if m <= n * (n + 1) // 4:
+        assert np.max(np.abs(sub["y"] - ref.y)) <= 1e-6 and np.max(np.abs(sub["y"] - dflt["y"])) <= 1e-6
+    assert not np.array_equal(sub["y"], dflt["y"])                    # (another algorithm: other last bits)
+
+
 @pytest.mark.parametrize("sizes", [(100,), (70, 20)])
 def test_failed_cholesky_check_takes_the_optimistic_step_back(gpu, sizes, monkeypatch):
     """Round 6: on the general path the rest of the step and the residual pass of the next iterate are queued behind the Cholesky check

@@ -483,13 +483,13 @@ def test_numerical_failure_of_the_kernel_falls_back_to_the_general_path(gpu, mon
     assert info.status == 5 and path == 1
 
 
-@pytest.mark.parametrize("seed", [70387, 70733])
-def test_warm_started_numerical_failure_of_the_kernel_retries_from_the_same_start(gpu, seed, monkeypatch):
+@pytest.mark.parametrize("seed,loose", [(70387, 1e-4), (70733, 1e-2)])
+def test_warm_started_numerical_failure_of_the_kernel_retries_from_the_same_start(gpu, seed, loose, monkeypatch):
     """a WARM-started solve (the B&B regime) that the kernel gives up on numerically is solved again by the general path
     from the caller's start point - the kernel leaves y, x, z, X, Z in device memory as the setters wrote them (hs_solve1_args.keep_on_fail)
     - before the caller's settings ladder sees a failure.  Two shapes of the fuzz family (found with tests/devtools/warm_fallback_search.py:
-    cond(M) about 1e14, the start is the general path's iterate at tolerance 1e-2): the kernel alone (HIPSDP_SOLVE1_NO_FALLBACK=1) ends in
-    status 5, the default returns exactly what the general path returns from that start - the same bits - and counts the retry."""
+    cond(M) about 1e14, the start is the general path's iterate at a loose tolerance): the kernel alone (HIPSDP_SOLVE1_NO_FALLBACK=1) ends
+    in status 5, the default returns exactly what the general path returns from that start - the same bits - and counts the retry."""
     import fuzz_shapes
     core, tag = fuzz_shapes.problem(seed)
     K = len(core.blocks)
@@ -497,7 +497,7 @@ def test_warm_started_numerical_failure_of_the_kernel_retries_from_the_same_star
     lib.hipsdp_solve1_fallbacks_warm.restype = C.c_longlong
     monkeypatch.setenv("HIPSDP_SOLVE1", "0")
     s = gpu.Solver(0); s.load_core(core)
-    s.solve(gaptol=1e-2, feastol=1e-2, pabstol=1e-2)
+    s.solve(gaptol=loose, feastol=loose, pabstol=loose)
     y0 = s.y(); X0 = [s.X(k) for k in range(K)]; Z0 = [s.Z(k) for k in range(K)]
     x0, z0 = s.lp() if core.q > 0 else (None, None)
     s.close()
@@ -522,7 +522,8 @@ def test_warm_started_numerical_failure_of_the_kernel_retries_from_the_same_star
     assert lib.hipsdp_solve1_fallbacks_warm() == before + 1
     gen = run("0", False)
     assert dflt[0] == 0 and dflt[3] == 1 and gen[3] == 1, tag
-    assert dflt[1] == gen[1] == 0 and dflt[2] == gen[2] and dflt[4] == gen[4], tag
+    assert dflt[1] == gen[1] and dflt[2] == gen[2] and dflt[4] == gen[4], tag
+    assert gen[1] == 0, tag                                  # (the two cases are ones the general path solves from that start)
     assert np.array_equal(dflt[5], gen[5]), tag
 
 
