@@ -1472,8 +1472,8 @@ int hs_copy_scalar(hipStream_t s, double* dst, const double* src)
 /* HIPSDP_SMALL_SOLVE=subst: the solves with the factor of M for m <= 128 substitute in the oracle's order (hs_kernels.h: hs_wl_msolve,
  * hs_wl2_msolve; chol.hip: k_msolve_sub64 / 128) instead of multiplying by explicitly inverted diagonal blocks with one correction per
  * triangular solve (the default since round 2).  Round 6 built it to test the reading that the general path parts from the oracle on
- * singular Schur complements BECAUSE of the inverted blocks - it does not hold up: on 27 fuzz shapes where the
- * one-launch kernel and the general path disagree, status agreement WITH THE ORACLE is 20 of 27 either way, and on a fresh slice of 400
+ * singular Schur complements BECAUSE of the inverted blocks - it does not hold up: on 24 fuzz shapes where the
+ * one-launch kernel and the general path disagree, status agreement WITH THE ORACLE is 17 (substitution) against 18 (inverse) of 24, and on a fresh slice of 400
  * shapes the two paths disagree on 6 (substitution) against 4 (inverse) - profiles/r06_small_solve_substitution.txt.  Kept as a switch
  * (read at every call: tests flip it), not as the default. */
 int hs_small_solve_by_substitution(void)
