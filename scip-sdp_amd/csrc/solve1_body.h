@@ -3268,7 +3268,7 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
        * operations in the same order as before - only by other lanes -: same bits.
        * (64 < m, the other instance: the factorization is the work of all wavefronts - s1_cholp2 -, the product X Rd comes first.) */
       const bool coop = S1_MBIG && m > 64;
-      const bool shadow = !S1_MBIG;
+      const bool shadow = !S1_MBIG;          /* (the overlapped form; the other instance runs the same work in phases of its own) */
       double mdiag = 1.0;
       int nforced = 0;
       long long tq0 = 0;
@@ -3350,82 +3350,96 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
       }
       else
       {
-      if ( wave == 0 )
-      {
-         /* (the factor overwrites M where it stands; its first column, g, is taken out first) */
-         for (int i = lane; i < m; i += 64)
+         /* 64 < m (the instance with two rows per lane): the factorization is the work of ALL wavefronts (s1_cholp2), so nothing runs
+          * beside it - but the predictor's right-hand side still does not need M: it is formed first (three phases that were behind
+          * the solves before: same cost), and its solve joins the two of the tau elimination on a wavefront of its own behind the
+          * factorization - three substitution passes side by side where there were a pass with two right-hand sides and, later, one
+          * with one, both on wavefront 0 (example_MkP's root, m = 105: 0.221 -> 0.20 ms per iteration). */
          {
-            VEC(V_g)[i] = Mx[MROW(i + 1)];
-            if ( coop )
-               VEC(V_dg)[i] = Mx[MROW(i + 1) + i + 1];
+            int tb = 0;
+            for (int k = 0; k < K; ++k)
+            {
+               const S1Blk& B = sh.blk[k];
+               const int p = B.p;
+               const double* X = sm + B.oX;
+               auto Rd = LP(B.Rd);
+               double* T1 = sm + B.oT1;
+               s1_mm(B.n, wave, lane, 0, S1_NW, tb,
+                  [&](int i, int kk) S1_INL { return X[i * p + kk]; }, [&](int kk, int j) S1_INL { return Rd[kk * p + j]; },
+                  [&](int i, int j, double v) S1_INL { T1[i * p + j] = v; });
+            }
          }
-         if ( P.prof_on ) tq0 = clock64();
-      }
-      if ( coop )
-      {
-         __syncthreads();
-         nforced = s1_cholp2(Mx, m, wave, lane, VEC(V_dg), P.pivot_rule, VEC(V_dg));
-      }
-      if ( wave == 0 )
-      {
-         if ( !coop )
+         S1_BAR();
+         dir_matrix(0.0, 1.0, QV(Q_rd), false, QV(Q_hl));
+         S1_BAR();
+         pass_A(true, QV(Q_hl), VEC(V_AH), 128, no_epi);
+         S1_BAR();
+         if ( wave == 0 )
          {
-            const double dg0 = (lane < m) ? Lm[lane * pm + lane] : 1.0;
-            (void) s1_cholp(Lm, m, pm, lane, true, dg0, P.pivot_rule, false, mdiag, nforced, zsrc);
+            /* (the factor overwrites M where it stands; its first column, g, is taken out first) */
+            for (int i = lane; i < m; i += 64)
+            {
+               VEC(V_g)[i] = Mx[MROW(i + 1)];
+               if ( coop )
+                  VEC(V_dg)[i] = Mx[MROW(i + 1) + i + 1];
+               VEC(V_h)[i] = VEC(V_AH)[i + 1] - eta * VEC(V_rp)[i];
+            }
+            if ( lane == 0 )
+               sh.fl[7] = 0;
+            if ( P.prof_on ) tq0 = clock64();
          }
-         if ( lane == 0 )
-            sh.fl[6] = nforced;
-         mdinv = s1_rcp(mdiag);
-         if ( P.prof_on && lane == 0 ) { const long long tq1 = clock64(); sh.prof[20] += (double) (tq1 - tq0); tq0 = tq1; }
-         msolve2(VEC(V_g), VEC(V_b), VEC(V_w), VEC(V_ub));
-         if ( P.prof_on && lane == 0 ) { const long long tq1 = clock64(); sh.prof[21] += (double) (tq1 - tq0); }
-         bool u2bad = false;
-         double bubp = 0.0;
-         for (int i = lane; i < m; i += 64)
+         S1_BAR();
+         if ( coop )
+            nforced = s1_cholp2(Mx, m, wave, lane, VEC(V_dg), P.pivot_rule, VEC(V_dg));
+         if ( wave == 0 )
          {
-            const double w = VEC(V_w)[i], ub = VEC(V_ub)[i];
-            VEC(V_u2)[i] = ub - w;
-            VEC(V_wt)[i + 1] = -w;
-            u2bad = u2bad || !(fabs(ub - w) < 1e300);
-            bubp = fma(VEC(V_b)[i], ub, bubp);
+            if ( !coop )
+            {
+               const double dg0 = (lane < m) ? Lm[lane * pm + lane] : 1.0;
+               (void) s1_cholp(Lm, m, pm, lane, true, dg0, P.pivot_rule, false, mdiag, nforced, zsrc);
+               mdinv = s1_rcp(mdiag);
+               if ( lane < m )
+                  VEC(V_dg)[lane] = mdinv;
+            }
+            if ( lane == 0 )
+               sh.fl[6] = nforced;
+            if ( P.prof_on && lane == 0 ) { const long long tq1 = clock64(); sh.prof[20] += (double) (tq1 - tq0); tq0 = tq1; }
          }
-         const unsigned long long anybad = __ballot(u2bad);
-         if ( lane == 0 )
-            sh.fl[7] = (anybad != 0ULL) ? 1 : 0;
-         const double bub = s1_wsum(bubp);
-         if ( lane == 0 )
+         S1_BAR();
+         if ( wave == 0 )
          {
-            VEC(V_wt)[0] = 1.0;
-            sh.sc[SC_BUB] = bub;
+            msolve2(VEC(V_g), NULL, VEC(V_w), NULL);
+            for (int i = lane; i < m; i += 64)
+               VEC(V_wt)[i + 1] = -VEC(V_w)[i];
+            if ( lane == 0 )
+               VEC(V_wt)[0] = 1.0;
+            if ( P.prof_on && lane == 0 ) { const long long tq1 = clock64(); sh.prof[21] += (double) (tq1 - tq0); }
          }
-      }
-      {
-         int tb = 0;
-         const int w0 = (S1_NW > 1) ? 1 : 0, nw = S1_NW - w0;
-         for (int k = 0; k < K; ++k)
+         else if ( wave == 1 )
          {
-            const S1Blk& B = sh.blk[k];
-            const int p = B.p;
-            const double* X = sm + B.oX;
-            auto Rd = LP(B.Rd);
-            double* T1 = sm + B.oT1;
-            s1_mm(B.n, wave, lane, w0, nw, tb,
-               [&](int i, int kk) S1_INL { return X[i * p + kk]; }, [&](int kk, int j) S1_INL { return Rd[kk * p + j]; },
-               [&](int i, int j, double v) S1_INL { T1[i * p + j] = v; });
+            if ( !coop )
+               mdinv = (lane < m) ? VEC(V_dg)[lane] : 1.0;
+            msolve2(VEC(V_b), NULL, VEC(V_ub), NULL);
+            double bubp = 0.0;
+            for (int i = lane; i < m; i += 64)
+               bubp = fma(VEC(V_b)[i], VEC(V_ub)[i], bubp);
+            const double bub = s1_wsum(bubp);
+            if ( lane == 0 )
+               sh.sc[SC_BUB] = bub;
          }
-      }
+         else if ( wave == 2 )
+         {
+            if ( !coop )
+               mdinv = (lane < m) ? VEC(V_dg)[lane] : 1.0;
+            msolve2(VEC(V_h), NULL, VEC(V_u1), NULL);
+         }
       }
       S1_BAR();
       S1_STAMP(6);
-      if ( !shadow && sh.fl[7] )
+      /* B_k = A_0 - sum w_i A_i, beta = c - D w (H of the predictor, -X - sym(X Rd Zinv) -> dX, hl, is there already); u2 = ub - w and
+       * the test of its entries */
       {
-         status = HS_S1_NUMERIC; numwhere = __LINE__;
-         break;
-      }
-      /* B_k = A_0 - sum w_i A_i, beta = c - D w; H of the predictor = -X - sym(X Rd Zinv) -> dX, hl (shadow: H is there already; u2 =
-       * ub - w and the test of its entries are the work of this phase) */
-      {
-         if ( shadow && tid < m )
+         if ( tid < m )
          {
             const double w = VEC(V_w)[tid], ub = VEC(V_ub)[tid];
             VEC(V_u2)[tid] = ub - w;
@@ -3445,19 +3459,15 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
          }
          for (int r = tro(128); r < q; r += S1_NT)
             QV(Q_beta)[r] = lp_row(r, wt);
-         if ( !shadow )
-            dir_matrix(0.0, 1.0, QV(Q_rd), false, QV(Q_hl));
       }
       S1_BAR();
-      if ( shadow && sh.fl[7] )
+      if ( sh.fl[7] )
       {
          status = HS_S1_NUMERIC; numwhere = __LINE__;
          break;
       }
       /* A(H), <B, H>; T1 = X B */
       {
-         if ( !shadow )
-            pass_A(true, QV(Q_hl), VEC(V_AH), 128, no_epi);
          bh_partials();
          int tb = 0;
          for (int k = 0; k < K; ++k)
@@ -3497,7 +3507,7 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
       }
       S1_BAR();
       if ( wave == 0 )
-         finish_dir(0.0, 0.0, rg, shadow);
+         finish_dir(0.0, 0.0, rg, true);
       S1_BAR();
       S1_STAMP(7);
       const double dta = sh.sc[SC_DTAU], dka = sh.sc[SC_DKAPPA];
