@@ -29,17 +29,17 @@ FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X FP64 matrix peak (vendor figure; rocB
 # FP64 matrix rate of the two n^3 products / the Gram product.  Keyed by (n, m), quoted from the committed file named in
 # "source" and labelled as such in the JSON line; one GPU only; None for sizes that were not profiled.
 PMC_FROM_PROFILES = {
-    (500, 1000): {"traffic_bytes_per_assembly": 23.30e9, "mfma_busy": {"n3_products": 0.760, "gram": 0.855},
-                  "executed_tflops": {"n3_products": 47.5, "gram": 55.0},
-                  "traffic_is": "L2-miss traffic (FETCH_SIZE x 2 + WRITE_SIZE) of one GENERAL assembly: 6.61 + 7.16 GB for the two n^3 products "
+    (500, 1000): {"traffic_bytes_per_assembly": 23.32e9, "mfma_busy": {"n3_products": 0.755, "gram": 0.842},
+                  "executed_tflops": {"n3_products": 49.8, "gram": 54.8},
+                  "traffic_is": "L2-miss traffic (FETCH_SIZE x 2 + WRITE_SIZE) of one GENERAL assembly: 6.69 + 7.17 GB for the two n^3 products "
                                 "(8.21 + 7.47 before their list was walked in sets of panels: profiles/r05_gemm_order_traffic.txt), "
-                                "9.53 GB for the Gram product (whose own kernel misses more often than the tile kernel it replaced and is "
-                                "9 % faster: profiles/r05_gram_l2_miss_experiments.txt); algorithmic 10 GB",
-                  "source": "profiles/r05_c_pmc_traffic_c2.txt, profiles/r05_c_pmc_mfma_util.txt (counter passes run the kernels 2-4 % slower and at "
+                                "9.46 GB for the Gram product (whose own kernel misses on 37 % of its L2 requests, the tile kernel it replaced on 14 %, and is "
+                                "9 % faster: profiles/r06_pmc_gram_l2.txt, profiles/r05_gram_l2_miss_experiments.txt); algorithmic 10 GB",
+                  "source": "profiles/r06_a_pmc_traffic_c2.txt, profiles/r06_a_pmc_mfma_util.txt (counter passes run the kernels 2-8 % slower and at "
                             "lower clocks than the timed solve; same-box A/B of the two list orders: profiles/r05_gemm_order_traffic.txt)"},
-    (1000, 2000): {"traffic_bytes_per_assembly": None, "mfma_busy": {"n3_products": 0.822, "gram": 0.874},
-                   "executed_tflops": {"n3_products": 60.2, "gram": 67.5},
-                   "source": "profiles/r05_c_pmc_mfma_util.txt"},
+    (1000, 2000): {"traffic_bytes_per_assembly": None, "mfma_busy": {"n3_products": 0.822, "gram": 0.872},
+                   "executed_tflops": {"n3_products": 59.9, "gram": 67.6},
+                   "source": "profiles/r06_a_pmc_mfma_util.txt"},
 }
 WORKLOAD_NAMES = {(500, 1000): "BASELINE configs[1] (C2)", (1000, 2000): "BASELINE.md T1 (north_star target size)",
                   (2000, 4000): "BASELINE configs[3] (C4)", (4000, 8000): "BASELINE.md T8"}
