@@ -162,7 +162,7 @@ long long hs_solve1_ws_doubles(int m, int q, int nblk, const int* n)
    for (int k = 0; k < nblk; ++k)
    {
       const long long nn = n[k], np = nn * (nn | 1), n2 = nn * nn, nlow = nn * (nn + 1) / 2;
-      t += 4 * np + 8;
+      t += 5 * np + 8;
       t += (m1 + 2) / 2 + 1 + (n2 + 2) / 2 + 1;                      /* voff, poff (ints) */
       t += (m1 * n2 + 2) + (m1 * nlow + 2) + (m1 * n2 + 2) / 2 + (m1 * nlow + 4) / 4 + 8;      /* vval, pval, vpq (u32), pvar (u16) */
       t += 2 * ((m1 + 3) / 4 + 2);                                  /* lv, hv */
@@ -257,7 +257,7 @@ struct S1Blk
 {
    int n, p, np, G;
    int oX, oZi, oLx, oLz, odX, odZ, oT1, oT2, oEig;
-   double *Z, *Rd, *E, *B;                                       /* cold matrices, pitch p (flat: LDS or workspace) */
+   double *Z, *Rd, *E, *B, *XR;                                  /* cold matrices, pitch p (flat: LDS or workspace); XR = X Rd of the iteration */
    int* voff; unsigned* vpq; double* vval;                        /* by variable: ALL entries (both triangles) in row-major order, vpq = row << 16 | col */
    int* poff; unsigned short* pvar; double* pval;                 /* by position r * n + c (r >= c): the variables that touch it */
    unsigned short* lv; unsigned short* hv; int nl, nh;            /* variables with few ("light") and many nonzeros in this block */
@@ -1841,7 +1841,7 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
       for (int k = 0; k < K; ++k)
       {
          S1Blk& B = sh.blk[k];
-         B.Z = take(B.np); B.Rd = take(B.np); B.E = take(B.np); B.B = take(B.np);
+         B.Z = take(B.np); B.Rd = take(B.np); B.E = take(B.np); B.B = take(B.np); B.XR = take(B.np);
       }
       /* (3) offset arrays */
       sh.roff = (int*) take((q + 2) / 2 + 1);
@@ -2623,18 +2623,19 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
    double sigma = 0.0, eta = 1.0;
    /* H (or dX) = sigmu Zinv - X - sym(T1 Zinv) into dX: the product and its transpose (Zinv T1^T) side by side, H from the epilogue;
     * LP part into `lpout` from `rlp` (rd for the right-hand side, dz for the step).  All threads; no barrier. */
-   auto dir_matrix_from = [&](int wfrom, double sigmu, double etalp, const double* rlp, bool useE, double* lpout) S1_INL
+   /* (t1: the entry of T1 at a flat index of its block - the array itself, or a formula that yields the same bits, see the corrector) */
+   auto dir_matrix_t1 = [&](int wfrom, double sigmu, double etalp, const double* rlp, bool useE, double* lpout, auto t1) S1_INL
    {
       int tb = 0;
       for (int k = 0; k < K; ++k)
       {
          const S1Blk& B = sh.blk[k];
          const int p = B.p;
-         const double* T1 = sm + B.oT1; const double* Zi = sm + B.oZi; const double* X = sm + B.oX;
+         const double* Zi = sm + B.oZi; const double* X = sm + B.oX;
          double* dX = sm + B.odX;
          s1_mm2(B.n, wave, lane, wfrom, S1_NW - wfrom, tb,
-            [&](int i, int kk) S1_INL { return T1[i * p + kk]; }, [&](int kk, int j) S1_INL { return Zi[kk * p + j]; },
-            [&](int i, int kk) S1_INL { return Zi[i * p + kk]; }, [&](int kk, int j) S1_INL { return T1[j * p + kk]; },
+            [&](int i, int kk) S1_INL { return t1(B, i * p + kk); }, [&](int kk, int j) S1_INL { return Zi[kk * p + j]; },
+            [&](int i, int kk) S1_INL { return Zi[i * p + kk]; }, [&](int kk, int j) S1_INL { return t1(B, j * p + kk); },
             [&](int i, int j, double v1, double v2) S1_INL { dX[i * p + j] = sigmu * Zi[i * p + j] - X[i * p + j] - 0.5 * (v1 + v2); });
       }
       for (int r = (wave >= wfrom ? tid - 64 * wfrom : q); r < q; r += S1_NT - 64 * wfrom)                /* (the tiles of the product are on the last wavefronts) */
@@ -2642,6 +2643,11 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
          const double xv = QV(Q_x)[r], zv = QV(Q_z)[r];
          lpout[r] = sigmu / zv - xv - (etalp * xv * rlp[r] + (useE ? QV(Q_elp)[r] : 0.0)) / zv;
       }
+   };
+   auto t1_array = [&](const S1Blk& B, int idx) S1_INL { return sm[B.oT1 + idx]; };
+   auto dir_matrix_from = [&](int wfrom, double sigmu, double etalp, const double* rlp, bool useE, double* lpout) S1_INL
+   {
+      dir_matrix_t1(wfrom, sigmu, etalp, rlp, useE, lpout, t1_array);
    };
    auto dir_matrix = [&](double sigmu, double etalp, const double* rlp, bool useE, double* lpout) S1_INL { dir_matrix_from(0, sigmu, etalp, rlp, useE, lpout); };
    /* wavefront 0, after A(H) is known: h, u1 = M^-1 h, dtau, dkappa, dy, coefficient vector [-dtau; dy] */
@@ -3307,9 +3313,10 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
                   const double* X = sm + B.oX;
                   auto Rd = LP(B.Rd);
                   double* T1 = sm + B.oT1;
+                  auto XR = LP(B.XR);
                   s1_mm(B.n, wave, lane, 1, S1_NW - 1, tb,
                      [&](int i, int kk) S1_INL { return X[i * p + kk]; }, [&](int kk, int j) S1_INL { return Rd[kk * p + j]; },
-                     [&](int i, int j, double v) S1_INL { T1[i * p + j] = v; });
+                     [&](int i, int j, double v) S1_INL { T1[i * p + j] = v; if ( AL ) XR[i * p + j] = v; });
                }
             }
             S1_BAR();
@@ -3364,9 +3371,10 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
                const double* X = sm + B.oX;
                auto Rd = LP(B.Rd);
                double* T1 = sm + B.oT1;
+               auto XR = LP(B.XR);
                s1_mm(B.n, wave, lane, 0, S1_NW, tb,
                   [&](int i, int kk) S1_INL { return X[i * p + kk]; }, [&](int kk, int j) S1_INL { return Rd[kk * p + j]; },
-                  [&](int i, int j, double v) S1_INL { T1[i * p + j] = v; });
+                  [&](int i, int j, double v) S1_INL { T1[i * p + j] = v; if ( AL ) XR[i * p + j] = v; });
             }
          }
          S1_BAR();
@@ -3567,22 +3575,34 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
       const double etk = dta * dka;
 
       /* ================= corrector */
+      /* T1 = eta X Rd + E.  X Rd is the product the predictor's right-hand side was made of: with every cold matrix in LDS its entries
+       * were kept (XR) and an entry of T1 is formed where the product below reads it - fma(eta, XR, E), the operation the epilogue of
+       * the product X Rd applied to the same two numbers: same bits, a product phase and its barrier less (round 6). */
+      if ( AL )
       {
-         int tb = 0;
-         for (int k = 0; k < K; ++k)
-         {
-            const S1Blk& B = sh.blk[k];
-            const int p = B.p;
-            const double* X = sm + B.oX; auto Rd = LP(B.Rd); auto E = LP(B.E);
-            double* T1 = sm + B.oT1;
-            const double et = eta;
-            s1_mm(B.n, wave, lane, 0, S1_NW, tb,
-               [&](int i, int kk) S1_INL { return X[i * p + kk]; }, [&](int kk, int j) S1_INL { return Rd[kk * p + j]; },
-               [&](int i, int j, double v) S1_INL { T1[i * p + j] = fma(et, v, E[i * p + j]); });
-         }
+         const double et = eta;
+         dir_matrix_t1(0, sigmu, eta, QV(Q_rd), true, QV(Q_hl),
+            [&](const S1Blk& B, int idx) S1_INL { return fma(et, LP(B.XR)[idx], LP(B.E)[idx]); });
       }
-      S1_BAR();
-      dir_matrix(sigmu, eta, QV(Q_rd), true, QV(Q_hl));
+      else
+      {
+         {
+            int tb = 0;
+            for (int k = 0; k < K; ++k)
+            {
+               const S1Blk& B = sh.blk[k];
+               const int p = B.p;
+               const double* X = sm + B.oX; auto Rd = LP(B.Rd); auto E = LP(B.E);
+               double* T1 = sm + B.oT1;
+               const double et = eta;
+               s1_mm(B.n, wave, lane, 0, S1_NW, tb,
+                  [&](int i, int kk) S1_INL { return X[i * p + kk]; }, [&](int kk, int j) S1_INL { return Rd[kk * p + j]; },
+                  [&](int i, int j, double v) S1_INL { T1[i * p + j] = fma(et, v, E[i * p + j]); });
+            }
+         }
+         S1_BAR();
+         dir_matrix(sigmu, eta, QV(Q_rd), true, QV(Q_hl));
+      }
       S1_BAR();
       pass_A(true, QV(Q_hl), VEC(V_AH), 128, no_epi);
       bh_partials();
