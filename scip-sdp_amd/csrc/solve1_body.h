@@ -1504,6 +1504,133 @@ __device__ __forceinline__ double s1_lmin(double* W, int n, int p, int lane, dou
    return s1_sturm_min<false>(dl, el, n, lane, scr, tprof);
 }
 
+/* ---- the same for 17 <= n <= 32 with TWO lanes per row (round 6): lane l serves row l & 31, half l >> 5.  The section costs its
+ * instruction count (profiles/r06_solve1_diag_block_attempt.txt), and at n = 32 it was 190 000 of the 830 000 cycles of an iteration,
+ * twice, on one wavefront with the others idle; with two lanes per row every lane forms half of its row's entry of A v and applies half
+ * of its row's part of the rank-2 update.  THE SAME BITS as s1_lmin: the entry of A v is ((a0 + a1) + (a2 + a3)) of four chains over the
+ * columns k + 1 + j + 4 i - the first half owns chains 0 and 1, the second 2 and 3, the two partial sums meet through one lane
+ * exchange -; the sums over rows (s1_wsum) see the same values in the same lanes, zeros in the lanes from 32 on as before. */
+__device__ __forceinline__ double s1_lmin2(double* W, int n, int p, int lane, double* scr, double* tprof)
+{
+   double* dd = scr;
+   double* ee = scr + n;
+   double* vv = scr + 2 * n;
+   double* ww = scr + 3 * n;
+   const int row = lane & 31, half = lane >> 5;
+   for (int k = 0; k + 2 < n; ++k)
+   {
+      const bool act = row > k && row < n;
+      const double xa = act ? W[row * p + k] : 0.0;
+      const double x0 = s1_lane(xa, k + 1);
+      const double s2 = s1_wsum((half == 0 && lane > k + 1) ? xa * xa : 0.0);
+      if ( lane == 0 )
+         dd[k] = W[k * p + k];
+      if ( !(s2 > 1e-290) )
+      {
+         if ( lane == 0 )
+            ee[k] = x0;
+         if ( s2 != s2 )
+            return s2;
+         continue;
+      }
+      const double h2 = x0 * x0 + s2;
+      const double rh = s1_rsqrt(h2);
+      const double beta = -copysign(h2 * rh, x0);
+      const double t = (x0 - beta) * copysign(rh, x0);          /* (beta - x0) / beta with 1 / beta = -sign(x0) / sqrt(h2) */
+      const double scale = s1_rcp(x0 - beta);
+      const double vl = (row == k + 1) ? 1.0 : xa * scale;           /* rows > k */
+      if ( act && half == 0 )
+         vv[row] = vl;
+      if ( lane == 0 )
+         ee[k] = beta;
+      S1_WSYNC();
+      /* p = t A v over the trailing block (rows, columns k + 1 .. n - 1), lower storage: this lane's two chains */
+      double part = 0.0;
+      if ( act )
+      {
+         double ca = 0.0, cb = 0.0;
+         int c = k + 1;
+         const int h2c = 2 * half;
+#define S1_WSYM(cc) W[((cc) <= row) ? row * p + (cc) : (cc) * p + row]
+         for (; c + 7 < n; c += 8)
+         {
+            const int c0 = c + h2c;
+            const double e0 = S1_WSYM(c0), e1 = S1_WSYM(c0 + 1), e2 = S1_WSYM(c0 + 4), e3 = S1_WSYM(c0 + 5);
+            const double v0 = vv[c0], v1 = vv[c0 + 1], v2 = vv[c0 + 4], v3 = vv[c0 + 5];
+            ca = fma(e0, v0, ca); cb = fma(e1, v1, cb);
+            ca = fma(e2, v2, ca); cb = fma(e3, v3, cb);
+         }
+         for (; c + 3 < n; c += 4)
+         {
+            const int c0 = c + h2c;
+            const double e0 = S1_WSYM(c0), e1 = S1_WSYM(c0 + 1);
+            const double v0 = vv[c0], v1 = vv[c0 + 1];
+            ca = fma(e0, v0, ca); cb = fma(e1, v1, cb);
+         }
+         {
+            /* (the last one to three columns: chains 0, 1, 2 take a term each - a product of zeros past the end, as in s1_lmin -, chain 3 none) */
+            const int c0 = c + h2c;
+            const bool in0 = c0 < n, in1 = c0 + 1 < n;
+            const int c0c = in0 ? c0 : k + 1, c1c = in1 ? c0 + 1 : k + 1;
+            const double e0l = S1_WSYM(c0c), e1l = S1_WSYM(c1c);
+            const double v0l = vv[c0c], v1l = vv[c1c];
+            ca = fma(in0 ? e0l : 0.0, in0 ? v0l : 0.0, ca);
+            if ( half == 0 )
+               cb = fma(in1 ? e1l : 0.0, in1 ? v1l : 0.0, cb);
+         }
+#undef S1_WSYM
+         part = ca + cb;
+      }
+      const double other = __shfl_xor(part, 32, 64);
+      const double pl = act ? t * (half == 0 ? part + other : other + part) : 0.0;
+      const double pvl = (half == 0 && act) ? pl * vl : 0.0;
+      const double pv = s1_wsum(pvl);
+      const double al = -0.5 * t * pv;
+      const double wl = pl + al * vl;
+      if ( act && half == 0 )
+         ww[row] = wl;
+      S1_WSYNC();
+      if ( act )
+      {
+         /* columns k + 1 .. row of the row: the first half of them here, the second in the other lane of the row */
+         double* rl = W + row * p;
+         const int cnt = row - k;
+         const int mid = k + 1 + ((cnt + 1) >> 1);
+         int c = half ? mid : k + 1;
+         const int ce = half ? row + 1 : mid;
+         for (; c + 4 <= ce; c += 4)
+         {
+            double r4[4], w4[4], v4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+            {
+               r4[u] = rl[c + u]; w4[u] = ww[c + u]; v4[u] = vv[c + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+               rl[c + u] = r4[u] - (vl * w4[u] + wl * v4[u]);
+         }
+         for (; c < ce; ++c)
+            rl[c] -= vl * ww[c] + wl * vv[c];
+      }
+      S1_WSYNC();
+   }
+   if ( lane == 0 )
+   {
+      if ( n >= 2 )
+      {
+         dd[n - 2] = W[(n - 2) * p + n - 2];
+         ee[n - 2] = W[(n - 1) * p + n - 2];
+      }
+      dd[n - 1] = W[(n - 1) * p + n - 1];
+      ee[n - 1] = 0.0;
+   }
+   S1_WSYNC();
+   const double dl = (lane < n) ? dd[lane] : 0.0;
+   const double el = (lane < n) ? ee[lane] : 0.0;
+   return s1_sturm_min<false>(dl, el, n, lane, scr, tprof);
+}
+
 /* ---- n x n x n product on the matrix cores: wavefront `wave` of the subset [w0, w0 + nw) takes the 16 x 16 tiles tbase + t with
  * (tbase + t) % nw == wave - w0.  la(i, k), lb(k, j): operand entries (called only inside the matrix); ep(i, j, value). */
 template<class LA, class LB, class EP>
@@ -2798,7 +2925,8 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
          double* tpr = (P.prof_on && t == 0) ? &sh.prof[19] : (double*) NULL;
          double* escr = sm + B.oEig + (t & 1) * (4 * ((B.n + 1) & ~1) + 32);
          const double lm = (S1_ALLU || B.n <= S1U_MAXN) ? s1u_lmin_n(Wm, B.n, B.p, lane, tpr)
-            : ((S1_ALL16 || B.n <= 16) ? s1_lmin16(Wm, B.n, B.p, lane, escr, tpr) : s1_lmin(Wm, B.n, B.p, lane, escr, tpr));
+            : ((S1_ALL16 || B.n <= 16) ? s1_lmin16(Wm, B.n, B.p, lane, escr, tpr)
+               : (B.n <= 32 ? s1_lmin2(Wm, B.n, B.p, lane, escr, tpr) : s1_lmin(Wm, B.n, B.p, lane, escr, tpr)));
          if ( lane == 0 )
             sh.sc[SC_LMIN0 + t] = lm;
       }
