@@ -2443,9 +2443,14 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
          s1_lp_schur_mm(sh.fl[33] == 1 ? sm + sh.fl[31] : P.Dext, sx, Mx, m1, q, pm1, mpk, wave, lane, w0);
          return;
       }
-      if ( wave != S1_NW - 1 )
+      /* (round 6: the variables are dealt out over ALL the wavefronts from w0 on - variable i to wavefront w0 + (i - 1) % nwv -
+       * where the last wavefront alone walked them 64 at a time: a lane's walk is what it was, the phase costs the busiest lane of
+       * a wavefront instead of the sum over two rounds and over the divergent loops of 64 lanes - example_MkP: 45 000 cycles on
+       * one wavefront with the others idle) */
+      if ( wave < w0 )
          return;
-      for (int i = lane + 1; i < m1; i += 64)
+      const int nwv = S1_NW - w0;
+      for (int i = 1 + (wave - w0) + nwv * lane; i < m1; i += 64 * nwv)
       {
          double* row = Mx + MROW(i);
          for (int j = 0; j <= i; ++j)
@@ -2465,6 +2470,8 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
             }
          }
       }
+      if ( wave != S1_NW - 1 )
+         return;
       double s00 = 0.0;
       const int t1 = LP(sh.coff)[1];
       for (int t = LP(sh.coff)[0] + lane; t < t1; t += 64)
