@@ -1277,26 +1277,38 @@ __device__ __forceinline__ double s1_sturm_min(double dl, double el, int n, int 
    return lo * nrm;
 }
 
-/* ---- the same for n <= 16 with the matrix in registers: lane = row, sixteen registers = its columns, the reduction fully unrolled.
- * The entries of the reflector and of w reach the lanes by v_readlane; no LDS access after the rows are loaded (the LDS form
- * below waits out six LDS round trips per column: 3100 cycles per column at n = 10, this one about 1000). */
+/* ---- the same for n <= 16 with the matrix in registers, the reduction fully unrolled.  Round 6: TWO lanes per row - lane l < 32
+ * serves row l & 15 and holds the eight entries of its row whose column has the parity l >> 4 - where one lane held all sixteen: the
+ * row's entry of A v is acc0 + acc1 of one chain over the even and one over the odd columns, each lane now forms ITS chain and updates
+ * its eight entries, the two meet through one lane exchange (half the multiply-adds and half the LDS reads of v and w per lane; the
+ * section costs its instruction count).  The sums over rows are taken in lanes 0 .. 15 as before: THE SAME BITS.
+ * The entries of the reflector and of w reach the lanes through 16 doubles of LDS each (v_readlane would make them scalar values, of
+ * which the kernel has none to spare); no other LDS access after the rows are loaded. */
 __device__ __forceinline__ double s1_lmin16(const double* W, int n, int p, int lane, double* bc, double* tprof)
 {
-   double a[16];
+   const int row = lane & 15, half = (lane >> 4) & 1;
+   const bool live = lane < 32 && row < n;
+   double ah[8];                                  /* ah[i] = entry (row, 2 i + half) */
 #pragma unroll
-   for (int j = 0; j < 16; ++j)
-      a[j] = (lane < n && j < n) ? W[lane * p + j] : 0.0;
+   for (int i = 0; i < 8; ++i)
+      ah[i] = (live && 2 * i + half < n) ? W[row * p + 2 * i + half] : 0.0;
    double dreg = 0.0, ereg = 0.0;
 #pragma unroll
    for (int k = 0; k < 14; ++k)
    {
       if ( k + 2 < n )
       {
-         const double xa = (lane > k) ? a[k] : 0.0;
+         /* entry k of the own row: it lives in the lane of parity k & 1, the other one fetches it */
+         const double mine = ah[k >> 1];
+         const double theirs = __shfl_xor(mine, 16, 64);
+         const double ek = (half == (k & 1)) ? mine : theirs;
+         const double xa = (row > k) ? ek : 0.0;
          const double x0 = s1_lane(xa, k + 1);
+         /* (the sums over rows exactly as the one-lane-per-row form wrote them - the lanes from 16 on sum garbage of their own that
+          * nobody reads: the compiler fuses the first addition of the second sum with its product, a select in between would stop it) */
          const double s2 = s1_lane(s1_sum16(lane > k + 1 ? xa * xa : 0.0), 0);
          if ( lane == k )
-            dreg = a[k];
+            dreg = ek;
          if ( s2 != s2 )
             return s2;
          if ( !(s2 > 1e-290) )
@@ -1311,53 +1323,56 @@ __device__ __forceinline__ double s1_lmin16(const double* W, int n, int p, int l
             const double beta = -copysign(h2 * rh, x0);
             const double t = (x0 - beta) * copysign(rh, x0);
             const double scale = s1_rcp(x0 - beta);
-            /* the reflector (zero in the lanes up to k) and, below, w reach all lanes through 16 doubles of LDS: one write, the
-             * sixteen entries read back as vector registers (v_readlane would make them scalar values, of which the kernel has none
-             * to spare).  Entries up to k are zero, so the sums and the update run over all sixteen columns without guards. */
-            const double vl = (lane == k + 1) ? 1.0 : ((lane > k + 1) ? xa * scale : 0.0);
+            /* the reflector is zero in the rows up to k, so the sums and the update run over all columns without guards */
+            const double vl = (row == k + 1) ? 1.0 : ((row > k + 1) ? xa * scale : 0.0);
             if ( lane == k )
                ereg = beta;
             if ( lane < 16 )
                bc[lane] = vl;
             S1_WSYNC();
-            double vv[16];
+            double vh[8];
 #pragma unroll
-            for (int j = 0; j < 16; ++j)
-               vv[j] = bc[j];
-            double acc0 = 0.0, acc1 = 0.0;
+            for (int i = 0; i < 8; ++i)
+               vh[i] = bc[2 * i + half];
+            double acc = 0.0;
 #pragma unroll
-            for (int j = 0; j < 16; j += 2)
-            {
-               acc0 = fma(a[j], vv[j], acc0);
-               acc1 = fma(a[j + 1], vv[j + 1], acc1);
-            }
-            const double pl = (lane > k) ? t * (acc0 + acc1) : 0.0;
+            for (int i = 0; i < 8; ++i)
+               acc = fma(ah[i], vh[i], acc);
+            const double oth = __shfl_xor(acc, 16, 64);
+            const double pl = (row > k) ? t * (half == 0 ? acc + oth : oth + acc) : 0.0;
             const double pv = s1_lane(s1_sum16(pl * vl), 0);
             const double wl = fma(-0.5 * t * pv, vl, pl);
             if ( lane < 16 )
                bc[16 + lane] = wl;
             S1_WSYNC();
 #pragma unroll
-            for (int j = 0; j < 16; ++j)
-               a[j] -= fma(vl, bc[16 + j], wl * vv[j]);
+            for (int i = 0; i < 8; ++i)
+               ah[i] -= fma(vl, bc[16 + 2 * i + half], wl * vh[i]);
          }
       }
    }
-   /* the rest of the diagonal and the last off-diagonal entry: a[lane], a[lane - 1] of the own row */
-   double own = 0.0, left = 0.0;
+   /* the rest of the diagonal and the last off-diagonal entry: entries row and row - 1 of the own row, from the lane that holds them */
+   double ownm = 0.0, leftm = 0.0;
 #pragma unroll
-   for (int j = 0; j < 16; ++j)
+   for (int i = 0; i < 8; ++i)
    {
-      if ( j == lane ) own = a[j];
-      if ( j + 1 == lane ) left = a[j];
+      if ( 2 * i + half == row ) ownm = ah[i];
+      if ( 2 * i + half + 1 == row ) leftm = ah[i];
    }
-   if ( lane + 2 >= n )
+   const double ownt = __shfl_xor(ownm, 16, 64), leftt = __shfl_xor(leftm, 16, 64);
+   const double own = (half == (row & 1)) ? ownm : ownt;
+   const double left = (half == ((row + 1) & 1)) ? leftm : leftt;
+   if ( lane < 16 && lane + 2 >= n )
       dreg = own;
    if ( n >= 2 )
    {
       const double elast = s1_lane(left, n - 1);
       if ( lane == n - 2 )
          ereg = elast;
+   }
+   if ( lane >= 16 )
+   {
+      dreg = 0.0; ereg = 0.0;
    }
    if ( tprof != NULL && lane == 0 )
       tprof[0] -= (double) clock64();
