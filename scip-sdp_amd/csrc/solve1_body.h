@@ -2701,7 +2701,28 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
             const S1Blk& B = sh.blk[k];
             const double* V = sm + (ofdX ? B.odX : B.oX);
             const int t1 = LP(B.voff)[i + 1];
-            for (int t = LP(B.voff)[i] + l16; t < t1; t += 16)
+            int t = LP(B.voff)[i] + l16;
+            /* (a dense matrix - the constant one, as a rule - is hundreds of entries for its sixteen lanes while the other groups have
+             * finished after one: four entries per trip, their positions, values and operands requested before the first of the four
+             * multiply-adds - the same chain in the same order, the round trips to LDS side by side instead of one after the other;
+             * one block of 32 rows: 25 000 -> cycles of one lane group per pass, round 6) */
+            for (; t + 48 < t1; t += 64)
+            {
+               unsigned pq[4]; double vv_[4], xx_[4];
+#pragma unroll
+               for (int u = 0; u < 4; ++u)
+               {
+                  pq[u] = LP(B.vpq)[t + 16 * u];
+                  vv_[u] = LP(B.vval)[t + 16 * u];
+               }
+#pragma unroll
+               for (int u = 0; u < 4; ++u)
+                  xx_[u] = V[(int) (pq[u] >> 16) * B.p + (int) (pq[u] & 0xffffu)];
+#pragma unroll
+               for (int u = 0; u < 4; ++u)
+                  s = fma(vv_[u], xx_[u], s);
+            }
+            for (; t < t1; t += 16)
             {
                const unsigned pq = LP(B.vpq)[t];
                const int pp = (int) (pq >> 16), qq = (int) (pq & 0xffffu);
