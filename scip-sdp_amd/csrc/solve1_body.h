@@ -3322,7 +3322,25 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
                      if ( t1 == t0 || (t1 - t0 > S1_LIGHT_MAX && i < j) )
                         continue;
                      double s0 = 0.0;
-                     for (int t = t0 + l16; t < t1; t += 16)
+                     int t = t0 + l16;
+                     /* (four entries per trip for a dense A_i, as in pass_A: same chain, the LDS round trips side by side) */
+                     for (; t + 48 < t1; t += 64)
+                     {
+                        unsigned pq[4]; double vv_[4], uu_[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                        {
+                           pq[u] = LP(B.vpq)[t + 16 * u];
+                           vv_[u] = LP(B.vval)[t + 16 * u];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                           uu_[u] = U[(int) (pq[u] & 0xffffu) * p + (int) (pq[u] >> 16)];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                           s0 = fma(vv_[u], uu_[u], s0);
+                     }
+                     for (; t < t1; t += 16)
                      {
                         const unsigned pq = LP(B.vpq)[t];
                         const int pp = (int) (pq >> 16), qq = (int) (pq & 0xffffu);
