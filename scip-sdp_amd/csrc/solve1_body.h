@@ -3428,6 +3428,48 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
                   acc = fma(ve, u, acc);
                }
             }
+            else if ( ns <= 8 )
+            {
+               /* five to eight non-empty rows in A_j (three off-diagonal entries: up to six): the same scheme with eight slots - the
+                * row numbers leave the loop over the entries of A_i, an entry's sixteen loads are independent of each other, a slot
+                * past ns multiplies a finite number by zero (u + 0 x = u exactly).  The general loop below asked for the row number
+                * of every slot again for every entry, a chain of two round trips per slot - 700 ns each once the lists live in the
+                * workspace (blocks from about 24 rows on): the pairs were 79 000 of the 730 000 cycles of an iteration at 32 rows */
+               int rr_[8];
+               decltype(LP(B.Tc)) TT_[8];
+               const auto Tb = LP(B.Tc) + s0i * n;
+#pragma unroll
+               for (int v_ = 0; v_ < 8; ++v_)
+               {
+                  const int sv = (v_ < ns) ? v_ : 0;
+                  rr_[v_] = (int) LP(B.lrp)[s0i + sv];
+                  TT_[v_] = Tb + sv * n;
+               }
+               unsigned abn = (e0 < e1) ? LP(B.vpq)[e0] : 0u;
+               double vn = (e0 < e1) ? LP(B.vval)[e0] : 0.0;
+               for (int e = e0; e < e1; ++e)
+               {
+                  const unsigned ab = abn;
+                  const double ve = vn;
+                  const int en = (e + 1 < e1) ? e + 1 : e;
+                  abn = LP(B.vpq)[en];
+                  vn = LP(B.vval)[en];
+                  const int aa_ = (int) (ab >> 16), bb_ = (int) (ab & 0xffffu);
+                  const double* xr = X + bb_ * p;
+                  double xl[8], tl[8];
+#pragma unroll
+                  for (int v_ = 0; v_ < 8; ++v_)
+                  {
+                     xl[v_] = xr[rr_[v_]];
+                     tl[v_] = TT_[v_][aa_];
+                  }
+                  double u = 0.0;
+#pragma unroll
+                  for (int v_ = 0; v_ < 8; ++v_)
+                     u = fma((v_ < ns) ? xl[v_] : 0.0, tl[v_], u);
+                  acc = fma(ve, u, acc);
+               }
+            }
             else
                for (int e = e0; e < e1; ++e)
                {
