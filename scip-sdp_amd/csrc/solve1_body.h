@@ -3428,47 +3428,56 @@ __global__ void __launch_bounds__(S1_NT) S1_KERNEL(const hs_solve1_args P)
                   acc = fma(ve, u, acc);
                }
             }
-            else if ( ns <= 8 )
+            else if ( ns <= S1_LIGHT_MAX )
             {
-               /* five to eight non-empty rows in A_j (three off-diagonal entries: up to six): the same scheme with eight slots - the
-                * row numbers leave the loop over the entries of A_i, an entry's sixteen loads are independent of each other, a slot
-                * past ns multiplies a finite number by zero (u + 0 x = u exactly).  The general loop below asked for the row number
-                * of every slot again for every entry, a chain of two round trips per slot - 700 ns each once the lists live in the
-                * workspace (blocks from about 24 rows on): the pairs were 79 000 of the 730 000 cycles of an iteration at 32 rows */
-               int rr_[8];
-               decltype(LP(B.Tc)) TT_[8];
-               const auto Tb = LP(B.Tc) + s0i * n;
-#pragma unroll
-               for (int v_ = 0; v_ < 8; ++v_)
+               /* more than four non-empty rows in A_j (three off-diagonal entries: up to six; a matrix counts as light up to
+                * S1_LIGHT_MAX entries): the same scheme with 8, 12, 16 or 24 slots - the row numbers leave the loop over the entries of
+                * A_i, an entry's loads are independent of each other, a slot past ns multiplies a finite number by zero (u + 0 x = u
+                * exactly).  The general loop below asked for the row number of every slot again for every entry, a chain of two round
+                * trips per slot (700 ns each once the lists live in the workspace): example_TT's tree 885 -> 957 node solves/s, two
+                * blocks of 30 rows -4.8 % (round 6) */
+               auto slots = [&](auto NStag) S1_INL
                {
-                  const int sv = (v_ < ns) ? v_ : 0;
-                  rr_[v_] = (int) LP(B.lrp)[s0i + sv];
-                  TT_[v_] = Tb + sv * n;
-               }
-               unsigned abn = (e0 < e1) ? LP(B.vpq)[e0] : 0u;
-               double vn = (e0 < e1) ? LP(B.vval)[e0] : 0.0;
-               for (int e = e0; e < e1; ++e)
-               {
-                  const unsigned ab = abn;
-                  const double ve = vn;
-                  const int en = (e + 1 < e1) ? e + 1 : e;
-                  abn = LP(B.vpq)[en];
-                  vn = LP(B.vval)[en];
-                  const int aa_ = (int) (ab >> 16), bb_ = (int) (ab & 0xffffu);
-                  const double* xr = X + bb_ * p;
-                  double xl[8], tl[8];
+                  constexpr int NSL = decltype(NStag)::value;
+                  int rr_[NSL];
+                  decltype(LP(B.Tc)) TT_[NSL];
+                  const auto Tb = LP(B.Tc) + s0i * n;
 #pragma unroll
-                  for (int v_ = 0; v_ < 8; ++v_)
+                  for (int v_ = 0; v_ < NSL; ++v_)
                   {
-                     xl[v_] = xr[rr_[v_]];
-                     tl[v_] = TT_[v_][aa_];
+                     const int sv = (v_ < ns) ? v_ : 0;
+                     rr_[v_] = (int) LP(B.lrp)[s0i + sv];
+                     TT_[v_] = Tb + sv * n;
                   }
-                  double u = 0.0;
+                  unsigned abn = (e0 < e1) ? LP(B.vpq)[e0] : 0u;
+                  double vn = (e0 < e1) ? LP(B.vval)[e0] : 0.0;
+                  for (int e = e0; e < e1; ++e)
+                  {
+                     const unsigned ab = abn;
+                     const double ve = vn;
+                     const int en = (e + 1 < e1) ? e + 1 : e;
+                     abn = LP(B.vpq)[en];
+                     vn = LP(B.vval)[en];
+                     const int aa_ = (int) (ab >> 16), bb_ = (int) (ab & 0xffffu);
+                     const double* xr = X + bb_ * p;
+                     double xl[NSL], tl[NSL];
 #pragma unroll
-                  for (int v_ = 0; v_ < 8; ++v_)
-                     u = fma((v_ < ns) ? xl[v_] : 0.0, tl[v_], u);
-                  acc = fma(ve, u, acc);
-               }
+                     for (int v_ = 0; v_ < NSL; ++v_)
+                     {
+                        xl[v_] = xr[rr_[v_]];
+                        tl[v_] = TT_[v_][aa_];
+                     }
+                     double u = 0.0;
+#pragma unroll
+                     for (int v_ = 0; v_ < NSL; ++v_)
+                        u = fma((v_ < ns) ? xl[v_] : 0.0, tl[v_], u);
+                     acc = fma(ve, u, acc);
+                  }
+               };
+               if ( ns <= 8 ) slots(std::integral_constant<int, 8>());
+               else if ( ns <= 12 ) slots(std::integral_constant<int, 12>());
+               else if ( ns <= 16 ) slots(std::integral_constant<int, 16>());
+               else slots(std::integral_constant<int, S1_LIGHT_MAX>());
             }
             else
                for (int e = e0; e < e1; ++e)
