@@ -18,6 +18,10 @@ if name.startswith("random:"):
     import test_gpu_solve1
     _, ns, m_, q_ = name.split(":")
     core = test_gpu_solve1.sized_sparse_core([int(v) for v in ns.split(",")], int(m_), int(q_), 5)
+elif name.endswith(".npz"):
+    # a node problem saved by tests/devtools/bnb_save_node.py
+    d = np.load(name)
+    core = ipm_ref.CoreProblem(d['b'], [d[k] for k in sorted(d.files) if k.startswith('A')], d['D'], d['c'])
 else:
     inst = sdpa_io.read_sdpa(os.path.join(ROOT, 'tests', 'golden', 'instances', name))
     D, c = sdpa_io.lp_dense(inst)
